@@ -1,0 +1,156 @@
+"""ctypes front-end of oracle/liboracle.so (TEST INFRASTRUCTURE).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import
+this module.  See oracle/pomdp_oracle.h for the contract.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+KINDS = {"rock": 0, "tag": 1, "battleship": 2, "tiger": 3, "network": 4}
+
+
+def build(force=False):
+    src = [os.path.join(_HERE, f) for f in ("pomdp_oracle.c", "pomdp_oracle.h")]
+    if (not force and os.path.exists(_LIB_PATH)
+            and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in src)):
+        return _LIB_PATH
+    subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        vp, i64p = C.c_void_p, C.POINTER(C.c_int64)
+        L.or_env_new.restype = vp
+        L.or_env_new.argtypes = [C.c_int, i64p, C.c_int]
+        L.or_env_free.argtypes = [vp]
+        for f in ("or_env_n_actions", "or_env_n_obs", "or_env_compact_len", "or_env_words", "or_env_reward_kind"):
+            getattr(L, f).restype = C.c_int
+            getattr(L, f).argtypes = [vp]
+        L.or_trace_mt.restype = C.c_int
+        L.or_trace_mt.argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.c_int64] + [vp] * 8
+        L.or_batch_reset.argtypes = [vp, vp, vp, C.c_int64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_int]
+        L.or_batch_step.restype = C.c_int64
+        L.or_batch_step.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int64, C.c_uint64, C.c_uint32, C.c_uint64,
+                                    C.c_int, C.c_int]
+        L.or_batch_compact.argtypes = [vp, vp, vp, C.c_int64]
+        L.or_synthetic_actions.argtypes = [vp, C.c_int64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.c_int]
+        L.or_max_threads.restype = C.c_int
+        L.or_philox4x32_10.argtypes = [vp, vp, vp]
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def env_args(name, **kw):
+    """Constructor kwargs (reference names and defaults) -> oracle arg vector."""
+    if name == "rock":
+        return [kw.get("board_size", 7), kw.get("num_rocks", 8)]
+    if name == "tag":
+        thr = int(kw.get("move_thr", 0))
+        return [kw.get("num_opponents", 1), kw.get("obs_cells", 29), thr & 0xFFFFFFFF, thr >> 32]
+    if name == "battleship":
+        bs = kw.get("board_size", (5, 5))
+        return [bs[0], bs[1], kw.get("max_len", 3)]
+    if name == "tiger":
+        return []
+    if name == "network":
+        return [kw.get("n_machines", 10), kw.get("problem_type", 3)]
+    raise KeyError(name)
+
+
+class OracleEnv(object):
+    """One oracle env configuration (a prototype the batch drivers clone per thread)."""
+
+    def __init__(self, name, **kwargs):
+        self.name = name
+        args = np.asarray(env_args(name, **kwargs), dtype=np.int64)
+        L = lib()
+        self._h = L.or_env_new(KINDS[name], args.ctypes.data_as(C.POINTER(C.c_int64)), len(args))
+        if not self._h:
+            raise ValueError("configuration rejected: %s %r" % (name, kwargs))
+        self.n_actions = L.or_env_n_actions(self._h)
+        self.n_obs = L.or_env_n_obs(self._h)
+        self.compact_len = L.or_env_compact_len(self._h)
+        self.words = L.or_env_words(self._h)
+        self.reward_dtype = np.float32 if L.or_env_reward_kind(self._h) else np.int32
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.or_env_free(self._h)
+            self._h = None
+
+    # ---- mode A ---------------------------------------------------------
+    def trace_mt(self, seed, actions, space_seed=None):
+        actions = np.ascontiguousarray(actions, dtype=np.int64)
+        T, S = len(actions), self.compact_len
+        out = dict(ob0=np.zeros(1, np.int64), state0=np.zeros(S, np.int64), ob=np.zeros(T, np.int64),
+                   reward=np.zeros(T, np.float64), done=np.zeros(T, np.uint8),
+                   state_pre=np.zeros((T, S), np.int64), state=np.zeros((T, S), np.int64),
+                   reset_ob=np.zeros(T, np.int64))
+        rc = lib().or_trace_mt(self._h, seed, seed if space_seed is None else space_seed, _ptr(actions), T,
+                               *[_ptr(out[k]) for k in ("ob0", "state0", "ob", "reward", "done", "state_pre",
+                                                        "state", "reset_ob")])
+        if rc:
+            raise ValueError("invalid action in tape")
+        out["ob0"] = out["ob0"][0]
+        out["actions"] = actions
+        return out
+
+    # ---- mode B ---------------------------------------------------------
+    def new_state(self, n):
+        return np.zeros((self.words, n), dtype=np.uint32)
+
+    def batch_reset(self, state, seed, lane0, t, nthreads=1):
+        n = state.shape[1]
+        ob = np.zeros(n, np.int32)
+        lib().or_batch_reset(self._h, _ptr(state), _ptr(ob), n, seed, lane0, t, nthreads)
+        return ob
+
+    def batch_step(self, state, actions, seed, lane0, t, auto_reset=True, done=None, nthreads=1):
+        n = state.shape[1]
+        actions = np.ascontiguousarray(actions, dtype=np.int32)
+        ob = np.zeros(n, np.int32)
+        reward = np.zeros(n, self.reward_dtype)
+        if done is None:
+            done = np.zeros(n, np.uint8)
+        bad = lib().or_batch_step(self._h, _ptr(state), _ptr(actions), _ptr(ob), _ptr(reward), _ptr(done), n,
+                                  seed, lane0, t, int(auto_reset), nthreads)
+        return ob, reward, done, int(bad)
+
+    def batch_compact(self, state):
+        n = state.shape[1]
+        out = np.zeros((n, self.compact_len), np.int64)
+        lib().or_batch_compact(self._h, _ptr(np.ascontiguousarray(state)), _ptr(out), n)
+        return out
+
+
+def synthetic_actions(n, seed, lane0, t, n_actions, nthreads=1):
+    a = np.zeros(n, np.int32)
+    lib().or_synthetic_actions(_ptr(a), n, seed, lane0, t, n_actions, nthreads)
+    return a
+
+
+def philox(ctr, key):
+    c = np.asarray(ctr, np.uint32)
+    k = np.asarray(key, np.uint32)
+    o = np.zeros(4, np.uint32)
+    lib().or_philox4x32_10(_ptr(c), _ptr(k), _ptr(o))
+    return o
+
+
+def max_threads():
+    return lib().or_max_threads()

@@ -1,0 +1,101 @@
+"""Reference (numpy) statement of the simulator's random-word contract.
+
+TEST INFRASTRUCTURE — part of the oracle.  Only tests/, __graft_entry__.smoke()
+and bench.py's cpu_baseline leg may import this module; the product path
+(gym_pomdp_amd/) never does.
+
+The contract (also restated in DESIGN.md §RNG and implemented independently in
+oracle/pomdp_oracle.c and gym_pomdp_amd/csrc/philox.hip.h):
+
+* generator: Philox4x32-10 (Salmon et al., SC'11), multipliers 0xD2511F53 /
+  0xCD9E8D57, Weyl key increments 0x9E3779B9 / 0xBB67AE85;
+* key   = (seed & 0xffffffff, seed >> 32);
+* ctr   = (lane, t & 0xffffffff, t >> 32, (stream << 24) | block);
+* the 32-bit word stream of (seed, lane, t, stream) is block 0's four outputs,
+  then block 1's, ... ; env code consumes that stream strictly sequentially,
+  with numpy's *legacy* RandomState constructions on top of it:
+    double   : a = w0 >> 5, b = w1 >> 6, k = a * 2**26 + b, U = k / 2**53
+    randint n: mask = bit-smear(n - 1); draw words until (w & mask) <= n - 1
+    binomial(1, p): one double, compared against a captured integer threshold.
+
+Streams: 0 np.random draws made inside step(); 1 np.random draws made inside
+reset(); 2 / 3 the gym-space RNG (Discrete.sample) inside step() / reset()
+(Tiger only); 4 the benchmark's synthetic random-action policy.
+"""
+import numpy as np
+
+STREAM_STEP = 0
+STREAM_RESET = 1
+STREAM_STEP_SPACE = 2
+STREAM_RESET_SPACE = 3
+STREAM_ACTION = 4
+
+_M0 = np.uint64(0xD2511F53)
+_M1 = np.uint64(0xCD9E8D57)
+_W0 = 0x9E3779B9
+_W1 = 0xBB67AE85
+_MASK32 = np.uint64(0xFFFFFFFF)
+
+
+def philox4x32_10(ctr, key):
+    """ctr: uint32[..., 4], key: uint32[..., 2] (broadcastable) -> uint32[..., 4]."""
+    ctr = np.asarray(ctr, dtype=np.uint64)
+    key = np.asarray(key, dtype=np.uint64)
+    c0, c1, c2, c3 = (ctr[..., i].copy() for i in range(4))
+    k0 = key[..., 0].copy()
+    k1 = key[..., 1].copy()
+    for _ in range(10):
+        p0 = _M0 * c0
+        p1 = _M1 * c2
+        hi0, lo0 = p0 >> np.uint64(32), p0 & _MASK32
+        hi1, lo1 = p1 >> np.uint64(32), p1 & _MASK32
+        c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
+        k0 = (k0 + np.uint64(_W0)) & _MASK32
+        k1 = (k1 + np.uint64(_W1)) & _MASK32
+    return np.stack([c0, c1, c2, c3], axis=-1).astype(np.uint32)
+
+
+def stream_words(seed, lane, t, stream, nwords):
+    """First `nwords` 32-bit words of the (seed, lane, t, stream) stream."""
+    nblk = (int(nwords) + 3) // 4
+    ctr = np.zeros((nblk, 4), dtype=np.uint64)
+    ctr[:, 0] = int(lane) & 0xFFFFFFFF
+    ctr[:, 1] = int(t) & 0xFFFFFFFF
+    ctr[:, 2] = (int(t) >> 32) & 0xFFFFFFFF
+    ctr[:, 3] = (int(stream) << 24) | np.arange(nblk, dtype=np.uint64)
+    key = np.array([int(seed) & 0xFFFFFFFF, (int(seed) >> 32) & 0xFFFFFFFF], dtype=np.uint64)
+    return philox4x32_10(ctr, key).reshape(-1)[:nwords]
+
+
+def synthetic_actions(seed, lane0, n, t, n_actions):
+    """The bench's synthetic uniform policy: lanes 4q..4q+3 share block
+    ctr=(q, t_lo, t_hi, STREAM_ACTION<<24); action = (word * n_actions) >> 32."""
+    lanes = np.arange(lane0, lane0 + n, dtype=np.uint64)
+    q = lanes >> np.uint64(2)
+    ctr = np.zeros((n, 4), dtype=np.uint64)
+    ctr[:, 0] = q & _MASK32
+    ctr[:, 1] = int(t) & 0xFFFFFFFF
+    ctr[:, 2] = (int(t) >> 32) & 0xFFFFFFFF
+    ctr[:, 3] = STREAM_ACTION << 24
+    key = np.array([int(seed) & 0xFFFFFFFF, (int(seed) >> 32) & 0xFFFFFFFF], dtype=np.uint64)
+    blk = philox4x32_10(ctr, key).astype(np.uint64)
+    w = blk[np.arange(n), (lanes & np.uint64(3)).astype(np.int64)]
+    return ((w * np.uint64(n_actions)) >> np.uint64(32)).astype(np.int32)
+
+
+# Known-answer vectors for Philox4x32-10 (Random123 kat_vectors).
+KAT = [
+    ((0x00000000, 0x00000000, 0x00000000, 0x00000000), (0x00000000, 0x00000000),
+     (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+    ((0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff), (0xffffffff, 0xffffffff),
+     (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+    ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+     (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)),
+]
+
+
+if __name__ == "__main__":
+    for ctr, key, out in KAT:
+        got = philox4x32_10(np.array(ctr), np.array(key))
+        assert tuple(int(x) for x in got) == out, (ctr, key, [hex(int(x)) for x in got])
+    print("philox KAT ok")

@@ -1,0 +1,845 @@
+/*
+ * pomdp_oracle.c — CPU restatement of d3sm0/gym_pomdp's reset()/step().
+ * TEST INFRASTRUCTURE (see pomdp_oracle.h).  Plain C, scalar, one env object
+ * per lane, written to read like the reference's Python; every block cites the
+ * reference file:line it follows (paths relative to gym_pomdp/envs/).
+ */
+#include "pomdp_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ======================================================================== */
+/* word sources                                                              */
+/* ======================================================================== */
+
+/* MT19937 (Matsumoto & Nishimura 1998) as numpy's legacy RandomState uses it:
+ * np.random.seed(int s) == init_genrand(s)  [SURVEY.md §8c, verified]. */
+void or_ws_seed_mt(or_ws *ws, uint32_t seed)
+{
+    memset(ws, 0, sizeof(*ws));
+    ws->kind = OR_WS_MT19937;
+    ws->mt[0] = seed;
+    for (int i = 1; i < 624; i++)
+        ws->mt[i] = 1812433253u * (ws->mt[i - 1] ^ (ws->mt[i - 1] >> 30)) + (uint32_t)i;
+    ws->mti = 624;
+}
+
+static void mt_refill(or_ws *ws)
+{
+    uint32_t *mt = ws->mt;
+    for (int k = 0; k < 624; k++) {
+        uint32_t y = (mt[k] & 0x80000000u) | (mt[(k + 1) % 624] & 0x7fffffffu);
+        uint32_t v = mt[(k + 397) % 624] ^ (y >> 1);
+        if (y & 1u) v ^= 0x9908b0dfu;
+        mt[k] = v;
+    }
+    ws->mti = 0;
+}
+
+void or_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+    uint32_t k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+void or_ws_philox(or_ws *ws, uint64_t seed, uint32_t lane, uint64_t t, uint32_t stream)
+{
+    ws->kind = OR_WS_PHILOX;
+    ws->key[0] = (uint32_t)seed;
+    ws->key[1] = (uint32_t)(seed >> 32);
+    ws->ctr[0] = lane;
+    ws->ctr[1] = (uint32_t)t;
+    ws->ctr[2] = (uint32_t)(t >> 32);
+    ws->ctr[3] = stream << 24;
+    ws->widx = 0;
+    ws->n_drawn = 0;
+}
+
+uint32_t or_ws_next32(or_ws *ws)
+{
+    ws->n_drawn++;
+    if (ws->kind == OR_WS_MT19937) {
+        if (ws->mti >= 624) mt_refill(ws);
+        uint32_t y = ws->mt[ws->mti++];
+        y ^= y >> 11;
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= y >> 18;
+        return y;
+    }
+    if ((ws->widx & 3u) == 0) {
+        uint32_t c[4] = { ws->ctr[0], ws->ctr[1], ws->ctr[2], ws->ctr[3] | ((ws->widx >> 2) & 0xFFFFFFu) };
+        or_philox4x32_10(c, ws->key, ws->blk);
+    }
+    return ws->blk[ws->widx++ & 3u];
+}
+
+/* numpy legacy next_double: (a >> 5, b >> 6) -> (a * 2^26 + b) / 2^53 */
+uint64_t or_draw_k53(or_ws *ws)
+{
+    uint64_t a = or_ws_next32(ws) >> 5;
+    uint64_t b = or_ws_next32(ws) >> 6;
+    return (a << 26) + b;
+}
+
+/* np.random.randint(n) on the legacy stream: smallest all-ones mask >= n-1,
+ * one 32-bit word per attempt, reject while (word & mask) > n-1; n == 1 draws nothing. */
+uint32_t or_draw_randint(or_ws *ws, uint32_t n)
+{
+    uint32_t rng = n - 1;
+    if (rng == 0) return 0;
+    uint32_t mask = rng;
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+    uint32_t v;
+    do { v = or_ws_next32(ws) & mask; } while (v > rng);
+    return v;
+}
+
+/* ======================================================================== */
+/* captured Bernoulli thresholds (tests/golden/thresholds.json, fixture F2)  */
+/* np.random.binomial(1, p) consumes one double U = k/2^53 and returns       */
+/*   p >  .5 : 1 iff k <= thr          p <= .5 : 1 iff k > thr               */
+/* ======================================================================== */
+#define TWO52 4503599627370496ULL
+static const uint64_t ROCK_THR[29] = {
+    9007199254740992ULL, 8853790118380056ULL, 8705606660380041ULL, 8562470874952118ULL,
+    8424210819838096ULL, 8290660409764310ULL, 8161659216931231ULL, 8037052278299120ULL,
+    7916689909438254ULL, 7800427524720092ULL, 7688125463633382ULL, 7579648823016592ULL,
+    7474867295005110ULL, 7373655010498564ULL, 7275890387960212ULL, 7181455987366794ULL,
+    7090238369133370ULL, 7002127957843708ULL, 6917018910622514ULL, 6834808989991382ULL,
+    6755399441055744ULL, 6678694872875276ULL, 6604603143875268ULL, 6533035251161307ULL,
+    6463905223604296ULL, 6397130018567403ULL, 6332629422150863ULL, 6270325952834808ULL,
+    6210144768404375ULL };
+#define TAG_MOVE_THR   7205759403792794ULL /* binomial(1, .8)  : 1 iff k <= thr */
+#define NET_FAIL_THR   8106479329266893ULL /* binomial(1, .1)  : 1 iff k >  thr */
+#define NET_FAILNB_THR 6034823500676464ULL /* binomial(1, .33) : 1 iff k >  thr */
+#define NET_OBS_THR    8556839292003942ULL /* binomial(1, .95) : 1 iff k <= thr */
+#define TIGER_THR      7656119366529843ULL /* uniform() > .85  : iff k > thr    */
+
+/* ======================================================================== */
+/* env objects                                                               */
+/* ======================================================================== */
+#define MAX_ROCKS 16
+#define MAX_OPP 4
+#define MAX_CELLS 128
+#define MAX_MACH 32
+
+typedef struct { int x, y; } coord;
+
+/* coord.py:155-160  Moves: NORTH (0,1) EAST (1,0) SOUTH (0,-1) WEST (-1,0) */
+static const coord MOVES[4] = { {0, 1}, {1, 0}, {0, -1}, {-1, 0} };
+/* battleship.py:12-21  Compass, enumeration order */
+static const coord COMPASS[9] = { {0, 1}, {1, 0}, {0, -1}, {-1, 0}, {0, 0}, {1, 1}, {1, -1}, {-1, -1}, {-1, 1} };
+
+struct or_env {
+    int kind;
+    /* ---- rock ---- */
+    int size, num_rocks, n_listed;
+    coord start, rock_pos[MAX_ROCKS];
+    int grid[16][16];          /* grid.board[x, y], -1 = empty (rock.py:108-111) */
+    coord agent;
+    int status[MAX_ROCKS];     /* Rock.status in {-1, 0, +1} */
+    /* ---- tag ---- */
+    int n_opponents, obs_cells;
+    uint64_t move_thr;
+    coord opp[MAX_OPP];
+    int num_opp;
+    /* ---- battleship ---- */
+    int xs, ys, max_len;       /* max_len = ctor max_len + 1 (battleship.py:75) */
+    uint8_t occ[16][16], vis[16][16];
+    int remaining;
+    /* ---- tiger ---- */
+    int tiger;
+    /* ---- network ---- */
+    int n_mach, nb_len[MAX_MACH], nb[MAX_MACH][4];
+    int up[MAX_MACH];
+};
+
+/* rock.py:43-64 */
+typedef struct { int size, k_a, k_b, sx, sy, n; int pos[16][2]; } rock_cfg;
+static const rock_cfg ROCK_CFGS[5] = {
+    { 2, 2, 1, 0, 0, 1, { {1, 0} } },
+    { 4, 4, 3, 0, 0, 3, { {1, 0}, {3, 1}, {2, 3} } },
+    { 7, 7, 8, 0, 3, 8, { {2, 0}, {0, 1}, {3, 1}, {6, 3}, {2, 4}, {3, 4}, {5, 5}, {1, 6} } },
+    { 11, 11, 11, 0, 5, 11,
+      { {0, 3}, {0, 7}, {1, 8}, {2, 4}, {3, 3}, {3, 8}, {4, 3}, {5, 8}, {6, 1}, {9, 3}, {9, 9} } },
+    { 15, 15, 15, 0, 5, 16,
+      { {0, 7}, {0, 3}, {1, 2}, {1, 2}, {2, 6}, {3, 7}, {3, 2}, {4, 7}, {5, 2}, {6, 9}, {9, 7}, {9, 1},
+        {11, 8}, {13, 10}, {14, 9}, {12, 2} } },
+};
+
+static int rock_init(or_env *e, int board_size, int num_rocks)
+{
+    const rock_cfg *c = NULL;
+    for (int i = 0; i < 5; i++) if (ROCK_CFGS[i].size == board_size) c = &ROCK_CFGS[i];
+    /* rock.py:101  assert board_size in config and num_rocks in config[bs]['size'] */
+    if (!c || (num_rocks != c->k_a && num_rocks != c->k_b)) return -1;
+    /* (2,2) and (4,4) pass the assert but reset() raises IndexError: rejected here */
+    if (num_rocks > c->n) return -1;
+    e->size = board_size; e->num_rocks = num_rocks; e->n_listed = c->n;
+    e->start.x = c->sx; e->start.y = c->sy;
+    for (int x = 0; x < 16; x++) for (int y = 0; y < 16; y++) e->grid[x][y] = -1;
+    for (int i = 0; i < c->n; i++) {            /* rock.py:110-111: every listed coord is stamped */
+        e->rock_pos[i].x = c->pos[i][0]; e->rock_pos[i].y = c->pos[i][1];
+        e->grid[c->pos[i][0]][c->pos[i][1]] = i;
+    }
+    return 0;
+}
+
+/* network.py:144-168 */
+static int network_init(or_env *e, int n, int problem_type)
+{
+    if (n < 1 || n > MAX_MACH) return -1;
+    e->n_mach = n;
+    memset(e->nb_len, 0, sizeof(e->nb_len));
+    if (problem_type == 3) {                     /* make_3legs_neighbours */
+        if (!(n >= 4 && n % 3 == 1)) return -1;
+        e->nb[0][0] = 1; e->nb[0][1] = 2; e->nb[0][2] = 3; e->nb_len[0] = 3;
+        for (int i = 1; i < n; i++) {
+            if (i < n - 3) e->nb[i][e->nb_len[i]++] = i + 3;
+            if (i <= 4) e->nb[i][e->nb_len[i]++] = 0;
+            else e->nb[i][e->nb_len[i]++] = i - 3;
+        }
+    } else {                                     /* make_ring_neighbours */
+        for (int i = 0; i < n; i++) {
+            e->nb[i][0] = (i + 1) % n; e->nb[i][1] = (i + n - 1) % n; e->nb_len[i] = 2;
+        }
+    }
+    return 0;
+}
+
+or_env *or_env_new(int kind, const int64_t *a, int nargs)
+{
+    or_env *e = (or_env *)calloc(1, sizeof(or_env));
+    e->kind = kind;
+    int rc = 0;
+    switch (kind) {
+    case OR_ENV_ROCK:
+        rc = nargs >= 2 ? rock_init(e, (int)a[0], (int)a[1]) : -1;
+        break;
+    case OR_ENV_TAG:
+        e->n_opponents = nargs >= 1 ? (int)a[0] : 1;
+        e->obs_cells = nargs >= 2 ? (int)a[1] : 29;
+        e->move_thr = nargs >= 4 ? ((uint64_t)(uint32_t)a[2] | ((uint64_t)(uint32_t)a[3] << 32)) : 0;
+        if (e->move_thr == 0) e->move_thr = TAG_MOVE_THR;
+        if (e->n_opponents < 1 || e->n_opponents > MAX_OPP) rc = -1;
+        break;
+    case OR_ENV_BATTLESHIP:
+        if (nargs < 3) { rc = -1; break; }
+        e->xs = (int)a[0]; e->ys = (int)a[1]; e->max_len = (int)a[2] + 1;
+        /* packed layout limits: <= 4 mask words (cells + 6 spare bits), remaining <= 63 */
+        if (e->xs < 1 || e->ys < 1 || e->xs > 16 || e->ys > 16 || e->xs * e->ys > 122) rc = -1;
+        if (a[2] < 2 || a[2] > 10) rc = -1;
+        break;
+    case OR_ENV_TIGER:
+        break;
+    case OR_ENV_NETWORK:
+        rc = nargs >= 2 ? network_init(e, (int)a[0], (int)a[1]) : -1;
+        break;
+    default:
+        rc = -1;
+    }
+    if (rc) { free(e); return NULL; }
+    return e;
+}
+
+or_env *or_env_clone(const or_env *e)
+{
+    or_env *c = (or_env *)malloc(sizeof(or_env));
+    memcpy(c, e, sizeof(or_env));
+    return c;
+}
+
+void or_env_free(or_env *e) { free(e); }
+
+int or_env_n_actions(const or_env *e)
+{
+    switch (e->kind) {
+    case OR_ENV_ROCK: return 5 + e->num_rocks;          /* rock.py:113 */
+    case OR_ENV_TAG: return 5;                           /* tag.py:92   */
+    case OR_ENV_BATTLESHIP: return e->xs * e->ys;        /* battleship.py:69 */
+    case OR_ENV_TIGER: return 3;                         /* tiger.py:52 */
+    default: return 2 * e->n_mach + 1;                   /* network.py:33 */
+    }
+}
+
+int or_env_n_obs(const or_env *e)
+{
+    switch (e->kind) {
+    case OR_ENV_ROCK: return 3;
+    case OR_ENV_TAG: return e->obs_cells + 1;            /* tag.py:94 */
+    case OR_ENV_BATTLESHIP: return 2;
+    default: return 3;
+    }
+}
+
+int or_env_compact_len(const or_env *e)
+{
+    switch (e->kind) {
+    case OR_ENV_ROCK: return 2 + e->num_rocks;
+    case OR_ENV_TAG: return 2 + e->n_opponents;
+    case OR_ENV_BATTLESHIP: return 1 + 2 * e->xs * e->ys;
+    case OR_ENV_TIGER: return 1;
+    default: return e->n_mach;
+    }
+}
+
+int or_env_reward_kind(const or_env *e)
+{
+    return (e->kind == OR_ENV_TAG || e->kind == OR_ENV_NETWORK) ? OR_REWARD_F32 : OR_REWARD_I32;
+}
+
+/* ------------------------------------------------------------------------ */
+/* RockSample                                                                */
+/* ------------------------------------------------------------------------ */
+/* rock.py:236-241 reset -> 266-271 _get_init_state -> 78-86 Rock.__init__:
+ * status = int(np.sign(np.random.uniform(0, 1) - .5)), rocks 0..K-1 in order. */
+static int rock_reset(or_env *e, or_ws *np_rng)
+{
+    e->agent = e->start;
+    for (int i = 0; i < e->num_rocks; i++) {
+        uint64_t k = or_draw_k53(np_rng);
+        e->status[i] = (k > TWO52) - (k < TWO52);
+    }
+    return 0; /* Obs.NULL */
+}
+
+/* rock.py:123-194 step, 401-407 _sample_ob, 383-387 _efficiency,
+ * coord.py:133-135 euclidean_distance (ord-1 norm == L1). */
+static void rock_step(or_env *e, int action, or_ws *np_rng, int *ob_out, double *rw_out, int *done_out)
+{
+    int reward = 0, ob = 0;
+    if (action < 4) {
+        if (action == 1) {                                   /* EAST  rock.py:135-141 */
+            if (e->agent.x + 1 < e->size) e->agent.x += 1;
+            else { *ob_out = 0; *rw_out = 10; *done_out = 1; return; }
+        } else if (action == 0) {                            /* NORTH rock.py:142-146 */
+            if (e->agent.y + 1 < e->size) e->agent.y += 1; else reward = -100;
+        } else if (action == 2) {                            /* SOUTH rock.py:147-151 */
+            if (e->agent.y - 1 >= 0) e->agent.y -= 1; else reward = -100;
+        } else {                                             /* WEST  rock.py:152-156 */
+            if (e->agent.x - 1 >= 0) e->agent.x -= 1; else reward = -100;
+        }
+    }
+    if (action == 4) {                                       /* SAMPLE rock.py:160-169 */
+        int rock = e->grid[e->agent.x][e->agent.y];
+        /* ids >= num_rocks raise IndexError in the reference;
+         * the build treats them as "no rock here". */
+        if (rock >= 0 && rock < e->num_rocks && e->status[rock] != 0) {
+            reward = e->status[rock] == 1 ? 10 : -10;
+            e->status[rock] = 0;
+        } else reward = -100;
+    }
+    if (action > 4) {                                        /* CHECK rock.py:171-175 */
+        int rock = action - 5;
+        int dx = e->agent.x - e->rock_pos[rock].x, dy = e->agent.y - e->rock_pos[rock].y;
+        int d = (dx < 0 ? -dx : dx) + (dy < 0 ? -dy : dy);
+        uint64_t k = or_draw_k53(np_rng);                    /* np.random.binomial(1, eff) */
+        int correct = k <= ROCK_THR[d];
+        if (correct) ob = e->status[rock] == 1 ? 2 : 1;      /* rock.py:404-407 */
+        else ob = e->status[rock] == 1 ? 1 : 2;
+    }
+    *ob_out = ob; *rw_out = reward; *done_out = (reward == -100);   /* rock.py:193 */
+}
+
+/* ------------------------------------------------------------------------ */
+/* Tag                                                                       */
+/* ------------------------------------------------------------------------ */
+/* tag.py:46-50 */
+static int tag_inside(coord c)
+{
+    if (c.y >= 2) return c.x >= 5 && c.x < 8 && c.y < 5;
+    return c.x >= 0 && c.x < 10 && c.y >= 0;
+}
+/* tag.py:52-57 */
+static coord tag_coord(int idx)
+{
+    coord c;
+    if (idx < 20) { c.x = idx % 10; c.y = idx / 10; return c; }
+    idx -= 20;
+    c.x = idx % 3 + 5; c.y = idx / 3 + 2;
+    return c;
+}
+/* tag.py:59-66 */
+static int tag_index(coord c)
+{
+    if (c.y < 2) return c.y * 10 + c.x;
+    return 20 + (c.y - 2) * 3 + c.x - 5;
+}
+/* tag.py:219-226 */
+static int tag_sample_ob(const or_env *e, int action)
+{
+    int ob = tag_index(e->agent);
+    if (action < 4)
+        for (int i = 0; i < e->n_opponents; i++)
+            if (e->opp[i].x == e->agent.x && e->opp[i].y == e->agent.y) ob = e->obs_cells;
+    return ob;
+}
+/* tag.py:97-102 reset, 181-193 _get_init_state, 43-44 TagGrid.sample = randint(0, 29) */
+static int tag_reset(or_env *e, or_ws *np_rng)
+{
+    e->agent = tag_coord((int)or_draw_randint(np_rng, 29));
+    for (int i = 0; i < e->n_opponents; i++) e->opp[i] = tag_coord((int)or_draw_randint(np_rng, 29));
+    e->num_opp = e->n_opponents;
+    return tag_sample_ob(e, 0);
+}
+/* tag.py:201-207 move_opponent, 260-280 _admissable_actions */
+static void tag_move_opponent(or_env *e, int i, or_ws *np_rng)
+{
+    coord o = e->opp[i], a = e->agent;
+    int acts[8], n = 0;                                /* indices into MOVES: N0 E1 S2 W3 */
+    if (o.x >= a.x) acts[n++] = 1;
+    if (o.y >= a.y) acts[n++] = 0;
+    if (o.x <= a.x) acts[n++] = 3;
+    if (o.y <= a.y) acts[n++] = 2;
+    if (o.x == a.x && o.y > a.y) acts[n++] = 0;
+    if (o.y == a.y && o.x > a.x) acts[n++] = 1;
+    if (o.x == a.x && o.y < a.y) acts[n++] = 2;
+    if (o.y == a.y && o.x < a.x) acts[n++] = 3;
+    uint64_t k = or_draw_k53(np_rng);                  /* binomial(1, move_prob) */
+    if (k <= e->move_thr) {
+        int pick = acts[or_draw_randint(np_rng, (uint32_t)n)];   /* np.random.choice(actions) */
+        coord nx = { o.x + MOVES[pick].x, o.y + MOVES[pick].y };
+        if (tag_inside(nx)) e->opp[i] = nx;
+    }
+}
+/* tag.py:108-143 */
+static void tag_step(or_env *e, int action, or_ws *np_rng, int *ob_out, double *rw_out, int *done_out)
+{
+    double reward;
+    if (action == 4) {
+        int tagged = 0;
+        reward = 0.;
+        for (int i = 0; i < e->n_opponents; i++) {
+            if (e->opp[i].x == e->agent.x && e->opp[i].y == e->agent.y) {
+                reward = 10.; tagged = 1; e->num_opp -= 1;
+            } else if (tag_inside(e->opp[i]) && e->num_opp > 0) {
+                tag_move_opponent(e, i, np_rng);
+            }
+        }
+        if (!tagged) reward = -10.;
+    } else {
+        reward = -1.;
+        coord nx = { e->agent.x + MOVES[action].x, e->agent.y + MOVES[action].y };
+        if (tag_inside(nx)) e->agent = nx;
+    }
+    *ob_out = tag_sample_ob(e, action);
+    *rw_out = reward;
+    *done_out = (e->num_opp == 0);
+}
+
+/* ------------------------------------------------------------------------ */
+/* BattleShip                                                                */
+/* ------------------------------------------------------------------------ */
+/* coord.py:115-116 */
+static int bs_inside(const or_env *e, coord c) { return c.x >= 0 && c.y >= 0 && c.x < e->xs && c.y < e->ys; }
+
+/* battleship.py:195-211 */
+static int bs_collision(const or_env *e, coord pos, int dir, int length)
+{
+    for (int i = 0; i < length + 1; i++) {
+        coord nx = { pos.x + COMPASS[dir].x, pos.y + COMPASS[dir].y };
+        if (!bs_inside(e, nx)) return 1;
+        if (e->occ[pos.x][pos.y]) return 1;
+        for (int adj = 0; adj < 8; adj++) {
+            coord c = { pos.x + COMPASS[adj].x, pos.y + COMPASS[adj].y };
+            if (bs_inside(e, c) && e->occ[c.x][c.y]) return 1;
+        }
+        pos = nx;
+    }
+    return 0;
+}
+
+/* battleship.py:131-137 reset, 167-180 _get_init_state, 182-193 mark_ship,
+ * coord.py:122-123 Grid.sample, battleship.py:33-37 Ship.__init__ (pos drawn before direction) */
+static int bs_reset(or_env *e, or_ws *np_rng)
+{
+    memset(e->occ, 0, sizeof(e->occ));
+    memset(e->vis, 0, sizeof(e->vis));
+    e->remaining = 0;
+    for (int length = e->max_len - 1; length >= 2; length--) {
+        coord pos; int dir;
+        for (;;) {
+            int idx = (int)or_draw_randint(np_rng, (uint32_t)(e->xs * e->ys));
+            pos.x = idx % e->xs; pos.y = idx / e->xs;          /* coord.py:118-120 */
+            dir = (int)or_draw_randint(np_rng, 4);
+            if (!bs_collision(e, pos, dir, length)) break;
+        }
+        for (int i = 0; i < length; i++) {
+            e->occ[pos.x][pos.y] = 1;
+            e->remaining += 1;                                 /* board is fresh: never visited */
+            pos.x += COMPASS[dir].x; pos.y += COMPASS[dir].y;
+        }
+    }
+    return 0;
+}
+
+/* battleship.py:91-122 */
+static void bs_step(or_env *e, int action, int *ob_out, double *rw_out, int *done_out)
+{
+    int x = action % e->xs, y = action / e->xs;
+    int reward = 0, obs, done = 0;
+    if (e->vis[x][y]) { reward -= 10; obs = 0; }
+    else {
+        if (e->occ[x][y]) { reward -= 1; obs = 1; e->remaining -= 1; }
+        else { reward -= 1; obs = 0; }
+        e->vis[x][y] = 1;
+    }
+    if (e->remaining == 0) { reward += e->xs * e->ys; done = 1; }
+    *ob_out = obs; *rw_out = reward; *done_out = done;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Tiger                                                                     */
+/* ------------------------------------------------------------------------ */
+/* tiger.py:60-66; state_space.sample() draws from the gym-space RNG */
+static int tiger_reset(or_env *e, or_ws *space_rng)
+{
+    e->tiger = (int)or_draw_randint(space_rng, 2);
+    return 2; /* Obs.NULL */
+}
+/* tiger.py:72-88, 117-119, 140-172 */
+static void tiger_step(or_env *e, int action, or_ws *np_rng, or_ws *space_rng,
+                       int *ob_out, double *rw_out, int *done_out)
+{
+    int terminal = (action != 2) && (action == e->tiger);
+    int rw = action == 2 ? -1 : (terminal ? -20 : 10);
+    if (terminal) { *ob_out = e->tiger; *rw_out = rw; *done_out = 1; return; }
+    if (action == 0 || action == 1) e->tiger = (int)or_draw_randint(space_rng, 2);
+    uint64_t k = or_draw_k53(np_rng);                 /* p = np.random.uniform(), always drawn */
+    int ob = 2;
+    if (action == 2) {
+        int flip = k > TIGER_THR;                     /* p > correct_prob (.85) */
+        ob = e->tiger == 0 ? (flip ? 1 : 0) : (flip ? 0 : 1);
+    }
+    *ob_out = ob; *rw_out = rw; *done_out = 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Network                                                                   */
+/* ------------------------------------------------------------------------ */
+/* network.py:61-69 */
+static int network_reset(or_env *e)
+{
+    for (int i = 0; i < e->n_mach; i++) e->up[i] = 1;
+    return 0; /* Obs.OFF */
+}
+/* network.py:71-114 */
+static void network_step(or_env *e, int action, or_ws *np_rng, int *ob_out, double *rw_out, int *done_out)
+{
+    int n = e->n_mach, n_fail[MAX_MACH];
+    double reward = 0;
+    int ob = 2;
+    for (int i = 0; i < n; i++) {
+        n_fail[i] = 0;
+        for (int j = 0; j < e->nb_len[i]; j++) if (e->up[e->nb[i][j]] == 0) n_fail[i] = 1;
+    }
+    for (int i = 0; i < n; i++) if (e->up[i] == 1) reward += e->nb_len[i] > 2 ? 2 : 1;
+    for (int i = 0; i < n; i++) {
+        if (e->up[i]) {
+            uint64_t k = or_draw_k53(np_rng);
+            if (!n_fail[i]) e->up[i] = 1 - (k > NET_FAIL_THR);
+            else e->up[i] = 1 - (k > NET_FAILNB_THR);
+        }
+    }
+    if (action < 2 * n) {
+        int machine = action / 2, reboot = action % 2;
+        if (reboot) {
+            reward -= 2.5;
+            e->up[machine] = 1;
+            ob = or_draw_k53(np_rng) <= NET_OBS_THR;
+        } else {
+            reward -= .1;
+            if (or_draw_k53(np_rng) <= NET_OBS_THR) ob = e->up[machine];
+            else ob = 1 - e->up[machine];
+        }
+    }
+    *ob_out = ob; *rw_out = reward; *done_out = 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* dispatch                                                                  */
+/* ------------------------------------------------------------------------ */
+int or_env_reset(or_env *e, or_ws *np_rng, or_ws *space_rng)
+{
+    switch (e->kind) {
+    case OR_ENV_ROCK: return rock_reset(e, np_rng);
+    case OR_ENV_TAG: return tag_reset(e, np_rng);
+    case OR_ENV_BATTLESHIP: return bs_reset(e, np_rng);
+    case OR_ENV_TIGER: return tiger_reset(e, space_rng);
+    default: return network_reset(e);
+    }
+}
+
+void or_env_step(or_env *e, int action, or_ws *np_rng, or_ws *space_rng, int *ob, double *reward, int *done)
+{
+    switch (e->kind) {
+    case OR_ENV_ROCK: rock_step(e, action, np_rng, ob, reward, done); break;
+    case OR_ENV_TAG: tag_step(e, action, np_rng, ob, reward, done); break;
+    case OR_ENV_BATTLESHIP: bs_step(e, action, ob, reward, done); break;
+    case OR_ENV_TIGER: tiger_step(e, action, np_rng, space_rng, ob, reward, done); break;
+    default: network_step(e, action, np_rng, ob, reward, done); break;
+    }
+}
+
+/* the reference-side parity format (oracle/ref_harness/harness.py: compact_state) */
+void or_env_compact(const or_env *e, int64_t *out)
+{
+    switch (e->kind) {
+    case OR_ENV_ROCK:
+        out[0] = e->agent.x; out[1] = e->agent.y;
+        for (int i = 0; i < e->num_rocks; i++) out[2 + i] = e->status[i];
+        break;
+    case OR_ENV_TAG:
+        out[0] = tag_index(e->agent);
+        for (int i = 0; i < e->n_opponents; i++) out[1 + i] = tag_index(e->opp[i]);
+        out[1 + e->n_opponents] = e->num_opp;
+        break;
+    case OR_ENV_BATTLESHIP: {
+        int c = e->xs * e->ys;
+        out[0] = e->remaining;
+        for (int a = 0; a < c; a++) {
+            out[1 + a] = e->occ[a % e->xs][a / e->xs];
+            out[1 + c + a] = e->vis[a % e->xs][a / e->xs];
+        }
+        break;
+    }
+    case OR_ENV_TIGER:
+        out[0] = e->tiger;
+        break;
+    default:
+        for (int i = 0; i < e->n_mach; i++) out[i] = e->up[i];
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* packed int32 lane state (the HIP path's HBM layout)    */
+/* ------------------------------------------------------------------------ */
+static int bs_mask_words(const or_env *e) { return (e->xs * e->ys + 6 + 31) / 32; }
+
+int or_env_words(const or_env *e)
+{
+    switch (e->kind) {
+    case OR_ENV_ROCK: return e->num_rocks <= 12 ? 1 : 2;
+    case OR_ENV_BATTLESHIP: return 2 * bs_mask_words(e);
+    default: return 1;
+    }
+}
+
+void or_env_pack(const or_env *e, uint32_t *w)
+{
+    int nw = or_env_words(e);
+    for (int i = 0; i < nw; i++) w[i] = 0;
+    switch (e->kind) {
+    case OR_ENV_ROCK:
+        w[0] = (uint32_t)e->agent.x | ((uint32_t)e->agent.y << 4);
+        for (int i = 0; i < e->num_rocks; i++) {
+            uint32_t code = (uint32_t)(e->status[i] + 1);
+            if (i < 12) w[0] |= code << (8 + 2 * i);
+            else w[1] |= code << (2 * (i - 12));
+        }
+        break;
+    case OR_ENV_TAG: {
+        w[0] = (uint32_t)tag_index(e->agent);
+        for (int i = 0; i < e->n_opponents; i++) w[0] |= (uint32_t)tag_index(e->opp[i]) << (5 + 5 * i);
+        int no = e->num_opp < -64 ? -64 : e->num_opp;          /* 7-bit two's complement, saturating */
+        w[0] |= ((uint32_t)no & 0x7Fu) << 25;
+        break;
+    }
+    case OR_ENV_BATTLESHIP: {
+        int mw = bs_mask_words(e), c = e->xs * e->ys;
+        for (int a = 0; a < c; a++) {
+            if (e->occ[a % e->xs][a / e->xs]) w[a >> 5] |= 1u << (a & 31);
+            if (e->vis[a % e->xs][a / e->xs]) w[mw + (a >> 5)] |= 1u << (a & 31);
+        }
+        w[2 * mw - 1] |= (uint32_t)e->remaining << 26;
+        break;
+    }
+    case OR_ENV_TIGER:
+        w[0] = (uint32_t)e->tiger;
+        break;
+    default:
+        for (int i = 0; i < e->n_mach; i++) w[0] |= (uint32_t)e->up[i] << i;
+    }
+}
+
+void or_env_unpack(or_env *e, const uint32_t *w)
+{
+    switch (e->kind) {
+    case OR_ENV_ROCK:
+        e->agent.x = w[0] & 15; e->agent.y = (w[0] >> 4) & 15;
+        for (int i = 0; i < e->num_rocks; i++) {
+            uint32_t code = i < 12 ? (w[0] >> (8 + 2 * i)) & 3u : (w[1] >> (2 * (i - 12))) & 3u;
+            e->status[i] = (int)code - 1;
+        }
+        break;
+    case OR_ENV_TAG: {
+        e->agent = tag_coord((int)(w[0] & 31));
+        for (int i = 0; i < e->n_opponents; i++) e->opp[i] = tag_coord((int)((w[0] >> (5 + 5 * i)) & 31));
+        int no = (int)((w[0] >> 25) & 0x7F);
+        e->num_opp = no >= 64 ? no - 128 : no;
+        break;
+    }
+    case OR_ENV_BATTLESHIP: {
+        int mw = bs_mask_words(e), c = e->xs * e->ys;
+        for (int a = 0; a < c; a++) {
+            e->occ[a % e->xs][a / e->xs] = (w[a >> 5] >> (a & 31)) & 1u;
+            e->vis[a % e->xs][a / e->xs] = (w[mw + (a >> 5)] >> (a & 31)) & 1u;
+        }
+        e->remaining = (int)(w[2 * mw - 1] >> 26);
+        break;
+    }
+    case OR_ENV_TIGER:
+        e->tiger = (int)(w[0] & 1);
+        break;
+    default:
+        for (int i = 0; i < e->n_mach; i++) e->up[i] = (w[0] >> i) & 1u;
+    }
+}
+
+/* ======================================================================== */
+/* mode A driver                                                             */
+/* ======================================================================== */
+int or_trace_mt(or_env *e, uint32_t seed, uint32_t space_seed, const int64_t *actions, int64_t T,
+                int64_t *ob0, int64_t *state0, int64_t *ob, double *reward, uint8_t *done,
+                int64_t *state_pre, int64_t *state, int64_t *reset_ob)
+{
+    or_ws *np_rng = (or_ws *)malloc(sizeof(or_ws)), *sp_rng = (or_ws *)malloc(sizeof(or_ws));
+    or_ws_seed_mt(np_rng, seed);          /* env.seed(seed) -> np.random.seed(seed) */
+    or_ws_seed_mt(sp_rng, space_seed);    /* gym.spaces RNG (stub-owned, Tiger only) */
+    int S = or_env_compact_len(e), nA = or_env_n_actions(e), rc = 0;
+    *ob0 = or_env_reset(e, np_rng, sp_rng);
+    or_env_compact(e, state0);
+    for (int64_t i = 0; i < T; i++) {
+        int o, d; double r;
+        if (actions[i] < 0 || actions[i] >= nA) { rc = -1; break; }
+        or_env_step(e, (int)actions[i], np_rng, sp_rng, &o, &r, &d);
+        ob[i] = o; reward[i] = r; done[i] = (uint8_t)d;
+        or_env_compact(e, state_pre + i * S);
+        reset_ob[i] = -1;
+        if (d) reset_ob[i] = or_env_reset(e, np_rng, sp_rng);
+        or_env_compact(e, state + i * S);
+    }
+    free(np_rng); free(sp_rng);
+    return rc;
+}
+
+/* ======================================================================== */
+/* mode B drivers                                                            */
+/* ======================================================================== */
+int or_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+void or_batch_reset(const or_env *proto, uint32_t *state, int32_t *ob, int64_t n,
+                    uint64_t seed, uint32_t lane0, uint64_t t, int nthreads)
+{
+    int W = or_env_words(proto);
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel num_threads(nthreads)
+    {
+        or_env e = *proto;
+        or_ws np_rng, sp_rng;
+        uint32_t w[8];
+#pragma omp for schedule(static)
+        for (int64_t i = 0; i < n; i++) {
+            or_ws_philox(&np_rng, seed, lane0 + (uint32_t)i, t, OR_STREAM_RESET);
+            or_ws_philox(&sp_rng, seed, lane0 + (uint32_t)i, t, OR_STREAM_RESET_SPACE);
+            int o = or_env_reset(&e, &np_rng, &sp_rng);
+            or_env_pack(&e, w);
+            for (int j = 0; j < W; j++) state[(int64_t)j * n + i] = w[j];
+            if (ob) ob[i] = o;
+        }
+    }
+}
+
+int64_t or_batch_step(const or_env *proto, uint32_t *state, const int32_t *action, int32_t *ob,
+                      void *reward, uint8_t *done, int64_t n, uint64_t seed, uint32_t lane0,
+                      uint64_t t, int auto_reset, int nthreads)
+{
+    int W = or_env_words(proto), nA = or_env_n_actions(proto), rk = or_env_reward_kind(proto);
+    int64_t bad = 0;
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel num_threads(nthreads) reduction(+ : bad)
+    {
+        or_env e = *proto;
+        or_ws np_rng, sp_rng;
+        uint32_t w[8];
+#pragma omp for schedule(static)
+        for (int64_t i = 0; i < n; i++) {
+            int o = 0, d = 0; double r = 0;
+            int a = action[i];
+            if (!auto_reset && done[i]) {           /* frozen lane: reference would assert */
+                d = 1;
+            } else if (a < 0 || a >= nA) {          /* reference: AssertionError; build: no-op + count */
+                bad++;
+            } else {
+                for (int j = 0; j < W; j++) w[j] = state[(int64_t)j * n + i];
+                or_env_unpack(&e, w);
+                or_ws_philox(&np_rng, seed, lane0 + (uint32_t)i, t, OR_STREAM_STEP);
+                or_ws_philox(&sp_rng, seed, lane0 + (uint32_t)i, t, OR_STREAM_STEP_SPACE);
+                or_env_step(&e, a, &np_rng, &sp_rng, &o, &r, &d);
+                if (d && auto_reset) {
+                    or_ws_philox(&np_rng, seed, lane0 + (uint32_t)i, t, OR_STREAM_RESET);
+                    or_ws_philox(&sp_rng, seed, lane0 + (uint32_t)i, t, OR_STREAM_RESET_SPACE);
+                    or_env_reset(&e, &np_rng, &sp_rng);
+                }
+                or_env_pack(&e, w);
+                for (int j = 0; j < W; j++) state[(int64_t)j * n + i] = w[j];
+            }
+            ob[i] = o;
+            if (rk == OR_REWARD_I32) ((int32_t *)reward)[i] = (int32_t)r;
+            else ((float *)reward)[i] = (float)r;
+            done[i] = (uint8_t)d;
+        }
+    }
+    return bad;
+}
+
+void or_batch_compact(const or_env *proto, const uint32_t *state, int64_t *out, int64_t n)
+{
+    int W = or_env_words(proto), S = or_env_compact_len(proto);
+    or_env e = *proto;
+    uint32_t w[8];
+    for (int64_t i = 0; i < n; i++) {
+        for (int j = 0; j < W; j++) w[j] = state[(int64_t)j * n + i];
+        or_env_unpack(&e, w);
+        or_env_compact(&e, out + i * S);
+    }
+}
+
+/* the bench's synthetic uniform policy (oracle/philox_ref.py: synthetic_actions) */
+void or_synthetic_actions(int32_t *action, int64_t n, uint64_t seed, uint32_t lane0, uint64_t t,
+                          uint32_t n_actions, int nthreads)
+{
+    uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+    for (int64_t i = 0; i < n; i++) {
+        uint32_t lane = lane0 + (uint32_t)i;
+        uint32_t c[4] = { lane >> 2, (uint32_t)t, (uint32_t)(t >> 32), (uint32_t)OR_STREAM_ACTION << 24 }, o[4];
+        or_philox4x32_10(c, key, o);
+        action[i] = (int32_t)(((uint64_t)o[lane & 3u] * n_actions) >> 32);
+    }
+}

@@ -1,0 +1,105 @@
+/*
+ * pomdp_oracle.h — CPU restatement of d3sm0/gym_pomdp's reset()/step() semantics.
+ *
+ * TEST INFRASTRUCTURE.  This library is the parity oracle for the HIP path in
+ * gym_pomdp_amd/csrc.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load it; the product path never does and fails loudly
+ * when its HIP extension is missing.
+ *
+ * Parity status: PINNED.  The restatement is checked (tests/test_oracle_*.py)
+ * against golden traces generated in the build container by importing the
+ * unmodified reference (tests/golden/generate_golden.py):
+ *   mode A  the reference on its native np.random.seed(s) MT19937 stream,
+ *   mode B  the reference with its MT19937 state overwritten so that numpy
+ *           derives its draws from this build's Philox4x32-10 word stream.
+ * Every function below cites the reference file:line it follows.
+ */
+#ifndef POMDP_ORACLE_H
+#define POMDP_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- 32-bit word sources ------------------------------------------------ */
+enum { OR_WS_MT19937 = 0, OR_WS_PHILOX = 1 };
+enum { OR_STREAM_STEP = 0, OR_STREAM_RESET = 1, OR_STREAM_STEP_SPACE = 2,
+       OR_STREAM_RESET_SPACE = 3, OR_STREAM_ACTION = 4 };
+
+typedef struct or_ws {
+    int kind;
+    /* MT19937 (numpy legacy RandomState, np.random.seed(int)) */
+    uint32_t mt[624];
+    int mti;
+    /* Philox4x32-10 stream: key=(seed lo,hi) ctr=(lane,t lo,t hi,stream<<24|blk) */
+    uint32_t key[2];
+    uint32_t ctr[4];
+    uint32_t blk[4];
+    uint32_t widx;
+    uint64_t n_drawn;
+} or_ws;
+
+void     or_ws_seed_mt(or_ws *ws, uint32_t seed);
+void     or_ws_philox(or_ws *ws, uint64_t seed, uint32_t lane, uint64_t t, uint32_t stream);
+uint32_t or_ws_next32(or_ws *ws);
+void     or_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+
+/* numpy legacy constructions on top of a word source */
+uint64_t or_draw_k53(or_ws *ws);           /* U = k / 2^53, k returned      */
+uint32_t or_draw_randint(or_ws *ws, uint32_t n); /* np.random.randint(n)    */
+
+/* ---- envs ---------------------------------------------------------------- */
+enum { OR_ENV_ROCK = 0, OR_ENV_TAG = 1, OR_ENV_BATTLESHIP = 2, OR_ENV_TIGER = 3, OR_ENV_NETWORK = 4 };
+enum { OR_REWARD_I32 = 0, OR_REWARD_F32 = 1 };
+
+typedef struct or_env or_env;
+
+/* args: rock (board_size, num_rocks)
+ *       tag (num_opponents, obs_cells, move_thr_lo, move_thr_hi)  thr==0 -> captured value for 0.8
+ *       battleship (x_size, y_size, max_len)
+ *       tiger ()
+ *       network (n_machines, problem_type)
+ * Returns NULL for configurations the reference rejects at construction. */
+or_env *or_env_new(int kind, const int64_t *args, int nargs);
+or_env *or_env_clone(const or_env *e);
+void    or_env_free(or_env *e);
+int     or_env_n_actions(const or_env *e);
+int     or_env_n_obs(const or_env *e);
+int     or_env_compact_len(const or_env *e);
+int     or_env_words(const or_env *e);        /* packed int32 words per lane (GPU layout) */
+int     or_env_reward_kind(const or_env *e);
+
+int  or_env_reset(or_env *e, or_ws *np_rng, or_ws *space_rng);   /* returns ob */
+void or_env_step(or_env *e, int action, or_ws *np_rng, or_ws *space_rng,
+                 int *ob, double *reward, int *done);
+void or_env_compact(const or_env *e, int64_t *out);
+void or_env_pack(const or_env *e, uint32_t *words);
+void or_env_unpack(or_env *e, const uint32_t *words);
+
+/* ---- mode A: sequential single-env trace on MT19937 ----------------------- */
+/* out_* arrays have T entries (state arrays T*compact_len).  reset() is called
+ * right after each done step.  Returns 0, or -1 on invalid action. */
+int or_trace_mt(or_env *e, uint32_t seed, uint32_t space_seed, const int64_t *actions, int64_t T,
+                int64_t *ob0, int64_t *state0, int64_t *ob, double *reward, uint8_t *done,
+                int64_t *state_pre, int64_t *state, int64_t *reset_ob);
+
+/* ---- mode B: batched lanes on Philox streams (GPU-parity + CPU baseline) --- */
+/* state: uint32 [words][n] SoA.  reward: int32[n] or float[n] per reward kind. */
+void or_batch_reset(const or_env *proto, uint32_t *state, int32_t *ob, int64_t n,
+                    uint64_t seed, uint32_t lane0, uint64_t t, int nthreads);
+/* returns the number of lanes whose action was out of range (treated as no-op) */
+int64_t or_batch_step(const or_env *proto, uint32_t *state, const int32_t *action, int32_t *ob,
+                      void *reward, uint8_t *done, int64_t n, uint64_t seed, uint32_t lane0,
+                      uint64_t t, int auto_reset, int nthreads);
+/* compact (reference-format) state of every lane: out[n][compact_len] */
+void or_batch_compact(const or_env *proto, const uint32_t *state, int64_t *out, int64_t n);
+void or_synthetic_actions(int32_t *action, int64_t n, uint64_t seed, uint32_t lane0, uint64_t t,
+                          uint32_t n_actions, int nthreads);
+int  or_max_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

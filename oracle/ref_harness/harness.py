@@ -1,0 +1,238 @@
+"""Drive the UNMODIFIED reference (d3sm0/gym_pomdp, /root/reference) to produce
+golden traces.  TEST INFRASTRUCTURE, container-only: /root/reference does not
+exist on the GPU box, so nothing here is imported by tests marked `gpu`, by
+smoke() or by bench.py — they consume the committed fixtures in tests/golden/.
+
+Two trace modes:
+
+mode A ("MT-exact")       env.seed(s) on the process-global legacy MT19937
+                          stream, exactly as a user of the reference would.
+mode B ("Philox-injected") before every reference reset()/step() call the
+                          global RandomState's MT19937 state is overwritten so
+                          that its next 624 outputs are the 32-bit words of the
+                          build's Philox stream for (seed, lane, t, stream).
+                          numpy's own C code then derives uniform / binomial /
+                          randint / choice from those words, so no numpy
+                          algorithm is restated on the reference side.
+
+No reference file is modified, copied or monkeypatched.
+"""
+import os
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_REPO = os.path.dirname(os.path.dirname(_HERE))
+REFERENCE_ROOT = os.environ.get("GYM_POMDP_REFERENCE", "/root/reference")
+
+if _REPO not in sys.path:
+    sys.path.insert(0, _REPO)
+from oracle import philox_ref as px  # noqa: E402
+
+
+def reference_available():
+    return os.path.isdir(os.path.join(REFERENCE_ROOT, "gym_pomdp"))
+
+
+def load_reference():
+    """Import the reference package under the gym/pygame stand-ins."""
+    sys.dont_write_bytecode = True  # never drop __pycache__ into /root/reference
+    stubs = os.path.join(_HERE, "stubs")
+    for p in (REFERENCE_ROOT, stubs):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import gym  # noqa: F401  (the stub)
+    import gym_pomdp  # noqa: F401  (the reference: registers its ids)
+    import gym_pomdp.envs as envs
+    return envs
+
+
+# ---------------------------------------------------------------------------
+# MT19937 state injection
+# ---------------------------------------------------------------------------
+def untemper(y):
+    """Invert MT19937's output tempering (vectorised, uint32)."""
+    y = np.asarray(y, dtype=np.uint64) & np.uint64(0xFFFFFFFF)
+    # y ^= y >> 18
+    y = y ^ (y >> np.uint64(18))
+    # y ^= (y << 15) & 0xefc60000
+    y = y ^ ((y << np.uint64(15)) & np.uint64(0xEFC60000))
+    # y ^= (y << 7) & 0x9d2c5680   (iterate to recover all bits)
+    x = y
+    for _ in range(5):
+        x = y ^ ((x << np.uint64(7)) & np.uint64(0x9D2C5680))
+    y = x & np.uint64(0xFFFFFFFF)
+    # y ^= y >> 11  (iterate)
+    x = y
+    for _ in range(3):
+        x = y ^ (x >> np.uint64(11))
+    return (x & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+
+
+N_INJECT = 624
+
+
+def inject_words(words, rs=None):
+    """Make the next len(words) (<= 624) uint32 outputs of `rs` (default: the
+    global np.random stream) equal `words`."""
+    key = np.zeros(N_INJECT, dtype=np.uint32)
+    w = np.asarray(words, dtype=np.uint32)
+    key[: len(w)] = untemper(w)
+    state = ("MT19937", key, 0, 0, 0.0)
+    if rs is None:
+        np.random.set_state(state)
+    else:
+        rs.set_state(state)
+
+
+def consumed_words(rs=None):
+    st = np.random.get_state() if rs is None else rs.get_state()
+    return int(st[2])
+
+
+def inject_stream(seed, lane, t, stream, rs=None):
+    inject_words(px.stream_words(seed, lane, t, stream, N_INJECT), rs)
+
+
+# ---------------------------------------------------------------------------
+# env construction and compact integer state
+# ---------------------------------------------------------------------------
+ENV_CLASSES = {
+    "rock": "RockEnv",
+    "tag": "TagEnv",
+    "battleship": "BattleShipEnv",
+    "tiger": "TigerEnv",
+    "network": "NetworkEnv",
+}
+
+
+def make_ref_env(name, **kwargs):
+    envs = load_reference()
+    return getattr(envs, ENV_CLASSES[name])(**kwargs)
+
+
+def compact_state(name, env):
+    """Integer view of the reference env's hidden state (the parity format).
+
+    rock:       [x, y, status_0 .. status_{K-1}]            status in {-1, 0, +1}
+    tag:        [agent_idx, opp_idx_0 .., num_opp]          TagGrid.get_index
+    battleship: [total_remaining, occ_0..occ_{C-1}, vis_0..vis_{C-1}], cell a = y*X + x
+    tiger:      [state]
+    network:    [s_0 .. s_{M-1}]
+    """
+    if name == "rock":
+        s = env.state
+        return np.array([s.agent_pos.x, s.agent_pos.y] + [r.status for r in s.rocks], dtype=np.int64)
+    if name == "tag":
+        s = env.state
+        g = env.grid
+        return np.array([g.get_index(s.agent_pos)] + [g.get_index(o) for o in s.opponent_pos] + [s.num_opp],
+                        dtype=np.int64)
+    if name == "battleship":
+        g = env.grid
+        occ, vis = [], []
+        for a in range(g.n_tiles):
+            c = g.board[a % g.x_size, a // g.x_size]
+            occ.append(int(c.occupied))
+            vis.append(int(c.visited))
+        return np.array([env.state.total_remaining] + occ + vis, dtype=np.int64)
+    if name == "tiger":
+        return np.array([int(env.state)], dtype=np.int64)
+    if name == "network":
+        return np.array([int(v) for v in env.state], dtype=np.int64)
+    raise KeyError(name)
+
+
+def _space_rng():
+    import gym.spaces as spaces
+    return spaces.np_random
+
+
+def _as_float(r):
+    return float(r)
+
+
+# ---------------------------------------------------------------------------
+# mode A
+# ---------------------------------------------------------------------------
+def trace_mode_a(name, kwargs, seed, actions, space_seed=None):
+    """Unmodified reference on the global MT stream.  reset() is called right
+    after every done step (the batched build's auto-reset)."""
+    env = make_ref_env(name, **kwargs)
+    if name == "tiger":
+        _space_rng().seed(seed if space_seed is None else space_seed)
+    env.seed(seed)
+    ob0 = env.reset()
+    s0 = compact_state(name, env)
+    T = len(actions)
+    ob = np.zeros(T, np.int64)
+    rew = np.zeros(T, np.float64)
+    done = np.zeros(T, np.uint8)
+    state_pre = np.zeros((T, len(s0)), np.int64)
+    state = np.zeros((T, len(s0)), np.int64)
+    reset_ob = np.full(T, -1, np.int64)
+    for i, a in enumerate(actions):
+        o, r, d, _ = env.step(int(a))
+        ob[i], rew[i], done[i] = int(o), _as_float(r), int(bool(d))
+        state_pre[i] = compact_state(name, env)
+        if d:
+            reset_ob[i] = int(env.reset())
+        state[i] = compact_state(name, env)
+    return dict(ob0=np.int64(ob0), state0=s0, actions=np.asarray(actions, np.int64), ob=ob, reward=rew,
+                done=done, state_pre=state_pre, state=state, reset_ob=reset_ob)
+
+
+# ---------------------------------------------------------------------------
+# mode B
+# ---------------------------------------------------------------------------
+def trace_mode_b(name, kwargs, seed, lanes, actions, t0=0):
+    """One reference env object per lane; RNG state injected before each call.
+
+    actions: int[len(lanes), T].  Call `c` of the batched env uses t = t0 + c:
+    the initial reset is t0, step i is t0 + 1 + i, and the auto-reset that
+    follows a done step shares that step's t (stream RESET instead of STEP).
+    """
+    lanes = list(lanes)
+    actions = np.asarray(actions)
+    L, T = actions.shape
+    assert L == len(lanes)
+    out = None
+    space = _space_rng() if name == "tiger" else None
+    max_used = 0
+    for li, lane in enumerate(lanes):
+        env = make_ref_env(name, **kwargs)
+        inject_stream(seed, lane, t0, px.STREAM_RESET)
+        if space is not None:
+            inject_stream(seed, lane, t0, px.STREAM_RESET_SPACE, space)
+        ob0 = env.reset()
+        max_used = max(max_used, consumed_words())
+        s0 = compact_state(name, env)
+        if out is None:
+            S = len(s0)
+            out = dict(ob0=np.zeros(L, np.int64), state0=np.zeros((L, S), np.int64),
+                       ob=np.zeros((L, T), np.int64), reward=np.zeros((L, T), np.float64),
+                       done=np.zeros((L, T), np.uint8), state_pre=np.zeros((L, T, S), np.int64),
+                       state=np.zeros((L, T, S), np.int64), reset_ob=np.full((L, T), -1, np.int64))
+        out["ob0"][li] = int(ob0)
+        out["state0"][li] = s0
+        for i in range(T):
+            t = t0 + 1 + i
+            inject_stream(seed, lane, t, px.STREAM_STEP)
+            if space is not None:
+                inject_stream(seed, lane, t, px.STREAM_STEP_SPACE, space)
+            o, r, d, _ = env.step(int(actions[li, i]))
+            max_used = max(max_used, consumed_words())
+            out["ob"][li, i], out["reward"][li, i], out["done"][li, i] = int(o), _as_float(r), int(bool(d))
+            out["state_pre"][li, i] = compact_state(name, env)
+            if d:
+                inject_stream(seed, lane, t, px.STREAM_RESET)
+                if space is not None:
+                    inject_stream(seed, lane, t, px.STREAM_RESET_SPACE, space)
+                out["reset_ob"][li, i] = int(env.reset())
+                max_used = max(max_used, consumed_words())
+            out["state"][li, i] = compact_state(name, env)
+    assert max_used < N_INJECT, "a reference call consumed more words than were injected"
+    out.update(lanes=np.asarray(lanes, np.int64), actions=actions.astype(np.int64), seed=np.int64(seed),
+               t0=np.int64(t0), max_words_per_call=np.int64(max_used))
+    return out

@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ from the UNMODIFIED reference.
+
+Runs only in the build container (needs /root/reference); the fixtures it
+writes are data (inputs + expected outputs) and are committed.  Usage:
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/generate_golden.py
+
+Fixtures:
+  F1  modeA_<case>.npz   reference on np.random.seed(s), >= 4 seeds per case
+  F2  thresholds.json    integer Bernoulli thresholds, found by bisection on
+                         numpy's own binomial() with an injected MT state
+  F3  modeB_<case>.npz   reference driven by the build's Philox word stream
+                         (per-lane env objects; includes F4 = initial resets)
+  F5  edge_cases.json    error behaviour of the reference at the boundary
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+sys.dont_write_bytecode = True
+
+from oracle.ref_harness import harness as h  # noqa: E402
+
+# (case name, env, kwargs, mode-A steps, mode-B lanes, mode-B steps, P(action 4) override for tag)
+CASES = [
+    ("rock_7_8", "rock", {}, 1000, 512, 48),
+    ("rock_7_7", "rock", dict(board_size=7, num_rocks=7), 600, 64, 32),
+    ("rock_11_11", "rock", dict(board_size=11, num_rocks=11), 1000, 256, 48),
+    ("rock_15_15", "rock", dict(board_size=15, num_rocks=15), 1000, 256, 48),
+    ("rock_4_3", "rock", dict(board_size=4, num_rocks=3), 600, 64, 32),
+    ("rock_2_1", "rock", dict(board_size=2, num_rocks=1), 300, 64, 32),
+    ("tag_1", "tag", {}, 4000, 512, 64),
+    ("tag_2", "tag", dict(num_opponents=2), 4000, 256, 64),
+    ("tag_4", "tag", dict(num_opponents=4), 2000, 128, 64),
+    ("battleship_5_5", "battleship", {}, 1500, 512, 48),
+    ("battleship_10_10", "battleship", dict(board_size=(10, 10), max_len=5), 2000, 48, 400),
+    ("battleship_8_6", "battleship", dict(board_size=(8, 6), max_len=4), 1000, 128, 64),
+    ("tiger", "tiger", {}, 1000, 512, 48),
+    ("network_10", "network", {}, 1000, 512, 48),
+    ("network_16_ring", "network", dict(n_machines=16, problem_type=1), 600, 128, 48),
+    ("network_31", "network", dict(n_machines=31, problem_type=3), 400, 64, 32),
+]
+MODE_A_SEEDS = [0, 1, 2, 123456789]
+MODE_B_SEED = 0x5EED1234ABCD
+
+
+def n_actions(env, kwargs):
+    e = h.make_ref_env(env, **kwargs)
+    return e.action_space.n
+
+
+def action_tape(env, nA, rs, shape):
+    a = rs.randint(nA, size=shape)
+    if env == "tag":  # bias towards TAG so that episodes end inside the tape
+        a = np.where(rs.uniform(size=shape) < 0.35, 4, a)
+    return a
+
+
+def small(d):
+    out = {}
+    for k, v in d.items():
+        v = np.asarray(v)
+        if k == "reward":
+            out[k] = v.astype(np.float64)
+        elif k in ("done",):
+            out[k] = v.astype(np.uint8)
+        elif k in ("lanes", "seed", "t0", "max_words_per_call"):
+            out[k] = v.astype(np.int64)
+        else:
+            fits8 = v.size == 0 or (v.min() >= -128 and v.max() <= 127)
+            out[k] = v.astype(np.int8 if fits8 else np.int16)
+            assert np.array_equal(out[k], v)
+    return out
+
+
+def gen_mode_a(case, env, kwargs, T):
+    nA = n_actions(env, kwargs)
+    traces = {}
+    for seed in MODE_A_SEEDS:
+        tries = 0
+        while True:  # RockSample(15,15)/(7,7) have crash cells: keep them out of the tape
+            acts = action_tape(env, nA, np.random.RandomState(1000003 * (tries + 1) + seed), T)
+            try:
+                tr = h.trace_mode_a(env, kwargs, seed, acts)
+                break
+            except IndexError:
+                tries += 1
+                assert tries < 50
+        for k, v in small(tr).items():
+            traces["s%d_%s" % (seed, k)] = v
+    traces["seeds"] = np.asarray(MODE_A_SEEDS, np.int64)
+    np.savez_compressed(os.path.join(HERE, "modeA_%s.npz" % case), **traces)
+    return sum(int(traces["s%d_done" % s].sum()) for s in MODE_A_SEEDS)
+
+
+def gen_mode_b(case, env, kwargs, L, T):
+    nA = n_actions(env, kwargs)
+    # lanes: a low block and a block straddling 2^20 (exercises the lane counter word)
+    lanes = list(range(L // 2)) + list(range((1 << 20) - L // 4, (1 << 20) + L // 4))
+    t0 = 0x1FFFFFFF0 if case == "rock_7_8" else 7   # rock_7_8 also exercises the high counter word of t
+    tries = 0
+    while True:
+        acts = action_tape(env, nA, np.random.RandomState(77 + tries), (len(lanes), T))
+        try:
+            tr = h.trace_mode_b(env, kwargs, MODE_B_SEED, lanes, acts, t0=t0)
+            break
+        except IndexError:
+            tries += 1
+            assert tries < 50
+    np.savez_compressed(os.path.join(HERE, "modeB_%s.npz" % case), **small(tr))
+    return int(tr["done"].sum()), int(tr["max_words_per_call"])
+
+
+def gen_thresholds():
+    def binom_at(p, k):
+        h.inject_words([(k >> 26) << 5, (k & ((1 << 26) - 1)) << 6])
+        r = int(np.random.binomial(1, p))
+        assert h.consumed_words() == 2  # exactly one double per call
+        return r
+
+    def bisect(p):
+        top = (1 << 53) - 1
+        r0, r1 = binom_at(p, 0), binom_at(p, top)
+        if r0 == r1:
+            return None, r0
+        lo, hi = 0, top
+        while hi - lo > 1:
+            m = (lo + hi) // 2
+            if binom_at(p, m) == r0:
+                lo = m
+            else:
+                hi = m
+        return lo, r0
+
+    out = {"doc": "np.random.binomial(1,p) on U=k/2^53: 'le' => 1 iff k <= thr; 'gt' => 1 iff k > thr. "
+                  "rock_thr[d] is for eff(d)=(1+2^(-d/20))/2 (rock.py:383-387); d=0 (p=1.0) is always 1 "
+                  "and carries 2^53."}
+    rock = []
+    for d in range(29):
+        eff = (1 + pow(2, -d / 20)) * .5
+        thr, r0 = bisect(eff)
+        if thr is None:
+            assert r0 == 1 and d == 0
+            thr = 1 << 53
+        else:
+            assert r0 == 1
+        rock.append(int(thr))
+    out["rock_thr"] = rock
+    for name, p, sense in (("tag_move", .8, "le"), ("net_fail", .1, "gt"), ("net_fail_neighbour", .33, "gt"),
+                           ("net_obs", .95, "le")):
+        thr, r0 = bisect(p)
+        assert r0 == (1 if sense == "le" else 0)
+        out[name] = {"p": p, "sense": sense, "thr": int(thr)}
+    # tiger.py:143-148 compares uniform() > .85 directly: U > .85  <=>  k > .85 * 2^53 (an exact integer)
+    out["tiger_listen"] = {"p": .85, "sense": "flip iff k > thr", "thr": int(.85 * 2 ** 53)}
+    assert float(out["tiger_listen"]["thr"]) / 2 ** 53 == .85
+    with open(os.path.join(HERE, "thresholds.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
+def gen_edge_cases():
+    envs = h.load_reference()
+    out = {}
+
+    def err(fn):
+        try:
+            fn()
+            return "ok"
+        except BaseException as e:  # noqa: BLE001
+            return type(e).__name__
+
+    for name, kw in (("rock", {}), ("tag", {}), ("battleship", {}), ("tiger", {}), ("network", {})):
+        e = h.make_ref_env(name, **kw)
+        out["%s.step_before_reset" % name] = err(lambda: e.step(0))
+        e.seed(0)
+        e.reset()
+        out["%s.action_out_of_range" % name] = err(lambda: e.step(e.action_space.n))
+        out["%s.action_negative" % name] = err(lambda: e.step(-1))
+        out["%s.action_float" % name] = err(lambda: e.step(1.0))
+        out["%s.n_actions" % name] = int(e.action_space.n)
+        out["%s.n_obs" % name] = int(e.observation_space.n)
+    # step after done
+    e = h.make_ref_env("rock")
+    e.seed(0)
+    e.reset()
+    e.step(3)  # WEST from x=0: -100, done
+    out["rock.step_after_done"] = err(lambda: e.step(0))
+    # constructor validation (rock.py:101)
+    for bs, k in ((7, 8), (7, 7), (7, 6), (3, 3), (11, 11), (15, 15), (2, 1), (4, 3)):
+        out["rock.ctor_%d_%d" % (bs, k)] = err(lambda: envs.RockEnv(board_size=bs, num_rocks=k))
+    # crash cell of RockSample(15,15): SAMPLE at (12,2)
+    e = envs.RockEnv(board_size=15, num_rocks=15)
+    e.seed(0)
+    e.reset()
+    from gym_pomdp.envs.coord import Coord
+    e.state.agent_pos = Coord(12, 2)
+    out["rock_15_15.sample_at_12_2"] = err(lambda: e.step(4))
+    out["network.make_3legs_10"] = envs.NetworkEnv.make_3legs_neighbours(10)
+    out["moves"] = {"NORTH": [0, 1], "EAST": [1, 0], "SOUTH": [0, -1], "WEST": [-1, 0]}  # coord.py:174-180
+    with open(os.path.join(HERE, "edge_cases.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+
+
+def main():
+    assert h.reference_available(), "needs /root/reference"
+    import warnings
+    warnings.simplefilter("ignore", RuntimeWarning)  # reference's belief side-stats divide 0/0 (rock.py:191)
+    gen_thresholds()
+    gen_edge_cases()
+    for case, env, kwargs, TA, L, TB in CASES:
+        da = gen_mode_a(case, env, kwargs, TA)
+        db, mw = gen_mode_b(case, env, kwargs, L, TB)
+        print("%-18s modeA dones=%4d  modeB dones=%5d  max words/call=%d" % (case, da, db, mw), flush=True)
+    with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
+        json.dump({"cases": [[c[0], c[1], {k: (list(v) if isinstance(v, tuple) else v) for k, v in c[2].items()}]
+                             for c in CASES],
+                   "mode_a_seeds": MODE_A_SEEDS, "mode_b_seed": MODE_B_SEED,
+                   "numpy": np.__version__}, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

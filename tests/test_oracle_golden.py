@@ -1,0 +1,159 @@
+"""The CPU oracle (oracle/pomdp_oracle.c) against the golden traces generated
+from the unmodified reference (tests/golden/generate_golden.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, golden_cases, golden_manifest, load_golden, saturate_tag_compact
+
+CASES = golden_cases()
+KEYS = ["ob", "reward", "done", "state_pre", "state", "reset_ob"]
+
+
+@pytest.mark.parametrize("case,env,kw", CASES, ids=[c[0] for c in CASES])
+def test_mode_a_mt_exact(oracle_lib, case, env, kw):
+    """Oracle on an emulated np.random.seed(s) MT19937 stream == the reference's own trace."""
+    g = load_golden("A", case)
+    o = oracle_lib.OracleEnv(env, **kw)
+    for seed in g["seeds"]:
+        pre = "s%d_" % seed
+        got = o.trace_mt(int(seed), g[pre + "actions"])
+        assert int(got["ob0"]) == int(g[pre + "ob0"])
+        assert np.array_equal(got["state0"], g[pre + "state0"])
+        for k in KEYS:
+            assert np.array_equal(got[k], g[pre + k].astype(got[k].dtype)), (case, seed, k)
+
+
+@pytest.mark.parametrize("case,env,kw", CASES, ids=[c[0] for c in CASES])
+def test_mode_b_philox_injected(oracle_lib, case, env, kw):
+    """Oracle batch drivers on Philox streams == the reference driven by the same words."""
+    g = load_golden("B", case)
+    o = oracle_lib.OracleEnv(env, **kw)
+    seed, t0 = int(g["seed"]), int(g["t0"])
+    lanes = g["lanes"]
+    L, T = g["actions"].shape
+    # lanes come in contiguous runs; run each run as its own batch with the right lane0
+    starts = [0] + [i for i in range(1, L) if lanes[i] != lanes[i - 1] + 1] + [L]
+    for s, e in zip(starts[:-1], starts[1:]):
+        n, lane0 = e - s, int(lanes[s])
+        st = o.new_state(n)
+        ob0 = o.batch_reset(st, seed, lane0, t0)
+        assert np.array_equal(ob0, g["ob0"][s:e])
+        assert np.array_equal(o.batch_compact(st), saturate_tag_compact(env, g["state0"][s:e]))
+        for i in range(T):
+            ob, rew, done, bad = o.batch_step(st, g["actions"][s:e, i], seed, lane0, t0 + 1 + i)
+            assert bad == 0
+            assert np.array_equal(ob, g["ob"][s:e, i]), (case, i)
+            assert np.array_equal(rew, g["reward"][s:e, i].astype(o.reward_dtype)), (case, i)
+            assert np.array_equal(done, g["done"][s:e, i]), (case, i)
+            assert np.array_equal(o.batch_compact(st), saturate_tag_compact(env, g["state"][s:e, i])), (case, i)
+
+
+@pytest.mark.parametrize("case,env,kw", CASES, ids=[c[0] for c in CASES])
+def test_mode_b_no_auto_reset(oracle_lib, case, env, kw):
+    """auto_reset=False: the terminal state is kept (== golden state_pre) and the lane freezes."""
+    g = load_golden("B", case)
+    o = oracle_lib.OracleEnv(env, **kw)
+    seed, t0 = int(g["seed"]), int(g["t0"])
+    lanes = g["lanes"]
+    n = next((i for i in range(1, len(lanes)) if lanes[i] != lanes[i - 1] + 1), len(lanes))
+    st = o.new_state(n)
+    o.batch_reset(st, seed, int(lanes[0]), t0)
+    frozen = np.zeros(n, bool)
+    done = np.zeros(n, np.uint8)
+    term = np.zeros((n, o.compact_len), np.int64)
+    for i in range(g["actions"].shape[1]):
+        ob, rew, done, _ = o.batch_step(st, g["actions"][:n, i], seed, int(lanes[0]), t0 + 1 + i,
+                                        auto_reset=False, done=done)
+        live = ~frozen
+        assert np.array_equal(ob[live], g["ob"][:n, i][live])
+        assert np.array_equal(done[live], g["done"][:n, i][live])
+        assert np.all(ob[frozen] == 0) and np.all(rew[frozen] == 0) and np.all(done[frozen] == 1)
+        comp = o.batch_compact(st)
+        exp = saturate_tag_compact(env, g["state_pre"][:n, i])
+        assert np.array_equal(comp[live], exp[live])
+        assert np.array_equal(comp[frozen], term[frozen])
+        newly = live & (done == 1)
+        term[newly] = comp[newly]
+        frozen |= newly
+        # golden lanes that auto-reset diverge from here on: stop comparing them
+        frozen |= g["done"][:n, i].astype(bool)
+
+
+def test_thresholds_match_fixture():
+    """The constants baked into the oracle are the captured numpy thresholds (fixture F2)."""
+    with open(os.path.join(GOLDEN, "thresholds.json")) as f:
+        thr = json.load(f)
+    src = open(os.path.join(os.path.dirname(GOLDEN), "..", "oracle", "pomdp_oracle.c")).read()
+    for v in thr["rock_thr"]:
+        assert "%dULL" % v in src
+    for k in ("tag_move", "net_fail", "net_fail_neighbour", "net_obs", "tiger_listen"):
+        assert "%dULL" % thr[k]["thr"] in src
+
+
+def test_thresholds_recomputed_with_libm():
+    """Informational pin: glibc exp/log/pow on this box reproduce the captured table."""
+    import math
+    with open(os.path.join(GOLDEN, "thresholds.json")) as f:
+        thr = json.load(f)
+    for d, want in enumerate(thr["rock_thr"]):
+        eff = (1 + pow(2, -d / 20)) * .5
+        q = 1.0 - (1.0 - eff)
+        assert math.floor(math.exp(math.log(q)) * 2 ** 53) == want
+
+
+def test_philox_kat(oracle_lib):
+    from oracle import philox_ref as px
+    for ctr, key, out in px.KAT:
+        assert tuple(int(x) for x in px.philox4x32_10(np.array(ctr), np.array(key))) == out
+        assert tuple(int(x) for x in oracle_lib.philox(ctr, key)) == out
+
+
+def test_synthetic_actions_agree(oracle_lib):
+    from oracle import philox_ref as px
+    for lane0, n, t, nA in ((0, 1000, 3, 13), (1 << 20, 257, (1 << 33) + 5, 100), (5, 64, 0, 5)):
+        a = oracle_lib.synthetic_actions(n, 42, lane0, t, nA, nthreads=2)
+        b = px.synthetic_actions(42, lane0, n, t, nA)
+        assert np.array_equal(a, b)
+        assert a.min() >= 0 and a.max() < nA
+
+
+def test_oracle_threads_agree(oracle_lib):
+    o = oracle_lib.OracleEnv("rock")
+    n = 5000
+    s1, s2 = o.new_state(n), o.new_state(n)
+    o.batch_reset(s1, 1, 0, 0, nthreads=1)
+    o.batch_reset(s2, 1, 0, 0, nthreads=4)
+    assert np.array_equal(s1, s2)
+    for t in range(1, 20):
+        a = oracle_lib.synthetic_actions(n, 9, 0, t, o.n_actions)
+        r1 = o.batch_step(s1, a, 1, 0, t, nthreads=1)
+        r2 = o.batch_step(s2, a, 1, 0, t, nthreads=4)
+        for x, y in zip(r1[:3], r2[:3]):
+            assert np.array_equal(x, y)
+        assert np.array_equal(s1, s2)
+
+
+def test_rejected_configs(oracle_lib):
+    with open(os.path.join(GOLDEN, "edge_cases.json")) as f:
+        edge = json.load(f)
+    for bs, k in ((7, 8), (7, 7), (7, 6), (3, 3), (11, 11), (15, 15), (2, 1), (4, 3)):
+        ok = edge["rock.ctor_%d_%d" % (bs, k)] == "ok"
+        if ok:
+            oracle_lib.OracleEnv("rock", board_size=bs, num_rocks=k)
+        else:
+            with pytest.raises(ValueError):
+                oracle_lib.OracleEnv("rock", board_size=bs, num_rocks=k)
+
+
+def test_invalid_action_counts(oracle_lib):
+    o = oracle_lib.OracleEnv("rock")
+    st = o.new_state(4)
+    o.batch_reset(st, 0, 0, 0)
+    before = st.copy()
+    ob, rew, done, bad = o.batch_step(st, np.array([13, -1, 0, 99]), 0, 0, 1)
+    assert bad == 3
+    assert np.array_equal(st[:, [0, 1, 3]], before[:, [0, 1, 3]])
+    assert np.all(ob[[0, 1, 3]] == 0) and np.all(rew[[0, 1, 3]] == 0) and np.all(done[[0, 1, 3]] == 0)
