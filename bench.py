@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/s of the batched step() hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--env rock|tag|battleship|tiger|network]
+
+Workload (BASELINE.json metric): RockSample(7,8), 2^20 lanes per GPU, i.i.d. uniform random
+actions from the synthetic policy (its kernel is inside the timed region), auto-reset on done.
+A "step" is one pass of the hot path over the whole batch: one action launch + one step launch.
+N > 1: one process per GPU (torch.distributed.run), lanes sharded by global lane id, no data-path
+collective — only the timing barrier / max-over-ranks (gloo, host side).  Scaling is weak: every
+GPU owns 2^20 lanes.
+
+Prints ONE JSON line on rank 0 with the driver's contract keys plus `roofline` (algorithmic
+bytes / HIP-event time of the step kernel alone) and `cpu_baseline` (the C oracle, OpenMP, on
+this box's host cores, N == 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+# env -> (make id, ctor kwargs, workload label, algorithmic bytes per env-step [SURVEY.md §8d], dtype)
+WORKLOADS = {
+    "rock": ("Rock-v0", {}, "RockSample(7,8)", 21, "int32"),
+    "rock15": ("Rock-v0", dict(board_size=15, num_rocks=15), "RockSample(15,15)", 29, "int32"),
+    "tag": ("Tag-v0", {}, "Tag-v0 (5x10 grid, 1 opponent)", 21, "int32"),
+    "battleship": ("Battleship-v0", dict(board_size=(10, 10), max_len=5), "BattleShip 10x10 max_len=5", 61, "int32"),
+    "tiger": ("Tiger-v0", {}, "Tiger-v0", 21, "int32"),
+    "network": ("Network-v0", {}, "Network-v0 (10 machines)", 21, "int32"),
+}
+ORACLE_NAME = {"rock": "rock", "rock15": "rock", "tag": "tag", "battleship": "battleship", "tiger": "tiger",
+               "network": "network"}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--env", default="rock", choices=sorted(WORKLOADS))
+    ap.add_argument("--lanes-per-gpu", type=int, default=1 << 20)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(env_key, kwargs, seed, budget_s):
+    """The C oracle (a port of the reference's step()/reset(), pinned to reference traces) on the
+    host cores of this box, same workload shape, bounded sample."""
+    from oracle import oracle_lib as ol
+    threads = min(ol.max_threads(), os.cpu_count() or 1)
+    o = ol.OracleEnv(ORACLE_NAME[env_key], **kwargs)
+    n = 1 << 18
+    st = o.new_state(n)
+    o.batch_reset(st, seed, 0, 0, nthreads=threads)
+    steps, t = 0, 1
+    t0 = time.perf_counter()
+    while True:
+        a = ol.synthetic_actions(n, seed ^ 0x5DEECE66D, 0, t, o.n_actions, nthreads=threads)
+        o.batch_step(st, a, seed, 0, t, nthreads=threads)
+        t += 1
+        steps += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s and steps >= 4:
+            break
+    return {"value": n * steps / el, "unit": "env-steps/s", "cores": threads, "kind": "port",
+            "sample": "%d lanes x %d steps of the same workload on the C oracle (OpenMP, %d threads, %.1f s)"
+                      % (n, steps, threads, el),
+            "reference_python_recorded": {"value": 6.0e4, "unit": "env-steps/s", "cores": 1,
+                                          "note": "reference's own Python loop, RockSample(7,8), measured in the "
+                                                  "build container (BASELINE.md); it cannot travel to this box"}}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="gloo")  # control plane only: barrier + max of the timings
+        pg = dist
+
+    import gym_pomdp_amd as gpa
+    env_id, kwargs, label, bytes_per_step, dtype = WORKLOADS[args.env]
+    n = args.lanes_per_gpu
+    env = gpa.make(env_id, batch_size=n, device=dev, seed=args.seed, lane_offset=rank * n, reuse_buffers=True,
+                   **kwargs)
+    actions = torch.empty(n, dtype=torch.int32, device=dev)
+    action_seed = args.seed ^ 0x5DEECE66D
+
+    def one_step():
+        env.synthetic_actions(out=actions, seed=action_seed)
+        env.step(actions)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if pg is not None:
+            pg.barrier()
+
+    env.reset()
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    barrier()
+    if pg is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        pg.all_reduce(tt, op=pg.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # ---- roofline of the dominant kernel: the step kernel alone, HIP events on its stream --------
+    env.synthetic_actions(out=actions, seed=action_seed)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(5):
+        env.step(actions)
+    torch.cuda.synchronize(dev)
+    ev0.record()
+    for _ in range(args.steps):
+        env.step(actions)
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    kern_ms = ev0.elapsed_time(ev1) / args.steps
+    achieved = bytes_per_step * n / (kern_ms * 1e-3) / 1e9
+    invalid = env.invalid_action_count()
+
+    if rank == 0:
+        total_lanes = n * world
+        out = {
+            "metric": "env steps/sec (whole node)",
+            "value": total_lanes * args.steps / elapsed,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": dtype,
+            "data": "synthetic",
+            "config": {"workload": "%s batch=%d lanes per GPU (%d total), uniform random actions "
+                                   "(synthetic-policy kernel timed), auto-reset" % (label, n, total_lanes),
+                       "lanes_per_gpu": n, "total_lanes": total_lanes, "parallelism": "lane-shard x%d, no collectives" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "step_kernel<%s>" % args.env, "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_step": bytes_per_step,
+                         "note": "step kernel launched back-to-back %d times, HIP events on its stream; "
+                                 "event time includes inter-launch gaps" % args.steps},
+            "invalid_actions": invalid,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.env, kwargs, args.seed, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if pg is not None:
+        pg.barrier()
+        pg.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

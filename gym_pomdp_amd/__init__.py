@@ -1,0 +1,50 @@
+"""gym_pomdp_amd — MI355X-native batched simulator for gym_pomdp's discrete POMDP envs.
+
+Drop-in boundary (reference: gym_pomdp/__init__.py:7-46): the same env ids resolve to batched
+classes with the same constructor kwargs plus `batch_size`, `device`, `seed`, `auto_reset`,
+`lane_offset`.  When `gym` or `gymnasium` is importable the ids are also registered there, so
+`gym.make("Rock-v0", batch_size=1 << 20)` works; `gym_pomdp_amd.make` is always available.
+"""
+import importlib
+
+from . import spaces  # noqa: F401
+from .envs import BattleShipEnv, NetworkEnv, RockEnv, TagEnv, TigerEnv  # noqa: F401
+
+__version__ = "0.1.0"
+
+# id -> entry point, as the reference registers them (gym_pomdp/__init__.py:7-41)
+registry = {
+    "Tiger-v0": "gym_pomdp_amd.envs:TigerEnv",
+    "Tag-v0": "gym_pomdp_amd.envs:TagEnv",
+    "Battleship-v0": "gym_pomdp_amd.envs:BattleShipEnv",
+    "Rock-v0": "gym_pomdp_amd.envs:RockEnv",
+    "Network-v0": "gym_pomdp_amd.envs:NetworkEnv",
+}
+
+
+def register(id, entry_point):
+    registry[id] = entry_point
+
+
+def make(id, **kwargs):
+    """gym.make look-alike: resolves `id` through this package's registry."""
+    if id not in registry:
+        raise KeyError("unknown env id %r (known: %s)" % (id, sorted(registry)))
+    mod, attr = registry[id].split(":")
+    return getattr(importlib.import_module(mod), attr)(**kwargs)
+
+
+def _register_with_gym():
+    for pkg in ("gym", "gymnasium"):
+        try:
+            reg = importlib.import_module(pkg + ".envs.registration")
+        except Exception:  # noqa: BLE001 - not installed
+            continue
+        for env_id, entry in registry.items():
+            try:
+                reg.register(id=env_id, entry_point=entry)
+            except Exception:  # noqa: BLE001 - already registered (e.g. by the reference)
+                pass
+
+
+_register_with_gym()

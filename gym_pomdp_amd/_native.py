@@ -1,0 +1,111 @@
+"""ctypes binding of libpomdp_hip.so (C ABI: include/pomdp_hip.h).
+
+The HIP library is the product: there is no CPU fallback.  `lib()` raises if the
+shared object is missing or does not export the ABI this package was written for.
+"""
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_REPO = os.path.dirname(_PKG)
+LIB_PATH = os.path.join(_PKG, "_lib", "libpomdp_hip.so")
+SOURCES = [os.path.join(_PKG, "csrc", f) for f in ("pomdp_kernels.hip", "envs.hip.h", "philox.hip.h")]
+HEADER = os.path.join(_REPO, "include", "pomdp_hip.h")
+ABI_VERSION = 1
+
+POMDP_AUTO_RESET = 1
+
+# every symbol include/pomdp_hip.h declares
+SYMBOLS = [
+    "pomdp_abi_version", "pomdp_error_string",
+    "pomdp_rock_reset", "pomdp_rock_step", "pomdp_tag_reset", "pomdp_tag_step",
+    "pomdp_battleship_reset", "pomdp_battleship_step", "pomdp_tiger_reset", "pomdp_tiger_step",
+    "pomdp_network_reset", "pomdp_network_step", "pomdp_synthetic_actions", "pomdp_philox_blocks",
+]
+
+
+class RockParams(C.Structure):
+    _fields_ = [("size", C.c_int32), ("num_rocks", C.c_int32), ("start_x", C.c_int32), ("start_y", C.c_int32),
+                ("rock_x", C.c_int8 * 16), ("rock_y", C.c_int8 * 16), ("grid", C.c_int8 * 256),
+                ("thr", C.c_uint64 * 32)]
+
+
+class TagParams(C.Structure):
+    _fields_ = [("num_opponents", C.c_int32), ("obs_cells", C.c_int32), ("move_thr", C.c_uint64)]
+
+
+class BattleShipParams(C.Structure):
+    _fields_ = [("x_size", C.c_int32), ("y_size", C.c_int32), ("max_len", C.c_int32)]
+
+
+class TigerParams(C.Structure):
+    _fields_ = [("listen_thr", C.c_uint64)]
+
+
+class NetworkParams(C.Structure):
+    _fields_ = [("n_machines", C.c_int32), ("deg_gt2_mask", C.c_uint32), ("nb_mask", C.c_uint32 * 32),
+                ("fail_thr", C.c_uint64), ("fail_nb_thr", C.c_uint64), ("obs_thr", C.c_uint64)]
+
+
+def hipcc_path():
+    return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    deps = SOURCES + [HEADER]
+    if (not force and os.path.exists(LIB_PATH)
+            and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps)):
+        return LIB_PATH
+    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+           "-o", LIB_PATH, SOURCES[0]]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "gym_pomdp_amd: HIP library %s is missing — build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    missing = [s for s in SYMBOLS if not hasattr(L, s)]
+    if missing:
+        raise RuntimeError("gym_pomdp_amd: %s does not export %s" % (LIB_PATH, missing))
+    L.pomdp_abi_version.restype = C.c_int
+    if L.pomdp_abi_version() != ABI_VERSION:
+        raise RuntimeError("gym_pomdp_amd: ABI version mismatch (%d != %d); rebuild the HIP library"
+                           % (L.pomdp_abi_version(), ABI_VERSION))
+    L.pomdp_error_string.restype = C.c_char_p
+    L.pomdp_error_string.argtypes = [C.c_int]
+    vp, i64, u64, u32, ci = C.c_void_p, C.c_int64, C.c_uint64, C.c_uint32, C.c_int
+    for env in ("rock", "tag", "battleship", "tiger", "network"):
+        r = getattr(L, "pomdp_%s_reset" % env)
+        r.restype = ci
+        r.argtypes = [vp, vp, vp, i64, u64, u32, u64, vp]
+        s = getattr(L, "pomdp_%s_step" % env)
+        s.restype = ci
+        s.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, u64, u32, u64, ci, vp]
+    L.pomdp_synthetic_actions.restype = ci
+    L.pomdp_synthetic_actions.argtypes = [vp, i64, u64, u32, u64, u32, vp]
+    L.pomdp_philox_blocks.restype = ci
+    L.pomdp_philox_blocks.argtypes = [vp, vp, i64, vp]
+    _lib = L
+    return L
+
+
+def check(code, what):
+    if code != 0:
+        raise RuntimeError("gym_pomdp_amd: %s failed: %s (code %d)"
+                           % (what, lib().pomdp_error_string(code).decode(), code))

@@ -1,0 +1,405 @@
+// envs.hip.h — per-lane transition / observation / reward functions of the five envs,
+// written against the packed int32 lane state documented in include/pomdp_hip.h.
+// Each Env type plugs into the generic kernels in pomdp_kernels.hip:
+//
+//   Params   plain-C params struct (kernarg, wave-uniform)
+//   Shared   lookup tables staged into LDS once per workgroup
+//   State    the lane's state words, in registers
+//   Reward   int32_t or float
+//
+// Reference semantics are cited per function (paths relative to gym_pomdp/envs/);
+// the quirks catalogued in SURVEY.md §9 are reproduced on purpose.
+#pragma once
+#include "../../include/pomdp_hip.h"
+#include "philox.hip.h"
+
+namespace pomdp {
+
+constexpr uint64_t TWO52 = 4503599627370496ull;
+
+// ===========================================================================
+// RockSample
+// ===========================================================================
+template <int W> // state words per lane: 1 (K <= 12) or 2
+struct RockEnv {
+    using Params = pomdp_rock_params;
+    using Reward = int32_t;
+    static constexpr int WORDS = W;
+    struct Shared {
+        int8_t grid[256];
+        int8_t rx[16], ry[16];
+        uint64_t thr[32];
+    };
+    struct State { uint64_t s; };
+
+    static __device__ __forceinline__ void stage(Shared &sh, const Params &p)
+    {
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) sh.grid[i] = p.grid[i];
+        for (int i = threadIdx.x; i < 16; i += blockDim.x) { sh.rx[i] = p.rock_x[i]; sh.ry[i] = p.rock_y[i]; }
+        for (int i = threadIdx.x; i < 32; i += blockDim.x) sh.thr[i] = p.thr[i];
+    }
+    static __device__ __forceinline__ int n_actions(const Params &p) { return 5 + p.num_rocks; }
+
+    static __device__ __forceinline__ void load(State &st, const uint32_t *state, int64_t n, int64_t i)
+    {
+        st.s = state[i];
+        if (W == 2) st.s |= (uint64_t)state[n + i] << 32;
+    }
+    static __device__ __forceinline__ void store(const State &st, uint32_t *state, int64_t n, int64_t i, bool)
+    {
+        state[i] = (uint32_t)st.s;
+        if (W == 2) state[n + i] = (uint32_t)(st.s >> 32);
+    }
+
+    // rock.py:236-241 reset -> 266-271 _get_init_state -> 78-86 Rock.__init__:
+    // status_j = sign(U_j - .5), rocks in index order, one double each.
+    static __device__ __forceinline__ int reset(const Shared &, const Params &p, State &st, const RngKey &key,
+                                                uint32_t lane)
+    {
+        uint64_t s = (uint32_t)p.start_x | ((uint32_t)p.start_y << 4);
+        const int K = p.num_rocks;
+        for (int b = 0; 2 * b < K; ++b) {
+            const uint4 w = stream_block(key, lane, POMDP_STREAM_RESET, (uint32_t)b);
+            const uint64_t ka = k53(w.x, w.y), kb = k53(w.z, w.w);
+            const uint64_t ca = (ka > TWO52) ? 2u : (ka < TWO52 ? 0u : 1u);
+            const uint64_t cb = (kb > TWO52) ? 2u : (kb < TWO52 ? 0u : 1u);
+            s |= ca << (8 + 4 * b);
+            if (2 * b + 1 < K) s |= cb << (10 + 4 * b);
+        }
+        st.s = s;
+        return 0; // Obs.NULL
+    }
+
+    // rock.py:123-194 step; 401-407 _sample_ob; 383-387 _efficiency; coord.py:133-135 (L1 distance)
+    static __device__ __forceinline__ void step(const Shared &sh, const Params &p, State &st, int a,
+                                                const RngKey &key, uint32_t lane, int &ob, Reward &rew, int &done)
+    {
+        uint64_t s = st.s;
+        int x = (int)(s & 15u), y = (int)((s >> 4) & 15u);
+        const int size = p.size;
+        ob = 0; rew = 0; done = 0;
+        if (a < 4) {
+            // 0 N (0,+1)  1 E (+1,0)  2 S (0,-1)  3 W (-1,0)      coord.py:155-160
+            const int nx = x + (a == 1) - (a == 3), ny = y + (a == 0) - (a == 2);
+            if ((unsigned)nx < (unsigned)size && (unsigned)ny < (unsigned)size) { x = nx; y = ny; }
+            else if (a == 1) { rew = 10; done = 1; }        // east exit          rock.py:138-141
+            else { rew = -100; done = 1; }                  // off-grid N/S/W     rock.py:146,151,156,193
+            s = (s & ~0xFFull) | (uint64_t)(x | (y << 4));
+        } else if (a == 4) {                                // SAMPLE             rock.py:160-169
+            const int id = sh.grid[x * 16 + y];
+            const int sh_ = 8 + 2 * (id & 15);
+            const uint32_t code = (uint32_t)(s >> sh_) & 3u;
+            if (id >= 0 && id < p.num_rocks && code != 1u) {
+                rew = code == 2u ? 10 : -10;
+                s = (s & ~(3ull << sh_)) | (1ull << sh_);
+            } else { rew = -100; done = 1; }
+        } else {                                            // CHECK rock a-5     rock.py:171-175
+            const int r = a - 5;
+            const int d = abs(x - sh.rx[r]) + abs(y - sh.ry[r]);
+            const uint4 w = stream_block(key, lane, POMDP_STREAM_STEP, 0u);
+            const bool correct = k53(w.x, w.y) <= sh.thr[d]; // np.random.binomial(1, eff)
+            const bool good = ((uint32_t)(s >> (8 + 2 * r)) & 3u) == 2u;
+            ob = (good == correct) ? 2 : 1;                 // rock.py:404-407
+        }
+        st.s = s;
+    }
+};
+
+// ===========================================================================
+// Tag
+// ===========================================================================
+struct TagEnv {
+    using Params = pomdp_tag_params;
+    using Reward = float;
+    static constexpr int WORDS = 1;
+    struct Shared { int unused; };
+    struct State { uint32_t w; };
+
+    static __device__ __forceinline__ void stage(Shared &, const Params &) {}
+    static __device__ __forceinline__ int n_actions(const Params &) { return 5; }
+    static __device__ __forceinline__ void load(State &st, const uint32_t *state, int64_t, int64_t i) { st.w = state[i]; }
+    static __device__ __forceinline__ void store(const State &st, uint32_t *state, int64_t, int64_t i, bool) { state[i] = st.w; }
+
+    // tag.py:52-57 get_tag_coord, 59-66 get_index, 46-50 is_inside
+    static __device__ __forceinline__ void coord(int idx, int &x, int &y)
+    {
+        if (idx < 20) { x = idx % 10; y = idx / 10; }
+        else { idx -= 20; x = idx % 3 + 5; y = idx / 3 + 2; }
+    }
+    static __device__ __forceinline__ int index(int x, int y) { return y < 2 ? y * 10 + x : 20 + (y - 2) * 3 + x - 5; }
+    static __device__ __forceinline__ bool inside(int x, int y)
+    {
+        return y >= 2 ? (x >= 5 && x < 8 && y < 5) : (x >= 0 && x < 10 && y >= 0);
+    }
+    static __device__ __forceinline__ int num_opp(uint32_t w) { return (int)w >> 25; } // sign-extending
+    static __device__ __forceinline__ uint32_t with_num_opp(uint32_t w, int no)
+    {
+        no = no < -64 ? -64 : no;
+        return (w & 0x01FFFFFFu) | ((uint32_t)no << 25);
+    }
+    // tag.py:219-226
+    static __device__ __forceinline__ int sample_ob(const Params &p, uint32_t w, int a)
+    {
+        const uint32_t agent = w & 31u;
+        int ob = (int)agent;
+        if (a < 4)
+            for (int j = 0; j < p.num_opponents; ++j)
+                if (((w >> (5 + 5 * j)) & 31u) == agent) ob = p.obs_cells;
+        return ob;
+    }
+
+    // tag.py:97-102 reset, 181-193 _get_init_state, 43-44 sample = randint(0, 29)
+    static __device__ __forceinline__ int reset(const Shared &, const Params &p, State &st, const RngKey &key,
+                                                uint32_t lane)
+    {
+        WordStream ws(key, lane, POMDP_STREAM_RESET);
+        uint32_t w = ws.randint(29u);
+        for (int j = 0; j < p.num_opponents; ++j) w |= ws.randint(29u) << (5 + 5 * j);
+        st.w = with_num_opp(w, p.num_opponents);
+        return sample_ob(p, st.w, 0);
+    }
+
+    // tag.py:108-143 step, 201-207 move_opponent, 260-280 _admissable_actions
+    static __device__ __forceinline__ void step(const Shared &, const Params &p, State &st, int a,
+                                                const RngKey &key, uint32_t lane, int &ob, Reward &rew, int &done)
+    {
+        uint32_t w = st.w;
+        const int agent = (int)(w & 31u);
+        int ax, ay;
+        coord(agent, ax, ay);
+        if (a == 4) {
+            WordStream ws(key, lane, POMDP_STREAM_STEP);
+            bool tagged = false;
+            int no = num_opp(w);
+            for (int j = 0; j < p.num_opponents; ++j) {
+                const int sh = 5 + 5 * j;
+                const int oi = (int)((w >> sh) & 31u);
+                if (oi == agent) { tagged = true; no -= 1; }
+                else if (no > 0) {
+                    int ox, oy;
+                    coord(oi, ox, oy);
+                    // admissible moves, 2 bits each (index into N0 E1 S2 W3), in the reference's list order
+                    uint32_t list = 0; int cnt = 0;
+                    if (ox >= ax) { list |= 1u << (2 * cnt); ++cnt; }
+                    if (oy >= ay) { list |= 0u << (2 * cnt); ++cnt; }
+                    if (ox <= ax) { list |= 3u << (2 * cnt); ++cnt; }
+                    if (oy <= ay) { list |= 2u << (2 * cnt); ++cnt; }
+                    if (ox == ax && oy > ay) { list |= 0u << (2 * cnt); ++cnt; }
+                    if (oy == ay && ox > ax) { list |= 1u << (2 * cnt); ++cnt; }
+                    if (ox == ax && oy < ay) { list |= 2u << (2 * cnt); ++cnt; }
+                    if (oy == ay && ox < ax) { list |= 3u << (2 * cnt); ++cnt; }
+                    if (ws.next_k53() <= p.move_thr) {                    // binomial(1, move_prob)
+                        const uint32_t pick = (list >> (2 * ws.randint((uint32_t)cnt))) & 3u; // np.random.choice
+                        const int nx = ox + (pick == 1u) - (pick == 3u), ny = oy + (pick == 0u) - (pick == 2u);
+                        if (inside(nx, ny)) w = (w & ~(31u << sh)) | ((uint32_t)index(nx, ny) << sh);
+                    }
+                }
+            }
+            rew = tagged ? 10.f : -10.f;
+            w = with_num_opp(w, no);
+        } else {
+            rew = -1.f;
+            const int nx = ax + (a == 1) - (a == 3), ny = ay + (a == 0) - (a == 2);
+            if (inside(nx, ny)) w = (w & ~31u) | (uint32_t)index(nx, ny);
+        }
+        ob = sample_ob(p, w, a);
+        done = num_opp(w) == 0;
+        st.w = w;
+    }
+};
+
+// ===========================================================================
+// BattleShip
+// ===========================================================================
+template <int MW> // mask words: ceil((cells + 6) / 32)
+struct BattleShipEnv {
+    using Params = pomdp_battleship_params;
+    using Reward = int32_t;
+    static constexpr int WORDS = 2 * MW;
+    struct Shared { int unused; };
+    struct State { uint32_t occ[MW], vis[MW]; };
+
+    static __device__ __forceinline__ void stage(Shared &, const Params &) {}
+    static __device__ __forceinline__ int n_actions(const Params &p) { return p.x_size * p.y_size; }
+    static __device__ __forceinline__ void load(State &st, const uint32_t *state, int64_t n, int64_t i)
+    {
+#pragma unroll
+        for (int j = 0; j < MW; ++j) { st.occ[j] = state[(int64_t)j * n + i]; st.vis[j] = state[(int64_t)(MW + j) * n + i]; }
+    }
+    // a step only changes the visited half; the occupied half is rewritten on reset
+    static __device__ __forceinline__ void store(const State &st, uint32_t *state, int64_t n, int64_t i, bool was_reset)
+    {
+#pragma unroll
+        for (int j = 0; j < MW; ++j) state[(int64_t)(MW + j) * n + i] = st.vis[j];
+        if (was_reset) {
+#pragma unroll
+            for (int j = 0; j < MW; ++j) state[(int64_t)j * n + i] = st.occ[j];
+        }
+    }
+    static __device__ __forceinline__ uint32_t word_of(const uint32_t (&m)[MW], int a)
+    {
+        uint32_t w = m[0];
+#pragma unroll
+        for (int j = 1; j < MW; ++j) w = (a >> 5) == j ? m[j] : w;
+        return w;
+    }
+    static __device__ __forceinline__ bool bit(const uint32_t (&m)[MW], int a) { return (word_of(m, a) >> (a & 31)) & 1u; }
+    static __device__ __forceinline__ void set_bit(uint32_t (&m)[MW], int a)
+    {
+#pragma unroll
+        for (int j = 0; j < MW; ++j) m[j] |= (a >> 5) == j ? (1u << (a & 31)) : 0u;
+    }
+    static __device__ __forceinline__ bool occupied(const Params &p, const State &st, int x, int y)
+    {
+        return (unsigned)x < (unsigned)p.x_size && (unsigned)y < (unsigned)p.y_size && bit(st.occ, y * p.x_size + x);
+    }
+
+    // battleship.py:131-137 reset, 167-180 _get_init_state, 195-211 collision, 182-193 mark_ship,
+    // coord.py:122-123 Grid.sample, battleship.py:33-37 Ship.__init__ (position word(s) before direction word)
+    static __device__ __forceinline__ int reset(const Shared &, const Params &p, State &st, const RngKey &key,
+                                                uint32_t lane)
+    {
+#pragma unroll
+        for (int j = 0; j < MW; ++j) { st.occ[j] = 0u; st.vis[j] = 0u; }
+        WordStream ws(key, lane, POMDP_STREAM_RESET);
+        const int X = p.x_size, Y = p.y_size;
+        int remaining = 0;
+        for (int len = p.max_len; len >= 2; --len) {
+            int px, py, dx, dy;
+            for (;;) {
+                const int idx = (int)ws.randint((uint32_t)(X * Y));
+                const uint32_t dir = ws.randint(4u);
+                px = idx % X; py = idx / X;
+                dx = (dir == 1u) - (dir == 3u); dy = (dir == 0u) - (dir == 2u); // Compass N E S W
+                bool hit = false;
+                int cx = px, cy = py;
+                for (int i = 0; i <= len && !hit; ++i) {
+                    const int nx = cx + dx, ny = cy + dy;
+                    if (!((unsigned)nx < (unsigned)X && (unsigned)ny < (unsigned)Y)) { hit = true; break; }
+                    // the cell itself (Compass.Null) and N, E, S, W, NE, SE, SW — NW is never looked at
+                    hit = occupied(p, st, cx, cy) || occupied(p, st, cx, cy + 1) || occupied(p, st, cx + 1, cy) ||
+                          occupied(p, st, cx, cy - 1) || occupied(p, st, cx - 1, cy) || occupied(p, st, cx + 1, cy + 1) ||
+                          occupied(p, st, cx + 1, cy - 1) || occupied(p, st, cx - 1, cy - 1);
+                    cx = nx; cy = ny;
+                }
+                if (!hit) break;
+            }
+            for (int i = 0; i < len; ++i) { set_bit(st.occ, py * X + px); px += dx; py += dy; }
+            remaining += len;
+        }
+        st.vis[MW - 1] = (uint32_t)remaining << 26;
+        return 0;
+    }
+
+    // battleship.py:91-122
+    static __device__ __forceinline__ void step(const Shared &, const Params &p, State &st, int a,
+                                                const RngKey &, uint32_t, int &ob, Reward &rew, int &done)
+    {
+        int remaining = (int)(st.vis[MW - 1] >> 26);
+        ob = 0; done = 0;
+        if (bit(st.vis, a)) rew = -10;
+        else {
+            rew = -1;
+            if (bit(st.occ, a)) { ob = 1; remaining -= 1; }
+            set_bit(st.vis, a);
+        }
+        if (remaining == 0) { rew += p.x_size * p.y_size; done = 1; }
+        st.vis[MW - 1] = (st.vis[MW - 1] & 0x03FFFFFFu) | ((uint32_t)remaining << 26);
+    }
+};
+
+// ===========================================================================
+// Tiger
+// ===========================================================================
+struct TigerEnv {
+    using Params = pomdp_tiger_params;
+    using Reward = int32_t;
+    static constexpr int WORDS = 1;
+    struct Shared { int unused; };
+    struct State { uint32_t w; };
+
+    static __device__ __forceinline__ void stage(Shared &, const Params &) {}
+    static __device__ __forceinline__ int n_actions(const Params &) { return 3; }
+    static __device__ __forceinline__ void load(State &st, const uint32_t *state, int64_t, int64_t i) { st.w = state[i]; }
+    static __device__ __forceinline__ void store(const State &st, uint32_t *state, int64_t, int64_t i, bool) { state[i] = st.w; }
+
+    // tiger.py:60-66: state = state_space.sample() (gym-space RNG -> stream RESET_SPACE); ob = NULL
+    static __device__ __forceinline__ int reset(const Shared &, const Params &, State &st, const RngKey &key,
+                                                uint32_t lane)
+    {
+        st.w = stream_block(key, lane, POMDP_STREAM_RESET_SPACE, 0u).x & 1u; // randint(2): mask 1, never rejects
+        return 2;
+    }
+    // tiger.py:72-88 step, 117-119 _sample_state, 140-149 _sample_ob, 155-172
+    static __device__ __forceinline__ void step(const Shared &, const Params &p, State &st, int a,
+                                                const RngKey &key, uint32_t lane, int &ob, Reward &rew, int &done)
+    {
+        const int tiger = (int)(st.w & 1u);
+        if (a != 2 && a == tiger) { ob = tiger; rew = -20; done = 1; return; } // terminal: ob is the state
+        done = 0;
+        if (a == 2) {
+            rew = -1;
+            const uint4 w = stream_block(key, lane, POMDP_STREAM_STEP, 0u);
+            const bool flip = k53(w.x, w.y) > p.listen_thr;                     // p > .85
+            ob = tiger ^ (int)flip;
+        } else {
+            rew = 10;
+            st.w = stream_block(key, lane, POMDP_STREAM_STEP_SPACE, 0u).x & 1u; // state resampled
+            ob = 2; // the uniform() the reference draws here has no effect on anything returned
+        }
+    }
+};
+
+// ===========================================================================
+// Network
+// ===========================================================================
+struct NetworkEnv {
+    using Params = pomdp_network_params;
+    using Reward = float;
+    static constexpr int WORDS = 1;
+    struct Shared { int unused; };
+    struct State { uint32_t w; };
+
+    static __device__ __forceinline__ void stage(Shared &, const Params &) {}
+    static __device__ __forceinline__ int n_actions(const Params &p) { return 2 * p.n_machines + 1; }
+    static __device__ __forceinline__ void load(State &st, const uint32_t *state, int64_t, int64_t i) { st.w = state[i]; }
+    static __device__ __forceinline__ void store(const State &st, uint32_t *state, int64_t, int64_t i, bool) { state[i] = st.w; }
+
+    // network.py:61-69: all machines up, ob = OFF (0)
+    static __device__ __forceinline__ int reset(const Shared &, const Params &p, State &st, const RngKey &, uint32_t)
+    {
+        st.w = p.n_machines >= 32 ? 0xFFFFFFFFu : ((1u << p.n_machines) - 1u);
+        return 0;
+    }
+    // network.py:71-114
+    static __device__ __forceinline__ void step(const Shared &, const Params &p, State &st, int a,
+                                                const RngKey &key, uint32_t lane, int &ob, Reward &rew, int &done)
+    {
+        const uint32_t s0 = st.w;
+        uint32_t s = s0;
+        const int M = p.n_machines;
+        // reward: 2 per up machine with > 2 neighbours, 1 per other up machine   network.py:87-92
+        double r = (double)(__popc(s0) + __popc(s0 & p.deg_gt2_mask));
+        WordStream ws(key, lane, POMDP_STREAM_STEP);
+        for (int i = 0; i < M; ++i) {                                            // network.py:82-85, 94-99
+            if ((s0 >> i) & 1u) {
+                const bool nb_failed = (~s0 & p.nb_mask[i]) != 0u;               // from the pre-update state
+                const uint64_t k = ws.next_k53();
+                if (k > (nb_failed ? p.fail_nb_thr : p.fail_thr)) s &= ~(1u << i);
+            }
+        }
+        ob = 2;
+        if (a < 2 * M) {                                                         // network.py:101-112
+            const int machine = a >> 1;
+            const uint64_t k = ws.next_k53();
+            const int truthful = k <= p.obs_thr;
+            if (a & 1) { r -= 2.5; s |= 1u << machine; ob = truthful; }
+            else { r -= .1; const int up = (int)((s >> machine) & 1u); ob = truthful ? up : 1 - up; }
+        }
+        rew = (float)r;
+        done = 0;
+        st.w = s;
+    }
+};
+
+} // namespace pomdp

@@ -1,0 +1,214 @@
+"""BatchedEnv — host-side mirror of the reference's gym.Env duck type
+(`reset() -> ob`, `step(a) -> (ob, reward, done, info)`, `seed`, `action_space`,
+`observation_space`; gym_pomdp/envs/rock.py:96-271 and siblings) for a batch of
+independent env instances ("lanes") whose state lives in HBM as packed int32
+columns and is advanced by the HIP kernels behind include/pomdp_hip.h.
+
+Semantics added by batching:
+  * lanes are globally numbered `lane_offset + i`; every random draw depends only on
+    (seed, global lane, call counter t, stream id), so sharding a batch over GPUs or
+    changing the launch geometry never changes a result;
+  * the call counter t advances by one on every reset()/step() call;
+  * `auto_reset=True` (default for batch_size > 1): a lane that reports done gets a
+    fresh episode inside the same step() call — the terminal (ob, reward, done=1) is
+    returned, the stored state is the new episode's;
+  * `auto_reset=False` (default for batch_size == 1, the reference's behaviour): done
+    lanes freeze; with batch_size == 1 stepping a done env raises AssertionError
+    exactly like the reference (rock.py:126).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from .. import _native
+from ..spaces import Discrete
+
+
+def _random_seed():
+    return int.from_bytes(os.urandom(8), "little")
+
+
+class BatchedEnv(object):
+    metadata = {"render.modes": ["ansi"]}
+    reward_range = (-float("inf"), float("inf"))
+    env_name = None           # "rock", "tag", ... (C-ABI entry-point infix)
+    reward_dtype = torch.int32
+
+    # ---- subclasses provide -------------------------------------------------
+    def _build_params(self):  # -> (ctypes Structure, words per lane, n_actions, n_obs)
+        raise NotImplementedError
+
+    # ---- construction ---------------------------------------------------------
+    def _setup(self, batch_size=1, device=None, seed=None, auto_reset=None, lane_offset=0, reuse_buffers=False):
+        batch_size = int(batch_size)
+        if batch_size < 1:
+            raise ValueError("batch_size must be >= 1")
+        if lane_offset < 0 or lane_offset + batch_size > 1 << 32:
+            raise ValueError("lane range must lie in [0, 2^32)")
+        self.batch_size = batch_size
+        self.num_envs = batch_size
+        self.lane_offset = int(lane_offset)
+        self.auto_reset = (batch_size > 1) if auto_reset is None else bool(auto_reset)
+        self.reuse_buffers = bool(reuse_buffers)
+        self._params, self.state_words, n_actions, n_obs = self._build_params()
+        self._params_ref = C.byref(self._params)
+        self.action_space = Discrete(n_actions)
+        self.observation_space = Discrete(n_obs)
+        self._seed = _random_seed() if seed is None else int(seed) & 0xFFFFFFFFFFFFFFFF
+        self._t = 0
+        self._lib = _native.lib()                       # raises if the HIP library is missing
+        self._reset_fn = getattr(self._lib, "pomdp_%s_reset" % self.env_name)
+        self._step_fn = getattr(self._lib, "pomdp_%s_step" % self.env_name)
+        if not torch.cuda.is_available():
+            raise RuntimeError("gym_pomdp_amd: no GPU visible — the batched envs run on MI355X only "
+                               "(there is no CPU fallback)")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if self.device.type != "cuda":
+            raise ValueError("device must be a cuda (ROCm) device, got %s" % self.device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        n = batch_size
+        self._state = torch.zeros((self.state_words, n), dtype=torch.int32, device=self.device)
+        self._err = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._done = torch.zeros(n, dtype=torch.uint8, device=self.device)
+        self._ob = torch.zeros(n, dtype=torch.int32, device=self.device)
+        self._reward = torch.zeros(n, dtype=self.reward_dtype, device=self.device)
+        self._has_reset = False
+        self._scalar_done = False
+
+    # ---- gym.Env surface --------------------------------------------------------
+    def seed(self, seed=None):
+        """Reference: np.random.seed(seed) on the global stream (rock.py:120-121).  Here: the
+        Philox key of this env's lanes; the call counter restarts."""
+        self._seed = _random_seed() if seed is None else int(seed) & 0xFFFFFFFFFFFFFFFF
+        self._t = 0
+        return [self._seed]
+
+    @property
+    def call_counter(self):
+        """t of the next reset()/step() call (the Philox counter word pair)."""
+        return self._t
+
+    @call_counter.setter
+    def call_counter(self, t):
+        self._t = int(t)
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def reset(self):
+        """All lanes start a new episode.  Returns ob: int32[N] tensor (python int if batch_size == 1)."""
+        t = self._t
+        self._t += 1
+        with torch.cuda.device(self.device):
+            ob = self._ob if self.reuse_buffers else torch.empty_like(self._ob)
+            rc = self._reset_fn(self._params_ref, self._state.data_ptr(), ob.data_ptr(), self.batch_size,
+                                self._seed, self.lane_offset, t, self._stream())
+            _native.check(rc, "pomdp_%s_reset" % self.env_name)
+            self._done.zero_()
+        self._has_reset = True
+        self._scalar_done = False
+        self.done = False if self.batch_size == 1 else self._done.view(torch.bool)
+        if self.batch_size == 1:
+            return int(ob.item())
+        return ob
+
+    def step(self, action):
+        """action: int32[N] tensor on this env's device (other integer tensors / arrays / lists are
+        converted); python int when batch_size == 1.  Returns (ob, reward, done, info) like the
+        reference, as tensors (python scalars when batch_size == 1); info["state"] aliases the live
+        packed state, as the reference's info["state"] aliases live internals."""
+        if not self._has_reset:
+            # the reference raises AttributeError here: `self.done` does not exist before reset()
+            raise AttributeError("%s: step() called before reset()" % type(self).__name__)
+        scalar = self.batch_size == 1
+        if scalar:
+            assert self.action_space.contains(action), "invalid action %r" % (action,)
+            assert self._scalar_done is False or self.auto_reset, "step() on a done env (call reset())"
+            action = torch.tensor([int(action)], dtype=torch.int32, device=self.device)
+        else:
+            action = self._as_action_tensor(action)
+        t = self._t
+        self._t += 1
+        with torch.cuda.device(self.device):
+            if self.reuse_buffers:
+                ob, reward = self._ob, self._reward
+            else:
+                ob, reward = torch.empty_like(self._ob), torch.empty_like(self._reward)
+            done = self._done if (self.reuse_buffers or not self.auto_reset) else torch.empty_like(self._done)
+            rc = self._step_fn(self._params_ref, self._state.data_ptr(), action.data_ptr(), ob.data_ptr(),
+                               reward.data_ptr(), done.data_ptr(), self._err.data_ptr(), self.batch_size,
+                               self._seed, self.lane_offset, t, _native.POMDP_AUTO_RESET if self.auto_reset else 0,
+                               self._stream())
+            _native.check(rc, "pomdp_%s_step" % self.env_name)
+        if not self.auto_reset and not self.reuse_buffers:
+            done = done.clone()
+        info = {"state": self._state}
+        if scalar:
+            d = bool(done.item())
+            self._scalar_done = d
+            self.done = d
+            r = reward.item()
+            return int(ob.item()), (int(r) if self.reward_dtype == torch.int32 else float(r)), d, info
+        self.done = done.view(torch.bool)
+        return ob, reward, self.done, info
+
+    def _as_action_tensor(self, action):
+        if isinstance(action, torch.Tensor):
+            if action.dtype.is_floating_point or action.dtype == torch.bool:
+                raise AssertionError("actions must be integers")
+            a = action.to(device=self.device, dtype=torch.int32)
+        else:
+            arr = np.asarray(action)
+            if arr.dtype.kind not in "iu":
+                raise AssertionError("actions must be integers")
+            a = torch.as_tensor(arr.astype(np.int32), device=self.device)
+        if a.shape != (self.batch_size,):
+            raise AssertionError("actions must have shape (%d,), got %s" % (self.batch_size, tuple(a.shape)))
+        return a.contiguous()
+
+    def render(self, mode="ansi", close=False):
+        if close:
+            return
+        raise NotImplementedError("rendering is out of scope for the batched envs (SURVEY.md §2: GUI)")
+
+    def close(self):
+        return
+
+    # ---- batch-side extras --------------------------------------------------------
+    @property
+    def state(self):
+        """Packed lane state, int32 [state_words, N] (layout: include/pomdp_hip.h)."""
+        return self._state
+
+    def set_state(self, state):
+        """Overwrite the packed lane state (planner hook `_set_state`; tensor copy)."""
+        self._state.copy_(torch.as_tensor(state, dtype=torch.int32, device=self.device).reshape(self._state.shape))
+        self._done.zero_()
+        self._scalar_done = False
+        self._has_reset = True
+        self.done = False if self.batch_size == 1 else self._done.view(torch.bool)
+
+    _set_state = set_state
+
+    def invalid_action_count(self):
+        """Lanes that were handed an out-of-range action since construction (they were left
+        untouched; the reference would have raised AssertionError).  Synchronises."""
+        return int(self._err.item())
+
+    def synthetic_actions(self, out=None, seed=None):
+        """Uniform random actions from the bench's synthetic policy (stream ACTION of the *current* call
+        counter); int32[N] on device.  batch_size and lane_offset must be multiples of 4."""
+        if out is None:
+            out = torch.empty(self.batch_size, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self._lib.pomdp_synthetic_actions(out.data_ptr(), self.batch_size,
+                                                   self._seed if seed is None else seed, self.lane_offset,
+                                                   self._t, self.action_space.n, self._stream())
+            _native.check(rc, "pomdp_synthetic_actions")
+        return out
+
+    def __repr__(self):
+        return "%s(batch_size=%d, device=%s)" % (type(self).__name__, self.batch_size, getattr(self, "device", "?"))

@@ -1,0 +1,49 @@
+"""BattleShip — batched mirror of gym_pomdp/envs/battleship.py:64-211 (`BattleShipEnv`)."""
+import torch
+
+from .. import _native
+from .base import BatchedEnv
+
+
+def make_params(board_size=(5, 5), max_len=3):
+    x, y = board_size
+    cells = x * y
+    if not (1 <= x <= 16 and 1 <= y <= 16 and cells <= 122):
+        raise ValueError("BattleShip: boards up to 122 cells fit the packed masks")
+    if not 2 <= max_len <= 10:
+        raise ValueError("BattleShip: max_len must be in 2..10")
+    p = _native.BattleShipParams()
+    p.x_size, p.y_size, p.max_len = x, y, max_len
+    mask_words = (cells + 6 + 31) // 32
+    return p, 2 * mask_words, cells, 2
+
+
+class BattleShipEnv(BatchedEnv):
+    """Action a shoots cell (a % X, a // X) (coord.py:118-120); observation 1 on a first hit else 0;
+    reward -10 for a revisit, -1 for a new cell, + X*Y when the last ship cell is hit
+    (battleship.py:91-122).  Ships of length max_len..2 are placed by rejection sampling at reset
+    (battleship.py:167-211)."""
+    env_name = "battleship"
+    reward_dtype = torch.int32
+
+    def __init__(self, board_size=(5, 5), max_len=3, **batch_kwargs):
+        self.board_size = tuple(board_size)
+        self.max_len = max_len
+        self.num_obs = 2
+        self._reward_range = (self.board_size[0] * self.board_size[1]) / 4.   # battleship.py:72
+        self._discount = 1.                                                   # battleship.py:73
+        self._setup(**batch_kwargs)
+
+    def _build_params(self):
+        return make_params(self.board_size, self.max_len)
+
+    def decode_state(self):
+        """int64 [N, 1 + 2*cells] = [total_remaining, occupied_0.., visited_0..], cell a = y*X + x."""
+        mw = self.state_words // 2
+        cells = self.board_size[0] * self.board_size[1]
+        s = self._state.to(torch.int64) & 0xFFFFFFFF
+        a = torch.arange(cells, device=self.device)
+        occ = (s[a // 32] >> (a % 32).unsqueeze(1)) & 1
+        vis = (s[mw + a // 32] >> (a % 32).unsqueeze(1)) & 1
+        rem = (s[2 * mw - 1] >> 26).unsqueeze(0)
+        return torch.cat([rem, occ, vis], dim=0).t().contiguous()

@@ -1,0 +1,58 @@
+"""RockSample — batched mirror of gym_pomdp/envs/rock.py:96-407 (`RockEnv`)."""
+import torch
+
+from .. import _native, tables
+from .base import BatchedEnv
+
+
+def make_params(board_size=7, num_rocks=8):
+    """rock.py:99-118: validates like the reference's ctor assert, builds the rock-id grid
+    (every listed coordinate is stamped), start position and the sensor threshold table."""
+    assert board_size in tables.ROCK_CONFIG and num_rocks in tables.ROCK_CONFIG[board_size][0], \
+        "unsupported RockSample(%r, %r)" % (board_size, num_rocks)
+    _, init_pos, rock_pos = tables.ROCK_CONFIG[board_size]
+    if num_rocks > len(rock_pos):
+        # (2,2) and (4,4) pass the reference's assert but raise IndexError in reset()
+        raise IndexError("RockSample(%d,%d): only %d rock positions are configured"
+                         % (board_size, num_rocks, len(rock_pos)))
+    p = _native.RockParams()
+    p.size, p.num_rocks = board_size, num_rocks
+    p.start_x, p.start_y = init_pos
+    for i in range(256):
+        p.grid[i] = -1
+    for idx, (x, y) in enumerate(rock_pos):
+        p.grid[x * 16 + y] = idx
+        p.rock_x[idx], p.rock_y[idx] = x, y
+    for d in range(32):
+        p.thr[d] = tables.ROCK_THR[min(d, len(tables.ROCK_THR) - 1)]
+    words = 1 if num_rocks <= 12 else 2
+    return p, words, 5 + num_rocks, 3
+
+
+class RockEnv(BatchedEnv):
+    """Actions 0 N, 1 E, 2 S, 3 W, 4 SAMPLE, 5+i CHECK rock i (rock.py:18-23, 171-172);
+    observations 0 NULL, 1 BAD, 2 GOOD (rock.py:12-15); reward int32 in {-100, -10, 0, 10}.
+
+    Deliberate divergence: SAMPLE on a cell whose stamped rock id is >=
+    num_rocks raises IndexError in the reference; here it is "no rock" (-100, done)."""
+    env_name = "rock"
+    reward_dtype = torch.int32
+
+    def __init__(self, board_size=7, num_rocks=8, use_heuristic=False, **batch_kwargs):
+        self.board_size = board_size
+        self.num_rocks = num_rocks
+        self._use_heuristic = use_heuristic
+        self._discount = .95         # rock.py:115
+        self._reward_range = 20      # rock.py:116
+        self._penalization = -100    # rock.py:117
+        self._setup(**batch_kwargs)
+
+    def _build_params(self):
+        return make_params(self.board_size, self.num_rocks)
+
+    def decode_state(self):
+        """Reference-format view: int64 [N, 2 + K] = [x, y, status_0..status_{K-1}], status in {-1,0,+1}."""
+        s = self._state.to(torch.int64) & 0xFFFFFFFF
+        v = s[0] if self.state_words == 1 else (s[0] | (s[1] << 32))
+        cols = [v & 15, (v >> 4) & 15] + [((v >> (8 + 2 * j)) & 3) - 1 for j in range(self.num_rocks)]
+        return torch.stack(cols, dim=1)

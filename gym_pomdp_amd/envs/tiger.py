@@ -1,0 +1,37 @@
+"""Tiger — batched mirror of gym_pomdp/envs/tiger.py:47-172 (`TigerEnv`)."""
+import torch
+
+from .. import _native, tables
+from ..spaces import Discrete
+from .base import BatchedEnv
+
+
+def make_params():
+    p = _native.TigerParams()
+    p.listen_thr = tables.TIGER_LISTEN_THR
+    return p, 1, 3, 3
+
+
+class TigerEnv(BatchedEnv):
+    """Actions 0 open-left, 1 open-right, 2 listen; observations 0 left, 1 right, 2 null
+    (tiger.py:10-24).  Opening the tiger's door: -20, done, and the *state* is returned as the
+    observation (tiger.py:81-83); opening the other door: +10, not done, tiger re-placed; listen: -1,
+    correct w.p. .85.  `correct_prob` is stored but unused, as in the reference (tiger.py:86, 141).
+    The hidden state comes from the gym-space RNG in the reference (tiger.py:64, 119), which
+    np.random.seed does not control: here it has its own word streams (RESET_SPACE / STEP_SPACE)."""
+    env_name = "tiger"
+    reward_dtype = torch.int32
+
+    def __init__(self, seed=0, correct_prob=.85, **batch_kwargs):
+        self.correct_prob = correct_prob
+        self.state_space = Discrete(2)     # tiger.py:53
+        self._discount = .95               # tiger.py:55
+        self._reward_range = 10            # tiger.py:56
+        batch_kwargs.setdefault("seed", seed)   # TigerEnv() seeds in its ctor (tiger.py:58)
+        self._setup(**batch_kwargs)
+
+    def _build_params(self):
+        return make_params()
+
+    def decode_state(self):
+        return (self._state[0].to(torch.int64) & 1).unsqueeze(1)

@@ -1,0 +1,160 @@
+/*
+ * pomdp_hip.h — C ABI of libpomdp_hip.so, the MI355X (gfx950) batched step()/reset()
+ * path for gym_pomdp's discrete envs.
+ *
+ * The reference (d3sm0/gym_pomdp) is pure Python and has no FFI; the boundary it
+ * exposes for this path is the gym.Env duck type of each env class:
+ *     reset() -> ob                     step(a) -> (ob, reward, done, info)
+ * Each entry point below replaces the *arithmetic* of one of those methods for a
+ * whole batch of independent env instances ("lanes"); the reference method it
+ * stands in for is cited per function (paths relative to gym_pomdp/envs/).
+ * The modules under gym_pomdp_amd/envs/ are the host-side mirror that calls these through ctypes
+ * (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *   - every pointer marked "device" is HBM the caller owns (e.g. a torch tensor's
+ *     data_ptr()); the library never allocates, frees or synchronises;
+ *   - `state` is struct-of-arrays: uint32 [words][n], word-major, lane i at state[w*n + i];
+ *   - params structs are read on the host at call time and passed to the kernel
+ *     by value (kernarg) — they may live on the caller's stack;
+ *   - `stream` is a hipStream_t (NULL = the null stream); launches are asynchronous;
+ *   - lanes are globally numbered: lane = lane0 + i.  Random draws depend only on
+ *     (seed, lane, t, stream-id), never on n, the grid or the GPU count, so a batch
+ *     sharded over several GPUs reproduces the single-GPU result exactly;
+ *   - return value: 0 = ok, > 0 = hipError_t of the launch, < 0 = POMDP_E_*.
+ *
+ * Random-word contract: Philox4x32-10, key = (seed lo, seed hi),
+ * ctr = (lane, t lo, t hi, stream_id << 24 | block); numpy legacy constructions on
+ * top (res53 doubles, masked-rejection randint).
+ */
+#ifndef POMDP_HIP_H
+#define POMDP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define POMDP_ABI_VERSION 1
+
+enum {
+    POMDP_E_BADARG = -1,     /* NULL pointer, n < 0, n + lane0 > 2^32 */
+    POMDP_E_BADPARAMS = -2,  /* params outside what the packed layout supports */
+};
+
+/* flags for *_step */
+enum {
+    POMDP_AUTO_RESET = 1,    /* done lanes get a fresh episode in the same call (stream RESET of the same t);
+                                without it `done` is in/out and done lanes freeze: (ob, reward, done) = (0, 0, 1) */
+};
+
+/* id of the word streams of one (seed, lane, t) */
+enum { POMDP_STREAM_STEP = 0, POMDP_STREAM_RESET = 1, POMDP_STREAM_STEP_SPACE = 2,
+       POMDP_STREAM_RESET_SPACE = 3, POMDP_STREAM_ACTION = 4 };
+
+/* ---- RockSample  (rock.py:96-407) ---------------------------------------- */
+/* state words: 1 if num_rocks <= 12 else 2.  64-bit view s = w0 | w1 << 32:
+ * bits 0-3 x, 4-7 y, bits 8+2j..9+2j = Rock j status + 1 (0 bad, 1 collected, 2 good). */
+typedef struct pomdp_rock_params {
+    int32_t  size;          /* board is size x size                       rock.py:108 */
+    int32_t  num_rocks;     /* K <= 16; actions = 5 + K                   rock.py:113 */
+    int32_t  start_x, start_y;                                         /* rock.py:107 */
+    int8_t   rock_x[16], rock_y[16];                                   /* rock.py:106 */
+    int8_t   grid[256];     /* grid[x * 16 + y] = rock id stamped at (x, y) or -1    rock.py:110-111 */
+    uint64_t thr[32];       /* thr[d]: sensor correct iff k53 <= thr[d], d = L1 distance  rock.py:383-407 */
+} pomdp_rock_params;
+
+/* replaces RockEnv.reset (rock.py:236-241, 266-271, 78-86).  ob (device, may be NULL) <- 0. */
+int pomdp_rock_reset(const pomdp_rock_params *p, uint32_t *state, int32_t *ob, int64_t n,
+                     uint64_t seed, uint32_t lane0, uint64_t t, void *stream);
+/* replaces RockEnv.step (rock.py:123-194).  reward in {-100,-10,0,10}; err (device uint32, may be
+ * NULL) counts lanes whose action was outside [0, 5+K): they are left untouched, (ob,reward,done)=(0,0,0). */
+int pomdp_rock_step(const pomdp_rock_params *p, uint32_t *state, const int32_t *action, int32_t *ob,
+                    int32_t *reward, uint8_t *done, uint32_t *err, int64_t n,
+                    uint64_t seed, uint32_t lane0, uint64_t t, int flags, void *stream);
+
+/* ---- Tag  (tag.py:36-291) -------------------------------------------------- */
+/* state: 1 word: bits 0-4 agent cell, bits 5+5j.. opponent j cell (j < 4), bits 25-31 num_opp
+ * (7-bit two's complement, saturating at -64). */
+typedef struct pomdp_tag_params {
+    int32_t  num_opponents; /* 1..4                                       tag.py:87 */
+    int32_t  obs_cells;     /* "opponent seen" observation value          tag.py:94 */
+    uint64_t move_thr;      /* opponent moves iff k53 <= move_thr         tag.py:204 */
+} pomdp_tag_params;
+
+/* replaces TagEnv.reset (tag.py:97-102, 181-193) */
+int pomdp_tag_reset(const pomdp_tag_params *p, uint32_t *state, int32_t *ob, int64_t n,
+                    uint64_t seed, uint32_t lane0, uint64_t t, void *stream);
+/* replaces TagEnv.step (tag.py:108-143); reward is float {-1, -10, +10} */
+int pomdp_tag_step(const pomdp_tag_params *p, uint32_t *state, const int32_t *action, int32_t *ob,
+                   float *reward, uint8_t *done, uint32_t *err, int64_t n,
+                   uint64_t seed, uint32_t lane0, uint64_t t, int flags, void *stream);
+
+/* ---- BattleShip  (battleship.py:12-211) ------------------------------------ */
+/* state: 2*MW words, MW = ceil((x_size*y_size + 6) / 32) <= 4: occupied mask words 0..MW-1 then
+ * visited mask words; cell a = y * x_size + x is bit a; total_remaining in bits 26-31 of the
+ * last visited word. */
+typedef struct pomdp_battleship_params {
+    int32_t x_size, y_size; /* x_size * y_size <= 122                     battleship.py:67 */
+    int32_t max_len;        /* ctor max_len (ships max_len .. 2), 2..10   battleship.py:74-75 */
+} pomdp_battleship_params;
+
+/* replaces BattleShipEnv.reset (battleship.py:131-137, 167-211) */
+int pomdp_battleship_reset(const pomdp_battleship_params *p, uint32_t *state, int32_t *ob, int64_t n,
+                           uint64_t seed, uint32_t lane0, uint64_t t, void *stream);
+/* replaces BattleShipEnv.step (battleship.py:91-122) */
+int pomdp_battleship_step(const pomdp_battleship_params *p, uint32_t *state, const int32_t *action,
+                          int32_t *ob, int32_t *reward, uint8_t *done, uint32_t *err, int64_t n,
+                          uint64_t seed, uint32_t lane0, uint64_t t, int flags, void *stream);
+
+/* ---- Tiger  (tiger.py:47-172) ---------------------------------------------- */
+/* state: 1 word, bit 0 = tiger door */
+typedef struct pomdp_tiger_params {
+    uint64_t listen_thr;    /* listen is wrong iff k53 > listen_thr       tiger.py:141-148 */
+} pomdp_tiger_params;
+
+/* replaces TigerEnv.reset (tiger.py:60-66); the hidden state comes from stream RESET_SPACE */
+int pomdp_tiger_reset(const pomdp_tiger_params *p, uint32_t *state, int32_t *ob, int64_t n,
+                      uint64_t seed, uint32_t lane0, uint64_t t, void *stream);
+/* replaces TigerEnv.step (tiger.py:72-88) */
+int pomdp_tiger_step(const pomdp_tiger_params *p, uint32_t *state, const int32_t *action, int32_t *ob,
+                     int32_t *reward, uint8_t *done, uint32_t *err, int64_t n,
+                     uint64_t seed, uint32_t lane0, uint64_t t, int flags, void *stream);
+
+/* ---- Network  (network.py:24-168) ------------------------------------------ */
+/* state: 1 word, bit i = machine i is up */
+typedef struct pomdp_network_params {
+    int32_t  n_machines;    /* <= 32                                      network.py:27 */
+    uint32_t deg_gt2_mask;  /* machines with more than 2 neighbours       network.py:89 */
+    uint32_t nb_mask[32];   /* neighbour set of machine i                 network.py:144-168 */
+    uint64_t fail_thr;      /* fails iff k53 >  fail_thr     (p = .1)     network.py:97 */
+    uint64_t fail_nb_thr;   /* fails iff k53 >  fail_nb_thr  (q = .33)    network.py:99 */
+    uint64_t obs_thr;       /* truthful iff k53 <= obs_thr   (.95)        network.py:106-109 */
+} pomdp_network_params;
+
+/* replaces NetworkEnv.reset (network.py:61-69) */
+int pomdp_network_reset(const pomdp_network_params *p, uint32_t *state, int32_t *ob, int64_t n,
+                        uint64_t seed, uint32_t lane0, uint64_t t, void *stream);
+/* replaces NetworkEnv.step (network.py:71-114); reward = float32(float64 reward of the reference) */
+int pomdp_network_step(const pomdp_network_params *p, uint32_t *state, const int32_t *action, int32_t *ob,
+                       float *reward, uint8_t *done, uint32_t *err, int64_t n,
+                       uint64_t seed, uint32_t lane0, uint64_t t, int flags, void *stream);
+
+/* ---- helpers ---------------------------------------------------------------- */
+/* synthetic uniform random policy used by bench.py: lanes 4q..4q+3 share the Philox block
+ * ctr = (q, t lo, t hi, STREAM_ACTION << 24); action = (word[lane & 3] * n_actions) >> 32.
+ * n and lane0 must be multiples of 4. */
+int pomdp_synthetic_actions(int32_t *action, int64_t n, uint64_t seed, uint32_t lane0, uint64_t t,
+                            uint32_t n_actions, void *stream);
+/* raw generator, for known-answer tests: out (device) <- Philox4x32-10 of each of the n_blocks
+ * (ctr[4], key[2]) pairs in `ctr_key` (device, uint32 [n_blocks][6]). */
+int pomdp_philox_blocks(const uint32_t *ctr_key, uint32_t *out, int64_t n_blocks, void *stream);
+
+int         pomdp_abi_version(void);
+const char *pomdp_error_string(int code);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,238 @@
+"""GPU parity: the HIP path (through the Python mirror, i.e. through the C ABI) against
+(1) the committed golden traces of the reference and (2) the CPU oracle on seeded inputs.
+Bit-exact for state words, observation, reward and done."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_cases, load_golden, saturate_tag_compact
+
+pytestmark = pytest.mark.gpu
+
+CASES = golden_cases()
+ENV_IDS = {"rock": "Rock-v0", "tag": "Tag-v0", "battleship": "Battleship-v0", "tiger": "Tiger-v0",
+           "network": "Network-v0"}
+
+
+def make_env(env, kw, **batch):
+    import gym_pomdp_amd as gpa
+    return gpa.make(ENV_IDS[env], **kw, **batch)
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+def runs(lanes):
+    L = len(lanes)
+    starts = [0] + [i for i in range(1, L) if lanes[i] != lanes[i - 1] + 1] + [L]
+    return list(zip(starts[:-1], starts[1:]))
+
+
+def test_philox_kat_on_device():
+    from gym_pomdp_amd import _native
+    from oracle import philox_ref as px
+    ck = torch.tensor([list(c) + list(k) for c, k, _ in px.KAT], dtype=torch.int64).to(torch.int32).cuda()
+    # int64 -> int32 wraps the unsigned values
+    out = torch.zeros((len(px.KAT), 4), dtype=torch.int32, device="cuda")
+    _native.check(_native.lib().pomdp_philox_blocks(ck.data_ptr(), out.data_ptr(), len(px.KAT), None), "philox")
+    torch.cuda.synchronize()
+    got = np_(out).view(np.uint32)
+    for row, (_, _, want) in zip(got, px.KAT):
+        assert tuple(int(x) for x in row) == want
+
+
+@pytest.mark.parametrize("case,env,kw", CASES, ids=[c[0] for c in CASES])
+def test_golden_mode_b(case, env, kw):
+    """HIP kernels == the unmodified reference driven by the same Philox words (fixture F3)."""
+    g = load_golden("B", case)
+    seed, t0 = int(g["seed"]), int(g["t0"])
+    T = g["actions"].shape[1]
+    for s, e in runs(g["lanes"]):
+        n = e - s
+        envb = make_env(env, kw, batch_size=n, seed=seed, lane_offset=int(g["lanes"][s]), auto_reset=True)
+        envb.call_counter = t0
+        ob0 = envb.reset()
+        if n == 1:
+            pytest.skip("single-lane run")
+        assert np.array_equal(np_(ob0), g["ob0"][s:e])
+        assert np.array_equal(np_(envb.decode_state()), saturate_tag_compact(env, g["state0"][s:e]))
+        for i in range(T):
+            a = torch.as_tensor(g["actions"][s:e, i].astype(np.int32), device="cuda")
+            ob, rew, done, info = envb.step(a)
+            assert np.array_equal(np_(ob), g["ob"][s:e, i]), (case, i)
+            assert np.array_equal(np_(rew), g["reward"][s:e, i].astype(np_(rew).dtype)), (case, i)
+            assert np.array_equal(np_(done), g["done"][s:e, i].astype(bool)), (case, i)
+            assert np.array_equal(np_(envb.decode_state()), saturate_tag_compact(env, g["state"][s:e, i])), (case, i)
+        assert envb.invalid_action_count() == 0
+
+
+ORACLE_CASES = [
+    ("rock", {}, 65536, 64),                                        # BASELINE.json configs[1]
+    ("rock", dict(board_size=15, num_rocks=15), 16384, 48),
+    ("rock", dict(board_size=11, num_rocks=11), 8192, 32),
+    ("tag", {}, 32768, 96),
+    ("tag", dict(num_opponents=3), 8192, 64),
+    ("battleship", dict(board_size=(10, 10), max_len=5), 8192, 160),
+    ("battleship", {}, 16384, 64),
+    ("tiger", {}, 32768, 32),
+    ("network", {}, 32768, 32),
+    ("network", dict(n_machines=31, problem_type=3), 4096, 16),
+]
+
+
+@pytest.mark.parametrize("env,kw,n,T", ORACLE_CASES, ids=["%s-%d" % (c[0], i) for i, c in enumerate(ORACLE_CASES)])
+def test_hip_vs_oracle(oracle_lib, env, kw, n, T):
+    """Same seeded inputs through the HIP path and the CPU oracle: identical words."""
+    seed, lane0 = 20260929, 4096
+    o = oracle_lib.OracleEnv(env, **kw)
+    e = make_env(env, kw, batch_size=n, seed=seed, lane_offset=lane0)
+    st = o.new_state(n)
+    ob_o = o.batch_reset(st, seed, lane0, 0, nthreads=8)
+    ob_g = e.reset()
+    assert np.array_equal(np_(ob_g), ob_o)
+    assert np.array_equal(np_(e.state).view(np.uint32), st)
+    n_done = 0
+    for t in range(1, T + 1):
+        a = oracle_lib.synthetic_actions(n, seed ^ 0xABCDEF, lane0, t, o.n_actions, nthreads=8)
+        a_g = e.synthetic_actions(seed=seed ^ 0xABCDEF)
+        assert np.array_equal(np_(a_g), a)
+        ob, rew, done, bad = o.batch_step(st, a, seed, lane0, t, nthreads=8)
+        ob_g, rew_g, done_g, _ = e.step(a_g)
+        assert np.array_equal(np_(ob_g), ob), t
+        assert np.array_equal(np_(rew_g), rew), t
+        assert np.array_equal(np_(done_g), done.astype(bool)), t
+        assert np.array_equal(np_(e.state).view(np.uint32), st), t
+        n_done += int(done.sum())
+    if env not in ("network",):
+        assert n_done > 0          # auto-reset path was exercised
+    assert e.invalid_action_count() == 0
+
+
+@pytest.mark.parametrize("env,kw", [("rock", {}), ("tag", {}), ("battleship", {}), ("tiger", {})])
+def test_no_auto_reset_freezes(oracle_lib, env, kw):
+    n, seed = 4096, 77
+    o = oracle_lib.OracleEnv(env, **kw)
+    e = make_env(env, kw, batch_size=n, seed=seed, auto_reset=False)
+    st = o.new_state(n)
+    o.batch_reset(st, seed, 0, 0)
+    e.reset()
+    done = np.zeros(n, np.uint8)
+    for t in range(1, 60):
+        a = oracle_lib.synthetic_actions(n, 5, 0, t, o.n_actions)
+        ob, rew, done, _ = o.batch_step(st, a, seed, 0, t, auto_reset=False, done=done)
+        ob_g, rew_g, done_g, _ = e.step(torch.as_tensor(a, device="cuda"))
+        assert np.array_equal(np_(ob_g), ob) and np.array_equal(np_(rew_g), rew)
+        assert np.array_equal(np_(done_g), done.astype(bool))
+        assert np.array_equal(np_(e.state).view(np.uint32), st)
+    assert done.sum() > 0
+
+
+def test_invalid_actions_are_counted_and_ignored():
+    e = make_env("rock", {}, batch_size=8, seed=1)
+    e.reset()
+    before = np_(e.state).copy()
+    a = torch.tensor([13, -1, 0, 99, 1, 2, 1 << 30, 5], dtype=torch.int32, device="cuda")
+    ob, rew, done, _ = e.step(a)
+    assert e.invalid_action_count() == 4
+    bad = [0, 1, 3, 6]
+    assert np.array_equal(np_(e.state)[:, bad], before[:, bad])
+    assert np.all(np_(ob)[bad] == 0) and np.all(np_(rew)[bad] == 0) and not np_(done)[bad].any()
+
+
+def test_sharding_invariance():
+    """Two half-batches with lane offsets == one full batch (what makes multi-GPU exact)."""
+    n, seed = 8192, 99
+    full = make_env("rock", {}, batch_size=n, seed=seed)
+    lo = make_env("rock", {}, batch_size=n // 2, seed=seed, lane_offset=0)
+    hi = make_env("rock", {}, batch_size=n // 2, seed=seed, lane_offset=n // 2)
+    for e in (full, lo, hi):
+        e.reset()
+    for t in range(20):
+        a = full.synthetic_actions()
+        r_full = full.step(a)
+        r_lo = lo.step(a[: n // 2].contiguous())
+        r_hi = hi.step(a[n // 2:].contiguous())
+        for k in range(3):
+            assert torch.equal(r_full[k], torch.cat([r_lo[k], r_hi[k]]))
+        assert torch.equal(full.state, torch.cat([lo.state, hi.state], dim=1))
+
+
+def test_scalar_env_mirrors_reference_errors():
+    """batch_size=1: python scalars in/out, AssertionError / AttributeError like the reference
+    (tests/golden/edge_cases.json)."""
+    import json
+    import os
+    from conftest import GOLDEN
+    with open(os.path.join(GOLDEN, "edge_cases.json")) as f:
+        edge = json.load(f)
+    for env in ("rock", "tag", "battleship", "tiger", "network"):
+        e = make_env(env, {})
+        assert e.action_space.n == edge["%s.n_actions" % env]
+        assert e.observation_space.n == edge["%s.n_obs" % env]
+        with pytest.raises(AttributeError):
+            e.step(0)
+        assert edge["%s.step_before_reset" % env] == "AttributeError"
+        ob = e.reset()
+        assert isinstance(ob, int)
+        for bad in (e.action_space.n, -1, 1.0):
+            with pytest.raises(AssertionError):
+                e.step(bad)
+        ob, r, d, info = e.step(0)
+        assert isinstance(ob, int) and isinstance(d, bool) and "state" in info
+    e = make_env("rock", {}, seed=3)
+    e.reset()
+    ob, r, d, _ = e.step(3)          # WEST from x = 0: -100, done
+    assert (ob, r, d) == (0, -100, True)
+    with pytest.raises(AssertionError):
+        e.step(0)
+    assert edge["rock.step_after_done"] == "AssertionError"
+
+
+def test_tiger_config1_rollout(oracle_lib):
+    """BASELINE.json configs[0]: Tiger-v0 single env, 100-step random-action rollout."""
+    e = make_env("tiger", {}, seed=11)
+    o = oracle_lib.OracleEnv("tiger")
+    st = o.new_state(1)
+    assert e.reset() == int(o.batch_reset(st, 11, 0, 0)[0])
+    t = 1
+    rs = np.random.RandomState(0)
+    for _ in range(100):
+        a = int(rs.randint(3))
+        ob, r, d, _ = e.step(a)
+        ob_o, r_o, d_o, _ = o.batch_step(st, [a], 11, 0, t, auto_reset=False)
+        assert (ob, r, d) == (int(ob_o[0]), int(r_o[0]), bool(d_o[0]))
+        t += 1
+        if d:
+            assert e.reset() == int(o.batch_reset(st, 11, 0, t)[0])
+            t += 1
+
+
+def test_full_size_properties():
+    """BASELINE.json metric size (2^20 lanes): properties that need no oracle run."""
+    n, seed = 1 << 20, 123
+    a_env = make_env("rock", {}, batch_size=n, seed=seed)
+    b_env = make_env("rock", {}, batch_size=n, seed=seed)
+    a_env.reset()
+    b_env.reset()
+    assert torch.equal(a_env.state, b_env.state)                      # determinism
+    s = a_env.decode_state()
+    assert torch.all(s[:, 0] == 0) and torch.all(s[:, 1] == 3)        # start cell
+    frac_good = (s[:, 2:] == 1).double().mean().item()
+    assert abs(frac_good - 0.5) < 2e-3                                # rocks are fair coins
+    tot_done = 0
+    for t in range(16):
+        act = a_env.synthetic_actions()
+        ob, rew, done, _ = a_env.step(act)
+        ob2, rew2, done2, _ = b_env.step(act)
+        assert torch.equal(ob, ob2) and torch.equal(rew, rew2) and torch.equal(done, done2)
+        assert torch.equal(a_env.state, b_env.state)
+        assert int(ob.min()) >= 0 and int(ob.max()) <= 2
+        assert set(torch.unique(rew).tolist()) <= {-100, -10, 0, 10}
+        assert torch.all(done == ((rew == -100) | ((rew == 10) & (act == 1))))   # rock.py:139-141, 193
+        assert torch.all((ob == 0) | (act >= 5))                                  # only CHECK observes
+        st = a_env.decode_state()
+        assert int(st[:, :2].max()) <= 6 and int(st[:, 2:].min()) >= -1 and int(st[:, 2:].max()) <= 1
+        tot_done += int(done.sum())
+    assert 0.05 < tot_done / (16 * n) < 0.25                          # episodes last ~8 steps
+    assert a_env.invalid_action_count() == 0
