@@ -5,7 +5,9 @@
 
 Workload (BASELINE.json metric): RockSample(7,8), 2^20 lanes per GPU, i.i.d. uniform random
 actions from the synthetic policy (its kernel is inside the timed region), auto-reset on done.
-A "step" is one pass of the hot path over the whole batch: one action launch + one step launch.
+A "step" is one pass of the hot path over the whole batch: one action launch + one step launch,
+issued by the library's C-side rollout driver (pomdp_rollout_synthetic) so that the interpreter is
+not between the launches; `--host-loop python` times the same steps through env.step() instead.
 N > 1: one process per GPU (torch.distributed.run), lanes sharded by global lane id, no data-path
 collective — only the timing barrier / max-over-ranks (gloo, host side).  Scaling is weak: every
 GPU owns 2^20 lanes.
@@ -49,6 +51,8 @@ def parse():
     ap.add_argument("--env", default="rock", choices=sorted(WORKLOADS))
     ap.add_argument("--lanes-per-gpu", type=int, default=1 << 20)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--host-loop", default="c", choices=["c", "python"],
+                    help="who issues the two launches of a step: the C rollout driver or a python loop over env.step()")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline sample")
     return ap.parse_args()
@@ -106,9 +110,17 @@ def main():
     actions = torch.empty(n, dtype=torch.int32, device=dev)
     action_seed = args.seed ^ 0x5DEECE66D
 
-    def one_step():
-        env.synthetic_actions(out=actions, seed=action_seed)
-        env.step(actions)
+    def run_steps(k):
+        if args.host_loop == "python":
+            for _ in range(k):
+                env.synthetic_actions(out=actions, seed=action_seed)
+                env.step(actions)
+        else:
+            left = k
+            while left > 0:
+                c = min(left, 100)
+                env.rollout_synthetic(c, action_seed=action_seed, actions=actions)
+                left -= c
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -116,12 +128,10 @@ def main():
             pg.barrier()
 
     env.reset()
-    for _ in range(args.warmup):
-        one_step()
+    run_steps(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
+    run_steps(args.steps)
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     barrier()
@@ -162,7 +172,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s batch=%d lanes per GPU (%d total), uniform random actions "
                                    "(synthetic-policy kernel timed), auto-reset" % (label, n, total_lanes),
-                       "lanes_per_gpu": n, "total_lanes": total_lanes, "parallelism": "lane-shard x%d, no collectives" % world},
+                       "lanes_per_gpu": n, "total_lanes": total_lanes, "host_loop": args.host_loop, "parallelism": "lane-shard x%d, no collectives" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "step_kernel<%s>" % args.env, "kernel_ms": kern_ms,

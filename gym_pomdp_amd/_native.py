@@ -16,6 +16,7 @@ HEADER = os.path.join(_REPO, "include", "pomdp_hip.h")
 ABI_VERSION = 1
 
 POMDP_AUTO_RESET = 1
+ENV_KIND = {"rock": 0, "tag": 1, "battleship": 2, "tiger": 3, "network": 4}
 
 # every symbol include/pomdp_hip.h declares
 SYMBOLS = [
@@ -23,6 +24,7 @@ SYMBOLS = [
     "pomdp_rock_reset", "pomdp_rock_step", "pomdp_tag_reset", "pomdp_tag_step",
     "pomdp_battleship_reset", "pomdp_battleship_step", "pomdp_tiger_reset", "pomdp_tiger_step",
     "pomdp_network_reset", "pomdp_network_step", "pomdp_synthetic_actions", "pomdp_philox_blocks",
+    "pomdp_rollout_synthetic",
 ]
 
 
@@ -99,6 +101,8 @@ def lib():
         s.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, u64, u32, u64, ci, vp]
     L.pomdp_synthetic_actions.restype = ci
     L.pomdp_synthetic_actions.argtypes = [vp, i64, u64, u32, u64, u32, vp]
+    L.pomdp_rollout_synthetic.restype = ci
+    L.pomdp_rollout_synthetic.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, i64, u64, u64, u32, u64, i64, ci, vp]
     L.pomdp_philox_blocks.restype = ci
     L.pomdp_philox_blocks.argtypes = [vp, vp, i64, vp]
     _lib = L

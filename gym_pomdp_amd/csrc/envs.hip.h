@@ -12,6 +12,7 @@
 #pragma once
 #include "../../include/pomdp_hip.h"
 #include "philox.hip.h"
+#include <type_traits>
 
 namespace pomdp {
 
@@ -20,88 +21,160 @@ constexpr uint64_t TWO52 = 4503599627370496ull;
 // ===========================================================================
 // RockSample
 // ===========================================================================
-template <int W> // state words per lane: 1 (K <= 12) or 2
+// ABLATE is a profiling aid (tools/microbench.hip): bit 0 drops the CHECK Philox block, bit 1 the
+// auto-reset, bit 2 the LDS table lookups.  The product only instantiates ABLATE = 0.
+template <int W, int ABLATE = 0> // W = state words per lane: 1 (K <= 12) or 2
 struct RockEnv {
     using Params = pomdp_rock_params;
     using Reward = int32_t;
+    using S = typename std::conditional<W == 1, uint32_t, uint64_t>::type; // 32-bit ALU when one word is enough
     static constexpr int WORDS = W;
     struct Shared {
-        int8_t grid[256];
-        int8_t rx[16], ry[16];
-        uint64_t thr[32];
+        uint64_t thr[32];   // sensor thresholds by L1 distance
+        int8_t grid[256];   // rock id stamped at [x * 16 + y], -1 = none
+        uint8_t rxy[16];    // rock j position, x | y << 4
     };
-    struct State { uint64_t s; };
+    struct State { S s; };
 
-    static __device__ __forceinline__ void stage(Shared &sh, const Params &p)
+    // One global-load latency: every thread fetches a slice of the kernarg-resident tables with
+    // unconditional (index-wrapped) loads, all issued before the first LDS write, so the compiler
+    // emits one s_waitcnt instead of one per predicated region; duplicate writers store equal values.
+    static __device__ __forceinline__ void stage(Shared &sh, const Params &p, int tid)
     {
-        for (int i = threadIdx.x; i < 256; i += blockDim.x) sh.grid[i] = p.grid[i];
-        for (int i = threadIdx.x; i < 16; i += blockDim.x) { sh.rx[i] = p.rock_x[i]; sh.ry[i] = p.rock_y[i]; }
-        for (int i = threadIdx.x; i < 32; i += blockDim.x) sh.thr[i] = p.thr[i];
+        const int8_t g = p.grid[tid & 255];
+        const uint64_t t = p.thr[tid & 31];
+        const int8_t rx = p.rock_x[tid & 15], ry = p.rock_y[tid & 15];
+        sh.grid[tid & 255] = g;
+        sh.thr[tid & 31] = t;
+        sh.rxy[tid & 15] = (uint8_t)((rx & 15) | (ry << 4));
     }
     static __device__ __forceinline__ int n_actions(const Params &p) { return 5 + p.num_rocks; }
 
     static __device__ __forceinline__ void load(State &st, const uint32_t *state, int64_t n, int64_t i)
     {
         st.s = state[i];
-        if (W == 2) st.s |= (uint64_t)state[n + i] << 32;
+        if (W == 2) st.s |= (S)((uint64_t)state[n + i] << 32);
     }
     static __device__ __forceinline__ void store(const State &st, uint32_t *state, int64_t n, int64_t i, bool)
     {
         state[i] = (uint32_t)st.s;
-        if (W == 2) state[n + i] = (uint32_t)(st.s >> 32);
+        if (W == 2) state[n + i] = (uint32_t)((uint64_t)st.s >> 32);
     }
+
+    static __device__ __forceinline__ uint32_t rock_code(uint64_t k) { return (k > TWO52) ? 2u : (k < TWO52 ? 0u : 1u); }
 
     // rock.py:236-241 reset -> 266-271 _get_init_state -> 78-86 Rock.__init__:
     // status_j = sign(U_j - .5), rocks in index order, one double each.
     static __device__ __forceinline__ int reset(const Shared &, const Params &p, State &st, const RngKey &key,
                                                 uint32_t lane)
     {
-        uint64_t s = (uint32_t)p.start_x | ((uint32_t)p.start_y << 4);
+        S s = (S)((uint32_t)p.start_x | ((uint32_t)p.start_y << 4));
         const int K = p.num_rocks;
         for (int b = 0; 2 * b < K; ++b) {
             const uint4 w = stream_block(key, lane, POMDP_STREAM_RESET, (uint32_t)b);
-            const uint64_t ka = k53(w.x, w.y), kb = k53(w.z, w.w);
-            const uint64_t ca = (ka > TWO52) ? 2u : (ka < TWO52 ? 0u : 1u);
-            const uint64_t cb = (kb > TWO52) ? 2u : (kb < TWO52 ? 0u : 1u);
-            s |= ca << (8 + 4 * b);
-            if (2 * b + 1 < K) s |= cb << (10 + 4 * b);
+            s |= (S)rock_code(k53(w.x, w.y)) << (8 + 4 * b);
+            if (2 * b + 1 < K) s |= (S)rock_code(k53(w.z, w.w)) << (10 + 4 * b);
         }
         st.s = s;
         return 0; // Obs.NULL
     }
 
-    // rock.py:123-194 step; 401-407 _sample_ob; 383-387 _efficiency; coord.py:133-135 (L1 distance)
+    // Wave-cooperative reset.  A fresh episode needs NB = ceil(K/2) Philox blocks (K doubles), but
+    // under random actions only ~1/8 of a wave's lanes reset in a given step while nearly every wave
+    // has at least one: done per lane, the whole wave would pay all NB blocks.  Instead the
+    // (resetting lane, block) pairs are dealt out across the 64 lanes — one Philox block per lane per
+    // pass — and the rock codes travel back through DPP / ds_bpermute.  Same words, same result as
+    // reset() above; ~1 pass per step instead of NB blocks.
+    static __device__ __forceinline__ void reset_where(const Shared &, const Params &p, State &st, bool fresh,
+                                                       const RngKey &key, uint32_t lane)
+    {
+        if (ABLATE & 2) return;
+        const uint64_t mask = __ballot(fresh);
+        if (mask == 0ull) return;                                      // wave-uniform
+        const int K = p.num_rocks;
+        const int NB = (K + 1) >> 1;                                   // blocks per reset (wave-uniform)
+        const int lid = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        const int me = (int)(threadIdx.x & 63u);
+        const int nreset = __popcll(mask);
+        // stable partition: resetting lanes first; lane r (< nreset) learns who the r-th resetting lane is
+        const int dst = fresh ? lid : nreset + (me - lid);
+        const int src_of_rank = __builtin_amdgcn_ds_permute(dst << 2, me);
+        uint64_t bits = 0;
+        const int ntask = nreset * NB;
+        if (NB == 4) {
+            // K = 7 or 8 (the metric config): the four tasks of one reset sit in one quad of lanes
+            for (int base = 0; base < ntask; base += 64) {
+                const int tid = base + me;
+                const int srcl = __shfl(src_of_rank, (tid >> 2) & 63, 64);
+                const int b = me & 3;
+                uint32_t v = 0;
+                if (tid < ntask) {
+                    const uint4 w = stream_block(key, lane - (uint32_t)me + (uint32_t)srcl, POMDP_STREAM_RESET, (uint32_t)b);
+                    const uint32_t cb = (2 * b + 1 < K) ? (rock_code(k53(w.z, w.w)) << 2) : 0u;
+                    v = (rock_code(k53(w.x, w.y)) | cb) << (4 * b);
+                }
+                v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true); // quad_perm [1,0,3,2]
+                v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true); // quad_perm [2,3,0,1]
+                const int t = lid * 4 - base;
+                const uint32_t got = (uint32_t)__shfl((int)v, t & 63, 64);
+                if (t >= 0 && t < 64) bits = (uint64_t)got << 8;
+            }
+        } else {
+            const uint32_t inv = (65536u + (uint32_t)NB - 1u) / (uint32_t)NB; // tid / NB == (tid * inv) >> 16 for tid < 512
+            for (int base = 0; base < ntask; base += 64) {
+                const int tid = base + me;
+                const int r = (int)(((uint32_t)tid * inv) >> 16);
+                const int b = tid - r * NB;
+                const int srcl = __shfl(src_of_rank, r & 63, 64);
+                uint32_t nib = 0;
+                if (tid < ntask) {
+                    const uint4 w = stream_block(key, lane - (uint32_t)me + (uint32_t)srcl, POMDP_STREAM_RESET, (uint32_t)b);
+                    nib = rock_code(k53(w.x, w.y)) | ((2 * b + 1 < K) ? (rock_code(k53(w.z, w.w)) << 2) : 0u);
+                }
+                for (int bb = 0; bb < NB; ++bb) {                       // wave-uniform trip count
+                    const int t = lid * NB + bb - base;
+                    const uint32_t got = (uint32_t)__shfl((int)nib, t & 63, 64);
+                    if (t >= 0 && t < 64) bits |= (uint64_t)got << (8 + 4 * bb);
+                }
+            }
+        }
+        if (fresh) st.s = (S)((uint64_t)((uint32_t)p.start_x | ((uint32_t)p.start_y << 4)) | bits);
+    }
+
+    // rock.py:123-194 step; 401-407 _sample_ob; 383-387 _efficiency; coord.py:133-135 (L1 distance).
+    // Branch-free: the three action classes (move / SAMPLE / CHECK) are all evaluated and selected,
+    // so a wave with mixed actions — every wave, under a random policy — runs one straight line.
     static __device__ __forceinline__ void step(const Shared &sh, const Params &p, State &st, int a,
                                                 const RngKey &key, uint32_t lane, int &ob, Reward &rew, int &done)
     {
-        uint64_t s = st.s;
-        int x = (int)(s & 15u), y = (int)((s >> 4) & 15u);
-        const int size = p.size;
-        ob = 0; rew = 0; done = 0;
-        if (a < 4) {
-            // 0 N (0,+1)  1 E (+1,0)  2 S (0,-1)  3 W (-1,0)      coord.py:155-160
-            const int nx = x + (a == 1) - (a == 3), ny = y + (a == 0) - (a == 2);
-            if ((unsigned)nx < (unsigned)size && (unsigned)ny < (unsigned)size) { x = nx; y = ny; }
-            else if (a == 1) { rew = 10; done = 1; }        // east exit          rock.py:138-141
-            else { rew = -100; done = 1; }                  // off-grid N/S/W     rock.py:146,151,156,193
-            s = (s & ~0xFFull) | (uint64_t)(x | (y << 4));
-        } else if (a == 4) {                                // SAMPLE             rock.py:160-169
-            const int id = sh.grid[x * 16 + y];
-            const int sh_ = 8 + 2 * (id & 15);
-            const uint32_t code = (uint32_t)(s >> sh_) & 3u;
-            if (id >= 0 && id < p.num_rocks && code != 1u) {
-                rew = code == 2u ? 10 : -10;
-                s = (s & ~(3ull << sh_)) | (1ull << sh_);
-            } else { rew = -100; done = 1; }
-        } else {                                            // CHECK rock a-5     rock.py:171-175
-            const int r = a - 5;
-            const int d = abs(x - sh.rx[r]) + abs(y - sh.ry[r]);
-            const uint4 w = stream_block(key, lane, POMDP_STREAM_STEP, 0u);
-            const bool correct = k53(w.x, w.y) <= sh.thr[d]; // np.random.binomial(1, eff)
-            const bool good = ((uint32_t)(s >> (8 + 2 * r)) & 3u) == 2u;
-            ob = (good == correct) ? 2 : 1;                 // rock.py:404-407
-        }
-        st.s = s;
+        const S s = st.s;
+        const int x = (int)(s & 15u), y = (int)((s >> 4) & 15u);
+        const int size = p.size, K = p.num_rocks;
+        // CHECK rock a-5 (rock.py:171-175): one double from stream STEP -> binomial(1, eff(d))
+        const int r = (a - 5) & 15;
+        const uint32_t rxy = (ABLATE & 4) ? (uint32_t)(r * 17) : sh.rxy[r];
+        const int d = abs(x - (int)(rxy & 15u)) + abs(y - (int)(rxy >> 4));
+        const uint4 w = (ABLATE & 1) ? make_uint4(lane * 2654435761u, lane, 0, 0) : stream_block(key, lane, POMDP_STREAM_STEP, 0u);
+        const bool correct = k53(w.x, w.y) <= ((ABLATE & 4) ? (uint64_t)d << 48 : sh.thr[d]);
+        const bool good = ((uint32_t)(s >> (8 + 2 * r)) & 3u) == 2u;
+        const int ob_check = (good == correct) ? 2 : 1;                        // rock.py:404-407
+        // SAMPLE (rock.py:160-169); ids >= K raise IndexError in the reference, "no rock" here
+        const int id = (ABLATE & 4) ? ((x ^ y) & 7) - (x & 1) : sh.grid[x * 16 + y];
+        const int sh_ = 8 + 2 * (id & 15);
+        const uint32_t code = (uint32_t)(s >> sh_) & 3u;
+        const bool sample_ok = (id >= 0) & (id < K) & (code != 1u);
+        const int rew_sample = sample_ok ? (code == 2u ? 10 : -10) : -100;
+        const S s_sample = sample_ok ? (S)((s & ~((S)3 << sh_)) | ((S)1 << sh_)) : s;
+        // move: 0 N (0,+1)  1 E (+1,0)  2 S (0,-1)  3 W (-1,0)   (coord.py:155-160, rock.py:134-158)
+        const int nx = x + (a == 1) - (a == 3), ny = y + (a == 0) - (a == 2);
+        const bool inside = ((unsigned)nx < (unsigned)size) & ((unsigned)ny < (unsigned)size);
+        const S s_move = inside ? (S)((s & ~(S)0xFF) | (S)(uint32_t)(nx | (ny << 4))) : s;
+        const int rew_move = inside ? 0 : (a == 1 ? 10 : -100);                // east exit / off-grid
+        const bool is_move = a < 4, is_sample = a == 4;
+        st.s = is_move ? s_move : (is_sample ? s_sample : s);
+        rew = is_move ? rew_move : (is_sample ? rew_sample : 0);
+        ob = (a > 4) ? ob_check : 0;
+        done = is_move ? !inside : (rew == -100);                              // rock.py:139-141, 193
     }
 };
 
@@ -115,7 +188,7 @@ struct TagEnv {
     struct Shared { int unused; };
     struct State { uint32_t w; };
 
-    static __device__ __forceinline__ void stage(Shared &, const Params &) {}
+    static __device__ __forceinline__ void stage(Shared &, const Params &, int) {}
     static __device__ __forceinline__ int n_actions(const Params &) { return 5; }
     static __device__ __forceinline__ void load(State &st, const uint32_t *state, int64_t, int64_t i) { st.w = state[i]; }
     static __device__ __forceinline__ void store(const State &st, uint32_t *state, int64_t, int64_t i, bool) { state[i] = st.w; }
@@ -157,6 +230,13 @@ struct TagEnv {
         for (int j = 0; j < p.num_opponents; ++j) w |= ws.randint(29u) << (5 + 5 * j);
         st.w = with_num_opp(w, p.num_opponents);
         return sample_ob(p, st.w, 0);
+    }
+
+    // Called convergently by every lane of the wave; `fresh` marks the lanes that start a new episode.
+    static __device__ __forceinline__ void reset_where(const Shared &sh, const Params &p, State &st, bool fresh,
+                                                       const RngKey &key, uint32_t lane)
+    {
+        if (fresh) reset(sh, p, st, key, lane);
     }
 
     // tag.py:108-143 step, 201-207 move_opponent, 260-280 _admissable_actions
@@ -219,7 +299,7 @@ struct BattleShipEnv {
     struct Shared { int unused; };
     struct State { uint32_t occ[MW], vis[MW]; };
 
-    static __device__ __forceinline__ void stage(Shared &, const Params &) {}
+    static __device__ __forceinline__ void stage(Shared &, const Params &, int) {}
     static __device__ __forceinline__ int n_actions(const Params &p) { return p.x_size * p.y_size; }
     static __device__ __forceinline__ void load(State &st, const uint32_t *state, int64_t n, int64_t i)
     {
@@ -291,6 +371,13 @@ struct BattleShipEnv {
         return 0;
     }
 
+    // Called convergently by every lane of the wave; `fresh` marks the lanes that start a new episode.
+    static __device__ __forceinline__ void reset_where(const Shared &sh, const Params &p, State &st, bool fresh,
+                                                       const RngKey &key, uint32_t lane)
+    {
+        if (fresh) reset(sh, p, st, key, lane);
+    }
+
     // battleship.py:91-122
     static __device__ __forceinline__ void step(const Shared &, const Params &p, State &st, int a,
                                                 const RngKey &, uint32_t, int &ob, Reward &rew, int &done)
@@ -318,7 +405,7 @@ struct TigerEnv {
     struct Shared { int unused; };
     struct State { uint32_t w; };
 
-    static __device__ __forceinline__ void stage(Shared &, const Params &) {}
+    static __device__ __forceinline__ void stage(Shared &, const Params &, int) {}
     static __device__ __forceinline__ int n_actions(const Params &) { return 3; }
     static __device__ __forceinline__ void load(State &st, const uint32_t *state, int64_t, int64_t i) { st.w = state[i]; }
     static __device__ __forceinline__ void store(const State &st, uint32_t *state, int64_t, int64_t i, bool) { state[i] = st.w; }
@@ -329,6 +416,13 @@ struct TigerEnv {
     {
         st.w = stream_block(key, lane, POMDP_STREAM_RESET_SPACE, 0u).x & 1u; // randint(2): mask 1, never rejects
         return 2;
+    }
+
+    // Called convergently by every lane of the wave; `fresh` marks the lanes that start a new episode.
+    static __device__ __forceinline__ void reset_where(const Shared &sh, const Params &p, State &st, bool fresh,
+                                                       const RngKey &key, uint32_t lane)
+    {
+        if (fresh) reset(sh, p, st, key, lane);
     }
     // tiger.py:72-88 step, 117-119 _sample_state, 140-149 _sample_ob, 155-172
     static __device__ __forceinline__ void step(const Shared &, const Params &p, State &st, int a,
@@ -360,7 +454,7 @@ struct NetworkEnv {
     struct Shared { int unused; };
     struct State { uint32_t w; };
 
-    static __device__ __forceinline__ void stage(Shared &, const Params &) {}
+    static __device__ __forceinline__ void stage(Shared &, const Params &, int) {}
     static __device__ __forceinline__ int n_actions(const Params &p) { return 2 * p.n_machines + 1; }
     static __device__ __forceinline__ void load(State &st, const uint32_t *state, int64_t, int64_t i) { st.w = state[i]; }
     static __device__ __forceinline__ void store(const State &st, uint32_t *state, int64_t, int64_t i, bool) { state[i] = st.w; }
@@ -370,6 +464,13 @@ struct NetworkEnv {
     {
         st.w = p.n_machines >= 32 ? 0xFFFFFFFFu : ((1u << p.n_machines) - 1u);
         return 0;
+    }
+
+    // Called convergently by every lane of the wave; `fresh` marks the lanes that start a new episode.
+    static __device__ __forceinline__ void reset_where(const Shared &sh, const Params &p, State &st, bool fresh,
+                                                       const RngKey &key, uint32_t lane)
+    {
+        if (fresh) reset(sh, p, st, key, lane);
     }
     // network.py:71-114
     static __device__ __forceinline__ void step(const Shared &, const Params &p, State &st, int a,

@@ -17,13 +17,14 @@
 namespace pomdp {
 
 constexpr int BLOCK = 256;        // 4 waves: one per SIMD
-constexpr int MAX_BLOCKS = 256 * 8; // 256 CUs x 8 resident workgroups, grid-stride beyond that
+constexpr int MAX_BLOCKS = 256 * 8; // helper kernels: 256 CUs x 8 resident workgroups, grid-stride beyond
 
 static inline int grid_for(int64_t n)
 {
     const int64_t b = (n + BLOCK - 1) / BLOCK;
     return (int)(b < 1 ? 1 : (b > MAX_BLOCKS ? MAX_BLOCKS : b));
 }
+static inline unsigned blocks_for(int64_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
 
 // ---------------------------------------------------------------------------
 // reset: every lane starts a fresh episode from stream RESET of (seed, lane, t)
@@ -33,10 +34,10 @@ __global__ __launch_bounds__(BLOCK) void reset_kernel(const typename Env::Params
                                                       int32_t *__restrict__ ob, int64_t n, RngKey key, uint32_t lane0)
 {
     __shared__ typename Env::Shared sh;
-    Env::stage(sh, p);
+    Env::stage(sh, p, (int)threadIdx.x);
     __syncthreads();
-    const int64_t stride = (int64_t)gridDim.x * BLOCK;
-    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) {
         typename Env::State st;
         const int o = Env::reset(sh, p, st, key, lane0 + (uint32_t)i);
         Env::store(st, state, n, i, true);
@@ -46,8 +47,16 @@ __global__ __launch_bounds__(BLOCK) void reset_kernel(const typename Env::Params
 
 // ---------------------------------------------------------------------------
 // step: transition + observation + reward (+ same-call auto-reset of done lanes)
+//
+// One workgroup = 256 threads = LPT x 256 consecutive lanes; thread `tid` owns lanes
+// base + tid + 256 * j (j < LPT), so every wave access is still one coalesced segment.
+// All HBM loads of all of a thread's lanes (action, state words, done flag) are issued
+// unconditionally before the table staging and its barrier: a wave pays one memory latency for
+// LPT x 64 lanes, and the independent per-lane chains (LDS lookups, Philox, cross-lane reset)
+// overlap.  Lanes past n read lane n-1 and have their stores predicated off.  Every lane of a
+// wave reaches Env::reset_where (wave-cooperative reset).
 // ---------------------------------------------------------------------------
-template <class Env>
+template <class Env, int LPT>
 __global__ __launch_bounds__(BLOCK) void step_kernel(const typename Env::Params p, uint32_t *__restrict__ state,
                                                      const int32_t *__restrict__ action, int32_t *__restrict__ ob,
                                                      typename Env::Reward *__restrict__ reward,
@@ -55,31 +64,47 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const typename Env::Params 
                                                      int64_t n, RngKey key, uint32_t lane0, int flags)
 {
     __shared__ typename Env::Shared sh;
-    Env::stage(sh, p);
-    __syncthreads();
     const bool auto_reset = flags & POMDP_AUTO_RESET;
+    const int64_t base = (int64_t)blockIdx.x * (BLOCK * LPT) + threadIdx.x;
+    int64_t idx[LPT];
+    bool in_range[LPT], was_done[LPT];
+    int a_raw[LPT];
+    typename Env::State st[LPT];
+#pragma unroll
+    for (int j = 0; j < LPT; ++j) {
+        idx[j] = base + (int64_t)j * BLOCK;
+        in_range[j] = idx[j] < n;
+        const int64_t ic = in_range[j] ? idx[j] : n - 1;
+        a_raw[j] = action[ic];
+        Env::load(st[j], state, n, ic);
+        was_done[j] = auto_reset ? false : (done[ic] != 0);          // frozen lane (the reference would assert)
+    }
+    Env::stage(sh, p, (int)threadIdx.x);
+    __syncthreads();
+
     const int n_act = Env::n_actions(p);
-    const int64_t stride = (int64_t)gridDim.x * BLOCK;
-    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
-        const int a = action[i];
-        int o = 0, d = 0;
-        typename Env::Reward r = 0;
-        if (!auto_reset && done[i]) {
-            d = 1;                                   // frozen lane (the reference would assert)
-        } else if ((unsigned)a >= (unsigned)n_act) {
-            if (err) atomicAdd(err, 1u);             // the reference asserts; the lane is left untouched
-        } else {
-            const uint32_t lane = lane0 + (uint32_t)i;
-            typename Env::State st;
-            Env::load(st, state, n, i);
-            Env::step(sh, p, st, a, key, lane, o, r, d);
-            const bool fresh = d && auto_reset;
-            if (fresh) Env::reset(sh, p, st, key, lane);
-            Env::store(st, state, n, i, fresh);
+    int o[LPT], d[LPT];
+    typename Env::Reward r[LPT];
+    bool live[LPT], valid[LPT];
+#pragma unroll
+    for (int j = 0; j < LPT; ++j) {
+        valid[j] = (unsigned)a_raw[j] < (unsigned)n_act;
+        live[j] = in_range[j] && valid[j] && !was_done[j];
+        Env::step(sh, p, st[j], valid[j] ? a_raw[j] : 0, key, lane0 + (uint32_t)idx[j], o[j], r[j], d[j]);
+        if (!live[j]) { o[j] = 0; r[j] = 0; d[j] = was_done[j]; }     // step result discarded unless live
+    }
+#pragma unroll
+    for (int j = 0; j < LPT; ++j) {
+        const bool fresh = live[j] && d[j] && auto_reset;
+        Env::reset_where(sh, p, st[j], fresh, key, lane0 + (uint32_t)idx[j]);
+        if (live[j]) Env::store(st[j], state, n, idx[j], fresh);
+        if (in_range[j]) {
+            ob[idx[j]] = o[j];
+            reward[idx[j]] = r[j];
+            done[idx[j]] = (uint8_t)d[j];
+            // the reference asserts on an out-of-range action; here the lane is left untouched and counted
+            if (!valid[j] && !was_done[j] && err) atomicAdd(err, 1u);
         }
-        ob[i] = o;
-        reward[i] = r;
-        done[i] = (uint8_t)d;
     }
 }
 
@@ -124,7 +149,7 @@ static int launch_reset(const typename Env::Params &p, uint32_t *state, int32_t 
 {
     if (!state || bad_range(n, lane0)) return POMDP_E_BADARG;
     if (n == 0) return 0;
-    hipLaunchKernelGGL(reset_kernel<Env>, dim3(grid_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, p, state, ob, n,
+    hipLaunchKernelGGL(reset_kernel<Env>, dim3(blocks_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, p, state, ob, n,
                        make_key(seed, t), lane0);
     return (int)hipGetLastError();
 }
@@ -136,8 +161,10 @@ static int launch_step(const typename Env::Params &p, uint32_t *state, const int
 {
     if (!state || !action || !ob || !reward || !done || bad_range(n, lane0)) return POMDP_E_BADARG;
     if (n == 0) return 0;
-    hipLaunchKernelGGL(step_kernel<Env>, dim3(grid_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, p, state, action, ob,
-                       reward, done, err, n, make_key(seed, t), lane0, flags);
+    // LPT = 1: measured on MI355X (tools/microbench.hip), 1 / 2 / 4 lanes per thread run within 2 % of
+    // each other at 2^20 and 2^22 lanes — the kernel is bound by VALU issue, not by latency.
+    hipLaunchKernelGGL((step_kernel<Env, 1>), dim3(blocks_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, p, state,
+                       action, ob, reward, done, err, n, make_key(seed, t), lane0, flags);
     return (int)hipGetLastError();
 }
 
@@ -267,6 +294,55 @@ int pomdp_synthetic_actions(int32_t *action, int64_t n, uint64_t seed, uint32_t 
     hipLaunchKernelGGL(synthetic_actions_kernel, dim3(grid_for(n / 4)), dim3(BLOCK), 0, (hipStream_t)stream,
                        (int4 *)action, n / 4, make_key(seed, t), lane0 >> 2, n_actions);
     return (int)hipGetLastError();
+}
+
+int pomdp_rollout_synthetic(int env, const void *params, uint32_t *state, int32_t *action, int32_t *ob, void *reward,
+                            uint8_t *done, uint32_t *err, int64_t n, uint64_t seed, uint64_t action_seed,
+                            uint32_t lane0, uint64_t t0, int64_t k_steps, int flags, void *stream)
+{
+    if (!params || k_steps < 0) return POMDP_E_BADARG;
+    uint32_t n_actions;
+    switch (env) {
+    case POMDP_ENV_ROCK: n_actions = 5u + (uint32_t)((const pomdp_rock_params *)params)->num_rocks; break;
+    case POMDP_ENV_TAG: n_actions = 5u; break;
+    case POMDP_ENV_BATTLESHIP: {
+        const pomdp_battleship_params *p = (const pomdp_battleship_params *)params;
+        n_actions = (uint32_t)(p->x_size * p->y_size);
+        break;
+    }
+    case POMDP_ENV_TIGER: n_actions = 3u; break;
+    case POMDP_ENV_NETWORK: n_actions = 2u * (uint32_t)((const pomdp_network_params *)params)->n_machines + 1u; break;
+    default: return POMDP_E_BADARG;
+    }
+    for (int64_t s = 0; s < k_steps; ++s) {
+        const uint64_t t = t0 + (uint64_t)s;
+        int rc = pomdp_synthetic_actions(action, n, action_seed, lane0, t, n_actions, stream);
+        if (rc) return rc;
+        switch (env) {
+        case POMDP_ENV_ROCK:
+            rc = pomdp_rock_step((const pomdp_rock_params *)params, state, action, ob, (int32_t *)reward, done, err, n,
+                                 seed, lane0, t, flags, stream);
+            break;
+        case POMDP_ENV_TAG:
+            rc = pomdp_tag_step((const pomdp_tag_params *)params, state, action, ob, (float *)reward, done, err, n, seed,
+                                lane0, t, flags, stream);
+            break;
+        case POMDP_ENV_BATTLESHIP:
+            rc = pomdp_battleship_step((const pomdp_battleship_params *)params, state, action, ob, (int32_t *)reward,
+                                       done, err, n, seed, lane0, t, flags, stream);
+            break;
+        case POMDP_ENV_TIGER:
+            rc = pomdp_tiger_step((const pomdp_tiger_params *)params, state, action, ob, (int32_t *)reward, done, err, n,
+                                  seed, lane0, t, flags, stream);
+            break;
+        default:
+            rc = pomdp_network_step((const pomdp_network_params *)params, state, action, ob, (float *)reward, done, err,
+                                    n, seed, lane0, t, flags, stream);
+            break;
+        }
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 int pomdp_philox_blocks(const uint32_t *ctr_key, uint32_t *out, int64_t n_blocks, void *stream)

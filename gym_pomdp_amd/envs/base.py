@@ -210,5 +210,27 @@ class BatchedEnv(object):
             _native.check(rc, "pomdp_synthetic_actions")
         return out
 
+    def rollout_synthetic(self, steps, action_seed=None, actions=None):
+        """`steps` consecutive step() calls under the synthetic uniform policy, issued from C
+        (pomdp_rollout_synthetic): the same two launches per step a python loop over
+        synthetic_actions() + step() makes, without the interpreter between them.  Outputs land in the
+        reusable buffers; returns (ob, reward, done) of the last step.  Asynchronous."""
+        if not self._has_reset:
+            raise AttributeError("%s: rollout before reset()" % type(self).__name__)
+        if actions is None:
+            if getattr(self, "_action_scratch", None) is None:
+                self._action_scratch = torch.empty(self.batch_size, dtype=torch.int32, device=self.device)
+            actions = self._action_scratch
+        t0 = self._t
+        self._t += int(steps)
+        with torch.cuda.device(self.device):
+            rc = self._lib.pomdp_rollout_synthetic(
+                _native.ENV_KIND[self.env_name], self._params_ref, self._state.data_ptr(), actions.data_ptr(),
+                self._ob.data_ptr(), self._reward.data_ptr(), self._done.data_ptr(), self._err.data_ptr(),
+                self.batch_size, self._seed, self._seed if action_seed is None else action_seed, self.lane_offset,
+                t0, int(steps), _native.POMDP_AUTO_RESET if self.auto_reset else 0, self._stream())
+            _native.check(rc, "pomdp_rollout_synthetic")
+        return self._ob, self._reward, self._done.view(torch.bool)
+
     def __repr__(self):
         return "%s(batch_size=%d, device=%s)" % (type(self).__name__, self.batch_size, getattr(self, "device", "?"))

@@ -151,6 +151,17 @@ int pomdp_synthetic_actions(int32_t *action, int64_t n, uint64_t seed, uint32_t 
  * (ctr[4], key[2]) pairs in `ctr_key` (device, uint32 [n_blocks][6]). */
 int pomdp_philox_blocks(const uint32_t *ctr_key, uint32_t *out, int64_t n_blocks, void *stream);
 
+/* Random-policy rollout driven from C: for s in [0, k_steps): pomdp_synthetic_actions at t0+s into
+ * `action` (device scratch, int32[n]) with key `action_seed`, then pomdp_<env>_step at t0+s.  Exactly
+ * the launches a host loop over step() would issue (2 per step), minus the host language's per-call
+ * overhead; the caller's call counter advances by k_steps.  `params` points at the env's
+ * pomdp_<env>_params; `reward` is int32 or float per env.  n and lane0 must be multiples of 4. */
+enum { POMDP_ENV_ROCK = 0, POMDP_ENV_TAG = 1, POMDP_ENV_BATTLESHIP = 2, POMDP_ENV_TIGER = 3, POMDP_ENV_NETWORK = 4 };
+int pomdp_rollout_synthetic(int env, const void *params, uint32_t *state, int32_t *action, int32_t *ob,
+                            void *reward, uint8_t *done, uint32_t *err, int64_t n, uint64_t seed,
+                            uint64_t action_seed, uint32_t lane0, uint64_t t0, int64_t k_steps, int flags,
+                            void *stream);
+
 int         pomdp_abi_version(void);
 const char *pomdp_error_string(int code);
 

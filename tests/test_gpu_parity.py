@@ -158,6 +158,22 @@ def test_sharding_invariance():
         assert torch.equal(full.state, torch.cat([lo.state, hi.state], dim=1))
 
 
+def test_c_rollout_driver_equals_python_loop():
+    """pomdp_rollout_synthetic issues the same launches as a python loop over step()."""
+    n, seed = 16384, 5
+    for env, kw in (("rock", {}), ("tag", {}), ("battleship", {}), ("network", {})):
+        a = make_env(env, kw, batch_size=n, seed=seed, reuse_buffers=True)
+        b = make_env(env, kw, batch_size=n, seed=seed)
+        a.reset()
+        b.reset()
+        a.rollout_synthetic(25, action_seed=99)
+        for _ in range(25):
+            ob, rew, done, _ = b.step(b.synthetic_actions(seed=99))
+        assert a.call_counter == b.call_counter
+        assert torch.equal(a.state, b.state)
+        assert torch.equal(a._ob, ob) and torch.equal(a._reward, rew) and torch.equal(a._done.view(torch.bool), done)
+
+
 def test_scalar_env_mirrors_reference_errors():
     """batch_size=1: python scalars in/out, AssertionError / AttributeError like the reference
     (tests/golden/edge_cases.json)."""

@@ -1,0 +1,131 @@
+// microbench.hip — standalone A/B harness for the RockSample step kernel (not part of the product).
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o /tmp/microbench tools/microbench.hip
+#include "../gym_pomdp_amd/csrc/pomdp_kernels.hip"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+using namespace pomdp;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
+
+// V0: pure traffic (same 21 B/lane, trivial ALU)
+__global__ __launch_bounds__(256) void traffic_kernel(uint32_t *__restrict__ state, const int32_t *__restrict__ action,
+                                                      int32_t *__restrict__ ob, int32_t *__restrict__ reward,
+                                                      uint8_t *__restrict__ done, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const uint32_t s = state[i];
+        const int a = action[i];
+        state[i] = s + (uint32_t)a;
+        ob[i] = a & 3;
+        reward[i] = a - 5;
+        done[i] = (uint8_t)(s & 1u);
+    }
+}
+
+// V0v: same traffic, 4 lanes per thread, 16-byte accesses
+__global__ __launch_bounds__(256) void traffic_kernel_v4(uint4 *__restrict__ state, const int4 *__restrict__ action,
+                                                         int4 *__restrict__ ob, int4 *__restrict__ reward,
+                                                         uint32_t *__restrict__ done, int64_t n4)
+{
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const uint4 s = state[i];
+        const int4 a = action[i];
+        state[i] = make_uint4(s.x + a.x, s.y + a.y, s.z + a.z, s.w + a.w);
+        ob[i] = make_int4(a.x & 3, a.y & 3, a.z & 3, a.w & 3);
+        reward[i] = make_int4(a.x - 5, a.y - 5, a.z - 5, a.w - 5);
+        done[i] = (s.x & 1u) | ((s.y & 1u) << 8) | ((s.z & 1u) << 16) | ((s.w & 1u) << 24);
+    }
+}
+
+// Philox-only: k blocks per lane, one store
+template <int NBLK>
+__global__ __launch_bounds__(256) void philox_kernel(uint32_t *__restrict__ out, int64_t n, RngKey key)
+{
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) { const uint4 w = stream_block(key, (uint32_t)i, 0, b); acc ^= w.x ^ w.y ^ w.z ^ w.w; }
+        out[i] = acc;
+    }
+}
+
+__global__ void empty_kernel() {}
+
+template <class F> static float time_it(F f, int iters)
+{
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 10; ++i) f(i);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < iters; ++i) f(100 + i);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms * 1e3f / iters;
+}
+
+int main(int argc, char **argv)
+{
+    const int64_t n = argc > 1 ? atoll(argv[1]) : (1 << 20);
+    const int iters = getenv("MB_ITERS") ? atoi(getenv("MB_ITERS")) : 500;
+    uint32_t *state; int32_t *action, *ob, *reward; uint8_t *done; uint32_t *err;
+    CK(hipMalloc(&state, n * 8)); CK(hipMalloc(&action, n * 4)); CK(hipMalloc(&ob, n * 4)); CK(hipMalloc(&reward, n * 4));
+    CK(hipMalloc(&done, n)); CK(hipMalloc(&err, 4)); CK(hipMemset(err, 0, 4));
+    // RockSample(7,8) params
+    pomdp_rock_params p = {};
+    p.size = 7; p.num_rocks = 8; p.start_x = 0; p.start_y = 3;
+    const int rp[8][2] = {{2,0},{0,1},{3,1},{6,3},{2,4},{3,4},{5,5},{1,6}};
+    for (int i = 0; i < 256; ++i) p.grid[i] = -1;
+    for (int i = 0; i < 8; ++i) { p.rock_x[i] = rp[i][0]; p.rock_y[i] = rp[i][1]; p.grid[rp[i][0] * 16 + rp[i][1]] = i; }
+    for (int d = 0; d < 32; ++d) p.thr[d] = 8000000000000000ull;
+    pomdp_rock_reset(&p, state, ob, n, 1, 0, 0, nullptr);
+    pomdp_synthetic_actions(action, n, 2, 0, 1, 13, nullptr);
+    CK(hipDeviceSynchronize());
+
+    printf("n = %lld lanes, %d iters, times in us per launch\n", (long long)n, iters);
+    printf("empty kernel                : %8.2f\n", time_it([&](int) { hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, 0); }, iters));
+    for (int blocks : {1024, 2048, 4096, 8192}) {
+        printf("traffic 21B  grid=%5d      : %8.2f\n", blocks,
+               time_it([&](int) { hipLaunchKernelGGL(traffic_kernel, dim3(blocks), dim3(256), 0, 0, state, action, ob, reward, done, n); }, iters));
+    }
+    for (int blocks : {256, 512, 1024, 2048}) {
+        printf("traffic 21B v4 grid=%5d    : %8.2f\n", blocks,
+               time_it([&](int) { hipLaunchKernelGGL(traffic_kernel_v4, dim3(blocks), dim3(256), 0, 0, (uint4 *)state, (const int4 *)action, (int4 *)ob, (int4 *)reward, (uint32_t *)done, n / 4); }, iters));
+    }
+    RngKey key = make_key(1, 5);
+    printf("philox 1 blk/lane           : %8.2f\n", time_it([&](int) { hipLaunchKernelGGL(philox_kernel<1>, dim3(2048), dim3(256), 0, 0, (uint32_t *)ob, n, key); }, iters));
+    printf("philox 2 blk/lane           : %8.2f\n", time_it([&](int) { hipLaunchKernelGGL(philox_kernel<2>, dim3(2048), dim3(256), 0, 0, (uint32_t *)ob, n, key); }, iters));
+    printf("philox 4 blk/lane           : %8.2f\n", time_it([&](int) { hipLaunchKernelGGL(philox_kernel<4>, dim3(2048), dim3(256), 0, 0, (uint32_t *)ob, n, key); }, iters));
+    printf("philox 8 blk/lane           : %8.2f\n", time_it([&](int) { hipLaunchKernelGGL(philox_kernel<8>, dim3(2048), dim3(256), 0, 0, (uint32_t *)ob, n, key); }, iters));
+    printf("synthetic actions           : %8.2f\n", time_it([&](int t) { pomdp_synthetic_actions(action, n, 2, 0, t, 13, nullptr); }, iters));
+    pomdp_synthetic_actions(action, n, 2, 0, 1, 13, nullptr);
+    printf("rock step (auto-reset)      : %8.2f\n", time_it([&](int t) { pomdp_rock_step(&p, state, action, ob, reward, done, err, n, 1, 0, t, 1, nullptr); }, iters));
+    {
+        auto run = [&](auto env_tag, const char *name) {
+            using E = decltype(env_tag);
+            printf("%-28s: LPT1 %8.2f", name, time_it([&](int t) {
+                hipLaunchKernelGGL((step_kernel<E, 1>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, p, state, action, ob, reward, done, err, n, make_key(1, t), 0u, 1);
+            }, iters));
+            printf("  LPT2 %8.2f", time_it([&](int t) {
+                hipLaunchKernelGGL((step_kernel<E, 2>), dim3((unsigned)((n + 511) / 512)), dim3(256), 0, 0, p, state, action, ob, reward, done, err, n, make_key(1, t), 0u, 1);
+            }, iters));
+            printf("  LPT4 %8.2f\n", time_it([&](int t) {
+                hipLaunchKernelGGL((step_kernel<E, 4>), dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, 0, p, state, action, ob, reward, done, err, n, make_key(1, t), 0u, 1);
+            }, iters));
+        };
+        run(RockEnv<1, 0>{}, "step full");
+        run(RockEnv<1, 1>{}, "step -checkphilox");
+        run(RockEnv<1, 2>{}, "step -reset");
+        run(RockEnv<1, 3>{}, "step -checkphilox -reset");
+        run(RockEnv<1, 4>{}, "step -lds");
+        run(RockEnv<1, 7>{}, "step -all");
+    }
+    printf("rock reset                  : %8.2f\n", time_it([&](int t) { pomdp_rock_reset(&p, state, ob, n, 1, 0, t, nullptr); }, iters));
+    return 0;
+}
