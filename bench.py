@@ -85,6 +85,18 @@ def cpu_baseline(env_key, kwargs, seed, budget_s):
                                                   "build container (BASELINE.md); it cannot travel to this box"}}
 
 
+def measured_traffic(env_key):
+    """HBM bytes per step-kernel launch from the committed PMC passes (profiles/traffic_*.json, produced by
+    tools/gpu_profile.sh: separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this command)."""
+    name = {"rock": "traffic_rock_7_8.json"}.get(env_key)
+    path = os.path.join(REPO, "profiles", name) if name else None
+    if not path or not os.path.exists(path):
+        return None, None
+    with open(path) as f:
+        t = json.load(f)
+    return t["hbm_bytes_per_launch"], "profiles/" + name
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -94,18 +106,19 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.gpus > 1 and world == 1:
         raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    pg = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group(backend="gloo")  # control plane only: barrier + max of the timings
-        pg = dist
-
+    n_dev = torch.cuda.device_count()
+    dev_index = local_rank % max(n_dev, 1)      # fewer GPUs than ranks (1-GPU dev box): ranks share devices
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     import gym_pomdp_amd as gpa
+    from gym_pomdp_amd import sharding
+    cp = sharding.ControlPlane()    # gloo, host side: barrier + max of the timings; no data-path collective
+
     env_id, kwargs, label, bytes_per_step, dtype = WORKLOADS[args.env]
     n = args.lanes_per_gpu
-    env = gpa.make(env_id, batch_size=n, device=dev, seed=args.seed, lane_offset=rank * n, reuse_buffers=True,
+    lane_offset, count = sharding.shard_range(n * world, rank, world)   # weak scaling: n lanes on every GPU
+    assert count == n
+    env = gpa.make(env_id, batch_size=n, device=dev, seed=args.seed, lane_offset=lane_offset, reuse_buffers=True,
                    **kwargs)
     actions = torch.empty(n, dtype=torch.int32, device=dev)
     action_seed = args.seed ^ 0x5DEECE66D
@@ -124,8 +137,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize(dev)
-        if pg is not None:
-            pg.barrier()
+        cp.barrier()
 
     env.reset()
     run_steps(args.warmup)
@@ -135,10 +147,7 @@ def main():
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     barrier()
-    if pg is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64)
-        pg.all_reduce(tt, op=pg.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = cp.max(elapsed)
 
     # ---- roofline of the dominant kernel: the step kernel alone, HIP events on its stream --------
     env.synthetic_actions(out=actions, seed=action_seed)
@@ -155,6 +164,7 @@ def main():
     achieved = bytes_per_step * n / (kern_ms * 1e-3) / 1e9
     invalid = env.invalid_action_count()
 
+    traffic, traffic_src = measured_traffic(args.env) if n == 1 << 20 else (None, None)
     if rank == 0:
         total_lanes = n * world
         out = {
@@ -172,9 +182,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s batch=%d lanes per GPU (%d total), uniform random actions "
                                    "(synthetic-policy kernel timed), auto-reset" % (label, n, total_lanes),
-                       "lanes_per_gpu": n, "total_lanes": total_lanes, "host_loop": args.host_loop, "parallelism": "lane-shard x%d, no collectives" % world},
+                       "lanes_per_gpu": n, "total_lanes": total_lanes, "host_loop": args.host_loop, "visible_gpus": n_dev, "parallelism": "lane-shard x%d, no collectives" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch",
+                         "traffic_source": traffic_src,
                          "kernel": "step_kernel<%s>" % args.env, "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_step": bytes_per_step,
                          "note": "step kernel launched back-to-back %d times, HIP events on its stream; "
@@ -184,9 +195,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.env, kwargs, args.seed, args.cpu_seconds)
         print(json.dumps(out), flush=True)
-    if pg is not None:
-        pg.barrier()
-        pg.destroy_process_group()
+    cp.close()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,140 @@
+"""Host-side logic that needs no GPU: the C-ABI library loads and exports every symbol the header
+declares, params structs mirror the header, config validation mirrors the reference's constructor
+behaviour, spaces follow gym's rules, and the product path fails loudly without a GPU."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, REPO
+
+
+def test_library_exports_every_declared_symbol():
+    from gym_pomdp_amd import _native
+    _native.build()
+    hdr = open(os.path.join(REPO, "include", "pomdp_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(pomdp_[a-z_0-9]+)\s*\(", hdr)))
+    assert declared, "no declarations parsed"
+    lib = C.CDLL(_native.LIB_PATH)
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+    assert sorted(_native.SYMBOLS) == declared
+    L = _native.lib()
+    assert L.pomdp_abi_version() == _native.ABI_VERSION
+    assert L.pomdp_error_string(0) == b"ok"
+    assert b"bad argument" in L.pomdp_error_string(-1)
+
+
+def test_bad_arguments_are_rejected_without_a_gpu():
+    from gym_pomdp_amd import _native
+    from gym_pomdp_amd.envs import rock
+    L = _native.lib()
+    p = rock.make_params()[0]
+    assert L.pomdp_rock_step(C.byref(p), None, None, None, None, None, None, 16, 0, 0, 0, 1, None) == -1
+    assert L.pomdp_rock_reset(C.byref(p), None, None, 16, 0, 0, 0, None) == -1
+    p.size = 99
+    assert L.pomdp_rock_reset(C.byref(p), None, None, 16, 0, 0, 0, None) == -2
+    assert L.pomdp_synthetic_actions(None, 16, 0, 0, 0, 13, None) == -1
+
+
+def test_struct_sizes_match_header_layout():
+    from gym_pomdp_amd import _native as n
+    assert C.sizeof(n.RockParams) == 16 + 16 + 16 + 256 + 32 * 8
+    assert C.sizeof(n.TagParams) == 16
+    assert C.sizeof(n.BattleShipParams) == 12
+    assert C.sizeof(n.TigerParams) == 8
+    assert C.sizeof(n.NetworkParams) == 8 + 32 * 4 + 3 * 8
+    assert n.RockParams.grid.offset == 48 and n.RockParams.thr.offset == 304
+
+
+def test_tables_match_captured_thresholds():
+    from gym_pomdp_amd import tables
+    with open(os.path.join(GOLDEN, "thresholds.json")) as f:
+        thr = json.load(f)
+    assert list(tables.ROCK_THR) == thr["rock_thr"]
+    assert tables.TAG_MOVE_THR == thr["tag_move"]["thr"]
+    assert tables.NET_FAIL_THR == thr["net_fail"]["thr"]
+    assert tables.NET_FAIL_NEIGHBOUR_THR == thr["net_fail_neighbour"]["thr"]
+    assert tables.NET_OBS_THR == thr["net_obs"]["thr"]
+    assert tables.TIGER_LISTEN_THR == thr["tiger_listen"]["thr"]
+    assert tables.bernoulli_threshold(.8) == (tables.TAG_MOVE_THR, "le")
+    assert tables.bernoulli_threshold(.1) == (tables.NET_FAIL_THR, "gt")
+
+
+def test_rock_params_follow_reference_config():
+    from gym_pomdp_amd.envs import rock
+    with open(os.path.join(GOLDEN, "edge_cases.json")) as f:
+        edge = json.load(f)
+    for bs, k in ((7, 8), (7, 7), (7, 6), (3, 3), (11, 11), (15, 15), (2, 1), (4, 3)):
+        if edge["rock.ctor_%d_%d" % (bs, k)] == "ok":
+            p, words, nA, nO = rock.make_params(bs, k)
+            assert (nA, nO) == (5 + k, 3) and words == (1 if k <= 12 else 2)
+        else:
+            with pytest.raises(AssertionError):
+                rock.make_params(bs, k)
+    with pytest.raises(IndexError):      # passes the reference's assert, IndexError in its reset()
+        rock.make_params(4, 4)
+    p = rock.make_params(15, 15)[0]
+    assert p.grid[1 * 16 + 2] == 3       # (1,2) is listed twice: the later index wins (rock.py:110-111)
+    assert p.grid[12 * 16 + 2] == 15     # stamped although num_rocks == 15
+    p = rock.make_params(7, 8)[0]
+    assert (p.start_x, p.start_y) == (0, 3) and p.grid[6 * 16 + 3] == 3 and p.grid[0] == -1
+
+
+def test_network_params_follow_reference_topology():
+    from gym_pomdp_amd.envs import network
+    with open(os.path.join(GOLDEN, "edge_cases.json")) as f:
+        edge = json.load(f)
+    p = network.make_params(10, 3)[0]
+    for i, nb in enumerate(edge["network.make_3legs_10"]):
+        assert p.nb_mask[i] == sum(1 << j for j in nb)
+    assert p.deg_gt2_mask == 1      # only machine 0 has more than 2 neighbours
+    ring = network.make_params(5, 1)[0]
+    assert ring.nb_mask[0] == (1 << 1) | (1 << 4) and ring.deg_gt2_mask == 0
+
+
+def test_other_params_validation():
+    from gym_pomdp_amd.envs import battleship, tag
+    assert battleship.make_params((10, 10), 5)[1:] == (8, 100, 2)
+    assert battleship.make_params((5, 5), 3)[1:] == (2, 25, 2)
+    with pytest.raises(ValueError):
+        battleship.make_params((12, 12), 5)
+    assert tag.make_params()[1:] == (1, 5, 30)
+    with pytest.raises(ValueError):
+        tag.make_params(num_opponents=5)
+    with pytest.raises(ValueError):
+        tag.make_params(board_size=(8, 8))
+
+
+def test_discrete_space_follows_gym_rules():
+    from gym_pomdp_amd.spaces import Discrete
+    d = Discrete(5)
+    assert d.n == 5 and d.contains(0) and d.contains(4) and not d.contains(5) and not d.contains(-1)
+    assert d.contains(np.int64(3)) and d.contains(np.array(2)) and not d.contains(np.array([2]))
+    assert not d.contains(1.0) and not d.contains(np.float32(1)) and not d.contains("1")
+    assert all(0 <= d.sample() < 5 for _ in range(50))
+    assert Discrete(3) == Discrete(3) and Discrete(3) != Discrete(4)
+
+
+def test_registry_and_loud_failure_without_gpu():
+    import torch
+    import gym_pomdp_amd as gpa
+    assert sorted(gpa.registry) == ["Battleship-v0", "Network-v0", "Rock-v0", "Tag-v0", "Tiger-v0"]
+    with pytest.raises(KeyError):
+        gpa.make("Pocman-v0")
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no GPU"):
+            gpa.make("Rock-v0", batch_size=4)
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under gym_pomdp_amd/ may reference it."""
+    pkg = os.path.join(REPO, "gym_pomdp_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(root, f)).read()
+                assert "oracle" not in src.replace("no CPU fallback", ""), os.path.join(root, f)

@@ -1,0 +1,101 @@
+"""Multi-process (gloo, world_size 2) coverage of the N > 1 path on CPU: the shard map, the
+control plane bench.py uses, and the sharding contract itself — two ranks that each advance their
+lane range (keyed by global lane id) reproduce the single-process batch exactly.  The lane
+arithmetic is done by the oracle here; on the GPU box tests/test_gpu_parity.py::test_sharding_invariance
+checks the same property on the HIP path."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from gym_pomdp_amd import sharding
+
+
+def test_shard_range_tiles_exactly():
+    for total in (0, 1, 4, 7, 1000, 1 << 20, (1 << 20) + 12, 65536):
+        for world in (1, 2, 3, 4, 8):
+            pos = 0
+            for r in range(world):
+                off, cnt = sharding.shard_range(total, r, world)
+                assert off == pos and cnt >= 0
+                assert off % sharding.ALIGN == 0
+                pos += cnt
+            assert pos == total
+    sizes = [sharding.shard_range(1 << 20, r, 8)[1] for r in range(8)]
+    assert sizes == [1 << 17] * 8
+    with pytest.raises(ValueError):
+        sharding.shard_range(10, 2, 2)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, total, steps, out_q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from oracle import oracle_lib as ol
+    cp = sharding.ControlPlane()
+    assert cp.world_size == world
+    off, cnt = sharding.shard_range(total, rank, world)
+    o = ol.OracleEnv("rock")
+    st = o.new_state(cnt)
+    o.batch_reset(st, 123, off, 0)
+    rew_sum = 0
+    for t in range(1, steps + 1):
+        a = ol.synthetic_actions(cnt, 77, off, t, o.n_actions)
+        ob, rew, done, _ = o.batch_step(st, a, 123, off, t)
+        rew_sum += int(rew.sum())
+    cp.barrier()
+    # control plane: max of a per-rank "time", sum of a per-rank counter
+    assert cp.max(1.0 + rank) == float(world)
+    assert cp.sum(cnt) == float(total)
+    gathered = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(gathered, torch.tensor([rew_sum], dtype=torch.int64))
+    out_q.put((rank, off, st.copy(), [int(g.item()) for g in gathered]))
+    cp.close()
+
+
+def test_two_rank_shards_equal_single_batch():
+    from oracle import oracle_lib as ol
+    ol.build()
+    total, steps, world = 4096 + 8, 12, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process reference run over the whole batch
+    o = ol.OracleEnv("rock")
+    st = o.new_state(total)
+    o.batch_reset(st, 123, 0, 0)
+    rew_sum = 0
+    for t in range(1, steps + 1):
+        a = ol.synthetic_actions(total, 77, 0, t, o.n_actions)
+        ob, rew, done, _ = o.batch_step(st, a, 123, 0, t)
+        rew_sum += int(rew.sum())
+    joined = np.concatenate([r[2] for r in results], axis=1)
+    assert np.array_equal(joined, st)
+    assert sum(results[0][3]) == rew_sum
+
+
+def test_control_plane_single_process():
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        os.environ.pop(k, None)
+    cp = sharding.ControlPlane()
+    assert cp.world_size == 1 and cp.max(3.5) == 3.5 and cp.sum(2) == 2.0
+    cp.barrier()
+    cp.close()
