@@ -61,7 +61,13 @@ struct RockEnv {
         if (W == 2) state[n + i] = (uint32_t)((uint64_t)st.s >> 32);
     }
 
-    static __device__ __forceinline__ uint32_t rock_code(uint64_t k) { return (k > TWO52) ? 2u : (k < TWO52 ? 0u : 1u); }
+    // status + 1 of a fresh rock from the two words of its double: sign(k53 - 2^52) + 1, in 32-bit ops.
+    // k53 = (w0 >> 5) << 26 | (w1 >> 6): bit 31 of w0 is the 2^52 bit; k53 == 2^52 iff every other kept bit is 0.
+    static __device__ __forceinline__ uint32_t rock_code(uint32_t w0, uint32_t w1)
+    {
+        const uint32_t rest = (w0 & 0x7FFFFFE0u) | (w1 >> 6);
+        return (w0 >> 31) ? (rest ? 2u : 1u) : 0u;
+    }
 
     // rock.py:236-241 reset -> 266-271 _get_init_state -> 78-86 Rock.__init__:
     // status_j = sign(U_j - .5), rocks in index order, one double each.
@@ -72,8 +78,8 @@ struct RockEnv {
         const int K = p.num_rocks;
         for (int b = 0; 2 * b < K; ++b) {
             const uint4 w = stream_block(key, lane, POMDP_STREAM_RESET, (uint32_t)b);
-            s |= (S)rock_code(k53(w.x, w.y)) << (8 + 4 * b);
-            if (2 * b + 1 < K) s |= (S)rock_code(k53(w.z, w.w)) << (10 + 4 * b);
+            s |= (S)rock_code(w.x, w.y) << (8 + 4 * b);
+            if (2 * b + 1 < K) s |= (S)rock_code(w.z, w.w) << (10 + 4 * b);
         }
         st.s = s;
         return 0; // Obs.NULL
@@ -110,8 +116,8 @@ struct RockEnv {
                 uint32_t v = 0;
                 if (tid < ntask) {
                     const uint4 w = stream_block(key, lane - (uint32_t)me + (uint32_t)srcl, POMDP_STREAM_RESET, (uint32_t)b);
-                    const uint32_t cb = (2 * b + 1 < K) ? (rock_code(k53(w.z, w.w)) << 2) : 0u;
-                    v = (rock_code(k53(w.x, w.y)) | cb) << (4 * b);
+                    const uint32_t cb = (2 * b + 1 < K) ? (rock_code(w.z, w.w) << 2) : 0u;
+                    v = (rock_code(w.x, w.y) | cb) << (4 * b);
                 }
                 v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true); // quad_perm [1,0,3,2]
                 v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true); // quad_perm [2,3,0,1]
@@ -129,7 +135,7 @@ struct RockEnv {
                 uint32_t nib = 0;
                 if (tid < ntask) {
                     const uint4 w = stream_block(key, lane - (uint32_t)me + (uint32_t)srcl, POMDP_STREAM_RESET, (uint32_t)b);
-                    nib = rock_code(k53(w.x, w.y)) | ((2 * b + 1 < K) ? (rock_code(k53(w.z, w.w)) << 2) : 0u);
+                    nib = rock_code(w.x, w.y) | ((2 * b + 1 < K) ? (rock_code(w.z, w.w) << 2) : 0u);
                 }
                 for (int bb = 0; bb < NB; ++bb) {                       // wave-uniform trip count
                     const int t = lid * NB + bb - base;
@@ -335,38 +341,49 @@ struct BattleShipEnv {
     }
 
     // battleship.py:131-137 reset, 167-180 _get_init_state, 195-211 collision, 182-193 mark_ship,
-    // coord.py:122-123 Grid.sample, battleship.py:33-37 Ship.__init__ (position word(s) before direction word)
+    // coord.py:122-123 Grid.sample, battleship.py:33-37 Ship.__init__ (position word(s) before direction word).
+    //
+    // The reference's collision() walks L+1 cells from pos and, for each, looks at the cell itself and
+    // its N, E, S, W, NE, SE, SW neighbours (Compass[0..7]; NW is never looked at).  Here that is one
+    // AND of two 128-bit masks: `blocked` = every cell that has an occupied cell in that 8-neighbourhood
+    // (7 shifted copies of the occupancy mask, column-wrap guarded), against the L+1 ship cells; the
+    // "pos + dir stays inside for i = 0..L" test reduces to the far end pos + (L+1) dir being inside.
+    typedef unsigned __int128 u128;
     static __device__ __forceinline__ int reset(const Shared &, const Params &p, State &st, const RngKey &key,
                                                 uint32_t lane)
     {
-#pragma unroll
-        for (int j = 0; j < MW; ++j) { st.occ[j] = 0u; st.vis[j] = 0u; }
         WordStream ws(key, lane, POMDP_STREAM_RESET);
         const int X = p.x_size, Y = p.y_size;
+        u128 col0 = 0;                                     // cells with x == 0
+        for (int y = 0; y < Y; ++y) col0 |= (u128)1 << (y * X);
+        const u128 colL = col0 << (X - 1);                 // cells with x == X - 1
+        u128 occ = 0;
         int remaining = 0;
         for (int len = p.max_len; len >= 2; --len) {
-            int px, py, dx, dy;
+            const u128 e = occ & ~col0, w = occ & ~colL;   // sources that may shift one column west / east
+            const u128 blocked = occ | (occ >> X) | (occ << X) | (e >> 1) | (w << 1) | (e >> (X + 1)) | (e << (X - 1)) |
+                                 (w << (X + 1));
+            int a0, dx, dy;
             for (;;) {
-                const int idx = (int)ws.randint((uint32_t)(X * Y));
+                a0 = (int)ws.randint((uint32_t)(X * Y));
                 const uint32_t dir = ws.randint(4u);
-                px = idx % X; py = idx / X;
-                dx = (dir == 1u) - (dir == 3u); dy = (dir == 0u) - (dir == 2u); // Compass N E S W
-                bool hit = false;
-                int cx = px, cy = py;
-                for (int i = 0; i <= len && !hit; ++i) {
-                    const int nx = cx + dx, ny = cy + dy;
-                    if (!((unsigned)nx < (unsigned)X && (unsigned)ny < (unsigned)Y)) { hit = true; break; }
-                    // the cell itself (Compass.Null) and N, E, S, W, NE, SE, SW — NW is never looked at
-                    hit = occupied(p, st, cx, cy) || occupied(p, st, cx, cy + 1) || occupied(p, st, cx + 1, cy) ||
-                          occupied(p, st, cx, cy - 1) || occupied(p, st, cx - 1, cy) || occupied(p, st, cx + 1, cy + 1) ||
-                          occupied(p, st, cx + 1, cy - 1) || occupied(p, st, cx - 1, cy - 1);
-                    cx = nx; cy = ny;
-                }
-                if (!hit) break;
+                dx = (dir == 1u) - (dir == 3u); dy = (dir == 0u) - (dir == 2u);   // Compass N E S W
+                const int px = a0 % X, py = a0 / X;
+                const int ex = px + (len + 1) * dx, ey = py + (len + 1) * dy;
+                if (!((unsigned)ex < (unsigned)X && (unsigned)ey < (unsigned)Y)) continue;
+                const int stride = dy * X + dx;                                   // bit distance between ship cells
+                const int lo = stride > 0 ? a0 : a0 + len * stride;               // lowest bit of the L+1 checked cells
+                const int gap = stride > 0 ? stride : -stride;
+                u128 cells = 0;
+                for (int i = 0; i <= len; ++i) cells |= (u128)1 << (lo + i * gap);
+                if ((cells & blocked) == 0) break;
             }
-            for (int i = 0; i < len; ++i) { set_bit(st.occ, py * X + px); px += dx; py += dy; }
+            const int stride = dy * X + dx;
+            for (int i = 0; i < len; ++i) occ |= (u128)1 << (a0 + i * stride);     // mark_ship: L cells from pos
             remaining += len;
         }
+#pragma unroll
+        for (int j = 0; j < MW; ++j) { st.occ[j] = (uint32_t)(occ >> (32 * j)); st.vis[j] = 0u; }
         st.vis[MW - 1] = (uint32_t)remaining << 26;
         return 0;
     }
@@ -472,7 +489,10 @@ struct NetworkEnv {
     {
         if (fresh) reset(sh, p, st, key, lane);
     }
-    // network.py:71-114
+    // network.py:71-114.  The reference draws one double per *up* machine in index order, then one for
+    // the action.  Lanes iterate over the draws (j = 0, 1, ...), not over the machines: j is
+    // wave-uniform, so the Philox block that feeds doubles 2q and 2q+1 is generated under a uniform
+    // condition and the only divergence left is the per-lane number of up machines.
     static __device__ __forceinline__ void step(const Shared &, const Params &p, State &st, int a,
                                                 const RngKey &key, uint32_t lane, int &ob, Reward &rew, int &done)
     {
@@ -481,19 +501,29 @@ struct NetworkEnv {
         const int M = p.n_machines;
         // reward: 2 per up machine with > 2 neighbours, 1 per other up machine   network.py:87-92
         double r = (double)(__popc(s0) + __popc(s0 & p.deg_gt2_mask));
-        WordStream ws(key, lane, POMDP_STREAM_STEP);
-        for (int i = 0; i < M; ++i) {                                            // network.py:82-85, 94-99
-            if ((s0 >> i) & 1u) {
-                const bool nb_failed = (~s0 & p.nb_mask[i]) != 0u;               // from the pre-update state
-                const uint64_t k = ws.next_k53();
-                if (k > (nb_failed ? p.fail_nb_thr : p.fail_thr)) s &= ~(1u << i);
+        // machines whose neighbourhood has a failure, from the pre-update state    network.py:82-85
+        uint32_t nb_failed = 0;
+        for (int i = 0; i < M; ++i) nb_failed |= ((~s0 & p.nb_mask[i]) != 0u ? 1u : 0u) << i;
+        const bool has_action = a < 2 * M;
+        const int n_draws = __popc(s0) + (has_action ? 1 : 0);
+        uint32_t todo = s0;
+        uint4 blk = make_uint4(0, 0, 0, 0);
+        uint64_t k_action = 0;
+        for (int j = 0; __any(j < n_draws); ++j) {
+            if ((j & 1) == 0) blk = stream_block(key, lane, POMDP_STREAM_STEP, (uint32_t)(j >> 1));
+            const uint64_t k = (j & 1) ? k53(blk.z, blk.w) : k53(blk.x, blk.y);
+            if (todo != 0u) {                                                    // network.py:94-99
+                const int i = __ffs((int)todo) - 1;
+                todo &= todo - 1u;
+                if (k > (((nb_failed >> i) & 1u) ? p.fail_nb_thr : p.fail_thr)) s &= ~(1u << i);
+            } else if (j < n_draws) {
+                k_action = k;
             }
         }
         ob = 2;
-        if (a < 2 * M) {                                                         // network.py:101-112
+        if (has_action) {                                                        // network.py:101-112
             const int machine = a >> 1;
-            const uint64_t k = ws.next_k53();
-            const int truthful = k <= p.obs_thr;
+            const int truthful = k_action <= p.obs_thr;
             if (a & 1) { r -= 2.5; s |= 1u << machine; ob = truthful; }
             else { r -= .1; const int up = (int)((s >> machine) & 1u); ob = truthful ? up : 1 - up; }
         }

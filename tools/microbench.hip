@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <chrono>
 
 using namespace pomdp;
 
@@ -125,6 +126,28 @@ int main(int argc, char **argv)
         run(RockEnv<1, 3>{}, "step -checkphilox -reset");
         run(RockEnv<1, 4>{}, "step -lds");
         run(RockEnv<1, 7>{}, "step -all");
+    }
+    {   // split the batch over S streams: policy + step per part, parts are independent
+        for (int S : {1, 2, 4}) {
+            std::vector<hipStream_t> st(S);
+            for (auto &x : st) CK(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
+            const int64_t part = n / S;
+            hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+            auto body = [&](int t) {
+                for (int k = 0; k < S; ++k) {
+                    pomdp_synthetic_actions(action + k * part, part, 2, (uint32_t)(k * part), t, 13, st[k]);
+                    pomdp_rock_step(&p, state + k * part, action + k * part, ob + k * part, reward + k * part, done + k * part, err, part, 1, (uint32_t)(k * part), t, 1, st[k]);
+                }
+            };
+            for (int i = 0; i < 10; ++i) body(i);
+            CK(hipDeviceSynchronize());
+            auto t0 = std::chrono::high_resolution_clock::now();
+            for (int i = 0; i < iters; ++i) body(100 + i);
+            CK(hipDeviceSynchronize());
+            auto t1 = std::chrono::high_resolution_clock::now();
+            printf("policy+step over %d stream(s): %8.2f us/step\n", S, std::chrono::duration<double, std::micro>(t1 - t0).count() / iters);
+            for (auto &x : st) CK(hipStreamDestroy(x));
+        }
     }
     printf("rock reset                  : %8.2f\n", time_it([&](int t) { pomdp_rock_reset(&p, state, ob, n, 1, 0, t, nullptr); }, iters));
     return 0;
