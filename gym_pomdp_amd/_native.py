@@ -16,6 +16,7 @@ HEADER = os.path.join(_REPO, "include", "pomdp_hip.h")
 ABI_VERSION = 1
 
 POMDP_AUTO_RESET = 1
+POMDP_ROLLOUT_ALL_ACTIONS = 1
 ENV_KIND = {"rock": 0, "tag": 1, "battleship": 2, "tiger": 3, "network": 4}
 
 # every symbol include/pomdp_hip.h declares
@@ -24,7 +25,7 @@ SYMBOLS = [
     "pomdp_rock_reset", "pomdp_rock_step", "pomdp_tag_reset", "pomdp_tag_step",
     "pomdp_battleship_reset", "pomdp_battleship_step", "pomdp_tiger_reset", "pomdp_tiger_step",
     "pomdp_network_reset", "pomdp_network_step", "pomdp_synthetic_actions", "pomdp_philox_blocks",
-    "pomdp_rollout_synthetic",
+    "pomdp_rollout_synthetic", "pomdp_legal_actions", "pomdp_rollout",
 ]
 
 
@@ -62,7 +63,7 @@ def build(force=False, verbose=False):
             and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps)):
         return LIB_PATH
     os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC",
            "-o", LIB_PATH, SOURCES[0]]
     if verbose:
         print(" ".join(cmd))
@@ -103,6 +104,10 @@ def lib():
     L.pomdp_synthetic_actions.argtypes = [vp, i64, u64, u32, u64, u32, vp]
     L.pomdp_rollout_synthetic.restype = ci
     L.pomdp_rollout_synthetic.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, i64, u64, u64, u32, u64, i64, ci, vp]
+    L.pomdp_legal_actions.restype = ci
+    L.pomdp_legal_actions.argtypes = [ci, vp, vp, vp, vp, i64, ci, vp]
+    L.pomdp_rollout.restype = ci
+    L.pomdp_rollout.argtypes = [ci, vp, vp, i64, i64, ci, C.c_double, ci, u64, u32, u64, vp, vp, vp, vp, vp, vp]
     L.pomdp_philox_blocks.restype = ci
     L.pomdp_philox_blocks.argtypes = [vp, vp, i64, vp]
     _lib = L

@@ -147,11 +147,46 @@ struct RockEnv {
         if (fresh) st.s = (S)((uint64_t)((uint32_t)p.start_x | ((uint32_t)p.start_y << 4)) | bits);
     }
 
+    // rock.py:273-291 _generate_legal, in the reference's list order: EAST, then NORTH / SOUTH / WEST when
+    // in-grid, SAMPLE on an uncollected rock, then CHECK(grid[rock.pos]) per uncollected rock (rock order;
+    // RockSample(15,15)'s duplicated coordinate makes CHECK 3 appear twice — kept, it weights the draw).
+    static __device__ __forceinline__ int legal_count(const Shared &sh, const Params &p, const State &st, uint32_t &pre,
+                                                      int &n_pre, uint32_t &alive)
+    {
+        const S s = st.s;
+        const int x = (int)(s & 15u), y = (int)((s >> 4) & 15u), K = p.num_rocks;
+        pre = 1u; n_pre = 1;                                                     // 3 bits per entry
+        if (y + 1 < p.size) { pre |= 0u << (3 * n_pre); ++n_pre; }
+        if (y - 1 >= 0) { pre |= 2u << (3 * n_pre); ++n_pre; }
+        if (x - 1 >= 0) { pre |= 3u << (3 * n_pre); ++n_pre; }
+        const int id = sh.grid[x * 16 + y];
+        if (id >= 0 && id < K && ((uint32_t)(s >> (8 + 2 * (id & 15))) & 3u) != 1u) { pre |= 4u << (3 * n_pre); ++n_pre; }
+        alive = 0;
+        for (int j = 0; j < K; ++j) alive |= ((((uint32_t)(s >> (8 + 2 * j)) & 3u) != 1u) ? 1u : 0u) << j;
+        return n_pre + __popc(alive);
+    }
+    static __device__ __forceinline__ int legal_nth(const Shared &sh, const Params &p, const State &st, int idx)
+    {
+        uint32_t pre, alive; int n_pre;
+        legal_count(sh, p, st, pre, n_pre, alive);
+        if (idx < n_pre) return (int)((pre >> (3 * idx)) & 7u);
+        for (int k = idx - n_pre; k > 0; --k) alive &= alive - 1u;               // drop the k lowest set bits
+        const int j = __ffs((int)alive) - 1;
+        const uint32_t rxy = sh.rxy[j & 15];
+        return 5 + sh.grid[(rxy & 15u) * 16 + (rxy >> 4)];
+    }
+    static __device__ __forceinline__ int legal_count(const Shared &sh, const Params &p, const State &st)
+    {
+        uint32_t pre, alive; int n_pre;
+        return legal_count(sh, p, st, pre, n_pre, alive);
+    }
+
     // rock.py:123-194 step; 401-407 _sample_ob; 383-387 _efficiency; coord.py:133-135 (L1 distance).
     // Branch-free: the three action classes (move / SAMPLE / CHECK) are all evaluated and selected,
     // so a wave with mixed actions — every wave, under a random policy — runs one straight line.
+    template <class RT>
     static __device__ __forceinline__ void step(const Shared &sh, const Params &p, State &st, int a,
-                                                const RngKey &key, uint32_t lane, int &ob, Reward &rew, int &done)
+                                                const RngKey &key, uint32_t lane, int &ob, RT &rew, int &done)
     {
         const S s = st.s;
         const int x = (int)(s & 15u), y = (int)((s >> 4) & 15u);
@@ -245,9 +280,14 @@ struct TagEnv {
         if (fresh) reset(sh, p, st, key, lane);
     }
 
+    // tag.py:228-229: every action is legal
+    static __device__ __forceinline__ int legal_count(const Shared &, const Params &p, const State &) { return n_actions(p); }
+    static __device__ __forceinline__ int legal_nth(const Shared &, const Params &, const State &, int idx) { return idx; }
+
     // tag.py:108-143 step, 201-207 move_opponent, 260-280 _admissable_actions
+    template <class RT>
     static __device__ __forceinline__ void step(const Shared &, const Params &p, State &st, int a,
-                                                const RngKey &key, uint32_t lane, int &ob, Reward &rew, int &done)
+                                                const RngKey &key, uint32_t lane, int &ob, RT &rew, int &done)
     {
         uint32_t w = st.w;
         const int agent = (int)(w & 31u);
@@ -395,9 +435,40 @@ struct BattleShipEnv {
         if (fresh) reset(sh, p, st, key, lane);
     }
 
+    // battleship.py:157-165 _generate_legal: the unvisited cells, ascending
+    static __device__ __forceinline__ uint32_t unvisited(const Params &p, const State &st, int j)
+    {
+        const int cells = p.x_size * p.y_size, lo = 32 * j;
+        const uint32_t valid = cells - lo >= 32 ? 0xFFFFFFFFu : (cells > lo ? (1u << (cells - lo)) - 1u : 0u);
+        return ~st.vis[j] & valid;
+    }
+    static __device__ __forceinline__ int legal_count(const Shared &, const Params &p, const State &st)
+    {
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < MW; ++j) c += __popc(unvisited(p, st, j));
+        return c;
+    }
+    static __device__ __forceinline__ int legal_nth(const Shared &, const Params &p, const State &st, int idx)
+    {
+        int a = 0;
+#pragma unroll
+        for (int j = 0; j < MW; ++j) {
+            uint32_t z = unvisited(p, st, j);
+            const int c = __popc(z);
+            if (idx >= 0 && idx < c) {
+                for (int k = idx; k > 0; --k) z &= z - 1u;
+                a = 32 * j + __ffs((int)z) - 1;
+            }
+            idx -= c;
+        }
+        return a;
+    }
+
     // battleship.py:91-122
+    template <class RT>
     static __device__ __forceinline__ void step(const Shared &, const Params &p, State &st, int a,
-                                                const RngKey &, uint32_t, int &ob, Reward &rew, int &done)
+                                                const RngKey &, uint32_t, int &ob, RT &rew, int &done)
     {
         int remaining = (int)(st.vis[MW - 1] >> 26);
         ob = 0; done = 0;
@@ -441,9 +512,14 @@ struct TigerEnv {
     {
         if (fresh) reset(sh, p, st, key, lane);
     }
+    // tiger.py:111-112: every action is legal
+    static __device__ __forceinline__ int legal_count(const Shared &, const Params &p, const State &) { return n_actions(p); }
+    static __device__ __forceinline__ int legal_nth(const Shared &, const Params &, const State &, int idx) { return idx; }
+
     // tiger.py:72-88 step, 117-119 _sample_state, 140-149 _sample_ob, 155-172
+    template <class RT>
     static __device__ __forceinline__ void step(const Shared &, const Params &p, State &st, int a,
-                                                const RngKey &key, uint32_t lane, int &ob, Reward &rew, int &done)
+                                                const RngKey &key, uint32_t lane, int &ob, RT &rew, int &done)
     {
         const int tiger = (int)(st.w & 1u);
         if (a != 2 && a == tiger) { ob = tiger; rew = -20; done = 1; return; } // terminal: ob is the state
@@ -489,12 +565,17 @@ struct NetworkEnv {
     {
         if (fresh) reset(sh, p, st, key, lane);
     }
+    // network.py:130-131: every action is legal
+    static __device__ __forceinline__ int legal_count(const Shared &, const Params &p, const State &) { return n_actions(p); }
+    static __device__ __forceinline__ int legal_nth(const Shared &, const Params &, const State &, int idx) { return idx; }
+
     // network.py:71-114.  The reference draws one double per *up* machine in index order, then one for
     // the action.  Lanes iterate over the draws (j = 0, 1, ...), not over the machines: j is
     // wave-uniform, so the Philox block that feeds doubles 2q and 2q+1 is generated under a uniform
     // condition and the only divergence left is the per-lane number of up machines.
+    template <class RT>
     static __device__ __forceinline__ void step(const Shared &, const Params &p, State &st, int a,
-                                                const RngKey &key, uint32_t lane, int &ob, Reward &rew, int &done)
+                                                const RngKey &key, uint32_t lane, int &ob, RT &rew, int &done)
     {
         const uint32_t s0 = st.w;
         uint32_t s = s0;
@@ -527,7 +608,7 @@ struct NetworkEnv {
             if (a & 1) { r -= 2.5; s |= 1u << machine; ob = truthful; }
             else { r -= .1; const int up = (int)((s >> machine) & 1u); ob = truthful ? up : 1 - up; }
         }
-        rew = (float)r;
+        rew = (RT)r;    // float32(float64 value) for the step kernel, the float64 itself for rollouts
         done = 0;
         st.w = s;
     }

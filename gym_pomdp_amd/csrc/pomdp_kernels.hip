@@ -109,6 +109,85 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const typename Env::Params 
 }
 
 // ---------------------------------------------------------------------------
+// planner hooks: _generate_legal and random rollouts
+// ---------------------------------------------------------------------------
+template <class Env>
+__global__ __launch_bounds__(BLOCK) void legal_kernel(const typename Env::Params p, const uint32_t *__restrict__ state,
+                                                      int32_t *__restrict__ list, int32_t *__restrict__ len, int64_t n,
+                                                      int stride)
+{
+    __shared__ typename Env::Shared sh;
+    Env::stage(sh, p, (int)threadIdx.x);
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    typename Env::State st;
+    Env::load(st, state, n, i);
+    const int c = Env::legal_count(sh, p, st);
+    len[i] = c;
+    for (int k = 0; k < stride; ++k) list[i * stride + k] = k < c ? Env::legal_nth(sh, p, st, k) : -1;
+}
+
+// Lane i simulates from root state column i / sims_per_root for up to `depth` steps: the state lives
+// in registers, the policy draw (stream ROLLOUT) and the env draws (stream STEP) come from the lane's
+// own Philox streams at t0 + k, the discounted return accumulates in IEEE double with separate
+// multiply and add (so a CPU restatement reproduces it bit-for-bit), nothing is written but the per-lane results.
+template <class Env>
+__global__ __launch_bounds__(BLOCK) void rollout_kernel(const typename Env::Params p, const uint32_t *__restrict__ state,
+                                                        int64_t n_roots, int64_t sims_per_root, int depth,
+                                                        double discount, int all_actions, RngKey key0, uint32_t lane0,
+                                                        double *__restrict__ ret, int32_t *__restrict__ n_steps,
+                                                        int32_t *__restrict__ first_action, int32_t *__restrict__ last_ob,
+                                                        uint8_t *__restrict__ terminated)
+{
+#pragma clang fp contract(off) // the discounted return must not be fused into FMAs (hipcc defaults to contract=fast)
+    __shared__ typename Env::Shared sh;
+    Env::stage(sh, p, (int)threadIdx.x);
+    __syncthreads();
+    const int64_t n = n_roots * sims_per_root;
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const bool in_range = i < n;
+    const int64_t ic = in_range ? i : n - 1;
+    typename Env::State st;
+    Env::load(st, state, n_roots, ic / sims_per_root);
+    const uint32_t lane = lane0 + (uint32_t)i;
+    const int n_act = Env::n_actions(p);
+    double acc = 0.0, disc = 1.0;
+    int k = 0, d = 0, o = 0, first = -1;
+    bool active = in_range;
+    uint64_t t = ((uint64_t)key0.t_hi << 32) | key0.t_lo;
+    for (int step = 0; step < depth; ++step, ++t) {
+        const int count = all_actions ? n_act : Env::legal_count(sh, p, st);
+        active = active && !d && count > 0;
+        if (!__any(active)) break;                                   // wave-uniform exit
+        RngKey key = key0;
+        key.t_lo = (uint32_t)t; key.t_hi = (uint32_t)(t >> 32);
+        const uint32_t w = stream_block(key, lane, POMDP_STREAM_ROLLOUT, 0u).x;
+        const int idx = (int)__umulhi(w, (uint32_t)(count > 0 ? count : 1));
+        const int a = all_actions ? idx : Env::legal_nth(sh, p, st, idx);
+        typename Env::State nx = st;
+        int o2, d2;
+        double r;
+        Env::step(sh, p, nx, a, key, lane, o2, r, d2);               // every lane runs it; inactive lanes discard
+        if (active) {
+            st = nx; o = o2; d = d2;
+            if (step == 0) first = a;
+            const double term = disc * r;
+            acc = acc + term;
+            disc = disc * discount;
+            k = step + 1;
+        }
+    }
+    if (in_range) {
+        ret[i] = acc;
+        n_steps[i] = k;
+        first_action[i] = first;
+        last_ob[i] = o;
+        terminated[i] = (uint8_t)d;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // helpers
 // ---------------------------------------------------------------------------
 // one thread = four consecutive lanes = one Philox block = one 16-byte store
@@ -181,9 +260,71 @@ static int bs_mask_words(const pomdp_battleship_params *p)
     return (cells + 6 + 31) / 32;
 }
 
+template <class Env>
+static int launch_legal(const typename Env::Params &p, const uint32_t *state, int32_t *list, int32_t *len, int64_t n,
+                        int stride, void *stream)
+{
+    if (!state || !list || !len || n < 0 || stride < 1) return POMDP_E_BADARG;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(legal_kernel<Env>, dim3(blocks_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, p, state, list, len,
+                       n, stride);
+    return (int)hipGetLastError();
+}
+template <class Env>
+static int launch_rollout(const typename Env::Params &p, const uint32_t *state, int64_t n_roots, int64_t sims,
+                          int depth, double discount, int flags, uint64_t seed, uint32_t lane0, uint64_t t0, double *ret,
+                          int32_t *n_steps, int32_t *first_action, int32_t *last_ob, uint8_t *terminated, void *stream)
+{
+    if (!state || !ret || !n_steps || !first_action || !last_ob || !terminated || n_roots < 0 || sims < 1 || depth < 0 ||
+        bad_range(n_roots * sims, lane0))
+        return POMDP_E_BADARG;
+    const int64_t n = n_roots * sims;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(rollout_kernel<Env>, dim3(blocks_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, p, state, n_roots,
+                       sims, depth, discount, (flags & POMDP_ROLLOUT_ALL_ACTIONS) ? 1 : 0, make_key(seed, t0), lane0, ret,
+                       n_steps, first_action, last_ob, terminated);
+    return (int)hipGetLastError();
+}
 } // namespace pomdp
 
 using namespace pomdp;
+
+// dispatch on (env kind, params) to the kernel instantiation; F is a generic lambda taking a tag type
+#define POMDP_DISPATCH(env, params, CALL)                                                                              \
+    switch (env) {                                                                                                     \
+    case POMDP_ENV_ROCK: {                                                                                             \
+        const pomdp_rock_params *p = (const pomdp_rock_params *)(params);                                              \
+        if (!rock_ok(p)) return POMDP_E_BADPARAMS;                                                                     \
+        if (p->num_rocks <= 12) { using E = RockEnv<1>; CALL; } else { using E = RockEnv<2>; CALL; }                     \
+    }                                                                                                                  \
+    case POMDP_ENV_TAG: {                                                                                              \
+        const pomdp_tag_params *p = (const pomdp_tag_params *)(params);                                                \
+        if (p->num_opponents < 1 || p->num_opponents > 4) return POMDP_E_BADPARAMS;                                    \
+        using E = TagEnv; CALL;                                                                                        \
+    }                                                                                                                  \
+    case POMDP_ENV_BATTLESHIP: {                                                                                       \
+        const pomdp_battleship_params *p = (const pomdp_battleship_params *)(params);                                  \
+        switch (bs_mask_words(p)) {                                                                                    \
+        case 1: { using E = BattleShipEnv<1>; CALL; }                                                                  \
+        case 2: { using E = BattleShipEnv<2>; CALL; }                                                                  \
+        case 3: { using E = BattleShipEnv<3>; CALL; }                                                                  \
+        case 4: { using E = BattleShipEnv<4>; CALL; }                                                                  \
+        default: return POMDP_E_BADPARAMS;                                                                             \
+        }                                                                                                              \
+    }                                                                                                                  \
+    case POMDP_ENV_TIGER: {                                                                                            \
+        const pomdp_tiger_params *p = (const pomdp_tiger_params *)(params);                                            \
+        using E = TigerEnv; CALL;                                                                                      \
+    }                                                                                                                  \
+    case POMDP_ENV_NETWORK: {                                                                                          \
+        const pomdp_network_params *p = (const pomdp_network_params *)(params);                                        \
+        if (p->n_machines < 1 || p->n_machines > 32) return POMDP_E_BADPARAMS;                                         \
+        using E = NetworkEnv; CALL;                                                                                    \
+    }                                                                                                                  \
+    default: return POMDP_E_BADARG;                                                                                    \
+    }
+
+
 
 extern "C" {
 
@@ -343,6 +484,23 @@ int pomdp_rollout_synthetic(int env, const void *params, uint32_t *state, int32_
         if (rc) return rc;
     }
     return 0;
+}
+
+int pomdp_legal_actions(int env, const void *params, const uint32_t *state, int32_t *list, int32_t *len, int64_t n,
+                        int stride, void *stream)
+{
+    if (!params) return POMDP_E_BADARG;
+    POMDP_DISPATCH(env, params, return launch_legal<E>(*p, state, list, len, n, stride, stream))
+}
+
+int pomdp_rollout(int env, const void *params, const uint32_t *root_state, int64_t n_roots, int64_t sims_per_root,
+                  int depth, double discount, int flags, uint64_t seed, uint32_t lane0, uint64_t t0, double *ret,
+                  int32_t *n_steps, int32_t *first_action, int32_t *last_ob, uint8_t *terminated, void *stream)
+{
+    if (!params) return POMDP_E_BADARG;
+    POMDP_DISPATCH(env, params, return launch_rollout<E>(*p, root_state, n_roots, sims_per_root, depth, discount, flags,
+                                                         seed, lane0, t0, ret, n_steps, first_action, last_ob,
+                                                         terminated, stream))
 }
 
 int pomdp_philox_blocks(const uint32_t *ctr_key, uint32_t *out, int64_t n_blocks, void *stream)

@@ -210,6 +210,71 @@ class BatchedEnv(object):
             _native.check(rc, "pomdp_synthetic_actions")
         return out
 
+    # ---- planner hooks (reference: _get_init_state / _set_state / _generate_legal / _discount) --------
+    def _get_init_state(self):
+        """A fresh batch of initial states (packed int32 [state_words, N]) without touching the live
+        state — the reference's `_get_init_state()` (rock.py:266-271 etc.).  Advances the call counter."""
+        t = self._t
+        self._t += 1
+        out = torch.empty_like(self._state)
+        with torch.cuda.device(self.device):
+            rc = self._reset_fn(self._params_ref, out.data_ptr(), None, self.batch_size, self._seed,
+                                self.lane_offset, t, self._stream())
+            _native.check(rc, "pomdp_%s_reset" % self.env_name)
+        return out
+
+    def legal_actions(self, state=None):
+        """`_generate_legal()` of every lane: (list int32 [N, n_actions] in the reference's order, padded
+        with -1; length int32 [N]).  `state` defaults to the live state."""
+        st = self._state if state is None else torch.as_tensor(state, dtype=torch.int32, device=self.device)
+        st = st.reshape(self.state_words, -1).contiguous()
+        n = st.shape[1]
+        stride = self.action_space.n
+        lst = torch.empty((n, stride), dtype=torch.int32, device=self.device)
+        ln = torch.empty(n, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self._lib.pomdp_legal_actions(_native.ENV_KIND[self.env_name], self._params_ref, st.data_ptr(),
+                                               lst.data_ptr(), ln.data_ptr(), n, stride, self._stream())
+            _native.check(rc, "pomdp_legal_actions")
+        return lst, ln
+
+    def _generate_legal(self):
+        """batch_size == 1: the reference's python list; otherwise the (list, length) tensors."""
+        lst, ln = self.legal_actions()
+        if self.batch_size == 1:
+            return lst[0, : int(ln.item())].tolist()
+        return lst, ln
+
+    def rollout(self, depth, sims_per_root=1, roots=None, discount=None, all_actions=False, lane_offset=None):
+        """Random rollouts from `roots` (packed states int32 [state_words, R]; default: the live state):
+        R * sims_per_root independent simulations of at most `depth` steps under a uniform policy over
+        `_generate_legal()` (or over all actions), discounted by `discount` (default: the env's
+        `_discount`).  Neither `roots` nor the live state is modified; the call counter advances by
+        `depth`.  Returns a dict of per-simulation tensors: ret float64, n_steps, first_action, last_ob
+        int32, terminated bool — simulation i belongs to root i // sims_per_root."""
+        st = self._state if roots is None else torch.as_tensor(roots, dtype=torch.int32, device=self.device)
+        st = st.reshape(self.state_words, -1).contiguous()
+        n_roots = st.shape[1]
+        n = n_roots * int(sims_per_root)
+        t0 = self._t
+        self._t += int(depth)
+        out = dict(ret=torch.empty(n, dtype=torch.float64, device=self.device),
+                   n_steps=torch.empty(n, dtype=torch.int32, device=self.device),
+                   first_action=torch.empty(n, dtype=torch.int32, device=self.device),
+                   last_ob=torch.empty(n, dtype=torch.int32, device=self.device),
+                   terminated=torch.empty(n, dtype=torch.uint8, device=self.device))
+        with torch.cuda.device(self.device):
+            rc = self._lib.pomdp_rollout(
+                _native.ENV_KIND[self.env_name], self._params_ref, st.data_ptr(), n_roots, int(sims_per_root),
+                int(depth), float(self._discount if discount is None else discount),
+                _native.POMDP_ROLLOUT_ALL_ACTIONS if all_actions else 0, self._seed,
+                self.lane_offset if lane_offset is None else int(lane_offset), t0, out["ret"].data_ptr(),
+                out["n_steps"].data_ptr(), out["first_action"].data_ptr(), out["last_ob"].data_ptr(),
+                out["terminated"].data_ptr(), self._stream())
+            _native.check(rc, "pomdp_rollout")
+        out["terminated"] = out["terminated"].view(torch.bool)
+        return out
+
     def rollout_synthetic(self, steps, action_seed=None, actions=None):
         """`steps` consecutive step() calls under the synthetic uniform policy, issued from C
         (pomdp_rollout_synthetic): the same two launches per step a python loop over

@@ -51,7 +51,10 @@ enum {
 
 /* id of the word streams of one (seed, lane, t) */
 enum { POMDP_STREAM_STEP = 0, POMDP_STREAM_RESET = 1, POMDP_STREAM_STEP_SPACE = 2,
-       POMDP_STREAM_RESET_SPACE = 3, POMDP_STREAM_ACTION = 4 };
+       POMDP_STREAM_RESET_SPACE = 3, POMDP_STREAM_ACTION = 4, POMDP_STREAM_ROLLOUT = 5 };
+
+/* env kinds for the generic entry points */
+enum { POMDP_ENV_ROCK = 0, POMDP_ENV_TAG = 1, POMDP_ENV_BATTLESHIP = 2, POMDP_ENV_TIGER = 3, POMDP_ENV_NETWORK = 4 };
 
 /* ---- RockSample  (rock.py:96-407) ---------------------------------------- */
 /* state words: 1 if num_rocks <= 12 else 2.  64-bit view s = w0 | w1 << 32:
@@ -156,11 +159,31 @@ int pomdp_philox_blocks(const uint32_t *ctr_key, uint32_t *out, int64_t n_blocks
  * the launches a host loop over step() would issue (2 per step), minus the host language's per-call
  * overhead; the caller's call counter advances by k_steps.  `params` points at the env's
  * pomdp_<env>_params; `reward` is int32 or float per env.  n and lane0 must be multiples of 4. */
-enum { POMDP_ENV_ROCK = 0, POMDP_ENV_TAG = 1, POMDP_ENV_BATTLESHIP = 2, POMDP_ENV_TIGER = 3, POMDP_ENV_NETWORK = 4 };
 int pomdp_rollout_synthetic(int env, const void *params, uint32_t *state, int32_t *action, int32_t *ob,
                             void *reward, uint8_t *done, uint32_t *err, int64_t n, uint64_t seed,
                             uint64_t action_seed, uint32_t lane0, uint64_t t0, int64_t k_steps, int flags,
                             void *stream);
+
+/* ---- planner hooks ------------------------------------- */
+/* replaces <Env>._generate_legal (rock.py:273-291, tag.py:228-229, battleship.py:157-165, tiger.py:111-112,
+ * network.py:130-131): list (device, int32 [n][stride], stride >= the env's action count) receives each
+ * lane's legal actions in the reference's list order, padded with -1; len (device, int32 [n]) their number. */
+int pomdp_legal_actions(int env, const void *params, const uint32_t *state, int32_t *list, int32_t *len,
+                        int64_t n, int stride, void *stream);
+
+/* Random rollouts — the simulations a POMCP-style planner runs through _set_state / _generate_legal /
+ * step / _discount.  Lane i (global id lane0 + i, i < n_roots * sims_per_root) starts from
+ * root_state column i / sims_per_root (uint32 [words][n_roots], read-only) and for k = 0 .. depth-1, while
+ * not done:  list = _generate_legal() (all actions with POMDP_ROLLOUT_ALL_ACTIONS);
+ *            a = list[(w * len(list)) >> 32], w = first word of stream ROLLOUT at (seed, lane, t0 + k);
+ *            (ob, r, done) = step(a) on stream STEP at (seed, lane, t0 + k);  ret += disc * r;  disc *= discount.
+ * The return accumulates in IEEE double (separate multiply and add).  Per-lane outputs (device):
+ * ret double[n], n_steps / first_action / last_ob int32[n], terminated uint8[n]. */
+enum { POMDP_ROLLOUT_ALL_ACTIONS = 1 };
+int pomdp_rollout(int env, const void *params, const uint32_t *root_state, int64_t n_roots, int64_t sims_per_root,
+                  int depth, double discount, int flags, uint64_t seed, uint32_t lane0, uint64_t t0,
+                  double *ret, int32_t *n_steps, int32_t *first_action, int32_t *last_ob, uint8_t *terminated,
+                  void *stream);
 
 int         pomdp_abi_version(void);
 const char *pomdp_error_string(int code);

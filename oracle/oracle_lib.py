@@ -45,6 +45,9 @@ def lib():
                                     C.c_int, C.c_int]
         L.or_batch_compact.argtypes = [vp, vp, vp, C.c_int64]
         L.or_synthetic_actions.argtypes = [vp, C.c_int64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.c_int]
+        L.or_batch_legal.argtypes = [vp, vp, vp, vp, C.c_int64]
+        L.or_batch_rollout.argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_int, C.c_double, C.c_int, C.c_uint64,
+                                       C.c_uint32, C.c_uint64, vp, vp, vp, vp, vp, C.c_int]
         L.or_max_threads.restype = C.c_int
         L.or_philox4x32_10.argtypes = [vp, vp, vp]
         _lib = L
@@ -136,6 +139,33 @@ class OracleEnv(object):
         out = np.zeros((n, self.compact_len), np.int64)
         lib().or_batch_compact(self._h, _ptr(np.ascontiguousarray(state)), _ptr(out), n)
         return out
+
+
+MAX_LEGAL = 160
+
+
+def _batch_legal(self, state):
+    """(lists int32 [n, MAX_LEGAL] padded with -1, lengths int32 [n]) — `_generate_legal()` per lane."""
+    n = state.shape[1]
+    out = np.zeros((n, MAX_LEGAL), np.int32)
+    ln = np.zeros(n, np.int32)
+    lib().or_batch_legal(self._h, _ptr(np.ascontiguousarray(state)), _ptr(out), _ptr(ln), n)
+    return out, ln
+
+
+def _batch_rollout(self, state, sims_per_root, depth, discount, seed, lane0, t0, all_actions=False, nthreads=1):
+    roots = state.shape[1]
+    n = roots * sims_per_root
+    out = dict(ret=np.zeros(n, np.float64), n_steps=np.zeros(n, np.int32), first_action=np.zeros(n, np.int32),
+               last_ob=np.zeros(n, np.int32), terminated=np.zeros(n, np.uint8))
+    lib().or_batch_rollout(self._h, _ptr(np.ascontiguousarray(state)), roots, sims_per_root, depth, discount,
+                           int(all_actions), seed, lane0, t0, _ptr(out["ret"]), _ptr(out["n_steps"]),
+                           _ptr(out["first_action"]), _ptr(out["last_ob"]), _ptr(out["terminated"]), nthreads)
+    return out
+
+
+OracleEnv.batch_legal = _batch_legal
+OracleEnv.batch_rollout = _batch_rollout
 
 
 def synthetic_actions(n, seed, lane0, t, n_actions, nthreads=1):

@@ -20,7 +20,8 @@ oracle/pomdp_oracle.c and gym_pomdp_amd/csrc/philox.hip.h):
 
 Streams: 0 np.random draws made inside step(); 1 np.random draws made inside
 reset(); 2 / 3 the gym-space RNG (Discrete.sample) inside step() / reset()
-(Tiger only); 4 the benchmark's synthetic random-action policy.
+(Tiger only); 4 the benchmark's synthetic random-action policy; 5 the rollout policy's pick
+among the legal actions (one word per rollout step).
 """
 import numpy as np
 
@@ -29,6 +30,7 @@ STREAM_RESET = 1
 STREAM_STEP_SPACE = 2
 STREAM_RESET_SPACE = 3
 STREAM_ACTION = 4
+STREAM_ROLLOUT = 5
 
 _M0 = np.uint64(0xD2511F53)
 _M1 = np.uint64(0xCD9E8D57)

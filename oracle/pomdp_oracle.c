@@ -843,3 +843,91 @@ void or_synthetic_actions(int32_t *action, int64_t n, uint64_t seed, uint32_t la
         action[i] = (int32_t)(((uint64_t)o[lane & 3u] * n_actions) >> 32);
     }
 }
+
+/* ======================================================================== */
+/* planner hooks: _generate_legal and random rollouts                        */
+/* ======================================================================== */
+int or_env_legal(const or_env *e, int *list)
+{
+    int n = 0;
+    switch (e->kind) {
+    case OR_ENV_ROCK: {                                   /* rock.py:273-291 */
+        list[n++] = 1;                                    /* EAST is always legal */
+        if (e->agent.y + 1 < e->size) list[n++] = 0;      /* NORTH */
+        if (e->agent.y - 1 >= 0) list[n++] = 2;           /* SOUTH */
+        if (e->agent.x - 1 >= 0) list[n++] = 3;           /* WEST */
+        int rock = e->grid[e->agent.x][e->agent.y];
+        if (rock >= 0 && rock < e->num_rocks && e->status[rock] != 0) list[n++] = 4;   /* SAMPLE */
+        for (int i = 0; i < e->num_rocks; i++)            /* CHECK grid[rock.pos] for every uncollected rock */
+            if (e->status[i] != 0) list[n++] = e->grid[e->rock_pos[i].x][e->rock_pos[i].y] + 1 + 4;
+        break;
+    }
+    case OR_ENV_BATTLESHIP:                               /* battleship.py:157-165: unvisited cells */
+        for (int a = 0; a < e->xs * e->ys; a++)
+            if (!e->vis[a % e->xs][a / e->xs]) list[n++] = a;
+        break;
+    default: {                                            /* tag.py:228-229, tiger.py:111-112, network.py:130-131 */
+        int na = or_env_n_actions(e);
+        for (int a = 0; a < na; a++) list[n++] = a;
+    }
+    }
+    return n;
+}
+
+void or_batch_legal(const or_env *proto, const uint32_t *state, int32_t *out, int32_t *len, int64_t n)
+{
+    int W = or_env_words(proto);
+    or_env e = *proto;
+    uint32_t w[8];
+    int list[OR_MAX_LEGAL];
+    for (int64_t i = 0; i < n; i++) {
+        for (int j = 0; j < W; j++) w[j] = state[(int64_t)j * n + i];
+        or_env_unpack(&e, w);
+        int l = or_env_legal(&e, list);
+        len[i] = l;
+        for (int j = 0; j < OR_MAX_LEGAL; j++) out[i * OR_MAX_LEGAL + j] = j < l ? list[j] : -1;
+    }
+}
+
+void or_batch_rollout(const or_env *proto, const uint32_t *state, int64_t n_roots, int64_t sims_per_root,
+                      int depth, double discount, int policy_all_actions, uint64_t seed, uint32_t lane0,
+                      uint64_t t0, double *ret, int32_t *n_steps, int32_t *first_action, int32_t *last_ob,
+                      uint8_t *terminated, int nthreads)
+{
+    int W = or_env_words(proto), nA = or_env_n_actions(proto);
+    int64_t n = n_roots * sims_per_root;
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel num_threads(nthreads)
+    {
+        or_env e = *proto;
+        or_ws np_rng, sp_rng, pol;
+        uint32_t w[8];
+        int list[OR_MAX_LEGAL];
+#pragma omp for schedule(static)
+        for (int64_t i = 0; i < n; i++) {
+            int64_t root = i / sims_per_root;
+            for (int j = 0; j < W; j++) w[j] = state[(int64_t)j * n_roots + root];
+            or_env_unpack(&e, w);
+            uint32_t lane = lane0 + (uint32_t)i;
+            double r_acc = 0.0, disc = 1.0;
+            int k = 0, d = 0, o = 0, first = -1;
+            for (; k < depth && !d; k++) {
+                int len;
+                if (policy_all_actions) { len = nA; for (int a = 0; a < nA; a++) list[a] = a; }
+                else len = or_env_legal(&e, list);
+                if (len == 0) break;                       /* BattleShip with every cell visited */
+                or_ws_philox(&pol, seed, lane, t0 + (uint64_t)k, OR_STREAM_ROLLOUT);
+                int a = list[((uint64_t)or_ws_next32(&pol) * (uint64_t)len) >> 32];
+                if (k == 0) first = a;
+                or_ws_philox(&np_rng, seed, lane, t0 + (uint64_t)k, OR_STREAM_STEP);
+                or_ws_philox(&sp_rng, seed, lane, t0 + (uint64_t)k, OR_STREAM_STEP_SPACE);
+                double r;
+                or_env_step(&e, a, &np_rng, &sp_rng, &o, &r, &d);
+                double term = disc * r;
+                r_acc = r_acc + term;
+                disc = disc * discount;
+            }
+            ret[i] = r_acc; n_steps[i] = k; first_action[i] = first; last_ob[i] = o; terminated[i] = (uint8_t)d;
+        }
+    }
+}

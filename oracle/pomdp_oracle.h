@@ -26,7 +26,7 @@ extern "C" {
 /* ---- 32-bit word sources ------------------------------------------------ */
 enum { OR_WS_MT19937 = 0, OR_WS_PHILOX = 1 };
 enum { OR_STREAM_STEP = 0, OR_STREAM_RESET = 1, OR_STREAM_STEP_SPACE = 2,
-       OR_STREAM_RESET_SPACE = 3, OR_STREAM_ACTION = 4 };
+       OR_STREAM_RESET_SPACE = 3, OR_STREAM_ACTION = 4, OR_STREAM_ROLLOUT = 5 };
 
 typedef struct or_ws {
     int kind;
@@ -98,6 +98,24 @@ void or_batch_compact(const or_env *proto, const uint32_t *state, int64_t *out, 
 void or_synthetic_actions(int32_t *action, int64_t n, uint64_t seed, uint32_t lane0, uint64_t t,
                           uint32_t n_actions, int nthreads);
 int  or_max_threads(void);
+
+/* ---- planner hooks ---------------------------------- */
+/* `_generate_legal()` of the current state, in the reference's list order (duplicates kept);
+ * returns the list length (<= OR_MAX_LEGAL). */
+#define OR_MAX_LEGAL 160
+int  or_env_legal(const or_env *e, int *list);
+/* legal lists of every lane of a packed batch: out[n][OR_MAX_LEGAL] padded with -1, len[n] */
+void or_batch_legal(const or_env *proto, const uint32_t *state, int32_t *out, int32_t *len, int64_t n);
+/* Random rollouts (POMCP-style simulations).  Lane i starts from root state column i / sims_per_root
+ * (state: uint32 [words][n_roots], read-only) and, for k = 0 .. depth-1 while not done:
+ *   list = policy ? all actions : _generate_legal();  w = word 0 of stream ROLLOUT at (seed, lane, t0+k)
+ *   a = list[(w * len(list)) >> 32];  (ob, r, done) = step(a) on stream STEP at (seed, lane, t0+k)
+ *   ret += disc * r;  disc *= discount      (IEEE double, separate multiply and add)
+ * Outputs per lane: ret (double), n_steps, first action, last observation, terminated flag. */
+void or_batch_rollout(const or_env *proto, const uint32_t *state, int64_t n_roots, int64_t sims_per_root,
+                      int depth, double discount, int policy_all_actions, uint64_t seed, uint32_t lane0,
+                      uint64_t t0, double *ret, int32_t *n_steps, int32_t *first_action, int32_t *last_ob,
+                      uint8_t *terminated, int nthreads);
 
 #ifdef __cplusplus
 }

@@ -236,3 +236,65 @@ def trace_mode_b(name, kwargs, seed, lanes, actions, t0=0):
     out.update(lanes=np.asarray(lanes, np.int64), actions=actions.astype(np.int64), seed=np.int64(seed),
                t0=np.int64(t0), max_words_per_call=np.int64(max_used))
     return out
+
+
+# ---------------------------------------------------------------------------
+# planner hooks: _generate_legal and random rollouts
+# ---------------------------------------------------------------------------
+MAX_LEGAL = 160
+
+
+def legal_list(env):
+    lst = [int(a) for a in env._generate_legal()]
+    assert len(lst) <= MAX_LEGAL
+    return lst + [-1] * (MAX_LEGAL - len(lst)), len(lst)
+
+
+def rollout_reference(name, kwargs, seed, root_lane0, n_roots, sims_per_root, depth, discount, t_reset, t0,
+                      lane0, all_actions=False):
+    """Reference-side statement of the build's rollout contract (oracle/pomdp_oracle.h: or_batch_rollout):
+    root r is the reference env reset on stream RESET of (seed, root_lane0 + r, t_reset); simulation s of
+    root r is a deep copy of it, advanced by the reference's own step() on injected STEP words, the action
+    being list[(w * len(list)) >> 32] with list = env._generate_legal() (or all actions) and w the first
+    word of stream ROLLOUT at (seed, lane, t0 + k)."""
+    import copy
+    space = _space_rng() if name == "tiger" else None
+    n = n_roots * sims_per_root
+    out = dict(ret=np.zeros(n, np.float64), n_steps=np.zeros(n, np.int64), first_action=np.full(n, -1, np.int64),
+               last_ob=np.zeros(n, np.int64), terminated=np.zeros(n, np.uint8), root_state=None,
+               root_legal=np.full((n_roots, MAX_LEGAL), -1, np.int64), root_legal_len=np.zeros(n_roots, np.int64))
+    for r in range(n_roots):
+        env = make_ref_env(name, **kwargs)
+        inject_stream(seed, root_lane0 + r, t_reset, px.STREAM_RESET)
+        if space is not None:
+            inject_stream(seed, root_lane0 + r, t_reset, px.STREAM_RESET_SPACE, space)
+        env.reset()
+        s0 = compact_state(name, env)
+        if out["root_state"] is None:
+            out["root_state"] = np.zeros((n_roots, len(s0)), np.int64)
+        out["root_state"][r] = s0
+        out["root_legal"][r], out["root_legal_len"][r] = legal_list(env)
+        n_act = env.action_space.n
+        for s in range(sims_per_root):
+            i = r * sims_per_root + s
+            lane = lane0 + i
+            e = copy.deepcopy(env)
+            ret, disc, k, done, ob = 0.0, 1.0, 0, False, 0
+            while k < depth and not done:
+                lst = list(range(n_act)) if all_actions else [int(a) for a in e._generate_legal()]
+                if not lst:
+                    break
+                w = int(px.stream_words(seed, lane, t0 + k, px.STREAM_ROLLOUT, 1)[0])
+                a = lst[(w * len(lst)) >> 32]
+                if k == 0:
+                    out["first_action"][i] = a
+                inject_stream(seed, lane, t0 + k, px.STREAM_STEP)
+                if space is not None:
+                    inject_stream(seed, lane, t0 + k, px.STREAM_STEP_SPACE, space)
+                ob, rw, done, _ = e.step(a)
+                term = disc * float(rw)
+                ret = ret + term
+                disc = disc * discount
+                k += 1
+            out["ret"][i], out["n_steps"][i], out["last_ob"][i], out["terminated"][i] = ret, k, int(ob), int(bool(done))
+    return out

@@ -117,6 +117,41 @@ def gen_mode_b(case, env, kwargs, L, T):
     return int(tr["done"].sum()), int(tr["max_words_per_call"])
 
 
+# (case, env, kwargs, roots, sims per root, depth, all_actions)
+ROLLOUT_CASES = [
+    ("rock_7_8", "rock", {}, 12, 16, 40, False),
+    ("rock_7_8_all", "rock", {}, 8, 16, 40, True),
+    ("rock_15_15", "rock", dict(board_size=15, num_rocks=15), 8, 16, 60, False),
+    ("rock_11_11", "rock", dict(board_size=11, num_rocks=11), 6, 16, 50, False),
+    ("tag_1", "tag", {}, 8, 16, 30, False),
+    ("tag_2", "tag", dict(num_opponents=2), 6, 8, 30, False),
+    ("battleship_5_5", "battleship", {}, 8, 16, 40, False),
+    ("battleship_10_10", "battleship", dict(board_size=(10, 10), max_len=5), 3, 6, 120, False),
+    ("tiger", "tiger", {}, 8, 16, 20, False),
+    ("network_10", "network", {}, 8, 8, 16, False),
+]
+ROLLOUT_SEED = 0xC0FFEE1234
+ROLLOUT_DISCOUNT = {"rock": .95, "tag": .95, "battleship": 1., "tiger": .95, "network": .95}  # the envs' _discount
+
+
+def gen_rollout(case, env, kwargs, R, S, depth, all_actions):
+    tries = 0
+    while True:
+        try:
+            tr = h.rollout_reference(env, kwargs, ROLLOUT_SEED + tries, root_lane0=1000, n_roots=R, sims_per_root=S,
+                                     depth=depth, discount=ROLLOUT_DISCOUNT[env], t_reset=3, t0=10,
+                                     lane0=(1 << 20) - 64, all_actions=all_actions)
+            break
+        except IndexError:      # RockSample crash cells
+            tries += 1
+            assert tries < 50
+    tr.update(seed=np.int64(ROLLOUT_SEED + tries), root_lane0=np.int64(1000), n_roots=np.int64(R),
+              sims_per_root=np.int64(S), depth=np.int64(depth), discount=np.float64(ROLLOUT_DISCOUNT[env]),
+              t_reset=np.int64(3), t0=np.int64(10), lane0=np.int64((1 << 20) - 64), all_actions=np.int64(all_actions))
+    np.savez_compressed(os.path.join(HERE, "rollout_%s.npz" % case), **tr)
+    return int(tr["terminated"].sum()), float(tr["n_steps"].mean())
+
+
 def gen_thresholds():
     def binom_at(p, k):
         h.inject_words([(k >> 26) << 5, (k & ((1 << 26) - 1)) << 6])
@@ -211,15 +246,21 @@ def main():
     assert h.reference_available(), "needs /root/reference"
     import warnings
     warnings.simplefilter("ignore", RuntimeWarning)  # reference's belief side-stats divide 0/0 (rock.py:191)
-    gen_thresholds()
-    gen_edge_cases()
-    for case, env, kwargs, TA, L, TB in CASES:
+    if "--rollouts-only" not in sys.argv:
+        gen_thresholds()
+        gen_edge_cases()
+    for case, env, kwargs, TA, L, TB in (CASES if "--rollouts-only" not in sys.argv else []):
         da = gen_mode_a(case, env, kwargs, TA)
         db, mw = gen_mode_b(case, env, kwargs, L, TB)
         print("%-18s modeA dones=%4d  modeB dones=%5d  max words/call=%d" % (case, da, db, mw), flush=True)
+    for case, env, kwargs, R, S, depth, alla in ROLLOUT_CASES:
+        nt, ms = gen_rollout(case, env, kwargs, R, S, depth, alla)
+        print("rollout %-18s terminated=%4d / %d  mean steps=%.1f" % (case, nt, R * S, ms), flush=True)
     with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
         json.dump({"cases": [[c[0], c[1], {k: (list(v) if isinstance(v, tuple) else v) for k, v in c[2].items()}]
                              for c in CASES],
+                   "rollout_cases": [[c[0], c[1], {k: (list(v) if isinstance(v, tuple) else v) for k, v in c[2].items()}]
+                                     for c in ROLLOUT_CASES],
                    "mode_a_seeds": MODE_A_SEEDS, "mode_b_seed": MODE_B_SEED,
                    "numpy": np.__version__}, f, indent=1)
 

@@ -252,3 +252,84 @@ def test_full_size_properties():
         tot_done += int(done.sum())
     assert 0.05 < tot_done / (16 * n) < 0.25                          # episodes last ~8 steps
     assert a_env.invalid_action_count() == 0
+
+
+# ---- planner hooks -------------------------------------------------------
+def _rollout_cases():
+    from conftest import golden_manifest
+    return [(c[0], c[1], {k: (tuple(v) if isinstance(v, list) else v) for k, v in c[2].items()})
+            for c in golden_manifest()["rollout_cases"]]
+
+
+ROLLOUTS = _rollout_cases()
+
+
+@pytest.mark.parametrize("case,env,kw", ROLLOUTS, ids=[c[0] for c in ROLLOUTS])
+def test_rollouts_and_legal_lists_match_reference(case, env, kw):
+    """HIP rollout / legal-action kernels == the reference's own _generate_legal() and step() loop
+    (fixture rollout_*.npz), including the float64 discounted return."""
+    import os
+    from conftest import GOLDEN
+    g = dict(np.load(os.path.join(GOLDEN, "rollout_%s.npz" % case)))
+    R, S = int(g["n_roots"]), int(g["sims_per_root"])
+    e = make_env(env, kw, batch_size=R, seed=int(g["seed"]), lane_offset=int(g["root_lane0"]))
+    e.call_counter = int(g["t_reset"])
+    e.reset()
+    assert np.array_equal(np_(e.decode_state()), saturate_tag_compact(env, g["root_state"]))
+    lst, ln = e.legal_actions()
+    A = e.action_space.n
+    assert np.array_equal(np_(ln), g["root_legal_len"])
+    assert np.array_equal(np_(lst), g["root_legal"][:, :A])
+    assert np.all(g["root_legal"][:, A:] == -1)
+    e.call_counter = int(g["t0"])
+    before = e.state.clone()
+    r = e.rollout(int(g["depth"]), sims_per_root=S, discount=float(g["discount"]),
+                  all_actions=bool(g["all_actions"]), lane_offset=int(g["lane0"]))
+    assert torch.equal(e.state, before)                                  # rollouts never touch the roots
+    assert e.call_counter == int(g["t0"]) + int(g["depth"])
+    assert np.array_equal(np_(r["ret"]), g["ret"])                       # IEEE double, bit-exact
+    for k in ("n_steps", "first_action", "last_ob"):
+        assert np.array_equal(np_(r[k]), g[k]), k
+    assert np.array_equal(np_(r["terminated"]), g["terminated"].astype(bool))
+
+
+@pytest.mark.parametrize("env,kw,roots,sims,depth", [
+    ("rock", dict(board_size=15, num_rocks=15), 64, 1024, 48),          # BASELINE.json configs[4] shape, scaled down
+    ("rock", {}, 4096, 8, 32),
+    ("tag", {}, 2048, 16, 40),
+    ("battleship", dict(board_size=(10, 10), max_len=5), 256, 16, 110),
+    ("network", {}, 1024, 16, 12),
+    ("tiger", {}, 4096, 4, 10),
+])
+def test_rollout_vs_oracle(oracle_lib, env, kw, roots, sims, depth):
+    seed, lane0 = 4242, 1 << 16
+    o = oracle_lib.OracleEnv(env, **kw)
+    e = make_env(env, kw, batch_size=roots, seed=seed, lane_offset=lane0)
+    st = o.new_state(roots)
+    o.batch_reset(st, seed, lane0, 0, nthreads=8)
+    e.reset()
+    for _ in range(3):                                                  # move the roots off the start state
+        a = oracle_lib.synthetic_actions(roots, 1, lane0, e.call_counter, o.n_actions)
+        o.batch_step(st, a, seed, lane0, e.call_counter, nthreads=8)
+        e.step(torch.as_tensor(a, device="cuda"))
+    assert np.array_equal(np_(e.state).view(np.uint32), st)
+    lists, lens = o.batch_legal(st)
+    lst, ln = e.legal_actions()
+    assert np.array_equal(np_(ln), lens) and np.array_equal(np_(lst), lists[:, : e.action_space.n])
+    t0 = e.call_counter
+    want = o.batch_rollout(st, sims, depth, e._discount, seed, lane0, t0, nthreads=8)
+    got = e.rollout(depth, sims_per_root=sims)
+    assert np.array_equal(np_(got["ret"]), want["ret"])
+    for k in ("n_steps", "first_action", "last_ob"):
+        assert np.array_equal(np_(got[k]), want[k]), k
+    assert np.array_equal(np_(got["terminated"]), want["terminated"].astype(bool))
+
+
+def test_scalar_planner_hooks():
+    e = make_env("rock", {}, seed=5)
+    e.reset()
+    assert e._generate_legal() == [1, 0, 2, 5, 6, 7, 8, 9, 10, 11, 12]   # start (0,3): no WEST, no rock underfoot
+    s0 = e._get_init_state()
+    assert s0.shape == (1, 1)
+    e._set_state(s0)
+    assert torch.equal(e.state, s0)

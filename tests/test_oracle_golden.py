@@ -157,3 +157,30 @@ def test_invalid_action_counts(oracle_lib):
     assert bad == 3
     assert np.array_equal(st[:, [0, 1, 3]], before[:, [0, 1, 3]])
     assert np.all(ob[[0, 1, 3]] == 0) and np.all(rew[[0, 1, 3]] == 0) and np.all(done[[0, 1, 3]] == 0)
+
+
+# ---- planner hooks: _generate_legal and rollouts --------------------------
+def _rollout_cases():
+    return [(c[0], c[1], {k: (tuple(v) if isinstance(v, list) else v) for k, v in c[2].items()})
+            for c in golden_manifest()["rollout_cases"]]
+
+
+ROLLOUTS = _rollout_cases()
+
+
+@pytest.mark.parametrize("case,env,kw", ROLLOUTS, ids=[c[0] for c in ROLLOUTS])
+def test_rollouts_and_legal_lists_match_reference(oracle_lib, case, env, kw):
+    g = dict(np.load(os.path.join(GOLDEN, "rollout_%s.npz" % case)))
+    o = oracle_lib.OracleEnv(env, **kw)
+    R, S = int(g["n_roots"]), int(g["sims_per_root"])
+    roots = o.new_state(R)
+    o.batch_reset(roots, int(g["seed"]), int(g["root_lane0"]), int(g["t_reset"]))
+    assert np.array_equal(o.batch_compact(roots), saturate_tag_compact(env, g["root_state"]))
+    lists, lens = o.batch_legal(roots)
+    assert np.array_equal(lens, g["root_legal_len"])
+    assert np.array_equal(lists, g["root_legal"])
+    r = o.batch_rollout(roots, S, int(g["depth"]), float(g["discount"]), int(g["seed"]), int(g["lane0"]),
+                        int(g["t0"]), all_actions=bool(g["all_actions"]), nthreads=2)
+    assert np.array_equal(r["ret"], g["ret"])                 # IEEE double, bit-exact
+    for k in ("n_steps", "first_action", "last_ob", "terminated"):
+        assert np.array_equal(r[k], g[k].astype(r[k].dtype)), k
