@@ -48,6 +48,8 @@ def lib():
         L.or_batch_legal.argtypes = [vp, vp, vp, vp, C.c_int64]
         L.or_batch_rollout.argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_int, C.c_double, C.c_int, C.c_uint64,
                                        C.c_uint32, C.c_uint64, vp, vp, vp, vp, vp, C.c_int]
+        L.or_bench_loop.restype = C.c_double
+        L.or_bench_loop.argtypes = [vp, C.c_int64, C.c_int64, C.c_uint64, C.c_int, vp]
         L.or_max_threads.restype = C.c_int
         L.or_philox4x32_10.argtypes = [vp, vp, vp]
         _lib = L
@@ -164,6 +166,13 @@ def _batch_rollout(self, state, sims_per_root, depth, discount, seed, lane0, t0,
     return out
 
 
+def _bench_loop(self, n, steps, seed, nthreads):
+    """seconds spent on `steps` x (synthetic policy + step) over n lanes, all in C."""
+    nd = C.c_int64(0)
+    return float(lib().or_bench_loop(self._h, n, steps, seed, nthreads, C.byref(nd)))
+
+
+OracleEnv.bench_loop = _bench_loop
 OracleEnv.batch_legal = _batch_legal
 OracleEnv.batch_rollout = _batch_rollout
 

@@ -844,6 +844,27 @@ void or_synthetic_actions(int32_t *action, int64_t n, uint64_t seed, uint32_t la
     }
 }
 
+double or_bench_loop(const or_env *proto, int64_t n, int64_t steps, uint64_t seed, int nthreads, int64_t *n_done)
+{
+    int W = or_env_words(proto);
+    uint32_t *state = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)W * (size_t)n);
+    int32_t *action = (int32_t *)malloc(sizeof(int32_t) * (size_t)n), *ob = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
+    void *reward = malloc(4 * (size_t)n);
+    uint8_t *done = (uint8_t *)calloc((size_t)n, 1);
+    int64_t dsum = 0;
+    or_batch_reset(proto, state, ob, n, seed, 0, 0, nthreads);
+    double t0 = omp_get_wtime();
+    for (int64_t s = 1; s <= steps; s++) {
+        or_synthetic_actions(action, n, seed ^ 0x5DEECE66DULL, 0, (uint64_t)s, (uint32_t)or_env_n_actions(proto), nthreads);
+        or_batch_step(proto, state, action, ob, reward, done, n, seed, 0, (uint64_t)s, 1, nthreads);
+        for (int64_t i = 0; i < n; i += 4097) dsum += done[i];
+    }
+    double el = omp_get_wtime() - t0;
+    if (n_done) *n_done = dsum;
+    free(state); free(action); free(ob); free(reward); free(done);
+    return el;
+}
+
 /* ======================================================================== */
 /* planner hooks: _generate_legal and random rollouts                        */
 /* ======================================================================== */

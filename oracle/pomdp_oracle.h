@@ -98,6 +98,10 @@ void or_batch_compact(const or_env *proto, const uint32_t *state, int64_t *out, 
 void or_synthetic_actions(int32_t *action, int64_t n, uint64_t seed, uint32_t lane0, uint64_t t,
                           uint32_t n_actions, int nthreads);
 int  or_max_threads(void);
+/* CPU baseline loop, entirely in C: reset n lanes, then `steps` x (synthetic actions + step with auto-reset)
+ * on `nthreads` OpenMP threads; returns the wall-clock seconds of the stepping part and the number of done
+ * lanes seen (so the work cannot be optimised away). */
+double or_bench_loop(const or_env *proto, int64_t n, int64_t steps, uint64_t seed, int nthreads, int64_t *n_done);
 
 /* ---- planner hooks ---------------------------------- */
 /* `_generate_legal()` of the current state, in the reference's list order (duplicates kept);

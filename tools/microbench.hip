@@ -26,6 +26,22 @@ __global__ __launch_bounds__(256) void traffic_kernel(uint32_t *__restrict__ sta
     }
 }
 
+template <int BS>
+__global__ __launch_bounds__(BS) void traffic_kernel_bs(uint32_t *__restrict__ state, const int32_t *__restrict__ action,
+                                                      int32_t *__restrict__ ob, int32_t *__restrict__ reward,
+                                                      uint8_t *__restrict__ done, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x;
+    if (i < n) {
+        const uint32_t s = state[i];
+        const int a = action[i];
+        state[i] = s + (uint32_t)a;
+        ob[i] = a & 3;
+        reward[i] = a - 5;
+        done[i] = (uint8_t)(s & 1u);
+    }
+}
+
 // V0v: same traffic, 4 lanes per thread, 16-byte accesses
 __global__ __launch_bounds__(256) void traffic_kernel_v4(uint4 *__restrict__ state, const int4 *__restrict__ action,
                                                          int4 *__restrict__ ob, int4 *__restrict__ reward,
@@ -95,6 +111,10 @@ int main(int argc, char **argv)
         printf("traffic 21B  grid=%5d      : %8.2f\n", blocks,
                time_it([&](int) { hipLaunchKernelGGL(traffic_kernel, dim3(blocks), dim3(256), 0, 0, state, action, ob, reward, done, n); }, iters));
     }
+    printf("traffic 21B  bs=64  1 lane/thr : %8.2f\n", time_it([&](int) { hipLaunchKernelGGL(traffic_kernel_bs<64>, dim3((unsigned)(n / 64)), dim3(64), 0, 0, state, action, ob, reward, done, n); }, iters));
+    printf("traffic 21B  bs=256 1 lane/thr : %8.2f\n", time_it([&](int) { hipLaunchKernelGGL(traffic_kernel_bs<256>, dim3((unsigned)(n / 256)), dim3(256), 0, 0, state, action, ob, reward, done, n); }, iters));
+    printf("traffic 21B  bs=512 1 lane/thr : %8.2f\n", time_it([&](int) { hipLaunchKernelGGL(traffic_kernel_bs<512>, dim3((unsigned)(n / 512)), dim3(512), 0, 0, state, action, ob, reward, done, n); }, iters));
+    printf("traffic 21B  bs=1024 1 lane/thr: %8.2f\n", time_it([&](int) { hipLaunchKernelGGL(traffic_kernel_bs<1024>, dim3((unsigned)(n / 1024)), dim3(1024), 0, 0, state, action, ob, reward, done, n); }, iters));
     for (int blocks : {256, 512, 1024, 2048}) {
         printf("traffic 21B v4 grid=%5d    : %8.2f\n", blocks,
                time_it([&](int) { hipLaunchKernelGGL(traffic_kernel_v4, dim3(blocks), dim3(256), 0, 0, (uint4 *)state, (const int4 *)action, (int4 *)ob, (int4 *)reward, (uint32_t *)done, n / 4); }, iters));
