@@ -58,6 +58,7 @@ def parse():
                          "sims-per-root random rollouts of --depth steps from each root (fused kernel, state in registers)")
     ap.add_argument("--depth", type=int, default=64)
     ap.add_argument("--sims-per-root", type=int, default=1024)
+    ap.add_argument("--action-seed", type=int, default=None, help="policy key (default: the env seed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline sample")
     return ap.parse_args()
@@ -176,7 +177,8 @@ def main():
     if args.mode == "rollout":
         return rollout_mode(args, env, cp, dev, rank, world, label)
     actions = torch.empty(n, dtype=torch.int32, device=dev)
-    action_seed = args.seed ^ 0x5DEECE66D
+    # by default policy and env share the Philox key (their streams differ by stream id)
+    action_seed = args.seed if args.action_seed is None else args.action_seed
 
     def run_steps(k):
         if args.host_loop == "python":

@@ -18,6 +18,26 @@ namespace pomdp {
 
 constexpr uint64_t TWO52 = 4503599627370496ull;
 
+// The synthetic policy's action of global lane `lane` at the call counter in `akey` (stream ACTION,
+// one Philox block per 4 consecutive lanes): what pomdp_synthetic_actions writes for that lane.
+__device__ __forceinline__ int synthetic_action(const RngKey &akey, uint32_t lane, uint32_t n_actions)
+{
+    const uint4 w = philox4x32_10(lane >> 2, akey.t_lo, akey.t_hi, (uint32_t)POMDP_STREAM_ACTION << 24, akey.k0, akey.k1);
+    const uint32_t sel = lane & 3u;
+    return (int)__umulhi(sel == 0 ? w.x : sel == 1 ? w.y : sel == 2 ? w.z : w.w, n_actions);
+}
+
+// default for envs without a cooperative reset: reset, then every lane derives its own next action
+template <class Env>
+__device__ __forceinline__ void reset_where_chain_default(const typename Env::Shared &sh, const typename Env::Params &p,
+                                                          typename Env::State &st, bool fresh, const RngKey &key,
+                                                          uint32_t lane, const RngKey &akey, uint32_t n_actions,
+                                                          int &next_action)
+{
+    Env::reset_where(sh, p, st, fresh, key, lane);
+    next_action = synthetic_action(akey, lane, n_actions);
+}
+
 // ===========================================================================
 // RockSample
 // ===========================================================================
@@ -91,12 +111,32 @@ struct RockEnv {
     // (resetting lane, block) pairs are dealt out across the 64 lanes — one Philox block per lane per
     // pass — and the rock codes travel back through DPP / ds_bpermute.  Same words, same result as
     // reset() above; ~1 pass per step instead of NB blocks.
-    static __device__ __forceinline__ void reset_where(const Shared &, const Params &p, State &st, bool fresh,
+    static __device__ __forceinline__ void reset_where(const Shared &sh, const Params &p, State &st, bool fresh,
                                                        const RngKey &key, uint32_t lane)
     {
-        if (ABLATE & 2) return;
+        int unused;
+        reset_core<false>(sh, p, st, fresh, key, lane, key, 1u, unused);
+    }
+    // Same pass, plus the synthetic policy's actions for the NEXT call counter (C-side rollout driver):
+    // the wave's 16 action blocks (one per 4 lanes) ride in lanes 0-15 of the first Philox pass, the
+    // reset tasks follow, so chaining the policy costs a handful of cross-lane moves instead of a kernel.
+    static __device__ __forceinline__ void reset_where_chain(const Shared &sh, const Params &p, State &st, bool fresh,
+                                                             const RngKey &key, uint32_t lane, const RngKey &akey,
+                                                             uint32_t n_actions, int &next_action)
+    {
+        // the chained launch is only used when policy and env share the Philox key (their streams differ by
+        // stream id), so the key schedule of the pooled pass stays wave-uniform (SGPRs)
+        reset_core<true>(sh, p, st, fresh, key, lane, akey, n_actions, next_action);
+    }
+
+    template <bool CHAIN>
+    static __device__ __forceinline__ void reset_core(const Shared &, const Params &p, State &st, bool fresh,
+                                                      const RngKey &key, uint32_t lane, const RngKey &akey,
+                                                      uint32_t n_actions, int &next_action)
+    {
+        if (ABLATE & 2) { if (CHAIN) next_action = synthetic_action(akey, lane, n_actions); return; }
         const uint64_t mask = __ballot(fresh);
-        if (mask == 0ull) return;                                      // wave-uniform
+        if (!CHAIN && mask == 0ull) return;                            // wave-uniform
         const int K = p.num_rocks;
         const int NB = (K + 1) >> 1;                                   // blocks per reset (wave-uniform)
         const int lid = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -106,26 +146,46 @@ struct RockEnv {
         const int dst = fresh ? lid : nreset + (me - lid);
         const int src_of_rank = __builtin_amdgcn_ds_permute(dst << 2, me);
         uint64_t bits = 0;
-        const int ntask = nreset * NB;
         if (NB == 4) {
-            // K = 7 or 8 (the metric config): the four tasks of one reset sit in one quad of lanes
+            // K = 7 or 8 (the metric config): the four tasks of one reset sit in one quad of lanes.
+            // Task list: [16 action tasks (CHAIN only)] ++ [4 tasks per resetting lane].
+            constexpr int NA = CHAIN ? 16 : 0;
+            const int ntask = NA + nreset * 4;
+            uint4 aw = make_uint4(0, 0, 0, 0);
             for (int base = 0; base < ntask; base += 64) {
                 const int tid = base + me;
-                const int srcl = __shfl(src_of_rank, (tid >> 2) & 63, 64);
+                const bool is_act = CHAIN && tid < NA;
+                const int rt = tid - NA;                                   // reset task index (negative for action tasks)
+                const int srcl = __shfl(src_of_rank, (rt >> 2) & 63, 64);
                 const int b = me & 3;
                 uint32_t v = 0;
                 if (tid < ntask) {
-                    const uint4 w = stream_block(key, lane - (uint32_t)me + (uint32_t)srcl, POMDP_STREAM_RESET, (uint32_t)b);
+                    // ONE Philox instance for both task kinds: the counter words are per-lane selects (a branch
+                    // on is_act would run the ten rounds twice under complementary exec masks)
+                    const uint32_t c0 = is_act ? ((lane - (uint32_t)me) >> 2) + (uint32_t)tid : lane - (uint32_t)me + (uint32_t)srcl;
+                    const uint32_t c1 = is_act ? akey.t_lo : key.t_lo, c2 = is_act ? akey.t_hi : key.t_hi;
+                    const uint32_t c3 = is_act ? ((uint32_t)POMDP_STREAM_ACTION << 24) : (((uint32_t)POMDP_STREAM_RESET << 24) | (uint32_t)b);
+                    const uint4 w = philox4x32_10(c0, c1, c2, c3, key.k0, key.k1);
+                    if (CHAIN && base == 0) aw = w;                    // wave-uniform condition; lanes >= 16 hold junk nobody reads
                     const uint32_t cb = (2 * b + 1 < K) ? (rock_code(w.z, w.w) << 2) : 0u;
-                    v = (rock_code(w.x, w.y) | cb) << (4 * b);
+                    v = is_act ? 0u : ((rock_code(w.x, w.y) | cb) << (4 * b));
                 }
                 v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true); // quad_perm [1,0,3,2]
                 v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true); // quad_perm [2,3,0,1]
-                const int t = lid * 4 - base;
+                const int t = NA + lid * 4 - base;
                 const uint32_t got = (uint32_t)__shfl((int)v, t & 63, 64);
                 if (t >= 0 && t < 64) bits = (uint64_t)got << 8;
+                if (CHAIN && base == 0) {
+                    // lane l takes word (l & 3) of the block computed by lane l >> 2
+                    const int q = me >> 2;
+                    const uint32_t x = (uint32_t)__shfl((int)aw.x, q, 64), y = (uint32_t)__shfl((int)aw.y, q, 64);
+                    const uint32_t z = (uint32_t)__shfl((int)aw.z, q, 64), ww = (uint32_t)__shfl((int)aw.w, q, 64);
+                    next_action = (int)__umulhi(b == 0 ? x : b == 1 ? y : b == 2 ? z : ww, n_actions);
+                }
             }
         } else {
+            if (CHAIN) next_action = synthetic_action(akey, lane, n_actions);
+            const int ntask = nreset * NB;
             const uint32_t inv = (65536u + (uint32_t)NB - 1u) / (uint32_t)NB; // tid / NB == (tid * inv) >> 16 for tid < 512
             for (int base = 0; base < ntask; base += 64) {
                 const int tid = base + me;
@@ -278,6 +338,12 @@ struct TagEnv {
                                                        const RngKey &key, uint32_t lane)
     {
         if (fresh) reset(sh, p, st, key, lane);
+    }
+    static __device__ __forceinline__ void reset_where_chain(const Shared &sh, const Params &p, State &st, bool fresh,
+                                                             const RngKey &key, uint32_t lane, const RngKey &akey,
+                                                             uint32_t n_actions, int &next_action)
+    {
+        reset_where_chain_default<TagEnv>(sh, p, st, fresh, key, lane, akey, n_actions, next_action);
     }
 
     // tag.py:228-229: every action is legal
@@ -434,6 +500,12 @@ struct BattleShipEnv {
     {
         if (fresh) reset(sh, p, st, key, lane);
     }
+    static __device__ __forceinline__ void reset_where_chain(const Shared &sh, const Params &p, State &st, bool fresh,
+                                                             const RngKey &key, uint32_t lane, const RngKey &akey,
+                                                             uint32_t n_actions, int &next_action)
+    {
+        reset_where_chain_default<BattleShipEnv<MW>>(sh, p, st, fresh, key, lane, akey, n_actions, next_action);
+    }
 
     // battleship.py:157-165 _generate_legal: the unvisited cells, ascending
     static __device__ __forceinline__ uint32_t unvisited(const Params &p, const State &st, int j)
@@ -512,6 +584,12 @@ struct TigerEnv {
     {
         if (fresh) reset(sh, p, st, key, lane);
     }
+    static __device__ __forceinline__ void reset_where_chain(const Shared &sh, const Params &p, State &st, bool fresh,
+                                                             const RngKey &key, uint32_t lane, const RngKey &akey,
+                                                             uint32_t n_actions, int &next_action)
+    {
+        reset_where_chain_default<TigerEnv>(sh, p, st, fresh, key, lane, akey, n_actions, next_action);
+    }
     // tiger.py:111-112: every action is legal
     static __device__ __forceinline__ int legal_count(const Shared &, const Params &p, const State &) { return n_actions(p); }
     static __device__ __forceinline__ int legal_nth(const Shared &, const Params &, const State &, int idx) { return idx; }
@@ -564,6 +642,12 @@ struct NetworkEnv {
                                                        const RngKey &key, uint32_t lane)
     {
         if (fresh) reset(sh, p, st, key, lane);
+    }
+    static __device__ __forceinline__ void reset_where_chain(const Shared &sh, const Params &p, State &st, bool fresh,
+                                                             const RngKey &key, uint32_t lane, const RngKey &akey,
+                                                             uint32_t n_actions, int &next_action)
+    {
+        reset_where_chain_default<NetworkEnv>(sh, p, st, fresh, key, lane, akey, n_actions, next_action);
     }
     // network.py:130-131: every action is legal
     static __device__ __forceinline__ int legal_count(const Shared &, const Params &p, const State &) { return n_actions(p); }

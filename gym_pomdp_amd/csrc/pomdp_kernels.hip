@@ -56,12 +56,15 @@ __global__ __launch_bounds__(BLOCK) void reset_kernel(const typename Env::Params
 // overlap.  Lanes past n read lane n-1 and have their stores predicated off.  Every lane of a
 // wave reaches Env::reset_where (wave-cooperative reset).
 // ---------------------------------------------------------------------------
-template <class Env, int LPT>
+// CHAIN (C-side rollout driver only): after stepping, action[i] is overwritten with the synthetic
+// policy's action for call counter t + 1 (key `akey`), so the next launch finds its input ready and
+// no separate policy kernel runs.
+template <class Env, int LPT, bool CHAIN = false>
 __global__ __launch_bounds__(BLOCK) void step_kernel(const typename Env::Params p, uint32_t *__restrict__ state,
-                                                     const int32_t *__restrict__ action, int32_t *__restrict__ ob,
-                                                     typename Env::Reward *__restrict__ reward,
+                                                     typename std::conditional<CHAIN, int32_t, const int32_t>::type *__restrict__ action,
+                                                     int32_t *__restrict__ ob, typename Env::Reward *__restrict__ reward,
                                                      uint8_t *__restrict__ done, uint32_t *__restrict__ err,
-                                                     int64_t n, RngKey key, uint32_t lane0, int flags)
+                                                     int64_t n, RngKey key, uint32_t lane0, int flags, RngKey akey = RngKey())
 {
     __shared__ typename Env::Shared sh;
     const bool auto_reset = flags & POMDP_AUTO_RESET;
@@ -96,7 +99,13 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const typename Env::Params 
 #pragma unroll
     for (int j = 0; j < LPT; ++j) {
         const bool fresh = live[j] && d[j] && auto_reset;
-        Env::reset_where(sh, p, st[j], fresh, key, lane0 + (uint32_t)idx[j]);
+        if (CHAIN) {
+            int a_next;
+            Env::reset_where_chain(sh, p, st[j], fresh, key, lane0 + (uint32_t)idx[j], akey, (uint32_t)n_act, a_next);
+            if (in_range[j]) const_cast<int32_t *>(action)[idx[j]] = a_next;
+        } else {
+            Env::reset_where(sh, p, st[j], fresh, key, lane0 + (uint32_t)idx[j]);
+        }
         if (live[j]) Env::store(st[j], state, n, idx[j], fresh);
         if (in_range[j]) {
             ob[idx[j]] = o[j];
@@ -244,6 +253,19 @@ static int launch_step(const typename Env::Params &p, uint32_t *state, const int
     // each other at 2^20 and 2^22 lanes — the kernel is bound by VALU issue, not by latency.
     hipLaunchKernelGGL((step_kernel<Env, 1>), dim3(blocks_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, p, state,
                        action, ob, reward, done, err, n, make_key(seed, t), lane0, flags);
+    return (int)hipGetLastError();
+}
+
+// step + policy for the next call counter in one launch (see step_kernel<.., CHAIN>)
+template <class Env>
+static int launch_step_chain(const typename Env::Params &p, uint32_t *state, int32_t *action, int32_t *ob,
+                             typename Env::Reward *reward, uint8_t *done, uint32_t *err, int64_t n, uint64_t seed,
+                             uint64_t action_seed, uint32_t lane0, uint64_t t, int flags, void *stream)
+{
+    if (!state || !action || !ob || !reward || !done || bad_range(n, lane0) || (lane0 & 3u)) return POMDP_E_BADARG;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL((step_kernel<Env, 1, true>), dim3(blocks_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, p, state,
+                       action, ob, reward, done, err, n, make_key(seed, t), lane0, flags, make_key(action_seed, t + 1));
     return (int)hipGetLastError();
 }
 
@@ -437,11 +459,80 @@ int pomdp_synthetic_actions(int32_t *action, int64_t n, uint64_t seed, uint32_t 
     return (int)hipGetLastError();
 }
 
+#define POMDP_CHAIN_CALL(E, P) rc = launch_step_chain<E>(*(P), state, action, ob, (typename E::Reward *)reward, done, err, n, seed, action_seed, lane0, t, flags, stream)
+#define POMDP_DISPATCH_STEP_CHAIN(env, params)                                                                         \
+    switch (env) {                                                                                                     \
+    case POMDP_ENV_ROCK: {                                                                                             \
+        const pomdp_rock_params *p = (const pomdp_rock_params *)(params);                                              \
+        if (!rock_ok(p)) return POMDP_E_BADPARAMS;                                                                     \
+        if (p->num_rocks <= 12) { POMDP_CHAIN_CALL(RockEnv<1>, p); } else { POMDP_CHAIN_CALL(RockEnv<2>, p); }           \
+        break;                                                                                                         \
+    }                                                                                                                  \
+    case POMDP_ENV_TAG: {                                                                                              \
+        const pomdp_tag_params *p = (const pomdp_tag_params *)(params);                                                \
+        if (p->num_opponents < 1 || p->num_opponents > 4) return POMDP_E_BADPARAMS;                                    \
+        POMDP_CHAIN_CALL(TagEnv, p);                                                                                   \
+        break;                                                                                                         \
+    }                                                                                                                  \
+    case POMDP_ENV_BATTLESHIP: {                                                                                       \
+        const pomdp_battleship_params *p = (const pomdp_battleship_params *)(params);                                  \
+        switch (bs_mask_words(p)) {                                                                                    \
+        case 1: POMDP_CHAIN_CALL(BattleShipEnv<1>, p); break;                                                          \
+        case 2: POMDP_CHAIN_CALL(BattleShipEnv<2>, p); break;                                                          \
+        case 3: POMDP_CHAIN_CALL(BattleShipEnv<3>, p); break;                                                          \
+        case 4: POMDP_CHAIN_CALL(BattleShipEnv<4>, p); break;                                                          \
+        default: return POMDP_E_BADPARAMS;                                                                             \
+        }                                                                                                              \
+        break;                                                                                                         \
+    }                                                                                                                  \
+    case POMDP_ENV_TIGER: POMDP_CHAIN_CALL(TigerEnv, (const pomdp_tiger_params *)(params)); break;                     \
+    default: {                                                                                                         \
+        const pomdp_network_params *p = (const pomdp_network_params *)(params);                                        \
+        if (p->n_machines < 1 || p->n_machines > 32) return POMDP_E_BADPARAMS;                                         \
+        POMDP_CHAIN_CALL(NetworkEnv, p);                                                                               \
+    }                                                                                                                  \
+    }
+
+#define POMDP_PLAIN_CALL(E, P) rc = launch_step<E>(*(P), state, action, ob, (typename E::Reward *)reward, done, err, n, seed, lane0, t, flags, stream)
+#define POMDP_DISPATCH_STEP_PLAIN(env, params)                                                                         \
+    switch (env) {                                                                                                     \
+    case POMDP_ENV_ROCK: {                                                                                             \
+        const pomdp_rock_params *p = (const pomdp_rock_params *)(params);                                              \
+        if (!rock_ok(p)) return POMDP_E_BADPARAMS;                                                                     \
+        if (p->num_rocks <= 12) { POMDP_PLAIN_CALL(RockEnv<1>, p); } else { POMDP_PLAIN_CALL(RockEnv<2>, p); }           \
+        break;                                                                                                         \
+    }                                                                                                                  \
+    case POMDP_ENV_TAG: {                                                                                              \
+        const pomdp_tag_params *p = (const pomdp_tag_params *)(params);                                                \
+        if (p->num_opponents < 1 || p->num_opponents > 4) return POMDP_E_BADPARAMS;                                    \
+        POMDP_PLAIN_CALL(TagEnv, p);                                                                                   \
+        break;                                                                                                         \
+    }                                                                                                                  \
+    case POMDP_ENV_BATTLESHIP: {                                                                                       \
+        const pomdp_battleship_params *p = (const pomdp_battleship_params *)(params);                                  \
+        switch (bs_mask_words(p)) {                                                                                    \
+        case 1: POMDP_PLAIN_CALL(BattleShipEnv<1>, p); break;                                                          \
+        case 2: POMDP_PLAIN_CALL(BattleShipEnv<2>, p); break;                                                          \
+        case 3: POMDP_PLAIN_CALL(BattleShipEnv<3>, p); break;                                                          \
+        case 4: POMDP_PLAIN_CALL(BattleShipEnv<4>, p); break;                                                          \
+        default: return POMDP_E_BADPARAMS;                                                                             \
+        }                                                                                                              \
+        break;                                                                                                         \
+    }                                                                                                                  \
+    case POMDP_ENV_TIGER: POMDP_PLAIN_CALL(TigerEnv, (const pomdp_tiger_params *)(params)); break;                     \
+    default: {                                                                                                         \
+        const pomdp_network_params *p = (const pomdp_network_params *)(params);                                        \
+        if (p->n_machines < 1 || p->n_machines > 32) return POMDP_E_BADPARAMS;                                         \
+        POMDP_PLAIN_CALL(NetworkEnv, p);                                                                               \
+    }                                                                                                                  \
+    }
+
 int pomdp_rollout_synthetic(int env, const void *params, uint32_t *state, int32_t *action, int32_t *ob, void *reward,
                             uint8_t *done, uint32_t *err, int64_t n, uint64_t seed, uint64_t action_seed,
                             uint32_t lane0, uint64_t t0, int64_t k_steps, int flags, void *stream)
 {
-    if (!params || k_steps < 0) return POMDP_E_BADARG;
+    if (!params || k_steps < 0 || !action) return POMDP_E_BADARG;
+    if (k_steps == 0) return 0;
     uint32_t n_actions;
     switch (env) {
     case POMDP_ENV_ROCK: n_actions = 5u + (uint32_t)((const pomdp_rock_params *)params)->num_rocks; break;
@@ -455,35 +546,26 @@ int pomdp_rollout_synthetic(int env, const void *params, uint32_t *state, int32_
     case POMDP_ENV_NETWORK: n_actions = 2u * (uint32_t)((const pomdp_network_params *)params)->n_machines + 1u; break;
     default: return POMDP_E_BADARG;
     }
+    // actions of the first step from the stand-alone policy kernel
+    int rc = pomdp_synthetic_actions(action, n, action_seed, lane0, t0, n_actions, stream);
+    if (rc) return rc;
+    if (action_seed == seed) {
+        // chained: every step launch also leaves the actions of the following call counter in `action`
+        for (int64_t s = 0; s < k_steps; ++s) {
+            const uint64_t t = t0 + (uint64_t)s;
+            POMDP_DISPATCH_STEP_CHAIN(env, params)
+            if (rc) return rc;
+        }
+        return 0;
+    }
+    // distinct policy key: policy launch + step launch per step
     for (int64_t s = 0; s < k_steps; ++s) {
         const uint64_t t = t0 + (uint64_t)s;
-        int rc = pomdp_synthetic_actions(action, n, action_seed, lane0, t, n_actions, stream);
-        if (rc) return rc;
-        switch (env) {
-        case POMDP_ENV_ROCK:
-            rc = pomdp_rock_step((const pomdp_rock_params *)params, state, action, ob, (int32_t *)reward, done, err, n,
-                                 seed, lane0, t, flags, stream);
-            break;
-        case POMDP_ENV_TAG:
-            rc = pomdp_tag_step((const pomdp_tag_params *)params, state, action, ob, (float *)reward, done, err, n, seed,
-                                lane0, t, flags, stream);
-            break;
-        case POMDP_ENV_BATTLESHIP:
-            rc = pomdp_battleship_step((const pomdp_battleship_params *)params, state, action, ob, (int32_t *)reward,
-                                       done, err, n, seed, lane0, t, flags, stream);
-            break;
-        case POMDP_ENV_TIGER:
-            rc = pomdp_tiger_step((const pomdp_tiger_params *)params, state, action, ob, (int32_t *)reward, done, err, n,
-                                  seed, lane0, t, flags, stream);
-            break;
-        default:
-            rc = pomdp_network_step((const pomdp_network_params *)params, state, action, ob, (float *)reward, done, err,
-                                    n, seed, lane0, t, flags, stream);
-            break;
-        }
+        if (s > 0 && (rc = pomdp_synthetic_actions(action, n, action_seed, lane0, t, n_actions, stream))) return rc;
+        POMDP_DISPATCH_STEP_PLAIN(env, params)
         if (rc) return rc;
     }
-    return 0;
+    return pomdp_synthetic_actions(action, n, action_seed, lane0, t0 + (uint64_t)k_steps, n_actions, stream);
 }
 
 int pomdp_legal_actions(int env, const void *params, const uint32_t *state, int32_t *list, int32_t *len, int64_t n,

@@ -156,8 +156,12 @@ int pomdp_philox_blocks(const uint32_t *ctr_key, uint32_t *out, int64_t n_blocks
 
 /* Random-policy rollout driven from C: for s in [0, k_steps): pomdp_synthetic_actions at t0+s into
  * `action` (device scratch, int32[n]) with key `action_seed`, then pomdp_<env>_step at t0+s.  Exactly
- * the launches a host loop over step() would issue (2 per step), minus the host language's per-call
- * overhead; the caller's call counter advances by k_steps.  `params` points at the env's
+ * the results a host loop over pomdp_synthetic_actions + step would produce, in k_steps + 1 launches:
+ * when action_seed == seed (policy and env share the Philox key; their streams differ by stream id) the
+ * policy kernel runs once, for t0, and every step launch also leaves the policy's actions for the
+ * following call counter in `action` (on RockSample they ride in the cooperative reset pass); with a
+ * distinct action_seed each step is a policy launch plus a step launch.  Either way `action` holds the
+ * actions of t0 + k_steps on return.  The caller's call counter advances by k_steps.  `params` points at the env's
  * pomdp_<env>_params; `reward` is int32 or float per env.  n and lane0 must be multiples of 4. */
 int pomdp_rollout_synthetic(int env, const void *params, uint32_t *state, int32_t *action, int32_t *ob,
                             void *reward, uint8_t *done, uint32_t *err, int64_t n, uint64_t seed,

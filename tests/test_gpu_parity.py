@@ -158,19 +158,26 @@ def test_sharding_invariance():
         assert torch.equal(full.state, torch.cat([lo.state, hi.state], dim=1))
 
 
-def test_c_rollout_driver_equals_python_loop():
-    """pomdp_rollout_synthetic issues the same launches as a python loop over step()."""
+@pytest.mark.parametrize("action_seed", [None, 99], ids=["chained-policy", "separate-policy-key"])
+def test_c_rollout_driver_equals_python_loop(action_seed):
+    """pomdp_rollout_synthetic == a python loop over synthetic_actions() + step(), both when the policy
+    shares the env's Philox key (actions for t+1 are produced inside the step launch) and when it does
+    not (policy launch + step launch per step)."""
     n, seed = 16384, 5
-    for env, kw in (("rock", {}), ("tag", {}), ("battleship", {}), ("network", {})):
+    for env, kw in (("rock", {}), ("rock", dict(board_size=15, num_rocks=15)), ("rock", dict(board_size=4, num_rocks=3)),
+                    ("tag", {}), ("battleship", {}), ("tiger", {}), ("network", {})):
         a = make_env(env, kw, batch_size=n, seed=seed, reuse_buffers=True)
         b = make_env(env, kw, batch_size=n, seed=seed)
         a.reset()
         b.reset()
-        a.rollout_synthetic(25, action_seed=99)
+        scratch = torch.empty(n, dtype=torch.int32, device="cuda")
+        a.rollout_synthetic(25, action_seed=action_seed, actions=scratch)
+        # on return the buffer holds the policy's actions for the next call counter
+        assert torch.equal(scratch, a.synthetic_actions(seed=action_seed))
         for _ in range(25):
-            ob, rew, done, _ = b.step(b.synthetic_actions(seed=99))
+            ob, rew, done, _ = b.step(b.synthetic_actions(seed=action_seed))
         assert a.call_counter == b.call_counter
-        assert torch.equal(a.state, b.state)
+        assert torch.equal(a.state, b.state), env
         assert torch.equal(a._ob, ob) and torch.equal(a._reward, rew) and torch.equal(a._done.view(torch.bool), done)
 
 
