@@ -139,7 +139,7 @@ def rollout_mode(args, env, cp, dev, rank, world, label):
     cp.close()
 
 
-def measured_traffic(env_key):
+def measured_traffic(env_key, chained=False):
     """HBM bytes per step-kernel launch from the committed PMC passes (profiles/traffic_*.json, produced by
     tools/gpu_profile.sh: separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this command)."""
     name = {"rock": "traffic_rock_7_8.json"}.get(env_key)
@@ -148,7 +148,8 @@ def measured_traffic(env_key):
         return None, None
     with open(path) as f:
         t = json.load(f)
-    return t["hbm_bytes_per_launch"], "profiles/" + name
+    key = "chain" if chained and "chain" in t else "plain"
+    return t[key]["hbm_bytes_per_launch"], "profiles/%s [%s]" % (name, key)
 
 
 def main():
@@ -199,12 +200,18 @@ def main():
     env.reset()
     run_steps(args.warmup)
     barrier()
+    tev0, tev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    tev0.record()
     run_steps(args.steps)
+    tev1.record()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     barrier()
     elapsed = cp.max(elapsed)
+    # HIP events on the launch stream over the timed region: with the chained policy the region is one
+    # step launch per step (plus one policy launch per 100 steps), so this is that kernel's average duration
+    timed_kernel_ms = tev0.elapsed_time(tev1) / args.steps
 
     # ---- roofline of the dominant kernel: the step kernel alone, HIP events on its stream --------
     # A ring of pre-generated action batches keeps the action distribution of the timed region
@@ -224,11 +231,14 @@ def main():
         env.step(ring[j & 15])
     ev1.record()
     torch.cuda.synchronize(dev)
-    kern_ms = ev0.elapsed_time(ev1) / args.steps
+    plain_ms = ev0.elapsed_time(ev1) / args.steps
+    plain_achieved = bytes_per_step * n / (plain_ms * 1e-3) / 1e9
+    chained = args.host_loop == "c" and action_seed == args.seed
+    kern_ms = timed_kernel_ms if chained else plain_ms
     achieved = bytes_per_step * n / (kern_ms * 1e-3) / 1e9
     invalid = env.invalid_action_count()
 
-    traffic, traffic_src = measured_traffic(args.env) if n == 1 << 20 else (None, None)
+    traffic, traffic_src = measured_traffic(args.env, chained) if n == 1 << 20 else (None, None)
     if rank == 0:
         total_lanes = n * world
         out = {
@@ -250,10 +260,15 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch",
                          "traffic_source": traffic_src,
-                         "kernel": "step_kernel<%s>" % args.env, "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_step": bytes_per_step,
-                         "note": "step kernel launched back-to-back %d times on a ring of 16 pre-generated action "
-                                 "batches, HIP events on its stream; event time includes inter-launch gaps" % args.steps},
+                         "kernel": ("step_kernel<%s, chain> (step + next-step policy, the launch of the timed region)"
+                                    if chained else "step_kernel<%s>") % args.env,
+                         "kernel_ms": kern_ms, "algorithmic_bytes_per_step": bytes_per_step,
+                         "plain_step_kernel": {"kernel": "step_kernel<%s> (what env.step() launches)" % args.env,
+                                               "kernel_ms": plain_ms, "achieved": plain_achieved,
+                                               "frac": plain_achieved / HBM_PEAK_GBS},
+                         "note": "kernel_ms: HIP events on the launch stream over the timed region (%d back-to-back "
+                                 "launches, gaps included); plain_step_kernel: the same with env.step() on a ring "
+                                 "of 16 pre-generated action batches" % args.steps},
             "invalid_actions": invalid,
         }
         if world == 1 and not args.no_cpu_baseline:

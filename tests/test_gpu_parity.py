@@ -78,6 +78,11 @@ ORACLE_CASES = [
     ("tiger", {}, 32768, 32),
     ("network", {}, 32768, 32),
     ("network", dict(n_machines=31, problem_type=3), 4096, 16),
+    ("rock", {}, 4004, 40),                                         # ragged: not a multiple of the wave / workgroup size
+    ("rock", dict(board_size=7, num_rocks=7), 1028, 40),            # odd K: last Philox block half used
+    ("rock", dict(board_size=2, num_rocks=1), 260, 24),
+    ("tag", dict(num_opponents=4), 516, 80),
+    ("battleship", dict(board_size=(8, 6), max_len=4), 1020, 120),
 ]
 
 
@@ -126,6 +131,28 @@ def test_no_auto_reset_freezes(oracle_lib, env, kw):
         assert np.array_equal(np_(done_g), done.astype(bool))
         assert np.array_equal(np_(e.state).view(np.uint32), st)
     assert done.sum() > 0
+
+
+def test_odd_batch_sizes_without_synthetic_policy(oracle_lib):
+    """batch sizes 1, 2, 3, 63, 65, 257 with host-provided actions (no multiple-of-4 requirement)."""
+    for n in (1, 2, 3, 63, 65, 257):
+        o = oracle_lib.OracleEnv("rock")
+        e = make_env("rock", {}, batch_size=n, seed=8, lane_offset=3, auto_reset=True)
+        st = o.new_state(n)
+        ob0 = o.batch_reset(st, 8, 3, 0)
+        r = e.reset()
+        assert np.array_equal(np.atleast_1d(np_(r) if n > 1 else r), ob0)
+        rs = np.random.RandomState(n)
+        for t in range(1, 30):
+            a = rs.randint(13, size=n).astype(np.int32)
+            ob, rew, done, _ = o.batch_step(st, a, 8, 3, t)
+            if n == 1:
+                o1, r1, d1, _ = e.step(int(a[0]))
+                assert (o1, r1, d1) == (int(ob[0]), int(rew[0]), bool(done[0]))
+            else:
+                og, rg, dg, _ = e.step(a)
+                assert np.array_equal(np_(og), ob) and np.array_equal(np_(rg), rew) and np.array_equal(np_(dg), done.astype(bool))
+            assert np.array_equal(np_(e.state).view(np.uint32), st)
 
 
 def test_invalid_actions_are_counted_and_ignored():

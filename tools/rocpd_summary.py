@@ -36,7 +36,32 @@ def pmc_stats(db):
     return "\n".join(out)
 
 
+def traffic_json(root, out_path, workload):
+    """profiles/traffic_*.json: HBM bytes per launch of the plain and the chained step kernel from the two
+    PMC passes (FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM, calibrated on the known read volume)."""
+    import json
+    f, w = db_of(os.path.join(root, "pmc_fetch")), db_of(os.path.join(root, "pmc_write"))
+    out = {"workload": workload, "fetch_correction": "x2 (gfx950 FETCH_SIZE reports half of a coalesced stream; "
+           "calibrated: the step kernels read exactly 8192 KB of state + action per launch)",
+           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of `python bench.py --steps 100 "
+                     "--no-cpu-baseline` (tools/gpu_profile.sh)"}
+    for key, pat in (("plain", "%step_kernel%false%"), ("chain", "%step_kernel%true%")):
+        vals = []
+        for db, cn in ((f, "FETCH_SIZE"), (w, "WRITE_SIZE")):
+            r = sqlite3.connect(db).execute("select avg(value), count(*) from counters_collection where counter_name=? "
+                                            "and kernel_name like ?", (cn, pat)).fetchone()
+            vals.append(r)
+        if vals[0][0] is None:
+            continue
+        out[key] = {"fetch_size_kb_reported": vals[0][0], "write_size_kb_reported": vals[1][0],
+                    "dispatches_sampled": [vals[0][1], vals[1][1]],
+                    "hbm_bytes_per_launch": int((2 * vals[0][0] + vals[1][0]) * 1024)}
+    json.dump(out, open(out_path, "w"), indent=1)
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[2] == "--traffic":
+        return traffic_json(sys.argv[1], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else "")
     root = sys.argv[1]
     for sub, fn, title in (("trace", kernel_stats, "rocprofv3 --kernel-trace --stats (durations)"),
                            ("pmc_fetch", pmc_stats, "rocprofv3 --pmc FETCH_SIZE (KB per dispatch, as reported)"),
