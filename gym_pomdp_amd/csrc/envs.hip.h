@@ -409,12 +409,16 @@ struct BattleShipEnv {
     using Reward = int32_t;
     static constexpr int WORDS = 2 * MW;
     struct Shared { int unused; };
-    struct State { uint32_t occ[MW], vis[MW]; };
+    // The mask words live in 4-wide vector registers (never in an addressable array: a dynamically indexed
+    // array would be spilled to LDS by the compiler); words >= MW stay zero.
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    struct State { v4u occ, vis; };
 
     static __device__ __forceinline__ void stage(Shared &, const Params &, int) {}
     static __device__ __forceinline__ int n_actions(const Params &p) { return p.x_size * p.y_size; }
     static __device__ __forceinline__ void load(State &st, const uint32_t *state, int64_t n, int64_t i)
     {
+        st.occ = (v4u)(0u); st.vis = (v4u)(0u);
 #pragma unroll
         for (int j = 0; j < MW; ++j) { st.occ[j] = state[(int64_t)j * n + i]; st.vis[j] = state[(int64_t)(MW + j) * n + i]; }
     }
@@ -428,18 +432,17 @@ struct BattleShipEnv {
             for (int j = 0; j < MW; ++j) state[(int64_t)j * n + i] = st.occ[j];
         }
     }
-    static __device__ __forceinline__ uint32_t word_of(const uint32_t (&m)[MW], int a)
+    static __device__ __forceinline__ uint32_t word_of(const v4u &m, int a)
     {
-        uint32_t w = m[0];
-#pragma unroll
-        for (int j = 1; j < MW; ++j) w = (a >> 5) == j ? m[j] : w;
-        return w;
+        const int j = a >> 5;
+        return j == 0 ? m.x : j == 1 ? m.y : j == 2 ? m.z : m.w;
     }
-    static __device__ __forceinline__ bool bit(const uint32_t (&m)[MW], int a) { return (word_of(m, a) >> (a & 31)) & 1u; }
-    static __device__ __forceinline__ void set_bit(uint32_t (&m)[MW], int a)
+    static __device__ __forceinline__ bool bit(const v4u &m, int a) { return (word_of(m, a) >> (a & 31)) & 1u; }
+    static __device__ __forceinline__ void set_bit(v4u &m, int a)
     {
-#pragma unroll
-        for (int j = 0; j < MW; ++j) m[j] |= (a >> 5) == j ? (1u << (a & 31)) : 0u;
+        const int j = a >> 5;
+        const uint32_t b = 1u << (a & 31);
+        m.x |= j == 0 ? b : 0u; m.y |= j == 1 ? b : 0u; m.z |= j == 2 ? b : 0u; m.w |= j == 3 ? b : 0u;
     }
     static __device__ __forceinline__ bool occupied(const Params &p, const State &st, int x, int y)
     {
@@ -494,11 +497,75 @@ struct BattleShipEnv {
         return 0;
     }
 
-    // Called convergently by every lane of the wave; `fresh` marks the lanes that start a new episode.
-    static __device__ __forceinline__ void reset_where(const Shared &sh, const Params &p, State &st, bool fresh,
+    // Wave-cooperative reset.  A BattleShip reset is a long sequential rejection loop (about 20 attempts on
+    // 10x10, 42 on 5x5) and roughly one wave in five holds a lane that needs one, so run per lane it stalls
+    // 63 other lanes behind ~2000 divergent vector instructions.  Here the whole wave serves one resetting
+    // lane at a time with wave-uniform control flow: one Philox pass yields a 64-word window of that lane's
+    // RESET stream (lane l holds word wbase + l), attempts read their words with v_readlane, and the
+    // placement test is 128-bit mask arithmetic on uniform values, which the compiler keeps on the scalar
+    // unit.  Same words in the same order as reset() above, hence the same boards.
+    static __device__ __forceinline__ void reset_where(const Shared &, const Params &p, State &st, bool fresh,
                                                        const RngKey &key, uint32_t lane)
     {
-        if (fresh) reset(sh, p, st, key, lane);
+        uint64_t todo = __ballot(fresh);
+        if (todo == 0ull) return;                                            // wave-uniform
+        const int me = (int)(threadIdx.x & 63u);
+        const int X = p.x_size, Y = p.y_size, cells = X * Y;
+        const uint32_t rmask = 0xFFFFFFFFu >> __clz((uint32_t)(cells - 1) | 1u); // randint(cells) bit-smear mask
+        u128 col0 = 0;
+        for (int y = 0; y < Y; ++y) col0 |= (u128)1 << (y * X);
+        const u128 colL = col0 << (X - 1);
+        while (todo != 0ull) {
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1ull;
+            const uint32_t glane = (uint32_t)__builtin_amdgcn_readlane((int)lane, src);
+            int wbase = 0, cursor = 0;
+            uint32_t word = 0;
+            auto refill = [&]() {                                            // lane l <- word wbase + l of the stream
+                const uint32_t wi = (uint32_t)(wbase + me);
+                const uint4 b = stream_block(key, glane, POMDP_STREAM_RESET, (wi >> 2) & 0xFFFFFFu);
+                const uint32_t sel = wi & 3u;
+                word = sel == 0 ? b.x : sel == 1 ? b.y : sel == 2 ? b.z : b.w;
+            };
+            auto next_word = [&]() -> uint32_t {
+                if (cursor - wbase >= 64) { wbase += 64; refill(); }
+                const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)word, cursor - wbase);
+                ++cursor;
+                return w;
+            };
+            refill();
+            u128 occ = 0;
+            int remaining = 0;
+            for (int len = p.max_len; len >= 2; --len) {
+                const u128 e = occ & ~col0, w = occ & ~colL;
+                const u128 blocked = occ | (occ >> X) | (occ << X) | (e >> 1) | (w << 1) | (e >> (X + 1)) | (e << (X - 1)) |
+                                     (w << (X + 1));
+                int a0, stride;
+                for (;;) {
+                    uint32_t v;
+                    do { v = next_word() & rmask; } while (v > (uint32_t)(cells - 1));   // np.random.randint(n_tiles)
+                    a0 = (int)v;
+                    const uint32_t dir = next_word() & 3u;                               // np.random.randint(4)
+                    const int dx = (dir == 1u) - (dir == 3u), dy = (dir == 0u) - (dir == 2u);
+                    const int px = a0 % X, py = a0 / X;
+                    const int ex = px + (len + 1) * dx, ey = py + (len + 1) * dy;
+                    stride = dy * X + dx;
+                    if (!((unsigned)ex < (unsigned)X && (unsigned)ey < (unsigned)Y)) continue;
+                    const int lo = stride > 0 ? a0 : a0 + len * stride;
+                    const int gap = stride > 0 ? stride : -stride;
+                    u128 cellsm = 0;
+                    for (int i = 0; i <= len; ++i) cellsm |= (u128)1 << (lo + i * gap);
+                    if ((cellsm & blocked) == 0) break;
+                }
+                for (int i = 0; i < len; ++i) occ |= (u128)1 << (a0 + i * stride);
+                remaining += len;
+            }
+            if (me == src) {
+#pragma unroll
+                for (int j = 0; j < MW; ++j) { st.occ[j] = (uint32_t)(occ >> (32 * j)); st.vis[j] = 0u; }
+                st.vis[MW - 1] = (uint32_t)remaining << 26;
+            }
+        }
     }
     static __device__ __forceinline__ void reset_where_chain(const Shared &sh, const Params &p, State &st, bool fresh,
                                                              const RngKey &key, uint32_t lane, const RngKey &akey,
