@@ -13,7 +13,7 @@ _REPO = os.path.dirname(_PKG)
 LIB_PATH = os.path.join(_PKG, "_lib", "libpomdp_hip.so")
 SOURCES = [os.path.join(_PKG, "csrc", f) for f in ("pomdp_kernels.hip", "envs.hip.h", "philox.hip.h")]
 HEADER = os.path.join(_REPO, "include", "pomdp_hip.h")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 POMDP_AUTO_RESET = 1
 POMDP_ROLLOUT_ALL_ACTIONS = 1
@@ -25,14 +25,14 @@ SYMBOLS = [
     "pomdp_rock_reset", "pomdp_rock_step", "pomdp_tag_reset", "pomdp_tag_step",
     "pomdp_battleship_reset", "pomdp_battleship_step", "pomdp_tiger_reset", "pomdp_tiger_step",
     "pomdp_network_reset", "pomdp_network_step", "pomdp_synthetic_actions", "pomdp_philox_blocks",
-    "pomdp_rollout_synthetic", "pomdp_legal_actions", "pomdp_rollout",
+    "pomdp_rollout_synthetic", "pomdp_legal_actions", "pomdp_rollout", "pomdp_compute_prob",
 ]
 
 
 class RockParams(C.Structure):
     _fields_ = [("size", C.c_int32), ("num_rocks", C.c_int32), ("start_x", C.c_int32), ("start_y", C.c_int32),
                 ("rock_x", C.c_int8 * 16), ("rock_y", C.c_int8 * 16), ("grid", C.c_int8 * 256),
-                ("thr", C.c_uint64 * 32)]
+                ("thr", C.c_uint64 * 32), ("eff", C.c_double * 32)]
 
 
 class TagParams(C.Structure):
@@ -106,6 +106,8 @@ def lib():
     L.pomdp_rollout_synthetic.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, i64, u64, u64, u32, u64, i64, ci, vp]
     L.pomdp_legal_actions.restype = ci
     L.pomdp_legal_actions.argtypes = [ci, vp, vp, vp, vp, i64, ci, vp]
+    L.pomdp_compute_prob.restype = ci
+    L.pomdp_compute_prob.argtypes = [ci, vp, vp, vp, vp, vp, i64, vp]
     L.pomdp_rollout.restype = ci
     L.pomdp_rollout.argtypes = [ci, vp, vp, i64, i64, ci, C.c_double, ci, u64, u32, u64, vp, vp, vp, vp, vp, vp]
     L.pomdp_philox_blocks.restype = ci

@@ -241,6 +241,19 @@ struct RockEnv {
         return legal_count(sh, p, st, pre, n_pre, alive);
     }
 
+    // rock.py:250-264 _compute_prob
+    static __device__ __forceinline__ double compute_prob(const Shared &sh, const Params &p, const State &st, int a, int ob)
+    {
+        if (a <= 4) return ob == 0 ? 1.0 : 0.0;
+        const S s = st.s;
+        const int x = (int)(s & 15u), y = (int)((s >> 4) & 15u), r = (a - 5) & 15;
+        const uint32_t rxy = sh.rxy[r];
+        const double eff = p.eff[abs(x - (int)(rxy & 15u)) + abs(y - (int)(rxy >> 4))];
+        const uint32_t code = (uint32_t)(s >> (8 + 2 * r)) & 3u;               // status + 1
+        if ((ob == 2 && code == 2u) || (ob == 1 && code == 0u)) return eff;
+        return 1 - eff;
+    }
+
     // rock.py:123-194 step; 401-407 _sample_ob; 383-387 _efficiency; coord.py:133-135 (L1 distance).
     // Branch-free: the three action classes (move / SAMPLE / CHECK) are all evaluated and selected,
     // so a wave with mixed actions — every wave, under a random policy — runs one straight line.
@@ -349,6 +362,16 @@ struct TagEnv {
     // tag.py:228-229: every action is legal
     static __device__ __forceinline__ int legal_count(const Shared &, const Params &p, const State &) { return n_actions(p); }
     static __device__ __forceinline__ int legal_nth(const Shared &, const Params &, const State &, int idx) { return idx; }
+
+    // tag.py:209-217 _compute_prob
+    static __device__ __forceinline__ double compute_prob(const Shared &, const Params &p, const State &st, int, int ob)
+    {
+        const uint32_t w = st.w, agent = w & 31u;
+        if (ob == p.obs_cells)
+            for (int j = 0; j < p.num_opponents; ++j)
+                if (((w >> (5 + 5 * j)) & 31u) == agent) return 1.0;
+        return ob == (int)agent ? 1.0 : 0.0;
+    }
 
     // tag.py:108-143 step, 201-207 move_opponent, 260-280 _admissable_actions
     template <class RT>
@@ -604,6 +627,14 @@ struct BattleShipEnv {
         return a;
     }
 
+    // battleship.py:80-89 _compute_prob (reads the grid as it is after the shot)
+    static __device__ __forceinline__ double compute_prob(const Shared &, const Params &, const State &st, int a, int ob)
+    {
+        if (ob == 0 && bit(st.vis, a)) return 1.0;
+        if (ob == 1 && bit(st.occ, a)) return 1.0;
+        return ob == 0 ? 1.0 : 0.0;
+    }
+
     // battleship.py:91-122
     template <class RT>
     static __device__ __forceinline__ void step(const Shared &, const Params &p, State &st, int a,
@@ -660,6 +691,14 @@ struct TigerEnv {
     // tiger.py:111-112: every action is legal
     static __device__ __forceinline__ int legal_count(const Shared &, const Params &p, const State &) { return n_actions(p); }
     static __device__ __forceinline__ int legal_nth(const Shared &, const Params &, const State &, int idx) { return idx; }
+
+    // tiger.py:125-138 _compute_prob
+    static __device__ __forceinline__ double compute_prob(const Shared &, const Params &, const State &st, int a, int ob)
+    {
+        if (a == 2 && ob != 2) return ((int)(st.w & 1u) == ob) ? .85 : 1 - .85;
+        if (a != 2 && ob == 2) return 1.0;
+        return 0.0;
+    }
 
     // tiger.py:72-88 step, 117-119 _sample_state, 140-149 _sample_ob, 155-172
     template <class RT>
@@ -719,6 +758,13 @@ struct NetworkEnv {
     // network.py:130-131: every action is legal
     static __device__ __forceinline__ int legal_count(const Shared &, const Params &p, const State &) { return n_actions(p); }
     static __device__ __forceinline__ int legal_nth(const Shared &, const Params &, const State &, int idx) { return idx; }
+
+    // network.py:43-55 _compute_prob
+    static __device__ __forceinline__ double compute_prob(const Shared &, const Params &p, const State &st, int a, int ob)
+    {
+        if (a < 2 * p.n_machines) return ((int)((st.w >> (a >> 1)) & 1u) == ob) ? .95 : 1 - .95;
+        return ob == 2 ? 1.0 : 0.0;
+    }
 
     // network.py:71-114.  The reference draws one double per *up* machine in index order, then one for
     // the action.  Lanes iterate over the draws (j = 0, 1, ...), not over the machines: j is

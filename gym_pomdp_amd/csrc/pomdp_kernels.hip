@@ -137,6 +137,22 @@ __global__ __launch_bounds__(BLOCK) void legal_kernel(const typename Env::Params
     for (int k = 0; k < stride; ++k) list[i * stride + k] = k < c ? Env::legal_nth(sh, p, st, k) : -1;
 }
 
+template <class Env>
+__global__ __launch_bounds__(BLOCK) void prob_kernel(const typename Env::Params p, const uint32_t *__restrict__ state,
+                                                     const int32_t *__restrict__ action, const int32_t *__restrict__ ob,
+                                                     double *__restrict__ out, int64_t n)
+{
+    __shared__ typename Env::Shared sh;
+    Env::stage(sh, p, (int)threadIdx.x);
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    typename Env::State st;
+    Env::load(st, state, n, i);
+    const int a = action[i];
+    out[i] = (unsigned)a < (unsigned)Env::n_actions(p) ? Env::compute_prob(sh, p, st, a, ob[i]) : 0.0;
+}
+
 // Lane i simulates from root state column i / sims_per_root for up to `depth` steps: the state lives
 // in registers, the policy draw (stream ROLLOUT) and the env draws (stream STEP) come from the lane's
 // own Philox streams at t0 + k, the discounted return accumulates in IEEE double with separate
@@ -290,6 +306,16 @@ static int launch_legal(const typename Env::Params &p, const uint32_t *state, in
     if (n == 0) return 0;
     hipLaunchKernelGGL(legal_kernel<Env>, dim3(blocks_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, p, state, list, len,
                        n, stride);
+    return (int)hipGetLastError();
+}
+template <class Env>
+static int launch_prob(const typename Env::Params &p, const uint32_t *state, const int32_t *action, const int32_t *ob,
+                       double *out, int64_t n, void *stream)
+{
+    if (!state || !action || !ob || !out || n < 0) return POMDP_E_BADARG;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(prob_kernel<Env>, dim3(blocks_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, p, state, action, ob,
+                       out, n);
     return (int)hipGetLastError();
 }
 template <class Env>
@@ -573,6 +599,13 @@ int pomdp_legal_actions(int env, const void *params, const uint32_t *state, int3
 {
     if (!params) return POMDP_E_BADARG;
     POMDP_DISPATCH(env, params, return launch_legal<E>(*p, state, list, len, n, stride, stream))
+}
+
+int pomdp_compute_prob(int env, const void *params, const uint32_t *state, const int32_t *action, const int32_t *ob,
+                       double *out, int64_t n, void *stream)
+{
+    if (!params) return POMDP_E_BADARG;
+    POMDP_DISPATCH(env, params, return launch_prob<E>(*p, state, action, ob, out, n, stream))
 }
 
 int pomdp_rollout(int env, const void *params, const uint32_t *root_state, int64_t n_roots, int64_t sims_per_root,

@@ -245,6 +245,27 @@ class BatchedEnv(object):
             return lst[0, : int(ln.item())].tolist()
         return lst, ln
 
+    def compute_prob(self, action, ob, state=None):
+        """`_compute_prob(action, next_state, ob)` per lane -> float64[N]: the likelihood of `ob` given that
+        `action` led to `state` (default: the live state)."""
+        st = self._state if state is None else torch.as_tensor(state, dtype=torch.int32, device=self.device)
+        st = st.reshape(self.state_words, -1).contiguous()
+        n = st.shape[1]
+        a = torch.as_tensor(action, device=self.device).to(torch.int32).reshape(n).contiguous()
+        o = torch.as_tensor(ob, device=self.device).to(torch.int32).reshape(n).contiguous()
+        out = torch.empty(n, dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self._lib.pomdp_compute_prob(_native.ENV_KIND[self.env_name], self._params_ref, st.data_ptr(),
+                                              a.data_ptr(), o.data_ptr(), out.data_ptr(), n, self._stream())
+            _native.check(rc, "pomdp_compute_prob")
+        return out
+
+    def _compute_prob(self, action, next_state, ob):
+        """Reference signature.  batch_size == 1: python scalars in, float out."""
+        if self.batch_size == 1 and not isinstance(action, torch.Tensor):
+            return float(self.compute_prob([int(action)], [int(ob)], next_state).item())
+        return self.compute_prob(action, ob, next_state)
+
     def rollout(self, depth, sims_per_root=1, roots=None, discount=None, all_actions=False, lane_offset=None):
         """Random rollouts from `roots` (packed states int32 [state_words, R]; default: the live state):
         R * sims_per_root independent simulations of at most `depth` steps under a uniform policy over

@@ -25,6 +25,7 @@ def make_params(board_size=7, num_rocks=8):
         p.rock_x[idx], p.rock_y[idx] = x, y
     for d in range(32):
         p.thr[d] = tables.ROCK_THR[min(d, len(tables.ROCK_THR) - 1)]
+        p.eff[d] = tables.ROCK_EFF[min(d, len(tables.ROCK_EFF) - 1)]
     words = 1 if num_rocks <= 12 else 2
     return p, words, 5 + num_rocks, 3
 

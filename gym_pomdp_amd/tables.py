@@ -31,6 +31,18 @@ ROCK_THR = (
     6463905223604296, 6397130018567403, 6332629422150863, 6270325952834808,
     6210144768404375,
 )
+ROCK_EFF_HEX = (
+    "0x1.0000000000000p+0", "0x1.f7479a6ec0218p-1", "0x1.eedb4008bd589p-1", "0x1.e6b859ae6b1b6p-1",
+    "0x1.dedc66d6df090p-1", "0x1.d744fccad69d6p-1", "0x1.cfefc5e67299fp-1", "0x1.c8da80e16d9f0p-1",
+    "0x1.c203001d9572ep-1", "0x1.bb6728fb505dcp-1", "0x1.b504f333f9de6p-1", "0x1.aeda6839e3c90p-1",
+    "0x1.a8e5a29dca9b6p-1", "0x1.a324cd798d804p-1", "0x1.9d9623dffc194p-1", "0x1.9837f0518db8ap-1",
+    "0x1.93088c35d733ap-1", "0x1.8e065f5995efcp-1", "0x1.892fdf7128332p-1", "0x1.84838f9f4c1d6p-1",
+    "0x1.8000000000000p-1", "0x1.7ba3cd376010cp-1", "0x1.776da0045eac4p-1", "0x1.735c2cd7358dbp-1",
+    "0x1.6f6e336b6f848p-1", "0x1.6ba27e656b4ebp-1", "0x1.67f7e2f3394cfp-1", "0x1.646d4070b6cf8p-1",
+    "0x1.6101800ecab97p-1",
+)
+# eff(d) = (1 + 2**(-d/20)) / 2 as the reference's float64 arithmetic produces it (rock.py:383-387); _compute_prob returns it
+ROCK_EFF = tuple(float.fromhex(h) for h in ROCK_EFF_HEX)
 TAG_MOVE_THR = 7205759403792794          # binomial(1, .8)  -> 1 iff k <= thr   (tag.py:204)
 NET_FAIL_THR = 8106479329266893          # binomial(1, .1)  -> 1 iff k >  thr   (network.py:97)
 NET_FAIL_NEIGHBOUR_THR = 6034823500676464  # binomial(1, .33) -> 1 iff k >  thr (network.py:99)

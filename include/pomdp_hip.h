@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define POMDP_ABI_VERSION 1
+#define POMDP_ABI_VERSION 2
 
 enum {
     POMDP_E_BADARG = -1,     /* NULL pointer, n < 0, n + lane0 > 2^32 */
@@ -66,6 +66,7 @@ typedef struct pomdp_rock_params {
     int8_t   rock_x[16], rock_y[16];                                   /* rock.py:106 */
     int8_t   grid[256];     /* grid[x * 16 + y] = rock id stamped at (x, y) or -1    rock.py:110-111 */
     uint64_t thr[32];       /* thr[d]: sensor correct iff k53 <= thr[d], d = L1 distance  rock.py:383-407 */
+    double   eff[32];       /* eff(d) itself, returned by pomdp_compute_prob            rock.py:383-387 */
 } pomdp_rock_params;
 
 /* replaces RockEnv.reset (rock.py:236-241, 266-271, 78-86).  ob (device, may be NULL) <- 0. */
@@ -174,6 +175,12 @@ int pomdp_rollout_synthetic(int env, const void *params, uint32_t *state, int32_
  * lane's legal actions in the reference's list order, padded with -1; len (device, int32 [n]) their number. */
 int pomdp_legal_actions(int env, const void *params, const uint32_t *state, int32_t *list, int32_t *len,
                         int64_t n, int stride, void *stream);
+
+/* replaces <Env>._compute_prob(action, next_state, ob) (rock.py:250-264, tag.py:209-217, battleship.py:80-89,
+ * tiger.py:125-138, network.py:43-55): the likelihood of observing ob[i] after action[i] led to state column i
+ * (BattleShip reads the grid, i.e. the state after the shot, as the reference does).  out: device double[n]. */
+int pomdp_compute_prob(int env, const void *params, const uint32_t *state, const int32_t *action, const int32_t *ob,
+                       double *out, int64_t n, void *stream);
 
 /* Random rollouts — the simulations a POMCP-style planner runs through _set_state / _generate_legal /
  * step / _discount.  Lane i (global id lane0 + i, i < n_roots * sims_per_root) starts from

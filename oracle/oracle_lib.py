@@ -48,6 +48,7 @@ def lib():
         L.or_batch_legal.argtypes = [vp, vp, vp, vp, C.c_int64]
         L.or_batch_rollout.argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_int, C.c_double, C.c_int, C.c_uint64,
                                        C.c_uint32, C.c_uint64, vp, vp, vp, vp, vp, C.c_int]
+        L.or_batch_compute_prob.argtypes = [vp, vp, vp, vp, vp, C.c_int64]
         L.or_bench_loop.restype = C.c_double
         L.or_bench_loop.argtypes = [vp, C.c_int64, C.c_int64, C.c_uint64, C.c_int, vp]
         L.or_max_threads.restype = C.c_int
@@ -172,6 +173,17 @@ def _bench_loop(self, n, steps, seed, nthreads):
     return float(lib().or_bench_loop(self._h, n, steps, seed, nthreads, C.byref(nd)))
 
 
+def _batch_compute_prob(self, state, action, ob):
+    """`_compute_prob(action, next_state=current state, ob)` per lane -> float64[n]"""
+    n = state.shape[1]
+    a = np.ascontiguousarray(action, np.int32)
+    o = np.ascontiguousarray(ob, np.int32)
+    out = np.zeros(n, np.float64)
+    lib().or_batch_compute_prob(self._h, _ptr(np.ascontiguousarray(state)), _ptr(a), _ptr(o), _ptr(out), n)
+    return out
+
+
+OracleEnv.batch_compute_prob = _batch_compute_prob
 OracleEnv.bench_loop = _bench_loop
 OracleEnv.batch_legal = _batch_legal
 OracleEnv.batch_rollout = _batch_rollout

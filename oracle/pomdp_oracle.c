@@ -952,3 +952,69 @@ void or_batch_rollout(const or_env *proto, const uint32_t *state, int64_t n_root
         }
     }
 }
+
+/* ======================================================================== */
+/* planner hook: observation likelihood _compute_prob(action, next_state, ob) */
+/* ======================================================================== */
+/* rock.py:383-387 eff(d) = (1 + pow(2, -d / 20)) * .5 for L1 distance d, captured from the reference
+ * (tests/golden/thresholds.json: rock_eff_hex) */
+static const double ROCK_EFF[29] = {
+    0x1.0000000000000p+0, 0x1.f7479a6ec0218p-1, 0x1.eedb4008bd589p-1, 0x1.e6b859ae6b1b6p-1,
+    0x1.dedc66d6df090p-1, 0x1.d744fccad69d6p-1, 0x1.cfefc5e67299fp-1, 0x1.c8da80e16d9f0p-1,
+    0x1.c203001d9572ep-1, 0x1.bb6728fb505dcp-1, 0x1.b504f333f9de6p-1, 0x1.aeda6839e3c90p-1,
+    0x1.a8e5a29dca9b6p-1, 0x1.a324cd798d804p-1, 0x1.9d9623dffc194p-1, 0x1.9837f0518db8ap-1,
+    0x1.93088c35d733ap-1, 0x1.8e065f5995efcp-1, 0x1.892fdf7128332p-1, 0x1.84838f9f4c1d6p-1,
+    0x1.8000000000000p-1, 0x1.7ba3cd376010cp-1, 0x1.776da0045eac4p-1, 0x1.735c2cd7358dbp-1,
+    0x1.6f6e336b6f848p-1, 0x1.6ba27e656b4ebp-1, 0x1.67f7e2f3394cfp-1, 0x1.646d4070b6cf8p-1,
+    0x1.6101800ecab97p-1 };
+
+double or_env_compute_prob(const or_env *e, int action, int ob)
+{
+    switch (e->kind) {
+    case OR_ENV_ROCK: {                                        /* rock.py:250-264 */
+        if (action <= 4) return ob == 0;
+        int rock = action - 5;
+        int dx = e->agent.x - e->rock_pos[rock].x, dy = e->agent.y - e->rock_pos[rock].y;
+        double eff = ROCK_EFF[(dx < 0 ? -dx : dx) + (dy < 0 ? -dy : dy)];
+        if (ob == 2 && e->status[rock] == 1) return eff;
+        if (ob == 1 && e->status[rock] == -1) return eff;
+        return 1 - eff;
+    }
+    case OR_ENV_TAG: {                                         /* tag.py:209-217 */
+        int p_ob = ob == tag_index(e->agent);
+        if (ob == e->obs_cells)
+            for (int i = 0; i < e->n_opponents; i++)
+                if (e->opp[i].x == e->agent.x && e->opp[i].y == e->agent.y) return 1.;
+        return p_ob;
+    }
+    case OR_ENV_BATTLESHIP: {                                  /* battleship.py:80-89: reads the live grid */
+        int x = action % e->xs, y = action / e->xs;
+        if (ob == 0 && e->vis[x][y]) return 1;
+        if (ob == 1 && e->occ[x][y]) return 1;
+        return ob == 0;
+    }
+    case OR_ENV_TIGER: {                                       /* tiger.py:125-138 */
+        double p_ob = 0.0;
+        if (action == 2 && ob != 2) p_ob = (e->tiger == ob) ? .85 : 1 - .85;
+        else if (action != 2 && ob == 2) p_ob = 1.;
+        return p_ob;
+    }
+    default:                                                   /* network.py:43-55 */
+        if (action < e->n_mach * 2) return e->up[action / 2] == ob ? .95 : 1 - .95;
+        if (ob == 2) return 1.;
+        return 0;
+    }
+}
+
+void or_batch_compute_prob(const or_env *proto, const uint32_t *state, const int32_t *action, const int32_t *ob,
+                           double *out, int64_t n)
+{
+    int W = or_env_words(proto);
+    or_env e = *proto;
+    uint32_t w[8];
+    for (int64_t i = 0; i < n; i++) {
+        for (int j = 0; j < W; j++) w[j] = state[(int64_t)j * n + i];
+        or_env_unpack(&e, w);
+        out[i] = or_env_compute_prob(&e, action[i], ob[i]);
+    }
+}

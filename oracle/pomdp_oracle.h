@@ -110,6 +110,11 @@ double or_bench_loop(const or_env *proto, int64_t n, int64_t steps, uint64_t see
 int  or_env_legal(const or_env *e, int *list);
 /* legal lists of every lane of a packed batch: out[n][OR_MAX_LEGAL] padded with -1, len[n] */
 void or_batch_legal(const or_env *proto, const uint32_t *state, int32_t *out, int32_t *len, int64_t n);
+/* `_compute_prob(action, next_state, ob)` with next_state = the env's current state
+ * (rock.py:250-264, tag.py:209-217, battleship.py:80-89, tiger.py:125-138, network.py:43-55) */
+double or_env_compute_prob(const or_env *e, int action, int ob);
+void   or_batch_compute_prob(const or_env *proto, const uint32_t *state, const int32_t *action, const int32_t *ob,
+                             double *out, int64_t n);
 /* Random rollouts (POMCP-style simulations).  Lane i starts from root state column i / sims_per_root
  * (state: uint32 [words][n_roots], read-only) and, for k = 0 .. depth-1 while not done:
  *   list = policy ? all actions : _generate_legal();  w = word 0 of stream ROLLOUT at (seed, lane, t0+k)

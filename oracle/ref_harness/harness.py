@@ -298,3 +298,44 @@ def rollout_reference(name, kwargs, seed, root_lane0, n_roots, sims_per_root, de
                 k += 1
             out["ret"][i], out["n_steps"][i], out["last_ob"][i], out["terminated"][i] = ret, k, int(ob), int(bool(done))
     return out
+
+
+def compute_prob_trace(name, kwargs, seed, lanes, actions, t0=0):
+    """`env._compute_prob(a, info["state"], o)` of the reference for every observation value o, right after
+    each step of a mode-B trace without auto-reset of the queried state (the query is made before reset())."""
+    lanes = list(lanes)
+    actions = np.asarray(actions)
+    L, T = actions.shape
+    space = _space_rng() if name == "tiger" else None
+    out = None
+    for li, lane in enumerate(lanes):
+        env = make_ref_env(name, **kwargs)
+        inject_stream(seed, lane, t0, px.STREAM_RESET)
+        if space is not None:
+            inject_stream(seed, lane, t0, px.STREAM_RESET_SPACE, space)
+        env.reset()
+        n_obs = env.observation_space.n
+        if out is None:
+            out = dict(prob=np.zeros((L, T, n_obs), np.float64), ob=np.zeros((L, T), np.int64),
+                       state_pre=None, done=np.zeros((L, T), np.uint8))
+        for i in range(T):
+            t = t0 + 1 + i
+            inject_stream(seed, lane, t, px.STREAM_STEP)
+            if space is not None:
+                inject_stream(seed, lane, t, px.STREAM_STEP_SPACE, space)
+            a = int(actions[li, i])
+            o, r, d, info = env.step(a)
+            st = compact_state(name, env)
+            if out["state_pre"] is None:
+                out["state_pre"] = np.zeros((L, T, len(st)), np.int64)
+            out["state_pre"][li, i] = st
+            out["ob"][li, i], out["done"][li, i] = int(o), int(bool(d))
+            for q in range(n_obs):
+                out["prob"][li, i, q] = float(env._compute_prob(a, info["state"], q))
+            if d:
+                inject_stream(seed, lane, t, px.STREAM_RESET)
+                if space is not None:
+                    inject_stream(seed, lane, t, px.STREAM_RESET_SPACE, space)
+                env.reset()
+    out.update(lanes=np.asarray(lanes, np.int64), actions=actions.astype(np.int64), seed=np.int64(seed), t0=np.int64(t0))
+    return out

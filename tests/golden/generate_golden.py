@@ -152,6 +152,26 @@ def gen_rollout(case, env, kwargs, R, S, depth, all_actions):
     return int(tr["terminated"].sum()), float(tr["n_steps"].mean())
 
 
+PROB_CASES = [("rock_7_8", "rock", {}, 48, 40), ("rock_15_15", "rock", dict(board_size=15, num_rocks=15), 24, 40),
+              ("tag_1", "tag", {}, 32, 40), ("tag_2", "tag", dict(num_opponents=2), 16, 40),
+              ("battleship_5_5", "battleship", {}, 32, 40), ("tiger", "tiger", {}, 32, 30),
+              ("network_10", "network", {}, 32, 30)]
+
+
+def gen_prob(case, env, kwargs, L, T):
+    nA = n_actions(env, kwargs)
+    tries = 0
+    while True:
+        acts = action_tape(env, nA, np.random.RandomState(4242 + tries), (L, T))
+        try:
+            tr = h.compute_prob_trace(env, kwargs, MODE_B_SEED, range(64, 64 + L), acts, t0=5)
+            break
+        except IndexError:
+            tries += 1
+            assert tries < 50
+    np.savez_compressed(os.path.join(HERE, "prob_%s.npz" % case), **tr)
+
+
 def gen_thresholds():
     def binom_at(p, k):
         h.inject_words([(k >> 26) << 5, (k & ((1 << 26) - 1)) << 6])
@@ -187,6 +207,10 @@ def gen_thresholds():
             assert r0 == 1
         rock.append(int(thr))
     out["rock_thr"] = rock
+    # eff(d) itself, as the reference computes it (rock.py:383-387), for _compute_prob
+    envs = h.load_reference()
+    from gym_pomdp.envs.coord import Coord
+    out["rock_eff_hex"] = [float(envs.RockEnv._efficiency(Coord(0, 0), Coord(d, 0))).hex() for d in range(29)]
     for name, p, sense in (("tag_move", .8, "le"), ("net_fail", .1, "gt"), ("net_fail_neighbour", .33, "gt"),
                            ("net_obs", .95, "le")):
         thr, r0 = bisect(p)
@@ -246,13 +270,16 @@ def main():
     assert h.reference_available(), "needs /root/reference"
     import warnings
     warnings.simplefilter("ignore", RuntimeWarning)  # reference's belief side-stats divide 0/0 (rock.py:191)
+    gen_thresholds()
     if "--rollouts-only" not in sys.argv:
-        gen_thresholds()
         gen_edge_cases()
     for case, env, kwargs, TA, L, TB in (CASES if "--rollouts-only" not in sys.argv else []):
         da = gen_mode_a(case, env, kwargs, TA)
         db, mw = gen_mode_b(case, env, kwargs, L, TB)
         print("%-18s modeA dones=%4d  modeB dones=%5d  max words/call=%d" % (case, da, db, mw), flush=True)
+    for case, env, kwargs, L, T in PROB_CASES:
+        gen_prob(case, env, kwargs, L, T)
+        print("compute_prob %-14s ok" % case, flush=True)
     for case, env, kwargs, R, S, depth, alla in ROLLOUT_CASES:
         nt, ms = gen_rollout(case, env, kwargs, R, S, depth, alla)
         print("rollout %-18s terminated=%4d / %d  mean steps=%.1f" % (case, nt, R * S, ms), flush=True)
@@ -261,6 +288,8 @@ def main():
                              for c in CASES],
                    "rollout_cases": [[c[0], c[1], {k: (list(v) if isinstance(v, tuple) else v) for k, v in c[2].items()}]
                                      for c in ROLLOUT_CASES],
+                   "prob_cases": [[c[0], c[1], {k: (list(v) if isinstance(v, tuple) else v) for k, v in c[2].items()}]
+                                  for c in PROB_CASES],
                    "mode_a_seeds": MODE_A_SEEDS, "mode_b_seed": MODE_B_SEED,
                    "numpy": np.__version__}, f, indent=1)
 

@@ -367,3 +367,42 @@ def test_scalar_planner_hooks():
     assert s0.shape == (1, 1)
     e._set_state(s0)
     assert torch.equal(e.state, s0)
+
+
+def _prob_cases():
+    from conftest import golden_manifest
+    return [(c[0], c[1], {k: (tuple(v) if isinstance(v, list) else v) for k, v in c[2].items()})
+            for c in golden_manifest()["prob_cases"]]
+
+
+PROBS = _prob_cases()
+
+
+@pytest.mark.parametrize("case,env,kw", PROBS, ids=[c[0] for c in PROBS])
+def test_compute_prob_matches_reference(case, env, kw):
+    """pomdp_compute_prob == the reference's _compute_prob for every observation value (fixture prob_*.npz)."""
+    import os
+    from conftest import GOLDEN
+    g = dict(np.load(os.path.join(GOLDEN, "prob_%s.npz" % case)))
+    seed, t0, lane0 = int(g["seed"]), int(g["t0"]), int(g["lanes"][0])
+    L, T, n_obs = g["prob"].shape
+    frozen = make_env(env, kw, batch_size=L, seed=seed, lane_offset=lane0, auto_reset=False)   # keeps terminal states
+    live = make_env(env, kw, batch_size=L, seed=seed, lane_offset=lane0, auto_reset=True)
+    for e in (frozen, live):
+        e.call_counter = t0
+        e.reset()
+    for i in range(T):
+        a = torch.as_tensor(g["actions"][:, i].astype(np.int32), device="cuda")
+        frozen.set_state(live.state)                 # same pre-step state, no lane frozen
+        frozen.call_counter = live.call_counter
+        ob, _, _, _ = frozen.step(a)
+        assert np.array_equal(np_(ob), g["ob"][:, i])
+        assert np.array_equal(np_(frozen.decode_state()), saturate_tag_compact(env, g["state_pre"][:, i]))
+        for q in range(n_obs):
+            got = frozen.compute_prob(a, torch.full((L,), q, dtype=torch.int32, device="cuda"))
+            assert np.array_equal(np_(got), g["prob"][:, i, q]), (case, i, q)
+        live.step(a)
+    s = make_env("tiger", {}, seed=1)
+    s.reset()
+    s.step(2)
+    assert s._compute_prob(2, None, 2) == 0.0 and s._compute_prob(0, None, 2) == 1.0

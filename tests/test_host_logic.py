@@ -42,7 +42,7 @@ def test_bad_arguments_are_rejected_without_a_gpu():
 
 def test_struct_sizes_match_header_layout():
     from gym_pomdp_amd import _native as n
-    assert C.sizeof(n.RockParams) == 16 + 16 + 16 + 256 + 32 * 8
+    assert C.sizeof(n.RockParams) == 16 + 16 + 16 + 256 + 32 * 8 + 32 * 8
     assert C.sizeof(n.TagParams) == 16
     assert C.sizeof(n.BattleShipParams) == 12
     assert C.sizeof(n.TigerParams) == 8

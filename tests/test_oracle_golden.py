@@ -184,3 +184,32 @@ def test_rollouts_and_legal_lists_match_reference(oracle_lib, case, env, kw):
     assert np.array_equal(r["ret"], g["ret"])                 # IEEE double, bit-exact
     for k in ("n_steps", "first_action", "last_ob", "terminated"):
         assert np.array_equal(r[k], g[k].astype(r[k].dtype)), k
+
+
+def _prob_cases():
+    return [(c[0], c[1], {k: (tuple(v) if isinstance(v, list) else v) for k, v in c[2].items()})
+            for c in golden_manifest()["prob_cases"]]
+
+
+PROBS = _prob_cases()
+
+
+@pytest.mark.parametrize("case,env,kw", PROBS, ids=[c[0] for c in PROBS])
+def test_compute_prob_matches_reference(oracle_lib, case, env, kw):
+    """_compute_prob(a, state after the step, o) for every observation value o (fixture prob_*.npz)."""
+    g = dict(np.load(os.path.join(GOLDEN, "prob_%s.npz" % case)))
+    o = oracle_lib.OracleEnv(env, **kw)
+    seed, t0, lane0 = int(g["seed"]), int(g["t0"]), int(g["lanes"][0])
+    L, T, n_obs = g["prob"].shape
+    st = o.new_state(L)
+    o.batch_reset(st, seed, lane0, t0)
+    for i in range(T):
+        a = g["actions"][:, i]
+        pre = st.copy()
+        ob, _, done, _ = o.batch_step(pre, a, seed, lane0, t0 + 1 + i, auto_reset=False)   # terminal state kept
+        assert np.array_equal(ob, g["ob"][:, i])
+        assert np.array_equal(o.batch_compact(pre), saturate_tag_compact(env, g["state_pre"][:, i]))
+        for q in range(n_obs):
+            got = o.batch_compute_prob(pre, a, np.full(L, q))
+            assert np.array_equal(got, g["prob"][:, i, q]), (case, i, q)
+        o.batch_step(st, a, seed, lane0, t0 + 1 + i)                                       # continue with auto-reset
