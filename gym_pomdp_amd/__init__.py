@@ -8,7 +8,7 @@ classes with the same constructor kwargs plus `batch_size`, `device`, `seed`, `a
 import importlib
 
 from . import spaces  # noqa: F401
-from .envs import BattleShipEnv, NetworkEnv, RockEnv, TagEnv, TigerEnv  # noqa: F401
+from .envs import BattleShipEnv, NetworkEnv, RockEnv, StochasticRockEnv, TagEnv, TigerEnv  # noqa: F401
 
 __version__ = "0.1.0"
 
@@ -18,6 +18,7 @@ registry = {
     "Tag-v0": "gym_pomdp_amd.envs:TagEnv",
     "Battleship-v0": "gym_pomdp_amd.envs:BattleShipEnv",
     "Rock-v0": "gym_pomdp_amd.envs:RockEnv",
+    "StochasticRock-v0": "gym_pomdp_amd.envs:StochasticRockEnv",   # the reference's entry point has a typo (line 35)
     "Network-v0": "gym_pomdp_amd.envs:NetworkEnv",
 }
 

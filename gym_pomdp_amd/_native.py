@@ -13,7 +13,7 @@ _REPO = os.path.dirname(_PKG)
 LIB_PATH = os.path.join(_PKG, "_lib", "libpomdp_hip.so")
 SOURCES = [os.path.join(_PKG, "csrc", f) for f in ("pomdp_kernels.hip", "envs.hip.h", "philox.hip.h")]
 HEADER = os.path.join(_REPO, "include", "pomdp_hip.h")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 POMDP_AUTO_RESET = 1
 POMDP_ROLLOUT_ALL_ACTIONS = 1
@@ -32,7 +32,8 @@ SYMBOLS = [
 class RockParams(C.Structure):
     _fields_ = [("size", C.c_int32), ("num_rocks", C.c_int32), ("start_x", C.c_int32), ("start_y", C.c_int32),
                 ("rock_x", C.c_int8 * 16), ("rock_y", C.c_int8 * 16), ("grid", C.c_int8 * 256),
-                ("thr", C.c_uint64 * 32), ("eff", C.c_double * 32)]
+                ("thr", C.c_uint64 * 32), ("eff", C.c_double * 32),
+                ("stochastic", C.c_int32), ("reserved", C.c_int32), ("act_thr", C.c_uint64)]
 
 
 class TagParams(C.Structure):

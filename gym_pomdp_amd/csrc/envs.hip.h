@@ -43,7 +43,8 @@ __device__ __forceinline__ void reset_where_chain_default(const typename Env::Sh
 // ===========================================================================
 // ABLATE is a profiling aid (tools/microbench.hip): bit 0 drops the CHECK Philox block, bit 1 the
 // auto-reset, bit 2 the LDS table lookups.  The product only instantiates ABLATE = 0.
-template <int W, int ABLATE = 0> // W = state words per lane: 1 (K <= 12) or 2
+// STOCH selects StochasticRockEnv (rock.py:428-504).
+template <int W, int ABLATE = 0, bool STOCH = false> // W = state words per lane: 1 (K <= 12) or 2
 struct RockEnv {
     using Params = pomdp_rock_params;
     using Reward = int32_t;
@@ -269,7 +270,12 @@ struct RockEnv {
         const uint32_t rxy = (ABLATE & 4) ? (uint32_t)(r * 17) : sh.rxy[r];
         const int d = abs(x - (int)(rxy & 15u)) + abs(y - (int)(rxy >> 4));
         const uint4 w = (ABLATE & 1) ? make_uint4(lane * 2654435761u, lane, 0, 0) : stream_block(key, lane, POMDP_STREAM_STEP, 0u);
-        const bool correct = k53(w.x, w.y) <= ((ABLATE & 4) ? (uint64_t)d << 48 : sh.thr[d]);
+        // StochasticRock: the first double of the step gates the whole action (rock.py:443), the sensor
+        // draw is then the second double of the same Philox block
+        const bool act = !STOCH || k53(w.x, w.y) <= p.act_thr;
+        const uint64_t k_sensor = STOCH ? k53(w.z, w.w) : k53(w.x, w.y);
+        const int penalty = STOCH ? 0 : -100;                                  // rock.py:117 / rock.py:432
+        const bool correct = k_sensor <= ((ABLATE & 4) ? (uint64_t)d << 48 : sh.thr[d]);
         const bool good = ((uint32_t)(s >> (8 + 2 * r)) & 3u) == 2u;
         const int ob_check = (good == correct) ? 2 : 1;                        // rock.py:404-407
         // SAMPLE (rock.py:160-169); ids >= K raise IndexError in the reference, "no rock" here
@@ -277,18 +283,26 @@ struct RockEnv {
         const int sh_ = 8 + 2 * (id & 15);
         const uint32_t code = (uint32_t)(s >> sh_) & 3u;
         const bool sample_ok = (id >= 0) & (id < K) & (code != 1u);
-        const int rew_sample = sample_ok ? (code == 2u ? 10 : -10) : -100;
+        const int rew_sample = sample_ok ? (code == 2u ? 10 : -10) : penalty;
         const S s_sample = sample_ok ? (S)((s & ~((S)3 << sh_)) | ((S)1 << sh_)) : s;
         // move: 0 N (0,+1)  1 E (+1,0)  2 S (0,-1)  3 W (-1,0)   (coord.py:155-160, rock.py:134-158)
         const int nx = x + (a == 1) - (a == 3), ny = y + (a == 0) - (a == 2);
         const bool inside = ((unsigned)nx < (unsigned)size) & ((unsigned)ny < (unsigned)size);
         const S s_move = inside ? (S)((s & ~(S)0xFF) | (S)(uint32_t)(nx | (ny << 4))) : s;
-        const int rew_move = inside ? 0 : (a == 1 ? 10 : -100);                // east exit / off-grid
+        const int rew_move = inside ? 0 : (a == 1 ? 10 : penalty);             // east exit / off-grid
         const bool is_move = a < 4, is_sample = a == 4;
-        st.s = is_move ? s_move : (is_sample ? s_sample : s);
-        rew = is_move ? rew_move : (is_sample ? rew_sample : 0);
-        ob = (a > 4) ? ob_check : 0;
-        done = is_move ? !inside : (rew == -100);                              // rock.py:139-141, 193
+        if (STOCH) {
+            // penalties are 0 and never terminate (rock.py:503 is commented out); only the east exit ends
+            st.s = act ? (is_move ? s_move : (is_sample ? s_sample : s)) : s;
+            rew = act ? (is_move ? rew_move : (is_sample ? rew_sample : 0)) : 0;
+            ob = (act && a > 4) ? ob_check : 0;
+            done = act && is_move && !inside && a == 1;
+        } else {
+            st.s = is_move ? s_move : (is_sample ? s_sample : s);
+            rew = is_move ? rew_move : (is_sample ? rew_sample : 0);
+            ob = (a > 4) ? ob_check : 0;
+            done = is_move ? !inside : (rew == -100);                          // rock.py:139-141, 193
+        }
     }
 };
 

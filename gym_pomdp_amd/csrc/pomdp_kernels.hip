@@ -285,6 +285,9 @@ static int launch_step_chain(const typename Env::Params &p, uint32_t *state, int
     return (int)hipGetLastError();
 }
 
+using StochRock1 = RockEnv<1, 0, true>;   // StochasticRockEnv, one / two state words
+using StochRock2 = RockEnv<2, 0, true>;
+
 static bool rock_ok(const pomdp_rock_params *p)
 {
     return p && p->size >= 1 && p->size <= 15 && p->num_rocks >= 1 && p->num_rocks <= 16 &&
@@ -343,6 +346,9 @@ using namespace pomdp;
     case POMDP_ENV_ROCK: {                                                                                             \
         const pomdp_rock_params *p = (const pomdp_rock_params *)(params);                                              \
         if (!rock_ok(p)) return POMDP_E_BADPARAMS;                                                                     \
+        if (p->stochastic) {                                                                                           \
+            if (p->num_rocks <= 12) { using E = StochRock1; CALL; } else { using E = StochRock2; CALL; } \
+        }                                                                                                              \
         if (p->num_rocks <= 12) { using E = RockEnv<1>; CALL; } else { using E = RockEnv<2>; CALL; }                     \
     }                                                                                                                  \
     case POMDP_ENV_TAG: {                                                                                              \
@@ -391,6 +397,7 @@ int pomdp_rock_reset(const pomdp_rock_params *p, uint32_t *state, int32_t *ob, i
                      uint32_t lane0, uint64_t t, void *stream)
 {
     if (!rock_ok(p)) return POMDP_E_BADPARAMS;
+    // reset is identical for StochasticRockEnv (it inherits RockEnv.reset)
     return p->num_rocks <= 12 ? launch_reset<RockEnv<1>>(*p, state, ob, n, seed, lane0, t, stream)
                               : launch_reset<RockEnv<2>>(*p, state, ob, n, seed, lane0, t, stream);
 }
@@ -400,6 +407,10 @@ int pomdp_rock_step(const pomdp_rock_params *p, uint32_t *state, const int32_t *
                     void *stream)
 {
     if (!rock_ok(p)) return POMDP_E_BADPARAMS;
+    if (p->stochastic)
+        return p->num_rocks <= 12
+                   ? launch_step<StochRock1>(*p, state, action, ob, reward, done, err, n, seed, lane0, t, flags, stream)
+                   : launch_step<StochRock2>(*p, state, action, ob, reward, done, err, n, seed, lane0, t, flags, stream);
     return p->num_rocks <= 12
                ? launch_step<RockEnv<1>>(*p, state, action, ob, reward, done, err, n, seed, lane0, t, flags, stream)
                : launch_step<RockEnv<2>>(*p, state, action, ob, reward, done, err, n, seed, lane0, t, flags, stream);
@@ -491,7 +502,9 @@ int pomdp_synthetic_actions(int32_t *action, int64_t n, uint64_t seed, uint32_t 
     case POMDP_ENV_ROCK: {                                                                                             \
         const pomdp_rock_params *p = (const pomdp_rock_params *)(params);                                              \
         if (!rock_ok(p)) return POMDP_E_BADPARAMS;                                                                     \
-        if (p->num_rocks <= 12) { POMDP_CHAIN_CALL(RockEnv<1>, p); } else { POMDP_CHAIN_CALL(RockEnv<2>, p); }           \
+        if (p->stochastic) {                                                                                           \
+            if (p->num_rocks <= 12) { POMDP_CHAIN_CALL(StochRock1, p); } else { POMDP_CHAIN_CALL(StochRock2, p); } \
+        } else if (p->num_rocks <= 12) { POMDP_CHAIN_CALL(RockEnv<1>, p); } else { POMDP_CHAIN_CALL(RockEnv<2>, p); }    \
         break;                                                                                                         \
     }                                                                                                                  \
     case POMDP_ENV_TAG: {                                                                                              \
@@ -525,7 +538,9 @@ int pomdp_synthetic_actions(int32_t *action, int64_t n, uint64_t seed, uint32_t 
     case POMDP_ENV_ROCK: {                                                                                             \
         const pomdp_rock_params *p = (const pomdp_rock_params *)(params);                                              \
         if (!rock_ok(p)) return POMDP_E_BADPARAMS;                                                                     \
-        if (p->num_rocks <= 12) { POMDP_PLAIN_CALL(RockEnv<1>, p); } else { POMDP_PLAIN_CALL(RockEnv<2>, p); }           \
+        if (p->stochastic) {                                                                                           \
+            if (p->num_rocks <= 12) { POMDP_PLAIN_CALL(StochRock1, p); } else { POMDP_PLAIN_CALL(StochRock2, p); } \
+        } else if (p->num_rocks <= 12) { POMDP_PLAIN_CALL(RockEnv<1>, p); } else { POMDP_PLAIN_CALL(RockEnv<2>, p); }    \
         break;                                                                                                         \
     }                                                                                                                  \
     case POMDP_ENV_TAG: {                                                                                              \

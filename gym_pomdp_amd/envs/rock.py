@@ -5,7 +5,7 @@ from .. import _native, tables
 from .base import BatchedEnv
 
 
-def make_params(board_size=7, num_rocks=8):
+def make_params(board_size=7, num_rocks=8, stochastic=False, p_move=.8):
     """rock.py:99-118: validates like the reference's ctor assert, builds the rock-id grid
     (every listed coordinate is stamped), start position and the sensor threshold table."""
     assert board_size in tables.ROCK_CONFIG and num_rocks in tables.ROCK_CONFIG[board_size][0], \
@@ -26,6 +26,15 @@ def make_params(board_size=7, num_rocks=8):
     for d in range(32):
         p.thr[d] = tables.ROCK_THR[min(d, len(tables.ROCK_THR) - 1)]
         p.eff[d] = tables.ROCK_EFF[min(d, len(tables.ROCK_EFF) - 1)]
+    if stochastic:
+        p.stochastic = 1
+        if p_move == .8:
+            p.act_thr = tables.TAG_MOVE_THR          # binomial(1, .8): the same captured threshold
+        else:
+            thr, sense = tables.bernoulli_threshold(p_move)
+            if sense != "le":
+                raise ValueError("StochasticRock: p_move <= 0.5 is not supported by the packed threshold compare")
+            p.act_thr = thr
     words = 1 if num_rocks <= 12 else 2
     return p, words, 5 + num_rocks, 3
 
@@ -42,6 +51,7 @@ class RockEnv(BatchedEnv):
     def __init__(self, board_size=7, num_rocks=8, use_heuristic=False, **batch_kwargs):
         self.board_size = board_size
         self.num_rocks = num_rocks
+        self.p_move = getattr(self, "p_move", None)
         self._use_heuristic = use_heuristic
         self._discount = .95         # rock.py:115
         self._reward_range = 20      # rock.py:116
@@ -57,3 +67,18 @@ class RockEnv(BatchedEnv):
         v = s[0] if self.state_words == 1 else (s[0] | (s[1] << 32))
         cols = [v & 15, (v >> 4) & 15] + [((v >> (8 + 2 * j)) & 3) - 1 for j in range(self.num_rocks)]
         return torch.stack(cols, dim=1)
+
+
+class StochasticRockEnv(RockEnv):
+    """gym_pomdp/envs/rock.py:428-504: RockSample where the whole action is skipped with probability
+    1 - p_move, the penalty is 0 and only the east exit terminates.  (The reference registers it as
+    "StochasticRock-v0" with a typo in the entry point, gym_pomdp/__init__.py:32-36, so `gym.make` fails
+    there; the class itself works and is what the fixtures were generated from.)"""
+
+    def __init__(self, board_size=7, num_rocks=8, use_heuristic=False, p_move=.8, **batch_kwargs):
+        self.p_move = p_move
+        super().__init__(board_size, num_rocks, use_heuristic, **batch_kwargs)
+        self._penalization = 0       # rock.py:432
+
+    def _build_params(self):
+        return make_params(self.board_size, self.num_rocks, stochastic=True, p_move=self.p_move)

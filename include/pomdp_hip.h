@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define POMDP_ABI_VERSION 2
+#define POMDP_ABI_VERSION 3
 
 enum {
     POMDP_E_BADARG = -1,     /* NULL pointer, n < 0, n + lane0 > 2^32 */
@@ -67,6 +67,10 @@ typedef struct pomdp_rock_params {
     int8_t   grid[256];     /* grid[x * 16 + y] = rock id stamped at (x, y) or -1    rock.py:110-111 */
     uint64_t thr[32];       /* thr[d]: sensor correct iff k53 <= thr[d], d = L1 distance  rock.py:383-407 */
     double   eff[32];       /* eff(d) itself, returned by pomdp_compute_prob            rock.py:383-387 */
+    int32_t  stochastic;    /* 1 = StochasticRockEnv (rock.py:428-504): the action is applied only when a
+                               binomial(1, p_move) draw succeeds, penalties are 0 and do not terminate */
+    int32_t  reserved;
+    uint64_t act_thr;       /* stochastic: act iff k53 <= act_thr (first double of stream STEP)  rock.py:443 */
 } pomdp_rock_params;
 
 /* replaces RockEnv.reset (rock.py:236-241, 266-271, 78-86).  ob (device, may be NULL) <- 0. */

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "liboracle.so")
 _lib = None
 
-KINDS = {"rock": 0, "tag": 1, "battleship": 2, "tiger": 3, "network": 4}
+KINDS = {"rock": 0, "stochrock": 0, "tag": 1, "battleship": 2, "tiger": 3, "network": 4}
 
 
 def build(force=False):
@@ -65,6 +65,9 @@ def env_args(name, **kw):
     """Constructor kwargs (reference names and defaults) -> oracle arg vector."""
     if name == "rock":
         return [kw.get("board_size", 7), kw.get("num_rocks", 8)]
+    if name == "stochrock":
+        thr = int(kw.get("act_thr", 0))
+        return [kw.get("board_size", 7), kw.get("num_rocks", 8), 1, thr & 0xFFFFFFFF, thr >> 32]
     if name == "tag":
         thr = int(kw.get("move_thr", 0))
         return [kw.get("num_opponents", 1), kw.get("obs_cells", 29), thr & 0xFFFFFFFF, thr >> 32]

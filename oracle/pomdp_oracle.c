@@ -151,6 +151,8 @@ struct or_env {
     int kind;
     /* ---- rock ---- */
     int size, num_rocks, n_listed;
+    int stochastic;            /* StochasticRockEnv (rock.py:428-504): action applied w.p. p_move, penalty 0 */
+    uint64_t act_thr;          /* binomial(1, p_move) == 1 iff k53 <= act_thr */
     coord start, rock_pos[MAX_ROCKS];
     int grid[16][16];          /* grid.board[x, y], -1 = empty (rock.py:108-111) */
     coord agent;
@@ -232,6 +234,9 @@ or_env *or_env_new(int kind, const int64_t *a, int nargs)
     switch (kind) {
     case OR_ENV_ROCK:
         rc = nargs >= 2 ? rock_init(e, (int)a[0], (int)a[1]) : -1;
+        e->stochastic = nargs >= 3 ? (int)a[2] : 0;
+        e->act_thr = nargs >= 5 ? ((uint64_t)(uint32_t)a[3] | ((uint64_t)(uint32_t)a[4] << 32)) : 0;
+        if (e->act_thr == 0) e->act_thr = TAG_MOVE_THR;      /* p_move = .8: the same captured threshold as binomial(1, .8) */
         break;
     case OR_ENV_TAG:
         e->n_opponents = nargs >= 1 ? (int)a[0] : 1;
@@ -325,16 +330,20 @@ static int rock_reset(or_env *e, or_ws *np_rng)
 static void rock_step(or_env *e, int action, or_ws *np_rng, int *ob_out, double *rw_out, int *done_out)
 {
     int reward = 0, ob = 0;
+    /* StochasticRockEnv.step (rock.py:434-504): `if np.random.binomial(1, p=self.p_move):` gates the whole
+     * action; _penalization is 0 and the `done = penalization == reward` line is commented out (rock.py:503) */
+    const int penal = e->stochastic ? 0 : -100;
+    if (e->stochastic && !(or_draw_k53(np_rng) <= e->act_thr)) { *ob_out = 0; *rw_out = 0; *done_out = 0; return; }
     if (action < 4) {
         if (action == 1) {                                   /* EAST  rock.py:135-141 */
             if (e->agent.x + 1 < e->size) e->agent.x += 1;
             else { *ob_out = 0; *rw_out = 10; *done_out = 1; return; }
         } else if (action == 0) {                            /* NORTH rock.py:142-146 */
-            if (e->agent.y + 1 < e->size) e->agent.y += 1; else reward = -100;
+            if (e->agent.y + 1 < e->size) e->agent.y += 1; else reward = penal;
         } else if (action == 2) {                            /* SOUTH rock.py:147-151 */
-            if (e->agent.y - 1 >= 0) e->agent.y -= 1; else reward = -100;
+            if (e->agent.y - 1 >= 0) e->agent.y -= 1; else reward = penal;
         } else {                                             /* WEST  rock.py:152-156 */
-            if (e->agent.x - 1 >= 0) e->agent.x -= 1; else reward = -100;
+            if (e->agent.x - 1 >= 0) e->agent.x -= 1; else reward = penal;
         }
     }
     if (action == 4) {                                       /* SAMPLE rock.py:160-169 */
@@ -344,7 +353,7 @@ static void rock_step(or_env *e, int action, or_ws *np_rng, int *ob_out, double 
         if (rock >= 0 && rock < e->num_rocks && e->status[rock] != 0) {
             reward = e->status[rock] == 1 ? 10 : -10;
             e->status[rock] = 0;
-        } else reward = -100;
+        } else reward = penal;
     }
     if (action > 4) {                                        /* CHECK rock.py:171-175 */
         int rock = action - 5;
@@ -355,7 +364,8 @@ static void rock_step(or_env *e, int action, or_ws *np_rng, int *ob_out, double 
         if (correct) ob = e->status[rock] == 1 ? 2 : 1;      /* rock.py:404-407 */
         else ob = e->status[rock] == 1 ? 1 : 2;
     }
-    *ob_out = ob; *rw_out = reward; *done_out = (reward == -100);   /* rock.py:193 */
+    *ob_out = ob; *rw_out = reward;
+    *done_out = e->stochastic ? 0 : (reward == -100);        /* rock.py:193 (commented out in the variant, rock.py:503) */
 }
 
 /* ------------------------------------------------------------------------ */

@@ -56,7 +56,7 @@ enum { OR_REWARD_I32 = 0, OR_REWARD_F32 = 1 };
 
 typedef struct or_env or_env;
 
-/* args: rock (board_size, num_rocks)
+/* args: rock (board_size, num_rocks[, stochastic, act_thr_lo, act_thr_hi])  stochastic = StochasticRockEnv
  *       tag (num_opponents, obs_cells, move_thr_lo, move_thr_hi)  thr==0 -> captured value for 0.8
  *       battleship (x_size, y_size, max_len)
  *       tiger ()

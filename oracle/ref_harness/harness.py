@@ -100,6 +100,7 @@ def inject_stream(seed, lane, t, stream, rs=None):
 # ---------------------------------------------------------------------------
 ENV_CLASSES = {
     "rock": "RockEnv",
+    "stochrock": "StochasticRockEnv",   # importable class; its gym id is broken by a typo (gym_pomdp/__init__.py:35)
     "tag": "TagEnv",
     "battleship": "BattleShipEnv",
     "tiger": "TigerEnv",
@@ -121,7 +122,7 @@ def compact_state(name, env):
     tiger:      [state]
     network:    [s_0 .. s_{M-1}]
     """
-    if name == "rock":
+    if name in ("rock", "stochrock"):
         s = env.state
         return np.array([s.agent_pos.x, s.agent_pos.y] + [r.status for r in s.rocks], dtype=np.int64)
     if name == "tag":

@@ -35,6 +35,8 @@ CASES = [
     ("rock_15_15", "rock", dict(board_size=15, num_rocks=15), 1000, 256, 48),
     ("rock_4_3", "rock", dict(board_size=4, num_rocks=3), 600, 64, 32),
     ("rock_2_1", "rock", dict(board_size=2, num_rocks=1), 300, 64, 32),
+    ("stochrock_7_8", "stochrock", {}, 1500, 256, 64),
+    ("stochrock_11_11", "stochrock", dict(board_size=11, num_rocks=11), 1000, 64, 64),
     ("tag_1", "tag", {}, 4000, 512, 64),
     ("tag_2", "tag", dict(num_opponents=2), 4000, 256, 64),
     ("tag_4", "tag", dict(num_opponents=4), 2000, 128, 64),
@@ -121,6 +123,7 @@ def gen_mode_b(case, env, kwargs, L, T):
 ROLLOUT_CASES = [
     ("rock_7_8", "rock", {}, 12, 16, 40, False),
     ("rock_7_8_all", "rock", {}, 8, 16, 40, True),
+    ("stochrock_7_8", "stochrock", {}, 8, 16, 60, False),
     ("rock_15_15", "rock", dict(board_size=15, num_rocks=15), 8, 16, 60, False),
     ("rock_11_11", "rock", dict(board_size=11, num_rocks=11), 6, 16, 50, False),
     ("tag_1", "tag", {}, 8, 16, 30, False),
@@ -131,7 +134,7 @@ ROLLOUT_CASES = [
     ("network_10", "network", {}, 8, 8, 16, False),
 ]
 ROLLOUT_SEED = 0xC0FFEE1234
-ROLLOUT_DISCOUNT = {"rock": .95, "tag": .95, "battleship": 1., "tiger": .95, "network": .95}  # the envs' _discount
+ROLLOUT_DISCOUNT = {"rock": .95, "stochrock": .95, "tag": .95, "battleship": 1., "tiger": .95, "network": .95}  # the envs' _discount
 
 
 def gen_rollout(case, env, kwargs, R, S, depth, all_actions):
@@ -152,7 +155,7 @@ def gen_rollout(case, env, kwargs, R, S, depth, all_actions):
     return int(tr["terminated"].sum()), float(tr["n_steps"].mean())
 
 
-PROB_CASES = [("rock_7_8", "rock", {}, 48, 40), ("rock_15_15", "rock", dict(board_size=15, num_rocks=15), 24, 40),
+PROB_CASES = [("rock_7_8", "rock", {}, 48, 40), ("stochrock_7_8", "stochrock", {}, 24, 40), ("rock_15_15", "rock", dict(board_size=15, num_rocks=15), 24, 40),
               ("tag_1", "tag", {}, 32, 40), ("tag_2", "tag", dict(num_opponents=2), 16, 40),
               ("battleship_5_5", "battleship", {}, 32, 40), ("tiger", "tiger", {}, 32, 30),
               ("network_10", "network", {}, 32, 30)]
@@ -273,7 +276,10 @@ def main():
     gen_thresholds()
     if "--rollouts-only" not in sys.argv:
         gen_edge_cases()
+    only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--only=")]
     for case, env, kwargs, TA, L, TB in (CASES if "--rollouts-only" not in sys.argv else []):
+        if only and not any(case.startswith(o) for o in only):
+            continue
         da = gen_mode_a(case, env, kwargs, TA)
         db, mw = gen_mode_b(case, env, kwargs, L, TB)
         print("%-18s modeA dones=%4d  modeB dones=%5d  max words/call=%d" % (case, da, db, mw), flush=True)

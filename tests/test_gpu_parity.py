@@ -10,7 +10,7 @@ from conftest import golden_cases, load_golden, saturate_tag_compact
 pytestmark = pytest.mark.gpu
 
 CASES = golden_cases()
-ENV_IDS = {"rock": "Rock-v0", "tag": "Tag-v0", "battleship": "Battleship-v0", "tiger": "Tiger-v0",
+ENV_IDS = {"rock": "Rock-v0", "stochrock": "StochasticRock-v0", "tag": "Tag-v0", "battleship": "Battleship-v0", "tiger": "Tiger-v0",
            "network": "Network-v0"}
 
 
@@ -78,6 +78,9 @@ ORACLE_CASES = [
     ("tiger", {}, 32768, 32),
     ("network", {}, 32768, 32),
     ("network", dict(n_machines=31, problem_type=3), 4096, 16),
+    ("stochrock", {}, 32768, 96),
+    ("stochrock", dict(board_size=4, num_rocks=3), 4096, 64),
+    ("stochrock", dict(board_size=15, num_rocks=15), 4096, 600),
     ("rock", {}, 4004, 40),                                         # ragged: not a multiple of the wave / workgroup size
     ("rock", dict(board_size=7, num_rocks=7), 1028, 40),            # odd K: last Philox block half used
     ("rock", dict(board_size=2, num_rocks=1), 260, 24),
@@ -192,6 +195,7 @@ def test_c_rollout_driver_equals_python_loop(action_seed):
     not (policy launch + step launch per step)."""
     n, seed = 16384, 5
     for env, kw in (("rock", {}), ("rock", dict(board_size=15, num_rocks=15)), ("rock", dict(board_size=4, num_rocks=3)),
+                    ("stochrock", {}),
                     ("tag", {}), ("battleship", {}), ("tiger", {}), ("network", {})):
         a = make_env(env, kw, batch_size=n, seed=seed, reuse_buffers=True)
         b = make_env(env, kw, batch_size=n, seed=seed)

@@ -42,7 +42,7 @@ def test_bad_arguments_are_rejected_without_a_gpu():
 
 def test_struct_sizes_match_header_layout():
     from gym_pomdp_amd import _native as n
-    assert C.sizeof(n.RockParams) == 16 + 16 + 16 + 256 + 32 * 8 + 32 * 8
+    assert C.sizeof(n.RockParams) == 16 + 16 + 16 + 256 + 32 * 8 + 32 * 8 + 16
     assert C.sizeof(n.TagParams) == 16
     assert C.sizeof(n.BattleShipParams) == 12
     assert C.sizeof(n.TigerParams) == 8
@@ -122,7 +122,7 @@ def test_discrete_space_follows_gym_rules():
 def test_registry_and_loud_failure_without_gpu():
     import torch
     import gym_pomdp_amd as gpa
-    assert sorted(gpa.registry) == ["Battleship-v0", "Network-v0", "Rock-v0", "Tag-v0", "Tiger-v0"]
+    assert sorted(gpa.registry) == ["Battleship-v0", "Network-v0", "Rock-v0", "StochasticRock-v0", "Tag-v0", "Tiger-v0"]
     with pytest.raises(KeyError):
         gpa.make("Pocman-v0")
     if not torch.cuda.is_available():
