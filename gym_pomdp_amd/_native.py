@@ -13,7 +13,7 @@ _REPO = os.path.dirname(_PKG)
 LIB_PATH = os.path.join(_PKG, "_lib", "libpomdp_hip.so")
 SOURCES = [os.path.join(_PKG, "csrc", f) for f in ("pomdp_kernels.hip", "envs.hip.h", "philox.hip.h")]
 HEADER = os.path.join(_REPO, "include", "pomdp_hip.h")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 POMDP_AUTO_RESET = 1
 POMDP_ROLLOUT_ALL_ACTIONS = 1
@@ -41,7 +41,8 @@ class TagParams(C.Structure):
 
 
 class BattleShipParams(C.Structure):
-    _fields_ = [("x_size", C.c_int32), ("y_size", C.c_int32), ("max_len", C.c_int32)]
+    _fields_ = [("x_size", C.c_int32), ("y_size", C.c_int32), ("max_len", C.c_int32), ("reserved", C.c_int32),
+                ("col0", C.c_uint32 * 4), ("vpat", (C.c_uint32 * 4) * 12)]
 
 
 class TigerParams(C.Structure):

@@ -446,40 +446,45 @@ struct BattleShipEnv {
     using Reward = int32_t;
     static constexpr int WORDS = 2 * MW;
     struct Shared { int unused; };
-    // The mask words live in 4-wide vector registers (never in an addressable array: a dynamically indexed
-    // array would be spilled to LDS by the compiler); words >= MW stay zero.
-    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-    struct State { v4u occ, vis; };
+    // Each 128-bit mask is two 64-bit registers (never an addressable array or vector: a dynamically indexed
+    // one is lowered through LDS by the compiler); bit tests are a 64-bit select and one variable shift.
+    struct Mask {
+        uint64_t lo, hi;
+        __device__ __forceinline__ uint32_t word(int j) const { return (uint32_t)((j < 2 ? lo : hi) >> (32 * (j & 1))); }
+        __device__ __forceinline__ void set_word(int j, uint32_t w)
+        {
+            const uint64_t m = 0xFFFFFFFFull << (32 * (j & 1)), v = (uint64_t)w << (32 * (j & 1));
+            if (j < 2) lo = (lo & ~m) | v; else hi = (hi & ~m) | v;
+        }
+    };
+    struct State { Mask occ, vis; };
 
     static __device__ __forceinline__ void stage(Shared &, const Params &, int) {}
     static __device__ __forceinline__ int n_actions(const Params &p) { return p.x_size * p.y_size; }
     static __device__ __forceinline__ void load(State &st, const uint32_t *state, int64_t n, int64_t i)
     {
-        st.occ = (v4u)(0u); st.vis = (v4u)(0u);
+        uint32_t o[4] = {0, 0, 0, 0}, v[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int j = 0; j < MW; ++j) { st.occ[j] = state[(int64_t)j * n + i]; st.vis[j] = state[(int64_t)(MW + j) * n + i]; }
+        for (int j = 0; j < MW; ++j) { o[j] = state[(int64_t)j * n + i]; v[j] = state[(int64_t)(MW + j) * n + i]; }
+        st.occ.lo = o[0] | ((uint64_t)o[1] << 32); st.occ.hi = o[2] | ((uint64_t)o[3] << 32);
+        st.vis.lo = v[0] | ((uint64_t)v[1] << 32); st.vis.hi = v[2] | ((uint64_t)v[3] << 32);
     }
     // a step only changes the visited half; the occupied half is rewritten on reset
     static __device__ __forceinline__ void store(const State &st, uint32_t *state, int64_t n, int64_t i, bool was_reset)
     {
 #pragma unroll
-        for (int j = 0; j < MW; ++j) state[(int64_t)(MW + j) * n + i] = st.vis[j];
+        for (int j = 0; j < MW; ++j) state[(int64_t)(MW + j) * n + i] = st.vis.word(j);
         if (was_reset) {
 #pragma unroll
-            for (int j = 0; j < MW; ++j) state[(int64_t)j * n + i] = st.occ[j];
+            for (int j = 0; j < MW; ++j) state[(int64_t)j * n + i] = st.occ.word(j);
         }
     }
-    static __device__ __forceinline__ uint32_t word_of(const v4u &m, int a)
+    static __device__ __forceinline__ bool bit(const Mask &m, int a) { return ((a < 64 ? m.lo : m.hi) >> (a & 63)) & 1ull; }
+    static __device__ __forceinline__ void set_bit(Mask &m, int a)
     {
-        const int j = a >> 5;
-        return j == 0 ? m.x : j == 1 ? m.y : j == 2 ? m.z : m.w;
-    }
-    static __device__ __forceinline__ bool bit(const v4u &m, int a) { return (word_of(m, a) >> (a & 31)) & 1u; }
-    static __device__ __forceinline__ void set_bit(v4u &m, int a)
-    {
-        const int j = a >> 5;
-        const uint32_t b = 1u << (a & 31);
-        m.x |= j == 0 ? b : 0u; m.y |= j == 1 ? b : 0u; m.z |= j == 2 ? b : 0u; m.w |= j == 3 ? b : 0u;
+        const uint64_t b = 1ull << (a & 63);
+        m.lo |= a < 64 ? b : 0ull;
+        m.hi |= a < 64 ? 0ull : b;
     }
     static __device__ __forceinline__ bool occupied(const Params &p, const State &st, int x, int y)
     {
@@ -528,19 +533,39 @@ struct BattleShipEnv {
             for (int i = 0; i < len; ++i) occ |= (u128)1 << (a0 + i * stride);     // mark_ship: L cells from pos
             remaining += len;
         }
-#pragma unroll
-        for (int j = 0; j < MW; ++j) { st.occ[j] = (uint32_t)(occ >> (32 * j)); st.vis[j] = 0u; }
-        st.vis[MW - 1] = (uint32_t)remaining << 26;
+        st.occ.lo = (uint64_t)occ; st.occ.hi = (uint64_t)(occ >> 64);
+        st.vis.lo = 0; st.vis.hi = 0;
+        st.vis.set_word(MW - 1, (uint32_t)remaining << 26);
         return 0;
     }
 
     // Wave-cooperative reset.  A BattleShip reset is a long sequential rejection loop (about 20 attempts on
-    // 10x10, 42 on 5x5) and roughly one wave in five holds a lane that needs one, so run per lane it stalls
-    // 63 other lanes behind ~2000 divergent vector instructions.  Here the whole wave serves one resetting
-    // lane at a time with wave-uniform control flow: one Philox pass yields a 64-word window of that lane's
-    // RESET stream (lane l holds word wbase + l), attempts read their words with v_readlane, and the
-    // placement test is 128-bit mask arithmetic on uniform values, which the compiler keeps on the scalar
-    // unit.  Same words in the same order as reset() above, hence the same boards.
+    // 10x10, 42 on 5x5) and roughly one wave in five holds a lane that needs one; run per lane it stalls 63
+    // other lanes behind ~2000 divergent instructions.  Here the whole wave serves one resetting lane at a
+    // time and evaluates up to 64 candidate placements at once:
+    //   1. one Philox pass gives a 64-word window of that lane's RESET stream (lane l holds word c + l);
+    //   2. the reference consumes the stream as [position words until one is < n_tiles][direction word],
+    //      repeated.  With A = ballot(word is an acceptable position), word l is a *direction* word iff
+    //      word l-1 is an accepted position word, i.e. D[l] = A[l-1] & ~D[l-1]: inside every run of ones of
+    //      A the roles alternate, which is the "escaped character" recurrence and has a branch-free 64-bit
+    //      solution (add-with-carry over the run starts; Langdale & Lemire, "Parsing gigabytes of JSON per
+    //      second", §3.1.1).  Lane l is a candidate iff A[l] & ~D[l]; its direction word is lane l+1's;
+    //   3. every candidate lane tests its placement with 128-bit mask arithmetic against `blocked`; the
+    //      lowest successful lane is the ship the reference would have placed, and the cursor moves just
+    //      past its direction word.  No success: the cursor moves past the last fully parsed word.
+    // Same words in the same order as reset() above, hence the same boards.
+    static __device__ __forceinline__ u128 u128_of(const uint32_t (&w)[4])
+    {
+        return (u128)(w[0] | ((uint64_t)w[1] << 32)) | ((u128)(w[2] | ((uint64_t)w[3] << 32)) << 64);
+    }
+    static __device__ __forceinline__ uint64_t direction_words(uint64_t a)
+    {
+        const uint64_t even = 0x5555555555555555ull;
+        const uint64_t follows = a << 1;                       // words preceded by an acceptable word
+        const uint64_t odd_starts = a & ~even & ~follows;      // runs of A that start on an odd bit
+        const uint64_t even_start_runs = odd_starts + a;       // carry ripples through those runs
+        return (even ^ (even_start_runs << 1)) & follows;
+    }
     static __device__ __forceinline__ void reset_where(const Shared &, const Params &p, State &st, bool fresh,
                                                        const RngKey &key, uint32_t lane)
     {
@@ -549,58 +574,59 @@ struct BattleShipEnv {
         const int me = (int)(threadIdx.x & 63u);
         const int X = p.x_size, Y = p.y_size, cells = X * Y;
         const uint32_t rmask = 0xFFFFFFFFu >> __clz((uint32_t)(cells - 1) | 1u); // randint(cells) bit-smear mask
-        u128 col0 = 0;
-        for (int y = 0; y < Y; ++y) col0 |= (u128)1 << (y * X);
-        const u128 colL = col0 << (X - 1);
+        const u128 col0 = u128_of(p.col0), colL = col0 << (X - 1);
         while (todo != 0ull) {
             const int src = __ffsll((long long)todo) - 1;
             todo &= todo - 1ull;
             const uint32_t glane = (uint32_t)__builtin_amdgcn_readlane((int)lane, src);
-            int wbase = 0, cursor = 0;
-            uint32_t word = 0;
-            auto refill = [&]() {                                            // lane l <- word wbase + l of the stream
-                const uint32_t wi = (uint32_t)(wbase + me);
-                const uint4 b = stream_block(key, glane, POMDP_STREAM_RESET, (wi >> 2) & 0xFFFFFFu);
-                const uint32_t sel = wi & 3u;
-                word = sel == 0 ? b.x : sel == 1 ? b.y : sel == 2 ? b.z : b.w;
-            };
-            auto next_word = [&]() -> uint32_t {
-                if (cursor - wbase >= 64) { wbase += 64; refill(); }
-                const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)word, cursor - wbase);
-                ++cursor;
-                return w;
-            };
-            refill();
+            int c = 0;                                                        // next unread word of the stream
             u128 occ = 0;
             int remaining = 0;
             for (int len = p.max_len; len >= 2; --len) {
                 const u128 e = occ & ~col0, w = occ & ~colL;
                 const u128 blocked = occ | (occ >> X) | (occ << X) | (e >> 1) | (w << 1) | (e >> (X + 1)) | (e << (X - 1)) |
                                      (w << (X + 1));
-                int a0, stride;
+                const u128 hpat = ((u128)1 << (len + 1)) - 1;                 // the L+1 checked cells, from bit 0
+                const u128 vpat = u128_of(p.vpat[len + 1]);
                 for (;;) {
-                    uint32_t v;
-                    do { v = next_word() & rmask; } while (v > (uint32_t)(cells - 1));   // np.random.randint(n_tiles)
-                    a0 = (int)v;
-                    const uint32_t dir = next_word() & 3u;                               // np.random.randint(4)
-                    const int dx = (dir == 1u) - (dir == 3u), dy = (dir == 0u) - (dir == 2u);
+                    const uint32_t wi = (uint32_t)(c + me);
+                    const uint4 blk = stream_block(key, glane, POMDP_STREAM_RESET, (wi >> 2) & 0xFFFFFFu);
+                    const uint32_t sel = wi & 3u;
+                    const uint32_t word = sel == 0 ? blk.x : sel == 1 ? blk.y : sel == 2 ? blk.z : blk.w;
+                    const uint64_t A = __ballot((word & rmask) <= (uint32_t)(cells - 1));
+                    const uint64_t D = direction_words(A);
+                    const uint64_t cand = A & ~D & 0x7FFFFFFFFFFFFFFFull;     // position word with its direction word in the window
+                    const uint32_t dirword = (uint32_t)__shfl((int)word, (me + 1) & 63, 64);
+                    const int a0 = (int)(word & rmask);
+                    const uint32_t dir = dirword & 3u;
+                    const int dx = (dir == 1u) - (dir == 3u), dy = (dir == 0u) - (dir == 2u);   // Compass N E S W
                     const int px = a0 % X, py = a0 / X;
                     const int ex = px + (len + 1) * dx, ey = py + (len + 1) * dy;
-                    stride = dy * X + dx;
-                    if (!((unsigned)ex < (unsigned)X && (unsigned)ey < (unsigned)Y)) continue;
+                    const int stride = dy * X + dx;
+                    const bool inside = (unsigned)ex < (unsigned)X && (unsigned)ey < (unsigned)Y;
                     const int lo = stride > 0 ? a0 : a0 + len * stride;
-                    const int gap = stride > 0 ? stride : -stride;
-                    u128 cellsm = 0;
-                    for (int i = 0; i <= len; ++i) cellsm |= (u128)1 << (lo + i * gap);
-                    if ((cellsm & blocked) == 0) break;
+                    const u128 cellsm = (dx != 0 ? hpat : vpat) << (lo & 127);
+                    const bool ok = ((cand >> me) & 1ull) && inside && (cellsm & blocked) == 0;
+                    const uint64_t succ = __ballot(ok);
+                    if (succ != 0ull) {
+                        const int r = __ffsll((long long)succ) - 1;
+                        const int a0w = __builtin_amdgcn_readlane(a0, r), sw = __builtin_amdgcn_readlane(stride, r);
+                        // mark_ship: L cells from pos = the L-cell pattern shifted to its lowest cell
+                        const int low = sw > 0 ? a0w : a0w + (len - 1) * sw;
+                        occ |= ((sw == 1 || sw == -1) ? (((u128)1 << len) - 1) : u128_of(p.vpat[len])) << low;
+                        remaining += len;
+                        c += r + 2;
+                        break;
+                    }
+                    // no placement here: word 63 is unread only if it is an accepted position word (its direction
+                    // word lies in the next window)
+                    c += ((A & ~D) >> 63) ? 63 : 64;
                 }
-                for (int i = 0; i < len; ++i) occ |= (u128)1 << (a0 + i * stride);
-                remaining += len;
             }
             if (me == src) {
-#pragma unroll
-                for (int j = 0; j < MW; ++j) { st.occ[j] = (uint32_t)(occ >> (32 * j)); st.vis[j] = 0u; }
-                st.vis[MW - 1] = (uint32_t)remaining << 26;
+                st.occ.lo = (uint64_t)occ; st.occ.hi = (uint64_t)(occ >> 64);
+                st.vis.lo = 0; st.vis.hi = 0;
+                st.vis.set_word(MW - 1, (uint32_t)remaining << 26);
             }
         }
     }
@@ -616,7 +642,7 @@ struct BattleShipEnv {
     {
         const int cells = p.x_size * p.y_size, lo = 32 * j;
         const uint32_t valid = cells - lo >= 32 ? 0xFFFFFFFFu : (cells > lo ? (1u << (cells - lo)) - 1u : 0u);
-        return ~st.vis[j] & valid;
+        return ~st.vis.word(j) & valid;
     }
     static __device__ __forceinline__ int legal_count(const Shared &, const Params &p, const State &st)
     {
@@ -654,7 +680,7 @@ struct BattleShipEnv {
     static __device__ __forceinline__ void step(const Shared &, const Params &p, State &st, int a,
                                                 const RngKey &, uint32_t, int &ob, RT &rew, int &done)
     {
-        int remaining = (int)(st.vis[MW - 1] >> 26);
+        int remaining = (int)(st.vis.word(MW - 1) >> 26);
         ob = 0; done = 0;
         if (bit(st.vis, a)) rew = -10;
         else {
@@ -663,7 +689,7 @@ struct BattleShipEnv {
             set_bit(st.vis, a);
         }
         if (remaining == 0) { rew += p.x_size * p.y_size; done = 1; }
-        st.vis[MW - 1] = (st.vis[MW - 1] & 0x03FFFFFFu) | ((uint32_t)remaining << 26);
+        st.vis.set_word(MW - 1, (st.vis.word(MW - 1) & 0x03FFFFFFu) | ((uint32_t)remaining << 26));
     }
 };
 

@@ -14,6 +14,13 @@ def make_params(board_size=(5, 5), max_len=3):
         raise ValueError("BattleShip: max_len must be in 2..10")
     p = _native.BattleShipParams()
     p.x_size, p.y_size, p.max_len = x, y, max_len
+    col0 = sum(1 << (yy * x) for yy in range(y))
+    for j in range(4):
+        p.col0[j] = (col0 >> (32 * j)) & 0xFFFFFFFF
+    for k in range(12):
+        v = sum(1 << (i * x) for i in range(k)) & ((1 << 128) - 1)
+        for j in range(4):
+            p.vpat[k][j] = (v >> (32 * j)) & 0xFFFFFFFF
     mask_words = (cells + 6 + 31) // 32
     return p, 2 * mask_words, cells, 2
 

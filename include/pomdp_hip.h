@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define POMDP_ABI_VERSION 3
+#define POMDP_ABI_VERSION 4
 
 enum {
     POMDP_E_BADARG = -1,     /* NULL pointer, n < 0, n + lane0 > 2^32 */
@@ -106,6 +106,11 @@ int pomdp_tag_step(const pomdp_tag_params *p, uint32_t *state, const int32_t *ac
 typedef struct pomdp_battleship_params {
     int32_t x_size, y_size; /* x_size * y_size <= 122                     battleship.py:67 */
     int32_t max_len;        /* ctor max_len (ships max_len .. 2), 2..10   battleship.py:74-75 */
+    int32_t reserved;
+    /* 128-bit cell masks (4 little-endian words each) the reset's placement test uses, derived from x_size
+     * and y_size on the host so that no lane recomputes them: */
+    uint32_t col0[4];       /* cells with x == 0 */
+    uint32_t vpat[12][4];   /* vpat[k]: k cells in a column, from cell 0 upwards (bits 0, X, 2X, ...) */
 } pomdp_battleship_params;
 
 /* replaces BattleShipEnv.reset (battleship.py:131-137, 167-211) */

@@ -44,7 +44,7 @@ def test_struct_sizes_match_header_layout():
     from gym_pomdp_amd import _native as n
     assert C.sizeof(n.RockParams) == 16 + 16 + 16 + 256 + 32 * 8 + 32 * 8 + 16
     assert C.sizeof(n.TagParams) == 16
-    assert C.sizeof(n.BattleShipParams) == 12
+    assert C.sizeof(n.BattleShipParams) == 16 + 16 + 12 * 16
     assert C.sizeof(n.TigerParams) == 8
     assert C.sizeof(n.NetworkParams) == 8 + 32 * 4 + 3 * 8
     assert n.RockParams.grid.offset == 48 and n.RockParams.thr.offset == 304

@@ -42,6 +42,35 @@ __global__ __launch_bounds__(BS) void traffic_kernel_bs(uint32_t *__restrict__ s
     }
 }
 
+// BattleShip-shaped traffic: 8 state words in, 4 out, + action/ob/reward/done
+__global__ __launch_bounds__(256) void bs_traffic_soa(uint32_t *__restrict__ state, const int32_t *__restrict__ action,
+                                                      int32_t *__restrict__ ob, int32_t *__restrict__ reward,
+                                                      uint8_t *__restrict__ done, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    uint32_t w[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w[j] = state[j * n + i];
+    const int a = action[i];
+    const uint32_t x = w[0] ^ w[1] ^ w[2] ^ w[3];
+#pragma unroll
+    for (int j = 4; j < 8; ++j) state[j * n + i] = w[j] + x + (uint32_t)a;
+    ob[i] = a & 1; reward[i] = a - 5; done[i] = (uint8_t)(x & 1u);
+}
+__global__ __launch_bounds__(256) void bs_traffic_v4(uint4 *__restrict__ state, const int32_t *__restrict__ action,
+                                                     int32_t *__restrict__ ob, int32_t *__restrict__ reward,
+                                                     uint8_t *__restrict__ done, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint4 o = state[i], v = state[n + i];
+    const int a = action[i];
+    const uint32_t x = o.x ^ o.y ^ o.z ^ o.w;
+    state[n + i] = make_uint4(v.x + x + a, v.y + x, v.z + x, v.w + x);
+    ob[i] = a & 1; reward[i] = a - 5; done[i] = (uint8_t)(x & 1u);
+}
+
 // V0v: same traffic, 4 lanes per thread, 16-byte accesses
 __global__ __launch_bounds__(256) void traffic_kernel_v4(uint4 *__restrict__ state, const int4 *__restrict__ action,
                                                          int4 *__restrict__ ob, int4 *__restrict__ reward,
@@ -94,6 +123,7 @@ int main(int argc, char **argv)
     uint32_t *state; int32_t *action, *ob, *reward; uint8_t *done; uint32_t *err;
     CK(hipMalloc(&state, n * 8)); CK(hipMalloc(&action, n * 4)); CK(hipMalloc(&ob, n * 4)); CK(hipMalloc(&reward, n * 4));
     CK(hipMalloc(&done, n)); CK(hipMalloc(&err, 4)); CK(hipMemset(err, 0, 4));
+    uint32_t *bsstate; CK(hipMalloc(&bsstate, n * 32)); CK(hipMemset(bsstate, 0, n * 32));
     // RockSample(7,8) params
     pomdp_rock_params p = {};
     p.size = 7; p.num_rocks = 8; p.start_x = 0; p.start_y = 3;
@@ -115,6 +145,8 @@ int main(int argc, char **argv)
     printf("traffic 21B  bs=256 1 lane/thr : %8.2f\n", time_it([&](int) { hipLaunchKernelGGL(traffic_kernel_bs<256>, dim3((unsigned)(n / 256)), dim3(256), 0, 0, state, action, ob, reward, done, n); }, iters));
     printf("traffic 21B  bs=512 1 lane/thr : %8.2f\n", time_it([&](int) { hipLaunchKernelGGL(traffic_kernel_bs<512>, dim3((unsigned)(n / 512)), dim3(512), 0, 0, state, action, ob, reward, done, n); }, iters));
     printf("traffic 21B  bs=1024 1 lane/thr: %8.2f\n", time_it([&](int) { hipLaunchKernelGGL(traffic_kernel_bs<1024>, dim3((unsigned)(n / 1024)), dim3(1024), 0, 0, state, action, ob, reward, done, n); }, iters));
+    printf("battleship traffic SoA dwords : %8.2f\n", time_it([&](int) { hipLaunchKernelGGL(bs_traffic_soa, dim3((unsigned)(n / 256)), dim3(256), 0, 0, bsstate, action, ob, reward, done, n); }, iters));
+    printf("battleship traffic 16B/lane   : %8.2f\n", time_it([&](int) { hipLaunchKernelGGL(bs_traffic_v4, dim3((unsigned)(n / 256)), dim3(256), 0, 0, (uint4 *)bsstate, action, ob, reward, done, n); }, iters));
     for (int blocks : {256, 512, 1024, 2048}) {
         printf("traffic 21B v4 grid=%5d    : %8.2f\n", blocks,
                time_it([&](int) { hipLaunchKernelGGL(traffic_kernel_v4, dim3(blocks), dim3(256), 0, 0, (uint4 *)state, (const int4 *)action, (int4 *)ob, (int4 *)reward, (uint32_t *)done, n / 4); }, iters));
