@@ -273,6 +273,20 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.env, kwargs, args.seed, args.cpu_seconds)
+            # the like-for-like "one env, python loop" usage of the reference, through this build's public API
+            # (batch_size=1: python scalars in and out, one launch + one sync per step)
+            e1 = gpa.make(env_id, device=dev, seed=args.seed, **kwargs)
+            e1.reset()
+            k, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < 1.0:
+                _, _, d, _ = e1.step(e1.action_space.sample())
+                if d:
+                    e1.reset()
+                k += 1
+            out["cpu_baseline"]["scalar_api_loop"] = {
+                "value": k / (time.perf_counter() - t0), "unit": "env-steps/s",
+                "note": "gym_pomdp_amd batch_size=1 python loop on the GPU (launch + sync per step); the reference's "
+                        "own python loop is in reference_python_recorded"}
         print(json.dumps(out), flush=True)
     cp.close()
 

@@ -77,6 +77,9 @@ class BatchedEnv(object):
         self._reward = torch.zeros(n, dtype=self.reward_dtype, device=self.device)
         self._has_reset = False
         self._scalar_done = False
+        self._done_bool = self._done.view(torch.bool)
+        self._ptrs = (self._state.data_ptr(), self._ob.data_ptr(), self._reward.data_ptr(), self._done.data_ptr(),
+                      self._err.data_ptr())
 
     # ---- gym.Env surface --------------------------------------------------------
     def seed(self, seed=None):
@@ -128,23 +131,34 @@ class BatchedEnv(object):
             assert self.action_space.contains(action), "invalid action %r" % (action,)
             assert self._scalar_done is False or self.auto_reset, "step() on a done env (call reset())"
             action = torch.tensor([int(action)], dtype=torch.int32, device=self.device)
-        else:
-            action = self._as_action_tensor(action)
+        elif not (isinstance(action, torch.Tensor) and action.dtype == torch.int32 and action.device == self.device
+                  and action.dim() == 1 and action.shape[0] == self.batch_size and action.is_contiguous()):
+            action = self._as_action_tensor(action)           # slow path: convert / validate
         t = self._t
         self._t += 1
-        with torch.cuda.device(self.device):
-            if self.reuse_buffers:
-                ob, reward = self._ob, self._reward
-            else:
-                ob, reward = torch.empty_like(self._ob), torch.empty_like(self._reward)
-            done = self._done if (self.reuse_buffers or not self.auto_reset) else torch.empty_like(self._done)
-            rc = self._step_fn(self._params_ref, self._state.data_ptr(), action.data_ptr(), ob.data_ptr(),
-                               reward.data_ptr(), done.data_ptr(), self._err.data_ptr(), self.batch_size,
-                               self._seed, self.lane_offset, t, _native.POMDP_AUTO_RESET if self.auto_reset else 0,
-                               self._stream())
-            _native.check(rc, "pomdp_%s_step" % self.env_name)
-        if not self.auto_reset and not self.reuse_buffers:
-            done = done.clone()
+        flags = _native.POMDP_AUTO_RESET if self.auto_reset else 0
+        same_device = torch.cuda.current_device() == self.device.index
+        if self.reuse_buffers and same_device:
+            # hot path: cached buffer pointers, no allocation, no device-context switch
+            ptrs = self._ptrs
+            rc = self._step_fn(self._params_ref, ptrs[0], action.data_ptr(), ptrs[1], ptrs[2], ptrs[3], ptrs[4],
+                               self.batch_size, self._seed, self.lane_offset, t, flags, self._stream())
+            if rc:
+                _native.check(rc, "pomdp_%s_step" % self.env_name)
+            ob, reward, done = self._ob, self._reward, self._done
+        else:
+            with torch.cuda.device(self.device):
+                if self.reuse_buffers:
+                    ob, reward = self._ob, self._reward
+                else:
+                    ob, reward = torch.empty_like(self._ob), torch.empty_like(self._reward)
+                done = self._done if (self.reuse_buffers or not self.auto_reset) else torch.empty_like(self._done)
+                rc = self._step_fn(self._params_ref, self._state.data_ptr(), action.data_ptr(), ob.data_ptr(),
+                                   reward.data_ptr(), done.data_ptr(), self._err.data_ptr(), self.batch_size,
+                                   self._seed, self.lane_offset, t, flags, self._stream())
+                _native.check(rc, "pomdp_%s_step" % self.env_name)
+            if not self.auto_reset and not self.reuse_buffers:
+                done = done.clone()
         info = {"state": self._state}
         if scalar:
             d = bool(done.item())
@@ -152,7 +166,7 @@ class BatchedEnv(object):
             self.done = d
             r = reward.item()
             return int(ob.item()), (int(r) if self.reward_dtype == torch.int32 else float(r)), d, info
-        self.done = done.view(torch.bool)
+        self.done = self._done_bool if done is self._done else done.view(torch.bool)
         return ob, reward, self.done, info
 
     def _as_action_tensor(self, action):
@@ -203,6 +217,13 @@ class BatchedEnv(object):
         counter); int32[N] on device.  batch_size and lane_offset must be multiples of 4."""
         if out is None:
             out = torch.empty(self.batch_size, dtype=torch.int32, device=self.device)
+        if torch.cuda.current_device() == self.device.index:
+            rc = self._lib.pomdp_synthetic_actions(out.data_ptr(), self.batch_size,
+                                                   self._seed if seed is None else seed, self.lane_offset,
+                                                   self._t, self.action_space.n, self._stream())
+            if rc:
+                _native.check(rc, "pomdp_synthetic_actions")
+            return out
         with torch.cuda.device(self.device):
             rc = self._lib.pomdp_synthetic_actions(out.data_ptr(), self.batch_size,
                                                    self._seed if seed is None else seed, self.lane_offset,
