@@ -71,12 +71,12 @@ struct RockEnv {
     }
     static __device__ __forceinline__ int n_actions(const Params &p) { return 5 + p.num_rocks; }
 
-    static __device__ __forceinline__ void load(State &st, const uint32_t *state, int64_t n, int64_t i)
+    static __device__ __forceinline__ void load(State &st, const uint32_t *state, int64_t n, uint32_t i)
     {
         st.s = state[i];
         if (W == 2) st.s |= (S)((uint64_t)state[n + i] << 32);
     }
-    static __device__ __forceinline__ void store(const State &st, uint32_t *state, int64_t n, int64_t i, bool)
+    static __device__ __forceinline__ void store(const State &st, uint32_t *state, int64_t n, uint32_t i, bool)
     {
         state[i] = (uint32_t)st.s;
         if (W == 2) state[n + i] = (uint32_t)((uint64_t)st.s >> 32);
@@ -318,8 +318,8 @@ struct TagEnv {
 
     static __device__ __forceinline__ void stage(Shared &, const Params &, int) {}
     static __device__ __forceinline__ int n_actions(const Params &) { return 5; }
-    static __device__ __forceinline__ void load(State &st, const uint32_t *state, int64_t, int64_t i) { st.w = state[i]; }
-    static __device__ __forceinline__ void store(const State &st, uint32_t *state, int64_t, int64_t i, bool) { state[i] = st.w; }
+    static __device__ __forceinline__ void load(State &st, const uint32_t *state, int64_t, uint32_t i) { st.w = state[i]; }
+    static __device__ __forceinline__ void store(const State &st, uint32_t *state, int64_t, uint32_t i, bool) { state[i] = st.w; }
 
     // tag.py:52-57 get_tag_coord, 59-66 get_index, 46-50 is_inside
     static __device__ __forceinline__ void coord(int idx, int &x, int &y)
@@ -461,7 +461,7 @@ struct BattleShipEnv {
 
     static __device__ __forceinline__ void stage(Shared &, const Params &, int) {}
     static __device__ __forceinline__ int n_actions(const Params &p) { return p.x_size * p.y_size; }
-    static __device__ __forceinline__ void load(State &st, const uint32_t *state, int64_t n, int64_t i)
+    static __device__ __forceinline__ void load(State &st, const uint32_t *state, int64_t n, uint32_t i)
     {
         uint32_t o[4] = {0, 0, 0, 0}, v[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -470,7 +470,7 @@ struct BattleShipEnv {
         st.vis.lo = v[0] | ((uint64_t)v[1] << 32); st.vis.hi = v[2] | ((uint64_t)v[3] << 32);
     }
     // a step only changes the visited half; the occupied half is rewritten on reset
-    static __device__ __forceinline__ void store(const State &st, uint32_t *state, int64_t n, int64_t i, bool was_reset)
+    static __device__ __forceinline__ void store(const State &st, uint32_t *state, int64_t n, uint32_t i, bool was_reset)
     {
 #pragma unroll
         for (int j = 0; j < MW; ++j) state[(int64_t)(MW + j) * n + i] = st.vis.word(j);
@@ -705,8 +705,8 @@ struct TigerEnv {
 
     static __device__ __forceinline__ void stage(Shared &, const Params &, int) {}
     static __device__ __forceinline__ int n_actions(const Params &) { return 3; }
-    static __device__ __forceinline__ void load(State &st, const uint32_t *state, int64_t, int64_t i) { st.w = state[i]; }
-    static __device__ __forceinline__ void store(const State &st, uint32_t *state, int64_t, int64_t i, bool) { state[i] = st.w; }
+    static __device__ __forceinline__ void load(State &st, const uint32_t *state, int64_t, uint32_t i) { st.w = state[i]; }
+    static __device__ __forceinline__ void store(const State &st, uint32_t *state, int64_t, uint32_t i, bool) { state[i] = st.w; }
 
     // tiger.py:60-66: state = state_space.sample() (gym-space RNG -> stream RESET_SPACE); ob = NULL
     static __device__ __forceinline__ int reset(const Shared &, const Params &, State &st, const RngKey &key,
@@ -773,8 +773,8 @@ struct NetworkEnv {
 
     static __device__ __forceinline__ void stage(Shared &, const Params &, int) {}
     static __device__ __forceinline__ int n_actions(const Params &p) { return 2 * p.n_machines + 1; }
-    static __device__ __forceinline__ void load(State &st, const uint32_t *state, int64_t, int64_t i) { st.w = state[i]; }
-    static __device__ __forceinline__ void store(const State &st, uint32_t *state, int64_t, int64_t i, bool) { state[i] = st.w; }
+    static __device__ __forceinline__ void load(State &st, const uint32_t *state, int64_t, uint32_t i) { st.w = state[i]; }
+    static __device__ __forceinline__ void store(const State &st, uint32_t *state, int64_t, uint32_t i, bool) { state[i] = st.w; }
 
     // network.py:61-69: all machines up, ob = OFF (0)
     static __device__ __forceinline__ int reset(const Shared &, const Params &p, State &st, const RngKey &, uint32_t)

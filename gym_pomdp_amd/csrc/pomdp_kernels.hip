@@ -68,16 +68,17 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const typename Env::Params 
 {
     __shared__ typename Env::Shared sh;
     const bool auto_reset = flags & POMDP_AUTO_RESET;
-    const int64_t base = (int64_t)blockIdx.x * (BLOCK * LPT) + threadIdx.x;
-    int64_t idx[LPT];
+    // 32-bit lane index (the ABI caps lane0 + n at 2^32): addresses become SGPR base + 32-bit VGPR offset
+    const uint32_t base = blockIdx.x * (uint32_t)(BLOCK * LPT) + threadIdx.x;
+    uint32_t idx[LPT];
     bool in_range[LPT], was_done[LPT];
     int a_raw[LPT];
     typename Env::State st[LPT];
 #pragma unroll
     for (int j = 0; j < LPT; ++j) {
-        idx[j] = base + (int64_t)j * BLOCK;
-        in_range[j] = idx[j] < n;
-        const int64_t ic = in_range[j] ? idx[j] : n - 1;
+        idx[j] = base + (uint32_t)(j * BLOCK);
+        in_range[j] = (uint64_t)idx[j] < (uint64_t)n;
+        const uint32_t ic = in_range[j] ? idx[j] : (uint32_t)(n - 1);
         a_raw[j] = action[ic];
         Env::load(st[j], state, n, ic);
         was_done[j] = auto_reset ? false : (done[ic] != 0);          // frozen lane (the reference would assert)
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const typename Env::Params 
     for (int j = 0; j < LPT; ++j) {
         valid[j] = (unsigned)a_raw[j] < (unsigned)n_act;
         live[j] = in_range[j] && valid[j] && !was_done[j];
-        Env::step(sh, p, st[j], valid[j] ? a_raw[j] : 0, key, lane0 + (uint32_t)idx[j], o[j], r[j], d[j]);
+        Env::step(sh, p, st[j], valid[j] ? a_raw[j] : 0, key, lane0 + idx[j], o[j], r[j], d[j]);
         if (!live[j]) { o[j] = 0; r[j] = 0; d[j] = was_done[j]; }     // step result discarded unless live
     }
 #pragma unroll
@@ -101,10 +102,10 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const typename Env::Params 
         const bool fresh = live[j] && d[j] && auto_reset;
         if (CHAIN) {
             int a_next;
-            Env::reset_where_chain(sh, p, st[j], fresh, key, lane0 + (uint32_t)idx[j], akey, (uint32_t)n_act, a_next);
+            Env::reset_where_chain(sh, p, st[j], fresh, key, lane0 + idx[j], akey, (uint32_t)n_act, a_next);
             if (in_range[j]) const_cast<int32_t *>(action)[idx[j]] = a_next;
         } else {
-            Env::reset_where(sh, p, st[j], fresh, key, lane0 + (uint32_t)idx[j]);
+            Env::reset_where(sh, p, st[j], fresh, key, lane0 + idx[j]);
         }
         if (live[j]) Env::store(st[j], state, n, idx[j], fresh);
         if (in_range[j]) {
