@@ -290,6 +290,17 @@ def test_full_size_properties():
         tot_done += int(done.sum())
     assert 0.05 < tot_done / (16 * n) < 0.25                          # episodes last ~8 steps
     assert a_env.invalid_action_count() == 0
+    # the same 2^20 lanes as 8 shards of 2^17 (what 8 GPUs would own): identical states, shard by shard
+    from gym_pomdp_amd import sharding
+    shards = []
+    for r in range(8):
+        off, cnt = sharding.shard_range(n, r, 8)
+        e = make_env("rock", {}, batch_size=cnt, seed=seed, lane_offset=off)
+        e.reset()
+        for _ in range(16):
+            e.step(e.synthetic_actions())
+        shards.append(e.state)
+    assert torch.equal(torch.cat(shards, dim=1), a_env.state)
 
 
 # ---- planner hooks -------------------------------------------------------
