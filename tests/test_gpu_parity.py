@@ -449,3 +449,39 @@ def test_bench_contract_line():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert d["value"] > 1e8          # the north star's single-GPU target, by a wide margin
+
+
+def test_randomised_configs_vs_oracle(oracle_lib):
+    """Property test: random (env config, batch size, seed, lane offset, call counter, auto-reset mode) — the HIP
+    path and the oracle stay word-for-word identical.  Seeded, so a failure is reproducible."""
+    rs = np.random.RandomState(20260929)
+    configs = [("rock", dict(board_size=b, num_rocks=k)) for b, k in ((2, 1), (4, 3), (7, 7), (7, 8), (11, 11), (15, 15))]
+    configs += [("stochrock", dict(board_size=b, num_rocks=k)) for b, k in ((4, 3), (7, 8), (15, 15))]
+    configs += [("tag", dict(num_opponents=k)) for k in (1, 2, 3, 4)]
+    configs += [("battleship", dict(board_size=bs, max_len=m)) for bs, m in (((5, 5), 3), ((6, 4), 2), ((8, 8), 4),
+                                                                             ((10, 10), 5), ((11, 11), 6), ((16, 7), 5))]
+    configs += [("tiger", {})]
+    configs += [("network", dict(n_machines=m, problem_type=p)) for m, p in ((4, 3), (10, 3), (16, 3), (5, 1), (32, 2),
+                                                                            (31, 3))]
+    for trial in range(36):
+        env, kw = configs[trial % len(configs)]
+        n = int(rs.choice([1, 5, 64, 100, 255, 256, 257, 1000, 4096])) * 4
+        seed = int(rs.randint(0, 2 ** 62))
+        lane0 = int(rs.randint(0, 2 ** 28)) * 4
+        t0 = int(rs.randint(0, 2 ** 36))
+        auto = bool(rs.randint(2))
+        o = oracle_lib.OracleEnv(env, **kw)
+        e = make_env(env, kw, batch_size=n, seed=seed, lane_offset=lane0, auto_reset=auto)
+        e.call_counter = t0
+        st = o.new_state(n)
+        assert np.array_equal(np_(e.reset()), o.batch_reset(st, seed, lane0, t0)), (env, kw)
+        done = np.zeros(n, np.uint8)
+        for t in range(t0 + 1, t0 + 1 + 24):
+            a = oracle_lib.synthetic_actions(n, seed + 1, lane0, t, o.n_actions)
+            ob, rew, done, _ = o.batch_step(st, a, seed, lane0, t, auto_reset=auto, done=done)
+            ob_g, rew_g, done_g, _ = e.step(torch.as_tensor(a, device="cuda"))
+            ctx = (env, kw, n, seed, lane0, t, auto)
+            assert np.array_equal(np_(ob_g), ob), ctx
+            assert np.array_equal(np_(rew_g), rew), ctx
+            assert np.array_equal(np_(done_g), done.astype(bool)), ctx
+            assert np.array_equal(np_(e.state).view(np.uint32), st), ctx
