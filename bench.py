@@ -166,8 +166,12 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     import gym_pomdp_amd as gpa
-    from gym_pomdp_amd import sharding
+    from gym_pomdp_amd import _native, sharding
     cp = sharding.ControlPlane()    # gloo, host side: barrier + max of the timings; no data-path collective
+    if not os.path.exists(_native.LIB_PATH):      # normally prebuilt by __graft_entry__.build(); never a CPU fallback
+        if rank == 0:
+            _native.build(verbose=True)
+        cp.barrier()
 
     env_id, kwargs, label, bytes_per_step, dtype = WORKLOADS[args.env]
     n = args.lanes_per_gpu

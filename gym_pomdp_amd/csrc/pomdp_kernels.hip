@@ -291,14 +291,24 @@ using StochRock2 = RockEnv<2, 0, true>;
 
 static bool rock_ok(const pomdp_rock_params *p)
 {
-    return p && p->size >= 1 && p->size <= 15 && p->num_rocks >= 1 && p->num_rocks <= 16 &&
-           (unsigned)p->start_x < (unsigned)p->size && (unsigned)p->start_y < (unsigned)p->size;
+    if (!(p && p->size >= 1 && p->size <= 15 && p->num_rocks >= 1 && p->num_rocks <= 16 &&
+          (unsigned)p->start_x < (unsigned)p->size && (unsigned)p->start_y < (unsigned)p->size))
+        return false;
+    for (int i = 0; i < p->num_rocks; ++i)     // rock coordinates index the LDS tables: keep them on the board
+        if ((unsigned)p->rock_x[i] >= (unsigned)p->size || (unsigned)p->rock_y[i] >= (unsigned)p->size) return false;
+    for (int i = 0; i < 256; ++i)
+        if (p->grid[i] < -1 || p->grid[i] > 15) return false;
+    return true;
 }
 static int bs_mask_words(const pomdp_battleship_params *p)
 {
     if (!p || p->x_size < 1 || p->y_size < 1 || p->x_size > 16 || p->y_size > 16) return 0;
     const int cells = p->x_size * p->y_size;
     if (cells > 122 || p->max_len < 2 || p->max_len > 10) return 0;
+    // a ship of length L needs L + 2 cells in a line (battleship.py:199-201): on a board where the longest ship
+    // cannot be placed the reference's rejection loop never ends, and neither would the kernel's
+    const int longest = p->x_size > p->y_size ? p->x_size : p->y_size;
+    if (longest < p->max_len + 2) return 0;
     return (cells + 6 + 31) / 32;
 }
 

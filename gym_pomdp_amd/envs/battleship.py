@@ -12,6 +12,10 @@ def make_params(board_size=(5, 5), max_len=3):
         raise ValueError("BattleShip: boards up to 122 cells fit the packed masks")
     if not 2 <= max_len <= 10:
         raise ValueError("BattleShip: max_len must be in 2..10")
+    if max(x, y) < max_len + 2:
+        # collision() wants length + 2 cells in a line (battleship.py:199-201); the reference's reset() would loop forever
+        raise ValueError("BattleShip: a %dx%d board cannot hold a ship of length %d (needs %d cells in a line)"
+                         % (x, y, max_len, max_len + 2))
     p = _native.BattleShipParams()
     p.x_size, p.y_size, p.max_len = x, y, max_len
     col0 = sum(1 << (yy * x) for yy in range(y))

@@ -17,7 +17,9 @@
  *   - `state` is struct-of-arrays: uint32 [words][n], word-major, lane i at state[w*n + i];
  *   - params structs are read on the host at call time and passed to the kernel
  *     by value (kernarg) — they may live on the caller's stack;
- *   - `stream` is a hipStream_t (NULL = the null stream); launches are asynchronous;
+ *   - `stream` is a hipStream_t (NULL = the null stream); launches are asynchronous; the calling thread's
+ *     current HIP device must be the one that owns `stream` and the buffers (the library never calls
+ *     hipSetDevice);
  *   - lanes are globally numbered: lane = lane0 + i.  Random draws depend only on
  *     (seed, lane, t, stream-id), never on n, the grid or the GPU count, so a batch
  *     sharded over several GPUs reproduces the single-GPU result exactly;

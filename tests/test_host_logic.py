@@ -38,6 +38,13 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     p.size = 99
     assert L.pomdp_rock_reset(C.byref(p), None, None, 16, 0, 0, 0, None) == -2
     assert L.pomdp_synthetic_actions(None, 16, 0, 0, 0, 13, None) == -1
+    q = rock.make_params()[0]
+    q.rock_x[0] = 9                       # off a 7x7 board
+    assert L.pomdp_rock_reset(C.byref(q), None, None, 16, 0, 0, 0, None) == -2
+    from gym_pomdp_amd import _native as nn
+    b = nn.BattleShipParams()
+    b.x_size, b.y_size, b.max_len = 3, 3, 3
+    assert L.pomdp_battleship_reset(C.byref(b), None, None, 16, 0, 0, 0, None) == -2
 
 
 def test_struct_sizes_match_header_layout():
@@ -102,6 +109,8 @@ def test_other_params_validation():
     assert battleship.make_params((5, 5), 3)[1:] == (2, 25, 2)
     with pytest.raises(ValueError):
         battleship.make_params((12, 12), 5)
+    with pytest.raises(ValueError):          # the reference's reset() would never terminate on this board
+        battleship.make_params((3, 3), 3)
     assert tag.make_params()[1:] == (1, 5, 30)
     with pytest.raises(ValueError):
         tag.make_params(num_opponents=5)
