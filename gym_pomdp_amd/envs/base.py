@@ -75,6 +75,17 @@ class BatchedEnv(object):
         self._done = torch.zeros(n, dtype=torch.uint8, device=self.device)
         self._ob = torch.zeros(n, dtype=torch.int32, device=self.device)
         self._reward = torch.zeros(n, dtype=self.reward_dtype, device=self.device)
+        if n == 1:
+            # scalar mode (the reference's usage): ob / reward / done share one 16-byte device buffer so that a
+            # step is one launch + one pinned D2H copy; the action is passed as a pointer into a device-resident
+            # table of all action values, so there is no per-step H2D copy either
+            self._scalar_buf = torch.zeros(4, dtype=torch.int32, device=self.device)
+            self._ob = self._scalar_buf[0:1]
+            self._reward = self._scalar_buf[1:2].view(self.reward_dtype)
+            self._done = self._scalar_buf[2:3].view(torch.uint8)[0:1]
+            self._action_table = torch.arange(n_actions, dtype=torch.int32, device=self.device)
+            self._host_out = torch.zeros(4, dtype=torch.int32).pin_memory()
+            self._host_reward = self._host_out[1:2].view(self.reward_dtype)
         self._has_reset = False
         self._scalar_done = False
         self._done_bool = self._done.view(torch.bool)
@@ -130,7 +141,7 @@ class BatchedEnv(object):
         if scalar:
             assert self.action_space.contains(action), "invalid action %r" % (action,)
             assert self._scalar_done is False or self.auto_reset, "step() on a done env (call reset())"
-            action = torch.tensor([int(action)], dtype=torch.int32, device=self.device)
+            return self._scalar_step(int(action))
         elif not (isinstance(action, torch.Tensor) and action.dtype == torch.int32 and action.device == self.device
                   and action.dim() == 1 and action.shape[0] == self.batch_size and action.is_contiguous()):
             action = self._as_action_tensor(action)           # slow path: convert / validate
@@ -160,14 +171,28 @@ class BatchedEnv(object):
             if not self.auto_reset and not self.reuse_buffers:
                 done = done.clone()
         info = {"state": self._state}
-        if scalar:
-            d = bool(done.item())
-            self._scalar_done = d
-            self.done = d
-            r = reward.item()
-            return int(ob.item()), (int(r) if self.reward_dtype == torch.int32 else float(r)), d, info
         self.done = self._done_bool if done is self._done else done.view(torch.bool)
         return ob, reward, self.done, info
+
+    def _scalar_step(self, action):
+        """batch_size == 1: one launch, one pinned device-to-host copy, python scalars out."""
+        t = self._t
+        self._t += 1
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device)
+            ptrs = self._ptrs
+            rc = self._step_fn(self._params_ref, ptrs[0], self._action_table.data_ptr() + 4 * action, ptrs[1], ptrs[2],
+                               ptrs[3], ptrs[4], 1, self._seed, self.lane_offset, t,
+                               _native.POMDP_AUTO_RESET if self.auto_reset else 0, stream.cuda_stream)
+            _native.check(rc, "pomdp_%s_step" % self.env_name)
+            self._host_out.copy_(self._scalar_buf, non_blocking=True)
+            stream.synchronize()
+        d = bool(self._host_out[2].item() & 0xFF)
+        self._scalar_done = d
+        self.done = d
+        r = self._host_reward[0].item()
+        return (int(self._host_out[0].item()), (int(r) if self.reward_dtype == torch.int32 else float(r)), d,
+                {"state": self._state})
 
     def _as_action_tensor(self, action):
         if isinstance(action, torch.Tensor):
