@@ -50,6 +50,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--env", default="rock", choices=sorted(WORKLOADS))
     ap.add_argument("--lanes-per-gpu", type=int, default=1 << 20)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default, what the driver's contract asks for): --lanes-per-gpu lanes on every GPU.  "
+                         "strong: --lanes-per-gpu is the TOTAL batch (SURVEY.md §8d reads the metric that way), split "
+                         "over the GPUs")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--host-loop", default="c", choices=["c", "python"],
                     help="who issues the two launches of a step: the C rollout driver or a python loop over env.step()")
@@ -174,9 +178,13 @@ def main():
         cp.barrier()
 
     env_id, kwargs, label, bytes_per_step, dtype = WORKLOADS[args.env]
-    n = args.lanes_per_gpu
-    lane_offset, count = sharding.shard_range(n * world, rank, world)   # weak scaling: n lanes on every GPU
-    assert count == n
+    if args.scaling == "strong":
+        lane_offset, n = sharding.shard_range(args.lanes_per_gpu, rank, world)   # the total batch split over the GPUs
+        assert n == args.lanes_per_gpu // world, "strong scaling needs a batch divisible by 4 * gpus"
+    else:
+        n = args.lanes_per_gpu
+        lane_offset, count = sharding.shard_range(n * world, rank, world)        # n lanes on every GPU
+        assert count == n
     env = gpa.make(env_id, batch_size=n, device=dev, seed=args.seed, lane_offset=lane_offset, reuse_buffers=True,
                    **kwargs)
     if args.mode == "rollout":
@@ -254,7 +262,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": dtype,
             "data": "synthetic",
