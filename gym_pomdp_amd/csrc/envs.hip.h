@@ -575,6 +575,7 @@ struct BattleShipEnv {
         const int X = p.x_size, Y = p.y_size, cells = X * Y;
         const uint32_t rmask = 0xFFFFFFFFu >> __clz((uint32_t)(cells - 1) | 1u); // randint(cells) bit-smear mask
         const u128 col0 = u128_of(p.col0), colL = col0 << (X - 1);
+        const uint32_t inv_x = (65536u + (uint32_t)X - 1u) / (uint32_t)X;   // a / X == (a * inv_x) >> 16 for a < 128, X <= 16
         while (todo != 0ull) {
             const int src = __ffsll((long long)todo) - 1;
             todo &= todo - 1ull;
@@ -583,9 +584,10 @@ struct BattleShipEnv {
             u128 occ = 0;
             int remaining = 0;
             for (int len = p.max_len; len >= 2; --len) {
-                const u128 e = occ & ~col0, w = occ & ~colL;
-                const u128 blocked = occ | (occ >> X) | (occ << X) | (e >> 1) | (w << 1) | (e >> (X + 1)) | (e << (X - 1)) |
-                                     (w << (X + 1));
+                // blocked = occ and its N, E, S, W, NE, SE, SW shifts (NW excluded) in four 128-bit shifts:
+                // h = {self, E, W}; south side = h << X (S, SE, SW); north side = {self, E} >> X (N, NE)
+                const u128 e1 = (occ & ~col0) >> 1, h = occ | e1 | ((occ & ~colL) << 1);
+                const u128 blocked = h | ((occ | e1) >> X) | (h << X);
                 const u128 hpat = ((u128)1 << (len + 1)) - 1;                 // the L+1 checked cells, from bit 0
                 const u128 vpat = u128_of(p.vpat[len + 1]);
                 for (;;) {
@@ -600,7 +602,7 @@ struct BattleShipEnv {
                     const int a0 = (int)(word & rmask);
                     const uint32_t dir = dirword & 3u;
                     const int dx = (dir == 1u) - (dir == 3u), dy = (dir == 0u) - (dir == 2u);   // Compass N E S W
-                    const int px = a0 % X, py = a0 / X;
+                    const int py = (int)(((uint32_t)a0 * inv_x) >> 16), px = a0 - py * X;
                     const int ex = px + (len + 1) * dx, ey = py + (len + 1) * dy;
                     const int stride = dy * X + dx;
                     const bool inside = (unsigned)ex < (unsigned)X && (unsigned)ey < (unsigned)Y;
