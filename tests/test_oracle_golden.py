@@ -213,3 +213,22 @@ def test_compute_prob_matches_reference(oracle_lib, case, env, kw):
             got = o.batch_compute_prob(pre, a, np.full(L, q))
             assert np.array_equal(got, g["prob"][:, i, q]), (case, i, q)
         o.batch_step(st, a, seed, lane0, t0 + 1 + i)                                       # continue with auto-reset
+
+
+def test_moves_axis_convention(oracle_lib):
+    """The reference's only known-answer test (coord.py:174-180, `TestCoord`): (2,2)+NORTH=(2,3), +EAST=(3,2),
+    +SOUTH=(2,1), +WEST=(1,2).  Checked on the oracle's RockSample agent from its start cell (0,3)."""
+    with open(os.path.join(GOLDEN, "edge_cases.json")) as f:
+        moves = json.load(f)["moves"]
+    assert moves == {"NORTH": [0, 1], "EAST": [1, 0], "SOUTH": [0, -1], "WEST": [-1, 0]}
+    o = oracle_lib.OracleEnv("rock")
+    for action, name in enumerate(("NORTH", "EAST", "SOUTH", "WEST")):
+        st = o.new_state(1)
+        o.batch_reset(st, 0, 0, 0)
+        x0, y0 = o.batch_compact(st)[0, :2]
+        ob, rew, done, _ = o.batch_step(st, [action], 0, 0, 1, auto_reset=False)
+        x1, y1 = o.batch_compact(st)[0, :2]
+        if name == "WEST":                      # x = 0: off-grid, -100 and done, position unchanged (rock.py:152-156)
+            assert (x1, y1, int(rew[0]), int(done[0])) == (x0, y0, -100, 1)
+        else:
+            assert [x1 - x0, y1 - y0] == moves[name] and int(rew[0]) == 0 and int(done[0]) == 0
