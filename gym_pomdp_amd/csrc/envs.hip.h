@@ -222,8 +222,12 @@ struct RockEnv {
         if (x - 1 >= 0) { pre |= 3u << (3 * n_pre); ++n_pre; }
         const int id = sh.grid[x * 16 + y];
         if (id >= 0 && id < K && ((uint32_t)(s >> (8 + 2 * (id & 15))) & 3u) != 1u) { pre |= 4u << (3 * n_pre); ++n_pre; }
-        alive = 0;
-        for (int j = 0; j < K; ++j) alive |= ((((uint32_t)(s >> (8 + 2 * j)) & 3u) != 1u) ? 1u : 0u) << j;
+        // uncollected rocks (code != 1), all K at once: with the 2-bit codes spread over even/odd bits,
+        // "collected" is (low bit set, high bit clear); alive stays in spread form, rock j at bit 2 j
+        const uint64_t r = (uint64_t)s >> 8;
+        const uint64_t even = 0x5555555555555555ull;
+        const uint64_t spread = ~(r & ~(r >> 1)) & even & ((1ull << (2 * K)) - 1ull);
+        alive = (uint32_t)spread;                                      // K <= 16 rocks: 32 bits
         return n_pre + __popc(alive);
     }
     static __device__ __forceinline__ int legal_nth(const Shared &sh, const Params &p, const State &st, int idx)
@@ -231,8 +235,9 @@ struct RockEnv {
         uint32_t pre, alive; int n_pre;
         legal_count(sh, p, st, pre, n_pre, alive);
         if (idx < n_pre) return (int)((pre >> (3 * idx)) & 7u);
-        for (int k = idx - n_pre; k > 0; --k) alive &= alive - 1u;               // drop the k lowest set bits
-        const int j = __ffs((int)alive) - 1;
+        // rock j sits at bit 2 j of `alive`: drop the k lowest set bits, take the next one
+        for (int k = idx - n_pre; k > 0; --k) alive &= alive - 1u;
+        const int j = (__ffs((int)alive) - 1) >> 1;
         const uint32_t rxy = sh.rxy[j & 15];
         return 5 + sh.grid[(rxy & 15u) * 16 + (rxy >> 4)];
     }
