@@ -485,3 +485,50 @@ def test_randomised_configs_vs_oracle(oracle_lib):
             assert np.array_equal(np_(rew_g), rew), ctx
             assert np.array_equal(np_(done_g), done.astype(bool)), ctx
             assert np.array_equal(np_(e.state).view(np.uint32), st), ctx
+
+
+def test_episode_statistics_match_the_reference_probes():
+    """Size-independent check at scale: under uniform random actions the done rate per step is 1 / (mean episode
+    length).  SURVEY.md §8d records the reference's mean episode lengths as probed by running it: RockSample(7,8)
+    ~8.3 steps, Tag ~430.  BattleShip 10x10 (14 ship cells, revisits allowed) is a coupon collector over 14 of 100
+    cells: 100 * H_14 = 325.2 steps — the reference itself gives 327.9 +- 7.5 over 300 episodes (SURVEY's "~285" was
+    a rougher probe)."""
+    def done_rate(env, kw, n, burn, steps):
+        e = make_env(env, kw, batch_size=n, seed=2024, reuse_buffers=True)
+        e.reset()
+        e.rollout_synthetic(burn)
+        tot = torch.zeros((), dtype=torch.int64, device="cuda")
+        for _ in range(steps):
+            e.rollout_synthetic(1)
+            tot += e._done.sum()
+        return tot.item() / (n * steps)
+
+    r = done_rate("rock", {}, 1 << 18, 64, 64)
+    assert abs(1 / r - 8.3) < 0.4, 1 / r
+    r = done_rate("tag", {}, 1 << 18, 2000, 200)
+    assert abs(1 / r - 430) < 45, 1 / r
+    r = done_rate("battleship", dict(board_size=(10, 10), max_len=5), 1 << 16, 1500, 400)
+    assert abs(1 / r - 100 * sum(1.0 / k for k in range(1, 15))) < 12, 1 / r
+
+
+def test_large_batch_windows_vs_oracle(oracle_lib):
+    """Maximum-size edge: 2^27 lanes in one batch (2.4 GB of columns); windows of lanes at the start, in the middle
+    and at the very end are checked word for word against the oracle."""
+    n, seed, steps, win = 1 << 27, 31337, 6, 2048
+    e = make_env("rock", {}, batch_size=n, seed=seed, reuse_buffers=True)
+    e.reset()
+    e.rollout_synthetic(steps)          # policy shares the env key
+    torch.cuda.synchronize()
+    o = oracle_lib.OracleEnv("rock")
+    for lane0 in (0, (1 << 26) - 1024, n - win):
+        st = o.new_state(win)
+        o.batch_reset(st, seed, lane0, 0, nthreads=4)
+        for t in range(1, steps + 1):
+            a = oracle_lib.synthetic_actions(win, seed, lane0, t, o.n_actions, nthreads=4)
+            ob, rew, done, _ = o.batch_step(st, a, seed, lane0, t, nthreads=4)
+        sl = slice(lane0, lane0 + win)
+        assert np.array_equal(np_(e.state[:, sl]).view(np.uint32), st), lane0
+        assert np.array_equal(np_(e._ob[sl]), ob) and np.array_equal(np_(e._reward[sl]), rew)
+        assert np.array_equal(np_(e._done[sl]), done)
+    del e
+    torch.cuda.empty_cache()
