@@ -68,6 +68,12 @@ class RockEnv(BatchedEnv):
         cols = [v & 15, (v >> 4) & 15] + [((v >> (8 + 2 * j)) & 3) - 1 for j in range(self.num_rocks)]
         return torch.stack(cols, dim=1)
 
+    def _encode_state(self, state=None):
+        """The reference's array encoding of the state, `[x_size * y + x, status_0 .. status_{K-1}]`
+        (rock.py:196-212 `_decode_state(as_array=True)`, 376-381 `__dict2np__`): int64 [N, 1 + K]."""
+        d = self.decode_state() if state is None else state
+        return torch.cat([(d[:, 1] * self.board_size + d[:, 0]).unsqueeze(1), d[:, 2:]], dim=1)
+
 
 class StochasticRockEnv(RockEnv):
     """gym_pomdp/envs/rock.py:428-504: RockSample where the whole action is skipped with probability

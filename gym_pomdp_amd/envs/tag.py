@@ -42,6 +42,11 @@ class TagEnv(BatchedEnv):
     def _build_params(self):
         return make_params(self.num_opponents, self.move_prob, self.obs_cells, self.board_size)
 
+    def _encode_state(self, state=None):
+        """The reference's `_encode_state` (tag.py:158-165): int32 [N, 1 + num_opponents] = [agent cell, opponent cells..]."""
+        d = self.decode_state() if state is None else state
+        return d[:, : 1 + self.num_opponents].to(torch.int32)
+
     def decode_state(self):
         """int64 [N, 2 + num_opponents] = [agent cell, opponent cells.., num_opp] (tag.py:158-165 order)."""
         w = self._state[0].to(torch.int64) & 0xFFFFFFFF

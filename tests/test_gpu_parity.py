@@ -374,6 +374,22 @@ def test_rollout_vs_oracle(oracle_lib, env, kw, roots, sims, depth):
     assert np.array_equal(np_(got["terminated"]), want["terminated"].astype(bool))
 
 
+def test_reference_state_encodings():
+    """_encode_state mirrors the reference's array encodings (rock.py:196-212, 376-381; tag.py:158-165)."""
+    e = make_env("rock", {}, batch_size=64, seed=1)
+    e.reset()
+    for _ in range(5):
+        e.step(e.synthetic_actions())
+    d = e.decode_state()
+    enc = e._encode_state()
+    assert enc.shape == (64, 9)
+    assert torch.equal(enc[:, 0], d[:, 1] * 7 + d[:, 0]) and torch.equal(enc[:, 1:], d[:, 2:])
+    t = make_env("tag", dict(num_opponents=2), batch_size=32, seed=1)
+    t.reset()
+    enc = t._encode_state()
+    assert enc.shape == (32, 3) and enc.dtype == torch.int32 and int(enc.min()) >= 0 and int(enc.max()) <= 28
+
+
 def test_scalar_planner_hooks():
     e = make_env("rock", {}, seed=5)
     e.reset()
