@@ -50,6 +50,7 @@ struct RockEnv {
     using Reward = int32_t;
     using S = typename std::conditional<W == 1, uint32_t, uint64_t>::type; // 32-bit ALU when one word is enough
     static constexpr int WORDS = W;
+    static constexpr bool POOLED_LPT2 = true;   // pomdp_kernels.hip: Finisher<RockEnv, 2, .>
     struct Shared {
         uint64_t thr[32];   // sensor thresholds by L1 distance
         int8_t grid[256];   // rock id stamped at [x * 16 + y], -1 = none
@@ -318,6 +319,7 @@ struct TagEnv {
     using Params = pomdp_tag_params;
     using Reward = float;
     static constexpr int WORDS = 1;
+    static constexpr bool POOLED_LPT2 = false;
     struct Shared { int unused; };
     struct State { uint32_t w; };
 
@@ -450,6 +452,7 @@ struct BattleShipEnv {
     using Params = pomdp_battleship_params;
     using Reward = int32_t;
     static constexpr int WORDS = 2 * MW;
+    static constexpr bool POOLED_LPT2 = false;
     struct Shared { int unused; };
     // Each 128-bit mask is two 64-bit registers (never an addressable array or vector: a dynamically indexed
     // one is lowered through LDS by the compiler); bit tests are a 64-bit select and one variable shift.
@@ -707,6 +710,7 @@ struct TigerEnv {
     using Params = pomdp_tiger_params;
     using Reward = int32_t;
     static constexpr int WORDS = 1;
+    static constexpr bool POOLED_LPT2 = false;
     struct Shared { int unused; };
     struct State { uint32_t w; };
 
@@ -775,6 +779,7 @@ struct NetworkEnv {
     using Params = pomdp_network_params;
     using Reward = float;
     static constexpr int WORDS = 1;
+    static constexpr bool POOLED_LPT2 = false;
     struct Shared { int unused; };
     struct State { uint32_t w; };
 

@@ -25,6 +25,8 @@ static inline int grid_for(int64_t n)
     return (int)(b < 1 ? 1 : (b > MAX_BLOCKS ? MAX_BLOCKS : b));
 }
 static inline unsigned blocks_for(int64_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
+// below this many lanes two lanes per thread would leave CUs without a workgroup (256 CUs x 4 x 512 lanes)
+constexpr int64_t LPT2_MIN_LANES = 1 << 19;
 
 // ---------------------------------------------------------------------------
 // reset: every lane starts a fresh episode from stream RESET of (seed, lane, t)
@@ -56,6 +58,95 @@ __global__ __launch_bounds__(BLOCK) void reset_kernel(const typename Env::Params
 // overlap.  Lanes past n read lane n-1 and have their stores predicated off.  Every lane of a
 // wave reaches Env::reset_where (wave-cooperative reset).
 // ---------------------------------------------------------------------------
+// ---------------------------------------------------------------------------
+// Finisher: what happens to a wave's lanes after the lane step — auto-reset of the done lanes and, for
+// CHAIN launches, the synthetic policy's actions of the next call counter.  Generic form: one
+// Env::reset_where[_chain] per sub-batch.
+// ---------------------------------------------------------------------------
+template <class Env, int LPT, bool CHAIN>
+struct Finisher {
+    static __device__ __forceinline__ void run(const typename Env::Shared &sh, const typename Env::Params &p,
+                                               typename Env::State (&st)[LPT], const bool (&fresh)[LPT],
+                                               const RngKey &key, const uint32_t (&lane)[LPT], const RngKey &akey,
+                                               uint32_t n_act, int (&a_next)[LPT])
+    {
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) {
+            if (CHAIN) Env::reset_where_chain(sh, p, st[j], fresh[j], key, lane[j], akey, n_act, a_next[j]);
+            else Env::reset_where(sh, p, st[j], fresh[j], key, lane[j]);
+        }
+    }
+};
+
+// RockSample with two lanes per thread: the reset tasks (4 Philox blocks per resetting lane when K is 7 or 8) and,
+// for CHAIN launches, the 32 policy blocks of BOTH 64-lane sub-batches of a wave share one task list, so that a
+// wave runs ~1.4 (CHAIN: ~1.8) Philox passes per 128 lanes instead of one per 64.  The exchange goes through a
+// wave-private LDS scratch (task -> source lane, task -> result); LDS operations of one wave complete in order,
+// so no barrier is involved.
+template <int W, int ABLATE, bool STOCH, bool CHAIN>
+struct Finisher<RockEnv<W, ABLATE, STOCH>, 2, CHAIN> {
+    using Env = RockEnv<W, ABLATE, STOCH>;
+    static __device__ __forceinline__ void run(const typename Env::Shared &sh, const typename Env::Params &p,
+                                               typename Env::State (&st)[2], const bool (&fresh)[2], const RngKey &key,
+                                               const uint32_t (&lane)[2], const RngKey &akey, uint32_t n_act,
+                                               int (&a_next)[2])
+    {
+        const int K = p.num_rocks;
+        if (((K + 1) >> 1) != 4) {                          // other rock counts: the per-sub-batch cooperative path
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (CHAIN) Env::reset_where_chain(sh, p, st[j], fresh[j], key, lane[j], akey, n_act, a_next[j]);
+                else Env::reset_where(sh, p, st[j], fresh[j], key, lane[j]);
+            }
+            return;
+        }
+        __shared__ uint8_t src_lds[BLOCK / 64][128];        // rank -> virtual lane (me + 64 * sub-batch)
+        __shared__ uint16_t res_lds[BLOCK / 64][128];       // rank -> the eight 2-bit rock codes
+        __shared__ uint32_t act_lds[BLOCK / 64][32][4];     // policy block of (sub-batch, quad)
+        const int wv = (int)(threadIdx.x >> 6), me = (int)(threadIdx.x & 63u);
+        const uint64_t m0 = __ballot(fresh[0]), m1 = __ballot(fresh[1]);
+        if (!CHAIN && (m0 | m1) == 0ull) return;             // wave-uniform
+        const int n0 = __popcll(m0), nres = n0 + __popcll(m1);
+        const int rank0 = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u));
+        const int rank1 = n0 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
+        if (fresh[0]) src_lds[wv][rank0] = (uint8_t)me;
+        if (fresh[1]) src_lds[wv][rank1] = (uint8_t)(me + 64);
+        constexpr int NA = CHAIN ? 32 : 0;                   // policy tasks first: (sub-batch j, quad q) at 16 j + q
+        const int ntask = NA + 4 * nres;
+        const uint32_t first0 = lane[0] - (uint32_t)me, first1 = lane[1] - (uint32_t)me;   // first lane of each sub-batch
+        for (int base = 0; base < ntask; base += 64) {
+            const int tid = base + me;
+            const bool is_act = CHAIN && tid < NA;
+            const int rt = tid - NA, b = me & 3;             // NA and base are multiples of 4: block index = me & 3
+            if (tid < ntask) {
+                const int v = is_act ? 0 : (int)src_lds[wv][(rt >> 2) & 127];
+                const uint32_t src_lane = ((v >> 6) ? first1 : first0) + (uint32_t)(v & 63);
+                const uint32_t act_q = (((tid >> 4) ? first1 : first0) >> 2) + (uint32_t)(tid & 15);
+                const uint32_t c0 = is_act ? act_q : src_lane;
+                const uint32_t c1 = is_act ? akey.t_lo : key.t_lo, c2 = is_act ? akey.t_hi : key.t_hi;
+                const uint32_t c3 = is_act ? ((uint32_t)POMDP_STREAM_ACTION << 24) : (((uint32_t)POMDP_STREAM_RESET << 24) | (uint32_t)b);
+                const uint4 w = philox4x32_10(c0, c1, c2, c3, key.k0, key.k1);
+                if (is_act) {
+                    act_lds[wv][tid & 31][0] = w.x; act_lds[wv][tid & 31][1] = w.y;
+                    act_lds[wv][tid & 31][2] = w.z; act_lds[wv][tid & 31][3] = w.w;
+                }
+                const uint32_t cb = (2 * b + 1 < K) ? (Env::rock_code(w.z, w.w) << 2) : 0u;
+                uint32_t code = is_act ? 0u : ((Env::rock_code(w.x, w.y) | cb) << (4 * b));
+                code |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)code, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+                code |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)code, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+                if (!is_act && b == 0) res_lds[wv][(rt >> 2) & 127] = (uint16_t)code;
+            }
+        }
+        const uint32_t start = (uint32_t)p.start_x | ((uint32_t)p.start_y << 4);
+        if (fresh[0]) st[0].s = (typename Env::S)(start | ((uint32_t)res_lds[wv][rank0] << 8));
+        if (fresh[1]) st[1].s = (typename Env::S)(start | ((uint32_t)res_lds[wv][rank1] << 8));
+        if (CHAIN) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) a_next[j] = (int)__umulhi(act_lds[wv][16 * j + (me >> 2)][me & 3], n_act);
+        }
+    }
+};
+
 // CHAIN (C-side rollout driver only): after stepping, action[i] is overwritten with the synthetic
 // policy's action for call counter t + 1 (key `akey`), so the next launch finds its input ready and
 // no separate policy kernel runs.
@@ -97,17 +188,16 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const typename Env::Params 
         Env::step(sh, p, st[j], valid[j] ? a_raw[j] : 0, key, lane0 + idx[j], o[j], r[j], d[j]);
         if (!live[j]) { o[j] = 0; r[j] = 0; d[j] = was_done[j]; }     // step result discarded unless live
     }
+    bool fresh[LPT];
+    uint32_t glane[LPT];
+    int a_next[LPT];
+#pragma unroll
+    for (int j = 0; j < LPT; ++j) { fresh[j] = live[j] && d[j] && auto_reset; glane[j] = lane0 + idx[j]; a_next[j] = 0; }
+    Finisher<Env, LPT, CHAIN>::run(sh, p, st, fresh, key, glane, akey, (uint32_t)n_act, a_next);
 #pragma unroll
     for (int j = 0; j < LPT; ++j) {
-        const bool fresh = live[j] && d[j] && auto_reset;
-        if (CHAIN) {
-            int a_next;
-            Env::reset_where_chain(sh, p, st[j], fresh, key, lane0 + idx[j], akey, (uint32_t)n_act, a_next);
-            if (in_range[j]) const_cast<int32_t *>(action)[idx[j]] = a_next;
-        } else {
-            Env::reset_where(sh, p, st[j], fresh, key, lane0 + idx[j]);
-        }
-        if (live[j]) Env::store(st[j], state, n, idx[j], fresh);
+        if (CHAIN) { if (in_range[j]) const_cast<int32_t *>(action)[idx[j]] = a_next[j]; }
+        if (live[j]) Env::store(st[j], state, n, idx[j], fresh[j]);
         if (in_range[j]) {
             ob[idx[j]] = o[j];
             reward[idx[j]] = r[j];
@@ -266,10 +356,15 @@ static int launch_step(const typename Env::Params &p, uint32_t *state, const int
 {
     if (!state || !action || !ob || !reward || !done || bad_range(n, lane0)) return POMDP_E_BADARG;
     if (n == 0) return 0;
-    // LPT = 1: measured on MI355X (tools/microbench.hip), 1 / 2 / 4 lanes per thread run within 2 % of
-    // each other at 2^20 and 2^22 lanes — the kernel is bound by VALU issue, not by latency.
-    hipLaunchKernelGGL((step_kernel<Env, 1>), dim3(blocks_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, p, state,
-                       action, ob, reward, done, err, n, make_key(seed, t), lane0, flags);
+    // Two lanes per thread where the env pools work across a wave's two 64-lane sub-batches (RockSample: the
+    // Finisher specialisation above) and the batch still gives every CU several workgroups; one lane per thread
+    // otherwise (measured equal within 2 % for the generic envs, tools/microbench.hip).
+    if (Env::POOLED_LPT2 && n >= LPT2_MIN_LANES)
+        hipLaunchKernelGGL((step_kernel<Env, 2>), dim3((unsigned)((n + 2 * BLOCK - 1) / (2 * BLOCK))), dim3(BLOCK), 0,
+                           (hipStream_t)stream, p, state, action, ob, reward, done, err, n, make_key(seed, t), lane0, flags);
+    else
+        hipLaunchKernelGGL((step_kernel<Env, 1>), dim3(blocks_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, p, state,
+                           action, ob, reward, done, err, n, make_key(seed, t), lane0, flags);
     return (int)hipGetLastError();
 }
 
@@ -281,8 +376,14 @@ static int launch_step_chain(const typename Env::Params &p, uint32_t *state, int
 {
     if (!state || !action || !ob || !reward || !done || bad_range(n, lane0) || (lane0 & 3u)) return POMDP_E_BADARG;
     if (n == 0) return 0;
-    hipLaunchKernelGGL((step_kernel<Env, 1, true>), dim3(blocks_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, p, state,
-                       action, ob, reward, done, err, n, make_key(seed, t), lane0, flags, make_key(action_seed, t + 1));
+    if (Env::POOLED_LPT2 && n >= LPT2_MIN_LANES)
+        hipLaunchKernelGGL((step_kernel<Env, 2, true>), dim3((unsigned)((n + 2 * BLOCK - 1) / (2 * BLOCK))), dim3(BLOCK),
+                           0, (hipStream_t)stream, p, state, action, ob, reward, done, err, n, make_key(seed, t), lane0,
+                           flags, make_key(action_seed, t + 1));
+    else
+        hipLaunchKernelGGL((step_kernel<Env, 1, true>), dim3(blocks_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, p,
+                           state, action, ob, reward, done, err, n, make_key(seed, t), lane0, flags,
+                           make_key(action_seed, t + 1));
     return (int)hipGetLastError();
 }
 

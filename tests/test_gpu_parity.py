@@ -527,20 +527,28 @@ def test_episode_statistics_match_the_reference_probes():
     assert abs(1 / r - 100 * sum(1.0 / k for k in range(1, 15))) < 12, 1 / r
 
 
-def test_large_batch_windows_vs_oracle(oracle_lib):
-    """Maximum-size edge: 2^27 lanes in one batch (2.4 GB of columns); windows of lanes at the start, in the middle
-    and at the very end are checked word for word against the oracle."""
-    n, seed, steps, win = 1 << 27, 31337, 6, 2048
-    e = make_env("rock", {}, batch_size=n, seed=seed, reuse_buffers=True)
+@pytest.mark.parametrize("env,kw,log2n,policy_seed", [
+    ("rock", {}, 27, None),                                    # maximum-size edge: 2.4 GB of columns in one batch
+    ("rock", dict(board_size=7, num_rocks=7), 19, None),       # two-lanes-per-thread path, odd K
+    ("rock", dict(board_size=15, num_rocks=15), 19, None),     # two-lanes-per-thread launch, per-sub-batch fallback
+    ("stochrock", {}, 20, None),
+    ("rock", {}, 20, 777),                                     # distinct policy key: plain two-lanes-per-thread launches
+])
+def test_large_batch_windows_vs_oracle(oracle_lib, env, kw, log2n, policy_seed):
+    """Big batches (the launch geometry switches to two lanes per thread at 2^19 lanes): windows of lanes at the
+    start, in the middle and at the very end are checked word for word against the oracle."""
+    n, seed, steps, win = 1 << log2n, 31337, 8, 2048
+    e = make_env(env, kw, batch_size=n, seed=seed, reuse_buffers=True)
     e.reset()
-    e.rollout_synthetic(steps)          # policy shares the env key
+    e.rollout_synthetic(steps, action_seed=policy_seed)
     torch.cuda.synchronize()
-    o = oracle_lib.OracleEnv("rock")
-    for lane0 in (0, (1 << 26) - 1024, n - win):
+    o = oracle_lib.OracleEnv(env, **kw)
+    aseed = seed if policy_seed is None else policy_seed
+    for lane0 in (0, (n >> 1) - 1024, n - win):
         st = o.new_state(win)
         o.batch_reset(st, seed, lane0, 0, nthreads=4)
         for t in range(1, steps + 1):
-            a = oracle_lib.synthetic_actions(win, seed, lane0, t, o.n_actions, nthreads=4)
+            a = oracle_lib.synthetic_actions(win, aseed, lane0, t, o.n_actions, nthreads=4)
             ob, rew, done, _ = o.batch_step(st, a, seed, lane0, t, nthreads=4)
         sl = slice(lane0, lane0 + win)
         assert np.array_equal(np_(e.state[:, sl]).view(np.uint32), st), lane0
