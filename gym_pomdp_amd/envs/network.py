@@ -48,3 +48,23 @@ class NetworkEnv(BatchedEnv):
     def decode_state(self):
         w = self._state[0].to(torch.int64) & 0xFFFFFFFF
         return torch.stack([(w >> i) & 1 for i in range(self._n_machines)], dim=1)
+
+    def step(self, action):
+        if self.batch_size == 1:
+            self.last_action = int(action)           # network.py:80, used by render
+        return super().step(action)
+
+    def reset(self):
+        self.last_action = self._n_machines * 2       # network.py:65
+        self._server = 0                              # network.py:68
+        return super().reset()
+
+    def render(self, mode="ansi", close=False, lane=0):
+        """network.py:116-120: prints `N: <machines up>, S: <server>\t<action>` for one lane (the reference's only
+        text renderer)."""
+        if close:
+            return
+        up = int(self.decode_state()[lane].sum().item())
+        a = getattr(self, "last_action", self._n_machines * 2)
+        act = "M: {} A: {}".format(*divmod(a, 2)) if a < self._n_machines * 2 else "Null"   # network.py:16-21
+        print("N: {}, S: {}".format(up, self._server), act, sep="\t")

@@ -390,6 +390,17 @@ def test_reference_state_encodings():
     assert enc.shape == (32, 3) and enc.dtype == torch.int32 and int(enc.min()) >= 0 and int(enc.max()) <= 28
 
 
+def test_network_ansi_render(capsys):
+    e = make_env("network", {}, seed=2)
+    e.reset()
+    e.render()
+    assert capsys.readouterr().out.strip() == "N: 10, S: 0\tNull"
+    e.step(5)
+    e.render()
+    out = capsys.readouterr().out.strip()
+    assert out.startswith("N: ") and out.endswith("M: 2 A: 1")
+
+
 def test_scalar_planner_hooks():
     e = make_env("rock", {}, seed=5)
     e.reset()
