@@ -41,22 +41,40 @@ __device__ __forceinline__ void reset_where_chain_default(const typename Env::Sh
 // ===========================================================================
 // RockSample
 // ===========================================================================
-// ABLATE is a profiling aid (tools/microbench.hip): bit 0 drops the CHECK Philox block, bit 1 the
-// auto-reset, bit 2 the LDS table lookups.  The product only instantiates ABLATE = 0.
-// STOCH selects StochasticRockEnv (rock.py:428-504).
+// Word contract of the RockSample envs ("split layout").  Every draw RockSample makes is a numpy double
+// = (high word H, low word L) -> k53 = (H >> 5) * 2^26 + (L >> 6).  H and L live in DIFFERENT Philox blocks:
+//   reset  (stream RESET, counter word 0 = lane):      double j = rock j:  H = block 2 (j >> 2), L = block 2 (j >> 2) + 1,
+//                                                       element j & 3;
+//   step   (stream STEP,  counter word 0 = lane >> 2): double j (RockEnv: j = 0 the sensor; StochasticRockEnv:
+//                                                       j = 0 the action gate, j = 1 the sensor): H = block 2 j,
+//                                                       L = block 2 j + 1, element lane & 3 — one block serves the four
+//                                                       lanes of a quad.
+// A comparison k53 <= thr is decided by H alone unless (H >> 5) == (thr >> 26), which happens with probability 2^-27
+// per draw; only then is the L block generated.  So a reset costs ceil(K / 4) blocks instead of ceil(K / 2), a
+// quad's sensor draws cost one block instead of four, and a wave's whole step fits one pooled Philox pass.
+//
+// ABLATE is a profiling aid (tools/microbench.hip): bit 0 drops the sensor Philox block, bit 1 the auto-reset,
+// bit 2 the LDS table lookups.  The product only instantiates ABLATE = 0.  STOCH selects StochasticRockEnv
+// (rock.py:428-504).
 template <int W, int ABLATE = 0, bool STOCH = false> // W = state words per lane: 1 (K <= 12) or 2
 struct RockEnv {
     using Params = pomdp_rock_params;
     using Reward = int32_t;
     using S = typename std::conditional<W == 1, uint32_t, uint64_t>::type; // 32-bit ALU when one word is enough
     static constexpr int WORDS = W;
-    static constexpr bool POOLED_LPT2 = true;   // pomdp_kernels.hip: Finisher<RockEnv, 2, .>
+    static constexpr bool POOLED_LPT2 = !STOCH;   // pomdp_kernels.hip: Finisher<RockEnv, 2, .>
     struct Shared {
-        uint64_t thr[32];   // sensor thresholds by L1 distance
-        int8_t grid[256];   // rock id stamped at [x * 16 + y], -1 = none
-        uint8_t rxy[16];    // rock j position, x | y << 4
+        uint32_t thr_hi[32];   // sensor threshold by L1 distance, thr >> 26  (compared with H >> 5)
+        uint32_t thr_lo[32];   // thr & (2^26 - 1)                            (compared with L >> 6 on a tie)
+        int8_t grid[256];      // rock id stamped at [x * 16 + y], -1 = none
+        uint8_t rxy[16];       // rock j position, x | y << 4
     };
     struct State { S s; };
+    // what the lane step leaves for the deferred sensor draw (pooled launches fetch H from the wave's task pass)
+    struct Aux { uint32_t th, tl; bool good, want; };
+
+    static constexpr uint32_t LO_MASK = (1u << 26) - 1u;
+    static constexpr uint32_t HALF_HI = 1u << 26;            // 2^52 >> 26: the reset's "U > .5" threshold
 
     // One global-load latency: every thread fetches a slice of the kernarg-resident tables with
     // unconditional (index-wrapped) loads, all issued before the first LDS write, so the compiler
@@ -67,7 +85,8 @@ struct RockEnv {
         const uint64_t t = p.thr[tid & 31];
         const int8_t rx = p.rock_x[tid & 15], ry = p.rock_y[tid & 15];
         sh.grid[tid & 255] = g;
-        sh.thr[tid & 31] = t;
+        sh.thr_hi[tid & 31] = (uint32_t)(t >> 26);
+        sh.thr_lo[tid & 31] = (uint32_t)t & LO_MASK;
         sh.rxy[tid & 15] = (uint8_t)((rx & 15) | (ry << 4));
     }
     static __device__ __forceinline__ int n_actions(const Params &p) { return 5 + p.num_rocks; }
@@ -83,12 +102,48 @@ struct RockEnv {
         if (W == 2) state[n + i] = (uint32_t)((uint64_t)st.s >> 32);
     }
 
-    // status + 1 of a fresh rock from the two words of its double: sign(k53 - 2^52) + 1, in 32-bit ops.
-    // k53 = (w0 >> 5) << 26 | (w1 >> 6): bit 31 of w0 is the 2^52 bit; k53 == 2^52 iff every other kept bit is 0.
-    static __device__ __forceinline__ uint32_t rock_code(uint32_t w0, uint32_t w1)
+    static __device__ __forceinline__ uint32_t elem(const uint4 &w, uint32_t e) { return e == 0 ? w.x : e == 1 ? w.y : e == 2 ? w.z : w.w; }
+
+    // ---- split-layout draws ---------------------------------------------------------------------------------
+    // k53 <= (th << 26 | tl)?  decided by the high word; `lo()` (the L word) is only evaluated on a tie
+    template <class LowWord>
+    static __device__ __forceinline__ bool k53_le(uint32_t H, uint32_t th, uint32_t tl, LowWord lo)
     {
-        const uint32_t rest = (w0 & 0x7FFFFFE0u) | (w1 >> 6);
-        return (w0 >> 31) ? (rest ? 2u : 1u) : 0u;
+        const uint32_t kh = H >> 5;
+        bool r = kh < th;
+        if (kh == th) r = (lo() >> 6) <= tl;                                  // probability 2^-27
+        return r;
+    }
+    // status + 1 of a fresh rock, sign(k53 - 2^52) + 1, from its high word; 3 = undecided (needs the low word)
+    static __device__ __forceinline__ uint32_t rock_code_hi(uint32_t H)
+    {
+        const uint32_t kh = H >> 5;
+        return kh > HALF_HI ? 2u : (kh < HALF_HI ? 0u : 3u);
+    }
+    static __device__ __forceinline__ uint32_t rock_code_lo(uint32_t L) { return (L >> 6) ? 2u : 1u; }   // kh == 2^26 exactly
+    // the 2-bit codes of rocks 4 g .. 4 g + 3 (8 bits) of lane `lane`'s fresh episode: one high block, low block on a tie
+    static __device__ __forceinline__ uint32_t reset_group(const RngKey &key, uint32_t lane, int g, int K)
+    {
+        const uint4 h = stream_block(key, lane, POMDP_STREAM_RESET, 2u * (uint32_t)g);
+        return reset_group_codes(h, key, lane, g, K);
+    }
+    static __device__ __forceinline__ uint32_t reset_group_codes(const uint4 &h, const RngKey &key, uint32_t lane, int g, int K)
+    {
+        uint32_t c0 = rock_code_hi(h.x), c1 = rock_code_hi(h.y), c2 = rock_code_hi(h.z), c3 = rock_code_hi(h.w);
+        if (c0 == 3u || c1 == 3u || c2 == 3u || c3 == 3u) {                    // some rock undecided: 2^-27 per rock
+            const uint4 l = stream_block(key, lane, POMDP_STREAM_RESET, 2u * (uint32_t)g + 1u);
+            if (c0 == 3u) c0 = rock_code_lo(l.x);
+            if (c1 == 3u) c1 = rock_code_lo(l.y);
+            if (c2 == 3u) c2 = rock_code_lo(l.z);
+            if (c3 == 3u) c3 = rock_code_lo(l.w);
+        }
+        const int j = 4 * g;
+        return (j < K ? c0 : 0u) | (j + 1 < K ? c1 << 2 : 0u) | (j + 2 < K ? c2 << 4 : 0u) | (j + 3 < K ? c3 << 6 : 0u);
+    }
+    // block `j2` (0 = sensor / gate high words, 1 = their low words, 2 / 3 = StochasticRock's sensor) of lane's quad
+    static __device__ __forceinline__ uint4 quad_block(const RngKey &key, uint32_t lane, uint32_t j2)
+    {
+        return philox4x32_10(lane >> 2, key.t_lo, key.t_hi, ((uint32_t)POMDP_STREAM_STEP << 24) | j2, key.k0, key.k1);
     }
 
     // rock.py:236-241 reset -> 266-271 _get_init_state -> 78-86 Rock.__init__:
@@ -96,38 +151,29 @@ struct RockEnv {
     static __device__ __forceinline__ int reset(const Shared &, const Params &p, State &st, const RngKey &key,
                                                 uint32_t lane)
     {
-        S s = (S)((uint32_t)p.start_x | ((uint32_t)p.start_y << 4));
+        uint64_t s = (uint32_t)p.start_x | ((uint32_t)p.start_y << 4);
         const int K = p.num_rocks;
-        for (int b = 0; 2 * b < K; ++b) {
-            const uint4 w = stream_block(key, lane, POMDP_STREAM_RESET, (uint32_t)b);
-            s |= (S)rock_code(w.x, w.y) << (8 + 4 * b);
-            if (2 * b + 1 < K) s |= (S)rock_code(w.z, w.w) << (10 + 4 * b);
-        }
-        st.s = s;
+        for (int g = 0; 4 * g < K; ++g) s |= (uint64_t)reset_group(key, lane, g, K) << (8 + 8 * g);
+        st.s = (S)s;
         return 0; // Obs.NULL
     }
 
-    // Wave-cooperative reset.  A fresh episode needs NB = ceil(K/2) Philox blocks (K doubles), but
-    // under random actions only ~1/8 of a wave's lanes reset in a given step while nearly every wave
-    // has at least one: done per lane, the whole wave would pay all NB blocks.  Instead the
-    // (resetting lane, block) pairs are dealt out across the 64 lanes — one Philox block per lane per
-    // pass — and the rock codes travel back through DPP / ds_bpermute.  Same words, same result as
-    // reset() above; ~1 pass per step instead of NB blocks.
+    // Wave-cooperative reset (one lane per thread launches).  A fresh episode needs NG = ceil(K/4) high blocks, only
+    // ~1/8 of a wave's lanes reset in a given step while nearly every wave has at least one: done per lane, the whole
+    // wave would pay all NG blocks.  Instead the (resetting lane, block) tasks are dealt out across the 64 lanes — one
+    // Philox block per lane per pass — and the rock codes travel back through ds_bpermute.
     static __device__ __forceinline__ void reset_where(const Shared &sh, const Params &p, State &st, bool fresh,
                                                        const RngKey &key, uint32_t lane)
     {
         int unused;
         reset_core<false>(sh, p, st, fresh, key, lane, key, 1u, unused);
     }
-    // Same pass, plus the synthetic policy's actions for the NEXT call counter (C-side rollout driver):
-    // the wave's 16 action blocks (one per 4 lanes) ride in lanes 0-15 of the first Philox pass, the
-    // reset tasks follow, so chaining the policy costs a handful of cross-lane moves instead of a kernel.
+    // Same pass, plus the synthetic policy's actions for the NEXT call counter (C-side rollout driver, policy and
+    // env sharing the Philox key): the wave's 16 action blocks ride in lanes 0-15 of the first pass.
     static __device__ __forceinline__ void reset_where_chain(const Shared &sh, const Params &p, State &st, bool fresh,
                                                              const RngKey &key, uint32_t lane, const RngKey &akey,
                                                              uint32_t n_actions, int &next_action)
     {
-        // the chained launch is only used when policy and env share the Philox key (their streams differ by
-        // stream id), so the key schedule of the pooled pass stays wave-uniform (SGPRs)
         reset_core<true>(sh, p, st, fresh, key, lane, akey, n_actions, next_action);
     }
 
@@ -140,70 +186,47 @@ struct RockEnv {
         const uint64_t mask = __ballot(fresh);
         if (!CHAIN && mask == 0ull) return;                            // wave-uniform
         const int K = p.num_rocks;
-        const int NB = (K + 1) >> 1;                                   // blocks per reset (wave-uniform)
+        const int NG = (K + 3) >> 2;                                   // high blocks per reset (wave-uniform, 1..4)
         const int lid = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
         const int me = (int)(threadIdx.x & 63u);
         const int nreset = __popcll(mask);
         // stable partition: resetting lanes first; lane r (< nreset) learns who the r-th resetting lane is
         const int dst = fresh ? lid : nreset + (me - lid);
         const int src_of_rank = __builtin_amdgcn_ds_permute(dst << 2, me);
+        constexpr int NA = CHAIN ? 16 : 0;                             // task list: [16 policy blocks] ++ [NG per reset]
+        const int ntask = NA + nreset * NG;
+        const uint32_t inv = (65536u + (uint32_t)NG - 1u) / (uint32_t)NG; // t / NG == (t * inv) >> 16 for t < 512
         uint64_t bits = 0;
-        if (NB == 4) {
-            // K = 7 or 8 (the metric config): the four tasks of one reset sit in one quad of lanes.
-            // Task list: [16 action tasks (CHAIN only)] ++ [4 tasks per resetting lane].
-            constexpr int NA = CHAIN ? 16 : 0;
-            const int ntask = NA + nreset * 4;
-            uint4 aw = make_uint4(0, 0, 0, 0);
-            for (int base = 0; base < ntask; base += 64) {
-                const int tid = base + me;
-                const bool is_act = CHAIN && tid < NA;
-                const int rt = tid - NA;                                   // reset task index (negative for action tasks)
-                const int srcl = __shfl(src_of_rank, (rt >> 2) & 63, 64);
-                const int b = me & 3;
-                uint32_t v = 0;
-                if (tid < ntask) {
-                    // ONE Philox instance for both task kinds: the counter words are per-lane selects (a branch
-                    // on is_act would run the ten rounds twice under complementary exec masks)
-                    const uint32_t c0 = is_act ? ((lane - (uint32_t)me) >> 2) + (uint32_t)tid : lane - (uint32_t)me + (uint32_t)srcl;
-                    const uint32_t c1 = is_act ? akey.t_lo : key.t_lo, c2 = is_act ? akey.t_hi : key.t_hi;
-                    const uint32_t c3 = is_act ? ((uint32_t)POMDP_STREAM_ACTION << 24) : (((uint32_t)POMDP_STREAM_RESET << 24) | (uint32_t)b);
-                    const uint4 w = philox4x32_10(c0, c1, c2, c3, key.k0, key.k1);
-                    if (CHAIN && base == 0) aw = w;                    // wave-uniform condition; lanes >= 16 hold junk nobody reads
-                    const uint32_t cb = (2 * b + 1 < K) ? (rock_code(w.z, w.w) << 2) : 0u;
-                    v = is_act ? 0u : ((rock_code(w.x, w.y) | cb) << (4 * b));
-                }
-                v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true); // quad_perm [1,0,3,2]
-                v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true); // quad_perm [2,3,0,1]
-                const int t = NA + lid * 4 - base;
-                const uint32_t got = (uint32_t)__shfl((int)v, t & 63, 64);
-                if (t >= 0 && t < 64) bits = (uint64_t)got << 8;
-                if (CHAIN && base == 0) {
-                    // lane l takes word (l & 3) of the block computed by lane l >> 2
-                    const int q = me >> 2;
-                    const uint32_t x = (uint32_t)__shfl((int)aw.x, q, 64), y = (uint32_t)__shfl((int)aw.y, q, 64);
-                    const uint32_t z = (uint32_t)__shfl((int)aw.z, q, 64), ww = (uint32_t)__shfl((int)aw.w, q, 64);
-                    next_action = (int)__umulhi(b == 0 ? x : b == 1 ? y : b == 2 ? z : ww, n_actions);
-                }
+        uint4 aw = make_uint4(0, 0, 0, 0);
+        for (int base = 0; base < ntask; base += 64) {
+            const int tid = base + me;
+            const bool is_act = CHAIN && tid < NA;
+            const int rt = tid < NA ? 0 : tid - NA;
+            const int r = (int)(((uint32_t)rt * inv) >> 16), g = rt - r * NG;
+            const int srcl = __shfl(src_of_rank, r & 63, 64);
+            uint32_t codes = 0;
+            if (tid < ntask) {
+                // ONE Philox instance for both task kinds: the counter words are per-lane selects
+                const uint32_t src_lane = lane - (uint32_t)me + (uint32_t)srcl;
+                const uint32_t c0 = is_act ? ((lane - (uint32_t)me) >> 2) + (uint32_t)tid : src_lane;
+                const uint32_t c1 = is_act ? akey.t_lo : key.t_lo, c2 = is_act ? akey.t_hi : key.t_hi;
+                const uint32_t c3 = is_act ? ((uint32_t)POMDP_STREAM_ACTION << 24) : (((uint32_t)POMDP_STREAM_RESET << 24) | (2u * (uint32_t)g));
+                const uint4 w = philox4x32_10(c0, c1, c2, c3, key.k0, key.k1);
+                if (CHAIN && base == 0) aw = w;                        // lanes >= 16 hold words nobody reads
+                if (!is_act) codes = reset_group_codes(w, key, src_lane, g, K);
             }
-        } else {
-            if (CHAIN) next_action = synthetic_action(akey, lane, n_actions);
-            const int ntask = nreset * NB;
-            const uint32_t inv = (65536u + (uint32_t)NB - 1u) / (uint32_t)NB; // tid / NB == (tid * inv) >> 16 for tid < 512
-            for (int base = 0; base < ntask; base += 64) {
-                const int tid = base + me;
-                const int r = (int)(((uint32_t)tid * inv) >> 16);
-                const int b = tid - r * NB;
-                const int srcl = __shfl(src_of_rank, r & 63, 64);
-                uint32_t nib = 0;
-                if (tid < ntask) {
-                    const uint4 w = stream_block(key, lane - (uint32_t)me + (uint32_t)srcl, POMDP_STREAM_RESET, (uint32_t)b);
-                    nib = rock_code(w.x, w.y) | ((2 * b + 1 < K) ? (rock_code(w.z, w.w) << 2) : 0u);
-                }
-                for (int bb = 0; bb < NB; ++bb) {                       // wave-uniform trip count
-                    const int t = lid * NB + bb - base;
-                    const uint32_t got = (uint32_t)__shfl((int)nib, t & 63, 64);
-                    if (t >= 0 && t < 64) bits |= (uint64_t)got << (8 + 4 * bb);
-                }
+            for (int gg = 0; gg < NG; ++gg) {                          // wave-uniform trip count
+                const int t = NA + lid * NG + gg - base;
+                const uint32_t got = (uint32_t)__shfl((int)codes, t & 63, 64);
+                if (t >= 0 && t < 64) bits |= (uint64_t)got << (8 + 8 * gg);
+            }
+            if (CHAIN && base == 0) {
+                // lane l takes word (l & 3) of the policy block computed by lane l >> 2
+                const int q = me >> 2;
+                const uint32_t x = (uint32_t)__shfl((int)aw.x, q, 64), y = (uint32_t)__shfl((int)aw.y, q, 64);
+                const uint32_t z = (uint32_t)__shfl((int)aw.z, q, 64), ww = (uint32_t)__shfl((int)aw.w, q, 64);
+                const int b = me & 3;
+                next_action = (int)__umulhi(b == 0 ? x : b == 1 ? y : b == 2 ? z : ww, n_actions);
             }
         }
         if (fresh) st.s = (S)((uint64_t)((uint32_t)p.start_x | ((uint32_t)p.start_y << 4)) | bits);
@@ -261,29 +284,25 @@ struct RockEnv {
         return 1 - eff;
     }
 
-    // rock.py:123-194 step; 401-407 _sample_ob; 383-387 _efficiency; coord.py:133-135 (L1 distance).
-    // Branch-free: the three action classes (move / SAMPLE / CHECK) are all evaluated and selected,
-    // so a wave with mixed actions — every wave, under a random policy — runs one straight line.
+    // Everything of rock.py:123-194 except the sensor's Bernoulli draw: transition, reward, done, and (in `aux`) what
+    // the draw will be compared with.  Branch-free: the three action classes (move / SAMPLE / CHECK) are all
+    // evaluated and selected, so a wave with mixed actions — every wave, under a random policy — runs one straight line.
     template <class RT>
-    static __device__ __forceinline__ void step(const Shared &sh, const Params &p, State &st, int a,
-                                                const RngKey &key, uint32_t lane, int &ob, RT &rew, int &done)
+    static __device__ __forceinline__ void step_pre(const Shared &sh, const Params &p, State &st, int a, RT &rew,
+                                                    int &done, Aux &aux)
     {
         const S s = st.s;
         const int x = (int)(s & 15u), y = (int)((s >> 4) & 15u);
         const int size = p.size, K = p.num_rocks;
-        // CHECK rock a-5 (rock.py:171-175): one double from stream STEP -> binomial(1, eff(d))
+        // CHECK rock a-5 (rock.py:171-175, 401-407, 383-387; coord.py:133-135: L1 distance)
         const int r = (a - 5) & 15;
         const uint32_t rxy = (ABLATE & 4) ? (uint32_t)(r * 17) : sh.rxy[r];
         const int d = abs(x - (int)(rxy & 15u)) + abs(y - (int)(rxy >> 4));
-        const uint4 w = (ABLATE & 1) ? make_uint4(lane * 2654435761u, lane, 0, 0) : stream_block(key, lane, POMDP_STREAM_STEP, 0u);
-        // StochasticRock: the first double of the step gates the whole action (rock.py:443), the sensor
-        // draw is then the second double of the same Philox block
-        const bool act = !STOCH || k53(w.x, w.y) <= p.act_thr;
-        const uint64_t k_sensor = STOCH ? k53(w.z, w.w) : k53(w.x, w.y);
+        aux.th = (ABLATE & 4) ? (uint32_t)d << 22 : sh.thr_hi[d];
+        aux.tl = (ABLATE & 4) ? 0u : sh.thr_lo[d];
+        aux.good = ((uint32_t)(s >> (8 + 2 * r)) & 3u) == 2u;
+        aux.want = a > 4;
         const int penalty = STOCH ? 0 : -100;                                  // rock.py:117 / rock.py:432
-        const bool correct = k_sensor <= ((ABLATE & 4) ? (uint64_t)d << 48 : sh.thr[d]);
-        const bool good = ((uint32_t)(s >> (8 + 2 * r)) & 3u) == 2u;
-        const int ob_check = (good == correct) ? 2 : 1;                        // rock.py:404-407
         // SAMPLE (rock.py:160-169); ids >= K raise IndexError in the reference, "no rock" here
         const int id = (ABLATE & 4) ? ((x ^ y) & 7) - (x & 1) : sh.grid[x * 16 + y];
         const int sh_ = 8 + 2 * (id & 15);
@@ -297,18 +316,43 @@ struct RockEnv {
         const S s_move = inside ? (S)((s & ~(S)0xFF) | (S)(uint32_t)(nx | (ny << 4))) : s;
         const int rew_move = inside ? 0 : (a == 1 ? 10 : penalty);             // east exit / off-grid
         const bool is_move = a < 4, is_sample = a == 4;
+        st.s = is_move ? s_move : (is_sample ? s_sample : s);
+        rew = is_move ? rew_move : (is_sample ? rew_sample : 0);
+        if (STOCH) done = is_move && !inside && a == 1;                        // penalties never terminate (rock.py:503)
+        else done = is_move ? !inside : (rew == -100);                         // rock.py:139-141, 193
+    }
+    // observation of a CHECK from the sensor's high word (rock.py:404-407); `lo` yields the low word on a tie
+    template <class LowWord>
+    static __device__ __forceinline__ int sensor_ob(const Aux &aux, uint32_t H, LowWord lo)
+    {
+        const bool correct = k53_le(H, aux.th, aux.tl, lo);
+        return aux.want ? ((aux.good == correct) ? 2 : 1) : 0;
+    }
+
+    // The whole step for one lane (launches that do not pool the quad's sensor block: one lane per thread, rollouts).
+    template <class RT>
+    static __device__ __forceinline__ void step(const Shared &sh, const Params &p, State &st, int a,
+                                                const RngKey &key, uint32_t lane, int &ob, RT &rew, int &done)
+    {
+        const uint32_t e = lane & 3u;
         if (STOCH) {
-            // penalties are 0 and never terminate (rock.py:503 is commented out); only the east exit ends
-            st.s = act ? (is_move ? s_move : (is_sample ? s_sample : s)) : s;
-            rew = act ? (is_move ? rew_move : (is_sample ? rew_sample : 0)) : 0;
-            ob = (act && a > 4) ? ob_check : 0;
-            done = act && is_move && !inside && a == 1;
-        } else {
-            st.s = is_move ? s_move : (is_sample ? s_sample : s);
-            rew = is_move ? rew_move : (is_sample ? rew_sample : 0);
-            ob = (a > 4) ? ob_check : 0;
-            done = is_move ? !inside : (rew == -100);                          // rock.py:139-141, 193
+            // the first double of the step gates the whole action (rock.py:443), the sensor draw is the second
+            const uint4 g = quad_block(key, lane, 0u);
+            const bool act = k53_le(elem(g, e), (uint32_t)(p.act_thr >> 26), (uint32_t)p.act_thr & LO_MASK,
+                                    [&]() { return elem(quad_block(key, lane, 1u), e); });
+            State nx = st;
+            Aux aux; RT r2; int d2;
+            step_pre(sh, p, nx, a, r2, d2, aux);
+            const uint4 h = quad_block(key, lane, 2u);
+            const int o2 = sensor_ob(aux, elem(h, e), [&]() { return elem(quad_block(key, lane, 3u), e); });
+            if (act) { st = nx; rew = r2; done = d2; ob = o2; }
+            else { rew = 0; done = 0; ob = 0; }
+            return;
         }
+        Aux aux;
+        step_pre(sh, p, st, a, rew, done, aux);
+        const uint4 h = (ABLATE & 1) ? make_uint4(lane * 2654435761u, lane, 0, 0) : quad_block(key, lane, 0u);
+        ob = sensor_ob(aux, elem(h, e), [&]() { return elem(quad_block(key, lane, 1u), e); });
     }
 };
 

@@ -25,8 +25,8 @@ static inline int grid_for(int64_t n)
     return (int)(b < 1 ? 1 : (b > MAX_BLOCKS ? MAX_BLOCKS : b));
 }
 static inline unsigned blocks_for(int64_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
-// below this many lanes two lanes per thread would leave CUs without a workgroup (256 CUs x 4 x 512 lanes)
-constexpr int64_t LPT2_MIN_LANES = 1 << 19;
+// below this many lanes one lane per thread is as fast or faster (measured: tools/microbench.hip at 2^16 .. 2^19)
+constexpr int64_t LPT2_MIN_LANES = 1 << 18;
 
 // ---------------------------------------------------------------------------
 // reset: every lane starts a fresh episode from stream RESET of (seed, lane, t)
@@ -59,16 +59,24 @@ __global__ __launch_bounds__(BLOCK) void reset_kernel(const typename Env::Params
 // wave reaches Env::reset_where (wave-cooperative reset).
 // ---------------------------------------------------------------------------
 // ---------------------------------------------------------------------------
-// Finisher: what happens to a wave's lanes after the lane step — auto-reset of the done lanes and, for
-// CHAIN launches, the synthetic policy's actions of the next call counter.  Generic form: one
-// Env::reset_where[_chain] per sub-batch.
+// Finisher: the lane step of a thread's lanes and what follows it — auto-reset of the done lanes and, for
+// CHAIN launches, the synthetic policy's actions of the next call counter.  Generic form: Env::step per lane,
+// one Env::reset_where[_chain] per 64-lane sub-batch.
 // ---------------------------------------------------------------------------
 template <class Env, int LPT, bool CHAIN>
 struct Finisher {
+    struct Aux {};
+    template <class RT>
+    static __device__ __forceinline__ void lane_step(const typename Env::Shared &sh, const typename Env::Params &p,
+                                                     typename Env::State &st, int a, const RngKey &key, uint32_t lane,
+                                                     int &ob, RT &rew, int &done, Aux &)
+    {
+        Env::step(sh, p, st, a, key, lane, ob, rew, done);
+    }
     static __device__ __forceinline__ void run(const typename Env::Shared &sh, const typename Env::Params &p,
                                                typename Env::State (&st)[LPT], const bool (&fresh)[LPT],
                                                const RngKey &key, const uint32_t (&lane)[LPT], const RngKey &akey,
-                                               uint32_t n_act, int (&a_next)[LPT])
+                                               uint32_t n_act, int (&a_next)[LPT], const Aux (&)[LPT], int (&)[LPT])
     {
 #pragma unroll
         for (int j = 0; j < LPT; ++j) {
@@ -78,71 +86,82 @@ struct Finisher {
     }
 };
 
-// RockSample with two lanes per thread: the reset tasks (4 Philox blocks per resetting lane when K is 7 or 8) and,
-// for CHAIN launches, the 32 policy blocks of BOTH 64-lane sub-batches of a wave share one task list, so that a
-// wave runs ~1.4 (CHAIN: ~1.8) Philox passes per 128 lanes instead of one per 64.  The exchange goes through a
-// wave-private LDS scratch (task -> source lane, task -> result); LDS operations of one wave complete in order,
-// so no barrier is involved.
-template <int W, int ABLATE, bool STOCH, bool CHAIN>
-struct Finisher<RockEnv<W, ABLATE, STOCH>, 2, CHAIN> {
-    using Env = RockEnv<W, ABLATE, STOCH>;
-    static __device__ __forceinline__ void run(const typename Env::Shared &sh, const typename Env::Params &p,
+// RockSample with two lanes per thread: ONE task list per wave (128 lanes) holds
+//   - the 32 sensor blocks of its quads (stream STEP is shared by the four lanes of a quad),
+//   - for CHAIN launches the 32 policy blocks of the next call counter,
+//   - ceil(K/4) reset blocks per resetting lane,
+// i.e. ~63 (CHAIN: ~95) Philox blocks for 128 lane-steps, dealt out 64 per pass.  The lane step therefore runs
+// WITHOUT its sensor draw (Env::step_pre) and the observation is completed here from the pooled words.  Tasks and
+// results are exchanged through a wave-private LDS scratch; LDS operations of one wave complete in order, so no
+// barrier is involved.  Low words (needed with probability 2^-27 per draw) are generated per lane on demand.
+template <int W, int ABLATE, bool CHAIN>
+struct Finisher<RockEnv<W, ABLATE, false>, 2, CHAIN> {
+    using Env = RockEnv<W, ABLATE, false>;
+    using Aux = typename Env::Aux;
+    template <class RT>
+    static __device__ __forceinline__ void lane_step(const typename Env::Shared &sh, const typename Env::Params &p,
+                                                     typename Env::State &st, int a, const RngKey &, uint32_t, int &ob,
+                                                     RT &rew, int &done, Aux &aux)
+    {
+        Env::step_pre(sh, p, st, a, rew, done, aux);
+        ob = 0;
+    }
+    static __device__ __forceinline__ void run(const typename Env::Shared &, const typename Env::Params &p,
                                                typename Env::State (&st)[2], const bool (&fresh)[2], const RngKey &key,
                                                const uint32_t (&lane)[2], const RngKey &akey, uint32_t n_act,
-                                               int (&a_next)[2])
+                                               int (&a_next)[2], const Aux (&aux)[2], int (&ob)[2])
     {
-        const int K = p.num_rocks;
-        if (((K + 1) >> 1) != 4) {                          // other rock counts: the per-sub-batch cooperative path
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                if (CHAIN) Env::reset_where_chain(sh, p, st[j], fresh[j], key, lane[j], akey, n_act, a_next[j]);
-                else Env::reset_where(sh, p, st[j], fresh[j], key, lane[j]);
-            }
-            return;
-        }
-        __shared__ uint8_t src_lds[BLOCK / 64][128];        // rank -> virtual lane (me + 64 * sub-batch)
-        __shared__ uint16_t res_lds[BLOCK / 64][128];       // rank -> the eight 2-bit rock codes
-        __shared__ uint32_t act_lds[BLOCK / 64][32][4];     // policy block of (sub-batch, quad)
+        __shared__ uint8_t src_lds[BLOCK / 64][128];         // reset rank -> virtual lane (me + 64 * sub-batch)
+        __shared__ uint8_t res_lds[BLOCK / 64][128][4];      // reset rank -> four 2-bit rock codes per group g
+        __shared__ uint32_t blk_lds[BLOCK / 64][64][4];      // [0,32): sensor blocks, [32,64): policy blocks; (sub-batch, quad)
         const int wv = (int)(threadIdx.x >> 6), me = (int)(threadIdx.x & 63u);
+        const int K = p.num_rocks, NG = (K + 3) >> 2;        // high blocks per reset
         const uint64_t m0 = __ballot(fresh[0]), m1 = __ballot(fresh[1]);
-        if (!CHAIN && (m0 | m1) == 0ull) return;             // wave-uniform
         const int n0 = __popcll(m0), nres = n0 + __popcll(m1);
         const int rank0 = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u));
         const int rank1 = n0 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
         if (fresh[0]) src_lds[wv][rank0] = (uint8_t)me;
         if (fresh[1]) src_lds[wv][rank1] = (uint8_t)(me + 64);
-        constexpr int NA = CHAIN ? 32 : 0;                   // policy tasks first: (sub-batch j, quad q) at 16 j + q
-        const int ntask = NA + 4 * nres;
+        constexpr int NQ = (ABLATE & 1) ? 0 : 32;            // sensor tasks
+        constexpr int NA = CHAIN ? 32 : 0;                   // policy tasks
+        const int ntask = NQ + NA + NG * nres;
+        const uint32_t inv = (65536u + (uint32_t)NG - 1u) / (uint32_t)NG;   // t / NG == (t * inv) >> 16 for t < 512
         const uint32_t first0 = lane[0] - (uint32_t)me, first1 = lane[1] - (uint32_t)me;   // first lane of each sub-batch
         for (int base = 0; base < ntask; base += 64) {
             const int tid = base + me;
-            const bool is_act = CHAIN && tid < NA;
-            const int rt = tid - NA, b = me & 3;             // NA and base are multiples of 4: block index = me & 3
             if (tid < ntask) {
-                const int v = is_act ? 0 : (int)src_lds[wv][(rt >> 2) & 127];
+                const bool is_q = tid < NQ, is_act = !is_q && tid < NQ + NA;
+                const int qt = is_q ? tid : tid - NQ;                          // (sub-batch, quad) index of a block task
+                const int rt = tid < NQ + NA ? 0 : tid - NQ - NA;
+                const int r = (int)(((uint32_t)rt * inv) >> 16), g = rt - r * NG;
+                const int v = (int)src_lds[wv][r & 127];
                 const uint32_t src_lane = ((v >> 6) ? first1 : first0) + (uint32_t)(v & 63);
-                const uint32_t act_q = (((tid >> 4) ? first1 : first0) >> 2) + (uint32_t)(tid & 15);
-                const uint32_t c0 = is_act ? act_q : src_lane;
+                const uint32_t quad = (((qt >> 4) ? first1 : first0) >> 2) + (uint32_t)(qt & 15);
+                // ONE Philox instance for the three task kinds: the counter words are per-lane selects
+                const uint32_t c0 = (is_q || is_act) ? quad : src_lane;
                 const uint32_t c1 = is_act ? akey.t_lo : key.t_lo, c2 = is_act ? akey.t_hi : key.t_hi;
-                const uint32_t c3 = is_act ? ((uint32_t)POMDP_STREAM_ACTION << 24) : (((uint32_t)POMDP_STREAM_RESET << 24) | (uint32_t)b);
+                const uint32_t c3 = is_q ? ((uint32_t)POMDP_STREAM_STEP << 24)
+                                         : (is_act ? ((uint32_t)POMDP_STREAM_ACTION << 24)
+                                                   : (((uint32_t)POMDP_STREAM_RESET << 24) | (2u * (uint32_t)g)));
                 const uint4 w = philox4x32_10(c0, c1, c2, c3, key.k0, key.k1);
-                if (is_act) {
-                    act_lds[wv][tid & 31][0] = w.x; act_lds[wv][tid & 31][1] = w.y;
-                    act_lds[wv][tid & 31][2] = w.z; act_lds[wv][tid & 31][3] = w.w;
+                if (is_q || is_act) {
+                    uint32_t *dst = blk_lds[wv][(is_act ? 32 : 0) + (qt & 31)];
+                    dst[0] = w.x; dst[1] = w.y; dst[2] = w.z; dst[3] = w.w;
+                } else {
+                    res_lds[wv][r & 127][g] = (uint8_t)Env::reset_group_codes(w, key, src_lane, g, K);
                 }
-                const uint32_t cb = (2 * b + 1 < K) ? (Env::rock_code(w.z, w.w) << 2) : 0u;
-                uint32_t code = is_act ? 0u : ((Env::rock_code(w.x, w.y) | cb) << (4 * b));
-                code |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)code, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
-                code |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)code, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
-                if (!is_act && b == 0) res_lds[wv][(rt >> 2) & 127] = (uint16_t)code;
             }
         }
         const uint32_t start = (uint32_t)p.start_x | ((uint32_t)p.start_y << 4);
-        if (fresh[0]) st[0].s = (typename Env::S)(start | ((uint32_t)res_lds[wv][rank0] << 8));
-        if (fresh[1]) st[1].s = (typename Env::S)(start | ((uint32_t)res_lds[wv][rank1] << 8));
-        if (CHAIN) {
+        const uint32_t used = NG >= 4 ? 0xFFFFFFFFu : ((1u << (8 * NG)) - 1u);   // groups >= NG were never written
+        const uint32_t *res32 = reinterpret_cast<const uint32_t *>(&res_lds[wv][0][0]);
+        if (fresh[0]) st[0].s = (typename Env::S)((uint64_t)start | ((uint64_t)(res32[rank0] & used) << 8));
+        if (fresh[1]) st[1].s = (typename Env::S)((uint64_t)start | ((uint64_t)(res32[rank1] & used) << 8));
 #pragma unroll
-            for (int j = 0; j < 2; ++j) a_next[j] = (int)__umulhi(act_lds[wv][16 * j + (me >> 2)][me & 3], n_act);
+        for (int j = 0; j < 2; ++j) {
+            const uint32_t H = (ABLATE & 1) ? lane[j] * 2654435761u : blk_lds[wv][16 * j + (me >> 2)][me & 3];
+            ob[j] = Env::sensor_ob(aux[j], H, [&]() { return Env::elem(Env::quad_block(key, lane[j], 1u), lane[j] & 3u); });
+            if (CHAIN) a_next[j] = (int)__umulhi(blk_lds[wv][32 + 16 * j + (me >> 2)][me & 3], n_act);
         }
     }
 };
@@ -177,25 +196,28 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const typename Env::Params 
     Env::stage(sh, p, (int)threadIdx.x);
     __syncthreads();
 
+    using Fin = Finisher<Env, LPT, CHAIN>;
     const int n_act = Env::n_actions(p);
     int o[LPT], d[LPT];
     typename Env::Reward r[LPT];
+    typename Fin::Aux aux[LPT];
     bool live[LPT], valid[LPT];
 #pragma unroll
     for (int j = 0; j < LPT; ++j) {
         valid[j] = (unsigned)a_raw[j] < (unsigned)n_act;
         live[j] = in_range[j] && valid[j] && !was_done[j];
-        Env::step(sh, p, st[j], valid[j] ? a_raw[j] : 0, key, lane0 + idx[j], o[j], r[j], d[j]);
-        if (!live[j]) { o[j] = 0; r[j] = 0; d[j] = was_done[j]; }     // step result discarded unless live
+        Fin::lane_step(sh, p, st[j], valid[j] ? a_raw[j] : 0, key, lane0 + idx[j], o[j], r[j], d[j], aux[j]);
+        if (!live[j]) { r[j] = 0; d[j] = was_done[j]; }               // step result discarded unless live
     }
     bool fresh[LPT];
     uint32_t glane[LPT];
     int a_next[LPT];
 #pragma unroll
     for (int j = 0; j < LPT; ++j) { fresh[j] = live[j] && d[j] && auto_reset; glane[j] = lane0 + idx[j]; a_next[j] = 0; }
-    Finisher<Env, LPT, CHAIN>::run(sh, p, st, fresh, key, glane, akey, (uint32_t)n_act, a_next);
+    Fin::run(sh, p, st, fresh, key, glane, akey, (uint32_t)n_act, a_next, aux, o);
 #pragma unroll
     for (int j = 0; j < LPT; ++j) {
+        if (!live[j]) o[j] = 0;
         if (CHAIN) { if (in_range[j]) const_cast<int32_t *>(action)[idx[j]] = a_next[j]; }
         if (live[j]) Env::store(st[j], state, n, idx[j], fresh[j]);
         if (in_range[j]) {

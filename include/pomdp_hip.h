@@ -25,9 +25,11 @@
  *     sharded over several GPUs reproduces the single-GPU result exactly;
  *   - return value: 0 = ok, > 0 = hipError_t of the launch, < 0 = POMDP_E_*.
  *
- * Random-word contract (DESIGN.md §RNG): Philox4x32-10, key = (seed lo, seed hi),
+ * Random-word contract (DESIGN.md §2): Philox4x32-10, key = (seed lo, seed hi),
  * ctr = (lane, t lo, t hi, stream_id << 24 | block); numpy legacy constructions on
- * top (res53 doubles, masked-rejection randint).
+ * top (res53 doubles, masked-rejection randint).  RockSample / StochasticRock lay their doubles out
+ * "split": high word of double j in block 2(j/4) [reset] or 2j [step, counter word 0 = lane / 4, element
+ * lane % 4], low word in the following block, generated only when the high word leaves a comparison undecided.
  */
 #ifndef POMDP_HIP_H
 #define POMDP_HIP_H

@@ -18,6 +18,9 @@ oracle/pomdp_oracle.c and gym_pomdp_amd/csrc/philox.hip.h):
     randint n: mask = bit-smear(n - 1); draw words until (w & mask) <= n - 1
     binomial(1, p): one double, compared against a captured integer threshold.
 
+RockSample / StochasticRock deviate from "strictly sequential" in how the words are laid out (not in how numpy
+consumes them): see rock_reset_words / rock_step_words below (split high / low blocks, quad-shared step stream).
+
 Streams: 0 np.random draws made inside step(); 1 np.random draws made inside
 reset(); 2 / 3 the gym-space RNG (Discrete.sample) inside step() / reset()
 (Tiger only); 4 the benchmark's synthetic random-action policy; 5 the rollout policy's pick
@@ -67,6 +70,39 @@ def stream_words(seed, lane, t, stream, nwords):
     ctr[:, 3] = (int(stream) << 24) | np.arange(nblk, dtype=np.uint64)
     key = np.array([int(seed) & 0xFFFFFFFF, (int(seed) >> 32) & 0xFFFFFFFF], dtype=np.uint64)
     return philox4x32_10(ctr, key).reshape(-1)[:nwords]
+
+
+def _block(seed, c0, t, stream, block):
+    ctr = np.array([int(c0) & 0xFFFFFFFF, int(t) & 0xFFFFFFFF, (int(t) >> 32) & 0xFFFFFFFF,
+                    (int(stream) << 24) | int(block)], dtype=np.uint64)
+    key = np.array([int(seed) & 0xFFFFFFFF, (int(seed) >> 32) & 0xFFFFFFFF], dtype=np.uint64)
+    return philox4x32_10(ctr, key)
+
+
+def rock_reset_words(seed, lane, t, n_rocks):
+    """RockSample's RESET stream in *split layout* (DESIGN.md §2): every draw of reset() is a double, and double j
+    takes its high word from element j & 3 of block 2 (j >> 2) and its low word from the same element of block
+    2 (j >> 2) + 1.  The kernels only generate the odd ("low") blocks when a high word leaves the comparison
+    undecided (probability 2^-27 per draw).  Returns the 2 * n_rocks words numpy consumes, in order."""
+    out = []
+    for j in range(n_rocks):
+        hi = _block(seed, lane, t, STREAM_RESET, 2 * (j >> 2))[j & 3]
+        lo = _block(seed, lane, t, STREAM_RESET, 2 * (j >> 2) + 1)[j & 3]
+        out += [int(hi), int(lo)]
+    return np.array(out, dtype=np.uint32)
+
+
+def rock_step_words(seed, lane, t, n_doubles=1):
+    """RockSample's STEP stream: split layout, and *shared by the four lanes of a quad* — the Philox counter carries
+    lane >> 2 and lane L uses element L & 3, so that one block serves four lanes' sensor draws.  Double j of the step
+    (j = 0 for RockEnv's sensor; StochasticRockEnv: j = 0 the action gate, j = 1 the sensor) has its high word in
+    block 2 j and its low word in block 2 j + 1."""
+    out = []
+    for j in range(n_doubles):
+        hi = _block(seed, lane >> 2, t, STREAM_STEP, 2 * j)[lane & 3]
+        lo = _block(seed, lane >> 2, t, STREAM_STEP, 2 * j + 1)[lane & 3]
+        out += [int(hi), int(lo)]
+    return np.array(out, dtype=np.uint32)
 
 
 def synthetic_actions(seed, lane0, n, t, n_actions):

@@ -69,6 +69,19 @@ void or_ws_philox(or_ws *ws, uint64_t seed, uint32_t lane, uint64_t t, uint32_t 
     ws->ctr[3] = stream << 24;
     ws->widx = 0;
     ws->n_drawn = 0;
+    ws->layout = 0;
+    ws->lane = lane;
+    ws->have_block = 0;
+}
+
+/* RockSample: every draw is a double, double j = (high word, low word) with the two halves in different Philox
+ * blocks (split layout); the STEP stream is additionally shared by the four lanes of a quad.  See
+ * oracle/philox_ref.py rock_reset_words / rock_step_words for the normative statement. */
+void or_ws_philox_env(or_ws *ws, int env_kind, uint64_t seed, uint32_t lane, uint64_t t, uint32_t stream)
+{
+    or_ws_philox(ws, seed, lane, t, stream);
+    if (env_kind == OR_ENV_ROCK && stream == OR_STREAM_RESET) ws->layout = 1;
+    if (env_kind == OR_ENV_ROCK && stream == OR_STREAM_STEP) { ws->layout = 2; ws->ctr[0] = lane >> 2; }
 }
 
 uint32_t or_ws_next32(or_ws *ws)
@@ -82,6 +95,18 @@ uint32_t or_ws_next32(or_ws *ws)
         y ^= (y << 15) & 0xefc60000u;
         y ^= y >> 18;
         return y;
+    }
+    if (ws->layout != 0) {
+        const uint32_t i = ws->widx++, j = i >> 1, half = i & 1u;        /* word i = half `half` of double j */
+        const uint32_t block = ws->layout == 1 ? 2u * (j >> 2) + half : 2u * j + half;
+        const uint32_t elem = ws->layout == 1 ? (j & 3u) : (ws->lane & 3u);
+        if (!ws->have_block || ws->cached_block != block) {
+            uint32_t c[4] = { ws->ctr[0], ws->ctr[1], ws->ctr[2], ws->ctr[3] | block };
+            or_philox4x32_10(c, ws->key, ws->blk);
+            ws->cached_block = block;
+            ws->have_block = 1;
+        }
+        return ws->blk[elem];
     }
     if ((ws->widx & 3u) == 0) {
         uint32_t c[4] = { ws->ctr[0], ws->ctr[1], ws->ctr[2], ws->ctr[3] | ((ws->widx >> 2) & 0xFFFFFFu) };
@@ -774,7 +799,7 @@ void or_batch_reset(const or_env *proto, uint32_t *state, int32_t *ob, int64_t n
         uint32_t w[8];
 #pragma omp for schedule(static)
         for (int64_t i = 0; i < n; i++) {
-            or_ws_philox(&np_rng, seed, lane0 + (uint32_t)i, t, OR_STREAM_RESET);
+            or_ws_philox_env(&np_rng, e.kind, seed, lane0 + (uint32_t)i, t, OR_STREAM_RESET);
             or_ws_philox(&sp_rng, seed, lane0 + (uint32_t)i, t, OR_STREAM_RESET_SPACE);
             int o = or_env_reset(&e, &np_rng, &sp_rng);
             or_env_pack(&e, w);
@@ -807,11 +832,11 @@ int64_t or_batch_step(const or_env *proto, uint32_t *state, const int32_t *actio
             } else {
                 for (int j = 0; j < W; j++) w[j] = state[(int64_t)j * n + i];
                 or_env_unpack(&e, w);
-                or_ws_philox(&np_rng, seed, lane0 + (uint32_t)i, t, OR_STREAM_STEP);
+                or_ws_philox_env(&np_rng, e.kind, seed, lane0 + (uint32_t)i, t, OR_STREAM_STEP);
                 or_ws_philox(&sp_rng, seed, lane0 + (uint32_t)i, t, OR_STREAM_STEP_SPACE);
                 or_env_step(&e, a, &np_rng, &sp_rng, &o, &r, &d);
                 if (d && auto_reset) {
-                    or_ws_philox(&np_rng, seed, lane0 + (uint32_t)i, t, OR_STREAM_RESET);
+                    or_ws_philox_env(&np_rng, e.kind, seed, lane0 + (uint32_t)i, t, OR_STREAM_RESET);
                     or_ws_philox(&sp_rng, seed, lane0 + (uint32_t)i, t, OR_STREAM_RESET_SPACE);
                     or_env_reset(&e, &np_rng, &sp_rng);
                 }
@@ -950,7 +975,7 @@ void or_batch_rollout(const or_env *proto, const uint32_t *state, int64_t n_root
                 or_ws_philox(&pol, seed, lane, t0 + (uint64_t)k, OR_STREAM_ROLLOUT);
                 int a = list[((uint64_t)or_ws_next32(&pol) * (uint64_t)len) >> 32];
                 if (k == 0) first = a;
-                or_ws_philox(&np_rng, seed, lane, t0 + (uint64_t)k, OR_STREAM_STEP);
+                or_ws_philox_env(&np_rng, e.kind, seed, lane, t0 + (uint64_t)k, OR_STREAM_STEP);
                 or_ws_philox(&sp_rng, seed, lane, t0 + (uint64_t)k, OR_STREAM_STEP_SPACE);
                 double r;
                 or_env_step(&e, a, &np_rng, &sp_rng, &o, &r, &d);

@@ -39,10 +39,17 @@ typedef struct or_ws {
     uint32_t blk[4];
     uint32_t widx;
     uint64_t n_drawn;
+    /* RockSample's split layout (oracle/philox_ref.py: rock_reset_words / rock_step_words):
+     * 0 = plain sequential stream, 1 = per-lane split (RESET), 2 = quad-shared split (STEP) */
+    int layout;
+    uint32_t lane, cached_block;
+    int have_block;
 } or_ws;
 
 void     or_ws_seed_mt(or_ws *ws, uint32_t seed);
 void     or_ws_philox(or_ws *ws, uint64_t seed, uint32_t lane, uint64_t t, uint32_t stream);
+/* word source of one env call: RockSample envs get the split layout for streams STEP / RESET */
+void     or_ws_philox_env(or_ws *ws, int env_kind, uint64_t seed, uint32_t lane, uint64_t t, uint32_t stream);
 uint32_t or_ws_next32(or_ws *ws);
 void     or_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 

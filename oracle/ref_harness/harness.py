@@ -91,8 +91,19 @@ def consumed_words(rs=None):
     return int(st[2])
 
 
-def inject_stream(seed, lane, t, stream, rs=None):
+def inject_stream(seed, lane, t, stream, rs=None, env=None, env_kwargs=None):
+    """Inject the words of (seed, lane, t, stream).  RockSample / StochasticRock use the split, quad-shared layout
+    of oracle/philox_ref.py (rock_reset_words / rock_step_words); every other env the plain sequential stream."""
+    if env in ("rock", "stochrock") and stream in (px.STREAM_STEP, px.STREAM_RESET):
+        if stream == px.STREAM_RESET:
+            w = px.rock_reset_words(seed, lane, t, (env_kwargs or {}).get("num_rocks", 8))
+        else:
+            w = px.rock_step_words(seed, lane, t, 2 if env == "stochrock" else 1)
+        # pad with a recognisable filler: consuming more words than the layout defines must be noticed
+        inject_words(np.concatenate([w, np.full(8, 0xDEADBEEF, np.uint32)]), rs)
+        return len(w)
     inject_words(px.stream_words(seed, lane, t, stream, N_INJECT), rs)
+    return N_INJECT
 
 
 # ---------------------------------------------------------------------------
@@ -203,10 +214,11 @@ def trace_mode_b(name, kwargs, seed, lanes, actions, t0=0):
     max_used = 0
     for li, lane in enumerate(lanes):
         env = make_ref_env(name, **kwargs)
-        inject_stream(seed, lane, t0, px.STREAM_RESET)
+        lim = inject_stream(seed, lane, t0, px.STREAM_RESET, env=name, env_kwargs=kwargs)
         if space is not None:
             inject_stream(seed, lane, t0, px.STREAM_RESET_SPACE, space)
         ob0 = env.reset()
+        assert consumed_words() <= lim
         max_used = max(max_used, consumed_words())
         s0 = compact_state(name, env)
         if out is None:
@@ -219,18 +231,20 @@ def trace_mode_b(name, kwargs, seed, lanes, actions, t0=0):
         out["state0"][li] = s0
         for i in range(T):
             t = t0 + 1 + i
-            inject_stream(seed, lane, t, px.STREAM_STEP)
+            lim = inject_stream(seed, lane, t, px.STREAM_STEP, env=name, env_kwargs=kwargs)
             if space is not None:
                 inject_stream(seed, lane, t, px.STREAM_STEP_SPACE, space)
             o, r, d, _ = env.step(int(actions[li, i]))
+            assert consumed_words() <= lim
             max_used = max(max_used, consumed_words())
             out["ob"][li, i], out["reward"][li, i], out["done"][li, i] = int(o), _as_float(r), int(bool(d))
             out["state_pre"][li, i] = compact_state(name, env)
             if d:
-                inject_stream(seed, lane, t, px.STREAM_RESET)
+                lim = inject_stream(seed, lane, t, px.STREAM_RESET, env=name, env_kwargs=kwargs)
                 if space is not None:
                     inject_stream(seed, lane, t, px.STREAM_RESET_SPACE, space)
                 out["reset_ob"][li, i] = int(env.reset())
+                assert consumed_words() <= lim
                 max_used = max(max_used, consumed_words())
             out["state"][li, i] = compact_state(name, env)
     assert max_used < N_INJECT, "a reference call consumed more words than were injected"
@@ -266,7 +280,7 @@ def rollout_reference(name, kwargs, seed, root_lane0, n_roots, sims_per_root, de
                root_legal=np.full((n_roots, MAX_LEGAL), -1, np.int64), root_legal_len=np.zeros(n_roots, np.int64))
     for r in range(n_roots):
         env = make_ref_env(name, **kwargs)
-        inject_stream(seed, root_lane0 + r, t_reset, px.STREAM_RESET)
+        inject_stream(seed, root_lane0 + r, t_reset, px.STREAM_RESET, env=name, env_kwargs=kwargs)
         if space is not None:
             inject_stream(seed, root_lane0 + r, t_reset, px.STREAM_RESET_SPACE, space)
         env.reset()
@@ -289,7 +303,7 @@ def rollout_reference(name, kwargs, seed, root_lane0, n_roots, sims_per_root, de
                 a = lst[(w * len(lst)) >> 32]
                 if k == 0:
                     out["first_action"][i] = a
-                inject_stream(seed, lane, t0 + k, px.STREAM_STEP)
+                inject_stream(seed, lane, t0 + k, px.STREAM_STEP, env=name, env_kwargs=kwargs)
                 if space is not None:
                     inject_stream(seed, lane, t0 + k, px.STREAM_STEP_SPACE, space)
                 ob, rw, done, _ = e.step(a)
@@ -311,7 +325,7 @@ def compute_prob_trace(name, kwargs, seed, lanes, actions, t0=0):
     out = None
     for li, lane in enumerate(lanes):
         env = make_ref_env(name, **kwargs)
-        inject_stream(seed, lane, t0, px.STREAM_RESET)
+        inject_stream(seed, lane, t0, px.STREAM_RESET, env=name, env_kwargs=kwargs)
         if space is not None:
             inject_stream(seed, lane, t0, px.STREAM_RESET_SPACE, space)
         env.reset()
@@ -321,7 +335,7 @@ def compute_prob_trace(name, kwargs, seed, lanes, actions, t0=0):
                        state_pre=None, done=np.zeros((L, T), np.uint8))
         for i in range(T):
             t = t0 + 1 + i
-            inject_stream(seed, lane, t, px.STREAM_STEP)
+            inject_stream(seed, lane, t, px.STREAM_STEP, env=name, env_kwargs=kwargs)
             if space is not None:
                 inject_stream(seed, lane, t, px.STREAM_STEP_SPACE, space)
             a = int(actions[li, i])
@@ -334,7 +348,7 @@ def compute_prob_trace(name, kwargs, seed, lanes, actions, t0=0):
             for q in range(n_obs):
                 out["prob"][li, i, q] = float(env._compute_prob(a, info["state"], q))
             if d:
-                inject_stream(seed, lane, t, px.STREAM_RESET)
+                inject_stream(seed, lane, t, px.STREAM_RESET, env=name, env_kwargs=kwargs)
                 if space is not None:
                     inject_stream(seed, lane, t, px.STREAM_RESET_SPACE, space)
                 env.reset()

@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Find lanes whose RockSample draws are *ties* of the split word layout — the high word alone leaves the
+comparison undecided (probability 2^-27 per draw), so the kernels must generate the low-word block — and record the
+reference's behaviour on exactly those lanes (fixture ties_rock.npz).  Container-only (needs /root/reference).
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/find_ties.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+sys.dont_write_bytecode = True
+from oracle import philox_ref as px  # noqa: E402
+from oracle.ref_harness import harness as h  # noqa: E402
+
+SEED = 0x7157157
+CHUNK = 1 << 21
+
+
+def blocks(c0, t, stream, block):
+    ctr = np.zeros((len(c0), 4), dtype=np.uint64)
+    ctr[:, 0] = c0
+    ctr[:, 1] = t & 0xFFFFFFFF
+    ctr[:, 2] = t >> 32
+    ctr[:, 3] = (stream << 24) | block
+    key = np.array([SEED & 0xFFFFFFFF, SEED >> 32], dtype=np.uint64)
+    return px.philox4x32_10(ctr, key)
+
+
+def main(n_reset=6, n_sensor=8):
+    thr = json.load(open(os.path.join(HERE, "thresholds.json")))["rock_thr"]
+    # first step from the start cell (0,3) of RockSample(7,8): L1 distance to rock i
+    rocks = [(2, 0), (0, 1), (3, 1), (6, 3), (2, 4), (3, 4), (5, 5), (1, 6)]
+    dist = [abs(0 - x) + abs(3 - y) for x, y in rocks]
+    thr_hi = {d: thr[d] >> 26 for d in set(dist)}
+    reset_ties, sensor_ties = [], []
+    lane = 0
+    while len(reset_ties) < n_reset or len(sensor_ties) < n_sensor:
+        c0 = np.arange(lane, lane + CHUNK, dtype=np.uint64)
+        if len(reset_ties) < n_reset:                                    # reset at t = 0: blocks 0 and 2, per lane
+            for g in (0, 1):
+                kh = blocks(c0, 0, px.STREAM_RESET, 2 * g) >> np.uint32(5)
+                for li, e in zip(*np.nonzero(kh == (1 << 26))):
+                    reset_ties.append((int(c0[li]), 4 * g + int(e)))
+        if len(sensor_ties) < n_sensor:                                  # first step at t = 1: block 0 of quad c0
+            kh = blocks(c0, 1, px.STREAM_STEP, 0) >> np.uint32(5)
+            for d, th in thr_hi.items():
+                for qi, e in zip(*np.nonzero(kh == th)):
+                    sensor_ties.append((int(c0[qi]) * 4 + int(e), d))
+        lane += CHUNK
+        print("searched", lane, "found", len(reset_ties), len(sensor_ties), flush=True)
+    reset_ties, sensor_ties = reset_ties[:n_reset], sensor_ties[:n_sensor]
+    # reference behaviour on those lanes: reset (t = 0), then one CHECK of a rock at the tied distance (t = 1)
+    lanes, actions = [], []
+    for ln, _ in reset_ties:
+        lanes.append(ln)
+        actions.append(5)
+    for ln, d in sensor_ties:
+        lanes.append(ln)
+        actions.append(5 + dist.index(d))
+    tr = h.trace_mode_b("rock", {}, SEED, lanes, np.array(actions).reshape(-1, 1), t0=0)
+    np.savez_compressed(os.path.join(HERE, "ties_rock.npz"), seed=np.int64(SEED), lanes=np.array(lanes, np.int64),
+                        actions=np.array(actions, np.int64), n_reset=np.int64(len(reset_ties)),
+                        tied_rock=np.array([r for _, r in reset_ties], np.int64),
+                        tied_dist=np.array([d for _, d in sensor_ties], np.int64),
+                        state0=tr["state0"], ob=tr["ob"][:, 0], reward=tr["reward"][:, 0], done=tr["done"][:, 0],
+                        state=tr["state"][:, 0])
+    print("reset ties", reset_ties, "\nsensor ties", sensor_ties)
+    print("state0 of tied rocks:", [int(tr["state0"][i][2 + r]) for i, (_, r) in enumerate(reset_ties)])
+
+
+if __name__ == "__main__":
+    main()

@@ -567,3 +567,25 @@ def test_large_batch_windows_vs_oracle(oracle_lib, env, kw, log2n, policy_seed):
         assert np.array_equal(np_(e._done[sl]), done)
     del e
     torch.cuda.empty_cache()
+
+
+def test_split_layout_ties():
+    """The 2^-27 path of RockSample's split word layout: lanes (found by tests/golden/find_ties.py) where a reset or
+    sensor draw is undecided by its high word, so the kernel has to generate the low-word block.  Expected values
+    come from the reference itself (fixture ties_rock.npz)."""
+    import os
+    from conftest import GOLDEN
+    g = dict(np.load(os.path.join(GOLDEN, "ties_rock.npz")))
+    seed = int(g["seed"])
+    for i, lane in enumerate(g["lanes"]):
+        lane = int(lane)
+        for n in (4, 1 << 18):                      # one-lane-per-thread path and the pooled two-lanes-per-thread path
+            base = lane & ~3 if n == 4 else max(0, (lane & ~3) - (n // 2))
+            col = lane - base
+            e = make_env("rock", {}, batch_size=n, seed=seed, lane_offset=base)
+            e.reset()
+            assert np.array_equal(np_(e.decode_state()[col]), g["state0"][i]), (lane, n)
+            a = torch.zeros(n, dtype=torch.int32, device="cuda")
+            a[col] = int(g["actions"][i])
+            ob, rew, done, _ = e.step(a)
+            assert (int(ob[col]), int(rew[col]), int(done[col])) == (int(g["ob"][i]), int(g["reward"][i]), int(g["done"][i])), (lane, n)

@@ -232,3 +232,22 @@ def test_moves_axis_convention(oracle_lib):
             assert (x1, y1, int(rew[0]), int(done[0])) == (x0, y0, -100, 1)
         else:
             assert [x1 - x0, y1 - y0] == moves[name] and int(rew[0]) == 0 and int(done[0]) == 0
+
+
+def test_split_layout_ties_oracle(oracle_lib):
+    """RockSample draws whose high word alone leaves the comparison undecided (fixture ties_rock.npz, lanes found by
+    tests/golden/find_ties.py): the low-word block decides, as in the reference."""
+    g = dict(np.load(os.path.join(GOLDEN, "ties_rock.npz")))
+    o = oracle_lib.OracleEnv("rock")
+    seed = int(g["seed"])
+    for i, lane in enumerate(g["lanes"]):
+        st = o.new_state(1)
+        o.batch_reset(st, seed, int(lane), 0)
+        assert np.array_equal(o.batch_compact(st)[0], g["state0"][i])
+        ob, rew, done, _ = o.batch_step(st, [int(g["actions"][i])], seed, int(lane), 1)
+        assert (int(ob[0]), int(rew[0]), int(done[0])) == (int(g["ob"][i]), int(g["reward"][i]), int(g["done"][i]))
+    # the tied rocks of the reset cases really sit on the 2^52 boundary of their high word
+    from oracle import philox_ref as px
+    for i in range(int(g["n_reset"])):
+        w = px.rock_reset_words(seed, int(g["lanes"][i]), 0, 8)
+        assert int(w[2 * int(g["tied_rock"][i])]) >> 5 == 1 << 26
