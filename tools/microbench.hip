@@ -178,9 +178,15 @@ int main(int argc, char **argv)
             printf("%-28s: LPT1 %8.2f", "chain step", time_it([&](int t) {
                 hipLaunchKernelGGL((step_kernel<E, 1, true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, p, state, action, ob, reward, done, err, n, make_key(1, t), 0u, 1, make_key(1, t + 1));
             }, iters));
-            printf("  LPT2 %8.2f\n", time_it([&](int t) {
+            printf("  LPT2 %8.2f", time_it([&](int t) {
                 hipLaunchKernelGGL((step_kernel<E, 2, true>), dim3((unsigned)((n + 511) / 512)), dim3(256), 0, 0, p, state, action, ob, reward, done, err, n, make_key(1, t), 0u, 1, make_key(1, t + 1));
             }, iters));
+            for (int lds_kb : {24, 36, 48, 72}) {   // occupancy limited by a dummy dynamic-LDS request
+                printf("  LPT2/lds%dk %6.2f", lds_kb, time_it([&](int t) {
+                    hipLaunchKernelGGL((step_kernel<E, 2, true>), dim3((unsigned)((n + 511) / 512)), dim3(256), lds_kb * 1024, 0, p, state, action, ob, reward, done, err, n, make_key(1, t), 0u, 1, make_key(1, t + 1));
+                }, iters));
+            }
+            printf("\n");
         }
         run(RockEnv<1, 1>{}, "step -checkphilox");
         run(RockEnv<1, 2>{}, "step -reset");
