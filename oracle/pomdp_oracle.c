@@ -71,7 +71,7 @@ void or_ws_philox(or_ws *ws, uint64_t seed, uint32_t lane, uint64_t t, uint32_t 
     ws->n_drawn = 0;
     ws->layout = 0;
     ws->lane = lane;
-    ws->have_block = 0;
+    ws->half_have[0] = ws->half_have[1] = 0;
 }
 
 /* RockSample: every draw is a double, double j = (high word, low word) with the two halves in different Philox
@@ -100,13 +100,13 @@ uint32_t or_ws_next32(or_ws *ws)
         const uint32_t i = ws->widx++, j = i >> 1, half = i & 1u;        /* word i = half `half` of double j */
         const uint32_t block = ws->layout == 1 ? 2u * (j >> 2) + half : 2u * j + half;
         const uint32_t elem = ws->layout == 1 ? (j & 3u) : (ws->lane & 3u);
-        if (!ws->have_block || ws->cached_block != block) {
+        if (!ws->half_have[half] || ws->half_idx[half] != block) {
             uint32_t c[4] = { ws->ctr[0], ws->ctr[1], ws->ctr[2], ws->ctr[3] | block };
-            or_philox4x32_10(c, ws->key, ws->blk);
-            ws->cached_block = block;
-            ws->have_block = 1;
+            or_philox4x32_10(c, ws->key, ws->half_blk[half]);
+            ws->half_idx[half] = block;
+            ws->half_have[half] = 1;
         }
-        return ws->blk[elem];
+        return ws->half_blk[half][elem];
     }
     if ((ws->widx & 3u) == 0) {
         uint32_t c[4] = { ws->ctr[0], ws->ctr[1], ws->ctr[2], ws->ctr[3] | ((ws->widx >> 2) & 0xFFFFFFu) };

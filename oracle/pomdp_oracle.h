@@ -42,8 +42,9 @@ typedef struct or_ws {
     /* RockSample's split layout (oracle/philox_ref.py: rock_reset_words / rock_step_words):
      * 0 = plain sequential stream, 1 = per-lane split (RESET), 2 = quad-shared split (STEP) */
     int layout;
-    uint32_t lane, cached_block;
-    int have_block;
+    uint32_t lane;
+    uint32_t half_blk[2][4], half_idx[2];   /* one cached block per half (high / low words) */
+    int half_have[2];
 } or_ws;
 
 void     or_ws_seed_mt(or_ws *ws, uint32_t seed);
