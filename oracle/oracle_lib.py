@@ -53,6 +53,13 @@ def lib():
         L.or_bench_loop.argtypes = [vp, C.c_int64, C.c_int64, C.c_uint64, C.c_int, vp]
         L.or_max_threads.restype = C.c_int
         L.or_philox4x32_10.argtypes = [vp, vp, vp]
+        L.or_batch_rock_belief_reset.argtypes = [vp, vp, vp, C.c_int64]
+        L.or_batch_rock_belief_update.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp, C.c_int64]
+        L.or_batch_history_clear.argtypes = [vp, vp, vp, C.c_int64]
+        L.or_batch_history_append.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int64]
+        L.or_batch_preferred.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int64]
+        L.or_batch_rock_select_target.argtypes = [vp, vp, vp, vp, C.c_int64]
+        L.or_batch_pick.argtypes = [vp, vp, C.c_int, vp, C.c_int64, C.c_uint64, C.c_uint32, C.c_uint64]
         _lib = L
     return _lib
 
@@ -186,6 +193,95 @@ def _batch_compute_prob(self, state, action, ob):
     return out
 
 
+# ---- heuristic-policy support (pomdp_oracle.h: or_rock_belief / or_history) -------------------------------
+class _BeliefPtrs(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("count", "measured", "lkv", "lkw", "prob_valuable")]
+
+
+class _HistoryPtrs(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("size", "last_action", "last_ob", "total_sample", "total_move")]
+
+
+class Belief(object):
+    """RockSample side statistics of n lanes: numpy arrays [K, n] (rock.py:78-86)."""
+    FIELDS = (("count", np.int32), ("measured", np.int32), ("lkv", np.float64), ("lkw", np.float64),
+              ("prob_valuable", np.float64))
+
+    def __init__(self, env, n):
+        self.env, self.n = env, n
+        K = env.n_actions - 5
+        for k, dt in self.FIELDS:
+            setattr(self, k, np.zeros((K, n), dt))
+        self.reset()
+
+    def _ptrs(self):
+        return C.byref(_BeliefPtrs(*[getattr(self, k).ctypes.data for k, _ in self.FIELDS]))
+
+    def reset(self, where=None):
+        w = None if where is None else _ptr(np.ascontiguousarray(where, np.uint8))
+        lib().or_batch_rock_belief_reset(self.env._h, self._ptrs(), w, self.n)
+
+    def update(self, state, action, ob, done, auto_reset=True):
+        lib().or_batch_rock_belief_update(
+            self.env._h, _ptr(np.ascontiguousarray(state)), _ptr(np.ascontiguousarray(action, np.int32)),
+            _ptr(np.ascontiguousarray(ob, np.int32)), _ptr(np.ascontiguousarray(done, np.uint8)), int(auto_reset),
+            self._ptrs(), self.n)
+
+    def select_target(self, state):
+        out = np.zeros(self.n, np.int32)
+        lib().or_batch_rock_select_target(self.env._h, _ptr(np.ascontiguousarray(state)), self._ptrs(), _ptr(out), self.n)
+        return out
+
+
+class HistorySums(object):
+    """Running sums standing in for the planner's History (pomdp_oracle.h: or_history)."""
+
+    def __init__(self, env, n):
+        self.env, self.n = env, n
+        self.is_rock = env.name in ("rock", "stochrock")
+        K = env.n_actions - 5 if self.is_rock else 0
+        self.size = np.zeros(n, np.int32)
+        self.last_action = np.zeros(n, np.int32)
+        self.last_ob = np.zeros(n, np.int32)
+        self.total_sample = np.zeros((K, n), np.int32)
+        self.total_move = np.zeros((K, n), np.int32)
+        self.clear()
+
+    def _ptrs(self):
+        return C.byref(_HistoryPtrs(self.size.ctypes.data, self.last_action.ctypes.data, self.last_ob.ctypes.data,
+                                    self.total_sample.ctypes.data if self.is_rock else None,
+                                    self.total_move.ctypes.data if self.is_rock else None))
+
+    def clear(self, where=None):
+        w = None if where is None else _ptr(np.ascontiguousarray(where, np.uint8))
+        lib().or_batch_history_clear(self.env._h, self._ptrs(), w, self.n)
+
+    def append(self, observation, action, next_observation, done, auto_reset=True):
+        lib().or_batch_history_append(
+            self.env._h, self._ptrs(), _ptr(np.ascontiguousarray(observation, np.int32)),
+            _ptr(np.ascontiguousarray(action, np.int32)), _ptr(np.ascontiguousarray(next_observation, np.int32)),
+            _ptr(np.ascontiguousarray(done, np.uint8)), int(auto_reset), self.n)
+
+
+def _batch_preferred(self, state, history, belief=None):
+    """`_generate_preferred(history)` per lane (use_heuristic=True): lists int32 [n, MAX_LEGAL], lengths int32 [n]."""
+    n = state.shape[1]
+    out = np.zeros((n, MAX_LEGAL), np.int32)
+    ln = np.zeros(n, np.int32)
+    lib().or_batch_preferred(self._h, _ptr(np.ascontiguousarray(state)), belief._ptrs() if belief is not None else None,
+                             history._ptrs(), _ptr(out), _ptr(ln), n)
+    return out, ln
+
+
+def pick(lists, lens, seed, lane0, t):
+    lists = np.ascontiguousarray(lists, np.int32)
+    lens = np.ascontiguousarray(lens, np.int32)
+    a = np.zeros(len(lens), np.int32)
+    lib().or_batch_pick(_ptr(lists), _ptr(lens), lists.shape[1], _ptr(a), len(lens), seed, lane0, t)
+    return a
+
+
+OracleEnv.batch_preferred = _batch_preferred
 OracleEnv.batch_compute_prob = _batch_compute_prob
 OracleEnv.bench_loop = _bench_loop
 OracleEnv.batch_legal = _batch_legal

@@ -121,6 +121,11 @@ def synthetic_actions(seed, lane0, n, t, n_actions):
     return ((w * np.uint64(n_actions)) >> np.uint64(32)).astype(np.int32)
 
 
+def action_word(seed, lane, t):
+    """The synthetic policy's 32-bit word of (seed, lane, t): element lane & 3 of block ctr = (lane >> 2, t, ACTION)."""
+    return int(_block(seed, lane >> 2, t, STREAM_ACTION, 0)[lane & 3])
+
+
 # Known-answer vectors for Philox4x32-10 (Random123 kat_vectors).
 KAT = [
     ((0x00000000, 0x00000000, 0x00000000, 0x00000000), (0x00000000, 0x00000000),

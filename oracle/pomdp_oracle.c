@@ -6,6 +6,7 @@
  */
 #include "pomdp_oracle.h"
 
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -1051,5 +1052,188 @@ void or_batch_compute_prob(const or_env *proto, const uint32_t *state, const int
         for (int j = 0; j < W; j++) w[j] = state[(int64_t)j * n + i];
         or_env_unpack(&e, w);
         out[i] = or_env_compute_prob(&e, action[i], ob[i]);
+    }
+}
+
+/* ======================================================================== */
+/* heuristic-policy support: side statistics, history sums, preferred lists  */
+/* ======================================================================== */
+void or_batch_rock_belief_reset(const or_env *proto, const or_rock_belief *b, const uint8_t *where, int64_t n)
+{
+    for (int j = 0; j < proto->num_rocks; j++)
+        for (int64_t i = 0; i < n; i++) {
+            if (where && !where[i]) continue;
+            int64_t k = (int64_t)j * n + i;                       /* rock.py:81-86 */
+            b->count[k] = 0; b->measured[k] = 0; b->lkv[k] = 1.; b->lkw[k] = 1.; b->prob_valuable[k] = .5;
+        }
+}
+
+void or_batch_rock_belief_update(const or_env *proto, const uint32_t *state, const int32_t *action, const int32_t *ob,
+                                 const uint8_t *done, int auto_reset, const or_rock_belief *b, int64_t n)
+{
+    int W = or_env_words(proto), K = proto->num_rocks;
+    or_env e = *proto;
+    uint32_t w[8];
+    for (int64_t i = 0; i < n; i++) {
+        if (done[i]) {                                            /* reset() builds new Rock objects */
+            if (auto_reset)
+                for (int j = 0; j < K; j++) {
+                    int64_t k = (int64_t)j * n + i;
+                    b->count[k] = 0; b->measured[k] = 0; b->lkv[k] = 1.; b->lkw[k] = 1.; b->prob_valuable[k] = .5;
+                }
+            continue;
+        }
+        int a = action[i];
+        if (a <= 4 || a >= 5 + K || ob[i] == 0) continue;         /* not an executed CHECK */
+        for (int j = 0; j < W; j++) w[j] = state[(int64_t)j * n + i];
+        or_env_unpack(&e, w);
+        int rock = a - 5;
+        int64_t k = (int64_t)rock * n + i;
+        int dx = e.agent.x - e.rock_pos[rock].x, dy = e.agent.y - e.rock_pos[rock].y;
+        double eff = ROCK_EFF[(dx < 0 ? -dx : dx) + (dy < 0 ? -dy : dy)];          /* rock.py:180 */
+        b->measured[k] += 1;                                      /* rock.py:178 */
+        if (ob[i] == 2) {                                         /* rock.py:182-185 */
+            b->count[k] += 1; b->lkv[k] *= eff; b->lkw[k] *= (1 - eff);
+        } else {                                                  /* rock.py:186-189 */
+            b->count[k] -= 1; b->lkw[k] *= eff; b->lkv[k] *= (1 - eff);
+        }
+        double denom = (.5 * b->lkv[k]) + (.5 * b->lkw[k]);       /* rock.py:190-191 */
+        b->prob_valuable[k] = (.5 * b->lkv[k]) / denom;
+    }
+}
+
+void or_batch_history_clear(const or_env *proto, const or_history *h, const uint8_t *where, int64_t n)
+{
+    int K = proto->kind == OR_ENV_ROCK ? proto->num_rocks : 0;
+    for (int64_t i = 0; i < n; i++) {
+        if (where && !where[i]) continue;
+        h->size[i] = 0; h->last_action[i] = -1; h->last_ob[i] = -1;
+        for (int j = 0; j < K; j++) { h->total_sample[(int64_t)j * n + i] = 0; h->total_move[(int64_t)j * n + i] = 0; }
+    }
+}
+
+void or_batch_history_append(const or_env *proto, const or_history *h, const int32_t *observation,
+                             const int32_t *action, const int32_t *next_observation, const uint8_t *done,
+                             int auto_reset, int64_t n)
+{
+    int K = proto->kind == OR_ENV_ROCK ? proto->num_rocks : 0;
+    for (int64_t i = 0; i < n; i++) {
+        if (done[i] && auto_reset) {                              /* next episode: a new, empty History */
+            h->size[i] = 0; h->last_action[i] = -1; h->last_ob[i] = -1;
+            for (int j = 0; j < K; j++) { h->total_sample[(int64_t)j * n + i] = 0; h->total_move[(int64_t)j * n + i] = 0; }
+            continue;
+        }
+        int a = action[i], o = next_observation[i];
+        h->size[i] += 1; h->last_action[i] = a; h->last_ob[i] = o;
+        if (a >= 5 && a < 5 + K) {
+            int64_t k = (int64_t)(a - 5) * n + i;
+            if (o == 2) h->total_sample[k] += 1;                  /* rock.py:305-309 */
+            else if (o == 1) h->total_sample[k] -= 1;
+            if (o == 2) h->total_move[k] += 1;                    /* rock.py:329-333: elif on transition.observation */
+            else if (observation[i] == 1) h->total_move[k] -= 1;
+        }
+    }
+}
+
+/* rock.py:293-374 */
+static int rock_preferred(const or_env *e, const or_rock_belief *b, const or_history *h, int64_t i, int64_t n, int *list)
+{
+    int K = e->num_rocks, cnt = 0;
+    int rock = e->grid[e->agent.x][e->agent.y];
+    /* ids >= num_rocks raise IndexError in the reference; the build treats such a cell as empty */
+    if (rock >= 0 && rock < K && e->status[rock] != 0 && h->size[i]) {
+        if (h->total_sample[(int64_t)rock * n + i] > 0) { list[0] = 4; return 1; }             /* rock.py:311-313 */
+    }
+    int all_bad = 1, north = 0, south = 0, west = 0, east = 0;
+    for (int idx = 0; idx < K; idx++) {
+        if (e->status[idx] == 0) continue;
+        if (h->total_move[(int64_t)idx * n + i] >= 0) {                                         /* rock.py:335-345 */
+            all_bad = 0;
+            if (e->rock_pos[idx].y > e->agent.y) north = 1;
+            else if (e->rock_pos[idx].y < e->agent.y) south = 1;
+            else if (e->rock_pos[idx].x < e->agent.x) west = 1;
+            else if (e->rock_pos[idx].x > e->agent.x) east = 1;
+        }
+    }
+    if (all_bad) { list[0] = 1; return 1; }                                                     /* rock.py:347-349 */
+    if (e->agent.y + 1 < e->size && north) list[cnt++] = 0;                                     /* rock.py:358-368 */
+    if (east) list[cnt++] = 1;
+    if (e->agent.y - 1 >= 0 && south) list[cnt++] = 2;
+    if (e->agent.x - 1 >= 0 && west) list[cnt++] = 3;
+    for (int idx = 0; idx < K; idx++) {                                                         /* rock.py:370-372 */
+        int64_t k = (int64_t)idx * n + i;
+        int c = b->count[k];
+        if (e->status[idx] != 0 && b->measured[k] < 5 && (c < 0 ? -c : c) < 2 && 0 < b->prob_valuable[k] &&
+            b->prob_valuable[k] < 1)
+            list[cnt++] = idx + 5;
+    }
+    if (cnt == 0) return or_env_legal(e, list);                                                 /* rock.py:374-375 */
+    return cnt;
+}
+
+/* tag.py:231-243, 68-74 is_corner, coord.py:75-77 opposite */
+static int tag_preferred(const or_env *e, const or_history *h, int64_t i, int *list)
+{
+    int cnt = 0;
+    if (h->size[i] == 0) return or_env_legal(e, list);
+    int corner = tag_inside(e->agent) &&
+                 (e->agent.y < 2 ? (e->agent.x == 0 || e->agent.x == 9) : (e->agent.y == 4 && (e->agent.x == 5 || e->agent.x == 7)));
+    if (h->last_ob[i] == 29 && corner) { list[0] = 4; return 1; }   /* grid.n_tiles == 29 whatever obs_cells is */
+    for (int d = 0; d < 4; d++) {
+        coord c = { e->agent.x + MOVES[d].x, e->agent.y + MOVES[d].y };
+        if (h->last_action[i] != (d + 2) % 4 && tag_inside(c)) list[cnt++] = d;
+    }
+    return cnt;
+}
+
+void or_batch_preferred(const or_env *proto, const uint32_t *state, const or_rock_belief *b, const or_history *h,
+                        int32_t *out, int32_t *len, int64_t n)
+{
+    int W = or_env_words(proto);
+    or_env e = *proto;
+    uint32_t w[8];
+    int list[OR_MAX_LEGAL];
+    for (int64_t i = 0; i < n; i++) {
+        for (int j = 0; j < W; j++) w[j] = state[(int64_t)j * n + i];
+        or_env_unpack(&e, w);
+        int l;
+        if (e.kind == OR_ENV_ROCK) l = rock_preferred(&e, b, h, i, n, list);
+        else if (e.kind == OR_ENV_TAG) l = tag_preferred(&e, h, i, list);
+        else l = or_env_legal(&e, list);
+        len[i] = l;
+        for (int j = 0; j < OR_MAX_LEGAL; j++) out[i * OR_MAX_LEGAL + j] = j < l ? list[j] : -1;
+    }
+}
+
+void or_batch_rock_select_target(const or_env *proto, const uint32_t *state, const or_rock_belief *b,
+                                 int32_t *target, int64_t n)
+{
+    int W = or_env_words(proto);
+    or_env e = *proto;
+    uint32_t w[8];
+    for (int64_t i = 0; i < n; i++) {
+        for (int j = 0; j < W; j++) w[j] = state[(int64_t)j * n + i];
+        or_env_unpack(&e, w);
+        double best = e.size * 2;                                                  /* rock.py:391 */
+        int best_rock = -1;
+        for (int idx = 0; idx < e.num_rocks; idx++)
+            if (e.status[idx] != 0 && b->count[(int64_t)idx * n + i] >= 0) {
+                double dx = e.agent.x - e.rock_pos[idx].x, dy = e.agent.y - e.rock_pos[idx].y;
+                double d = sqrt(dx * dx + dy * dy);                                /* coord.py:83-85 */
+                if (d < best) { best = d; best_rock = idx; }
+            }
+        target[i] = best_rock;
+    }
+}
+
+void or_batch_pick(const int32_t *list, const int32_t *len, int stride, int32_t *action, int64_t n, uint64_t seed,
+                   uint32_t lane0, uint64_t t)
+{
+    uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
+    for (int64_t i = 0; i < n; i++) {
+        uint32_t lane = lane0 + (uint32_t)i;
+        uint32_t c[4] = { lane >> 2, (uint32_t)t, (uint32_t)(t >> 32), (uint32_t)OR_STREAM_ACTION << 24 }, o[4];
+        or_philox4x32_10(c, key, o);
+        action[i] = len[i] > 0 ? list[i * stride + (int32_t)(((uint64_t)o[lane & 3u] * (uint32_t)len[i]) >> 32)] : -1;
     }
 }

@@ -134,6 +134,52 @@ void or_batch_rollout(const or_env *proto, const uint32_t *state, int64_t n_root
                       uint64_t t0, double *ret, int32_t *n_steps, int32_t *first_action, int32_t *last_ob,
                       uint8_t *terminated, int nthreads);
 
+
+/* ---- heuristic-policy support ------------------------ */
+/* RockSample's per-rock side statistics (rock.py:78-86: count, measured, lkw, lkv, prob_valuable), struct of
+ * arrays [num_rocks][n].  The reference updates them inside step() on every CHECK (rock.py:177-191). */
+typedef struct or_rock_belief {
+    int32_t *count, *measured;
+    double *lkv, *lkw, *prob_valuable;
+} or_rock_belief;
+/* where == NULL: every lane; otherwise lanes with where[i] != 0.  Fresh Rock objects: 0, 0, 1., 1., .5 */
+void or_batch_rock_belief_reset(const or_env *proto, const or_rock_belief *b, const uint8_t *where, int64_t n);
+/* after a step: `state` is the stored (post auto-reset) state, (action, ob, done) what the step returned.
+ * A lane that executed CHECK j (ob != 0) updates rock j as rock.py:177-191 does; with auto_reset a done lane's
+ * statistics are those of a fresh episode. */
+void or_batch_rock_belief_update(const or_env *proto, const uint32_t *state, const int32_t *action, const int32_t *ob,
+                                 const uint8_t *done, int auto_reset, const or_rock_belief *b, int64_t n);
+
+/* What `_generate_preferred(history)` reads from the planner's History (rock.py:525-550; tag.py:233-239 reads
+ * history.size and history[-1].action / .ob), kept as running sums so the history itself need not be stored:
+ *   size, last_action = history[-1].action, last_ob = history[-1].next_observation             [n]
+ *   total_sample[j] = sum over transitions with action == CHECK j of (+1 next_ob GOOD, -1 next_ob BAD)   rock.py:303-310
+ *   total_move[j]   = same transitions: +1 if next_ob GOOD, else -1 if *observation* is BAD              rock.py:327-334
+ * (the two rock sums, [num_rocks][n], are NULL for the other envs).  Unbounded history only (max_size=None). */
+typedef struct or_history {
+    int32_t *size, *last_action, *last_ob;
+    int32_t *total_sample, *total_move;
+} or_history;
+void or_batch_history_clear(const or_env *proto, const or_history *h, const uint8_t *where, int64_t n);
+/* history.append(Transition(observation, action, reward, next_observation, done)); with auto_reset a done
+ * transition ends the episode and the lane's history starts over (empty). */
+void or_batch_history_append(const or_env *proto, const or_history *h, const int32_t *observation,
+                             const int32_t *action, const int32_t *next_observation, const uint8_t *done,
+                             int auto_reset, int64_t n);
+/* `_generate_preferred(history)` with use_heuristic=True (rock.py:293-374, tag.py:231-243; tiger.py:114-115 and
+ * network.py:138-139 return the legal list; BattleShip has no such method and gets its legal list):
+ * out[n][OR_MAX_LEGAL] padded with -1, len[n].  b may be NULL for non-rock envs. */
+void or_batch_preferred(const or_env *proto, const uint32_t *state, const or_rock_belief *b, const or_history *h,
+                        int32_t *out, int32_t *len, int64_t n);
+/* RockEnv._select_target (rock.py:389-399): nearest (straight-line distance — the reference's
+ * `manhattan_distance` is sqrt(dx^2+dy^2), coord.py:83-85) uncollected rock with count >= 0, first wins; -1 if none */
+void or_batch_rock_select_target(const or_env *proto, const uint32_t *state, const or_rock_belief *b,
+                                 int32_t *target, int64_t n);
+/* action[i] = list[i][(w * len[i]) >> 32], w = the synthetic policy's word of (seed, lane0 + i, t) (stream ACTION,
+ * shared by the four lanes of a quad like or_synthetic_actions); -1 where len[i] == 0 */
+void or_batch_pick(const int32_t *list, const int32_t *len, int stride, int32_t *action, int64_t n, uint64_t seed,
+                   uint32_t lane0, uint64_t t);
+
 #ifdef __cplusplus
 }
 #endif

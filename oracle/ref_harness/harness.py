@@ -354,3 +354,94 @@ def compute_prob_trace(name, kwargs, seed, lanes, actions, t0=0):
                 env.reset()
     out.update(lanes=np.asarray(lanes, np.int64), actions=actions.astype(np.int64), seed=np.int64(seed), t0=np.int64(t0))
     return out
+
+
+# ---------------------------------------------------------------------------
+# heuristic policy: side statistics, _generate_preferred, _select_target
+# ---------------------------------------------------------------------------
+MAX_PREF = 32
+
+
+class _TagRecord(object):
+    """tag.py:233-239 reads `history.size`, `history[-1].action` and `history[-1].ob`; the module it imports them
+    from (gym_pomdp.envs.history, tag.py:303) is not part of the reference tree, so the harness supplies the
+    minimal container with exactly those attributes."""
+    __slots__ = ("action", "ob")
+
+    def __init__(self, action, ob):
+        self.action, self.ob = action, ob
+
+
+class _TagHistory(list):
+    @property
+    def size(self):
+        return len(self)
+
+
+def heuristic_trace(name, kwargs, seed, lanes, T, t0=0):
+    """Reference envs driven by their own `_generate_preferred(history)` (use_heuristic=True for RockSample), one env
+    per lane, Philox-injected like mode B.  The action of lane L at call t is list[(w * len(list)) >> 32] with w the
+    synthetic policy's word (philox_ref.action_word) and list chosen by L & 3: 0, 1 -> _generate_preferred(history),
+    2 -> _generate_legal(), 3 -> all actions — so that the side statistics also see what the heuristic itself never
+    does.  The history is the reference's own History of Transition(observation, action, reward, next_observation,
+    done) records (rock.py:525-550), rebuilt empty after every reset.  Recorded per (lane, step): the preferred list
+    *before* the step, _select_target, the action, (ob, reward, done), and after the call (post auto-reset) the
+    compact state and every rock's count / measured / lkv / lkw / prob_valuable."""
+    load_reference()
+    import gym_pomdp.envs.rock as rk
+    is_rock = name in ("rock", "stochrock")
+    lanes = list(lanes)
+    L = len(lanes)
+    out = None
+    for li, lane in enumerate(lanes):
+        env = make_ref_env(name, use_heuristic=True, **kwargs) if is_rock else make_ref_env(name, **kwargs)
+        inject_stream(seed, lane, t0, px.STREAM_RESET, env=name, env_kwargs=kwargs)
+        ob_prev = int(env.reset())
+        hist = rk.History() if is_rock else _TagHistory()
+        n_act = env.action_space.n
+        s0 = compact_state(name, env)
+        K = len(env.state.rocks) if is_rock else 0
+        if out is None:
+            out = dict(pref=np.full((L, T, MAX_PREF), -1, np.int64), pref_len=np.zeros((L, T), np.int64),
+                       target=np.full((L, T), -1, np.int64), action=np.zeros((L, T), np.int64),
+                       ob=np.zeros((L, T), np.int64), reward=np.zeros((L, T), np.float64),
+                       done=np.zeros((L, T), np.uint8), state0=np.zeros((L, len(s0)), np.int64),
+                       state=np.zeros((L, T, len(s0)), np.int64),
+                       count=np.zeros((L, T, K), np.int64), measured=np.zeros((L, T, K), np.int64),
+                       lkv=np.zeros((L, T, K), np.float64), lkw=np.zeros((L, T, K), np.float64),
+                       prob_valuable=np.zeros((L, T, K), np.float64))
+        out["state0"][li] = s0
+        for i in range(T):
+            t = t0 + 1 + i
+            pref = [int(a) for a in env._generate_preferred(hist)]
+            assert 0 < len(pref) <= MAX_PREF
+            out["pref"][li, i, : len(pref)] = pref
+            out["pref_len"][li, i] = len(pref)
+            if is_rock:
+                out["target"][li, i] = int(rk.RockEnv._select_target(env.state, env.grid.x_size))
+            pol = lane & 3
+            lst = pref if pol < 2 else ([int(a) for a in env._generate_legal()] if pol == 2 else list(range(n_act)))
+            a = lst[(px.action_word(seed, lane, t) * len(lst)) >> 32]
+            lim = inject_stream(seed, lane, t, px.STREAM_STEP, env=name, env_kwargs=kwargs)
+            o, r, d, _ = env.step(a)
+            assert consumed_words() <= lim
+            if is_rock:
+                hist.append(rk.Transition(observation=ob_prev, action=a, reward=r, next_observation=int(o), done=d))
+            else:
+                hist.append(_TagRecord(a, int(o)))
+            out["action"][li, i], out["ob"][li, i] = a, int(o)
+            out["reward"][li, i], out["done"][li, i] = float(r), int(bool(d))
+            if d:
+                inject_stream(seed, lane, t, px.STREAM_RESET, env=name, env_kwargs=kwargs)
+                ob_prev = int(env.reset())
+                hist = rk.History() if is_rock else _TagHistory()
+            else:
+                ob_prev = int(o)
+            out["state"][li, i] = compact_state(name, env)
+            for j in range(K):
+                rr = env.state.rocks[j]
+                out["count"][li, i, j], out["measured"][li, i, j] = rr.count, rr.measured
+                out["lkv"][li, i, j], out["lkw"][li, i, j] = rr.lkv, rr.lkw
+                out["prob_valuable"][li, i, j] = rr.prob_valuable
+    out.update(lanes=np.asarray(lanes, np.int64), seed=np.int64(seed), t0=np.int64(t0))
+    return out

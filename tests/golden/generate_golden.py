@@ -175,6 +175,38 @@ def gen_prob(case, env, kwargs, L, T):
     np.savez_compressed(os.path.join(HERE, "prob_%s.npz" % case), **tr)
 
 
+# heuristic policy traces: (case, env, kwargs, lanes, steps)
+HEUR_CASES = [("rock_7_8", "rock", {}, 96, 96), ("rock_11_11", "rock", dict(board_size=11, num_rocks=11), 32, 96),
+              ("rock_15_15", "rock", dict(board_size=15, num_rocks=15), 32, 128),
+              ("rock_4_3", "rock", dict(board_size=4, num_rocks=3), 32, 48),
+              ("stochrock_7_8", "stochrock", {}, 48, 128),
+              ("tag_1", "tag", {}, 64, 128), ("tag_2", "tag", dict(num_opponents=2), 32, 128)]
+HEUR_SEED = 0xBE11EF5EED
+
+
+def gen_heuristic(case, env, kwargs, L, T):
+    lanes = list(range(L // 2)) + list(range((1 << 20) - L // 4, (1 << 20) + L // 4))
+    tries = 0
+    while True:
+        try:
+            tr = h.heuristic_trace(env, kwargs, HEUR_SEED + tries, lanes, T, t0=11)
+            break
+        except IndexError:      # RockSample crash cells
+            tries += 1
+            assert tries < 50
+    out = {}
+    for k, v in tr.items():
+        v = np.asarray(v)
+        if v.dtype == np.float64 or k in ("lanes", "seed", "t0"):
+            out[k] = v
+        else:
+            fits8 = v.size == 0 or (v.min() >= -128 and v.max() <= 127)
+            out[k] = v.astype(np.int8 if fits8 else np.int16)
+            assert np.array_equal(out[k], v)
+    np.savez_compressed(os.path.join(HERE, "heur_%s.npz" % case), **out)
+    return int(tr["done"].sum()), float(tr["pref_len"].mean()), tries
+
+
 def gen_thresholds():
     def binom_at(p, k):
         h.inject_words([(k >> 26) << 5, (k & ((1 << 26) - 1)) << 6])
@@ -274,6 +306,11 @@ def main():
     import warnings
     warnings.simplefilter("ignore", RuntimeWarning)  # reference's belief side-stats divide 0/0 (rock.py:191)
     gen_thresholds()
+    if "--heuristic-only" in sys.argv:
+        for case, env, kwargs, L, T in HEUR_CASES:
+            nd, ml, tries = gen_heuristic(case, env, kwargs, L, T)
+            print("heuristic %-16s dones=%4d  mean preferred-list length=%.2f  (seed retries %d)" % (case, nd, ml, tries), flush=True)
+        return
     if "--rollouts-only" not in sys.argv:
         gen_edge_cases()
     only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--only=")]
@@ -289,6 +326,9 @@ def main():
     for case, env, kwargs, R, S, depth, alla in ROLLOUT_CASES:
         nt, ms = gen_rollout(case, env, kwargs, R, S, depth, alla)
         print("rollout %-18s terminated=%4d / %d  mean steps=%.1f" % (case, nt, R * S, ms), flush=True)
+    for case, env, kwargs, L, T in HEUR_CASES:
+        nd, ml, tries = gen_heuristic(case, env, kwargs, L, T)
+        print("heuristic %-16s dones=%4d  mean preferred-list length=%.2f  (seed retries %d)" % (case, nd, ml, tries), flush=True)
     with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
         json.dump({"cases": [[c[0], c[1], {k: (list(v) if isinstance(v, tuple) else v) for k, v in c[2].items()}]
                              for c in CASES],
@@ -296,6 +336,8 @@ def main():
                                      for c in ROLLOUT_CASES],
                    "prob_cases": [[c[0], c[1], {k: (list(v) if isinstance(v, tuple) else v) for k, v in c[2].items()}]
                                   for c in PROB_CASES],
+                   "heuristic_cases": [[c[0], c[1], {k: (list(v) if isinstance(v, tuple) else v) for k, v in c[2].items()}]
+                                       for c in HEUR_CASES],
                    "mode_a_seeds": MODE_A_SEEDS, "mode_b_seed": MODE_B_SEED,
                    "numpy": np.__version__}, f, indent=1)
 
