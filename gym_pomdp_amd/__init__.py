@@ -8,6 +8,7 @@ classes with the same constructor kwargs plus `batch_size`, `device`, `seed`, `a
 import importlib
 
 from . import spaces  # noqa: F401
+from .history import History, Transition  # noqa: F401
 from .envs import BattleShipEnv, NetworkEnv, RockEnv, StochasticRockEnv, TagEnv, TigerEnv  # noqa: F401
 
 __version__ = "0.1.0"

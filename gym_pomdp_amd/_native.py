@@ -13,7 +13,7 @@ _REPO = os.path.dirname(_PKG)
 LIB_PATH = os.path.join(_PKG, "_lib", "libpomdp_hip.so")
 SOURCES = [os.path.join(_PKG, "csrc", f) for f in ("pomdp_kernels.hip", "envs.hip.h", "philox.hip.h")]
 HEADER = os.path.join(_REPO, "include", "pomdp_hip.h")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 POMDP_AUTO_RESET = 1
 POMDP_ROLLOUT_ALL_ACTIONS = 1
@@ -26,6 +26,8 @@ SYMBOLS = [
     "pomdp_battleship_reset", "pomdp_battleship_step", "pomdp_tiger_reset", "pomdp_tiger_step",
     "pomdp_network_reset", "pomdp_network_step", "pomdp_synthetic_actions", "pomdp_philox_blocks",
     "pomdp_rollout_synthetic", "pomdp_legal_actions", "pomdp_rollout", "pomdp_compute_prob",
+    "pomdp_rock_belief_reset", "pomdp_rock_belief_update", "pomdp_rock_select_target", "pomdp_history_clear",
+    "pomdp_history_append", "pomdp_preferred_actions", "pomdp_pick_actions",
 ]
 
 
@@ -52,6 +54,14 @@ class TigerParams(C.Structure):
 class NetworkParams(C.Structure):
     _fields_ = [("n_machines", C.c_int32), ("deg_gt2_mask", C.c_uint32), ("nb_mask", C.c_uint32 * 32),
                 ("fail_thr", C.c_uint64), ("fail_nb_thr", C.c_uint64), ("obs_thr", C.c_uint64)]
+
+
+class RockBelief(C.Structure):      # pomdp_rock_belief: device pointers, [num_rocks][n]
+    _fields_ = [(k, C.c_void_p) for k in ("count", "measured", "lkv", "lkw", "prob_valuable")]
+
+
+class HistoryPtrs(C.Structure):     # pomdp_history: device pointers
+    _fields_ = [(k, C.c_void_p) for k in ("size", "last_action", "last_ob", "total_sample", "total_move")]
 
 
 def hipcc_path():
@@ -112,6 +122,20 @@ def lib():
     L.pomdp_compute_prob.argtypes = [ci, vp, vp, vp, vp, vp, i64, vp]
     L.pomdp_rollout.restype = ci
     L.pomdp_rollout.argtypes = [ci, vp, vp, i64, i64, ci, C.c_double, ci, u64, u32, u64, vp, vp, vp, vp, vp, vp]
+    L.pomdp_rock_belief_reset.restype = ci
+    L.pomdp_rock_belief_reset.argtypes = [vp, vp, vp, i64, vp]
+    L.pomdp_rock_belief_update.restype = ci
+    L.pomdp_rock_belief_update.argtypes = [vp, vp, vp, vp, vp, vp, i64, ci, vp]
+    L.pomdp_rock_select_target.restype = ci
+    L.pomdp_rock_select_target.argtypes = [vp, vp, vp, vp, i64, vp]
+    L.pomdp_history_clear.restype = ci
+    L.pomdp_history_clear.argtypes = [ci, vp, vp, vp, i64, vp]
+    L.pomdp_history_append.restype = ci
+    L.pomdp_history_append.argtypes = [ci, vp, vp, vp, vp, vp, vp, i64, ci, vp]
+    L.pomdp_preferred_actions.restype = ci
+    L.pomdp_preferred_actions.argtypes = [ci, vp, vp, vp, vp, vp, vp, i64, ci, vp]
+    L.pomdp_pick_actions.restype = ci
+    L.pomdp_pick_actions.argtypes = [vp, vp, ci, vp, i64, u64, u32, u64, vp]
     L.pomdp_philox_blocks.restype = ci
     L.pomdp_philox_blocks.argtypes = [vp, vp, i64, vp]
     _lib = L

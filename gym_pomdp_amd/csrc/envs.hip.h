@@ -271,6 +271,82 @@ struct RockEnv {
         return legal_count(sh, p, st, pre, n_pre, alive);
     }
 
+    // ---- heuristic-policy support ------------------------------------------------------
+    // rock.py:177-191: side statistics of the rock a CHECK just measured (CHECK does not move the agent, so the
+    // stored position is the one the reading was taken from)
+    static __device__ __forceinline__ void belief_update(const Shared &sh, const Params &p, const State &st, int a, int ob,
+                                                         const pomdp_rock_belief &b, int64_t n, uint32_t i)
+    {
+        const S s = st.s;
+        const int x = (int)(s & 15u), y = (int)((s >> 4) & 15u), r = (a - 5) & 15;
+        const uint32_t rxy = sh.rxy[r];
+        const double eff = p.eff[abs(x - (int)(rxy & 15u)) + abs(y - (int)(rxy >> 4))];
+        const int64_t k = (int64_t)r * n + i;
+        double lkv = b.lkv[k], lkw = b.lkw[k];
+        b.measured[k] += 1;
+        if (ob == 2) { b.count[k] += 1; lkv *= eff; lkw *= (1 - eff); }
+        else         { b.count[k] -= 1; lkw *= eff; lkv *= (1 - eff); }
+        b.lkv[k] = lkv;
+        b.lkw[k] = lkw;
+        const double denom = (.5 * lkv) + (.5 * lkw);
+        b.prob_valuable[k] = (.5 * lkv) / denom;
+    }
+
+    // rock.py:293-374 _generate_preferred with use_heuristic=True, as a bitmask over actions: every list the
+    // heuristic builds is in ascending action order ([SAMPLE], [EAST], or N/E/S/W then the CHECKs by rock index);
+    // 0 = the heuristic produced nothing and the caller falls back to _generate_legal() (rock.py:374-375)
+    static __device__ __forceinline__ uint32_t preferred_mask(const Shared &sh, const Params &p, const State &st,
+                                                              const pomdp_rock_belief &b, const pomdp_history &h,
+                                                              int64_t n, uint32_t i)
+    {
+        const S s = st.s;
+        const int x = (int)(s & 15u), y = (int)((s >> 4) & 15u), K = p.num_rocks;
+        const int id = sh.grid[x * 16 + y];
+        if (id >= 0 && id < K && ((uint32_t)(s >> (8 + 2 * (id & 15))) & 3u) != 1u && h.size[i] != 0)
+            if (h.total_sample[(int64_t)id * n + i] > 0) return 1u << 4;                          // rock.py:300-313
+        bool all_bad = true, north = false, south = false, west = false, east = false;
+        uint32_t checks = 0;
+        for (int j = 0; j < K; ++j) {
+            if (((uint32_t)(s >> (8 + 2 * j)) & 3u) == 1u) continue;                              // collected
+            const int64_t k = (int64_t)j * n + i;
+            if (h.total_move[k] >= 0) {                                                           // rock.py:335-345
+                all_bad = false;
+                const uint32_t rxy = sh.rxy[j];
+                const int rx = (int)(rxy & 15u), ry = (int)(rxy >> 4);
+                if (ry > y) north = true;
+                else if (ry < y) south = true;
+                else if (rx < x) west = true;
+                else if (rx > x) east = true;
+            }
+            const double pv = b.prob_valuable[k];
+            if (b.measured[k] < 5 && abs(b.count[k]) < 2 && 0 < pv && pv < 1) checks |= 1u << (5 + j);   // rock.py:370-372
+        }
+        if (all_bad) return 1u << 1;                                                              // rock.py:347-349
+        uint32_t m = checks;
+        if (y + 1 < p.size && north) m |= 1u << 0;                                                // rock.py:358-368
+        if (east) m |= 1u << 1;
+        if (y - 1 >= 0 && south) m |= 1u << 2;
+        if (x - 1 >= 0 && west) m |= 1u << 3;
+        return m;
+    }
+
+    // rock.py:389-399 _select_target; distances compared as dx^2 + dy^2 (the reference takes the square root of the
+    // same integers, coord.py:83-85, and every candidate is below its initial bound of 2 * size)
+    static __device__ __forceinline__ int select_target(const Shared &sh, const Params &p, const State &st,
+                                                        const pomdp_rock_belief &b, int64_t n, uint32_t i)
+    {
+        const S s = st.s;
+        const int x = (int)(s & 15u), y = (int)((s >> 4) & 15u), K = p.num_rocks;
+        int best = 4 * p.size * p.size, best_rock = -1;
+        for (int j = 0; j < K; ++j) {
+            if (((uint32_t)(s >> (8 + 2 * j)) & 3u) == 1u || b.count[(int64_t)j * n + i] < 0) continue;
+            const uint32_t rxy = sh.rxy[j];
+            const int dx = x - (int)(rxy & 15u), dy = y - (int)(rxy >> 4), d2 = dx * dx + dy * dy;
+            if (d2 < best) { best = d2; best_rock = j; }
+        }
+        return best_rock;
+    }
+
     // rock.py:250-264 _compute_prob
     static __device__ __forceinline__ double compute_prob(const Shared &sh, const Params &p, const State &st, int a, int ob)
     {
@@ -427,6 +503,27 @@ struct TagEnv {
     // tag.py:228-229: every action is legal
     static __device__ __forceinline__ int legal_count(const Shared &, const Params &p, const State &) { return n_actions(p); }
     static __device__ __forceinline__ int legal_nth(const Shared &, const Params &, const State &, int idx) { return idx; }
+
+    // tag.py:231-243 _generate_preferred as a bitmask (ascending order is the reference's list order); tag.py:68-74
+    // is_corner, coord.py:75-77 opposite.  history.size == 0 gives the legal list (all five actions).
+    static __device__ __forceinline__ uint32_t preferred_mask(const Shared &, const Params &, const State &st,
+                                                              const pomdp_rock_belief &, const pomdp_history &h,
+                                                              int64_t, uint32_t i)
+    {
+        if (h.size[i] == 0) return 0x1Fu;
+        const int agent = (int)(st.w & 31u);
+        int x, y;
+        coord(agent, x, y);
+        const bool corner = y < 2 ? (x == 0 || x == 9) : (y == 4 && (x == 5 || x == 7));
+        if (h.last_ob[i] == 29 && corner) return 1u << 4;          // grid.n_tiles, whatever obs_cells was set to
+        const int la = h.last_action[i];
+        uint32_t m = 0;
+        const int dx[4] = {0, 1, 0, -1}, dy[4] = {1, 0, -1, 0};
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+            if (la != ((d + 2) & 3) && inside(x + dx[d], y + dy[d])) m |= 1u << d;
+        return m;
+    }
 
     // tag.py:209-217 _compute_prob
     static __device__ __forceinline__ double compute_prob(const Shared &, const Params &p, const State &st, int, int ob)
@@ -721,6 +818,10 @@ struct BattleShipEnv {
         return a;
     }
 
+    // no heuristic: _generate_preferred is _generate_legal (0 = fall back to the legal list)
+    static __device__ __forceinline__ uint32_t preferred_mask(const Shared &, const Params &, const State &,
+                                                              const pomdp_rock_belief &, const pomdp_history &, int64_t,
+                                                              uint32_t) { return 0u; }
     // battleship.py:80-89 _compute_prob (reads the grid as it is after the shot)
     static __device__ __forceinline__ double compute_prob(const Shared &, const Params &, const State &st, int a, int ob)
     {
@@ -787,6 +888,10 @@ struct TigerEnv {
     static __device__ __forceinline__ int legal_count(const Shared &, const Params &p, const State &) { return n_actions(p); }
     static __device__ __forceinline__ int legal_nth(const Shared &, const Params &, const State &, int idx) { return idx; }
 
+    // no heuristic: _generate_preferred is _generate_legal (0 = fall back to the legal list)
+    static __device__ __forceinline__ uint32_t preferred_mask(const Shared &, const Params &, const State &,
+                                                              const pomdp_rock_belief &, const pomdp_history &, int64_t,
+                                                              uint32_t) { return 0u; }
     // tiger.py:125-138 _compute_prob
     static __device__ __forceinline__ double compute_prob(const Shared &, const Params &, const State &st, int a, int ob)
     {
@@ -855,6 +960,10 @@ struct NetworkEnv {
     static __device__ __forceinline__ int legal_count(const Shared &, const Params &p, const State &) { return n_actions(p); }
     static __device__ __forceinline__ int legal_nth(const Shared &, const Params &, const State &, int idx) { return idx; }
 
+    // no heuristic: _generate_preferred is _generate_legal (0 = fall back to the legal list)
+    static __device__ __forceinline__ uint32_t preferred_mask(const Shared &, const Params &, const State &,
+                                                              const pomdp_rock_belief &, const pomdp_history &, int64_t,
+                                                              uint32_t) { return 0u; }
     // network.py:43-55 _compute_prob
     static __device__ __forceinline__ double compute_prob(const Shared &, const Params &p, const State &st, int a, int ob)
     {

@@ -266,6 +266,134 @@ __global__ __launch_bounds__(BLOCK) void prob_kernel(const typename Env::Params 
     out[i] = (unsigned)a < (unsigned)Env::n_actions(p) ? Env::compute_prob(sh, p, st, a, ob[i]) : 0.0;
 }
 
+// ---------------------------------------------------------------------------
+// heuristic-policy support: side statistics, history sums, _generate_preferred
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void belief_reset_kernel(pomdp_rock_belief b, int K, const uint8_t *__restrict__ where,
+                                                             int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n || (where && !where[i])) return;
+    for (int j = 0; j < K; ++j) {                                              // rock.py:81-86
+        const int64_t k = (int64_t)j * n + i;
+        b.count[k] = 0; b.measured[k] = 0; b.lkv[k] = 1.; b.lkw[k] = 1.; b.prob_valuable[k] = .5;
+    }
+}
+
+template <class Env>
+__global__ __launch_bounds__(BLOCK) void belief_update_kernel(const typename Env::Params p, const uint32_t *__restrict__ state,
+                                                              const int32_t *__restrict__ action, const int32_t *__restrict__ ob,
+                                                              const uint8_t *__restrict__ done, pomdp_rock_belief b, int64_t n,
+                                                              int auto_reset)
+{
+    __shared__ typename Env::Shared sh;
+    Env::stage(sh, p, (int)threadIdx.x);
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    if (done[i]) {
+        if (auto_reset)
+            for (int j = 0; j < p.num_rocks; ++j) {
+                const int64_t k = (int64_t)j * n + i;
+                b.count[k] = 0; b.measured[k] = 0; b.lkv[k] = 1.; b.lkw[k] = 1.; b.prob_valuable[k] = .5;
+            }
+        return;
+    }
+    const int a = action[i], o = ob[i];
+    if (a <= 4 || a >= 5 + p.num_rocks || o == 0) return;                      // not an executed CHECK
+    typename Env::State st;
+    Env::load(st, state, n, (uint32_t)i);
+    Env::belief_update(sh, p, st, a, o, b, n, (uint32_t)i);
+}
+
+template <class Env>
+__global__ __launch_bounds__(BLOCK) void select_target_kernel(const typename Env::Params p, const uint32_t *__restrict__ state,
+                                                              pomdp_rock_belief b, int32_t *__restrict__ target, int64_t n)
+{
+    __shared__ typename Env::Shared sh;
+    Env::stage(sh, p, (int)threadIdx.x);
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    typename Env::State st;
+    Env::load(st, state, n, (uint32_t)i);
+    target[i] = Env::select_target(sh, p, st, b, n, (uint32_t)i);
+}
+
+__global__ __launch_bounds__(BLOCK) void history_clear_kernel(pomdp_history h, int K, const uint8_t *__restrict__ where, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n || (where && !where[i])) return;
+    h.size[i] = 0; h.last_action[i] = -1; h.last_ob[i] = -1;
+    for (int j = 0; j < K; ++j) { h.total_sample[(int64_t)j * n + i] = 0; h.total_move[(int64_t)j * n + i] = 0; }
+}
+
+// rock.py:541-544 History.append + the sums _generate_preferred takes over the records (rock.py:303-310, 327-334)
+__global__ __launch_bounds__(BLOCK) void history_append_kernel(pomdp_history h, int K, const int32_t *__restrict__ observation,
+                                                               const int32_t *__restrict__ action,
+                                                               const int32_t *__restrict__ next_observation,
+                                                               const uint8_t *__restrict__ done, int64_t n, int auto_reset)
+{
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    if (done[i] && auto_reset) {                                               // next episode: a new, empty History
+        h.size[i] = 0; h.last_action[i] = -1; h.last_ob[i] = -1;
+        for (int j = 0; j < K; ++j) { h.total_sample[(int64_t)j * n + i] = 0; h.total_move[(int64_t)j * n + i] = 0; }
+        return;
+    }
+    const int a = action[i], o = next_observation[i];
+    h.size[i] += 1; h.last_action[i] = a; h.last_ob[i] = o;
+    if (a >= 5 && a < 5 + K) {
+        const int64_t k = (int64_t)(a - 5) * n + i;
+        const int ds = (o == 2) - (o == 1);
+        const int dm = o == 2 ? 1 : (observation[i] == 1 ? -1 : 0);
+        if (ds) h.total_sample[k] += ds;
+        if (dm) h.total_move[k] += dm;
+    }
+}
+
+template <class Env>
+__global__ __launch_bounds__(BLOCK) void preferred_kernel(const typename Env::Params p, const uint32_t *__restrict__ state,
+                                                          pomdp_rock_belief b, pomdp_history h, int32_t *__restrict__ list,
+                                                          int32_t *__restrict__ len, int64_t n, int stride)
+{
+    __shared__ typename Env::Shared sh;
+    Env::stage(sh, p, (int)threadIdx.x);
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    typename Env::State st;
+    Env::load(st, state, n, (uint32_t)i);
+    uint32_t m = Env::preferred_mask(sh, p, st, b, h, n, (uint32_t)i);
+    if (m) {                                                                   // ascending action order
+        const int c = __popc(m);
+        len[i] = c;
+        for (int k = 0; k < stride; ++k) {
+            int a = -1;
+            if (k < c) { a = __ffs((int)m) - 1; m &= m - 1u; }
+            list[i * stride + k] = a;
+        }
+    } else {                                                                   // _generate_legal()
+        const int c = Env::legal_count(sh, p, st);
+        len[i] = c;
+        for (int k = 0; k < stride; ++k) list[i * stride + k] = k < c ? Env::legal_nth(sh, p, st, k) : -1;
+    }
+}
+
+// the caller's np.random.choice(list): the synthetic policy's word of the lane picks the element
+__global__ __launch_bounds__(BLOCK) void pick_actions_kernel(const int32_t *__restrict__ list, const int32_t *__restrict__ len,
+                                                             int stride, int32_t *__restrict__ action, int64_t n, RngKey key,
+                                                             uint32_t lane0)
+{
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t lane = lane0 + (uint32_t)i, e = lane & 3u;
+    const uint4 w = stream_block(key, lane >> 2, POMDP_STREAM_ACTION, 0u);
+    const uint32_t word = e == 0 ? w.x : e == 1 ? w.y : e == 2 ? w.z : w.w;
+    const int c = len[i];
+    action[i] = c > 0 ? list[i * stride + (int64_t)__umulhi(word, (uint32_t)c)] : -1;
+}
+
 // Lane i simulates from root state column i / sims_per_root for up to `depth` steps: the state lives
 // in registers, the policy draw (stream ROLLOUT) and the env draws (stream STEP) come from the lane's
 // own Philox streams at t0 + k, the discounted return accumulates in IEEE double with separate
@@ -468,6 +596,40 @@ static int launch_rollout(const typename Env::Params &p, const uint32_t *state, 
     hipLaunchKernelGGL(rollout_kernel<Env>, dim3(blocks_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, p, state, n_roots,
                        sims, depth, discount, (flags & POMDP_ROLLOUT_ALL_ACTIONS) ? 1 : 0, make_key(seed, t0), lane0, ret,
                        n_steps, first_action, last_ob, terminated);
+    return (int)hipGetLastError();
+}
+static bool belief_ok(const pomdp_rock_belief *b) { return b && b->count && b->measured && b->lkv && b->lkw && b->prob_valuable; }
+static bool history_ok(const pomdp_history *h, bool rock)
+{
+    return h && h->size && h->last_action && h->last_ob && (!rock || (h->total_sample && h->total_move));
+}
+static const pomdp_rock_belief NO_BELIEF = {nullptr, nullptr, nullptr, nullptr, nullptr};
+
+template <class Env>
+static int launch_belief_update(const typename Env::Params &p, const uint32_t *state, const int32_t *action, const int32_t *ob,
+                                const uint8_t *done, const pomdp_rock_belief *b, int64_t n, int flags, void *stream)
+{
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(belief_update_kernel<Env>, dim3(blocks_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, p, state, action,
+                       ob, done, *b, n, (flags & POMDP_AUTO_RESET) ? 1 : 0);
+    return (int)hipGetLastError();
+}
+template <class Env>
+static int launch_select_target(const typename Env::Params &p, const uint32_t *state, const pomdp_rock_belief *b,
+                                int32_t *target, int64_t n, void *stream)
+{
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(select_target_kernel<Env>, dim3(blocks_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, p, state, *b,
+                       target, n);
+    return (int)hipGetLastError();
+}
+template <class Env>
+static int launch_preferred(const typename Env::Params &p, const uint32_t *state, const pomdp_rock_belief *b,
+                            const pomdp_history *h, int32_t *list, int32_t *len, int64_t n, int stride, void *stream)
+{
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(preferred_kernel<Env>, dim3(blocks_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, p, state,
+                       b ? *b : NO_BELIEF, *h, list, len, n, stride);
     return (int)hipGetLastError();
 }
 } // namespace pomdp
@@ -765,6 +927,81 @@ int pomdp_rollout(int env, const void *params, const uint32_t *root_state, int64
     POMDP_DISPATCH(env, params, return launch_rollout<E>(*p, root_state, n_roots, sims_per_root, depth, discount, flags,
                                                          seed, lane0, t0, ret, n_steps, first_action, last_ob,
                                                          terminated, stream))
+}
+
+int pomdp_rock_belief_reset(const pomdp_rock_params *p, const pomdp_rock_belief *b, const uint8_t *where, int64_t n,
+                            void *stream)
+{
+    if (!p || !belief_ok(b) || n < 0) return POMDP_E_BADARG;
+    if (!rock_ok(p)) return POMDP_E_BADPARAMS;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(belief_reset_kernel, dim3(blocks_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, *b, p->num_rocks, where, n);
+    return (int)hipGetLastError();
+}
+
+int pomdp_rock_belief_update(const pomdp_rock_params *p, const uint32_t *state, const int32_t *action, const int32_t *ob,
+                             const uint8_t *done, const pomdp_rock_belief *b, int64_t n, int flags, void *stream)
+{
+    if (!p || !state || !action || !ob || !done || !belief_ok(b) || n < 0) return POMDP_E_BADARG;
+    if (!rock_ok(p)) return POMDP_E_BADPARAMS;
+    if (p->num_rocks <= 12) return launch_belief_update<RockEnv<1>>(*p, state, action, ob, done, b, n, flags, stream);
+    return launch_belief_update<RockEnv<2>>(*p, state, action, ob, done, b, n, flags, stream);
+}
+
+int pomdp_rock_select_target(const pomdp_rock_params *p, const uint32_t *state, const pomdp_rock_belief *b, int32_t *target,
+                             int64_t n, void *stream)
+{
+    if (!p || !state || !target || !belief_ok(b) || n < 0) return POMDP_E_BADARG;
+    if (!rock_ok(p)) return POMDP_E_BADPARAMS;
+    if (p->num_rocks <= 12) return launch_select_target<RockEnv<1>>(*p, state, b, target, n, stream);
+    return launch_select_target<RockEnv<2>>(*p, state, b, target, n, stream);
+}
+
+static int history_rocks(int env, const void *params)
+{
+    if (env != POMDP_ENV_ROCK) return (env >= POMDP_ENV_TAG && env <= POMDP_ENV_NETWORK) ? 0 : -1;
+    const pomdp_rock_params *p = (const pomdp_rock_params *)params;
+    return (p && rock_ok(p)) ? p->num_rocks : -1;
+}
+
+int pomdp_history_clear(int env, const void *params, const pomdp_history *h, const uint8_t *where, int64_t n, void *stream)
+{
+    const int K = history_rocks(env, params);
+    if (K < 0 || !history_ok(h, K > 0) || n < 0) return POMDP_E_BADARG;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(history_clear_kernel, dim3(blocks_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, *h, K, where, n);
+    return (int)hipGetLastError();
+}
+
+int pomdp_history_append(int env, const void *params, const pomdp_history *h, const int32_t *observation,
+                         const int32_t *action, const int32_t *next_observation, const uint8_t *done, int64_t n, int flags,
+                         void *stream)
+{
+    const int K = history_rocks(env, params);
+    if (K < 0 || !history_ok(h, K > 0) || !observation || !action || !next_observation || !done || n < 0)
+        return POMDP_E_BADARG;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(history_append_kernel, dim3(blocks_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, *h, K, observation,
+                       action, next_observation, done, n, (flags & POMDP_AUTO_RESET) ? 1 : 0);
+    return (int)hipGetLastError();
+}
+
+int pomdp_preferred_actions(int env, const void *params, const uint32_t *state, const pomdp_rock_belief *b,
+                            const pomdp_history *h, int32_t *list, int32_t *len, int64_t n, int stride, void *stream)
+{
+    if (!params || !state || !list || !len || n < 0 || stride < 1) return POMDP_E_BADARG;
+    if (!history_ok(h, env == POMDP_ENV_ROCK) || (env == POMDP_ENV_ROCK && !belief_ok(b))) return POMDP_E_BADARG;
+    POMDP_DISPATCH(env, params, return launch_preferred<E>(*p, state, b, h, list, len, n, stride, stream))
+}
+
+int pomdp_pick_actions(const int32_t *list, const int32_t *len, int stride, int32_t *action, int64_t n, uint64_t seed,
+                       uint32_t lane0, uint64_t t, void *stream)
+{
+    if (!list || !len || !action || stride < 1 || bad_range(n, lane0)) return POMDP_E_BADARG;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(pick_actions_kernel, dim3(blocks_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, list, len, stride,
+                       action, n, make_key(seed, t), lane0);
+    return (int)hipGetLastError();
 }
 
 int pomdp_philox_blocks(const uint32_t *ctr_key, uint32_t *out, int64_t n_blocks, void *stream)

@@ -88,6 +88,7 @@ class BatchedEnv(object):
             self._host_reward = self._host_out[1:2].view(self.reward_dtype)
         self._has_reset = False
         self._scalar_done = False
+        self._tracker = None          # per-step side effects beyond (state, ob, reward, done): RockSample's side statistics
         self._done_bool = self._done.view(torch.bool)
         self._ptrs = (self._state.data_ptr(), self._ob.data_ptr(), self._reward.data_ptr(), self._done.data_ptr(),
                       self._err.data_ptr())
@@ -122,6 +123,8 @@ class BatchedEnv(object):
                                 self._seed, self.lane_offset, t, self._stream())
             _native.check(rc, "pomdp_%s_reset" % self.env_name)
             self._done.zero_()
+            if self._tracker is not None:
+                self._tracker.on_reset()
         self._has_reset = True
         self._scalar_done = False
         self.done = False if self.batch_size == 1 else self._done.view(torch.bool)
@@ -170,6 +173,8 @@ class BatchedEnv(object):
                 _native.check(rc, "pomdp_%s_step" % self.env_name)
             if not self.auto_reset and not self.reuse_buffers:
                 done = done.clone()
+        if self._tracker is not None:
+            self._tracker.on_step(action, ob, done, flags)
         info = {"state": self._state}
         self.done = self._done_bool if done is self._done else done.view(torch.bool)
         return ob, reward, self.done, info
@@ -185,6 +190,9 @@ class BatchedEnv(object):
                                ptrs[3], ptrs[4], 1, self._seed, self.lane_offset, t,
                                _native.POMDP_AUTO_RESET if self.auto_reset else 0, stream.cuda_stream)
             _native.check(rc, "pomdp_%s_step" % self.env_name)
+            if self._tracker is not None:
+                self._tracker.on_step(self._action_table[action:action + 1], self._ob, self._done,
+                                      _native.POMDP_AUTO_RESET if self.auto_reset else 0)
             self._host_out.copy_(self._scalar_buf, non_blocking=True)
             stream.synchronize()
         d = bool(self._host_out[2].item() & 0xFF)
@@ -229,6 +237,8 @@ class BatchedEnv(object):
         self._scalar_done = False
         self._has_reset = True
         self.done = False if self.batch_size == 1 else self._done.view(torch.bool)
+        if self._tracker is not None:
+            self._tracker.on_reset()
 
     _set_state = set_state
 
@@ -290,6 +300,47 @@ class BatchedEnv(object):
         if self.batch_size == 1:
             return lst[0, : int(ln.item())].tolist()
         return lst, ln
+
+    def preferred_actions(self, history, state=None):
+        """`_generate_preferred(history)` of every lane, in the shape of legal_actions(): (list int32 [N, n_actions]
+        padded with -1, length int32 [N]).  `history` is a gym_pomdp_amd.history.History of this env."""
+        st = self._state if state is None else torch.as_tensor(state, dtype=torch.int32, device=self.device)
+        st = st.reshape(self.state_words, -1).contiguous()
+        n = st.shape[1]
+        if n != self.batch_size:
+            raise ValueError("preferred_actions: the history and side statistics cover exactly batch_size lanes")
+        stride = self.action_space.n
+        lst = torch.empty((n, stride), dtype=torch.int32, device=self.device)
+        ln = torch.empty(n, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self._lib.pomdp_preferred_actions(_native.ENV_KIND[self.env_name], self._params_ref, st.data_ptr(),
+                                                   self._belief_ref(), history._ref, lst.data_ptr(), ln.data_ptr(), n,
+                                                   stride, self._stream())
+            _native.check(rc, "pomdp_preferred_actions")
+        return lst, ln
+
+    def _belief_ref(self):
+        return None
+
+    def _generate_preferred(self, history):
+        """Reference signature (tag.py:231-243; tiger.py:114-115, network.py:138-139: the legal list).
+        batch_size == 1: a python list; otherwise the (list, length) tensors."""
+        lst, ln = self.preferred_actions(history)
+        if self.batch_size == 1:
+            return lst[0, : int(ln.item())].tolist()
+        return lst, ln
+
+    def pick_actions(self, lists, lengths, seed=None, out=None):
+        """The caller's `np.random.choice(list)` for every lane (rock.py:564): element (w * length) >> 32 of each
+        lane's list, w being the synthetic policy's word at the *current* call counter.  -> int32[N]."""
+        if out is None:
+            out = torch.empty(self.batch_size, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self._lib.pomdp_pick_actions(lists.data_ptr(), lengths.data_ptr(), lists.shape[1], out.data_ptr(),
+                                              self.batch_size, self._seed if seed is None else seed, self.lane_offset,
+                                              self._t, self._stream())
+            _native.check(rc, "pomdp_pick_actions")
+        return out
 
     def compute_prob(self, action, ob, state=None):
         """`_compute_prob(action, next_state, ob)` per lane -> float64[N]: the likelihood of `ob` given that

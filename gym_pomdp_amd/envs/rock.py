@@ -1,8 +1,42 @@
 """RockSample — batched mirror of gym_pomdp/envs/rock.py:96-407 (`RockEnv`)."""
+import ctypes as C
+
 import torch
 
 from .. import _native, tables
 from .base import BatchedEnv
+
+
+class _BeliefTracker(object):
+    """RockSample's side statistics (rock.py:78-86 count / measured / lkv / lkw / prob_valuable), which the
+    reference's step() maintains on every CHECK (rock.py:177-191): float64 / int32 tensors [K, N] updated by one
+    extra launch after each step (include/pomdp_hip.h: pomdp_rock_belief_update)."""
+    FIELDS = (("count", torch.int32), ("measured", torch.int32), ("lkv", torch.float64), ("lkw", torch.float64),
+              ("prob_valuable", torch.float64))
+
+    def __init__(self, env):
+        self.env = env
+        k, n = env.num_rocks, env.batch_size
+        self.tensors = {f: torch.zeros((k, n), dtype=dt, device=env.device) for f, dt in self.FIELDS}
+        self.ptrs = _native.RockBelief(*[self.tensors[f].data_ptr() for f, _ in self.FIELDS])
+        self.ref = C.byref(self.ptrs)
+        self.on_reset()
+
+    def on_reset(self, where=None):
+        env = self.env
+        with torch.cuda.device(env.device):
+            rc = env._lib.pomdp_rock_belief_reset(env._params_ref, self.ref, None if where is None else where.data_ptr(),
+                                                  env.batch_size, env._stream())
+        _native.check(rc, "pomdp_rock_belief_reset")
+
+    def on_step(self, action, ob, done, flags):
+        env = self.env
+        with torch.cuda.device(env.device):
+            rc = env._lib.pomdp_rock_belief_update(env._params_ref, env._state.data_ptr(), action.data_ptr(),
+                                                   ob.data_ptr(), done.data_ptr(), self.ref, env.batch_size, flags,
+                                                   env._stream())
+        if rc:
+            _native.check(rc, "pomdp_rock_belief_update")
 
 
 def make_params(board_size=7, num_rocks=8, stochastic=False, p_move=.8):
@@ -48,7 +82,10 @@ class RockEnv(BatchedEnv):
     env_name = "rock"
     reward_dtype = torch.int32
 
-    def __init__(self, board_size=7, num_rocks=8, use_heuristic=False, **batch_kwargs):
+    def __init__(self, board_size=7, num_rocks=8, use_heuristic=False, track_belief=None, **batch_kwargs):
+        """`use_heuristic` as in the reference (rock.py:99, 294).  `track_belief` (default: use_heuristic) keeps the
+        per-rock side statistics the reference always keeps; off by default because they cost a second launch per
+        step and nothing but the heuristic reads them."""
         self.board_size = board_size
         self.num_rocks = num_rocks
         self.p_move = getattr(self, "p_move", None)
@@ -57,6 +94,50 @@ class RockEnv(BatchedEnv):
         self._reward_range = 20      # rock.py:116
         self._penalization = -100    # rock.py:117
         self._setup(**batch_kwargs)
+        if use_heuristic if track_belief is None else track_belief:
+            with torch.cuda.device(self.device):
+                self._tracker = _BeliefTracker(self)
+
+    @property
+    def belief(self):
+        """dict of the side-statistic tensors [K, N] (count, measured int32; lkv, lkw, prob_valuable float64), or
+        None when they are not tracked."""
+        return None if self._tracker is None else self._tracker.tensors
+
+    def _belief_ref(self):
+        if self._tracker is None:
+            raise RuntimeError("RockEnv: side statistics are not tracked (construct with use_heuristic=True or "
+                               "track_belief=True)")
+        return self._tracker.ref
+
+    def set_belief(self, belief):
+        """Overwrite the side statistics (what the reference's `_set_state(info["state"])` does through
+        `rock.__dict__.update(r)`, rock.py:200-203); set_state() alone leaves fresh Rock statistics."""
+        for f, _ in _BeliefTracker.FIELDS:
+            self._tracker.tensors[f].copy_(torch.as_tensor(belief[f], device=self.device).reshape(self.num_rocks, -1))
+
+    def _generate_preferred(self, history):
+        """rock.py:293-374.  Without use_heuristic: `_generate_legal()`."""
+        if not self._use_heuristic:
+            return self._generate_legal()
+        return super()._generate_preferred(history)
+
+    def select_target(self, state=None):
+        """`_select_target` (rock.py:389-399) per lane: index of the nearest uncollected rock whose count is >= 0
+        (straight-line distance, lowest index on ties), -1 if none -> int32[N]."""
+        st = self._state if state is None else torch.as_tensor(state, dtype=torch.int32, device=self.device)
+        st = st.reshape(self.state_words, -1).contiguous()
+        out = torch.empty(self.batch_size, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self._lib.pomdp_rock_select_target(self._params_ref, st.data_ptr(), self._belief_ref(), out.data_ptr(),
+                                                    self.batch_size, self._stream())
+            _native.check(rc, "pomdp_rock_select_target")
+        return out
+
+    def _select_target(self, rock_state=None, x_size=None):
+        """Reference signature (a staticmethod there, taking the state object and the board size)."""
+        t = self.select_target(rock_state)
+        return int(t.item()) if self.batch_size == 1 else t
 
     def _build_params(self):
         return make_params(self.board_size, self.num_rocks)

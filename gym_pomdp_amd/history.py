@@ -1,0 +1,82 @@
+"""History / Transition — the planner-side record `_generate_preferred(history)` reads
+(gym_pomdp/envs/rock.py:525-550; tag.py:233-239 reads `history.size`, `history[-1].action`, `history[-1].ob`).
+
+Batched, device-resident: instead of a list of records per lane the history keeps, per lane, exactly what the
+heuristics take from it — size, the last action and observation, and for RockSample the two per-rock sums of
+rock.py:303-310 / 327-334 (include/pomdp_hip.h: pomdp_history).  Unbounded histories only (`max_size=None`, the
+reference's default): a sliding window cannot be summarised by running sums.
+"""
+import ctypes as C
+from typing import NamedTuple
+
+import torch
+
+from . import _native
+
+
+class Transition(NamedTuple):
+    """rock.py:525-530, same field order.  Fields are int32[N] / uint8[N] tensors (python scalars when N == 1)."""
+    observation: object
+    action: object
+    reward: object
+    next_observation: object
+    done: object
+
+
+class History(object):
+    def __init__(self, env, max_size=None):
+        if max_size is not None:
+            raise NotImplementedError("History: only unbounded histories (max_size=None) are kept on the device")
+        self._env = env
+        n, dev = env.batch_size, env.device
+        self._kind = _native.ENV_KIND[env.env_name]
+        k = env.num_rocks if env.env_name == "rock" else 0
+        self._size = torch.zeros(n, dtype=torch.int32, device=dev)
+        self.last_action = torch.zeros(n, dtype=torch.int32, device=dev)
+        self.last_ob = torch.zeros(n, dtype=torch.int32, device=dev)
+        self.total_sample = torch.zeros((k, n), dtype=torch.int32, device=dev)
+        self.total_move = torch.zeros((k, n), dtype=torch.int32, device=dev)
+        self._ptrs = _native.HistoryPtrs(self._size.data_ptr(), self.last_action.data_ptr(), self.last_ob.data_ptr(),
+                                         self.total_sample.data_ptr() if k else None,
+                                         self.total_move.data_ptr() if k else None)
+        self._ref = C.byref(self._ptrs)
+        self.clear()
+
+    @property
+    def size(self):
+        """rock.py:546-548.  python int when batch_size == 1, else int32[N]."""
+        return int(self._size.item()) if self._env.batch_size == 1 else self._size
+
+    def _as(self, v, dtype):
+        if isinstance(v, torch.Tensor) and v.dtype == dtype and v.device == self._env.device and v.is_contiguous():
+            return v
+        if isinstance(v, torch.Tensor) and v.dtype == torch.bool and dtype == torch.uint8:
+            return v.to(self._env.device).contiguous().view(torch.uint8)
+        return torch.as_tensor(v, device=self._env.device).to(dtype).reshape(self._env.batch_size).contiguous()
+
+    def clear(self, where=None):
+        """Empty history for every lane, or for the lanes where `where` is set (a new History() per episode)."""
+        env = self._env
+        w = None if where is None else self._as(where, torch.uint8)
+        with torch.cuda.device(env.device):
+            rc = env._lib.pomdp_history_clear(self._kind, env._params_ref, self._ref,
+                                              None if w is None else w.data_ptr(), env.batch_size, env._stream())
+            _native.check(rc, "pomdp_history_clear")
+
+    def append(self, transition, auto_reset=None):
+        """rock.py:541-544.  With auto_reset (default: the env's setting) a lane whose transition is terminal starts
+        the next episode with an empty history, as a planner that builds a new History() per episode would."""
+        env = self._env
+        ar = env.auto_reset if auto_reset is None else bool(auto_reset)
+        obs = self._as(transition.observation, torch.int32)
+        act = self._as(transition.action, torch.int32)
+        nxt = self._as(transition.next_observation, torch.int32)
+        done = self._as(transition.done, torch.uint8)
+        with torch.cuda.device(env.device):
+            rc = env._lib.pomdp_history_append(self._kind, env._params_ref, self._ref, obs.data_ptr(), act.data_ptr(),
+                                               nxt.data_ptr(), done.data_ptr(), env.batch_size,
+                                               _native.POMDP_AUTO_RESET if ar else 0, env._stream())
+            _native.check(rc, "pomdp_history_append")
+
+    def __repr__(self):
+        return "size:%s" % (self.size,)

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define POMDP_ABI_VERSION 4
+#define POMDP_ABI_VERSION 5
 
 enum {
     POMDP_E_BADARG = -1,     /* NULL pointer, n < 0, n + lane0 > 2^32 */
@@ -208,6 +208,64 @@ int pomdp_rollout(int env, const void *params, const uint32_t *root_state, int64
                   int depth, double discount, int flags, uint64_t seed, uint32_t lane0, uint64_t t0,
                   double *ret, int32_t *n_steps, int32_t *first_action, int32_t *last_ob, uint8_t *terminated,
                   void *stream);
+
+/* ---- heuristic-policy support --------------------------- */
+/* RockSample's per-rock side statistics — the Rock fields count, measured, lkv, lkw, prob_valuable of rock.py:78-86,
+ * which RockEnv.step updates on every CHECK (rock.py:177-191) and `_generate_preferred` / `_select_target` read.
+ * Device pointers, struct of arrays [num_rocks][n] (rock j of lane i at [j * n + i]). */
+typedef struct pomdp_rock_belief {
+    int32_t *count;          /* +1 per GOOD reading, -1 per BAD                     rock.py:183,187 */
+    int32_t *measured;       /* number of CHECKs of this rock                       rock.py:178 */
+    double  *lkv, *lkw;      /* likelihood of the readings if valuable / worthless  rock.py:184-189 */
+    double  *prob_valuable;  /* .5 lkv / (.5 lkv + .5 lkw)                          rock.py:190-191 */
+} pomdp_rock_belief;
+
+/* fresh Rock objects (0, 0, 1., 1., .5) for every lane, or for the lanes with where[i] != 0 (device uint8, may be NULL) */
+int pomdp_rock_belief_reset(const pomdp_rock_params *p, const pomdp_rock_belief *b, const uint8_t *where, int64_t n,
+                            void *stream);
+/* The part of RockEnv.step that maintains the statistics (rock.py:177-191), run after pomdp_rock_step on its outputs:
+ * a lane whose action was CHECK j and whose ob != 0 updates rock j with eff(d) of the stored agent position (CHECK
+ * does not move); with POMDP_AUTO_RESET a done lane gets fresh statistics (its reset() built new Rock objects),
+ * without it done lanes are left alone. */
+int pomdp_rock_belief_update(const pomdp_rock_params *p, const uint32_t *state, const int32_t *action, const int32_t *ob,
+                             const uint8_t *done, const pomdp_rock_belief *b, int64_t n, int flags, void *stream);
+/* replaces RockEnv._select_target (rock.py:389-399): the nearest (straight-line; the reference's `manhattan_distance`
+ * is sqrt(dx^2+dy^2), coord.py:83-85) uncollected rock with count >= 0, lowest index on ties, -1 if none. */
+int pomdp_rock_select_target(const pomdp_rock_params *p, const uint32_t *state, const pomdp_rock_belief *b,
+                             int32_t *target, int64_t n, void *stream);
+
+/* What `_generate_preferred(history)` reads from the planner's History of Transition(observation, action, reward,
+ * next_observation, done) records (rock.py:525-550; tag.py:233-239 reads history.size, history[-1].action and
+ * history[-1].ob), kept per lane as running sums so the records themselves need not be stored (unbounded
+ * history, max_size=None).  Device pointers:
+ *   size, last_action, last_ob                                                                   int32 [n]
+ *   total_sample[j] = sum over CHECK-j transitions of (+1 if next_ob GOOD, -1 if next_ob BAD)     rock.py:303-310
+ *   total_move[j]   = sum over CHECK-j transitions of (+1 if next_ob GOOD, else -1 if the *previous*
+ *                     observation was BAD — the reference's elif reads transition.observation)    rock.py:327-334
+ * the two sums are int32 [num_rocks][n] for RockSample and unused (may be NULL) for the other envs. */
+typedef struct pomdp_history {
+    int32_t *size, *last_action, *last_ob;
+    int32_t *total_sample, *total_move;
+} pomdp_history;
+
+/* History() — empty history for every lane / the lanes with where[i] != 0 (last_action = last_ob = -1) */
+int pomdp_history_clear(int env, const void *params, const pomdp_history *h, const uint8_t *where, int64_t n,
+                        void *stream);
+/* history.append(Transition(observation, action, reward, next_observation, done)) per lane (rock.py:541-544).  With
+ * POMDP_AUTO_RESET a done transition ends the episode and the lane's history starts over, empty. */
+int pomdp_history_append(int env, const void *params, const pomdp_history *h, const int32_t *observation,
+                         const int32_t *action, const int32_t *next_observation, const uint8_t *done, int64_t n,
+                         int flags, void *stream);
+/* replaces <Env>._generate_preferred(history) (rock.py:293-374 with use_heuristic=True, tag.py:231-243;
+ * tiger.py:114-115, network.py:138-139 and BattleShip, which has none, give the legal list).  Output as
+ * pomdp_legal_actions: list int32 [n][stride] in the reference's order padded with -1, len int32 [n].
+ * b is read for RockSample only. */
+int pomdp_preferred_actions(int env, const void *params, const uint32_t *state, const pomdp_rock_belief *b,
+                            const pomdp_history *h, int32_t *list, int32_t *len, int64_t n, int stride, void *stream);
+/* the caller's `np.random.choice(list)` over per-lane lists (rock.py:564): action[i] = list[i][(w * len[i]) >> 32]
+ * with w the synthetic policy's word of (seed, lane0 + i, t) — the word pomdp_synthetic_actions uses; -1 if len[i] == 0 */
+int pomdp_pick_actions(const int32_t *list, const int32_t *len, int stride, int32_t *action, int64_t n, uint64_t seed,
+                       uint32_t lane0, uint64_t t, void *stream);
 
 int         pomdp_abi_version(void);
 const char *pomdp_error_string(int code);

@@ -589,3 +589,113 @@ def test_split_layout_ties():
             a[col] = int(g["actions"][i])
             ob, rew, done, _ = e.step(a)
             assert (int(ob[col]), int(rew[col]), int(done[col])) == (int(g["ob"][i]), int(g["reward"][i]), int(g["done"][i])), (lane, n)
+
+
+# ---- heuristic policy support -----------------------------------------------------------
+from conftest import OracleHeuristicOps, golden_manifest, heuristic_replay  # noqa: E402
+
+HEUR = [tuple(c) for c in golden_manifest().get("heuristic_cases", [])]
+
+
+class HipHeuristicOps(object):
+    """The ops heuristic_replay drives, on the HIP path through the Python mirror (History, preferred_actions,
+    select_target, pick_actions, step with tracked side statistics)."""
+
+    def __init__(self, env, kw):
+        self.env_name, self.kw = env, kw
+        self.is_rock = env in ("rock", "stochrock")
+
+    def reset(self, n, seed, lane0, t):
+        from gym_pomdp_amd import History
+        extra = dict(use_heuristic=True) if self.is_rock else {}
+        self.e = make_env(self.env_name, dict(self.kw, **extra), batch_size=n, seed=seed, lane_offset=lane0, auto_reset=True)
+        self.e.call_counter = t
+        ob = self.e.reset()
+        self.h = History(self.e)
+        return np_(ob)
+
+    def preferred(self):
+        l, n = self.e._generate_preferred(self.h)
+        return np_(l), np_(n)
+
+    def legal(self):
+        l, n = self.e.legal_actions()
+        return np_(l), np_(n)
+
+    def target(self):
+        return np_(self.e.select_target())
+
+    def pick(self, lists, lens, t):
+        assert self.e.call_counter == t
+        l = torch.as_tensor(np.ascontiguousarray(lists, np.int32), device="cuda")
+        n = torch.as_tensor(np.ascontiguousarray(lens, np.int32), device="cuda")
+        return np_(self.e.pick_actions(l, n))
+
+    def step(self, a, t):
+        assert self.e.call_counter == t
+        self._a = torch.as_tensor(a, device="cuda")
+        ob, rew, done, _ = self.e.step(self._a)
+        self._ob, self._done = ob, done
+        return np_(ob), np_(rew), np_(done).astype(np.uint8)
+
+    def reset_ob(self):
+        d = np_(self.e.decode_state())
+        return np.where((d[:, 1:-1] == d[:, :1]).any(axis=1), 29, d[:, 0]).astype(np.int32)
+
+    def track(self, prev_ob, a, ob, done):
+        from gym_pomdp_amd import Transition
+        self.h.append(Transition(torch.as_tensor(prev_ob, device="cuda"), self._a, None, self._ob, self._done))
+
+    def compact(self):
+        return np_(self.e.decode_state())
+
+    def belief(self):
+        return {k: np_(v) for k, v in self.e.belief.items()}
+
+
+@pytest.mark.parametrize("case,env,kw", HEUR, ids=[c[0] for c in HEUR])
+def test_heuristic_golden(case, env, kw):
+    """Side statistics (float64, bit for bit), _generate_preferred, _select_target and the picked actions of the HIP
+    path == the reference run with use_heuristic=True on injected Philox words."""
+    from oracle import oracle_lib as ol
+    heuristic_replay(case, env, ol.OracleEnv(env, **kw), HipHeuristicOps(env, kw))
+
+
+@pytest.mark.parametrize("env,kw,n,T", [("rock", {}, 16384, 96), ("rock", dict(board_size=15, num_rocks=15), 8192, 96),
+                                        ("stochrock", {}, 4096, 128), ("tag", {}, 8192, 128)],
+                         ids=["rock_7_8", "rock_15_15", "stochrock_7_8", "tag_1"])
+def test_heuristic_vs_oracle_at_scale(env, kw, n, T):
+    """A device-resident heuristic-policy loop (preferred -> pick -> step -> statistics -> history) against the oracle's
+    restatement, every lane following its own preferred list."""
+    from oracle import oracle_lib as ol
+    o = ol.OracleEnv(env, **kw)
+    seed, lane0 = 0xFEED5EED, (1 << 20) - 512
+    cpu, gpu = OracleHeuristicOps(ol, o), HipHeuristicOps(env, kw)
+    prev_c, prev_g = cpu.reset(n, seed, lane0, 0), gpu.reset(n, seed, lane0, 0)
+    assert np.array_equal(prev_c, prev_g)
+    is_rock = env in ("rock", "stochrock")
+    n_done = 0
+    for t in range(1, T + 1):
+        (lc, nc), (lg, ng) = cpu.preferred(), gpu.preferred()
+        assert np.array_equal(nc, ng), t
+        assert np.array_equal(lc[:, : lg.shape[1]], lg), t
+        if is_rock:
+            assert np.array_equal(cpu.target(), gpu.target()), t
+        ac, ag = cpu.pick(lc, nc, t), gpu.pick(lg, ng, t)
+        assert np.array_equal(ac, ag), t
+        oc, og = cpu.step(ac, t), gpu.step(ag, t)
+        for x, y in zip(oc, og):
+            assert np.array_equal(x, y.astype(x.dtype)), t
+        cpu.track(prev_c, ac, oc[0], oc[2])
+        gpu.track(prev_g, ag, og[0], og[2])
+        prev_c = prev_g = np.where(oc[2] != 0, 0 if is_rock else cpu.reset_ob(), oc[0]).astype(np.int32)
+        n_done += int(oc[2].sum())
+        assert np.array_equal(cpu.compact(), saturate_tag_compact(env, gpu.compact())), t
+        if is_rock:
+            bc, bg = cpu.belief(), gpu.belief()
+            for k in bc:
+                same = (bc[k] == bg[k]) | ((bc[k] != bc[k]) & (bg[k] != bg[k]))
+                assert same.all(), (t, k)
+        for k in ("size", "last_action", "last_ob", "total_sample", "total_move"):
+            assert np.array_equal(getattr(cpu.h, k), np_(getattr(gpu.h, "_size" if k == "size" else k))), (t, k)
+    assert n_done > 0

@@ -6,7 +6,8 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, golden_cases, golden_manifest, load_golden, saturate_tag_compact
+from conftest import (GOLDEN, OracleHeuristicOps, golden_cases, golden_manifest, heuristic_replay, load_golden,
+                      saturate_tag_compact)
 
 CASES = golden_cases()
 KEYS = ["ob", "reward", "done", "state_pre", "state", "reset_ob"]
@@ -255,96 +256,6 @@ def test_split_layout_ties_oracle(oracle_lib):
 
 # ---- heuristic policy support -------------------------------------------------------
 HEUR = [tuple(c) for c in golden_manifest().get("heuristic_cases", [])]
-
-
-def heuristic_replay(case, env, o, ops):
-    """Replay a heur_<case>.npz fixture through `ops` (the oracle here, the HIP path in test_gpu_parity.py) and compare
-    everything the reference recorded.  `ops` supplies: reset(n, seed, lane0, t) -> ob; preferred() -> (lists, lens);
-    legal() -> (lists, lens); target(); pick(lists, lens, t); step(actions, t) -> (ob, reward, done);
-    track(prev_ob, actions, ob, done); compact(); belief() -> dict of [K, n] arrays."""
-    g = np.load(os.path.join(GOLDEN, "heur_%s.npz" % case))
-    seed, t0, lanes = int(g["seed"]), int(g["t0"]), g["lanes"]
-    L, T = g["action"].shape
-    is_rock = env in ("rock", "stochrock")
-    starts = [0] + [i for i in range(1, L) if lanes[i] != lanes[i - 1] + 1] + [L]
-    for s, e in zip(starts[:-1], starts[1:]):
-        n, lane0 = e - s, int(lanes[s])
-        pol = (lanes[s:e] & 3)
-        prev_ob = ops.reset(n, seed, lane0, t0)
-        assert np.array_equal(ops.compact(), saturate_tag_compact(env, g["state0"][s:e]))
-        for i in range(T):
-            t = t0 + 1 + i
-            pl, pn = ops.preferred()
-            assert np.array_equal(pn, g["pref_len"][s:e, i]), (case, i)
-            assert np.array_equal(pl[:, :32], g["pref"][s:e, i]), (case, i)
-            if is_rock:
-                assert np.array_equal(ops.target(), g["target"][s:e, i]), (case, i)
-            ll, ln = ops.legal()
-            nA = o.n_actions
-            a_pref, a_legal = ops.pick(pl, pn, t), ops.pick(ll, ln, t)
-            a_all = ops.pick(np.tile(np.arange(nA, dtype=np.int32), (n, 1)), np.full(n, nA, np.int32), t)
-            a = np.where(pol < 2, a_pref, np.where(pol == 2, a_legal, a_all)).astype(np.int32)
-            assert np.array_equal(a, g["action"][s:e, i]), (case, i)
-            ob, rew, done = ops.step(a, t)
-            assert np.array_equal(ob, g["ob"][s:e, i]) and np.array_equal(done, g["done"][s:e, i]), (case, i)
-            assert np.array_equal(rew.astype(np.float64), g["reward"][s:e, i]), (case, i)
-            ops.track(prev_ob, a, ob, done)
-            prev_ob = np.where(done != 0, 0 if is_rock else ops.reset_ob(), ob).astype(np.int32)
-            assert np.array_equal(ops.compact(), saturate_tag_compact(env, g["state"][s:e, i])), (case, i)
-            if is_rock:
-                b = ops.belief()
-                for k in ("count", "measured"):
-                    assert np.array_equal(b[k].T, g[k][s:e, i]), (case, i, k)
-                for k in ("lkv", "lkw", "prob_valuable"):          # float64, bit for bit (NaN == NaN: 0/0 happens)
-                    assert np.array_equal(b[k].T.view(np.uint64), g[k][s:e, i].view(np.uint64)), (case, i, k)
-
-
-class OracleHeuristicOps(object):
-    def __init__(self, ol, o):
-        self.ol, self.o = ol, o
-
-    def reset(self, n, seed, lane0, t):
-        self.n, self.seed, self.lane0 = n, seed, lane0
-        self.st = self.o.new_state(n)
-        ob = self.o.batch_reset(self.st, seed, lane0, t)
-        self.is_rock = self.o.name in ("rock", "stochrock")
-        self.b = self.ol.Belief(self.o, n) if self.is_rock else None
-        self.h = self.ol.HistorySums(self.o, n)
-        return ob
-
-    def preferred(self):
-        return self.o.batch_preferred(self.st, self.h, self.b)
-
-    def legal(self):
-        return self.o.batch_legal(self.st)
-
-    def target(self):
-        return self.b.select_target(self.st)
-
-    def pick(self, lists, lens, t):
-        return self.ol.pick(lists, lens, self.seed, self.lane0, t)
-
-    def step(self, a, t):
-        self._pre = self.st.copy()
-        ob, rew, done, bad = self.o.batch_step(self.st, a, self.seed, self.lane0, t)
-        assert bad == 0
-        return ob, rew, done
-
-    def reset_ob(self):
-        """observation a Tag lane's reset() returned inside the last auto-resetting step"""
-        comp = self.o.batch_compact(self.st)
-        return np.where((comp[:, 1:-1] == comp[:, :1]).any(axis=1), 29, comp[:, 0]).astype(np.int32)
-
-    def track(self, prev_ob, a, ob, done):
-        if self.b is not None:
-            self.b.update(self.st, a, ob, done)
-        self.h.append(prev_ob, a, ob, done)
-
-    def compact(self):
-        return self.o.batch_compact(self.st)
-
-    def belief(self):
-        return {k: getattr(self.b, k) for k, _ in self.ol.Belief.FIELDS}
 
 
 @pytest.mark.parametrize("case,env,kw", HEUR, ids=[c[0] for c in HEUR])
