@@ -27,7 +27,7 @@ SYMBOLS = [
     "pomdp_network_reset", "pomdp_network_step", "pomdp_synthetic_actions", "pomdp_philox_blocks",
     "pomdp_rollout_synthetic", "pomdp_legal_actions", "pomdp_rollout", "pomdp_compute_prob",
     "pomdp_rock_belief_reset", "pomdp_rock_belief_update", "pomdp_rock_select_target", "pomdp_history_clear",
-    "pomdp_history_append", "pomdp_preferred_actions", "pomdp_pick_actions",
+    "pomdp_history_append", "pomdp_preferred_actions", "pomdp_pick_actions", "pomdp_heuristic_steps",
 ]
 
 
@@ -136,6 +136,8 @@ def lib():
     L.pomdp_preferred_actions.argtypes = [ci, vp, vp, vp, vp, vp, vp, i64, ci, vp]
     L.pomdp_pick_actions.restype = ci
     L.pomdp_pick_actions.argtypes = [vp, vp, ci, vp, i64, u64, u32, u64, vp]
+    L.pomdp_heuristic_steps.restype = ci
+    L.pomdp_heuristic_steps.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, u64, u32, u64, i64, ci, vp]
     L.pomdp_philox_blocks.restype = ci
     L.pomdp_philox_blocks.argtypes = [vp, vp, i64, vp]
     _lib = L

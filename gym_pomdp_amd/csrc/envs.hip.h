@@ -157,6 +157,7 @@ struct RockEnv {
         st.s = (S)s;
         return 0; // Obs.NULL
     }
+    static __device__ __forceinline__ int reset_ob(const Params &, const State &) { return 0; }   // what reset() returned
 
     // Wave-cooperative reset (one lane per thread launches).  A fresh episode needs NG = ceil(K/4) high blocks, only
     // ~1/8 of a wave's lanes reset in a given step while nearly every wave has at least one: done per lane, the whole
@@ -486,6 +487,7 @@ struct TagEnv {
         st.w = with_num_opp(w, p.num_opponents);
         return sample_ob(p, st.w, 0);
     }
+    static __device__ __forceinline__ int reset_ob(const Params &p, const State &st) { return sample_ob(p, st.w, 0); }
 
     // Called convergently by every lane of the wave; `fresh` marks the lanes that start a new episode.
     static __device__ __forceinline__ void reset_where(const Shared &sh, const Params &p, State &st, bool fresh,
@@ -610,6 +612,7 @@ struct BattleShipEnv {
 
     static __device__ __forceinline__ void stage(Shared &, const Params &, int) {}
     static __device__ __forceinline__ int n_actions(const Params &p) { return p.x_size * p.y_size; }
+    static __device__ __forceinline__ int reset_ob(const Params &, const State &) { return 0; }   // battleship.py:131-137
     static __device__ __forceinline__ void load(State &st, const uint32_t *state, int64_t n, uint32_t i)
     {
         uint32_t o[4] = {0, 0, 0, 0}, v[4] = {0, 0, 0, 0};
@@ -871,6 +874,7 @@ struct TigerEnv {
         st.w = stream_block(key, lane, POMDP_STREAM_RESET_SPACE, 0u).x & 1u; // randint(2): mask 1, never rejects
         return 2;
     }
+    static __device__ __forceinline__ int reset_ob(const Params &, const State &) { return 2; }
 
     // Called convergently by every lane of the wave; `fresh` marks the lanes that start a new episode.
     static __device__ __forceinline__ void reset_where(const Shared &sh, const Params &p, State &st, bool fresh,
@@ -943,6 +947,7 @@ struct NetworkEnv {
         st.w = p.n_machines >= 32 ? 0xFFFFFFFFu : ((1u << p.n_machines) - 1u);
         return 0;
     }
+    static __device__ __forceinline__ int reset_ob(const Params &, const State &) { return 0; }
 
     // Called convergently by every lane of the wave; `fresh` marks the lanes that start a new episode.
     static __device__ __forceinline__ void reset_where(const Shared &sh, const Params &p, State &st, bool fresh,

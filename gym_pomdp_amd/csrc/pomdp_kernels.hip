@@ -394,6 +394,98 @@ __global__ __launch_bounds__(BLOCK) void pick_actions_kernel(const int32_t *__re
     action[i] = c > 0 ? list[i * stride + (int64_t)__umulhi(word, (uint32_t)c)] : -1;
 }
 
+// RockSample envs maintain side statistics; the other envs have none
+template <class Env, class = void>
+struct BeliefOps {
+    static __device__ __forceinline__ void update(const typename Env::Shared &, const typename Env::Params &,
+                                                  const typename Env::State &, int, int, const pomdp_rock_belief &, int64_t,
+                                                  uint32_t) {}
+};
+template <int W, int ABLATE, bool STOCH>
+struct BeliefOps<RockEnv<W, ABLATE, STOCH>, void> {
+    using Env = RockEnv<W, ABLATE, STOCH>;
+    static __device__ __forceinline__ void update(const typename Env::Shared &sh, const typename Env::Params &p,
+                                                  const typename Env::State &st, int a, int o, const pomdp_rock_belief &b,
+                                                  int64_t n, uint32_t i) { Env::belief_update(sh, p, st, a, o, b, n, i); }
+};
+template <class Env>
+static __device__ __forceinline__ void heuristic_belief_update(const typename Env::Shared &sh, const typename Env::Params &p,
+                                                               const typename Env::State &st, int a, int o,
+                                                               const pomdp_rock_belief &b, int64_t n, uint32_t i)
+{
+    BeliefOps<Env>::update(sh, p, st, a, o, b, n, i);
+}
+
+// One heuristic-policy step in one launch: choice(_generate_preferred(history)) -> step -> side statistics ->
+// history.append, i.e. preferred_kernel + pick_actions_kernel + step_kernel + belief_update_kernel +
+// history_append_kernel on the same call counter, with the lists never leaving registers.
+template <class Env>
+__global__ __launch_bounds__(BLOCK) void heuristic_step_kernel(const typename Env::Params p, uint32_t *__restrict__ state,
+                                                               pomdp_rock_belief b, pomdp_history h, int K,
+                                                               int32_t *__restrict__ prev_ob, int32_t *__restrict__ action,
+                                                               int32_t *__restrict__ ob, typename Env::Reward *__restrict__ reward,
+                                                               uint8_t *__restrict__ done, int64_t n, RngKey key, uint32_t lane0,
+                                                               int flags)
+{
+    __shared__ typename Env::Shared sh;
+    Env::stage(sh, p, (int)threadIdx.x);
+    __syncthreads();
+    const bool auto_reset = flags & POMDP_AUTO_RESET;
+    const uint32_t idx = blockIdx.x * (uint32_t)BLOCK + threadIdx.x;
+    const bool in_range = (uint64_t)idx < (uint64_t)n;
+    const uint32_t i = in_range ? idx : (uint32_t)(n - 1);
+    const uint32_t lane = lane0 + i;
+    typename Env::State st;
+    Env::load(st, state, n, i);
+    const bool was_done = auto_reset ? false : (done[i] != 0);
+    // the policy: a = list[(w * len(list)) >> 32] over the preferred list (ascending mask order) or the legal list
+    const uint32_t e = lane & 3u;
+    const uint4 wq = stream_block(key, lane >> 2, POMDP_STREAM_ACTION, 0u);
+    const uint32_t word = e == 0 ? wq.x : e == 1 ? wq.y : e == 2 ? wq.z : wq.w;
+    uint32_t m = Env::preferred_mask(sh, p, st, b, h, n, i);
+    int a;
+    if (m) {
+        for (int k = (int)__umulhi(word, (uint32_t)__popc(m)); k > 0; --k) m &= m - 1u;
+        a = __ffs((int)m) - 1;
+    } else {
+        a = Env::legal_nth(sh, p, st, (int)__umulhi(word, (uint32_t)Env::legal_count(sh, p, st)));
+    }
+    const bool live = in_range && !was_done;
+    int o, d;
+    typename Env::Reward r;
+    Env::step(sh, p, st, a, key, lane, o, r, d);
+    if (!live) { o = 0; r = 0; d = was_done; }
+    const bool fresh = live && d && auto_reset;
+    Env::reset_where(sh, p, st, fresh, key, lane);                             // wave-cooperative: every lane calls it
+    if (!in_range) return;
+    action[i] = live ? a : -1;
+    ob[i] = o;
+    reward[i] = r;
+    done[i] = (uint8_t)d;
+    if (!live) return;
+    Env::store(st, state, n, i, fresh);
+    if (fresh) {                                                               // new episode: fresh Rock objects, empty History
+        for (int j = 0; j < K; ++j) {
+            const int64_t k = (int64_t)j * n + i;
+            b.count[k] = 0; b.measured[k] = 0; b.lkv[k] = 1.; b.lkw[k] = 1.; b.prob_valuable[k] = .5;
+            h.total_sample[k] = 0; h.total_move[k] = 0;
+        }
+        h.size[i] = 0; h.last_action[i] = -1; h.last_ob[i] = -1;
+        prev_ob[i] = Env::reset_ob(p, st);
+        return;
+    }
+    h.size[i] += 1; h.last_action[i] = a; h.last_ob[i] = o;                    // a terminal transition is recorded too
+    if (a >= 5 && a < 5 + K) {                                                 // K > 0: RockSample CHECK
+        const int64_t k = (int64_t)(a - 5) * n + i;
+        const int ds = (o == 2) - (o == 1);
+        const int dm = o == 2 ? 1 : (prev_ob[i] == 1 ? -1 : 0);
+        if (ds) h.total_sample[k] += ds;
+        if (dm) h.total_move[k] += dm;
+        if (o != 0 && !d) heuristic_belief_update<Env>(sh, p, st, a, o, b, n, i);
+    }
+    prev_ob[i] = o;
+}
+
 // Lane i simulates from root state column i / sims_per_root for up to `depth` steps: the state lives
 // in registers, the policy draw (stream ROLLOUT) and the env draws (stream STEP) come from the lane's
 // own Philox streams at t0 + k, the discounted return accumulates in IEEE double with separate
@@ -631,6 +723,22 @@ static int launch_preferred(const typename Env::Params &p, const uint32_t *state
     hipLaunchKernelGGL(preferred_kernel<Env>, dim3(blocks_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, p, state,
                        b ? *b : NO_BELIEF, *h, list, len, n, stride);
     return (int)hipGetLastError();
+}
+template <class Env>
+static int launch_heuristic_steps(const typename Env::Params &p, uint32_t *state, const pomdp_rock_belief *b,
+                                  const pomdp_history *h, int K, int32_t *prev_ob, int32_t *action, int32_t *ob, void *reward,
+                                  uint8_t *done, int64_t n, uint64_t seed, uint32_t lane0, uint64_t t0, int64_t k_steps,
+                                  int flags, void *stream)
+{
+    if (n == 0) return 0;
+    for (int64_t s = 0; s < k_steps; ++s) {
+        hipLaunchKernelGGL(heuristic_step_kernel<Env>, dim3(blocks_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, p, state,
+                           b ? *b : NO_BELIEF, *h, K, prev_ob, action, ob, (typename Env::Reward *)reward, done, n,
+                           make_key(seed, t0 + (uint64_t)s), lane0, flags);
+        const int rc = (int)hipGetLastError();
+        if (rc) return rc;
+    }
+    return 0;
 }
 } // namespace pomdp
 
@@ -1002,6 +1110,18 @@ int pomdp_pick_actions(const int32_t *list, const int32_t *len, int stride, int3
     hipLaunchKernelGGL(pick_actions_kernel, dim3(blocks_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, list, len, stride,
                        action, n, make_key(seed, t), lane0);
     return (int)hipGetLastError();
+}
+
+int pomdp_heuristic_steps(int env, const void *params, uint32_t *state, const pomdp_rock_belief *b, const pomdp_history *h,
+                          int32_t *prev_ob, int32_t *action, int32_t *ob, void *reward, uint8_t *done, int64_t n,
+                          uint64_t seed, uint32_t lane0, uint64_t t0, int64_t k_steps, int flags, void *stream)
+{
+    const int K = history_rocks(env, params);
+    if (K < 0 || !params || !state || !prev_ob || !action || !ob || !reward || !done || k_steps < 0 || bad_range(n, lane0))
+        return POMDP_E_BADARG;
+    if (!history_ok(h, K > 0) || (K > 0 && !belief_ok(b))) return POMDP_E_BADARG;
+    POMDP_DISPATCH(env, params, return launch_heuristic_steps<E>(*p, state, b, h, K, prev_ob, action, ob, reward, done, n, seed,
+                                                                 lane0, t0, k_steps, flags, stream))
 }
 
 int pomdp_philox_blocks(const uint32_t *ctr_key, uint32_t *out, int64_t n_blocks, void *stream)

@@ -87,6 +87,7 @@ class BatchedEnv(object):
             self._host_out = torch.zeros(4, dtype=torch.int32).pin_memory()
             self._host_reward = self._host_out[1:2].view(self.reward_dtype)
         self._has_reset = False
+        self._last_reset = None
         self._scalar_done = False
         self._tracker = None          # per-step side effects beyond (state, ob, reward, done): RockSample's side statistics
         self._done_bool = self._done.view(torch.bool)
@@ -127,6 +128,7 @@ class BatchedEnv(object):
                 self._tracker.on_reset()
         self._has_reset = True
         self._scalar_done = False
+        self._last_reset = (ob, t)      # History() picks the current observation up from here
         self.done = False if self.batch_size == 1 else self._done.view(torch.bool)
         if self.batch_size == 1:
             return int(ob.item())
@@ -341,6 +343,30 @@ class BatchedEnv(object):
                                               self._t, self._stream())
             _native.check(rc, "pomdp_pick_actions")
         return out
+
+    def heuristic_steps(self, history, steps=1):
+        """`steps` consecutive steps under the env's own heuristic policy, one launch each
+        (pomdp_heuristic_steps): a = choice(_generate_preferred(history)); step(a); side statistics;
+        history.append(Transition(observation, a, reward, ob, done)) — the loop of rock.py:557-573 for every lane,
+        with the results of that call sequence.  Returns the last step's (action, ob, reward, done) in reusable
+        buffers; `history.prev_ob` holds the observation each lane sees afterwards.  Asynchronous."""
+        if not self._has_reset:
+            raise AttributeError("%s: heuristic_steps before reset()" % type(self).__name__)
+        if history.prev_ob is None:
+            raise ValueError("History was built without the current observation: History(env, observation=ob)")
+        if getattr(self, "_action_scratch", None) is None:
+            self._action_scratch = torch.empty(self.batch_size, dtype=torch.int32, device=self.device)
+        t0 = self._t
+        self._t += int(steps)
+        with torch.cuda.device(self.device):
+            rc = self._lib.pomdp_heuristic_steps(
+                _native.ENV_KIND[self.env_name], self._params_ref, self._state.data_ptr(),
+                self._belief_ref() if self.env_name == "rock" else None, history._ref, history.prev_ob.data_ptr(),
+                self._action_scratch.data_ptr(), self._ob.data_ptr(), self._reward.data_ptr(), self._done.data_ptr(),
+                self.batch_size, self._seed, self.lane_offset, t0, int(steps),
+                _native.POMDP_AUTO_RESET if self.auto_reset else 0, self._stream())
+            _native.check(rc, "pomdp_heuristic_steps")
+        return self._action_scratch, self._ob, self._reward, self._done.view(torch.bool)
 
     def compute_prob(self, action, ob, state=None):
         """`_compute_prob(action, next_state, ob)` per lane -> float64[N]: the likelihood of `ob` given that

@@ -24,11 +24,17 @@ class Transition(NamedTuple):
 
 
 class History(object):
-    def __init__(self, env, max_size=None):
+    def __init__(self, env, max_size=None, observation=None):
+        """`observation`: what the agent currently sees (int32[N]); only env.heuristic_steps() needs it, as the
+        `observation` field of the next transition.  Defaults to what env.reset() just returned."""
         if max_size is not None:
             raise NotImplementedError("History: only unbounded histories (max_size=None) are kept on the device")
         self._env = env
         n, dev = env.batch_size, env.device
+        if observation is None and getattr(env, "_last_reset", None) is not None and env._last_reset[1] + 1 == env.call_counter:
+            observation = env._last_reset[0]
+        self.prev_ob = None if observation is None else \
+            torch.as_tensor(observation, device=dev).to(torch.int32).reshape(n).clone()
         self._kind = _native.ENV_KIND[env.env_name]
         k = env.num_rocks if env.env_name == "rock" else 0
         self._size = torch.zeros(n, dtype=torch.int32, device=dev)

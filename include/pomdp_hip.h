@@ -267,6 +267,19 @@ int pomdp_preferred_actions(int env, const void *params, const uint32_t *state, 
 int pomdp_pick_actions(const int32_t *list, const int32_t *len, int stride, int32_t *action, int64_t n, uint64_t seed,
                        uint32_t lane0, uint64_t t, void *stream);
 
+/* k_steps consecutive heuristic-policy steps, one launch each: per lane, at call counter t = t0 + s,
+ *     a = choice(_generate_preferred(history))      == pomdp_preferred_actions + pomdp_pick_actions(seed, t)
+ *     (ob, reward, done) = step(a)                   == pomdp_<env>_step(seed, t)
+ *     side statistics, history.append(Transition(prev_ob, a, reward, ob, done))
+ *                                                    == pomdp_rock_belief_update + pomdp_history_append
+ *     prev_ob <- ob, or what reset() returned on a lane that auto-reset
+ * with exactly the results of that five-launch sequence (the rollout loop of rock.py:557-573 for a batch).
+ * prev_ob (device int32[n], in/out) starts as the observation reset() returned; action receives the chosen actions
+ * (-1 on frozen lanes).  b is read for RockSample only.  The caller's call counter advances by k_steps. */
+int pomdp_heuristic_steps(int env, const void *params, uint32_t *state, const pomdp_rock_belief *b, const pomdp_history *h,
+                          int32_t *prev_ob, int32_t *action, int32_t *ob, void *reward, uint8_t *done, int64_t n,
+                          uint64_t seed, uint32_t lane0, uint64_t t0, int64_t k_steps, int flags, void *stream);
+
 int         pomdp_abi_version(void);
 const char *pomdp_error_string(int code);
 

@@ -699,3 +699,55 @@ def test_heuristic_vs_oracle_at_scale(env, kw, n, T):
         for k in ("size", "last_action", "last_ob", "total_sample", "total_move"):
             assert np.array_equal(getattr(cpu.h, k), np_(getattr(gpu.h, "_size" if k == "size" else k))), (t, k)
     assert n_done > 0
+
+
+@pytest.mark.parametrize("env,kw,n,T,auto", [("rock", {}, 8192, 64, True), ("rock", dict(board_size=15, num_rocks=15), 4096, 64, True),
+                                             ("stochrock", {}, 4096, 96, True), ("tag", {}, 8192, 96, True),
+                                             ("tag", dict(num_opponents=2), 4096, 96, False), ("rock", {}, 4096, 48, False),
+                                             ("tiger", {}, 4096, 24, True), ("battleship", {}, 4096, 40, True),
+                                             ("network", {}, 4096, 16, True)],
+                         ids=["rock_7_8", "rock_15_15", "stochrock_7_8", "tag_1", "tag_2_noreset", "rock_7_8_noreset", "tiger",
+                              "battleship_5_5", "network_10"])
+def test_fused_heuristic_steps_match_the_call_sequence(env, kw, n, T, auto):
+    """pomdp_heuristic_steps (one launch per step) == preferred_actions -> pick_actions -> step (+ side statistics) ->
+    History.append issued separately, on every output, the state, the statistics and the history sums."""
+    from gym_pomdp_amd import History, Transition
+    is_rock = env in ("rock", "stochrock")
+    extra = dict(use_heuristic=True) if is_rock else {}
+    mk = lambda: make_env(env, dict(kw, **extra), batch_size=n, seed=77, lane_offset=4096, auto_reset=auto)  # noqa: E731
+    ea, eb = mk(), mk()
+    oa, ob_ = ea.reset(), eb.reset()
+    ha, hb = History(ea), History(eb)
+    prev = oa.clone()
+    for t in range(T):
+        lst, ln = ea.preferred_actions(ha) if (is_rock or env == "tag") else ea.legal_actions()
+        a = ea.pick_actions(lst, ln)
+        if not auto:                              # frozen lanes: the fused path reports action -1 and leaves them alone
+            frozen = ea._done.bool().clone()
+        o, r, d, _ = ea.step(a)
+        ha.append(Transition(prev, a, r, o, d))
+        if env == "tag":
+            dec = ea.decode_state()
+            reset_ob = torch.where((dec[:, 1:-1] == dec[:, :1]).any(dim=1), torch.full_like(dec[:, 0], 29), dec[:, 0]).to(torch.int32)
+        else:
+            reset_ob = torch.full_like(o, 2 if env == "tiger" else 0)
+        prev = torch.where(d & auto, reset_ob, o)
+        fa, fo, fr, fd = eb.heuristic_steps(hb, 1)
+        if auto:
+            assert torch.equal(fa, a), t
+        else:
+            assert torch.equal(fa[~frozen], a[~frozen]) and bool((fa[frozen] == -1).all()), t
+        assert torch.equal(fo, o) and torch.equal(fr, r) and torch.equal(fd, d), t
+        assert torch.equal(ea.state, eb.state), t
+        if not auto:
+            live = ~frozen
+            assert torch.equal(hb._size[live], ha._size[live]), t
+            continue
+        assert torch.equal(hb.prev_ob, prev), t
+        for k in ("_size", "last_action", "last_ob", "total_sample", "total_move"):
+            assert torch.equal(getattr(ha, k), getattr(hb, k)), (t, k)
+        if is_rock:
+            for k in ea.belief:
+                x, y = ea.belief[k], eb.belief[k]
+                assert bool(((x == y) | (x.isnan() & y.isnan() if x.is_floating_point() else False)).all()), (t, k)
+    assert int(ea._done.sum()) >= 0
