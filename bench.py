@@ -57,9 +57,11 @@ def parse():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--host-loop", default="c", choices=["c", "python"],
                     help="who issues the two launches of a step: the C rollout driver or a python loop over env.step()")
-    ap.add_argument("--mode", default="step", choices=["step", "rollout"],
+    ap.add_argument("--mode", default="step", choices=["step", "rollout", "heuristic"],
                     help="step: the headline metric.  rollout: BASELINE.json configs[4] shape — every launch runs "
-                         "sims-per-root random rollouts of --depth steps from each root (fused kernel, state in registers)")
+                         "sims-per-root random rollouts of --depth steps from each root (fused kernel, state in registers).  "
+                         "heuristic: every lane follows the env's own _generate_preferred(history) policy "
+                         "(use_heuristic=True; rock / rock15 / tag), one fused launch per step")
     ap.add_argument("--depth", type=int, default=64)
     ap.add_argument("--sims-per-root", type=int, default=1024)
     ap.add_argument("--action-seed", type=int, default=None, help="policy key (default: the env seed)")
@@ -143,6 +145,53 @@ def rollout_mode(args, env, cp, dev, rank, world, label):
     cp.close()
 
 
+def heuristic_mode(args, gpa, env_id, kwargs, cp, dev, rank, world, label, n, lane_offset):
+    """Every lane runs the reference's heuristic rollout loop (rock.py:557-573): choice(_generate_preferred(history)),
+    step, side statistics, history.append — one pomdp_heuristic_steps launch per step."""
+    is_rock = env_id == "Rock-v0"
+    env = gpa.make(env_id, batch_size=n, device=dev, seed=args.seed, lane_offset=lane_offset, reuse_buffers=True,
+                   **dict(kwargs, **(dict(use_heuristic=True) if is_rock else {})))
+    env.reset()
+    hist = gpa.History(env)
+
+    def run(k):
+        while k > 0:
+            c = min(k, 100)
+            env.heuristic_steps(hist, c)
+            k -= c
+
+    run(args.warmup)
+    torch.cuda.synchronize(dev)
+    cp.barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    run(args.steps)
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    elapsed = cp.max(time.perf_counter() - t0)
+    cp.barrier()
+    kern_ms = ev0.elapsed_time(ev1) / args.steps
+    # algorithmic bytes per lane-step (DESIGN.md §9): what one launch must read and write per lane
+    K = env.num_rocks if is_rock else 0
+    alg = (4 + 4 + 4 + K * (4 + 4 + 4 + 8)) + (4 + 4 + 4 + 4 + 1 + 4 + 4 + 4 + 4) + (0 if is_rock else 8)
+    achieved = alg * n / (kern_ms * 1e-3) / 1e9
+    if rank == 0:
+        print(json.dumps({
+            "metric": "env steps/sec (whole node), heuristic policy", "value": n * world * args.steps / elapsed,
+            "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
+            "vs_baseline": None, "dtype": "int32 (+ f64 side statistics)", "data": "synthetic",
+            "config": {"workload": "%s batch=%d lanes per GPU, every lane follows _generate_preferred(history) "
+                                   "(use_heuristic=True), auto-reset, one fused launch per step" % (label, n),
+                       "lanes_per_gpu": n, "mean_history_size": float(hist._size.float().mean().item()),
+                       "parallelism": "lane-shard x%d, no collectives" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "heuristic_step_kernel",
+                         "kernel_ms": kern_ms, "algorithmic_bytes_per_step": alg}}), flush=True)
+    cp.close()
+
+
 def measured_traffic(env_key, chained=False):
     """HBM bytes per step-kernel launch from the committed PMC passes (profiles/traffic_*.json, produced by
     tools/gpu_profile.sh: separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this command)."""
@@ -185,6 +234,8 @@ def main():
         n = args.lanes_per_gpu
         lane_offset, count = sharding.shard_range(n * world, rank, world)        # n lanes on every GPU
         assert count == n
+    if args.mode == "heuristic":
+        return heuristic_mode(args, gpa, env_id, kwargs, cp, dev, rank, world, label, n, lane_offset)
     env = gpa.make(env_id, batch_size=n, device=dev, seed=args.seed, lane_offset=lane_offset, reuse_buffers=True,
                    **kwargs)
     if args.mode == "rollout":

@@ -26,7 +26,7 @@ SYMBOLS = [
     "pomdp_battleship_reset", "pomdp_battleship_step", "pomdp_tiger_reset", "pomdp_tiger_step",
     "pomdp_network_reset", "pomdp_network_step", "pomdp_synthetic_actions", "pomdp_philox_blocks",
     "pomdp_rollout_synthetic", "pomdp_legal_actions", "pomdp_rollout", "pomdp_compute_prob",
-    "pomdp_rock_belief_reset", "pomdp_rock_belief_update", "pomdp_rock_select_target", "pomdp_history_clear",
+    "pomdp_rock_belief_reset", "pomdp_rock_belief_refresh", "pomdp_rock_belief_update", "pomdp_rock_select_target", "pomdp_history_clear",
     "pomdp_history_append", "pomdp_preferred_actions", "pomdp_pick_actions", "pomdp_heuristic_steps",
 ]
 
@@ -57,11 +57,11 @@ class NetworkParams(C.Structure):
 
 
 class RockBelief(C.Structure):      # pomdp_rock_belief: device pointers, [num_rocks][n]
-    _fields_ = [(k, C.c_void_p) for k in ("count", "measured", "lkv", "lkw", "prob_valuable")]
+    _fields_ = [(k, C.c_void_p) for k in ("count", "measured", "lkv", "lkw", "prob_valuable", "check_ok")]
 
 
 class HistoryPtrs(C.Structure):     # pomdp_history: device pointers
-    _fields_ = [(k, C.c_void_p) for k in ("size", "last_action", "last_ob", "total_sample", "total_move")]
+    _fields_ = [(k, C.c_void_p) for k in ("size", "last_action", "last_ob", "total_sample", "total_move", "move_ok")]
 
 
 def hipcc_path():
@@ -124,6 +124,8 @@ def lib():
     L.pomdp_rollout.argtypes = [ci, vp, vp, i64, i64, ci, C.c_double, ci, u64, u32, u64, vp, vp, vp, vp, vp, vp]
     L.pomdp_rock_belief_reset.restype = ci
     L.pomdp_rock_belief_reset.argtypes = [vp, vp, vp, i64, vp]
+    L.pomdp_rock_belief_refresh.restype = ci
+    L.pomdp_rock_belief_refresh.argtypes = [vp, vp, i64, vp]
     L.pomdp_rock_belief_update.restype = ci
     L.pomdp_rock_belief_update.argtypes = [vp, vp, vp, vp, vp, vp, i64, ci, vp]
     L.pomdp_rock_select_target.restype = ci

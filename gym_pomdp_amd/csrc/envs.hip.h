@@ -273,8 +273,13 @@ struct RockEnv {
     }
 
     // ---- heuristic-policy support ------------------------------------------------------
+    // the "worth another CHECK" test of rock.py:371 on one rock's statistics
+    static __device__ __forceinline__ bool check_ok(int measured, int count, double pv)
+    {
+        return measured < 5 && abs(count) < 2 && 0 < pv && pv < 1;
+    }
     // rock.py:177-191: side statistics of the rock a CHECK just measured (CHECK does not move the agent, so the
-    // stored position is the one the reading was taken from)
+    // stored position is the one the reading was taken from); keeps the rock's bit of b.check_ok current
     static __device__ __forceinline__ void belief_update(const Shared &sh, const Params &p, const State &st, int a, int ob,
                                                          const pomdp_rock_belief &b, int64_t n, uint32_t i)
     {
@@ -284,46 +289,52 @@ struct RockEnv {
         const double eff = p.eff[abs(x - (int)(rxy & 15u)) + abs(y - (int)(rxy >> 4))];
         const int64_t k = (int64_t)r * n + i;
         double lkv = b.lkv[k], lkw = b.lkw[k];
-        b.measured[k] += 1;
-        if (ob == 2) { b.count[k] += 1; lkv *= eff; lkw *= (1 - eff); }
-        else         { b.count[k] -= 1; lkw *= eff; lkv *= (1 - eff); }
+        const int measured = b.measured[k] + 1;
+        int count = b.count[k];
+        if (ob == 2) { count += 1; lkv *= eff; lkw *= (1 - eff); }
+        else         { count -= 1; lkw *= eff; lkv *= (1 - eff); }
+        const double denom = (.5 * lkv) + (.5 * lkw);
+        const double pv = (.5 * lkv) / denom;
+        b.measured[k] = measured;
+        b.count[k] = count;
         b.lkv[k] = lkv;
         b.lkw[k] = lkw;
-        const double denom = (.5 * lkv) + (.5 * lkw);
-        b.prob_valuable[k] = (.5 * lkv) / denom;
+        b.prob_valuable[k] = pv;
+        const uint32_t bit = 1u << r, m = b.check_ok[i];
+        b.check_ok[i] = check_ok(measured, count, pv) ? (m | bit) : (m & ~bit);
     }
 
     // rock.py:293-374 _generate_preferred with use_heuristic=True, as a bitmask over actions: every list the
     // heuristic builds is in ascending action order ([SAMPLE], [EAST], or N/E/S/W then the CHECKs by rock index);
-    // 0 = the heuristic produced nothing and the caller falls back to _generate_legal() (rock.py:374-375)
+    // 0 = the heuristic produced nothing and the caller falls back to _generate_legal() (rock.py:374-375).
+    // Per-rock tests come from the two derived words b.check_ok / h.move_ok: 16 bytes per lane, whatever K is.
     static __device__ __forceinline__ uint32_t preferred_mask(const Shared &sh, const Params &p, const State &st,
                                                               const pomdp_rock_belief &b, const pomdp_history &h,
                                                               int64_t n, uint32_t i)
     {
         const S s = st.s;
         const int x = (int)(s & 15u), y = (int)((s >> 4) & 15u), K = p.num_rocks;
+        const uint32_t ck = b.check_ok[i], mv = h.move_ok[i];
+        const int hsize = h.size[i];
         const int id = sh.grid[x * 16 + y];
-        if (id >= 0 && id < K && ((uint32_t)(s >> (8 + 2 * (id & 15))) & 3u) != 1u && h.size[i] != 0)
+        if (id >= 0 && id < K && ((uint32_t)(s >> (8 + 2 * (id & 15))) & 3u) != 1u && hsize != 0)
             if (h.total_sample[(int64_t)id * n + i] > 0) return 1u << 4;                          // rock.py:300-313
-        bool all_bad = true, north = false, south = false, west = false, east = false;
-        uint32_t checks = 0;
-        for (int j = 0; j < K; ++j) {
-            if (((uint32_t)(s >> (8 + 2 * j)) & 3u) == 1u) continue;                              // collected
-            const int64_t k = (int64_t)j * n + i;
-            if (h.total_move[k] >= 0) {                                                           // rock.py:335-345
-                all_bad = false;
-                const uint32_t rxy = sh.rxy[j];
-                const int rx = (int)(rxy & 15u), ry = (int)(rxy >> 4);
-                if (ry > y) north = true;
-                else if (ry < y) south = true;
-                else if (rx < x) west = true;
-                else if (rx > x) east = true;
-            }
-            const double pv = b.prob_valuable[k];
-            if (b.measured[k] < 5 && abs(b.count[k]) < 2 && 0 < pv && pv < 1) checks |= 1u << (5 + j);   // rock.py:370-372
+        uint32_t alive = 0;                                                                       // uncollected rocks
+        for (int j = 0; j < K; ++j) alive |= (uint32_t)(((uint32_t)(s >> (8 + 2 * j)) & 3u) != 1u) << j;
+        uint32_t am = alive & mv;                                                                 // rock.py:335: total >= 0
+        if (!am) return 1u << 1;                                                                  // all_bad: rock.py:347-349
+        bool north = false, south = false, west = false, east = false;
+        while (am) {                                                                              // rock.py:338-345
+            const int j = __ffs((int)am) - 1;
+            am &= am - 1u;
+            const uint32_t rxy = sh.rxy[j];
+            const int rx = (int)(rxy & 15u), ry = (int)(rxy >> 4);
+            if (ry > y) north = true;
+            else if (ry < y) south = true;
+            else if (rx < x) west = true;
+            else if (rx > x) east = true;
         }
-        if (all_bad) return 1u << 1;                                                              // rock.py:347-349
-        uint32_t m = checks;
+        uint32_t m = (alive & ck) << 5;                                                           // rock.py:370-372
         if (y + 1 < p.size && north) m |= 1u << 0;                                                // rock.py:358-368
         if (east) m |= 1u << 1;
         if (y - 1 >= 0 && south) m |= 1u << 2;

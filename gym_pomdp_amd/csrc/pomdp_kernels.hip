@@ -278,6 +278,19 @@ __global__ __launch_bounds__(BLOCK) void belief_reset_kernel(pomdp_rock_belief b
         const int64_t k = (int64_t)j * n + i;
         b.count[k] = 0; b.measured[k] = 0; b.lkv[k] = 1.; b.lkw[k] = 1.; b.prob_valuable[k] = .5;
     }
+    b.check_ok[i] = (1u << K) - 1u;                                            // a fresh rock passes the test of rock.py:371
+}
+
+__global__ __launch_bounds__(BLOCK) void belief_refresh_kernel(pomdp_rock_belief b, int K, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    uint32_t m = 0;
+    for (int j = 0; j < K; ++j) {
+        const int64_t k = (int64_t)j * n + i;
+        m |= (uint32_t)RockEnv<1>::check_ok(b.measured[k], b.count[k], b.prob_valuable[k]) << j;
+    }
+    b.check_ok[i] = m;
 }
 
 template <class Env>
@@ -292,11 +305,13 @@ __global__ __launch_bounds__(BLOCK) void belief_update_kernel(const typename Env
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     if (done[i]) {
-        if (auto_reset)
+        if (auto_reset) {
             for (int j = 0; j < p.num_rocks; ++j) {
                 const int64_t k = (int64_t)j * n + i;
                 b.count[k] = 0; b.measured[k] = 0; b.lkv[k] = 1.; b.lkw[k] = 1.; b.prob_valuable[k] = .5;
             }
+            b.check_ok[i] = (1u << p.num_rocks) - 1u;
+        }
         return;
     }
     const int a = action[i], o = ob[i];
@@ -320,12 +335,29 @@ __global__ __launch_bounds__(BLOCK) void select_target_kernel(const typename Env
     target[i] = Env::select_target(sh, p, st, b, n, (uint32_t)i);
 }
 
+// the two sums over CHECK-j transitions (rock.py:303-310, 327-334) and the derived bit j of move_ok
+static __device__ __forceinline__ void history_check_sums(const pomdp_history &h, int j, int next_ob, int prev_ob, int64_t n,
+                                                          uint32_t i)
+{
+    const int64_t k = (int64_t)j * n + i;
+    const int ds = (next_ob == 2) - (next_ob == 1);
+    const int dm = next_ob == 2 ? 1 : (prev_ob == 1 ? -1 : 0);
+    if (ds) h.total_sample[k] += ds;
+    if (dm) {
+        const int tm = h.total_move[k] + dm;
+        h.total_move[k] = tm;
+        const uint32_t bit = 1u << j, m = h.move_ok[i];
+        h.move_ok[i] = tm >= 0 ? (m | bit) : (m & ~bit);
+    }
+}
+
 __global__ __launch_bounds__(BLOCK) void history_clear_kernel(pomdp_history h, int K, const uint8_t *__restrict__ where, int64_t n)
 {
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n || (where && !where[i])) return;
     h.size[i] = 0; h.last_action[i] = -1; h.last_ob[i] = -1;
     for (int j = 0; j < K; ++j) { h.total_sample[(int64_t)j * n + i] = 0; h.total_move[(int64_t)j * n + i] = 0; }
+    if (K) h.move_ok[i] = (1u << K) - 1u;
 }
 
 // rock.py:541-544 History.append + the sums _generate_preferred takes over the records (rock.py:303-310, 327-334)
@@ -339,17 +371,12 @@ __global__ __launch_bounds__(BLOCK) void history_append_kernel(pomdp_history h, 
     if (done[i] && auto_reset) {                                               // next episode: a new, empty History
         h.size[i] = 0; h.last_action[i] = -1; h.last_ob[i] = -1;
         for (int j = 0; j < K; ++j) { h.total_sample[(int64_t)j * n + i] = 0; h.total_move[(int64_t)j * n + i] = 0; }
+        if (K) h.move_ok[i] = (1u << K) - 1u;
         return;
     }
     const int a = action[i], o = next_observation[i];
     h.size[i] += 1; h.last_action[i] = a; h.last_ob[i] = o;
-    if (a >= 5 && a < 5 + K) {
-        const int64_t k = (int64_t)(a - 5) * n + i;
-        const int ds = (o == 2) - (o == 1);
-        const int dm = o == 2 ? 1 : (observation[i] == 1 ? -1 : 0);
-        if (ds) h.total_sample[k] += ds;
-        if (dm) h.total_move[k] += dm;
-    }
+    if (a >= 5 && a < 5 + K) history_check_sums(h, a - 5, o, observation[i], n, (uint32_t)i);
 }
 
 template <class Env>
@@ -470,17 +497,14 @@ __global__ __launch_bounds__(BLOCK) void heuristic_step_kernel(const typename En
             b.count[k] = 0; b.measured[k] = 0; b.lkv[k] = 1.; b.lkw[k] = 1.; b.prob_valuable[k] = .5;
             h.total_sample[k] = 0; h.total_move[k] = 0;
         }
+        if (K) { b.check_ok[i] = (1u << K) - 1u; h.move_ok[i] = (1u << K) - 1u; }
         h.size[i] = 0; h.last_action[i] = -1; h.last_ob[i] = -1;
         prev_ob[i] = Env::reset_ob(p, st);
         return;
     }
     h.size[i] += 1; h.last_action[i] = a; h.last_ob[i] = o;                    // a terminal transition is recorded too
     if (a >= 5 && a < 5 + K) {                                                 // K > 0: RockSample CHECK
-        const int64_t k = (int64_t)(a - 5) * n + i;
-        const int ds = (o == 2) - (o == 1);
-        const int dm = o == 2 ? 1 : (prev_ob[i] == 1 ? -1 : 0);
-        if (ds) h.total_sample[k] += ds;
-        if (dm) h.total_move[k] += dm;
+        history_check_sums(h, a - 5, o, prev_ob[i], n, i);
         if (o != 0 && !d) heuristic_belief_update<Env>(sh, p, st, a, o, b, n, i);
     }
     prev_ob[i] = o;
@@ -690,12 +714,15 @@ static int launch_rollout(const typename Env::Params &p, const uint32_t *state, 
                        n_steps, first_action, last_ob, terminated);
     return (int)hipGetLastError();
 }
-static bool belief_ok(const pomdp_rock_belief *b) { return b && b->count && b->measured && b->lkv && b->lkw && b->prob_valuable; }
+static bool belief_ok(const pomdp_rock_belief *b)
+{
+    return b && b->count && b->measured && b->lkv && b->lkw && b->prob_valuable && b->check_ok;
+}
 static bool history_ok(const pomdp_history *h, bool rock)
 {
-    return h && h->size && h->last_action && h->last_ob && (!rock || (h->total_sample && h->total_move));
+    return h && h->size && h->last_action && h->last_ob && (!rock || (h->total_sample && h->total_move && h->move_ok));
 }
-static const pomdp_rock_belief NO_BELIEF = {nullptr, nullptr, nullptr, nullptr, nullptr};
+static const pomdp_rock_belief NO_BELIEF = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 
 template <class Env>
 static int launch_belief_update(const typename Env::Params &p, const uint32_t *state, const int32_t *action, const int32_t *ob,
@@ -1044,6 +1071,15 @@ int pomdp_rock_belief_reset(const pomdp_rock_params *p, const pomdp_rock_belief 
     if (!rock_ok(p)) return POMDP_E_BADPARAMS;
     if (n == 0) return 0;
     hipLaunchKernelGGL(belief_reset_kernel, dim3(blocks_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, *b, p->num_rocks, where, n);
+    return (int)hipGetLastError();
+}
+
+int pomdp_rock_belief_refresh(const pomdp_rock_params *p, const pomdp_rock_belief *b, int64_t n, void *stream)
+{
+    if (!p || !belief_ok(b) || n < 0) return POMDP_E_BADARG;
+    if (!rock_ok(p)) return POMDP_E_BADPARAMS;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(belief_refresh_kernel, dim3(blocks_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, *b, p->num_rocks, n);
     return (int)hipGetLastError();
 }
 

@@ -18,7 +18,8 @@ class _BeliefTracker(object):
         self.env = env
         k, n = env.num_rocks, env.batch_size
         self.tensors = {f: torch.zeros((k, n), dtype=dt, device=env.device) for f, dt in self.FIELDS}
-        self.ptrs = _native.RockBelief(*[self.tensors[f].data_ptr() for f, _ in self.FIELDS])
+        self.check_ok = torch.zeros(n, dtype=torch.int32, device=env.device)   # derived word (pomdp_rock_belief.check_ok)
+        self.ptrs = _native.RockBelief(*([self.tensors[f].data_ptr() for f, _ in self.FIELDS] + [self.check_ok.data_ptr()]))
         self.ref = C.byref(self.ptrs)
         self.on_reset()
 
@@ -115,6 +116,9 @@ class RockEnv(BatchedEnv):
         `rock.__dict__.update(r)`, rock.py:200-203); set_state() alone leaves fresh Rock statistics."""
         for f, _ in _BeliefTracker.FIELDS:
             self._tracker.tensors[f].copy_(torch.as_tensor(belief[f], device=self.device).reshape(self.num_rocks, -1))
+        with torch.cuda.device(self.device):
+            rc = self._lib.pomdp_rock_belief_refresh(self._params_ref, self._tracker.ref, self.batch_size, self._stream())
+            _native.check(rc, "pomdp_rock_belief_refresh")
 
     def _generate_preferred(self, history):
         """rock.py:293-374.  Without use_heuristic: `_generate_legal()`."""

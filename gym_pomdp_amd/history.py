@@ -42,9 +42,11 @@ class History(object):
         self.last_ob = torch.zeros(n, dtype=torch.int32, device=dev)
         self.total_sample = torch.zeros((k, n), dtype=torch.int32, device=dev)
         self.total_move = torch.zeros((k, n), dtype=torch.int32, device=dev)
+        self.move_ok = torch.zeros(n if k else 0, dtype=torch.int32, device=dev)   # derived: bit j = total_move[j] >= 0
         self._ptrs = _native.HistoryPtrs(self._size.data_ptr(), self.last_action.data_ptr(), self.last_ob.data_ptr(),
                                          self.total_sample.data_ptr() if k else None,
-                                         self.total_move.data_ptr() if k else None)
+                                         self.total_move.data_ptr() if k else None,
+                                         self.move_ok.data_ptr() if k else None)
         self._ref = C.byref(self._ptrs)
         self.clear()
 

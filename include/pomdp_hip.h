@@ -218,11 +218,17 @@ typedef struct pomdp_rock_belief {
     int32_t *measured;       /* number of CHECKs of this rock                       rock.py:178 */
     double  *lkv, *lkw;      /* likelihood of the readings if valuable / worthless  rock.py:184-189 */
     double  *prob_valuable;  /* .5 lkv / (.5 lkv + .5 lkw)                          rock.py:190-191 */
+    uint32_t *check_ok;      /* [n] derived: bit j = measured[j] < 5 && |count[j]| < 2 && 0 < prob_valuable[j] < 1, the
+                                "worth another CHECK" test of rock.py:371.  Maintained by the entry points below so
+                                that the policy reads one word per lane instead of 20 bytes per rock; after writing
+                                the arrays directly call pomdp_rock_belief_refresh. */
 } pomdp_rock_belief;
 
 /* fresh Rock objects (0, 0, 1., 1., .5) for every lane, or for the lanes with where[i] != 0 (device uint8, may be NULL) */
 int pomdp_rock_belief_reset(const pomdp_rock_params *p, const pomdp_rock_belief *b, const uint8_t *where, int64_t n,
                             void *stream);
+/* recompute check_ok from count / measured / prob_valuable (after the caller overwrote them, e.g. _set_state) */
+int pomdp_rock_belief_refresh(const pomdp_rock_params *p, const pomdp_rock_belief *b, int64_t n, void *stream);
 /* The part of RockEnv.step that maintains the statistics (rock.py:177-191), run after pomdp_rock_step on its outputs:
  * a lane whose action was CHECK j and whose ob != 0 updates rock j with eff(d) of the stored agent position (CHECK
  * does not move); with POMDP_AUTO_RESET a done lane gets fresh statistics (its reset() built new Rock objects),
@@ -242,10 +248,12 @@ int pomdp_rock_select_target(const pomdp_rock_params *p, const uint32_t *state, 
  *   total_sample[j] = sum over CHECK-j transitions of (+1 if next_ob GOOD, -1 if next_ob BAD)     rock.py:303-310
  *   total_move[j]   = sum over CHECK-j transitions of (+1 if next_ob GOOD, else -1 if the *previous*
  *                     observation was BAD — the reference's elif reads transition.observation)    rock.py:327-334
- * the two sums are int32 [num_rocks][n] for RockSample and unused (may be NULL) for the other envs. */
+ * the two sums are int32 [num_rocks][n] for RockSample and unused (may be NULL, like move_ok) for the other envs. */
 typedef struct pomdp_history {
     int32_t *size, *last_action, *last_ob;
     int32_t *total_sample, *total_move;
+    uint32_t *move_ok;      /* [n] derived, RockSample only: bit j = total_move[j] >= 0 (the test of rock.py:335),
+                               maintained by pomdp_history_clear / _append / pomdp_heuristic_steps */
 } pomdp_history;
 
 /* History() — empty history for every lane / the lanes with where[i] != 0 (last_action = last_ob = -1) */

@@ -698,7 +698,31 @@ def test_heuristic_vs_oracle_at_scale(env, kw, n, T):
                 assert same.all(), (t, k)
         for k in ("size", "last_action", "last_ob", "total_sample", "total_move"):
             assert np.array_equal(getattr(cpu.h, k), np_(getattr(gpu.h, "_size" if k == "size" else k))), (t, k)
+        if is_rock:      # the derived words the policy reads == the per-rock tests on the oracle's full arrays
+            K = o.n_actions - 5
+            w = (1 << np.arange(K, dtype=np.int64))[:, None]
+            ok = (bc["measured"] < 5) & (np.abs(bc["count"]) < 2) & (bc["prob_valuable"] > 0) & (bc["prob_valuable"] < 1)
+            assert np.array_equal((ok * w).sum(axis=0), np_(gpu.e._tracker.check_ok).astype(np.int64) & 0xFFFFFFFF), t
+            assert np.array_equal(((cpu.h.total_move >= 0) * w).sum(axis=0), np_(gpu.h.move_ok).astype(np.int64) & 0xFFFFFFFF), t
     assert n_done > 0
+
+
+def test_set_belief_refreshes_the_derived_word():
+    """set_belief() (the statistics part of the reference's _set_state, rock.py:200-203) recomputes check_ok."""
+    e = make_env("rock", dict(use_heuristic=True), batch_size=256, seed=3)
+    e.reset()
+    g = torch.Generator(device="cpu").manual_seed(5)
+    K, n = 8, 256
+    b = dict(count=torch.randint(-3, 4, (K, n), generator=g, dtype=torch.int32),
+             measured=torch.randint(0, 8, (K, n), generator=g, dtype=torch.int32),
+             lkv=torch.rand((K, n), generator=g, dtype=torch.float64), lkw=torch.rand((K, n), generator=g, dtype=torch.float64),
+             prob_valuable=torch.rand((K, n), generator=g, dtype=torch.float64).round(decimals=1))
+    e.set_belief(b)
+    ok = (b["measured"] < 5) & (b["count"].abs() < 2) & (b["prob_valuable"] > 0) & (b["prob_valuable"] < 1)
+    want = (ok.to(torch.int64) << torch.arange(K)[:, None]).sum(dim=0)
+    assert torch.equal(e._tracker.check_ok.cpu().to(torch.int64), want)
+    for k in b:
+        assert torch.equal(e.belief[k].cpu(), b[k])
 
 
 @pytest.mark.parametrize("env,kw,n,T,auto", [("rock", {}, 8192, 64, True), ("rock", dict(board_size=15, num_rocks=15), 4096, 64, True),
