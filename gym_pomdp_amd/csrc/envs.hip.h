@@ -63,6 +63,7 @@ struct RockEnv {
     using S = typename std::conditional<W == 1, uint32_t, uint64_t>::type; // 32-bit ALU when one word is enough
     static constexpr int WORDS = W;
     static constexpr bool POOLED_LPT2 = !STOCH;   // pomdp_kernels.hip: Finisher<RockEnv, 2, .>
+    static constexpr int ABL = ABLATE;            // experiment switches (tools/microbench.hip); 0 in the product
     struct Shared {
         uint32_t thr_hi[32];   // sensor threshold by L1 distance, thr >> 26  (compared with H >> 5)
         uint32_t thr_lo[32];   // thr & (2^26 - 1)                            (compared with L >> 6 on a tie)
@@ -79,27 +80,37 @@ struct RockEnv {
     // One global-load latency: every thread fetches a slice of the kernarg-resident tables with
     // unconditional (index-wrapped) loads, all issued before the first LDS write, so the compiler
     // emits one s_waitcnt instead of one per predicated region; duplicate writers store equal values.
-    static __device__ __forceinline__ void stage(Shared &sh, const Params &p, int tid)
+    // Split in two so that a kernel can put independent work between the table loads and their first use.
+    struct Staged { int8_t g, rx, ry; uint64_t t; };
+    static __device__ __forceinline__ Staged stage_load(const Params &p, int tid)
     {
-        const int8_t g = p.grid[tid & 255];
-        const uint64_t t = p.thr[tid & 31];
-        const int8_t rx = p.rock_x[tid & 15], ry = p.rock_y[tid & 15];
-        sh.grid[tid & 255] = g;
-        sh.thr_hi[tid & 31] = (uint32_t)(t >> 26);
-        sh.thr_lo[tid & 31] = (uint32_t)t & LO_MASK;
-        sh.rxy[tid & 15] = (uint8_t)((rx & 15) | (ry << 4));
+        Staged r;
+        r.g = p.grid[tid & 255];
+        r.t = p.thr[tid & 31];
+        r.rx = p.rock_x[tid & 15];
+        r.ry = p.rock_y[tid & 15];
+        return r;
     }
+    static __device__ __forceinline__ void stage_store(Shared &sh, const Staged &r, int tid)
+    {
+        sh.grid[tid & 255] = r.g;
+        sh.thr_hi[tid & 31] = (uint32_t)(r.t >> 26);
+        sh.thr_lo[tid & 31] = (uint32_t)r.t & LO_MASK;
+        sh.rxy[tid & 15] = (uint8_t)((r.rx & 15) | (r.ry << 4));
+    }
+    static __device__ __forceinline__ void stage(Shared &sh, const Params &p, int tid) { stage_store(sh, stage_load(p, tid), tid); }
     static __device__ __forceinline__ int n_actions(const Params &p) { return 5 + p.num_rocks; }
 
+    static constexpr bool NT = !(ABLATE & 16);
     static __device__ __forceinline__ void load(State &st, const uint32_t *state, int64_t n, uint32_t i)
     {
-        st.s = state[i];
-        if (W == 2) st.s |= (S)((uint64_t)state[n + i] << 32);
+        st.s = ld_stream<NT>(state + i);
+        if (W == 2) st.s |= (S)((uint64_t)ld_stream<NT>(state + n + i) << 32);
     }
     static __device__ __forceinline__ void store(const State &st, uint32_t *state, int64_t n, uint32_t i, bool)
     {
-        state[i] = (uint32_t)st.s;
-        if (W == 2) state[n + i] = (uint32_t)((uint64_t)st.s >> 32);
+        st_stream<NT>(state + i, (uint32_t)st.s);
+        if (W == 2) st_stream<NT>(state + n + i, (uint32_t)((uint64_t)st.s >> 32));
     }
 
     static __device__ __forceinline__ uint32_t elem(const uint4 &w, uint32_t e) { return e == 0 ? w.x : e == 1 ? w.y : e == 2 ? w.z : w.w; }
@@ -452,13 +463,14 @@ struct TagEnv {
     using Reward = float;
     static constexpr int WORDS = 1;
     static constexpr bool POOLED_LPT2 = false;
+    static constexpr int ABL = 0;
     struct Shared { int unused; };
     struct State { uint32_t w; };
 
     static __device__ __forceinline__ void stage(Shared &, const Params &, int) {}
     static __device__ __forceinline__ int n_actions(const Params &) { return 5; }
-    static __device__ __forceinline__ void load(State &st, const uint32_t *state, int64_t, uint32_t i) { st.w = state[i]; }
-    static __device__ __forceinline__ void store(const State &st, uint32_t *state, int64_t, uint32_t i, bool) { state[i] = st.w; }
+    static __device__ __forceinline__ void load(State &st, const uint32_t *state, int64_t, uint32_t i) { st.w = ld_stream(state + i); }
+    static __device__ __forceinline__ void store(const State &st, uint32_t *state, int64_t, uint32_t i, bool) { st_stream(state + i, st.w); }
 
     // tag.py:52-57 get_tag_coord, 59-66 get_index, 46-50 is_inside
     static __device__ __forceinline__ void coord(int idx, int &x, int &y)
@@ -607,6 +619,7 @@ struct BattleShipEnv {
     using Reward = int32_t;
     static constexpr int WORDS = 2 * MW;
     static constexpr bool POOLED_LPT2 = false;
+    static constexpr int ABL = 0;
     struct Shared { int unused; };
     // Each 128-bit mask is two 64-bit registers (never an addressable array or vector: a dynamically indexed
     // one is lowered through LDS by the compiler); bit tests are a 64-bit select and one variable shift.
@@ -628,7 +641,7 @@ struct BattleShipEnv {
     {
         uint32_t o[4] = {0, 0, 0, 0}, v[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int j = 0; j < MW; ++j) { o[j] = state[(int64_t)j * n + i]; v[j] = state[(int64_t)(MW + j) * n + i]; }
+        for (int j = 0; j < MW; ++j) { o[j] = ld_stream(state + (int64_t)j * n + i); v[j] = ld_stream(state + (int64_t)(MW + j) * n + i); }
         st.occ.lo = o[0] | ((uint64_t)o[1] << 32); st.occ.hi = o[2] | ((uint64_t)o[3] << 32);
         st.vis.lo = v[0] | ((uint64_t)v[1] << 32); st.vis.hi = v[2] | ((uint64_t)v[3] << 32);
     }
@@ -636,10 +649,10 @@ struct BattleShipEnv {
     static __device__ __forceinline__ void store(const State &st, uint32_t *state, int64_t n, uint32_t i, bool was_reset)
     {
 #pragma unroll
-        for (int j = 0; j < MW; ++j) state[(int64_t)(MW + j) * n + i] = st.vis.word(j);
+        for (int j = 0; j < MW; ++j) st_stream(state + (int64_t)(MW + j) * n + i, (uint32_t)st.vis.word(j));
         if (was_reset) {
 #pragma unroll
-            for (int j = 0; j < MW; ++j) state[(int64_t)j * n + i] = st.occ.word(j);
+            for (int j = 0; j < MW; ++j) st_stream(state + (int64_t)j * n + i, (uint32_t)st.occ.word(j));
         }
     }
     static __device__ __forceinline__ bool bit(const Mask &m, int a) { return ((a < 64 ? m.lo : m.hi) >> (a & 63)) & 1ull; }
@@ -870,13 +883,14 @@ struct TigerEnv {
     using Reward = int32_t;
     static constexpr int WORDS = 1;
     static constexpr bool POOLED_LPT2 = false;
+    static constexpr int ABL = 0;
     struct Shared { int unused; };
     struct State { uint32_t w; };
 
     static __device__ __forceinline__ void stage(Shared &, const Params &, int) {}
     static __device__ __forceinline__ int n_actions(const Params &) { return 3; }
-    static __device__ __forceinline__ void load(State &st, const uint32_t *state, int64_t, uint32_t i) { st.w = state[i]; }
-    static __device__ __forceinline__ void store(const State &st, uint32_t *state, int64_t, uint32_t i, bool) { state[i] = st.w; }
+    static __device__ __forceinline__ void load(State &st, const uint32_t *state, int64_t, uint32_t i) { st.w = ld_stream(state + i); }
+    static __device__ __forceinline__ void store(const State &st, uint32_t *state, int64_t, uint32_t i, bool) { st_stream(state + i, st.w); }
 
     // tiger.py:60-66: state = state_space.sample() (gym-space RNG -> stream RESET_SPACE); ob = NULL
     static __device__ __forceinline__ int reset(const Shared &, const Params &, State &st, const RngKey &key,
@@ -944,13 +958,14 @@ struct NetworkEnv {
     using Reward = float;
     static constexpr int WORDS = 1;
     static constexpr bool POOLED_LPT2 = false;
+    static constexpr int ABL = 0;
     struct Shared { int unused; };
     struct State { uint32_t w; };
 
     static __device__ __forceinline__ void stage(Shared &, const Params &, int) {}
     static __device__ __forceinline__ int n_actions(const Params &p) { return 2 * p.n_machines + 1; }
-    static __device__ __forceinline__ void load(State &st, const uint32_t *state, int64_t, uint32_t i) { st.w = state[i]; }
-    static __device__ __forceinline__ void store(const State &st, uint32_t *state, int64_t, uint32_t i, bool) { state[i] = st.w; }
+    static __device__ __forceinline__ void load(State &st, const uint32_t *state, int64_t, uint32_t i) { st.w = ld_stream(state + i); }
+    static __device__ __forceinline__ void store(const State &st, uint32_t *state, int64_t, uint32_t i, bool) { st_stream(state + i, st.w); }
 
     // network.py:61-69: all machines up, ob = OFF (0)
     static __device__ __forceinline__ int reset(const Shared &, const Params &p, State &st, const RngKey &, uint32_t)

@@ -66,6 +66,7 @@ __global__ __launch_bounds__(BLOCK) void reset_kernel(const typename Env::Params
 template <class Env, int LPT, bool CHAIN>
 struct Finisher {
     struct Aux {};
+    static constexpr bool HAS_PREPASS = false;
     template <class RT>
     static __device__ __forceinline__ void lane_step(const typename Env::Shared &sh, const typename Env::Params &p,
                                                      typename Env::State &st, int a, const RngKey &key, uint32_t lane,
@@ -106,6 +107,31 @@ struct Finisher<RockEnv<W, ABLATE, false>, 2, CHAIN> {
         Env::step_pre(sh, p, st, a, rew, done, aux);
         ob = 0;
     }
+    // wave-private LDS scratch (one instance each: function-local statics of these accessors)
+    static __device__ __forceinline__ uint32_t (&blk_lds())[BLOCK / 64][64][4]
+    {
+        __shared__ uint32_t a[BLOCK / 64][64][4];            // [0,32): sensor blocks, [32,64): policy blocks; (sub-batch, quad)
+        return a;
+    }
+    // The data-independent half of the task list — the wave's 32 sensor blocks (lanes 0-31) and, for CHAIN launches,
+    // the 32 policy blocks of the next call counter (lanes 32-63) — depends on lane ids only, so the kernel runs it
+    // right after issuing its HBM loads: one Philox pass hidden under the load latency.
+    static constexpr bool HAS_PREPASS = !(ABLATE & 8);
+    static __device__ __forceinline__ void prepass(const RngKey &key, const uint32_t (&lane)[2], const RngKey &akey)
+    {
+        const int wv = (int)(threadIdx.x >> 6), me = (int)(threadIdx.x & 63u);
+        const uint32_t first0 = lane[0] - (uint32_t)me, first1 = lane[1] - (uint32_t)me;   // first lane of each sub-batch
+        const bool is_act = me >= 32;
+        if (CHAIN || !is_act) {
+            const int qt = me & 31;                                            // (sub-batch, quad) index
+            const uint32_t quad = (((qt >> 4) ? first1 : first0) >> 2) + (uint32_t)(qt & 15);
+            const uint32_t c1 = is_act ? akey.t_lo : key.t_lo, c2 = is_act ? akey.t_hi : key.t_hi;
+            const uint32_t c3 = (uint32_t)(is_act ? POMDP_STREAM_ACTION : POMDP_STREAM_STEP) << 24;
+            const uint4 w = philox4x32_10(quad, c1, c2, c3, key.k0, key.k1);
+            uint32_t *dst = blk_lds()[wv][me];
+            dst[0] = w.x; dst[1] = w.y; dst[2] = w.z; dst[3] = w.w;
+        }
+    }
     static __device__ __forceinline__ void run(const typename Env::Shared &, const typename Env::Params &p,
                                                typename Env::State (&st)[2], const bool (&fresh)[2], const RngKey &key,
                                                const uint32_t (&lane)[2], const RngKey &akey, uint32_t n_act,
@@ -113,8 +139,8 @@ struct Finisher<RockEnv<W, ABLATE, false>, 2, CHAIN> {
     {
         __shared__ uint8_t src_lds[BLOCK / 64][128];         // reset rank -> virtual lane (me + 64 * sub-batch)
         __shared__ uint8_t res_lds[BLOCK / 64][128][4];      // reset rank -> four 2-bit rock codes per group g
-        __shared__ uint32_t blk_lds[BLOCK / 64][64][4];      // [0,32): sensor blocks, [32,64): policy blocks; (sub-batch, quad)
         const int wv = (int)(threadIdx.x >> 6), me = (int)(threadIdx.x & 63u);
+        if (!HAS_PREPASS) prepass(key, lane, akey);
         const int K = p.num_rocks, NG = (K + 3) >> 2;        // high blocks per reset
         const uint64_t m0 = __ballot(fresh[0]), m1 = __ballot(fresh[1]);
         const int n0 = __popcll(m0), nres = n0 + __popcll(m1);
@@ -122,34 +148,18 @@ struct Finisher<RockEnv<W, ABLATE, false>, 2, CHAIN> {
         const int rank1 = n0 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
         if (fresh[0]) src_lds[wv][rank0] = (uint8_t)me;
         if (fresh[1]) src_lds[wv][rank1] = (uint8_t)(me + 64);
-        constexpr int NQ = (ABLATE & 1) ? 0 : 32;            // sensor tasks
-        constexpr int NA = CHAIN ? 32 : 0;                   // policy tasks
-        const int ntask = NQ + NA + NG * nres;
+        const int ntask = NG * nres;                         // reset blocks: NG per resetting lane, 64 per pass
         const uint32_t inv = (65536u + (uint32_t)NG - 1u) / (uint32_t)NG;   // t / NG == (t * inv) >> 16 for t < 512
-        const uint32_t first0 = lane[0] - (uint32_t)me, first1 = lane[1] - (uint32_t)me;   // first lane of each sub-batch
+        const uint32_t first0 = lane[0] - (uint32_t)me, first1 = lane[1] - (uint32_t)me;
         for (int base = 0; base < ntask; base += 64) {
-            const int tid = base + me;
-            if (tid < ntask) {
-                const bool is_q = tid < NQ, is_act = !is_q && tid < NQ + NA;
-                const int qt = is_q ? tid : tid - NQ;                          // (sub-batch, quad) index of a block task
-                const int rt = tid < NQ + NA ? 0 : tid - NQ - NA;
+            const int rt = base + me;
+            if (rt < ntask) {
                 const int r = (int)(((uint32_t)rt * inv) >> 16), g = rt - r * NG;
                 const int v = (int)src_lds[wv][r & 127];
                 const uint32_t src_lane = ((v >> 6) ? first1 : first0) + (uint32_t)(v & 63);
-                const uint32_t quad = (((qt >> 4) ? first1 : first0) >> 2) + (uint32_t)(qt & 15);
-                // ONE Philox instance for the three task kinds: the counter words are per-lane selects
-                const uint32_t c0 = (is_q || is_act) ? quad : src_lane;
-                const uint32_t c1 = is_act ? akey.t_lo : key.t_lo, c2 = is_act ? akey.t_hi : key.t_hi;
-                const uint32_t c3 = is_q ? ((uint32_t)POMDP_STREAM_STEP << 24)
-                                         : (is_act ? ((uint32_t)POMDP_STREAM_ACTION << 24)
-                                                   : (((uint32_t)POMDP_STREAM_RESET << 24) | (2u * (uint32_t)g)));
-                const uint4 w = philox4x32_10(c0, c1, c2, c3, key.k0, key.k1);
-                if (is_q || is_act) {
-                    uint32_t *dst = blk_lds[wv][(is_act ? 32 : 0) + (qt & 31)];
-                    dst[0] = w.x; dst[1] = w.y; dst[2] = w.z; dst[3] = w.w;
-                } else {
-                    res_lds[wv][r & 127][g] = (uint8_t)Env::reset_group_codes(w, key, src_lane, g, K);
-                }
+                const uint4 w = philox4x32_10(src_lane, key.t_lo, key.t_hi,
+                                              ((uint32_t)POMDP_STREAM_RESET << 24) | (2u * (uint32_t)g), key.k0, key.k1);
+                res_lds[wv][r & 127][g] = (uint8_t)Env::reset_group_codes(w, key, src_lane, g, K);
             }
         }
         const uint32_t start = (uint32_t)p.start_x | ((uint32_t)p.start_y << 4);
@@ -159,9 +169,9 @@ struct Finisher<RockEnv<W, ABLATE, false>, 2, CHAIN> {
         if (fresh[1]) st[1].s = (typename Env::S)((uint64_t)start | ((uint64_t)(res32[rank1] & used) << 8));
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const uint32_t H = (ABLATE & 1) ? lane[j] * 2654435761u : blk_lds[wv][16 * j + (me >> 2)][me & 3];
+            const uint32_t H = (ABLATE & 1) ? lane[j] * 2654435761u : blk_lds()[wv][16 * j + (me >> 2)][me & 3];
             ob[j] = Env::sensor_ob(aux[j], H, [&]() { return Env::elem(Env::quad_block(key, lane[j], 1u), lane[j] & 3u); });
-            if (CHAIN) a_next[j] = (int)__umulhi(blk_lds[wv][32 + 16 * j + (me >> 2)][me & 3], n_act);
+            if (CHAIN) a_next[j] = (int)__umulhi(blk_lds()[wv][32 + 16 * j + (me >> 2)][me & 3], n_act);
         }
     }
 };
@@ -189,14 +199,24 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const typename Env::Params 
         idx[j] = base + (uint32_t)(j * BLOCK);
         in_range[j] = (uint64_t)idx[j] < (uint64_t)n;
         const uint32_t ic = in_range[j] ? idx[j] : (uint32_t)(n - 1);
-        a_raw[j] = action[ic];
+        a_raw[j] = ld_stream<!(Env::ABL & 16)>(action + ic);
         Env::load(st[j], state, n, ic);
-        was_done[j] = auto_reset ? false : (done[ic] != 0);          // frozen lane (the reference would assert)
+        was_done[j] = auto_reset ? false : (ld_stream(done + ic) != 0);   // frozen lane (the reference would assert)
     }
-    Env::stage(sh, p, (int)threadIdx.x);
+    using Fin = Finisher<Env, LPT, CHAIN>;
+    if constexpr (Fin::HAS_PREPASS) {
+        // table loads, then the Philox blocks that depend on lane ids only, then the first use of any load
+        uint32_t gl[LPT];
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) gl[j] = lane0 + idx[j];
+        const auto staged = Env::stage_load(p, (int)threadIdx.x);
+        Fin::prepass(key, gl, akey);
+        Env::stage_store(sh, staged, (int)threadIdx.x);
+    } else {
+        Env::stage(sh, p, (int)threadIdx.x);
+    }
     __syncthreads();
 
-    using Fin = Finisher<Env, LPT, CHAIN>;
     const int n_act = Env::n_actions(p);
     int o[LPT], d[LPT];
     typename Env::Reward r[LPT];
@@ -218,12 +238,13 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const typename Env::Params 
 #pragma unroll
     for (int j = 0; j < LPT; ++j) {
         if (!live[j]) o[j] = 0;
-        if (CHAIN) { if (in_range[j]) const_cast<int32_t *>(action)[idx[j]] = a_next[j]; }
+        constexpr bool NT = !(Env::ABL & 16);
+        if (CHAIN) { if (in_range[j]) st_stream<NT>(const_cast<int32_t *>(action) + idx[j], (int32_t)a_next[j]); }
         if (live[j]) Env::store(st[j], state, n, idx[j], fresh[j]);
         if (in_range[j]) {
-            ob[idx[j]] = o[j];
-            reward[idx[j]] = r[j];
-            done[idx[j]] = (uint8_t)d[j];
+            st_stream<NT>(ob + idx[j], (int32_t)o[j]);
+            st_stream<NT>(reward + idx[j], r[j]);
+            st_stream<NT>(done + idx[j], (uint8_t)d[j]);
             // the reference asserts on an out-of-range action; here the lane is left untouched and counted
             if (!valid[j] && !was_done[j] && err) atomicAdd(err, 1u);
         }
@@ -580,8 +601,10 @@ __global__ __launch_bounds__(BLOCK) void synthetic_actions_kernel(int4 *__restri
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n4; i += stride) {
         const uint4 w = philox4x32_10(q0 + (uint32_t)i, key.t_lo, key.t_hi, (uint32_t)POMDP_STREAM_ACTION << 24,
                                       key.k0, key.k1);
-        action[i] = make_int4((int)__umulhi(w.x, n_actions), (int)__umulhi(w.y, n_actions),
-                              (int)__umulhi(w.z, n_actions), (int)__umulhi(w.w, n_actions));
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        const v4i a = {(int)__umulhi(w.x, n_actions), (int)__umulhi(w.y, n_actions), (int)__umulhi(w.z, n_actions),
+                       (int)__umulhi(w.w, n_actions)};
+        __builtin_nontemporal_store(a, reinterpret_cast<v4i *>(action) + i);      // streamed, like every lane column
     }
 }
 

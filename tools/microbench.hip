@@ -188,6 +188,27 @@ int main(int argc, char **argv)
             }
             printf("\n");
         }
+        {   // ABLATE 8: the data-independent Philox pass runs after the loads were consumed instead of under their latency
+            using E = RockEnv<1, 8>;
+            printf("%-28s: plain LPT2 %8.2f", "late prepass (ablate 8)", time_it([&](int t) {
+                hipLaunchKernelGGL((step_kernel<E, 2>), dim3((unsigned)((n + 511) / 512)), dim3(256), 0, 0, p, state, action, ob, reward, done, err, n, make_key(1, t), 0u, 1);
+            }, iters));
+            printf("  chain LPT2 %8.2f\n", time_it([&](int t) {
+                hipLaunchKernelGGL((step_kernel<E, 2, true>), dim3((unsigned)((n + 511) / 512)), dim3(256), 0, 0, p, state, action, ob, reward, done, err, n, make_key(1, t), 0u, 1, make_key(1, t + 1));
+            }, iters));
+        }
+        {
+            auto nt = [&](auto env_tag, const char *name) {
+                using E = decltype(env_tag);
+                printf("%-28s: plain LPT2 %8.2f", name, time_it([&](int t) {
+                    hipLaunchKernelGGL((step_kernel<E, 2>), dim3((unsigned)((n + 511) / 512)), dim3(256), 0, 0, p, state, action, ob, reward, done, err, n, make_key(1, t), 0u, 1);
+                }, iters));
+                printf("  chain LPT2 %8.2f\n", time_it([&](int t) {
+                    hipLaunchKernelGGL((step_kernel<E, 2, true>), dim3((unsigned)((n + 511) / 512)), dim3(256), 0, 0, p, state, action, ob, reward, done, err, n, make_key(1, t), 0u, 1, make_key(1, t + 1));
+                }, iters));
+            };
+            nt(RockEnv<1, 16>{}, "cached loads/stores (ablate 16)");
+        }
         run(RockEnv<1, 1>{}, "step -checkphilox");
         run(RockEnv<1, 2>{}, "step -reset");
         run(RockEnv<1, 3>{}, "step -checkphilox -reset");
@@ -213,6 +234,62 @@ int main(int argc, char **argv)
             CK(hipDeviceSynchronize());
             auto t1 = std::chrono::high_resolution_clock::now();
             printf("policy+step over %d stream(s): %8.2f us/step\n", S, std::chrono::duration<double, std::micro>(t1 - t0).count() / iters);
+            for (auto &x : st) CK(hipStreamDestroy(x));
+        }
+    }
+    printf("pomdp_rollout_synthetic (C driver, chained), per step: %8.2f\n",
+           time_it([&](int t) { pomdp_rollout_synthetic(POMDP_ENV_ROCK, &p, state, action, ob, reward, done, err, n, 1, 1, 0, (uint64_t)t * 100, 100, 1, nullptr); }, iters / 100 + 1) / 100);
+    {   // does the CPU's run-ahead matter?  chained step launches on the null stream / a created stream, paced by a busy-wait
+        using E = RockEnv<1, 0>;
+        hipStream_t cs; CK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+        for (hipStream_t strm : {(hipStream_t)0, cs}) {
+            for (double pace_us : {0.0, 3.0, 5.0, 6.5}) {
+                hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+                auto launch = [&](int t) {
+                    hipLaunchKernelGGL((step_kernel<E, 2, true>), dim3((unsigned)((n + 511) / 512)), dim3(256), 0, strm, p, state, action, ob, reward, done, err, n, make_key(1, t), 0u, 1, make_key(1, t + 1));
+                };
+                for (int i = 0; i < 10; ++i) launch(i);
+                CK(hipDeviceSynchronize());
+                CK(hipEventRecord(e0, strm));
+                auto w0 = std::chrono::high_resolution_clock::now();
+                for (int i = 0; i < iters; ++i) {
+                    auto l0 = std::chrono::high_resolution_clock::now();
+                    launch(100 + i);
+                    while (std::chrono::duration<double, std::micro>(std::chrono::high_resolution_clock::now() - l0).count() < pace_us) {}
+                }
+                auto w1 = std::chrono::high_resolution_clock::now();
+                CK(hipEventRecord(e1, strm));
+                CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                printf("chain step, %s stream, launch paced to %.1f us: %6.2f us/step by events, cpu issue %.2f us/launch\n",
+                       strm ? "created" : "null", pace_us, ms * 1e3f / iters,
+                       std::chrono::duration<double, std::micro>(w1 - w0).count() / iters);
+            }
+        }
+        CK(hipStreamDestroy(cs));
+    }
+    {   // chained step launches (step + next policy in one kernel), batch split over S streams, launches interleaved
+        using E = RockEnv<1, 0>;
+        for (int S : {1, 2, 4, 8}) {
+            std::vector<hipStream_t> st(S);
+            for (auto &x : st) CK(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
+            const int64_t part = n / S;
+            auto body = [&](int t) {
+                for (int k = 0; k < S; ++k) {
+                    const int64_t o = k * part;
+                    if (part >= (1 << 18))
+                        hipLaunchKernelGGL((step_kernel<E, 2, true>), dim3((unsigned)((part + 511) / 512)), dim3(256), 0, st[k], p, state + o, action + o, ob + o, reward + o, done + o, err, part, make_key(1, t), (uint32_t)o, 1, make_key(1, t + 1));
+                    else
+                        hipLaunchKernelGGL((step_kernel<E, 1, true>), dim3((unsigned)((part + 255) / 256)), dim3(256), 0, st[k], p, state + o, action + o, ob + o, reward + o, done + o, err, part, make_key(1, t), (uint32_t)o, 1, make_key(1, t + 1));
+                }
+            };
+            for (int i = 0; i < 10; ++i) body(i);
+            CK(hipDeviceSynchronize());
+            auto t0 = std::chrono::high_resolution_clock::now();
+            for (int i = 0; i < iters; ++i) body(100 + i);
+            CK(hipDeviceSynchronize());
+            auto t1 = std::chrono::high_resolution_clock::now();
+            printf("chained step over %d stream(s): %8.2f us/step\n", S, std::chrono::duration<double, std::micro>(t1 - t0).count() / iters);
             for (auto &x : st) CK(hipStreamDestroy(x));
         }
     }
