@@ -17,13 +17,20 @@
 namespace pomdp {
 
 // Streaming access to the per-lane columns.  Every byte of a column is read or written exactly once per launch and
-// the per-XCD L2 does not keep lines across a kernel boundary anyway, so the columns go through with the `nt` bit:
-// no write-back burst at the end of the launch, no allocation on the way in.  Measured on the RockSample step
-// kernel at 2^20 lanes: 9.06 -> 7.71 us per launch (tools/microbench.hip, ABLATE bit 16 turns it off).
+// the per-XCD L2 keeps nothing across a kernel boundary, so
+//   - stores are device-scope write-through (`global_store ... sc1`): the lines leave L2 while the kernel is still
+//     computing instead of in one write-back burst when it ends;
+//   - loads carry the `nt` bit (no allocation on the way in).
+// Measured on the RockSample step kernel at 2^20 lanes (tools/microbench.hip; ABLATE bit 16 = plain cached access):
+// 9.06 us cached -> 7.9 us with nt loads and stores -> 7.2 us with write-through stores.  Load policy alone: no effect.
 template <bool STREAM = true, class T>
 __device__ __forceinline__ T ld_stream(const T *p) { return STREAM ? __builtin_nontemporal_load(p) : *p; }
 template <bool STREAM = true, class T>
-__device__ __forceinline__ void st_stream(T *p, T v) { if (STREAM) __builtin_nontemporal_store(v, p); else *p = v; }
+__device__ __forceinline__ void st_stream(T *p, T v)
+{
+    if (STREAM) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
 
 struct RngKey {          // wave-uniform part of the counter/key
     uint32_t k0, k1;     // seed lo, hi
