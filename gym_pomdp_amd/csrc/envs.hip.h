@@ -38,6 +38,21 @@ __device__ __forceinline__ void reset_where_chain_default(const typename Env::Sh
     next_action = synthetic_action(akey, lane, n_actions);
 }
 
+// index of the n-th (0-based) set bit of m, branch-free: a binary search on popcounts (n < popc(m))
+__device__ __forceinline__ int nth_set_bit(uint32_t m, int n)
+{
+    int pos = 0;
+#pragma unroll
+    for (int w = 16; w >= 1; w >>= 1) {
+        const int c = __popc(m & ((1u << w) - 1u));
+        const bool up = n >= c;
+        n -= up ? c : 0;
+        pos += up ? w : 0;
+        m = up ? (m >> w) : m;
+    }
+    return pos;
+}
+
 // ===========================================================================
 // RockSample
 // ===========================================================================
@@ -271,9 +286,8 @@ struct RockEnv {
         uint32_t pre, alive; int n_pre;
         legal_count(sh, p, st, pre, n_pre, alive);
         if (idx < n_pre) return (int)((pre >> (3 * idx)) & 7u);
-        // rock j sits at bit 2 j of `alive`: drop the k lowest set bits, take the next one
-        for (int k = idx - n_pre; k > 0; --k) alive &= alive - 1u;
-        const int j = (__ffs((int)alive) - 1) >> 1;
+        // rock j sits at bit 2 j of `alive`: the (idx - n_pre)-th set bit, without a data-dependent loop
+        const int j = nth_set_bit(alive, idx - n_pre) >> 1;
         const uint32_t rxy = sh.rxy[j & 15];
         return 5 + sh.grid[(rxy & 15u) * 16 + (rxy >> 4)];
     }
@@ -428,6 +442,18 @@ struct RockEnv {
         return aux.want ? ((aux.good == correct) ? 2 : 1) : 0;
     }
 
+    // The step of a lane that was handed its sensor high word H (element lane & 3 of the quad's STEP block): the fused
+    // rollout kernel computes one such block per lane every four steps and passes the words around the quad.
+    static constexpr bool QUAD_SENSOR = !STOCH;
+    template <class RT>
+    static __device__ __forceinline__ void step_with_H(const Shared &sh, const Params &p, State &st, int a, const RngKey &key,
+                                                       uint32_t lane, uint32_t H, int &ob, RT &rew, int &done)
+    {
+        Aux aux;
+        step_pre(sh, p, st, a, rew, done, aux);
+        ob = sensor_ob(aux, H, [&]() { return elem(quad_block(key, lane, 1u), lane & 3u); });
+    }
+
     // The whole step for one lane (launches that do not pool the quad's sensor block: one lane per thread, rollouts).
     template <class RT>
     static __device__ __forceinline__ void step(const Shared &sh, const Params &p, State &st, int a,
@@ -463,6 +489,7 @@ struct TagEnv {
     using Reward = float;
     static constexpr int WORDS = 1;
     static constexpr bool POOLED_LPT2 = false;
+    static constexpr bool QUAD_SENSOR = false;
     static constexpr int ABL = 0;
     struct Shared { int unused; };
     struct State { uint32_t w; };
@@ -619,6 +646,7 @@ struct BattleShipEnv {
     using Reward = int32_t;
     static constexpr int WORDS = 2 * MW;
     static constexpr bool POOLED_LPT2 = false;
+    static constexpr bool QUAD_SENSOR = false;
     static constexpr int ABL = 0;
     struct Shared { int unused; };
     // Each 128-bit mask is two 64-bit registers (never an addressable array or vector: a dynamically indexed
@@ -883,6 +911,7 @@ struct TigerEnv {
     using Reward = int32_t;
     static constexpr int WORDS = 1;
     static constexpr bool POOLED_LPT2 = false;
+    static constexpr bool QUAD_SENSOR = false;
     static constexpr int ABL = 0;
     struct Shared { int unused; };
     struct State { uint32_t w; };
@@ -958,6 +987,7 @@ struct NetworkEnv {
     using Reward = float;
     static constexpr int WORDS = 1;
     static constexpr bool POOLED_LPT2 = false;
+    static constexpr bool QUAD_SENSOR = false;
     static constexpr int ABL = 0;
     struct Shared { int unused; };
     struct State { uint32_t w; };

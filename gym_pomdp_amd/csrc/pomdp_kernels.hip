@@ -531,10 +531,20 @@ __global__ __launch_bounds__(BLOCK) void heuristic_step_kernel(const typename En
     prev_ob[i] = o;
 }
 
-// Lane i simulates from root state column i / sims_per_root for up to `depth` steps: the state lives
-// in registers, the policy draw (stream ROLLOUT) and the env draws (stream STEP) come from the lane's
-// own Philox streams at t0 + k, the discounted return accumulates in IEEE double with separate
-// multiply and add (so a CPU restatement reproduces it bit-for-bit), nothing is written but the per-lane results.
+// Lane i simulates from root state column i / sims_per_root for up to `depth` steps: the state lives in registers
+// and nothing is written but the per-lane results.  Random words, four steps at a time:
+//   - the policy pick of step k is word k of the lane's ROLLOUT stream at t0: one Philox block per four steps;
+//   - the env draws come from stream STEP at t0 + k, as in step().  RockSample's STEP block is shared by the four
+//     lanes of a quad, so lane e of a quad computes the block of step 4 g + e and the words travel by DPP
+//     quad-broadcast: one block per lane per four steps instead of four.
+// The discounted return accumulates in IEEE double with separate multiply and add (so a CPU restatement reproduces
+// it bit-for-bit).
+template <int J>
+static __device__ __forceinline__ uint32_t quad_bcast(uint32_t v)     // v of lane J of the caller's quad
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, J * 0x55, 0xF, 0xF, false);
+}
+
 template <class Env>
 __global__ __launch_bounds__(BLOCK) void rollout_kernel(const typename Env::Params p, const uint32_t *__restrict__ state,
                                                         int64_t n_roots, int64_t sims_per_root, int depth,
@@ -552,34 +562,58 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(const typename Env::Para
     const bool in_range = i < n;
     const int64_t ic = in_range ? i : n - 1;
     typename Env::State st;
-    Env::load(st, state, n_roots, ic / sims_per_root);
+    Env::load(st, state, n_roots, (uint32_t)(ic / sims_per_root));
     const uint32_t lane = lane0 + (uint32_t)i;
     const int n_act = Env::n_actions(p);
     double acc = 0.0, disc = 1.0;
     int k = 0, d = 0, o = 0, first = -1;
-    bool active = in_range;
-    uint64_t t = ((uint64_t)key0.t_hi << 32) | key0.t_lo;
-    for (int step = 0; step < depth; ++step, ++t) {
-        const int count = all_actions ? n_act : Env::legal_count(sh, p, st);
-        active = active && !d && count > 0;
-        if (!__any(active)) break;                                   // wave-uniform exit
-        RngKey key = key0;
-        key.t_lo = (uint32_t)t; key.t_hi = (uint32_t)(t >> 32);
-        const uint32_t w = stream_block(key, lane, POMDP_STREAM_ROLLOUT, 0u).x;
-        const int idx = (int)__umulhi(w, (uint32_t)(count > 0 ? count : 1));
-        const int a = all_actions ? idx : Env::legal_nth(sh, p, st, idx);
-        typename Env::State nx = st;
-        int o2, d2;
-        double r;
-        Env::step(sh, p, nx, a, key, lane, o2, r, d2);               // every lane runs it; inactive lanes discard
-        if (active) {
-            st = nx; o = o2; d = d2;
-            if (step == 0) first = a;
-            const double term = disc * r;
-            acc = acc + term;
-            disc = disc * discount;
-            k = step + 1;
+    bool active = in_range, live_wave = true;
+    const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo;
+    for (int base = 0; base < depth && live_wave; base += 4) {
+        const uint4 pw = stream_block(key0, lane, POMDP_STREAM_ROLLOUT, (uint32_t)(base >> 2));
+        uint4 sq = make_uint4(0, 0, 0, 0);
+        if constexpr (Env::QUAD_SENSOR) {            // this lane's share: the quad's STEP block of step base + (lane & 3)
+            const uint64_t te = t0 + (uint64_t)base + (uint64_t)(lane & 3u);
+            RngKey ke = key0;
+            ke.t_lo = (uint32_t)te; ke.t_hi = (uint32_t)(te >> 32);
+            sq = Env::quad_block(ke, lane, 0u);
         }
+        auto one_step = [&](auto jc) {
+            constexpr int J = decltype(jc)::value;
+            const int step = base + J;
+            if (step >= depth || !live_wave) return;
+            const int count = all_actions ? n_act : Env::legal_count(sh, p, st);
+            active = active && !d && count > 0;
+            if (!__any(active)) { live_wave = false; return; }           // wave-uniform exit
+            const uint64_t t = t0 + (uint64_t)step;
+            RngKey key = key0;
+            key.t_lo = (uint32_t)t; key.t_hi = (uint32_t)(t >> 32);
+            const uint32_t w = J == 0 ? pw.x : J == 1 ? pw.y : J == 2 ? pw.z : pw.w;
+            const int idx = (int)__umulhi(w, (uint32_t)(count > 0 ? count : 1));
+            const int a = all_actions ? idx : Env::legal_nth(sh, p, st, idx);
+            typename Env::State nx = st;
+            int o2, d2;
+            double r;
+            if constexpr (Env::QUAD_SENSOR) {      // every lane runs it (the broadcasts need the whole quad); inactive lanes discard
+                const uint32_t e = lane & 3u;
+                const uint32_t hx = quad_bcast<J>(sq.x), hy = quad_bcast<J>(sq.y), hz = quad_bcast<J>(sq.z), hw = quad_bcast<J>(sq.w);
+                Env::step_with_H(sh, p, nx, a, key, lane, e == 0 ? hx : e == 1 ? hy : e == 2 ? hz : hw, o2, r, d2);
+            } else {
+                Env::step(sh, p, nx, a, key, lane, o2, r, d2);
+            }
+            if (active) {
+                st = nx; o = o2; d = d2;
+                if (step == 0) first = a;
+                const double term = disc * r;
+                acc = acc + term;
+                disc = disc * discount;
+                k = step + 1;
+            }
+        };
+        one_step(std::integral_constant<int, 0>{});
+        one_step(std::integral_constant<int, 1>{});
+        one_step(std::integral_constant<int, 2>{});
+        one_step(std::integral_constant<int, 3>{});
     }
     if (in_range) {
         ret[i] = acc;

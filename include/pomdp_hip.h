@@ -199,7 +199,7 @@ int pomdp_compute_prob(int env, const void *params, const uint32_t *state, const
  * step / _discount.  Lane i (global id lane0 + i, i < n_roots * sims_per_root) starts from
  * root_state column i / sims_per_root (uint32 [words][n_roots], read-only) and for k = 0 .. depth-1, while
  * not done:  list = _generate_legal() (all actions with POMDP_ROLLOUT_ALL_ACTIONS);
- *            a = list[(w * len(list)) >> 32], w = first word of stream ROLLOUT at (seed, lane, t0 + k);
+ *            a = list[(w * len(list)) >> 32], w = word k of stream ROLLOUT at (seed, lane, t0);
  *            (ob, r, done) = step(a) on stream STEP at (seed, lane, t0 + k);  ret += disc * r;  disc *= discount.
  * The return accumulates in IEEE double (separate multiply and add).  Per-lane outputs (device):
  * ret double[n], n_steps / first_action / last_ob int32[n], terminated uint8[n]. */

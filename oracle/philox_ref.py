@@ -24,7 +24,7 @@ consumes them): see rock_reset_words / rock_step_words below (split high / low b
 Streams: 0 np.random draws made inside step(); 1 np.random draws made inside
 reset(); 2 / 3 the gym-space RNG (Discrete.sample) inside step() / reset()
 (Tiger only); 4 the benchmark's synthetic random-action policy; 5 the rollout policy's pick
-among the legal actions (one word per rollout step).
+among the legal actions (word k of the stream of the rollout's first call counter picks step k).
 """
 import numpy as np
 

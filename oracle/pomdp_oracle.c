@@ -973,7 +973,7 @@ void or_batch_rollout(const or_env *proto, const uint32_t *state, int64_t n_root
                 if (policy_all_actions) { len = nA; for (int a = 0; a < nA; a++) list[a] = a; }
                 else len = or_env_legal(&e, list);
                 if (len == 0) break;                       /* BattleShip with every cell visited */
-                or_ws_philox(&pol, seed, lane, t0 + (uint64_t)k, OR_STREAM_ROLLOUT);
+                if (k == 0) or_ws_philox(&pol, seed, lane, t0, OR_STREAM_ROLLOUT);   /* word k of this stream picks step k */
                 int a = list[((uint64_t)or_ws_next32(&pol) * (uint64_t)len) >> 32];
                 if (k == 0) first = a;
                 or_ws_philox_env(&np_rng, e.kind, seed, lane, t0 + (uint64_t)k, OR_STREAM_STEP);

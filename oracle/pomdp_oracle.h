@@ -125,7 +125,7 @@ void   or_batch_compute_prob(const or_env *proto, const uint32_t *state, const i
                              double *out, int64_t n);
 /* Random rollouts (POMCP-style simulations).  Lane i starts from root state column i / sims_per_root
  * (state: uint32 [words][n_roots], read-only) and, for k = 0 .. depth-1 while not done:
- *   list = policy ? all actions : _generate_legal();  w = word 0 of stream ROLLOUT at (seed, lane, t0+k)
+ *   list = policy ? all actions : _generate_legal();  w = word k of stream ROLLOUT at (seed, lane, t0)
  *   a = list[(w * len(list)) >> 32];  (ob, r, done) = step(a) on stream STEP at (seed, lane, t0+k)
  *   ret += disc * r;  disc *= discount      (IEEE double, separate multiply and add)
  * Outputs per lane: ret (double), n_steps, first action, last observation, terminated flag. */

@@ -270,8 +270,8 @@ def rollout_reference(name, kwargs, seed, root_lane0, n_roots, sims_per_root, de
     """Reference-side statement of the build's rollout contract (oracle/pomdp_oracle.h: or_batch_rollout):
     root r is the reference env reset on stream RESET of (seed, root_lane0 + r, t_reset); simulation s of
     root r is a deep copy of it, advanced by the reference's own step() on injected STEP words, the action
-    being list[(w * len(list)) >> 32] with list = env._generate_legal() (or all actions) and w the first
-    word of stream ROLLOUT at (seed, lane, t0 + k)."""
+    being list[(w * len(list)) >> 32] with list = env._generate_legal() (or all actions) and w word k of
+    stream ROLLOUT at (seed, lane, t0)."""
     import copy
     space = _space_rng() if name == "tiger" else None
     n = n_roots * sims_per_root
@@ -294,12 +294,13 @@ def rollout_reference(name, kwargs, seed, root_lane0, n_roots, sims_per_root, de
             i = r * sims_per_root + s
             lane = lane0 + i
             e = copy.deepcopy(env)
+            pol_words = px.stream_words(seed, lane, t0, px.STREAM_ROLLOUT, depth)
             ret, disc, k, done, ob = 0.0, 1.0, 0, False, 0
             while k < depth and not done:
                 lst = list(range(n_act)) if all_actions else [int(a) for a in e._generate_legal()]
                 if not lst:
                     break
-                w = int(px.stream_words(seed, lane, t0 + k, px.STREAM_ROLLOUT, 1)[0])
+                w = int(pol_words[k])
                 a = lst[(w * len(lst)) >> 32]
                 if k == 0:
                     out["first_action"][i] = a
