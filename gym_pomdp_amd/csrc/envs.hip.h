@@ -587,11 +587,64 @@ struct TagEnv {
         return ob == (int)agent ? 1.0 : 0.0;
     }
 
+    // cell -> (x, y) with selects only (cells 0-19: two rows of ten; 20-28: three rows of three above x = 5..7)
+    static __device__ __forceinline__ void coord_fast(int idx, int &x, int &y)
+    {
+        const bool top = idx >= 20;
+        const int t = idx - 20, ty = (t * 11) >> 5;                 // t / 3 for t in 0..8
+        const int by = idx >= 10;
+        y = top ? ty + 2 : by;
+        x = top ? t - 3 * ty + 5 : idx - 10 * by;
+    }
+
+    // tag.py:108-143 with one opponent (the default and the benchmark configuration), branch-free: under a random
+    // policy every wave holds both moves and TAGs, so both outcomes are evaluated and selected.  The failed TAG's
+    // draws are words 0-2 of block 0 of the lane's STEP stream: binomial(1, move_prob) on (w0, w1), then
+    // np.random.choice over a list whose length is 2 or 4, i.e. randint with an exact mask — one word, no rejection.
+    template <class RT>
+    static __device__ __forceinline__ void step_one_opponent(const Params &p, State &st, int a, const RngKey &key,
+                                                             uint32_t lane, int &ob, RT &rew, int &done)
+    {
+        const uint32_t w = st.w;
+        const int agent = (int)(w & 31u), oi = (int)((w >> 5) & 31u), no = num_opp(w);
+        int ax, ay, ox, oy;
+        coord_fast(agent, ax, ay);
+        coord_fast(oi, ox, oy);
+        // a < 4: the agent moves if the target cell exists (tag.py:112-117)
+        const int nx = ax + (a == 1) - (a == 3), ny = ay + (a == 0) - (a == 2);
+        const uint32_t agent_m = inside(nx, ny) ? (uint32_t)index(nx, ny) : (uint32_t)agent;
+        // a == 4 (tag.py:119-134): tagged iff co-located; otherwise the opponent may flee (tag.py:201-207, 260-280)
+        const bool colocated = oi == agent;
+        uint32_t list = 0; int cnt = 0;
+        if (ox >= ax) { list |= 1u << (2 * cnt); ++cnt; }
+        if (oy >= ay) { ++cnt; }                                     // NORTH = 0: nothing to or in
+        if (ox <= ax) { list |= 3u << (2 * cnt); ++cnt; }
+        if (oy <= ay) { list |= 2u << (2 * cnt); ++cnt; }
+        if (ox == ax && oy > ay) { ++cnt; }
+        if (oy == ay && ox > ax) { list |= 1u << (2 * cnt); ++cnt; }
+        if (ox == ax && oy < ay) { list |= 2u << (2 * cnt); ++cnt; }
+        if (oy == ay && ox < ax) { list |= 3u << (2 * cnt); ++cnt; }
+        const uint4 blk = stream_block(key, lane, POMDP_STREAM_STEP, 0u);
+        const bool flee = k53(blk.x, blk.y) <= p.move_thr;           // binomial(1, move_prob)
+        const uint32_t pick = (list >> (2 * (blk.z & (uint32_t)(cnt - 1)))) & 3u;   // cnt is 2 or 4 off the agent's cell
+        const int mx = ox + (pick == 1u) - (pick == 3u), my = oy + (pick == 0u) - (pick == 2u);
+        const bool moved = !colocated && no > 0 && flee && inside(mx, my);
+        const uint32_t opp_t = moved ? (uint32_t)index(mx, my) : (uint32_t)oi;
+        const uint32_t w_tag = with_num_opp((w & ~(31u << 5)) | (opp_t << 5), no - (int)colocated);
+        const bool tag = a == 4;
+        const uint32_t wn = tag ? w_tag : ((w & ~31u) | agent_m);
+        rew = tag ? (colocated ? 10.f : -10.f) : -1.f;
+        ob = (!tag && ((wn >> 5) & 31u) == (wn & 31u)) ? p.obs_cells : (int)(wn & 31u);   // tag.py:219-226
+        done = num_opp(wn) == 0;
+        st.w = wn;
+    }
+
     // tag.py:108-143 step, 201-207 move_opponent, 260-280 _admissable_actions
     template <class RT>
     static __device__ __forceinline__ void step(const Shared &, const Params &p, State &st, int a,
                                                 const RngKey &key, uint32_t lane, int &ob, RT &rew, int &done)
     {
+        if (p.num_opponents == 1) { step_one_opponent(p, st, a, key, lane, ob, rew, done); return; }   // wave-uniform
         uint32_t w = st.w;
         const int agent = (int)(w & 31u);
         int ax, ay;
