@@ -488,7 +488,7 @@ struct TagEnv {
     using Params = pomdp_tag_params;
     using Reward = float;
     static constexpr int WORDS = 1;
-    static constexpr bool POOLED_LPT2 = false;
+    static constexpr bool POOLED_LPT2 = true;     // pomdp_kernels.hip: Finisher<TagEnv, 2, .>
     static constexpr bool QUAD_SENSOR = false;
     static constexpr int ABL = 0;
     struct Shared { int unused; };
@@ -598,12 +598,15 @@ struct TagEnv {
     }
 
     // tag.py:108-143 with one opponent (the default and the benchmark configuration), branch-free: under a random
-    // policy every wave holds both moves and TAGs, so both outcomes are evaluated and selected.  The failed TAG's
-    // draws are words 0-2 of block 0 of the lane's STEP stream: binomial(1, move_prob) on (w0, w1), then
-    // np.random.choice over a list whose length is 2 or 4, i.e. randint with an exact mask — one word, no rejection.
+    // policy every wave holds both moves and TAGs, so both outcomes are evaluated and selected.  Only a failed TAG
+    // on a live opponent draws random numbers — words 0-2 of block 0 of the lane's STEP stream: binomial(1,
+    // move_prob) on (w0, w1), then np.random.choice over a list whose length is 2 or 4, i.e. randint with an exact
+    // mask (one word, no rejection).  The step is therefore split: `pre` does everything but the opponent's flight
+    // and says whether the draw is needed, `flee` applies it; launches that pool Philox work call them separately.
+    struct Flight { uint32_t list; int cnt, ox, oy; bool need; };
     template <class RT>
-    static __device__ __forceinline__ void step_one_opponent(const Params &p, State &st, int a, const RngKey &key,
-                                                             uint32_t lane, int &ob, RT &rew, int &done)
+    static __device__ __forceinline__ void step_one_opponent_pre(const Params &p, State &st, int a, int &ob, RT &rew,
+                                                                 int &done, Flight &f)
     {
         const uint32_t w = st.w;
         const int agent = (int)(w & 31u), oi = (int)((w >> 5) & 31u), no = num_opp(w);
@@ -624,19 +627,50 @@ struct TagEnv {
         if (oy == ay && ox > ax) { list |= 1u << (2 * cnt); ++cnt; }
         if (ox == ax && oy < ay) { list |= 2u << (2 * cnt); ++cnt; }
         if (oy == ay && ox < ax) { list |= 3u << (2 * cnt); ++cnt; }
-        const uint4 blk = stream_block(key, lane, POMDP_STREAM_STEP, 0u);
-        const bool flee = k53(blk.x, blk.y) <= p.move_thr;           // binomial(1, move_prob)
-        const uint32_t pick = (list >> (2 * (blk.z & (uint32_t)(cnt - 1)))) & 3u;   // cnt is 2 or 4 off the agent's cell
-        const int mx = ox + (pick == 1u) - (pick == 3u), my = oy + (pick == 0u) - (pick == 2u);
-        const bool moved = !colocated && no > 0 && flee && inside(mx, my);
-        const uint32_t opp_t = moved ? (uint32_t)index(mx, my) : (uint32_t)oi;
-        const uint32_t w_tag = with_num_opp((w & ~(31u << 5)) | (opp_t << 5), no - (int)colocated);
         const bool tag = a == 4;
+        const uint32_t w_tag = with_num_opp(w, no - (int)colocated);
         const uint32_t wn = tag ? w_tag : ((w & ~31u) | agent_m);
         rew = tag ? (colocated ? 10.f : -10.f) : -1.f;
         ob = (!tag && ((wn >> 5) & 31u) == (wn & 31u)) ? p.obs_cells : (int)(wn & 31u);   // tag.py:219-226
         done = num_opp(wn) == 0;
         st.w = wn;
+        f.list = list; f.cnt = cnt; f.ox = ox; f.oy = oy;
+        f.need = tag && !colocated && no > 0;
+    }
+    // the opponent's flight from words 0-2 of the lane's STEP block (tag.py:201-207)
+    static __device__ __forceinline__ void flee(const Params &p, State &st, const Flight &f, uint32_t w0, uint32_t w1,
+                                                uint32_t w2)
+    {
+        const uint32_t pick = (f.list >> (2 * (w2 & (uint32_t)(f.cnt - 1)))) & 3u;   // cnt is 2 or 4 off the agent's cell
+        const int mx = f.ox + (pick == 1u) - (pick == 3u), my = f.oy + (pick == 0u) - (pick == 2u);
+        const bool moved = f.need && k53(w0, w1) <= p.move_thr && inside(mx, my);
+        if (moved) st.w = (st.w & ~(31u << 5)) | ((uint32_t)index(mx, my) << 5);
+    }
+    template <class RT>
+    static __device__ __forceinline__ void step_one_opponent(const Params &p, State &st, int a, const RngKey &key,
+                                                             uint32_t lane, int &ob, RT &rew, int &done)
+    {
+        Flight f;
+        step_one_opponent_pre(p, st, a, ob, rew, done, f);
+        const uint4 blk = stream_block(key, lane, POMDP_STREAM_STEP, 0u);
+        flee(p, st, f, blk.x, blk.y, blk.z);
+    }
+    // reset() from the four words of block 0 of the lane's RESET stream (tag.py:181-193: randint(29) per cell, each a
+    // masked-rejection loop); false when the rejections ran past the block (probability < 1e-3) — the caller then
+    // takes the general path
+    static __device__ __forceinline__ bool reset_from_block(const Params &p, State &st, const uint4 &b)
+    {
+        const uint32_t wd[4] = {b.x, b.y, b.z, b.w};
+        uint32_t w = 0; int have = 0;
+        const int want = 1 + p.num_opponents;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t v = wd[j] & 31u;
+            if (have < want && v <= 28u) { w |= v << (5 * have); ++have; }
+        }
+        if (have < want) return false;
+        st.w = with_num_opp(w, p.num_opponents);
+        return true;
     }
 
     // tag.py:108-143 step, 201-207 move_opponent, 260-280 _admissable_actions

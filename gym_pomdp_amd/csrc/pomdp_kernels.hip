@@ -176,6 +176,85 @@ struct Finisher<RockEnv<W, ABLATE, false>, 2, CHAIN> {
     }
 };
 
+// Tag with two lanes per thread: only a failed TAG on a live opponent draws (about a fifth of the lanes under a random
+// policy) and resets are rare (episodes last hundreds of steps), so per-lane Philox blocks would be mostly wasted.
+// ONE task list per wave (128 lanes): for CHAIN launches the 32 policy blocks of the next call counter, one STEP block
+// per lane whose opponent may flee, one RESET block per resetting lane — ~58 blocks for 128 lane-steps instead of 256
+// (512 chained), dealt out 64 per pass through a wave-private LDS scratch like RockSample's.  The lane step runs
+// without the flight (TagEnv::step_one_opponent_pre) and TagEnv::flee completes it from the pooled words.
+// More than one opponent (wave-uniform, from the params): the general per-lane path.
+template <bool CHAIN>
+struct Finisher<TagEnv, 2, CHAIN> {
+    using Env = TagEnv;
+    using Aux = typename Env::Flight;
+    static constexpr bool HAS_PREPASS = false;
+    template <class RT>
+    static __device__ __forceinline__ void lane_step(const typename Env::Shared &sh, const typename Env::Params &p,
+                                                     typename Env::State &st, int a, const RngKey &key, uint32_t lane,
+                                                     int &ob, RT &rew, int &done, Aux &aux)
+    {
+        if (p.num_opponents == 1) Env::step_one_opponent_pre(p, st, a, ob, rew, done, aux);
+        else { aux.need = false; Env::step(sh, p, st, a, key, lane, ob, rew, done); }
+    }
+    static __device__ __forceinline__ void run(const typename Env::Shared &sh, const typename Env::Params &p,
+                                               typename Env::State (&st)[2], const bool (&fresh)[2], const RngKey &key,
+                                               const uint32_t (&lane)[2], const RngKey &akey, uint32_t n_act,
+                                               int (&a_next)[2], const Aux (&aux)[2], int (&)[2])
+    {
+        if (p.num_opponents != 1) {                                            // wave-uniform
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (CHAIN) Env::reset_where_chain(sh, p, st[j], fresh[j], key, lane[j], akey, n_act, a_next[j]);
+                else Env::reset_where(sh, p, st[j], fresh[j], key, lane[j]);
+            }
+            return;
+        }
+        __shared__ uint8_t src_lds[BLOCK / 64][128];         // task rank -> virtual lane (me + 64 * sub-batch)
+        __shared__ uint32_t res_lds[BLOCK / 64][32 + 128][4];   // [0,32): policy blocks (sub-batch, quad); then task results
+        const int wv = (int)(threadIdx.x >> 6), me = (int)(threadIdx.x & 63u);
+        // flights first, resets after them: a lane is never both (a failed TAG does not end the episode)
+        const uint64_t f0 = __ballot(aux[0].need), f1 = __ballot(aux[1].need);
+        const uint64_t r0 = __ballot(fresh[0]), r1 = __ballot(fresh[1]);
+        const int nf0 = __popcll(f0), nfl = nf0 + __popcll(f1), nr0 = __popcll(r0), ntsk = nfl + nr0 + __popcll(r1);
+        auto below = [&](uint64_t m) {
+            return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        };
+        const int rank[2] = {aux[0].need ? below(f0) : nfl + below(r0),
+                             aux[1].need ? nf0 + below(f1) : nfl + nr0 + below(r1)};
+        if (aux[0].need || fresh[0]) src_lds[wv][rank[0]] = (uint8_t)me;
+        if (aux[1].need || fresh[1]) src_lds[wv][rank[1]] = (uint8_t)(me + 64);
+        constexpr int NA = CHAIN ? 32 : 0;
+        const int ntask = NA + ntsk;
+        const uint32_t first0 = lane[0] - (uint32_t)me, first1 = lane[1] - (uint32_t)me;   // first lane of each sub-batch
+        for (int base = 0; base < ntask; base += 64) {
+            const int tid = base + me;
+            if (tid < ntask) {
+                const bool is_act = tid < NA;
+                const int r = is_act ? 0 : tid - NA;
+                const int v = (int)src_lds[wv][r & 127];
+                const uint32_t src_lane = ((v >> 6) ? first1 : first0) + (uint32_t)(v & 63);
+                const uint32_t quad = (((tid >> 4) ? first1 : first0) >> 2) + (uint32_t)(tid & 15);
+                const uint32_t c0 = is_act ? quad : src_lane;
+                const uint32_t c1 = is_act ? akey.t_lo : key.t_lo, c2 = is_act ? akey.t_hi : key.t_hi;
+                const uint32_t strm = is_act ? POMDP_STREAM_ACTION : (r < nfl ? POMDP_STREAM_STEP : POMDP_STREAM_RESET);
+                const uint4 w = philox4x32_10(c0, c1, c2, strm << 24, key.k0, key.k1);
+                uint32_t *dst = res_lds[wv][is_act ? tid : 32 + (r & 127)];
+                dst[0] = w.x; dst[1] = w.y; dst[2] = w.z; dst[3] = w.w;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const uint32_t *res = res_lds[wv][32 + (rank[j] & 127)];
+            if (aux[j].need) Env::flee(p, st[j], aux[j], res[0], res[1], res[2]);
+            if (fresh[j]) {
+                const uint4 b = make_uint4(res[0], res[1], res[2], res[3]);
+                if (!Env::reset_from_block(p, st[j], b)) Env::reset(sh, p, st[j], key, lane[j]);   // rejections ran past the block
+            }
+            if (CHAIN) a_next[j] = (int)__umulhi(res_lds[wv][16 * j + (me >> 2)][me & 3], n_act);
+        }
+    }
+};
+
 // CHAIN (C-side rollout driver only): after stepping, action[i] is overwritten with the synthetic
 // policy's action for call counter t + 1 (key `akey`), so the next launch finds its input ready and
 // no separate policy kernel runs.

@@ -544,6 +544,9 @@ def test_episode_statistics_match_the_reference_probes():
     ("rock", dict(board_size=15, num_rocks=15), 19, None),     # two-lanes-per-thread launch, per-sub-batch fallback
     ("stochrock", {}, 20, None),
     ("rock", {}, 20, 777),                                     # distinct policy key: plain two-lanes-per-thread launches
+    ("tag", {}, 20, None),                                     # Tag's pooled pass (flights + resets + chained policy)
+    ("tag", {}, 19, 777),                                      # the same from plain launches
+    ("tag", dict(num_opponents=2), 19, None),                  # two lanes per thread, general multi-opponent path
 ])
 def test_large_batch_windows_vs_oracle(oracle_lib, env, kw, log2n, policy_seed):
     """Big batches (the launch geometry switches to two lanes per thread at 2^19 lanes): windows of lanes at the
@@ -567,6 +570,31 @@ def test_large_batch_windows_vs_oracle(oracle_lib, env, kw, log2n, policy_seed):
         assert np.array_equal(np_(e._done[sl]), done)
     del e
     torch.cuda.empty_cache()
+
+
+def test_tag_pooled_resets_including_the_rejection_fallback(oracle_lib):
+    """Every lane of a 2^18-lane Tag batch tags its opponent in the same step, so all of them start a new episode
+    inside the pooled pass: most resets come from the four words of the pooled RESET block, the lanes whose
+    masked-rejection draws run past that block (a few in a thousand) take the general path.  All against the oracle."""
+    n, seed, lane0 = 1 << 18, 99, 1 << 19
+    e = make_env("tag", {}, batch_size=n, seed=seed, lane_offset=lane0)
+    e.reset()
+    cell = (torch.arange(n, device="cuda", dtype=torch.int64) * 7) % 29
+    packed = (cell | (cell << 5) | (1 << 25)).to(torch.int32).reshape(1, n)
+    e.set_state(packed)
+    t = e.call_counter
+    ob, rew, done, _ = e.step(torch.full((n,), 4, dtype=torch.int32, device="cuda"))
+    o = oracle_lib.OracleEnv("tag")
+    st = np_(packed).view(np.uint32).copy()
+    ob_o, rew_o, done_o, _ = o.batch_step(st, np.full(n, 4, np.int32), seed, lane0, t, nthreads=4)
+    assert bool(done.all()) and done_o.all()
+    assert np.array_equal(np_(ob), ob_o) and np.array_equal(np_(rew), rew_o)
+    assert np.array_equal(np_(e.state).view(np.uint32), st)
+    # the fallback was exercised: some lanes' first four RESET words hold fewer than two accepted draws
+    from oracle import philox_ref as px
+    lanes = np.arange(lane0, lane0 + 4096)
+    acc = np.array([(px.stream_words(seed, int(l), t, px.STREAM_RESET, 4) & 31 <= 28).sum() for l in lanes])
+    assert (acc < 2).sum() > 0
 
 
 def test_split_layout_ties():
