@@ -44,7 +44,7 @@ def traffic_json(root, out_path, workload):
     out = {"workload": workload, "fetch_correction": "x2 (gfx950 FETCH_SIZE reports half of a coalesced stream; "
            "calibrated: the step kernels read exactly 8192 KB of state + action per launch)",
            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of `python bench.py --steps 100 "
-                     "--no-cpu-baseline` (tools/gpu_profile.sh)"}
+                     "--no-cpu-baseline` (tools/gpu_profile_round.sh)"}
     for key, pat in (("plain", "%step_kernel<%>, _, false>(%"), ("chain", "%step_kernel<%>, _, true>(%")):
         vals = []
         for db, cn in ((f, "FETCH_SIZE"), (w, "WRITE_SIZE")):
