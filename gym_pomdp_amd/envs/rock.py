@@ -153,6 +153,18 @@ class RockEnv(BatchedEnv):
         cols = [v & 15, (v >> 4) & 15] + [((v >> (8 + 2 * j)) & 3) - 1 for j in range(self.num_rocks)]
         return torch.stack(cols, dim=1)
 
+    def _decode_state(self, state, as_array=True):
+        """Inverse of `_encode_state` for a batch (the reference's `_decode_state` builds a RockState from its
+        dict encoding, rock.py:196-212): int [N, 1 + K] = [x_size * y + x, status..] -> packed int32
+        [state_words, N] as set_state() takes it."""
+        s = torch.as_tensor(state, device=self.device).to(torch.int64).reshape(-1, 1 + self.num_rocks)
+        v = (s[:, 0] % self.board_size) | ((s[:, 0] // self.board_size) << 4)
+        for j in range(self.num_rocks):
+            v = v | ((s[:, 1 + j] + 1) << (8 + 2 * j))
+        words = [v & 0xFFFFFFFF] + ([v >> 32] if self.state_words == 2 else [])
+        words = [torch.where(w >= 1 << 31, w - (1 << 32), w).to(torch.int32) for w in words]
+        return torch.stack(words, dim=0)
+
     def _encode_state(self, state=None):
         """The reference's array encoding of the state, `[x_size * y + x, status_0 .. status_{K-1}]`
         (rock.py:196-212 `_decode_state(as_array=True)`, 376-381 `__dict2np__`): int64 [N, 1 + K]."""

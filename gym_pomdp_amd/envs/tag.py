@@ -47,6 +47,19 @@ class TagEnv(BatchedEnv):
         d = self.decode_state() if state is None else state
         return d[:, : 1 + self.num_opponents].to(torch.int32)
 
+    def _decode_state(self, state):
+        """The reference's `_decode_state` (tag.py:167-179) for a batch: encoded int [N, 1 + num_opponents] ->
+        packed int32 [1, N] as set_state() takes it; num_opp counts the opponent entries > -1, like the reference."""
+        s = torch.as_tensor(state, device=self.device).to(torch.int64).reshape(-1, 1 + self.num_opponents)
+        w = s[:, 0] & 31
+        num = torch.zeros_like(w)
+        for j in range(self.num_opponents):
+            opp = s[:, 1 + j]
+            num = num + (opp > -1).to(torch.int64)
+            w = w | ((opp.clamp(min=0) & 31) << (5 + 5 * j))
+        w = w | ((num & 0x7F) << 25)
+        return torch.where(w >= 1 << 31, w - (1 << 32), w).to(torch.int32).reshape(1, -1)
+
     def decode_state(self):
         """int64 [N, 2 + num_opponents] = [agent cell, opponent cells.., num_opp] (tag.py:158-165 order)."""
         w = self._state[0].to(torch.int64) & 0xFFFFFFFF

@@ -35,3 +35,18 @@ class TigerEnv(BatchedEnv):
 
     def decode_state(self):
         return (self._state[0].to(torch.int64) & 1).unsqueeze(1)
+
+    def step(self, action):
+        if self.batch_size == 1:
+            self.last_action = int(action)           # tiger.py:76, used by render
+        return super().step(action)
+
+    def render(self, mode="ansi", close=False, lane=0):
+        """tiger.py:90-101, the text mode (the reference's own line indexes the integer action and raises; the
+        message is kept, the action printed as it is)."""
+        if close:
+            return
+        if mode != "ansi":
+            raise NotImplementedError("only the text renderer exists here (SURVEY.md §2: GUI out of scope)")
+        print("Current step: {}, tiger is in state: {}, action took: {}".format(
+            self.call_counter, int(self.decode_state()[lane, 0].item()), getattr(self, "last_action", None)))

@@ -803,3 +803,32 @@ def test_fused_heuristic_steps_match_the_call_sequence(env, kw, n, T, auto):
                 x, y = ea.belief[k], eb.belief[k]
                 assert bool(((x == y) | (x.isnan() & y.isnan() if x.is_floating_point() else False)).all()), (t, k)
     assert int(ea._done.sum()) >= 0
+
+
+def test_encoded_state_round_trips(capsys):
+    """Host-side views: _encode_state -> _decode_state -> set_state reproduces the packed state
+    (RockSample one and two words, Tag with several opponents); the text renderers print."""
+    for env, kw in (("rock", {}), ("rock", dict(board_size=15, num_rocks=15)), ("tag", dict(num_opponents=3))):
+        e = make_env(env, kw, batch_size=4096, seed=5)
+        e.reset()
+        for _ in range(6):
+            e.step(e.synthetic_actions())
+        packed = e.state.clone()
+        enc = e._encode_state()
+        dec = e._decode_state(enc)
+        if env == "tag":    # the reference's decoding is lossy: num_opp becomes the number of listed opponents (tag.py:171-173)
+            assert torch.equal(dec & 0x01FFFFFF, packed & 0x01FFFFFF) and bool(((dec >> 25) == 3).all())
+        else:
+            assert torch.equal(dec, packed), (env, kw)
+        e.set_state(dec)
+        assert torch.equal(e.state, dec)
+    t = make_env("tiger", {}, batch_size=1, seed=1)
+    t.reset()
+    t.step(2)
+    t.render()
+    n = make_env("network", {}, batch_size=1, seed=1)
+    n.reset()
+    n.step(3)
+    n.render()
+    out = capsys.readouterr().out
+    assert "tiger is in state" in out and "M: 1 A: 1" in out

@@ -12,7 +12,7 @@ cd /tmp
 rocprofv3 --kernel-trace --stats -d $W/trace -o t -- python $REPO/bench.py --steps 2000 --no-cpu-baseline > $W/bench_traced.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $W/pmc_fetch -o f -- python $REPO/bench.py --steps 100 --no-cpu-baseline > $W/bench_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $W/pmc_write -o w -- python $REPO/bench.py --steps 100 --no-cpu-baseline > $W/bench_write.log 2>&1
-(echo "# tools/gpu_profile_round.sh $TAG: python bench.py --steps 2000 --no-cpu-baseline under rocprofv3 (MI355X)"; python $REPO/tools/rocpd_summary.py $W | cut -c1-300) > $OUT/headline.txt
+(echo "# tools/gpu_profile_round.sh $TAG: python bench.py --steps 2000 --no-cpu-baseline under rocprofv3 (MI355X)"; python $REPO/tools/rocpd_summary.py $W | awk '{ if (substr($0,1,1)=="{") print; else print substr($0,1,300) }') > $OUT/headline.txt
 python $REPO/tools/rocpd_summary.py $W --traffic $OUT/traffic.json "RockSample(7,8) 2^20 lanes"
 # 2. instruction / occupancy counters of the step kernels
 cd $REPO
@@ -25,17 +25,17 @@ cd /tmp
 for e in rock15 tag battleship tiger network; do
   rm -rf $W/e; mkdir -p $W/e
   rocprofv3 --kernel-trace --stats -d $W/e/trace -o e -- python $REPO/bench.py --env $e --steps 1500 --warmup 300 --no-cpu-baseline > $W/e/bench_traced.log 2>&1
-  (echo "##### bench.py --env $e --steps 1500 --warmup 300 --no-cpu-baseline"; python $REPO/tools/rocpd_summary.py $W/e | cut -c1-260) >> $OUT/envs.txt
+  (echo "##### bench.py --env $e --steps 1500 --warmup 300 --no-cpu-baseline"; python $REPO/tools/rocpd_summary.py $W/e | awk '{ if (substr($0,1,1)=="{") print; else print substr($0,1,260) }') >> $OUT/envs.txt
 done
 for e in rock15 rock; do
   rm -rf $W/e; mkdir -p $W/e
   rocprofv3 --kernel-trace --stats -d $W/e/trace -o e -- python $REPO/bench.py --env $e --mode rollout --lanes-per-gpu 2097152 --steps 200 --warmup 100 > $W/e/bench_traced.log 2>&1
-  (echo "##### bench.py --env $e --mode rollout --lanes-per-gpu 2097152 --steps 200 --warmup 100"; python $REPO/tools/rocpd_summary.py $W/e | cut -c1-260) >> $OUT/envs.txt
+  (echo "##### bench.py --env $e --mode rollout --lanes-per-gpu 2097152 --steps 200 --warmup 100"; python $REPO/tools/rocpd_summary.py $W/e | awk '{ if (substr($0,1,1)=="{") print; else print substr($0,1,260) }') >> $OUT/envs.txt
 done
 for e in rock rock15 tag; do
   rm -rf $W/e; mkdir -p $W/e
   rocprofv3 --kernel-trace --stats -d $W/e/trace -o e -- python $REPO/bench.py --env $e --mode heuristic --steps 500 --warmup 100 > $W/e/bench_traced.log 2>&1
-  (echo "##### bench.py --env $e --mode heuristic --steps 500 --warmup 100"; python $REPO/tools/rocpd_summary.py $W/e | cut -c1-260) >> $OUT/envs.txt
+  (echo "##### bench.py --env $e --mode heuristic --steps 500 --warmup 100"; python $REPO/tools/rocpd_summary.py $W/e | awk '{ if (substr($0,1,1)=="{") print; else print substr($0,1,260) }') >> $OUT/envs.txt
 done
 # 4. the default bench line, unprofiled
 cd $REPO
