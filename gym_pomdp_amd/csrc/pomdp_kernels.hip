@@ -259,11 +259,12 @@ struct Finisher<TagEnv, 2, CHAIN> {
 // policy's action for call counter t + 1 (key `akey`), so the next launch finds its input ready and
 // no separate policy kernel runs.
 template <class Env, int LPT, bool CHAIN = false>
-__global__ __launch_bounds__(BLOCK) void step_kernel(const typename Env::Params p, uint32_t *__restrict__ state,
+__global__ __launch_bounds__(BLOCK) void step_kernel(uint32_t *__restrict__ state,
                                                      typename std::conditional<CHAIN, int32_t, const int32_t>::type *__restrict__ action,
                                                      int32_t *__restrict__ ob, typename Env::Reward *__restrict__ reward,
                                                      uint8_t *__restrict__ done, uint32_t *__restrict__ err,
-                                                     int64_t n, RngKey key, uint32_t lane0, int flags, RngKey akey = RngKey())
+                                                     int64_t n, RngKey key, uint32_t lane0, int flags, RngKey akey,
+                                                     const typename Env::Params p)   // pointers first: what a wave needs first
 {
     __shared__ typename Env::Shared sh;
     const bool auto_reset = flags & POMDP_AUTO_RESET;
@@ -763,10 +764,10 @@ static int launch_step(const typename Env::Params &p, uint32_t *state, const int
     // otherwise (measured equal within 2 % for the generic envs, tools/microbench.hip).
     if (Env::POOLED_LPT2 && n >= LPT2_MIN_LANES)
         hipLaunchKernelGGL((step_kernel<Env, 2>), dim3((unsigned)((n + 2 * BLOCK - 1) / (2 * BLOCK))), dim3(BLOCK), 0,
-                           (hipStream_t)stream, p, state, action, ob, reward, done, err, n, make_key(seed, t), lane0, flags);
+                           (hipStream_t)stream, state, action, ob, reward, done, err, n, make_key(seed, t), lane0, flags, RngKey(), p);
     else
-        hipLaunchKernelGGL((step_kernel<Env, 1>), dim3(blocks_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, p, state,
-                           action, ob, reward, done, err, n, make_key(seed, t), lane0, flags);
+        hipLaunchKernelGGL((step_kernel<Env, 1>), dim3(blocks_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, state,
+                           action, ob, reward, done, err, n, make_key(seed, t), lane0, flags, RngKey(), p);
     return (int)hipGetLastError();
 }
 
@@ -780,12 +781,11 @@ static int launch_step_chain(const typename Env::Params &p, uint32_t *state, int
     if (n == 0) return 0;
     if (Env::POOLED_LPT2 && n >= LPT2_MIN_LANES)
         hipLaunchKernelGGL((step_kernel<Env, 2, true>), dim3((unsigned)((n + 2 * BLOCK - 1) / (2 * BLOCK))), dim3(BLOCK),
-                           0, (hipStream_t)stream, p, state, action, ob, reward, done, err, n, make_key(seed, t), lane0,
-                           flags, make_key(action_seed, t + 1));
+                           0, (hipStream_t)stream, state, action, ob, reward, done, err, n, make_key(seed, t), lane0,
+                           flags, make_key(action_seed, t + 1), p);
     else
-        hipLaunchKernelGGL((step_kernel<Env, 1, true>), dim3(blocks_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, p,
-                           state, action, ob, reward, done, err, n, make_key(seed, t), lane0, flags,
-                           make_key(action_seed, t + 1));
+        hipLaunchKernelGGL((step_kernel<Env, 1, true>), dim3(blocks_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob, reward, done, err, n, make_key(seed, t), lane0, flags,
+                           make_key(action_seed, t + 1), p);
     return (int)hipGetLastError();
 }
 

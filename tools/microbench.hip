@@ -163,27 +163,27 @@ int main(int argc, char **argv)
         auto run = [&](auto env_tag, const char *name) {
             using E = decltype(env_tag);
             printf("%-28s: LPT1 %8.2f", name, time_it([&](int t) {
-                hipLaunchKernelGGL((step_kernel<E, 1>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, p, state, action, ob, reward, done, err, n, make_key(1, t), 0u, 1);
+                hipLaunchKernelGGL((step_kernel<E, 1>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, state, action, ob, reward, done, err, n, make_key(1, t), 0u, 1, RngKey(), p);
             }, iters));
             printf("  LPT2 %8.2f", time_it([&](int t) {
-                hipLaunchKernelGGL((step_kernel<E, 2>), dim3((unsigned)((n + 511) / 512)), dim3(256), 0, 0, p, state, action, ob, reward, done, err, n, make_key(1, t), 0u, 1);
+                hipLaunchKernelGGL((step_kernel<E, 2>), dim3((unsigned)((n + 511) / 512)), dim3(256), 0, 0, state, action, ob, reward, done, err, n, make_key(1, t), 0u, 1, RngKey(), p);
             }, iters));
             printf("  LPT4 %8.2f\n", time_it([&](int t) {
-                hipLaunchKernelGGL((step_kernel<E, 4>), dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, 0, p, state, action, ob, reward, done, err, n, make_key(1, t), 0u, 1);
+                hipLaunchKernelGGL((step_kernel<E, 4>), dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, 0, state, action, ob, reward, done, err, n, make_key(1, t), 0u, 1, RngKey(), p);
             }, iters));
         };
         run(RockEnv<1, 0>{}, "step full");
         {
             using E = RockEnv<1, 0>;
             printf("%-28s: LPT1 %8.2f", "chain step", time_it([&](int t) {
-                hipLaunchKernelGGL((step_kernel<E, 1, true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, p, state, action, ob, reward, done, err, n, make_key(1, t), 0u, 1, make_key(1, t + 1));
+                hipLaunchKernelGGL((step_kernel<E, 1, true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, state, action, ob, reward, done, err, n, make_key(1, t), 0u, 1, make_key(1, t + 1), p);
             }, iters));
             printf("  LPT2 %8.2f", time_it([&](int t) {
-                hipLaunchKernelGGL((step_kernel<E, 2, true>), dim3((unsigned)((n + 511) / 512)), dim3(256), 0, 0, p, state, action, ob, reward, done, err, n, make_key(1, t), 0u, 1, make_key(1, t + 1));
+                hipLaunchKernelGGL((step_kernel<E, 2, true>), dim3((unsigned)((n + 511) / 512)), dim3(256), 0, 0, state, action, ob, reward, done, err, n, make_key(1, t), 0u, 1, make_key(1, t + 1), p);
             }, iters));
             for (int lds_kb : {24, 36, 48, 72}) {   // occupancy limited by a dummy dynamic-LDS request
                 printf("  LPT2/lds%dk %6.2f", lds_kb, time_it([&](int t) {
-                    hipLaunchKernelGGL((step_kernel<E, 2, true>), dim3((unsigned)((n + 511) / 512)), dim3(256), lds_kb * 1024, 0, p, state, action, ob, reward, done, err, n, make_key(1, t), 0u, 1, make_key(1, t + 1));
+                    hipLaunchKernelGGL((step_kernel<E, 2, true>), dim3((unsigned)((n + 511) / 512)), dim3(256), lds_kb * 1024, 0, state, action, ob, reward, done, err, n, make_key(1, t), 0u, 1, make_key(1, t + 1), p);
                 }, iters));
             }
             printf("\n");
@@ -191,20 +191,20 @@ int main(int argc, char **argv)
         {   // ABLATE 8: the data-independent Philox pass runs after the loads were consumed instead of under their latency
             using E = RockEnv<1, 8>;
             printf("%-28s: plain LPT2 %8.2f", "late prepass (ablate 8)", time_it([&](int t) {
-                hipLaunchKernelGGL((step_kernel<E, 2>), dim3((unsigned)((n + 511) / 512)), dim3(256), 0, 0, p, state, action, ob, reward, done, err, n, make_key(1, t), 0u, 1);
+                hipLaunchKernelGGL((step_kernel<E, 2>), dim3((unsigned)((n + 511) / 512)), dim3(256), 0, 0, state, action, ob, reward, done, err, n, make_key(1, t), 0u, 1, RngKey(), p);
             }, iters));
             printf("  chain LPT2 %8.2f\n", time_it([&](int t) {
-                hipLaunchKernelGGL((step_kernel<E, 2, true>), dim3((unsigned)((n + 511) / 512)), dim3(256), 0, 0, p, state, action, ob, reward, done, err, n, make_key(1, t), 0u, 1, make_key(1, t + 1));
+                hipLaunchKernelGGL((step_kernel<E, 2, true>), dim3((unsigned)((n + 511) / 512)), dim3(256), 0, 0, state, action, ob, reward, done, err, n, make_key(1, t), 0u, 1, make_key(1, t + 1), p);
             }, iters));
         }
         {
             auto nt = [&](auto env_tag, const char *name) {
                 using E = decltype(env_tag);
                 printf("%-28s: plain LPT2 %8.2f", name, time_it([&](int t) {
-                    hipLaunchKernelGGL((step_kernel<E, 2>), dim3((unsigned)((n + 511) / 512)), dim3(256), 0, 0, p, state, action, ob, reward, done, err, n, make_key(1, t), 0u, 1);
+                    hipLaunchKernelGGL((step_kernel<E, 2>), dim3((unsigned)((n + 511) / 512)), dim3(256), 0, 0, state, action, ob, reward, done, err, n, make_key(1, t), 0u, 1, RngKey(), p);
                 }, iters));
                 printf("  chain LPT2 %8.2f\n", time_it([&](int t) {
-                    hipLaunchKernelGGL((step_kernel<E, 2, true>), dim3((unsigned)((n + 511) / 512)), dim3(256), 0, 0, p, state, action, ob, reward, done, err, n, make_key(1, t), 0u, 1, make_key(1, t + 1));
+                    hipLaunchKernelGGL((step_kernel<E, 2, true>), dim3((unsigned)((n + 511) / 512)), dim3(256), 0, 0, state, action, ob, reward, done, err, n, make_key(1, t), 0u, 1, make_key(1, t + 1), p);
                 }, iters));
             };
             nt(RockEnv<1, 16>{}, "cached loads/stores (ablate 16)");
@@ -246,7 +246,7 @@ int main(int argc, char **argv)
             for (double pace_us : {0.0, 3.0, 5.0, 6.5}) {
                 hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
                 auto launch = [&](int t) {
-                    hipLaunchKernelGGL((step_kernel<E, 2, true>), dim3((unsigned)((n + 511) / 512)), dim3(256), 0, strm, p, state, action, ob, reward, done, err, n, make_key(1, t), 0u, 1, make_key(1, t + 1));
+                    hipLaunchKernelGGL((step_kernel<E, 2, true>), dim3((unsigned)((n + 511) / 512)), dim3(256), 0, strm, state, action, ob, reward, done, err, n, make_key(1, t), 0u, 1, make_key(1, t + 1), p);
                 };
                 for (int i = 0; i < 10; ++i) launch(i);
                 CK(hipDeviceSynchronize());
@@ -278,9 +278,9 @@ int main(int argc, char **argv)
                 for (int k = 0; k < S; ++k) {
                     const int64_t o = k * part;
                     if (part >= (1 << 18))
-                        hipLaunchKernelGGL((step_kernel<E, 2, true>), dim3((unsigned)((part + 511) / 512)), dim3(256), 0, st[k], p, state + o, action + o, ob + o, reward + o, done + o, err, part, make_key(1, t), (uint32_t)o, 1, make_key(1, t + 1));
+                        hipLaunchKernelGGL((step_kernel<E, 2, true>), dim3((unsigned)((part + 511) / 512)), dim3(256), 0, st[k], state + o, action + o, ob + o, reward + o, done + o, err, part, make_key(1, t), (uint32_t)o, 1, make_key(1, t + 1), p);
                     else
-                        hipLaunchKernelGGL((step_kernel<E, 1, true>), dim3((unsigned)((part + 255) / 256)), dim3(256), 0, st[k], p, state + o, action + o, ob + o, reward + o, done + o, err, part, make_key(1, t), (uint32_t)o, 1, make_key(1, t + 1));
+                        hipLaunchKernelGGL((step_kernel<E, 1, true>), dim3((unsigned)((part + 255) / 256)), dim3(256), 0, st[k], state + o, action + o, ob + o, reward + o, done + o, err, part, make_key(1, t), (uint32_t)o, 1, make_key(1, t + 1), p);
                 }
             };
             for (int i = 0; i < 10; ++i) body(i);
