@@ -76,9 +76,10 @@ class BatchedEnv(object):
         self._ob = torch.zeros(n, dtype=torch.int32, device=self.device)
         self._reward = torch.zeros(n, dtype=self.reward_dtype, device=self.device)
         if n == 1:
-            # scalar mode (the reference's usage): ob / reward / done share one 16-byte device buffer so that a
-            # step is one launch + one pinned D2H copy; the action is passed as a pointer into a device-resident
-            # table of all action values, so there is no per-step H2D copy either
+            # scalar mode (the reference's usage): the step kernel writes ob / reward / done straight into 16 bytes of
+            # pinned host memory (device-visible under unified addressing), so a step is one launch + one stream
+            # synchronisation, no copy; the action is passed as a pointer into a device-resident table of all action
+            # values, so there is no per-step H2D copy either
             self._scalar_buf = torch.zeros(4, dtype=torch.int32, device=self.device)
             self._ob = self._scalar_buf[0:1]
             self._reward = self._scalar_buf[1:2].view(self.reward_dtype)
@@ -86,6 +87,10 @@ class BatchedEnv(object):
             self._action_table = torch.arange(n_actions, dtype=torch.int32, device=self.device)
             self._host_out = torch.zeros(4, dtype=torch.int32).pin_memory()
             self._host_reward = self._host_out[1:2].view(self.reward_dtype)
+            self._host_ob_t = self._host_out[0:1]
+            self._host_done_t = self._host_out[2:3].view(torch.uint8)[0:1]
+            hp = self._host_out.data_ptr()
+            self._host_ptrs = (hp, hp + 4, hp + 8)
         self._has_reset = False
         self._last_reset = None
         self._scalar_done = False
@@ -124,6 +129,8 @@ class BatchedEnv(object):
                                 self._seed, self.lane_offset, t, self._stream())
             _native.check(rc, "pomdp_%s_reset" % self.env_name)
             self._done.zero_()
+            if self.batch_size == 1:
+                self._host_out[2] = 0            # the done flag the scalar step keeps in pinned host memory
             if self._tracker is not None:
                 self._tracker.on_reset()
         self._has_reset = True
@@ -187,15 +194,14 @@ class BatchedEnv(object):
         self._t += 1
         with torch.cuda.device(self.device):
             stream = torch.cuda.current_stream(self.device)
-            ptrs = self._ptrs
-            rc = self._step_fn(self._params_ref, ptrs[0], self._action_table.data_ptr() + 4 * action, ptrs[1], ptrs[2],
-                               ptrs[3], ptrs[4], 1, self._seed, self.lane_offset, t,
+            ptrs, hp = self._ptrs, self._host_ptrs
+            rc = self._step_fn(self._params_ref, ptrs[0], self._action_table.data_ptr() + 4 * action, hp[0], hp[1],
+                               hp[2], ptrs[4], 1, self._seed, self.lane_offset, t,
                                _native.POMDP_AUTO_RESET if self.auto_reset else 0, stream.cuda_stream)
             _native.check(rc, "pomdp_%s_step" % self.env_name)
             if self._tracker is not None:
-                self._tracker.on_step(self._action_table[action:action + 1], self._ob, self._done,
+                self._tracker.on_step(self._action_table[action:action + 1], self._host_ob_t, self._host_done_t,
                                       _native.POMDP_AUTO_RESET if self.auto_reset else 0)
-            self._host_out.copy_(self._scalar_buf, non_blocking=True)
             stream.synchronize()
         d = bool(self._host_out[2].item() & 0xFF)
         self._scalar_done = d
@@ -236,6 +242,8 @@ class BatchedEnv(object):
         """Overwrite the packed lane state (planner hook `_set_state`; tensor copy)."""
         self._state.copy_(torch.as_tensor(state, dtype=torch.int32, device=self.device).reshape(self._state.shape))
         self._done.zero_()
+        if self.batch_size == 1:
+            self._host_out[2] = 0
         self._scalar_done = False
         self._has_reset = True
         self.done = False if self.batch_size == 1 else self._done.view(torch.bool)
