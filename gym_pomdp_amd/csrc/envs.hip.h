@@ -1137,24 +1137,41 @@ struct NetworkEnv {
         for (int i = 0; i < M; ++i) nb_failed |= ((~s0 & p.nb_mask[i]) != 0u ? 1u : 0u) << i;
         const bool has_action = a < 2 * M;
         const int n_draws = __popc(s0) + (has_action ? 1 : 0);
+        // Split word layout: double j compares by its high word — element j & 3 of block 2 (j >> 2) —
+        // and needs its low word (same element of the next block) only on a tie, probability 2^-27 per draw.  One
+        // Philox block therefore serves four draws instead of two.  Thresholds as (high 27 bits, low 26 bits).
+        constexpr uint32_t LO = (1u << 26) - 1u;
+        const uint32_t th_fail = (uint32_t)(p.fail_thr >> 26), tl_fail = (uint32_t)p.fail_thr & LO;
+        const uint32_t th_nb = (uint32_t)(p.fail_nb_thr >> 26), tl_nb = (uint32_t)p.fail_nb_thr & LO;
+        const uint32_t th_obs = (uint32_t)(p.obs_thr >> 26), tl_obs = (uint32_t)p.obs_thr & LO;
         uint32_t todo = s0;
         uint4 blk = make_uint4(0, 0, 0, 0);
-        uint64_t k_action = 0;
+        bool truthful = false;
         for (int j = 0; __any(j < n_draws); ++j) {
-            if ((j & 1) == 0) blk = stream_block(key, lane, POMDP_STREAM_STEP, (uint32_t)(j >> 1));
-            const uint64_t k = (j & 1) ? k53(blk.z, blk.w) : k53(blk.x, blk.y);
-            if (todo != 0u) {                                                    // network.py:94-99
-                const int i = __ffs((int)todo) - 1;
+            if ((j & 3) == 0) blk = stream_block(key, lane, POMDP_STREAM_STEP, 2u * (uint32_t)(j >> 2));
+            const uint32_t H = (j & 3) == 0 ? blk.x : (j & 3) == 1 ? blk.y : (j & 3) == 2 ? blk.z : blk.w;
+            const bool machine_draw = todo != 0u;                                // network.py:94-99, else the action's draw
+            const int i = __ffs((int)todo) - 1;
+            const bool nbf = machine_draw && ((nb_failed >> (i & 31)) & 1u);
+            const uint32_t th = machine_draw ? (nbf ? th_nb : th_fail) : th_obs;
+            const uint32_t tl = machine_draw ? (nbf ? tl_nb : tl_fail) : tl_obs;
+            const uint32_t kh = H >> 5;
+            bool le = kh < th;                                                   // k53 <= thr, decided by the high word
+            if (kh == th) {                                                      // tie: fetch the low word
+                const uint4 lo = stream_block(key, lane, POMDP_STREAM_STEP, 2u * (uint32_t)(j >> 2) + 1u);
+                const uint32_t L = (j & 3) == 0 ? lo.x : (j & 3) == 1 ? lo.y : (j & 3) == 2 ? lo.z : lo.w;
+                le = (L >> 6) <= tl;
+            }
+            if (machine_draw) {
+                if (!le) s &= ~(1u << i);                                        // fails iff k > thr
                 todo &= todo - 1u;
-                if (k > (((nb_failed >> i) & 1u) ? p.fail_nb_thr : p.fail_thr)) s &= ~(1u << i);
             } else if (j < n_draws) {
-                k_action = k;
+                truthful = le;
             }
         }
         ob = 2;
         if (has_action) {                                                        // network.py:101-112
             const int machine = a >> 1;
-            const int truthful = k_action <= p.obs_thr;
             if (a & 1) { r -= 2.5; s |= 1u << machine; ob = truthful; }
             else { r -= .1; const int up = (int)((s >> machine) & 1u); ob = truthful ? up : 1 - up; }
         }

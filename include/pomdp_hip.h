@@ -29,7 +29,8 @@
  * ctr = (lane, t lo, t hi, stream_id << 24 | block); numpy legacy constructions on
  * top (res53 doubles, masked-rejection randint).  RockSample / StochasticRock lay their doubles out
  * "split": high word of double j in block 2(j/4) [reset] or 2j [step, counter word 0 = lane / 4, element
- * lane % 4], low word in the following block, generated only when the high word leaves a comparison undecided.
+ * lane % 4], low word in the following block, generated only when the high word leaves a comparison undecided;
+ * Network's step uses the per-lane form (block 2(j/4), element j % 4) for its one-double-per-machine draws.
  */
 #ifndef POMDP_HIP_H
 #define POMDP_HIP_H

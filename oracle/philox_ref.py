@@ -18,8 +18,9 @@ oracle/pomdp_oracle.c and gym_pomdp_amd/csrc/philox.hip.h):
     randint n: mask = bit-smear(n - 1); draw words until (w & mask) <= n - 1
     binomial(1, p): one double, compared against a captured integer threshold.
 
-RockSample / StochasticRock deviate from "strictly sequential" in how the words are laid out (not in how numpy
-consumes them): see rock_reset_words / rock_step_words below (split high / low blocks, quad-shared step stream).
+RockSample / StochasticRock and Network's step() deviate from "strictly sequential" in how the words are laid out (not
+in how numpy consumes them): see split_words / rock_reset_words / rock_step_words below (split high / low blocks,
+RockSample's quad-shared step stream).
 
 Streams: 0 np.random draws made inside step(); 1 np.random draws made inside
 reset(); 2 / 3 the gym-space RNG (Discrete.sample) inside step() / reset()
@@ -77,6 +78,19 @@ def _block(seed, c0, t, stream, block):
                     (int(stream) << 24) | int(block)], dtype=np.uint64)
     key = np.array([int(seed) & 0xFFFFFFFF, (int(seed) >> 32) & 0xFFFFFFFF], dtype=np.uint64)
     return philox4x32_10(ctr, key)
+
+
+def split_words(seed, lane, t, stream, n_doubles):
+    """Per-lane *split layout* of a stream whose draws are all doubles: double j takes its high word from element
+    j & 3 of block 2 (j >> 2) and its low word from the same element of block 2 (j >> 2) + 1; the kernels generate
+    the odd ("low") blocks only when a high word leaves a comparison undecided.  Returns the 2 * n_doubles words
+    numpy consumes, in order.  Used by RockSample's RESET stream and Network's STEP stream."""
+    out = []
+    for j in range(n_doubles):
+        hi = _block(seed, lane, t, stream, 2 * (j >> 2))[j & 3]
+        lo = _block(seed, lane, t, stream, 2 * (j >> 2) + 1)[j & 3]
+        out += [int(hi), int(lo)]
+    return np.array(out, dtype=np.uint32)
 
 
 def rock_reset_words(seed, lane, t, n_rocks):

@@ -83,6 +83,8 @@ void or_ws_philox_env(or_ws *ws, int env_kind, uint64_t seed, uint32_t lane, uin
     or_ws_philox(ws, seed, lane, t, stream);
     if (env_kind == OR_ENV_ROCK && stream == OR_STREAM_RESET) ws->layout = 1;
     if (env_kind == OR_ENV_ROCK && stream == OR_STREAM_STEP) { ws->layout = 2; ws->ctr[0] = lane >> 2; }
+    /* Network: every draw of step() is a double too (one per up machine, one for the action): per-lane split layout */
+    if (env_kind == OR_ENV_NETWORK && stream == OR_STREAM_STEP) ws->layout = 1;
 }
 
 uint32_t or_ws_next32(or_ws *ws)

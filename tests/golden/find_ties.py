@@ -74,5 +74,36 @@ def main(n_reset=6, n_sensor=8):
     print("state0 of tied rocks:", [int(tr["state0"][i][2 + r]) for i, (_, r) in enumerate(reset_ties)])
 
 
+def main_network(n_ties=5):
+    """Network-v0 (10 machines): after reset every machine is up, so the first step draws doubles 0..9 against the
+    p = .1 failure threshold and double 10 (action 0 = ping machine 0) against the .95 observation threshold — split
+    layout, high words in elements of blocks 0, 2, 4 of the lane's STEP stream.  Ties on any of them."""
+    thr = json.load(open(os.path.join(HERE, "thresholds.json")))
+    th_fail, th_obs = thr["net_fail"]["thr"] >> 26, thr["net_obs"]["thr"] >> 26
+    ties, lane = [], 0
+    while len(ties) < n_ties:
+        c0 = np.arange(lane, lane + CHUNK, dtype=np.uint64)
+        for g in (0, 1, 2):
+            kh = blocks(c0, 1, px.STREAM_STEP, 2 * g) >> np.uint32(5)
+            for li, e in zip(*np.nonzero(kh == th_fail)):
+                if 4 * g + int(e) < 10:
+                    ties.append((int(c0[li]), 4 * g + int(e)))
+            if g == 2:
+                for li in np.nonzero(kh[:, 2] == th_obs)[0]:
+                    ties.append((int(c0[li]), 10))
+        lane += CHUNK
+        print("searched", lane, "found", len(ties), flush=True)
+    ties = ties[:n_ties]
+    lanes = [ln for ln, _ in ties]
+    tr = h.trace_mode_b("network", {}, SEED, lanes, np.zeros((len(lanes), 1), np.int64), t0=0)
+    np.savez_compressed(os.path.join(HERE, "ties_network.npz"), seed=np.int64(SEED), lanes=np.array(lanes, np.int64),
+                        tied_draw=np.array([j for _, j in ties], np.int64), ob=tr["ob"][:, 0], reward=tr["reward"][:, 0],
+                        state=tr["state"][:, 0])
+    print("network ties (lane, draw):", ties)
+
+
 if __name__ == "__main__":
-    main()
+    if "--network" in sys.argv:
+        main_network()
+    else:
+        main()

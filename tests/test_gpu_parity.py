@@ -619,6 +619,24 @@ def test_split_layout_ties():
             assert (int(ob[col]), int(rew[col]), int(done[col])) == (int(g["ob"][i]), int(g["reward"][i]), int(g["done"][i])), (lane, n)
 
 
+def test_network_split_layout_ties():
+    """The 2^-27 path of Network's split word layout (fixture ties_network.npz: the reference on lanes where a failure
+    or observation draw is undecided by its high word)."""
+    import os
+    from conftest import GOLDEN
+    g = dict(np.load(os.path.join(GOLDEN, "ties_network.npz")))
+    seed = int(g["seed"])
+    for i, lane in enumerate(g["lanes"]):
+        lane = int(lane)
+        base = lane & ~3
+        e = make_env("network", {}, batch_size=4, seed=seed, lane_offset=base)
+        e.reset()
+        ob, rew, done, _ = e.step(torch.zeros(4, dtype=torch.int32, device="cuda"))
+        col = lane - base
+        assert int(ob[col]) == int(g["ob"][i]) and float(rew[col]) == float(np.float32(g["reward"][i])), lane
+        assert np.array_equal(np_(e.decode_state()[col]), g["state"][i]), lane
+
+
 # ---- heuristic policy support (SURVEY.md §8f rank 3) -----------------------------------------------------------
 from conftest import OracleHeuristicOps, golden_manifest, heuristic_replay  # noqa: E402
 

@@ -254,6 +254,25 @@ def test_split_layout_ties_oracle(oracle_lib):
         assert int(w[2 * int(g["tied_rock"][i])]) >> 5 == 1 << 26
 
 
+def test_network_split_layout_ties_oracle(oracle_lib):
+    """Network draws decided by the low word (fixture ties_network.npz from tests/golden/find_ties.py --network)."""
+    import json
+    g = dict(np.load(os.path.join(GOLDEN, "ties_network.npz")))
+    thr = json.load(open(os.path.join(GOLDEN, "thresholds.json")))
+    o = oracle_lib.OracleEnv("network")
+    seed = int(g["seed"])
+    from oracle import philox_ref as px
+    for i, lane in enumerate(g["lanes"]):
+        st = o.new_state(1)
+        o.batch_reset(st, seed, int(lane), 0)
+        ob, rew, done, _ = o.batch_step(st, [0], seed, int(lane), 1)
+        assert int(ob[0]) == int(g["ob"][i]) and float(rew[0]) == np.float32(g["reward"][i])
+        assert np.array_equal(o.batch_compact(st)[0], g["state"][i])
+        j = int(g["tied_draw"][i])
+        want = thr["net_obs"]["thr"] if j == 10 else thr["net_fail"]["thr"]
+        assert int(px.split_words(seed, int(lane), 1, px.STREAM_STEP, 11)[2 * j]) >> 5 == want >> 26   # really a tie
+
+
 # ---- heuristic policy support (SURVEY.md §8f rank 3) -------------------------------------------------------
 HEUR = [tuple(c) for c in golden_manifest().get("heuristic_cases", [])]
 
