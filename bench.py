@@ -177,9 +177,11 @@ def heuristic_mode(args, gpa, env_id, kwargs, cp, dev, rank, world, label, n, la
     elapsed = cp.max(time.perf_counter() - t0)
     cp.barrier()
     kern_ms = ev0.elapsed_time(ev1) / args.steps
-    # algorithmic bytes per lane-step: what one launch must read and write per lane
-    K = env.num_rocks if is_rock else 0
-    alg = (4 + 4 + 4 + K * (4 + 4 + 4 + 8)) + (4 + 4 + 4 + 4 + 1 + 4 + 4 + 4 + 4) + (0 if is_rock else 8)
+    # algorithmic bytes per lane-step: what one launch must read and write per lane whatever the action —
+    # read state, history size, prev_ob and the two derived words (Tag: last_action / last_ob instead): 20 B;
+    # write state, action, ob, reward, done, prev_ob, size, last_action, last_ob: 33 B; a CHECK's statistics update
+    # (one rock's five fields and two sums) is not counted
+    alg = 20 + 33 + 8 * (env.state_words - 1)
     achieved = alg * n / (kern_ms * 1e-3) / 1e9
     if rank == 0:
         print(json.dumps({

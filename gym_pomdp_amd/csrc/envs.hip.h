@@ -337,10 +337,15 @@ struct RockEnv {
                                                               const pomdp_rock_belief &b, const pomdp_history &h,
                                                               int64_t n, uint32_t i)
     {
+        return preferred_mask(sh, p, st, h, n, i, ld_stream(b.check_ok + i), ld_stream(h.move_ok + i), ld_stream(h.size + i));
+    }
+    // the same with the lane's three per-lane words already loaded (the fused kernel issues those loads up front)
+    static __device__ __forceinline__ uint32_t preferred_mask(const Shared &sh, const Params &p, const State &st,
+                                                              const pomdp_history &h, int64_t n, uint32_t i, uint32_t ck,
+                                                              uint32_t mv, int hsize)
+    {
         const S s = st.s;
         const int x = (int)(s & 15u), y = (int)((s >> 4) & 15u), K = p.num_rocks;
-        const uint32_t ck = b.check_ok[i], mv = h.move_ok[i];
-        const int hsize = h.size[i];
         const int id = sh.grid[x * 16 + y];
         if (id >= 0 && id < K && ((uint32_t)(s >> (8 + 2 * (id & 15))) & 3u) != 1u && hsize != 0)
             if (h.total_sample[(int64_t)id * n + i] > 0) return 1u << 4;                          // rock.py:300-313
@@ -558,11 +563,17 @@ struct TagEnv {
 
     // tag.py:231-243 _generate_preferred as a bitmask (ascending order is the reference's list order); tag.py:68-74
     // is_corner, coord.py:75-77 opposite.  history.size == 0 gives the legal list (all five actions).
-    static __device__ __forceinline__ uint32_t preferred_mask(const Shared &, const Params &, const State &st,
+    static __device__ __forceinline__ uint32_t preferred_mask(const Shared &sh, const Params &p, const State &st,
                                                               const pomdp_rock_belief &, const pomdp_history &h,
-                                                              int64_t, uint32_t i)
+                                                              int64_t n, uint32_t i)
     {
-        if (h.size[i] == 0) return 0x1Fu;
+        return preferred_mask(sh, p, st, h, n, i, 0u, 0u, ld_stream(h.size + i));
+    }
+    static __device__ __forceinline__ uint32_t preferred_mask(const Shared &, const Params &, const State &st,
+                                                              const pomdp_history &h, int64_t, uint32_t i, uint32_t,
+                                                              uint32_t, int hsize)
+    {
+        if (hsize == 0) return 0x1Fu;
         const int agent = (int)(st.w & 31u);
         int x, y;
         coord(agent, x, y);
@@ -964,6 +975,9 @@ struct BattleShipEnv {
     static __device__ __forceinline__ uint32_t preferred_mask(const Shared &, const Params &, const State &,
                                                               const pomdp_rock_belief &, const pomdp_history &, int64_t,
                                                               uint32_t) { return 0u; }
+    static __device__ __forceinline__ uint32_t preferred_mask(const Shared &, const Params &, const State &,
+                                                              const pomdp_history &, int64_t, uint32_t, uint32_t, uint32_t,
+                                                              int) { return 0u; }
     // battleship.py:80-89 _compute_prob (reads the grid as it is after the shot)
     static __device__ __forceinline__ double compute_prob(const Shared &, const Params &, const State &st, int a, int ob)
     {
@@ -1037,6 +1051,9 @@ struct TigerEnv {
     static __device__ __forceinline__ uint32_t preferred_mask(const Shared &, const Params &, const State &,
                                                               const pomdp_rock_belief &, const pomdp_history &, int64_t,
                                                               uint32_t) { return 0u; }
+    static __device__ __forceinline__ uint32_t preferred_mask(const Shared &, const Params &, const State &,
+                                                              const pomdp_history &, int64_t, uint32_t, uint32_t, uint32_t,
+                                                              int) { return 0u; }
     // tiger.py:125-138 _compute_prob
     static __device__ __forceinline__ double compute_prob(const Shared &, const Params &, const State &st, int a, int ob)
     {
@@ -1112,6 +1129,9 @@ struct NetworkEnv {
     static __device__ __forceinline__ uint32_t preferred_mask(const Shared &, const Params &, const State &,
                                                               const pomdp_rock_belief &, const pomdp_history &, int64_t,
                                                               uint32_t) { return 0u; }
+    static __device__ __forceinline__ uint32_t preferred_mask(const Shared &, const Params &, const State &,
+                                                              const pomdp_history &, int64_t, uint32_t, uint32_t, uint32_t,
+                                                              int) { return 0u; }
     // network.py:43-55 _compute_prob
     static __device__ __forceinline__ double compute_prob(const Shared &, const Params &p, const State &st, int a, int ob)
     {

@@ -556,28 +556,28 @@ __global__ __launch_bounds__(BLOCK) void heuristic_step_kernel(const typename En
                                                                int flags)
 {
     __shared__ typename Env::Shared sh;
-    Env::stage(sh, p, (int)threadIdx.x);
-    __syncthreads();
     const bool auto_reset = flags & POMDP_AUTO_RESET;
     const uint32_t idx = blockIdx.x * (uint32_t)BLOCK + threadIdx.x;
     const bool in_range = (uint64_t)idx < (uint64_t)n;
     const uint32_t i = in_range ? idx : (uint32_t)(n - 1);
     const uint32_t lane = lane0 + i;
+    // every per-lane word first (one memory latency), then the tables, then the Philox block that depends on the lane id only
     typename Env::State st;
     Env::load(st, state, n, i);
-    const bool was_done = auto_reset ? false : (done[i] != 0);
-    // the policy: a = list[(w * len(list)) >> 32] over the preferred list (ascending mask order) or the legal list
+    const int hsize = ld_stream(h.size + i), pob = ld_stream(prev_ob + i);
+    const uint32_t ck = K ? ld_stream(b.check_ok + i) : 0u, mv = K ? ld_stream(h.move_ok + i) : 0u;
+    const bool was_done = auto_reset ? false : (ld_stream(done + i) != 0);
+    // policy word: element lane & 3 of the quad's ACTION block
     const uint32_t e = lane & 3u;
     const uint4 wq = stream_block(key, lane >> 2, POMDP_STREAM_ACTION, 0u);
     const uint32_t word = e == 0 ? wq.x : e == 1 ? wq.y : e == 2 ? wq.z : wq.w;
-    uint32_t m = Env::preferred_mask(sh, p, st, b, h, n, i);
+    Env::stage(sh, p, (int)threadIdx.x);
+    __syncthreads();
+    // the policy: a = list[(w * len(list)) >> 32] over the preferred list (ascending mask order) or the legal list
+    const uint32_t m = Env::preferred_mask(sh, p, st, h, n, i, ck, mv, hsize);
     int a;
-    if (m) {
-        for (int k = (int)__umulhi(word, (uint32_t)__popc(m)); k > 0; --k) m &= m - 1u;
-        a = __ffs((int)m) - 1;
-    } else {
-        a = Env::legal_nth(sh, p, st, (int)__umulhi(word, (uint32_t)Env::legal_count(sh, p, st)));
-    }
+    if (m) a = nth_set_bit(m, (int)__umulhi(word, (uint32_t)__popc(m)));
+    else a = Env::legal_nth(sh, p, st, (int)__umulhi(word, (uint32_t)Env::legal_count(sh, p, st)));
     const bool live = in_range && !was_done;
     int o, d;
     typename Env::Reward r;
@@ -586,10 +586,10 @@ __global__ __launch_bounds__(BLOCK) void heuristic_step_kernel(const typename En
     const bool fresh = live && d && auto_reset;
     Env::reset_where(sh, p, st, fresh, key, lane);                             // wave-cooperative: every lane calls it
     if (!in_range) return;
-    action[i] = live ? a : -1;
-    ob[i] = o;
-    reward[i] = r;
-    done[i] = (uint8_t)d;
+    st_stream(action + i, (int32_t)(live ? a : -1));
+    st_stream(ob + i, (int32_t)o);
+    st_stream(reward + i, r);
+    st_stream(done + i, (uint8_t)d);
     if (!live) return;
     Env::store(st, state, n, i, fresh);
     if (fresh) {                                                               // new episode: fresh Rock objects, empty History
@@ -598,17 +598,17 @@ __global__ __launch_bounds__(BLOCK) void heuristic_step_kernel(const typename En
             b.count[k] = 0; b.measured[k] = 0; b.lkv[k] = 1.; b.lkw[k] = 1.; b.prob_valuable[k] = .5;
             h.total_sample[k] = 0; h.total_move[k] = 0;
         }
-        if (K) { b.check_ok[i] = (1u << K) - 1u; h.move_ok[i] = (1u << K) - 1u; }
-        h.size[i] = 0; h.last_action[i] = -1; h.last_ob[i] = -1;
-        prev_ob[i] = Env::reset_ob(p, st);
+        if (K) { st_stream(b.check_ok + i, (1u << K) - 1u); st_stream(h.move_ok + i, (1u << K) - 1u); }
+        st_stream(h.size + i, 0); st_stream(h.last_action + i, -1); st_stream(h.last_ob + i, -1);
+        st_stream(prev_ob + i, (int32_t)Env::reset_ob(p, st));
         return;
     }
-    h.size[i] += 1; h.last_action[i] = a; h.last_ob[i] = o;                    // a terminal transition is recorded too
+    st_stream(h.size + i, hsize + 1); st_stream(h.last_action + i, (int32_t)a); st_stream(h.last_ob + i, (int32_t)o);   // terminal transitions too
     if (a >= 5 && a < 5 + K) {                                                 // K > 0: RockSample CHECK
-        history_check_sums(h, a - 5, o, prev_ob[i], n, i);
+        history_check_sums(h, a - 5, o, pob, n, i);
         if (o != 0 && !d) heuristic_belief_update<Env>(sh, p, st, a, o, b, n, i);
     }
-    prev_ob[i] = o;
+    st_stream(prev_ob + i, (int32_t)o);
 }
 
 // Lane i simulates from root state column i / sims_per_root for up to `depth` steps: the state lives in registers
