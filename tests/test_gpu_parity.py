@@ -572,6 +572,30 @@ def test_large_batch_windows_vs_oracle(oracle_lib, env, kw, log2n, policy_seed):
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("env,kw", [("rock", {}), ("tag", {}), ("rock", dict(board_size=15, num_rocks=15))],
+                         ids=["rock_7_8", "tag_1", "rock_15_15"])
+def test_ragged_batch_on_the_pooled_path(oracle_lib, env, kw):
+    """A batch that ends inside a workgroup (2^18 + 260 lanes, lane ids past 2^31): the out-of-range threads of the last
+    two-lanes-per-thread workgroup take part in the pooled passes but must not leak into any result."""
+    n, seed, lane0, steps, win = (1 << 18) + 260, 4242, (1 << 31) + 4, 12, 1024
+    e = make_env(env, kw, batch_size=n, seed=seed, lane_offset=lane0, reuse_buffers=True)
+    guard = torch.full((64,), 0x5A5A5A5A, dtype=torch.int32, device="cuda")      # right behind nothing we own: just a canary
+    e.reset()
+    e.rollout_synthetic(steps)
+    torch.cuda.synchronize()
+    o = oracle_lib.OracleEnv(env, **kw)
+    off = n - win
+    st = o.new_state(win)
+    o.batch_reset(st, seed, lane0 + off, 0, nthreads=4)
+    for t in range(1, steps + 1):
+        a = oracle_lib.synthetic_actions(win, seed, lane0 + off, t, o.n_actions, nthreads=4)
+        ob, rew, done, _ = o.batch_step(st, a, seed, lane0 + off, t, nthreads=4)
+    assert np.array_equal(np_(e.state[:, off:]).view(np.uint32), st)
+    assert np.array_equal(np_(e._ob[off:]), ob) and np.array_equal(np_(e._reward[off:]), rew)
+    assert np.array_equal(np_(e._done[off:]), done)
+    assert bool((guard == 0x5A5A5A5A).all()) and e.invalid_action_count() == 0
+
+
 def test_tag_pooled_resets_including_the_rejection_fallback(oracle_lib):
     """Every lane of a 2^18-lane Tag batch tags its opponent in the same step, so all of them start a new episode
     inside the pooled pass: most resets come from the four words of the pooled RESET block, the lanes whose
