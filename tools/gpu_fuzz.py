@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep (dev aid, GPU box): random env configs, batch sizes (both launch geometries), lane offsets,
+call counters, auto-reset on/off, valid and invalid actions — HIP path vs the oracle, word for word.
+usage: python tools/gpu_fuzz.py [seconds]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import torch  # noqa: E402
+import gym_pomdp_amd as gpa  # noqa: E402
+from oracle import oracle_lib as ol  # noqa: E402
+
+CONFIGS = [
+    ("rock", "Rock-v0", {}), ("rock", "Rock-v0", dict(board_size=7, num_rocks=7)),
+    ("rock", "Rock-v0", dict(board_size=11, num_rocks=11)), ("rock", "Rock-v0", dict(board_size=15, num_rocks=15)),
+    ("rock", "Rock-v0", dict(board_size=4, num_rocks=3)), ("stochrock", "StochasticRock-v0", {}),
+    ("tag", "Tag-v0", {}), ("tag", "Tag-v0", dict(num_opponents=2)), ("tag", "Tag-v0", dict(num_opponents=4)),
+    ("battleship", "Battleship-v0", {}), ("battleship", "Battleship-v0", dict(board_size=(10, 10), max_len=5)),
+    ("battleship", "Battleship-v0", dict(board_size=(8, 6), max_len=4)),
+    ("tiger", "Tiger-v0", {}), ("network", "Network-v0", {}), ("network", "Network-v0", dict(n_machines=16, problem_type=1)),
+    ("network", "Network-v0", dict(n_machines=31, problem_type=3)),
+]
+
+
+def main(budget):
+    rs = np.random.RandomState(int(time.time()) & 0xFFFFFF)
+    t_end, cases = time.time() + budget, 0
+    while time.time() < t_end:
+        name, env_id, kw = CONFIGS[rs.randint(len(CONFIGS))]
+        big = rs.rand() < 0.3
+        n = int(rs.randint(1 << 18, (1 << 18) + 3000)) if big else int(rs.randint(2, 6000))
+        lane0 = int(rs.randint(0, 1 << 30)) * 4 % ((1 << 32) - n - 8)
+        seed = int(rs.randint(1 << 62))
+        t0 = int(rs.randint(1 << 40)) if rs.rand() < 0.5 else int(rs.randint(100))
+        auto = bool(rs.rand() < 0.7)
+        steps = 6 if big else 30
+        e = gpa.make(env_id, batch_size=n, seed=seed, lane_offset=lane0, auto_reset=auto, **kw)
+        e.call_counter = t0
+        o = ol.OracleEnv(name, **kw)
+        st = o.new_state(n)
+        ob_o = o.batch_reset(st, seed, lane0, t0, nthreads=8)
+        ob_g = e.reset()
+        assert np.array_equal(ob_g.cpu().numpy(), ob_o), (name, kw, n, "reset ob")
+        done = np.zeros(n, np.uint8)
+        bad_total = 0
+        for k in range(steps):
+            t = t0 + 1 + k
+            a = rs.randint(o.n_actions, size=n).astype(np.int32)
+            if rs.rand() < 0.3:                                  # a few out-of-range actions
+                idx = rs.randint(n, size=max(1, n // 500))
+                a[idx] = rs.choice([-1, o.n_actions, 1 << 20], size=len(idx))
+            ob_o, rew_o, done, bad = o.batch_step(st, a, seed, lane0, t, auto_reset=auto, done=done, nthreads=8)
+            bad_total += bad
+            ob_g, rew_g, done_g, _ = e.step(torch.as_tensor(a, device="cuda"))
+            ctx = (name, kw, n, lane0, seed, t, auto)
+            assert np.array_equal(ob_g.cpu().numpy(), ob_o), ctx
+            assert np.array_equal(rew_g.cpu().numpy(), rew_o), ctx
+            assert np.array_equal(done_g.cpu().numpy(), done.astype(bool)), ctx
+            assert np.array_equal(e.state.cpu().numpy().view(np.uint32), st), ctx
+        assert e.invalid_action_count() == bad_total, (name, kw, n)
+        cases += 1
+        del e
+    print("fuzz ok: %d random cases in %.0f s" % (cases, budget))
+
+
+if __name__ == "__main__":
+    main(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0)
