@@ -91,6 +91,9 @@ class BatchedEnv(object):
             self._host_done_t = self._host_out[2:3].view(torch.uint8)[0:1]
             hp = self._host_out.data_ptr()
             self._host_ptrs = (hp, hp + 4, hp + 8)
+            self._host_np = self._host_out.numpy()                       # same memory, cheap scalar reads
+            self._host_reward_np = self._host_reward.numpy()
+            self._action_base = self._action_table.data_ptr()
         self._has_reset = False
         self._last_reset = None
         self._scalar_done = False
@@ -189,26 +192,31 @@ class BatchedEnv(object):
         return ob, reward, self.done, info
 
     def _scalar_step(self, action):
-        """batch_size == 1: one launch, one pinned device-to-host copy, python scalars out."""
+        """batch_size == 1: one launch writing into pinned host memory, one stream synchronisation, python scalars out."""
         t = self._t
-        self._t += 1
-        with torch.cuda.device(self.device):
-            stream = torch.cuda.current_stream(self.device)
-            ptrs, hp = self._ptrs, self._host_ptrs
-            rc = self._step_fn(self._params_ref, ptrs[0], self._action_table.data_ptr() + 4 * action, hp[0], hp[1],
-                               hp[2], ptrs[4], 1, self._seed, self.lane_offset, t,
-                               _native.POMDP_AUTO_RESET if self.auto_reset else 0, stream.cuda_stream)
+        self._t = t + 1
+        flags = _native.POMDP_AUTO_RESET if self.auto_reset else 0
+        if torch.cuda.current_device() != self.device.index:
+            with torch.cuda.device(self.device):
+                return self._scalar_launch(action, t, flags)
+        return self._scalar_launch(action, t, flags)
+
+    def _scalar_launch(self, action, t, flags):
+        stream = torch.cuda.current_stream(self.device)
+        ptrs, hp = self._ptrs, self._host_ptrs
+        rc = self._step_fn(self._params_ref, ptrs[0], self._action_base + 4 * action, hp[0], hp[1], hp[2], ptrs[4], 1,
+                           self._seed, self.lane_offset, t, flags, stream.cuda_stream)
+        if rc:
             _native.check(rc, "pomdp_%s_step" % self.env_name)
-            if self._tracker is not None:
-                self._tracker.on_step(self._action_table[action:action + 1], self._host_ob_t, self._host_done_t,
-                                      _native.POMDP_AUTO_RESET if self.auto_reset else 0)
-            stream.synchronize()
-        d = bool(self._host_out[2].item() & 0xFF)
+        if self._tracker is not None:
+            self._tracker.on_step(self._action_table[action:action + 1], self._host_ob_t, self._host_done_t, flags)
+        stream.synchronize()
+        h = self._host_np
+        d = bool(h[2] & 0xFF)
         self._scalar_done = d
         self.done = d
-        r = self._host_reward[0].item()
-        return (int(self._host_out[0].item()), (int(r) if self.reward_dtype == torch.int32 else float(r)), d,
-                {"state": self._state})
+        r = self._host_reward_np[0]
+        return int(h[0]), (int(r) if self.reward_dtype == torch.int32 else float(r)), d, {"state": self._state}
 
     def _as_action_tensor(self, action):
         if isinstance(action, torch.Tensor):
