@@ -268,20 +268,30 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(uint32_t *__restrict__ stat
 {
     __shared__ typename Env::Shared sh;
     const bool auto_reset = flags & POMDP_AUTO_RESET;
-    // 32-bit lane index (the ABI caps lane0 + n at 2^32): addresses become SGPR base + 32-bit VGPR offset
-    const uint32_t base = blockIdx.x * (uint32_t)(BLOCK * LPT) + threadIdx.x;
-    uint32_t idx[LPT];
+    // Addressing: the workgroup's first lane is wave-uniform, so every column gets a per-workgroup base pointer in
+    // SGPRs and a thread only ever adds a small 32-bit offset (rel < BLOCK * LPT) — `global_load/store v_off, s[base]`
+    // with no per-access 64-bit VALU arithmetic, for any n up to the ABI's 2^32 lanes.
+    const uint32_t wg0 = blockIdx.x * (uint32_t)(BLOCK * LPT);
+    const uint32_t last = (uint32_t)((uint64_t)(n - 1) - wg0);        // offset of lane n-1 (the grid has no empty workgroup)
+    auto *const action_w = action + wg0;
+    uint32_t *const state_w = state + wg0;
+    int32_t *const ob_w = ob + wg0;
+    typename Env::Reward *const reward_w = reward + wg0;
+    uint8_t *const done_w = done + wg0;
+    uint32_t idx[LPT], rel[LPT];
     bool in_range[LPT], was_done[LPT];
     int a_raw[LPT];
     typename Env::State st[LPT];
 #pragma unroll
     for (int j = 0; j < LPT; ++j) {
-        idx[j] = base + (uint32_t)(j * BLOCK);
-        in_range[j] = (uint64_t)idx[j] < (uint64_t)n;
-        const uint32_t ic = in_range[j] ? idx[j] : (uint32_t)(n - 1);
-        a_raw[j] = ld_stream<!(Env::ABL & 16)>(action + ic);
-        Env::load(st[j], state, n, ic);
-        was_done[j] = auto_reset ? false : (ld_stream(done + ic) != 0);   // frozen lane (the reference would assert)
+        rel[j] = threadIdx.x + (uint32_t)(j * BLOCK);
+        idx[j] = wg0 + rel[j];
+        in_range[j] = rel[j] <= last;
+        const uint32_t rc = in_range[j] ? rel[j] : last;               // out-of-range threads read lane n-1
+        __builtin_assume(rc < (uint32_t)(BLOCK * LPT));
+        a_raw[j] = ld_stream<!(Env::ABL & 16)>(action_w + rc);
+        Env::load(st[j], state_w, n, rc);
+        was_done[j] = auto_reset ? false : (ld_stream(done_w + rc) != 0);   // frozen lane (the reference would assert)
     }
     using Fin = Finisher<Env, LPT, CHAIN>;
     if constexpr (Fin::HAS_PREPASS) {
@@ -319,12 +329,12 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(uint32_t *__restrict__ stat
     for (int j = 0; j < LPT; ++j) {
         if (!live[j]) o[j] = 0;
         constexpr bool NT = !(Env::ABL & 16);
-        if (CHAIN) { if (in_range[j]) st_stream<NT>(const_cast<int32_t *>(action) + idx[j], (int32_t)a_next[j]); }
-        if (live[j]) Env::store(st[j], state, n, idx[j], fresh[j]);
+        if (CHAIN) { if (in_range[j]) st_stream<NT>(const_cast<int32_t *>(action_w) + rel[j], (int32_t)a_next[j]); }
+        if (live[j]) Env::store(st[j], state_w, n, rel[j], fresh[j]);
         if (in_range[j]) {
-            st_stream<NT>(ob + idx[j], (int32_t)o[j]);
-            st_stream<NT>(reward + idx[j], r[j]);
-            st_stream<NT>(done + idx[j], (uint8_t)d[j]);
+            st_stream<NT>(ob_w + rel[j], (int32_t)o[j]);
+            st_stream<NT>(reward_w + rel[j], r[j]);
+            st_stream<NT>(done_w + rel[j], (uint8_t)d[j]);
             // the reference asserts on an out-of-range action; here the lane is left untouched and counted
             if (!valid[j] && !was_done[j] && err) atomicAdd(err, 1u);
         }
