@@ -42,6 +42,30 @@ __global__ __launch_bounds__(BS) void traffic_kernel_bs(uint32_t *__restrict__ s
     }
 }
 
+// the same 21 B/lane with the product's streaming accessors (nt loads, write-through stores), one or two lanes per thread,
+// plus NB Philox blocks per thread of register-only work: the floor for a kernel that moves the step kernel's bytes
+template <int LPT, int NB>
+__global__ __launch_bounds__(256) void traffic_stream(uint32_t *__restrict__ state, const int32_t *__restrict__ action,
+                                                      int32_t *__restrict__ ob, int32_t *__restrict__ reward,
+                                                      uint8_t *__restrict__ done, int64_t n, RngKey key)
+{
+    const uint32_t wg0 = blockIdx.x * (uint32_t)(256 * LPT);
+    uint32_t s[LPT]; int a[LPT];
+#pragma unroll
+    for (int j = 0; j < LPT; ++j) { s[j] = ld_stream(state + wg0 + threadIdx.x + j * 256); a[j] = ld_stream(action + wg0 + threadIdx.x + j * 256); }
+    uint32_t acc = 0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) { const uint4 w = stream_block(key, wg0 + threadIdx.x, 0u, (uint32_t)b); acc ^= w.x ^ w.y ^ w.z ^ w.w; }
+#pragma unroll
+    for (int j = 0; j < LPT; ++j) {
+        const uint32_t i = wg0 + threadIdx.x + j * 256;
+        st_stream(state + i, s[j] + (uint32_t)a[j] + (acc & 1u));
+        st_stream(ob + i, (int32_t)(a[j] & 3));
+        st_stream(reward + i, (int32_t)(a[j] - 5));
+        st_stream(done + i, (uint8_t)(s[j] & 1u));
+    }
+}
+
 // BattleShip-shaped traffic: 8 state words in, 4 out, + action/ob/reward/done
 __global__ __launch_bounds__(256) void bs_traffic_soa(uint32_t *__restrict__ state, const int32_t *__restrict__ action,
                                                       int32_t *__restrict__ ob, int32_t *__restrict__ reward,
@@ -145,6 +169,18 @@ int main(int argc, char **argv)
     printf("traffic 21B  bs=256 1 lane/thr : %8.2f\n", time_it([&](int) { hipLaunchKernelGGL(traffic_kernel_bs<256>, dim3((unsigned)(n / 256)), dim3(256), 0, 0, state, action, ob, reward, done, n); }, iters));
     printf("traffic 21B  bs=512 1 lane/thr : %8.2f\n", time_it([&](int) { hipLaunchKernelGGL(traffic_kernel_bs<512>, dim3((unsigned)(n / 512)), dim3(512), 0, 0, state, action, ob, reward, done, n); }, iters));
     printf("traffic 21B  bs=1024 1 lane/thr: %8.2f\n", time_it([&](int) { hipLaunchKernelGGL(traffic_kernel_bs<1024>, dim3((unsigned)(n / 1024)), dim3(1024), 0, 0, state, action, ob, reward, done, n); }, iters));
+    printf("streamed 21B  1 lane/thr, +0/1/2/4/6 philox blocks : %6.2f %6.2f %6.2f %6.2f %6.2f\n",
+           time_it([&](int t) { hipLaunchKernelGGL((traffic_stream<1, 0>), dim3((unsigned)(n / 256)), dim3(256), 0, 0, state, action, ob, reward, done, n, make_key(1, t)); }, iters),
+           time_it([&](int t) { hipLaunchKernelGGL((traffic_stream<1, 1>), dim3((unsigned)(n / 256)), dim3(256), 0, 0, state, action, ob, reward, done, n, make_key(1, t)); }, iters),
+           time_it([&](int t) { hipLaunchKernelGGL((traffic_stream<1, 2>), dim3((unsigned)(n / 256)), dim3(256), 0, 0, state, action, ob, reward, done, n, make_key(1, t)); }, iters),
+           time_it([&](int t) { hipLaunchKernelGGL((traffic_stream<1, 4>), dim3((unsigned)(n / 256)), dim3(256), 0, 0, state, action, ob, reward, done, n, make_key(1, t)); }, iters),
+           time_it([&](int t) { hipLaunchKernelGGL((traffic_stream<1, 6>), dim3((unsigned)(n / 256)), dim3(256), 0, 0, state, action, ob, reward, done, n, make_key(1, t)); }, iters));
+    printf("streamed 21B  2 lanes/thr, +0/2/4/8/12 philox blocks: %6.2f %6.2f %6.2f %6.2f %6.2f\n",
+           time_it([&](int t) { hipLaunchKernelGGL((traffic_stream<2, 0>), dim3((unsigned)(n / 512)), dim3(256), 0, 0, state, action, ob, reward, done, n, make_key(1, t)); }, iters),
+           time_it([&](int t) { hipLaunchKernelGGL((traffic_stream<2, 2>), dim3((unsigned)(n / 512)), dim3(256), 0, 0, state, action, ob, reward, done, n, make_key(1, t)); }, iters),
+           time_it([&](int t) { hipLaunchKernelGGL((traffic_stream<2, 4>), dim3((unsigned)(n / 512)), dim3(256), 0, 0, state, action, ob, reward, done, n, make_key(1, t)); }, iters),
+           time_it([&](int t) { hipLaunchKernelGGL((traffic_stream<2, 8>), dim3((unsigned)(n / 512)), dim3(256), 0, 0, state, action, ob, reward, done, n, make_key(1, t)); }, iters),
+           time_it([&](int t) { hipLaunchKernelGGL((traffic_stream<2, 12>), dim3((unsigned)(n / 512)), dim3(256), 0, 0, state, action, ob, reward, done, n, make_key(1, t)); }, iters));
     printf("battleship traffic SoA dwords : %8.2f\n", time_it([&](int) { hipLaunchKernelGGL(bs_traffic_soa, dim3((unsigned)(n / 256)), dim3(256), 0, 0, bsstate, action, ob, reward, done, n); }, iters));
     printf("battleship traffic 16B/lane   : %8.2f\n", time_it([&](int) { hipLaunchKernelGGL(bs_traffic_v4, dim3((unsigned)(n / 256)), dim3(256), 0, 0, (uint4 *)bsstate, action, ob, reward, done, n); }, iters));
     for (int blocks : {256, 512, 1024, 2048}) {
