@@ -63,7 +63,7 @@ __global__ __launch_bounds__(BLOCK) void reset_kernel(const typename Env::Params
 // CHAIN launches, the synthetic policy's actions of the next call counter.  Generic form: Env::step per lane,
 // one Env::reset_where[_chain] per 64-lane sub-batch.
 // ---------------------------------------------------------------------------
-template <class Env, int LPT, bool CHAIN>
+template <class Env, int LPT, bool CHAIN, class = void>
 struct Finisher {
     struct Aux {};
     static constexpr bool HAS_PREPASS = false;
@@ -95,10 +95,12 @@ struct Finisher {
 // WITHOUT its sensor draw (Env::step_pre) and the observation is completed here from the pooled words.  Tasks and
 // results are exchanged through a wave-private LDS scratch; LDS operations of one wave complete in order, so no
 // barrier is involved.  Low words (needed with probability 2^-27 per draw) are generated per lane on demand.
-template <int W, int ABLATE, bool CHAIN>
-struct Finisher<RockEnv<W, ABLATE, false>, 2, CHAIN> {
+template <int W, int ABLATE, int LPT, bool CHAIN>
+struct Finisher<RockEnv<W, ABLATE, false>, LPT, CHAIN, typename std::enable_if<(LPT >= 2)>::type> {
     using Env = RockEnv<W, ABLATE, false>;
     using Aux = typename Env::Aux;
+    static constexpr int NQ = 16 * LPT;                      // quads (sensor blocks) of the wave's 64 * LPT lanes
+    static constexpr int NA = CHAIN ? 16 * LPT : 0;          // policy blocks of the next call counter
     template <class RT>
     static __device__ __forceinline__ void lane_step(const typename Env::Shared &sh, const typename Env::Params &p,
                                                      typename Env::State &st, int a, const RngKey &, uint32_t, int &ob,
@@ -108,70 +110,75 @@ struct Finisher<RockEnv<W, ABLATE, false>, 2, CHAIN> {
         ob = 0;
     }
     // wave-private LDS scratch (one instance each: function-local statics of these accessors)
-    static __device__ __forceinline__ uint32_t (&blk_lds())[BLOCK / 64][64][4]
+    static __device__ __forceinline__ uint32_t (&blk_lds())[BLOCK / 64][32 * LPT][4]
     {
-        __shared__ uint32_t a[BLOCK / 64][64][4];            // [0,32): sensor blocks, [32,64): policy blocks; (sub-batch, quad)
+        __shared__ uint32_t a[BLOCK / 64][32 * LPT][4];      // [0, NQ): sensor blocks, [NQ, 2 NQ): policy blocks; (sub-batch, quad)
         return a;
     }
-    // The data-independent half of the task list — the wave's 32 sensor blocks (lanes 0-31) and, for CHAIN launches,
-    // the 32 policy blocks of the next call counter (lanes 32-63) — depends on lane ids only, so the kernel runs it
-    // right after issuing its HBM loads: one Philox pass hidden under the load latency.
+    // The data-independent part of the task list — the wave's sensor blocks and, for CHAIN launches, the policy blocks
+    // of the next call counter — depends on lane ids only, so the kernel runs it right after issuing its HBM loads:
+    // Philox passes hidden under the load latency.  Sub-batch j of a thread is 256 j lanes further on.
     static constexpr bool HAS_PREPASS = !(ABLATE & 8);
-    static __device__ __forceinline__ void prepass(const RngKey &key, const uint32_t (&lane)[2], const RngKey &akey)
+    static __device__ __forceinline__ void prepass(const RngKey &key, const uint32_t (&lane)[LPT], const RngKey &akey)
     {
         const int wv = (int)(threadIdx.x >> 6), me = (int)(threadIdx.x & 63u);
-        const uint32_t first0 = lane[0] - (uint32_t)me, first1 = lane[1] - (uint32_t)me;   // first lane of each sub-batch
-        const bool is_act = me >= 32;
-        if (CHAIN || !is_act) {
-            const int qt = me & 31;                                            // (sub-batch, quad) index
-            const uint32_t quad = (((qt >> 4) ? first1 : first0) >> 2) + (uint32_t)(qt & 15);
-            const uint32_t c1 = is_act ? akey.t_lo : key.t_lo, c2 = is_act ? akey.t_hi : key.t_hi;
-            const uint32_t c3 = (uint32_t)(is_act ? POMDP_STREAM_ACTION : POMDP_STREAM_STEP) << 24;
-            const uint4 w = philox4x32_10(quad, c1, c2, c3, key.k0, key.k1);
-            uint32_t *dst = blk_lds()[wv][me];
-            dst[0] = w.x; dst[1] = w.y; dst[2] = w.z; dst[3] = w.w;
+        const uint32_t first0 = lane[0] - (uint32_t)me;                        // first lane of the wave's sub-batch 0
+#pragma unroll
+        for (int base = 0; base < NQ + NA; base += 64) {
+            const int tid = base + me;
+            if (tid < NQ + NA) {
+                const bool is_act = tid >= NQ;
+                const int qt = is_act ? tid - NQ : tid;                        // (sub-batch, quad) index
+                const uint32_t quad = ((first0 + (uint32_t)(qt >> 4) * BLOCK) >> 2) + (uint32_t)(qt & 15);
+                const uint32_t c1 = is_act ? akey.t_lo : key.t_lo, c2 = is_act ? akey.t_hi : key.t_hi;
+                const uint32_t c3 = (uint32_t)(is_act ? POMDP_STREAM_ACTION : POMDP_STREAM_STEP) << 24;
+                const uint4 w = philox4x32_10(quad, c1, c2, c3, key.k0, key.k1);
+                uint32_t *dst = blk_lds()[wv][tid];
+                dst[0] = w.x; dst[1] = w.y; dst[2] = w.z; dst[3] = w.w;
+            }
         }
     }
     static __device__ __forceinline__ void run(const typename Env::Shared &, const typename Env::Params &p,
-                                               typename Env::State (&st)[2], const bool (&fresh)[2], const RngKey &key,
-                                               const uint32_t (&lane)[2], const RngKey &akey, uint32_t n_act,
-                                               int (&a_next)[2], const Aux (&aux)[2], int (&ob)[2])
+                                               typename Env::State (&st)[LPT], const bool (&fresh)[LPT], const RngKey &key,
+                                               const uint32_t (&lane)[LPT], const RngKey &akey, uint32_t n_act,
+                                               int (&a_next)[LPT], const Aux (&aux)[LPT], int (&ob)[LPT])
     {
-        __shared__ uint8_t src_lds[BLOCK / 64][128];         // reset rank -> virtual lane (me + 64 * sub-batch)
-        __shared__ uint8_t res_lds[BLOCK / 64][128][4];      // reset rank -> four 2-bit rock codes per group g
+        __shared__ uint8_t src_lds[BLOCK / 64][64 * LPT];    // reset rank -> virtual lane (me + 64 * sub-batch)
+        __shared__ uint8_t res_lds[BLOCK / 64][64 * LPT][4]; // reset rank -> four 2-bit rock codes per group g
         const int wv = (int)(threadIdx.x >> 6), me = (int)(threadIdx.x & 63u);
         if (!HAS_PREPASS) prepass(key, lane, akey);
         const int K = p.num_rocks, NG = (K + 3) >> 2;        // high blocks per reset
-        const uint64_t m0 = __ballot(fresh[0]), m1 = __ballot(fresh[1]);
-        const int n0 = __popcll(m0), nres = n0 + __popcll(m1);
-        const int rank0 = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u));
-        const int rank1 = n0 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
-        if (fresh[0]) src_lds[wv][rank0] = (uint8_t)me;
-        if (fresh[1]) src_lds[wv][rank1] = (uint8_t)(me + 64);
+        int rank[LPT], nres = 0;
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) {
+            const uint64_t m = __ballot(fresh[j]);
+            rank[j] = nres + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            nres += __popcll(m);
+            if (fresh[j]) src_lds[wv][rank[j]] = (uint8_t)(me + 64 * j);
+        }
         const int ntask = NG * nres;                         // reset blocks: NG per resetting lane, 64 per pass
-        const uint32_t inv = (65536u + (uint32_t)NG - 1u) / (uint32_t)NG;   // t / NG == (t * inv) >> 16 for t < 512
-        const uint32_t first0 = lane[0] - (uint32_t)me, first1 = lane[1] - (uint32_t)me;
+        const uint32_t inv = (65536u + (uint32_t)NG - 1u) / (uint32_t)NG;   // t / NG == (t * inv) >> 16 for t < 16384
+        const uint32_t first0 = lane[0] - (uint32_t)me;
         for (int base = 0; base < ntask; base += 64) {
             const int rt = base + me;
             if (rt < ntask) {
                 const int r = (int)(((uint32_t)rt * inv) >> 16), g = rt - r * NG;
-                const int v = (int)src_lds[wv][r & 127];
-                const uint32_t src_lane = ((v >> 6) ? first1 : first0) + (uint32_t)(v & 63);
+                const int v = (int)src_lds[wv][r & (64 * LPT - 1)];
+                const uint32_t src_lane = first0 + (uint32_t)(v >> 6) * BLOCK + (uint32_t)(v & 63);
                 const uint4 w = philox4x32_10(src_lane, key.t_lo, key.t_hi,
                                               ((uint32_t)POMDP_STREAM_RESET << 24) | (2u * (uint32_t)g), key.k0, key.k1);
-                res_lds[wv][r & 127][g] = (uint8_t)Env::reset_group_codes(w, key, src_lane, g, K);
+                res_lds[wv][r & (64 * LPT - 1)][g] = (uint8_t)Env::reset_group_codes(w, key, src_lane, g, K);
             }
         }
         const uint32_t start = (uint32_t)p.start_x | ((uint32_t)p.start_y << 4);
         const uint32_t used = NG >= 4 ? 0xFFFFFFFFu : ((1u << (8 * NG)) - 1u);   // groups >= NG were never written
         const uint32_t *res32 = reinterpret_cast<const uint32_t *>(&res_lds[wv][0][0]);
-        if (fresh[0]) st[0].s = (typename Env::S)((uint64_t)start | ((uint64_t)(res32[rank0] & used) << 8));
-        if (fresh[1]) st[1].s = (typename Env::S)((uint64_t)start | ((uint64_t)(res32[rank1] & used) << 8));
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < LPT; ++j) {
+            if (fresh[j]) st[j].s = (typename Env::S)((uint64_t)start | ((uint64_t)(res32[rank[j]] & used) << 8));
             const uint32_t H = (ABLATE & 1) ? lane[j] * 2654435761u : blk_lds()[wv][16 * j + (me >> 2)][me & 3];
             ob[j] = Env::sensor_ob(aux[j], H, [&]() { return Env::elem(Env::quad_block(key, lane[j], 1u), lane[j] & 3u); });
-            if (CHAIN) a_next[j] = (int)__umulhi(blk_lds()[wv][32 + 16 * j + (me >> 2)][me & 3], n_act);
+            if (CHAIN) a_next[j] = (int)__umulhi(blk_lds()[wv][NQ + 16 * j + (me >> 2)][me & 3], n_act);
         }
     }
 };
@@ -184,7 +191,7 @@ struct Finisher<RockEnv<W, ABLATE, false>, 2, CHAIN> {
 // without the flight (TagEnv::step_one_opponent_pre) and TagEnv::flee completes it from the pooled words.
 // More than one opponent (wave-uniform, from the params): the general per-lane path.
 template <bool CHAIN>
-struct Finisher<TagEnv, 2, CHAIN> {
+struct Finisher<TagEnv, 2, CHAIN, void> {
     using Env = TagEnv;
     using Aux = typename Env::Flight;
     static constexpr bool HAS_PREPASS = false;

@@ -217,6 +217,9 @@ int main(int argc, char **argv)
             printf("  LPT2 %8.2f", time_it([&](int t) {
                 hipLaunchKernelGGL((step_kernel<E, 2, true>), dim3((unsigned)((n + 511) / 512)), dim3(256), 0, 0, state, action, ob, reward, done, err, n, make_key(1, t), 0u, 1, make_key(1, t + 1), p);
             }, iters));
+            printf("  LPT4 %8.2f", time_it([&](int t) {
+                hipLaunchKernelGGL((step_kernel<E, 4, true>), dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, 0, state, action, ob, reward, done, err, n, make_key(1, t), 0u, 1, make_key(1, t + 1), p);
+            }, iters));
             for (int lds_kb : {24, 36, 48, 72}) {   // occupancy limited by a dummy dynamic-LDS request
                 printf("  LPT2/lds%dk %6.2f", lds_kb, time_it([&](int t) {
                     hipLaunchKernelGGL((step_kernel<E, 2, true>), dim3((unsigned)((n + 511) / 512)), dim3(256), lds_kb * 1024, 0, state, action, ob, reward, done, err, n, make_key(1, t), 0u, 1, make_key(1, t + 1), p);
