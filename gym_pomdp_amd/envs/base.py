@@ -405,24 +405,28 @@ class BatchedEnv(object):
             return float(self.compute_prob([int(action)], [int(ob)], next_state).item())
         return self.compute_prob(action, ob, next_state)
 
-    def rollout(self, depth, sims_per_root=1, roots=None, discount=None, all_actions=False, lane_offset=None):
+    def rollout(self, depth, sims_per_root=1, roots=None, discount=None, all_actions=False, lane_offset=None, out=None):
         """Random rollouts from `roots` (packed states int32 [state_words, R]; default: the live state):
         R * sims_per_root independent simulations of at most `depth` steps under a uniform policy over
         `_generate_legal()` (or over all actions), discounted by `discount` (default: the env's
         `_discount`).  Neither `roots` nor the live state is modified; the call counter advances by
         `depth`.  Returns a dict of per-simulation tensors: ret float64, n_steps, first_action, last_ob
-        int32, terminated bool — simulation i belongs to root i // sims_per_root."""
+        int32, terminated bool — simulation i belongs to root i // sims_per_root.  `out`: the dict of an earlier
+        call of the same shape, to reuse its buffers."""
         st = self._state if roots is None else torch.as_tensor(roots, dtype=torch.int32, device=self.device)
         st = st.reshape(self.state_words, -1).contiguous()
         n_roots = st.shape[1]
         n = n_roots * int(sims_per_root)
         t0 = self._t
         self._t += int(depth)
-        out = dict(ret=torch.empty(n, dtype=torch.float64, device=self.device),
-                   n_steps=torch.empty(n, dtype=torch.int32, device=self.device),
-                   first_action=torch.empty(n, dtype=torch.int32, device=self.device),
-                   last_ob=torch.empty(n, dtype=torch.int32, device=self.device),
-                   terminated=torch.empty(n, dtype=torch.uint8, device=self.device))
+        if out is None:
+            out = dict(ret=torch.empty(n, dtype=torch.float64, device=self.device),
+                       n_steps=torch.empty(n, dtype=torch.int32, device=self.device),
+                       first_action=torch.empty(n, dtype=torch.int32, device=self.device),
+                       last_ob=torch.empty(n, dtype=torch.int32, device=self.device),
+                       terminated=torch.empty(n, dtype=torch.uint8, device=self.device))
+        else:                              # a dict returned by an earlier call of the same shape: buffers are reused
+            out["terminated"] = out["terminated"].view(torch.uint8)
         with torch.cuda.device(self.device):
             rc = self._lib.pomdp_rollout(
                 _native.ENV_KIND[self.env_name], self._params_ref, st.data_ptr(), n_roots, int(sims_per_root),
