@@ -13,7 +13,7 @@ _REPO = os.path.dirname(_PKG)
 LIB_PATH = os.path.join(_PKG, "_lib", "libpomdp_hip.so")
 SOURCES = [os.path.join(_PKG, "csrc", f) for f in ("pomdp_kernels.hip", "envs.hip.h", "philox.hip.h")]
 HEADER = os.path.join(_REPO, "include", "pomdp_hip.h")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 POMDP_AUTO_RESET = 1
 POMDP_ROLLOUT_ALL_ACTIONS = 1
@@ -62,6 +62,10 @@ class RockBelief(C.Structure):      # pomdp_rock_belief: device pointers, [num_r
 
 class HistoryPtrs(C.Structure):     # pomdp_history: device pointers
     _fields_ = [(k, C.c_void_p) for k in ("size", "last_action", "last_ob", "total_sample", "total_move", "move_ok")]
+
+
+class Returns(C.Structure):         # pomdp_returns
+    _fields_ = [("discount", C.c_double), ("ret", C.c_void_p), ("disc", C.c_void_p), ("ret_done", C.c_void_p)]
 
 
 def hipcc_path():
@@ -139,7 +143,7 @@ def lib():
     L.pomdp_pick_actions.restype = ci
     L.pomdp_pick_actions.argtypes = [vp, vp, ci, vp, i64, u64, u32, u64, vp]
     L.pomdp_heuristic_steps.restype = ci
-    L.pomdp_heuristic_steps.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, u64, u32, u64, i64, ci, vp]
+    L.pomdp_heuristic_steps.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, u64, u32, u64, i64, ci, vp]
     L.pomdp_philox_blocks.restype = ci
     L.pomdp_philox_blocks.argtypes = [vp, vp, i64, vp]
     _lib = L

@@ -566,7 +566,7 @@ static __device__ __forceinline__ void heuristic_belief_update(const typename En
 // history_append_kernel on the same call counter, with the lists never leaving registers.
 template <class Env>
 __global__ __launch_bounds__(BLOCK) void heuristic_step_kernel(const typename Env::Params p, uint32_t *__restrict__ state,
-                                                               pomdp_rock_belief b, pomdp_history h, int K,
+                                                               pomdp_rock_belief b, pomdp_history h, int K, pomdp_returns R,
                                                                int32_t *__restrict__ prev_ob, int32_t *__restrict__ action,
                                                                int32_t *__restrict__ ob, typename Env::Reward *__restrict__ reward,
                                                                uint8_t *__restrict__ done, int64_t n, RngKey key, uint32_t lane0,
@@ -609,6 +609,15 @@ __global__ __launch_bounds__(BLOCK) void heuristic_step_kernel(const typename En
     st_stream(done + i, (uint8_t)d);
     if (!live) return;
     Env::store(st, state, n, i, fresh);
+    if (R.ret) {                                                               // r += rw * discount; discount *= _discount
+#pragma clang fp contract(off)
+        const double dc = R.disc[i];
+        const double term = dc * (double)r;
+        const double acc = R.ret[i] + term;
+        if (d) R.ret_done[i] = acc;
+        R.ret[i] = fresh ? 0.0 : acc;
+        R.disc[i] = fresh ? 1.0 : dc * R.discount;
+    }
     if (fresh) {                                                               // new episode: fresh Rock objects, empty History
         for (int j = 0; j < K; ++j) {
             const int64_t k = (int64_t)j * n + i;
@@ -907,13 +916,15 @@ static int launch_preferred(const typename Env::Params &p, const uint32_t *state
 template <class Env>
 static int launch_heuristic_steps(const typename Env::Params &p, uint32_t *state, const pomdp_rock_belief *b,
                                   const pomdp_history *h, int K, int32_t *prev_ob, int32_t *action, int32_t *ob, void *reward,
-                                  uint8_t *done, int64_t n, uint64_t seed, uint32_t lane0, uint64_t t0, int64_t k_steps,
-                                  int flags, void *stream)
+                                  uint8_t *done, const pomdp_returns *returns, int64_t n, uint64_t seed, uint32_t lane0,
+                                  uint64_t t0, int64_t k_steps, int flags, void *stream)
 {
     if (n == 0) return 0;
+    static const pomdp_returns NO_RETURNS = {0.0, nullptr, nullptr, nullptr};
     for (int64_t s = 0; s < k_steps; ++s) {
         hipLaunchKernelGGL(heuristic_step_kernel<Env>, dim3(blocks_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, p, state,
-                           b ? *b : NO_BELIEF, *h, K, prev_ob, action, ob, (typename Env::Reward *)reward, done, n,
+                           b ? *b : NO_BELIEF, *h, K, returns ? *returns : NO_RETURNS, prev_ob, action, ob,
+                           (typename Env::Reward *)reward, done, n,
                            make_key(seed, t0 + (uint64_t)s), lane0, flags);
         const int rc = (int)hipGetLastError();
         if (rc) return rc;
@@ -1302,15 +1313,17 @@ int pomdp_pick_actions(const int32_t *list, const int32_t *len, int stride, int3
 }
 
 int pomdp_heuristic_steps(int env, const void *params, uint32_t *state, const pomdp_rock_belief *b, const pomdp_history *h,
-                          int32_t *prev_ob, int32_t *action, int32_t *ob, void *reward, uint8_t *done, int64_t n,
-                          uint64_t seed, uint32_t lane0, uint64_t t0, int64_t k_steps, int flags, void *stream)
+                          int32_t *prev_ob, int32_t *action, int32_t *ob, void *reward, uint8_t *done,
+                          const pomdp_returns *returns, int64_t n, uint64_t seed, uint32_t lane0, uint64_t t0,
+                          int64_t k_steps, int flags, void *stream)
 {
     const int K = history_rocks(env, params);
     if (K < 0 || !params || !state || !prev_ob || !action || !ob || !reward || !done || k_steps < 0 || bad_range(n, lane0))
         return POMDP_E_BADARG;
     if (!history_ok(h, K > 0) || (K > 0 && !belief_ok(b))) return POMDP_E_BADARG;
-    POMDP_DISPATCH(env, params, return launch_heuristic_steps<E>(*p, state, b, h, K, prev_ob, action, ob, reward, done, n, seed,
-                                                                 lane0, t0, k_steps, flags, stream))
+    if (returns && !(returns->ret && returns->disc && returns->ret_done)) return POMDP_E_BADARG;
+    POMDP_DISPATCH(env, params, return launch_heuristic_steps<E>(*p, state, b, h, K, prev_ob, action, ob, reward, done, returns,
+                                                                 n, seed, lane0, t0, k_steps, flags, stream))
 }
 
 int pomdp_philox_blocks(const uint32_t *ctr_key, uint32_t *out, int64_t n_blocks, void *stream)

@@ -360,12 +360,13 @@ class BatchedEnv(object):
             _native.check(rc, "pomdp_pick_actions")
         return out
 
-    def heuristic_steps(self, history, steps=1):
+    def heuristic_steps(self, history, steps=1, returns=None):
         """`steps` consecutive steps under the env's own heuristic policy, one launch each
         (pomdp_heuristic_steps): a = choice(_generate_preferred(history)); step(a); side statistics;
         history.append(Transition(observation, a, reward, ob, done)) — the loop of rock.py:557-573 for every lane,
         with the results of that call sequence.  Returns the last step's (action, ob, reward, done) in reusable
-        buffers; `history.prev_ob` holds the observation each lane sees afterwards.  Asynchronous."""
+        buffers; `history.prev_ob` holds the observation each lane sees afterwards.  `returns`
+        (gym_pomdp_amd.Returns) accumulates the loop's discounted return per lane.  Asynchronous."""
         if not self._has_reset:
             raise AttributeError("%s: heuristic_steps before reset()" % type(self).__name__)
         if history.prev_ob is None:
@@ -379,7 +380,7 @@ class BatchedEnv(object):
                 _native.ENV_KIND[self.env_name], self._params_ref, self._state.data_ptr(),
                 self._belief_ref() if self.env_name == "rock" else None, history._ref, history.prev_ob.data_ptr(),
                 self._action_scratch.data_ptr(), self._ob.data_ptr(), self._reward.data_ptr(), self._done.data_ptr(),
-                self.batch_size, self._seed, self.lane_offset, t0, int(steps),
+                None if returns is None else returns._ref, self.batch_size, self._seed, self.lane_offset, t0, int(steps),
                 _native.POMDP_AUTO_RESET if self.auto_reset else 0, self._stream())
             _native.check(rc, "pomdp_heuristic_steps")
         return self._action_scratch, self._ob, self._reward, self._done.view(torch.bool)

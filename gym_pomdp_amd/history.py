@@ -88,3 +88,18 @@ class History(object):
 
     def __repr__(self):
         return "size:%s" % (self.size,)
+
+
+class Returns(object):
+    """Per-lane discounted return of the heuristic rollout loop, `r += rw * discount; discount *= env._discount`
+    (rock.py:569-570), accumulated on the device by env.heuristic_steps(history, steps, returns=...): `ret`, `disc`
+    (running, float64[N]) and `ret_done` (return of the lane's last finished episode, NaN until one finishes)."""
+
+    def __init__(self, env, discount=None):
+        n, dev = env.batch_size, env.device
+        self.discount = float(env._discount if discount is None else discount)
+        self.ret = torch.zeros(n, dtype=torch.float64, device=dev)
+        self.disc = torch.ones(n, dtype=torch.float64, device=dev)
+        self.ret_done = torch.full((n,), float("nan"), dtype=torch.float64, device=dev)
+        self._ptrs = _native.Returns(self.discount, self.ret.data_ptr(), self.disc.data_ptr(), self.ret_done.data_ptr())
+        self._ref = C.byref(self._ptrs)

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define POMDP_ABI_VERSION 5
+#define POMDP_ABI_VERSION 6
 
 enum {
     POMDP_E_BADARG = -1,     /* NULL pointer, n < 0, n + lane0 > 2^32 */
@@ -284,10 +284,20 @@ int pomdp_pick_actions(const int32_t *list, const int32_t *len, int stride, int3
  *     prev_ob <- ob, or what reset() returned on a lane that auto-reset
  * with exactly the results of that five-launch sequence (the rollout loop of rock.py:557-573 for a batch).
  * prev_ob (device int32[n], in/out) starts as the observation reset() returned; action receives the chosen actions
- * (-1 on frozen lanes).  b is read for RockSample only.  The caller's call counter advances by k_steps. */
+ * (-1 on frozen lanes).  b is read for RockSample only.  The caller's call counter advances by k_steps.
+ * `returns` (may be NULL) adds the loop's discounted return, `r += rw * discount; discount *= env._discount`
+ * (rock.py:569-570), in IEEE double with separate multiply and add: ret[i] += disc[i] * reward; disc[i] *= discount.
+ * When a lane's episode ends, ret_done[i] receives its return; with POMDP_AUTO_RESET ret[i] / disc[i] then restart at
+ * 0 / 1 for the new episode, without it they keep the finished episode's values (the lane is frozen). */
+typedef struct pomdp_returns {
+    double  discount;       /* the env's _discount (rock.py:115, tag.py:91, ...) */
+    double *ret, *disc;     /* device double[n], in/out; start them at 0 and 1 */
+    double *ret_done;       /* device double[n], out: return of the last finished episode of the lane */
+} pomdp_returns;
 int pomdp_heuristic_steps(int env, const void *params, uint32_t *state, const pomdp_rock_belief *b, const pomdp_history *h,
-                          int32_t *prev_ob, int32_t *action, int32_t *ob, void *reward, uint8_t *done, int64_t n,
-                          uint64_t seed, uint32_t lane0, uint64_t t0, int64_t k_steps, int flags, void *stream);
+                          int32_t *prev_ob, int32_t *action, int32_t *ob, void *reward, uint8_t *done,
+                          const pomdp_returns *returns, int64_t n, uint64_t seed, uint32_t lane0, uint64_t t0,
+                          int64_t k_steps, int flags, void *stream);
 
 int         pomdp_abi_version(void);
 const char *pomdp_error_string(int code);

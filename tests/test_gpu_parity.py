@@ -874,3 +874,36 @@ def test_encoded_state_round_trips(capsys):
     n.render()
     out = capsys.readouterr().out
     assert "tiger is in state" in out and "M: 1 A: 1" in out
+
+
+@pytest.mark.parametrize("env,kw,auto", [("rock", {}, True), ("rock", {}, False), ("tag", {}, True), ("stochrock", {}, True)],
+                         ids=["rock_auto", "rock_frozen", "tag_auto", "stochrock_auto"])
+def test_heuristic_returns_accumulate_like_the_reference_loop(env, kw, auto):
+    """`r += rw * discount; discount *= env._discount` of the reference's rollout loop (rock.py:569-570), per lane on the
+    device == the same float64 recurrence applied on the host to the per-step rewards, bit for bit; ret_done carries the
+    return of each finished episode."""
+    from gym_pomdp_amd import History, Returns
+    is_rock = env in ("rock", "stochrock")
+    n, T = 4096, 80
+    e = make_env(env, dict(kw, **(dict(use_heuristic=True) if is_rock else {})), batch_size=n, seed=11, auto_reset=auto)
+    e.reset()
+    h, R = History(e), Returns(e)
+    ret, disc = np.zeros(n), np.ones(n)
+    ret_done = np.full(n, np.nan)
+    frozen = np.zeros(n, bool)
+    for t in range(T):
+        _, _, rew, done = e.heuristic_steps(h, 1, returns=R)
+        r, d = np_(rew).astype(np.float64), np_(done)
+        live = ~frozen
+        term = disc * r
+        acc = ret + term
+        ret_done = np.where(live & d, acc, ret_done)
+        fresh = live & d & auto
+        ret = np.where(live, np.where(fresh, 0.0, acc), ret)
+        disc = np.where(live, np.where(fresh, 1.0, disc * e._discount), disc)
+        if not auto:
+            frozen |= d
+        assert np.array_equal(np_(R.ret), ret) and np.array_equal(np_(R.disc), disc), t
+        both_nan = np.isnan(np_(R.ret_done)) & np.isnan(ret_done)
+        assert ((np_(R.ret_done) == ret_done) | both_nan).all(), t
+    assert np.isfinite(ret_done).sum() > 0 or env == "stochrock"

@@ -278,6 +278,25 @@ int main(int argc, char **argv)
     }
     printf("pomdp_rollout_synthetic (C driver, chained), per step: %8.2f\n",
            time_it([&](int t) { pomdp_rollout_synthetic(POMDP_ENV_ROCK, &p, state, action, ob, reward, done, err, n, 1, 1, 0, (uint64_t)t * 100, 100, 1, nullptr); }, iters / 100 + 1) / 100);
+    {   // hipGraph replay of 100 chained step launches vs the same launches issued one by one
+        using E = RockEnv<1, 0>;
+        hipStream_t gs; CK(hipStreamCreateWithFlags(&gs, hipStreamNonBlocking));
+        hipGraph_t g; hipGraphExec_t ge;
+        CK(hipStreamBeginCapture(gs, hipStreamCaptureModeGlobal));
+        for (int t = 0; t < 100; ++t)
+            hipLaunchKernelGGL((step_kernel<E, 2, true>), dim3((unsigned)((n + 511) / 512)), dim3(256), 0, gs, state, action, ob, reward, done, err, n, make_key(1, 1000 + t), 0u, 1, make_key(1, 1001 + t), p);
+        CK(hipStreamEndCapture(gs, &g));
+        CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        for (int i = 0; i < 3; ++i) CK(hipGraphLaunch(ge, gs));
+        CK(hipStreamSynchronize(gs));
+        const int reps = iters / 100 + 1;
+        auto t0 = std::chrono::high_resolution_clock::now();
+        for (int i = 0; i < reps; ++i) CK(hipGraphLaunch(ge, gs));
+        CK(hipStreamSynchronize(gs));
+        auto t1 = std::chrono::high_resolution_clock::now();
+        printf("hipGraph of 100 chained steps, per step: %8.2f\n", std::chrono::duration<double, std::micro>(t1 - t0).count() / (reps * 100.0));
+        CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g)); CK(hipStreamDestroy(gs));
+    }
     {   // does the CPU's run-ahead matter?  chained step launches on the null stream / a created stream, paced by a busy-wait
         using E = RockEnv<1, 0>;
         hipStream_t cs; CK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
