@@ -539,7 +539,8 @@ def test_episode_statistics_match_the_reference_probes():
 
 
 @pytest.mark.parametrize("env,kw,log2n,policy_seed", [
-    ("rock", {}, 27, None),                                    # maximum-size edge: 2.4 GB of columns in one batch
+    ("rock", {}, 32, None),                                    # the ABI's maximum: 2^32 - 1024 lanes, 73 GB of columns
+    ("rock", {}, 27, None),                                    # 2.4 GB of columns in one batch
     ("rock", dict(board_size=7, num_rocks=7), 19, None),       # two-lanes-per-thread path, odd K
     ("rock", dict(board_size=15, num_rocks=15), 19, None),     # two-lanes-per-thread launch, per-sub-batch fallback
     ("stochrock", {}, 20, None),
@@ -551,7 +552,7 @@ def test_episode_statistics_match_the_reference_probes():
 def test_large_batch_windows_vs_oracle(oracle_lib, env, kw, log2n, policy_seed):
     """Big batches (the launch geometry switches to two lanes per thread at 2^19 lanes): windows of lanes at the
     start, in the middle and at the very end are checked word for word against the oracle."""
-    n, seed, steps, win = 1 << log2n, 31337, 8, 2048
+    n, seed, steps, win = (1 << log2n) - (1024 if log2n == 32 else 0), 31337, (4 if log2n == 32 else 8), 2048
     e = make_env(env, kw, batch_size=n, seed=seed, reuse_buffers=True)
     e.reset()
     e.rollout_synthetic(steps, action_seed=policy_seed)
