@@ -350,7 +350,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s batch=%d lanes per GPU (%d total), uniform random actions "
                                    "(synthetic-policy kernel timed), auto-reset" % (label, n, total_lanes),
-                       "lanes_per_gpu": n, "total_lanes": total_lanes, "host_loop": args.host_loop, "visible_gpus": n_dev, "parallelism": "lane-shard x%d, no collectives" % world},
+                       "lanes_per_gpu": n, "total_lanes": total_lanes, "host_loop": args.host_loop, "visible_gpus": n_dev,
+                       "untimed_prewarm_s": args.prewarm, "parallelism": "lane-shard x%d, no collectives" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch",
                          "traffic_source": traffic_src,
