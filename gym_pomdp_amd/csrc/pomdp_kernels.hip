@@ -79,10 +79,25 @@ struct Finisher {
                                                const RngKey &key, const uint32_t (&lane)[LPT], const RngKey &akey,
                                                uint32_t n_act, int (&a_next)[LPT], const Aux (&)[LPT], int (&)[LPT])
     {
+        // CHAIN: the workgroup's BLOCK * LPT consecutive lanes share BLOCK * LPT / 4 policy blocks (one per quad); its
+        // first wave(s) compute each once, the others pick their word up from LDS, instead of every lane computing
+        // its quad's block itself
+        constexpr int NQ = BLOCK * LPT / 4;
+        __shared__ uint32_t pol[CHAIN ? NQ : 1][4];
+        if (CHAIN && (int)threadIdx.x < NQ) {                                  // whole waves: NQ is a multiple of 64
+            const uint32_t quad = ((lane[0] - threadIdx.x) >> 2) + threadIdx.x;
+            const uint4 w = philox4x32_10(quad, akey.t_lo, akey.t_hi, (uint32_t)POMDP_STREAM_ACTION << 24, akey.k0, akey.k1);
+            pol[threadIdx.x][0] = w.x; pol[threadIdx.x][1] = w.y; pol[threadIdx.x][2] = w.z; pol[threadIdx.x][3] = w.w;
+        }
 #pragma unroll
-        for (int j = 0; j < LPT; ++j) {
-            if (CHAIN) Env::reset_where_chain(sh, p, st[j], fresh[j], key, lane[j], akey, n_act, a_next[j]);
-            else Env::reset_where(sh, p, st[j], fresh[j], key, lane[j]);
+        for (int j = 0; j < LPT; ++j) Env::reset_where(sh, p, st[j], fresh[j], key, lane[j]);
+        if (CHAIN) {
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < LPT; ++j) {
+                const uint32_t rel = threadIdx.x + (uint32_t)(j * BLOCK);
+                a_next[j] = (int)__umulhi(pol[rel >> 2][rel & 3], n_act);
+            }
         }
     }
 };
