@@ -134,10 +134,25 @@ struct Finisher<RockEnv<W, ABLATE, false>, LPT, CHAIN, typename std::enable_if<(
     // of the next call counter — depends on lane ids only, so the kernel runs it right after issuing its HBM loads:
     // Philox passes hidden under the load latency.  Sub-batch j of a thread is 256 j lanes further on.
     static constexpr bool HAS_PREPASS = !(ABLATE & 8);
+    // Plain launches at two lanes per thread have only 32 such blocks per wave — half a pass.  There the waves of a
+    // workgroup pair up: one wave of each pair computes both waves' 32 sensor blocks in one full pass, the other skips
+    // the pre-pass; which of the two works alternates with the workgroup index so that the SIMDs stay balanced.  The
+    // blocks are first read after the table-staging barrier, which makes them visible across the pair at no extra cost.
+    static constexpr bool PAIRED = !CHAIN && LPT == 2 && HAS_PREPASS;
     static __device__ __forceinline__ void prepass(const RngKey &key, const uint32_t (&lane)[LPT], const RngKey &akey)
     {
         const int wv = (int)(threadIdx.x >> 6), me = (int)(threadIdx.x & 63u);
         const uint32_t first0 = lane[0] - (uint32_t)me;                        // first lane of the wave's sub-batch 0
+        if (PAIRED) {
+            if ((wv & 1) != (int)(blockIdx.x & 1u)) return;                    // the pair's other wave does it (wave-uniform)
+            const int tw = (wv & ~1) + (me >> 5), tt = me & 31;                // target wave, its (sub-batch, quad) index
+            const uint32_t tfirst = first0 + (uint32_t)(tw - wv) * 64u;
+            const uint32_t quad = ((tfirst + (uint32_t)(tt >> 4) * BLOCK) >> 2) + (uint32_t)(tt & 15);
+            const uint4 w = philox4x32_10(quad, key.t_lo, key.t_hi, (uint32_t)POMDP_STREAM_STEP << 24, key.k0, key.k1);
+            uint32_t *dst = blk_lds()[tw][tt];
+            dst[0] = w.x; dst[1] = w.y; dst[2] = w.z; dst[3] = w.w;
+            return;
+        }
 #pragma unroll
         for (int base = 0; base < NQ + NA; base += 64) {
             const int tid = base + me;
