@@ -614,7 +614,13 @@ struct TagEnv {
     // move_prob) on (w0, w1), then np.random.choice over a list whose length is 2 or 4, i.e. randint with an exact
     // mask (one word, no rejection).  The step is therefore split: `pre` does everything but the opponent's flight
     // and says whether the draw is needed, `flee` applies it; launches that pool Philox work call them separately.
-    struct Flight { uint32_t list; int cnt, ox, oy; bool need; };
+    struct Flight { uint32_t list; int ox, oy; bool need; };
+    // tag.py:260-280 `_admissable_actions`: the list the eight appends build depends only on the signs of
+    // (opponent - agent) in x and y.  Entry k = 3 (sign dx + 1) + (sign dy + 1), four 2-bit moves each (N0 E1 S2 W3,
+    // the reference's order); the two-element lists of the diagonal cases are stored twice over, so that
+    // `word & 3` picks from them exactly as randint(2)'s `word & 1` does.  k = 4 (same cell) never draws.
+    static constexpr uint64_t ADMISSIBLE_LO = 0x61993100adccecbbull;   // k = 0..7
+    static constexpr uint32_t ADMISSIBLE_8 = 0x11u;                     // k = 8
     template <class RT>
     static __device__ __forceinline__ void step_one_opponent_pre(const Params &p, State &st, int a, int &ob, RT &rew,
                                                                  int &done, Flight &f)
@@ -629,15 +635,9 @@ struct TagEnv {
         const uint32_t agent_m = inside(nx, ny) ? (uint32_t)index(nx, ny) : (uint32_t)agent;
         // a == 4 (tag.py:119-134): tagged iff co-located; otherwise the opponent may flee (tag.py:201-207, 260-280)
         const bool colocated = oi == agent;
-        uint32_t list = 0; int cnt = 0;
-        if (ox >= ax) { list |= 1u << (2 * cnt); ++cnt; }
-        if (oy >= ay) { ++cnt; }                                     // NORTH = 0: nothing to or in
-        if (ox <= ax) { list |= 3u << (2 * cnt); ++cnt; }
-        if (oy <= ay) { list |= 2u << (2 * cnt); ++cnt; }
-        if (ox == ax && oy > ay) { ++cnt; }
-        if (oy == ay && ox > ax) { list |= 1u << (2 * cnt); ++cnt; }
-        if (ox == ax && oy < ay) { list |= 2u << (2 * cnt); ++cnt; }
-        if (oy == ay && ox < ax) { list |= 3u << (2 * cnt); ++cnt; }
+        const int sx1 = min(max(ox - ax, -1), 1) + 1, sy1 = min(max(oy - ay, -1), 1) + 1;   // v_med3_i32
+        const int k = 3 * sx1 + sy1;
+        const uint32_t list = k == 8 ? ADMISSIBLE_8 : (uint32_t)(ADMISSIBLE_LO >> (8 * (k & 7))) & 0xFFu;
         const bool tag = a == 4;
         const uint32_t w_tag = with_num_opp(w, no - (int)colocated);
         const uint32_t wn = tag ? w_tag : ((w & ~31u) | agent_m);
@@ -645,14 +645,14 @@ struct TagEnv {
         ob = (!tag && ((wn >> 5) & 31u) == (wn & 31u)) ? p.obs_cells : (int)(wn & 31u);   // tag.py:219-226
         done = num_opp(wn) == 0;
         st.w = wn;
-        f.list = list; f.cnt = cnt; f.ox = ox; f.oy = oy;
+        f.list = list; f.ox = ox; f.oy = oy;
         f.need = tag && !colocated && no > 0;
     }
     // the opponent's flight from words 0-2 of the lane's STEP block (tag.py:201-207)
     static __device__ __forceinline__ void flee(const Params &p, State &st, const Flight &f, uint32_t w0, uint32_t w1,
                                                 uint32_t w2)
     {
-        const uint32_t pick = (f.list >> (2 * (w2 & (uint32_t)(f.cnt - 1)))) & 3u;   // cnt is 2 or 4 off the agent's cell
+        const uint32_t pick = (f.list >> (2 * (w2 & 3u))) & 3u;       // np.random.choice: randint(2 or 4), exact mask
         const int mx = f.ox + (pick == 1u) - (pick == 3u), my = f.oy + (pick == 0u) - (pick == 2u);
         const bool moved = f.need && k53(w0, w1) <= p.move_thr && inside(mx, my);
         if (moved) st.w = (st.w & ~(31u << 5)) | ((uint32_t)index(mx, my) << 5);
