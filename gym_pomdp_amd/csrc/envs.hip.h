@@ -496,10 +496,12 @@ struct TagEnv {
     static constexpr bool POOLED_LPT2 = true;     // pomdp_kernels.hip: Finisher<TagEnv, 2, .>
     static constexpr bool QUAD_SENSOR = false;
     static constexpr int ABL = 0;
-    struct Shared { int unused; };
+    // The T-shaped board never changes (tag.py:36-78): two small LDS tables replace the coordinate arithmetic of the
+    // hot step — cell -> x | y << 4, and (cell, move N0 E1 S2 W3) -> the cell the move leads to, or the cell itself
+    // when that square does not exist.  Every workgroup computes them once (threads 0-127, one entry each).
+    struct Shared { uint8_t xy[32]; uint8_t mv[32 * 4]; };
     struct State { uint32_t w; };
 
-    static __device__ __forceinline__ void stage(Shared &, const Params &, int) {}
     static __device__ __forceinline__ int n_actions(const Params &) { return 5; }
     static __device__ __forceinline__ void load(State &st, const uint32_t *state, int64_t, uint32_t i) { st.w = ld_stream(state + i); }
     static __device__ __forceinline__ void store(const State &st, uint32_t *state, int64_t, uint32_t i, bool) { st_stream(state + i, st.w); }
@@ -514,6 +516,17 @@ struct TagEnv {
     static __device__ __forceinline__ bool inside(int x, int y)
     {
         return y >= 2 ? (x >= 5 && x < 8 && y < 5) : (x >= 0 && x < 10 && y >= 0);
+    }
+    static __device__ __forceinline__ void stage(Shared &sh, const Params &, int tid)
+    {
+        if (tid < 128) {
+            const int cell = min(tid >> 2, 28), d = tid & 3;
+            int x, y;
+            coord(cell, x, y);
+            const int nx = x + (d == 1) - (d == 3), ny = y + (d == 0) - (d == 2);
+            sh.mv[tid] = (uint8_t)(inside(nx, ny) ? index(nx, ny) : cell);
+            if (d == 0) sh.xy[tid >> 2] = (uint8_t)(x | (y << 4));
+        }
     }
     static __device__ __forceinline__ int num_opp(uint32_t w) { return (int)w >> 25; } // sign-extending
     static __device__ __forceinline__ uint32_t with_num_opp(uint32_t w, int no)
@@ -598,23 +611,13 @@ struct TagEnv {
         return ob == (int)agent ? 1.0 : 0.0;
     }
 
-    // cell -> (x, y) with selects only (cells 0-19: two rows of ten; 20-28: three rows of three above x = 5..7)
-    static __device__ __forceinline__ void coord_fast(int idx, int &x, int &y)
-    {
-        const bool top = idx >= 20;
-        const int t = idx - 20, ty = (t * 11) >> 5;                 // t / 3 for t in 0..8
-        const int by = idx >= 10;
-        y = top ? ty + 2 : by;
-        x = top ? t - 3 * ty + 5 : idx - 10 * by;
-    }
-
     // tag.py:108-143 with one opponent (the default and the benchmark configuration), branch-free: under a random
     // policy every wave holds both moves and TAGs, so both outcomes are evaluated and selected.  Only a failed TAG
     // on a live opponent draws random numbers — words 0-2 of block 0 of the lane's STEP stream: binomial(1,
     // move_prob) on (w0, w1), then np.random.choice over a list whose length is 2 or 4, i.e. randint with an exact
     // mask (one word, no rejection).  The step is therefore split: `pre` does everything but the opponent's flight
     // and says whether the draw is needed, `flee` applies it; launches that pool Philox work call them separately.
-    struct Flight { uint32_t list; int ox, oy; bool need; };
+    struct Flight { uint32_t list; int oi; bool need; };
     // tag.py:260-280 `_admissable_actions`: the list the eight appends build depends only on the signs of
     // (opponent - agent) in x and y.  Entry k = 3 (sign dx + 1) + (sign dy + 1), four 2-bit moves each (N0 E1 S2 W3,
     // the reference's order); the two-element lists of the diagonal cases are stored twice over, so that
@@ -622,20 +625,18 @@ struct TagEnv {
     static constexpr uint64_t ADMISSIBLE_LO = 0x61993100adccecbbull;   // k = 0..7
     static constexpr uint32_t ADMISSIBLE_8 = 0x11u;                     // k = 8
     template <class RT>
-    static __device__ __forceinline__ void step_one_opponent_pre(const Params &p, State &st, int a, int &ob, RT &rew,
-                                                                 int &done, Flight &f)
+    static __device__ __forceinline__ void step_one_opponent_pre(const Shared &sh, const Params &p, State &st, int a,
+                                                                 int &ob, RT &rew, int &done, Flight &f)
     {
         const uint32_t w = st.w;
         const int agent = (int)(w & 31u), oi = (int)((w >> 5) & 31u), no = num_opp(w);
-        int ax, ay, ox, oy;
-        coord_fast(agent, ax, ay);
-        coord_fast(oi, ox, oy);
+        const int axy = sh.xy[agent], oxy = sh.xy[oi];
         // a < 4: the agent moves if the target cell exists (tag.py:112-117)
-        const int nx = ax + (a == 1) - (a == 3), ny = ay + (a == 0) - (a == 2);
-        const uint32_t agent_m = inside(nx, ny) ? (uint32_t)index(nx, ny) : (uint32_t)agent;
+        const uint32_t agent_m = sh.mv[4 * agent + (a & 3)];
         // a == 4 (tag.py:119-134): tagged iff co-located; otherwise the opponent may flee (tag.py:201-207, 260-280)
         const bool colocated = oi == agent;
-        const int sx1 = min(max(ox - ax, -1), 1) + 1, sy1 = min(max(oy - ay, -1), 1) + 1;   // v_med3_i32
+        const int dx = (oxy & 15) - (axy & 15), dy = (oxy >> 4) - (axy >> 4);
+        const int sx1 = min(max(dx, -1), 1) + 1, sy1 = min(max(dy, -1), 1) + 1;              // v_med3_i32
         const int k = 3 * sx1 + sy1;
         const uint32_t list = k == 8 ? ADMISSIBLE_8 : (uint32_t)(ADMISSIBLE_LO >> (8 * (k & 7))) & 0xFFu;
         const bool tag = a == 4;
@@ -645,26 +646,25 @@ struct TagEnv {
         ob = (!tag && ((wn >> 5) & 31u) == (wn & 31u)) ? p.obs_cells : (int)(wn & 31u);   // tag.py:219-226
         done = num_opp(wn) == 0;
         st.w = wn;
-        f.list = list; f.ox = ox; f.oy = oy;
+        f.list = list; f.oi = oi;
         f.need = tag && !colocated && no > 0;
     }
     // the opponent's flight from words 0-2 of the lane's STEP block (tag.py:201-207)
-    static __device__ __forceinline__ void flee(const Params &p, State &st, const Flight &f, uint32_t w0, uint32_t w1,
-                                                uint32_t w2)
+    static __device__ __forceinline__ void flee(const Shared &sh, const Params &p, State &st, const Flight &f, uint32_t w0,
+                                                uint32_t w1, uint32_t w2)
     {
         const uint32_t pick = (f.list >> (2 * (w2 & 3u))) & 3u;       // np.random.choice: randint(2 or 4), exact mask
-        const int mx = f.ox + (pick == 1u) - (pick == 3u), my = f.oy + (pick == 0u) - (pick == 2u);
-        const bool moved = f.need && k53(w0, w1) <= p.move_thr && inside(mx, my);
-        if (moved) st.w = (st.w & ~(31u << 5)) | ((uint32_t)index(mx, my) << 5);
+        const uint32_t to = sh.mv[4 * f.oi + (int)pick];               // the cell itself if the square does not exist
+        if (f.need && k53(w0, w1) <= p.move_thr) st.w = (st.w & ~(31u << 5)) | (to << 5);
     }
     template <class RT>
-    static __device__ __forceinline__ void step_one_opponent(const Params &p, State &st, int a, const RngKey &key,
-                                                             uint32_t lane, int &ob, RT &rew, int &done)
+    static __device__ __forceinline__ void step_one_opponent(const Shared &sh, const Params &p, State &st, int a,
+                                                             const RngKey &key, uint32_t lane, int &ob, RT &rew, int &done)
     {
         Flight f;
-        step_one_opponent_pre(p, st, a, ob, rew, done, f);
+        step_one_opponent_pre(sh, p, st, a, ob, rew, done, f);
         const uint4 blk = stream_block(key, lane, POMDP_STREAM_STEP, 0u);
-        flee(p, st, f, blk.x, blk.y, blk.z);
+        flee(sh, p, st, f, blk.x, blk.y, blk.z);
     }
     // reset() from the four words of block 0 of the lane's RESET stream (tag.py:181-193: randint(29) per cell, each a
     // masked-rejection loop); false when the rejections ran past the block (probability < 1e-3) — the caller then
@@ -686,10 +686,10 @@ struct TagEnv {
 
     // tag.py:108-143 step, 201-207 move_opponent, 260-280 _admissable_actions
     template <class RT>
-    static __device__ __forceinline__ void step(const Shared &, const Params &p, State &st, int a,
+    static __device__ __forceinline__ void step(const Shared &sh, const Params &p, State &st, int a,
                                                 const RngKey &key, uint32_t lane, int &ob, RT &rew, int &done)
     {
-        if (p.num_opponents == 1) { step_one_opponent(p, st, a, key, lane, ob, rew, done); return; }   // wave-uniform
+        if (p.num_opponents == 1) { step_one_opponent(sh, p, st, a, key, lane, ob, rew, done); return; }   // wave-uniform
         uint32_t w = st.w;
         const int agent = (int)(w & 31u);
         int ax, ay;

@@ -230,7 +230,7 @@ struct Finisher<TagEnv, 2, CHAIN, void> {
                                                      typename Env::State &st, int a, const RngKey &key, uint32_t lane,
                                                      int &ob, RT &rew, int &done, Aux &aux)
     {
-        if (p.num_opponents == 1) Env::step_one_opponent_pre(p, st, a, ob, rew, done, aux);
+        if (p.num_opponents == 1) Env::step_one_opponent_pre(sh, p, st, a, ob, rew, done, aux);
         else { aux.need = false; Env::step(sh, p, st, a, key, lane, ob, rew, done); }
     }
     static __device__ __forceinline__ void run(const typename Env::Shared &sh, const typename Env::Params &p,
@@ -282,7 +282,7 @@ struct Finisher<TagEnv, 2, CHAIN, void> {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const uint32_t *res = res_lds[wv][32 + (rank[j] & 127)];
-            if (aux[j].need) Env::flee(p, st[j], aux[j], res[0], res[1], res[2]);
+            if (aux[j].need) Env::flee(sh, p, st[j], aux[j], res[0], res[1], res[2]);
             if (fresh[j]) {
                 const uint4 b = make_uint4(res[0], res[1], res[2], res[3]);
                 if (!Env::reset_from_block(p, st[j], b)) Env::reset(sh, p, st[j], key, lane[j]);   // rejections ran past the block
