@@ -965,45 +965,43 @@ static int launch_heuristic_steps(const typename Env::Params &p, uint32_t *state
 
 using namespace pomdp;
 
-// dispatch on (env kind, params) to the kernel instantiation; F is a generic lambda taking a tag type
-#define POMDP_DISPATCH(env, params, CALL)                                                                              \
-    switch (env) {                                                                                                     \
-    case POMDP_ENV_ROCK: {                                                                                             \
-        const pomdp_rock_params *p = (const pomdp_rock_params *)(params);                                              \
-        if (!rock_ok(p)) return POMDP_E_BADPARAMS;                                                                     \
-        if (p->stochastic) {                                                                                           \
-            if (p->num_rocks <= 12) { using E = StochRock1; CALL; } else { using E = StochRock2; CALL; } \
-        }                                                                                                              \
-        if (p->num_rocks <= 12) { using E = RockEnv<1>; CALL; } else { using E = RockEnv<2>; CALL; }                     \
-    }                                                                                                                  \
-    case POMDP_ENV_TAG: {                                                                                              \
-        const pomdp_tag_params *p = (const pomdp_tag_params *)(params);                                                \
-        if (p->num_opponents < 1 || p->num_opponents > 4) return POMDP_E_BADPARAMS;                                    \
-        using E = TagEnv; CALL;                                                                                        \
-    }                                                                                                                  \
-    case POMDP_ENV_BATTLESHIP: {                                                                                       \
-        const pomdp_battleship_params *p = (const pomdp_battleship_params *)(params);                                  \
-        switch (bs_mask_words(p)) {                                                                                    \
-        case 1: { using E = BattleShipEnv<1>; CALL; }                                                                  \
-        case 2: { using E = BattleShipEnv<2>; CALL; }                                                                  \
-        case 3: { using E = BattleShipEnv<3>; CALL; }                                                                  \
-        case 4: { using E = BattleShipEnv<4>; CALL; }                                                                  \
-        default: return POMDP_E_BADPARAMS;                                                                             \
-        }                                                                                                              \
-    }                                                                                                                  \
-    case POMDP_ENV_TIGER: {                                                                                            \
-        const pomdp_tiger_params *p = (const pomdp_tiger_params *)(params);                                            \
-        using E = TigerEnv; CALL;                                                                                      \
-    }                                                                                                                  \
-    case POMDP_ENV_NETWORK: {                                                                                          \
-        const pomdp_network_params *p = (const pomdp_network_params *)(params);                                        \
-        if (p->n_machines < 1 || p->n_machines > 32) return POMDP_E_BADPARAMS;                                         \
-        using E = NetworkEnv; CALL;                                                                                    \
-    }                                                                                                                  \
-    default: return POMDP_E_BADARG;                                                                                    \
+// Resolve (env kind, params) to the env type the kernels are instantiated for, validate the params against what the
+// packed layouts support, and call f(EnvTag<Env>{}, typed params).
+template <class E> struct EnvTag { using Env = E; };
+template <class F>
+static int dispatch_env(int env, const void *params, F &&f)
+{
+    switch (env) {
+    case POMDP_ENV_ROCK: {
+        const pomdp_rock_params *p = (const pomdp_rock_params *)params;
+        if (!rock_ok(p)) return POMDP_E_BADPARAMS;
+        if (p->stochastic) return p->num_rocks <= 12 ? f(EnvTag<StochRock1>{}, *p) : f(EnvTag<StochRock2>{}, *p);
+        return p->num_rocks <= 12 ? f(EnvTag<RockEnv<1>>{}, *p) : f(EnvTag<RockEnv<2>>{}, *p);
     }
-
-
+    case POMDP_ENV_TAG: {
+        const pomdp_tag_params *p = (const pomdp_tag_params *)params;
+        if (p->num_opponents < 1 || p->num_opponents > 4) return POMDP_E_BADPARAMS;
+        return f(EnvTag<TagEnv>{}, *p);
+    }
+    case POMDP_ENV_BATTLESHIP: {
+        const pomdp_battleship_params *p = (const pomdp_battleship_params *)params;
+        switch (bs_mask_words(p)) {
+        case 1: return f(EnvTag<BattleShipEnv<1>>{}, *p);
+        case 2: return f(EnvTag<BattleShipEnv<2>>{}, *p);
+        case 3: return f(EnvTag<BattleShipEnv<3>>{}, *p);
+        case 4: return f(EnvTag<BattleShipEnv<4>>{}, *p);
+        default: return POMDP_E_BADPARAMS;
+        }
+    }
+    case POMDP_ENV_TIGER: return f(EnvTag<TigerEnv>{}, *(const pomdp_tiger_params *)params);
+    case POMDP_ENV_NETWORK: {
+        const pomdp_network_params *p = (const pomdp_network_params *)params;
+        if (p->n_machines < 1 || p->n_machines > 32) return POMDP_E_BADPARAMS;
+        return f(EnvTag<NetworkEnv>{}, *p);
+    }
+    default: return POMDP_E_BADARG;
+    }
+}
 
 extern "C" {
 
@@ -1121,78 +1119,6 @@ int pomdp_synthetic_actions(int32_t *action, int64_t n, uint64_t seed, uint32_t 
     return (int)hipGetLastError();
 }
 
-#define POMDP_CHAIN_CALL(E, P) rc = launch_step_chain<E>(*(P), state, action, ob, (typename E::Reward *)reward, done, err, n, seed, action_seed, lane0, t, flags, stream)
-#define POMDP_DISPATCH_STEP_CHAIN(env, params)                                                                         \
-    switch (env) {                                                                                                     \
-    case POMDP_ENV_ROCK: {                                                                                             \
-        const pomdp_rock_params *p = (const pomdp_rock_params *)(params);                                              \
-        if (!rock_ok(p)) return POMDP_E_BADPARAMS;                                                                     \
-        if (p->stochastic) {                                                                                           \
-            if (p->num_rocks <= 12) { POMDP_CHAIN_CALL(StochRock1, p); } else { POMDP_CHAIN_CALL(StochRock2, p); } \
-        } else if (p->num_rocks <= 12) { POMDP_CHAIN_CALL(RockEnv<1>, p); } else { POMDP_CHAIN_CALL(RockEnv<2>, p); }    \
-        break;                                                                                                         \
-    }                                                                                                                  \
-    case POMDP_ENV_TAG: {                                                                                              \
-        const pomdp_tag_params *p = (const pomdp_tag_params *)(params);                                                \
-        if (p->num_opponents < 1 || p->num_opponents > 4) return POMDP_E_BADPARAMS;                                    \
-        POMDP_CHAIN_CALL(TagEnv, p);                                                                                   \
-        break;                                                                                                         \
-    }                                                                                                                  \
-    case POMDP_ENV_BATTLESHIP: {                                                                                       \
-        const pomdp_battleship_params *p = (const pomdp_battleship_params *)(params);                                  \
-        switch (bs_mask_words(p)) {                                                                                    \
-        case 1: POMDP_CHAIN_CALL(BattleShipEnv<1>, p); break;                                                          \
-        case 2: POMDP_CHAIN_CALL(BattleShipEnv<2>, p); break;                                                          \
-        case 3: POMDP_CHAIN_CALL(BattleShipEnv<3>, p); break;                                                          \
-        case 4: POMDP_CHAIN_CALL(BattleShipEnv<4>, p); break;                                                          \
-        default: return POMDP_E_BADPARAMS;                                                                             \
-        }                                                                                                              \
-        break;                                                                                                         \
-    }                                                                                                                  \
-    case POMDP_ENV_TIGER: POMDP_CHAIN_CALL(TigerEnv, (const pomdp_tiger_params *)(params)); break;                     \
-    default: {                                                                                                         \
-        const pomdp_network_params *p = (const pomdp_network_params *)(params);                                        \
-        if (p->n_machines < 1 || p->n_machines > 32) return POMDP_E_BADPARAMS;                                         \
-        POMDP_CHAIN_CALL(NetworkEnv, p);                                                                               \
-    }                                                                                                                  \
-    }
-
-#define POMDP_PLAIN_CALL(E, P) rc = launch_step<E>(*(P), state, action, ob, (typename E::Reward *)reward, done, err, n, seed, lane0, t, flags, stream)
-#define POMDP_DISPATCH_STEP_PLAIN(env, params)                                                                         \
-    switch (env) {                                                                                                     \
-    case POMDP_ENV_ROCK: {                                                                                             \
-        const pomdp_rock_params *p = (const pomdp_rock_params *)(params);                                              \
-        if (!rock_ok(p)) return POMDP_E_BADPARAMS;                                                                     \
-        if (p->stochastic) {                                                                                           \
-            if (p->num_rocks <= 12) { POMDP_PLAIN_CALL(StochRock1, p); } else { POMDP_PLAIN_CALL(StochRock2, p); } \
-        } else if (p->num_rocks <= 12) { POMDP_PLAIN_CALL(RockEnv<1>, p); } else { POMDP_PLAIN_CALL(RockEnv<2>, p); }    \
-        break;                                                                                                         \
-    }                                                                                                                  \
-    case POMDP_ENV_TAG: {                                                                                              \
-        const pomdp_tag_params *p = (const pomdp_tag_params *)(params);                                                \
-        if (p->num_opponents < 1 || p->num_opponents > 4) return POMDP_E_BADPARAMS;                                    \
-        POMDP_PLAIN_CALL(TagEnv, p);                                                                                   \
-        break;                                                                                                         \
-    }                                                                                                                  \
-    case POMDP_ENV_BATTLESHIP: {                                                                                       \
-        const pomdp_battleship_params *p = (const pomdp_battleship_params *)(params);                                  \
-        switch (bs_mask_words(p)) {                                                                                    \
-        case 1: POMDP_PLAIN_CALL(BattleShipEnv<1>, p); break;                                                          \
-        case 2: POMDP_PLAIN_CALL(BattleShipEnv<2>, p); break;                                                          \
-        case 3: POMDP_PLAIN_CALL(BattleShipEnv<3>, p); break;                                                          \
-        case 4: POMDP_PLAIN_CALL(BattleShipEnv<4>, p); break;                                                          \
-        default: return POMDP_E_BADPARAMS;                                                                             \
-        }                                                                                                              \
-        break;                                                                                                         \
-    }                                                                                                                  \
-    case POMDP_ENV_TIGER: POMDP_PLAIN_CALL(TigerEnv, (const pomdp_tiger_params *)(params)); break;                     \
-    default: {                                                                                                         \
-        const pomdp_network_params *p = (const pomdp_network_params *)(params);                                        \
-        if (p->n_machines < 1 || p->n_machines > 32) return POMDP_E_BADPARAMS;                                         \
-        POMDP_PLAIN_CALL(NetworkEnv, p);                                                                               \
-    }                                                                                                                  \
-    }
-
 int pomdp_rollout_synthetic(int env, const void *params, uint32_t *state, int32_t *action, int32_t *ob, void *reward,
                             uint8_t *done, uint32_t *err, int64_t n, uint64_t seed, uint64_t action_seed,
                             uint32_t lane0, uint64_t t0, int64_t k_steps, int flags, void *stream)
@@ -1219,7 +1145,11 @@ int pomdp_rollout_synthetic(int env, const void *params, uint32_t *state, int32_
         // chained: every step launch also leaves the actions of the following call counter in `action`
         for (int64_t s = 0; s < k_steps; ++s) {
             const uint64_t t = t0 + (uint64_t)s;
-            POMDP_DISPATCH_STEP_CHAIN(env, params)
+            rc = dispatch_env(env, params, [&](auto tag, const auto &p) {
+                using E = typename decltype(tag)::Env;
+                return launch_step_chain<E>(p, state, action, ob, (typename E::Reward *)reward, done, err, n, seed, action_seed,
+                                            lane0, t, flags, stream);
+            });
             if (rc) return rc;
         }
         return 0;
@@ -1228,7 +1158,10 @@ int pomdp_rollout_synthetic(int env, const void *params, uint32_t *state, int32_
     for (int64_t s = 0; s < k_steps; ++s) {
         const uint64_t t = t0 + (uint64_t)s;
         if (s > 0 && (rc = pomdp_synthetic_actions(action, n, action_seed, lane0, t, n_actions, stream))) return rc;
-        POMDP_DISPATCH_STEP_PLAIN(env, params)
+        rc = dispatch_env(env, params, [&](auto tag, const auto &p) {
+            using E = typename decltype(tag)::Env;
+            return launch_step<E>(p, state, action, ob, (typename E::Reward *)reward, done, err, n, seed, lane0, t, flags, stream);
+        });
         if (rc) return rc;
     }
     return pomdp_synthetic_actions(action, n, action_seed, lane0, t0 + (uint64_t)k_steps, n_actions, stream);
@@ -1238,14 +1171,20 @@ int pomdp_legal_actions(int env, const void *params, const uint32_t *state, int3
                         int stride, void *stream)
 {
     if (!params) return POMDP_E_BADARG;
-    POMDP_DISPATCH(env, params, return launch_legal<E>(*p, state, list, len, n, stride, stream))
+    return dispatch_env(env, params, [&](auto tag, const auto &p) {
+        using E = typename decltype(tag)::Env;
+        return launch_legal<E>(p, state, list, len, n, stride, stream);
+    });
 }
 
 int pomdp_compute_prob(int env, const void *params, const uint32_t *state, const int32_t *action, const int32_t *ob,
                        double *out, int64_t n, void *stream)
 {
     if (!params) return POMDP_E_BADARG;
-    POMDP_DISPATCH(env, params, return launch_prob<E>(*p, state, action, ob, out, n, stream))
+    return dispatch_env(env, params, [&](auto tag, const auto &p) {
+        using E = typename decltype(tag)::Env;
+        return launch_prob<E>(p, state, action, ob, out, n, stream);
+    });
 }
 
 int pomdp_rollout(int env, const void *params, const uint32_t *root_state, int64_t n_roots, int64_t sims_per_root,
@@ -1253,9 +1192,11 @@ int pomdp_rollout(int env, const void *params, const uint32_t *root_state, int64
                   int32_t *n_steps, int32_t *first_action, int32_t *last_ob, uint8_t *terminated, void *stream)
 {
     if (!params) return POMDP_E_BADARG;
-    POMDP_DISPATCH(env, params, return launch_rollout<E>(*p, root_state, n_roots, sims_per_root, depth, discount, flags,
-                                                         seed, lane0, t0, ret, n_steps, first_action, last_ob,
-                                                         terminated, stream))
+    return dispatch_env(env, params, [&](auto tag, const auto &p) {
+        using E = typename decltype(tag)::Env;
+        return launch_rollout<E>(p, root_state, n_roots, sims_per_root, depth, discount, flags, seed, lane0, t0, ret, n_steps,
+                                 first_action, last_ob, terminated, stream);
+    });
 }
 
 int pomdp_rock_belief_reset(const pomdp_rock_params *p, const pomdp_rock_belief *b, const uint8_t *where, int64_t n,
@@ -1329,7 +1270,10 @@ int pomdp_preferred_actions(int env, const void *params, const uint32_t *state, 
 {
     if (!params || !state || !list || !len || n < 0 || stride < 1) return POMDP_E_BADARG;
     if (!history_ok(h, env == POMDP_ENV_ROCK) || (env == POMDP_ENV_ROCK && !belief_ok(b))) return POMDP_E_BADARG;
-    POMDP_DISPATCH(env, params, return launch_preferred<E>(*p, state, b, h, list, len, n, stride, stream))
+    return dispatch_env(env, params, [&](auto tag, const auto &p) {
+        using E = typename decltype(tag)::Env;
+        return launch_preferred<E>(p, state, b, h, list, len, n, stride, stream);
+    });
 }
 
 int pomdp_pick_actions(const int32_t *list, const int32_t *len, int stride, int32_t *action, int64_t n, uint64_t seed,
@@ -1352,8 +1296,11 @@ int pomdp_heuristic_steps(int env, const void *params, uint32_t *state, const po
         return POMDP_E_BADARG;
     if (!history_ok(h, K > 0) || (K > 0 && !belief_ok(b))) return POMDP_E_BADARG;
     if (returns && !(returns->ret && returns->disc && returns->ret_done)) return POMDP_E_BADARG;
-    POMDP_DISPATCH(env, params, return launch_heuristic_steps<E>(*p, state, b, h, K, prev_ob, action, ob, reward, done, returns,
-                                                                 n, seed, lane0, t0, k_steps, flags, stream))
+    return dispatch_env(env, params, [&](auto tag, const auto &p) {
+        using E = typename decltype(tag)::Env;
+        return launch_heuristic_steps<E>(p, state, b, h, K, prev_ob, action, ob, reward, done, returns, n, seed, lane0, t0,
+                                         k_steps, flags, stream);
+    });
 }
 
 int pomdp_philox_blocks(const uint32_t *ctr_key, uint32_t *out, int64_t n_blocks, void *stream)
