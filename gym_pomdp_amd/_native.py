@@ -11,7 +11,9 @@ import subprocess
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _REPO = os.path.dirname(_PKG)
 LIB_PATH = os.path.join(_PKG, "_lib", "libpomdp_hip.so")
-SOURCES = [os.path.join(_PKG, "csrc", f) for f in ("pomdp_kernels.hip", "envs.hip.h", "philox.hip.h")]
+SOURCES = [os.path.join(_PKG, "csrc", f) for f in ("pomdp_kernels.hip", "envs.hip.h", "envs_common.hip.h", "philox.hip.h",
+                                                   "envs/rock.hip.h", "envs/tag.hip.h", "envs/battleship.hip.h",
+                                                   "envs/tiger.hip.h", "envs/network.hip.h")]
 HEADER = os.path.join(_REPO, "include", "pomdp_hip.h")
 ABI_VERSION = 6
 

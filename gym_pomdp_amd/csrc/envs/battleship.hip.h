@@ -1,0 +1,274 @@
+// envs/battleship.hip.h — BattleShip (gym_pomdp/envs/battleship.py): the lane functions the generic kernels of pomdp_kernels.hip call.
+// Included by envs.hip.h (which holds the Env interface description and the shared helpers).
+#pragma once
+#include "../envs_common.hip.h"
+
+namespace pomdp {
+
+template <int MW> // mask words: ceil((cells + 6) / 32)
+struct BattleShipEnv {
+    using Params = pomdp_battleship_params;
+    using Reward = int32_t;
+    static constexpr int WORDS = 2 * MW;
+    static constexpr bool POOLED_LPT2 = false;
+    static constexpr bool QUAD_SENSOR = false;
+    static constexpr int ABL = 0;
+    struct Shared { int unused; };
+    // Each 128-bit mask is two 64-bit registers (never an addressable array or vector: a dynamically indexed
+    // one is lowered through LDS by the compiler); bit tests are a 64-bit select and one variable shift.
+    struct Mask {
+        uint64_t lo, hi;
+        __device__ __forceinline__ uint32_t word(int j) const { return (uint32_t)((j < 2 ? lo : hi) >> (32 * (j & 1))); }
+        __device__ __forceinline__ void set_word(int j, uint32_t w)
+        {
+            const uint64_t m = 0xFFFFFFFFull << (32 * (j & 1)), v = (uint64_t)w << (32 * (j & 1));
+            if (j < 2) lo = (lo & ~m) | v; else hi = (hi & ~m) | v;
+        }
+    };
+    struct State { Mask occ, vis; };
+
+    static __device__ __forceinline__ void stage(Shared &, const Params &, int) {}
+    static __device__ __forceinline__ int n_actions(const Params &p) { return p.x_size * p.y_size; }
+    static __device__ __forceinline__ int reset_ob(const Params &, const State &) { return 0; }   // battleship.py:131-137
+    static __device__ __forceinline__ void load(State &st, const uint32_t *state, int64_t n, uint32_t i)
+    {
+        uint32_t o[4] = {0, 0, 0, 0}, v[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < MW; ++j) { o[j] = ld_stream(state + (int64_t)j * n + i); v[j] = ld_stream(state + (int64_t)(MW + j) * n + i); }
+        st.occ.lo = o[0] | ((uint64_t)o[1] << 32); st.occ.hi = o[2] | ((uint64_t)o[3] << 32);
+        st.vis.lo = v[0] | ((uint64_t)v[1] << 32); st.vis.hi = v[2] | ((uint64_t)v[3] << 32);
+    }
+    // a step only changes the visited half; the occupied half is rewritten on reset
+    static __device__ __forceinline__ void store(const State &st, uint32_t *state, int64_t n, uint32_t i, bool was_reset)
+    {
+#pragma unroll
+        for (int j = 0; j < MW; ++j) st_stream(state + (int64_t)(MW + j) * n + i, (uint32_t)st.vis.word(j));
+        if (was_reset) {
+#pragma unroll
+            for (int j = 0; j < MW; ++j) st_stream(state + (int64_t)j * n + i, (uint32_t)st.occ.word(j));
+        }
+    }
+    static __device__ __forceinline__ bool bit(const Mask &m, int a) { return ((a < 64 ? m.lo : m.hi) >> (a & 63)) & 1ull; }
+    static __device__ __forceinline__ void set_bit(Mask &m, int a)
+    {
+        const uint64_t b = 1ull << (a & 63);
+        m.lo |= a < 64 ? b : 0ull;
+        m.hi |= a < 64 ? 0ull : b;
+    }
+    static __device__ __forceinline__ bool occupied(const Params &p, const State &st, int x, int y)
+    {
+        return (unsigned)x < (unsigned)p.x_size && (unsigned)y < (unsigned)p.y_size && bit(st.occ, y * p.x_size + x);
+    }
+
+    // battleship.py:131-137 reset, 167-180 _get_init_state, 195-211 collision, 182-193 mark_ship,
+    // coord.py:122-123 Grid.sample, battleship.py:33-37 Ship.__init__ (position word(s) before direction word).
+    //
+    // The reference's collision() walks L+1 cells from pos and, for each, looks at the cell itself and
+    // its N, E, S, W, NE, SE, SW neighbours (Compass[0..7]; NW is never looked at).  Here that is one
+    // AND of two 128-bit masks: `blocked` = every cell that has an occupied cell in that 8-neighbourhood
+    // (7 shifted copies of the occupancy mask, column-wrap guarded), against the L+1 ship cells; the
+    // "pos + dir stays inside for i = 0..L" test reduces to the far end pos + (L+1) dir being inside.
+    typedef unsigned __int128 u128;
+    static __device__ __forceinline__ int reset(const Shared &, const Params &p, State &st, const RngKey &key,
+                                                uint32_t lane)
+    {
+        WordStream ws(key, lane, POMDP_STREAM_RESET);
+        const int X = p.x_size, Y = p.y_size;
+        u128 col0 = 0;                                     // cells with x == 0
+        for (int y = 0; y < Y; ++y) col0 |= (u128)1 << (y * X);
+        const u128 colL = col0 << (X - 1);                 // cells with x == X - 1
+        u128 occ = 0;
+        int remaining = 0;
+        for (int len = p.max_len; len >= 2; --len) {
+            const u128 e = occ & ~col0, w = occ & ~colL;   // sources that may shift one column west / east
+            const u128 blocked = occ | (occ >> X) | (occ << X) | (e >> 1) | (w << 1) | (e >> (X + 1)) | (e << (X - 1)) |
+                                 (w << (X + 1));
+            int a0, dx, dy;
+            for (;;) {
+                a0 = (int)ws.randint((uint32_t)(X * Y));
+                const uint32_t dir = ws.randint(4u);
+                dx = (dir == 1u) - (dir == 3u); dy = (dir == 0u) - (dir == 2u);   // Compass N E S W
+                const int px = a0 % X, py = a0 / X;
+                const int ex = px + (len + 1) * dx, ey = py + (len + 1) * dy;
+                if (!((unsigned)ex < (unsigned)X && (unsigned)ey < (unsigned)Y)) continue;
+                const int stride = dy * X + dx;                                   // bit distance between ship cells
+                const int lo = stride > 0 ? a0 : a0 + len * stride;               // lowest bit of the L+1 checked cells
+                const int gap = stride > 0 ? stride : -stride;
+                u128 cells = 0;
+                for (int i = 0; i <= len; ++i) cells |= (u128)1 << (lo + i * gap);
+                if ((cells & blocked) == 0) break;
+            }
+            const int stride = dy * X + dx;
+            for (int i = 0; i < len; ++i) occ |= (u128)1 << (a0 + i * stride);     // mark_ship: L cells from pos
+            remaining += len;
+        }
+        st.occ.lo = (uint64_t)occ; st.occ.hi = (uint64_t)(occ >> 64);
+        st.vis.lo = 0; st.vis.hi = 0;
+        st.vis.set_word(MW - 1, (uint32_t)remaining << 26);
+        return 0;
+    }
+
+    // Wave-cooperative reset.  A BattleShip reset is a long sequential rejection loop (about 20 attempts on
+    // 10x10, 42 on 5x5) and roughly one wave in five holds a lane that needs one; run per lane it stalls 63
+    // other lanes behind ~2000 divergent instructions.  Here the whole wave serves one resetting lane at a
+    // time and evaluates up to 64 candidate placements at once:
+    //   1. one Philox pass gives a 64-word window of that lane's RESET stream (lane l holds word c + l);
+    //   2. the reference consumes the stream as [position words until one is < n_tiles][direction word],
+    //      repeated.  With A = ballot(word is an acceptable position), word l is a *direction* word iff
+    //      word l-1 is an accepted position word, i.e. D[l] = A[l-1] & ~D[l-1]: inside every run of ones of
+    //      A the roles alternate, which is the "escaped character" recurrence and has a branch-free 64-bit
+    //      solution (add-with-carry over the run starts; Langdale & Lemire, "Parsing gigabytes of JSON per
+    //      second", §3.1.1).  Lane l is a candidate iff A[l] & ~D[l]; its direction word is lane l+1's;
+    //   3. every candidate lane tests its placement with 128-bit mask arithmetic against `blocked`; the
+    //      lowest successful lane is the ship the reference would have placed, and the cursor moves just
+    //      past its direction word.  No success: the cursor moves past the last fully parsed word.
+    // Same words in the same order as reset() above, hence the same boards.
+    static __device__ __forceinline__ u128 u128_of(const uint32_t (&w)[4])
+    {
+        return (u128)(w[0] | ((uint64_t)w[1] << 32)) | ((u128)(w[2] | ((uint64_t)w[3] << 32)) << 64);
+    }
+    static __device__ __forceinline__ uint64_t direction_words(uint64_t a)
+    {
+        const uint64_t even = 0x5555555555555555ull;
+        const uint64_t follows = a << 1;                       // words preceded by an acceptable word
+        const uint64_t odd_starts = a & ~even & ~follows;      // runs of A that start on an odd bit
+        const uint64_t even_start_runs = odd_starts + a;       // carry ripples through those runs
+        return (even ^ (even_start_runs << 1)) & follows;
+    }
+    static __device__ __forceinline__ void reset_where(const Shared &, const Params &p, State &st, bool fresh,
+                                                       const RngKey &key, uint32_t lane)
+    {
+        uint64_t todo = __ballot(fresh);
+        if (todo == 0ull) return;                                            // wave-uniform
+        const int me = (int)(threadIdx.x & 63u);
+        const int X = p.x_size, Y = p.y_size, cells = X * Y;
+        const uint32_t rmask = 0xFFFFFFFFu >> __clz((uint32_t)(cells - 1) | 1u); // randint(cells) bit-smear mask
+        const u128 col0 = u128_of(p.col0), colL = col0 << (X - 1);
+        const uint32_t inv_x = (65536u + (uint32_t)X - 1u) / (uint32_t)X;   // a / X == (a * inv_x) >> 16 for a < 128, X <= 16
+        while (todo != 0ull) {
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1ull;
+            const uint32_t glane = (uint32_t)__builtin_amdgcn_readlane((int)lane, src);
+            int c = 0;                                                        // next unread word of the stream
+            u128 occ = 0;
+            int remaining = 0;
+            for (int len = p.max_len; len >= 2; --len) {
+                // blocked = occ and its N, E, S, W, NE, SE, SW shifts (NW excluded) in four 128-bit shifts:
+                // h = {self, E, W}; south side = h << X (S, SE, SW); north side = {self, E} >> X (N, NE)
+                const u128 e1 = (occ & ~col0) >> 1, h = occ | e1 | ((occ & ~colL) << 1);
+                const u128 blocked = h | ((occ | e1) >> X) | (h << X);
+                const u128 hpat = ((u128)1 << (len + 1)) - 1;                 // the L+1 checked cells, from bit 0
+                const u128 vpat = u128_of(p.vpat[len + 1]);
+                for (;;) {
+                    const uint32_t wi = (uint32_t)(c + me);
+                    const uint4 blk = stream_block(key, glane, POMDP_STREAM_RESET, (wi >> 2) & 0xFFFFFFu);
+                    const uint32_t sel = wi & 3u;
+                    const uint32_t word = sel == 0 ? blk.x : sel == 1 ? blk.y : sel == 2 ? blk.z : blk.w;
+                    const uint64_t A = __ballot((word & rmask) <= (uint32_t)(cells - 1));
+                    const uint64_t D = direction_words(A);
+                    const uint64_t cand = A & ~D & 0x7FFFFFFFFFFFFFFFull;     // position word with its direction word in the window
+                    const uint32_t dirword = (uint32_t)__shfl((int)word, (me + 1) & 63, 64);
+                    const int a0 = (int)(word & rmask);
+                    const uint32_t dir = dirword & 3u;
+                    const int dx = (dir == 1u) - (dir == 3u), dy = (dir == 0u) - (dir == 2u);   // Compass N E S W
+                    const int py = (int)(((uint32_t)a0 * inv_x) >> 16), px = a0 - py * X;
+                    const int ex = px + (len + 1) * dx, ey = py + (len + 1) * dy;
+                    const int stride = dy * X + dx;
+                    const bool inside = (unsigned)ex < (unsigned)X && (unsigned)ey < (unsigned)Y;
+                    const int lo = stride > 0 ? a0 : a0 + len * stride;
+                    const u128 cellsm = (dx != 0 ? hpat : vpat) << (lo & 127);
+                    const bool ok = ((cand >> me) & 1ull) && inside && (cellsm & blocked) == 0;
+                    const uint64_t succ = __ballot(ok);
+                    if (succ != 0ull) {
+                        const int r = __ffsll((long long)succ) - 1;
+                        const int a0w = __builtin_amdgcn_readlane(a0, r), sw = __builtin_amdgcn_readlane(stride, r);
+                        // mark_ship: L cells from pos = the L-cell pattern shifted to its lowest cell
+                        const int low = sw > 0 ? a0w : a0w + (len - 1) * sw;
+                        occ |= ((sw == 1 || sw == -1) ? (((u128)1 << len) - 1) : u128_of(p.vpat[len])) << low;
+                        remaining += len;
+                        c += r + 2;
+                        break;
+                    }
+                    // no placement here: word 63 is unread only if it is an accepted position word (its direction
+                    // word lies in the next window)
+                    c += ((A & ~D) >> 63) ? 63 : 64;
+                }
+            }
+            if (me == src) {
+                st.occ.lo = (uint64_t)occ; st.occ.hi = (uint64_t)(occ >> 64);
+                st.vis.lo = 0; st.vis.hi = 0;
+                st.vis.set_word(MW - 1, (uint32_t)remaining << 26);
+            }
+        }
+    }
+    static __device__ __forceinline__ void reset_where_chain(const Shared &sh, const Params &p, State &st, bool fresh,
+                                                             const RngKey &key, uint32_t lane, const RngKey &akey,
+                                                             uint32_t n_actions, int &next_action)
+    {
+        reset_where_chain_default<BattleShipEnv<MW>>(sh, p, st, fresh, key, lane, akey, n_actions, next_action);
+    }
+
+    // battleship.py:157-165 _generate_legal: the unvisited cells, ascending
+    static __device__ __forceinline__ uint32_t unvisited(const Params &p, const State &st, int j)
+    {
+        const int cells = p.x_size * p.y_size, lo = 32 * j;
+        const uint32_t valid = cells - lo >= 32 ? 0xFFFFFFFFu : (cells > lo ? (1u << (cells - lo)) - 1u : 0u);
+        return ~st.vis.word(j) & valid;
+    }
+    static __device__ __forceinline__ int legal_count(const Shared &, const Params &p, const State &st)
+    {
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < MW; ++j) c += __popc(unvisited(p, st, j));
+        return c;
+    }
+    static __device__ __forceinline__ int legal_nth(const Shared &, const Params &p, const State &st, int idx)
+    {
+        int a = 0;
+#pragma unroll
+        for (int j = 0; j < MW; ++j) {
+            uint32_t z = unvisited(p, st, j);
+            const int c = __popc(z);
+            if (idx >= 0 && idx < c) {
+                for (int k = idx; k > 0; --k) z &= z - 1u;
+                a = 32 * j + __ffs((int)z) - 1;
+            }
+            idx -= c;
+        }
+        return a;
+    }
+
+    // no heuristic: _generate_preferred is _generate_legal (0 = fall back to the legal list)
+    static __device__ __forceinline__ uint32_t preferred_mask(const Shared &, const Params &, const State &,
+                                                              const pomdp_rock_belief &, const pomdp_history &, int64_t,
+                                                              uint32_t) { return 0u; }
+    static __device__ __forceinline__ uint32_t preferred_mask(const Shared &, const Params &, const State &,
+                                                              const pomdp_history &, int64_t, uint32_t, uint32_t, uint32_t,
+                                                              int) { return 0u; }
+    // battleship.py:80-89 _compute_prob (reads the grid as it is after the shot)
+    static __device__ __forceinline__ double compute_prob(const Shared &, const Params &, const State &st, int a, int ob)
+    {
+        if (ob == 0 && bit(st.vis, a)) return 1.0;
+        if (ob == 1 && bit(st.occ, a)) return 1.0;
+        return ob == 0 ? 1.0 : 0.0;
+    }
+
+    // battleship.py:91-122
+    template <class RT>
+    static __device__ __forceinline__ void step(const Shared &, const Params &p, State &st, int a,
+                                                const RngKey &, uint32_t, int &ob, RT &rew, int &done)
+    {
+        int remaining = (int)(st.vis.word(MW - 1) >> 26);
+        ob = 0; done = 0;
+        if (bit(st.vis, a)) rew = -10;
+        else {
+            rew = -1;
+            if (bit(st.occ, a)) { ob = 1; remaining -= 1; }
+            set_bit(st.vis, a);
+        }
+        if (remaining == 0) { rew += p.x_size * p.y_size; done = 1; }
+        st.vis.set_word(MW - 1, (st.vis.word(MW - 1) & 0x03FFFFFFu) | ((uint32_t)remaining << 26));
+    }
+};
+
+} // namespace pomdp

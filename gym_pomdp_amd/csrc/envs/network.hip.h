@@ -1,0 +1,123 @@
+// envs/network.hip.h — Network (gym_pomdp/envs/network.py): the lane functions the generic kernels of pomdp_kernels.hip call.
+// Included by envs.hip.h (which holds the Env interface description and the shared helpers).
+#pragma once
+#include "../envs_common.hip.h"
+
+namespace pomdp {
+
+struct NetworkEnv {
+    using Params = pomdp_network_params;
+    using Reward = float;
+    static constexpr int WORDS = 1;
+    static constexpr bool POOLED_LPT2 = false;
+    static constexpr bool QUAD_SENSOR = false;
+    static constexpr int ABL = 0;
+    struct Shared { int unused; };
+    struct State { uint32_t w; };
+
+    static __device__ __forceinline__ void stage(Shared &, const Params &, int) {}
+    static __device__ __forceinline__ int n_actions(const Params &p) { return 2 * p.n_machines + 1; }
+    static __device__ __forceinline__ void load(State &st, const uint32_t *state, int64_t, uint32_t i) { st.w = ld_stream(state + i); }
+    static __device__ __forceinline__ void store(const State &st, uint32_t *state, int64_t, uint32_t i, bool) { st_stream(state + i, st.w); }
+
+    // network.py:61-69: all machines up, ob = OFF (0)
+    static __device__ __forceinline__ int reset(const Shared &, const Params &p, State &st, const RngKey &, uint32_t)
+    {
+        st.w = p.n_machines >= 32 ? 0xFFFFFFFFu : ((1u << p.n_machines) - 1u);
+        return 0;
+    }
+    static __device__ __forceinline__ int reset_ob(const Params &, const State &) { return 0; }
+
+    // Called convergently by every lane of the wave; `fresh` marks the lanes that start a new episode.
+    static __device__ __forceinline__ void reset_where(const Shared &sh, const Params &p, State &st, bool fresh,
+                                                       const RngKey &key, uint32_t lane)
+    {
+        if (fresh) reset(sh, p, st, key, lane);
+    }
+    static __device__ __forceinline__ void reset_where_chain(const Shared &sh, const Params &p, State &st, bool fresh,
+                                                             const RngKey &key, uint32_t lane, const RngKey &akey,
+                                                             uint32_t n_actions, int &next_action)
+    {
+        reset_where_chain_default<NetworkEnv>(sh, p, st, fresh, key, lane, akey, n_actions, next_action);
+    }
+    // network.py:130-131: every action is legal
+    static __device__ __forceinline__ int legal_count(const Shared &, const Params &p, const State &) { return n_actions(p); }
+    static __device__ __forceinline__ int legal_nth(const Shared &, const Params &, const State &, int idx) { return idx; }
+
+    // no heuristic: _generate_preferred is _generate_legal (0 = fall back to the legal list)
+    static __device__ __forceinline__ uint32_t preferred_mask(const Shared &, const Params &, const State &,
+                                                              const pomdp_rock_belief &, const pomdp_history &, int64_t,
+                                                              uint32_t) { return 0u; }
+    static __device__ __forceinline__ uint32_t preferred_mask(const Shared &, const Params &, const State &,
+                                                              const pomdp_history &, int64_t, uint32_t, uint32_t, uint32_t,
+                                                              int) { return 0u; }
+    // network.py:43-55 _compute_prob
+    static __device__ __forceinline__ double compute_prob(const Shared &, const Params &p, const State &st, int a, int ob)
+    {
+        if (a < 2 * p.n_machines) return ((int)((st.w >> (a >> 1)) & 1u) == ob) ? .95 : 1 - .95;
+        return ob == 2 ? 1.0 : 0.0;
+    }
+
+    // network.py:71-114.  The reference draws one double per *up* machine in index order, then one for
+    // the action.  Lanes iterate over the draws (j = 0, 1, ...), not over the machines: j is
+    // wave-uniform, so the Philox block that feeds doubles 2q and 2q+1 is generated under a uniform
+    // condition and the only divergence left is the per-lane number of up machines.
+    template <class RT>
+    static __device__ __forceinline__ void step(const Shared &, const Params &p, State &st, int a,
+                                                const RngKey &key, uint32_t lane, int &ob, RT &rew, int &done)
+    {
+        const uint32_t s0 = st.w;
+        uint32_t s = s0;
+        const int M = p.n_machines;
+        // reward: 2 per up machine with > 2 neighbours, 1 per other up machine   network.py:87-92
+        double r = (double)(__popc(s0) + __popc(s0 & p.deg_gt2_mask));
+        // machines whose neighbourhood has a failure, from the pre-update state    network.py:82-85
+        uint32_t nb_failed = 0;
+        for (int i = 0; i < M; ++i) nb_failed |= ((~s0 & p.nb_mask[i]) != 0u ? 1u : 0u) << i;
+        const bool has_action = a < 2 * M;
+        const int n_draws = __popc(s0) + (has_action ? 1 : 0);
+        // Split word layout: double j compares by its high word — element j & 3 of block 2 (j >> 2) —
+        // and needs its low word (same element of the next block) only on a tie, probability 2^-27 per draw.  One
+        // Philox block therefore serves four draws instead of two.  Thresholds as (high 27 bits, low 26 bits).
+        constexpr uint32_t LO = (1u << 26) - 1u;
+        const uint32_t th_fail = (uint32_t)(p.fail_thr >> 26), tl_fail = (uint32_t)p.fail_thr & LO;
+        const uint32_t th_nb = (uint32_t)(p.fail_nb_thr >> 26), tl_nb = (uint32_t)p.fail_nb_thr & LO;
+        const uint32_t th_obs = (uint32_t)(p.obs_thr >> 26), tl_obs = (uint32_t)p.obs_thr & LO;
+        uint32_t todo = s0;
+        uint4 blk = make_uint4(0, 0, 0, 0);
+        bool truthful = false;
+        for (int j = 0; __any(j < n_draws); ++j) {
+            if ((j & 3) == 0) blk = stream_block(key, lane, POMDP_STREAM_STEP, 2u * (uint32_t)(j >> 2));
+            const uint32_t H = (j & 3) == 0 ? blk.x : (j & 3) == 1 ? blk.y : (j & 3) == 2 ? blk.z : blk.w;
+            const bool machine_draw = todo != 0u;                                // network.py:94-99, else the action's draw
+            const int i = __ffs((int)todo) - 1;
+            const bool nbf = machine_draw && ((nb_failed >> (i & 31)) & 1u);
+            const uint32_t th = machine_draw ? (nbf ? th_nb : th_fail) : th_obs;
+            const uint32_t tl = machine_draw ? (nbf ? tl_nb : tl_fail) : tl_obs;
+            const uint32_t kh = H >> 5;
+            bool le = kh < th;                                                   // k53 <= thr, decided by the high word
+            if (kh == th) {                                                      // tie: fetch the low word
+                const uint4 lo = stream_block(key, lane, POMDP_STREAM_STEP, 2u * (uint32_t)(j >> 2) + 1u);
+                const uint32_t L = (j & 3) == 0 ? lo.x : (j & 3) == 1 ? lo.y : (j & 3) == 2 ? lo.z : lo.w;
+                le = (L >> 6) <= tl;
+            }
+            if (machine_draw) {
+                if (!le) s &= ~(1u << i);                                        // fails iff k > thr
+                todo &= todo - 1u;
+            } else if (j < n_draws) {
+                truthful = le;
+            }
+        }
+        ob = 2;
+        if (has_action) {                                                        // network.py:101-112
+            const int machine = a >> 1;
+            if (a & 1) { r -= 2.5; s |= 1u << machine; ob = truthful; }
+            else { r -= .1; const int up = (int)((s >> machine) & 1u); ob = truthful ? up : 1 - up; }
+        }
+        rew = (RT)r;    // float32(float64 value) for the step kernel, the float64 itself for rollouts
+        done = 0;
+        st.w = s;
+    }
+};
+
+} // namespace pomdp

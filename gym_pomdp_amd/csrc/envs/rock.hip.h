@@ -1,0 +1,438 @@
+// envs/rock.hip.h — RockSample / StochasticRock (gym_pomdp/envs/rock.py): the lane functions the generic kernels of pomdp_kernels.hip call.
+// Included by envs.hip.h (which holds the Env interface description and the shared helpers).
+#pragma once
+#include "../envs_common.hip.h"
+
+namespace pomdp {
+
+// Word contract of the RockSample envs ("split layout").  Every draw RockSample makes is a numpy double
+// = (high word H, low word L) -> k53 = (H >> 5) * 2^26 + (L >> 6).  H and L live in DIFFERENT Philox blocks:
+//   reset  (stream RESET, counter word 0 = lane):      double j = rock j:  H = block 2 (j >> 2), L = block 2 (j >> 2) + 1,
+//                                                       element j & 3;
+//   step   (stream STEP,  counter word 0 = lane >> 2): double j (RockEnv: j = 0 the sensor; StochasticRockEnv:
+//                                                       j = 0 the action gate, j = 1 the sensor): H = block 2 j,
+//                                                       L = block 2 j + 1, element lane & 3 — one block serves the four
+//                                                       lanes of a quad.
+// A comparison k53 <= thr is decided by H alone unless (H >> 5) == (thr >> 26), which happens with probability 2^-27
+// per draw; only then is the L block generated.  So a reset costs ceil(K / 4) blocks instead of ceil(K / 2), a
+// quad's sensor draws cost one block instead of four, and a wave's whole step fits one pooled Philox pass.
+//
+// ABLATE is a profiling aid (tools/microbench.hip): bit 0 drops the sensor Philox block, bit 1 the auto-reset,
+// bit 2 the LDS table lookups.  The product only instantiates ABLATE = 0.  STOCH selects StochasticRockEnv
+// (rock.py:428-504).
+template <int W, int ABLATE = 0, bool STOCH = false> // W = state words per lane: 1 (K <= 12) or 2
+struct RockEnv {
+    using Params = pomdp_rock_params;
+    using Reward = int32_t;
+    using S = typename std::conditional<W == 1, uint32_t, uint64_t>::type; // 32-bit ALU when one word is enough
+    static constexpr int WORDS = W;
+    static constexpr bool POOLED_LPT2 = !STOCH;   // pomdp_kernels.hip: Finisher<RockEnv, 2, .>
+    static constexpr int ABL = ABLATE;            // experiment switches (tools/microbench.hip); 0 in the product
+    struct Shared {
+        uint32_t thr_hi[32];   // sensor threshold by L1 distance, thr >> 26  (compared with H >> 5)
+        uint32_t thr_lo[32];   // thr & (2^26 - 1)                            (compared with L >> 6 on a tie)
+        int8_t grid[256];      // rock id stamped at [x * 16 + y], -1 = none
+        uint8_t rxy[16];       // rock j position, x | y << 4
+    };
+    struct State { S s; };
+    // what the lane step leaves for the deferred sensor draw (pooled launches fetch H from the wave's task pass)
+    struct Aux { uint32_t th, tl; bool good, want; };
+
+    static constexpr uint32_t LO_MASK = (1u << 26) - 1u;
+    static constexpr uint32_t HALF_HI = 1u << 26;            // 2^52 >> 26: the reset's "U > .5" threshold
+
+    // One global-load latency: every thread fetches a slice of the kernarg-resident tables with
+    // unconditional (index-wrapped) loads, all issued before the first LDS write, so the compiler
+    // emits one s_waitcnt instead of one per predicated region; duplicate writers store equal values.
+    // Split in two so that a kernel can put independent work between the table loads and their first use.
+    struct Staged { int8_t g, rx, ry; uint64_t t; };
+    static __device__ __forceinline__ Staged stage_load(const Params &p, int tid)
+    {
+        Staged r;
+        r.g = p.grid[tid & 255];
+        r.t = p.thr[tid & 31];
+        r.rx = p.rock_x[tid & 15];
+        r.ry = p.rock_y[tid & 15];
+        return r;
+    }
+    static __device__ __forceinline__ void stage_store(Shared &sh, const Staged &r, int tid)
+    {
+        sh.grid[tid & 255] = r.g;
+        sh.thr_hi[tid & 31] = (uint32_t)(r.t >> 26);
+        sh.thr_lo[tid & 31] = (uint32_t)r.t & LO_MASK;
+        sh.rxy[tid & 15] = (uint8_t)((r.rx & 15) | (r.ry << 4));
+    }
+    static __device__ __forceinline__ void stage(Shared &sh, const Params &p, int tid) { stage_store(sh, stage_load(p, tid), tid); }
+    static __device__ __forceinline__ int n_actions(const Params &p) { return 5 + p.num_rocks; }
+
+    static constexpr bool NT = !(ABLATE & 16);
+    static __device__ __forceinline__ void load(State &st, const uint32_t *state, int64_t n, uint32_t i)
+    {
+        st.s = ld_stream<NT>(state + i);
+        if (W == 2) st.s |= (S)((uint64_t)ld_stream<NT>(state + n + i) << 32);
+    }
+    static __device__ __forceinline__ void store(const State &st, uint32_t *state, int64_t n, uint32_t i, bool)
+    {
+        st_stream<NT>(state + i, (uint32_t)st.s);
+        if (W == 2) st_stream<NT>(state + n + i, (uint32_t)((uint64_t)st.s >> 32));
+    }
+
+    static __device__ __forceinline__ uint32_t elem(const uint4 &w, uint32_t e) { return e == 0 ? w.x : e == 1 ? w.y : e == 2 ? w.z : w.w; }
+
+    // ---- split-layout draws ---------------------------------------------------------------------------------
+    // k53 <= (th << 26 | tl)?  decided by the high word; `lo()` (the L word) is only evaluated on a tie
+    template <class LowWord>
+    static __device__ __forceinline__ bool k53_le(uint32_t H, uint32_t th, uint32_t tl, LowWord lo)
+    {
+        const uint32_t kh = H >> 5;
+        bool r = kh < th;
+        if (kh == th) r = (lo() >> 6) <= tl;                                  // probability 2^-27
+        return r;
+    }
+    // status + 1 of a fresh rock, sign(k53 - 2^52) + 1, from its high word; 3 = undecided (needs the low word)
+    static __device__ __forceinline__ uint32_t rock_code_hi(uint32_t H)
+    {
+        const uint32_t kh = H >> 5;
+        return kh > HALF_HI ? 2u : (kh < HALF_HI ? 0u : 3u);
+    }
+    static __device__ __forceinline__ uint32_t rock_code_lo(uint32_t L) { return (L >> 6) ? 2u : 1u; }   // kh == 2^26 exactly
+    // the 2-bit codes of rocks 4 g .. 4 g + 3 (8 bits) of lane `lane`'s fresh episode: one high block, low block on a tie
+    static __device__ __forceinline__ uint32_t reset_group(const RngKey &key, uint32_t lane, int g, int K)
+    {
+        const uint4 h = stream_block(key, lane, POMDP_STREAM_RESET, 2u * (uint32_t)g);
+        return reset_group_codes(h, key, lane, g, K);
+    }
+    static __device__ __forceinline__ uint32_t reset_group_codes(const uint4 &h, const RngKey &key, uint32_t lane, int g, int K)
+    {
+        uint32_t c0 = rock_code_hi(h.x), c1 = rock_code_hi(h.y), c2 = rock_code_hi(h.z), c3 = rock_code_hi(h.w);
+        if (c0 == 3u || c1 == 3u || c2 == 3u || c3 == 3u) {                    // some rock undecided: 2^-27 per rock
+            const uint4 l = stream_block(key, lane, POMDP_STREAM_RESET, 2u * (uint32_t)g + 1u);
+            if (c0 == 3u) c0 = rock_code_lo(l.x);
+            if (c1 == 3u) c1 = rock_code_lo(l.y);
+            if (c2 == 3u) c2 = rock_code_lo(l.z);
+            if (c3 == 3u) c3 = rock_code_lo(l.w);
+        }
+        const int j = 4 * g;
+        return (j < K ? c0 : 0u) | (j + 1 < K ? c1 << 2 : 0u) | (j + 2 < K ? c2 << 4 : 0u) | (j + 3 < K ? c3 << 6 : 0u);
+    }
+    // block `j2` (0 = sensor / gate high words, 1 = their low words, 2 / 3 = StochasticRock's sensor) of lane's quad
+    static __device__ __forceinline__ uint4 quad_block(const RngKey &key, uint32_t lane, uint32_t j2)
+    {
+        return philox4x32_10(lane >> 2, key.t_lo, key.t_hi, ((uint32_t)POMDP_STREAM_STEP << 24) | j2, key.k0, key.k1);
+    }
+
+    // rock.py:236-241 reset -> 266-271 _get_init_state -> 78-86 Rock.__init__:
+    // status_j = sign(U_j - .5), rocks in index order, one double each.
+    static __device__ __forceinline__ int reset(const Shared &, const Params &p, State &st, const RngKey &key,
+                                                uint32_t lane)
+    {
+        uint64_t s = (uint32_t)p.start_x | ((uint32_t)p.start_y << 4);
+        const int K = p.num_rocks;
+        for (int g = 0; 4 * g < K; ++g) s |= (uint64_t)reset_group(key, lane, g, K) << (8 + 8 * g);
+        st.s = (S)s;
+        return 0; // Obs.NULL
+    }
+    static __device__ __forceinline__ int reset_ob(const Params &, const State &) { return 0; }   // what reset() returned
+
+    // Wave-cooperative reset (one lane per thread launches).  A fresh episode needs NG = ceil(K/4) high blocks, only
+    // ~1/8 of a wave's lanes reset in a given step while nearly every wave has at least one: done per lane, the whole
+    // wave would pay all NG blocks.  Instead the (resetting lane, block) tasks are dealt out across the 64 lanes — one
+    // Philox block per lane per pass — and the rock codes travel back through ds_bpermute.
+    static __device__ __forceinline__ void reset_where(const Shared &sh, const Params &p, State &st, bool fresh,
+                                                       const RngKey &key, uint32_t lane)
+    {
+        int unused;
+        reset_core<false>(sh, p, st, fresh, key, lane, key, 1u, unused);
+    }
+    // Same pass, plus the synthetic policy's actions for the NEXT call counter (C-side rollout driver, policy and
+    // env sharing the Philox key): the wave's 16 action blocks ride in lanes 0-15 of the first pass.
+    static __device__ __forceinline__ void reset_where_chain(const Shared &sh, const Params &p, State &st, bool fresh,
+                                                             const RngKey &key, uint32_t lane, const RngKey &akey,
+                                                             uint32_t n_actions, int &next_action)
+    {
+        reset_core<true>(sh, p, st, fresh, key, lane, akey, n_actions, next_action);
+    }
+
+    template <bool CHAIN>
+    static __device__ __forceinline__ void reset_core(const Shared &, const Params &p, State &st, bool fresh,
+                                                      const RngKey &key, uint32_t lane, const RngKey &akey,
+                                                      uint32_t n_actions, int &next_action)
+    {
+        if (ABLATE & 2) { if (CHAIN) next_action = synthetic_action(akey, lane, n_actions); return; }
+        const uint64_t mask = __ballot(fresh);
+        if (!CHAIN && mask == 0ull) return;                            // wave-uniform
+        const int K = p.num_rocks;
+        const int NG = (K + 3) >> 2;                                   // high blocks per reset (wave-uniform, 1..4)
+        const int lid = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        const int me = (int)(threadIdx.x & 63u);
+        const int nreset = __popcll(mask);
+        // stable partition: resetting lanes first; lane r (< nreset) learns who the r-th resetting lane is
+        const int dst = fresh ? lid : nreset + (me - lid);
+        const int src_of_rank = __builtin_amdgcn_ds_permute(dst << 2, me);
+        constexpr int NA = CHAIN ? 16 : 0;                             // task list: [16 policy blocks] ++ [NG per reset]
+        const int ntask = NA + nreset * NG;
+        const uint32_t inv = (65536u + (uint32_t)NG - 1u) / (uint32_t)NG; // t / NG == (t * inv) >> 16 for t < 512
+        uint64_t bits = 0;
+        uint4 aw = make_uint4(0, 0, 0, 0);
+        for (int base = 0; base < ntask; base += 64) {
+            const int tid = base + me;
+            const bool is_act = CHAIN && tid < NA;
+            const int rt = tid < NA ? 0 : tid - NA;
+            const int r = (int)(((uint32_t)rt * inv) >> 16), g = rt - r * NG;
+            const int srcl = __shfl(src_of_rank, r & 63, 64);
+            uint32_t codes = 0;
+            if (tid < ntask) {
+                // ONE Philox instance for both task kinds: the counter words are per-lane selects
+                const uint32_t src_lane = lane - (uint32_t)me + (uint32_t)srcl;
+                const uint32_t c0 = is_act ? ((lane - (uint32_t)me) >> 2) + (uint32_t)tid : src_lane;
+                const uint32_t c1 = is_act ? akey.t_lo : key.t_lo, c2 = is_act ? akey.t_hi : key.t_hi;
+                const uint32_t c3 = is_act ? ((uint32_t)POMDP_STREAM_ACTION << 24) : (((uint32_t)POMDP_STREAM_RESET << 24) | (2u * (uint32_t)g));
+                const uint4 w = philox4x32_10(c0, c1, c2, c3, key.k0, key.k1);
+                if (CHAIN && base == 0) aw = w;                        // lanes >= 16 hold words nobody reads
+                if (!is_act) codes = reset_group_codes(w, key, src_lane, g, K);
+            }
+            for (int gg = 0; gg < NG; ++gg) {                          // wave-uniform trip count
+                const int t = NA + lid * NG + gg - base;
+                const uint32_t got = (uint32_t)__shfl((int)codes, t & 63, 64);
+                if (t >= 0 && t < 64) bits |= (uint64_t)got << (8 + 8 * gg);
+            }
+            if (CHAIN && base == 0) {
+                // lane l takes word (l & 3) of the policy block computed by lane l >> 2
+                const int q = me >> 2;
+                const uint32_t x = (uint32_t)__shfl((int)aw.x, q, 64), y = (uint32_t)__shfl((int)aw.y, q, 64);
+                const uint32_t z = (uint32_t)__shfl((int)aw.z, q, 64), ww = (uint32_t)__shfl((int)aw.w, q, 64);
+                const int b = me & 3;
+                next_action = (int)__umulhi(b == 0 ? x : b == 1 ? y : b == 2 ? z : ww, n_actions);
+            }
+        }
+        if (fresh) st.s = (S)((uint64_t)((uint32_t)p.start_x | ((uint32_t)p.start_y << 4)) | bits);
+    }
+
+    // rock.py:273-291 _generate_legal, in the reference's list order: EAST, then NORTH / SOUTH / WEST when
+    // in-grid, SAMPLE on an uncollected rock, then CHECK(grid[rock.pos]) per uncollected rock (rock order;
+    // RockSample(15,15)'s duplicated coordinate makes CHECK 3 appear twice — kept, it weights the draw).
+    static __device__ __forceinline__ int legal_count(const Shared &sh, const Params &p, const State &st, uint32_t &pre,
+                                                      int &n_pre, uint32_t &alive)
+    {
+        const S s = st.s;
+        const int x = (int)(s & 15u), y = (int)((s >> 4) & 15u), K = p.num_rocks;
+        pre = 1u; n_pre = 1;                                                     // 3 bits per entry
+        if (y + 1 < p.size) { pre |= 0u << (3 * n_pre); ++n_pre; }
+        if (y - 1 >= 0) { pre |= 2u << (3 * n_pre); ++n_pre; }
+        if (x - 1 >= 0) { pre |= 3u << (3 * n_pre); ++n_pre; }
+        const int id = sh.grid[x * 16 + y];
+        if (id >= 0 && id < K && ((uint32_t)(s >> (8 + 2 * (id & 15))) & 3u) != 1u) { pre |= 4u << (3 * n_pre); ++n_pre; }
+        // uncollected rocks (code != 1), all K at once: with the 2-bit codes spread over even/odd bits,
+        // "collected" is (low bit set, high bit clear); alive stays in spread form, rock j at bit 2 j
+        const uint64_t r = (uint64_t)s >> 8;
+        const uint64_t even = 0x5555555555555555ull;
+        const uint64_t spread = ~(r & ~(r >> 1)) & even & ((1ull << (2 * K)) - 1ull);
+        alive = (uint32_t)spread;                                      // K <= 16 rocks: 32 bits
+        return n_pre + __popc(alive);
+    }
+    static __device__ __forceinline__ int legal_nth(const Shared &sh, const Params &p, const State &st, int idx)
+    {
+        uint32_t pre, alive; int n_pre;
+        legal_count(sh, p, st, pre, n_pre, alive);
+        if (idx < n_pre) return (int)((pre >> (3 * idx)) & 7u);
+        // rock j sits at bit 2 j of `alive`: the (idx - n_pre)-th set bit, without a data-dependent loop
+        const int j = nth_set_bit(alive, idx - n_pre) >> 1;
+        const uint32_t rxy = sh.rxy[j & 15];
+        return 5 + sh.grid[(rxy & 15u) * 16 + (rxy >> 4)];
+    }
+    static __device__ __forceinline__ int legal_count(const Shared &sh, const Params &p, const State &st)
+    {
+        uint32_t pre, alive; int n_pre;
+        return legal_count(sh, p, st, pre, n_pre, alive);
+    }
+
+    // ---- heuristic-policy support ------------------------------------------------------
+    // the "worth another CHECK" test of rock.py:371 on one rock's statistics
+    static __device__ __forceinline__ bool check_ok(int measured, int count, double pv)
+    {
+        return measured < 5 && abs(count) < 2 && 0 < pv && pv < 1;
+    }
+    // rock.py:177-191: side statistics of the rock a CHECK just measured (CHECK does not move the agent, so the
+    // stored position is the one the reading was taken from); keeps the rock's bit of b.check_ok current
+    static __device__ __forceinline__ void belief_update(const Shared &sh, const Params &p, const State &st, int a, int ob,
+                                                         const pomdp_rock_belief &b, int64_t n, uint32_t i)
+    {
+        const S s = st.s;
+        const int x = (int)(s & 15u), y = (int)((s >> 4) & 15u), r = (a - 5) & 15;
+        const uint32_t rxy = sh.rxy[r];
+        const double eff = p.eff[abs(x - (int)(rxy & 15u)) + abs(y - (int)(rxy >> 4))];
+        const int64_t k = (int64_t)r * n + i;
+        double lkv = b.lkv[k], lkw = b.lkw[k];
+        const int measured = b.measured[k] + 1;
+        int count = b.count[k];
+        if (ob == 2) { count += 1; lkv *= eff; lkw *= (1 - eff); }
+        else         { count -= 1; lkw *= eff; lkv *= (1 - eff); }
+        const double denom = (.5 * lkv) + (.5 * lkw);
+        const double pv = (.5 * lkv) / denom;
+        b.measured[k] = measured;
+        b.count[k] = count;
+        b.lkv[k] = lkv;
+        b.lkw[k] = lkw;
+        b.prob_valuable[k] = pv;
+        const uint32_t bit = 1u << r, m = b.check_ok[i];
+        b.check_ok[i] = check_ok(measured, count, pv) ? (m | bit) : (m & ~bit);
+    }
+
+    // rock.py:293-374 _generate_preferred with use_heuristic=True, as a bitmask over actions: every list the
+    // heuristic builds is in ascending action order ([SAMPLE], [EAST], or N/E/S/W then the CHECKs by rock index);
+    // 0 = the heuristic produced nothing and the caller falls back to _generate_legal() (rock.py:374-375).
+    // Per-rock tests come from the two derived words b.check_ok / h.move_ok: 16 bytes per lane, whatever K is.
+    static __device__ __forceinline__ uint32_t preferred_mask(const Shared &sh, const Params &p, const State &st,
+                                                              const pomdp_rock_belief &b, const pomdp_history &h,
+                                                              int64_t n, uint32_t i)
+    {
+        return preferred_mask(sh, p, st, h, n, i, ld_stream(b.check_ok + i), ld_stream(h.move_ok + i), ld_stream(h.size + i));
+    }
+    // the same with the lane's three per-lane words already loaded (the fused kernel issues those loads up front)
+    static __device__ __forceinline__ uint32_t preferred_mask(const Shared &sh, const Params &p, const State &st,
+                                                              const pomdp_history &h, int64_t n, uint32_t i, uint32_t ck,
+                                                              uint32_t mv, int hsize)
+    {
+        const S s = st.s;
+        const int x = (int)(s & 15u), y = (int)((s >> 4) & 15u), K = p.num_rocks;
+        const int id = sh.grid[x * 16 + y];
+        if (id >= 0 && id < K && ((uint32_t)(s >> (8 + 2 * (id & 15))) & 3u) != 1u && hsize != 0)
+            if (h.total_sample[(int64_t)id * n + i] > 0) return 1u << 4;                          // rock.py:300-313
+        uint32_t alive = 0;                                                                       // uncollected rocks
+        for (int j = 0; j < K; ++j) alive |= (uint32_t)(((uint32_t)(s >> (8 + 2 * j)) & 3u) != 1u) << j;
+        uint32_t am = alive & mv;                                                                 // rock.py:335: total >= 0
+        if (!am) return 1u << 1;                                                                  // all_bad: rock.py:347-349
+        bool north = false, south = false, west = false, east = false;
+        while (am) {                                                                              // rock.py:338-345
+            const int j = __ffs((int)am) - 1;
+            am &= am - 1u;
+            const uint32_t rxy = sh.rxy[j];
+            const int rx = (int)(rxy & 15u), ry = (int)(rxy >> 4);
+            if (ry > y) north = true;
+            else if (ry < y) south = true;
+            else if (rx < x) west = true;
+            else if (rx > x) east = true;
+        }
+        uint32_t m = (alive & ck) << 5;                                                           // rock.py:370-372
+        if (y + 1 < p.size && north) m |= 1u << 0;                                                // rock.py:358-368
+        if (east) m |= 1u << 1;
+        if (y - 1 >= 0 && south) m |= 1u << 2;
+        if (x - 1 >= 0 && west) m |= 1u << 3;
+        return m;
+    }
+
+    // rock.py:389-399 _select_target; distances compared as dx^2 + dy^2 (the reference takes the square root of the
+    // same integers, coord.py:83-85, and every candidate is below its initial bound of 2 * size)
+    static __device__ __forceinline__ int select_target(const Shared &sh, const Params &p, const State &st,
+                                                        const pomdp_rock_belief &b, int64_t n, uint32_t i)
+    {
+        const S s = st.s;
+        const int x = (int)(s & 15u), y = (int)((s >> 4) & 15u), K = p.num_rocks;
+        int best = 4 * p.size * p.size, best_rock = -1;
+        for (int j = 0; j < K; ++j) {
+            if (((uint32_t)(s >> (8 + 2 * j)) & 3u) == 1u || b.count[(int64_t)j * n + i] < 0) continue;
+            const uint32_t rxy = sh.rxy[j];
+            const int dx = x - (int)(rxy & 15u), dy = y - (int)(rxy >> 4), d2 = dx * dx + dy * dy;
+            if (d2 < best) { best = d2; best_rock = j; }
+        }
+        return best_rock;
+    }
+
+    // rock.py:250-264 _compute_prob
+    static __device__ __forceinline__ double compute_prob(const Shared &sh, const Params &p, const State &st, int a, int ob)
+    {
+        if (a <= 4) return ob == 0 ? 1.0 : 0.0;
+        const S s = st.s;
+        const int x = (int)(s & 15u), y = (int)((s >> 4) & 15u), r = (a - 5) & 15;
+        const uint32_t rxy = sh.rxy[r];
+        const double eff = p.eff[abs(x - (int)(rxy & 15u)) + abs(y - (int)(rxy >> 4))];
+        const uint32_t code = (uint32_t)(s >> (8 + 2 * r)) & 3u;               // status + 1
+        if ((ob == 2 && code == 2u) || (ob == 1 && code == 0u)) return eff;
+        return 1 - eff;
+    }
+
+    // Everything of rock.py:123-194 except the sensor's Bernoulli draw: transition, reward, done, and (in `aux`) what
+    // the draw will be compared with.  Branch-free: the three action classes (move / SAMPLE / CHECK) are all
+    // evaluated and selected, so a wave with mixed actions — every wave, under a random policy — runs one straight line.
+    template <class RT>
+    static __device__ __forceinline__ void step_pre(const Shared &sh, const Params &p, State &st, int a, RT &rew,
+                                                    int &done, Aux &aux)
+    {
+        const S s = st.s;
+        const int x = (int)(s & 15u), y = (int)((s >> 4) & 15u);
+        const int size = p.size, K = p.num_rocks;
+        // CHECK rock a-5 (rock.py:171-175, 401-407, 383-387; coord.py:133-135: L1 distance)
+        const int r = (a - 5) & 15;
+        const uint32_t rxy = (ABLATE & 4) ? (uint32_t)(r * 17) : sh.rxy[r];
+        const int d = abs(x - (int)(rxy & 15u)) + abs(y - (int)(rxy >> 4));
+        aux.th = (ABLATE & 4) ? (uint32_t)d << 22 : sh.thr_hi[d];
+        aux.tl = (ABLATE & 4) ? 0u : sh.thr_lo[d];
+        aux.good = ((uint32_t)(s >> (8 + 2 * r)) & 3u) == 2u;
+        aux.want = a > 4;
+        const int penalty = STOCH ? 0 : -100;                                  // rock.py:117 / rock.py:432
+        // SAMPLE (rock.py:160-169); ids >= K raise IndexError in the reference, "no rock" here
+        const int id = (ABLATE & 4) ? ((x ^ y) & 7) - (x & 1) : sh.grid[x * 16 + y];
+        const int sh_ = 8 + 2 * (id & 15);
+        const uint32_t code = (uint32_t)(s >> sh_) & 3u;
+        const bool sample_ok = (id >= 0) & (id < K) & (code != 1u);
+        const int rew_sample = sample_ok ? (code == 2u ? 10 : -10) : penalty;
+        const S s_sample = sample_ok ? (S)((s & ~((S)3 << sh_)) | ((S)1 << sh_)) : s;
+        // move: 0 N (0,+1)  1 E (+1,0)  2 S (0,-1)  3 W (-1,0)   (coord.py:155-160, rock.py:134-158)
+        const int nx = x + (a == 1) - (a == 3), ny = y + (a == 0) - (a == 2);
+        const bool inside = ((unsigned)nx < (unsigned)size) & ((unsigned)ny < (unsigned)size);
+        const S s_move = inside ? (S)((s & ~(S)0xFF) | (S)(uint32_t)(nx | (ny << 4))) : s;
+        const int rew_move = inside ? 0 : (a == 1 ? 10 : penalty);             // east exit / off-grid
+        const bool is_move = a < 4, is_sample = a == 4;
+        st.s = is_move ? s_move : (is_sample ? s_sample : s);
+        rew = is_move ? rew_move : (is_sample ? rew_sample : 0);
+        if (STOCH) done = is_move && !inside && a == 1;                        // penalties never terminate (rock.py:503)
+        else done = is_move ? !inside : (rew == -100);                         // rock.py:139-141, 193
+    }
+    // observation of a CHECK from the sensor's high word (rock.py:404-407); `lo` yields the low word on a tie
+    template <class LowWord>
+    static __device__ __forceinline__ int sensor_ob(const Aux &aux, uint32_t H, LowWord lo)
+    {
+        const bool correct = k53_le(H, aux.th, aux.tl, lo);
+        return aux.want ? ((aux.good == correct) ? 2 : 1) : 0;
+    }
+
+    // The step of a lane that was handed its sensor high word H (element lane & 3 of the quad's STEP block): the fused
+    // rollout kernel computes one such block per lane every four steps and passes the words around the quad.
+    static constexpr bool QUAD_SENSOR = !STOCH;
+    template <class RT>
+    static __device__ __forceinline__ void step_with_H(const Shared &sh, const Params &p, State &st, int a, const RngKey &key,
+                                                       uint32_t lane, uint32_t H, int &ob, RT &rew, int &done)
+    {
+        Aux aux;
+        step_pre(sh, p, st, a, rew, done, aux);
+        ob = sensor_ob(aux, H, [&]() { return elem(quad_block(key, lane, 1u), lane & 3u); });
+    }
+
+    // The whole step for one lane (launches that do not pool the quad's sensor block: one lane per thread, rollouts).
+    template <class RT>
+    static __device__ __forceinline__ void step(const Shared &sh, const Params &p, State &st, int a,
+                                                const RngKey &key, uint32_t lane, int &ob, RT &rew, int &done)
+    {
+        const uint32_t e = lane & 3u;
+        if (STOCH) {
+            // the first double of the step gates the whole action (rock.py:443), the sensor draw is the second
+            const uint4 g = quad_block(key, lane, 0u);
+            const bool act = k53_le(elem(g, e), (uint32_t)(p.act_thr >> 26), (uint32_t)p.act_thr & LO_MASK,
+                                    [&]() { return elem(quad_block(key, lane, 1u), e); });
+            State nx = st;
+            Aux aux; RT r2; int d2;
+            step_pre(sh, p, nx, a, r2, d2, aux);
+            const uint4 h = quad_block(key, lane, 2u);
+            const int o2 = sensor_ob(aux, elem(h, e), [&]() { return elem(quad_block(key, lane, 3u), e); });
+            if (act) { st = nx; rew = r2; done = d2; ob = o2; }
+            else { rew = 0; done = 0; ob = 0; }
+            return;
+        }
+        Aux aux;
+        step_pre(sh, p, st, a, rew, done, aux);
+        const uint4 h = (ABLATE & 1) ? make_uint4(lane * 2654435761u, lane, 0, 0) : quad_block(key, lane, 0u);
+        ob = sensor_ob(aux, elem(h, e), [&]() { return elem(quad_block(key, lane, 1u), e); });
+    }
+};
+
+} // namespace pomdp

@@ -1,0 +1,254 @@
+// envs/tag.hip.h — Tag (gym_pomdp/envs/tag.py): the lane functions the generic kernels of pomdp_kernels.hip call.
+// Included by envs.hip.h (which holds the Env interface description and the shared helpers).
+#pragma once
+#include "../envs_common.hip.h"
+
+namespace pomdp {
+
+struct TagEnv {
+    using Params = pomdp_tag_params;
+    using Reward = float;
+    static constexpr int WORDS = 1;
+    static constexpr bool POOLED_LPT2 = true;     // pomdp_kernels.hip: Finisher<TagEnv, 2, .>
+    static constexpr bool QUAD_SENSOR = false;
+    static constexpr int ABL = 0;
+    // The T-shaped board never changes (tag.py:36-78): two small LDS tables replace the coordinate arithmetic of the
+    // hot step — cell -> x | y << 4, and (cell, move N0 E1 S2 W3) -> the cell the move leads to, or the cell itself
+    // when that square does not exist.  Every workgroup computes them once (threads 0-127, one entry each).
+    struct Shared { uint8_t xy[32]; uint8_t mv[32 * 4]; };
+    struct State { uint32_t w; };
+
+    static __device__ __forceinline__ int n_actions(const Params &) { return 5; }
+    static __device__ __forceinline__ void load(State &st, const uint32_t *state, int64_t, uint32_t i) { st.w = ld_stream(state + i); }
+    static __device__ __forceinline__ void store(const State &st, uint32_t *state, int64_t, uint32_t i, bool) { st_stream(state + i, st.w); }
+
+    // tag.py:52-57 get_tag_coord, 59-66 get_index, 46-50 is_inside
+    static __device__ __forceinline__ void coord(int idx, int &x, int &y)
+    {
+        if (idx < 20) { x = idx % 10; y = idx / 10; }
+        else { idx -= 20; x = idx % 3 + 5; y = idx / 3 + 2; }
+    }
+    static __device__ __forceinline__ int index(int x, int y) { return y < 2 ? y * 10 + x : 20 + (y - 2) * 3 + x - 5; }
+    static __device__ __forceinline__ bool inside(int x, int y)
+    {
+        return y >= 2 ? (x >= 5 && x < 8 && y < 5) : (x >= 0 && x < 10 && y >= 0);
+    }
+    static __device__ __forceinline__ void stage(Shared &sh, const Params &, int tid)
+    {
+        if (tid < 128) {
+            const int cell = min(tid >> 2, 28), d = tid & 3;
+            int x, y;
+            coord(cell, x, y);
+            const int nx = x + (d == 1) - (d == 3), ny = y + (d == 0) - (d == 2);
+            sh.mv[tid] = (uint8_t)(inside(nx, ny) ? index(nx, ny) : cell);
+            if (d == 0) sh.xy[tid >> 2] = (uint8_t)(x | (y << 4));
+        }
+    }
+    static __device__ __forceinline__ int num_opp(uint32_t w) { return (int)w >> 25; } // sign-extending
+    static __device__ __forceinline__ uint32_t with_num_opp(uint32_t w, int no)
+    {
+        no = no < -64 ? -64 : no;
+        return (w & 0x01FFFFFFu) | ((uint32_t)no << 25);
+    }
+    // tag.py:219-226
+    static __device__ __forceinline__ int sample_ob(const Params &p, uint32_t w, int a)
+    {
+        const uint32_t agent = w & 31u;
+        int ob = (int)agent;
+        if (a < 4)
+            for (int j = 0; j < p.num_opponents; ++j)
+                if (((w >> (5 + 5 * j)) & 31u) == agent) ob = p.obs_cells;
+        return ob;
+    }
+
+    // tag.py:97-102 reset, 181-193 _get_init_state, 43-44 sample = randint(0, 29)
+    static __device__ __forceinline__ int reset(const Shared &, const Params &p, State &st, const RngKey &key,
+                                                uint32_t lane)
+    {
+        WordStream ws(key, lane, POMDP_STREAM_RESET);
+        uint32_t w = ws.randint(29u);
+        for (int j = 0; j < p.num_opponents; ++j) w |= ws.randint(29u) << (5 + 5 * j);
+        st.w = with_num_opp(w, p.num_opponents);
+        return sample_ob(p, st.w, 0);
+    }
+    static __device__ __forceinline__ int reset_ob(const Params &p, const State &st) { return sample_ob(p, st.w, 0); }
+
+    // Called convergently by every lane of the wave; `fresh` marks the lanes that start a new episode.
+    static __device__ __forceinline__ void reset_where(const Shared &sh, const Params &p, State &st, bool fresh,
+                                                       const RngKey &key, uint32_t lane)
+    {
+        if (fresh) reset(sh, p, st, key, lane);
+    }
+    static __device__ __forceinline__ void reset_where_chain(const Shared &sh, const Params &p, State &st, bool fresh,
+                                                             const RngKey &key, uint32_t lane, const RngKey &akey,
+                                                             uint32_t n_actions, int &next_action)
+    {
+        reset_where_chain_default<TagEnv>(sh, p, st, fresh, key, lane, akey, n_actions, next_action);
+    }
+
+    // tag.py:228-229: every action is legal
+    static __device__ __forceinline__ int legal_count(const Shared &, const Params &p, const State &) { return n_actions(p); }
+    static __device__ __forceinline__ int legal_nth(const Shared &, const Params &, const State &, int idx) { return idx; }
+
+    // tag.py:231-243 _generate_preferred as a bitmask (ascending order is the reference's list order); tag.py:68-74
+    // is_corner, coord.py:75-77 opposite.  history.size == 0 gives the legal list (all five actions).
+    static __device__ __forceinline__ uint32_t preferred_mask(const Shared &sh, const Params &p, const State &st,
+                                                              const pomdp_rock_belief &, const pomdp_history &h,
+                                                              int64_t n, uint32_t i)
+    {
+        return preferred_mask(sh, p, st, h, n, i, 0u, 0u, ld_stream(h.size + i));
+    }
+    static __device__ __forceinline__ uint32_t preferred_mask(const Shared &, const Params &, const State &st,
+                                                              const pomdp_history &h, int64_t, uint32_t i, uint32_t,
+                                                              uint32_t, int hsize)
+    {
+        if (hsize == 0) return 0x1Fu;
+        const int agent = (int)(st.w & 31u);
+        int x, y;
+        coord(agent, x, y);
+        const bool corner = y < 2 ? (x == 0 || x == 9) : (y == 4 && (x == 5 || x == 7));
+        if (h.last_ob[i] == 29 && corner) return 1u << 4;          // grid.n_tiles, whatever obs_cells was set to
+        const int la = h.last_action[i];
+        uint32_t m = 0;
+        const int dx[4] = {0, 1, 0, -1}, dy[4] = {1, 0, -1, 0};
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+            if (la != ((d + 2) & 3) && inside(x + dx[d], y + dy[d])) m |= 1u << d;
+        return m;
+    }
+
+    // tag.py:209-217 _compute_prob
+    static __device__ __forceinline__ double compute_prob(const Shared &, const Params &p, const State &st, int, int ob)
+    {
+        const uint32_t w = st.w, agent = w & 31u;
+        if (ob == p.obs_cells)
+            for (int j = 0; j < p.num_opponents; ++j)
+                if (((w >> (5 + 5 * j)) & 31u) == agent) return 1.0;
+        return ob == (int)agent ? 1.0 : 0.0;
+    }
+
+    // tag.py:108-143 with one opponent (the default and the benchmark configuration), branch-free: under a random
+    // policy every wave holds both moves and TAGs, so both outcomes are evaluated and selected.  Only a failed TAG
+    // on a live opponent draws random numbers — words 0-2 of block 0 of the lane's STEP stream: binomial(1,
+    // move_prob) on (w0, w1), then np.random.choice over a list whose length is 2 or 4, i.e. randint with an exact
+    // mask (one word, no rejection).  The step is therefore split: `pre` does everything but the opponent's flight
+    // and says whether the draw is needed, `flee` applies it; launches that pool Philox work call them separately.
+    struct Flight { uint32_t list; int oi; bool need; };
+    // tag.py:260-280 `_admissable_actions`: the list the eight appends build depends only on the signs of
+    // (opponent - agent) in x and y.  Entry k = 3 (sign dx + 1) + (sign dy + 1), four 2-bit moves each (N0 E1 S2 W3,
+    // the reference's order); the two-element lists of the diagonal cases are stored twice over, so that
+    // `word & 3` picks from them exactly as randint(2)'s `word & 1` does.  k = 4 (same cell) never draws.
+    static constexpr uint64_t ADMISSIBLE_LO = 0x61993100adccecbbull;   // k = 0..7
+    static constexpr uint32_t ADMISSIBLE_8 = 0x11u;                     // k = 8
+    template <class RT>
+    static __device__ __forceinline__ void step_one_opponent_pre(const Shared &sh, const Params &p, State &st, int a,
+                                                                 int &ob, RT &rew, int &done, Flight &f)
+    {
+        const uint32_t w = st.w;
+        const int agent = (int)(w & 31u), oi = (int)((w >> 5) & 31u), no = num_opp(w);
+        const int axy = sh.xy[agent], oxy = sh.xy[oi];
+        // a < 4: the agent moves if the target cell exists (tag.py:112-117)
+        const uint32_t agent_m = sh.mv[4 * agent + (a & 3)];
+        // a == 4 (tag.py:119-134): tagged iff co-located; otherwise the opponent may flee (tag.py:201-207, 260-280)
+        const bool colocated = oi == agent;
+        const int dx = (oxy & 15) - (axy & 15), dy = (oxy >> 4) - (axy >> 4);
+        const int sx1 = min(max(dx, -1), 1) + 1, sy1 = min(max(dy, -1), 1) + 1;              // v_med3_i32
+        const int k = 3 * sx1 + sy1;
+        const uint32_t list = k == 8 ? ADMISSIBLE_8 : (uint32_t)(ADMISSIBLE_LO >> (8 * (k & 7))) & 0xFFu;
+        const bool tag = a == 4;
+        const uint32_t w_tag = with_num_opp(w, no - (int)colocated);
+        const uint32_t wn = tag ? w_tag : ((w & ~31u) | agent_m);
+        rew = tag ? (colocated ? 10.f : -10.f) : -1.f;
+        ob = (!tag && ((wn >> 5) & 31u) == (wn & 31u)) ? p.obs_cells : (int)(wn & 31u);   // tag.py:219-226
+        done = num_opp(wn) == 0;
+        st.w = wn;
+        f.list = list; f.oi = oi;
+        f.need = tag && !colocated && no > 0;
+    }
+    // the opponent's flight from words 0-2 of the lane's STEP block (tag.py:201-207)
+    static __device__ __forceinline__ void flee(const Shared &sh, const Params &p, State &st, const Flight &f, uint32_t w0,
+                                                uint32_t w1, uint32_t w2)
+    {
+        const uint32_t pick = (f.list >> (2 * (w2 & 3u))) & 3u;       // np.random.choice: randint(2 or 4), exact mask
+        const uint32_t to = sh.mv[4 * f.oi + (int)pick];               // the cell itself if the square does not exist
+        if (f.need && k53(w0, w1) <= p.move_thr) st.w = (st.w & ~(31u << 5)) | (to << 5);
+    }
+    template <class RT>
+    static __device__ __forceinline__ void step_one_opponent(const Shared &sh, const Params &p, State &st, int a,
+                                                             const RngKey &key, uint32_t lane, int &ob, RT &rew, int &done)
+    {
+        Flight f;
+        step_one_opponent_pre(sh, p, st, a, ob, rew, done, f);
+        const uint4 blk = stream_block(key, lane, POMDP_STREAM_STEP, 0u);
+        flee(sh, p, st, f, blk.x, blk.y, blk.z);
+    }
+    // reset() from the four words of block 0 of the lane's RESET stream (tag.py:181-193: randint(29) per cell, each a
+    // masked-rejection loop); false when the rejections ran past the block (probability < 1e-3) — the caller then
+    // takes the general path
+    static __device__ __forceinline__ bool reset_from_block(const Params &p, State &st, const uint4 &b)
+    {
+        const uint32_t wd[4] = {b.x, b.y, b.z, b.w};
+        uint32_t w = 0; int have = 0;
+        const int want = 1 + p.num_opponents;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t v = wd[j] & 31u;
+            if (have < want && v <= 28u) { w |= v << (5 * have); ++have; }
+        }
+        if (have < want) return false;
+        st.w = with_num_opp(w, p.num_opponents);
+        return true;
+    }
+
+    // tag.py:108-143 step, 201-207 move_opponent, 260-280 _admissable_actions
+    template <class RT>
+    static __device__ __forceinline__ void step(const Shared &sh, const Params &p, State &st, int a,
+                                                const RngKey &key, uint32_t lane, int &ob, RT &rew, int &done)
+    {
+        if (p.num_opponents == 1) { step_one_opponent(sh, p, st, a, key, lane, ob, rew, done); return; }   // wave-uniform
+        uint32_t w = st.w;
+        const int agent = (int)(w & 31u);
+        int ax, ay;
+        coord(agent, ax, ay);
+        if (a == 4) {
+            WordStream ws(key, lane, POMDP_STREAM_STEP);
+            bool tagged = false;
+            int no = num_opp(w);
+            for (int j = 0; j < p.num_opponents; ++j) {
+                const int sh = 5 + 5 * j;
+                const int oi = (int)((w >> sh) & 31u);
+                if (oi == agent) { tagged = true; no -= 1; }
+                else if (no > 0) {
+                    int ox, oy;
+                    coord(oi, ox, oy);
+                    // admissible moves, 2 bits each (index into N0 E1 S2 W3), in the reference's list order
+                    uint32_t list = 0; int cnt = 0;
+                    if (ox >= ax) { list |= 1u << (2 * cnt); ++cnt; }
+                    if (oy >= ay) { list |= 0u << (2 * cnt); ++cnt; }
+                    if (ox <= ax) { list |= 3u << (2 * cnt); ++cnt; }
+                    if (oy <= ay) { list |= 2u << (2 * cnt); ++cnt; }
+                    if (ox == ax && oy > ay) { list |= 0u << (2 * cnt); ++cnt; }
+                    if (oy == ay && ox > ax) { list |= 1u << (2 * cnt); ++cnt; }
+                    if (ox == ax && oy < ay) { list |= 2u << (2 * cnt); ++cnt; }
+                    if (oy == ay && ox < ax) { list |= 3u << (2 * cnt); ++cnt; }
+                    if (ws.next_k53() <= p.move_thr) {                    // binomial(1, move_prob)
+                        const uint32_t pick = (list >> (2 * ws.randint((uint32_t)cnt))) & 3u; // np.random.choice
+                        const int nx = ox + (pick == 1u) - (pick == 3u), ny = oy + (pick == 0u) - (pick == 2u);
+                        if (inside(nx, ny)) w = (w & ~(31u << sh)) | ((uint32_t)index(nx, ny) << sh);
+                    }
+                }
+            }
+            rew = tagged ? 10.f : -10.f;
+            w = with_num_opp(w, no);
+        } else {
+            rew = -1.f;
+            const int nx = ax + (a == 1) - (a == 3), ny = ay + (a == 0) - (a == 2);
+            if (inside(nx, ny)) w = (w & ~31u) | (uint32_t)index(nx, ny);
+        }
+        ob = sample_ob(p, w, a);
+        done = num_opp(w) == 0;
+        st.w = w;
+    }
+};
+
+} // namespace pomdp

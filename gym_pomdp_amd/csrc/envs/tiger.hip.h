@@ -1,0 +1,84 @@
+// envs/tiger.hip.h — Tiger (gym_pomdp/envs/tiger.py): the lane functions the generic kernels of pomdp_kernels.hip call.
+// Included by envs.hip.h (which holds the Env interface description and the shared helpers).
+#pragma once
+#include "../envs_common.hip.h"
+
+namespace pomdp {
+
+struct TigerEnv {
+    using Params = pomdp_tiger_params;
+    using Reward = int32_t;
+    static constexpr int WORDS = 1;
+    static constexpr bool POOLED_LPT2 = false;
+    static constexpr bool QUAD_SENSOR = false;
+    static constexpr int ABL = 0;
+    struct Shared { int unused; };
+    struct State { uint32_t w; };
+
+    static __device__ __forceinline__ void stage(Shared &, const Params &, int) {}
+    static __device__ __forceinline__ int n_actions(const Params &) { return 3; }
+    static __device__ __forceinline__ void load(State &st, const uint32_t *state, int64_t, uint32_t i) { st.w = ld_stream(state + i); }
+    static __device__ __forceinline__ void store(const State &st, uint32_t *state, int64_t, uint32_t i, bool) { st_stream(state + i, st.w); }
+
+    // tiger.py:60-66: state = state_space.sample() (gym-space RNG -> stream RESET_SPACE); ob = NULL
+    static __device__ __forceinline__ int reset(const Shared &, const Params &, State &st, const RngKey &key,
+                                                uint32_t lane)
+    {
+        st.w = stream_block(key, lane, POMDP_STREAM_RESET_SPACE, 0u).x & 1u; // randint(2): mask 1, never rejects
+        return 2;
+    }
+    static __device__ __forceinline__ int reset_ob(const Params &, const State &) { return 2; }
+
+    // Called convergently by every lane of the wave; `fresh` marks the lanes that start a new episode.
+    static __device__ __forceinline__ void reset_where(const Shared &sh, const Params &p, State &st, bool fresh,
+                                                       const RngKey &key, uint32_t lane)
+    {
+        if (fresh) reset(sh, p, st, key, lane);
+    }
+    static __device__ __forceinline__ void reset_where_chain(const Shared &sh, const Params &p, State &st, bool fresh,
+                                                             const RngKey &key, uint32_t lane, const RngKey &akey,
+                                                             uint32_t n_actions, int &next_action)
+    {
+        reset_where_chain_default<TigerEnv>(sh, p, st, fresh, key, lane, akey, n_actions, next_action);
+    }
+    // tiger.py:111-112: every action is legal
+    static __device__ __forceinline__ int legal_count(const Shared &, const Params &p, const State &) { return n_actions(p); }
+    static __device__ __forceinline__ int legal_nth(const Shared &, const Params &, const State &, int idx) { return idx; }
+
+    // no heuristic: _generate_preferred is _generate_legal (0 = fall back to the legal list)
+    static __device__ __forceinline__ uint32_t preferred_mask(const Shared &, const Params &, const State &,
+                                                              const pomdp_rock_belief &, const pomdp_history &, int64_t,
+                                                              uint32_t) { return 0u; }
+    static __device__ __forceinline__ uint32_t preferred_mask(const Shared &, const Params &, const State &,
+                                                              const pomdp_history &, int64_t, uint32_t, uint32_t, uint32_t,
+                                                              int) { return 0u; }
+    // tiger.py:125-138 _compute_prob
+    static __device__ __forceinline__ double compute_prob(const Shared &, const Params &, const State &st, int a, int ob)
+    {
+        if (a == 2 && ob != 2) return ((int)(st.w & 1u) == ob) ? .85 : 1 - .85;
+        if (a != 2 && ob == 2) return 1.0;
+        return 0.0;
+    }
+
+    // tiger.py:72-88 step, 117-119 _sample_state, 140-149 _sample_ob, 155-172
+    template <class RT>
+    static __device__ __forceinline__ void step(const Shared &, const Params &p, State &st, int a,
+                                                const RngKey &key, uint32_t lane, int &ob, RT &rew, int &done)
+    {
+        const int tiger = (int)(st.w & 1u);
+        if (a != 2 && a == tiger) { ob = tiger; rew = -20; done = 1; return; } // terminal: ob is the state
+        done = 0;
+        if (a == 2) {
+            rew = -1;
+            const uint4 w = stream_block(key, lane, POMDP_STREAM_STEP, 0u);
+            const bool flip = k53(w.x, w.y) > p.listen_thr;                     // p > .85
+            ob = tiger ^ (int)flip;
+        } else {
+            rew = 10;
+            st.w = stream_block(key, lane, POMDP_STREAM_STEP_SPACE, 0u).x & 1u; // state resampled
+            ob = 2; // the uniform() the reference draws here has no effect on anything returned
+        }
+    }
+};
+
+} // namespace pomdp
