@@ -5,9 +5,11 @@
 
 Workload (BASELINE.json metric): RockSample(7,8), 2^20 lanes per GPU, i.i.d. uniform random
 actions from the synthetic policy (its kernel is inside the timed region), auto-reset on done.
-A "step" is one pass of the hot path over the whole batch: one action launch + one step launch,
-issued by the library's C-side rollout driver (pomdp_rollout_synthetic) so that the interpreter is
-not between the launches; `--host-loop python` times the same steps through env.step() instead.
+A "step" is one pass of the hot path over the whole batch.  The steps are issued by the library's C-side
+rollout driver (pomdp_rollout_synthetic), which by default runs up to 64 consecutive steps inside one
+launch (every step's outputs are still computed and written; a lane's state stays in registers between
+its steps); `--fuse 0` launches every step separately, `--host-loop python` times the same steps through
+env.step() instead.
 N > 1: one process per GPU (torch.distributed.run), lanes sharded by global lane id, no data-path
 collective — only the timing barrier / max-over-ranks (gloo, host side).  Scaling is weak: every
 GPU owns 2^20 lanes.
@@ -73,6 +75,9 @@ def parse():
     ap.add_argument("--prewarm", type=float, default=0.5,
                     help="seconds of untimed launches before the W warm-up steps: a GPU coming out of idle runs its first "
                          "~0.1-1 s below full clock (a compute-only kernel like the fused rollout is up to 1.4x slower there)")
+    ap.add_argument("--fuse", type=int, default=1, choices=[0, 1],
+                    help="1: the C driver may run up to 64 consecutive steps inside one launch (steps_kernel: every step's "
+                         "outputs still computed and written, state in registers between steps); 0: one launch per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline sample")
     return ap.parse_args()
@@ -215,7 +220,7 @@ def heuristic_mode(args, gpa, env_id, kwargs, cp, dev, rank, world, label, n, la
     cp.close()
 
 
-def measured_traffic(env_key, chained=False):
+def measured_traffic(env_key, chained=False, fused=False):
     """HBM bytes per step-kernel launch from the committed PMC passes (profiles/traffic_*.json, produced by
     tools/gpu_profile.sh: separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this command)."""
     name = {"rock": "traffic_rock_7_8.json"}.get(env_key)
@@ -224,7 +229,7 @@ def measured_traffic(env_key, chained=False):
         return None, None
     with open(path) as f:
         t = json.load(f)
-    key = "chain" if chained and "chain" in t else "plain"
+    key = "fused" if fused and "fused" in t else ("chain" if chained and "chain" in t else "plain")
     return t[key]["hbm_bytes_per_launch"], "profiles/%s [%s]" % (name, key)
 
 
@@ -275,8 +280,8 @@ def main():
         else:
             left = k
             while left > 0:
-                c = min(left, 100)
-                env.rollout_synthetic(c, action_seed=action_seed, actions=actions)
+                c = min(left, 128)         # two full 64-step launches per call when fused
+                env.rollout_synthetic(c, action_seed=action_seed, actions=actions, fuse=bool(args.fuse) and action_seed == args.seed)
                 left -= c
 
     def barrier():
@@ -321,11 +326,22 @@ def main():
     plain_ms = ev0.elapsed_time(ev1) / args.steps
     plain_achieved = bytes_per_step * n / (plain_ms * 1e-3) / 1e9
     chained = args.host_loop == "c" and action_seed == args.seed
+    fused = chained and bool(args.fuse)
     kern_ms = timed_kernel_ms if chained else plain_ms
     achieved = bytes_per_step * n / (kern_ms * 1e-3) / 1e9
+    chain1_ms = None
+    if fused:      # the same chained steps launched one by one (step_kernel<., chain>), for reference
+        k1 = min(args.steps, 1000)
+        env.rollout_synthetic(64, action_seed=action_seed, actions=actions, fuse=False)
+        torch.cuda.synchronize(dev)
+        ev0.record()
+        env.rollout_synthetic(k1, action_seed=action_seed, actions=actions, fuse=False)
+        ev1.record()
+        torch.cuda.synchronize(dev)
+        chain1_ms = ev0.elapsed_time(ev1) / k1
     invalid = env.invalid_action_count()
 
-    traffic, traffic_src = measured_traffic(args.env, chained) if n == 1 << 20 else (None, None)
+    traffic, traffic_src = measured_traffic(args.env, chained, fused) if n == 1 << 20 else (None, None)
     if rank == 0:
         total_lanes = n * world
         metric = "env steps/sec (whole node)"
@@ -351,19 +367,30 @@ def main():
             "config": {"workload": "%s batch=%d lanes per GPU (%d total), uniform random actions "
                                    "(synthetic-policy kernel timed), auto-reset" % (label, n, total_lanes),
                        "lanes_per_gpu": n, "total_lanes": total_lanes, "host_loop": args.host_loop, "visible_gpus": n_dev,
+                       "steps_per_launch": 64 if fused else 1,
                        "untimed_prewarm_s": args.prewarm, "parallelism": "lane-shard x%d, no collectives" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch",
                          "traffic_source": traffic_src,
-                         "kernel": ("step_kernel<%s, chain> (step + next-step policy, the launch of the timed region)"
+                         "kernel": (("steps_kernel<%s> (64 chained steps per launch: step + next-step policy, every step's "
+                                     "outputs written, state in registers between steps; the launch of the timed region)")
+                                    if fused else
+                                    "step_kernel<%s, chain> (step + next-step policy, the launch of the timed region)"
                                     if chained else "step_kernel<%s>") % args.env,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_step": bytes_per_step,
+                         "steps_per_launch": 64 if fused else 1,
+                         "launch_ms": kern_ms * (64 if fused else 1),
+                         "chained_step_kernel": None if chain1_ms is None else {
+                             "kernel": "step_kernel<%s, chain> (the same steps, one launch each)" % args.env,
+                             "kernel_ms": chain1_ms, "achieved": bytes_per_step * n / (chain1_ms * 1e-3) / 1e9,
+                             "frac": bytes_per_step * n / (chain1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
                          "plain_step_kernel": {"kernel": "step_kernel<%s> (what env.step() launches)" % args.env,
                                                "kernel_ms": plain_ms, "achieved": plain_achieved,
                                                "frac": plain_achieved / HBM_PEAK_GBS},
                          "note": "kernel_ms: HIP events on the launch stream over the timed region (%d back-to-back "
-                                 "launches, gaps included); plain_step_kernel: the same with env.step() on a ring "
-                                 "of 16 pre-generated action batches" % args.steps},
+                                 "steps, gaps included) / steps; launch_ms = kernel_ms x steps_per_launch; traffic is per "
+                                 "launch; plain_step_kernel: env.step() on a ring of 16 pre-generated action batches"
+                                 % args.steps},
             "invalid_actions": invalid,
         }
         if world == 1 and not args.no_cpu_baseline:

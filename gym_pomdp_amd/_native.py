@@ -18,6 +18,7 @@ HEADER = os.path.join(_REPO, "include", "pomdp_hip.h")
 ABI_VERSION = 6
 
 POMDP_AUTO_RESET = 1
+POMDP_FUSE_STEPS = 2
 POMDP_ROLLOUT_ALL_ACTIONS = 1
 ENV_KIND = {"rock": 0, "tag": 1, "battleship": 2, "tiger": 3, "network": 4}
 

@@ -67,6 +67,7 @@ template <class Env, int LPT, bool CHAIN, class = void>
 struct Finisher {
     struct Aux {};
     static constexpr bool HAS_PREPASS = false;
+    static constexpr bool LOOP_BARRIER = CHAIN;      // run() shares `pol` across waves: a fused multi-step loop must fence its reuse
     template <class RT>
     static __device__ __forceinline__ void lane_step(const typename Env::Shared &sh, const typename Env::Params &p,
                                                      typename Env::State &st, int a, const RngKey &key, uint32_t lane,
@@ -114,6 +115,7 @@ template <int W, int ABLATE, int LPT, bool CHAIN>
 struct Finisher<RockEnv<W, ABLATE, false>, LPT, CHAIN, typename std::enable_if<(LPT >= 2)>::type> {
     using Env = RockEnv<W, ABLATE, false>;
     using Aux = typename Env::Aux;
+    static constexpr bool LOOP_BARRIER = false;              // every scratch array is wave-private
     static constexpr int NQ = 16 * LPT;                      // quads (sensor blocks) of the wave's 64 * LPT lanes
     static constexpr int NA = CHAIN ? 16 * LPT : 0;          // policy blocks of the next call counter
     template <class RT>
@@ -225,6 +227,7 @@ struct Finisher<TagEnv, 2, CHAIN, void> {
     using Env = TagEnv;
     using Aux = typename Env::Flight;
     static constexpr bool HAS_PREPASS = false;
+    static constexpr bool LOOP_BARRIER = false;
     template <class RT>
     static __device__ __forceinline__ void lane_step(const typename Env::Shared &sh, const typename Env::Params &p,
                                                      typename Env::State &st, int a, const RngKey &key, uint32_t lane,
@@ -375,6 +378,96 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(uint32_t *__restrict__ stat
             // the reference asserts on an out-of-range action; here the lane is left untouched and counted
             if (!valid[j] && !was_done[j] && err) atomicAdd(err, 1u);
         }
+    }
+}
+
+// k consecutive chained steps in ONE launch: exactly the memory state k launches of step_kernel<Env, LPT, true> leave —
+// every step's ob / reward / done / state / next action is computed and written — but a lane's state and action stay in
+// registers from one step to the next (nothing is re-read) and there is one launch ramp per k steps instead of per
+// step.  Possible because a lane's step t+1 depends only on its own step t and all cooperation (pooled Philox passes,
+// cooperative resets) is wave- or workgroup-local: no grid-wide synchronisation is involved.
+template <class Env, int LPT>
+__global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ state, int32_t *__restrict__ action,
+                                                      int32_t *__restrict__ ob, typename Env::Reward *__restrict__ reward,
+                                                      uint8_t *__restrict__ done, uint32_t *__restrict__ err, int64_t n,
+                                                      RngKey key0, uint32_t lane0, int flags, RngKey akey0, int k_steps,
+                                                      const typename Env::Params p)
+{
+    __shared__ typename Env::Shared sh;
+    const bool auto_reset = flags & POMDP_AUTO_RESET;
+    const uint32_t wg0 = blockIdx.x * (uint32_t)(BLOCK * LPT);
+    const uint32_t last = (uint32_t)((uint64_t)(n - 1) - wg0);
+    int32_t *const action_w = action + wg0;
+    uint32_t *const state_w = state + wg0;
+    int32_t *const ob_w = ob + wg0;
+    typename Env::Reward *const reward_w = reward + wg0;
+    uint8_t *const done_w = done + wg0;
+    uint32_t rel[LPT], glane[LPT];
+    bool in_range[LPT], was_done[LPT];
+    int a_cur[LPT];
+    typename Env::State st[LPT];
+#pragma unroll
+    for (int j = 0; j < LPT; ++j) {
+        rel[j] = threadIdx.x + (uint32_t)(j * BLOCK);
+        glane[j] = lane0 + wg0 + rel[j];
+        in_range[j] = rel[j] <= last;
+        const uint32_t rc = in_range[j] ? rel[j] : last;
+        __builtin_assume(rc < (uint32_t)(BLOCK * LPT));
+        a_cur[j] = ld_stream(action_w + rc);
+        Env::load(st[j], state_w, n, rc);
+        was_done[j] = auto_reset ? false : (ld_stream(done_w + rc) != 0);
+    }
+    using Fin = Finisher<Env, LPT, true>;
+    const int n_act = Env::n_actions(p);
+    const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo, ta0 = ((uint64_t)akey0.t_hi << 32) | akey0.t_lo;
+    for (int s = 0; s < k_steps; ++s) {
+        RngKey key = key0, akey = akey0;
+        key.t_lo = (uint32_t)(t0 + (uint64_t)s); key.t_hi = (uint32_t)((t0 + (uint64_t)s) >> 32);
+        akey.t_lo = (uint32_t)(ta0 + (uint64_t)s); akey.t_hi = (uint32_t)((ta0 + (uint64_t)s) >> 32);
+        if (s == 0) {                                    // tables once; the first pre-pass rides under the load latency
+            if constexpr (Fin::HAS_PREPASS) {
+                const auto staged = Env::stage_load(p, (int)threadIdx.x);
+                Fin::prepass(key, glane, akey);
+                Env::stage_store(sh, staged, (int)threadIdx.x);
+            } else {
+                Env::stage(sh, p, (int)threadIdx.x);
+            }
+            __syncthreads();
+        } else {
+            if constexpr (Fin::HAS_PREPASS) Fin::prepass(key, glane, akey);
+        }
+        int o[LPT], d[LPT];
+        typename Env::Reward r[LPT];
+        typename Fin::Aux aux[LPT];
+        bool live[LPT], valid[LPT], fresh[LPT];
+        int a_next[LPT];
+        typename Env::State before[LPT];
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) {
+            before[j] = st[j];
+            valid[j] = (unsigned)a_cur[j] < (unsigned)n_act;
+            live[j] = in_range[j] && valid[j] && !was_done[j];
+            Fin::lane_step(sh, p, st[j], valid[j] ? a_cur[j] : 0, key, glane[j], o[j], r[j], d[j], aux[j]);
+            if (!live[j]) { r[j] = 0; d[j] = was_done[j]; }
+            fresh[j] = live[j] && d[j] && auto_reset;
+            a_next[j] = 0;
+        }
+        Fin::run(sh, p, st, fresh, key, glane, akey, (uint32_t)n_act, a_next, aux, o);
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) {
+            if (!live[j]) { o[j] = 0; st[j] = before[j]; }                  // a lane that did not step keeps its state
+            if (in_range[j]) st_stream(action_w + rel[j], (int32_t)a_next[j]);
+            if (live[j]) Env::store(st[j], state_w, n, rel[j], fresh[j]);
+            if (in_range[j]) {
+                st_stream(ob_w + rel[j], (int32_t)o[j]);
+                st_stream(reward_w + rel[j], r[j]);
+                st_stream(done_w + rel[j], (uint8_t)d[j]);
+                if (!valid[j] && !was_done[j] && err) atomicAdd(err, 1u);
+            }
+            a_cur[j] = a_next[j];
+            was_done[j] = auto_reset ? false : (d[j] != 0);
+        }
+        if constexpr (Fin::LOOP_BARRIER) __syncthreads();
     }
 }
 
@@ -845,6 +938,24 @@ static int launch_step_chain(const typename Env::Params &p, uint32_t *state, int
     return (int)hipGetLastError();
 }
 
+// the same as k launch_step_chain calls at t, t + 1, ..., in one launch
+template <class Env>
+static int launch_steps_fused(const typename Env::Params &p, uint32_t *state, int32_t *action, int32_t *ob,
+                              typename Env::Reward *reward, uint8_t *done, uint32_t *err, int64_t n, uint64_t seed,
+                              uint64_t action_seed, uint32_t lane0, uint64_t t, int k, int flags, void *stream)
+{
+    if (!state || !action || !ob || !reward || !done || bad_range(n, lane0) || (lane0 & 3u) || k < 1) return POMDP_E_BADARG;
+    if (n == 0) return 0;
+    if (Env::POOLED_LPT2 && n >= LPT2_MIN_LANES)
+        hipLaunchKernelGGL((steps_kernel<Env, 2>), dim3((unsigned)((n + 2 * BLOCK - 1) / (2 * BLOCK))), dim3(BLOCK), 0,
+                           (hipStream_t)stream, state, action, ob, reward, done, err, n, make_key(seed, t), lane0, flags,
+                           make_key(action_seed, t + 1), k, p);
+    else
+        hipLaunchKernelGGL((steps_kernel<Env, 1>), dim3(blocks_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, state, action,
+                           ob, reward, done, err, n, make_key(seed, t), lane0, flags, make_key(action_seed, t + 1), k, p);
+    return (int)hipGetLastError();
+}
+
 using StochRock1 = RockEnv<1, 0, true>;   // StochasticRockEnv, one / two state words
 using StochRock2 = RockEnv<2, 0, true>;
 
@@ -1142,7 +1253,22 @@ int pomdp_rollout_synthetic(int env, const void *params, uint32_t *state, int32_
     int rc = pomdp_synthetic_actions(action, n, action_seed, lane0, t0, n_actions, stream);
     if (rc) return rc;
     if (action_seed == seed) {
-        // chained: every step launch also leaves the actions of the following call counter in `action`
+        // chained: every step also leaves the actions of the following call counter in `action`.  With
+        // POMDP_FUSE_STEPS up to FUSE_MAX consecutive steps share one launch (steps_kernel); otherwise one launch per step.
+        if (flags & POMDP_FUSE_STEPS) {
+            constexpr int64_t FUSE_MAX = 64;
+            for (int64_t s = 0; s < k_steps; s += FUSE_MAX) {
+                const int c = (int)(k_steps - s < FUSE_MAX ? k_steps - s : FUSE_MAX);
+                const uint64_t t = t0 + (uint64_t)s;
+                rc = dispatch_env(env, params, [&](auto tag, const auto &p) {
+                    using E = typename decltype(tag)::Env;
+                    return launch_steps_fused<E>(p, state, action, ob, (typename E::Reward *)reward, done, err, n, seed,
+                                                 action_seed, lane0, t, c, flags, stream);
+                });
+                if (rc) return rc;
+            }
+            return 0;
+        }
         for (int64_t s = 0; s < k_steps; ++s) {
             const uint64_t t = t0 + (uint64_t)s;
             rc = dispatch_env(env, params, [&](auto tag, const auto &p) {

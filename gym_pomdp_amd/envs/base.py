@@ -440,11 +440,14 @@ class BatchedEnv(object):
         out["terminated"] = out["terminated"].view(torch.bool)
         return out
 
-    def rollout_synthetic(self, steps, action_seed=None, actions=None):
+    def rollout_synthetic(self, steps, action_seed=None, actions=None, fuse=False):
         """`steps` consecutive step() calls under the synthetic uniform policy, issued from C
-        (pomdp_rollout_synthetic): the same two launches per step a python loop over
-        synthetic_actions() + step() makes, without the interpreter between them.  Outputs land in the
-        reusable buffers; returns (ob, reward, done) of the last step.  Asynchronous."""
+        (pomdp_rollout_synthetic): the same launches per step a python loop over synthetic_actions() + step()
+        makes, without the interpreter between them.  `fuse=True` (policy key == env key only): up to 64
+        consecutive steps share one launch — every step's outputs are still computed and written, so all
+        buffers end up exactly as after the per-step launches, but a lane's state stays in registers between
+        its steps.  Outputs land in the reusable buffers; returns (ob, reward, done) of the last step.
+        Asynchronous."""
         if not self._has_reset:
             raise AttributeError("%s: rollout before reset()" % type(self).__name__)
         if actions is None:
@@ -458,7 +461,8 @@ class BatchedEnv(object):
                 _native.ENV_KIND[self.env_name], self._params_ref, self._state.data_ptr(), actions.data_ptr(),
                 self._ob.data_ptr(), self._reward.data_ptr(), self._done.data_ptr(), self._err.data_ptr(),
                 self.batch_size, self._seed, self._seed if action_seed is None else action_seed, self.lane_offset,
-                t0, int(steps), _native.POMDP_AUTO_RESET if self.auto_reset else 0, self._stream())
+                t0, int(steps), (_native.POMDP_AUTO_RESET if self.auto_reset else 0) |
+                (_native.POMDP_FUSE_STEPS if fuse else 0), self._stream())
             _native.check(rc, "pomdp_rollout_synthetic")
         return self._ob, self._reward, self._done.view(torch.bool)
 

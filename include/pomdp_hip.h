@@ -52,6 +52,7 @@ enum {
 enum {
     POMDP_AUTO_RESET = 1,    /* done lanes get a fresh episode in the same call (stream RESET of the same t);
                                 without it `done` is in/out and done lanes freeze: (ob, reward, done) = (0, 0, 1) */
+    POMDP_FUSE_STEPS = 2,    /* pomdp_rollout_synthetic only: consecutive steps may share a launch (see there) */
 };
 
 /* id of the word streams of one (seed, lane, t) */
@@ -175,7 +176,10 @@ int pomdp_philox_blocks(const uint32_t *ctr_key, uint32_t *out, int64_t n_blocks
  * when action_seed == seed (policy and env share the Philox key; their streams differ by stream id) the
  * policy kernel runs once, for t0, and every step launch also leaves the policy's actions for the
  * following call counter in `action` (on RockSample they ride in the cooperative reset pass); with a
- * distinct action_seed each step is a policy launch plus a step launch.  Either way `action` holds the
+ * distinct action_seed each step is a policy launch plus a step launch.  With POMDP_FUSE_STEPS in `flags` (shared key
+ * only) up to 64 consecutive steps run inside one launch: every step's state / ob / reward / done / next action is still
+ * computed and written, in the same order, so every buffer holds what the per-step launches leave, but a lane's state
+ * and action stay in registers between its steps and the launch ramp is paid once per 64 steps.  Either way `action` holds the
  * actions of t0 + k_steps on return.  The caller's call counter advances by k_steps.  `params` points at the env's
  * pomdp_<env>_params; `reward` is int32 or float per env.  n and lane0 must be multiples of 4. */
 int pomdp_rollout_synthetic(int env, const void *params, uint32_t *state, int32_t *action, int32_t *ob,

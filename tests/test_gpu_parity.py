@@ -908,3 +908,29 @@ def test_heuristic_returns_accumulate_like_the_reference_loop(env, kw, auto):
         both_nan = np.isnan(np_(R.ret_done)) & np.isnan(ret_done)
         assert ((np_(R.ret_done) == ret_done) | both_nan).all(), t
     assert np.isfinite(ret_done).sum() > 0 or env == "stochrock"
+
+
+FUSE_CASES = [("rock", {}, (1 << 18) + 260, True), ("rock", {}, 4100, True), ("rock", {}, (1 << 18) + 4, False),
+              ("rock", dict(board_size=15, num_rocks=15), 1 << 18, True), ("stochrock", {}, 1 << 18, True),
+              ("tag", {}, (1 << 18) + 516, True), ("tag", {}, 5000, False), ("tag", dict(num_opponents=3), 1 << 18, True),
+              ("battleship", {}, 20000, True), ("battleship", dict(board_size=(10, 10), max_len=5), 8192, True),
+              ("tiger", {}, 30000, True), ("tiger", {}, 30000, False), ("network", {}, 30000, True)]
+
+
+@pytest.mark.parametrize("env,kw,n,auto", FUSE_CASES, ids=["%s-%d-%s" % (c[0], c[2], "auto" if c[3] else "frozen") for c in FUSE_CASES])
+def test_fused_steps_leave_what_per_step_launches_leave(env, kw, n, auto):
+    """pomdp_rollout_synthetic with POMDP_FUSE_STEPS (up to 64 steps per launch, state and action in registers between
+    steps) == the same steps launched one by one: state, action scratch, ob, reward, done and the error counter, after
+    runs that cross the 64-step launch boundary, for both launch geometries and with frozen (no auto-reset) lanes."""
+    steps = [1, 3, 64, 65, 7]
+    a = make_env(env, kw, batch_size=n, seed=2718, lane_offset=8, auto_reset=auto, reuse_buffers=True)
+    b = make_env(env, kw, batch_size=n, seed=2718, lane_offset=8, auto_reset=auto, reuse_buffers=True)
+    a.reset()
+    b.reset()
+    for k in steps:
+        a.rollout_synthetic(k, fuse=False)
+        b.rollout_synthetic(k, fuse=True)
+        for name in ("_state", "_action_scratch", "_ob", "_reward", "_done"):
+            assert torch.equal(getattr(a, name), getattr(b, name)), (env, kw, n, auto, k, name)
+    assert a.invalid_action_count() == b.invalid_action_count() == 0
+    assert a.call_counter == b.call_counter

@@ -10,14 +10,14 @@ mkdir -p $OUT $W
 cd /tmp
 # 1. headline workload: kernel trace, then the two HBM byte counters in separate passes
 rocprofv3 --kernel-trace --stats -d $W/trace -o t -- python $REPO/bench.py --steps 2000 --no-cpu-baseline > $W/bench_traced.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $W/pmc_fetch -o f -- python $REPO/bench.py --steps 100 --no-cpu-baseline > $W/bench_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $W/pmc_write -o w -- python $REPO/bench.py --steps 100 --no-cpu-baseline > $W/bench_write.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $W/pmc_fetch -o f -- python $REPO/bench.py --prewarm 0 --warmup 64 --steps 640 --no-cpu-baseline > $W/bench_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $W/pmc_write -o w -- python $REPO/bench.py --prewarm 0 --warmup 64 --steps 640 --no-cpu-baseline > $W/bench_write.log 2>&1
 (echo "# tools/gpu_profile_round.sh $TAG: python bench.py --steps 2000 --no-cpu-baseline under rocprofv3 (MI355X)"; python $REPO/tools/rocpd_summary.py $W | awk '{ if (substr($0,1,1)=="{") print; else print substr($0,1,300) }') > $OUT/headline.txt
 python $REPO/tools/rocpd_summary.py $W --traffic $OUT/traffic.json "RockSample(7,8) 2^20 lanes"
 # 2. instruction / occupancy counters of the step kernels
 cd $REPO
 (echo "# rocprofv3 --pmc passes over 'python bench.py --env rock --steps 100 --no-cpu-baseline' (tools/gpu_pmc_env.sh rock), MI355X";
- echo "# 8192 waves per launch (two lanes per thread): divide SQ_INSTS_* by 8192 for per-wave (128-lane) counts";
+ echo "# 8192 waves per launch (two lanes per thread): divide SQ_INSTS_* by 8192 for per-wave (128-lane) counts; steps_kernel launches are 64 steps each";
  bash tools/gpu_pmc_env.sh rock 2>/dev/null) > $OUT/pmc_valu.txt
 # 3. every env, the fused rollouts and the heuristic policy: kernel traces
 cd /tmp

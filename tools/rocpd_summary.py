@@ -45,7 +45,8 @@ def traffic_json(root, out_path, workload):
            "calibrated: the step kernels read exactly 8192 KB of state + action per launch)",
            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of `python bench.py --steps 100 "
                      "--no-cpu-baseline` (tools/gpu_profile_round.sh)"}
-    for key, pat in (("plain", "%step_kernel<%>, _, false>(%"), ("chain", "%step_kernel<%>, _, true>(%")):
+    for key, pat in (("plain", "%step_kernel<%>, _, false>(%"), ("chain", "%step_kernel<%>, _, true>(%"),
+                     ("fused", "%steps_kernel<%")):
         vals = []
         for db, cn in ((f, "FETCH_SIZE"), (w, "WRITE_SIZE")):
             r = sqlite3.connect(db).execute("select avg(value), count(*) from counters_collection where counter_name=? "
