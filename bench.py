@@ -53,7 +53,7 @@ ORACLE_NAME = {"rock": "rock", "rock15": "rock", "tag": "tag", "battleship": "ba
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--steps", type=int, default=2048)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--env", default="rock", choices=sorted(WORKLOADS))
     ap.add_argument("--lanes-per-gpu", type=int, default=1 << 20)
@@ -87,7 +87,7 @@ def prewarm(args, run, dev):
     """Untimed clock spin-up: keep the GPU busy with the workload's own launches for --prewarm seconds."""
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < args.prewarm:
-        run(50)
+        run(64)
         torch.cuda.synchronize(dev)
 
 

@@ -43,8 +43,9 @@ def traffic_json(root, out_path, workload):
     f, w = db_of(os.path.join(root, "pmc_fetch")), db_of(os.path.join(root, "pmc_write"))
     out = {"workload": workload, "fetch_correction": "x2 (gfx950 FETCH_SIZE reports half of a coalesced stream; "
            "calibrated: the step kernels read exactly 8192 KB of state + action per launch)",
-           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of `python bench.py --steps 100 "
-                     "--no-cpu-baseline` (tools/gpu_profile_round.sh)"}
+           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of `python bench.py --prewarm 0 "
+                     "--warmup 64 --steps 640 --no-cpu-baseline` (tools/gpu_profile_round.sh); `fused` = one 64-step "
+                     "steps_kernel launch, `chain` / `plain` = one single-step launch"}
     for key, pat in (("plain", "%step_kernel<%>, _, false>(%"), ("chain", "%step_kernel<%>, _, true>(%"),
                      ("fused", "%steps_kernel<%")):
         vals = []
