@@ -386,7 +386,10 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(uint32_t *__restrict__ stat
 // registers from one step to the next (nothing is re-read) and there is one launch ramp per k steps instead of per
 // step.  Possible because a lane's step t+1 depends only on its own step t and all cooperation (pooled Philox passes,
 // cooperative resets) is wave- or workgroup-local: no grid-wide synchronisation is involved.
-template <class Env, int LPT>
+// SIMPLE: every thread's lanes exist (n is a multiple of the workgroup's BLOCK * LPT lanes) and done lanes auto-reset, so
+// no lane is ever out of range or frozen, and the actions are the driver's own (always valid): the bookkeeping for those
+// cases is compiled out.
+template <class Env, int LPT, bool SIMPLE>
 __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ state, int32_t *__restrict__ action,
                                                       int32_t *__restrict__ ob, typename Env::Reward *__restrict__ reward,
                                                       uint8_t *__restrict__ done, uint32_t *__restrict__ err, int64_t n,
@@ -394,9 +397,9 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
                                                       const typename Env::Params p)
 {
     __shared__ typename Env::Shared sh;
-    const bool auto_reset = flags & POMDP_AUTO_RESET;
+    const bool auto_reset = SIMPLE || (flags & POMDP_AUTO_RESET);
     const uint32_t wg0 = blockIdx.x * (uint32_t)(BLOCK * LPT);
-    const uint32_t last = (uint32_t)((uint64_t)(n - 1) - wg0);
+    const uint32_t last = SIMPLE ? (uint32_t)(BLOCK * LPT - 1) : (uint32_t)((uint64_t)(n - 1) - wg0);
     int32_t *const action_w = action + wg0;
     uint32_t *const state_w = state + wg0;
     int32_t *const ob_w = ob + wg0;
@@ -410,7 +413,7 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
     for (int j = 0; j < LPT; ++j) {
         rel[j] = threadIdx.x + (uint32_t)(j * BLOCK);
         glane[j] = lane0 + wg0 + rel[j];
-        in_range[j] = rel[j] <= last;
+        in_range[j] = SIMPLE || rel[j] <= last;
         const uint32_t rc = in_range[j] ? rel[j] : last;
         __builtin_assume(rc < (uint32_t)(BLOCK * LPT));
         a_cur[j] = ld_stream(action_w + rc);
@@ -445,8 +448,8 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
 #pragma unroll
         for (int j = 0; j < LPT; ++j) {
             before[j] = st[j];
-            valid[j] = (unsigned)a_cur[j] < (unsigned)n_act;
-            live[j] = in_range[j] && valid[j] && !was_done[j];
+            valid[j] = SIMPLE || (unsigned)a_cur[j] < (unsigned)n_act;
+            live[j] = SIMPLE || (in_range[j] && valid[j] && !was_done[j]);
             Fin::lane_step(sh, p, st[j], valid[j] ? a_cur[j] : 0, key, glane[j], o[j], r[j], d[j], aux[j]);
             if (!live[j]) { r[j] = 0; d[j] = was_done[j]; }
             fresh[j] = live[j] && d[j] && auto_reset;
@@ -946,13 +949,15 @@ static int launch_steps_fused(const typename Env::Params &p, uint32_t *state, in
 {
     if (!state || !action || !ob || !reward || !done || bad_range(n, lane0) || (lane0 & 3u) || k < 1) return POMDP_E_BADARG;
     if (n == 0) return 0;
-    if (Env::POOLED_LPT2 && n >= LPT2_MIN_LANES)
-        hipLaunchKernelGGL((steps_kernel<Env, 2>), dim3((unsigned)((n + 2 * BLOCK - 1) / (2 * BLOCK))), dim3(BLOCK), 0,
-                           (hipStream_t)stream, state, action, ob, reward, done, err, n, make_key(seed, t), lane0, flags,
-                           make_key(action_seed, t + 1), k, p);
-    else
-        hipLaunchKernelGGL((steps_kernel<Env, 1>), dim3(blocks_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, state, action,
-                           ob, reward, done, err, n, make_key(seed, t), lane0, flags, make_key(action_seed, t + 1), k, p);
+    const bool lpt2 = Env::POOLED_LPT2 && n >= LPT2_MIN_LANES;
+    const bool simple = (flags & POMDP_AUTO_RESET) && n % (lpt2 ? 2 * BLOCK : BLOCK) == 0;
+    const dim3 grid(lpt2 ? (unsigned)((n + 2 * BLOCK - 1) / (2 * BLOCK)) : blocks_for(n));
+#define POMDP_LAUNCH_STEPS(LPT_, SIMPLE_)                                                                              \
+    hipLaunchKernelGGL((steps_kernel<Env, LPT_, SIMPLE_>), grid, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob,  \
+                       reward, done, err, n, make_key(seed, t), lane0, flags, make_key(action_seed, t + 1), k, p)
+    if (lpt2) { if (simple) POMDP_LAUNCH_STEPS(2, true); else POMDP_LAUNCH_STEPS(2, false); }
+    else { if (simple) POMDP_LAUNCH_STEPS(1, true); else POMDP_LAUNCH_STEPS(1, false); }
+#undef POMDP_LAUNCH_STEPS
     return (int)hipGetLastError();
 }
 
