@@ -104,16 +104,21 @@ struct RockEnv {
     }
     static __device__ __forceinline__ uint32_t reset_group_codes(const uint4 &h, const RngKey &key, uint32_t lane, int g, int K)
     {
-        uint32_t c0 = rock_code_hi(h.x), c1 = rock_code_hi(h.y), c2 = rock_code_hi(h.z), c3 = rock_code_hi(h.w);
-        if (c0 == 3u || c1 == 3u || c2 == 3u || c3 == 3u) {                    // some rock undecided: 2^-27 per rock
+        // (H >> 5) compared with 2^26: above for H >= 2^31 + 32 (code 2, good), below for H < 2^31 (code 0, bad), so
+        // the code is twice the top bit unless H lies in the 32 values in between — the tie the low word decides.
+        const uint32_t TOP = 0x80000000u;
+        uint32_t codes = ((h.x >> 30) & 2u) | ((h.y >> 28) & 8u) | ((h.z >> 26) & 32u) | ((h.w >> 24) & 128u);
+        if (min(min(h.x ^ TOP, h.y ^ TOP), min(h.z ^ TOP, h.w ^ TOP)) < 32u) { // some rock undecided: 2^-27 per rock
             const uint4 l = stream_block(key, lane, POMDP_STREAM_RESET, 2u * (uint32_t)g + 1u);
+            uint32_t c0 = rock_code_hi(h.x), c1 = rock_code_hi(h.y), c2 = rock_code_hi(h.z), c3 = rock_code_hi(h.w);
             if (c0 == 3u) c0 = rock_code_lo(l.x);
             if (c1 == 3u) c1 = rock_code_lo(l.y);
             if (c2 == 3u) c2 = rock_code_lo(l.z);
             if (c3 == 3u) c3 = rock_code_lo(l.w);
+            codes = c0 | (c1 << 2) | (c2 << 4) | (c3 << 6);
         }
-        const int j = 4 * g;
-        return (j < K ? c0 : 0u) | (j + 1 < K ? c1 << 2 : 0u) | (j + 2 < K ? c2 << 4 : 0u) | (j + 3 < K ? c3 << 6 : 0u);
+        const int left = K - 4 * g;                                            // rocks of this group that exist (wave-uniform)
+        return codes & (left >= 4 ? 0xFFu : ((1u << (2 * left)) - 1u));
     }
     // block `j2` (0 = sensor / gate high words, 1 = their low words, 2 / 3 = StochasticRock's sensor) of lane's quad
     static __device__ __forceinline__ uint4 quad_block(const RngKey &key, uint32_t lane, uint32_t j2)
