@@ -278,6 +278,19 @@ int main(int argc, char **argv)
     }
     printf("pomdp_rollout_synthetic (C driver, chained), per step: %8.2f\n",
            time_it([&](int t) { pomdp_rollout_synthetic(POMDP_ENV_ROCK, &p, state, action, ob, reward, done, err, n, 1, 1, 0, (uint64_t)t * 100, 100, 1, nullptr); }, iters / 100 + 1) / 100);
+    {   // fused multi-step launches: 64 chained steps per launch (SIMPLE = full workgroups, auto-reset), per step
+        using E = RockEnv<1, 0>;
+        const int reps = iters / 64 + 1;
+        printf("steps_kernel (64 steps per launch), per step: LPT2 simple %6.2f", time_it([&](int t) {
+            hipLaunchKernelGGL((steps_kernel<E, 2, true>), dim3((unsigned)(n / 512)), dim3(256), 0, 0, state, action, ob, reward, done, err, n, make_key(1, 64 * t), 0u, 1, make_key(1, 64 * t + 1), 64, p);
+        }, reps) / 64);
+        printf("  LPT2 general %6.2f", time_it([&](int t) {
+            hipLaunchKernelGGL((steps_kernel<E, 2, false>), dim3((unsigned)((n + 511) / 512)), dim3(256), 0, 0, state, action, ob, reward, done, err, n, make_key(1, 64 * t), 0u, 1, make_key(1, 64 * t + 1), 64, p);
+        }, reps) / 64);
+        printf("  LPT4 simple %6.2f\n", time_it([&](int t) {
+            hipLaunchKernelGGL((steps_kernel<E, 4, true>), dim3((unsigned)(n / 1024)), dim3(256), 0, 0, state, action, ob, reward, done, err, n, make_key(1, 64 * t), 0u, 1, make_key(1, 64 * t + 1), 64, p);
+        }, reps) / 64);
+    }
     {   // hipGraph replay of 100 chained step launches vs the same launches issued one by one
         using E = RockEnv<1, 0>;
         hipStream_t gs; CK(hipStreamCreateWithFlags(&gs, hipStreamNonBlocking));
