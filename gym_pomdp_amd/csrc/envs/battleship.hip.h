@@ -11,6 +11,7 @@ struct BattleShipEnv {
     using Reward = int32_t;
     static constexpr int WORDS = 2 * MW;
     static constexpr bool POOLED_LPT2 = false;
+    static constexpr bool POOLED_ANY_LPT = false;
     static constexpr bool QUAD_SENSOR = false;
     static constexpr int ABL = 0;
     struct Shared { int unused; };

@@ -10,6 +10,7 @@ struct NetworkEnv {
     using Reward = float;
     static constexpr int WORDS = 1;
     static constexpr bool POOLED_LPT2 = false;
+    static constexpr bool POOLED_ANY_LPT = false;
     static constexpr bool QUAD_SENSOR = false;
     static constexpr int ABL = 0;
     struct Shared { int unused; };

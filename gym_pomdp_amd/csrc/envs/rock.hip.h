@@ -27,6 +27,7 @@ struct RockEnv {
     using S = typename std::conditional<W == 1, uint32_t, uint64_t>::type; // 32-bit ALU when one word is enough
     static constexpr int WORDS = W;
     static constexpr bool POOLED_LPT2 = !STOCH;   // pomdp_kernels.hip: Finisher<RockEnv, 2, .>
+    static constexpr bool POOLED_ANY_LPT = !STOCH; // ... and for any other number of lanes per thread >= 2
     static constexpr int ABL = ABLATE;            // experiment switches (tools/microbench.hip); 0 in the product
     struct Shared {
         uint32_t thr_hi[32];   // sensor threshold by L1 distance, thr >> 26  (compared with H >> 5)

@@ -10,6 +10,7 @@ struct TagEnv {
     using Reward = float;
     static constexpr int WORDS = 1;
     static constexpr bool POOLED_LPT2 = true;     // pomdp_kernels.hip: Finisher<TagEnv, 2, .>
+    static constexpr bool POOLED_ANY_LPT = false;
     static constexpr bool QUAD_SENSOR = false;
     static constexpr int ABL = 0;
     // The T-shaped board never changes (tag.py:36-78): two small LDS tables replace the coordinate arithmetic of the

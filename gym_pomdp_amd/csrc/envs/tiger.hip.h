@@ -10,6 +10,7 @@ struct TigerEnv {
     using Reward = int32_t;
     static constexpr int WORDS = 1;
     static constexpr bool POOLED_LPT2 = false;
+    static constexpr bool POOLED_ANY_LPT = false;
     static constexpr bool QUAD_SENSOR = false;
     static constexpr int ABL = 0;
     struct Shared { int unused; };
