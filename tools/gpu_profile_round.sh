@@ -16,8 +16,8 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $W/pmc_write -o w -- python $REPO/b
 python $REPO/tools/rocpd_summary.py $W --traffic $OUT/traffic.json "RockSample(7,8) 2^20 lanes"
 # 2. instruction / occupancy counters of the step kernels
 cd $REPO
-(echo "# rocprofv3 --pmc passes over 'python bench.py --env rock --steps 100 --no-cpu-baseline' (tools/gpu_pmc_env.sh rock), MI355X";
- echo "# 8192 waves per launch (two lanes per thread): divide SQ_INSTS_* by SQ_WAVES for per-wave counts (128 lanes at two lanes per thread, 256 at four); steps_kernel launches are 64 steps each";
+(echo "# rocprofv3 --pmc passes over 'python bench.py --env rock --prewarm 0 --warmup 64 --steps 640 --no-cpu-baseline' (tools/gpu_pmc_env.sh rock), MI355X";
+ echo "# divide SQ_INSTS_* by SQ_WAVES for per-wave counts (128 lanes at two lanes per thread, 256 at four); steps_kernel launches are 64 steps each";
  bash tools/gpu_pmc_env.sh rock 2>/dev/null) > $OUT/pmc_valu.txt
 # 3. every env, the fused rollouts and the heuristic policy: kernel traces
 cd /tmp
