@@ -68,7 +68,7 @@ def parse():
                     help="step: the headline metric.  rollout: BASELINE.json configs[4] shape — every launch runs "
                          "sims-per-root random rollouts of --depth steps from each root (fused kernel, state in registers).  "
                          "heuristic: every lane follows the env's own _generate_preferred(history) policy "
-                         "(use_heuristic=True; rock / rock15 / tag), one fused launch per step")
+                         "(use_heuristic=True; rock / rock15 / tag), up to 64 steps per fused launch")
     ap.add_argument("--depth", type=int, default=64)
     ap.add_argument("--sims-per-root", type=int, default=1024)
     ap.add_argument("--action-seed", type=int, default=None, help="policy key (default: the env seed)")
@@ -181,7 +181,7 @@ def heuristic_mode(args, gpa, env_id, kwargs, cp, dev, rank, world, label, n, la
 
     def run(k):
         while k > 0:
-            c = min(k, 100)
+            c = min(k, 128)                  # up to 64 steps per launch
             env.heuristic_steps(hist, c)
             k -= c
 
@@ -198,11 +198,11 @@ def heuristic_mode(args, gpa, env_id, kwargs, cp, dev, rank, world, label, n, la
     elapsed = cp.max(time.perf_counter() - t0)
     cp.barrier()
     kern_ms = ev0.elapsed_time(ev1) / args.steps
-    # algorithmic bytes per lane-step: what one launch must read and write per lane whatever the action —
-    # read state, history size, prev_ob and the two derived words (Tag: last_action / last_ob instead): 20 B;
-    # write state, action, ob, reward, done, prev_ob, size, last_action, last_ob: 33 B; a CHECK's statistics update
-    # (one rock's five fields and two sums) is not counted
-    alg = 20 + 33 + 8 * (env.state_words - 1)
+    # algorithmic bytes per lane-step: with up to 64 steps per launch the lane's history words stay in
+    # registers, so a step must write action, ob, reward, done and the state words: 13 B + 4 B per state word (a CHECK's
+    # statistics update — one rock's five fields and two sums — is not counted, nor the 40 B per lane read and written
+    # once per launch)
+    alg = 13 + 4 * env.state_words
     achieved = alg * n / (kern_ms * 1e-3) / 1e9
     if rank == 0:
         print(json.dumps({
@@ -211,7 +211,7 @@ def heuristic_mode(args, gpa, env_id, kwargs, cp, dev, rank, world, label, n, la
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "int32 (+ f64 side statistics)", "data": "synthetic",
             "config": {"workload": "%s batch=%d lanes per GPU, every lane follows _generate_preferred(history) "
-                                   "(use_heuristic=True), auto-reset, one fused launch per step" % (label, n),
+                                   "(use_heuristic=True), auto-reset, up to 64 steps per fused launch" % (label, n),
                        "lanes_per_gpu": n, "mean_history_size": float(hist._size.float().mean().item()),
                        "parallelism": "lane-shard x%d, no collectives" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -246,6 +246,9 @@ struct BattleShipEnv {
     static __device__ __forceinline__ uint32_t preferred_mask(const Shared &, const Params &, const State &,
                                                               const pomdp_history &, int64_t, uint32_t, uint32_t, uint32_t,
                                                               int) { return 0u; }
+    static __device__ __forceinline__ uint32_t preferred_mask(const Shared &, const Params &, const State &,
+                                                              const pomdp_history &, int64_t, uint32_t, uint32_t, uint32_t,
+                                                              int, int, int) { return 0u; }
     // battleship.py:80-89 _compute_prob (reads the grid as it is after the shot)
     static __device__ __forceinline__ double compute_prob(const Shared &, const Params &, const State &st, int a, int ob)
     {

@@ -259,9 +259,9 @@ struct RockEnv {
         return measured < 5 && abs(count) < 2 && 0 < pv && pv < 1;
     }
     // rock.py:177-191: side statistics of the rock a CHECK just measured (CHECK does not move the agent, so the
-    // stored position is the one the reading was taken from); keeps the rock's bit of b.check_ok current
+    // stored position is the one the reading was taken from); keeps the rock's bit of the caller's copy of b.check_ok current
     static __device__ __forceinline__ void belief_update(const Shared &sh, const Params &p, const State &st, int a, int ob,
-                                                         const pomdp_rock_belief &b, int64_t n, uint32_t i)
+                                                         const pomdp_rock_belief &b, int64_t n, uint32_t i, uint32_t &ck)
     {
         const S s = st.s;
         const int x = (int)(s & 15u), y = (int)((s >> 4) & 15u), r = (a - 5) & 15;
@@ -280,8 +280,8 @@ struct RockEnv {
         b.lkv[k] = lkv;
         b.lkw[k] = lkw;
         b.prob_valuable[k] = pv;
-        const uint32_t bit = 1u << r, m = b.check_ok[i];
-        b.check_ok[i] = check_ok(measured, count, pv) ? (m | bit) : (m & ~bit);
+        const uint32_t bit = 1u << r;                                            // the caller keeps b.check_ok[i] in `ck`
+        ck = check_ok(measured, count, pv) ? (ck | bit) : (ck & ~bit);
     }
 
     // rock.py:293-374 _generate_preferred with use_heuristic=True, as a bitmask over actions: every list the
@@ -293,6 +293,12 @@ struct RockEnv {
                                                               int64_t n, uint32_t i)
     {
         return preferred_mask(sh, p, st, h, n, i, ld_stream(b.check_ok + i), ld_stream(h.move_ok + i), ld_stream(h.size + i));
+    }
+    static __device__ __forceinline__ uint32_t preferred_mask(const Shared &sh, const Params &p, const State &st,
+                                                              const pomdp_history &h, int64_t n, uint32_t i, uint32_t ck,
+                                                              uint32_t mv, int hsize, int, int)
+    {
+        return preferred_mask(sh, p, st, h, n, i, ck, mv, hsize);
     }
     // the same with the lane's three per-lane words already loaded (the fused kernel issues those loads up front)
     static __device__ __forceinline__ uint32_t preferred_mask(const Shared &sh, const Params &p, const State &st,

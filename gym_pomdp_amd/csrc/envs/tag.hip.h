@@ -99,17 +99,24 @@ struct TagEnv {
     {
         return preferred_mask(sh, p, st, h, n, i, 0u, 0u, ld_stream(h.size + i));
     }
+    static __device__ __forceinline__ uint32_t preferred_mask(const Shared &sh, const Params &p, const State &st,
+                                                              const pomdp_history &h, int64_t n, uint32_t i, uint32_t ck,
+                                                              uint32_t mv, int hsize)
+    {
+        return preferred_mask(sh, p, st, h, n, i, ck, mv, hsize, hsize ? h.last_action[i] : -1, hsize ? h.last_ob[i] : -1);
+    }
+    // with history[-1].action / .ob already in registers (the fused multi-step loop)
     static __device__ __forceinline__ uint32_t preferred_mask(const Shared &, const Params &, const State &st,
-                                                              const pomdp_history &h, int64_t, uint32_t i, uint32_t,
-                                                              uint32_t, int hsize)
+                                                              const pomdp_history &, int64_t, uint32_t, uint32_t,
+                                                              uint32_t, int hsize, int last_action, int last_ob)
     {
         if (hsize == 0) return 0x1Fu;
         const int agent = (int)(st.w & 31u);
         int x, y;
         coord(agent, x, y);
         const bool corner = y < 2 ? (x == 0 || x == 9) : (y == 4 && (x == 5 || x == 7));
-        if (h.last_ob[i] == 29 && corner) return 1u << 4;          // grid.n_tiles, whatever obs_cells was set to
-        const int la = h.last_action[i];
+        if (last_ob == 29 && corner) return 1u << 4;               // grid.n_tiles, whatever obs_cells was set to
+        const int la = last_action;
         uint32_t m = 0;
         const int dx[4] = {0, 1, 0, -1}, dy[4] = {1, 0, -1, 0};
 #pragma unroll

@@ -562,7 +562,9 @@ __global__ __launch_bounds__(BLOCK) void belief_update_kernel(const typename Env
     if (a <= 4 || a >= 5 + p.num_rocks || o == 0) return;                      // not an executed CHECK
     typename Env::State st;
     Env::load(st, state, n, (uint32_t)i);
-    Env::belief_update(sh, p, st, a, o, b, n, (uint32_t)i);
+    uint32_t ck = b.check_ok[i];
+    Env::belief_update(sh, p, st, a, o, b, n, (uint32_t)i, ck);
+    b.check_ok[i] = ck;
 }
 
 template <class Env>
@@ -581,7 +583,7 @@ __global__ __launch_bounds__(BLOCK) void select_target_kernel(const typename Env
 
 // the two sums over CHECK-j transitions (rock.py:303-310, 327-334) and the derived bit j of move_ok
 static __device__ __forceinline__ void history_check_sums(const pomdp_history &h, int j, int next_ob, int prev_ob, int64_t n,
-                                                          uint32_t i)
+                                                          uint32_t i, uint32_t &mv)          // mv: the caller's copy of h.move_ok[i]
 {
     const int64_t k = (int64_t)j * n + i;
     const int ds = (next_ob == 2) - (next_ob == 1);
@@ -590,8 +592,8 @@ static __device__ __forceinline__ void history_check_sums(const pomdp_history &h
     if (dm) {
         const int tm = h.total_move[k] + dm;
         h.total_move[k] = tm;
-        const uint32_t bit = 1u << j, m = h.move_ok[i];
-        h.move_ok[i] = tm >= 0 ? (m | bit) : (m & ~bit);
+        const uint32_t bit = 1u << j;
+        mv = tm >= 0 ? (mv | bit) : (mv & ~bit);
     }
 }
 
@@ -620,7 +622,11 @@ __global__ __launch_bounds__(BLOCK) void history_append_kernel(pomdp_history h, 
     }
     const int a = action[i], o = next_observation[i];
     h.size[i] += 1; h.last_action[i] = a; h.last_ob[i] = o;
-    if (a >= 5 && a < 5 + K) history_check_sums(h, a - 5, o, observation[i], n, (uint32_t)i);
+    if (a >= 5 && a < 5 + K) {
+        uint32_t mv = h.move_ok[i];
+        history_check_sums(h, a - 5, o, observation[i], n, (uint32_t)i, mv);
+        h.move_ok[i] = mv;
+    }
 }
 
 template <class Env>
@@ -670,97 +676,115 @@ template <class Env, class = void>
 struct BeliefOps {
     static __device__ __forceinline__ void update(const typename Env::Shared &, const typename Env::Params &,
                                                   const typename Env::State &, int, int, const pomdp_rock_belief &, int64_t,
-                                                  uint32_t) {}
+                                                  uint32_t, uint32_t &) {}
 };
 template <int W, int ABLATE, bool STOCH>
 struct BeliefOps<RockEnv<W, ABLATE, STOCH>, void> {
     using Env = RockEnv<W, ABLATE, STOCH>;
     static __device__ __forceinline__ void update(const typename Env::Shared &sh, const typename Env::Params &p,
                                                   const typename Env::State &st, int a, int o, const pomdp_rock_belief &b,
-                                                  int64_t n, uint32_t i) { Env::belief_update(sh, p, st, a, o, b, n, i); }
+                                                  int64_t n, uint32_t i, uint32_t &ck) { Env::belief_update(sh, p, st, a, o, b, n, i, ck); }
 };
 template <class Env>
 static __device__ __forceinline__ void heuristic_belief_update(const typename Env::Shared &sh, const typename Env::Params &p,
                                                                const typename Env::State &st, int a, int o,
-                                                               const pomdp_rock_belief &b, int64_t n, uint32_t i)
+                                                               const pomdp_rock_belief &b, int64_t n, uint32_t i, uint32_t &ck)
 {
-    BeliefOps<Env>::update(sh, p, st, a, o, b, n, i);
+    BeliefOps<Env>::update(sh, p, st, a, o, b, n, i, ck);
 }
 
-// One heuristic-policy step in one launch: choice(_generate_preferred(history)) -> step -> side statistics ->
+// k heuristic-policy steps in one launch: per step choice(_generate_preferred(history)) -> step -> side statistics ->
 // history.append, i.e. preferred_kernel + pick_actions_kernel + step_kernel + belief_update_kernel +
-// history_append_kernel on the same call counter, with the lists never leaving registers.
+// history_append_kernel on the same call counter, with the lists never leaving registers.  Across the k steps a lane's
+// state, its history words (size, last action / observation, prev_ob), the two derived words and the running return stay
+// in registers and are written back once; the per-rock arrays are read and written in place when a CHECK touches them;
+// every step's action / ob / reward / done (and state) is written as the single-step launches write them.
 template <class Env>
-__global__ __launch_bounds__(BLOCK) void heuristic_step_kernel(const typename Env::Params p, uint32_t *__restrict__ state,
-                                                               pomdp_rock_belief b, pomdp_history h, int K, pomdp_returns R,
-                                                               int32_t *__restrict__ prev_ob, int32_t *__restrict__ action,
-                                                               int32_t *__restrict__ ob, typename Env::Reward *__restrict__ reward,
-                                                               uint8_t *__restrict__ done, int64_t n, RngKey key, uint32_t lane0,
-                                                               int flags)
+__global__ __launch_bounds__(BLOCK) void heuristic_steps_kernel(const typename Env::Params p, uint32_t *__restrict__ state,
+                                                                pomdp_rock_belief b, pomdp_history h, int K, pomdp_returns R,
+                                                                int32_t *__restrict__ prev_ob, int32_t *__restrict__ action,
+                                                                int32_t *__restrict__ ob, typename Env::Reward *__restrict__ reward,
+                                                                uint8_t *__restrict__ done, int64_t n, RngKey key0, uint32_t lane0,
+                                                                int flags, int k_steps)
 {
+#pragma clang fp contract(off)
     __shared__ typename Env::Shared sh;
     const bool auto_reset = flags & POMDP_AUTO_RESET;
     const uint32_t idx = blockIdx.x * (uint32_t)BLOCK + threadIdx.x;
     const bool in_range = (uint64_t)idx < (uint64_t)n;
     const uint32_t i = in_range ? idx : (uint32_t)(n - 1);
     const uint32_t lane = lane0 + i;
-    // every per-lane word first (one memory latency), then the tables, then the Philox block that depends on the lane id only
+    // every per-lane word first (one memory latency), then the tables
     typename Env::State st;
     Env::load(st, state, n, i);
-    const int hsize = ld_stream(h.size + i), pob = ld_stream(prev_ob + i);
-    const uint32_t ck = K ? ld_stream(b.check_ok + i) : 0u, mv = K ? ld_stream(h.move_ok + i) : 0u;
-    const bool was_done = auto_reset ? false : (ld_stream(done + i) != 0);
-    // policy word: element lane & 3 of the quad's ACTION block
-    const uint32_t e = lane & 3u;
-    const uint4 wq = stream_block(key, lane >> 2, POMDP_STREAM_ACTION, 0u);
-    const uint32_t word = e == 0 ? wq.x : e == 1 ? wq.y : e == 2 ? wq.z : wq.w;
+    int hsize = ld_stream(h.size + i), pob = ld_stream(prev_ob + i);
+    int la = ld_stream(h.last_action + i), lo = ld_stream(h.last_ob + i);
+    uint32_t ck = K ? ld_stream(b.check_ok + i) : 0u, mv = K ? ld_stream(h.move_ok + i) : 0u;
+    bool was_done = auto_reset ? false : (ld_stream(done + i) != 0);
+    double ret = R.ret ? R.ret[i] : 0.0, disc = R.ret ? R.disc[i] : 1.0;
     Env::stage(sh, p, (int)threadIdx.x);
     __syncthreads();
-    // the policy: a = list[(w * len(list)) >> 32] over the preferred list (ascending mask order) or the legal list
-    const uint32_t m = Env::preferred_mask(sh, p, st, h, n, i, ck, mv, hsize);
-    int a;
-    if (m) a = nth_set_bit(m, (int)__umulhi(word, (uint32_t)__popc(m)));
-    else a = Env::legal_nth(sh, p, st, (int)__umulhi(word, (uint32_t)Env::legal_count(sh, p, st)));
-    const bool live = in_range && !was_done;
-    int o, d;
-    typename Env::Reward r;
-    Env::step(sh, p, st, a, key, lane, o, r, d);
-    if (!live) { o = 0; r = 0; d = was_done; }
-    const bool fresh = live && d && auto_reset;
-    Env::reset_where(sh, p, st, fresh, key, lane);                             // wave-cooperative: every lane calls it
-    if (!in_range) return;
-    st_stream(action + i, (int32_t)(live ? a : -1));
-    st_stream(ob + i, (int32_t)o);
-    st_stream(reward + i, r);
-    st_stream(done + i, (uint8_t)d);
-    if (!live) return;
-    Env::store(st, state, n, i, fresh);
-    if (R.ret) {                                                               // r += rw * discount; discount *= _discount
-#pragma clang fp contract(off)
-        const double dc = R.disc[i];
-        const double term = dc * (double)r;
-        const double acc = R.ret[i] + term;
-        if (d) R.ret_done[i] = acc;
-        R.ret[i] = fresh ? 0.0 : acc;
-        R.disc[i] = fresh ? 1.0 : dc * R.discount;
-    }
-    if (fresh) {                                                               // new episode: fresh Rock objects, empty History
-        for (int j = 0; j < K; ++j) {
-            const int64_t k = (int64_t)j * n + i;
-            b.count[k] = 0; b.measured[k] = 0; b.lkv[k] = 1.; b.lkw[k] = 1.; b.prob_valuable[k] = .5;
-            h.total_sample[k] = 0; h.total_move[k] = 0;
+    const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo;
+    const uint32_t e = lane & 3u;
+    for (int s = 0; s < k_steps; ++s) {
+        RngKey key = key0;
+        key.t_lo = (uint32_t)(t0 + (uint64_t)s); key.t_hi = (uint32_t)((t0 + (uint64_t)s) >> 32);
+        // the policy: a = list[(w * len(list)) >> 32] over the preferred list (ascending mask order) or the legal list,
+        // w = element lane & 3 of the quad's ACTION block
+        const uint4 wq = stream_block(key, lane >> 2, POMDP_STREAM_ACTION, 0u);
+        const uint32_t word = e == 0 ? wq.x : e == 1 ? wq.y : e == 2 ? wq.z : wq.w;
+        const uint32_t m = Env::preferred_mask(sh, p, st, h, n, i, ck, mv, hsize, la, lo);
+        int a;
+        if (m) a = nth_set_bit(m, (int)__umulhi(word, (uint32_t)__popc(m)));
+        else a = Env::legal_nth(sh, p, st, (int)__umulhi(word, (uint32_t)Env::legal_count(sh, p, st)));
+        const bool live = in_range && !was_done;
+        const typename Env::State before = st;
+        int o, d;
+        typename Env::Reward r;
+        Env::step(sh, p, st, a, key, lane, o, r, d);
+        if (!live) { o = 0; r = 0; d = was_done; st = before; }
+        const bool fresh = live && d && auto_reset;
+        Env::reset_where(sh, p, st, fresh, key, lane);                         // wave-cooperative: every lane calls it
+        if (in_range) {
+            st_stream(action + i, (int32_t)(live ? a : -1));
+            st_stream(ob + i, (int32_t)o);
+            st_stream(reward + i, r);
+            st_stream(done + i, (uint8_t)d);
         }
-        if (K) { st_stream(b.check_ok + i, (1u << K) - 1u); st_stream(h.move_ok + i, (1u << K) - 1u); }
-        st_stream(h.size + i, 0); st_stream(h.last_action + i, -1); st_stream(h.last_ob + i, -1);
-        st_stream(prev_ob + i, (int32_t)Env::reset_ob(p, st));
-        return;
+        if (live) {
+            Env::store(st, state, n, i, fresh);
+            if (R.ret) {                                                       // r += rw * discount; discount *= _discount
+                const double term = disc * (double)r;
+                const double acc = ret + term;
+                if (d) R.ret_done[i] = acc;
+                ret = fresh ? 0.0 : acc;
+                disc = fresh ? 1.0 : disc * R.discount;
+            }
+            if (fresh) {                                                       // new episode: fresh Rock objects, empty History
+                for (int j = 0; j < K; ++j) {
+                    const int64_t k = (int64_t)j * n + i;
+                    b.count[k] = 0; b.measured[k] = 0; b.lkv[k] = 1.; b.lkw[k] = 1.; b.prob_valuable[k] = .5;
+                    h.total_sample[k] = 0; h.total_move[k] = 0;
+                }
+                ck = mv = K ? (1u << K) - 1u : 0u;
+                hsize = 0; la = -1; lo = -1;
+                pob = Env::reset_ob(p, st);
+            } else {
+                hsize += 1; la = a; lo = o;                                    // a terminal transition is recorded too
+                if (a >= 5 && a < 5 + K) {                                     // K > 0: RockSample CHECK
+                    history_check_sums(h, a - 5, o, pob, n, i, mv);
+                    if (o != 0 && !d) heuristic_belief_update<Env>(sh, p, st, a, o, b, n, i, ck);
+                }
+                pob = o;
+            }
+            was_done = auto_reset ? false : (d != 0);
+        }
     }
-    st_stream(h.size + i, hsize + 1); st_stream(h.last_action + i, (int32_t)a); st_stream(h.last_ob + i, (int32_t)o);   // terminal transitions too
-    if (a >= 5 && a < 5 + K) {                                                 // K > 0: RockSample CHECK
-        history_check_sums(h, a - 5, o, pob, n, i);
-        if (o != 0 && !d) heuristic_belief_update<Env>(sh, p, st, a, o, b, n, i);
-    }
-    st_stream(prev_ob + i, (int32_t)o);
+    if (!in_range) return;
+    st_stream(h.size + i, (int32_t)hsize); st_stream(h.last_action + i, (int32_t)la); st_stream(h.last_ob + i, (int32_t)lo);
+    st_stream(prev_ob + i, (int32_t)pob);
+    if (K) { st_stream(b.check_ok + i, ck); st_stream(h.move_ok + i, mv); }
+    if (R.ret) { R.ret[i] = ret; R.disc[i] = disc; }
 }
 
 // Lane i simulates from root state column i / sims_per_root for up to `depth` steps: the state lives in registers
@@ -1075,11 +1099,12 @@ static int launch_heuristic_steps(const typename Env::Params &p, uint32_t *state
 {
     if (n == 0) return 0;
     static const pomdp_returns NO_RETURNS = {0.0, nullptr, nullptr, nullptr};
-    for (int64_t s = 0; s < k_steps; ++s) {
-        hipLaunchKernelGGL(heuristic_step_kernel<Env>, dim3(blocks_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, p, state,
+    constexpr int64_t FUSE_MAX = 64;                      // steps per launch
+    for (int64_t s = 0; s < k_steps; s += FUSE_MAX) {
+        const int c = (int)(k_steps - s < FUSE_MAX ? k_steps - s : FUSE_MAX);
+        hipLaunchKernelGGL(heuristic_steps_kernel<Env>, dim3(blocks_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, p, state,
                            b ? *b : NO_BELIEF, *h, K, returns ? *returns : NO_RETURNS, prev_ob, action, ob,
-                           (typename Env::Reward *)reward, done, n,
-                           make_key(seed, t0 + (uint64_t)s), lane0, flags);
+                           (typename Env::Reward *)reward, done, n, make_key(seed, t0 + (uint64_t)s), lane0, flags, c);
         const int rc = (int)hipGetLastError();
         if (rc) return rc;
     }

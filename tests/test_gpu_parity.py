@@ -935,3 +935,42 @@ def test_fused_steps_leave_what_per_step_launches_leave(env, kw, n, auto):
             assert torch.equal(getattr(a, name), getattr(b, name)), (env, kw, n, auto, k, name)
     assert a.invalid_action_count() == b.invalid_action_count() == 0
     assert a.call_counter == b.call_counter
+
+
+HEUR_FUSE_CASES = [("rock", {}, 8192 + 12, True), ("rock", {}, 4096, False), ("rock", dict(board_size=15, num_rocks=15), 4096, True),
+                   ("stochrock", {}, 4096, True), ("tag", {}, 8192, True), ("tag", dict(num_opponents=2), 4096, False),
+                   ("battleship", {}, 4096, True), ("tiger", {}, 4096, True), ("network", {}, 4096, True)]
+
+
+@pytest.mark.parametrize("env,kw,n,auto", HEUR_FUSE_CASES,
+                         ids=["%s-%d-%s" % (c[0], c[2], "auto" if c[3] else "frozen") for c in HEUR_FUSE_CASES])
+def test_heuristic_steps_in_one_launch_equal_single_step_launches(env, kw, n, auto):
+    """env.heuristic_steps(history, k) runs up to 64 steps per launch with the lane's history words, derived words and
+    running return in registers: every array it owns must end up exactly as after k one-step launches."""
+    from gym_pomdp_amd import History, Returns
+    is_rock = env in ("rock", "stochrock")
+    mk = lambda: make_env(env, dict(kw, **(dict(use_heuristic=True) if is_rock else {})), batch_size=n, seed=31, lane_offset=64,  # noqa: E731
+                          auto_reset=auto)
+    ea, eb = mk(), mk()
+    ea.reset()
+    eb.reset()
+    ha, hb, ra, rb = History(ea), History(eb), Returns(ea), Returns(eb)
+    for k in (1, 3, 64, 65, 7):
+        for _ in range(k):
+            outs_a = ea.heuristic_steps(ha, 1, returns=ra)
+        outs_b = eb.heuristic_steps(hb, k, returns=rb)
+        ctx = (env, kw, n, auto, k)
+        for x, y in zip(outs_a, outs_b):
+            assert torch.equal(x, y), ctx
+        assert torch.equal(ea.state, eb.state), ctx
+        for name in ("_size", "last_action", "last_ob", "total_sample", "total_move", "move_ok", "prev_ob"):
+            assert torch.equal(getattr(ha, name), getattr(hb, name)), ctx + (name,)
+        for name in ("ret", "disc", "ret_done"):
+            x, y = getattr(ra, name), getattr(rb, name)
+            assert bool(((x == y) | (x.isnan() & y.isnan())).all()), ctx + (name,)
+        if is_rock:
+            assert torch.equal(ea._tracker.check_ok, eb._tracker.check_ok), ctx
+            for name in ea.belief:
+                x, y = ea.belief[name], eb.belief[name]
+                assert bool(((x == y) | (x.isnan() & y.isnan() if x.is_floating_point() else False)).all()), ctx + (name,)
+    assert ea.call_counter == eb.call_counter
