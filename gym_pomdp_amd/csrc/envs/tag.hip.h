@@ -187,8 +187,10 @@ struct TagEnv {
     {
         Flight f;
         step_one_opponent_pre(sh, p, st, a, ob, rew, done, f);
-        const uint4 blk = stream_block(key, lane, POMDP_STREAM_STEP, 0u);
-        flee(sh, p, st, f, blk.x, blk.y, blk.z);
+        if (__any(f.need)) {                             // a policy that rarely tags (the heuristic one) rarely pays for the block
+            const uint4 blk = stream_block(key, lane, POMDP_STREAM_STEP, 0u);
+            flee(sh, p, st, f, blk.x, blk.y, blk.z);
+        }
     }
     // reset() from the four words of block 0 of the lane's RESET stream (tag.py:181-193: randint(29) per cell, each a
     // masked-rejection loop); false when the rejections ran past the block (probability < 1e-3) — the caller then

@@ -693,6 +693,12 @@ static __device__ __forceinline__ void heuristic_belief_update(const typename En
     BeliefOps<Env>::update(sh, p, st, a, o, b, n, i, ck);
 }
 
+template <int J>
+static __device__ __forceinline__ uint32_t quad_bcast(uint32_t v)     // v of lane J of the caller's quad
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, J * 0x55, 0xF, 0xF, false);
+}
+
 // k heuristic-policy steps in one launch: per step choice(_generate_preferred(history)) -> step -> side statistics ->
 // history.append, i.e. preferred_kernel + pick_actions_kernel + step_kernel + belief_update_kernel +
 // history_append_kernel on the same call counter, with the lists never leaving registers.  Across the k steps a lane's
@@ -726,59 +732,81 @@ __global__ __launch_bounds__(BLOCK) void heuristic_steps_kernel(const typename E
     __syncthreads();
     const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo;
     const uint32_t e = lane & 3u;
-    for (int s = 0; s < k_steps; ++s) {
-        RngKey key = key0;
-        key.t_lo = (uint32_t)(t0 + (uint64_t)s); key.t_hi = (uint32_t)((t0 + (uint64_t)s) >> 32);
-        // the policy: a = list[(w * len(list)) >> 32] over the preferred list (ascending mask order) or the legal list,
-        // w = element lane & 3 of the quad's ACTION block
-        const uint4 wq = stream_block(key, lane >> 2, POMDP_STREAM_ACTION, 0u);
-        const uint32_t word = e == 0 ? wq.x : e == 1 ? wq.y : e == 2 ? wq.z : wq.w;
-        const uint32_t m = Env::preferred_mask(sh, p, st, h, n, i, ck, mv, hsize, la, lo);
-        int a;
-        if (m) a = nth_set_bit(m, (int)__umulhi(word, (uint32_t)__popc(m)));
-        else a = Env::legal_nth(sh, p, st, (int)__umulhi(word, (uint32_t)Env::legal_count(sh, p, st)));
-        const bool live = in_range && !was_done;
-        const typename Env::State before = st;
-        int o, d;
-        typename Env::Reward r;
-        Env::step(sh, p, st, a, key, lane, o, r, d);
-        if (!live) { o = 0; r = 0; d = was_done; st = before; }
-        const bool fresh = live && d && auto_reset;
-        Env::reset_where(sh, p, st, fresh, key, lane);                         // wave-cooperative: every lane calls it
-        if (in_range) {
-            st_stream(action + i, (int32_t)(live ? a : -1));
-            st_stream(ob + i, (int32_t)o);
-            st_stream(reward + i, r);
-            st_stream(done + i, (uint8_t)d);
-        }
-        if (live) {
-            Env::store(st, state, n, i, fresh);
-            if (R.ret) {                                                       // r += rw * discount; discount *= _discount
-                const double term = disc * (double)r;
-                const double acc = ret + term;
-                if (d) R.ret_done[i] = acc;
-                ret = fresh ? 0.0 : acc;
-                disc = fresh ? 1.0 : disc * R.discount;
-            }
-            if (fresh) {                                                       // new episode: fresh Rock objects, empty History
-                for (int j = 0; j < K; ++j) {
-                    const int64_t k = (int64_t)j * n + i;
-                    b.count[k] = 0; b.measured[k] = 0; b.lkv[k] = 1.; b.lkw[k] = 1.; b.prob_valuable[k] = .5;
-                    h.total_sample[k] = 0; h.total_move[k] = 0;
-                }
-                ck = mv = K ? (1u << K) - 1u : 0u;
-                hsize = 0; la = -1; lo = -1;
-                pob = Env::reset_ob(p, st);
+    // Random words four steps at a time, as in the rollout kernel: the policy's ACTION block is shared by the four lanes
+    // of a quad (and so is RockSample's STEP block), so lane e of a quad computes the block(s) of step base + e and the
+    // words travel by DPP quad-broadcast — one block per lane per four steps instead of four.
+    for (int base = 0; base < k_steps; base += 4) {
+        const uint64_t te = t0 + (uint64_t)base + (uint64_t)e;
+        RngKey ke = key0;
+        ke.t_lo = (uint32_t)te; ke.t_hi = (uint32_t)(te >> 32);
+        const uint4 aq = stream_block(ke, lane >> 2, POMDP_STREAM_ACTION, 0u);
+        uint4 sq = make_uint4(0, 0, 0, 0);
+        if constexpr (Env::QUAD_SENSOR) sq = Env::quad_block(ke, lane, 0u);
+        auto one_step = [&](auto jc) {
+            constexpr int J = decltype(jc)::value;
+            const int s = base + J;
+            if (s >= k_steps) return;                                          // wave-uniform
+            RngKey key = key0;
+            key.t_lo = (uint32_t)(t0 + (uint64_t)s); key.t_hi = (uint32_t)((t0 + (uint64_t)s) >> 32);
+            // the policy: a = list[(w * len(list)) >> 32] over the preferred list (ascending mask order) or the legal list
+            const uint32_t ax = quad_bcast<J>(aq.x), ay = quad_bcast<J>(aq.y), az = quad_bcast<J>(aq.z), aw = quad_bcast<J>(aq.w);
+            const uint32_t word = e == 0 ? ax : e == 1 ? ay : e == 2 ? az : aw;
+            const uint32_t m = Env::preferred_mask(sh, p, st, h, n, i, ck, mv, hsize, la, lo);
+            int a;
+            if (m) a = nth_set_bit(m, (int)__umulhi(word, (uint32_t)__popc(m)));
+            else a = Env::legal_nth(sh, p, st, (int)__umulhi(word, (uint32_t)Env::legal_count(sh, p, st)));
+            const bool live = in_range && !was_done;
+            const typename Env::State before = st;
+            int o, d;
+            typename Env::Reward r;
+            if constexpr (Env::QUAD_SENSOR) {
+                const uint32_t hx = quad_bcast<J>(sq.x), hy = quad_bcast<J>(sq.y), hz = quad_bcast<J>(sq.z), hw = quad_bcast<J>(sq.w);
+                Env::step_with_H(sh, p, st, a, key, lane, e == 0 ? hx : e == 1 ? hy : e == 2 ? hz : hw, o, r, d);
             } else {
-                hsize += 1; la = a; lo = o;                                    // a terminal transition is recorded too
-                if (a >= 5 && a < 5 + K) {                                     // K > 0: RockSample CHECK
-                    history_check_sums(h, a - 5, o, pob, n, i, mv);
-                    if (o != 0 && !d) heuristic_belief_update<Env>(sh, p, st, a, o, b, n, i, ck);
-                }
-                pob = o;
+                Env::step(sh, p, st, a, key, lane, o, r, d);
             }
-            was_done = auto_reset ? false : (d != 0);
-        }
+            if (!live) { o = 0; r = 0; d = was_done; st = before; }
+            const bool fresh = live && d && auto_reset;
+            Env::reset_where(sh, p, st, fresh, key, lane);                     // wave-cooperative: every lane calls it
+            if (in_range) {
+                st_stream(action + i, (int32_t)(live ? a : -1));
+                st_stream(ob + i, (int32_t)o);
+                st_stream(reward + i, r);
+                st_stream(done + i, (uint8_t)d);
+            }
+            if (live) {
+                Env::store(st, state, n, i, fresh);
+                if (R.ret) {                                                   // r += rw * discount; discount *= _discount
+                    const double term = disc * (double)r;
+                    const double acc = ret + term;
+                    if (d) R.ret_done[i] = acc;
+                    ret = fresh ? 0.0 : acc;
+                    disc = fresh ? 1.0 : disc * R.discount;
+                }
+                if (fresh) {                                                   // new episode: fresh Rock objects, empty History
+                    for (int j = 0; j < K; ++j) {
+                        const int64_t k = (int64_t)j * n + i;
+                        b.count[k] = 0; b.measured[k] = 0; b.lkv[k] = 1.; b.lkw[k] = 1.; b.prob_valuable[k] = .5;
+                        h.total_sample[k] = 0; h.total_move[k] = 0;
+                    }
+                    ck = mv = K ? (1u << K) - 1u : 0u;
+                    hsize = 0; la = -1; lo = -1;
+                    pob = Env::reset_ob(p, st);
+                } else {
+                    hsize += 1; la = a; lo = o;                                // a terminal transition is recorded too
+                    if (a >= 5 && a < 5 + K) {                                 // K > 0: RockSample CHECK
+                        history_check_sums(h, a - 5, o, pob, n, i, mv);
+                        if (o != 0 && !d) heuristic_belief_update<Env>(sh, p, st, a, o, b, n, i, ck);
+                    }
+                    pob = o;
+                }
+                was_done = auto_reset ? false : (d != 0);
+            }
+        };
+        one_step(std::integral_constant<int, 0>{});
+        one_step(std::integral_constant<int, 1>{});
+        one_step(std::integral_constant<int, 2>{});
+        one_step(std::integral_constant<int, 3>{});
     }
     if (!in_range) return;
     st_stream(h.size + i, (int32_t)hsize); st_stream(h.last_action + i, (int32_t)la); st_stream(h.last_ob + i, (int32_t)lo);
@@ -795,12 +823,6 @@ __global__ __launch_bounds__(BLOCK) void heuristic_steps_kernel(const typename E
 //     quad-broadcast: one block per lane per four steps instead of four.
 // The discounted return accumulates in IEEE double with separate multiply and add (so a CPU restatement reproduces
 // it bit-for-bit).
-template <int J>
-static __device__ __forceinline__ uint32_t quad_bcast(uint32_t v)     // v of lane J of the caller's quad
-{
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, J * 0x55, 0xF, 0xF, false);
-}
-
 template <class Env>
 __global__ __launch_bounds__(BLOCK) void rollout_kernel(const typename Env::Params p, const uint32_t *__restrict__ state,
                                                         int64_t n_roots, int64_t sims_per_root, int depth,
