@@ -34,6 +34,10 @@ struct RockEnv {
         uint32_t thr_lo[32];   // thr & (2^26 - 1)                            (compared with L >> 6 on a tie)
         int8_t grid[256];      // rock id stamped at [x * 16 + y], -1 = none
         uint8_t rxy[16];       // rock j position, x | y << 4
+        // heuristic-policy launches only (stage_policy): rock sets by position, bit j = rock j
+        uint32_t dir_y[16];    // [y]: rocks with ry > y | rocks with ry < y << 16
+        uint32_t dir_x[16];    // [x]: rocks with rx < x | rocks with rx > x << 16
+        uint32_t row[16];      // [y]: rocks with ry == y
     };
     struct State { S s; };
     // what the lane step leaves for the deferred sensor draw (pooled launches fetch H from the wave's task pass)
@@ -65,6 +69,23 @@ struct RockEnv {
     }
     static __device__ __forceinline__ void stage(Shared &sh, const Params &p, int tid) { stage_store(sh, stage_load(p, tid), tid); }
     static __device__ __forceinline__ int n_actions(const Params &p) { return 5 + p.num_rocks; }
+    // the position tables preferred_mask reads; kernels that call it run this next to stage()
+    static __device__ __forceinline__ void stage_policy(Shared &sh, const Params &p, int tid)
+    {
+        if (tid >= 16) return;
+        uint32_t above = 0, below = 0, left = 0, right = 0, same = 0;
+        for (int j = 0; j < p.num_rocks; ++j) {
+            const int rx = p.rock_x[j], ry = p.rock_y[j];
+            above |= (uint32_t)(ry > tid) << j;
+            below |= (uint32_t)(ry < tid) << j;
+            same |= (uint32_t)(ry == tid) << j;
+            left |= (uint32_t)(rx < tid) << j;
+            right |= (uint32_t)(rx > tid) << j;
+        }
+        sh.dir_y[tid] = above | (below << 16);
+        sh.dir_x[tid] = left | (right << 16);
+        sh.row[tid] = same;
+    }
 
     static constexpr bool NT = !(ABLATE & 16);
     static __device__ __forceinline__ void load(State &st, const uint32_t *state, int64_t n, uint32_t i)
@@ -310,21 +331,19 @@ struct RockEnv {
         const int id = sh.grid[x * 16 + y];
         if (id >= 0 && id < K && ((uint32_t)(s >> (8 + 2 * (id & 15))) & 3u) != 1u && hsize != 0)
             if (h.total_sample[(int64_t)id * n + i] > 0) return 1u << 4;                          // rock.py:300-313
-        uint32_t alive = 0;                                                                       // uncollected rocks
-        for (int j = 0; j < K; ++j) alive |= (uint32_t)(((uint32_t)(s >> (8 + 2 * j)) & 3u) != 1u) << j;
-        uint32_t am = alive & mv;                                                                 // rock.py:335: total >= 0
+        // uncollected rocks (code != 1), bit j = rock j: spread form as in legal_count, then the even bits squeezed together
+        const uint64_t r = (uint64_t)s >> 8;
+        uint32_t alive = (uint32_t)(~(r & ~(r >> 1)) & 0x5555555555555555ull & ((1ull << (2 * K)) - 1ull));
+        alive = (alive | (alive >> 1)) & 0x33333333u;
+        alive = (alive | (alive >> 2)) & 0x0F0F0F0Fu;
+        alive = (alive | (alive >> 4)) & 0x00FF00FFu;
+        alive = (alive | (alive >> 8)) & 0x0000FFFFu;
+        const uint32_t am = alive & mv;                                                           // rock.py:335: total >= 0
         if (!am) return 1u << 1;                                                                  // all_bad: rock.py:347-349
-        bool north = false, south = false, west = false, east = false;
-        while (am) {                                                                              // rock.py:338-345
-            const int j = __ffs((int)am) - 1;
-            am &= am - 1u;
-            const uint32_t rxy = sh.rxy[j];
-            const int rx = (int)(rxy & 15u), ry = (int)(rxy >> 4);
-            if (ry > y) north = true;
-            else if (ry < y) south = true;
-            else if (rx < x) west = true;
-            else if (rx > x) east = true;
-        }
+        // rock.py:338-345, per rock: north if above, else south if below, else (same row) west if left, else east if right
+        const uint32_t dy = sh.dir_y[y], dx = sh.dir_x[x], same = am & sh.row[y];
+        const bool north = (am & dy & 0xFFFFu) != 0, south = (am & (dy >> 16)) != 0;
+        const bool west = (same & dx & 0xFFFFu) != 0, east = (same & (dx >> 16)) != 0;
         uint32_t m = (alive & ck) << 5;                                                           // rock.py:370-372
         if (y + 1 < p.size && north) m |= 1u << 0;                                                // rock.py:358-368
         if (east) m |= 1u << 1;

@@ -629,6 +629,15 @@ __global__ __launch_bounds__(BLOCK) void history_append_kernel(pomdp_history h, 
     }
 }
 
+// envs whose _generate_preferred reads extra LDS tables fill them with Env::stage_policy
+template <class Env, class = void> struct HasPolicyTables : std::false_type {};
+template <class Env> struct HasPolicyTables<Env, std::void_t<decltype(&Env::stage_policy)>> : std::true_type {};
+template <class Env>
+static __device__ __forceinline__ void stage_policy_tables(typename Env::Shared &sh, const typename Env::Params &p)
+{
+    if constexpr (HasPolicyTables<Env>::value) Env::stage_policy(sh, p, (int)threadIdx.x);
+}
+
 template <class Env>
 __global__ __launch_bounds__(BLOCK) void preferred_kernel(const typename Env::Params p, const uint32_t *__restrict__ state,
                                                           pomdp_rock_belief b, pomdp_history h, int32_t *__restrict__ list,
@@ -636,6 +645,7 @@ __global__ __launch_bounds__(BLOCK) void preferred_kernel(const typename Env::Pa
 {
     __shared__ typename Env::Shared sh;
     Env::stage(sh, p, (int)threadIdx.x);
+    stage_policy_tables<Env>(sh, p);
     __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
@@ -729,6 +739,7 @@ __global__ __launch_bounds__(BLOCK) void heuristic_steps_kernel(const typename E
     bool was_done = auto_reset ? false : (ld_stream(done + i) != 0);
     double ret = R.ret ? R.ret[i] : 0.0, disc = R.ret ? R.disc[i] : 1.0;
     Env::stage(sh, p, (int)threadIdx.x);
+    stage_policy_tables<Env>(sh, p);
     __syncthreads();
     const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo;
     const uint32_t e = lane & 3u;
