@@ -34,8 +34,8 @@ for e in rock15 rock; do
 done
 for e in rock rock15 tag; do
   rm -rf $W/e; mkdir -p $W/e
-  rocprofv3 --kernel-trace --stats -d $W/e/trace -o e -- python $REPO/bench.py --env $e --mode heuristic --steps 500 --warmup 100 > $W/e/bench_traced.log 2>&1
-  (echo "##### bench.py --env $e --mode heuristic --steps 500 --warmup 100"; python $REPO/tools/rocpd_summary.py $W/e | awk '{ if (substr($0,1,1)=="{") print; else print substr($0,1,260) }') >> $OUT/envs.txt
+  rocprofv3 --kernel-trace --stats -d $W/e/trace -o e -- python $REPO/bench.py --env $e --mode heuristic --steps 1024 --warmup 128 > $W/e/bench_traced.log 2>&1
+  (echo "##### bench.py --env $e --mode heuristic --steps 1024 --warmup 128"; python $REPO/tools/rocpd_summary.py $W/e | awk '{ if (substr($0,1,1)=="{") print; else print substr($0,1,260) }') >> $OUT/envs.txt
 done
 # 4. the default bench line, unprofiled
 cd $REPO
