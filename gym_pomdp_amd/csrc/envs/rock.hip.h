@@ -30,10 +30,11 @@ struct RockEnv {
     static constexpr bool POOLED_ANY_LPT = !STOCH; // ... and for any other number of lanes per thread >= 2
     static constexpr int ABL = ABLATE;            // experiment switches (tools/microbench.hip); 0 in the product
     struct Shared {
-        uint32_t thr_hi[32];   // sensor threshold by L1 distance, thr >> 26  (compared with H >> 5)
-        uint32_t thr_lo[32];   // thr & (2^26 - 1)                            (compared with L >> 6 on a tie)
+        uint2 thr[32];         // sensor threshold by L1 distance: .x = thr >> 26 (compared with H >> 5),
+                               // .y = thr & (2^26 - 1) (compared with L >> 6 on a tie) — one 8-byte LDS read
         int8_t grid[256];      // rock id stamped at [x * 16 + y], -1 = none
         uint8_t rxy[16];       // rock j position, x | y << 4
+        uint16_t rpos[16];     // the same as x | y << 8: one v_sad_u8 against the agent's bytes is the L1 distance
         // heuristic-policy launches only (stage_policy): rock sets by position, bit j = rock j
         uint32_t dir_y[16];    // [y]: rocks with ry > y | rocks with ry < y << 16
         uint32_t dir_x[16];    // [x]: rocks with rx < x | rocks with rx > x << 16
@@ -63,9 +64,9 @@ struct RockEnv {
     static __device__ __forceinline__ void stage_store(Shared &sh, const Staged &r, int tid)
     {
         sh.grid[tid & 255] = r.g;
-        sh.thr_hi[tid & 31] = (uint32_t)(r.t >> 26);
-        sh.thr_lo[tid & 31] = (uint32_t)r.t & LO_MASK;
+        sh.thr[tid & 31] = make_uint2((uint32_t)(r.t >> 26), (uint32_t)r.t & LO_MASK);
         sh.rxy[tid & 15] = (uint8_t)((r.rx & 15) | (r.ry << 4));
+        sh.rpos[tid & 15] = (uint16_t)((r.rx & 15) | ((r.ry & 15) << 8));
     }
     static __device__ __forceinline__ void stage(Shared &sh, const Params &p, int tid) { stage_store(sh, stage_load(p, tid), tid); }
     static __device__ __forceinline__ int n_actions(const Params &p) { return 5 + p.num_rocks; }
@@ -390,34 +391,38 @@ struct RockEnv {
                                                     int &done, Aux &aux)
     {
         const S s = st.s;
-        const int x = (int)(s & 15u), y = (int)((s >> 4) & 15u);
-        const int size = p.size, K = p.num_rocks;
-        // CHECK rock a-5 (rock.py:171-175, 401-407, 383-387; coord.py:133-135: L1 distance)
+        const uint32_t x = (uint32_t)s & 15u, y = ((uint32_t)s >> 4) & 15u;
+        const uint32_t size = (uint32_t)p.size, K = (uint32_t)p.num_rocks;
+        // CHECK rock a-5 (rock.py:171-175, 401-407, 383-387; coord.py:133-135: L1 distance = sum of absolute byte differences)
         const int r = (a - 5) & 15;
-        const uint32_t rxy = (ABLATE & 4) ? (uint32_t)(r * 17) : sh.rxy[r];
-        const int d = abs(x - (int)(rxy & 15u)) + abs(y - (int)(rxy >> 4));
-        aux.th = (ABLATE & 4) ? (uint32_t)d << 22 : sh.thr_hi[d];
-        aux.tl = (ABLATE & 4) ? 0u : sh.thr_lo[d];
+        const uint32_t rp = (ABLATE & 4) ? (uint32_t)(r * 257) : sh.rpos[r];
+        const uint32_t d = __builtin_amdgcn_sad_u8(x | (y << 8), rp, 0u);
+        const uint2 thr = (ABLATE & 4) ? make_uint2(d << 22, 0u) : sh.thr[d];
+        aux.th = thr.x;
+        aux.tl = thr.y;
         aux.good = ((uint32_t)(s >> (8 + 2 * r)) & 3u) == 2u;
         aux.want = a > 4;
         const int penalty = STOCH ? 0 : -100;                                  // rock.py:117 / rock.py:432
-        // SAMPLE (rock.py:160-169); ids >= K raise IndexError in the reference, "no rock" here
-        const int id = (ABLATE & 4) ? ((x ^ y) & 7) - (x & 1) : sh.grid[x * 16 + y];
+        // SAMPLE (rock.py:160-169); ids >= K raise IndexError in the reference, "no rock" here (-1 wraps above K)
+        const int id = (ABLATE & 4) ? (int)((x ^ y) & 7) - (int)(x & 1) : sh.grid[x * 16 + y];
         const int sh_ = 8 + 2 * (id & 15);
         const uint32_t code = (uint32_t)(s >> sh_) & 3u;
-        const bool sample_ok = (id >= 0) & (id < K) & (code != 1u);
+        const bool sample_ok = ((uint32_t)id < K) & (code != 1u);
         const int rew_sample = sample_ok ? (code == 2u ? 10 : -10) : penalty;
         const S s_sample = sample_ok ? (S)((s & ~((S)3 << sh_)) | ((S)1 << sh_)) : s;
-        // move: 0 N (0,+1)  1 E (+1,0)  2 S (0,-1)  3 W (-1,0)   (coord.py:155-160, rock.py:134-158)
-        const int nx = x + (a == 1) - (a == 3), ny = y + (a == 0) - (a == 2);
-        const bool inside = ((unsigned)nx < (unsigned)size) & ((unsigned)ny < (unsigned)size);
-        const S s_move = inside ? (S)((s & ~(S)0xFF) | (S)(uint32_t)(nx | (ny << 4))) : s;
+        // move: 0 N (0,+1)  1 E (+1,0)  2 S (0,-1)  3 W (-1,0)   (coord.py:155-160, rock.py:134-158): the steps are
+        // 2-bit signed fields of two constants, zero for every other action (a < 16; is_move masks the rest)
+        const uint32_t a2 = (uint32_t)a << 1;
+        const uint32_t nx = x + (uint32_t)__builtin_amdgcn_sbfe(0xC4, a2, 2u), ny = y + (uint32_t)__builtin_amdgcn_sbfe(0x31, a2, 2u);
+        const bool inside = max(nx, ny) < size;                                // -1 wraps
+        const S s_move = inside ? (S)((s & ~(S)0xFF) | (S)(nx | (ny << 4))) : s;
         const int rew_move = inside ? 0 : (a == 1 ? 10 : penalty);             // east exit / off-grid
         const bool is_move = a < 4, is_sample = a == 4;
         st.s = is_move ? s_move : (is_sample ? s_sample : s);
         rew = is_move ? rew_move : (is_sample ? rew_sample : 0);
-        if (STOCH) done = is_move && !inside && a == 1;                        // penalties never terminate (rock.py:503)
-        else done = is_move ? !inside : (rew == -100);                         // rock.py:139-141, 193
+        // done (rock.py:139-141, 193): a move that left the grid, or the -100 penalty — as lane-mask logic, not selects
+        if (STOCH) done = is_move & !inside & (a == 1);                        // penalties never terminate (rock.py:503)
+        else done = (is_move & !inside) | (!is_move & is_sample & !sample_ok);
     }
     // observation of a CHECK from the sensor's high word (rock.py:404-407); `lo` yields the low word on a tie
     template <class LowWord>
