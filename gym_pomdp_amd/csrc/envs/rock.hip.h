@@ -408,21 +408,28 @@ struct RockEnv {
         const int sh_ = 8 + 2 * (id & 15);
         const uint32_t code = (uint32_t)(s >> sh_) & 3u;
         const bool sample_ok = ((uint32_t)id < K) & (code != 1u);
-        const int rew_sample = sample_ok ? (code == 2u ? 10 : -10) : penalty;
-        const S s_sample = sample_ok ? (S)((s & ~((S)3 << sh_)) | ((S)1 << sh_)) : s;
         // move: 0 N (0,+1)  1 E (+1,0)  2 S (0,-1)  3 W (-1,0)   (coord.py:155-160, rock.py:134-158): the steps are
         // 2-bit signed fields of two constants, zero for every other action (a < 16; is_move masks the rest)
         const uint32_t a2 = (uint32_t)a << 1;
         const uint32_t nx = x + (uint32_t)__builtin_amdgcn_sbfe(0xC4, a2, 2u), ny = y + (uint32_t)__builtin_amdgcn_sbfe(0x31, a2, 2u);
         const bool inside = max(nx, ny) < size;                                // -1 wraps
-        const S s_move = inside ? (S)((s & ~(S)0xFF) | (S)(nx | (ny << 4))) : s;
-        const int rew_move = inside ? 0 : (a == 1 ? 10 : penalty);             // east exit / off-grid
-        const bool is_move = a < 4, is_sample = a == 4;
-        st.s = is_move ? s_move : (is_sample ? s_sample : s);
-        rew = is_move ? rew_move : (is_sample ? rew_sample : 0);
-        // done (rock.py:139-141, 193): a move that left the grid, or the -100 penalty — as lane-mask logic, not selects
-        if (STOCH) done = is_move & !inside & (a == 1);                        // penalties never terminate (rock.py:503)
-        else done = (is_move & !inside) | (!is_move & is_sample & !sample_ok);
+        const bool is_move = a < 4, is_sample = a == 4, east = a == 1;
+        // The three action classes meet in lane-mask logic (scalar unit) and a handful of selects:
+        // state ^= the bits that change — the position byte of a move that stays inside, or a sampled rock's code -> 1
+        const bool moved = is_move & inside, left = is_move & !inside, sampled = is_sample & sample_ok,
+                   missed = is_sample & !sample_ok;
+        const uint32_t d_move = ((uint32_t)s & 0xFFu) ^ (nx | (ny << 4));
+        const S d_sample = (S)(code ^ 1u) << sh_;                              // code 0 or 2 -> 1 (collected)
+        st.s = s ^ (moved ? (S)d_move : (sampled ? d_sample : (S)0));
+        // reward: +10 east exit / good rock, -10 bad rock, penalty for leaving elsewhere or sampling nothing, else 0
+        const bool good_rock = code == 2u;
+        int rw = ((left & east) | (sampled & good_rock)) ? 10 : 0;
+        rw = (sampled & !good_rock) ? -10 : rw;
+        rw = ((left & !east) | missed) ? penalty : rw;
+        rew = rw;
+        // done (rock.py:139-141, 193): a move that left the grid, or the -100 penalty
+        if (STOCH) done = left & east;                                         // penalties never terminate (rock.py:503)
+        else done = left | missed;
     }
     // observation of a CHECK from the sensor's high word (rock.py:404-407); `lo` yields the low word on a tie
     template <class LowWord>
