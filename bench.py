@@ -6,10 +6,11 @@
 Workload (BASELINE.json metric): RockSample(7,8), 2^20 lanes per GPU, i.i.d. uniform random
 actions from the synthetic policy (its kernel is inside the timed region), auto-reset on done.
 A "step" is one pass of the hot path over the whole batch.  The steps are issued by the library's C-side
-rollout driver (pomdp_rollout_synthetic), which by default runs up to 64 consecutive steps inside one
-launch (every step's outputs are still computed and written; a lane's state stays in registers between
-its steps); `--fuse 0` launches every step separately, `--host-loop python` times the same steps through
-env.step() instead.
+drivers, by default as trajectory collection (pomdp_collect_synthetic): up to 64 consecutive steps inside one
+launch, every step's action / ob / reward / done written to its own [step][lane] row, a lane's state in
+registers between its steps.  `--collect 0` runs the same fused launches with every step overwriting the same
+N-element outputs (pomdp_rollout_synthetic; what per-step launches leave), `--fuse 0` launches every step
+separately, `--host-loop python` times the same steps through env.step() instead.
 N > 1: one process per GPU (torch.distributed.run), lanes sharded by global lane id, no data-path
 collective — only the timing barrier / max-over-ranks (gloo, host side).  Scaling is weak: every
 GPU owns 2^20 lanes.
@@ -78,6 +79,10 @@ def parse():
     ap.add_argument("--fuse", type=int, default=1, choices=[0, 1],
                     help="1: the C driver may run up to 64 consecutive steps inside one launch (steps_kernel: every step's "
                          "outputs still computed and written, state in registers between steps); 0: one launch per step")
+    ap.add_argument("--collect", type=int, default=1, choices=[0, 1],
+                    help="step mode, fused launches: 1 = keep every step's action / ob / reward / done in [128][N] "
+                         "trajectory buffers (env.collect_synthetic); 0 = every step overwrites the same N-element "
+                         "outputs, as per-step launches do (env.rollout_synthetic).  Same bytes written either way")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline sample")
     return ap.parse_args()
@@ -272,8 +277,17 @@ def main():
     # by default policy and env share the Philox key (their streams differ by stream id)
     action_seed = args.seed if args.action_seed is None else args.action_seed
 
+    traj = {}
+    collect = bool(args.collect) and bool(args.fuse) and args.host_loop == "c" and action_seed == args.seed
+
     def run_steps(k):
-        if args.host_loop == "python":
+        if collect:
+            left = k
+            while left > 0:
+                c = min(left, 128)
+                traj[c] = env.collect_synthetic(c, out=traj.get(c))
+                left -= c
+        elif args.host_loop == "python":
             for _ in range(k):
                 env.synthetic_actions(out=actions, seed=action_seed)
                 env.step(actions)
@@ -367,13 +381,14 @@ def main():
             "config": {"workload": "%s batch=%d lanes per GPU (%d total), uniform random actions "
                                    "(synthetic-policy kernel timed), auto-reset" % (label, n, total_lanes),
                        "lanes_per_gpu": n, "total_lanes": total_lanes, "host_loop": args.host_loop, "visible_gpus": n_dev,
-                       "steps_per_launch": 64 if fused else 1,
+                       "steps_per_launch": 64 if fused else 1, "trajectories_kept": collect,
                        "untimed_prewarm_s": args.prewarm, "parallelism": "lane-shard x%d, no collectives" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch",
                          "traffic_source": traffic_src,
                          "kernel": (("steps_kernel<%s> (64 chained steps per launch: step + next-step policy, every step's "
-                                     "outputs written, state in registers between steps; the launch of the timed region)")
+                                     "outputs written" + (" to its own trajectory row" if collect else " over the previous step's") +
+                                     ", state in registers between steps; the launch of the timed region)")
                                     if fused else
                                     "step_kernel<%s, chain> (step + next-step policy, the launch of the timed region)"
                                     if chained else "step_kernel<%s>") % args.env,

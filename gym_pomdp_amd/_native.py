@@ -15,7 +15,7 @@ SOURCES = [os.path.join(_PKG, "csrc", f) for f in ("pomdp_kernels.hip", "envs.hi
                                                    "envs/rock.hip.h", "envs/tag.hip.h", "envs/battleship.hip.h",
                                                    "envs/tiger.hip.h", "envs/network.hip.h")]
 HEADER = os.path.join(_REPO, "include", "pomdp_hip.h")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 POMDP_AUTO_RESET = 1
 POMDP_FUSE_STEPS = 2
@@ -28,7 +28,7 @@ SYMBOLS = [
     "pomdp_rock_reset", "pomdp_rock_step", "pomdp_tag_reset", "pomdp_tag_step",
     "pomdp_battleship_reset", "pomdp_battleship_step", "pomdp_tiger_reset", "pomdp_tiger_step",
     "pomdp_network_reset", "pomdp_network_step", "pomdp_synthetic_actions", "pomdp_philox_blocks",
-    "pomdp_rollout_synthetic", "pomdp_legal_actions", "pomdp_rollout", "pomdp_compute_prob",
+    "pomdp_rollout_synthetic", "pomdp_collect_synthetic", "pomdp_legal_actions", "pomdp_rollout", "pomdp_compute_prob",
     "pomdp_rock_belief_reset", "pomdp_rock_belief_refresh", "pomdp_rock_belief_update", "pomdp_rock_select_target", "pomdp_history_clear",
     "pomdp_history_append", "pomdp_preferred_actions", "pomdp_pick_actions", "pomdp_heuristic_steps",
 ]
@@ -123,6 +123,8 @@ def lib():
     L.pomdp_synthetic_actions.argtypes = [vp, i64, u64, u32, u64, u32, vp]
     L.pomdp_rollout_synthetic.restype = ci
     L.pomdp_rollout_synthetic.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, i64, u64, u64, u32, u64, i64, ci, vp]
+    L.pomdp_collect_synthetic.restype = ci
+    L.pomdp_collect_synthetic.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, i64, u64, u32, u64, i64, i64, ci, vp]
     L.pomdp_legal_actions.restype = ci
     L.pomdp_legal_actions.argtypes = [ci, vp, vp, vp, vp, i64, ci, vp]
     L.pomdp_compute_prob.restype = ci

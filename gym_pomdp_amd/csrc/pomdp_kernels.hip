@@ -394,17 +394,19 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
                                                       int32_t *__restrict__ ob, typename Env::Reward *__restrict__ reward,
                                                       uint8_t *__restrict__ done, uint32_t *__restrict__ err, int64_t n,
                                                       RngKey key0, uint32_t lane0, int flags, RngKey akey0, int k_steps,
-                                                      const typename Env::Params p)
+                                                      int64_t rec, const typename Env::Params p)
 {
     __shared__ typename Env::Shared sh;
     const bool auto_reset = SIMPLE || (flags & POMDP_AUTO_RESET);
     const uint32_t wg0 = blockIdx.x * (uint32_t)(BLOCK * LPT);
     const uint32_t last = SIMPLE ? (uint32_t)(BLOCK * LPT - 1) : (uint32_t)((uint64_t)(n - 1) - wg0);
-    int32_t *const action_w = action + wg0;
+    // rec = 0: every step overwrites the same n-element outputs (what the per-step launches do); rec = row pitch in
+    // elements: step s writes row s of ob / reward / done and row s + 1 of action (row s being the actions it took)
+    int32_t *action_w = action + wg0;
     uint32_t *const state_w = state + wg0;
-    int32_t *const ob_w = ob + wg0;
-    typename Env::Reward *const reward_w = reward + wg0;
-    uint8_t *const done_w = done + wg0;
+    int32_t *ob_w = ob + wg0;
+    typename Env::Reward *reward_w = reward + wg0;
+    uint8_t *done_w = done + wg0;
     uint32_t rel[LPT], glane[LPT];
     bool in_range[LPT], was_done[LPT];
     int a_cur[LPT];
@@ -420,6 +422,7 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
         Env::load(st[j], state_w, n, rc);
         was_done[j] = auto_reset ? false : (ld_stream(done_w + rc) != 0);
     }
+    action_w += rec;
     using Fin = Finisher<Env, LPT, true>;
     const int n_act = Env::n_actions(p);
     const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo, ta0 = ((uint64_t)akey0.t_hi << 32) | akey0.t_lo;
@@ -470,6 +473,7 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
             a_cur[j] = a_next[j];
             was_done[j] = auto_reset ? false : (d[j] != 0);
         }
+        action_w += rec; ob_w += rec; reward_w += rec; done_w += rec;
         if constexpr (Fin::LOOP_BARRIER) __syncthreads();
     }
 }
@@ -1002,7 +1006,7 @@ static int launch_step_chain(const typename Env::Params &p, uint32_t *state, int
 template <class Env>
 static int launch_steps_fused(const typename Env::Params &p, uint32_t *state, int32_t *action, int32_t *ob,
                               typename Env::Reward *reward, uint8_t *done, uint32_t *err, int64_t n, uint64_t seed,
-                              uint64_t action_seed, uint32_t lane0, uint64_t t, int k, int flags, void *stream)
+                              uint64_t action_seed, uint32_t lane0, uint64_t t, int k, int flags, int64_t rec, void *stream)
 {
     if (!state || !action || !ob || !reward || !done || bad_range(n, lane0) || (lane0 & 3u) || k < 1) return POMDP_E_BADARG;
     if (n == 0) return 0;
@@ -1011,7 +1015,7 @@ static int launch_steps_fused(const typename Env::Params &p, uint32_t *state, in
     const dim3 grid(lpt2 ? (unsigned)((n + 2 * BLOCK - 1) / (2 * BLOCK)) : blocks_for(n));
 #define POMDP_LAUNCH_STEPS(LPT_, SIMPLE_)                                                                              \
     hipLaunchKernelGGL((steps_kernel<Env, LPT_, SIMPLE_>), grid, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob,  \
-                       reward, done, err, n, make_key(seed, t), lane0, flags, make_key(action_seed, t + 1), k, p)
+                       reward, done, err, n, make_key(seed, t), lane0, flags, make_key(action_seed, t + 1), k, rec, p)
     // RockSample's pooled passes exist for any number of lanes per thread; in the fused loop (no load latency to hide)
     // four per thread, with fuller passes, beat two by 5 % from 2^20 lanes up (3.97 vs 4.16 us per step) when the state
     // is one word; with two state words (K > 12) the extra registers cost more (5.04 vs 4.74 us)
@@ -1019,7 +1023,7 @@ static int launch_steps_fused(const typename Env::Params &p, uint32_t *state, in
         n >= (1 << 20)) {
         const dim3 grid4((unsigned)(n / (4 * BLOCK)));
         hipLaunchKernelGGL((steps_kernel<Env, 4, true>), grid4, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob, reward,
-                           done, err, n, make_key(seed, t), lane0, flags, make_key(action_seed, t + 1), k, p);
+                           done, err, n, make_key(seed, t), lane0, flags, make_key(action_seed, t + 1), k, rec, p);
     } else if (lpt2) { if (simple) POMDP_LAUNCH_STEPS(2, true); else POMDP_LAUNCH_STEPS(2, false); }
     else { if (simple) POMDP_LAUNCH_STEPS(1, true); else POMDP_LAUNCH_STEPS(1, false); }
 #undef POMDP_LAUNCH_STEPS
@@ -1301,25 +1305,30 @@ int pomdp_synthetic_actions(int32_t *action, int64_t n, uint64_t seed, uint32_t 
     return (int)hipGetLastError();
 }
 
+// the env's action count from its params; 0 = unknown env
+static uint32_t env_action_count(int env, const void *params)
+{
+    switch (env) {
+    case POMDP_ENV_ROCK: return 5u + (uint32_t)((const pomdp_rock_params *)params)->num_rocks;
+    case POMDP_ENV_TAG: return 5u;
+    case POMDP_ENV_BATTLESHIP: {
+        const pomdp_battleship_params *p = (const pomdp_battleship_params *)params;
+        return (uint32_t)(p->x_size * p->y_size);
+    }
+    case POMDP_ENV_TIGER: return 3u;
+    case POMDP_ENV_NETWORK: return 2u * (uint32_t)((const pomdp_network_params *)params)->n_machines + 1u;
+    default: return 0u;
+    }
+}
+
 int pomdp_rollout_synthetic(int env, const void *params, uint32_t *state, int32_t *action, int32_t *ob, void *reward,
                             uint8_t *done, uint32_t *err, int64_t n, uint64_t seed, uint64_t action_seed,
                             uint32_t lane0, uint64_t t0, int64_t k_steps, int flags, void *stream)
 {
     if (!params || k_steps < 0 || !action) return POMDP_E_BADARG;
     if (k_steps == 0) return 0;
-    uint32_t n_actions;
-    switch (env) {
-    case POMDP_ENV_ROCK: n_actions = 5u + (uint32_t)((const pomdp_rock_params *)params)->num_rocks; break;
-    case POMDP_ENV_TAG: n_actions = 5u; break;
-    case POMDP_ENV_BATTLESHIP: {
-        const pomdp_battleship_params *p = (const pomdp_battleship_params *)params;
-        n_actions = (uint32_t)(p->x_size * p->y_size);
-        break;
-    }
-    case POMDP_ENV_TIGER: n_actions = 3u; break;
-    case POMDP_ENV_NETWORK: n_actions = 2u * (uint32_t)((const pomdp_network_params *)params)->n_machines + 1u; break;
-    default: return POMDP_E_BADARG;
-    }
+    const uint32_t n_actions = env_action_count(env, params);
+    if (!n_actions) return POMDP_E_BADARG;
     // actions of the first step from the stand-alone policy kernel
     int rc = pomdp_synthetic_actions(action, n, action_seed, lane0, t0, n_actions, stream);
     if (rc) return rc;
@@ -1334,7 +1343,7 @@ int pomdp_rollout_synthetic(int env, const void *params, uint32_t *state, int32_
                 rc = dispatch_env(env, params, [&](auto tag, const auto &p) {
                     using E = typename decltype(tag)::Env;
                     return launch_steps_fused<E>(p, state, action, ob, (typename E::Reward *)reward, done, err, n, seed,
-                                                 action_seed, lane0, t, c, flags, stream);
+                                                 action_seed, lane0, t, c, flags, 0, stream);
                 });
                 if (rc) return rc;
             }
@@ -1362,6 +1371,30 @@ int pomdp_rollout_synthetic(int env, const void *params, uint32_t *state, int32_
         if (rc) return rc;
     }
     return pomdp_synthetic_actions(action, n, action_seed, lane0, t0 + (uint64_t)k_steps, n_actions, stream);
+}
+
+int pomdp_collect_synthetic(int env, const void *params, uint32_t *state, int32_t *action, int32_t *ob, void *reward,
+                            uint8_t *done, uint32_t *err, int64_t n, uint64_t seed, uint32_t lane0, uint64_t t0,
+                            int64_t k_steps, int64_t pitch, int flags, void *stream)
+{
+    if (!params || k_steps < 0 || pitch < n || !(flags & POMDP_AUTO_RESET)) return POMDP_E_BADARG;
+    if (k_steps == 0 || n == 0) return 0;
+    const uint32_t n_actions = env_action_count(env, params);
+    if (!n_actions) return POMDP_E_BADARG;
+    int rc = pomdp_synthetic_actions(action, n, seed, lane0, t0, n_actions, stream);    // row 0: the actions of t0
+    if (rc) return rc;
+    constexpr int64_t FUSE_MAX = 64;
+    for (int64_t s = 0; s < k_steps; s += FUSE_MAX) {
+        const int c = (int)(k_steps - s < FUSE_MAX ? k_steps - s : FUSE_MAX);
+        rc = dispatch_env(env, params, [&](auto tag, const auto &p) {
+            using E = typename decltype(tag)::Env;
+            using R = typename E::Reward;
+            return launch_steps_fused<E>(p, state, action + s * pitch, ob + s * pitch, (R *)reward + s * pitch,
+                                         done + s * pitch, err, n, seed, seed, lane0, t0 + (uint64_t)s, c, flags, pitch, stream);
+        });
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 int pomdp_legal_actions(int env, const void *params, const uint32_t *state, int32_t *list, int32_t *len, int64_t n,

@@ -466,5 +466,34 @@ class BatchedEnv(object):
             _native.check(rc, "pomdp_rollout_synthetic")
         return self._ob, self._reward, self._done.view(torch.bool)
 
+    def collect_synthetic(self, steps, out=None):
+        """`steps` consecutive step() calls under the synthetic uniform policy with every step's results KEPT
+        (pomdp_collect_synthetic): returns {"action": int32 [steps + 1, N] (row s = the actions of step s, last row = the
+        next call's), "ob": int32 [steps, N], "reward": [steps, N], "done": bool [steps, N]} — row s equals what
+        synthetic_actions() + step() return at that call.  The batched form of the reference callers' episode
+        loops (rock.py:553-575); up to 64 steps per launch, auto_reset envs only.  `out`: a dict from an earlier call
+        to write into.  Asynchronous."""
+        if not self._has_reset:
+            raise AttributeError("%s: collect before reset()" % type(self).__name__)
+        if not self.auto_reset:
+            raise ValueError("collect_synthetic needs auto_reset=True")
+        steps, n = int(steps), self.batch_size
+        if out is None:
+            out = {"action": torch.empty((steps + 1, n), dtype=torch.int32, device=self.device),
+                   "ob": torch.empty((steps, n), dtype=torch.int32, device=self.device),
+                   "reward": torch.empty((steps, n), dtype=self._reward.dtype, device=self.device),
+                   "done_u8": torch.empty((steps, n), dtype=torch.uint8, device=self.device)}
+            out["done"] = out["done_u8"].view(torch.bool)
+        assert out["action"].shape == (steps + 1, n) and out["ob"].shape == (steps, n)
+        t0 = self._t
+        self._t += steps
+        with torch.cuda.device(self.device):
+            rc = self._lib.pomdp_collect_synthetic(
+                _native.ENV_KIND[self.env_name], self._params_ref, self._state.data_ptr(), out["action"].data_ptr(),
+                out["ob"].data_ptr(), out["reward"].data_ptr(), out["done_u8"].data_ptr(), self._err.data_ptr(),
+                n, self._seed, self.lane_offset, t0, steps, n, _native.POMDP_AUTO_RESET, self._stream())
+            _native.check(rc, "pomdp_collect_synthetic")
+        return out
+
     def __repr__(self):
         return "%s(batch_size=%d, device=%s)" % (type(self).__name__, self.batch_size, getattr(self, "device", "?"))

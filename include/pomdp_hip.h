@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define POMDP_ABI_VERSION 6
+#define POMDP_ABI_VERSION 7
 
 enum {
     POMDP_E_BADARG = -1,     /* NULL pointer, n < 0, n + lane0 > 2^32 */
@@ -186,6 +186,17 @@ int pomdp_rollout_synthetic(int env, const void *params, uint32_t *state, int32_
                             void *reward, uint8_t *done, uint32_t *err, int64_t n, uint64_t seed,
                             uint64_t action_seed, uint32_t lane0, uint64_t t0, int64_t k_steps, int flags,
                             void *stream);
+
+/* Trajectory collection under the same policy (shared key, fused launches, POMDP_AUTO_RESET required): the k_steps
+ * steps of pomdp_rollout_synthetic, but step s writes ROW s of ob / reward / done (device, [k_steps][pitch], pitch >= n
+ * elements) instead of overwriting one row, and `action` (device, int32 [k_steps + 1][pitch]) receives the actions of
+ * call counter t0 + s in row s (row k_steps = the actions the next call would take).  Row s of every output equals what
+ * pomdp_synthetic_actions + pomdp_<env>_step at t0 + s leave in their n-element buffers; `state` ends as after the last
+ * step.  This is the batched form of the reference callers' episode loops (rock.py:553-575): one launch per 64 steps,
+ * each lane's state in registers, 17 bytes per lane-step written and nothing read. */
+int pomdp_collect_synthetic(int env, const void *params, uint32_t *state, int32_t *action, int32_t *ob, void *reward,
+                            uint8_t *done, uint32_t *err, int64_t n, uint64_t seed, uint32_t lane0, uint64_t t0,
+                            int64_t k_steps, int64_t pitch, int flags, void *stream);
 
 /* ---- planner hooks ------------------------------------- */
 /* replaces <Env>._generate_legal (rock.py:273-291, tag.py:228-229, battleship.py:157-165, tiger.py:111-112,

@@ -974,3 +974,48 @@ def test_heuristic_steps_in_one_launch_equal_single_step_launches(env, kw, n, au
                 x, y = ea.belief[name], eb.belief[name]
                 assert bool(((x == y) | (x.isnan() & y.isnan() if x.is_floating_point() else False)).all()), ctx + (name,)
     assert ea.call_counter == eb.call_counter
+
+
+COLLECT_CASES = [("rock", {}, 1 << 20, 66), ("rock", {}, (1 << 16) + 260, 70), ("rock", {}, 4100, 130),
+                 ("rock", dict(board_size=15, num_rocks=15), 1 << 16, 70), ("stochrock", {}, 1 << 14, 70),
+                 ("tag", {}, (1 << 16) + 516, 70), ("tag", dict(num_opponents=3), 1 << 14, 70), ("battleship", {}, 20000, 70),
+                 ("tiger", {}, 30000, 70), ("network", {}, 30000, 70)]
+
+
+@pytest.mark.parametrize("env,kw,n,steps", COLLECT_CASES, ids=["%s-%d" % (c[0], c[2]) for c in COLLECT_CASES])
+def test_collected_trajectories_equal_the_per_step_calls(env, kw, n, steps):
+    """env.collect_synthetic(k) keeps every step's results: row s of action / ob / reward / done must be what
+    synthetic_actions() + step() return at that call (itself checked against the oracle above), across the 64-step
+    launch boundary and for every launch geometry; the state and the call counter end where the loop ends."""
+    a = make_env(env, kw, batch_size=n, seed=99, lane_offset=12, reuse_buffers=True)
+    b = make_env(env, kw, batch_size=n, seed=99, lane_offset=12, reuse_buffers=True)
+    a.reset()
+    b.reset()
+    a.rollout_synthetic(3, fuse=True)                      # start from a call counter other than the reset's
+    b.rollout_synthetic(3, fuse=True)
+    tr = b.collect_synthetic(steps)
+    check = sorted(set(range(0, steps, 9)) | {0, 1, 62, 63, 64, 65, steps - 1})
+    for s in range(steps):
+        act = a.synthetic_actions()
+        ob, rew, done, _ = a.step(act)
+        if s in check:
+            ctx = (env, kw, n, s)
+            assert torch.equal(tr["action"][s], act), ctx
+            assert torch.equal(tr["ob"][s], ob), ctx
+            assert torch.equal(tr["reward"][s], rew), ctx
+            assert torch.equal(tr["done"][s], done), ctx
+    assert torch.equal(tr["action"][steps], a.synthetic_actions())
+    assert torch.equal(a.state, b.state)
+    assert a.call_counter == b.call_counter
+    assert b.invalid_action_count() == 0
+    again = b.collect_synthetic(steps, out=tr)             # buffers are reusable
+    assert again is tr
+
+
+def test_collect_needs_auto_reset_and_a_reset():
+    e = make_env("tiger", {}, batch_size=64, seed=1, auto_reset=False)
+    with pytest.raises(AttributeError):
+        e.collect_synthetic(4)
+    e.reset()
+    with pytest.raises(ValueError):
+        e.collect_synthetic(4)
