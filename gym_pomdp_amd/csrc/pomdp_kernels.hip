@@ -408,13 +408,14 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
     typename Env::Reward *reward_w = reward + wg0;
     uint8_t *done_w = done + wg0;
     uint32_t rel[LPT], glane[LPT];
-    bool in_range[LPT], was_done[LPT];
+    bool in_range[LPT], was_done[LPT], ever_fresh[LPT];
     int a_cur[LPT];
     typename Env::State st[LPT];
 #pragma unroll
     for (int j = 0; j < LPT; ++j) {
         rel[j] = threadIdx.x + (uint32_t)(j * BLOCK);
         glane[j] = lane0 + wg0 + rel[j];
+        ever_fresh[j] = false;
         in_range[j] = SIMPLE || rel[j] <= last;
         const uint32_t rc = in_range[j] ? rel[j] : last;
         __builtin_assume(rc < (uint32_t)(BLOCK * LPT));
@@ -463,7 +464,7 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
         for (int j = 0; j < LPT; ++j) {
             if (!live[j]) { o[j] = 0; st[j] = before[j]; }                  // a lane that did not step keeps its state
             if (in_range[j]) st_stream(action_w + rel[j], (int32_t)a_next[j]);
-            if (live[j]) Env::store(st[j], state_w, n, rel[j], fresh[j]);
+            ever_fresh[j] |= fresh[j];
             if (in_range[j]) {
                 st_stream(ob_w + rel[j], (int32_t)o[j]);
                 st_stream(reward_w + rel[j], r[j]);
@@ -476,6 +477,11 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
         action_w += rec; ob_w += rec; reward_w += rec; done_w += rec;
         if constexpr (Fin::LOOP_BARRIER) __syncthreads();
     }
+    // the state is the loop's carry: it lived in registers and reaches memory once (a lane that never stepped writes back
+    // what it read; BattleShip's ship words only if some step of the launch dealt a new board)
+#pragma unroll
+    for (int j = 0; j < LPT; ++j)
+        if (in_range[j]) Env::store(st[j], state_w, n, rel[j], ever_fresh[j]);
 }
 
 // ---------------------------------------------------------------------------
@@ -745,6 +751,7 @@ __global__ __launch_bounds__(BLOCK) void heuristic_steps_kernel(const typename E
     Env::stage(sh, p, (int)threadIdx.x);
     stage_policy_tables<Env>(sh, p);
     __syncthreads();
+    bool ever_fresh = false;
     const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo;
     const uint32_t e = lane & 3u;
     // Random words four steps at a time, as in the rollout kernel: the policy's ACTION block is shared by the four lanes
@@ -789,8 +796,8 @@ __global__ __launch_bounds__(BLOCK) void heuristic_steps_kernel(const typename E
                 st_stream(reward + i, r);
                 st_stream(done + i, (uint8_t)d);
             }
+            ever_fresh |= fresh;
             if (live) {
-                Env::store(st, state, n, i, fresh);
                 if (R.ret) {                                                   // r += rw * discount; discount *= _discount
                     const double term = disc * (double)r;
                     const double acc = ret + term;
@@ -824,6 +831,7 @@ __global__ __launch_bounds__(BLOCK) void heuristic_steps_kernel(const typename E
         one_step(std::integral_constant<int, 3>{});
     }
     if (!in_range) return;
+    Env::store(st, state, n, i, ever_fresh);                                   // the loop's carry, written once
     st_stream(h.size + i, (int32_t)hsize); st_stream(h.last_action + i, (int32_t)la); st_stream(h.last_ob + i, (int32_t)lo);
     st_stream(prev_ob + i, (int32_t)pob);
     if (K) { st_stream(b.check_ok + i, ck); st_stream(h.move_ok + i, mv); }
