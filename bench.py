@@ -203,11 +203,11 @@ def heuristic_mode(args, gpa, env_id, kwargs, cp, dev, rank, world, label, n, la
     elapsed = cp.max(time.perf_counter() - t0)
     cp.barrier()
     kern_ms = ev0.elapsed_time(ev1) / args.steps
-    # algorithmic bytes per lane-step: with up to 64 steps per launch the lane's history words stay in
-    # registers, so a step must write action, ob, reward, done and the state words: 13 B + 4 B per state word (a CHECK's
-    # statistics update — one rock's five fields and two sums — is not counted, nor the 40 B per lane read and written
-    # once per launch)
-    alg = 13 + 4 * env.state_words
+    # algorithmic bytes per lane-step: with up to 64 steps per launch the lane's state and history words
+    # stay in registers, so a step must write action, ob, reward, done = 13 B; state in / out once per launch (a CHECK's
+    # statistics update — one rock's five fields and two sums — is not counted, nor the 40 B of history words per lane
+    # read and written once per launch)
+    alg = 13.0 + 8.0 * env.state_words / 64.0
     achieved = alg * n / (kern_ms * 1e-3) / 1e9
     if rank == 0:
         print(json.dumps({
@@ -342,7 +342,12 @@ def main():
     chained = args.host_loop == "c" and action_seed == args.seed
     fused = chained and bool(args.fuse)
     kern_ms = timed_kernel_ms if chained else plain_ms
-    achieved = bytes_per_step * n / (kern_ms * 1e-3) / 1e9
+    # Algorithmic bytes per lane-step.  One launch per step moves SURVEY.md §8d's figure: state in + state out + action
+    # in 4 + ob 4 + reward 4 + done 1.  A fused launch of 64 steps has to write each step's action, ob, reward and done
+    # (13 B) but reads the state and the first actions, and writes the state, once: 13 + (figure - 9) / 64.  Pricing the
+    # fused launch at the per-step figure would credit it with bytes it never has to move (BattleShip: 61 vs 13.8).
+    alg_bytes = 13.0 + (bytes_per_step - 9) / 64.0 if fused else float(bytes_per_step)
+    achieved = alg_bytes * n / (kern_ms * 1e-3) / 1e9
     chain1_ms = None
     if fused:      # the same chained steps launched one by one (step_kernel<., chain>), for reference
         k1 = min(args.steps, 1000)
@@ -392,7 +397,8 @@ def main():
                                     if fused else
                                     "step_kernel<%s, chain> (step + next-step policy, the launch of the timed region)"
                                     if chained else "step_kernel<%s>") % args.env,
-                         "kernel_ms": kern_ms, "algorithmic_bytes_per_step": bytes_per_step,
+                         "kernel_ms": kern_ms, "algorithmic_bytes_per_step": alg_bytes,
+                         "algorithmic_bytes_per_step_unfused": bytes_per_step,
                          "steps_per_launch": 64 if fused else 1,
                          "launch_ms": kern_ms * (64 if fused else 1),
                          "chained_step_kernel": None if chain1_ms is None else {
@@ -404,7 +410,9 @@ def main():
                                                "frac": plain_achieved / HBM_PEAK_GBS},
                          "note": "kernel_ms: HIP events on the launch stream over the timed region (%d back-to-back "
                                  "steps, gaps included) / steps; launch_ms = kernel_ms x steps_per_launch; traffic is per "
-                                 "launch; plain_step_kernel: env.step() on a ring of 16 pre-generated action batches"
+                                 "launch; algorithmic bytes: 13 B of outputs per step + state in/out and first actions once "
+                                 "per fused launch, the full per-step figure for the single-step kernels; "
+                                 "plain_step_kernel: env.step() on a ring of 16 pre-generated action batches"
                                  % args.steps},
             "invalid_actions": invalid,
         }

@@ -68,6 +68,17 @@ struct Finisher {
     struct Aux {};
     static constexpr bool HAS_PREPASS = false;
     static constexpr bool LOOP_BARRIER = CHAIN;      // run() shares `pol` across waves: a fused multi-step loop must fence its reuse
+    // The fused multi-step loop does not use `pol` at one lane per thread: lane e of a quad computes the quad's policy
+    // block of step s + e once per four steps and the words travel by ds_bpermute (steps_kernel), so the loop has no
+    // barrier at all and a wave that runs a long cooperative reset (BattleShip) no longer stalls the other three.
+    static constexpr bool QUAD_POLICY = CHAIN && LPT == 1;
+    static __device__ __forceinline__ void resets_only(const typename Env::Shared &sh, const typename Env::Params &p,
+                                                       typename Env::State (&st)[LPT], const bool (&fresh)[LPT],
+                                                       const RngKey &key, const uint32_t (&lane)[LPT])
+    {
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) Env::reset_where(sh, p, st[j], fresh[j], key, lane[j]);
+    }
     template <class RT>
     static __device__ __forceinline__ void lane_step(const typename Env::Shared &sh, const typename Env::Params &p,
                                                      typename Env::State &st, int a, const RngKey &key, uint32_t lane,
@@ -389,6 +400,10 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(uint32_t *__restrict__ stat
 // SIMPLE: every thread's lanes exist (n is a multiple of the workgroup's BLOCK * LPT lanes) and done lanes auto-reset, so
 // no lane is ever out of range or frozen, and the actions are the driver's own (always valid): the bookkeeping for those
 // cases is compiled out.
+// Finishers that take the fused loop's policy words from quad-multiplexed blocks (generic form, one lane per thread)
+template <class Fin, class = void> struct quad_policy_of : std::false_type {};
+template <class Fin> struct quad_policy_of<Fin, std::enable_if_t<Fin::QUAD_POLICY>> : std::true_type {};
+
 template <class Env, int LPT, bool SIMPLE>
 __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ state, int32_t *__restrict__ action,
                                                       int32_t *__restrict__ ob, typename Env::Reward *__restrict__ reward,
@@ -425,6 +440,8 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
     }
     action_w += rec;
     using Fin = Finisher<Env, LPT, true>;
+    constexpr bool quad_policy = quad_policy_of<Fin>::value;
+    uint4 aq = make_uint4(0, 0, 0, 0);
     const int n_act = Env::n_actions(p);
     const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo, ta0 = ((uint64_t)akey0.t_hi << 32) | akey0.t_lo;
     for (int s = 0; s < k_steps; ++s) {
@@ -459,7 +476,21 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
             fresh[j] = live[j] && d[j] && auto_reset;
             a_next[j] = 0;
         }
-        Fin::run(sh, p, st, fresh, key, glane, akey, (uint32_t)n_act, a_next, aux, o);
+        if constexpr (quad_policy) {
+            const uint32_t e = glane[0] & 3u;
+            if ((s & 3) == 0) {                                              // this lane's block: the policy of step s + e
+                const uint64_t te = ta0 + (uint64_t)s + (uint64_t)e;
+                aq = philox4x32_10(glane[0] >> 2, (uint32_t)te, (uint32_t)(te >> 32), (uint32_t)POMDP_STREAM_ACTION << 24,
+                                   akey0.k0, akey0.k1);
+            }
+            Fin::resets_only(sh, p, st, fresh, key, glane);
+            const int src = (int)((threadIdx.x & 60u) | (uint32_t)(s & 3));  // the lane of my quad that holds step s's block
+            const uint32_t wx = (uint32_t)__shfl((int)aq.x, src, 64), wy = (uint32_t)__shfl((int)aq.y, src, 64);
+            const uint32_t wz = (uint32_t)__shfl((int)aq.z, src, 64), ww = (uint32_t)__shfl((int)aq.w, src, 64);
+            a_next[0] = (int)__umulhi(e == 0 ? wx : e == 1 ? wy : e == 2 ? wz : ww, (uint32_t)n_act);
+        } else {
+            Fin::run(sh, p, st, fresh, key, glane, akey, (uint32_t)n_act, a_next, aux, o);
+        }
 #pragma unroll
         for (int j = 0; j < LPT; ++j) {
             if (!live[j]) { o[j] = 0; st[j] = before[j]; }                  // a lane that did not step keeps its state
@@ -475,7 +506,7 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
             was_done[j] = auto_reset ? false : (d[j] != 0);
         }
         action_w += rec; ob_w += rec; reward_w += rec; done_w += rec;
-        if constexpr (Fin::LOOP_BARRIER) __syncthreads();
+        if constexpr (Fin::LOOP_BARRIER && !quad_policy) __syncthreads();
     }
     // the state is the loop's carry: it lived in registers and reaches memory once (a lane that never stepped writes back
     // what it read; BattleShip's ship words only if some step of the launch dealt a new board)
