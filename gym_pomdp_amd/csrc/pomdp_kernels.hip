@@ -1014,12 +1014,15 @@ static int launch_step(const typename Env::Params &p, uint32_t *state, const int
     // Two lanes per thread where the env pools work across a wave's two 64-lane sub-batches (RockSample: the
     // Finisher specialisation above) and the batch still gives every CU several workgroups; one lane per thread
     // otherwise (measured equal within 2 % for the generic envs, tools/microbench.hip).
-    if (Env::POOLED_LPT2 && n >= LPT2_MIN_LANES)
-        hipLaunchKernelGGL((step_kernel<Env, 2>), dim3((unsigned)((n + 2 * BLOCK - 1) / (2 * BLOCK))), dim3(BLOCK), 0,
-                           (hipStream_t)stream, state, action, ob, reward, done, err, n, make_key(seed, t), lane0, flags, RngKey(), p);
-    else
-        hipLaunchKernelGGL((step_kernel<Env, 1>), dim3(blocks_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, state,
-                           action, ob, reward, done, err, n, make_key(seed, t), lane0, flags, RngKey(), p);
+    if constexpr (Env::POOLED_LPT2) {
+        if (n >= LPT2_MIN_LANES) {
+            hipLaunchKernelGGL((step_kernel<Env, 2>), dim3((unsigned)((n + 2 * BLOCK - 1) / (2 * BLOCK))), dim3(BLOCK), 0,
+                               (hipStream_t)stream, state, action, ob, reward, done, err, n, make_key(seed, t), lane0, flags, RngKey(), p);
+            return (int)hipGetLastError();
+        }
+    }
+    hipLaunchKernelGGL((step_kernel<Env, 1>), dim3(blocks_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, state,
+                       action, ob, reward, done, err, n, make_key(seed, t), lane0, flags, RngKey(), p);
     return (int)hipGetLastError();
 }
 
@@ -1031,13 +1034,16 @@ static int launch_step_chain(const typename Env::Params &p, uint32_t *state, int
 {
     if (!state || !action || !ob || !reward || !done || bad_range(n, lane0) || (lane0 & 3u)) return POMDP_E_BADARG;
     if (n == 0) return 0;
-    if (Env::POOLED_LPT2 && n >= LPT2_MIN_LANES)
-        hipLaunchKernelGGL((step_kernel<Env, 2, true>), dim3((unsigned)((n + 2 * BLOCK - 1) / (2 * BLOCK))), dim3(BLOCK),
-                           0, (hipStream_t)stream, state, action, ob, reward, done, err, n, make_key(seed, t), lane0,
-                           flags, make_key(action_seed, t + 1), p);
-    else
-        hipLaunchKernelGGL((step_kernel<Env, 1, true>), dim3(blocks_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob, reward, done, err, n, make_key(seed, t), lane0, flags,
-                           make_key(action_seed, t + 1), p);
+    if constexpr (Env::POOLED_LPT2) {
+        if (n >= LPT2_MIN_LANES) {
+            hipLaunchKernelGGL((step_kernel<Env, 2, true>), dim3((unsigned)((n + 2 * BLOCK - 1) / (2 * BLOCK))), dim3(BLOCK),
+                               0, (hipStream_t)stream, state, action, ob, reward, done, err, n, make_key(seed, t), lane0,
+                               flags, make_key(action_seed, t + 1), p);
+            return (int)hipGetLastError();
+        }
+    }
+    hipLaunchKernelGGL((step_kernel<Env, 1, true>), dim3(blocks_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, state, action,
+                       ob, reward, done, err, n, make_key(seed, t), lane0, flags, make_key(action_seed, t + 1), p);
     return (int)hipGetLastError();
 }
 
@@ -1052,19 +1058,27 @@ static int launch_steps_fused(const typename Env::Params &p, uint32_t *state, in
     const bool lpt2 = Env::POOLED_LPT2 && n >= LPT2_MIN_LANES;
     const bool simple = (flags & POMDP_AUTO_RESET) && n % (lpt2 ? 2 * BLOCK : BLOCK) == 0;
     const dim3 grid(lpt2 ? (unsigned)((n + 2 * BLOCK - 1) / (2 * BLOCK)) : blocks_for(n));
-#define POMDP_LAUNCH_STEPS(LPT_, SIMPLE_)                                                                              \
-    hipLaunchKernelGGL((steps_kernel<Env, LPT_, SIMPLE_>), grid, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob,  \
+#define POMDP_LAUNCH_STEPS(LPT_, SIMPLE_, GRID_)                                                                       \
+    hipLaunchKernelGGL((steps_kernel<Env, LPT_, SIMPLE_>), GRID_, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob, \
                        reward, done, err, n, make_key(seed, t), lane0, flags, make_key(action_seed, t + 1), k, rec, p)
     // RockSample's pooled passes exist for any number of lanes per thread; in the fused loop (no load latency to hide)
     // four per thread, with fuller passes, beat two by 5 % from 2^20 lanes up (3.97 vs 4.16 us per step) when the state
-    // is one word; with two state words (K > 12) the extra registers cost more (5.04 vs 4.74 us)
-    if (lpt2 && Env::POOLED_ANY_LPT && Env::WORDS == 1 && (flags & POMDP_AUTO_RESET) && n % (4 * BLOCK) == 0 &&
-        n >= (1 << 20)) {
-        const dim3 grid4((unsigned)(n / (4 * BLOCK)));
-        hipLaunchKernelGGL((steps_kernel<Env, 4, true>), grid4, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob, reward,
-                           done, err, n, make_key(seed, t), lane0, flags, make_key(action_seed, t + 1), k, rec, p);
-    } else if (lpt2) { if (simple) POMDP_LAUNCH_STEPS(2, true); else POMDP_LAUNCH_STEPS(2, false); }
-    else { if (simple) POMDP_LAUNCH_STEPS(1, true); else POMDP_LAUNCH_STEPS(1, false); }
+    // is one word; with two state words (K > 12) the extra registers cost more (5.04 vs 4.74 us).  Only the geometries
+    // an env can take are instantiated.
+    bool launched = false;
+    if constexpr (Env::POOLED_ANY_LPT && Env::WORDS == 1) {
+        if (lpt2 && (flags & POMDP_AUTO_RESET) && n % (4 * BLOCK) == 0 && n >= (1 << 20)) {
+            POMDP_LAUNCH_STEPS(4, true, dim3((unsigned)(n / (4 * BLOCK))));
+            launched = true;
+        }
+    }
+    if constexpr (Env::POOLED_LPT2) {
+        if (!launched && lpt2) {
+            if (simple) POMDP_LAUNCH_STEPS(2, true, grid); else POMDP_LAUNCH_STEPS(2, false, grid);
+            launched = true;
+        }
+    }
+    if (!launched) { if (simple) POMDP_LAUNCH_STEPS(1, true, grid); else POMDP_LAUNCH_STEPS(1, false, grid); }
 #undef POMDP_LAUNCH_STEPS
     return (int)hipGetLastError();
 }
