@@ -126,6 +126,34 @@ __global__ __launch_bounds__(256) void philox_kernel(uint32_t *__restrict__ out,
 
 __global__ void empty_kernel() {}
 
+// the fused loop's store pattern with NB Philox blocks per THREAD-step of register work and nothing else: k steps, four lanes per
+// thread, each step writes action / ob / reward (4 B) and done (1 B) per lane with the product's write-through stores; rows
+// advance by rec elements per step.  The floor for a launch that has to emit 13 B per lane-step.
+template <int NB>
+__global__ __launch_bounds__(256) void fused_store_floor(int32_t *__restrict__ action, int32_t *__restrict__ ob,
+                                                         int32_t *__restrict__ reward, uint8_t *__restrict__ done, int k,
+                                                         int64_t rec, RngKey key)
+{
+    const uint32_t wg0 = blockIdx.x * 1024u;
+    int32_t *a_w = action + wg0, *o_w = ob + wg0, *r_w = reward + wg0;
+    uint8_t *d_w = done + wg0;
+    uint32_t v = threadIdx.x;
+    for (int s = 0; s < k; ++s) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) { const uint4 w = stream_block(key, wg0 + threadIdx.x, (uint32_t)s, (uint32_t)b); v ^= w.x ^ w.y ^ w.z ^ w.w; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t rel = threadIdx.x + 256u * j;
+            st_stream(a_w + rel, (int32_t)(v + j));
+            st_stream(o_w + rel, (int32_t)(v & 3u));
+            st_stream(r_w + rel, (int32_t)(v >> 7));
+            st_stream(d_w + rel, (uint8_t)(v & 1u));
+        }
+        v = v * 5u + 1u;
+        a_w += rec; o_w += rec; r_w += rec; d_w += rec;
+    }
+}
+
 template <class F> static float time_it(F f, int iters)
 {
     hipEvent_t e0, e1;
@@ -282,14 +310,42 @@ int main(int argc, char **argv)
         using E = RockEnv<1, 0>;
         const int reps = iters / 64 + 1;
         printf("steps_kernel (64 steps per launch), per step: LPT2 simple %6.2f", time_it([&](int t) {
-            hipLaunchKernelGGL((steps_kernel<E, 2, true>), dim3((unsigned)(n / 512)), dim3(256), 0, 0, state, action, ob, reward, done, err, n, make_key(1, 64 * t), 0u, 1, make_key(1, 64 * t + 1), 64, p);
+            hipLaunchKernelGGL((steps_kernel<E, 2, true>), dim3((unsigned)(n / 512)), dim3(256), 0, 0, state, action, ob, reward, done, err, n, make_key(1, 64 * t), 0u, 1, make_key(1, 64 * t + 1), 64, 0, p);
         }, reps) / 64);
         printf("  LPT2 general %6.2f", time_it([&](int t) {
-            hipLaunchKernelGGL((steps_kernel<E, 2, false>), dim3((unsigned)((n + 511) / 512)), dim3(256), 0, 0, state, action, ob, reward, done, err, n, make_key(1, 64 * t), 0u, 1, make_key(1, 64 * t + 1), 64, p);
+            hipLaunchKernelGGL((steps_kernel<E, 2, false>), dim3((unsigned)((n + 511) / 512)), dim3(256), 0, 0, state, action, ob, reward, done, err, n, make_key(1, 64 * t), 0u, 1, make_key(1, 64 * t + 1), 64, 0, p);
         }, reps) / 64);
         printf("  LPT4 simple %6.2f\n", time_it([&](int t) {
-            hipLaunchKernelGGL((steps_kernel<E, 4, true>), dim3((unsigned)(n / 1024)), dim3(256), 0, 0, state, action, ob, reward, done, err, n, make_key(1, 64 * t), 0u, 1, make_key(1, 64 * t + 1), 64, p);
+            hipLaunchKernelGGL((steps_kernel<E, 4, true>), dim3((unsigned)(n / 1024)), dim3(256), 0, 0, state, action, ob, reward, done, err, n, make_key(1, 64 * t), 0u, 1, make_key(1, 64 * t + 1), 64, 0, p);
         }, reps) / 64);
+    }
+    {   // where the fused loop's time goes: the LPT4 SIMPLE kernel with pieces ablated (results are wrong, timing only)
+        const int reps = iters / 64 + 1;
+        auto fused4 = [&](auto tag, const char *what) {
+            using E = decltype(tag);
+            printf("  steps_kernel LPT4 simple, %-44s %6.2f us/step\n", what, time_it([&](int t) {
+                hipLaunchKernelGGL((steps_kernel<E, 4, true>), dim3((unsigned)(n / 1024)), dim3(256), 0, 0, state, action, ob, reward, done, err, n, make_key(1, 64 * t), 0u, 1, make_key(1, 64 * t + 1), 64, 0, p);
+            }, reps) / 64);
+        };
+        fused4(RockEnv<1, 0>{}, "as shipped");
+        fused4(RockEnv<1, 1>{}, "without the sensor Philox block (1)");
+        fused4(RockEnv<1, 2>{}, "without auto-reset (2)");
+        fused4(RockEnv<1, 4>{}, "without the LDS table lookups (4)");
+        fused4(RockEnv<1, 7>{}, "without all three (7)");
+        int32_t *ta, *to, *tr; uint8_t *td;                         // 64-row trajectory buffers
+        CK(hipMalloc(&ta, 65 * n * 4)); CK(hipMalloc(&to, 64 * n * 4)); CK(hipMalloc(&tr, 64 * n * 4)); CK(hipMalloc(&td, 64 * n));
+        printf("  steps_kernel LPT4 simple, one row per step (rec = n)                   %6.2f us/step\n", time_it([&](int t) {
+            hipLaunchKernelGGL((steps_kernel<RockEnv<1, 0>, 4, true>), dim3((unsigned)(n / 1024)), dim3(256), 0, 0, state, ta, to, tr, td, err, n, make_key(1, 64 * t), 0u, 1, make_key(1, 64 * t + 1), 64, n, p);
+        }, reps) / 64);
+        printf("  store floor (13 B per lane-step, 64 steps per launch), Philox blocks per thread-step 0 / 1 / 2 / 3, same row | own row:\n   ");
+        for (int64_t rec : {(int64_t)0, n}) {
+            printf(" %6.2f", time_it([&](int t) { hipLaunchKernelGGL((fused_store_floor<0>), dim3((unsigned)(n / 1024)), dim3(256), 0, 0, ta, to, tr, td, 64, rec, make_key(1, t)); }, reps) / 64);
+            printf(" %6.2f", time_it([&](int t) { hipLaunchKernelGGL((fused_store_floor<1>), dim3((unsigned)(n / 1024)), dim3(256), 0, 0, ta, to, tr, td, 64, rec, make_key(1, t)); }, reps) / 64);
+            printf(" %6.2f", time_it([&](int t) { hipLaunchKernelGGL((fused_store_floor<2>), dim3((unsigned)(n / 1024)), dim3(256), 0, 0, ta, to, tr, td, 64, rec, make_key(1, t)); }, reps) / 64);
+            printf(" %6.2f  |", time_it([&](int t) { hipLaunchKernelGGL((fused_store_floor<3>), dim3((unsigned)(n / 1024)), dim3(256), 0, 0, ta, to, tr, td, 64, rec, make_key(1, t)); }, reps) / 64);
+        }
+        printf("\n");
+        CK(hipFree(ta)); CK(hipFree(to)); CK(hipFree(tr)); CK(hipFree(td));
     }
     {   // hipGraph replay of 100 chained step launches vs the same launches issued one by one
         using E = RockEnv<1, 0>;
