@@ -177,9 +177,10 @@ int pomdp_philox_blocks(const uint32_t *ctr_key, uint32_t *out, int64_t n_blocks
  * policy kernel runs once, for t0, and every step launch also leaves the policy's actions for the
  * following call counter in `action` (on RockSample they ride in the cooperative reset pass); with a
  * distinct action_seed each step is a policy launch plus a step launch.  With POMDP_FUSE_STEPS in `flags` (shared key
- * only) up to 64 consecutive steps run inside one launch: every step's state / ob / reward / done / next action is still
- * computed and written, in the same order, so every buffer holds what the per-step launches leave, but a lane's state
- * and action stay in registers between its steps and the launch ramp is paid once per 64 steps.  Either way `action` holds the
+ * only) up to 64 consecutive steps run inside one launch: every step's ob / reward / done / next action is still
+ * computed and written, in the same order, and the state when the launch ends, so every buffer holds what the per-step
+ * launches leave, but a lane's state and action stay in registers between its steps and the launch ramp is paid once
+ * per 64 steps.  Either way `action` holds the
  * actions of t0 + k_steps on return.  The caller's call counter advances by k_steps.  `params` points at the env's
  * pomdp_<env>_params; `reward` is int32 or float per env.  n and lane0 must be multiples of 4. */
 int pomdp_rollout_synthetic(int env, const void *params, uint32_t *state, int32_t *action, int32_t *ob,
@@ -193,7 +194,7 @@ int pomdp_rollout_synthetic(int env, const void *params, uint32_t *state, int32_
  * call counter t0 + s in row s (row k_steps = the actions the next call would take).  Row s of every output equals what
  * pomdp_synthetic_actions + pomdp_<env>_step at t0 + s leave in their n-element buffers; `state` ends as after the last
  * step.  This is the batched form of the reference callers' episode loops (rock.py:553-575): one launch per 64 steps,
- * each lane's state in registers, 17 bytes per lane-step written and nothing read. */
+ * each lane's state in registers, 13 bytes per lane-step written, state and first actions read once per launch. */
 int pomdp_collect_synthetic(int env, const void *params, uint32_t *state, int32_t *action, int32_t *ob, void *reward,
                             uint8_t *done, uint32_t *err, int64_t n, uint64_t seed, uint32_t lane0, uint64_t t0,
                             int64_t k_steps, int64_t pitch, int flags, void *stream);
