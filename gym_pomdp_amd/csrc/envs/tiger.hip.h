@@ -14,7 +14,10 @@ struct TigerEnv {
     static constexpr bool QUAD_SENSOR = false;
     static constexpr int ABL = 0;
     struct Shared { int unused; };
-    struct State { uint32_t w; };
+    // w: the tiger's door (what is stored).  rs: registers only — the fresh episode's door when this step ended the
+    // episode (see step()), NO_RS otherwise.
+    static constexpr uint32_t NO_RS = 0xFFFFFFFFu;
+    struct State { uint32_t w; uint32_t rs = NO_RS; };
 
     static __device__ __forceinline__ void stage(Shared &, const Params &, int) {}
     static __device__ __forceinline__ int n_actions(const Params &) { return 3; }
@@ -34,7 +37,13 @@ struct TigerEnv {
     static __device__ __forceinline__ void reset_where(const Shared &sh, const Params &p, State &st, bool fresh,
                                                        const RngKey &key, uint32_t lane)
     {
-        if (fresh) reset(sh, p, st, key, lane);
+        // a lane is fresh because the step just before (same key, same lane) opened the tiger's door, and that step
+        // already drew the new episode's door from stream RESET_SPACE: no second Philox block
+        if (fresh) {
+            if (st.rs != NO_RS) st.w = st.rs;
+            else reset(sh, p, st, key, lane);
+        }
+        st.rs = NO_RS;
     }
     static __device__ __forceinline__ void reset_where_chain(const Shared &sh, const Params &p, State &st, bool fresh,
                                                              const RngKey &key, uint32_t lane, const RngKey &akey,
@@ -64,24 +73,27 @@ struct TigerEnv {
         return 0.0;
     }
 
-    // tiger.py:72-88 step, 117-119 _sample_state, 140-149 _sample_ob, 155-172
+    // tiger.py:72-88 step, 117-119 _sample_state, 140-149 _sample_ob, 155-172.
+    // A step draws from exactly one place: LISTEN one double of stream STEP; the wrong door one word of stream STEP_SPACE
+    // (the state is resampled); the tiger's door nothing — but the auto-reset that follows draws one word of stream
+    // RESET_SPACE at the same call counter.  So the lane computes ONE Philox block whose stream id is a per-lane select,
+    // instead of the wave walking through three divergent blocks; the fresh episode's door is parked in st.rs.
     template <class RT>
     static __device__ __forceinline__ void step(const Shared &, const Params &p, State &st, int a,
                                                 const RngKey &key, uint32_t lane, int &ob, RT &rew, int &done)
     {
         const int tiger = (int)(st.w & 1u);
-        if (a != 2 && a == tiger) { ob = tiger; rew = -20; done = 1; return; } // terminal: ob is the state
-        done = 0;
-        if (a == 2) {
-            rew = -1;
-            const uint4 w = stream_block(key, lane, POMDP_STREAM_STEP, 0u);
-            const bool flip = k53(w.x, w.y) > p.listen_thr;                     // p > .85
-            ob = tiger ^ (int)flip;
-        } else {
-            rew = 10;
-            st.w = stream_block(key, lane, POMDP_STREAM_STEP_SPACE, 0u).x & 1u; // state resampled
-            ob = 2; // the uniform() the reference draws here has no effect on anything returned
-        }
+        const bool listen = a == 2, right = !listen && a == tiger;               // right: terminal, ob is the state
+        const uint32_t stream = listen ? (uint32_t)POMDP_STREAM_STEP
+                                       : (right ? (uint32_t)POMDP_STREAM_RESET_SPACE : (uint32_t)POMDP_STREAM_STEP_SPACE);
+        const uint4 w = stream_block(key, lane, stream, 0u);
+        const uint32_t door = w.x & 1u;                                          // randint(2): mask 1, never rejects
+        const bool flip = k53(w.x, w.y) > p.listen_thr;                          // p > .85
+        ob = right ? tiger : (listen ? (tiger ^ (int)flip) : 2);
+        rew = right ? -20 : (listen ? -1 : 10);
+        done = right;
+        st.rs = right ? door : NO_RS;
+        st.w = (listen | right) ? st.w : door;     // wrong door: state resampled (the uniform() drawn there affects nothing)
     }
 };
 
