@@ -168,6 +168,7 @@ struct Finisher<RockEnv<W, ABLATE, false>, LPT, CHAIN, typename std::enable_if<(
         }
 #pragma unroll
         for (int base = 0; base < NQ + NA; base += 64) {
+            if ((ABLATE & 1) && NQ % 64 == 0 && base < NQ) continue;           // timing experiment: no sensor blocks
             const int tid = base + me;
             if (tid < NQ + NA) {
                 const bool is_act = tid >= NQ;
@@ -194,10 +195,10 @@ struct Finisher<RockEnv<W, ABLATE, false>, LPT, CHAIN, typename std::enable_if<(
         int rank[LPT], nres = 0;
 #pragma unroll
         for (int j = 0; j < LPT; ++j) {
-            const uint64_t m = __ballot(fresh[j]);
+            const uint64_t m = (ABLATE & 2) ? 0ull : __ballot(fresh[j]);      // ABLATE 2 (timing experiment): nobody resets
             rank[j] = nres + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
             nres += __popcll(m);
-            if (fresh[j]) src_lds[wv][rank[j]] = (uint8_t)(me + 64 * j);
+            if (!(ABLATE & 2) && fresh[j]) src_lds[wv][rank[j]] = (uint8_t)(me + 64 * j);
         }
         const int ntask = NG * nres;                         // reset blocks: NG per resetting lane, 64 per pass
         const uint32_t inv = (65536u + (uint32_t)NG - 1u) / (uint32_t)NG;   // t / NG == (t * inv) >> 16 for t < 16384
@@ -218,7 +219,7 @@ struct Finisher<RockEnv<W, ABLATE, false>, LPT, CHAIN, typename std::enable_if<(
         const uint32_t *res32 = reinterpret_cast<const uint32_t *>(&res_lds[wv][0][0]);
 #pragma unroll
         for (int j = 0; j < LPT; ++j) {
-            if (fresh[j]) st[j].s = (typename Env::S)((uint64_t)start | ((uint64_t)(res32[rank[j]] & used) << 8));
+            if (!(ABLATE & 2) && fresh[j]) st[j].s = (typename Env::S)((uint64_t)start | ((uint64_t)(res32[rank[j]] & used) << 8));
             const uint32_t H = (ABLATE & 1) ? lane[j] * 2654435761u : blk_lds()[wv][16 * j + (me >> 2)][me & 3];
             ob[j] = Env::sensor_ob(aux[j], H, [&]() { return Env::elem(Env::quad_block(key, lane[j], 1u), lane[j] & 3u); });
             if (CHAIN) a_next[j] = (int)__umulhi(blk_lds()[wv][NQ + 16 * j + (me >> 2)][me & 3], n_act);
