@@ -7,14 +7,17 @@ namespace pomdp {
 
 // Word contract of the RockSample envs ("split layout").  Every draw RockSample makes is a numpy double
 // = (high word H, low word L) -> k53 = (H >> 5) * 2^26 + (L >> 6).  H and L live in DIFFERENT Philox blocks:
-//   reset  (stream RESET, counter word 0 = lane):      double j = rock j:  H = block 2 (j >> 2), L = block 2 (j >> 2) + 1,
-//                                                       element j & 3;
+//   reset  (stream RESET, counter word 0 = lane):      double j = rock j = 4 q + e:  H = element e of block 2 (j >> 4)
+//                                                       rotated right by 8 q + 8 bits, L = the same element of block
+//                                                       2 (j >> 4) + 1 under the same rotation — reset() only uses
+//                                                       sign(U - .5), the top bit of H, so ONE block's bits 7, 15, 23, 31
+//                                                       of its four words are sixteen rocks' statuses;
 //   step   (stream STEP,  counter word 0 = lane >> 2): double j (RockEnv: j = 0 the sensor; StochasticRockEnv:
 //                                                       j = 0 the action gate, j = 1 the sensor): H = block 2 j,
 //                                                       L = block 2 j + 1, element lane & 3 — one block serves the four
 //                                                       lanes of a quad.
 // A comparison k53 <= thr is decided by H alone unless (H >> 5) == (thr >> 26), which happens with probability 2^-27
-// per draw; only then is the L block generated.  So a reset costs ceil(K / 4) blocks instead of ceil(K / 2), a
+// per draw; only then is the L block generated.  So a reset costs ONE block instead of ceil(K / 2), a
 // quad's sensor draws cost one block instead of four, and a wave's whole step fits one pooled Philox pass.
 //
 // ABLATE is a profiling aid (tools/microbench.hip): bit 0 drops the sensor Philox block, bit 1 the auto-reset,
@@ -119,29 +122,35 @@ struct RockEnv {
         return kh > HALF_HI ? 2u : (kh < HALF_HI ? 0u : 3u);
     }
     static __device__ __forceinline__ uint32_t rock_code_lo(uint32_t L) { return (L >> 6) ? 2u : 1u; }   // kh == 2^26 exactly
-    // the 2-bit codes of rocks 4 g .. 4 g + 3 (8 bits) of lane `lane`'s fresh episode: one high block, low block on a tie
-    static __device__ __forceinline__ uint32_t reset_group(const RngKey &key, uint32_t lane, int g, int K)
+    // The 2-bit codes of all K <= 16 rocks (bit pair j = rock j) of lane `lane`'s fresh episode from its RESET block.
+    // Rock j = 4 q + e reads element e rotated right by 8 q + 8: its top bit is bit 8 q + 7 of the element, and the code
+    // (status + 1) is twice that bit unless the rotated word lies in the 32 values just above 2^31 — the tie the low
+    // word decides.  Bit 8 q + 7 of element e belongs at bit 2 j + 1 = 8 q + 2 e + 1: a shift by 6 - 2 e for all q at once.
+    static __device__ __forceinline__ uint32_t reset_codes(const RngKey &key, uint32_t lane, int K)
     {
-        const uint4 h = stream_block(key, lane, POMDP_STREAM_RESET, 2u * (uint32_t)g);
-        return reset_group_codes(h, key, lane, g, K);
+        return reset_codes(stream_block(key, lane, POMDP_STREAM_RESET, 0u), key, lane, K);
     }
-    static __device__ __forceinline__ uint32_t reset_group_codes(const uint4 &h, const RngKey &key, uint32_t lane, int g, int K)
+    static __device__ __forceinline__ uint32_t reset_codes(const uint4 &h, const RngKey &key, uint32_t lane, int K)
     {
-        // (H >> 5) compared with 2^26: above for H >= 2^31 + 32 (code 2, good), below for H < 2^31 (code 0, bad), so
-        // the code is twice the top bit unless H lies in the 32 values in between — the tie the low word decides.
-        const uint32_t TOP = 0x80000000u;
-        uint32_t codes = ((h.x >> 30) & 2u) | ((h.y >> 28) & 8u) | ((h.z >> 26) & 32u) | ((h.w >> 24) & 128u);
-        if (min(min(h.x ^ TOP, h.y ^ TOP), min(h.z ^ TOP, h.w ^ TOP)) < 32u) { // some rock undecided: 2^-27 per rock
-            const uint4 l = stream_block(key, lane, POMDP_STREAM_RESET, 2u * (uint32_t)g + 1u);
-            uint32_t c0 = rock_code_hi(h.x), c1 = rock_code_hi(h.y), c2 = rock_code_hi(h.z), c3 = rock_code_hi(h.w);
-            if (c0 == 3u) c0 = rock_code_lo(l.x);
-            if (c1 == 3u) c1 = rock_code_lo(l.y);
-            if (c2 == 3u) c2 = rock_code_lo(l.z);
-            if (c3 == 3u) c3 = rock_code_lo(l.w);
-            codes = c0 | (c1 << 2) | (c2 << 4) | (c3 << 6);
+        const uint32_t M = 0x80808080u;
+        uint32_t codes = ((h.x & M) >> 6) | ((h.y & M) >> 4) | ((h.z & M) >> 2) | (h.w & M);
+        // A tied rotation is 1, twenty-six zeros, five free bits: at most six bits set in the element (2.7e-4 per element);
+        // only then look closer
+        if (min(min(__popc(h.x), __popc(h.y)), min(__popc(h.z), __popc(h.w))) <= 6) {
+            const uint32_t w[4] = {h.x, h.y, h.z, h.w};
+            bool have_lo = false;
+            uint4 l = make_uint4(0, 0, 0, 0);
+            for (int j = 0; j < K; ++j) {
+                const int e = j & 3, rot = (8 * ((j >> 2) & 3) + 8) & 31;
+                const uint32_t H = __builtin_rotateright32(w[e], (uint32_t)rot);
+                if (rock_code_hi(H) != 3u) continue;
+                if (!have_lo) { l = stream_block(key, lane, POMDP_STREAM_RESET, 1u); have_lo = true; }
+                const uint32_t lw[4] = {l.x, l.y, l.z, l.w};
+                const uint32_t c = rock_code_lo(__builtin_rotateright32(lw[e], (uint32_t)rot));
+                codes = (codes & ~(3u << (2 * j))) | (c << (2 * j));
+            }
         }
-        const int left = K - 4 * g;                                            // rocks of this group that exist (wave-uniform)
-        return codes & (left >= 4 ? 0xFFu : ((1u << (2 * left)) - 1u));
+        return codes & (K >= 16 ? 0xFFFFFFFFu : ((1u << (2 * K)) - 1u));      // rocks that exist (wave-uniform)
     }
     // block `j2` (0 = sensor / gate high words, 1 = their low words, 2 / 3 = StochasticRock's sensor) of lane's quad
     static __device__ __forceinline__ uint4 quad_block(const RngKey &key, uint32_t lane, uint32_t j2)
@@ -154,18 +163,16 @@ struct RockEnv {
     static __device__ __forceinline__ int reset(const Shared &, const Params &p, State &st, const RngKey &key,
                                                 uint32_t lane)
     {
-        uint64_t s = (uint32_t)p.start_x | ((uint32_t)p.start_y << 4);
-        const int K = p.num_rocks;
-        for (int g = 0; 4 * g < K; ++g) s |= (uint64_t)reset_group(key, lane, g, K) << (8 + 8 * g);
-        st.s = (S)s;
+        const uint64_t s = (uint32_t)p.start_x | ((uint32_t)p.start_y << 4);
+        st.s = (S)(s | ((uint64_t)reset_codes(key, lane, p.num_rocks) << 8));
         return 0; // Obs.NULL
     }
     static __device__ __forceinline__ int reset_ob(const Params &, const State &) { return 0; }   // what reset() returned
 
-    // Wave-cooperative reset (one lane per thread launches).  A fresh episode needs NG = ceil(K/4) high blocks, only
-    // ~1/8 of a wave's lanes reset in a given step while nearly every wave has at least one: done per lane, the whole
-    // wave would pay all NG blocks.  Instead the (resetting lane, block) tasks are dealt out across the 64 lanes — one
-    // Philox block per lane per pass — and the rock codes travel back through ds_bpermute.
+    // Wave-cooperative reset (one lane per thread launches).  A fresh episode needs one block, only ~1/8 of a wave's
+    // lanes reset in a given step while nearly every wave has at least one: done per lane, the whole wave would pay a
+    // block per step for eight resets.  Instead the resetting lanes' blocks are dealt out across the 64 lanes — with the
+    // chained policy's blocks in the same pass — and the rock codes travel back through ds_bpermute.
     static __device__ __forceinline__ void reset_where(const Shared &sh, const Params &p, State &st, bool fresh,
                                                        const RngKey &key, uint32_t lane)
     {
@@ -190,23 +197,20 @@ struct RockEnv {
         const uint64_t mask = __ballot(fresh);
         if (!CHAIN && mask == 0ull) return;                            // wave-uniform
         const int K = p.num_rocks;
-        const int NG = (K + 3) >> 2;                                   // high blocks per reset (wave-uniform, 1..4)
         const int lid = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
         const int me = (int)(threadIdx.x & 63u);
         const int nreset = __popcll(mask);
         // stable partition: resetting lanes first; lane r (< nreset) learns who the r-th resetting lane is
         const int dst = fresh ? lid : nreset + (me - lid);
         const int src_of_rank = __builtin_amdgcn_ds_permute(dst << 2, me);
-        constexpr int NA = CHAIN ? 16 : 0;                             // task list: [16 policy blocks] ++ [NG per reset]
-        const int ntask = NA + nreset * NG;
-        const uint32_t inv = (65536u + (uint32_t)NG - 1u) / (uint32_t)NG; // t / NG == (t * inv) >> 16 for t < 512
-        uint64_t bits = 0;
+        constexpr int NA = CHAIN ? 16 : 0;                             // task list: [16 policy blocks] ++ [one per reset]
+        const int ntask = NA + nreset;                                 // <= 80: two passes at most
+        uint32_t bits = 0;
         uint4 aw = make_uint4(0, 0, 0, 0);
         for (int base = 0; base < ntask; base += 64) {
             const int tid = base + me;
             const bool is_act = CHAIN && tid < NA;
-            const int rt = tid < NA ? 0 : tid - NA;
-            const int r = (int)(((uint32_t)rt * inv) >> 16), g = rt - r * NG;
+            const int r = tid < NA ? 0 : tid - NA;
             const int srcl = __shfl(src_of_rank, r & 63, 64);
             uint32_t codes = 0;
             if (tid < ntask) {
@@ -214,16 +218,14 @@ struct RockEnv {
                 const uint32_t src_lane = lane - (uint32_t)me + (uint32_t)srcl;
                 const uint32_t c0 = is_act ? ((lane - (uint32_t)me) >> 2) + (uint32_t)tid : src_lane;
                 const uint32_t c1 = is_act ? akey.t_lo : key.t_lo, c2 = is_act ? akey.t_hi : key.t_hi;
-                const uint32_t c3 = is_act ? ((uint32_t)POMDP_STREAM_ACTION << 24) : (((uint32_t)POMDP_STREAM_RESET << 24) | (2u * (uint32_t)g));
+                const uint32_t c3 = (uint32_t)(is_act ? POMDP_STREAM_ACTION : POMDP_STREAM_RESET) << 24;
                 const uint4 w = philox4x32_10(c0, c1, c2, c3, key.k0, key.k1);
                 if (CHAIN && base == 0) aw = w;                        // lanes >= 16 hold words nobody reads
-                if (!is_act) codes = reset_group_codes(w, key, src_lane, g, K);
+                if (!is_act) codes = reset_codes(w, key, src_lane, K);
             }
-            for (int gg = 0; gg < NG; ++gg) {                          // wave-uniform trip count
-                const int t = NA + lid * NG + gg - base;
-                const uint32_t got = (uint32_t)__shfl((int)codes, t & 63, 64);
-                if (t >= 0 && t < 64) bits |= (uint64_t)got << (8 + 8 * gg);
-            }
+            const int t = NA + lid - base;                             // where this lane's own reset task ran
+            const uint32_t got = (uint32_t)__shfl((int)codes, t & 63, 64);
+            if (t >= 0 && t < 64) bits = got;
             if (CHAIN && base == 0) {
                 // lane l takes word (l & 3) of the policy block computed by lane l >> 2
                 const int q = me >> 2;
@@ -233,7 +235,7 @@ struct RockEnv {
                 next_action = (int)__umulhi(b == 0 ? x : b == 1 ? y : b == 2 ? z : ww, n_actions);
             }
         }
-        if (fresh) st.s = (S)((uint64_t)((uint32_t)p.start_x | ((uint32_t)p.start_y << 4)) | bits);
+        if (fresh) st.s = (S)((uint64_t)((uint32_t)p.start_x | ((uint32_t)p.start_y << 4)) | ((uint64_t)bits << 8));
     }
 
     // rock.py:273-291 _generate_legal, in the reference's list order: EAST, then NORTH / SOUTH / WEST when

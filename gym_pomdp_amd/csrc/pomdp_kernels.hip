@@ -188,10 +188,10 @@ struct Finisher<RockEnv<W, ABLATE, false>, LPT, CHAIN, typename std::enable_if<(
                                                int (&a_next)[LPT], const Aux (&aux)[LPT], int (&ob)[LPT])
     {
         __shared__ uint8_t src_lds[BLOCK / 64][64 * LPT];    // reset rank -> virtual lane (me + 64 * sub-batch)
-        __shared__ uint8_t res_lds[BLOCK / 64][64 * LPT][4]; // reset rank -> four 2-bit rock codes per group g
+        __shared__ uint32_t res_lds[BLOCK / 64][64 * LPT];   // reset rank -> the 2-bit codes of the fresh episode's rocks
         const int wv = (int)(threadIdx.x >> 6), me = (int)(threadIdx.x & 63u);
         if (!HAS_PREPASS) prepass(key, lane, akey);
-        const int K = p.num_rocks, NG = (K + 3) >> 2;        // high blocks per reset
+        const int K = p.num_rocks;
         int rank[LPT], nres = 0;
 #pragma unroll
         for (int j = 0; j < LPT; ++j) {
@@ -200,26 +200,20 @@ struct Finisher<RockEnv<W, ABLATE, false>, LPT, CHAIN, typename std::enable_if<(
             nres += __popcll(m);
             if (!(ABLATE & 2) && fresh[j]) src_lds[wv][rank[j]] = (uint8_t)(me + 64 * j);
         }
-        const int ntask = NG * nres;                         // reset blocks: NG per resetting lane, 64 per pass
-        const uint32_t inv = (65536u + (uint32_t)NG - 1u) / (uint32_t)NG;   // t / NG == (t * inv) >> 16 for t < 16384
         const uint32_t first0 = lane[0] - (uint32_t)me;
-        for (int base = 0; base < ntask; base += 64) {
-            const int rt = base + me;
-            if (rt < ntask) {
-                const int r = (int)(((uint32_t)rt * inv) >> 16), g = rt - r * NG;
+        for (int base = 0; base < nres; base += 64) {        // one RESET block per resetting lane, 64 per pass
+            const int r = base + me;
+            if (r < nres) {
                 const int v = (int)src_lds[wv][r & (64 * LPT - 1)];
                 const uint32_t src_lane = first0 + (uint32_t)(v >> 6) * BLOCK + (uint32_t)(v & 63);
-                const uint4 w = philox4x32_10(src_lane, key.t_lo, key.t_hi,
-                                              ((uint32_t)POMDP_STREAM_RESET << 24) | (2u * (uint32_t)g), key.k0, key.k1);
-                res_lds[wv][r & (64 * LPT - 1)][g] = (uint8_t)Env::reset_group_codes(w, key, src_lane, g, K);
+                const uint4 w = philox4x32_10(src_lane, key.t_lo, key.t_hi, (uint32_t)POMDP_STREAM_RESET << 24, key.k0, key.k1);
+                res_lds[wv][r & (64 * LPT - 1)] = Env::reset_codes(w, key, src_lane, K);
             }
         }
         const uint32_t start = (uint32_t)p.start_x | ((uint32_t)p.start_y << 4);
-        const uint32_t used = NG >= 4 ? 0xFFFFFFFFu : ((1u << (8 * NG)) - 1u);   // groups >= NG were never written
-        const uint32_t *res32 = reinterpret_cast<const uint32_t *>(&res_lds[wv][0][0]);
 #pragma unroll
         for (int j = 0; j < LPT; ++j) {
-            if (!(ABLATE & 2) && fresh[j]) st[j].s = (typename Env::S)((uint64_t)start | ((uint64_t)(res32[rank[j]] & used) << 8));
+            if (!(ABLATE & 2) && fresh[j]) st[j].s = (typename Env::S)((uint64_t)start | ((uint64_t)res_lds[wv][rank[j] & (64 * LPT - 1)] << 8));
             const uint32_t H = (ABLATE & 1) ? lane[j] * 2654435761u : blk_lds()[wv][16 * j + (me >> 2)][me & 3];
             ob[j] = Env::sensor_ob(aux[j], H, [&]() { return Env::elem(Env::quad_block(key, lane[j], 1u), lane[j] & 3u); });
             if (CHAIN) a_next[j] = (int)__umulhi(blk_lds()[wv][NQ + 16 * j + (me >> 2)][me & 3], n_act);

@@ -93,15 +93,25 @@ def split_words(seed, lane, t, stream, n_doubles):
     return np.array(out, dtype=np.uint32)
 
 
+def rotr32(w, r):
+    w, r = int(w) & 0xFFFFFFFF, int(r) & 31
+    return ((w >> r) | (w << (32 - r))) & 0xFFFFFFFF
+
+
 def rock_reset_words(seed, lane, t, n_rocks):
-    """RockSample's RESET stream in *split layout* (DESIGN.md §2): every draw of reset() is a double, and double j
-    takes its high word from element j & 3 of block 2 (j >> 2) and its low word from the same element of block
-    2 (j >> 2) + 1.  The kernels only generate the odd ("low") blocks when a high word leaves the comparison
-    undecided (probability 2^-27 per draw).  Returns the 2 * n_rocks words numpy consumes, in order."""
+    """RockSample's RESET stream ("rotated split layout").  reset() draws one double per rock and only
+    uses sign(U - .5), i.e. the top bit of the double's high word (the rest matters only when the top 27 bits are
+    exactly 2^26: a tie, probability 2^-27).  One Philox block therefore serves SIXTEEN rocks: rock j = 4 q + e
+    (e = j & 3, q = (j >> 2) & 3) takes as its high word element e of block 2 (j >> 4) rotated right by 8 q + 8 bits
+    (q = 3: unrotated), and as its low word the same element of block 2 (j >> 4) + 1 under the same rotation.  The
+    top bits of the four rotations are bits 7, 15, 23, 31 of the element — independent fair bits — so the rock
+    statuses are independent Bernoulli(1/2) exactly as in the reference.  The kernels generate the low block only on a
+    tie.  Returns the 2 * n_rocks words numpy consumes, in order."""
     out = []
     for j in range(n_rocks):
-        hi = _block(seed, lane, t, STREAM_RESET, 2 * (j >> 2))[j & 3]
-        lo = _block(seed, lane, t, STREAM_RESET, 2 * (j >> 2) + 1)[j & 3]
+        e, rot = j & 3, 8 * ((j >> 2) & 3) + 8
+        hi = rotr32(_block(seed, lane, t, STREAM_RESET, 2 * (j >> 4))[e], rot)
+        lo = rotr32(_block(seed, lane, t, STREAM_RESET, 2 * (j >> 4) + 1)[e], rot)
         out += [int(hi), int(lo)]
     return np.array(out, dtype=np.uint32)
 

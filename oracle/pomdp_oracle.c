@@ -81,7 +81,7 @@ void or_ws_philox(or_ws *ws, uint64_t seed, uint32_t lane, uint64_t t, uint32_t 
 void or_ws_philox_env(or_ws *ws, int env_kind, uint64_t seed, uint32_t lane, uint64_t t, uint32_t stream)
 {
     or_ws_philox(ws, seed, lane, t, stream);
-    if (env_kind == OR_ENV_ROCK && stream == OR_STREAM_RESET) ws->layout = 1;
+    if (env_kind == OR_ENV_ROCK && stream == OR_STREAM_RESET) ws->layout = 3;   /* rotated: one block, sixteen rocks */
     if (env_kind == OR_ENV_ROCK && stream == OR_STREAM_STEP) { ws->layout = 2; ws->ctr[0] = lane >> 2; }
     /* Network: every draw of step() is a double too (one per up machine, one for the action): per-lane split layout */
     if (env_kind == OR_ENV_NETWORK && stream == OR_STREAM_STEP) ws->layout = 1;
@@ -101,15 +101,19 @@ uint32_t or_ws_next32(or_ws *ws)
     }
     if (ws->layout != 0) {
         const uint32_t i = ws->widx++, j = i >> 1, half = i & 1u;        /* word i = half `half` of double j */
-        const uint32_t block = ws->layout == 1 ? 2u * (j >> 2) + half : 2u * j + half;
-        const uint32_t elem = ws->layout == 1 ? (j & 3u) : (ws->lane & 3u);
+        /* layout 1: per-lane split (four doubles per block pair); 2: quad-shared split (one double per lane per pair);
+         * 3: RockSample reset — double j = element j & 3 of block pair j >> 4, rotated right by 8 ((j >> 2) & 3) + 8 */
+        const uint32_t block = ws->layout == 1 ? 2u * (j >> 2) + half : ws->layout == 3 ? 2u * (j >> 4) + half : 2u * j + half;
+        const uint32_t elem = ws->layout == 2 ? (ws->lane & 3u) : (j & 3u);
+        const uint32_t rot = ws->layout == 3 ? ((8u * ((j >> 2) & 3u) + 8u) & 31u) : 0u;
         if (!ws->half_have[half] || ws->half_idx[half] != block) {
             uint32_t c[4] = { ws->ctr[0], ws->ctr[1], ws->ctr[2], ws->ctr[3] | block };
             or_philox4x32_10(c, ws->key, ws->half_blk[half]);
             ws->half_idx[half] = block;
             ws->half_have[half] = 1;
         }
-        return ws->half_blk[half][elem];
+        const uint32_t w = ws->half_blk[half][elem];
+        return rot ? ((w >> rot) | (w << (32u - rot))) : w;
     }
     if ((ws->widx & 3u) == 0) {
         uint32_t c[4] = { ws->ctr[0], ws->ctr[1], ws->ctr[2], ws->ctr[3] | ((ws->widx >> 2) & 0xFFFFFFu) };
