@@ -117,8 +117,8 @@ struct Finisher {
 // RockSample with two lanes per thread: ONE task list per wave (128 lanes) holds
 //   - the 32 sensor blocks of its quads (stream STEP is shared by the four lanes of a quad),
 //   - for CHAIN launches the 32 policy blocks of the next call counter,
-//   - ceil(K/4) reset blocks per resetting lane,
-// i.e. ~63 (CHAIN: ~95) Philox blocks for 128 lane-steps, dealt out 64 per pass.  The lane step therefore runs
+//   - one reset block per resetting lane (the rotated layout: a block's four words carry sixteen rocks' statuses),
+// i.e. ~48 (CHAIN: ~80) Philox blocks for 128 lane-steps, dealt out 64 per pass.  The lane step therefore runs
 // WITHOUT its sensor draw (Env::step_pre) and the observation is completed here from the pooled words.  Tasks and
 // results are exchanged through a wave-private LDS scratch; LDS operations of one wave complete in order, so no
 // barrier is involved.  Low words (needed with probability 2^-27 per draw) are generated per lane on demand.

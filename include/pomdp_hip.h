@@ -28,8 +28,10 @@
  * Random-word contract: Philox4x32-10, key = (seed lo, seed hi),
  * ctr = (lane, t lo, t hi, stream_id << 24 | block); numpy legacy constructions on
  * top (res53 doubles, masked-rejection randint).  RockSample / StochasticRock lay their doubles out
- * "split": high word of double j in block 2(j/4) [reset] or 2j [step, counter word 0 = lane / 4, element
- * lane % 4], low word in the following block, generated only when the high word leaves a comparison undecided;
+ * "split": the high word of a double in one block, its low word in the following block, generated only when the
+ * high word leaves a comparison undecided.  step: block 2j for the step's double j, counter word 0 = lane / 4,
+ * element lane % 4 (one block serves a quad).  reset: rock j = 4q + e reads element e of block 2(j/16) rotated right
+ * by 8q + 8 bits (reset() only uses the top bit of the double: one block serves sixteen rocks).
  * Network's step uses the per-lane form (block 2(j/4), element j % 4) for its one-double-per-machine draws.
  */
 #ifndef POMDP_HIP_H
