@@ -13,10 +13,19 @@ struct NetworkEnv {
     static constexpr bool POOLED_ANY_LPT = false;
     static constexpr bool QUAD_SENSOR = false;
     static constexpr int ABL = 0;
-    struct Shared { int unused; };
+    // nbf[k][v]: the machines that see a failed neighbour when the down machines among 4 k .. 4 k + 3 are the set v
+    // (network.py:82-85) — the OR over the nibbles of ~state replaces a loop over the machines
+    struct Shared { uint32_t nbf[8][16]; };
     struct State { uint32_t w; };
 
-    static __device__ __forceinline__ void stage(Shared &, const Params &, int) {}
+    static __device__ __forceinline__ void stage(Shared &sh, const Params &p, int tid)
+    {
+        if (tid >= 128) return;
+        const int k = tid >> 4, v = tid & 15;
+        uint32_t m = 0;
+        for (int i = 0; i < p.n_machines; ++i) m |= (((p.nb_mask[i] >> (4 * k)) & (uint32_t)v) != 0u ? 1u : 0u) << i;
+        sh.nbf[k][v] = m;
+    }
     static __device__ __forceinline__ int n_actions(const Params &p) { return 2 * p.n_machines + 1; }
     static __device__ __forceinline__ void load(State &st, const uint32_t *state, int64_t, uint32_t i) { st.w = ld_stream(state + i); }
     static __device__ __forceinline__ void store(const State &st, uint32_t *state, int64_t, uint32_t i, bool) { st_stream(state + i, st.w); }
@@ -67,50 +76,49 @@ struct NetworkEnv {
     // wave-uniform, so the Philox block that feeds doubles 2q and 2q+1 is generated under a uniform
     // condition and the only divergence left is the per-lane number of up machines.
     template <class RT>
-    static __device__ __forceinline__ void step(const Shared &, const Params &p, State &st, int a,
+    static __device__ __forceinline__ void step(const Shared &sh, const Params &p, State &st, int a,
                                                 const RngKey &key, uint32_t lane, int &ob, RT &rew, int &done)
     {
         const uint32_t s0 = st.w;
-        uint32_t s = s0;
         const int M = p.n_machines;
         // reward: 2 per up machine with > 2 neighbours, 1 per other up machine   network.py:87-92
-        double r = (double)(__popc(s0) + __popc(s0 & p.deg_gt2_mask));
+        const int n_up = __popc(s0);
+        double r = (double)(n_up + __popc(s0 & p.deg_gt2_mask));
         // machines whose neighbourhood has a failure, from the pre-update state    network.py:82-85
+        const uint32_t down = ~s0 & (M >= 32 ? 0xFFFFFFFFu : ((1u << M) - 1u));
         uint32_t nb_failed = 0;
-        for (int i = 0; i < M; ++i) nb_failed |= ((~s0 & p.nb_mask[i]) != 0u ? 1u : 0u) << i;
+        for (int k = 0; 4 * k < M; ++k) nb_failed |= sh.nbf[k][(down >> (4 * k)) & 15u];      // wave-uniform trip count
         const bool has_action = a < 2 * M;
-        const int n_draws = __popc(s0) + (has_action ? 1 : 0);
+        const int n_draws = n_up + (has_action ? 1 : 0);
         // Split word layout: double j compares by its high word — element j & 3 of block 2 (j >> 2) —
         // and needs its low word (same element of the next block) only on a tie, probability 2^-27 per draw.  One
         // Philox block therefore serves four draws instead of two.  Thresholds as (high 27 bits, low 26 bits).
+        // Draw j belongs to the j-th up machine (lowest set bit of `todo`), draw n_up to the action.
         constexpr uint32_t LO = (1u << 26) - 1u;
         const uint32_t th_fail = (uint32_t)(p.fail_thr >> 26), tl_fail = (uint32_t)p.fail_thr & LO;
         const uint32_t th_nb = (uint32_t)(p.fail_nb_thr >> 26), tl_nb = (uint32_t)p.fail_nb_thr & LO;
         const uint32_t th_obs = (uint32_t)(p.obs_thr >> 26), tl_obs = (uint32_t)p.obs_thr & LO;
-        uint32_t todo = s0;
+        uint32_t todo = s0, s = s0;
         uint4 blk = make_uint4(0, 0, 0, 0);
         bool truthful = false;
-        for (int j = 0; __any(j < n_draws); ++j) {
+        for (int j = 0; __any(j < n_draws); ++j) {                               // j is wave-uniform
             if ((j & 3) == 0) blk = stream_block(key, lane, POMDP_STREAM_STEP, 2u * (uint32_t)(j >> 2));
             const uint32_t H = (j & 3) == 0 ? blk.x : (j & 3) == 1 ? blk.y : (j & 3) == 2 ? blk.z : blk.w;
-            const bool machine_draw = todo != 0u;                                // network.py:94-99, else the action's draw
-            const int i = __ffs((int)todo) - 1;
-            const bool nbf = machine_draw && ((nb_failed >> (i & 31)) & 1u);
+            const uint32_t lb = todo & (0u - todo);                              // this draw's machine; 0 = none left
+            const bool machine_draw = lb != 0u;                                  // network.py:94-99, else the action's draw
+            const bool nbf = (nb_failed & lb) != 0u;
             const uint32_t th = machine_draw ? (nbf ? th_nb : th_fail) : th_obs;
-            const uint32_t tl = machine_draw ? (nbf ? tl_nb : tl_fail) : tl_obs;
             const uint32_t kh = H >> 5;
             bool le = kh < th;                                                   // k53 <= thr, decided by the high word
-            if (kh == th) {                                                      // tie: fetch the low word
+            if (kh == th && j < n_draws) {                                       // tie: fetch the low word
+                const uint32_t tl = machine_draw ? (nbf ? tl_nb : tl_fail) : tl_obs;
                 const uint4 lo = stream_block(key, lane, POMDP_STREAM_STEP, 2u * (uint32_t)(j >> 2) + 1u);
                 const uint32_t L = (j & 3) == 0 ? lo.x : (j & 3) == 1 ? lo.y : (j & 3) == 2 ? lo.z : lo.w;
                 le = (L >> 6) <= tl;
             }
-            if (machine_draw) {
-                if (!le) s &= ~(1u << i);                                        // fails iff k > thr
-                todo &= todo - 1u;
-            } else if (j < n_draws) {
-                truthful = le;
-            }
+            s &= le ? 0xFFFFFFFFu : ~lb;                                         // fails iff k > thr (lb == 0: nothing)
+            truthful = (j == n_up) ? le : truthful;                              // only read when the action draws
+            todo ^= lb;
         }
         ob = 2;
         if (has_action) {                                                        // network.py:101-112
