@@ -151,6 +151,11 @@ struct BattleShipEnv {
             todo &= todo - 1ull;
             const uint32_t glane = (uint32_t)__builtin_amdgcn_readlane((int)lane, src);
             int c = 0;                                                        // next unread word of the stream
+            // One Philox pass yields 64 consecutive words and a ship consumes only a dozen of them, so the window is
+            // kept across ships (and retries): lane l reads word c + l out of the window that starts at c0 through
+            // ds_bpermute, as long as at least 32 of its words are still ahead of the cursor
+            int c0 = -64;
+            uint32_t wword = 0;
             u128 occ = 0;
             int remaining = 0;
             for (int len = p.max_len; len >= 2; --len) {
@@ -161,14 +166,19 @@ struct BattleShipEnv {
                 const u128 hpat = ((u128)1 << (len + 1)) - 1;                 // the L+1 checked cells, from bit 0
                 const u128 vpat = u128_of(p.vpat[len + 1]);
                 for (;;) {
-                    const uint32_t wi = (uint32_t)(c + me);
-                    const uint4 blk = stream_block(key, glane, POMDP_STREAM_RESET, (wi >> 2) & 0xFFFFFFu);
-                    const uint32_t sel = wi & 3u;
-                    const uint32_t word = sel == 0 ? blk.x : sel == 1 ? blk.y : sel == 2 ? blk.z : blk.w;
-                    const uint64_t A = __ballot((word & rmask) <= (uint32_t)(cells - 1));
+                    if (c - c0 > 32) {                                        // wave-uniform: refill the window at the cursor
+                        const uint32_t wi = (uint32_t)(c + me);
+                        const uint4 blk = stream_block(key, glane, POMDP_STREAM_RESET, (wi >> 2) & 0xFFFFFFu);
+                        const uint32_t sel = wi & 3u;
+                        wword = sel == 0 ? blk.x : sel == 1 ? blk.y : sel == 2 ? blk.z : blk.w;
+                        c0 = c;
+                    }
+                    const int off = c - c0, nv = 64 - off;                    // nv words of the window lie at or after the cursor
+                    const uint32_t word = (uint32_t)__shfl((int)wword, (me + off) & 63, 64);
+                    const uint64_t A = __ballot(me < nv && (word & rmask) <= (uint32_t)(cells - 1));
                     const uint64_t D = direction_words(A);
-                    const uint64_t cand = A & ~D & 0x7FFFFFFFFFFFFFFFull;     // position word with its direction word in the window
-                    const uint32_t dirword = (uint32_t)__shfl((int)word, (me + 1) & 63, 64);
+                    const uint64_t cand = A & ~D & ((1ull << (nv - 1)) - 1ull);   // position word with its direction word in the window
+                    const uint32_t dirword = (uint32_t)__shfl((int)wword, (me + off + 1) & 63, 64);
                     const int a0 = (int)(word & rmask);
                     const uint32_t dir = dirword & 3u;
                     const int dx = (dir == 1u) - (dir == 3u), dy = (dir == 0u) - (dir == 2u);   // Compass N E S W
@@ -190,9 +200,9 @@ struct BattleShipEnv {
                         c += r + 2;
                         break;
                     }
-                    // no placement here: word 63 is unread only if it is an accepted position word (its direction
-                    // word lies in the next window)
-                    c += ((A & ~D) >> 63) ? 63 : 64;
+                    // no placement here: the window's last word is unread only if it is an accepted position word (its
+                    // direction word lies in the next window)
+                    c += (((A & ~D) >> (nv - 1)) & 1ull) ? nv - 1 : nv;
                 }
             }
             if (me == src) {
