@@ -45,7 +45,7 @@ struct RockEnv {
     };
     struct State { S s; };
     // what the lane step leaves for the deferred sensor draw (pooled launches fetch H from the wave's task pass)
-    struct Aux { uint32_t th, tl; bool good, want; };
+    struct Aux { uint32_t th; uint8_t r; bool good, want; };   // th: sensor threshold (high 27 bits) of a CHECK of rock r
 
     static constexpr uint32_t LO_MASK = (1u << 26) - 1u;
     static constexpr uint32_t HALF_HI = 1u << 26;            // 2^52 >> 26: the reset's "U > .5" threshold
@@ -399,9 +399,8 @@ struct RockEnv {
         const int r = (a - 5) & 15;
         const uint32_t rp = (ABLATE & 4) ? (uint32_t)(r * 257) : sh.rpos[r];
         const uint32_t d = __builtin_amdgcn_sad_u8(x | (y << 8), rp, 0u);
-        const uint2 thr = (ABLATE & 4) ? make_uint2(d << 22, 0u) : sh.thr[d];
-        aux.th = thr.x;
-        aux.tl = thr.y;
+        aux.th = (ABLATE & 4) ? d << 22 : sh.thr[d].x;
+        aux.r = (uint8_t)r;
         aux.good = ((uint32_t)(s >> (8 + 2 * r)) & 3u) == 2u;
         aux.want = a > 4;
         const int penalty = STOCH ? 0 : -100;                                  // rock.py:117 / rock.py:432
@@ -433,11 +432,77 @@ struct RockEnv {
         if (STOCH) done = left & east;                                         // penalties never terminate (rock.py:503)
         else done = left | missed;
     }
+    // the low 26 bits of the sensor threshold of a CHECK of rock r from where the lane stands (a CHECK does not move it):
+    // only a tie asks for them, so they are looked up there instead of travelling with every step
+    static __device__ __forceinline__ uint32_t thr_lo_of(const Shared &sh, const State &st, int r)
+    {
+        if (ABLATE & 4) return 0u;
+        const uint32_t x = (uint32_t)st.s & 15u, y = ((uint32_t)st.s >> 4) & 15u;
+        return sh.thr[__builtin_amdgcn_sad_u8(x | (y << 8), sh.rpos[r & 15], 0u)].y;
+    }
+    // ---- the lane step from a (position, action) -> outcome table ----------------------------------------------
+    // Everything step_pre derives from the agent's cell and the action alone — where a move leads and whether it leaves
+    // the board, which rock lies under a SAMPLE, the sensor threshold of a CHECK from here — is one 32-bit entry, built
+    // in LDS by the workgroup when a multi-step launch starts (one thread per cell, one pass over the actions) and read
+    // with a single lookup per lane-step instead of two dependent ones plus the arithmetic.  One-word states only (K <= 12).
+    //   a <  4: bits 0-7 = position byte XOR the new position byte (0 if the move leaves), bit 8 = leaves, bit 9 = leaves east
+    //   a == 4: bits 0-4 = bit offset of the cell's rock code in the state (8 if none), bit 6 = a rock id < K lies here
+    //   a >= 5: the sensor threshold's high 27 bits at this distance
+    static constexpr int TAB_ACTIONS = 17;
+    struct StepTab { uint32_t e[TAB_ACTIONS][256]; };
+    static __device__ __forceinline__ void build_tab(StepTab &tab, const Shared &sh, const Params &p, int pos)
+    {
+        const uint32_t x = (uint32_t)pos & 15u, y = (uint32_t)pos >> 4, size = (uint32_t)p.size, K = (uint32_t)p.num_rocks;
+        const int id = sh.grid[x * 16 + y];                                     // grid is indexed [x][y], pos is x | y << 4
+        for (int a = 0; a < 5 + (int)K && a < TAB_ACTIONS; ++a) {
+            uint32_t e;
+            if (a < 4) {
+                const uint32_t nx = x + (uint32_t)((a == 1) - (a == 3)), ny = y + (uint32_t)((a == 0) - (a == 2));
+                const bool inside = max(nx, ny) < size;
+                e = inside ? ((uint32_t)pos ^ (nx | (ny << 4))) : (0x100u | (a == 1 ? 0x200u : 0u));
+            } else if (a == 4) {
+                const bool rock = (uint32_t)id < K;
+                e = rock ? ((8u + 2u * (uint32_t)id) | 0x40u) : 8u;
+            } else {
+                e = sh.thr[__builtin_amdgcn_sad_u8(x | (y << 8), sh.rpos[a - 5], 0u) & 31u].x;
+            }
+            tab.e[a][pos] = e;
+        }
+    }
+    template <class RT>
+    static __device__ __forceinline__ void step_tab(const StepTab &tab, State &st, int a, RT &rew, int &done, Aux &aux)
+    {
+        static_assert(W == 1 && !STOCH, "table-driven step: one-word RockSample states");
+        const uint32_t s = st.s;
+        const uint32_t e = tab.e[a][s & 0xFFu];
+        const bool is_move = a < 4, is_sample = a == 4;
+        // CHECK rock a - 5: its code sits at bits 2 a - 2, 2 a - 1 of the state; good = the upper one (codes are 0, 1, 2)
+        aux.th = e;
+        aux.r = (uint8_t)((a - 5) & 15);
+        aux.good = ((s >> ((2 * a - 1) & 31)) & 1u) != 0u;
+        aux.want = a > 4;
+        // SAMPLE
+        const uint32_t sh_ = e & 31u, code = (s >> sh_) & 3u;
+        const bool sample_ok = ((e & 0x40u) != 0u) & (code != 1u);
+        const bool sampled = is_sample & sample_ok, missed = is_sample & !sample_ok;
+        // move
+        const bool left = is_move & ((e & 0x100u) != 0u), exit_east = is_move & ((e & 0x200u) != 0u);
+        st.s = s ^ (is_move ? (e & 0xFFu) : (sampled ? (code ^ 1u) << sh_ : 0u));
+        const bool good_rock = code == 2u;
+        int rw = (exit_east | (sampled & good_rock)) ? 10 : 0;
+        rw = (sampled & !good_rock) ? -10 : rw;
+        rw = ((left & !exit_east) | missed) ? -100 : rw;
+        rew = rw;
+        done = left | missed;
+    }
+
     // observation of a CHECK from the sensor's high word (rock.py:404-407); `lo` yields the low word on a tie
     template <class LowWord>
-    static __device__ __forceinline__ int sensor_ob(const Aux &aux, uint32_t H, LowWord lo)
+    static __device__ __forceinline__ int sensor_ob(const Shared &sh, const State &st, const Aux &aux, uint32_t H, LowWord lo)
     {
-        const bool correct = k53_le(H, aux.th, aux.tl, lo);
+        const uint32_t kh = H >> 5;
+        bool correct = kh < aux.th;
+        if (kh == aux.th) correct = (lo() >> 6) <= thr_lo_of(sh, st, aux.r);  // probability 2^-27
         return aux.want ? ((aux.good == correct) ? 2 : 1) : 0;
     }
 
@@ -450,7 +515,7 @@ struct RockEnv {
     {
         Aux aux;
         step_pre(sh, p, st, a, rew, done, aux);
-        ob = sensor_ob(aux, H, [&]() { return elem(quad_block(key, lane, 1u), lane & 3u); });
+        ob = sensor_ob(sh, st, aux, H, [&]() { return elem(quad_block(key, lane, 1u), lane & 3u); });
     }
 
     // The whole step for one lane (launches that do not pool the quad's sensor block: one lane per thread, rollouts).
@@ -468,7 +533,7 @@ struct RockEnv {
             Aux aux; RT r2; int d2;
             step_pre(sh, p, nx, a, r2, d2, aux);
             const uint4 h = quad_block(key, lane, 2u);
-            const int o2 = sensor_ob(aux, elem(h, e), [&]() { return elem(quad_block(key, lane, 3u), e); });
+            const int o2 = sensor_ob(sh, nx, aux, elem(h, e), [&]() { return elem(quad_block(key, lane, 3u), e); });
             if (act) { st = nx; rew = r2; done = d2; ob = o2; }
             else { rew = 0; done = 0; ob = 0; }
             return;
@@ -476,7 +541,7 @@ struct RockEnv {
         Aux aux;
         step_pre(sh, p, st, a, rew, done, aux);
         const uint4 h = (ABLATE & 1) ? make_uint4(lane * 2654435761u, lane, 0, 0) : quad_block(key, lane, 0u);
-        ob = sensor_ob(aux, elem(h, e), [&]() { return elem(quad_block(key, lane, 1u), e); });
+        ob = sensor_ob(sh, st, aux, elem(h, e), [&]() { return elem(quad_block(key, lane, 1u), e); });
     }
 };
 

@@ -137,6 +137,14 @@ struct Finisher<RockEnv<W, ABLATE, false>, LPT, CHAIN, typename std::enable_if<(
         Env::step_pre(sh, p, st, a, rew, done, aux);
         ob = 0;
     }
+    // the same from the (position, action) table of a multi-step launch (RockEnv::StepTab)
+    template <class Tab, class RT>
+    static __device__ __forceinline__ void lane_step_tab(const Tab &tab, typename Env::State &st, int a, int &ob, RT &rew,
+                                                         int &done, Aux &aux)
+    {
+        Env::step_tab(tab, st, a, rew, done, aux);
+        ob = 0;
+    }
     // wave-private LDS scratch (one instance each: function-local statics of these accessors)
     static __device__ __forceinline__ uint32_t (&blk_lds())[BLOCK / 64][32 * LPT][4]
     {
@@ -182,7 +190,7 @@ struct Finisher<RockEnv<W, ABLATE, false>, LPT, CHAIN, typename std::enable_if<(
             }
         }
     }
-    static __device__ __forceinline__ void run(const typename Env::Shared &, const typename Env::Params &p,
+    static __device__ __forceinline__ void run(const typename Env::Shared &sh, const typename Env::Params &p,
                                                typename Env::State (&st)[LPT], const bool (&fresh)[LPT], const RngKey &key,
                                                const uint32_t (&lane)[LPT], const RngKey &akey, uint32_t n_act,
                                                int (&a_next)[LPT], const Aux (&aux)[LPT], int (&ob)[LPT])
@@ -215,7 +223,7 @@ struct Finisher<RockEnv<W, ABLATE, false>, LPT, CHAIN, typename std::enable_if<(
         for (int j = 0; j < LPT; ++j) {
             if (!(ABLATE & 2) && fresh[j]) st[j].s = (typename Env::S)((uint64_t)start | ((uint64_t)res_lds[wv][rank[j] & (64 * LPT - 1)] << 8));
             const uint32_t H = (ABLATE & 1) ? lane[j] * 2654435761u : blk_lds()[wv][16 * j + (me >> 2)][me & 3];
-            ob[j] = Env::sensor_ob(aux[j], H, [&]() { return Env::elem(Env::quad_block(key, lane[j], 1u), lane[j] & 3u); });
+            ob[j] = Env::sensor_ob(sh, st[j], aux[j], H, [&]() { return Env::elem(Env::quad_block(key, lane[j], 1u), lane[j] & 3u); });
             if (CHAIN) a_next[j] = (int)__umulhi(blk_lds()[wv][NQ + 16 * j + (me >> 2)][me & 3], n_act);
         }
     }
@@ -399,7 +407,11 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(uint32_t *__restrict__ stat
 template <class Fin, class = void> struct quad_policy_of : std::false_type {};
 template <class Fin> struct quad_policy_of<Fin, std::enable_if_t<Fin::QUAD_POLICY>> : std::true_type {};
 
-template <class Env, int LPT, bool SIMPLE>
+struct NoTab {};
+template <class Env, bool ON> struct step_tab_of { using type = NoTab; };
+template <class Env> struct step_tab_of<Env, true> { using type = typename Env::StepTab; };
+
+template <class Env, int LPT, bool SIMPLE, bool TAB = false>
 __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ state, int32_t *__restrict__ action,
                                                       int32_t *__restrict__ ob, typename Env::Reward *__restrict__ reward,
                                                       uint8_t *__restrict__ done, uint32_t *__restrict__ err, int64_t n,
@@ -407,6 +419,8 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
                                                       int64_t rec, const typename Env::Params p)
 {
     __shared__ typename Env::Shared sh;
+    __shared__ typename step_tab_of<Env, TAB>::type tab;   // TAB: the lane step reads a (position, action) table built below
+    static_assert(!TAB || SIMPLE, "the table-driven step serves the SIMPLE instantiation");
     const bool auto_reset = SIMPLE || (flags & POMDP_AUTO_RESET);
     const uint32_t wg0 = blockIdx.x * (uint32_t)(BLOCK * LPT);
     const uint32_t last = SIMPLE ? (uint32_t)(BLOCK * LPT - 1) : (uint32_t)((uint64_t)(n - 1) - wg0);
@@ -452,6 +466,10 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
                 Env::stage(sh, p, (int)threadIdx.x);
             }
             __syncthreads();
+            if constexpr (TAB) {                         // BLOCK threads = the 256 position bytes
+                Env::build_tab(tab, sh, p, (int)threadIdx.x);
+                __syncthreads();
+            }
         } else {
             if constexpr (Fin::HAS_PREPASS) Fin::prepass(key, glane, akey);
         }
@@ -466,7 +484,8 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
             before[j] = st[j];
             valid[j] = SIMPLE || (unsigned)a_cur[j] < (unsigned)n_act;
             live[j] = SIMPLE || (in_range[j] && valid[j] && !was_done[j]);
-            Fin::lane_step(sh, p, st[j], valid[j] ? a_cur[j] : 0, key, glane[j], o[j], r[j], d[j], aux[j]);
+            if constexpr (TAB) Fin::lane_step_tab(tab, st[j], a_cur[j], o[j], r[j], d[j], aux[j]);
+            else Fin::lane_step(sh, p, st[j], valid[j] ? a_cur[j] : 0, key, glane[j], o[j], r[j], d[j], aux[j]);
             if (!live[j]) { r[j] = 0; d[j] = was_done[j]; }
             fresh[j] = live[j] && d[j] && auto_reset;
             a_next[j] = 0;
@@ -1063,7 +1082,13 @@ static int launch_steps_fused(const typename Env::Params &p, uint32_t *state, in
     bool launched = false;
     if constexpr (Env::POOLED_ANY_LPT && Env::WORDS == 1) {
         if (lpt2 && (flags & POMDP_AUTO_RESET) && n % (4 * BLOCK) == 0 && n >= (1 << 20)) {
-            POMDP_LAUNCH_STEPS(4, true, dim3((unsigned)(n / (4 * BLOCK))));
+            // from 16 steps per launch on the lane step reads the (position, action) table the workgroup builds first
+            if (k >= 16 && p.num_rocks + 5 <= Env::TAB_ACTIONS)
+                hipLaunchKernelGGL((steps_kernel<Env, 4, true, true>), dim3((unsigned)(n / (4 * BLOCK))), dim3(BLOCK), 0,
+                                   (hipStream_t)stream, state, action, ob, reward, done, err, n, make_key(seed, t), lane0, flags,
+                                   make_key(action_seed, t + 1), k, rec, p);
+            else
+                POMDP_LAUNCH_STEPS(4, true, dim3((unsigned)(n / (4 * BLOCK))));
             launched = true;
         }
     }

@@ -910,7 +910,8 @@ def test_heuristic_returns_accumulate_like_the_reference_loop(env, kw, auto):
     assert np.isfinite(ret_done).sum() > 0 or env == "stochrock"
 
 
-FUSE_CASES = [("rock", {}, 1 << 20, True), ("rock", dict(board_size=7, num_rocks=7), (1 << 20) + 1024, True),   # four lanes per thread
+FUSE_CASES = [("rock", {}, 1 << 20, True), ("rock", dict(board_size=7, num_rocks=7), (1 << 20) + 1024, True),   # four lanes per thread,
+              ("rock", dict(board_size=11, num_rocks=11), 1 << 20, True), ("rock", dict(board_size=4, num_rocks=3), 1 << 20, True),  # table-driven step
               ("rock", {}, (1 << 18) + 260, True), ("rock", {}, 4100, True), ("rock", {}, (1 << 18) + 4, False),
               ("rock", dict(board_size=15, num_rocks=15), 1 << 18, True), ("stochrock", {}, 1 << 18, True),
               ("tag", {}, (1 << 18) + 516, True), ("tag", {}, 5000, False), ("tag", dict(num_opponents=3), 1 << 18, True),
