@@ -444,11 +444,11 @@ struct RockEnv {
     // Everything step_pre derives from the agent's cell and the action alone — where a move leads and whether it leaves
     // the board, which rock lies under a SAMPLE, the sensor threshold of a CHECK from here — is one 32-bit entry, built
     // in LDS by the workgroup when a multi-step launch starts (one thread per cell, one pass over the actions) and read
-    // with a single lookup per lane-step instead of two dependent ones plus the arithmetic.  One-word states only (K <= 12).
+    // with a single lookup per lane-step instead of two dependent ones plus the arithmetic.
     //   a <  4: bits 0-7 = position byte XOR the new position byte (0 if the move leaves), bit 8 = leaves, bit 9 = leaves east
-    //   a == 4: bits 0-4 = bit offset of the cell's rock code in the state (8 if none), bit 6 = a rock id < K lies here
+    //   a == 4: bits 0-5 = bit offset of the cell's rock code in the state (8 if none), bit 6 = a rock id < K lies here
     //   a >= 5: the sensor threshold's high 27 bits at this distance
-    static constexpr int TAB_ACTIONS = 17;
+    static constexpr int TAB_ACTIONS = W == 1 ? 17 : 21;                    // 5 + K: K <= 12 in one state word, <= 16 in two
     struct StepTab { uint32_t e[TAB_ACTIONS][256]; };
     static __device__ __forceinline__ void build_tab(StepTab &tab, const Shared &sh, const Params &p, int pos)
     {
@@ -472,22 +472,22 @@ struct RockEnv {
     template <class RT>
     static __device__ __forceinline__ void step_tab(const StepTab &tab, State &st, int a, RT &rew, int &done, Aux &aux)
     {
-        static_assert(W == 1 && !STOCH, "table-driven step: one-word RockSample states");
-        const uint32_t s = st.s;
-        const uint32_t e = tab.e[a][s & 0xFFu];
+        static_assert(!STOCH, "table-driven step: RockEnv");
+        const S s = st.s;
+        const uint32_t e = tab.e[a][(uint32_t)s & 0xFFu];
         const bool is_move = a < 4, is_sample = a == 4;
         // CHECK rock a - 5: its code sits at bits 2 a - 2, 2 a - 1 of the state; good = the upper one (codes are 0, 1, 2)
         aux.th = e;
         aux.r = (uint8_t)((a - 5) & 15);
-        aux.good = ((s >> ((2 * a - 1) & 31)) & 1u) != 0u;
+        aux.good = ((uint32_t)(s >> ((2 * a - 1) & (8 * (int)sizeof(S) - 1))) & 1u) != 0u;
         aux.want = a > 4;
         // SAMPLE
-        const uint32_t sh_ = e & 31u, code = (s >> sh_) & 3u;
+        const uint32_t sh_ = e & 63u, code = (uint32_t)(s >> sh_) & 3u;
         const bool sample_ok = ((e & 0x40u) != 0u) & (code != 1u);
         const bool sampled = is_sample & sample_ok, missed = is_sample & !sample_ok;
         // move
         const bool left = is_move & ((e & 0x100u) != 0u), exit_east = is_move & ((e & 0x200u) != 0u);
-        st.s = s ^ (is_move ? (e & 0xFFu) : (sampled ? (code ^ 1u) << sh_ : 0u));
+        st.s = s ^ (is_move ? (S)(e & 0xFFu) : (sampled ? (S)(code ^ 1u) << sh_ : (S)0));
         const bool good_rock = code == 2u;
         int rw = (exit_east | (sampled & good_rock)) ? 10 : 0;
         rw = (sampled & !good_rock) ? -10 : rw;

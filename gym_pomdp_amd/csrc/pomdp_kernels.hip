@@ -1080,8 +1080,8 @@ static int launch_steps_fused(const typename Env::Params &p, uint32_t *state, in
     // is one word; with two state words (K > 12) the extra registers cost more (5.04 vs 4.74 us).  Only the geometries
     // an env can take are instantiated.
     bool launched = false;
-    if constexpr (Env::POOLED_ANY_LPT && Env::WORDS == 1) {
-        if (lpt2 && (flags & POMDP_AUTO_RESET) && n % (4 * BLOCK) == 0 && n >= (1 << 20)) {
+    if constexpr (Env::POOLED_ANY_LPT) {
+        if (lpt2 && (flags & POMDP_AUTO_RESET) && n % (4 * BLOCK) == 0 && n >= (1 << 20) && (Env::WORDS == 1 || k >= 16)) {
             // from 16 steps per launch on the lane step reads the (position, action) table the workgroup builds first
             if (k >= 16 && p.num_rocks + 5 <= Env::TAB_ACTIONS)
                 hipLaunchKernelGGL((steps_kernel<Env, 4, true, true>), dim3((unsigned)(n / (4 * BLOCK))), dim3(BLOCK), 0,

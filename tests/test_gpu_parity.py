@@ -912,6 +912,7 @@ def test_heuristic_returns_accumulate_like_the_reference_loop(env, kw, auto):
 
 FUSE_CASES = [("rock", {}, 1 << 20, True), ("rock", dict(board_size=7, num_rocks=7), (1 << 20) + 1024, True),   # four lanes per thread,
               ("rock", dict(board_size=11, num_rocks=11), 1 << 20, True), ("rock", dict(board_size=4, num_rocks=3), 1 << 20, True),  # table-driven step
+              ("rock", dict(board_size=15, num_rocks=15), 1 << 20, True),                                            # ... with two state words
               ("rock", {}, (1 << 18) + 260, True), ("rock", {}, 4100, True), ("rock", {}, (1 << 18) + 4, False),
               ("rock", dict(board_size=15, num_rocks=15), 1 << 18, True), ("stochrock", {}, 1 << 18, True),
               ("tag", {}, (1 << 18) + 516, True), ("tag", {}, 5000, False), ("tag", dict(num_opponents=3), 1 << 18, True),
@@ -977,7 +978,7 @@ def test_heuristic_steps_in_one_launch_equal_single_step_launches(env, kw, n, au
     assert ea.call_counter == eb.call_counter
 
 
-COLLECT_CASES = [("rock", {}, 1 << 20, 66), ("rock", {}, (1 << 16) + 260, 70), ("rock", {}, 4100, 130),
+COLLECT_CASES = [("rock", {}, 1 << 20, 66), ("rock", dict(board_size=15, num_rocks=15), 1 << 20, 40), ("rock", {}, (1 << 16) + 260, 70), ("rock", {}, 4100, 130),
                  ("rock", dict(board_size=15, num_rocks=15), 1 << 16, 70), ("stochrock", {}, 1 << 14, 70),
                  ("tag", {}, (1 << 16) + 516, 70), ("tag", dict(num_opponents=3), 1 << 14, 70), ("battleship", {}, 20000, 70),
                  ("tiger", {}, 30000, 70), ("network", {}, 30000, 70)]
