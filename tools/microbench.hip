@@ -327,7 +327,10 @@ int main(int argc, char **argv)
                 hipLaunchKernelGGL((steps_kernel<E, 4, true>), dim3((unsigned)(n / 1024)), dim3(256), 0, 0, state, action, ob, reward, done, err, n, make_key(1, 64 * t), 0u, 1, make_key(1, 64 * t + 1), 64, 0, p);
             }, reps) / 64);
         };
-        fused4(RockEnv<1, 0>{}, "as shipped");
+        printf("  steps_kernel LPT4 simple, lane step from the (position, action) table     %6.2f us/step  <- as shipped from 16 steps per launch\n", time_it([&](int t) {
+            hipLaunchKernelGGL((steps_kernel<RockEnv<1, 0>, 4, true, true>), dim3((unsigned)(n / 1024)), dim3(256), 0, 0, state, action, ob, reward, done, err, n, make_key(1, 64 * t), 0u, 1, make_key(1, 64 * t + 1), 64, 0, p);
+        }, reps) / 64);
+        fused4(RockEnv<1, 0>{}, "arithmetic lane step");
         fused4(RockEnv<1, 1>{}, "without the sensor Philox block (1)");
         fused4(RockEnv<1, 2>{}, "without auto-reset (2)");
         fused4(RockEnv<1, 4>{}, "without the LDS table lookups (4)");
