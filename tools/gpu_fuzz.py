@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity sweep (dev aid, GPU box): random env configs, batch sizes (both launch geometries), lane offsets,
-call counters, auto-reset on/off, valid and invalid actions — HIP path vs the oracle, word for word.
+call counters, auto-reset on/off, valid and invalid actions — HIP path vs the oracle, word for word; one case in eight
+is a trajectory collection (fused launches, up to 2^20 + 2048 lanes) checked row by row against the oracle.
 usage: python tools/gpu_fuzz.py [seconds]"""
 import os
 import sys
@@ -26,10 +27,47 @@ CONFIGS = [
 ]
 
 
+def collect_case(rs):
+    """Trajectory collection (fused launches; from 2^20 lanes RockSample's four-lanes-per-thread loop with the table-driven
+    lane step) against the oracle stepped with the synthetic policy's actions, row by row."""
+    from oracle import philox_ref as px
+    name, env_id, kw = CONFIGS[rs.randint(len(CONFIGS))]
+    pick = rs.rand()
+    n = (1 << 20) + 1024 * int(rs.randint(0, 3)) if pick < 0.4 else \
+        int(rs.randint(1 << 18, (1 << 18) + 3000)) // 4 * 4 if pick < 0.6 else int(rs.randint(8, 6000)) // 4 * 4
+    lane0 = int(rs.randint(0, 1 << 30)) * 4 % ((1 << 32) - n - 8)
+    seed = int(rs.randint(1 << 62))
+    t0 = int(rs.randint(1 << 40)) if rs.rand() < 0.5 else int(rs.randint(100))
+    steps = int(rs.randint(1, 24)) if n >= (1 << 20) else int(rs.randint(1, 80))
+    e = gpa.make(env_id, batch_size=n, seed=seed, lane_offset=lane0, **kw)
+    e.call_counter = t0
+    o = ol.OracleEnv(name, **kw)
+    st = o.new_state(n)
+    ob_o = o.batch_reset(st, seed, lane0, t0, nthreads=8)
+    assert np.array_equal(e.reset().cpu().numpy(), ob_o), (name, kw, n, "reset ob")
+    tr = e.collect_synthetic(steps)
+    done = np.zeros(n, np.uint8)
+    for k in range(steps):
+        t = t0 + 1 + k
+        a = px.synthetic_actions(seed, lane0, n, t, o.n_actions)
+        ob_o, rew_o, done, bad = o.batch_step(st, a, seed, lane0, t, auto_reset=True, done=done, nthreads=8)
+        ctx = ("collect", name, kw, n, lane0, seed, t0, steps, k)
+        assert bad == 0, ctx
+        assert np.array_equal(tr["action"][k].cpu().numpy(), a), ctx
+        assert np.array_equal(tr["ob"][k].cpu().numpy(), ob_o), ctx
+        assert np.array_equal(tr["reward"][k].cpu().numpy(), rew_o), ctx
+        assert np.array_equal(tr["done"][k].cpu().numpy(), done.astype(bool)), ctx
+    assert np.array_equal(e.state.cpu().numpy().view(np.uint32), st), ("collect", name, kw, n, "state")
+
+
 def main(budget):
     rs = np.random.RandomState(int(time.time()) & 0xFFFFFF)
     t_end, cases = time.time() + budget, 0
     while time.time() < t_end:
+        if rs.rand() < 0.12:
+            collect_case(rs)
+            cases += 1
+            continue
         name, env_id, kw = CONFIGS[rs.randint(len(CONFIGS))]
         big = rs.rand() < 0.3
         n = int(rs.randint(1 << 18, (1 << 18) + 3000)) if big else int(rs.randint(2, 6000))
