@@ -32,6 +32,14 @@ __device__ __forceinline__ void st_stream(T *p, T v)
     else *p = v;
 }
 
+// four consecutive 32-bit columns entries of one thread, streamed (16-byte accesses, no allocation in L2)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4 ld_stream4(const uint32_t *p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p)); }
+__device__ __forceinline__ void st_stream4(uint32_t *p, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    __builtin_nontemporal_store(u32x4{a, b, c, d}, reinterpret_cast<u32x4 *>(p));
+}
+
 struct RngKey {          // wave-uniform part of the counter/key
     uint32_t k0, k1;     // seed lo, hi
     uint32_t t_lo, t_hi; // call counter of the batched env

@@ -1061,6 +1061,103 @@ static int launch_step_chain(const typename Env::Params &p, uint32_t *state, int
     return (int)hipGetLastError();
 }
 
+// The fused RockSample loop with a thread owning four CONSECUTIVE lanes — a quad.  RockSample's word contract shares the
+// STEP block and the policy's ACTION block among the four lanes of a quad, so with this mapping both blocks are the
+// thread's own: two Philox blocks per thread-step straight into registers, lane j taking element j — no exchange through LDS,
+// no selects.  A thread's outputs are four consecutive elements of each column: one 16-byte store per int32 column and one
+// 4-byte store of the packed done bytes per step instead of twenty scalar stores; state and first actions come in the
+// same way.  The lane step is the table-driven one; resets are pooled per wave as in Finisher<RockEnv>.  Full workgroups
+// of 1024 lanes and auto-reset only (the launcher's SIMPLE conditions).  Same results as steps_kernel: the mapping of lanes
+// to threads is invisible to a lane's random words.
+template <class Env>
+__global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict__ state, int32_t *__restrict__ action,
+                                                           int32_t *__restrict__ ob, int32_t *__restrict__ reward,
+                                                           uint8_t *__restrict__ done, int64_t n, RngKey key0, uint32_t lane0,
+                                                           RngKey akey0, int k_steps, int64_t rec,
+                                                           const typename Env::Params p)
+{
+    constexpr int W = Env::WORDS;
+    using S = typename Env::S;
+    __shared__ typename Env::Shared sh;
+    __shared__ typename Env::StepTab tab;
+    __shared__ uint8_t src_lds[BLOCK / 64][256];             // reset rank -> lane within the wave's 256
+    __shared__ uint32_t res_lds[BLOCK / 64][256];            // reset rank -> the fresh episode's rock codes
+    const int wv = (int)(threadIdx.x >> 6), me = (int)(threadIdx.x & 63u);
+    const uint32_t l0 = blockIdx.x * (uint32_t)(4 * BLOCK) + 4u * threadIdx.x;   // this thread's first lane within the shard
+    const uint32_t glane0 = lane0 + l0;                                          // ... and its global lane id (a multiple of 4)
+    const uint32_t wave0 = glane0 - 4u * (uint32_t)me;                           // global lane id of the wave's first lane
+    uint32_t *action_w = reinterpret_cast<uint32_t *>(action) + l0, *ob_w = reinterpret_cast<uint32_t *>(ob) + l0;
+    uint32_t *reward_w = reinterpret_cast<uint32_t *>(reward) + l0;
+    uint32_t *done_w = reinterpret_cast<uint32_t *>(done + l0);
+    typename Env::State st[4];
+    int a_cur[4];
+    {
+        const u32x4 a4 = ld_stream4(action_w), s_lo = ld_stream4(state + l0);
+        u32x4 s_hi = {0, 0, 0, 0};
+        if (W == 2) s_hi = ld_stream4(state + n + l0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a_cur[j] = (int)a4[j];
+            st[j].s = (S)((uint64_t)s_lo[j] | ((uint64_t)s_hi[j] << 32));
+        }
+    }
+    action_w += rec;
+    Env::stage(sh, p, (int)threadIdx.x);
+    __syncthreads();
+    Env::build_tab(tab, sh, p, (int)threadIdx.x);
+    __syncthreads();
+    const uint32_t n_act = (uint32_t)Env::n_actions(p);
+    const int K = p.num_rocks;
+    const uint32_t start = (uint32_t)p.start_x | ((uint32_t)p.start_y << 4);
+    const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo, ta0 = ((uint64_t)akey0.t_hi << 32) | akey0.t_lo;
+    for (int s = 0; s < k_steps; ++s) {
+        RngKey key = key0;
+        key.t_lo = (uint32_t)(t0 + (uint64_t)s); key.t_hi = (uint32_t)((t0 + (uint64_t)s) >> 32);
+        const uint64_t ta = ta0 + (uint64_t)s;
+        // the quad's sensor words of this step and its policy words of the next call counter
+        const uint4 sw = philox4x32_10(glane0 >> 2, key.t_lo, key.t_hi, (uint32_t)POMDP_STREAM_STEP << 24, key.k0, key.k1);
+        const uint4 pw = philox4x32_10(glane0 >> 2, (uint32_t)ta, (uint32_t)(ta >> 32), (uint32_t)POMDP_STREAM_ACTION << 24, key.k0, key.k1);
+        const uint32_t H[4] = {sw.x, sw.y, sw.z, sw.w}, P[4] = {pw.x, pw.y, pw.z, pw.w};
+        int r[4], d[4], rank[4], nres = 0;
+        typename Env::Aux aux[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            Env::step_tab(tab, st[j], a_cur[j], r[j], d[j], aux[j]);
+            const uint64_t m = __ballot(d[j] != 0);                            // done lanes start a new episode
+            rank[j] = nres + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            nres += __popcll(m);
+            if (d[j]) src_lds[wv][rank[j]] = (uint8_t)(4 * me + j);
+        }
+        for (int base = 0; base < nres; base += 64) {        // one RESET block per resetting lane, 64 per pass
+            const int q = base + me;
+            if (q < nres) {
+                const uint32_t src_lane = wave0 + (uint32_t)src_lds[wv][q & 255];
+                const uint4 w = philox4x32_10(src_lane, key.t_lo, key.t_hi, (uint32_t)POMDP_STREAM_RESET << 24, key.k0, key.k1);
+                res_lds[wv][q & 255] = Env::reset_codes(w, key, src_lane, K);
+            }
+        }
+        uint32_t o[4], a_next[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (d[j]) st[j].s = (S)((uint64_t)start | ((uint64_t)res_lds[wv][rank[j] & 255] << 8));
+            const uint32_t lane = glane0 + (uint32_t)j;
+            o[j] = (uint32_t)Env::sensor_ob(sh, st[j], aux[j], H[j], [&]() { return Env::elem(Env::quad_block(key, lane, 1u), (uint32_t)j); });
+            a_next[j] = __umulhi(P[j], n_act);
+            a_cur[j] = (int)a_next[j];
+        }
+        st_stream4(action_w, a_next[0], a_next[1], a_next[2], a_next[3]);
+        st_stream4(ob_w, o[0], o[1], o[2], o[3]);
+        st_stream4(reward_w, (uint32_t)r[0], (uint32_t)r[1], (uint32_t)r[2], (uint32_t)r[3]);
+        st_stream(done_w, (uint32_t)d[0] | ((uint32_t)d[1] << 8) | ((uint32_t)d[2] << 16) | ((uint32_t)d[3] << 24));
+        action_w += rec; ob_w += rec; reward_w += rec; done_w += rec / 4;
+    }
+    // the state is the loop's carry: it reaches memory once
+    st_stream4(state + l0, (uint32_t)st[0].s, (uint32_t)st[1].s, (uint32_t)st[2].s, (uint32_t)st[3].s);
+    if (W == 2)
+        st_stream4(state + n + l0, (uint32_t)((uint64_t)st[0].s >> 32), (uint32_t)((uint64_t)st[1].s >> 32),
+                   (uint32_t)((uint64_t)st[2].s >> 32), (uint32_t)((uint64_t)st[3].s >> 32));
+}
+
 // the same as k launch_step_chain calls at t, t + 1, ..., in one launch
 template <class Env>
 static int launch_steps_fused(const typename Env::Params &p, uint32_t *state, int32_t *action, int32_t *ob,
@@ -1083,9 +1180,10 @@ static int launch_steps_fused(const typename Env::Params &p, uint32_t *state, in
     if constexpr (Env::POOLED_ANY_LPT) {
         if (lpt2 && (flags & POMDP_AUTO_RESET) && n % (4 * BLOCK) == 0 && n >= (1 << 20) && (Env::WORDS == 1 || k >= 16)) {
             // from 16 steps per launch on the lane step reads the (position, action) table the workgroup builds first
-            if (k >= 16 && p.num_rocks + 5 <= Env::TAB_ACTIONS)
-                hipLaunchKernelGGL((steps_kernel<Env, 4, true, true>), dim3((unsigned)(n / (4 * BLOCK))), dim3(BLOCK), 0,
-                                   (hipStream_t)stream, state, action, ob, reward, done, err, n, make_key(seed, t), lane0, flags,
+            // (and a thread owns a quad of consecutive lanes: steps_quad_kernel; rows of a 16-byte-aligned pitch)
+            if (k >= 16 && p.num_rocks + 5 <= Env::TAB_ACTIONS && rec % 4 == 0 && action_seed == seed)
+                hipLaunchKernelGGL((steps_quad_kernel<Env>), dim3((unsigned)(n / (4 * BLOCK))), dim3(BLOCK), 0,
+                                   (hipStream_t)stream, state, action, ob, reward, done, n, make_key(seed, t), lane0,
                                    make_key(action_seed, t + 1), k, rec, p);
             else
                 POMDP_LAUNCH_STEPS(4, true, dim3((unsigned)(n / (4 * BLOCK))));

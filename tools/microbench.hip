@@ -126,6 +126,30 @@ __global__ __launch_bounds__(256) void philox_kernel(uint32_t *__restrict__ out,
 
 __global__ void empty_kernel() {}
 
+// the same floor with a thread owning four CONSECUTIVE lanes: one 16-byte store per int32 column and one 4-byte store for
+// the done bytes per thread-step instead of twenty scalar stores
+template <int NB>
+__global__ __launch_bounds__(256) void fused_store_floor_v4(int32_t *__restrict__ action, int32_t *__restrict__ ob,
+                                                            int32_t *__restrict__ reward, uint8_t *__restrict__ done, int k,
+                                                            int64_t rec, RngKey key)
+{
+    const uint32_t l0 = blockIdx.x * 1024u + 4u * threadIdx.x;
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    v4i *a_w = reinterpret_cast<v4i *>(action + l0), *o_w = reinterpret_cast<v4i *>(ob + l0), *r_w = reinterpret_cast<v4i *>(reward + l0);
+    uint32_t *d_w = reinterpret_cast<uint32_t *>(done + l0);
+    uint32_t v = threadIdx.x;
+    for (int s = 0; s < k; ++s) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) { const uint4 w = stream_block(key, l0 >> 2, (uint32_t)s, (uint32_t)b); v ^= w.x ^ w.y ^ w.z ^ w.w; }
+        __builtin_nontemporal_store(v4i{(int)v, (int)v + 1, (int)v + 2, (int)v + 3}, a_w);
+        __builtin_nontemporal_store(v4i{(int)(v & 3u), 0, 1, 2}, o_w);
+        __builtin_nontemporal_store(v4i{(int)(v >> 7), 0, 10, -10}, r_w);
+        st_stream(d_w, v & 0x01010101u);
+        v = v * 5u + 1u;
+        a_w += rec / 4; o_w += rec / 4; r_w += rec / 4; d_w += rec / 4;
+    }
+}
+
 // the fused loop's store pattern with NB Philox blocks per THREAD-step of register work and nothing else: k steps, four lanes per
 // thread, each step writes action / ob / reward (4 B) and done (1 B) per lane with the product's write-through stores; rows
 // advance by rec elements per step.  The floor for a launch that has to emit 13 B per lane-step.
@@ -346,6 +370,11 @@ int main(int argc, char **argv)
             printf(" %6.2f", time_it([&](int t) { hipLaunchKernelGGL((fused_store_floor<1>), dim3((unsigned)(n / 1024)), dim3(256), 0, 0, ta, to, tr, td, 64, rec, make_key(1, t)); }, reps) / 64);
             printf(" %6.2f", time_it([&](int t) { hipLaunchKernelGGL((fused_store_floor<2>), dim3((unsigned)(n / 1024)), dim3(256), 0, 0, ta, to, tr, td, 64, rec, make_key(1, t)); }, reps) / 64);
             printf(" %6.2f  |", time_it([&](int t) { hipLaunchKernelGGL((fused_store_floor<3>), dim3((unsigned)(n / 1024)), dim3(256), 0, 0, ta, to, tr, td, 64, rec, make_key(1, t)); }, reps) / 64);
+        }
+        printf("\n   ... a thread owning four consecutive lanes (16-byte stores), 0 / 2 blocks:");
+        for (int64_t rec : {(int64_t)0, n}) {
+            printf(" %6.2f", time_it([&](int t) { hipLaunchKernelGGL((fused_store_floor_v4<0>), dim3((unsigned)(n / 1024)), dim3(256), 0, 0, ta, to, tr, td, 64, rec, make_key(1, t)); }, reps) / 64);
+            printf(" %6.2f  |", time_it([&](int t) { hipLaunchKernelGGL((fused_store_floor_v4<2>), dim3((unsigned)(n / 1024)), dim3(256), 0, 0, ta, to, tr, td, 64, rec, make_key(1, t)); }, reps) / 64);
         }
         printf("\n");
         CK(hipFree(ta)); CK(hipFree(to)); CK(hipFree(tr)); CK(hipFree(td));
