@@ -45,9 +45,9 @@ def traffic_json(root, out_path, workload):
            "calibrated: the step kernels read exactly 8192 KB of state + action per launch)",
            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of `python bench.py --prewarm 0 "
                      "--warmup 64 --steps 640 --no-cpu-baseline` (tools/gpu_profile_round.sh); `fused` = one 64-step "
-                     "steps_kernel launch, `chain` / `plain` = one single-step launch"}
+                     "steps_quad_kernel / steps_kernel launch, `chain` / `plain` = one single-step launch"}
     for key, pat in (("plain", "%step_kernel<%>, _, false>(%"), ("chain", "%step_kernel<%>, _, true>(%"),
-                     ("fused", "%steps_kernel<%")):
+                     ("fused", "%steps%kernel<%")):
         vals = []
         for db, cn in ((f, "FETCH_SIZE"), (w, "WRITE_SIZE")):
             r = sqlite3.connect(db).execute("select avg(value), count(*) from counters_collection where counter_name=? "
