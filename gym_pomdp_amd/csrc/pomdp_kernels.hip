@@ -1158,6 +1158,100 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
                    (uint32_t)((uint64_t)st[2].s >> 32), (uint32_t)((uint64_t)st[3].s >> 32));
 }
 
+// Tag (one opponent) with a quad per thread: the policy's ACTION block is the thread's own, the flights of failed TAGs
+// (about a fifth of the lanes) and the rare resets are pooled per wave of 256 lanes — one Philox pass instead of the two per
+// 256 lanes that Finisher<TagEnv, 2> needs with the policy blocks in its task list — and the outputs leave as 16-byte stores.
+__global__ __launch_bounds__(BLOCK) void tag_steps_quad_kernel(uint32_t *__restrict__ state, int32_t *__restrict__ action,
+                                                               int32_t *__restrict__ ob, float *__restrict__ reward,
+                                                               uint8_t *__restrict__ done, int64_t n, RngKey key0,
+                                                               uint32_t lane0, RngKey akey0, int k_steps, int64_t rec,
+                                                               const TagEnv::Params p)
+{
+    using Env = TagEnv;
+    __shared__ Env::Shared sh;
+    __shared__ uint8_t src_lds[BLOCK / 64][256];             // task rank -> lane within the wave's 256
+    __shared__ uint32_t res_lds[BLOCK / 64][256][4];         // task rank -> its Philox block
+    const int wv = (int)(threadIdx.x >> 6), me = (int)(threadIdx.x & 63u);
+    const uint32_t l0 = blockIdx.x * (uint32_t)(4 * BLOCK) + 4u * threadIdx.x;
+    const uint32_t glane0 = lane0 + l0, wave0 = glane0 - 4u * (uint32_t)me;
+    uint32_t *action_w = reinterpret_cast<uint32_t *>(action) + l0, *ob_w = reinterpret_cast<uint32_t *>(ob) + l0;
+    uint32_t *reward_w = reinterpret_cast<uint32_t *>(reward) + l0;
+    uint32_t *done_w = reinterpret_cast<uint32_t *>(done + l0);
+    Env::State st[4];
+    int a_cur[4];
+    {
+        const u32x4 a4 = ld_stream4(action_w), s4 = ld_stream4(state + l0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a_cur[j] = (int)a4[j]; st[j].w = s4[j]; }
+    }
+    action_w += rec;
+    Env::stage(sh, p, (int)threadIdx.x);
+    __syncthreads();
+    const uint32_t n_act = (uint32_t)Env::n_actions(p);
+    const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo, ta0 = ((uint64_t)akey0.t_hi << 32) | akey0.t_lo;
+    for (int s = 0; s < k_steps; ++s) {
+        RngKey key = key0;
+        key.t_lo = (uint32_t)(t0 + (uint64_t)s); key.t_hi = (uint32_t)((t0 + (uint64_t)s) >> 32);
+        const uint64_t ta = ta0 + (uint64_t)s;
+        const uint4 pw = philox4x32_10(glane0 >> 2, (uint32_t)ta, (uint32_t)(ta >> 32), (uint32_t)POMDP_STREAM_ACTION << 24, key.k0, key.k1);
+        const uint32_t P[4] = {pw.x, pw.y, pw.z, pw.w};
+        int o[4], d[4];
+        float r[4];
+        Env::Flight f[4];
+        uint64_t fm[4], rm[4];
+        int nfl = 0, nrs = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            Env::step_one_opponent_pre(sh, p, st[j], a_cur[j], o[j], r[j], d[j], f[j]);
+            fm[j] = __ballot(f[j].need);
+            rm[j] = __ballot(d[j] != 0);
+            nfl += __popcll(fm[j]);
+            nrs += __popcll(rm[j]);
+        }
+        // task list: the flights, then the resets (a lane is never both: a failed TAG does not end the episode)
+        auto below = [&](uint64_t m) {
+            return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        };
+        int rank[4], cf = 0, cr = nfl;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            rank[j] = f[j].need ? cf + below(fm[j]) : cr + below(rm[j]);
+            cf += __popcll(fm[j]);
+            cr += __popcll(rm[j]);
+            if (f[j].need || d[j]) src_lds[wv][rank[j] & 255] = (uint8_t)(4 * me + j);
+        }
+        const int ntask = nfl + nrs;
+        for (int base = 0; base < ntask; base += 64) {
+            const int q = base + me;
+            if (q < ntask) {
+                const uint32_t src_lane = wave0 + (uint32_t)src_lds[wv][q & 255];
+                const uint32_t strm = q < nfl ? POMDP_STREAM_STEP : POMDP_STREAM_RESET;
+                const uint4 w = philox4x32_10(src_lane, key.t_lo, key.t_hi, strm << 24, key.k0, key.k1);
+                uint32_t *dst = res_lds[wv][q & 255];
+                dst[0] = w.x; dst[1] = w.y; dst[2] = w.z; dst[3] = w.w;
+            }
+        }
+        uint32_t a_next[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t *res = res_lds[wv][rank[j] & 255];
+            if (f[j].need) Env::flee(sh, p, st[j], f[j], res[0], res[1], res[2]);
+            if (d[j]) {
+                const uint4 b = make_uint4(res[0], res[1], res[2], res[3]);
+                if (!Env::reset_from_block(p, st[j], b)) Env::reset(sh, p, st[j], key, glane0 + (uint32_t)j);   // rejections ran past the block
+            }
+            a_next[j] = __umulhi(P[j], n_act);
+            a_cur[j] = (int)a_next[j];
+        }
+        st_stream4(action_w, a_next[0], a_next[1], a_next[2], a_next[3]);
+        st_stream4(ob_w, (uint32_t)o[0], (uint32_t)o[1], (uint32_t)o[2], (uint32_t)o[3]);
+        st_stream4(reward_w, __float_as_uint(r[0]), __float_as_uint(r[1]), __float_as_uint(r[2]), __float_as_uint(r[3]));
+        st_stream(done_w, (uint32_t)d[0] | ((uint32_t)d[1] << 8) | ((uint32_t)d[2] << 16) | ((uint32_t)d[3] << 24));
+        action_w += rec; ob_w += rec; reward_w += rec; done_w += rec / 4;
+    }
+    st_stream4(state + l0, st[0].w, st[1].w, st[2].w, st[3].w);
+}
+
 // the same as k launch_step_chain calls at t, t + 1, ..., in one launch
 template <class Env>
 static int launch_steps_fused(const typename Env::Params &p, uint32_t *state, int32_t *action, int32_t *ob,
@@ -1177,6 +1271,14 @@ static int launch_steps_fused(const typename Env::Params &p, uint32_t *state, in
     // is one word; with two state words (K > 12) the extra registers cost more (5.04 vs 4.74 us).  Only the geometries
     // an env can take are instantiated.
     bool launched = false;
+    if constexpr (std::is_same<Env, TagEnv>::value) {
+        if (lpt2 && (flags & POMDP_AUTO_RESET) && n % (4 * BLOCK) == 0 && n >= (1 << 20) && p.num_opponents == 1 &&
+            rec % 4 == 0 && action_seed == seed) {
+            hipLaunchKernelGGL(tag_steps_quad_kernel, dim3((unsigned)(n / (4 * BLOCK))), dim3(BLOCK), 0, (hipStream_t)stream, state,
+                               action, ob, reward, done, n, make_key(seed, t), lane0, make_key(action_seed, t + 1), k, rec, p);
+            launched = true;
+        }
+    }
     if constexpr (Env::POOLED_ANY_LPT) {
         if (lpt2 && (flags & POMDP_AUTO_RESET) && n % (4 * BLOCK) == 0 && n >= (1 << 20) && (Env::WORDS == 1 || k >= 16)) {
             // from 16 steps per launch on the lane step reads the (position, action) table the workgroup builds first

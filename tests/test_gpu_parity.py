@@ -916,6 +916,7 @@ FUSE_CASES = [("rock", {}, 1 << 20, True), ("rock", dict(board_size=7, num_rocks
               ("rock", {}, (1 << 18) + 260, True), ("rock", {}, 4100, True), ("rock", {}, (1 << 18) + 4, False),
               ("rock", dict(board_size=15, num_rocks=15), 1 << 18, True), ("stochrock", {}, 1 << 18, True),
               ("tag", {}, (1 << 18) + 516, True), ("tag", {}, 5000, False), ("tag", dict(num_opponents=3), 1 << 18, True),
+              ("tag", {}, 1 << 20, True), ("tag", dict(num_opponents=2), 1 << 20, True),                              # a quad per thread / not
               ("battleship", {}, 20000, True), ("battleship", dict(board_size=(10, 10), max_len=5), 8192, True),
               ("tiger", {}, 30000, True), ("tiger", {}, 30000, False), ("network", {}, 30000, True)]
 
@@ -980,7 +981,7 @@ def test_heuristic_steps_in_one_launch_equal_single_step_launches(env, kw, n, au
 
 COLLECT_CASES = [("rock", {}, 1 << 20, 66), ("rock", dict(board_size=15, num_rocks=15), 1 << 20, 40), ("rock", {}, (1 << 16) + 260, 70), ("rock", {}, 4100, 130),
                  ("rock", dict(board_size=15, num_rocks=15), 1 << 16, 70), ("stochrock", {}, 1 << 14, 70),
-                 ("tag", {}, (1 << 16) + 516, 70), ("tag", dict(num_opponents=3), 1 << 14, 70), ("battleship", {}, 20000, 70),
+                 ("tag", {}, (1 << 16) + 516, 70), ("tag", {}, 1 << 20, 70), ("tag", dict(num_opponents=3), 1 << 14, 70), ("battleship", {}, 20000, 70),
                  ("tiger", {}, 30000, 70), ("network", {}, 30000, 70)]
 
 
