@@ -1252,6 +1252,69 @@ __global__ __launch_bounds__(BLOCK) void tag_steps_quad_kernel(uint32_t *__restr
     st_stream4(state + l0, st[0].w, st[1].w, st[2].w, st[3].w);
 }
 
+// The generic fused loop with a quad per thread, for envs whose lane step is light enough that four of them fit a thread
+// (Env::QUAD_FUSED; one state word): the policy's ACTION block is the thread's own, Env::step / Env::reset_where run per
+// lane as in steps_kernel, the outputs leave as 16-byte stores.  Full workgroups of 1024 lanes, auto-reset.
+template <class Env, class = void> struct quad_fused : std::false_type {};
+template <class Env> struct quad_fused<Env, std::enable_if_t<Env::QUAD_FUSED>> : std::true_type {};
+
+template <class Env>
+__global__ __launch_bounds__(BLOCK) void steps_quad_generic_kernel(uint32_t *__restrict__ state, int32_t *__restrict__ action,
+                                                                   int32_t *__restrict__ ob,
+                                                                   typename Env::Reward *__restrict__ reward,
+                                                                   uint8_t *__restrict__ done, int64_t n, RngKey key0,
+                                                                   uint32_t lane0, RngKey akey0, int k_steps, int64_t rec,
+                                                                   const typename Env::Params p)
+{
+    static_assert(Env::WORDS == 1 && sizeof(typename Env::Reward) == 4, "one state word, 4-byte rewards");
+    __shared__ typename Env::Shared sh;
+    const uint32_t l0 = blockIdx.x * (uint32_t)(4 * BLOCK) + 4u * threadIdx.x;
+    const uint32_t glane0 = lane0 + l0;
+    uint32_t *action_w = reinterpret_cast<uint32_t *>(action) + l0, *ob_w = reinterpret_cast<uint32_t *>(ob) + l0;
+    uint32_t *reward_w = reinterpret_cast<uint32_t *>(reward) + l0;
+    uint32_t *done_w = reinterpret_cast<uint32_t *>(done + l0);
+    typename Env::State st[4];
+    int a_cur[4];
+    {
+        const u32x4 a4 = ld_stream4(action_w);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a_cur[j] = (int)a4[j]; Env::load(st[j], state, n, l0 + (uint32_t)j); }
+    }
+    action_w += rec;
+    Env::stage(sh, p, (int)threadIdx.x);
+    __syncthreads();
+    const uint32_t n_act = (uint32_t)Env::n_actions(p);
+    const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo, ta0 = ((uint64_t)akey0.t_hi << 32) | akey0.t_lo;
+    for (int s = 0; s < k_steps; ++s) {
+        RngKey key = key0;
+        key.t_lo = (uint32_t)(t0 + (uint64_t)s); key.t_hi = (uint32_t)((t0 + (uint64_t)s) >> 32);
+        const uint64_t ta = ta0 + (uint64_t)s;
+        const uint4 pw = philox4x32_10(glane0 >> 2, (uint32_t)ta, (uint32_t)(ta >> 32), (uint32_t)POMDP_STREAM_ACTION << 24, key.k0, key.k1);
+        const uint32_t P[4] = {pw.x, pw.y, pw.z, pw.w};
+        uint32_t o4[4], r4[4], a_next[4], dpack = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int o, d;
+            typename Env::Reward r;
+            const uint32_t lane = glane0 + (uint32_t)j;
+            Env::step(sh, p, st[j], a_cur[j], key, lane, o, r, d);
+            Env::reset_where(sh, p, st[j], d != 0, key, lane);                 // wave-convergent: every lane calls it
+            o4[j] = (uint32_t)o;
+            __builtin_memcpy(&r4[j], &r, 4);
+            dpack |= (uint32_t)(d != 0) << (8 * j);
+            a_next[j] = __umulhi(P[j], n_act);
+            a_cur[j] = (int)a_next[j];
+        }
+        st_stream4(action_w, a_next[0], a_next[1], a_next[2], a_next[3]);
+        st_stream4(ob_w, o4[0], o4[1], o4[2], o4[3]);
+        st_stream4(reward_w, r4[0], r4[1], r4[2], r4[3]);
+        st_stream(done_w, dpack);
+        action_w += rec; ob_w += rec; reward_w += rec; done_w += rec / 4;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Env::store(st[j], state, n, l0 + (uint32_t)j, true);
+}
+
 // the same as k launch_step_chain calls at t, t + 1, ..., in one launch
 template <class Env>
 static int launch_steps_fused(const typename Env::Params &p, uint32_t *state, int32_t *action, int32_t *ob,
@@ -1276,6 +1339,14 @@ static int launch_steps_fused(const typename Env::Params &p, uint32_t *state, in
             rec % 4 == 0 && action_seed == seed) {
             hipLaunchKernelGGL(tag_steps_quad_kernel, dim3((unsigned)(n / (4 * BLOCK))), dim3(BLOCK), 0, (hipStream_t)stream, state,
                                action, ob, reward, done, n, make_key(seed, t), lane0, make_key(action_seed, t + 1), k, rec, p);
+            launched = true;
+        }
+    }
+    if constexpr (quad_fused<Env>::value) {
+        if ((flags & POMDP_AUTO_RESET) && n % (4 * BLOCK) == 0 && n >= (1 << 20) && rec % 4 == 0 && action_seed == seed) {
+            hipLaunchKernelGGL((steps_quad_generic_kernel<Env>), dim3((unsigned)(n / (4 * BLOCK))), dim3(BLOCK), 0,
+                               (hipStream_t)stream, state, action, ob, reward, done, n, make_key(seed, t), lane0,
+                               make_key(action_seed, t + 1), k, rec, p);
             launched = true;
         }
     }

@@ -918,7 +918,8 @@ FUSE_CASES = [("rock", {}, 1 << 20, True), ("rock", dict(board_size=7, num_rocks
               ("tag", {}, (1 << 18) + 516, True), ("tag", {}, 5000, False), ("tag", dict(num_opponents=3), 1 << 18, True),
               ("tag", {}, 1 << 20, True), ("tag", dict(num_opponents=2), 1 << 20, True),                              # a quad per thread / not
               ("battleship", {}, 20000, True), ("battleship", dict(board_size=(10, 10), max_len=5), 8192, True),
-              ("tiger", {}, 30000, True), ("tiger", {}, 30000, False), ("network", {}, 30000, True)]
+              ("tiger", {}, 30000, True), ("tiger", {}, 30000, False), ("network", {}, 30000, True),
+              ("tiger", {}, 1 << 20, True), ("network", {}, 1 << 20, True)]                                          # a quad per thread / not
 
 
 @pytest.mark.parametrize("env,kw,n,auto", FUSE_CASES, ids=["%s-%d-%s" % (c[0], c[2], "auto" if c[3] else "frozen") for c in FUSE_CASES])
