@@ -128,7 +128,7 @@ __global__ void empty_kernel() {}
 
 // the same floor with a thread owning four CONSECUTIVE lanes: one 16-byte store per int32 column and one 4-byte store for
 // the done bytes per thread-step instead of twenty scalar stores
-template <int NB>
+template <int NB, int POLICY = 0>   // POLICY 0: nontemporal, 1: plain cached, 2: write-through (sc1)
 __global__ __launch_bounds__(256) void fused_store_floor_v4(int32_t *__restrict__ action, int32_t *__restrict__ ob,
                                                             int32_t *__restrict__ reward, uint8_t *__restrict__ done, int k,
                                                             int64_t rec, RngKey key)
@@ -141,10 +141,15 @@ __global__ __launch_bounds__(256) void fused_store_floor_v4(int32_t *__restrict_
     for (int s = 0; s < k; ++s) {
 #pragma unroll
         for (int b = 0; b < NB; ++b) { const uint4 w = stream_block(key, l0 >> 2, (uint32_t)s, (uint32_t)b); v ^= w.x ^ w.y ^ w.z ^ w.w; }
-        __builtin_nontemporal_store(v4i{(int)v, (int)v + 1, (int)v + 2, (int)v + 3}, a_w);
-        __builtin_nontemporal_store(v4i{(int)(v & 3u), 0, 1, 2}, o_w);
-        __builtin_nontemporal_store(v4i{(int)(v >> 7), 0, 10, -10}, r_w);
-        st_stream(d_w, v & 0x01010101u);
+        auto put = [&](v4i *q, v4i x) {
+            if (POLICY == 0) __builtin_nontemporal_store(x, q);
+            else if (POLICY == 1) *q = x;
+            else asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(q), "v"(x) : "memory");
+        };
+        put(a_w, v4i{(int)v, (int)v + 1, (int)v + 2, (int)v + 3});
+        put(o_w, v4i{(int)(v & 3u), 0, 1, 2});
+        put(r_w, v4i{(int)(v >> 7), 0, 10, -10});
+        if (POLICY == 1) *d_w = v & 0x01010101u; else st_stream(d_w, v & 0x01010101u);
         v = v * 5u + 1u;
         a_w += rec / 4; o_w += rec / 4; r_w += rec / 4; d_w += rec / 4;
     }
@@ -375,6 +380,11 @@ int main(int argc, char **argv)
         for (int64_t rec : {(int64_t)0, n}) {
             printf(" %6.2f", time_it([&](int t) { hipLaunchKernelGGL((fused_store_floor_v4<0>), dim3((unsigned)(n / 1024)), dim3(256), 0, 0, ta, to, tr, td, 64, rec, make_key(1, t)); }, reps) / 64);
             printf(" %6.2f  |", time_it([&](int t) { hipLaunchKernelGGL((fused_store_floor_v4<2>), dim3((unsigned)(n / 1024)), dim3(256), 0, 0, ta, to, tr, td, 64, rec, make_key(1, t)); }, reps) / 64);
+        }
+        printf("\n   ... the same with plain cached | write-through stores, 2 blocks, same row, own row:");
+        for (int64_t rec : {(int64_t)0, n}) {
+            printf(" %6.2f", time_it([&](int t) { hipLaunchKernelGGL((fused_store_floor_v4<2, 1>), dim3((unsigned)(n / 1024)), dim3(256), 0, 0, ta, to, tr, td, 64, rec, make_key(1, t)); }, reps) / 64);
+            printf(" %6.2f  |", time_it([&](int t) { hipLaunchKernelGGL((fused_store_floor_v4<2, 2>), dim3((unsigned)(n / 1024)), dim3(256), 0, 0, ta, to, tr, td, 64, rec, make_key(1, t)); }, reps) / 64);
         }
         printf("\n");
         CK(hipFree(ta)); CK(hipFree(to)); CK(hipFree(tr)); CK(hipFree(td));
