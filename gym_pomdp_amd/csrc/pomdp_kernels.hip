@@ -12,6 +12,7 @@
 
 #include "../../include/pomdp_hip.h"
 #include "envs.hip.h"
+#include <cstdlib>
 #include "philox.hip.h"
 
 namespace pomdp {
@@ -1342,8 +1343,9 @@ static int launch_steps_fused(const typename Env::Params &p, uint32_t *state, in
             launched = true;
         }
     }
+    static const bool no_quad = getenv("POMDP_NO_QUAD") != nullptr;       // A/B switch for tools/ (timing experiments)
     if constexpr (quad_fused<Env>::value) {
-        if ((flags & POMDP_AUTO_RESET) && n % (4 * BLOCK) == 0 && n >= (1 << 20) && rec % 4 == 0 && action_seed == seed) {
+        if (!no_quad && (flags & POMDP_AUTO_RESET) && n % (4 * BLOCK) == 0 && n >= (1 << 20) && rec % 4 == 0 && action_seed == seed) {
             hipLaunchKernelGGL((steps_quad_generic_kernel<Env>), dim3((unsigned)(n / (4 * BLOCK))), dim3(BLOCK), 0,
                                (hipStream_t)stream, state, action, ob, reward, done, n, make_key(seed, t), lane0,
                                make_key(action_seed, t + 1), k, rec, p);
