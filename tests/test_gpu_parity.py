@@ -1051,3 +1051,29 @@ def test_collect_row_pitch_through_the_c_abi():
         _native.ENV_KIND["rock"], b._params_ref, b._state.data_ptr(), act.data_ptr(), ob.data_ptr(), rew.data_ptr(),
         done.data_ptr(), b._err.data_ptr(), n, b._seed, b.lane_offset, 0, steps, n - 4, _native.POMDP_AUTO_RESET, None)
     assert bad == -1                                        # POMDP_E_BADARG: pitch < n
+
+
+@pytest.mark.parametrize("kw,auto", [({}, False), ({}, True), (dict(board_size=15, num_rocks=15), False)],
+                         ids=["rock_7_8-frozen", "rock_7_8-auto", "rock_15_15-frozen"])
+def test_step_contract_over_a_whole_2_20_batch(oracle_lib, kw, auto):
+    """env.step() at 2^20 lanes against the oracle over the WHOLE batch, with caller-supplied actions of which a few are out
+    of range and, without auto-reset, with lanes freezing as their episodes end."""
+    n, seed, lane0 = 1 << 20, 606, 1 << 12
+    e = make_env("rock", kw, batch_size=n, seed=seed, lane_offset=lane0, auto_reset=auto, reuse_buffers=True)
+    o = oracle_lib.OracleEnv("rock", **kw)
+    st = o.new_state(n)
+    assert np.array_equal(np_(e.reset()), o.batch_reset(st, seed, lane0, 0, nthreads=8))
+    rs = np.random.RandomState(5)
+    done = np.zeros(n, np.uint8)
+    bad_total = 0
+    for t in range(1, 9):
+        a = rs.randint(o.n_actions, size=n).astype(np.int32)
+        idx = rs.randint(n, size=2000)
+        a[idx] = rs.choice([-1, o.n_actions, 1 << 20], size=len(idx))
+        ob, rew, done, bad = o.batch_step(st, a, seed, lane0, t, auto_reset=auto, done=done, nthreads=8)
+        bad_total += bad
+        ob_g, rew_g, done_g, _ = e.step(torch.as_tensor(a, device="cuda"))
+        assert np.array_equal(np_(ob_g), ob) and np.array_equal(np_(rew_g), rew), t
+        assert np.array_equal(np_(done_g), done.astype(bool)), t
+        assert np.array_equal(np_(e.state).view(np.uint32), st), t
+    assert e.invalid_action_count() == bad_total > 0
