@@ -1025,20 +1025,24 @@ def test_collect_needs_auto_reset_and_a_reset():
         e.collect_synthetic(4)
 
 
-def test_collect_row_pitch_through_the_c_abi():
-    """pomdp_collect_synthetic with pitch > n: rows start every `pitch` elements and the padding is left alone."""
+@pytest.mark.parametrize("env,n,pitch,steps", [("rock", 5000, 5120, 67), ("rock", 1 << 20, (1 << 20) + 64, 20),
+                                               ("tag", 1 << 20, (1 << 20) + 8, 20), ("tiger", 1 << 20, (1 << 20) + 4, 20),
+                                               ("rock", 1 << 20, (1 << 20) + 2, 18)],      # a pitch the 16-byte stores cannot take
+                         ids=["rock-5000", "rock-quad", "tag-quad", "tiger-quad", "rock-odd-pitch"])
+def test_collect_row_pitch_through_the_c_abi(env, n, pitch, steps):
+    """pomdp_collect_synthetic with pitch > n: rows start every `pitch` elements and the padding is left alone (also in the
+    launches where a thread owns four consecutive lanes and stores 16 bytes at a time)."""
     from gym_pomdp_amd import _native
-    n, pitch, steps = 5000, 5120, 67
-    a = make_env("rock", {}, batch_size=n, seed=5, reuse_buffers=True)
-    b = make_env("rock", {}, batch_size=n, seed=5, reuse_buffers=True)
+    a = make_env(env, {}, batch_size=n, seed=5, reuse_buffers=True)
+    b = make_env(env, {}, batch_size=n, seed=5, reuse_buffers=True)
     a.reset()
     b.reset()
     act = torch.full((steps + 1, pitch), -7, dtype=torch.int32, device="cuda")
     ob = torch.full((steps, pitch), -7, dtype=torch.int32, device="cuda")
-    rew = torch.full((steps, pitch), -7, dtype=torch.int32, device="cuda")
+    rew = torch.full((steps, pitch), -7, dtype=b._reward.dtype, device="cuda")
     done = torch.full((steps, pitch), 9, dtype=torch.uint8, device="cuda")
     rc = _native.lib().pomdp_collect_synthetic(
-        _native.ENV_KIND["rock"], b._params_ref, b._state.data_ptr(), act.data_ptr(), ob.data_ptr(), rew.data_ptr(),
+        _native.ENV_KIND[b.env_name], b._params_ref, b._state.data_ptr(), act.data_ptr(), ob.data_ptr(), rew.data_ptr(),
         done.data_ptr(), b._err.data_ptr(), n, b._seed, b.lane_offset, b._t, steps, pitch, _native.POMDP_AUTO_RESET, None)
     _native.check(rc, "pomdp_collect_synthetic")
     torch.cuda.synchronize()
@@ -1048,7 +1052,7 @@ def test_collect_row_pitch_through_the_c_abi():
     assert torch.equal(a.state, b.state)
     assert bool((act[:, n:] == -7).all()) and bool((ob[:, n:] == -7).all()) and bool((done[:, n:] == 9).all())
     bad = _native.lib().pomdp_collect_synthetic(
-        _native.ENV_KIND["rock"], b._params_ref, b._state.data_ptr(), act.data_ptr(), ob.data_ptr(), rew.data_ptr(),
+        _native.ENV_KIND[b.env_name], b._params_ref, b._state.data_ptr(), act.data_ptr(), ob.data_ptr(), rew.data_ptr(),
         done.data_ptr(), b._err.data_ptr(), n, b._seed, b.lane_offset, 0, steps, n - 4, _native.POMDP_AUTO_RESET, None)
     assert bad == -1                                        # POMDP_E_BADARG: pitch < n
 
