@@ -151,9 +151,10 @@ def rollout_mode(args, env, cp, dev, rank, world, label):
                 total.add_(r["n_steps"].sum())
 
     args.prewarm = max(args.prewarm, 3.0)     # a compute-only kernel: the first seconds after idle run at ~half speed
-    prewarm(args, lambda k: run(k, False), dev)
-    run(args.warmup, False)
+    prewarm(args, lambda k: run(k, True), dev)        # with the step count's reduction in: its first launches are slow too
+    run(args.warmup, True)
     torch.cuda.synchronize(dev)
+    total.zero_()
     cp.barrier()
     t0 = time.perf_counter()
     run(args.steps, True)
