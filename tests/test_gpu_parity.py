@@ -1081,3 +1081,22 @@ def test_step_contract_over_a_whole_2_20_batch(oracle_lib, kw, auto):
         assert np.array_equal(np_(done_g), done.astype(bool)), t
         assert np.array_equal(np_(e.state).view(np.uint32), st), t
     assert e.invalid_action_count() == bad_total > 0
+
+
+@pytest.mark.parametrize("env,kw", [("rock", {}), ("tag", {}), ("tiger", {}), ("battleship", {})],
+                         ids=["rock", "tag", "tiger", "battleship"])
+def test_collected_trajectories_do_not_depend_on_the_sharding(env, kw):
+    """Lane sharding is exact for the fused launches too: the trajectories of lanes [0, 2^21) collected by one env equal
+    those collected by two envs that own 2^20 lanes each (what two GPUs would do), row for row."""
+    half, steps, seed = 1 << 20, 20, 8
+    whole = make_env(env, kw, batch_size=2 * half, seed=seed)
+    parts = [make_env(env, kw, batch_size=half, seed=seed, lane_offset=k * half) for k in range(2)]
+    for e in [whole] + parts:
+        e.reset()
+    tw = whole.collect_synthetic(steps)
+    for k, e in enumerate(parts):
+        tp = e.collect_synthetic(steps)
+        sl = slice(k * half, (k + 1) * half)
+        for name in ("action", "ob", "reward", "done"):
+            assert torch.equal(tw[name][:, sl], tp[name]), (env, k, name)
+        assert torch.equal(whole.state[:, sl], e.state), (env, k)
