@@ -156,12 +156,21 @@ def rollout_mode(args, env, cp, dev, rank, world, label):
     torch.cuda.synchronize(dev)
     total.zero_()
     cp.barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record()
     run(args.steps, True)
+    ev1.record()
     torch.cuda.synchronize(dev)
     elapsed = cp.max(time.perf_counter() - t0)
     cp.barrier()
+    launch_ms = ev0.elapsed_time(ev1) / args.steps
     steps_done = cp.sum(int(total.item()))
+    # a fused rollout moves next to nothing — the root's state words in, 21 B of results out per
+    # simulation of up to `depth` steps — so the HBM figure only shows how far from memory-bound it is; what bounds
+    # the kernel is VALU issue (~200 instructions per lane-step)
+    alg_per_sim = 21.0 + 4.0 * env.state_words / sims
+    achieved = alg_per_sim * roots_n * sims / (launch_ms * 1e-3) / 1e9
     if rank == 0:
         print(json.dumps({
             "metric": "env steps/sec (whole node), fused random rollouts", "value": steps_done / elapsed,
@@ -172,7 +181,12 @@ def rollout_mode(args, env, cp, dev, rank, world, label):
                                    "_generate_legal(), one fused rollout launch per step" % (label, roots_n, sims, args.depth),
                        "lanes_per_gpu": roots_n * sims, "mean_steps_per_simulation": steps_done / (args.steps * roots_n * sims * world),
                        "parallelism": "lane-shard x%d, no collectives" % world},
-            "roofline": None}), flush=True)
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "rollout_kernel<%s>" % args.env,
+                         "kernel_ms": launch_ms, "algorithmic_bytes_per_simulation": alg_per_sim,
+                         "note": "compute-bound by construction: the state lives in registers for the whole simulation; "
+                                 "kernel_ms = HIP events over the timed region / launches (the step count's reduction "
+                                 "included); lane-steps per second is `value`"}}), flush=True)
     cp.close()
 
 
