@@ -42,12 +42,13 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 WORKLOADS = {
     "rock": ("Rock-v0", {}, "RockSample(7,8)", 21, "int32"),
     "rock15": ("Rock-v0", dict(board_size=15, num_rocks=15), "RockSample(15,15)", 29, "int32"),
+    "stochrock": ("StochasticRock-v0", {}, "StochasticRock(7,8)", 21, "int32"),
     "tag": ("Tag-v0", {}, "Tag-v0 (5x10 grid, 1 opponent)", 21, "int32"),
     "battleship": ("Battleship-v0", dict(board_size=(10, 10), max_len=5), "BattleShip 10x10 max_len=5", 61, "int32"),
     "tiger": ("Tiger-v0", {}, "Tiger-v0", 21, "int32"),
     "network": ("Network-v0", {}, "Network-v0 (10 machines)", 21, "int32"),
 }
-ORACLE_NAME = {"rock": "rock", "rock15": "rock", "tag": "tag", "battleship": "battleship", "tiger": "tiger",
+ORACLE_NAME = {"rock": "rock", "rock15": "rock", "stochrock": "stochrock", "tag": "tag", "battleship": "battleship", "tiger": "tiger",
                "network": "network"}
 
 

@@ -1255,7 +1255,8 @@ __global__ __launch_bounds__(BLOCK) void tag_steps_quad_kernel(uint32_t *__restr
 
 // The generic fused loop with a quad per thread, for envs whose lane step is light enough that four of them fit a thread
 // (Env::QUAD_FUSED; one state word): the policy's ACTION block is the thread's own, Env::step / Env::reset_where run per
-// lane as in steps_kernel, the outputs leave as 16-byte stores.  Full workgroups of 1024 lanes, auto-reset.
+// lane as in steps_kernel, the outputs leave as 16-byte stores.  Full workgroups of 1024 lanes, auto-reset.  Only for envs
+// whose reset_where does not assume that a wave's 64 lanes are consecutive (RockSample's cooperative reset does).
 template <class Env, class = void> struct quad_fused : std::false_type {};
 template <class Env> struct quad_fused<Env, std::enable_if_t<Env::QUAD_FUSED>> : std::true_type {};
 
