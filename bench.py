@@ -236,7 +236,7 @@ def heuristic_mode(args, gpa, env_id, kwargs, cp, dev, rank, world, label, n, la
                        "lanes_per_gpu": n, "mean_history_size": float(hist._size.float().mean().item()),
                        "parallelism": "lane-shard x%d, no collectives" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "heuristic_step_kernel",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "heuristic_steps_kernel (up to 64 steps per launch)",
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_step": alg}}), flush=True)
     cp.close()
 
