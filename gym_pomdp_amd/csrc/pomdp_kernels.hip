@@ -1335,9 +1335,13 @@ static int launch_steps_fused(const typename Env::Params &p, uint32_t *state, in
     // four per thread, with fuller passes, beat two by 5 % from 2^20 lanes up (3.97 vs 4.16 us per step) when the state
     // is one word; with two state words (K > 12) the extra registers cost more (5.04 vs 4.74 us).  Only the geometries
     // an env can take are instantiated.
+    // the quad-per-thread loops move 16 bytes at a time (4 for the done bytes): columns that start on such a boundary only
+    const bool quad_ok = ((reinterpret_cast<uintptr_t>(state) | reinterpret_cast<uintptr_t>(action) | reinterpret_cast<uintptr_t>(ob) |
+                           reinterpret_cast<uintptr_t>(reward)) & 15u) == 0 && (reinterpret_cast<uintptr_t>(done) & 3u) == 0 &&
+                         rec % 4 == 0 && action_seed == seed;
     bool launched = false;
     if constexpr (std::is_same<Env, TagEnv>::value) {
-        if (lpt2 && (flags & POMDP_AUTO_RESET) && n % (4 * BLOCK) == 0 && n >= (1 << 20) && p.num_opponents == 1 &&
+        if (quad_ok && lpt2 && (flags & POMDP_AUTO_RESET) && n % (4 * BLOCK) == 0 && n >= (1 << 20) && p.num_opponents == 1 &&
             rec % 4 == 0 && action_seed == seed) {
             hipLaunchKernelGGL(tag_steps_quad_kernel, dim3((unsigned)(n / (4 * BLOCK))), dim3(BLOCK), 0, (hipStream_t)stream, state,
                                action, ob, reward, done, n, make_key(seed, t), lane0, make_key(action_seed, t + 1), k, rec, p);
@@ -1346,7 +1350,7 @@ static int launch_steps_fused(const typename Env::Params &p, uint32_t *state, in
     }
     static const bool no_quad = getenv("POMDP_NO_QUAD") != nullptr;       // A/B switch for tools/ (timing experiments)
     if constexpr (quad_fused<Env>::value) {
-        if (!no_quad && (flags & POMDP_AUTO_RESET) && n % (4 * BLOCK) == 0 && n >= (1 << 20) && rec % 4 == 0 && action_seed == seed) {
+        if (quad_ok && !no_quad && (flags & POMDP_AUTO_RESET) && n % (4 * BLOCK) == 0 && n >= (1 << 20) && rec % 4 == 0 && action_seed == seed) {
             hipLaunchKernelGGL((steps_quad_generic_kernel<Env>), dim3((unsigned)(n / (4 * BLOCK))), dim3(BLOCK), 0,
                                (hipStream_t)stream, state, action, ob, reward, done, n, make_key(seed, t), lane0,
                                make_key(action_seed, t + 1), k, rec, p);
@@ -1357,7 +1361,7 @@ static int launch_steps_fused(const typename Env::Params &p, uint32_t *state, in
         if (lpt2 && (flags & POMDP_AUTO_RESET) && n % (4 * BLOCK) == 0 && n >= (1 << 20) && (Env::WORDS == 1 || k >= 16)) {
             // from 16 steps per launch on the lane step reads the (position, action) table the workgroup builds first
             // (and a thread owns a quad of consecutive lanes: steps_quad_kernel; rows of a 16-byte-aligned pitch)
-            if (k >= 16 && p.num_rocks + 5 <= Env::TAB_ACTIONS && rec % 4 == 0 && action_seed == seed)
+            if (k >= 16 && p.num_rocks + 5 <= Env::TAB_ACTIONS && quad_ok)
                 hipLaunchKernelGGL((steps_quad_kernel<Env>), dim3((unsigned)(n / (4 * BLOCK))), dim3(BLOCK), 0,
                                    (hipStream_t)stream, state, action, ob, reward, done, n, make_key(seed, t), lane0,
                                    make_key(action_seed, t + 1), k, rec, p);

@@ -1100,3 +1100,28 @@ def test_collected_trajectories_do_not_depend_on_the_sharding(env, kw):
         for name in ("action", "ob", "reward", "done"):
             assert torch.equal(tw[name][:, sl], tp[name]), (env, k, name)
         assert torch.equal(whole.state[:, sl], e.state), (env, k)
+
+
+def test_collect_into_columns_that_are_not_16_byte_aligned():
+    """The quad-per-thread launches store 16 bytes at a time; columns that do not start on such a boundary (here: views one
+    element into their allocations) must take the scalar path and give the same trajectories."""
+    from gym_pomdp_amd import _native
+    n, steps = 1 << 20, 18
+    a = make_env("rock", {}, batch_size=n, seed=77, reuse_buffers=True)
+    b = make_env("rock", {}, batch_size=n, seed=77, reuse_buffers=True)
+    a.reset()
+    b.reset()
+    act = torch.zeros((steps + 1) * n + 1, dtype=torch.int32, device="cuda")[1:]
+    ob = torch.zeros(steps * n + 1, dtype=torch.int32, device="cuda")[1:]
+    rew = torch.zeros(steps * n + 1, dtype=torch.int32, device="cuda")[1:]
+    done = torch.zeros(steps * n + 1, dtype=torch.uint8, device="cuda")[1:]
+    assert act.data_ptr() % 16 == 4 and done.data_ptr() % 4 == 1
+    rc = _native.lib().pomdp_collect_synthetic(
+        _native.ENV_KIND["rock"], b._params_ref, b._state.data_ptr(), act.data_ptr(), ob.data_ptr(), rew.data_ptr(),
+        done.data_ptr(), b._err.data_ptr(), n, b._seed, b.lane_offset, b._t, steps, n, _native.POMDP_AUTO_RESET, None)
+    _native.check(rc, "pomdp_collect_synthetic")
+    torch.cuda.synchronize()
+    ref = a.collect_synthetic(steps)
+    assert torch.equal(act.view(steps + 1, n), ref["action"]) and torch.equal(ob.view(steps, n), ref["ob"])
+    assert torch.equal(rew.view(steps, n), ref["reward"]) and torch.equal(done.view(steps, n), ref["done_u8"])
+    assert torch.equal(a.state, b.state)
