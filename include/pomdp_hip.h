@@ -196,7 +196,9 @@ int pomdp_rollout_synthetic(int env, const void *params, uint32_t *state, int32_
  * call counter t0 + s in row s (row k_steps = the actions the next call would take).  Row s of every output equals what
  * pomdp_synthetic_actions + pomdp_<env>_step at t0 + s leave in their n-element buffers; `state` ends as after the last
  * step.  This is the batched form of the reference callers' episode loops (rock.py:553-575): one launch per 64 steps,
- * each lane's state in registers, 13 bytes per lane-step written, state and first actions read once per launch. */
+ * each lane's state in registers, 13 bytes per lane-step written, state and first actions read once per launch.  Any
+ * alignment and pitch >= n is accepted; columns on 16-byte boundaries (done: 4) with a pitch that is a multiple of 4 take the
+ * launches that store 16 bytes per thread. */
 int pomdp_collect_synthetic(int env, const void *params, uint32_t *state, int32_t *action, int32_t *ob, void *reward,
                             uint8_t *done, uint32_t *err, int64_t n, uint64_t seed, uint32_t lane0, uint64_t t0,
                             int64_t k_steps, int64_t pitch, int flags, void *stream);
