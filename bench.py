@@ -11,9 +11,18 @@ launch, every step's action / ob / reward / done written to its own [step][lane]
 registers between its steps.  `--collect 0` runs the same fused launches with every step overwriting the same
 N-element outputs (pomdp_rollout_synthetic; what per-step launches leave), `--fuse 0` launches every step
 separately, `--host-loop python` times the same steps through env.step() instead.
-N > 1: one process per GPU (torch.distributed.run), lanes sharded by global lane id, no data-path
-collective — only the timing barrier / max-over-ranks (gloo, host side).  Scaling is weak: every
-GPU owns 2^20 lanes.
+N > 1: one process per GPU, lanes sharded by global lane id, no data-path collective — only the timing
+barrier / max-over-ranks (gloo, host side).  `python bench.py --gpus N` starts its N ranks itself (it re-executes
+under `python -m torch.distributed.run`); started under torch.distributed.run already, it uses the ranks it was
+given.  Scaling is weak (every GPU owns --lanes-per-gpu lanes; `value` is the whole-job rate); for N > 1 the line
+also carries `strong_scaling`: the same K steps on a batch of --lanes-per-gpu lanes IN TOTAL split over the N GPUs.
+
+Timing protocol: for each master seed in --seeds (default 0,1,2) the env is re-seeded and reset, W
+warm-up steps run, and the region "barrier, sync, K steps, sync" is timed R times (R = --repeats, default 31 for
+K < 2048 else 5); every region is max-reduced over the ranks; a seed's figure is the median of its regions and the
+line's `value` / `ms_per_step` the median over the seeds (config.seed_values has all of them and the min / max).
+Every buffer the timed steps write is allocated, and touched by the same chunking of K, before the first timed
+region.
 
 Prints ONE JSON line on rank 0 with the driver's contract keys plus `roofline` (algorithmic
 bytes / HIP-event time of the step kernel alone) and `cpu_baseline` (the C oracle, OpenMP, on
@@ -63,7 +72,10 @@ def parse():
                     help="weak (default, what the driver's contract asks for): --lanes-per-gpu lanes on every GPU.  "
                          "strong: --lanes-per-gpu is the TOTAL batch (SURVEY.md §8d reads the metric that way), split "
                          "over the GPUs")
-    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--seed", type=int, default=None, help="a single master seed (shorthand for --seeds S)")
+    ap.add_argument("--seeds", default="0,1,2", help="master seeds of the timing protocol (SURVEY.md §8d: 0, then 1 and 2)")
+    ap.add_argument("--repeats", type=int, default=0,
+                    help="timed regions of K steps per seed (median reported); 0 = 31 if K < 2048 else 5")
     ap.add_argument("--host-loop", default="c", choices=["c", "python"],
                     help="who issues the two launches of a step: the C rollout driver or a python loop over env.step()")
     ap.add_argument("--mode", default="step", choices=["step", "rollout", "heuristic"],
@@ -89,12 +101,53 @@ def parse():
     return ap.parse_args()
 
 
-def prewarm(args, run, dev):
+def prewarm(args, run, dev, k=64):
     """Untimed clock spin-up: keep the GPU busy with the workload's own launches for --prewarm seconds."""
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < args.prewarm:
-        run(64)
+        run(k)
         torch.cuda.synchronize(dev)
+
+
+def median(xs):
+    xs = sorted(xs)
+    m = len(xs) // 2
+    return xs[m] if len(xs) % 2 else 0.5 * (xs[m - 1] + xs[m])
+
+
+def timed_regions(run, k, repeats, dev, cp):
+    """`repeats` times: barrier + device sync, K steps, device sync — wall clock (max over ranks) and HIP-event time
+    on the launch stream.  Returns ([wall seconds], [event milliseconds])."""
+    walls, evs = [], []
+    for _ in range(repeats):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(dev)
+        cp.barrier()
+        t0 = time.perf_counter()
+        e0.record()
+        run(k)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        cp.barrier()
+        walls.append(cp.max(el))
+        evs.append(e0.elapsed_time(e1))
+    return walls, evs
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks (one per GPU) and hand over."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def cpu_baseline(env_key, kwargs, seed, budget_s):
@@ -242,8 +295,9 @@ def heuristic_mode(args, gpa, env_id, kwargs, cp, dev, rank, world, label, n, la
 
 
 def measured_traffic(env_key, chained=False, fused=False):
-    """HBM bytes per step-kernel launch from the committed PMC passes (profiles/traffic_*.json, produced by
-    tools/gpu_profile.sh: separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this command)."""
+    """HBM bytes per step-kernel launch RECORDED by the committed PMC passes (profiles/traffic_*.json, produced by
+    tools/gpu_profile_round.sh: separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this command) — not
+    measured in this run."""
     name = {"rock": "traffic_rock_7_8.json"}.get(env_key)
     path = os.path.join(REPO, "profiles", name) if name else None
     if not path or not os.path.exists(path):
@@ -251,18 +305,92 @@ def measured_traffic(env_key, chained=False, fused=False):
     with open(path) as f:
         t = json.load(f)
     key = "fused" if fused and "fused" in t else ("chain" if chained and "chain" in t else "plain")
-    return t[key]["hbm_bytes_per_launch"], "profiles/%s [%s]" % (name, key)
+    return t[key]["hbm_bytes_per_launch"], "recorded, not measured in this run: profiles/%s [%s]" % (name, key)
+
+
+class StepWorkload(object):
+    """K consecutive steps of one env shard under the synthetic policy, every buffer allocated up front."""
+
+    CHUNK = 128          # steps per C-driver call (two full 64-step launches when fused)
+
+    def __init__(self, args, gpa, env_id, kwargs, dev, n, lane_offset, seed):
+        self.args, self.dev, self.n = args, dev, n
+        self.env = gpa.make(env_id, batch_size=n, device=dev, seed=seed, lane_offset=lane_offset, reuse_buffers=True, **kwargs)
+        self.actions = torch.empty(n, dtype=torch.int32, device=dev)
+        self.shared_key = args.action_seed is None
+        self.collect = bool(args.collect) and bool(args.fuse) and args.host_loop == "c" and self.shared_key
+        self.chained = args.host_loop == "c" and self.shared_key
+        self.fused = self.chained and bool(args.fuse)
+        self.views = {}
+        if self.collect:
+            # one [CHUNK + 1][n] trajectory buffer per column; a call of c steps writes the first c (+ 1) rows
+            c = min(self.CHUNK, max(args.steps, args.warmup, 1))
+            e = self.env
+            self.traj = {"action": torch.zeros((c + 1, n), dtype=torch.int32, device=dev),
+                         "ob": torch.zeros((c, n), dtype=torch.int32, device=dev),
+                         "reward": torch.zeros((c, n), dtype=e._reward.dtype, device=dev),
+                         "done_u8": torch.zeros((c, n), dtype=torch.uint8, device=dev)}
+
+    def _view(self, c):
+        v = self.views.get(c)
+        if v is None:
+            t = self.traj
+            v = {"action": t["action"][:c + 1], "ob": t["ob"][:c], "reward": t["reward"][:c], "done_u8": t["done_u8"][:c]}
+            v["done"] = v["done_u8"].view(torch.bool)
+            self.views[c] = v
+        return v
+
+    def reseed(self, seed):
+        self.env.seed(seed)
+        self.env.reset()
+
+    def action_seed(self):
+        return self.env._seed if self.shared_key else self.args.action_seed
+
+    def run(self, k):
+        env, left = self.env, k
+        if self.collect:
+            while left > 0:
+                c = min(left, self.CHUNK)
+                env.collect_synthetic(c, out=self._view(c))
+                left -= c
+        elif self.args.host_loop == "python":
+            for _ in range(k):
+                env.synthetic_actions(out=self.actions, seed=self.action_seed())
+                env.step(self.actions)
+        else:
+            while left > 0:
+                c = min(left, self.CHUNK)
+                env.rollout_synthetic(c, action_seed=self.action_seed(), actions=self.actions, fuse=self.fused)
+                left -= c
+
+    def measure(self, seeds, cp):
+        """The §8d protocol.  -> (per-seed [(seed, median wall s, min, max, median event ms)])."""
+        args, k = self.args, self.args.steps
+        repeats = args.repeats or (31 if k < 2048 else 5)
+        rows = []
+        for i, seed in enumerate(seeds):
+            self.reseed(seed)
+            if i == 0:
+                prewarm(args, self.run, self.dev, k)      # same chunking as the timed region: every row it writes is touched
+            self.run(args.warmup)
+            self.run(k)                                    # untimed pass over exactly the timed call sequence
+            walls, evs = timed_regions(self.run, k, repeats, self.dev, cp)
+            rows.append((seed, median(walls), min(walls), max(walls), median(evs)))
+        return rows, repeats
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    seeds = [args.seed] if args.seed is not None else [int(x) for x in args.seeds.split(",") if x != ""]
+    args.seed = seeds[0]
     n_dev = torch.cuda.device_count()
     dev_index = local_rank % max(n_dev, 1)      # fewer GPUs than ranks (1-GPU dev box): ranks share devices
     torch.cuda.set_device(dev_index)
@@ -285,59 +413,35 @@ def main():
         assert count == n
     if args.mode == "heuristic":
         return heuristic_mode(args, gpa, env_id, kwargs, cp, dev, rank, world, label, n, lane_offset)
-    env = gpa.make(env_id, batch_size=n, device=dev, seed=args.seed, lane_offset=lane_offset, reuse_buffers=True,
-                   **kwargs)
     if args.mode == "rollout":
+        env = gpa.make(env_id, batch_size=n, device=dev, seed=args.seed, lane_offset=lane_offset, reuse_buffers=True, **kwargs)
         return rollout_mode(args, env, cp, dev, rank, world, label)
-    actions = torch.empty(n, dtype=torch.int32, device=dev)
-    # by default policy and env share the Philox key (their streams differ by stream id)
-    action_seed = args.seed if args.action_seed is None else args.action_seed
 
-    traj = {}
-    collect = bool(args.collect) and bool(args.fuse) and args.host_loop == "c" and action_seed == args.seed
+    shards = cp.gather((lane_offset, n, dev_index))        # who owns which global lanes, on which device
+    wl = StepWorkload(args, gpa, env_id, kwargs, dev, n, lane_offset, seeds[0])
+    env = wl.env
+    rows, repeats = wl.measure(seeds, cp)
+    elapsed = median([r[1] for r in rows])
+    timed_kernel_ms = median([r[4] for r in rows]) / args.steps
+    fused_kernel = _native.lib().pomdp_last_fused_kernel().decode() if wl.fused else None
+    chained, fused, collect = wl.chained, wl.fused, wl.collect
+    action_seed = wl.action_seed()
 
-    def run_steps(k):
-        if collect:
-            left = k
-            while left > 0:
-                c = min(left, 128)
-                traj[c] = env.collect_synthetic(c, out=traj.get(c))
-                left -= c
-        elif args.host_loop == "python":
-            for _ in range(k):
-                env.synthetic_actions(out=actions, seed=action_seed)
-                env.step(actions)
-        else:
-            left = k
-            while left > 0:
-                c = min(left, 128)         # two full 64-step launches per call when fused
-                env.rollout_synthetic(c, action_seed=action_seed, actions=actions, fuse=bool(args.fuse) and action_seed == args.seed)
-                left -= c
+    # ---- the same K steps on a batch of --lanes-per-gpu lanes IN TOTAL, split over the GPUs (N > 1, weak runs) -------
+    strong = None
+    if world > 1 and args.scaling == "weak" and args.lanes_per_gpu % (4 * world) == 0:
+        off_s, n_s = sharding.shard_range(args.lanes_per_gpu, rank, world)
+        wl_s = StepWorkload(args, gpa, env_id, kwargs, dev, n_s, off_s, seeds[0])
+        rows_s, _ = wl_s.measure(seeds[:1], cp)
+        strong = {"total_lanes": args.lanes_per_gpu, "lanes_per_gpu": n_s, "value": args.lanes_per_gpu * args.steps / rows_s[0][1],
+                  "unit": "env-steps/s", "ms_per_step": rows_s[0][1] / args.steps * 1e3, "seed": seeds[0],
+                  "kernel": _native.lib().pomdp_last_fused_kernel().decode() if wl_s.fused else None}
+        del wl_s
 
-    def barrier():
-        torch.cuda.synchronize(dev)
-        cp.barrier()
-
-    env.reset()
-    prewarm(args, run_steps, dev)
-    run_steps(args.warmup)
-    barrier()
-    tev0, tev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    tev0.record()
-    run_steps(args.steps)
-    tev1.record()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    barrier()
-    elapsed = cp.max(elapsed)
-    # HIP events on the launch stream over the timed region: with the chained policy the region is one
-    # step launch per step (plus one policy launch per 100 steps), so this is that kernel's average duration
-    timed_kernel_ms = tev0.elapsed_time(tev1) / args.steps
-
-    # ---- roofline of the dominant kernel: the step kernel alone, HIP events on its stream --------
+    # ---- the single-step kernels, for reference: HIP events on their stream ------------------------------------------
     # A ring of pre-generated action batches keeps the action distribution of the timed region
     # (i.i.d. uniform every step); replaying ONE batch would make lanes repeat their action forever.
+    k1 = min(max(args.steps, 256), 1024)
     ring = []
     for j in range(16):
         a = torch.empty(n, dtype=torch.int32, device=dev)
@@ -345,32 +449,31 @@ def main():
         env.synthetic_actions(out=a, seed=action_seed)
         ring.append(a)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for j in range(16):
-        env.step(ring[j])
+    for j in range(64):
+        env.step(ring[j & 15])
     torch.cuda.synchronize(dev)
     ev0.record()
-    for j in range(args.steps):
+    for j in range(k1):
         env.step(ring[j & 15])
     ev1.record()
     torch.cuda.synchronize(dev)
-    plain_ms = ev0.elapsed_time(ev1) / args.steps
+    plain_ms = ev0.elapsed_time(ev1) / k1
     plain_achieved = bytes_per_step * n / (plain_ms * 1e-3) / 1e9
-    chained = args.host_loop == "c" and action_seed == args.seed
-    fused = chained and bool(args.fuse)
     kern_ms = timed_kernel_ms if chained else plain_ms
     # Algorithmic bytes per lane-step.  One launch per step moves SURVEY.md §8d's figure: state in + state out + action
-    # in 4 + ob 4 + reward 4 + done 1.  A fused launch of 64 steps has to write each step's action, ob, reward and done
-    # (13 B) but reads the state and the first actions, and writes the state, once: 13 + (figure - 9) / 64.  Pricing the
-    # fused launch at the per-step figure would credit it with bytes it never has to move (BattleShip: 61 vs 13.8).
-    alg_bytes = 13.0 + (bytes_per_step - 9) / 64.0 if fused else float(bytes_per_step)
+    # in 4 + ob 4 + reward 4 + done 1.  A fused launch of up to 64 steps has to write each step's action, ob, reward and
+    # done (13 B) but reads the state once, writes it once and writes the first actions: 13 + (figure - 9) / steps per
+    # launch.  Pricing the fused launch at the per-step figure would credit it with bytes it never has to move
+    # (BattleShip: 61 vs 13.8).
+    spl = min(64, args.steps) if fused else 1
+    alg_bytes = 13.0 + (bytes_per_step - 9) / float(spl) if fused else float(bytes_per_step)
     achieved = alg_bytes * n / (kern_ms * 1e-3) / 1e9
     chain1_ms = None
     if fused:      # the same chained steps launched one by one (step_kernel<., chain>), for reference
-        k1 = min(args.steps, 1000)
-        env.rollout_synthetic(64, action_seed=action_seed, actions=actions, fuse=False)
+        env.rollout_synthetic(64, action_seed=action_seed, actions=wl.actions, fuse=False)
         torch.cuda.synchronize(dev)
         ev0.record()
-        env.rollout_synthetic(k1, action_seed=action_seed, actions=actions, fuse=False)
+        env.rollout_synthetic(k1, action_seed=action_seed, actions=wl.actions, fuse=False)
         ev1.record()
         torch.cuda.synchronize(dev)
         chain1_ms = ev0.elapsed_time(ev1) / k1
@@ -386,6 +489,15 @@ def main():
                     metric = json.load(f)["metric"]
             except Exception:  # noqa: BLE001
                 metric = "env steps/sec (whole node), RockSample(7,8) batch=2^20, 1/2/4/8 MI355X"
+        seed_values = [total_lanes * args.steps / r[1] for r in rows]
+        if fused:
+            kernel_name = "%s — %d chained steps per launch: step + next-step policy, every step's outputs written%s, " \
+                          "state in registers between steps; the only kernel of the timed region" % (
+                              fused_kernel, spl, " to its own trajectory row" if collect else " over the previous step's")
+        elif chained:
+            kernel_name = "step_kernel<%s, chain> (step + next-step policy, the launch of the timed region)" % args.env
+        else:
+            kernel_name = "step_kernel<%s>" % args.env
         out = {
             "metric": metric,
             "value": total_lanes * args.steps / elapsed,
@@ -399,24 +511,31 @@ def main():
             "vs_baseline": None,
             "dtype": dtype,
             "data": "synthetic",
-            "config": {"workload": "%s batch=%d lanes per GPU (%d total), uniform random actions "
-                                   "(synthetic-policy kernel timed), auto-reset" % (label, n, total_lanes),
+            "config": {"workload": "%s batch=%d lanes per GPU (%d total, %s scaling), uniform random actions from the "
+                                   "synthetic policy (generated inside the timed launches), auto-reset"
+                                   % (label, n, total_lanes, args.scaling),
                        "lanes_per_gpu": n, "total_lanes": total_lanes, "host_loop": args.host_loop, "visible_gpus": n_dev,
-                       "steps_per_launch": 64 if fused else 1, "trajectories_kept": collect,
-                       "untimed_prewarm_s": args.prewarm, "parallelism": "lane-shard x%d, no collectives" % world},
+                       "steps_per_launch": spl, "trajectories_kept": collect,
+                       "seeds": seeds, "repeats": repeats,
+                       "protocol": "per seed: reseed + reset, W warm-up steps, one untimed pass of K steps, then `repeats` "
+                                   "timed regions of exactly K steps (barrier + device sync on both sides, max over ranks); "
+                                   "value = median over seeds of the per-seed median region",
+                       "seed_values": {"per_seed": seed_values, "min": min(seed_values), "median": median(seed_values),
+                                       "max": max(seed_values),
+                                       "region_ms": [{"seed": r[0], "median": r[1] * 1e3, "min": r[2] * 1e3, "max": r[3] * 1e3}
+                                                     for r in rows]},
+                       "untimed_prewarm_s": args.prewarm, "parallelism": "lane-shard x%d, no collectives" % world,
+                       "shards": [{"rank": r, "lane_offset": s[0], "lanes": s[1], "device": s[2]} for r, s in enumerate(shards)],
+                       "host_cpus": os.cpu_count(),
+                       "host_cpus_usable": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per 64-step launch" if fused else "bytes per launch",
                          "traffic_source": traffic_src,
-                         "kernel": (("steps_kernel<%s> (64 chained steps per launch: step + next-step policy, every step's "
-                                     "outputs written" + (" to its own trajectory row" if collect else " over the previous step's") +
-                                     ", state in registers between steps; the launch of the timed region)")
-                                    if fused else
-                                    "step_kernel<%s, chain> (step + next-step policy, the launch of the timed region)"
-                                    if chained else "step_kernel<%s>") % args.env,
+                         "kernel": kernel_name,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_step": alg_bytes,
                          "algorithmic_bytes_per_step_unfused": bytes_per_step,
-                         "steps_per_launch": 64 if fused else 1,
-                         "launch_ms": kern_ms * (64 if fused else 1),
+                         "steps_per_launch": spl,
+                         "launch_ms": kern_ms * spl,
                          "chained_step_kernel": None if chain1_ms is None else {
                              "kernel": "step_kernel<%s, chain> (the same steps, one launch each)" % args.env,
                              "kernel_ms": chain1_ms, "achieved": bytes_per_step * n / (chain1_ms * 1e-3) / 1e9,
@@ -424,14 +543,16 @@ def main():
                          "plain_step_kernel": {"kernel": "step_kernel<%s> (what env.step() launches)" % args.env,
                                                "kernel_ms": plain_ms, "achieved": plain_achieved,
                                                "frac": plain_achieved / HBM_PEAK_GBS},
-                         "note": "kernel_ms: HIP events on the launch stream over the timed region (%d back-to-back "
-                                 "steps, gaps included) / steps; launch_ms = kernel_ms x steps_per_launch; traffic is per "
-                                 "launch; algorithmic bytes: 13 B of outputs per step + state in/out and first actions once "
+                         "note": "kernel_ms: HIP events on the launch stream around each timed region of %d back-to-back "
+                                 "steps (median over regions and seeds) / steps; launch_ms = kernel_ms x steps_per_launch; "
+                                 "algorithmic bytes: 13 B of outputs per step + state in/out and first actions once "
                                  "per fused launch, the full per-step figure for the single-step kernels; "
                                  "plain_step_kernel: env.step() on a ring of 16 pre-generated action batches"
                                  % args.steps},
             "invalid_actions": invalid,
         }
+        if strong is not None:
+            out["strong_scaling"] = strong
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.env, kwargs, args.seed, args.cpu_seconds)
             # the like-for-like "one env, python loop" usage of the reference, through this build's public API

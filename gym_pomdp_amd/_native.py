@@ -15,7 +15,7 @@ SOURCES = [os.path.join(_PKG, "csrc", f) for f in ("pomdp_kernels.hip", "envs.hi
                                                    "envs/rock.hip.h", "envs/tag.hip.h", "envs/battleship.hip.h",
                                                    "envs/tiger.hip.h", "envs/network.hip.h")]
 HEADER = os.path.join(_REPO, "include", "pomdp_hip.h")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 POMDP_AUTO_RESET = 1
 POMDP_FUSE_STEPS = 2
@@ -24,7 +24,7 @@ ENV_KIND = {"rock": 0, "tag": 1, "battleship": 2, "tiger": 3, "network": 4}
 
 # every symbol include/pomdp_hip.h declares
 SYMBOLS = [
-    "pomdp_abi_version", "pomdp_error_string",
+    "pomdp_abi_version", "pomdp_error_string", "pomdp_last_fused_kernel",
     "pomdp_rock_reset", "pomdp_rock_step", "pomdp_tag_reset", "pomdp_tag_step",
     "pomdp_battleship_reset", "pomdp_battleship_step", "pomdp_tiger_reset", "pomdp_tiger_step",
     "pomdp_network_reset", "pomdp_network_step", "pomdp_synthetic_actions", "pomdp_philox_blocks",
@@ -111,6 +111,8 @@ def lib():
                            % (L.pomdp_abi_version(), ABI_VERSION))
     L.pomdp_error_string.restype = C.c_char_p
     L.pomdp_error_string.argtypes = [C.c_int]
+    L.pomdp_last_fused_kernel.restype = C.c_char_p
+    L.pomdp_last_fused_kernel.argtypes = []
     vp, i64, u64, u32, ci = C.c_void_p, C.c_int64, C.c_uint64, C.c_uint32, C.c_int
     for env in ("rock", "tag", "battleship", "tiger", "network"):
         r = getattr(L, "pomdp_%s_reset" % env)

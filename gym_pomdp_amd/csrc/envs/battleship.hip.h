@@ -10,10 +10,10 @@ struct BattleShipEnv {
     using Params = pomdp_battleship_params;
     using Reward = int32_t;
     static constexpr int WORDS = 2 * MW;
+    static constexpr const char *NAME = MW == 1 ? "BattleShipEnv<1>" : MW == 2 ? "BattleShipEnv<2>" : MW == 3 ? "BattleShipEnv<3>" : "BattleShipEnv<4>";
     static constexpr bool POOLED_LPT2 = false;
     static constexpr bool POOLED_ANY_LPT = false;
     static constexpr bool QUAD_SENSOR = false;
-    static constexpr int ABL = 0;
     struct Shared { int unused; };
     // Each 128-bit mask is two 64-bit registers (never an addressable array or vector: a dynamically indexed
     // one is lowered through LDS by the compiler); bit tests are a 64-bit select and one variable shift.

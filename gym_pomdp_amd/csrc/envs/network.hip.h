@@ -9,10 +9,10 @@ struct NetworkEnv {
     using Params = pomdp_network_params;
     using Reward = float;
     static constexpr int WORDS = 1;
+    static constexpr const char *NAME = "NetworkEnv";
     static constexpr bool POOLED_LPT2 = false;
     static constexpr bool POOLED_ANY_LPT = false;
     static constexpr bool QUAD_SENSOR = false;
-    static constexpr int ABL = 0;
     // nbf[k][v]: the machines that see a failed neighbour when the down machines among 4 k .. 4 k + 3 are the set v
     // (network.py:82-85) — the OR over the nibbles of ~state replaces a loop over the machines
     struct Shared { uint32_t nbf[8][16]; };

@@ -20,18 +20,16 @@ namespace pomdp {
 // per draw; only then is the L block generated.  So a reset costs ONE block instead of ceil(K / 2), a
 // quad's sensor draws cost one block instead of four, and a wave's whole step fits one pooled Philox pass.
 //
-// ABLATE is a profiling aid (tools/microbench.hip): bit 0 drops the sensor Philox block, bit 1 the auto-reset,
-// bit 2 the LDS table lookups.  The product only instantiates ABLATE = 0.  STOCH selects StochasticRockEnv
-// (rock.py:428-504).
-template <int W, int ABLATE = 0, bool STOCH = false> // W = state words per lane: 1 (K <= 12) or 2
+// STOCH selects StochasticRockEnv (rock.py:428-504).
+template <int W, bool STOCH = false> // W = state words per lane: 1 (K <= 12) or 2
 struct RockEnv {
     using Params = pomdp_rock_params;
     using Reward = int32_t;
     using S = typename std::conditional<W == 1, uint32_t, uint64_t>::type; // 32-bit ALU when one word is enough
     static constexpr int WORDS = W;
+    static constexpr const char *NAME = STOCH ? (W == 1 ? "StochasticRockEnv<1>" : "StochasticRockEnv<2>") : (W == 1 ? "RockEnv<1>" : "RockEnv<2>");
     static constexpr bool POOLED_LPT2 = !STOCH;   // pomdp_kernels.hip: Finisher<RockEnv, 2, .>
     static constexpr bool POOLED_ANY_LPT = !STOCH; // ... and for any other number of lanes per thread >= 2
-    static constexpr int ABL = ABLATE;            // experiment switches (tools/microbench.hip); 0 in the product
     struct Shared {
         uint2 thr[32];         // sensor threshold by L1 distance: .x = thr >> 26 (compared with H >> 5),
                                // .y = thr & (2^26 - 1) (compared with L >> 6 on a tie) — one 8-byte LDS read
@@ -91,16 +89,15 @@ struct RockEnv {
         sh.row[tid] = same;
     }
 
-    static constexpr bool NT = !(ABLATE & 16);
     static __device__ __forceinline__ void load(State &st, const uint32_t *state, int64_t n, uint32_t i)
     {
-        st.s = ld_stream<NT>(state + i);
-        if (W == 2) st.s |= (S)((uint64_t)ld_stream<NT>(state + n + i) << 32);
+        st.s = ld_stream(state + i);
+        if (W == 2) st.s |= (S)((uint64_t)ld_stream(state + n + i) << 32);
     }
     static __device__ __forceinline__ void store(const State &st, uint32_t *state, int64_t n, uint32_t i, bool)
     {
-        st_stream<NT>(state + i, (uint32_t)st.s);
-        if (W == 2) st_stream<NT>(state + n + i, (uint32_t)((uint64_t)st.s >> 32));
+        st_stream(state + i, (uint32_t)st.s);
+        if (W == 2) st_stream(state + n + i, (uint32_t)((uint64_t)st.s >> 32));
     }
 
     static __device__ __forceinline__ uint32_t elem(const uint4 &w, uint32_t e) { return e == 0 ? w.x : e == 1 ? w.y : e == 2 ? w.z : w.w; }
@@ -193,7 +190,6 @@ struct RockEnv {
                                                       const RngKey &key, uint32_t lane, const RngKey &akey,
                                                       uint32_t n_actions, int &next_action)
     {
-        if (ABLATE & 2) { if (CHAIN) next_action = synthetic_action(akey, lane, n_actions); return; }
         const uint64_t mask = __ballot(fresh);
         if (!CHAIN && mask == 0ull) return;                            // wave-uniform
         const int K = p.num_rocks;
@@ -397,15 +393,15 @@ struct RockEnv {
         const uint32_t size = (uint32_t)p.size, K = (uint32_t)p.num_rocks;
         // CHECK rock a-5 (rock.py:171-175, 401-407, 383-387; coord.py:133-135: L1 distance = sum of absolute byte differences)
         const int r = (a - 5) & 15;
-        const uint32_t rp = (ABLATE & 4) ? (uint32_t)(r * 257) : sh.rpos[r];
+        const uint32_t rp = sh.rpos[r];
         const uint32_t d = __builtin_amdgcn_sad_u8(x | (y << 8), rp, 0u);
-        aux.th = (ABLATE & 4) ? d << 22 : sh.thr[d].x;
+        aux.th = sh.thr[d].x;
         aux.r = (uint8_t)r;
         aux.good = ((uint32_t)(s >> (8 + 2 * r)) & 3u) == 2u;
         aux.want = a > 4;
         const int penalty = STOCH ? 0 : -100;                                  // rock.py:117 / rock.py:432
         // SAMPLE (rock.py:160-169); ids >= K raise IndexError in the reference, "no rock" here (-1 wraps above K)
-        const int id = (ABLATE & 4) ? (int)((x ^ y) & 7) - (int)(x & 1) : sh.grid[x * 16 + y];
+        const int id = sh.grid[x * 16 + y];
         const int sh_ = 8 + 2 * (id & 15);
         const uint32_t code = (uint32_t)(s >> sh_) & 3u;
         const bool sample_ok = ((uint32_t)id < K) & (code != 1u);
@@ -436,7 +432,6 @@ struct RockEnv {
     // only a tie asks for them, so they are looked up there instead of travelling with every step
     static __device__ __forceinline__ uint32_t thr_lo_of(const Shared &sh, const State &st, int r)
     {
-        if (ABLATE & 4) return 0u;
         const uint32_t x = (uint32_t)st.s & 15u, y = ((uint32_t)st.s >> 4) & 15u;
         return sh.thr[__builtin_amdgcn_sad_u8(x | (y << 8), sh.rpos[r & 15], 0u)].y;
     }
@@ -540,7 +535,7 @@ struct RockEnv {
         }
         Aux aux;
         step_pre(sh, p, st, a, rew, done, aux);
-        const uint4 h = (ABLATE & 1) ? make_uint4(lane * 2654435761u, lane, 0, 0) : quad_block(key, lane, 0u);
+        const uint4 h = quad_block(key, lane, 0u);
         ob = sensor_ob(sh, st, aux, elem(h, e), [&]() { return elem(quad_block(key, lane, 1u), e); });
     }
 };

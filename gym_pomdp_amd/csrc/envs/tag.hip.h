@@ -9,10 +9,10 @@ struct TagEnv {
     using Params = pomdp_tag_params;
     using Reward = float;
     static constexpr int WORDS = 1;
+    static constexpr const char *NAME = "TagEnv";
     static constexpr bool POOLED_LPT2 = true;     // pomdp_kernels.hip: Finisher<TagEnv, 2, .>
     static constexpr bool POOLED_ANY_LPT = false;
     static constexpr bool QUAD_SENSOR = false;
-    static constexpr int ABL = 0;
     // The T-shaped board never changes (tag.py:36-78): two small LDS tables replace the coordinate arithmetic of the
     // hot step — cell -> x | y << 4, and (cell, move N0 E1 S2 W3) -> the cell the move leads to, or the cell itself
     // when that square does not exist.  Every workgroup computes them once (threads 0-127, one entry each).

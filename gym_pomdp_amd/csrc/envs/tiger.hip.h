@@ -9,11 +9,11 @@ struct TigerEnv {
     using Params = pomdp_tiger_params;
     using Reward = int32_t;
     static constexpr int WORDS = 1;
+    static constexpr const char *NAME = "TigerEnv";
     static constexpr bool POOLED_LPT2 = false;
     static constexpr bool POOLED_ANY_LPT = false;
     static constexpr bool QUAD_SENSOR = false;
     static constexpr bool QUAD_FUSED = true;      // pomdp_kernels.hip: steps_quad_generic_kernel
-    static constexpr int ABL = 0;
     struct Shared { int unused; };
     // w: the tiger's door (what is stored).  rs: registers only — the fresh episode's door when this step ended the
     // episode (see step()), NO_RS otherwise.

@@ -21,7 +21,7 @@ namespace pomdp {
 //   - stores are device-scope write-through (`global_store ... sc1`): the lines leave L2 while the kernel is still
 //     computing instead of in one write-back burst when it ends;
 //   - loads carry the `nt` bit (no allocation on the way in).
-// Measured on the RockSample step kernel at 2^20 lanes (tools/microbench.hip; ABLATE bit 16 = plain cached access):
+// Measured on the RockSample step kernel at 2^20 lanes (round-1 tools/microbench.hip, plain cached access as the A arm):
 // 9.06 us cached -> 7.9 us with nt loads and stores -> 7.2 us with write-through stores.  Load policy alone: no effect.
 template <bool STREAM = true, class T>
 __device__ __forceinline__ T ld_stream(const T *p) { return STREAM ? __builtin_nontemporal_load(p) : *p; }

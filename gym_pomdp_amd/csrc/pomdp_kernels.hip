@@ -12,12 +12,15 @@
 
 #include "../../include/pomdp_hip.h"
 #include "envs.hip.h"
-#include <cstdlib>
 #include "philox.hip.h"
+#include <cstdio>
 
 namespace pomdp {
 
 constexpr int BLOCK = 256;        // 4 waves: one per SIMD
+// launcher -> fused kernels only (never part of the ABI's flags): the launch derives the actions of its first step from
+// the synthetic policy itself and writes them to row 0 of `action`, instead of reading what a policy launch left there
+constexpr int FLAG_GEN_FIRST = 1 << 8;
 constexpr int MAX_BLOCKS = 256 * 8; // helper kernels: 256 CUs x 8 resident workgroups, grid-stride beyond
 
 static inline int grid_for(int64_t n)
@@ -123,9 +126,9 @@ struct Finisher {
 // WITHOUT its sensor draw (Env::step_pre) and the observation is completed here from the pooled words.  Tasks and
 // results are exchanged through a wave-private LDS scratch; LDS operations of one wave complete in order, so no
 // barrier is involved.  Low words (needed with probability 2^-27 per draw) are generated per lane on demand.
-template <int W, int ABLATE, int LPT, bool CHAIN>
-struct Finisher<RockEnv<W, ABLATE, false>, LPT, CHAIN, typename std::enable_if<(LPT >= 2)>::type> {
-    using Env = RockEnv<W, ABLATE, false>;
+template <int W, int LPT, bool CHAIN>
+struct Finisher<RockEnv<W, false>, LPT, CHAIN, typename std::enable_if<(LPT >= 2)>::type> {
+    using Env = RockEnv<W, false>;
     using Aux = typename Env::Aux;
     static constexpr bool LOOP_BARRIER = false;              // every scratch array is wave-private
     static constexpr int NQ = 16 * LPT;                      // quads (sensor blocks) of the wave's 64 * LPT lanes
@@ -155,12 +158,12 @@ struct Finisher<RockEnv<W, ABLATE, false>, LPT, CHAIN, typename std::enable_if<(
     // The data-independent part of the task list — the wave's sensor blocks and, for CHAIN launches, the policy blocks
     // of the next call counter — depends on lane ids only, so the kernel runs it right after issuing its HBM loads:
     // Philox passes hidden under the load latency.  Sub-batch j of a thread is 256 j lanes further on.
-    static constexpr bool HAS_PREPASS = !(ABLATE & 8);
+    static constexpr bool HAS_PREPASS = true;
     // Plain launches at two lanes per thread have only 32 such blocks per wave — half a pass.  There the waves of a
     // workgroup pair up: one wave of each pair computes both waves' 32 sensor blocks in one full pass, the other skips
     // the pre-pass; which of the two works alternates with the workgroup index so that the SIMDs stay balanced.  The
     // blocks are first read after the table-staging barrier, which makes them visible across the pair at no extra cost.
-    static constexpr bool PAIRED = !CHAIN && LPT == 2 && HAS_PREPASS;
+    static constexpr bool PAIRED = !CHAIN && LPT == 2;
     static __device__ __forceinline__ void prepass(const RngKey &key, const uint32_t (&lane)[LPT], const RngKey &akey)
     {
         const int wv = (int)(threadIdx.x >> 6), me = (int)(threadIdx.x & 63u);
@@ -177,7 +180,6 @@ struct Finisher<RockEnv<W, ABLATE, false>, LPT, CHAIN, typename std::enable_if<(
         }
 #pragma unroll
         for (int base = 0; base < NQ + NA; base += 64) {
-            if ((ABLATE & 1) && NQ % 64 == 0 && base < NQ) continue;           // timing experiment: no sensor blocks
             const int tid = base + me;
             if (tid < NQ + NA) {
                 const bool is_act = tid >= NQ;
@@ -199,15 +201,14 @@ struct Finisher<RockEnv<W, ABLATE, false>, LPT, CHAIN, typename std::enable_if<(
         __shared__ uint8_t src_lds[BLOCK / 64][64 * LPT];    // reset rank -> virtual lane (me + 64 * sub-batch)
         __shared__ uint32_t res_lds[BLOCK / 64][64 * LPT];   // reset rank -> the 2-bit codes of the fresh episode's rocks
         const int wv = (int)(threadIdx.x >> 6), me = (int)(threadIdx.x & 63u);
-        if (!HAS_PREPASS) prepass(key, lane, akey);
         const int K = p.num_rocks;
         int rank[LPT], nres = 0;
 #pragma unroll
         for (int j = 0; j < LPT; ++j) {
-            const uint64_t m = (ABLATE & 2) ? 0ull : __ballot(fresh[j]);      // ABLATE 2 (timing experiment): nobody resets
+            const uint64_t m = __ballot(fresh[j]);
             rank[j] = nres + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
             nres += __popcll(m);
-            if (!(ABLATE & 2) && fresh[j]) src_lds[wv][rank[j]] = (uint8_t)(me + 64 * j);
+            if (fresh[j]) src_lds[wv][rank[j]] = (uint8_t)(me + 64 * j);
         }
         const uint32_t first0 = lane[0] - (uint32_t)me;
         for (int base = 0; base < nres; base += 64) {        // one RESET block per resetting lane, 64 per pass
@@ -222,8 +223,8 @@ struct Finisher<RockEnv<W, ABLATE, false>, LPT, CHAIN, typename std::enable_if<(
         const uint32_t start = (uint32_t)p.start_x | ((uint32_t)p.start_y << 4);
 #pragma unroll
         for (int j = 0; j < LPT; ++j) {
-            if (!(ABLATE & 2) && fresh[j]) st[j].s = (typename Env::S)((uint64_t)start | ((uint64_t)res_lds[wv][rank[j] & (64 * LPT - 1)] << 8));
-            const uint32_t H = (ABLATE & 1) ? lane[j] * 2654435761u : blk_lds()[wv][16 * j + (me >> 2)][me & 3];
+            if (fresh[j]) st[j].s = (typename Env::S)((uint64_t)start | ((uint64_t)res_lds[wv][rank[j] & (64 * LPT - 1)] << 8));
+            const uint32_t H = blk_lds()[wv][16 * j + (me >> 2)][me & 3];
             ob[j] = Env::sensor_ob(sh, st[j], aux[j], H, [&]() { return Env::elem(Env::quad_block(key, lane[j], 1u), lane[j] & 3u); });
             if (CHAIN) a_next[j] = (int)__umulhi(blk_lds()[wv][NQ + 16 * j + (me >> 2)][me & 3], n_act);
         }
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(uint32_t *__restrict__ stat
         in_range[j] = rel[j] <= last;
         const uint32_t rc = in_range[j] ? rel[j] : last;               // out-of-range threads read lane n-1
         __builtin_assume(rc < (uint32_t)(BLOCK * LPT));
-        a_raw[j] = ld_stream<!(Env::ABL & 16)>(action_w + rc);
+        a_raw[j] = ld_stream(action_w + rc);
         Env::load(st[j], state_w, n, rc);
         was_done[j] = auto_reset ? false : (ld_stream(done_w + rc) != 0);   // frozen lane (the reference would assert)
     }
@@ -383,13 +384,12 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(uint32_t *__restrict__ stat
 #pragma unroll
     for (int j = 0; j < LPT; ++j) {
         if (!live[j]) o[j] = 0;
-        constexpr bool NT = !(Env::ABL & 16);
-        if (CHAIN) { if (in_range[j]) st_stream<NT>(const_cast<int32_t *>(action_w) + rel[j], (int32_t)a_next[j]); }
+        if (CHAIN) { if (in_range[j]) st_stream(const_cast<int32_t *>(action_w) + rel[j], (int32_t)a_next[j]); }
         if (live[j]) Env::store(st[j], state_w, n, rel[j], fresh[j]);
         if (in_range[j]) {
-            st_stream<NT>(ob_w + rel[j], (int32_t)o[j]);
-            st_stream<NT>(reward_w + rel[j], r[j]);
-            st_stream<NT>(done_w + rel[j], (uint8_t)d[j]);
+            st_stream(ob_w + rel[j], (int32_t)o[j]);
+            st_stream(reward_w + rel[j], r[j]);
+            st_stream(done_w + rel[j], (uint8_t)d[j]);
             // the reference asserts on an out-of-range action; here the lane is left untouched and counted
             if (!valid[j] && !was_done[j] && err) atomicAdd(err, 1u);
         }
@@ -444,16 +444,25 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
         in_range[j] = SIMPLE || rel[j] <= last;
         const uint32_t rc = in_range[j] ? rel[j] : last;
         __builtin_assume(rc < (uint32_t)(BLOCK * LPT));
-        a_cur[j] = ld_stream(action_w + rc);
+        a_cur[j] = (flags & FLAG_GEN_FIRST) ? 0 : ld_stream(action_w + rc);
         Env::load(st[j], state_w, n, rc);
         was_done[j] = auto_reset ? false : (ld_stream(done_w + rc) != 0);
     }
-    action_w += rec;
     using Fin = Finisher<Env, LPT, true>;
     constexpr bool quad_policy = quad_policy_of<Fin>::value;
     uint4 aq = make_uint4(0, 0, 0, 0);
     const int n_act = Env::n_actions(p);
     const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo, ta0 = ((uint64_t)akey0.t_hi << 32) | akey0.t_lo;
+    if (flags & FLAG_GEN_FIRST) {                        // wave-uniform: the policy's actions of the first call counter
+        RngKey fkey = akey0;
+        fkey.t_lo = (uint32_t)(ta0 - 1ull); fkey.t_hi = (uint32_t)((ta0 - 1ull) >> 32);
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) {
+            a_cur[j] = synthetic_action(fkey, glane[j], (uint32_t)n_act);
+            if (in_range[j]) st_stream(action_w + rel[j], (int32_t)a_cur[j]);
+        }
+    }
+    action_w += rec;
     for (int s = 0; s < k_steps; ++s) {
         RngKey key = key0, akey = akey0;
         key.t_lo = (uint32_t)(t0 + (uint64_t)s); key.t_hi = (uint32_t)((t0 + (uint64_t)s) >> 32);
@@ -744,9 +753,9 @@ struct BeliefOps {
                                                   const typename Env::State &, int, int, const pomdp_rock_belief &, int64_t,
                                                   uint32_t, uint32_t &) {}
 };
-template <int W, int ABLATE, bool STOCH>
-struct BeliefOps<RockEnv<W, ABLATE, STOCH>, void> {
-    using Env = RockEnv<W, ABLATE, STOCH>;
+template <int W, bool STOCH>
+struct BeliefOps<RockEnv<W, STOCH>, void> {
+    using Env = RockEnv<W, STOCH>;
     static __device__ __forceinline__ void update(const typename Env::Shared &sh, const typename Env::Params &p,
                                                   const typename Env::State &st, int a, int o, const pomdp_rock_belief &b,
                                                   int64_t n, uint32_t i, uint32_t &ck) { Env::belief_update(sh, p, st, a, o, b, n, i, ck); }
@@ -974,18 +983,19 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(const typename Env::Para
 // ---------------------------------------------------------------------------
 // helpers
 // ---------------------------------------------------------------------------
-// one thread = four consecutive lanes = one Philox block = one 16-byte store
-__global__ __launch_bounds__(BLOCK) void synthetic_actions_kernel(int4 *__restrict__ action, int64_t n4, RngKey key,
+// one thread = four consecutive lanes = one Philox block = one 16-byte store (the last quad of a ragged batch: scalar stores)
+__global__ __launch_bounds__(BLOCK) void synthetic_actions_kernel(int32_t *__restrict__ action, int64_t n, RngKey key,
                                                                  uint32_t q0, uint32_t n_actions)
 {
-    const int64_t stride = (int64_t)gridDim.x * BLOCK;
+    const int64_t stride = (int64_t)gridDim.x * BLOCK, n4 = (n + 3) >> 2;
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n4; i += stride) {
         const uint4 w = philox4x32_10(q0 + (uint32_t)i, key.t_lo, key.t_hi, (uint32_t)POMDP_STREAM_ACTION << 24,
                                       key.k0, key.k1);
         typedef int v4i __attribute__((ext_vector_type(4)));
         const v4i a = {(int)__umulhi(w.x, n_actions), (int)__umulhi(w.y, n_actions), (int)__umulhi(w.z, n_actions),
                        (int)__umulhi(w.w, n_actions)};
-        __builtin_nontemporal_store(a, reinterpret_cast<v4i *>(action) + i);      // streamed, like every lane column
+        if (4 * i + 4 <= n) __builtin_nontemporal_store(a, reinterpret_cast<v4i *>(action) + i);   // streamed, like every lane column
+        else for (int64_t l = 4 * i; l < n; ++l) action[l] = a[(int)(l & 3)];
     }
 }
 
@@ -1062,6 +1072,19 @@ static int launch_step_chain(const typename Env::Params &p, uint32_t *state, int
     return (int)hipGetLastError();
 }
 
+// The actions of a quad-per-thread launch's first step: read from row 0 of `action`, or (gen_first, wave-uniform) the
+// quad's block of the synthetic policy at the call counter before akey0's — computed here and written to that row.
+static __device__ __forceinline__ u32x4 first_actions4(uint32_t *action_row0, int gen_first, uint32_t glane0, const RngKey &akey0,
+                                                       uint32_t n_act)
+{
+    if (!gen_first) return ld_stream4(action_row0);
+    const uint64_t tf = (((uint64_t)akey0.t_hi << 32) | akey0.t_lo) - 1ull;
+    const uint4 w = philox4x32_10(glane0 >> 2, (uint32_t)tf, (uint32_t)(tf >> 32), (uint32_t)POMDP_STREAM_ACTION << 24, akey0.k0, akey0.k1);
+    const u32x4 a = {__umulhi(w.x, n_act), __umulhi(w.y, n_act), __umulhi(w.z, n_act), __umulhi(w.w, n_act)};
+    st_stream4(action_row0, a[0], a[1], a[2], a[3]);
+    return a;
+}
+
 // The fused RockSample loop with a thread owning four CONSECUTIVE lanes — a quad.  RockSample's word contract shares the
 // STEP block and the policy's ACTION block among the four lanes of a quad, so with this mapping both blocks are the
 // thread's own: two Philox blocks per thread-step straight into registers, lane j taking element j — no exchange through LDS,
@@ -1074,7 +1097,7 @@ template <class Env>
 __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict__ state, int32_t *__restrict__ action,
                                                            int32_t *__restrict__ ob, int32_t *__restrict__ reward,
                                                            uint8_t *__restrict__ done, int64_t n, RngKey key0, uint32_t lane0,
-                                                           RngKey akey0, int k_steps, int64_t rec,
+                                                           RngKey akey0, int k_steps, int64_t rec, int gen_first,
                                                            const typename Env::Params p)
 {
     constexpr int W = Env::WORDS;
@@ -1092,10 +1115,12 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
     uint32_t *done_w = reinterpret_cast<uint32_t *>(done + l0);
     typename Env::State st[4];
     int a_cur[4];
+    const uint32_t n_act = (uint32_t)Env::n_actions(p);
     {
-        const u32x4 a4 = ld_stream4(action_w), s_lo = ld_stream4(state + l0);
+        const u32x4 s_lo = ld_stream4(state + l0);
         u32x4 s_hi = {0, 0, 0, 0};
         if (W == 2) s_hi = ld_stream4(state + n + l0);
+        const u32x4 a4 = first_actions4(action_w, gen_first, glane0, akey0, n_act);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             a_cur[j] = (int)a4[j];
@@ -1107,7 +1132,6 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
     __syncthreads();
     Env::build_tab(tab, sh, p, (int)threadIdx.x);
     __syncthreads();
-    const uint32_t n_act = (uint32_t)Env::n_actions(p);
     const int K = p.num_rocks;
     const uint32_t start = (uint32_t)p.start_x | ((uint32_t)p.start_y << 4);
     const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo, ta0 = ((uint64_t)akey0.t_hi << 32) | akey0.t_lo;
@@ -1166,7 +1190,7 @@ __global__ __launch_bounds__(BLOCK) void tag_steps_quad_kernel(uint32_t *__restr
                                                                int32_t *__restrict__ ob, float *__restrict__ reward,
                                                                uint8_t *__restrict__ done, int64_t n, RngKey key0,
                                                                uint32_t lane0, RngKey akey0, int k_steps, int64_t rec,
-                                                               const TagEnv::Params p)
+                                                               int gen_first, const TagEnv::Params p)
 {
     using Env = TagEnv;
     __shared__ Env::Shared sh;
@@ -1180,15 +1204,16 @@ __global__ __launch_bounds__(BLOCK) void tag_steps_quad_kernel(uint32_t *__restr
     uint32_t *done_w = reinterpret_cast<uint32_t *>(done + l0);
     Env::State st[4];
     int a_cur[4];
+    const uint32_t n_act = (uint32_t)Env::n_actions(p);
     {
-        const u32x4 a4 = ld_stream4(action_w), s4 = ld_stream4(state + l0);
+        const u32x4 s4 = ld_stream4(state + l0);
+        const u32x4 a4 = first_actions4(action_w, gen_first, glane0, akey0, n_act);
 #pragma unroll
         for (int j = 0; j < 4; ++j) { a_cur[j] = (int)a4[j]; st[j].w = s4[j]; }
     }
     action_w += rec;
     Env::stage(sh, p, (int)threadIdx.x);
     __syncthreads();
-    const uint32_t n_act = (uint32_t)Env::n_actions(p);
     const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo, ta0 = ((uint64_t)akey0.t_hi << 32) | akey0.t_lo;
     for (int s = 0; s < k_steps; ++s) {
         RngKey key = key0;
@@ -1266,7 +1291,7 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_generic_kernel(uint32_t *__r
                                                                    typename Env::Reward *__restrict__ reward,
                                                                    uint8_t *__restrict__ done, int64_t n, RngKey key0,
                                                                    uint32_t lane0, RngKey akey0, int k_steps, int64_t rec,
-                                                                   const typename Env::Params p)
+                                                                   int gen_first, const typename Env::Params p)
 {
     static_assert(Env::WORDS == 1 && sizeof(typename Env::Reward) == 4, "one state word, 4-byte rewards");
     __shared__ typename Env::Shared sh;
@@ -1277,15 +1302,17 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_generic_kernel(uint32_t *__r
     uint32_t *done_w = reinterpret_cast<uint32_t *>(done + l0);
     typename Env::State st[4];
     int a_cur[4];
+    const uint32_t n_act = (uint32_t)Env::n_actions(p);
     {
-        const u32x4 a4 = ld_stream4(action_w);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { a_cur[j] = (int)a4[j]; Env::load(st[j], state, n, l0 + (uint32_t)j); }
+        for (int j = 0; j < 4; ++j) Env::load(st[j], state, n, l0 + (uint32_t)j);
+        const u32x4 a4 = first_actions4(action_w, gen_first, glane0, akey0, n_act);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a_cur[j] = (int)a4[j];
     }
     action_w += rec;
     Env::stage(sh, p, (int)threadIdx.x);
     __syncthreads();
-    const uint32_t n_act = (uint32_t)Env::n_actions(p);
     const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo, ta0 = ((uint64_t)akey0.t_hi << 32) | akey0.t_lo;
     for (int s = 0; s < k_steps; ++s) {
         RngKey key = key0;
@@ -1317,56 +1344,85 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_generic_kernel(uint32_t *__r
     for (int j = 0; j < 4; ++j) Env::store(st[j], state, n, l0 + (uint32_t)j, true);
 }
 
-// the same as k launch_step_chain calls at t, t + 1, ..., in one launch
+// Smallest batch each quad-per-thread loop takes (1024 lanes per workgroup).  Measured on MI355X, us per fused step at
+// 2^17 / 2^18 / 2^19 / 2^20 lanes (profiles/r02_small_shards.txt): RockSample(7,8) quad 1.50 / 1.52 / 1.82 / 2.89 against
+// 1.25 / 1.39 / 1.99 with one or two lanes per thread; Tag 1.91 / 1.90 / 2.11 / 3.12 against 0.97 / 1.43 / 2.00; Tiger
+// 0.67 / 0.72 / 1.26 / 2.82 against 0.55 / 0.83 / 1.52 — below these sizes every kernel is bound by the latency of one
+// wave's step (1.1-1.5 us), and more, lighter waves hide it better than fewer, heavier ones.
+// POMDP_QUAD_MIN_LANES overrides all three at build time for same-box A/B runs (tools/ab_build.sh lib ... -D...).
+#ifdef POMDP_QUAD_MIN_LANES
+constexpr int64_t QUAD_MIN_ROCK = POMDP_QUAD_MIN_LANES, QUAD_MIN_TAG = POMDP_QUAD_MIN_LANES, QUAD_MIN_GENERIC = POMDP_QUAD_MIN_LANES;
+#else
+constexpr int64_t QUAD_MIN_ROCK = 1 << 19, QUAD_MIN_TAG = 1 << 20, QUAD_MIN_GENERIC = 1 << 18;
+#endif
+
+// which kernel the calling thread's most recent fused launch picked (pomdp_last_fused_kernel: bench.py names the kernel
+// it timed from this instead of guessing the launcher's choice)
+static thread_local char g_last_fused[96] = "";
+static void note_fused(const char *kernel, const char *env, const char *variant)
+{
+    snprintf(g_last_fused, sizeof g_last_fused, "%s<%s%s>", kernel, env, variant);
+}
+
+// the same as k launch_step_chain calls at t, t + 1, ..., in one launch.  gen_first: the launch derives the actions of
+// call counter t itself (and writes them to `action`) instead of reading them — the caller skips the policy launch.
 template <class Env>
 static int launch_steps_fused(const typename Env::Params &p, uint32_t *state, int32_t *action, int32_t *ob,
                               typename Env::Reward *reward, uint8_t *done, uint32_t *err, int64_t n, uint64_t seed,
-                              uint64_t action_seed, uint32_t lane0, uint64_t t, int k, int flags, int64_t rec, void *stream)
+                              uint64_t action_seed, uint32_t lane0, uint64_t t, int k, int flags, int64_t rec, bool gen_first,
+                              void *stream)
 {
     if (!state || !action || !ob || !reward || !done || bad_range(n, lane0) || (lane0 & 3u) || k < 1) return POMDP_E_BADARG;
     if (n == 0) return 0;
     const bool lpt2 = Env::POOLED_LPT2 && n >= LPT2_MIN_LANES;
     const bool simple = (flags & POMDP_AUTO_RESET) && n % (lpt2 ? 2 * BLOCK : BLOCK) == 0;
     const dim3 grid(lpt2 ? (unsigned)((n + 2 * BLOCK - 1) / (2 * BLOCK)) : blocks_for(n));
+    const int kflags = (flags & POMDP_AUTO_RESET) | (gen_first ? FLAG_GEN_FIRST : 0);
+    const int gf = gen_first ? 1 : 0;
 #define POMDP_LAUNCH_STEPS(LPT_, SIMPLE_, GRID_)                                                                       \
-    hipLaunchKernelGGL((steps_kernel<Env, LPT_, SIMPLE_>), GRID_, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob, \
-                       reward, done, err, n, make_key(seed, t), lane0, flags, make_key(action_seed, t + 1), k, rec, p)
+    do {                                                                                                                 \
+        note_fused("steps_kernel", Env::NAME, ", " #LPT_ ", " #SIMPLE_);                                                 \
+        hipLaunchKernelGGL((steps_kernel<Env, LPT_, SIMPLE_>), GRID_, dim3(BLOCK), 0, (hipStream_t)stream, state, action, \
+                           ob, reward, done, err, n, make_key(seed, t), lane0, kflags, make_key(action_seed, t + 1), k,   \
+                           rec, p);                                                                                      \
+    } while (0)
     // RockSample's pooled passes exist for any number of lanes per thread; in the fused loop (no load latency to hide)
     // four per thread, with fuller passes, beat two by 5 % from 2^20 lanes up (3.97 vs 4.16 us per step) when the state
     // is one word; with two state words (K > 12) the extra registers cost more (5.04 vs 4.74 us).  Only the geometries
     // an env can take are instantiated.
-    // the quad-per-thread loops move 16 bytes at a time (4 for the done bytes): columns that start on such a boundary only
+    // the quad-per-thread loops move 16 bytes at a time (4 for the done bytes): columns that start on such a boundary
+    // only, full workgroups of 1024 lanes, auto-reset, policy and env on one Philox key
     const bool quad_ok = ((reinterpret_cast<uintptr_t>(state) | reinterpret_cast<uintptr_t>(action) | reinterpret_cast<uintptr_t>(ob) |
                            reinterpret_cast<uintptr_t>(reward)) & 15u) == 0 && (reinterpret_cast<uintptr_t>(done) & 3u) == 0 &&
-                         rec % 4 == 0 && action_seed == seed;
+                         rec % 4 == 0 && action_seed == seed && (flags & POMDP_AUTO_RESET) && n % (4 * BLOCK) == 0;
+    const dim3 qgrid((unsigned)(n / (4 * BLOCK)));
     bool launched = false;
     if constexpr (std::is_same<Env, TagEnv>::value) {
-        if (quad_ok && lpt2 && (flags & POMDP_AUTO_RESET) && n % (4 * BLOCK) == 0 && n >= (1 << 20) && p.num_opponents == 1 &&
-            rec % 4 == 0 && action_seed == seed) {
-            hipLaunchKernelGGL(tag_steps_quad_kernel, dim3((unsigned)(n / (4 * BLOCK))), dim3(BLOCK), 0, (hipStream_t)stream, state,
-                               action, ob, reward, done, n, make_key(seed, t), lane0, make_key(action_seed, t + 1), k, rec, p);
+        if (quad_ok && n >= QUAD_MIN_TAG && p.num_opponents == 1) {
+            note_fused("tag_steps_quad_kernel", "", "");
+            hipLaunchKernelGGL(tag_steps_quad_kernel, qgrid, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob, reward,
+                               done, n, make_key(seed, t), lane0, make_key(action_seed, t + 1), k, rec, gf, p);
             launched = true;
         }
     }
-    static const bool no_quad = getenv("POMDP_NO_QUAD") != nullptr;       // A/B switch for tools/ (timing experiments)
     if constexpr (quad_fused<Env>::value) {
-        if (quad_ok && !no_quad && (flags & POMDP_AUTO_RESET) && n % (4 * BLOCK) == 0 && n >= (1 << 20) && rec % 4 == 0 && action_seed == seed) {
-            hipLaunchKernelGGL((steps_quad_generic_kernel<Env>), dim3((unsigned)(n / (4 * BLOCK))), dim3(BLOCK), 0,
-                               (hipStream_t)stream, state, action, ob, reward, done, n, make_key(seed, t), lane0,
-                               make_key(action_seed, t + 1), k, rec, p);
+        if (quad_ok && n >= QUAD_MIN_GENERIC) {
+            note_fused("steps_quad_generic_kernel", Env::NAME, "");
+            hipLaunchKernelGGL((steps_quad_generic_kernel<Env>), qgrid, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob,
+                               reward, done, n, make_key(seed, t), lane0, make_key(action_seed, t + 1), k, rec, gf, p);
             launched = true;
         }
     }
     if constexpr (Env::POOLED_ANY_LPT) {
-        if (lpt2 && (flags & POMDP_AUTO_RESET) && n % (4 * BLOCK) == 0 && n >= (1 << 20) && (Env::WORDS == 1 || k >= 16)) {
-            // from 16 steps per launch on the lane step reads the (position, action) table the workgroup builds first
-            // (and a thread owns a quad of consecutive lanes: steps_quad_kernel; rows of a 16-byte-aligned pitch)
-            if (k >= 16 && p.num_rocks + 5 <= Env::TAB_ACTIONS && quad_ok)
-                hipLaunchKernelGGL((steps_quad_kernel<Env>), dim3((unsigned)(n / (4 * BLOCK))), dim3(BLOCK), 0,
-                                   (hipStream_t)stream, state, action, ob, reward, done, n, make_key(seed, t), lane0,
-                                   make_key(action_seed, t + 1), k, rec, p);
-            else
-                POMDP_LAUNCH_STEPS(4, true, dim3((unsigned)(n / (4 * BLOCK))));
+        // from 16 steps per launch on the lane step reads the (position, action) table the workgroup builds first and a
+        // thread owns a quad of consecutive lanes (steps_quad_kernel)
+        if (quad_ok && n >= QUAD_MIN_ROCK && k >= 16 && p.num_rocks + 5 <= Env::TAB_ACTIONS) {
+            note_fused("steps_quad_kernel", Env::NAME, "");
+            hipLaunchKernelGGL((steps_quad_kernel<Env>), qgrid, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob, reward,
+                               done, n, make_key(seed, t), lane0, make_key(action_seed, t + 1), k, rec, gf, p);
+            launched = true;
+        } else if (lpt2 && (flags & POMDP_AUTO_RESET) && n % (4 * BLOCK) == 0 && n >= (1 << 20) && Env::WORDS == 1) {
+            POMDP_LAUNCH_STEPS(4, true, qgrid);
             launched = true;
         }
     }
@@ -1381,8 +1437,8 @@ static int launch_steps_fused(const typename Env::Params &p, uint32_t *state, in
     return (int)hipGetLastError();
 }
 
-using StochRock1 = RockEnv<1, 0, true>;   // StochasticRockEnv, one / two state words
-using StochRock2 = RockEnv<2, 0, true>;
+using StochRock1 = RockEnv<1, true>;   // StochasticRockEnv, one / two state words
+using StochRock2 = RockEnv<2, true>;
 
 static bool rock_ok(const pomdp_rock_params *p)
 {
@@ -1544,6 +1600,8 @@ extern "C" {
 
 int pomdp_abi_version(void) { return POMDP_ABI_VERSION; }
 
+const char *pomdp_last_fused_kernel(void) { return g_last_fused; }
+
 const char *pomdp_error_string(int code)
 {
     if (code == 0) return "ok";
@@ -1649,10 +1707,11 @@ int pomdp_network_step(const pomdp_network_params *p, uint32_t *state, const int
 int pomdp_synthetic_actions(int32_t *action, int64_t n, uint64_t seed, uint32_t lane0, uint64_t t, uint32_t n_actions,
                             void *stream)
 {
-    if (!action || bad_range(n, lane0) || (n & 3) || (lane0 & 3u) || n_actions == 0) return POMDP_E_BADARG;
+    if (!action || bad_range(n, lane0) || (lane0 & 3u) || (reinterpret_cast<uintptr_t>(action) & 15u) || n_actions == 0)
+        return POMDP_E_BADARG;
     if (n == 0) return 0;
-    hipLaunchKernelGGL(synthetic_actions_kernel, dim3(grid_for(n / 4)), dim3(BLOCK), 0, (hipStream_t)stream,
-                       (int4 *)action, n / 4, make_key(seed, t), lane0 >> 2, n_actions);
+    hipLaunchKernelGGL(synthetic_actions_kernel, dim3(grid_for((n + 3) / 4)), dim3(BLOCK), 0, (hipStream_t)stream, action, n,
+                       make_key(seed, t), lane0 >> 2, n_actions);
     return (int)hipGetLastError();
 }
 
@@ -1672,34 +1731,45 @@ static uint32_t env_action_count(int env, const void *params)
     }
 }
 
+// params and buffers of the C-side episode loops, checked before anything is enqueued
+static int check_driver_args(int env, const void *params, const void *state, const void *action, const void *ob,
+                             const void *reward, const void *done, int64_t n, uint32_t lane0, int64_t k_steps)
+{
+    if (!params || !state || !action || !ob || !reward || !done || k_steps < 0 || bad_range(n, lane0) || (lane0 & 3u))
+        return POMDP_E_BADARG;
+    return dispatch_env(env, params, [](auto, const auto &) { return 0; });      // POMDP_E_BADPARAMS / unknown env
+}
+
 int pomdp_rollout_synthetic(int env, const void *params, uint32_t *state, int32_t *action, int32_t *ob, void *reward,
                             uint8_t *done, uint32_t *err, int64_t n, uint64_t seed, uint64_t action_seed,
                             uint32_t lane0, uint64_t t0, int64_t k_steps, int flags, void *stream)
 {
-    if (!params || k_steps < 0 || !action) return POMDP_E_BADARG;
-    if (k_steps == 0) return 0;
+    int rc = check_driver_args(env, params, state, action, ob, reward, done, n, lane0, k_steps);
+    if (rc) return rc;
+    if (k_steps == 0 || n == 0) return 0;
     const uint32_t n_actions = env_action_count(env, params);
-    if (!n_actions) return POMDP_E_BADARG;
+    if (action_seed == seed && (flags & POMDP_FUSE_STEPS)) {
+        // chained and fused: up to FUSE_MAX consecutive steps share one launch (steps_kernel and its quad-per-thread
+        // forms); every step also leaves the actions of the following call counter in `action`; the first launch
+        // derives the actions of t0 itself
+        constexpr int64_t FUSE_MAX = 64;
+        for (int64_t s = 0; s < k_steps; s += FUSE_MAX) {
+            const int c = (int)(k_steps - s < FUSE_MAX ? k_steps - s : FUSE_MAX);
+            const uint64_t t = t0 + (uint64_t)s;
+            rc = dispatch_env(env, params, [&](auto tag, const auto &p) {
+                using E = typename decltype(tag)::Env;
+                return launch_steps_fused<E>(p, state, action, ob, (typename E::Reward *)reward, done, err, n, seed,
+                                             action_seed, lane0, t, c, flags, 0, s == 0, stream);
+            });
+            if (rc) return rc;
+        }
+        return 0;
+    }
     // actions of the first step from the stand-alone policy kernel
-    int rc = pomdp_synthetic_actions(action, n, action_seed, lane0, t0, n_actions, stream);
+    rc = pomdp_synthetic_actions(action, n, action_seed, lane0, t0, n_actions, stream);
     if (rc) return rc;
     if (action_seed == seed) {
-        // chained: every step also leaves the actions of the following call counter in `action`.  With
-        // POMDP_FUSE_STEPS up to FUSE_MAX consecutive steps share one launch (steps_kernel); otherwise one launch per step.
-        if (flags & POMDP_FUSE_STEPS) {
-            constexpr int64_t FUSE_MAX = 64;
-            for (int64_t s = 0; s < k_steps; s += FUSE_MAX) {
-                const int c = (int)(k_steps - s < FUSE_MAX ? k_steps - s : FUSE_MAX);
-                const uint64_t t = t0 + (uint64_t)s;
-                rc = dispatch_env(env, params, [&](auto tag, const auto &p) {
-                    using E = typename decltype(tag)::Env;
-                    return launch_steps_fused<E>(p, state, action, ob, (typename E::Reward *)reward, done, err, n, seed,
-                                                 action_seed, lane0, t, c, flags, 0, stream);
-                });
-                if (rc) return rc;
-            }
-            return 0;
-        }
+        // chained: one launch per step, which also leaves the actions of the following call counter in `action`
         for (int64_t s = 0; s < k_steps; ++s) {
             const uint64_t t = t0 + (uint64_t)s;
             rc = dispatch_env(env, params, [&](auto tag, const auto &p) {
@@ -1728,20 +1798,19 @@ int pomdp_collect_synthetic(int env, const void *params, uint32_t *state, int32_
                             uint8_t *done, uint32_t *err, int64_t n, uint64_t seed, uint32_t lane0, uint64_t t0,
                             int64_t k_steps, int64_t pitch, int flags, void *stream)
 {
-    if (!params || k_steps < 0 || pitch < n || !(flags & POMDP_AUTO_RESET)) return POMDP_E_BADARG;
-    if (k_steps == 0 || n == 0) return 0;
-    const uint32_t n_actions = env_action_count(env, params);
-    if (!n_actions) return POMDP_E_BADARG;
-    int rc = pomdp_synthetic_actions(action, n, seed, lane0, t0, n_actions, stream);    // row 0: the actions of t0
+    int rc = check_driver_args(env, params, state, action, ob, reward, done, n, lane0, k_steps);
     if (rc) return rc;
+    if (pitch < n || !(flags & POMDP_AUTO_RESET)) return POMDP_E_BADARG;
+    if (k_steps == 0 || n == 0) return 0;
     constexpr int64_t FUSE_MAX = 64;
-    for (int64_t s = 0; s < k_steps; s += FUSE_MAX) {
+    for (int64_t s = 0; s < k_steps; s += FUSE_MAX) {      // the first launch writes row 0 (the actions of t0) itself
         const int c = (int)(k_steps - s < FUSE_MAX ? k_steps - s : FUSE_MAX);
         rc = dispatch_env(env, params, [&](auto tag, const auto &p) {
             using E = typename decltype(tag)::Env;
             using R = typename E::Reward;
             return launch_steps_fused<E>(p, state, action + s * pitch, ob + s * pitch, (R *)reward + s * pitch,
-                                         done + s * pitch, err, n, seed, seed, lane0, t0 + (uint64_t)s, c, flags, pitch, stream);
+                                         done + s * pitch, err, n, seed, seed, lane0, t0 + (uint64_t)s, c, flags, pitch,
+                                         s == 0, stream);
         });
         if (rc) return rc;
     }

@@ -267,7 +267,9 @@ class BatchedEnv(object):
 
     def synthetic_actions(self, out=None, seed=None):
         """Uniform random actions from the bench's synthetic policy (stream ACTION of the *current* call
-        counter); int32[N] on device.  batch_size and lane_offset must be multiples of 4."""
+        counter); int32[N] on device.  lane_offset must be a multiple of 4."""
+        if self.lane_offset % 4:
+            raise ValueError("synthetic_actions: lane_offset must be a multiple of 4 (got %d)" % self.lane_offset)
         if out is None:
             out = torch.empty(self.batch_size, dtype=torch.int32, device=self.device)
         if torch.cuda.current_device() == self.device.index:
@@ -450,6 +452,7 @@ class BatchedEnv(object):
         Asynchronous."""
         if not self._has_reset:
             raise AttributeError("%s: rollout before reset()" % type(self).__name__)
+        self._check_driver_use("rollout_synthetic")
         if actions is None:
             if getattr(self, "_action_scratch", None) is None:
                 self._action_scratch = torch.empty(self.batch_size, dtype=torch.int32, device=self.device)
@@ -466,6 +469,17 @@ class BatchedEnv(object):
             _native.check(rc, "pomdp_rollout_synthetic")
         return self._ob, self._reward, self._done.view(torch.bool)
 
+    def _check_driver_use(self, what):
+        """The C-side episode loops advance the packed state only: they know nothing of RockSample's side statistics
+        (use_heuristic / track_belief envs), and the synthetic policy shares one Philox block among global lanes
+        4q .. 4q+3, so a shard has to start on such a boundary."""
+        if self._tracker is not None:
+            raise ValueError("%s: this env maintains RockSample's side statistics (use_heuristic / track_belief), which "
+                             "the C-side drivers do not update — use step() or heuristic_steps()" % what)
+        if self.lane_offset % 4:
+            raise ValueError("%s: lane_offset must be a multiple of 4 (got %d): the synthetic policy's Philox block is "
+                             "shared by global lanes 4q .. 4q+3" % (what, self.lane_offset))
+
     def collect_synthetic(self, steps, out=None):
         """`steps` consecutive step() calls under the synthetic uniform policy with every step's results KEPT
         (pomdp_collect_synthetic): returns {"action": int32 [steps + 1, N] (row s = the actions of step s, last row = the
@@ -477,6 +491,7 @@ class BatchedEnv(object):
             raise AttributeError("%s: collect before reset()" % type(self).__name__)
         if not self.auto_reset:
             raise ValueError("collect_synthetic needs auto_reset=True")
+        self._check_driver_use("collect_synthetic")
         steps, n = int(steps), self.batch_size
         if out is None:
             out = {"action": torch.empty((steps + 1, n), dtype=torch.int32, device=self.device),
@@ -487,11 +502,15 @@ class BatchedEnv(object):
         assert out["action"].shape == (steps + 1, n) and out["ob"].shape == (steps, n)
         t0 = self._t
         self._t += steps
-        with torch.cuda.device(self.device):
-            rc = self._lib.pomdp_collect_synthetic(
-                _native.ENV_KIND[self.env_name], self._params_ref, self._state.data_ptr(), out["action"].data_ptr(),
-                out["ob"].data_ptr(), out["reward"].data_ptr(), out["done_u8"].data_ptr(), self._err.data_ptr(),
-                n, self._seed, self.lane_offset, t0, steps, n, _native.POMDP_AUTO_RESET, self._stream())
+        args = (_native.ENV_KIND[self.env_name], self._params_ref, self._ptrs[0], out["action"].data_ptr(),
+                out["ob"].data_ptr(), out["reward"].data_ptr(), out["done_u8"].data_ptr(), self._ptrs[4],
+                n, self._seed, self.lane_offset, t0, steps, n, _native.POMDP_AUTO_RESET)
+        if torch.cuda.current_device() == self.device.index:      # no device-context switch on the common path
+            rc = self._lib.pomdp_collect_synthetic(*args, self._stream())
+        else:
+            with torch.cuda.device(self.device):
+                rc = self._lib.pomdp_collect_synthetic(*args, self._stream())
+        if rc:
             _native.check(rc, "pomdp_collect_synthetic")
         return out
 

@@ -73,6 +73,14 @@ class ControlPlane(object):
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return float(t.item())
 
+    def gather(self, obj):
+        """[obj of rank 0, obj of rank 1, ...] on every rank (small python objects: shard ranges, labels)."""
+        if self.dist is None:
+            return [obj]
+        out = [None] * self.world_size
+        self.dist.all_gather_object(out, obj)
+        return out
+
     def close(self):
         if self.dist is not None and self.dist.is_initialized():
             self.dist.barrier()

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define POMDP_ABI_VERSION 7
+#define POMDP_ABI_VERSION 8
 
 enum {
     POMDP_E_BADARG = -1,     /* NULL pointer, n < 0, n + lane0 > 2^32 */
@@ -165,7 +165,7 @@ int pomdp_network_step(const pomdp_network_params *p, uint32_t *state, const int
 /* ---- helpers ---------------------------------------------------------------- */
 /* synthetic uniform random policy used by bench.py: lanes 4q..4q+3 share the Philox block
  * ctr = (q, t lo, t hi, STREAM_ACTION << 24); action = (word[lane & 3] * n_actions) >> 32.
- * n and lane0 must be multiples of 4. */
+ * lane0 must be a multiple of 4 and `action` 16-byte aligned; n is arbitrary. */
 int pomdp_synthetic_actions(int32_t *action, int64_t n, uint64_t seed, uint32_t lane0, uint64_t t,
                             uint32_t n_actions, void *stream);
 /* raw generator, for known-answer tests: out (device) <- Philox4x32-10 of each of the n_blocks
@@ -182,9 +182,11 @@ int pomdp_philox_blocks(const uint32_t *ctr_key, uint32_t *out, int64_t n_blocks
  * only) up to 64 consecutive steps run inside one launch: every step's ob / reward / done / next action is still
  * computed and written, in the same order, and the state when the launch ends, so every buffer holds what the per-step
  * launches leave, but a lane's state and action stay in registers between its steps and the launch ramp is paid once
- * per 64 steps.  Either way `action` holds the
- * actions of t0 + k_steps on return.  The caller's call counter advances by k_steps.  `params` points at the env's
- * pomdp_<env>_params; `reward` is int32 or float per env.  n and lane0 must be multiples of 4. */
+ * per 64 steps; the first launch derives the actions of t0 itself, so there is no policy launch at all.  Either way
+ * `action` holds the actions of t0 + k_steps on return.  The caller's call counter advances by k_steps.  `params` points
+ * at the env's pomdp_<env>_params; `reward` is int32 or float per env.  lane0 must be a multiple of 4 (the policy's
+ * Philox block is shared by global lanes 4q .. 4q+3); n is arbitrary.  Params and pointers are checked before anything
+ * is enqueued. */
 int pomdp_rollout_synthetic(int env, const void *params, uint32_t *state, int32_t *action, int32_t *ob,
                             void *reward, uint8_t *done, uint32_t *err, int64_t n, uint64_t seed,
                             uint64_t action_seed, uint32_t lane0, uint64_t t0, int64_t k_steps, int flags,
@@ -321,6 +323,10 @@ int pomdp_heuristic_steps(int env, const void *params, uint32_t *state, const po
 
 int         pomdp_abi_version(void);
 const char *pomdp_error_string(int code);
+/* introspection: the kernel (name<template arguments>, as a profiler shows it) that the calling thread's most recent
+ * pomdp_rollout_synthetic(POMDP_FUSE_STEPS) / pomdp_collect_synthetic launch picked for the batch geometry it was given;
+ * "" before the first such call.  The string is thread-local and overwritten by the next call. */
+const char *pomdp_last_fused_kernel(void);
 
 #ifdef __cplusplus
 }

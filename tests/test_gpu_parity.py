@@ -450,34 +450,6 @@ def test_compute_prob_matches_reference(case, env, kw):
     assert s._compute_prob(2, None, 2) == 0.0 and s._compute_prob(0, None, 2) == 1.0
 
 
-def test_bench_contract_line():
-    """bench.py prints ONE JSON line with the driver's keys, roofline and cpu_baseline objects."""
-    import json
-    import os
-    import subprocess
-    import sys
-    from conftest import REPO
-    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "20", "--warmup", "2",
-                          "--cpu-seconds", "2"], capture_output=True, text=True, timeout=600, cwd=REPO)
-    assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
-    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
-        assert k in d, k
-    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 2 and d["scaling"] == "weak"
-    assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
-    r = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
-        assert k in r, k
-    assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
-    c = d["cpu_baseline"]
-    for k in ("value", "unit", "cores", "kind", "sample"):
-        assert k in c, k
-    assert d["value"] > 1e8          # the north star's single-GPU target, by a wide margin
-
-
 def test_randomised_configs_vs_oracle(oracle_lib):
     """Property test: random (env config, batch size, seed, lane offset, call counter, auto-reset mode) — the HIP
     path and the oracle stay word-for-word identical.  Seeded, so a failure is reproducible."""

@@ -1,0 +1,184 @@
+"""GPU parity of the kernels bench.py TIMES — the fused multi-step launches behind env.collect_synthetic /
+env.rollout_synthetic(fuse=True) (steps_quad_kernel, tag_steps_quad_kernel, steps_quad_generic_kernel, steps_kernel) and
+the fused rollout kernel — against the CPU oracle DIRECTLY: every row of every collected step over the whole batch, at
+BASELINE.json's per-GPU sizes (metric: RockSample(7,8) 2^20 lanes; C3 Tag 2^20; C4 BattleShip 10x10 2^19 lanes per GPU;
+C5 RockSample(15,15) 2^21 simulations per GPU = 2048 roots x 1024).  Plus: env.seed(), and the bench command the driver
+runs (single GPU with --steps 20 --warmup 5, and --gpus 2 self-launched with both ranks on the one visible GPU)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO
+from test_gpu_parity import make_env, np_
+
+pytestmark = pytest.mark.gpu
+
+FULL = [("rock", {}, 1 << 20, 70), ("rock", dict(board_size=15, num_rocks=15), 1 << 20, 70), ("tag", {}, 1 << 20, 70),
+        ("tiger", {}, 1 << 20, 70), ("network", {}, 1 << 20, 70),
+        ("battleship", dict(board_size=(10, 10), max_len=5), 1 << 19, 70),            # C4: 2^22 lanes over 8 GPUs
+        ("stochrock", {}, 1 << 18, 70), ("battleship", {}, 1 << 18, 70),
+        # the shards a 2^20-lane batch leaves per GPU at 2, 4 and 8 GPUs
+        ("rock", {}, 1 << 19, 66), ("rock", {}, 1 << 18, 66), ("rock", {}, 1 << 17, 66),
+        ("tag", {}, 1 << 17, 66), ("tiger", {}, 1 << 17, 66), ("network", {}, 1 << 17, 66)]
+
+
+@pytest.mark.parametrize("env,kw,n,steps", FULL, ids=["%s%s-%d" % (c[0], "-".join(str(v) for v in c[1].values()), c[2]) for c in FULL])
+def test_collected_rows_equal_the_oracle(oracle_lib, env, kw, n, steps):
+    """collect_synthetic(steps) — what bench.py's timed region calls — against oracle.batch_step fed with the synthetic
+    policy's actions: every row (action, ob, reward, done) over the whole batch, across the 64-step launch boundary, then
+    the final state."""
+    seed, lane0, t0 = 20260929, 1 << 22, (1 << 33) + 5
+    nt = oracle_lib.max_threads()
+    e = make_env(env, kw, batch_size=n, seed=seed, lane_offset=lane0, reuse_buffers=True)
+    e.call_counter = t0
+    o = oracle_lib.OracleEnv(env, **kw)
+    st = o.new_state(n)
+    assert np.array_equal(np_(e.reset()), o.batch_reset(st, seed, lane0, t0, nthreads=nt))
+    tr = e.collect_synthetic(steps)
+    done = np.zeros(n, np.uint8)
+    for k in range(steps):
+        t = t0 + 1 + k
+        a = oracle_lib.synthetic_actions(n, seed, lane0, t, o.n_actions, nthreads=nt)
+        ob, rew, done, bad = o.batch_step(st, a, seed, lane0, t, auto_reset=True, done=done, nthreads=nt)
+        ctx = (env, kw, n, k)
+        assert bad == 0, ctx
+        assert np.array_equal(np_(tr["action"][k]), a), ctx
+        assert np.array_equal(np_(tr["ob"][k]), ob), ctx
+        assert np.array_equal(np_(tr["reward"][k]), rew), ctx
+        assert np.array_equal(np_(tr["done"][k]), done.astype(bool)), ctx
+    assert np.array_equal(np_(tr["action"][steps]), oracle_lib.synthetic_actions(n, seed, lane0, t0 + 1 + steps, o.n_actions, nthreads=nt))
+    assert np.array_equal(np_(e.state).view(np.uint32), st)
+    assert e.invalid_action_count() == 0
+
+
+@pytest.mark.parametrize("env,kw,n", [("rock", {}, 1 << 20), ("tag", {}, 1 << 20), ("network", {}, 1 << 18)],
+                         ids=["rock", "tag", "network"])
+def test_fused_overwrite_mode_equals_the_oracle(oracle_lib, env, kw, n):
+    """rollout_synthetic(fuse=True) (bench.py --collect 0): after k fused steps the N-element outputs hold the LAST step's
+    results and `actions` the following call counter's — against the oracle."""
+    seed, lane0 = 31337, 4096
+    nt = oracle_lib.max_threads()
+    e = make_env(env, kw, batch_size=n, seed=seed, lane_offset=lane0, reuse_buffers=True)
+    o = oracle_lib.OracleEnv(env, **kw)
+    st = o.new_state(n)
+    o.batch_reset(st, seed, lane0, 0, nthreads=nt)
+    e.reset()
+    done, t = np.zeros(n, np.uint8), 1
+    for k in (20, 64, 3):
+        ob_g, rew_g, done_g = e.rollout_synthetic(k, fuse=True)
+        for _ in range(k):
+            a = oracle_lib.synthetic_actions(n, seed, lane0, t, o.n_actions, nthreads=nt)
+            ob, rew, done, bad = o.batch_step(st, a, seed, lane0, t, auto_reset=True, done=done, nthreads=nt)
+            t += 1
+        assert np.array_equal(np_(ob_g), ob) and np.array_equal(np_(rew_g), rew) and np.array_equal(np_(done_g), done.astype(bool)), (env, k)
+        assert np.array_equal(np_(e._action_scratch), oracle_lib.synthetic_actions(n, seed, lane0, t, o.n_actions, nthreads=nt))
+        assert np.array_equal(np_(e.state).view(np.uint32), st), (env, k)
+
+
+def test_rollouts_at_the_c5_per_gpu_size(oracle_lib):
+    """BASELINE.json configs[4] per GPU: RockSample(15,15), 2048 roots x 1024 simulations = 2^21 lanes, one fused rollout
+    launch — every simulation's return (float64, bit for bit), length, first action, last observation and termination."""
+    kw, roots, sims, depth = dict(board_size=15, num_rocks=15), 2048, 1024, 64
+    seed, lane0 = 55, 1 << 21                                            # the second GPU's lane range
+    nt = oracle_lib.max_threads()
+    o = oracle_lib.OracleEnv("rock", **kw)
+    e = make_env("rock", kw, batch_size=roots, seed=seed, lane_offset=lane0)
+    st = o.new_state(roots)
+    o.batch_reset(st, seed, lane0, 0, nthreads=nt)
+    e.reset()
+    for _ in range(4):
+        a = oracle_lib.synthetic_actions(roots, seed, lane0, e.call_counter, o.n_actions)
+        o.batch_step(st, a, seed, lane0, e.call_counter, nthreads=nt)
+        e.step(torch.as_tensor(a, device="cuda"))
+    assert np.array_equal(np_(e.state).view(np.uint32), st)
+    t0 = e.call_counter
+    want = o.batch_rollout(st, sims, depth, e._discount, seed, lane0, t0, nthreads=nt)
+    got = e.rollout(depth, sims_per_root=sims)
+    assert np.array_equal(np_(got["ret"]).view(np.uint64), want["ret"].view(np.uint64))
+    for k in ("n_steps", "first_action", "last_ob"):
+        assert np.array_equal(np_(got[k]), want[k]), k
+    assert np.array_equal(np_(got["terminated"]), want["terminated"].astype(bool))
+    assert int(want["n_steps"].sum()) > roots * sims                      # the simulations really ran
+
+
+@pytest.mark.parametrize("env,kw", [("rock", {}), ("tag", {}), ("battleship", {}), ("tiger", {}), ("network", {})],
+                         ids=["rock", "tag", "battleship", "tiger", "network"])
+def test_seed_call_equals_a_fresh_env(env, kw):
+    """a16: env.seed(s) (rock.py:120-121 etc.) puts an env that already ran where a fresh env built with seed=s starts:
+    same reset observation, same trajectory; and returns [s] like gym's seed()."""
+    n = 4096
+    used = make_env(env, kw, batch_size=n, seed=1, lane_offset=64)
+    used.reset()
+    for _ in range(5):
+        used.step(used.synthetic_actions())
+    assert used.seed(987654321) == [987654321]
+    fresh = make_env(env, kw, batch_size=n, seed=987654321, lane_offset=64)
+    assert torch.equal(used.reset(), fresh.reset()) and torch.equal(used.state, fresh.state)
+    for _ in range(12):
+        a = fresh.synthetic_actions()
+        assert torch.equal(used.synthetic_actions(), a)
+        ra, rb = used.step(a), fresh.step(a)
+        assert all(torch.equal(x, y) for x, y in zip(ra[:3], rb[:3]))
+        assert torch.equal(used.state, fresh.state)
+    one, two = make_env(env, kw, seed=3), make_env(env, kw, seed=99)     # scalar mode (the reference's usage)
+    one.reset()
+    one.step(0)
+    one.seed(99)
+    assert one.reset() == two.reset()
+    assert one.step(1)[:3] == two.step(1)[:3]
+
+
+def _bench(*argv, timeout=900):
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + [str(a) for a in argv], capture_output=True, text=True,
+                         timeout=timeout, cwd=REPO, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_line_as_the_driver_runs_it():
+    """`python bench.py --gpus 1 --steps 20 --warmup 5`: ONE JSON line with the contract's keys, and the figures of the
+    timed region — no allocation inside it, the fused kernel named as a profiler shows it, the per-step time and roofline
+    fraction of the committed profiles (within the spread of a short region)."""
+    d = _bench("--gpus", 1, "--steps", 20, "--warmup", 5, "--cpu-seconds", 2)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
+    assert d["config"]["seeds"] == [0, 1, 2] and d["config"]["repeats"] >= 30 and len(d["config"]["seed_values"]["per_seed"]) == 3
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["kernel"].startswith("steps_quad_kernel<RockEnv<1>>"), r["kernel"]
+    assert r["kernel_ms"] < 4.0e-3 and r["frac"] > 0.45, r             # profiles: 2.95-3.0 us per step, 0.58-0.60
+    assert d["ms_per_step"] < 5e-3, d["ms_per_step"]                   # by wall clock, launch + sync wake-up included
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert d["value"] > 1e8          # the north star's single-GPU target, by a wide margin
+
+
+def test_bench_self_launches_two_ranks_on_the_one_gpu():
+    """`python bench.py --gpus 2` (no torch.distributed.run around it) starts its two ranks itself; with one visible GPU
+    they share it.  The shards tile the global lane range, the line reports both scaling modes."""
+    d = _bench("--gpus", 2, "--steps", 64, "--warmup", 5, "--seeds", "0", "--repeats", 5)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    cfg = d["config"]
+    assert cfg["lanes_per_gpu"] == 1 << 20 and cfg["total_lanes"] == 2 << 20
+    sh = sorted(cfg["shards"], key=lambda s: s["rank"])
+    assert [s["rank"] for s in sh] == [0, 1]
+    assert sh[0]["lane_offset"] == 0 and sh[1]["lane_offset"] == sh[0]["lanes"] == 1 << 20 and sh[1]["lanes"] == 1 << 20
+    assert d["value"] > 1e8 and "cpu_baseline" not in d
+    s = d["strong_scaling"]
+    assert s["total_lanes"] == 1 << 20 and s["lanes_per_gpu"] == 1 << 19 and s["value"] > 1e8

@@ -99,3 +99,66 @@ def test_control_plane_single_process():
     assert cp.world_size == 1 and cp.max(3.5) == 3.5 and cp.sum(2) == 2.0
     cp.barrier()
     cp.close()
+
+
+def test_control_plane_gather_single_process():
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        os.environ.pop(k, None)
+    cp = sharding.ControlPlane()
+    assert cp.gather((0, 16)) == [(0, 16)]
+    cp.close()
+
+
+def _gather_worker(rank, world, port, out_q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    cp = sharding.ControlPlane()
+    out_q.put((rank, cp.gather(sharding.shard_range(1 << 20, rank, world)), cp.max(rank + 1.0)))
+    cp.close()
+
+
+def test_control_plane_gathers_the_shard_table_over_gloo():
+    """What bench.py does with N ranks: every rank learns every rank's (lane_offset, lanes), timings are max-reduced."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, table, mx in results:
+        assert table == [(0, 1 << 19), (1 << 19, 1 << 19)] and mx == 2.0
+
+
+def test_bench_starts_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` outside torch.distributed.run re-executes itself under it, one rank per GPU, rendezvous
+    on 127.0.0.1, all of its own arguments passed on; under torch.distributed.run (WORLD_SIZE set) it does not."""
+    import subprocess
+    import sys
+    from conftest import REPO
+    sys.path.insert(0, REPO)
+    import bench
+    calls = []
+    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: calls.append((cmd, env)) or 0)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "20", "--warmup", "5"])
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    with pytest.raises(SystemExit) as ex:
+        bench.main()
+    assert ex.value.code == 0 and len(calls) == 1
+    cmd, env = calls[0]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and "--nnodes=1" in cmd
+    i = cmd.index(os.path.abspath(bench.__file__))
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "20", "--warmup", "5"]
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # a rank started with the wrong world size says so instead of running
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(SystemExit) as ex:
+        bench.main()
+    assert "WORLD_SIZE=2" in str(ex.value.code) and len(calls) == 1

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Fused-launch time per step at the shard sizes a 2^20-lane batch leaves per GPU (2^17 .. 2^20, and below), for every
+library variant given: python tools/gpu_small_shards.py [libA.so libB.so ...]   (default: the product library).
+Variants come from tools/ab_build.sh (e.g. -DPOMDP_QUAD_MIN_LANES=4096: the quad-per-thread loops from 4096 lanes up).
+Prints us per step of collect_synthetic(64) by HIP events, and the kernel the launcher picked."""
+import os
+import subprocess
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+ENVS = [("rock", "Rock-v0", {}), ("rock15", "Rock-v0", dict(board_size=15, num_rocks=15)), ("tag", "Tag-v0", {}),
+        ("tiger", "Tiger-v0", {}), ("network", "Network-v0", {}),
+        ("battleship", "Battleship-v0", dict(board_size=(10, 10), max_len=5))]
+
+
+def one(lib_path):
+    import torch
+    from gym_pomdp_amd import _native
+    if lib_path:
+        _native.LIB_PATH = lib_path
+    import gym_pomdp_amd as gpa
+    L = _native.lib()
+    print("library: %s" % _native.LIB_PATH)
+    for name, env_id, kw in ENVS:
+        for lg in (14, 16, 17, 18, 19, 20):
+            n = 1 << lg
+            e = gpa.make(env_id, batch_size=n, seed=0, reuse_buffers=True, **kw)
+            e.reset()
+            tr = e.collect_synthetic(64)
+            for _ in range(20):
+                e.collect_synthetic(64, out=tr)
+            torch.cuda.synchronize()
+            best = 1e9
+            for _ in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    e.collect_synthetic(64, out=tr)
+                e1.record()
+                torch.cuda.synchronize()
+                best = min(best, e0.elapsed_time(e1) / 640 * 1e3)
+            print("%-10s 2^%d lanes: %7.3f us/step  %8.3e lane-steps/s  %s" % (name, lg, best, n / best * 1e6,
+                                                                               L.pomdp_last_fused_kernel().decode()), flush=True)
+            del e, tr
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--one":
+        one(sys.argv[2] if len(sys.argv) > 2 and sys.argv[2] != "-" else None)
+    else:
+        for lib in (sys.argv[1:] or ["-"]):
+            subprocess.check_call([sys.executable, os.path.abspath(__file__), "--one", lib])

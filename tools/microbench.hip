@@ -265,9 +265,9 @@ int main(int argc, char **argv)
                 hipLaunchKernelGGL((step_kernel<E, 4>), dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, 0, state, action, ob, reward, done, err, n, make_key(1, t), 0u, 1, RngKey(), p);
             }, iters));
         };
-        run(RockEnv<1, 0>{}, "step full");
+        run(RockEnv<1>{}, "step full");
         {
-            using E = RockEnv<1, 0>;
+            using E = RockEnv<1>;
             printf("%-28s: LPT1 %8.2f", "chain step", time_it([&](int t) {
                 hipLaunchKernelGGL((step_kernel<E, 1, true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, state, action, ob, reward, done, err, n, make_key(1, t), 0u, 1, make_key(1, t + 1), p);
             }, iters));
@@ -284,32 +284,6 @@ int main(int argc, char **argv)
             }
             printf("\n");
         }
-        {   // ABLATE 8: the data-independent Philox pass runs after the loads were consumed instead of under their latency
-            using E = RockEnv<1, 8>;
-            printf("%-28s: plain LPT2 %8.2f", "late prepass (ablate 8)", time_it([&](int t) {
-                hipLaunchKernelGGL((step_kernel<E, 2>), dim3((unsigned)((n + 511) / 512)), dim3(256), 0, 0, state, action, ob, reward, done, err, n, make_key(1, t), 0u, 1, RngKey(), p);
-            }, iters));
-            printf("  chain LPT2 %8.2f\n", time_it([&](int t) {
-                hipLaunchKernelGGL((step_kernel<E, 2, true>), dim3((unsigned)((n + 511) / 512)), dim3(256), 0, 0, state, action, ob, reward, done, err, n, make_key(1, t), 0u, 1, make_key(1, t + 1), p);
-            }, iters));
-        }
-        {
-            auto nt = [&](auto env_tag, const char *name) {
-                using E = decltype(env_tag);
-                printf("%-28s: plain LPT2 %8.2f", name, time_it([&](int t) {
-                    hipLaunchKernelGGL((step_kernel<E, 2>), dim3((unsigned)((n + 511) / 512)), dim3(256), 0, 0, state, action, ob, reward, done, err, n, make_key(1, t), 0u, 1, RngKey(), p);
-                }, iters));
-                printf("  chain LPT2 %8.2f\n", time_it([&](int t) {
-                    hipLaunchKernelGGL((step_kernel<E, 2, true>), dim3((unsigned)((n + 511) / 512)), dim3(256), 0, 0, state, action, ob, reward, done, err, n, make_key(1, t), 0u, 1, make_key(1, t + 1), p);
-                }, iters));
-            };
-            nt(RockEnv<1, 16>{}, "cached loads/stores (ablate 16)");
-        }
-        run(RockEnv<1, 1>{}, "step -checkphilox");
-        run(RockEnv<1, 2>{}, "step -reset");
-        run(RockEnv<1, 3>{}, "step -checkphilox -reset");
-        run(RockEnv<1, 4>{}, "step -lds");
-        run(RockEnv<1, 7>{}, "step -all");
     }
     {   // split the batch over S streams: policy + step per part, parts are independent
         for (int S : {1, 2, 4}) {
@@ -336,7 +310,7 @@ int main(int argc, char **argv)
     printf("pomdp_rollout_synthetic (C driver, chained), per step: %8.2f\n",
            time_it([&](int t) { pomdp_rollout_synthetic(POMDP_ENV_ROCK, &p, state, action, ob, reward, done, err, n, 1, 1, 0, (uint64_t)t * 100, 100, 1, nullptr); }, iters / 100 + 1) / 100);
     {   // fused multi-step launches: 64 chained steps per launch (SIMPLE = full workgroups, auto-reset), per step
-        using E = RockEnv<1, 0>;
+        using E = RockEnv<1>;
         const int reps = iters / 64 + 1;
         printf("steps_kernel (64 steps per launch), per step: LPT2 simple %6.2f", time_it([&](int t) {
             hipLaunchKernelGGL((steps_kernel<E, 2, true>), dim3((unsigned)(n / 512)), dim3(256), 0, 0, state, action, ob, reward, done, err, n, make_key(1, 64 * t), 0u, 1, make_key(1, 64 * t + 1), 64, 0, p);
@@ -348,7 +322,9 @@ int main(int argc, char **argv)
             hipLaunchKernelGGL((steps_kernel<E, 4, true>), dim3((unsigned)(n / 1024)), dim3(256), 0, 0, state, action, ob, reward, done, err, n, make_key(1, 64 * t), 0u, 1, make_key(1, 64 * t + 1), 64, 0, p);
         }, reps) / 64);
     }
-    {   // where the fused loop's time goes: the LPT4 SIMPLE kernel with pieces ablated (results are wrong, timing only)
+    {   // the LPT4 SIMPLE fused loop with the table-driven and the arithmetic lane step (the ablation variants of round 1 —
+        // no sensor block / no auto-reset / no LDS lookups — were built from RockEnv<W, ABLATE>, which the product no longer
+        // carries: `git show 2884871:tools/microbench.hip` has them)
         const int reps = iters / 64 + 1;
         auto fused4 = [&](auto tag, const char *what) {
             using E = decltype(tag);
@@ -357,17 +333,13 @@ int main(int argc, char **argv)
             }, reps) / 64);
         };
         printf("  steps_kernel LPT4 simple, lane step from the (position, action) table     %6.2f us/step  <- as shipped from 16 steps per launch\n", time_it([&](int t) {
-            hipLaunchKernelGGL((steps_kernel<RockEnv<1, 0>, 4, true, true>), dim3((unsigned)(n / 1024)), dim3(256), 0, 0, state, action, ob, reward, done, err, n, make_key(1, 64 * t), 0u, 1, make_key(1, 64 * t + 1), 64, 0, p);
+            hipLaunchKernelGGL((steps_kernel<RockEnv<1>, 4, true, true>), dim3((unsigned)(n / 1024)), dim3(256), 0, 0, state, action, ob, reward, done, err, n, make_key(1, 64 * t), 0u, 1, make_key(1, 64 * t + 1), 64, 0, p);
         }, reps) / 64);
-        fused4(RockEnv<1, 0>{}, "arithmetic lane step");
-        fused4(RockEnv<1, 1>{}, "without the sensor Philox block (1)");
-        fused4(RockEnv<1, 2>{}, "without auto-reset (2)");
-        fused4(RockEnv<1, 4>{}, "without the LDS table lookups (4)");
-        fused4(RockEnv<1, 7>{}, "without all three (7)");
+        fused4(RockEnv<1>{}, "arithmetic lane step");
         int32_t *ta, *to, *tr; uint8_t *td;                         // 64-row trajectory buffers
         CK(hipMalloc(&ta, 65 * n * 4)); CK(hipMalloc(&to, 64 * n * 4)); CK(hipMalloc(&tr, 64 * n * 4)); CK(hipMalloc(&td, 64 * n));
         printf("  steps_kernel LPT4 simple, one row per step (rec = n)                   %6.2f us/step\n", time_it([&](int t) {
-            hipLaunchKernelGGL((steps_kernel<RockEnv<1, 0>, 4, true>), dim3((unsigned)(n / 1024)), dim3(256), 0, 0, state, ta, to, tr, td, err, n, make_key(1, 64 * t), 0u, 1, make_key(1, 64 * t + 1), 64, n, p);
+            hipLaunchKernelGGL((steps_kernel<RockEnv<1>, 4, true>), dim3((unsigned)(n / 1024)), dim3(256), 0, 0, state, ta, to, tr, td, err, n, make_key(1, 64 * t), 0u, 1, make_key(1, 64 * t + 1), 64, n, p);
         }, reps) / 64);
         printf("  store floor (13 B per lane-step, 64 steps per launch), Philox blocks per thread-step 0 / 1 / 2 / 3, same row | own row:\n   ");
         for (int64_t rec : {(int64_t)0, n}) {
@@ -390,7 +362,7 @@ int main(int argc, char **argv)
         CK(hipFree(ta)); CK(hipFree(to)); CK(hipFree(tr)); CK(hipFree(td));
     }
     {   // hipGraph replay of 100 chained step launches vs the same launches issued one by one
-        using E = RockEnv<1, 0>;
+        using E = RockEnv<1>;
         hipStream_t gs; CK(hipStreamCreateWithFlags(&gs, hipStreamNonBlocking));
         hipGraph_t g; hipGraphExec_t ge;
         CK(hipStreamBeginCapture(gs, hipStreamCaptureModeGlobal));
@@ -409,7 +381,7 @@ int main(int argc, char **argv)
         CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g)); CK(hipStreamDestroy(gs));
     }
     {   // does the CPU's run-ahead matter?  chained step launches on the null stream / a created stream, paced by a busy-wait
-        using E = RockEnv<1, 0>;
+        using E = RockEnv<1>;
         hipStream_t cs; CK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
         for (hipStream_t strm : {(hipStream_t)0, cs}) {
             for (double pace_us : {0.0, 3.0, 5.0, 6.5}) {
@@ -438,7 +410,7 @@ int main(int argc, char **argv)
         CK(hipStreamDestroy(cs));
     }
     {   // chained step launches (step + next policy in one kernel), batch split over S streams, launches interleaved
-        using E = RockEnv<1, 0>;
+        using E = RockEnv<1>;
         for (int S : {1, 2, 4, 8}) {
             std::vector<hipStream_t> st(S);
             for (auto &x : st) CK(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
