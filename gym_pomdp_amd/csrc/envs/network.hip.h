@@ -71,6 +71,68 @@ struct NetworkEnv {
         return ob == 2 ? 1.0 : 0.0;
     }
 
+    // ---- pieces of the step for the quad-per-thread fused loop (pomdp_kernels.hip: network_steps_quad_kernel) ----------
+    // Thresholds against the draw's HIGH word itself: k53 <= thr is decided by (H >> 5) < (thr >> 26), i.e. H < T with
+    // T = (thr >> 26) << 5, unless H lies in [T, T + 32) — the tie (probability 2^-27) that asks for the low word.
+    struct Thr { uint32_t fail, nb, obs; };
+    static __device__ __forceinline__ Thr thresholds(const Params &p)
+    {
+        return Thr{(uint32_t)(p.fail_thr >> 26) << 5, (uint32_t)(p.fail_nb_thr >> 26) << 5, (uint32_t)(p.obs_thr >> 26) << 5};
+    }
+    // machines that see a failed neighbour (network.py:82-85), from the nibble tables
+    static __device__ __forceinline__ uint32_t nb_failed_of(const Shared &sh, const Params &p, uint32_t s0)
+    {
+        const int M = p.n_machines;
+        const uint32_t down = ~s0 & (M >= 32 ? 0xFFFFFFFFu : ((1u << M) - 1u));
+        uint32_t nbf = 0;
+        for (int k = 0; 4 * k < M; ++k) nbf |= sh.nbf[k][(down >> (4 * k)) & 15u];          // wave-uniform trip count
+        return nbf;
+    }
+    // N consecutive draws of a lane's STEP stream (high words of one Philox block) applied to the next N up machines of
+    // `todo` (network.py:94-99, index order): returns the machines that fail, removes the N from `todo`, and folds "some
+    // draw was a tie" into `near` (the minimum of H - T over the draws; a tie has H - T < 32 — the caller then takes the
+    // exact per-lane form, so a false alarm from a slot without a machine costs time, 2^-27 of the time, and nothing
+    // else).  A slot without a machine (todo ran out) kills nothing.
+    template <int N>
+    static __device__ __forceinline__ uint32_t draws(const uint32_t (&H)[N], uint32_t &todo, uint32_t nbf, const Thr &T, uint32_t &near)
+    {
+        uint32_t kill = 0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const uint32_t lb = todo & (0u - todo);                              // this draw's machine; 0 = none left
+            todo ^= lb;
+            const uint32_t t = (nbf & lb) ? T.nb : T.fail;
+            kill |= H[k] < t ? 0u : lb;                                          // fails iff k53 > thr
+            near = min(near, H[k] - t);
+        }
+        return kill;
+    }
+    static __device__ __forceinline__ uint32_t draw4(const uint4 &h, uint32_t &todo, uint32_t nbf, const Thr &T, uint32_t &near)
+    {
+        const uint32_t H[4] = {h.x, h.y, h.z, h.w};
+        return draws<4>(H, todo, nbf, T, near);
+    }
+    // the action's draw (network.py:106-109): word `w` of the same stream; truthful iff k53 <= obs_thr
+    static __device__ __forceinline__ bool truthful_of(uint32_t w, const Thr &T, uint32_t &near)
+    {
+        near = min(near, w - T.obs);
+        return w < T.obs;
+    }
+    // reward, observation and the reboot (network.py:87-92, 101-112) once the machine draws are in: s = state after the
+    // failures, base = reward before the action's cost
+    template <class RT>
+    static __device__ __forceinline__ void finish(const Params &p, uint32_t &s, int a, int base, bool truthful, int &ob, RT &rew)
+    {
+        double r = (double)base;
+        ob = 2;
+        if (a < 2 * p.n_machines) {
+            const int machine = a >> 1;
+            if (a & 1) { r -= 2.5; s |= 1u << machine; ob = truthful; }
+            else { r -= .1; const int up = (int)((s >> machine) & 1u); ob = truthful ? up : 1 - up; }
+        }
+        rew = (RT)r;
+    }
+
     // network.py:71-114.  The reference draws one double per *up* machine in index order, then one for
     // the action.  Lanes iterate over the draws (j = 0, 1, ...), not over the machines: j is
     // wave-uniform, so the Philox block that feeds doubles 2q and 2q+1 is generated under a uniform

@@ -1278,6 +1278,195 @@ __global__ __launch_bounds__(BLOCK) void tag_steps_quad_kernel(uint32_t *__restr
     st_stream4(state + l0, st[0].w, st[1].w, st[2].w, st[3].w);
 }
 
+// Network with a quad per thread.  The reference draws one double per UP machine and one for the action (network.py:94-109),
+// from the lane's own stream, four high words per Philox block (split layout).  Under a random policy a lane
+// has 1.4 machines up on average (12 % of the lanes have three or more, 2 % four or more), so almost every lane-step is
+// served by the FIRST block of its stream: each of the thread's four lanes computes that block and applies its first two
+// words to its first two up machines straight-line (NetworkEnv::draws), the action's draw being the word after the last
+// machine — no loop to the wave's largest draw count, which is what steps_kernel<NetworkEnv> pays for every lane.  Lanes
+// with more draws to make (a third machine, or the action's draw behind three) hand (machines left, failed-neighbour set,
+// the block's other two words) to a per-wave task list; one pooled pass per 64 such lanes continues their streams — the
+// two words, then block by block — and returns the machines that fail and the action's draw.  The policy's ACTION block
+// is the thread's own, the outputs leave as 16-byte stores, the reward comes from a table of the float32(float64) values
+// the reference's arithmetic gives.  A draw decided by its low word (2^-27 per draw) sends the lane through
+// NetworkEnv::step, the exact per-lane form.  Network never terminates, so there is no reset.
+template <int NB>   // bytes of the machine set: ceil(n_machines / 8)
+__global__ __launch_bounds__(BLOCK) void network_steps_quad_kernel(uint32_t *__restrict__ state, int32_t *__restrict__ action,
+                                                                   int32_t *__restrict__ ob, float *__restrict__ reward,
+                                                                   uint8_t *__restrict__ done, int64_t n, RngKey key0,
+                                                                   uint32_t lane0, RngKey akey0, int k_steps, int64_t rec,
+                                                                   int gen_first, const NetworkEnv::Params p)
+{
+    using Env = NetworkEnv;
+    __shared__ Env::Shared sh;                               // the nibble tables of the exact per-lane form (ties only)
+    __shared__ uint32_t nbf8[NB][256];                       // nbf8[k][v]: machines that see a failed neighbour when the down
+                                                             // machines among 8 k .. 8 k + 7 are the set v (network.py:82-85)
+    __shared__ float rtab[3][68];                            // reward by (no action / ping / reboot, 2 per up machine with > 2
+                                                             // neighbours + 1 per other up machine): network.py:87-92, 103, 110
+    __shared__ uint32_t task_lds[BLOCK / 64][256][6];        // task rank -> {lane within the wave's 256 | has_action << 8, machines
+                                                             // left, failed-neighbour set, words 2 and 3 of the lane's first
+                                                             // block}; overwritten with {machines that fail, flags}
+    const int wv = (int)(threadIdx.x >> 6), me = (int)(threadIdx.x & 63u);
+    const uint32_t l0 = blockIdx.x * (uint32_t)(4 * BLOCK) + 4u * threadIdx.x;
+    const uint32_t glane0 = lane0 + l0, wave0 = glane0 - 4u * (uint32_t)me;
+    uint32_t *action_w = reinterpret_cast<uint32_t *>(action) + l0, *ob_w = reinterpret_cast<uint32_t *>(ob) + l0;
+    uint32_t *reward_w = reinterpret_cast<uint32_t *>(reward) + l0;
+    uint32_t *done_w = reinterpret_cast<uint32_t *>(done + l0);
+    const uint32_t n_act = (uint32_t)Env::n_actions(p);
+    uint32_t st[4];
+    int a_cur[4];
+    {
+        const u32x4 s4 = ld_stream4(state + l0);
+        const u32x4 a4 = first_actions4(action_w, gen_first, glane0, akey0, n_act);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a_cur[j] = (int)a4[j]; st[j] = s4[j]; }
+    }
+    action_w += rec;
+    Env::stage(sh, p, (int)threadIdx.x);
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb) {                        // BLOCK threads = the 256 values of a byte
+        uint32_t m = 0;
+        for (int i = 0; i < p.n_machines; ++i) m |= (((p.nb_mask[i] >> (8 * kb)) & threadIdx.x) != 0u ? 1u : 0u) << i;
+        nbf8[kb][threadIdx.x] = m;
+    }
+    if (threadIdx.x < 3 * 68) {                              // r = float32(float64(base) - cost), as the reference computes it
+        const int kind = (int)threadIdx.x / 68, b = (int)threadIdx.x % 68;
+        double r = (double)b;
+        if (kind == 1) r -= .1;
+        if (kind == 2) r -= 2.5;
+        rtab[kind][b] = (float)r;
+    }
+    __syncthreads();
+    const Env::Thr T = Env::thresholds(p);
+    const uint32_t all_up = p.n_machines >= 32 ? 0xFFFFFFFFu : ((1u << p.n_machines) - 1u);
+    const int M2 = 2 * p.n_machines;
+    const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo, ta0 = ((uint64_t)akey0.t_hi << 32) | akey0.t_lo;
+    for (int s = 0; s < k_steps; ++s) {
+        RngKey key = key0;
+        key.t_lo = (uint32_t)(t0 + (uint64_t)s); key.t_hi = (uint32_t)((t0 + (uint64_t)s) >> 32);
+        const uint64_t ta = ta0 + (uint64_t)s;
+        const uint4 pw = philox4x32_10(glane0 >> 2, (uint32_t)ta, (uint32_t)(ta >> 32), (uint32_t)POMDP_STREAM_ACTION << 24, key.k0, key.k1);
+        const uint32_t P[4] = {pw.x, pw.y, pw.z, pw.w};
+        uint32_t kill[4], todo[4], nbf[4], near[4], hz[4], hw[4];
+        int base[4];
+        bool truthful[4], more[4], act_pending[4];
+        uint64_t mm[4];
+        int ntask = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t s0 = st[j];
+            const uint4 h = stream_block(key, glane0 + (uint32_t)j, POMDP_STREAM_STEP, 0u);
+            const int n_up = __popc(s0);
+            base[j] = n_up + __popc(s0 & p.deg_gt2_mask);                      // network.py:87-92
+            {
+                const uint32_t down = ~s0 & all_up;
+                uint32_t f = nbf8[0][down & 255u];
+#pragma unroll
+                for (int kb = 1; kb < NB; ++kb) f |= nbf8[kb][(down >> (8 * kb)) & 255u];
+                nbf[j] = f;
+            }
+            todo[j] = s0;
+            near[j] = 0xFFFFFFFFu;
+            const uint32_t H2[2] = {h.x, h.y};
+            kill[j] = Env::draws<2>(H2, todo[j], nbf[j], T, near[j]);
+            hz[j] = h.z; hw[j] = h.w;
+            const bool has_action = a_cur[j] < M2;
+            uint32_t aw = n_up == 1 ? h.y : h.x;                                // word n_up of the block (n_up < 3), as selects
+            aw = n_up >= 2 ? h.z : aw;
+            uint32_t near_a = 0xFFFFFFFFu;
+            const bool tr = Env::truthful_of(aw, T, near_a);
+            const bool here = has_action && n_up < 3;                           // the action's draw is one of these three words
+            truthful[j] = here && tr;
+            near[j] = min(near[j], here ? near_a : 0xFFFFFFFFu);
+            act_pending[j] = has_action && !here;
+            more[j] = todo[j] != 0u || act_pending[j];
+            mm[j] = __ballot(more[j]);
+            ntask += __popcll(mm[j]);
+        }
+        if (ntask) {                                                           // wave-uniform
+            int rank[4], c = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                rank[j] = c + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm[j], 0u));
+                c += __popcll(mm[j]);
+                if (more[j]) {
+                    uint32_t *t = task_lds[wv][rank[j] & 255];
+                    t[0] = (uint32_t)(4 * me + j) | ((uint32_t)act_pending[j] << 8); t[1] = todo[j]; t[2] = nbf[j];
+                    t[3] = hz[j]; t[4] = hw[j];
+                }
+            }
+            for (int b0 = 0; b0 < ntask; b0 += 64) {
+                const int q = b0 + me;
+                if (q < ntask) {
+                    uint32_t *t = task_lds[wv][q & 255];
+                    const uint32_t w0 = t[0], src_lane = wave0 + (w0 & 255u), nb = t[2];
+                    uint32_t td = t[1], nr = 0xFFFFFFFFu;
+                    bool pend = (w0 >> 8) & 1u, tr = false;
+                    // words 2 and 3 of the first block, then the stream's following blocks
+                    const uint32_t H2[2] = {t[3], t[4]};
+                    int left = __popc(td);
+                    uint32_t kl = Env::draws<2>(H2, td, nb, T, nr);
+                    if (pend && left < 2) { tr = Env::truthful_of(left == 0 ? H2[0] : H2[1], T, nr); pend = false; }
+                    for (uint32_t blk = 1; td != 0u || pend; ++blk) {
+                        const uint4 h = stream_block(key, src_lane, POMDP_STREAM_STEP, 2u * blk);
+                        left = __popc(td);
+                        kl |= Env::draw4(h, td, nb, T, nr);
+                        if (pend && left < 4) {
+                            uint32_t w = left == 1 ? h.y : h.x;
+                            w = left == 2 ? h.z : w;
+                            w = left == 3 ? h.w : w;
+                            tr = Env::truthful_of(w, T, nr);
+                            pend = false;
+                        }
+                    }
+                    t[0] = kl; t[1] = (uint32_t)tr | (nr < 32u ? 2u : 0u);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (more[j]) {
+                    const uint32_t *t = task_lds[wv][rank[j] & 255];
+                    const uint32_t fl = t[1];
+                    kill[j] |= t[0];
+                    if (act_pending[j]) truthful[j] = fl & 1u;
+                    if (fl & 2u) near[j] = 0u;
+                }
+            }
+        }
+        uint32_t o4[4], r4[4], a_next[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int o;
+            float r;
+            if (near[j] < 32u) {                                               // a draw decided by its low word: the exact per-lane form
+                Env::State e{st[j]};
+                int d;
+                Env::step(sh, p, e, a_cur[j], key, glane0 + (uint32_t)j, o, r, d);
+                st[j] = e.w;
+            } else {                                                           // network.py:101-112
+                const int a = a_cur[j], machine = (a >> 1) & 31;
+                const bool has_action = a < M2, reboot = has_action && (a & 1);
+                uint32_t sn = st[j] & ~kill[j];
+                sn |= reboot ? 1u << machine : 0u;
+                const int up = (int)((sn >> machine) & 1u);                    // a rebooted machine is up: ob = truthful either way
+                o = has_action ? (truthful[j] ? up : 1 - up) : 2;
+                r = rtab[has_action ? 1 + (a & 1) : 0][base[j]];
+                st[j] = sn;
+            }
+            o4[j] = (uint32_t)o;
+            r4[j] = __float_as_uint(r);
+            a_next[j] = __umulhi(P[j], n_act);
+            a_cur[j] = (int)a_next[j];
+        }
+        st_stream4(action_w, a_next[0], a_next[1], a_next[2], a_next[3]);
+        st_stream4(ob_w, o4[0], o4[1], o4[2], o4[3]);
+        st_stream4(reward_w, r4[0], r4[1], r4[2], r4[3]);
+        st_stream(done_w, 0u);                                                 // network.py:113: never done
+        action_w += rec; ob_w += rec; reward_w += rec; done_w += rec / 4;
+    }
+    st_stream4(state + l0, st[0], st[1], st[2], st[3]);
+}
+
 // The generic fused loop with a quad per thread, for envs whose lane step is light enough that four of them fit a thread
 // (Env::QUAD_FUSED; one state word): the policy's ACTION block is the thread's own, Env::step / Env::reset_where run per
 // lane as in steps_kernel, the outputs leave as 16-byte stores.  Full workgroups of 1024 lanes, auto-reset.  Only for envs
@@ -1351,9 +1540,10 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_generic_kernel(uint32_t *__r
 // wave's step (1.1-1.5 us), and more, lighter waves hide it better than fewer, heavier ones.
 // POMDP_QUAD_MIN_LANES overrides all three at build time for same-box A/B runs (tools/ab_build.sh lib ... -D...).
 #ifdef POMDP_QUAD_MIN_LANES
-constexpr int64_t QUAD_MIN_ROCK = POMDP_QUAD_MIN_LANES, QUAD_MIN_TAG = POMDP_QUAD_MIN_LANES, QUAD_MIN_GENERIC = POMDP_QUAD_MIN_LANES;
+constexpr int64_t QUAD_MIN_ROCK = POMDP_QUAD_MIN_LANES, QUAD_MIN_TAG = POMDP_QUAD_MIN_LANES, QUAD_MIN_GENERIC = POMDP_QUAD_MIN_LANES,
+                  QUAD_MIN_NETWORK = POMDP_QUAD_MIN_LANES;
 #else
-constexpr int64_t QUAD_MIN_ROCK = 1 << 19, QUAD_MIN_TAG = 1 << 20, QUAD_MIN_GENERIC = 1 << 18;
+constexpr int64_t QUAD_MIN_ROCK = 1 << 19, QUAD_MIN_TAG = 1 << 20, QUAD_MIN_GENERIC = 1 << 18, QUAD_MIN_NETWORK = 1 << 19;
 #endif
 
 // which kernel the calling thread's most recent fused launch picked (pomdp_last_fused_kernel: bench.py names the kernel
@@ -1402,6 +1592,22 @@ static int launch_steps_fused(const typename Env::Params &p, uint32_t *state, in
             note_fused("tag_steps_quad_kernel", "", "");
             hipLaunchKernelGGL(tag_steps_quad_kernel, qgrid, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob, reward,
                                done, n, make_key(seed, t), lane0, make_key(action_seed, t + 1), k, rec, gf, p);
+            launched = true;
+        }
+    }
+    if constexpr (std::is_same<Env, NetworkEnv>::value) {
+        if (quad_ok && n >= QUAD_MIN_NETWORK) {
+            note_fused("network_steps_quad_kernel", "", "");
+#define POMDP_LAUNCH_NET(NB_)                                                                                            \
+    hipLaunchKernelGGL(network_steps_quad_kernel<NB_>, qgrid, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob, reward, \
+                       done, n, make_key(seed, t), lane0, make_key(action_seed, t + 1), k, rec, gf, p)
+            switch ((p.n_machines + 7) / 8) {
+            case 1: POMDP_LAUNCH_NET(1); break;
+            case 2: POMDP_LAUNCH_NET(2); break;
+            case 3: POMDP_LAUNCH_NET(3); break;
+            default: POMDP_LAUNCH_NET(4); break;
+            }
+#undef POMDP_LAUNCH_NET
             launched = true;
         }
     }

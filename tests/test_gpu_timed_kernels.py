@@ -24,7 +24,9 @@ FULL = [("rock", {}, 1 << 20, 70), ("rock", dict(board_size=15, num_rocks=15), 1
         ("stochrock", {}, 1 << 18, 70), ("battleship", {}, 1 << 18, 70),
         # the shards a 2^20-lane batch leaves per GPU at 2, 4 and 8 GPUs
         ("rock", {}, 1 << 19, 66), ("rock", {}, 1 << 18, 66), ("rock", {}, 1 << 17, 66),
-        ("tag", {}, 1 << 17, 66), ("tiger", {}, 1 << 17, 66), ("network", {}, 1 << 17, 66)]
+        ("tag", {}, 1 << 17, 66), ("tiger", {}, 1 << 17, 66), ("network", {}, 1 << 17, 66), ("network", {}, 1 << 19, 66),
+        # Network's quad-per-thread loop with streams that run past their first block on most lanes
+        ("network", dict(n_machines=16, problem_type=1), 1 << 19, 40), ("network", dict(n_machines=31, problem_type=3), 1 << 19, 40)]
 
 
 @pytest.mark.parametrize("env,kw,n,steps", FULL, ids=["%s%s-%d" % (c[0], "-".join(str(v) for v in c[1].values()), c[2]) for c in FULL])
@@ -78,6 +80,31 @@ def test_fused_overwrite_mode_equals_the_oracle(oracle_lib, env, kw, n):
         assert np.array_equal(np_(ob_g), ob) and np.array_equal(np_(rew_g), rew) and np.array_equal(np_(done_g), done.astype(bool)), (env, k)
         assert np.array_equal(np_(e._action_scratch), oracle_lib.synthetic_actions(n, seed, lane0, t, o.n_actions, nthreads=nt))
         assert np.array_equal(np_(e.state).view(np.uint32), st), (env, k)
+
+
+def test_network_ties_inside_the_fused_launch(oracle_lib):
+    """Lanes whose first step has a draw decided by its low word (tests/golden/ties_network.npz, found by find_ties.py; the
+    oracle's handling of them is pinned to the reference there) inside a batch large enough for network_steps_quad_kernel:
+    draw 2 lies in the block every lane computes (-> the exact per-lane form), draws 4, 5 and 9 in the pooled continuation."""
+    g = dict(np.load(os.path.join(REPO, "tests", "golden", "ties_network.npz")))
+    seed, n = int(g["seed"]), 1 << 19
+    o = oracle_lib.OracleEnv("network")
+    for lane, draw in zip(g["lanes"], g["tied_draw"]):
+        lane = int(lane)
+        lane0 = max(0, (lane & ~1023) - 4096)
+        e = make_env("network", {}, batch_size=n, seed=seed, lane_offset=lane0, reuse_buffers=True)
+        e.reset()
+        tr = e.collect_synthetic(16)
+        w0, wn = lane - 8 - (lane & 3), 32                                  # a window of whole quads around the lane
+        st = o.new_state(wn)
+        o.batch_reset(st, seed, w0, 0)
+        for k in range(16):
+            a = oracle_lib.synthetic_actions(wn, seed, w0, 1 + k, o.n_actions)
+            ob, rew, done, bad = o.batch_step(st, a, seed, w0, 1 + k)
+            sl = slice(w0 - lane0, w0 - lane0 + wn)
+            assert np.array_equal(np_(tr["action"][k, sl]), a), (lane, draw, k)
+            assert np.array_equal(np_(tr["ob"][k, sl]), ob) and np.array_equal(np_(tr["reward"][k, sl]), rew), (lane, draw, k)
+        assert np.array_equal(np_(e.state[:, sl]).view(np.uint32), st), (lane, draw)
 
 
 def test_rollouts_at_the_c5_per_gpu_size(oracle_lib):
