@@ -27,7 +27,7 @@ SYMBOLS = [
     "pomdp_abi_version", "pomdp_error_string", "pomdp_last_fused_kernel",
     "pomdp_rock_reset", "pomdp_rock_step", "pomdp_tag_reset", "pomdp_tag_step",
     "pomdp_battleship_reset", "pomdp_battleship_step", "pomdp_tiger_reset", "pomdp_tiger_step",
-    "pomdp_network_reset", "pomdp_network_step", "pomdp_synthetic_actions", "pomdp_philox_blocks",
+    "pomdp_network_reset", "pomdp_network_step", "pomdp_step", "pomdp_synthetic_actions", "pomdp_philox_blocks",
     "pomdp_rollout_synthetic", "pomdp_collect_synthetic", "pomdp_legal_actions", "pomdp_rollout", "pomdp_compute_prob",
     "pomdp_rock_belief_reset", "pomdp_rock_belief_refresh", "pomdp_rock_belief_update", "pomdp_rock_select_target", "pomdp_history_clear",
     "pomdp_history_append", "pomdp_preferred_actions", "pomdp_pick_actions", "pomdp_heuristic_steps",
@@ -59,12 +59,19 @@ class NetworkParams(C.Structure):
                 ("fail_thr", C.c_uint64), ("fail_nb_thr", C.c_uint64), ("obs_thr", C.c_uint64)]
 
 
+class StepArgs(C.Structure):        # pomdp_step_args
+    _fields_ = [("env", C.c_int32), ("flags", C.c_int32), ("params", C.c_void_p), ("state", C.c_void_p), ("ob", C.c_void_p),
+                ("reward", C.c_void_p), ("done", C.c_void_p), ("err", C.c_void_p), ("n", C.c_int64), ("seed", C.c_uint64),
+                ("lane0", C.c_uint32), ("reserved", C.c_uint32)]
+
+
 class RockBelief(C.Structure):      # pomdp_rock_belief: device pointers, [num_rocks][n]
     _fields_ = [(k, C.c_void_p) for k in ("count", "measured", "lkv", "lkw", "prob_valuable", "check_ok")]
 
 
-class HistoryPtrs(C.Structure):     # pomdp_history: device pointers
-    _fields_ = [(k, C.c_void_p) for k in ("size", "last_action", "last_ob", "total_sample", "total_move", "move_ok")]
+class HistoryPtrs(C.Structure):     # pomdp_history: device pointers + the window size of a bounded history
+    _fields_ = [(k, C.c_void_p) for k in ("size", "last_action", "last_ob", "total_sample", "total_move", "move_ok", "ring", "head")] + \
+               [("max_size", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Returns(C.Structure):         # pomdp_returns
@@ -121,6 +128,8 @@ def lib():
         s = getattr(L, "pomdp_%s_step" % env)
         s.restype = ci
         s.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, u64, u32, u64, ci, vp]
+    L.pomdp_step.restype = ci
+    L.pomdp_step.argtypes = [vp, vp, u64, vp]
     L.pomdp_synthetic_actions.restype = ci
     L.pomdp_synthetic_actions.argtypes = [vp, i64, u64, u32, u64, u32, vp]
     L.pomdp_rollout_synthetic.restype = ci

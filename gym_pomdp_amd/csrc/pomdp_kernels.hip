@@ -646,13 +646,15 @@ __global__ __launch_bounds__(BLOCK) void select_target_kernel(const typename Env
     target[i] = Env::select_target(sh, p, st, b, n, (uint32_t)i);
 }
 
-// the two sums over CHECK-j transitions (rock.py:303-310, 327-334) and the derived bit j of move_ok
-static __device__ __forceinline__ void history_check_sums(const pomdp_history &h, int j, int next_ob, int prev_ob, int64_t n,
-                                                          uint32_t i, uint32_t &mv)          // mv: the caller's copy of h.move_ok[i]
+// the two sums over CHECK-j transitions (rock.py:303-310, 327-334) and the derived bit j of move_ok: the contribution of
+// one transition (action CHECK j, next observation, observation before it) is added (sign = 1) or, when a bounded history
+// drops the transition, taken out again (sign = -1)
+static __device__ __forceinline__ void history_check_sums(const pomdp_history &h, int j, int next_ob, bool prev_bad, int64_t n,
+                                                          uint32_t i, uint32_t &mv, int sign = 1)   // mv: the caller's copy of h.move_ok[i]
 {
     const int64_t k = (int64_t)j * n + i;
-    const int ds = (next_ob == 2) - (next_ob == 1);
-    const int dm = next_ob == 2 ? 1 : (prev_ob == 1 ? -1 : 0);
+    const int ds = sign * ((next_ob == 2) - (next_ob == 1));
+    const int dm = sign * (next_ob == 2 ? 1 : (prev_bad ? -1 : 0));
     if (ds) h.total_sample[k] += ds;
     if (dm) {
         const int tm = h.total_move[k] + dm;
@@ -662,6 +664,29 @@ static __device__ __forceinline__ void history_check_sums(const pomdp_history &h
     }
 }
 
+// history.append(transition) of rock.py:541-544 on the lane's words: `size` (the list length), the window of a bounded
+// history (max_size >= 0: one byte per kept transition — action | next_ob << 5 | (observation == BAD) << 7 — in a ring of
+// max_size + 1 rows, `head` = the row the next transition goes to, which holds the OLDEST one once the ring is full:
+// the reference pops element 0 when size > max_size and then appends, so the list settles at max_size + 1 records) and,
+// for RockSample (K > 0), the two per-rock sums kept current as transitions enter and leave the window.
+static __device__ __forceinline__ void history_push(const pomdp_history &h, int K, int a, int next_ob, int prev_ob, int64_t n,
+                                                    uint32_t i, int &hsize, int &head, uint32_t &mv)
+{
+    const int W = h.max_size + 1;                                              // 0: unbounded
+    if (W > 0 && K > 0) {
+        uint8_t *slot = h.ring + (int64_t)head * n + i;
+        if (hsize == W) {                                                      // self._history.pop(0)
+            const uint32_t old = *slot;
+            const int oa = (int)(old & 31u);
+            if (oa >= 5 && oa < 5 + K) history_check_sums(h, oa - 5, (int)((old >> 5) & 3u), (old >> 7) != 0u, n, i, mv, -1);
+        }
+        *slot = (uint8_t)((uint32_t)a | ((uint32_t)next_ob << 5) | ((prev_ob == 1) ? 128u : 0u));
+        head = head + 1 == W ? 0 : head + 1;
+    }
+    hsize = (W > 0 && hsize == W) ? W : hsize + 1;
+    if (a >= 5 && a < 5 + K) history_check_sums(h, a - 5, next_ob, prev_ob == 1, n, i, mv);
+}
+
 __global__ __launch_bounds__(BLOCK) void history_clear_kernel(pomdp_history h, int K, const uint8_t *__restrict__ where, int64_t n)
 {
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -669,6 +694,7 @@ __global__ __launch_bounds__(BLOCK) void history_clear_kernel(pomdp_history h, i
     h.size[i] = 0; h.last_action[i] = -1; h.last_ob[i] = -1;
     for (int j = 0; j < K; ++j) { h.total_sample[(int64_t)j * n + i] = 0; h.total_move[(int64_t)j * n + i] = 0; }
     if (K) h.move_ok[i] = (1u << K) - 1u;
+    if (h.head) h.head[i] = 0;
 }
 
 // rock.py:541-544 History.append + the sums _generate_preferred takes over the records (rock.py:303-310, 327-334)
@@ -683,15 +709,16 @@ __global__ __launch_bounds__(BLOCK) void history_append_kernel(pomdp_history h, 
         h.size[i] = 0; h.last_action[i] = -1; h.last_ob[i] = -1;
         for (int j = 0; j < K; ++j) { h.total_sample[(int64_t)j * n + i] = 0; h.total_move[(int64_t)j * n + i] = 0; }
         if (K) h.move_ok[i] = (1u << K) - 1u;
+        if (h.head) h.head[i] = 0;
         return;
     }
     const int a = action[i], o = next_observation[i];
-    h.size[i] += 1; h.last_action[i] = a; h.last_ob[i] = o;
-    if (a >= 5 && a < 5 + K) {
-        uint32_t mv = h.move_ok[i];
-        history_check_sums(h, a - 5, o, observation[i], n, (uint32_t)i, mv);
-        h.move_ok[i] = mv;
-    }
+    int hsize = h.size[i], head = h.head ? h.head[i] : 0;
+    uint32_t mv = K ? h.move_ok[i] : 0u;
+    history_push(h, K, a, o, observation[i], n, (uint32_t)i, hsize, head, mv);
+    h.size[i] = hsize; h.last_action[i] = a; h.last_ob[i] = o;
+    if (K) h.move_ok[i] = mv;
+    if (h.head) h.head[i] = head;
 }
 
 // envs whose _generate_preferred reads extra LDS tables fill them with Env::stage_policy
@@ -798,7 +825,7 @@ __global__ __launch_bounds__(BLOCK) void heuristic_steps_kernel(const typename E
     // every per-lane word first (one memory latency), then the tables
     typename Env::State st;
     Env::load(st, state, n, i);
-    int hsize = ld_stream(h.size + i), pob = ld_stream(prev_ob + i);
+    int hsize = ld_stream(h.size + i), pob = ld_stream(prev_ob + i), head = h.head ? ld_stream(h.head + i) : 0;
     int la = ld_stream(h.last_action + i), lo = ld_stream(h.last_ob + i);
     uint32_t ck = K ? ld_stream(b.check_ok + i) : 0u, mv = K ? ld_stream(h.move_ok + i) : 0u;
     bool was_done = auto_reset ? false : (ld_stream(done + i) != 0);
@@ -867,14 +894,13 @@ __global__ __launch_bounds__(BLOCK) void heuristic_steps_kernel(const typename E
                         h.total_sample[k] = 0; h.total_move[k] = 0;
                     }
                     ck = mv = K ? (1u << K) - 1u : 0u;
-                    hsize = 0; la = -1; lo = -1;
+                    hsize = 0; la = -1; lo = -1; head = 0;
                     pob = Env::reset_ob(p, st);
                 } else {
-                    hsize += 1; la = a; lo = o;                                // a terminal transition is recorded too
-                    if (a >= 5 && a < 5 + K) {                                 // K > 0: RockSample CHECK
-                        history_check_sums(h, a - 5, o, pob, n, i, mv);
-                        if (o != 0 && !d) heuristic_belief_update<Env>(sh, p, st, a, o, b, n, i, ck);
-                    }
+                    history_push(h, K, a, o, pob, n, i, hsize, head, mv);      // a terminal transition is recorded too
+                    la = a; lo = o;
+                    if (a >= 5 && a < 5 + K && o != 0 && !d)                   // K > 0: RockSample CHECK
+                        heuristic_belief_update<Env>(sh, p, st, a, o, b, n, i, ck);
                     pob = o;
                 }
                 was_done = auto_reset ? false : (d != 0);
@@ -890,6 +916,7 @@ __global__ __launch_bounds__(BLOCK) void heuristic_steps_kernel(const typename E
     st_stream(h.size + i, (int32_t)hsize); st_stream(h.last_action + i, (int32_t)la); st_stream(h.last_ob + i, (int32_t)lo);
     st_stream(prev_ob + i, (int32_t)pob);
     if (K) { st_stream(b.check_ok + i, ck); st_stream(h.move_ok + i, mv); }
+    if (h.head) st_stream(h.head + i, (int32_t)head);
     if (R.ret) { R.ret[i] = ret; R.disc[i] = disc; }
 }
 
@@ -1710,7 +1737,9 @@ static bool belief_ok(const pomdp_rock_belief *b)
 }
 static bool history_ok(const pomdp_history *h, bool rock)
 {
-    return h && h->size && h->last_action && h->last_ob && (!rock || (h->total_sample && h->total_move && h->move_ok));
+    if (!(h && h->size && h->last_action && h->last_ob && (!rock || (h->total_sample && h->total_move && h->move_ok)))) return false;
+    if (h->max_size < -1 || h->max_size > 62) return false;                    // window of at most 63 transitions
+    return h->max_size < 0 || !rock || (h->ring && h->head);                   // a bounded RockSample history keeps its window
 }
 static const pomdp_rock_belief NO_BELIEF = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 
@@ -1908,6 +1937,29 @@ int pomdp_network_step(const pomdp_network_params *p, uint32_t *state, const int
 {
     if (!p || p->n_machines < 1 || p->n_machines > 32) return POMDP_E_BADPARAMS;
     return launch_step<NetworkEnv>(*p, state, action, ob, reward, done, err, n, seed, lane0, t, flags, stream);
+}
+
+int pomdp_step(const pomdp_step_args *a, const int32_t *action, uint64_t t, void *stream)
+{
+    if (!a || !a->params) return POMDP_E_BADARG;
+    switch (a->env) {
+    case POMDP_ENV_ROCK:
+        return pomdp_rock_step((const pomdp_rock_params *)a->params, a->state, action, a->ob, (int32_t *)a->reward, a->done, a->err,
+                               a->n, a->seed, a->lane0, t, a->flags, stream);
+    case POMDP_ENV_TAG:
+        return pomdp_tag_step((const pomdp_tag_params *)a->params, a->state, action, a->ob, (float *)a->reward, a->done, a->err,
+                              a->n, a->seed, a->lane0, t, a->flags, stream);
+    case POMDP_ENV_BATTLESHIP:
+        return pomdp_battleship_step((const pomdp_battleship_params *)a->params, a->state, action, a->ob, (int32_t *)a->reward,
+                                     a->done, a->err, a->n, a->seed, a->lane0, t, a->flags, stream);
+    case POMDP_ENV_TIGER:
+        return pomdp_tiger_step((const pomdp_tiger_params *)a->params, a->state, action, a->ob, (int32_t *)a->reward, a->done,
+                                a->err, a->n, a->seed, a->lane0, t, a->flags, stream);
+    case POMDP_ENV_NETWORK:
+        return pomdp_network_step((const pomdp_network_params *)a->params, a->state, action, a->ob, (float *)a->reward, a->done,
+                                  a->err, a->n, a->seed, a->lane0, t, a->flags, stream);
+    default: return POMDP_E_BADARG;
+    }
 }
 
 int pomdp_synthetic_actions(int32_t *action, int64_t n, uint64_t seed, uint32_t lane0, uint64_t t, uint32_t n_actions,

@@ -50,7 +50,7 @@ class BatchedEnv(object):
         self.batch_size = batch_size
         self.num_envs = batch_size
         self.lane_offset = int(lane_offset)
-        self.auto_reset = (batch_size > 1) if auto_reset is None else bool(auto_reset)
+        self._auto_reset = (batch_size > 1) if auto_reset is None else bool(auto_reset)
         self.reuse_buffers = bool(reuse_buffers)
         self._params, self.state_words, n_actions, n_obs = self._build_params()
         self._params_ref = C.byref(self._params)
@@ -101,12 +101,32 @@ class BatchedEnv(object):
         self._done_bool = self._done.view(torch.bool)
         self._ptrs = (self._state.data_ptr(), self._ob.data_ptr(), self._reward.data_ptr(), self._done.data_ptr(),
                       self._err.data_ptr())
+        # everything of a step() call that does not change between calls, bound once (include/pomdp_hip.h: pomdp_step_args)
+        self._step_args = _native.StepArgs(
+            env=_native.ENV_KIND[self.env_name], flags=_native.POMDP_AUTO_RESET if self._auto_reset else 0,
+            params=C.addressof(self._params), state=self._ptrs[0], ob=self._ptrs[1], reward=self._ptrs[2],
+            done=self._ptrs[3], err=self._ptrs[4], n=n, seed=self._seed, lane0=self.lane_offset, reserved=0)
+        self._step_args_ref = C.byref(self._step_args)
+        self._bound_step = self._lib.pomdp_step
+        self._action_shape = torch.Size((n,))
+        self._dev_index = self.device.index
+        self._info = {"state": self._state}
+
+    @property
+    def auto_reset(self):
+        return self._auto_reset
+
+    @auto_reset.setter
+    def auto_reset(self, value):
+        self._auto_reset = bool(value)
+        self._step_args.flags = _native.POMDP_AUTO_RESET if self._auto_reset else 0
 
     # ---- gym.Env surface --------------------------------------------------------
     def seed(self, seed=None):
         """Reference: np.random.seed(seed) on the global stream (rock.py:120-121).  Here: the
         Philox key of this env's lanes; the call counter restarts."""
         self._seed = _random_seed() if seed is None else int(seed) & 0xFFFFFFFFFFFFFFFF
+        self._step_args.seed = self._seed
         self._t = 0
         return [self._seed]
 
@@ -120,7 +140,8 @@ class BatchedEnv(object):
         self._t = int(t)
 
     def _stream(self):
-        return torch.cuda.current_stream(self.device).cuda_stream
+        """hipStream_t of torch's current stream on this env's device (the raw handle: no Stream object is built)."""
+        return torch._C._cuda_getCurrentRawStream(self._dev_index)
 
     def reset(self):
         """All lanes start a new episode.  Returns ob: int32[N] tensor (python int if batch_size == 1)."""
@@ -152,44 +173,42 @@ class BatchedEnv(object):
         if not self._has_reset:
             # the reference raises AttributeError here: `self.done` does not exist before reset()
             raise AttributeError("%s: step() called before reset()" % type(self).__name__)
-        scalar = self.batch_size == 1
-        if scalar:
+        if self.batch_size == 1:
             assert self.action_space.contains(action), "invalid action %r" % (action,)
-            assert self._scalar_done is False or self.auto_reset, "step() on a done env (call reset())"
+            assert self._scalar_done is False or self._auto_reset, "step() on a done env (call reset())"
             return self._scalar_step(int(action))
-        elif not (isinstance(action, torch.Tensor) and action.dtype == torch.int32 and action.device == self.device
-                  and action.dim() == 1 and action.shape[0] == self.batch_size and action.is_contiguous()):
+        if not (type(action) is torch.Tensor and action.dtype is torch.int32 and action.shape == self._action_shape
+                and action.device == self.device and action.is_contiguous()):
             action = self._as_action_tensor(action)           # slow path: convert / validate
         t = self._t
-        self._t += 1
-        flags = _native.POMDP_AUTO_RESET if self.auto_reset else 0
-        same_device = torch.cuda.current_device() == self.device.index
-        if self.reuse_buffers and same_device:
-            # hot path: cached buffer pointers, no allocation, no device-context switch
-            ptrs = self._ptrs
-            rc = self._step_fn(self._params_ref, ptrs[0], action.data_ptr(), ptrs[1], ptrs[2], ptrs[3], ptrs[4],
-                               self.batch_size, self._seed, self.lane_offset, t, flags, self._stream())
+        self._t = t + 1
+        if self.reuse_buffers and torch._C._cuda_getDevice() == self._dev_index:
+            # hot path: one FFI call with four arguments (the rest is bound in self._step_args), no allocation, no
+            # device-context switch, the raw stream handle
+            rc = self._bound_step(self._step_args_ref, action.data_ptr(), t, torch._C._cuda_getCurrentRawStream(self._dev_index))
             if rc:
                 _native.check(rc, "pomdp_%s_step" % self.env_name)
-            ob, reward, done = self._ob, self._reward, self._done
-        else:
-            with torch.cuda.device(self.device):
-                if self.reuse_buffers:
-                    ob, reward = self._ob, self._reward
-                else:
-                    ob, reward = torch.empty_like(self._ob), torch.empty_like(self._reward)
-                done = self._done if (self.reuse_buffers or not self.auto_reset) else torch.empty_like(self._done)
-                rc = self._step_fn(self._params_ref, self._state.data_ptr(), action.data_ptr(), ob.data_ptr(),
-                                   reward.data_ptr(), done.data_ptr(), self._err.data_ptr(), self.batch_size,
-                                   self._seed, self.lane_offset, t, flags, self._stream())
-                _native.check(rc, "pomdp_%s_step" % self.env_name)
-            if not self.auto_reset and not self.reuse_buffers:
-                done = done.clone()
+            if self._tracker is not None:
+                self._tracker.on_step(action, self._ob, self._done, self._step_args.flags)
+            self.done = self._done_bool
+            return self._ob, self._reward, self._done_bool, self._info
+        flags = _native.POMDP_AUTO_RESET if self._auto_reset else 0
+        with torch.cuda.device(self.device):
+            if self.reuse_buffers:
+                ob, reward = self._ob, self._reward
+            else:
+                ob, reward = torch.empty_like(self._ob), torch.empty_like(self._reward)
+            done = self._done if (self.reuse_buffers or not self._auto_reset) else torch.empty_like(self._done)
+            rc = self._step_fn(self._params_ref, self._state.data_ptr(), action.data_ptr(), ob.data_ptr(),
+                               reward.data_ptr(), done.data_ptr(), self._err.data_ptr(), self.batch_size,
+                               self._seed, self.lane_offset, t, flags, self._stream())
+            _native.check(rc, "pomdp_%s_step" % self.env_name)
+        if not self._auto_reset and not self.reuse_buffers:
+            done = done.clone()
         if self._tracker is not None:
             self._tracker.on_step(action, ob, done, flags)
-        info = {"state": self._state}
         self.done = self._done_bool if done is self._done else done.view(torch.bool)
-        return ob, reward, self.done, info
+        return ob, reward, self.done, self._info
 
     def _scalar_step(self, action):
         """batch_size == 1: one launch writing into pinned host memory, one stream synchronisation, python scalars out."""

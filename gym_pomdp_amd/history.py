@@ -3,8 +3,10 @@
 
 Batched, device-resident: instead of a list of records per lane the history keeps, per lane, exactly what the
 heuristics take from it — size, the last action and observation, and for RockSample the two per-rock sums of
-rock.py:303-310 / 327-334 (include/pomdp_hip.h: pomdp_history).  Unbounded histories only (`max_size=None`, the
-reference's default): a sliding window cannot be summarised by running sums.
+rock.py:303-310 / 327-334 (include/pomdp_hip.h: pomdp_history).  `History(env, max_size=k)` is the reference's bounded
+history (rock.py:533-544: append() pops the oldest record once the list holds more than k, so it settles at k + 1
+records): `size` stops at k + 1 and, for RockSample, the window itself is kept — one byte per transition in a ring of
+k + 1 rows — so that a record's contribution leaves the two sums when the record leaves the window.
 """
 import ctypes as C
 from typing import NamedTuple
@@ -27,8 +29,9 @@ class History(object):
     def __init__(self, env, max_size=None, observation=None):
         """`observation`: what the agent currently sees (int32[N]); only env.heuristic_steps() needs it, as the
         `observation` field of the next transition.  Defaults to what env.reset() just returned."""
-        if max_size is not None:
-            raise NotImplementedError("History: only unbounded histories (max_size=None) are kept on the device")
+        if max_size is not None and not 0 <= int(max_size) <= 62:
+            raise ValueError("History: max_size must be None or in [0, 62] (a window of at most 63 transitions per lane)")
+        self._max_size = None if max_size is None else int(max_size)
         self._env = env
         n, dev = env.batch_size, env.device
         if observation is None and getattr(env, "_last_reset", None) is not None and env._last_reset[1] + 1 == env.call_counter:
@@ -43,10 +46,16 @@ class History(object):
         self.total_sample = torch.zeros((k, n), dtype=torch.int32, device=dev)
         self.total_move = torch.zeros((k, n), dtype=torch.int32, device=dev)
         self.move_ok = torch.zeros(n if k else 0, dtype=torch.int32, device=dev)   # derived: bit j = total_move[j] >= 0
+        bounded = self._max_size is not None
+        self.ring = torch.zeros((self._max_size + 1, n) if bounded and k else (0, n), dtype=torch.uint8, device=dev)
+        self.head = torch.zeros(n if bounded else 0, dtype=torch.int32, device=dev)
         self._ptrs = _native.HistoryPtrs(self._size.data_ptr(), self.last_action.data_ptr(), self.last_ob.data_ptr(),
                                          self.total_sample.data_ptr() if k else None,
                                          self.total_move.data_ptr() if k else None,
-                                         self.move_ok.data_ptr() if k else None)
+                                         self.move_ok.data_ptr() if k else None,
+                                         self.ring.data_ptr() if bounded and k else None,
+                                         self.head.data_ptr() if bounded else None,
+                                         self._max_size if bounded else -1, 0)
         self._ref = C.byref(self._ptrs)
         self.clear()
 

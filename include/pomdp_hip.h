@@ -162,6 +162,28 @@ int pomdp_network_step(const pomdp_network_params *p, uint32_t *state, const int
                        float *reward, uint8_t *done, uint32_t *err, int64_t n,
                        uint64_t seed, uint32_t lane0, uint64_t t, int flags, void *stream);
 
+/* ---- step with bound arguments ------------------------------------------------ */
+/* Everything of a pomdp_<env>_step call that does not change from one step of a batched env to the next, gathered once by
+ * the caller (host memory the caller owns; the library only reads it during the call).  pomdp_step(args, action, t, stream)
+ * is pomdp_<env>_step(args->params, args->state, action, args->ob, args->reward, args->done, args->err, args->n, args->seed,
+ * args->lane0, t, args->flags, stream) for the env kind args->env: the same kernels, the same results — what it saves is
+ * the marshalling of thirteen arguments per call in the host language's FFI (ctypes: ~1 us of a ~7 us env.step()). */
+typedef struct pomdp_step_args {
+    int32_t   env;       /* POMDP_ENV_* */
+    int32_t   flags;     /* POMDP_AUTO_RESET or 0 */
+    const void *params;  /* the env's pomdp_<env>_params (host) */
+    uint32_t *state;     /* device, [words][n] */
+    int32_t  *ob;        /* device [n] */
+    void     *reward;    /* device [n], int32 or float per env */
+    uint8_t  *done;      /* device [n] */
+    uint32_t *err;       /* device uint32, may be NULL */
+    int64_t   n;
+    uint64_t  seed;
+    uint32_t  lane0;
+    uint32_t  reserved;
+} pomdp_step_args;
+int pomdp_step(const pomdp_step_args *args, const int32_t *action, uint64_t t, void *stream);
+
 /* ---- helpers ---------------------------------------------------------------- */
 /* synthetic uniform random policy used by bench.py: lanes 4q..4q+3 share the Philox block
  * ctr = (q, t lo, t hi, STREAM_ACTION << 24); action = (word[lane & 3] * n_actions) >> 32.
@@ -265,8 +287,8 @@ int pomdp_rock_select_target(const pomdp_rock_params *p, const uint32_t *state, 
 
 /* What `_generate_preferred(history)` reads from the planner's History of Transition(observation, action, reward,
  * next_observation, done) records (rock.py:525-550; tag.py:233-239 reads history.size, history[-1].action and
- * history[-1].ob), kept per lane as running sums so the records themselves need not be stored (unbounded
- * history, max_size=None).  Device pointers:
+ * history[-1].ob), kept per lane as running sums so that no list of records has to be walked (a bounded history keeps
+ * one byte per record of its window besides, see `ring`).  Device pointers:
  *   size, last_action, last_ob                                                                   int32 [n]
  *   total_sample[j] = sum over CHECK-j transitions of (+1 if next_ob GOOD, -1 if next_ob BAD)     rock.py:303-310
  *   total_move[j]   = sum over CHECK-j transitions of (+1 if next_ob GOOD, else -1 if the *previous*
@@ -277,6 +299,15 @@ typedef struct pomdp_history {
     int32_t *total_sample, *total_move;
     uint32_t *move_ok;      /* [n] derived, RockSample only: bit j = total_move[j] >= 0 (the test of rock.py:335),
                                maintained by pomdp_history_clear / _append / pomdp_heuristic_steps */
+    /* History(max_size=k) of rock.py:533-544: append() pops the oldest record once the list holds more than k, so the
+     * list settles at k + 1 records and the sums above cover that window only.  max_size = -1: unbounded (the reference's
+     * default; ring and head may be NULL).  0 <= max_size <= 62: `size` stops at max_size + 1; for RockSample the window
+     * itself is kept so that a record's contribution can leave the sums again: ring uint8 [max_size + 1][n], one byte per
+     * kept transition (action | next_ob << 5 | (observation == BAD) << 7), head int32 [n] = the row the next transition
+     * goes to (the oldest one once the ring is full).  Both may be NULL for the other envs. */
+    uint8_t *ring;
+    int32_t *head;
+    int32_t max_size, reserved;
 } pomdp_history;
 
 /* History() — empty history for every lane / the lanes with where[i] != 0 (last_action = last_ob = -1) */

@@ -199,7 +199,8 @@ class _BeliefPtrs(C.Structure):
 
 
 class _HistoryPtrs(C.Structure):
-    _fields_ = [(k, C.c_void_p) for k in ("size", "last_action", "last_ob", "total_sample", "total_move")]
+    _fields_ = [(k, C.c_void_p) for k in ("size", "last_action", "last_ob", "total_sample", "total_move")] + \
+               [("max_size", C.c_int32), ("reserved", C.c_int32)] + [(k, C.c_void_p) for k in ("rec_obs", "rec_act", "rec_next")]
 
 
 class Belief(object):
@@ -236,7 +237,8 @@ class Belief(object):
 class HistorySums(object):
     """Running sums standing in for the planner's History (pomdp_oracle.h: or_history)."""
 
-    def __init__(self, env, n):
+    def __init__(self, env, n, max_size=None):
+        """max_size: History(max_size) of rock.py:533-544 — the records themselves are kept, as the reference keeps them."""
         self.env, self.n = env, n
         self.is_rock = env.name in ("rock", "stochrock")
         K = env.n_actions - 5 if self.is_rock else 0
@@ -245,12 +247,16 @@ class HistorySums(object):
         self.last_ob = np.zeros(n, np.int32)
         self.total_sample = np.zeros((K, n), np.int32)
         self.total_move = np.zeros((K, n), np.int32)
+        self.max_size = -1 if max_size is None else int(max_size)
+        rows = self.max_size + 1 if self.max_size >= 0 else 0
+        self.rec = [np.zeros((rows, n), np.int32) for _ in range(3)]
         self.clear()
 
     def _ptrs(self):
         return C.byref(_HistoryPtrs(self.size.ctypes.data, self.last_action.ctypes.data, self.last_ob.ctypes.data,
                                     self.total_sample.ctypes.data if self.is_rock else None,
-                                    self.total_move.ctypes.data if self.is_rock else None))
+                                    self.total_move.ctypes.data if self.is_rock else None, self.max_size, 0,
+                                    *[r.ctypes.data if self.max_size >= 0 else None for r in self.rec]))
 
     def clear(self, where=None):
         w = None if where is None else _ptr(np.ascontiguousarray(where, np.uint8))

@@ -1130,6 +1130,22 @@ void or_batch_history_append(const or_env *proto, const or_history *h, const int
             continue;
         }
         int a = action[i], o = next_observation[i];
+        if (h->max_size >= 0) {                                   /* rock.py:541-544: the records themselves */
+            int sz = h->size[i];
+            if (sz > h->max_size) {                               /* self._history.pop(0) */
+                for (int r = 1; r < sz; r++) {
+                    h->rec_obs[(int64_t)(r - 1) * n + i] = h->rec_obs[(int64_t)r * n + i];
+                    h->rec_act[(int64_t)(r - 1) * n + i] = h->rec_act[(int64_t)r * n + i];
+                    h->rec_next[(int64_t)(r - 1) * n + i] = h->rec_next[(int64_t)r * n + i];
+                }
+                sz -= 1;
+            }
+            h->rec_obs[(int64_t)sz * n + i] = observation[i];    /* self._history.append(transition) */
+            h->rec_act[(int64_t)sz * n + i] = a;
+            h->rec_next[(int64_t)sz * n + i] = o;
+            h->size[i] = sz + 1; h->last_action[i] = a; h->last_ob[i] = o;
+            continue;
+        }
         h->size[i] += 1; h->last_action[i] = a; h->last_ob[i] = o;
         if (a >= 5 && a < 5 + K) {
             int64_t k = (int64_t)(a - 5) * n + i;
@@ -1141,6 +1157,20 @@ void or_batch_history_append(const or_env *proto, const or_history *h, const int
     }
 }
 
+/* the two per-rock sums over the history's transitions: rock.py:303-310 (sample) and rock.py:327-334 (move) */
+static int history_total(const or_history *h, int rock, int move, int64_t i, int64_t n)
+{
+    if (h->max_size < 0) return (move ? h->total_move : h->total_sample)[(int64_t)rock * n + i];
+    int total = 0;
+    for (int r = 0; r < h->size[i]; r++) {                        /* for transition in history */
+        if (h->rec_act[(int64_t)r * n + i] != rock + 5) continue;
+        int nx = h->rec_next[(int64_t)r * n + i];
+        if (nx == 2) total += 1;
+        else if ((move ? h->rec_obs[(int64_t)r * n + i] : nx) == 1) total -= 1;
+    }
+    return total;
+}
+
 /* rock.py:293-374 */
 static int rock_preferred(const or_env *e, const or_rock_belief *b, const or_history *h, int64_t i, int64_t n, int *list)
 {
@@ -1148,12 +1178,12 @@ static int rock_preferred(const or_env *e, const or_rock_belief *b, const or_his
     int rock = e->grid[e->agent.x][e->agent.y];
     /* ids >= num_rocks raise IndexError in the reference; the build treats such a cell as empty */
     if (rock >= 0 && rock < K && e->status[rock] != 0 && h->size[i]) {
-        if (h->total_sample[(int64_t)rock * n + i] > 0) { list[0] = 4; return 1; }             /* rock.py:311-313 */
+        if (history_total(h, rock, 0, i, n) > 0) { list[0] = 4; return 1; }                    /* rock.py:311-313 */
     }
     int all_bad = 1, north = 0, south = 0, west = 0, east = 0;
     for (int idx = 0; idx < K; idx++) {
         if (e->status[idx] == 0) continue;
-        if (h->total_move[(int64_t)idx * n + i] >= 0) {                                         /* rock.py:335-345 */
+        if (history_total(h, idx, 1, i, n) >= 0) {                                              /* rock.py:335-345 */
             all_bad = 0;
             if (e->rock_pos[idx].y > e->agent.y) north = 1;
             else if (e->rock_pos[idx].y < e->agent.y) south = 1;

@@ -155,10 +155,16 @@ void or_batch_rock_belief_update(const or_env *proto, const uint32_t *state, con
  *   size, last_action = history[-1].action, last_ob = history[-1].next_observation             [n]
  *   total_sample[j] = sum over transitions with action == CHECK j of (+1 next_ob GOOD, -1 next_ob BAD)   rock.py:303-310
  *   total_move[j]   = same transitions: +1 if next_ob GOOD, else -1 if *observation* is BAD              rock.py:327-334
- * (the two rock sums, [num_rocks][n], are NULL for the other envs).  Unbounded history only (max_size=None). */
+ * (the two rock sums, [num_rocks][n], are NULL for the other envs).
+ * Bounded histories (History(max_size=k), rock.py:533-544) are kept the way the reference keeps them — a list of the
+ * records themselves, oldest first, from which append() pops element 0 when size > max_size BEFORE appending (so the
+ * list settles at k + 1 records) — in rec_obs / rec_act / rec_next [max_size + 1][n]; `size` is then the list length and
+ * the two sums are taken over the stored records each time they are asked for.  max_size < 0: unbounded. */
 typedef struct or_history {
     int32_t *size, *last_action, *last_ob;
     int32_t *total_sample, *total_move;
+    int32_t max_size, reserved;
+    int32_t *rec_obs, *rec_act, *rec_next;
 } or_history;
 void or_batch_history_clear(const or_env *proto, const or_history *h, const uint8_t *where, int64_t n);
 /* history.append(Transition(observation, action, reward, next_observation, done)); with auto_reset a done

@@ -384,13 +384,14 @@ class _TagHistory(list):
         return len(self)
 
 
-def heuristic_trace(name, kwargs, seed, lanes, T, t0=0):
+def heuristic_trace(name, kwargs, seed, lanes, T, t0=0, max_size=None):
     """Reference envs driven by their own `_generate_preferred(history)` (use_heuristic=True for RockSample), one env
     per lane, Philox-injected like mode B.  The action of lane L at call t is list[(w * len(list)) >> 32] with w the
     synthetic policy's word (philox_ref.action_word) and list chosen by L & 3: 0, 1 -> _generate_preferred(history),
     2 -> _generate_legal(), 3 -> all actions — so that the side statistics also see what the heuristic itself never
     does.  The history is the reference's own History of Transition(observation, action, reward, next_observation,
-    done) records (rock.py:525-550), rebuilt empty after every reset.  Recorded per (lane, step): the preferred list
+    done) records (rock.py:525-550), rebuilt empty after every reset — `History(max_size)` when max_size is given
+    (rock.py:533-544: the oldest record is popped once the list holds more than max_size).  Recorded per (lane, step): the preferred list
     *before* the step, _select_target, the action, (ob, reward, done), and after the call (post auto-reset) the
     compact state and every rock's count / measured / lkv / lkw / prob_valuable."""
     load_reference()
@@ -403,7 +404,7 @@ def heuristic_trace(name, kwargs, seed, lanes, T, t0=0):
         env = make_ref_env(name, use_heuristic=True, **kwargs) if is_rock else make_ref_env(name, **kwargs)
         inject_stream(seed, lane, t0, px.STREAM_RESET, env=name, env_kwargs=kwargs)
         ob_prev = int(env.reset())
-        hist = rk.History() if is_rock else _TagHistory()
+        hist = rk.History(max_size) if is_rock else _TagHistory()
         n_act = env.action_space.n
         s0 = compact_state(name, env)
         K = len(env.state.rocks) if is_rock else 0
@@ -440,7 +441,7 @@ def heuristic_trace(name, kwargs, seed, lanes, T, t0=0):
             if d:
                 inject_stream(seed, lane, t, px.STREAM_RESET, env=name, env_kwargs=kwargs)
                 ob_prev = int(env.reset())
-                hist = rk.History() if is_rock else _TagHistory()
+                hist = rk.History(max_size) if is_rock else _TagHistory()
             else:
                 ob_prev = int(o)
             out["state"][li, i] = compact_state(name, env)

@@ -57,6 +57,7 @@ def heuristic_replay(case, env, o, ops):
     track(prev_ob, actions, ob, done); compact(); belief() -> dict of [K, n] arrays."""
     g = np.load(os.path.join(GOLDEN, "heur_%s.npz" % case))
     seed, t0, lanes = int(g["seed"]), int(g["t0"]), g["lanes"]
+    ops.max_size = int(g["max_size"]) if "max_size" in g.files else None     # History(max_size), rock.py:533-544
     L, T = g["action"].shape
     is_rock = env in ("rock", "stochrock")
     starts = [0] + [i for i in range(1, L) if lanes[i] != lanes[i - 1] + 1] + [L]
@@ -106,7 +107,7 @@ class OracleHeuristicOps(object):
         ob = self.o.batch_reset(self.st, seed, lane0, t)
         self.is_rock = self.o.name in ("rock", "stochrock")
         self.b = self.ol.Belief(self.o, n) if self.is_rock else None
-        self.h = self.ol.HistorySums(self.o, n)
+        self.h = self.ol.HistorySums(self.o, n, max_size=getattr(self, "max_size", None))
         return ob
 
     def preferred(self):

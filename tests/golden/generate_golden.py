@@ -181,15 +181,20 @@ HEUR_CASES = [("rock_7_8", "rock", {}, 96, 96), ("rock_11_11", "rock", dict(boar
               ("rock_4_3", "rock", dict(board_size=4, num_rocks=3), 32, 48),
               ("stochrock_7_8", "stochrock", {}, 48, 128),
               ("tag_1", "tag", {}, 64, 128), ("tag_2", "tag", dict(num_opponents=2), 32, 128)]
+# ... and with the planner's history bounded: History(max_size) of rock.py:533-544 (case -> max_size)
+HEUR_BOUNDED = [("rock_7_8_hist8", "rock", {}, 64, 160, 8), ("rock_11_11_hist2", "rock", dict(board_size=11, num_rocks=11), 32, 128, 2),
+                ("rock_4_3_hist0", "rock", dict(board_size=4, num_rocks=3), 32, 64, 0)]
 HEUR_SEED = 0xBE11EF5EED
 
 
-def gen_heuristic(case, env, kwargs, L, T):
+def gen_heuristic(case, env, kwargs, L, T, max_size=None):
     lanes = list(range(L // 2)) + list(range((1 << 20) - L // 4, (1 << 20) + L // 4))
     tries = 0
     while True:
         try:
-            tr = h.heuristic_trace(env, kwargs, HEUR_SEED + tries, lanes, T, t0=11)
+            tr = h.heuristic_trace(env, kwargs, HEUR_SEED + tries, lanes, T, t0=11, max_size=max_size)
+            if max_size is not None:
+                tr["max_size"] = np.int64(max_size)
             break
         except IndexError:      # RockSample crash cells
             tries += 1
@@ -197,7 +202,7 @@ def gen_heuristic(case, env, kwargs, L, T):
     out = {}
     for k, v in tr.items():
         v = np.asarray(v)
-        if v.dtype == np.float64 or k in ("lanes", "seed", "t0"):
+        if v.dtype == np.float64 or k in ("lanes", "seed", "t0", "max_size"):
             out[k] = v
         else:
             fits8 = v.size == 0 or (v.min() >= -128 and v.max() <= 127)
@@ -306,6 +311,11 @@ def main():
     import warnings
     warnings.simplefilter("ignore", RuntimeWarning)  # reference's belief side-stats divide 0/0 (rock.py:191)
     gen_thresholds()
+    if "--bounded-history-only" in sys.argv:
+        for case, env, kwargs, L, T, ms in HEUR_BOUNDED:
+            nd, ml, tries = gen_heuristic(case, env, kwargs, L, T, max_size=ms)
+            print("heuristic %-16s dones=%4d  mean preferred-list length=%.2f  (seed retries %d)" % (case, nd, ml, tries), flush=True)
+        return
     if "--heuristic-only" in sys.argv:
         for case, env, kwargs, L, T in HEUR_CASES:
             nd, ml, tries = gen_heuristic(case, env, kwargs, L, T)
@@ -329,6 +339,9 @@ def main():
     for case, env, kwargs, L, T in HEUR_CASES:
         nd, ml, tries = gen_heuristic(case, env, kwargs, L, T)
         print("heuristic %-16s dones=%4d  mean preferred-list length=%.2f  (seed retries %d)" % (case, nd, ml, tries), flush=True)
+    for case, env, kwargs, L, T, ms in HEUR_BOUNDED:
+        nd, ml, tries = gen_heuristic(case, env, kwargs, L, T, max_size=ms)
+        print("heuristic %-16s dones=%4d  mean preferred-list length=%.2f  (seed retries %d)" % (case, nd, ml, tries), flush=True)
     with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
         json.dump({"cases": [[c[0], c[1], {k: (list(v) if isinstance(v, tuple) else v) for k, v in c[2].items()}]
                              for c in CASES],
@@ -337,7 +350,7 @@ def main():
                    "prob_cases": [[c[0], c[1], {k: (list(v) if isinstance(v, tuple) else v) for k, v in c[2].items()}]
                                   for c in PROB_CASES],
                    "heuristic_cases": [[c[0], c[1], {k: (list(v) if isinstance(v, tuple) else v) for k, v in c[2].items()}]
-                                       for c in HEUR_CASES],
+                                       for c in HEUR_CASES + HEUR_BOUNDED],
                    "mode_a_seeds": MODE_A_SEEDS, "mode_b_seed": MODE_B_SEED,
                    "numpy": np.__version__}, f, indent=1)
 

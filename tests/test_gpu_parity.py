@@ -654,7 +654,7 @@ class HipHeuristicOps(object):
         self.e = make_env(self.env_name, dict(self.kw, **extra), batch_size=n, seed=seed, lane_offset=lane0, auto_reset=True)
         self.e.call_counter = t
         ob = self.e.reset()
-        self.h = History(self.e)
+        self.h = History(self.e, max_size=getattr(self, "max_size", None))
         return np_(ob)
 
     def preferred(self):
@@ -704,16 +704,21 @@ def test_heuristic_golden(case, env, kw):
     heuristic_replay(case, env, ol.OracleEnv(env, **kw), HipHeuristicOps(env, kw))
 
 
-@pytest.mark.parametrize("env,kw,n,T", [("rock", {}, 16384, 96), ("rock", dict(board_size=15, num_rocks=15), 8192, 96),
-                                        ("stochrock", {}, 4096, 128), ("tag", {}, 8192, 128)],
-                         ids=["rock_7_8", "rock_15_15", "stochrock_7_8", "tag_1"])
-def test_heuristic_vs_oracle_at_scale(env, kw, n, T):
+@pytest.mark.parametrize("env,kw,n,T,max_size", [("rock", {}, 16384, 96, None), ("rock", dict(board_size=15, num_rocks=15), 8192, 96, None),
+                                                 ("stochrock", {}, 4096, 128, None), ("tag", {}, 8192, 128, None),
+                                                 ("rock", {}, 8192, 96, 8), ("rock", dict(board_size=11, num_rocks=11), 4096, 96, 0),
+                                                 ("rock", dict(board_size=15, num_rocks=15), 4096, 128, 30), ("tag", {}, 4096, 64, 2)],
+                         ids=["rock_7_8", "rock_15_15", "stochrock_7_8", "tag_1", "rock_7_8-hist8", "rock_11_11-hist0",
+                              "rock_15_15-hist30", "tag_1-hist2"])
+def test_heuristic_vs_oracle_at_scale(env, kw, n, T, max_size):
     """A device-resident heuristic-policy loop (preferred -> pick -> step -> statistics -> history) against the oracle's
-    restatement, every lane following its own preferred list."""
+    restatement, every lane following its own preferred list; with max_size the planner's history is History(max_size)
+    (rock.py:533-544), which the oracle keeps as the reference does — a list of records with pop(0)."""
     from oracle import oracle_lib as ol
     o = ol.OracleEnv(env, **kw)
     seed, lane0 = 0xFEED5EED, (1 << 20) - 512
     cpu, gpu = OracleHeuristicOps(ol, o), HipHeuristicOps(env, kw)
+    cpu.max_size = gpu.max_size = max_size
     prev_c, prev_g = cpu.reset(n, seed, lane0, 0), gpu.reset(n, seed, lane0, 0)
     assert np.array_equal(prev_c, prev_g)
     is_rock = env in ("rock", "stochrock")
@@ -739,15 +744,22 @@ def test_heuristic_vs_oracle_at_scale(env, kw, n, T):
             for k in bc:
                 same = (bc[k] == bg[k]) | ((bc[k] != bc[k]) & (bg[k] != bg[k]))
                 assert same.all(), (t, k)
-        for k in ("size", "last_action", "last_ob", "total_sample", "total_move"):
+        # (a bounded history's sums: the oracle walks its records when asked, so only the HIP side keeps them as arrays)
+        for k in ("size", "last_action", "last_ob") + (("total_sample", "total_move") if max_size is None else ()):
             assert np.array_equal(getattr(cpu.h, k), np_(getattr(gpu.h, "_size" if k == "size" else k))), (t, k)
+        if max_size is not None:
+            assert int(cpu.h.size.max()) <= max_size + 1
         if is_rock:      # the derived words the policy reads == the per-rock tests on the oracle's full arrays
             K = o.n_actions - 5
             w = (1 << np.arange(K, dtype=np.int64))[:, None]
             ok = (bc["measured"] < 5) & (np.abs(bc["count"]) < 2) & (bc["prob_valuable"] > 0) & (bc["prob_valuable"] < 1)
             assert np.array_equal((ok * w).sum(axis=0), np_(gpu.e._tracker.check_ok).astype(np.int64) & 0xFFFFFFFF), t
-            assert np.array_equal(((cpu.h.total_move >= 0) * w).sum(axis=0), np_(gpu.h.move_ok).astype(np.int64) & 0xFFFFFFFF), t
-    assert n_done > 0
+            if max_size is None:
+                assert np.array_equal(((cpu.h.total_move >= 0) * w).sum(axis=0), np_(gpu.h.move_ok).astype(np.int64) & 0xFFFFFFFF), t
+            else:
+                assert np.array_equal(((np_(gpu.h.total_move) >= 0) * w).sum(axis=0), np_(gpu.h.move_ok).astype(np.int64) & 0xFFFFFFFF), t
+    # (a policy that forgets its old CHECKs keeps re-measuring: with a short window no episode need end inside T steps)
+    assert n_done > 0 or max_size is not None
 
 
 def test_set_belief_refreshes_the_derived_word():
@@ -772,19 +784,24 @@ def test_set_belief_refreshes_the_derived_word():
                                              ("stochrock", {}, 4096, 96, True), ("tag", {}, 8192, 96, True),
                                              ("tag", dict(num_opponents=2), 4096, 96, False), ("rock", {}, 4096, 48, False),
                                              ("tiger", {}, 4096, 24, True), ("battleship", {}, 4096, 40, True),
-                                             ("network", {}, 4096, 16, True)],
+                                             ("network", {}, 4096, 16, True),
+                                             ("rock", dict(hist=8), 8192, 96, True), ("rock", dict(hist=0), 4096, 48, False),
+                                             ("tag", dict(hist=1), 4096, 48, True)],
                          ids=["rock_7_8", "rock_15_15", "stochrock_7_8", "tag_1", "tag_2_noreset", "rock_7_8_noreset", "tiger",
-                              "battleship_5_5", "network_10"])
+                              "battleship_5_5", "network_10", "rock_7_8-hist8", "rock_7_8-hist0-noreset", "tag_1-hist1"])
 def test_fused_heuristic_steps_match_the_call_sequence(env, kw, n, T, auto):
     """pomdp_heuristic_steps (one launch per step) == preferred_actions -> pick_actions -> step (+ side statistics) ->
-    History.append issued separately, on every output, the state, the statistics and the history sums."""
+    History.append issued separately, on every output, the state, the statistics and the history sums — also with a
+    bounded History(max_size) (`hist`), whose window the two paths keep in step."""
     from gym_pomdp_amd import History, Transition
+    kw = dict(kw)
+    max_size = kw.pop("hist", None)
     is_rock = env in ("rock", "stochrock")
     extra = dict(use_heuristic=True) if is_rock else {}
     mk = lambda: make_env(env, dict(kw, **extra), batch_size=n, seed=77, lane_offset=4096, auto_reset=auto)  # noqa: E731
     ea, eb = mk(), mk()
     oa, ob_ = ea.reset(), eb.reset()
-    ha, hb = History(ea), History(eb)
+    ha, hb = History(ea, max_size=max_size), History(eb, max_size=max_size)
     prev = oa.clone()
     for t in range(T):
         lst, ln = ea.preferred_actions(ha) if (is_rock or env == "tag") else ea.legal_actions()
@@ -811,8 +828,10 @@ def test_fused_heuristic_steps_match_the_call_sequence(env, kw, n, T, auto):
             assert torch.equal(hb._size[live], ha._size[live]), t
             continue
         assert torch.equal(hb.prev_ob, prev), t
-        for k in ("_size", "last_action", "last_ob", "total_sample", "total_move"):
+        for k in ("_size", "last_action", "last_ob", "total_sample", "total_move", "head", "ring"):
             assert torch.equal(getattr(ha, k), getattr(hb, k)), (t, k)
+        if max_size is not None:
+            assert int(ha._size.max()) <= max_size + 1
         if is_rock:
             for k in ea.belief:
                 x, y = ea.belief[k], eb.belief[k]
@@ -915,22 +934,25 @@ def test_fused_steps_leave_what_per_step_launches_leave(env, kw, n, auto):
 
 HEUR_FUSE_CASES = [("rock", {}, 8192 + 12, True), ("rock", {}, 4096, False), ("rock", dict(board_size=15, num_rocks=15), 4096, True),
                    ("stochrock", {}, 4096, True), ("tag", {}, 8192, True), ("tag", dict(num_opponents=2), 4096, False),
-                   ("battleship", {}, 4096, True), ("tiger", {}, 4096, True), ("network", {}, 4096, True)]
+                   ("battleship", {}, 4096, True), ("tiger", {}, 4096, True), ("network", {}, 4096, True),
+                   ("rock", dict(hist=5), 4096 + 12, True), ("rock", dict(board_size=15, num_rocks=15, hist=40), 4096, True)]
 
 
 @pytest.mark.parametrize("env,kw,n,auto", HEUR_FUSE_CASES,
-                         ids=["%s-%d-%s" % (c[0], c[2], "auto" if c[3] else "frozen") for c in HEUR_FUSE_CASES])
+                         ids=["%s%s-%d-%s" % (c[0], "-hist%d" % c[1]["hist"] if "hist" in c[1] else "", c[2], "auto" if c[3] else "frozen") for c in HEUR_FUSE_CASES])
 def test_heuristic_steps_in_one_launch_equal_single_step_launches(env, kw, n, auto):
     """env.heuristic_steps(history, k) runs up to 64 steps per launch with the lane's history words, derived words and
     running return in registers: every array it owns must end up exactly as after k one-step launches."""
     from gym_pomdp_amd import History, Returns
+    kw = dict(kw)
+    max_size = kw.pop("hist", None)                     # History(max_size): the window travels through the multi-step launch too
     is_rock = env in ("rock", "stochrock")
     mk = lambda: make_env(env, dict(kw, **(dict(use_heuristic=True) if is_rock else {})), batch_size=n, seed=31, lane_offset=64,  # noqa: E731
                           auto_reset=auto)
     ea, eb = mk(), mk()
     ea.reset()
     eb.reset()
-    ha, hb, ra, rb = History(ea), History(eb), Returns(ea), Returns(eb)
+    ha, hb, ra, rb = History(ea, max_size=max_size), History(eb, max_size=max_size), Returns(ea), Returns(eb)
     for k in (1, 3, 64, 65, 7):
         for _ in range(k):
             outs_a = ea.heuristic_steps(ha, 1, returns=ra)
@@ -939,7 +961,7 @@ def test_heuristic_steps_in_one_launch_equal_single_step_launches(env, kw, n, au
         for x, y in zip(outs_a, outs_b):
             assert torch.equal(x, y), ctx
         assert torch.equal(ea.state, eb.state), ctx
-        for name in ("_size", "last_action", "last_ob", "total_sample", "total_move", "move_ok", "prev_ob"):
+        for name in ("_size", "last_action", "last_ob", "total_sample", "total_move", "move_ok", "prev_ob", "head", "ring"):
             assert torch.equal(getattr(ha, name), getattr(hb, name)), ctx + (name,)
         for name in ("ret", "disc", "ret_done"):
             x, y = getattr(ra, name), getattr(rb, name)
