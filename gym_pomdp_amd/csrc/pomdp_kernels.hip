@@ -1615,8 +1615,10 @@ __global__ __launch_bounds__(BLOCK) void battleship_steps_quad_kernel(uint32_t *
             }
             int nps = k_steps;
             const uint64_t col = (uint64_t)wcol0 + (uint64_t)idx;
-            // The lane's actions come from the policy's blocks again (reading them back from the action rows phase 1 wrote would
-            // put a load, and with it a wait for the loop's own stores, into every iteration: measured 3x slower)
+            // The lane's actions come from the policy's blocks again.  Reading them back from the action rows phase 1 wrote was
+            // measured slower both ways: a load inside the loop makes every iteration wait for the loop's own stores (3x), a
+            // burst of the lane's <= 63 scattered loads through LDS before the loop costs more than the blocks (3.66 vs 2.85 us
+            // per step at 2^19 lanes)
             for (int s = 1; s < k_steps; ++s) {
                 const bool act = mine && s > s0 && nps == k_steps;
                 if (!__any(act)) continue;                                     // wave-uniform
