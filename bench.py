@@ -19,7 +19,8 @@ also carries `strong_scaling`: the same K steps on a batch of --lanes-per-gpu la
 
 Timing protocol: for each master seed in --seeds (default 0,1,2) the env is re-seeded and reset, W
 warm-up steps run, and the region "barrier, sync, K steps, sync" is timed R times (R = --repeats, default 31 for
-K < 2048 else 5); every region is max-reduced over the ranks; a seed's figure is the median of its regions and the
+K < 2048 else 5; even regions by wall clock, odd ones by HIP events for the kernel time); every wall-clock region is
+max-reduced over the ranks; a seed's figure is the median of its regions and the
 line's `value` / `ms_per_step` the median over the seeds (config.seed_values has all of them and the min / max).
 Every buffer the timed steps write is allocated, and touched by the same chunking of K, before the first timed
 region.
@@ -116,22 +117,34 @@ def median(xs):
 
 
 def timed_regions(run, k, repeats, dev, cp):
-    """`repeats` times: barrier + device sync, K steps, device sync — wall clock (max over ranks) and HIP-event time
-    on the launch stream.  Returns ([wall seconds], [event milliseconds])."""
+    """`repeats` times: barrier + device sync, K steps, device sync.  Even regions are timed by wall clock (max over ranks),
+    odd ones by HIP events on the launch stream (their records would otherwise sit inside the wall-clock window: ~3 us
+    of host time each, which is 4 % of a 20-step region); a single region carries both.
+    Returns ([wall seconds], [event milliseconds])."""
     walls, evs = [], []
-    for _ in range(repeats):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for r in range(repeats):
+        with_events = (r & 1) == 1 or repeats == 1
         torch.cuda.synchronize(dev)
         cp.barrier()
-        t0 = time.perf_counter()
-        e0.record()
-        run(k)
-        e1.record()
-        torch.cuda.synchronize(dev)
-        el = time.perf_counter() - t0
-        cp.barrier()
-        walls.append(cp.max(el))
-        evs.append(e0.elapsed_time(e1))
+        if with_events:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            e0.record()
+            run(k)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            el = time.perf_counter() - t0
+            cp.barrier()
+            evs.append(e0.elapsed_time(e1))
+            if repeats == 1:
+                walls.append(cp.max(el))
+        else:
+            t0 = time.perf_counter()
+            run(k)
+            torch.cuda.synchronize(dev)
+            el = time.perf_counter() - t0
+            cp.barrier()
+            walls.append(cp.max(el))
     return walls, evs
 
 

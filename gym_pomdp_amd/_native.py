@@ -28,7 +28,7 @@ SYMBOLS = [
     "pomdp_rock_reset", "pomdp_rock_step", "pomdp_tag_reset", "pomdp_tag_step",
     "pomdp_battleship_reset", "pomdp_battleship_step", "pomdp_tiger_reset", "pomdp_tiger_step",
     "pomdp_network_reset", "pomdp_network_step", "pomdp_step", "pomdp_synthetic_actions", "pomdp_philox_blocks",
-    "pomdp_rollout_synthetic", "pomdp_collect_synthetic", "pomdp_legal_actions", "pomdp_rollout", "pomdp_compute_prob",
+    "pomdp_rollout_synthetic", "pomdp_collect_synthetic", "pomdp_collect", "pomdp_legal_actions", "pomdp_rollout", "pomdp_compute_prob",
     "pomdp_rock_belief_reset", "pomdp_rock_belief_refresh", "pomdp_rock_belief_update", "pomdp_rock_select_target", "pomdp_history_clear",
     "pomdp_history_append", "pomdp_preferred_actions", "pomdp_pick_actions", "pomdp_heuristic_steps",
 ]
@@ -63,6 +63,12 @@ class StepArgs(C.Structure):        # pomdp_step_args
     _fields_ = [("env", C.c_int32), ("flags", C.c_int32), ("params", C.c_void_p), ("state", C.c_void_p), ("ob", C.c_void_p),
                 ("reward", C.c_void_p), ("done", C.c_void_p), ("err", C.c_void_p), ("n", C.c_int64), ("seed", C.c_uint64),
                 ("lane0", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class CollectArgs(C.Structure):     # pomdp_collect_args
+    _fields_ = [("env", C.c_int32), ("flags", C.c_int32), ("params", C.c_void_p), ("state", C.c_void_p), ("action", C.c_void_p),
+                ("ob", C.c_void_p), ("reward", C.c_void_p), ("done", C.c_void_p), ("err", C.c_void_p), ("n", C.c_int64),
+                ("pitch", C.c_int64), ("seed", C.c_uint64), ("lane0", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class RockBelief(C.Structure):      # pomdp_rock_belief: device pointers, [num_rocks][n]
@@ -136,6 +142,8 @@ def lib():
     L.pomdp_rollout_synthetic.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, i64, u64, u64, u32, u64, i64, ci, vp]
     L.pomdp_collect_synthetic.restype = ci
     L.pomdp_collect_synthetic.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, i64, u64, u32, u64, i64, i64, ci, vp]
+    L.pomdp_collect.restype = ci
+    L.pomdp_collect.argtypes = [vp, u64, i64, vp]
     L.pomdp_legal_actions.restype = ci
     L.pomdp_legal_actions.argtypes = [ci, vp, vp, vp, vp, i64, ci, vp]
     L.pomdp_compute_prob.restype = ci

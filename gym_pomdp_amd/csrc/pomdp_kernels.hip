@@ -2254,6 +2254,13 @@ int pomdp_collect_synthetic(int env, const void *params, uint32_t *state, int32_
     return 0;
 }
 
+int pomdp_collect(const pomdp_collect_args *a, uint64_t t0, int64_t k_steps, void *stream)
+{
+    if (!a) return POMDP_E_BADARG;
+    return pomdp_collect_synthetic(a->env, a->params, a->state, a->action, a->ob, a->reward, a->done, a->err, a->n, a->seed,
+                                   a->lane0, t0, k_steps, a->pitch, a->flags, stream);
+}
+
 int pomdp_legal_actions(int env, const void *params, const uint32_t *state, int32_t *list, int32_t *len, int64_t n,
                         int stride, void *stream)
 {

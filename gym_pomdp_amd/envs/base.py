@@ -518,17 +518,24 @@ class BatchedEnv(object):
                    "reward": torch.empty((steps, n), dtype=self._reward.dtype, device=self.device),
                    "done_u8": torch.empty((steps, n), dtype=torch.uint8, device=self.device)}
             out["done"] = out["done_u8"].view(torch.bool)
-        assert out["action"].shape == (steps + 1, n) and out["ob"].shape == (steps, n)
+        bound = out.get("_bound")
+        if bound is None or bound[2] != steps:
+            # the call's per-buffer arguments, bound once per `out` (include/pomdp_hip.h: pomdp_collect_args)
+            assert out["action"].shape == (steps + 1, n) and out["ob"].shape == (steps, n)
+            a = _native.CollectArgs(env=_native.ENV_KIND[self.env_name], flags=_native.POMDP_AUTO_RESET,
+                                    params=C.addressof(self._params), state=self._ptrs[0], action=out["action"].data_ptr(),
+                                    ob=out["ob"].data_ptr(), reward=out["reward"].data_ptr(), done=out["done_u8"].data_ptr(),
+                                    err=self._ptrs[4], n=n, pitch=n, seed=self._seed,
+                                    lane0=self.lane_offset, reserved=0)
+            bound = out["_bound"] = (a, C.byref(a), steps)
+        bound[0].seed = self._seed
         t0 = self._t
-        self._t += steps
-        args = (_native.ENV_KIND[self.env_name], self._params_ref, self._ptrs[0], out["action"].data_ptr(),
-                out["ob"].data_ptr(), out["reward"].data_ptr(), out["done_u8"].data_ptr(), self._ptrs[4],
-                n, self._seed, self.lane_offset, t0, steps, n, _native.POMDP_AUTO_RESET)
-        if torch.cuda.current_device() == self.device.index:      # no device-context switch on the common path
-            rc = self._lib.pomdp_collect_synthetic(*args, self._stream())
+        self._t = t0 + steps
+        if torch._C._cuda_getDevice() == self._dev_index:         # no device-context switch on the common path
+            rc = self._lib.pomdp_collect(bound[1], t0, steps, torch._C._cuda_getCurrentRawStream(self._dev_index))
         else:
             with torch.cuda.device(self.device):
-                rc = self._lib.pomdp_collect_synthetic(*args, self._stream())
+                rc = self._lib.pomdp_collect(bound[1], t0, steps, self._stream())
         if rc:
             _native.check(rc, "pomdp_collect_synthetic")
         return out

@@ -227,6 +227,24 @@ int pomdp_collect_synthetic(int env, const void *params, uint32_t *state, int32_
                             uint8_t *done, uint32_t *err, int64_t n, uint64_t seed, uint32_t lane0, uint64_t t0,
                             int64_t k_steps, int64_t pitch, int flags, void *stream);
 
+/* pomdp_collect_synthetic with its per-batch arguments bound once (see pomdp_step_args): pomdp_collect(a, t0, k, stream) is
+ * pomdp_collect_synthetic(a->env, a->params, a->state, a->action, a->ob, a->reward, a->done, a->err, a->n, a->seed, a->lane0,
+ * t0, k, a->pitch, a->flags, stream). */
+typedef struct pomdp_collect_args {
+    int32_t   env, flags;
+    const void *params;
+    uint32_t *state;
+    int32_t  *action;    /* device [k + 1][pitch] */
+    int32_t  *ob;        /* device [k][pitch] */
+    void     *reward;
+    uint8_t  *done;
+    uint32_t *err;
+    int64_t   n, pitch;
+    uint64_t  seed;
+    uint32_t  lane0, reserved;
+} pomdp_collect_args;
+int pomdp_collect(const pomdp_collect_args *args, uint64_t t0, int64_t k_steps, void *stream);
+
 /* ---- planner hooks ------------------------------------- */
 /* replaces <Env>._generate_legal (rock.py:273-291, tag.py:228-229, battleship.py:157-165, tiger.py:111-112,
  * network.py:130-131): list (device, int32 [n][stride], stride >= the env's action count) receives each
