@@ -55,10 +55,11 @@ WORKLOADS = {
     "stochrock": ("StochasticRock-v0", {}, "StochasticRock(7,8)", 21, "int32"),
     "tag": ("Tag-v0", {}, "Tag-v0 (5x10 grid, 1 opponent)", 21, "int32"),
     "battleship": ("Battleship-v0", dict(board_size=(10, 10), max_len=5), "BattleShip 10x10 max_len=5", 61, "int32"),
+    "battleship5": ("Battleship-v0", {}, "BattleShip 5x5 max_len=3 (the reference's default)", 29, "int32"),
     "tiger": ("Tiger-v0", {}, "Tiger-v0", 21, "int32"),
     "network": ("Network-v0", {}, "Network-v0 (10 machines)", 21, "int32"),
 }
-ORACLE_NAME = {"rock": "rock", "rock15": "rock", "stochrock": "stochrock", "tag": "tag", "battleship": "battleship", "tiger": "tiger",
+ORACLE_NAME = {"rock": "rock", "rock15": "rock", "stochrock": "stochrock", "tag": "tag", "battleship": "battleship", "battleship5": "battleship", "tiger": "tiger",
                "network": "network"}
 
 

@@ -14,7 +14,6 @@ struct BattleShipEnv {
     static constexpr bool POOLED_LPT2 = false;
     static constexpr bool POOLED_ANY_LPT = false;
     static constexpr bool QUAD_SENSOR = false;
-    static constexpr bool DEFERRED_RESETS = true;  // pomdp_kernels.hip: battleship_steps_quad_kernel
     struct Shared { int unused; };
     // Each 128-bit mask is two 64-bit registers (never an addressable array or vector: a dynamically indexed
     // one is lowered through LDS by the compiler); bit tests are a 64-bit select and one variable shift.
@@ -108,75 +107,6 @@ struct BattleShipEnv {
         st.vis.lo = 0; st.vis.hi = 0;
         st.vis.set_word(MW - 1, (uint32_t)remaining << 26);
         return 0;
-    }
-
-    // ---- the same boards, many lanes at once (pomdp_kernels.hip: battleship_steps_quad_kernel, phase 2) -------------------
-    // reset() above, reshaped for lanes that run it in lockstep: ONE loop in which every lane consumes exactly one word of
-    // its RESET stream per iteration — so the Philox blocks are generated under a wave-uniform condition, four iterations
-    // per block — and a two-state machine per lane says what the word is: a position word (accepted when <= n_tiles - 1,
-    // np.random.randint's masked rejection) or the direction word that follows an accepted position (battleship.py:33-37,
-    // 171-176).  The placement test and mark_ship are the mask arithmetic of reset_where(); the column patterns come from
-    // `vp` (LDS copy of p.vpat: one 16-byte read per lane whatever its ship length).  Lanes with go == false idle through.
-    struct SeqTables { uint32_t vp[12][4]; };
-    static __device__ __forceinline__ void stage_seq(SeqTables &t, const Params &p, int tid)
-    {
-        if (tid < 48) t.vp[tid >> 2][tid & 3] = p.vpat[(tid >> 2) % 12][tid & 3];
-    }
-    static __device__ __forceinline__ u128 blocked_of(u128 occ, u128 col0, u128 colL, int X)
-    {
-        // occ and its N, E, S, W, NE, SE, SW shifts (NW excluded): h = {self, E, W}; south side = h << X; north = {self, E} >> X
-        const u128 e1 = (occ & ~col0) >> 1, h = occ | e1 | ((occ & ~colL) << 1);
-        return h | ((occ | e1) >> X) | (h << X);
-    }
-    static __device__ __forceinline__ void reset_lockstep(const SeqTables &t, const Params &p, State &st, bool go, const RngKey &key,
-                                                          uint32_t lane)
-    {
-        const int X = p.x_size, Y = p.y_size, cells = X * Y;
-        const uint32_t rmask = 0xFFFFFFFFu >> __clz((uint32_t)(cells - 1) | 1u);
-        const uint32_t inv_x = (65536u + (uint32_t)X - 1u) / (uint32_t)X;      // a / X == (a * inv_x) >> 16 for a < 128, X <= 16
-        const u128 col0 = u128_of(p.col0), colL = col0 << (X - 1);
-        u128 occ = 0, blocked = 0;
-        int len = go ? p.max_len : 1, remaining = 0, a0 = 0;                   // len < 2: nothing (left) to place
-        bool want_dir = false;
-        for (uint32_t blk = 0; __any(len >= 2); ++blk) {
-            const uint4 b4 = stream_block(key, lane, POMDP_STREAM_RESET, blk & 0xFFFFFFu);
-            const uint32_t W4[4] = {b4.x, b4.y, b4.z, b4.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const uint32_t w = W4[e];
-                const bool live = len >= 2;
-                // as a direction word: the placement from a0 (Compass N E S W)
-                const uint32_t dir = w & 3u;
-                const int dx = (dir == 1u) - (dir == 3u), dy = (dir == 0u) - (dir == 2u);
-                const int py = (int)(((uint32_t)a0 * inv_x) >> 16), px = a0 - py * X;
-                const int ex = px + (len + 1) * dx, ey = py + (len + 1) * dy, stride = dy * X + dx;
-                const bool inside = (unsigned)ex < (unsigned)X && (unsigned)ey < (unsigned)Y;
-                const int lo = stride > 0 ? a0 : a0 + len * stride;
-                const uint32_t *v1 = t.vp[(len + 1) % 12], *v0 = t.vp[len % 12];
-                const u128 vpat1 = u128_of4(v1[0], v1[1], v1[2], v1[3]), vpat0 = u128_of4(v0[0], v0[1], v0[2], v0[3]);
-                const u128 test = (dx != 0 ? (u128)((1ull << (len + 1)) - 1ull) : vpat1) << (lo & 127);
-                const bool place = live && want_dir && inside && (test & blocked) == 0;
-                if (__any(place)) {                                            // wave-uniform: skip the marking when nobody places
-                    if (place) {
-                        const int low = stride > 0 ? a0 : a0 + (len - 1) * stride;
-                        occ |= (dx != 0 ? (u128)((1ull << len) - 1ull) : vpat0) << (low & 127);
-                        remaining += len;
-                        len -= 1;
-                        blocked = blocked_of(occ, col0, colL, X);
-                    }
-                }
-                // as a position word: accepted when it is a tile
-                const uint32_t v = w & rmask;
-                const bool accept = live && !want_dir && v <= (uint32_t)(cells - 1);
-                a0 = accept ? (int)v : a0;
-                want_dir = accept;                                             // a direction word is always consumed: back to positions
-            }
-        }
-        if (go) {
-            st.occ.lo = (uint64_t)occ; st.occ.hi = (uint64_t)(occ >> 64);
-            st.vis.lo = 0; st.vis.hi = 0;
-            st.vis.set_word(MW - 1, (uint32_t)remaining << 26);
-        }
     }
 
     // Wave-cooperative reset.  A BattleShip reset is a long sequential rejection loop (about 20 attempts on

@@ -1494,174 +1494,6 @@ __global__ __launch_bounds__(BLOCK) void network_steps_quad_kernel(uint32_t *__r
     st_stream4(state + l0, st[0], st[1], st[2], st[3]);
 }
 
-// BattleShip with a quad per thread and DEFERRED resets.  A fresh board is a long sequential rejection loop (battleship.py:167-180:
-// about 23 words of the lane's RESET stream on 10x10) that one lane in ~285 needs per step; served when it comes up — by the
-// whole wave, one lane at a time (BattleShipEnv::reset_where) — it is two thirds of all instructions steps_kernel<BattleShipEnv>
-// issues.  But nothing forces a lane's steps to be computed in lockstep with its neighbours': its random words depend on
-// (lane, t) only and every step has its own output row.  So the launch runs in two phases per wave:
-//   1. all k steps for every lane, a lane that finishes an episode PAUSING there (its terminal ob / reward / done are
-//      written; the rows after it get placeholders) — no reset anywhere in the loop;
-//   2. the paused lanes (about a fifth of the wave after 64 steps) are dealt out over the wave's threads, one lane each:
-//      every pool thread builds its lane's board with the plain per-lane loop (64 boards at the price of one), then plays
-//      the lane's remaining steps, writing their rows itself.  A lane that finishes again pauses again and goes into the
-//      next round, until nobody is left.
-// The policy's ACTION block is the thread's own in phase 1 (all action rows are complete after it); phase 2 derives the
-// lane's actions from the same blocks.  Same rows as k single-step launches: which thread computes a lane-step, and when,
-// is invisible to its random words.
-template <class Env, class = void> struct deferred_resets : std::false_type {};
-template <class Env> struct deferred_resets<Env, std::enable_if_t<Env::DEFERRED_RESETS>> : std::true_type {};
-
-template <int MW>
-__global__ __launch_bounds__(BLOCK) void battleship_steps_quad_kernel(uint32_t *__restrict__ state, int32_t *__restrict__ action,
-                                                                      int32_t *__restrict__ ob, int32_t *__restrict__ reward,
-                                                                      uint8_t *__restrict__ done, int64_t n, RngKey key0,
-                                                                      uint32_t lane0, RngKey akey0, int k_steps, int64_t rec,
-                                                                      int gen_first, uint32_t first, const pomdp_battleship_params p)
-{
-    // n: lanes of the shard (the pitch of the state's word columns); first: the shard lane this launch's grid starts at
-    using Env = BattleShipEnv<MW>;
-    __shared__ typename Env::Shared sh;
-    __shared__ uint8_t task_lds[BLOCK / 64][256];            // task rank -> lane within the wave's 256
-    __shared__ uint8_t ps_lds[BLOCK / 64][256];              // ... and the step at which that lane finished its episode
-    __shared__ uint32_t res_lds[BLOCK / 64][64][2 * MW + 1]; // pool thread -> {step at which the lane paused again (k_steps: it
-                                                             // ran to the end), the lane's state words}
-    __shared__ typename Env::SeqTables seq;                  // the column patterns of the board builder
-    Env::stage_seq(seq, p, (int)threadIdx.x);
-    __syncthreads();
-    const int wv = (int)(threadIdx.x >> 6), me = (int)(threadIdx.x & 63u);
-    const uint32_t l0 = first + blockIdx.x * (uint32_t)(4 * BLOCK) + 4u * threadIdx.x;
-    const uint32_t glane0 = lane0 + l0, wave0 = glane0 - 4u * (uint32_t)me, wcol0 = l0 - 4u * (uint32_t)me;
-    uint32_t *action_w = reinterpret_cast<uint32_t *>(action) + l0, *ob_w = reinterpret_cast<uint32_t *>(ob) + l0;
-    uint32_t *reward_w = reinterpret_cast<uint32_t *>(reward) + l0;
-    uint32_t *done_w = reinterpret_cast<uint32_t *>(done + l0);
-    const uint32_t n_act = (uint32_t)Env::n_actions(p);
-    typename Env::State st[4];
-    int a_cur[4];
-    {
-        uint32_t w[2 * MW][4];
-#pragma unroll
-        for (int q = 0; q < 2 * MW; ++q) {
-            const u32x4 v = ld_stream4(state + (int64_t)q * n + l0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) w[q][j] = v[j];
-        }
-        const u32x4 a4 = first_actions4(action_w, gen_first, glane0, akey0, n_act);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            a_cur[j] = (int)a4[j];
-            st[j].occ.lo = st[j].occ.hi = st[j].vis.lo = st[j].vis.hi = 0;
-#pragma unroll
-            for (int q = 0; q < MW; ++q) { st[j].occ.set_word(q, w[q][j]); st[j].vis.set_word(q, w[MW + q][j]); }
-        }
-    }
-    action_w += rec;
-    const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo, ta0 = ((uint64_t)akey0.t_hi << 32) | akey0.t_lo;
-    int ps[4] = {k_steps, k_steps, k_steps, k_steps};       // the step at which the lane paused; k_steps = running
-    // ---- phase 1: every step of every lane up to the end of its episode ------------------------------------------------
-    for (int s = 0; s < k_steps; ++s) {
-        const uint64_t ta = ta0 + (uint64_t)s;
-        const uint4 pw = philox4x32_10(glane0 >> 2, (uint32_t)ta, (uint32_t)(ta >> 32), (uint32_t)POMDP_STREAM_ACTION << 24, akey0.k0, akey0.k1);
-        const uint32_t P[4] = {pw.x, pw.y, pw.z, pw.w};
-        uint32_t o4[4], r4[4], a_next[4], dpack = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int o = 0, r = 0, d = 0;
-            if (ps[j] == k_steps) {
-                Env::step(sh, p, st[j], a_cur[j], key0, 0u, o, r, d);           // battleship.py:91-122: draws nothing
-                if (d) ps[j] = s;
-            }
-            o4[j] = (uint32_t)o; r4[j] = (uint32_t)r;
-            dpack |= (uint32_t)(d != 0) << (8 * j);
-            a_next[j] = __umulhi(P[j], n_act);
-            a_cur[j] = (int)a_next[j];
-        }
-        st_stream4(action_w, a_next[0], a_next[1], a_next[2], a_next[3]);
-        st_stream4(ob_w, o4[0], o4[1], o4[2], o4[3]);
-        st_stream4(reward_w, r4[0], r4[1], r4[2], r4[3]);
-        st_stream(done_w, dpack);
-        action_w += rec; ob_w += rec; reward_w += rec; done_w += rec / 4;
-    }
-    // ---- phase 2: fresh boards for the paused lanes, and the steps they missed ----------------------------------------------
-    bool fenced = false;
-    for (;;) {
-        uint64_t mm[4];
-        int rank[4], ntask = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            mm[j] = __ballot(ps[j] < k_steps);
-            rank[j] = ntask + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm[j], 0u));
-            ntask += __popcll(mm[j]);
-        }
-        if (ntask == 0) break;                                                 // wave-uniform
-        // Phase 1's rows (the placeholders that phase 2 overwrites, the action rows it reads back) were stored by threads of THIS
-        // wave: they only have to have left the wave's memory pipeline — a wait on its store counter, which is what a
-        // workgroup-scope fence is here; an agent-scope __threadfence() would write back and invalidate the XCD's whole L2,
-        // once per wave (measured: 2.5 us per step of 2^20 lanes)
-        if (!fenced) { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); fenced = true; }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (ps[j] < k_steps) { task_lds[wv][rank[j] & 255] = (uint8_t)(4 * me + j); ps_lds[wv][rank[j] & 255] = (uint8_t)ps[j]; }
-        for (int base = 0; base < ntask; base += 64) {
-            const int q = base + me;
-            const bool mine = q < ntask;
-            const int idx = mine ? (int)task_lds[wv][q & 255] : 0, s0 = mine ? (int)ps_lds[wv][q & 255] : k_steps;
-            const uint32_t lane = wave0 + (uint32_t)idx;
-            typename Env::State b;
-            b.occ.lo = b.occ.hi = b.vis.lo = b.vis.hi = 0;
-            {                                                                  // battleship.py:131-137 at the call counter of step s0
-                RngKey kr = key0;
-                kr.t_lo = (uint32_t)(t0 + (uint64_t)s0); kr.t_hi = (uint32_t)((t0 + (uint64_t)s0) >> 32);
-                Env::reset_lockstep(seq, p, b, mine, kr, lane);
-            }
-            int nps = k_steps;
-            const uint64_t col = (uint64_t)wcol0 + (uint64_t)idx;
-            // The lane's actions come from the policy's blocks again.  Reading them back from the action rows phase 1 wrote was
-            // measured slower both ways: a load inside the loop makes every iteration wait for the loop's own stores (3x), a
-            // burst of the lane's <= 63 scattered loads through LDS before the loop costs more than the blocks (3.66 vs 2.85 us
-            // per step at 2^19 lanes)
-            for (int s = 1; s < k_steps; ++s) {
-                const bool act = mine && s > s0 && nps == k_steps;
-                if (!__any(act)) continue;                                     // wave-uniform
-                if (act) {
-                    RngKey ka = akey0;                                         // the action of step s: the policy at call counter t0 + s
-                    const uint64_t tp = ta0 + (uint64_t)s - 1ull;
-                    ka.t_lo = (uint32_t)tp; ka.t_hi = (uint32_t)(tp >> 32);
-                    const int a = synthetic_action(ka, lane, n_act);
-                    int o, r, d;
-                    Env::step(sh, p, b, a, key0, 0u, o, r, d);
-                    const int64_t at = (int64_t)s * rec + (int64_t)col;
-                    st_stream(ob + at, (int32_t)o);
-                    st_stream(reward + at, (int32_t)r);
-                    st_stream(done + at, (uint8_t)d);
-                    if (d) nps = s;
-                }
-            }
-            if (mine) {
-                uint32_t *res = res_lds[wv][me];
-                res[0] = (uint32_t)nps;
-#pragma unroll
-                for (int w = 0; w < MW; ++w) { res[1 + w] = b.occ.word(w); res[1 + MW + w] = b.vis.word(w); }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (ps[j] < k_steps && rank[j] >= base && rank[j] < base + 64) {
-                    const uint32_t *res = res_lds[wv][rank[j] - base];
-                    ps[j] = (int)res[0];
-                    if (ps[j] == k_steps) {
-#pragma unroll
-                        for (int w = 0; w < MW; ++w) { st[j].occ.set_word(w, res[1 + w]); st[j].vis.set_word(w, res[1 + MW + w]); }
-                    }
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < MW; ++q) {
-        st_stream4(state + (int64_t)q * n + l0, st[0].occ.word(q), st[1].occ.word(q), st[2].occ.word(q), st[3].occ.word(q));
-        st_stream4(state + (int64_t)(MW + q) * n + l0, st[0].vis.word(q), st[1].vis.word(q), st[2].vis.word(q), st[3].vis.word(q));
-    }
-}
-
 // The generic fused loop with a quad per thread, for envs whose lane step is light enough that four of them fit a thread
 // (Env::QUAD_FUSED; one state word): the policy's ACTION block is the thread's own, Env::step / Env::reset_where run per
 // lane as in steps_kernel, the outputs leave as 16-byte stores.  Full workgroups of 1024 lanes, auto-reset.  Only for envs
@@ -1736,10 +1568,9 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_generic_kernel(uint32_t *__r
 // POMDP_QUAD_MIN_LANES overrides all three at build time for same-box A/B runs (tools/ab_build.sh lib ... -D...).
 #ifdef POMDP_QUAD_MIN_LANES
 constexpr int64_t QUAD_MIN_ROCK = POMDP_QUAD_MIN_LANES, QUAD_MIN_TAG = POMDP_QUAD_MIN_LANES, QUAD_MIN_GENERIC = POMDP_QUAD_MIN_LANES,
-                  QUAD_MIN_NETWORK = POMDP_QUAD_MIN_LANES, QUAD_MIN_BATTLESHIP = POMDP_QUAD_MIN_LANES;
+                  QUAD_MIN_NETWORK = POMDP_QUAD_MIN_LANES;
 #else
-constexpr int64_t QUAD_MIN_ROCK = 1 << 19, QUAD_MIN_TAG = 1 << 20, QUAD_MIN_GENERIC = 1 << 18, QUAD_MIN_NETWORK = 1 << 19,
-                  QUAD_MIN_BATTLESHIP = 1 << 19;
+constexpr int64_t QUAD_MIN_ROCK = 1 << 19, QUAD_MIN_TAG = 1 << 20, QUAD_MIN_GENERIC = 1 << 18, QUAD_MIN_NETWORK = 1 << 19;
 #endif
 
 // which kernel the calling thread's most recent fused launch picked (pomdp_last_fused_kernel: bench.py names the kernel
@@ -1788,16 +1619,6 @@ static int launch_steps_fused(const typename Env::Params &p, uint32_t *state, in
             note_fused("tag_steps_quad_kernel", "", "");
             hipLaunchKernelGGL(tag_steps_quad_kernel, qgrid, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob, reward,
                                done, n, make_key(seed, t), lane0, make_key(action_seed, t + 1), k, rec, gf, p);
-            launched = true;
-        }
-    }
-    if constexpr (deferred_resets<Env>::value) {
-        if (quad_ok && n >= QUAD_MIN_BATTLESHIP && k <= 64) {
-            // (one launch for the whole shard: splitting it into launches of 2^19 or 2^18 lanes was measured at 7.45 / 8.95 us per
-            // step of 2^20 lanes against 5.55 — every launch pays its own phase-2 chain)
-            note_fused("battleship_steps_quad_kernel", Env::NAME, "");
-            hipLaunchKernelGGL(battleship_steps_quad_kernel<Env::WORDS / 2>, qgrid, dim3(BLOCK), 0, (hipStream_t)stream, state, action,
-                               ob, reward, done, n, make_key(seed, t), lane0, make_key(action_seed, t + 1), k, rec, gf, 0u, p);
             launched = true;
         }
     }

@@ -385,7 +385,11 @@ class BatchedEnv(object):
         """`steps` consecutive steps under the env's own heuristic policy, one launch each
         (pomdp_heuristic_steps): a = choice(_generate_preferred(history)); step(a); side statistics;
         history.append(Transition(observation, a, reward, ob, done)) — the loop of rock.py:557-573 for every lane,
-        with the results of that call sequence.  Returns the last step's (action, ob, reward, done) in reusable
+        with the results of that call sequence.  (The reference's own loop builds `Transition(ob, action, next_ob, rw,
+        done)` POSITIONALLY into the fields (observation, action, reward, next_observation, done), rock.py:566 — its
+        `next_observation` therefore holds the reward and `_generate_preferred`'s history sums never fire there.  This
+        path, like the fixtures' harness, fills the fields by name, i.e. the intended order; DESIGN.md §3 lists it among
+        the deliberate divergences.)  Returns the last step's (action, ob, reward, done) in reusable
         buffers; `history.prev_ob` holds the observation each lane sees afterwards.  `returns`
         (gym_pomdp_amd.Returns) accumulates the loop's discounted return per lane.  Asynchronous."""
         if not self._has_reset:

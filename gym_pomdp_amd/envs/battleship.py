@@ -39,14 +39,18 @@ class BattleShipEnv(BatchedEnv):
 
     def __init__(self, board_size=(5, 5), max_len=3, **batch_kwargs):
         self.board_size = tuple(board_size)
-        self.max_len = max_len
+        self._max_len = max_len                  # the ctor argument: ships of length max_len .. 2
+        # the reference's attributes of the same names hold other values (battleship.py:74-75: `self.max_len = max_len + 1`,
+        # the exclusive end of `range(2, self.max_len)`, and `self.total_remaining = max_len - 1`, which reset() overwrites)
+        self.max_len = max_len + 1
+        self.total_remaining = max_len - 1
         self.num_obs = 2
         self._reward_range = (self.board_size[0] * self.board_size[1]) / 4.   # battleship.py:72
         self._discount = 1.                                                   # battleship.py:73
         self._setup(**batch_kwargs)
 
     def _build_params(self):
-        return make_params(self.board_size, self.max_len)
+        return make_params(self.board_size, self._max_len)
 
     def decode_state(self):
         """int64 [N, 1 + 2*cells] = [total_remaining, occupied_0.., visited_0..], cell a = y*X + x."""

@@ -27,7 +27,7 @@ FULL = [("rock", {}, 1 << 20, 70), ("rock", dict(board_size=15, num_rocks=15), 1
         ("tag", {}, 1 << 17, 66), ("tiger", {}, 1 << 17, 66), ("network", {}, 1 << 17, 66), ("network", {}, 1 << 19, 66),
         # Network's quad-per-thread loop with streams that run past their first block on most lanes
         ("network", dict(n_machines=16, problem_type=1), 1 << 19, 40), ("network", dict(n_machines=31, problem_type=3), 1 << 19, 40),
-        # BattleShip's deferred-reset loop on boards whose episodes are short (several rounds of paused lanes per launch)
+        # BattleShip on boards whose episodes are short (resets in most waves at every step)
         ("battleship", {}, 1 << 19, 130), ("battleship", dict(board_size=(8, 6), max_len=4), 1 << 19, 70),
         ("battleship", dict(board_size=(10, 10), max_len=5), 1 << 20, 20)]
 
@@ -63,7 +63,7 @@ def test_collected_rows_equal_the_oracle(oracle_lib, env, kw, n, steps):
 
 @pytest.mark.parametrize("env,kw,n", [("rock", {}, 1 << 20), ("tag", {}, 1 << 20), ("network", {}, 1 << 18), ("network", {}, 1 << 19),
                                       ("battleship", {}, 1 << 19)],
-                         ids=["rock", "tag", "network", "network-quad", "battleship-deferred"])
+                         ids=["rock", "tag", "network", "network-quad", "battleship"])
 def test_fused_overwrite_mode_equals_the_oracle(oracle_lib, env, kw, n):
     """rollout_synthetic(fuse=True) (bench.py --collect 0): after k fused steps the N-element outputs hold the LAST step's
     results and `actions` the following call counter's — against the oracle."""
