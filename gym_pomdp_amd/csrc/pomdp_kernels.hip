@@ -1962,6 +1962,14 @@ int pomdp_step(const pomdp_step_args *a, const int32_t *action, uint64_t t, void
     }
 }
 
+int pomdp_step_sync(const pomdp_step_args *a, const int32_t *action, uint64_t t, void *stream)
+{
+    const int rc = pomdp_step(a, action, t, stream);
+    return rc ? rc : (int)hipStreamSynchronize((hipStream_t)stream);
+}
+
+int pomdp_stream_sync(void *stream) { return (int)hipStreamSynchronize((hipStream_t)stream); }
+
 int pomdp_synthetic_actions(int32_t *action, int64_t n, uint64_t seed, uint32_t lane0, uint64_t t, uint32_t n_actions,
                             void *stream)
 {

@@ -108,6 +108,13 @@ class BatchedEnv(object):
             done=self._ptrs[3], err=self._ptrs[4], n=n, seed=self._seed, lane0=self.lane_offset, reserved=0)
         self._step_args_ref = C.byref(self._step_args)
         self._bound_step = self._lib.pomdp_step
+        if n == 1:                       # scalar mode: the same call with ob / reward / done in pinned host memory
+            self._scalar_args = _native.StepArgs(
+                env=self._step_args.env, flags=self._step_args.flags, params=C.addressof(self._params), state=self._ptrs[0],
+                ob=self._host_ptrs[0], reward=self._host_ptrs[1], done=self._host_ptrs[2], err=self._ptrs[4], n=1,
+                seed=self._seed, lane0=self.lane_offset, reserved=0)
+            self._scalar_args_ref = C.byref(self._scalar_args)
+            self._bound_step_sync = self._lib.pomdp_step_sync
         self._action_shape = torch.Size((n,))
         self._dev_index = self.device.index
         self._info = {"state": self._state}
@@ -120,6 +127,8 @@ class BatchedEnv(object):
     def auto_reset(self, value):
         self._auto_reset = bool(value)
         self._step_args.flags = _native.POMDP_AUTO_RESET if self._auto_reset else 0
+        if self.batch_size == 1:
+            self._scalar_args.flags = self._step_args.flags
 
     # ---- gym.Env surface --------------------------------------------------------
     def seed(self, seed=None):
@@ -127,6 +136,8 @@ class BatchedEnv(object):
         Philox key of this env's lanes; the call counter restarts."""
         self._seed = _random_seed() if seed is None else int(seed) & 0xFFFFFFFFFFFFFFFF
         self._step_args.seed = self._seed
+        if self.batch_size == 1:
+            self._scalar_args.seed = self._seed
         self._t = 0
         return [self._seed]
 
@@ -147,6 +158,18 @@ class BatchedEnv(object):
         """All lanes start a new episode.  Returns ob: int32[N] tensor (python int if batch_size == 1)."""
         t = self._t
         self._t += 1
+        if self.batch_size == 1 and torch._C._cuda_getDevice() == self._dev_index:
+            # scalar mode: the observation goes straight to pinned host memory; launch, wait, read
+            stream = torch._C._cuda_getCurrentRawStream(self._dev_index)
+            rc = self._reset_fn(self._params_ref, self._ptrs[0], self._host_ptrs[0], 1, self._seed, self.lane_offset, t, stream)
+            _native.check(rc or self._lib.pomdp_stream_sync(stream), "pomdp_%s_reset" % self.env_name)
+            self._host_out[2] = 0
+            if self._tracker is not None:
+                self._tracker.on_reset()
+            ob = int(self._host_np[0])
+            self._has_reset, self._scalar_done, self.done = True, False, False
+            self._last_reset = (ob, t)
+            return ob
         with torch.cuda.device(self.device):
             ob = self._ob if self.reuse_buffers else torch.empty_like(self._ob)
             rc = self._reset_fn(self._params_ref, self._state.data_ptr(), ob.data_ptr(), self.batch_size,
@@ -211,31 +234,31 @@ class BatchedEnv(object):
         return ob, reward, self.done, self._info
 
     def _scalar_step(self, action):
-        """batch_size == 1: one launch writing into pinned host memory, one stream synchronisation, python scalars out."""
+        """batch_size == 1: one launch writing into pinned host memory and one stream synchronisation — both inside ONE
+        FFI call (pomdp_step_sync) — python scalars out."""
         t = self._t
         self._t = t + 1
-        flags = _native.POMDP_AUTO_RESET if self.auto_reset else 0
-        if torch.cuda.current_device() != self.device.index:
+        if self._tracker is None and torch._C._cuda_getDevice() == self._dev_index:
+            rc = self._bound_step_sync(self._scalar_args_ref, self._action_base + 4 * action, t,
+                                       torch._C._cuda_getCurrentRawStream(self._dev_index))
+            if rc:
+                _native.check(rc, "pomdp_%s_step" % self.env_name)
+        else:
             with torch.cuda.device(self.device):
-                return self._scalar_launch(action, t, flags)
-        return self._scalar_launch(action, t, flags)
-
-    def _scalar_launch(self, action, t, flags):
-        stream = torch.cuda.current_stream(self.device)
-        ptrs, hp = self._ptrs, self._host_ptrs
-        rc = self._step_fn(self._params_ref, ptrs[0], self._action_base + 4 * action, hp[0], hp[1], hp[2], ptrs[4], 1,
-                           self._seed, self.lane_offset, t, flags, stream.cuda_stream)
-        if rc:
-            _native.check(rc, "pomdp_%s_step" % self.env_name)
-        if self._tracker is not None:
-            self._tracker.on_step(self._action_table[action:action + 1], self._host_ob_t, self._host_done_t, flags)
-        stream.synchronize()
+                stream = torch.cuda.current_stream(self.device)
+                rc = self._bound_step(self._scalar_args_ref, self._action_base + 4 * action, t, stream.cuda_stream)
+                if rc:
+                    _native.check(rc, "pomdp_%s_step" % self.env_name)
+                if self._tracker is not None:
+                    self._tracker.on_step(self._action_table[action:action + 1], self._host_ob_t, self._host_done_t,
+                                          self._scalar_args.flags)
+                stream.synchronize()
         h = self._host_np
         d = bool(h[2] & 0xFF)
         self._scalar_done = d
         self.done = d
         r = self._host_reward_np[0]
-        return int(h[0]), (int(r) if self.reward_dtype == torch.int32 else float(r)), d, {"state": self._state}
+        return int(h[0]), (int(r) if self.reward_dtype == torch.int32 else float(r)), d, self._info
 
     def _as_action_tensor(self, action):
         if isinstance(action, torch.Tensor):

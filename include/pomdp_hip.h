@@ -13,7 +13,7 @@
  *
  * Conventions
  *   - every pointer marked "device" is HBM the caller owns (e.g. a torch tensor's
- *     data_ptr()); the library never allocates, frees or synchronises;
+ *     data_ptr()); the library never allocates or frees, and never synchronises (pomdp_step_sync, which exists to do so, aside);
  *   - `state` is struct-of-arrays: uint32 [words][n], word-major, lane i at state[w*n + i];
  *   - params structs are read on the host at call time and passed to the kernel
  *     by value (kernarg) — they may live on the caller's stack;
@@ -183,6 +183,12 @@ typedef struct pomdp_step_args {
     uint32_t  reserved;
 } pomdp_step_args;
 int pomdp_step(const pomdp_step_args *args, const int32_t *action, uint64_t t, void *stream);
+/* pomdp_step followed by hipStreamSynchronize(stream) — the ONE entry point of this library that blocks.  For hosts that
+ * step a single env the way the reference is used (python scalars in and out, batch of 1, ob / reward / done pointing at
+ * pinned host memory): launch and wait cost one FFI call instead of two plus a stream object. */
+int pomdp_step_sync(const pomdp_step_args *args, const int32_t *action, uint64_t t, void *stream);
+/* hipStreamSynchronize(stream) by itself, for the same hosts (after a pomdp_<env>_reset whose `ob` points at host memory) */
+int pomdp_stream_sync(void *stream);
 
 /* ---- helpers ---------------------------------------------------------------- */
 /* synthetic uniform random policy used by bench.py: lanes 4q..4q+3 share the Philox block
