@@ -173,6 +173,51 @@ struct TagEnv {
         f.list = list; f.oi = oi;
         f.need = tag && !colocated && no > 0;
     }
+    // ---- the same from a (agent cell, opponent cell, action) -> outcome table --------------------------------------------
+    // Everything step_one_opponent_pre derives from the two cells and the action — where a move leads, what the agent then
+    // sees, whether a TAG finds the opponent, the admissible-move list of its flight — is one 32-bit entry of a table the
+    // workgroup builds in LDS when a multi-step launch starts (tag_steps_quad_kernel), indexed [action][opponent << 5 | agent]
+    // (the low ten bits of the state word as they are): one lookup instead of three dependent ones plus the sign / list
+    // arithmetic.
+    //   a <  4: bits 0-4 the agent's cell after the move, bits 14-19 the observation (obs_cells where it now stands on the
+    //           opponent, else its cell)
+    //   a == 4: bits 5-12 the admissible-move list of the opponent's flight, bit 13 co-located (the TAG succeeds)
+    struct StepTab { uint32_t e[5][1024]; };
+    static __host__ __device__ __forceinline__ bool tab_ok(const Params &p) { return p.num_opponents == 1 && (unsigned)p.obs_cells < 64u; }
+    static __device__ __forceinline__ void build_tab(StepTab &tab, const Shared &sh, const Params &p, int tid)
+    {
+        for (int slot = tid; slot < 1024; slot += 256) {
+            const int agent = min(slot & 31, 28), oi = min(slot >> 5, 28);      // cells >= 29 do not occur: any value will do
+            const int axy = sh.xy[agent], oxy = sh.xy[oi];
+            const int dx = (oxy & 15) - (axy & 15), dy = (oxy >> 4) - (axy >> 4);
+            const int k = 3 * (min(max(dx, -1), 1) + 1) + min(max(dy, -1), 1) + 1;
+            const uint32_t list = k == 8 ? ADMISSIBLE_8 : (uint32_t)(ADMISSIBLE_LO >> (8 * (k & 7))) & 0xFFu;
+            tab.e[4][slot] = (list << 5) | ((uint32_t)(oi == agent) << 13);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const uint32_t to = sh.mv[4 * agent + a];
+                tab.e[a][slot] = to | ((to == (uint32_t)oi ? (uint32_t)p.obs_cells : to) << 14);
+            }
+        }
+    }
+    template <class RT>
+    static __device__ __forceinline__ void step_one_opponent_tab(const StepTab &tab, State &st, int a, int &ob, RT &rew, int &done,
+                                                                 Flight &f)
+    {
+        const uint32_t w = st.w;
+        const uint32_t e = tab.e[a][w & 1023u];
+        const int no = num_opp(w);
+        const bool tag = a == 4, colocated = (e >> 13) & 1u;
+        const uint32_t w_tag = with_num_opp(w, no - (int)colocated);
+        const uint32_t wn = tag ? w_tag : ((w & ~31u) | (e & 31u));
+        rew = tag ? (colocated ? 10.f : -10.f) : -1.f;
+        ob = tag ? (int)(w & 31u) : (int)((e >> 14) & 63u);                   // tag.py:219-226
+        done = num_opp(wn) == 0;
+        st.w = wn;
+        f.list = (e >> 5) & 0xFFu; f.oi = (int)((w >> 5) & 31u);
+        f.need = tag && !colocated && no > 0;
+    }
+
     // the opponent's flight from words 0-2 of the lane's STEP block (tag.py:201-207)
     static __device__ __forceinline__ void flee(const Shared &sh, const Params &p, State &st, const Flight &f, uint32_t w0,
                                                 uint32_t w1, uint32_t w2)

@@ -1213,6 +1213,7 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
 // Tag (one opponent) with a quad per thread: the policy's ACTION block is the thread's own, the flights of failed TAGs
 // (about a fifth of the lanes) and the rare resets are pooled per wave of 256 lanes — one Philox pass instead of the two per
 // 256 lanes that Finisher<TagEnv, 2> needs with the policy blocks in its task list — and the outputs leave as 16-byte stores.
+template <bool TAB>   // TAB: the lane step reads the (cells, action) table built when the launch starts (from 16 steps per launch)
 __global__ __launch_bounds__(BLOCK) void tag_steps_quad_kernel(uint32_t *__restrict__ state, int32_t *__restrict__ action,
                                                                int32_t *__restrict__ ob, float *__restrict__ reward,
                                                                uint8_t *__restrict__ done, int64_t n, RngKey key0,
@@ -1221,6 +1222,7 @@ __global__ __launch_bounds__(BLOCK) void tag_steps_quad_kernel(uint32_t *__restr
 {
     using Env = TagEnv;
     __shared__ Env::Shared sh;
+    __shared__ typename std::conditional<TAB, Env::StepTab, NoTab>::type tab;
     __shared__ uint8_t src_lds[BLOCK / 64][256];             // task rank -> lane within the wave's 256
     __shared__ uint32_t res_lds[BLOCK / 64][256][4];         // task rank -> its Philox block
     const int wv = (int)(threadIdx.x >> 6), me = (int)(threadIdx.x & 63u);
@@ -1241,6 +1243,10 @@ __global__ __launch_bounds__(BLOCK) void tag_steps_quad_kernel(uint32_t *__restr
     action_w += rec;
     Env::stage(sh, p, (int)threadIdx.x);
     __syncthreads();
+    if constexpr (TAB) {
+        Env::build_tab(tab, sh, p, (int)threadIdx.x);
+        __syncthreads();
+    }
     const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo, ta0 = ((uint64_t)akey0.t_hi << 32) | akey0.t_lo;
     for (int s = 0; s < k_steps; ++s) {
         RngKey key = key0;
@@ -1255,7 +1261,8 @@ __global__ __launch_bounds__(BLOCK) void tag_steps_quad_kernel(uint32_t *__restr
         int nfl = 0, nrs = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            Env::step_one_opponent_pre(sh, p, st[j], a_cur[j], o[j], r[j], d[j], f[j]);
+            if constexpr (TAB) Env::step_one_opponent_tab(tab, st[j], a_cur[j], o[j], r[j], d[j], f[j]);
+            else Env::step_one_opponent_pre(sh, p, st[j], a_cur[j], o[j], r[j], d[j], f[j]);
             fm[j] = __ballot(f[j].need);
             rm[j] = __ballot(d[j] != 0);
             nfl += __popcll(fm[j]);
@@ -1616,9 +1623,15 @@ static int launch_steps_fused(const typename Env::Params &p, uint32_t *state, in
     bool launched = false;
     if constexpr (std::is_same<Env, TagEnv>::value) {
         if (quad_ok && n >= QUAD_MIN_TAG && p.num_opponents == 1) {
-            note_fused("tag_steps_quad_kernel", "", "");
-            hipLaunchKernelGGL(tag_steps_quad_kernel, qgrid, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob, reward,
-                               done, n, make_key(seed, t), lane0, make_key(action_seed, t + 1), k, rec, gf, p);
+            if (k >= 16 && TagEnv::tab_ok(p)) {
+                note_fused("tag_steps_quad_kernel", "true", "");
+                hipLaunchKernelGGL(tag_steps_quad_kernel<true>, qgrid, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob, reward,
+                                   done, n, make_key(seed, t), lane0, make_key(action_seed, t + 1), k, rec, gf, p);
+            } else {
+                note_fused("tag_steps_quad_kernel", "false", "");
+                hipLaunchKernelGGL(tag_steps_quad_kernel<false>, qgrid, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob, reward,
+                                   done, n, make_key(seed, t), lane0, make_key(action_seed, t + 1), k, rec, gf, p);
+            }
             launched = true;
         }
     }
