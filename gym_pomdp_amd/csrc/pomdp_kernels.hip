@@ -1568,16 +1568,17 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_generic_kernel(uint32_t *__r
 }
 
 // Smallest batch each quad-per-thread loop takes (1024 lanes per workgroup).  Measured on MI355X, us per fused step at
-// 2^17 / 2^18 / 2^19 / 2^20 lanes (profiles/r02_small_shards.txt): RockSample(7,8) quad 1.50 / 1.52 / 1.82 / 2.89 against
-// 1.25 / 1.39 / 1.99 with one or two lanes per thread; Tag 1.91 / 1.90 / 2.11 / 3.12 against 0.97 / 1.43 / 2.00; Tiger
-// 0.67 / 0.72 / 1.26 / 2.82 against 0.55 / 0.83 / 1.52 — below these sizes every kernel is bound by the latency of one
-// wave's step (1.1-1.5 us), and more, lighter waves hide it better than fewer, heavier ones.
-// POMDP_QUAD_MIN_LANES overrides all three at build time for same-box A/B runs (tools/ab_build.sh lib ... -D...).
+// 2^17 / 2^18 / 2^19 / 2^20 lanes (profiles/r02_small_shards_gates.txt, r02b_small_shards.txt): RockSample(7,8) quad 1.50 /
+// 1.52 / 1.82 / 2.89 against 1.25 / 1.39 / 1.99 with one or two lanes per thread; Tag (table-driven) 1.59 / 1.61 / 1.83 /
+// 2.67 against 0.96 / 1.43 / 2.00; Tiger 0.67 / 0.72 / 1.26 / 2.82 against 0.55 / 0.83 / 1.52; Network 2.30 / 2.30 / 2.91 /
+// 4.72 against 2.01 / 2.67 / 4.53 — below these sizes every kernel is bound by the latency of one wave's step
+// (1.1-2.3 us), and more, lighter waves hide it better than fewer, heavier ones.
+// POMDP_QUAD_MIN_LANES overrides all of them at build time for same-box A/B runs (tools/ab_build.sh lib ... -D...).
 #ifdef POMDP_QUAD_MIN_LANES
 constexpr int64_t QUAD_MIN_ROCK = POMDP_QUAD_MIN_LANES, QUAD_MIN_TAG = POMDP_QUAD_MIN_LANES, QUAD_MIN_GENERIC = POMDP_QUAD_MIN_LANES,
                   QUAD_MIN_NETWORK = POMDP_QUAD_MIN_LANES;
 #else
-constexpr int64_t QUAD_MIN_ROCK = 1 << 19, QUAD_MIN_TAG = 1 << 20, QUAD_MIN_GENERIC = 1 << 18, QUAD_MIN_NETWORK = 1 << 19;
+constexpr int64_t QUAD_MIN_ROCK = 1 << 19, QUAD_MIN_TAG = 1 << 19, QUAD_MIN_GENERIC = 1 << 18, QUAD_MIN_NETWORK = 1 << 18;
 #endif
 
 // which kernel the calling thread's most recent fused launch picked (pomdp_last_fused_kernel: bench.py names the kernel

@@ -24,7 +24,8 @@ FULL = [("rock", {}, 1 << 20, 70), ("rock", dict(board_size=15, num_rocks=15), 1
         ("stochrock", {}, 1 << 18, 70), ("battleship", {}, 1 << 18, 70),
         # the shards a 2^20-lane batch leaves per GPU at 2, 4 and 8 GPUs
         ("rock", {}, 1 << 19, 66), ("rock", {}, 1 << 18, 66), ("rock", {}, 1 << 17, 66),
-        ("tag", {}, 1 << 17, 66), ("tiger", {}, 1 << 17, 66), ("network", {}, 1 << 17, 66), ("network", {}, 1 << 19, 66),
+        ("tag", {}, 1 << 17, 66), ("tag", {}, 1 << 19, 66), ("tiger", {}, 1 << 17, 66), ("tiger", {}, 1 << 18, 66),
+        ("network", {}, 1 << 17, 66), ("network", {}, 1 << 18, 66), ("network", {}, 1 << 19, 66),
         # Network's quad-per-thread loop with streams that run past their first block on most lanes
         ("network", dict(n_machines=16, problem_type=1), 1 << 19, 40), ("network", dict(n_machines=31, problem_type=3), 1 << 19, 40),
         # BattleShip on boards whose episodes are short (resets in most waves at every step)
