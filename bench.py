@@ -19,7 +19,7 @@ also carries `strong_scaling`: the same K steps on a batch of --lanes-per-gpu la
 
 Timing protocol: for each master seed in --seeds (default 0,1,2) the env is re-seeded and reset, W
 warm-up steps run, and the region "barrier, sync, K steps, sync" is timed R times (R = --repeats, default 31 for
-K < 2048 else 5; even regions by wall clock, odd ones by HIP events for the kernel time); every wall-clock region is
+K < 1000 else 7; even regions by wall clock, odd ones by HIP events for the kernel time); every wall-clock region is
 max-reduced over the ranks; a seed's figure is the median of its regions and the
 line's `value` / `ms_per_step` the median over the seeds (config.seed_values has all of them and the min / max).
 Every buffer the timed steps write is allocated, and touched by the same chunking of K, before the first timed
@@ -66,8 +66,8 @@ ORACLE_NAME = {"rock": "rock", "rock15": "rock", "stochrock": "stochrock", "tag"
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2048)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000, help="timed steps per region (SURVEY.md §8d: T = 1000 after 10 warm-up steps)")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--env", default="rock", choices=sorted(WORKLOADS))
     ap.add_argument("--lanes-per-gpu", type=int, default=1 << 20)
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -77,7 +77,7 @@ def parse():
     ap.add_argument("--seed", type=int, default=None, help="a single master seed (shorthand for --seeds S)")
     ap.add_argument("--seeds", default="0,1,2", help="master seeds of the timing protocol (SURVEY.md §8d: 0, then 1 and 2)")
     ap.add_argument("--repeats", type=int, default=0,
-                    help="timed regions of K steps per seed (median reported); 0 = 31 if K < 2048 else 5")
+                    help="timed regions of K steps per seed (median reported); 0 = 31 if K < 1000 else 7")
     ap.add_argument("--host-loop", default="c", choices=["c", "python"],
                     help="who issues the two launches of a step: the C rollout driver or a python loop over env.step()")
     ap.add_argument("--mode", default="step", choices=["step", "rollout", "heuristic"],
@@ -381,7 +381,7 @@ class StepWorkload(object):
     def measure(self, seeds, cp):
         """The §8d protocol.  -> (per-seed [(seed, median wall s, min, max, median event ms)])."""
         args, k = self.args, self.args.steps
-        repeats = args.repeats or (31 if k < 2048 else 5)
+        repeats = args.repeats or (31 if k < 1000 else 7)
         rows = []
         for i, seed in enumerate(seeds):
             self.reseed(seed)
