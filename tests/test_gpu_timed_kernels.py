@@ -30,7 +30,10 @@ FULL = [("rock", {}, 1 << 20, 70), ("rock", dict(board_size=15, num_rocks=15), 1
         ("network", dict(n_machines=16, problem_type=1), 1 << 19, 40), ("network", dict(n_machines=31, problem_type=3), 1 << 19, 40),
         # BattleShip on boards whose episodes are short (resets in most waves at every step)
         ("battleship", {}, 1 << 19, 130), ("battleship", dict(board_size=(8, 6), max_len=4), 1 << 19, 70),
-        ("battleship", dict(board_size=(10, 10), max_len=5), 1 << 20, 20)]
+        ("battleship", dict(board_size=(10, 10), max_len=5), 1 << 20, 20),
+        # batches that are not a multiple of 4 (the last shard of an odd total): ragged last workgroup, scalar tail of the first actions
+        ("rock", {}, 4099, 70), ("tag", {}, (1 << 18) + 5, 20), ("network", {}, 777, 70), ("tiger", {}, 3, 70),
+        ("battleship", {}, 259, 70)]
 
 
 @pytest.mark.parametrize("env,kw,n,steps", FULL, ids=["%s%s-%d" % (c[0], "-".join(str(v) for v in c[1].values()), c[2]) for c in FULL])
