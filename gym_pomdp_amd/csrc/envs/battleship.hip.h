@@ -129,6 +129,17 @@ struct BattleShipEnv {
         return (u128)(w0 | ((uint64_t)w1 << 32)) | ((u128)(w2 | ((uint64_t)w3 << 32)) << 64);
     }
     static __device__ __forceinline__ u128 u128_of(const uint32_t (&w)[4]) { return u128_of4(w[0], w[1], w[2], w[3]); }
+    // 128-bit shifts by 1 <= s <= 63 (a board is at most 16 wide): the general form selects between three cases
+    static __device__ __forceinline__ u128 shl_small(u128 a, int s)
+    {
+        const uint64_t lo = (uint64_t)a, hi = (uint64_t)(a >> 64);
+        return (u128)(lo << s) | ((u128)((hi << s) | (lo >> (64 - s))) << 64);
+    }
+    static __device__ __forceinline__ u128 shr_small(u128 a, int s)
+    {
+        const uint64_t lo = (uint64_t)a, hi = (uint64_t)(a >> 64);
+        return (u128)((lo >> s) | (hi << (64 - s))) | ((u128)(hi >> s) << 64);
+    }
     static __device__ __forceinline__ uint64_t direction_words(uint64_t a)
     {
         const uint64_t even = 0x5555555555555555ull;
@@ -144,6 +155,8 @@ struct BattleShipEnv {
         if (todo == 0ull) return;                                            // wave-uniform
         const int me = (int)(threadIdx.x & 63u);
         const int X = p.x_size, Y = p.y_size, cells = X * Y;
+        __builtin_assume(X >= 1 && X <= 16 && Y >= 1 && Y <= 16);          // bs_mask_words(): what the launchers let through —
+        __builtin_assume(p.max_len >= 2 && p.max_len <= 10);                // 128-bit shifts by X or by a ship length stay below 64
         const uint32_t rmask = 0xFFFFFFFFu >> __clz((uint32_t)(cells - 1) | 1u); // randint(cells) bit-smear mask
         const u128 col0 = u128_of(p.col0), colL = col0 << (X - 1);
         const uint32_t inv_x = (65536u + (uint32_t)X - 1u) / (uint32_t)X;   // a / X == (a * inv_x) >> 16 for a < 128, X <= 16
@@ -160,11 +173,12 @@ struct BattleShipEnv {
             u128 occ = 0;
             int remaining = 0;
             for (int len = p.max_len; len >= 2; --len) {
+                __builtin_assume(len <= 10);
                 // blocked = occ and its N, E, S, W, NE, SE, SW shifts (NW excluded) in four 128-bit shifts:
                 // h = {self, E, W}; south side = h << X (S, SE, SW); north side = {self, E} >> X (N, NE)
                 const u128 e1 = (occ & ~col0) >> 1, h = occ | e1 | ((occ & ~colL) << 1);
-                const u128 blocked = h | ((occ | e1) >> X) | (h << X);
-                const u128 hpat = ((u128)1 << (len + 1)) - 1;                 // the L+1 checked cells, from bit 0
+                const u128 blocked = h | shr_small(occ | e1, X) | shl_small(h, X);
+                const u128 hpat = (u128)((1ull << (len + 1)) - 1ull);         // the L+1 checked cells, from bit 0 (L + 1 <= 11)
                 const u128 vpat = u128_of(p.vpat[len + 1]);
                 for (;;) {
                     if (c - c0 > 32) {                                        // wave-uniform: refill the window at the cursor
@@ -196,7 +210,7 @@ struct BattleShipEnv {
                         const int a0w = __builtin_amdgcn_readlane(a0, r), sw = __builtin_amdgcn_readlane(stride, r);
                         // mark_ship: L cells from pos = the L-cell pattern shifted to its lowest cell
                         const int low = sw > 0 ? a0w : a0w + (len - 1) * sw;
-                        occ |= ((sw == 1 || sw == -1) ? (((u128)1 << len) - 1) : u128_of(p.vpat[len])) << low;
+                        occ |= ((sw == 1 || sw == -1) ? (u128)((1ull << len) - 1ull) : u128_of(p.vpat[len])) << low;
                         remaining += len;
                         c += r + 2;
                         break;
