@@ -88,7 +88,7 @@ def parse():
     ap.add_argument("--depth", type=int, default=64)
     ap.add_argument("--sims-per-root", type=int, default=1024)
     ap.add_argument("--action-seed", type=int, default=None, help="policy key (default: the env seed)")
-    ap.add_argument("--prewarm", type=float, default=0.5,
+    ap.add_argument("--prewarm", type=float, default=2.0,
                     help="seconds of untimed launches before the W warm-up steps: a GPU coming out of idle runs its first "
                          "~0.1-1 s below full clock (a compute-only kernel like the fused rollout is up to 1.4x slower there)")
     ap.add_argument("--fuse", type=int, default=1, choices=[0, 1],
