@@ -125,6 +125,10 @@ class BatchedEnv(object):
 
     @auto_reset.setter
     def auto_reset(self, value):
+        if self._auto_reset and not value and self.batch_size > 1:
+            # without auto-reset `done` is in/out (a set flag freezes the lane); what the buffer holds now are the flags the
+            # last auto-resetting step RETURNED, and those lanes have fresh episodes
+            self._done.zero_()
         self._auto_reset = bool(value)
         self._step_args.flags = _native.POMDP_AUTO_RESET if self._auto_reset else 0
         if self.batch_size == 1:

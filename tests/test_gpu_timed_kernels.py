@@ -217,3 +217,45 @@ def test_bench_self_launches_two_ranks_on_the_one_gpu():
     assert d["value"] > 1e8 and "cpu_baseline" not in d
     s = d["strong_scaling"]
     assert s["total_lanes"] == 1 << 20 and s["lanes_per_gpu"] == 1 << 19 and s["value"] > 1e8
+
+
+def test_launcher_picks_the_documented_kernel_per_shard_size():
+    """pomdp_last_fused_kernel() after a fused call: the quad-per-thread loops from the shard sizes DESIGN.md §5 lists
+    (RockSample 2^19, Tag 2^19, Tiger 2^18, Network 2^18), the one- / two-lanes-per-thread loops below, the generic loop
+    for BattleShip and StochasticRock, and the arithmetic lane step for launches shorter than 16 steps."""
+    from gym_pomdp_amd import _native
+    L = _native.lib()
+    want = [("rock", {}, 1 << 20, 64, "steps_quad_kernel<RockEnv<1>>"), ("rock", {}, 1 << 19, 64, "steps_quad_kernel<RockEnv<1>>"),
+            ("rock", {}, 1 << 18, 64, "steps_kernel<RockEnv<1>, 2, true>"), ("rock", {}, 1 << 17, 64, "steps_kernel<RockEnv<1>, 1, true>"),
+            ("rock", {}, 1 << 20, 5, "steps_kernel<RockEnv<1>, 4, true>"), ("rock", dict(board_size=15, num_rocks=15), 1 << 20, 64, "steps_quad_kernel<RockEnv<2>>"),
+            ("rock", {}, (1 << 19) + 4, 64, "steps_kernel<RockEnv<1>, 2, false>"),
+            ("tag", {}, 1 << 19, 64, "tag_steps_quad_kernel<true>"), ("tag", {}, 1 << 19, 8, "tag_steps_quad_kernel<false>"),
+            ("tag", {}, 1 << 18, 64, "steps_kernel<TagEnv, 2, true>"), ("tag", dict(num_opponents=2), 1 << 20, 64, "steps_kernel<TagEnv, 2, true>"),
+            ("tiger", {}, 1 << 18, 64, "steps_quad_generic_kernel<TigerEnv>"), ("tiger", {}, 1 << 17, 64, "steps_kernel<TigerEnv, 1, true>"),
+            ("network", {}, 1 << 18, 64, "network_steps_quad_kernel<>"), ("network", {}, 1 << 17, 64, "steps_kernel<NetworkEnv, 1, true>"),
+            ("battleship", {}, 1 << 19, 64, "steps_kernel<BattleShipEnv<1>, 1, true>"), ("stochrock", {}, 1 << 19, 64, "steps_kernel<StochasticRockEnv<1>, 1, true>")]
+    for env, kw, n, k, name in want:
+        e = make_env(env, kw, batch_size=n, seed=1, reuse_buffers=True)
+        e.reset()
+        e.collect_synthetic(k)
+        assert L.pomdp_last_fused_kernel().decode() == name, (env, kw, n, k, L.pomdp_last_fused_kernel())
+        del e
+
+
+def test_bound_argument_entry_points_equal_the_plain_ones():
+    """pomdp_step / pomdp_collect (arguments bound once in a struct) launch what pomdp_<env>_step / pomdp_collect_synthetic
+    launch: same outputs, same state — through the Python mirror's two paths (reuse_buffers=True takes the bound ones)."""
+    for env, kw in (("rock", {}), ("tag", {}), ("battleship", {}), ("tiger", {}), ("network", {})):
+        a = make_env(env, kw, batch_size=8192, seed=5, lane_offset=16, reuse_buffers=True)      # pomdp_step
+        b = make_env(env, kw, batch_size=8192, seed=5, lane_offset=16, reuse_buffers=False)     # pomdp_<env>_step
+        assert torch.equal(a.reset(), b.reset())
+        for _ in range(6):
+            act = b.synthetic_actions()
+            ra, rb = a.step(act), b.step(act)
+            assert all(torch.equal(x, y) for x, y in zip(ra[:3], rb[:3])) and torch.equal(a.state, b.state), env
+        a.auto_reset = False                      # the bound flags follow the attribute
+        b.auto_reset = False
+        for _ in range(4):
+            act = b.synthetic_actions()
+            ra, rb = a.step(act), b.step(act)
+            assert all(torch.equal(x, y) for x, y in zip(ra[:3], rb[:3])) and torch.equal(a.state, b.state), env
