@@ -30,6 +30,8 @@ struct RockEnv {
     static constexpr const char *NAME = STOCH ? (W == 1 ? "StochasticRockEnv<1>" : "StochasticRockEnv<2>") : (W == 1 ? "RockEnv<1>" : "RockEnv<2>");
     static constexpr bool POOLED_LPT2 = !STOCH;   // pomdp_kernels.hip: Finisher<RockEnv, 2, .>
     static constexpr bool POOLED_ANY_LPT = !STOCH; // ... and for any other number of lanes per thread >= 2
+    static constexpr bool STOCHASTIC = STOCH;
+    static constexpr bool QUAD_TAB = true;        // pomdp_kernels.hip: steps_quad_kernel (RockEnv and StochasticRockEnv)
     struct Shared {
         uint2 thr[32];         // sensor threshold by L1 distance: .x = thr >> 26 (compared with H >> 5),
                                // .y = thr & (2^26 - 1) (compared with L >> 6 on a tie) — one 8-byte LDS read
@@ -467,7 +469,6 @@ struct RockEnv {
     template <class RT>
     static __device__ __forceinline__ void step_tab(const StepTab &tab, State &st, int a, RT &rew, int &done, Aux &aux)
     {
-        static_assert(!STOCH, "table-driven step: RockEnv");
         const S s = st.s;
         const uint32_t e = tab.e[a][(uint32_t)s & 0xFFu];
         const bool is_move = a < 4, is_sample = a == 4;
@@ -486,9 +487,9 @@ struct RockEnv {
         const bool good_rock = code == 2u;
         int rw = (exit_east | (sampled & good_rock)) ? 10 : 0;
         rw = (sampled & !good_rock) ? -10 : rw;
-        rw = ((left & !exit_east) | missed) ? -100 : rw;
+        rw = ((left & !exit_east) | missed) ? (STOCH ? 0 : -100) : rw;          // rock.py:117 / rock.py:432
         rew = rw;
-        done = left | missed;
+        done = STOCH ? exit_east : (left | missed);                            // penalties never terminate there (rock.py:503)
     }
 
     // observation of a CHECK from the sensor's high word (rock.py:404-407); `lo` yields the low word on a tie

@@ -1166,15 +1166,32 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
         RngKey key = key0;
         key.t_lo = (uint32_t)(t0 + (uint64_t)s); key.t_hi = (uint32_t)((t0 + (uint64_t)s) >> 32);
         const uint64_t ta = ta0 + (uint64_t)s;
-        // the quad's sensor words of this step and its policy words of the next call counter
-        const uint4 sw = philox4x32_10(glane0 >> 2, key.t_lo, key.t_hi, (uint32_t)POMDP_STREAM_STEP << 24, key.k0, key.k1);
+        // the quad's sensor words of this step (StochasticRock: block 2 of the stream — block 0 gates the actions, rock.py:443)
+        // and its policy words of the next call counter
+        constexpr uint32_t SENSOR_BLOCK = Env::STOCHASTIC ? 2u : 0u;
+        const uint4 sw = philox4x32_10(glane0 >> 2, key.t_lo, key.t_hi, ((uint32_t)POMDP_STREAM_STEP << 24) | SENSOR_BLOCK, key.k0, key.k1);
         const uint4 pw = philox4x32_10(glane0 >> 2, (uint32_t)ta, (uint32_t)(ta >> 32), (uint32_t)POMDP_STREAM_ACTION << 24, key.k0, key.k1);
         const uint32_t H[4] = {sw.x, sw.y, sw.z, sw.w}, P[4] = {pw.x, pw.y, pw.z, pw.w};
+        bool acts[4] = {true, true, true, true};
+        if constexpr (Env::STOCHASTIC) {                                       // the action is applied iff binomial(1, p_move) says so
+            const uint4 gw = Env::quad_block(key, glane0, 0u);
+            const uint32_t G[4] = {gw.x, gw.y, gw.z, gw.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acts[j] = Env::k53_le(G[j], (uint32_t)(p.act_thr >> 26), (uint32_t)p.act_thr & Env::LO_MASK,
+                                      [&]() { return Env::elem(Env::quad_block(key, glane0, 1u), (uint32_t)j); });
+        }
         int r[4], d[4], rank[4], nres = 0;
         typename Env::Aux aux[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            Env::step_tab(tab, st[j], a_cur[j], r[j], d[j], aux[j]);
+            if constexpr (Env::STOCHASTIC) {
+                typename Env::State nx = st[j];
+                Env::step_tab(tab, nx, a_cur[j], r[j], d[j], aux[j]);
+                if (acts[j]) st[j] = nx; else { r[j] = 0; d[j] = 0; aux[j].want = false; }
+            } else {
+                Env::step_tab(tab, st[j], a_cur[j], r[j], d[j], aux[j]);
+            }
             const uint64_t m = __ballot(d[j] != 0);                            // done lanes start a new episode
             rank[j] = nres + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
             nres += __popcll(m);
@@ -1193,7 +1210,7 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
         for (int j = 0; j < 4; ++j) {
             if (d[j]) st[j].s = (S)((uint64_t)start | ((uint64_t)res_lds[wv][rank[j] & 255] << 8));
             const uint32_t lane = glane0 + (uint32_t)j;
-            o[j] = (uint32_t)Env::sensor_ob(sh, st[j], aux[j], H[j], [&]() { return Env::elem(Env::quad_block(key, lane, 1u), (uint32_t)j); });
+            o[j] = (uint32_t)Env::sensor_ob(sh, st[j], aux[j], H[j], [&]() { return Env::elem(Env::quad_block(key, lane, SENSOR_BLOCK + 1u), (uint32_t)j); });
             a_next[j] = __umulhi(P[j], n_act);
             a_cur[j] = (int)a_next[j];
         }
@@ -1505,6 +1522,8 @@ __global__ __launch_bounds__(BLOCK) void network_steps_quad_kernel(uint32_t *__r
 // (Env::QUAD_FUSED; one state word): the policy's ACTION block is the thread's own, Env::step / Env::reset_where run per
 // lane as in steps_kernel, the outputs leave as 16-byte stores.  Full workgroups of 1024 lanes, auto-reset.  Only for envs
 // whose reset_where does not assume that a wave's 64 lanes are consecutive (RockSample's cooperative reset does).
+template <class Env, class = void> struct quad_tab : std::false_type {};
+template <class Env> struct quad_tab<Env, std::enable_if_t<Env::QUAD_TAB>> : std::true_type {};
 template <class Env, class = void> struct quad_fused : std::false_type {};
 template <class Env> struct quad_fused<Env, std::enable_if_t<Env::QUAD_FUSED>> : std::true_type {};
 
@@ -1660,15 +1679,18 @@ static int launch_steps_fused(const typename Env::Params &p, uint32_t *state, in
             launched = true;
         }
     }
-    if constexpr (Env::POOLED_ANY_LPT) {
+    if constexpr (quad_tab<Env>::value) {
         // from 16 steps per launch on the lane step reads the (position, action) table the workgroup builds first and a
-        // thread owns a quad of consecutive lanes (steps_quad_kernel)
+        // thread owns a quad of consecutive lanes (steps_quad_kernel: RockSample and StochasticRock)
         if (quad_ok && n >= QUAD_MIN_ROCK && k >= 16 && p.num_rocks + 5 <= Env::TAB_ACTIONS) {
             note_fused("steps_quad_kernel", Env::NAME, "");
             hipLaunchKernelGGL((steps_quad_kernel<Env>), qgrid, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob, reward,
                                done, n, make_key(seed, t), lane0, make_key(action_seed, t + 1), k, rec, gf, p);
             launched = true;
-        } else if (lpt2 && (flags & POMDP_AUTO_RESET) && n % (4 * BLOCK) == 0 && n >= (1 << 20) && Env::WORDS == 1) {
+        }
+    }
+    if constexpr (Env::POOLED_ANY_LPT) {
+        if (!launched && lpt2 && (flags & POMDP_AUTO_RESET) && n % (4 * BLOCK) == 0 && n >= (1 << 20) && Env::WORDS == 1) {
             POMDP_LAUNCH_STEPS(4, true, qgrid);
             launched = true;
         }

@@ -21,7 +21,8 @@ pytestmark = pytest.mark.gpu
 FULL = [("rock", {}, 1 << 20, 70), ("rock", dict(board_size=15, num_rocks=15), 1 << 20, 70), ("tag", {}, 1 << 20, 70),
         ("tiger", {}, 1 << 20, 70), ("network", {}, 1 << 20, 70),
         ("battleship", dict(board_size=(10, 10), max_len=5), 1 << 19, 70),            # C4: 2^22 lanes over 8 GPUs
-        ("stochrock", {}, 1 << 18, 70), ("battleship", {}, 1 << 18, 70),
+        ("stochrock", {}, 1 << 18, 70), ("stochrock", {}, 1 << 19, 70), ("stochrock", dict(board_size=15, num_rocks=15), 1 << 19, 40),
+        ("battleship", {}, 1 << 18, 70),
         # the shards a 2^20-lane batch leaves per GPU at 2, 4 and 8 GPUs
         ("rock", {}, 1 << 19, 66), ("rock", {}, 1 << 18, 66), ("rock", {}, 1 << 17, 66),
         ("tag", {}, 1 << 17, 66), ("tag", {}, 1 << 19, 66), ("tiger", {}, 1 << 17, 66), ("tiger", {}, 1 << 18, 66),
@@ -222,7 +223,7 @@ def test_bench_self_launches_two_ranks_on_the_one_gpu():
 def test_launcher_picks_the_documented_kernel_per_shard_size():
     """pomdp_last_fused_kernel() after a fused call: the quad-per-thread loops from the shard sizes DESIGN.md §5 lists
     (RockSample 2^19, Tag 2^19, Tiger 2^18, Network 2^18), the one- / two-lanes-per-thread loops below, the generic loop
-    for BattleShip and StochasticRock, and the arithmetic lane step for launches shorter than 16 steps."""
+    for BattleShip, and the arithmetic lane step for launches shorter than 16 steps."""
     from gym_pomdp_amd import _native
     L = _native.lib()
     want = [("rock", {}, 1 << 20, 64, "steps_quad_kernel<RockEnv<1>>"), ("rock", {}, 1 << 19, 64, "steps_quad_kernel<RockEnv<1>>"),
@@ -233,7 +234,8 @@ def test_launcher_picks_the_documented_kernel_per_shard_size():
             ("tag", {}, 1 << 18, 64, "steps_kernel<TagEnv, 2, true>"), ("tag", dict(num_opponents=2), 1 << 20, 64, "steps_kernel<TagEnv, 2, true>"),
             ("tiger", {}, 1 << 18, 64, "steps_quad_generic_kernel<TigerEnv>"), ("tiger", {}, 1 << 17, 64, "steps_kernel<TigerEnv, 1, true>"),
             ("network", {}, 1 << 18, 64, "network_steps_quad_kernel<>"), ("network", {}, 1 << 17, 64, "steps_kernel<NetworkEnv, 1, true>"),
-            ("battleship", {}, 1 << 19, 64, "steps_kernel<BattleShipEnv<1>, 1, true>"), ("stochrock", {}, 1 << 19, 64, "steps_kernel<StochasticRockEnv<1>, 1, true>")]
+            ("battleship", {}, 1 << 19, 64, "steps_kernel<BattleShipEnv<1>, 1, true>"), ("stochrock", {}, 1 << 19, 64, "steps_quad_kernel<StochasticRockEnv<1>>"),
+            ("stochrock", {}, 1 << 18, 64, "steps_kernel<StochasticRockEnv<1>, 1, true>")]
     for env, kw, n, k, name in want:
         e = make_env(env, kw, batch_size=n, seed=1, reuse_buffers=True)
         e.reset()
