@@ -493,7 +493,8 @@ def main():
         chain1_ms = ev0.elapsed_time(ev1) / k1
     invalid = env.invalid_action_count()
 
-    traffic, traffic_src = measured_traffic(args.env, chained, fused) if n == 1 << 20 else (None, None)
+    # the recorded PMC figure belongs to a launch of the recorded shape only: 2^20 lanes, 64 steps per fused launch
+    traffic, traffic_src = measured_traffic(args.env, chained, fused) if (n == 1 << 20 and spl in (1, 64)) else (None, None)
     if rank == 0:
         total_lanes = n * world
         metric = "env steps/sec (whole node)"
