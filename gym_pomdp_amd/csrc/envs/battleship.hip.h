@@ -180,6 +180,7 @@ struct BattleShipEnv {
                 const u128 blocked = h | shr_small(occ | e1, X) | shl_small(h, X);
                 const u128 hpat = (u128)((1ull << (len + 1)) - 1ull);         // the L+1 checked cells, from bit 0 (L + 1 <= 11)
                 const u128 vpat = u128_of(p.vpat[len + 1]);
+                const u128 vship = u128_of(p.vpat[len]);                      // mark_ship's column pattern: fetched here, not on the success path
                 for (;;) {
                     if (c - c0 > 32) {                                        // wave-uniform: refill the window at the cursor
                         const uint32_t wi = (uint32_t)(c + me);
@@ -210,7 +211,7 @@ struct BattleShipEnv {
                         const int a0w = __builtin_amdgcn_readlane(a0, r), sw = __builtin_amdgcn_readlane(stride, r);
                         // mark_ship: L cells from pos = the L-cell pattern shifted to its lowest cell
                         const int low = sw > 0 ? a0w : a0w + (len - 1) * sw;
-                        occ |= ((sw == 1 || sw == -1) ? (u128)((1ull << len) - 1ull) : u128_of(p.vpat[len])) << low;
+                        occ |= ((sw == 1 || sw == -1) ? (u128)((1ull << len) - 1ull) : vship) << low;
                         remaining += len;
                         c += r + 2;
                         break;
