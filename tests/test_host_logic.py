@@ -57,6 +57,32 @@ def test_struct_sizes_match_header_layout():
     assert n.RockParams.grid.offset == 48 and n.RockParams.thr.offset == 304
 
 
+def test_ctypes_structs_match_the_header_as_gcc_lays_it_out(tmp_path):
+    """Every struct of include/pomdp_hip.h against its ctypes mirror: sizeof and the offset of every field, from a
+    program gcc compiles against the header itself."""
+    import subprocess
+    from gym_pomdp_amd import _native as n
+    pairs = {"pomdp_rock_params": n.RockParams, "pomdp_tag_params": n.TagParams, "pomdp_battleship_params": n.BattleShipParams,
+             "pomdp_tiger_params": n.TigerParams, "pomdp_network_params": n.NetworkParams, "pomdp_step_args": n.StepArgs,
+             "pomdp_collect_args": n.CollectArgs, "pomdp_rock_belief": n.RockBelief, "pomdp_history": n.HistoryPtrs,
+             "pomdp_returns": n.Returns}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "pomdp_hip.h"', 'int main(void) {']
+    for cname, cls in pairs.items():
+        lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for f in cls._fields_:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, f[0], cname, f[0]))
+    lines.append('return 0; }')
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(REPO, "include"), "-o", str(exe), str(src)])
+    got = dict(l.split() for l in subprocess.check_output([str(exe)], text=True).splitlines())
+    for cname, cls in pairs.items():
+        assert int(got[cname]) == C.sizeof(cls), cname
+        for f in cls._fields_:
+            assert int(got["%s.%s" % (cname, f[0])]) == getattr(cls, f[0]).offset, (cname, f[0])
+
+
 def test_tables_match_captured_thresholds():
     from gym_pomdp_amd import tables
     with open(os.path.join(GOLDEN, "thresholds.json")) as f:
