@@ -33,9 +33,12 @@ def collect_case(rs):
     from oracle import philox_ref as px
     name, env_id, kw = CONFIGS[rs.randint(len(CONFIGS))]
     pick = rs.rand()
-    n = (1 << 20) + 1024 * int(rs.randint(0, 3)) if pick < 0.4 else \
-        int(rs.randint(1 << 18, (1 << 18) + 3000)) // 4 * 4 if pick < 0.6 else int(rs.randint(8, 6000)) // 4 * 4
-    lane0 = int(rs.randint(0, 1 << 30)) * 4 % ((1 << 32) - n - 8)
+    # full workgroups at and above the gates of the quad-per-thread loops (2^18: Tiger, Network; 2^19: RockSample, Tag), ragged
+    # batches around 2^18, small batches (any size: the fused drivers generate their own first actions)
+    n = (1 << 20) + 1024 * int(rs.randint(0, 3)) if pick < 0.3 else \
+        (1 << int(rs.randint(18, 20))) + 1024 * int(rs.randint(0, 3)) if pick < 0.5 else \
+        int(rs.randint(1 << 18, (1 << 18) + 3000)) if pick < 0.65 else int(rs.randint(1, 6000))
+    lane0 = int(rs.randint(0, 1 << 30)) * 4 % ((1 << 32) - n - 8) // 4 * 4
     seed = int(rs.randint(1 << 62))
     t0 = int(rs.randint(1 << 40)) if rs.rand() < 0.5 else int(rs.randint(100))
     steps = int(rs.randint(1, 24)) if n >= (1 << 20) else int(rs.randint(1, 80))
