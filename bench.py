@@ -339,11 +339,7 @@ class StepWorkload(object):
         if self.collect:
             # one [CHUNK + 1][n] trajectory buffer per column; a call of c steps writes the first c (+ 1) rows
             c = min(self.CHUNK, max(args.steps, args.warmup, 1))
-            e = self.env
-            self.traj = {"action": torch.zeros((c + 1, n), dtype=torch.int32, device=dev),
-                         "ob": torch.zeros((c, n), dtype=torch.int32, device=dev),
-                         "reward": torch.zeros((c, n), dtype=e._reward.dtype, device=dev),
-                         "done_u8": torch.zeros((c, n), dtype=torch.uint8, device=dev)}
+            self.traj = self.env.trajectory_buffers(c)      # one allocation, column starts staggered (envs/base.py: staggered)
 
     def _view(self, c):
         v = self.views.get(c)

@@ -30,6 +30,25 @@ def _random_seed():
     return int.from_bytes(os.urandom(8), "little")
 
 
+STAGGER_BYTES = 4096
+
+
+def staggered(specs, device):
+    """One allocation carved into the given columns — [(shape, dtype), ...] -> [tensor, ...], zero-filled — with the k-th
+    column starting k * 4 KB past a 4 KB boundary of its own.  Why: separate allocations of this size all start on the same
+    2 MB boundary, a kernel that touches element i of every column at the same time (every step kernel does) then keeps
+    hitting the same HBM channel, and the store stream of a fused launch runs 6 % (RockSample) to 14 % (Tiger) slower than
+    with the columns spread (tools/gpu_store_layout_probe.py, profiles/r02c_store_layout.txt)."""
+    offs, total = [], 0
+    for k, (shape, dtype) in enumerate(specs):
+        nbytes = int(torch.Size(shape).numel()) * torch.empty((), dtype=dtype).element_size()
+        total = -(-total // STAGGER_BYTES) * STAGGER_BYTES + (k % 16) * STAGGER_BYTES
+        offs.append((total, nbytes))
+        total += nbytes
+    pool = torch.zeros(total + STAGGER_BYTES, dtype=torch.uint8, device=device)
+    return [pool[o:o + nb].view(dtype).view(shape) for (o, nb), (shape, dtype) in zip(offs, specs)]
+
+
 class BatchedEnv(object):
     metadata = {"render.modes": ["ansi"]}
     reward_range = (-float("inf"), float("inf"))
@@ -70,11 +89,9 @@ class BatchedEnv(object):
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
         n = batch_size
-        self._state = torch.zeros((self.state_words, n), dtype=torch.int32, device=self.device)
         self._err = torch.zeros(1, dtype=torch.int32, device=self.device)
-        self._done = torch.zeros(n, dtype=torch.uint8, device=self.device)
-        self._ob = torch.zeros(n, dtype=torch.int32, device=self.device)
-        self._reward = torch.zeros(n, dtype=self.reward_dtype, device=self.device)
+        self._state, self._ob, self._reward, self._done = staggered(
+            [((self.state_words, n), torch.int32), ((n,), torch.int32), ((n,), self.reward_dtype), ((n,), torch.uint8)], self.device)
         if n == 1:
             # scalar mode (the reference's usage): the step kernel writes ob / reward / done straight into 16 bytes of
             # pinned host memory (device-visible under unified addressing), so a step is one launch + one stream
@@ -519,6 +536,14 @@ class BatchedEnv(object):
             _native.check(rc, "pomdp_rollout_synthetic")
         return self._ob, self._reward, self._done.view(torch.bool)
 
+    def trajectory_buffers(self, steps):
+        """The `out` dict of collect_synthetic(steps): action int32 [steps + 1, N], ob int32 [steps, N], reward [steps, N],
+        done bool [steps, N] (and its uint8 view "done_u8"), carved from one allocation with staggered column starts."""
+        n = self.batch_size
+        a, o, r, d = staggered([((steps + 1, n), torch.int32), ((steps, n), torch.int32), ((steps, n), self._reward.dtype),
+                                ((steps, n), torch.uint8)], self.device)
+        return {"action": a, "ob": o, "reward": r, "done_u8": d, "done": d.view(torch.bool)}
+
     def _check_driver_use(self, what):
         """The C-side episode loops advance the packed state only: they know nothing of RockSample's side statistics
         (use_heuristic / track_belief envs), and the synthetic policy shares one Philox block among global lanes
@@ -544,11 +569,7 @@ class BatchedEnv(object):
         self._check_driver_use("collect_synthetic")
         steps, n = int(steps), self.batch_size
         if out is None:
-            out = {"action": torch.empty((steps + 1, n), dtype=torch.int32, device=self.device),
-                   "ob": torch.empty((steps, n), dtype=torch.int32, device=self.device),
-                   "reward": torch.empty((steps, n), dtype=self._reward.dtype, device=self.device),
-                   "done_u8": torch.empty((steps, n), dtype=torch.uint8, device=self.device)}
-            out["done"] = out["done_u8"].view(torch.bool)
+            out = self.trajectory_buffers(steps)
         bound = out.get("_bound")
         if bound is None or bound[2] != steps:
             # the call's per-buffer arguments, bound once per `out` (include/pomdp_hip.h: pomdp_collect_args)
