@@ -4,7 +4,7 @@ import ctypes as C
 import torch
 
 from .. import _native, tables
-from .base import BatchedEnv
+from .base import BatchedEnv, staggered
 
 
 class _BeliefTracker(object):
@@ -17,8 +17,9 @@ class _BeliefTracker(object):
     def __init__(self, env):
         self.env = env
         k, n = env.num_rocks, env.batch_size
-        self.tensors = {f: torch.zeros((k, n), dtype=dt, device=env.device) for f, dt in self.FIELDS}
-        self.check_ok = torch.zeros(n, dtype=torch.int32, device=env.device)   # derived word (pomdp_rock_belief.check_ok)
+        cols = staggered([((k, n), dt) for _, dt in self.FIELDS] + [((n,), torch.int32)], env.device)   # one allocation, spread starts
+        self.tensors = {f: c for (f, _), c in zip(self.FIELDS, cols)}
+        self.check_ok = cols[-1]                                                # derived word (pomdp_rock_belief.check_ok)
         self.ptrs = _native.RockBelief(*([self.tensors[f].data_ptr() for f, _ in self.FIELDS] + [self.check_ok.data_ptr()]))
         self.ref = C.byref(self.ptrs)
         self.on_reset()

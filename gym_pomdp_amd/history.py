@@ -40,12 +40,10 @@ class History(object):
             torch.as_tensor(observation, device=dev).to(torch.int32).reshape(n).clone()
         self._kind = _native.ENV_KIND[env.env_name]
         k = env.num_rocks if env.env_name == "rock" else 0
-        self._size = torch.zeros(n, dtype=torch.int32, device=dev)
-        self.last_action = torch.zeros(n, dtype=torch.int32, device=dev)
-        self.last_ob = torch.zeros(n, dtype=torch.int32, device=dev)
-        self.total_sample = torch.zeros((k, n), dtype=torch.int32, device=dev)
-        self.total_move = torch.zeros((k, n), dtype=torch.int32, device=dev)
-        self.move_ok = torch.zeros(n if k else 0, dtype=torch.int32, device=dev)   # derived: bit j = total_move[j] >= 0
+        from .envs.base import staggered           # one allocation, column starts spread over the HBM channels
+        (self._size, self.last_action, self.last_ob, self.total_sample, self.total_move, self.move_ok) = staggered(
+            [((n,), torch.int32), ((n,), torch.int32), ((n,), torch.int32), ((k, n), torch.int32), ((k, n), torch.int32),
+             ((n if k else 0,), torch.int32)], dev)                                # move_ok: derived, bit j = total_move[j] >= 0
         bounded = self._max_size is not None
         self.ring = torch.zeros((self._max_size + 1, n) if bounded and k else (0, n), dtype=torch.uint8, device=dev)
         self.head = torch.zeros(n if bounded else 0, dtype=torch.int32, device=dev)
