@@ -129,16 +129,28 @@ struct BattleShipEnv {
         return (u128)(w0 | ((uint64_t)w1 << 32)) | ((u128)(w2 | ((uint64_t)w3 << 32)) << 64);
     }
     static __device__ __forceinline__ u128 u128_of(const uint32_t (&w)[4]) { return u128_of4(w[0], w[1], w[2], w[3]); }
-    // 128-bit shifts by 1 <= s <= 63 (a board is at most 16 wide): the general form selects between three cases
-    static __device__ __forceinline__ u128 shl_small(u128 a, int s)
+    // The cooperative reset's cell masks in the narrowest type that holds the board (cells + 6 <= 32 MW bits): one
+    // 32-bit word for the reference's default 5x5 board, one 64-bit word up to 58 cells, 128 bits beyond — uniform mask
+    // arithmetic runs on the scalar unit, where a 128-bit operation is four instructions and a 32-bit one is one.
+    using M = typename std::conditional<MW == 1, uint32_t, typename std::conditional<MW == 2, uint64_t, u128>::type>::type;
+    static constexpr int MBITS = MW == 1 ? 32 : MW == 2 ? 64 : 128;
+    static __device__ __forceinline__ M mask_of(const uint32_t (&w)[4]) { return (M)u128_of(w); }
+    // shifts by 1 <= s <= 63 (a board is at most 16 wide): for 128 bits the general form selects between three cases
+    static __device__ __forceinline__ M shl_small(M a, int s)
     {
-        const uint64_t lo = (uint64_t)a, hi = (uint64_t)(a >> 64);
-        return (u128)(lo << s) | ((u128)((hi << s) | (lo >> (64 - s))) << 64);
+        if constexpr (MW <= 2) return (M)(a << s);
+        else {
+            const uint64_t lo = (uint64_t)a, hi = (uint64_t)((u128)a >> 64);
+            return (M)((u128)(lo << s) | ((u128)((hi << s) | (lo >> (64 - s))) << 64));
+        }
     }
-    static __device__ __forceinline__ u128 shr_small(u128 a, int s)
+    static __device__ __forceinline__ M shr_small(M a, int s)
     {
-        const uint64_t lo = (uint64_t)a, hi = (uint64_t)(a >> 64);
-        return (u128)((lo >> s) | (hi << (64 - s))) | ((u128)(hi >> s) << 64);
+        if constexpr (MW <= 2) return (M)(a >> s);
+        else {
+            const uint64_t lo = (uint64_t)a, hi = (uint64_t)((u128)a >> 64);
+            return (M)((u128)((lo >> s) | (hi << (64 - s))) | ((u128)(hi >> s) << 64));
+        }
     }
     static __device__ __forceinline__ uint64_t direction_words(uint64_t a)
     {
@@ -158,7 +170,7 @@ struct BattleShipEnv {
         __builtin_assume(X >= 1 && X <= 16 && Y >= 1 && Y <= 16);          // bs_mask_words(): what the launchers let through —
         __builtin_assume(p.max_len >= 2 && p.max_len <= 10);                // 128-bit shifts by X or by a ship length stay below 64
         const uint32_t rmask = 0xFFFFFFFFu >> __clz((uint32_t)(cells - 1) | 1u); // randint(cells) bit-smear mask
-        const u128 col0 = u128_of(p.col0), colL = col0 << (X - 1);
+        const M col0 = mask_of(p.col0), colL = (M)(col0 << (X - 1));
         const uint32_t inv_x = (65536u + (uint32_t)X - 1u) / (uint32_t)X;   // a / X == (a * inv_x) >> 16 for a < 128, X <= 16
         while (todo != 0ull) {
             const int src = __ffsll((long long)todo) - 1;
@@ -170,17 +182,17 @@ struct BattleShipEnv {
             // ds_bpermute, as long as at least 32 of its words are still ahead of the cursor
             int c0 = -64;
             uint32_t wword = 0;
-            u128 occ = 0;
+            M occ = 0;
             int remaining = 0;
             for (int len = p.max_len; len >= 2; --len) {
                 __builtin_assume(len <= 10);
                 // blocked = occ and its N, E, S, W, NE, SE, SW shifts (NW excluded) in four 128-bit shifts:
                 // h = {self, E, W}; south side = h << X (S, SE, SW); north side = {self, E} >> X (N, NE)
-                const u128 e1 = (occ & ~col0) >> 1, h = occ | e1 | ((occ & ~colL) << 1);
-                const u128 blocked = h | shr_small(occ | e1, X) | shl_small(h, X);
-                const u128 hpat = (u128)((1ull << (len + 1)) - 1ull);         // the L+1 checked cells, from bit 0 (L + 1 <= 11)
-                const u128 vpat = u128_of(p.vpat[len + 1]);
-                const u128 vship = u128_of(p.vpat[len]);                      // mark_ship's column pattern: fetched here, not on the success path
+                const M e1 = (M)((occ & ~col0) >> 1), h = (M)(occ | e1 | (M)((occ & ~colL) << 1));
+                const M blocked = (M)(h | shr_small((M)(occ | e1), X) | shl_small(h, X));
+                const M hpat = (M)((1ull << (len + 1)) - 1ull);         // the L+1 checked cells, from bit 0 (L + 1 <= 11)
+                const M vpat = mask_of(p.vpat[len + 1]);
+                const M vship = mask_of(p.vpat[len]);                      // mark_ship's column pattern: fetched here, not on the success path
                 for (;;) {
                     if (c - c0 > 32) {                                        // wave-uniform: refill the window at the cursor
                         const uint32_t wi = (uint32_t)(c + me);
@@ -203,7 +215,7 @@ struct BattleShipEnv {
                     const int stride = dy * X + dx;
                     const bool inside = (unsigned)ex < (unsigned)X && (unsigned)ey < (unsigned)Y;
                     const int lo = stride > 0 ? a0 : a0 + len * stride;
-                    const u128 cellsm = (dx != 0 ? hpat : vpat) << (lo & 127);
+                    const M cellsm = (M)((dx != 0 ? hpat : vpat) << (lo & (MBITS - 1)));
                     const bool ok = ((cand >> me) & 1ull) && inside && (cellsm & blocked) == 0;
                     const uint64_t succ = __ballot(ok);
                     if (succ != 0ull) {
@@ -211,7 +223,7 @@ struct BattleShipEnv {
                         const int a0w = __builtin_amdgcn_readlane(a0, r), sw = __builtin_amdgcn_readlane(stride, r);
                         // mark_ship: L cells from pos = the L-cell pattern shifted to its lowest cell
                         const int low = sw > 0 ? a0w : a0w + (len - 1) * sw;
-                        occ |= ((sw == 1 || sw == -1) ? (u128)((1ull << len) - 1ull) : vship) << low;
+                        occ |= (M)(((sw == 1 || sw == -1) ? (M)((1ull << len) - 1ull) : vship) << (low & (MBITS - 1)));
                         remaining += len;
                         c += r + 2;
                         break;
@@ -222,7 +234,7 @@ struct BattleShipEnv {
                 }
             }
             if (me == src) {
-                st.occ.lo = (uint64_t)occ; st.occ.hi = (uint64_t)(occ >> 64);
+                st.occ.lo = (uint64_t)occ; st.occ.hi = MW > 2 ? (uint64_t)((u128)occ >> 64) : 0ull;
                 st.vis.lo = 0; st.vis.hi = 0;
                 st.vis.set_word(MW - 1, (uint32_t)remaining << 26);
             }
