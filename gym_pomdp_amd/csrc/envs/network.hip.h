@@ -137,9 +137,47 @@ struct NetworkEnv {
     // the action.  Lanes iterate over the draws (j = 0, 1, ...), not over the machines: j is
     // wave-uniform, so the Philox block that feeds doubles 2q and 2q+1 is generated under a uniform
     // condition and the only divergence left is the per-lane number of up machines.
+    // The step as the single-step kernels, the rollouts and the generic fused loop run it: the FIRST block of the lane's
+    // stream is computed unconditionally and its four words applied straight-line (draw4) — under a random policy 98 % of the
+    // lanes need no more — then the wave loops, block by block, only while some lane still has machines to draw for or its
+    // action's draw ahead.  A draw decided by its low word (2^-27) sends the lane through step_exact.
     template <class RT>
     static __device__ __forceinline__ void step(const Shared &sh, const Params &p, State &st, int a,
                                                 const RngKey &key, uint32_t lane, int &ob, RT &rew, int &done)
+    {
+        const uint32_t s0 = st.w;
+        const int n_up = __popc(s0), base = n_up + __popc(s0 & p.deg_gt2_mask);       // network.py:87-92
+        const uint32_t nbf = nb_failed_of(sh, p, s0);
+        const Thr T = thresholds(p);
+        const bool has_action = a < 2 * p.n_machines;
+        uint32_t todo = s0, near = 0xFFFFFFFFu, kill = 0;
+        bool pend = has_action, truthful = false;
+        int left = n_up;
+        uint4 h = stream_block(key, lane, POMDP_STREAM_STEP, 0u);
+        for (uint32_t blk = 1;; ++blk) {
+            kill |= draw4(h, todo, nbf, T, near);
+            if (pend && left < 4) {                                              // the action's draw: the word after the last machine's
+                uint32_t w = left == 1 ? h.y : h.x;
+                w = left == 2 ? h.z : w;
+                w = left == 3 ? h.w : w;
+                truthful = truthful_of(w, T, near);
+                pend = false;
+            }
+            if (!__any(todo != 0u || pend)) break;                               // wave-uniform
+            left = __popc(todo);
+            h = stream_block(key, lane, POMDP_STREAM_STEP, 2u * blk);
+        }
+        if (near < 32u) { step_exact(sh, p, st, a, key, lane, ob, rew, done); return; }
+        uint32_t s = s0 & ~kill;
+        finish(p, s, a, base, truthful, ob, rew);
+        done = 0;
+        st.w = s;
+    }
+
+    // the same, one draw at a time with the low words at hand: the exact form (ties; and what the fast forms are checked against)
+    template <class RT>
+    static __device__ __forceinline__ void step_exact(const Shared &sh, const Params &p, State &st, int a,
+                                                      const RngKey &key, uint32_t lane, int &ob, RT &rew, int &done)
     {
         const uint32_t s0 = st.w;
         const int M = p.n_machines;

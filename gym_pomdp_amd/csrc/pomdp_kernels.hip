@@ -1340,7 +1340,7 @@ __global__ __launch_bounds__(BLOCK) void tag_steps_quad_kernel(uint32_t *__restr
 // two words, then block by block — and returns the machines that fail and the action's draw.  The policy's ACTION block
 // is the thread's own, the outputs leave as 16-byte stores, the reward comes from a table of the float32(float64) values
 // the reference's arithmetic gives.  A draw decided by its low word (2^-27 per draw) sends the lane through
-// NetworkEnv::step, the exact per-lane form.  Network never terminates, so there is no reset.
+// NetworkEnv::step_exact, the exact per-lane form.  Network never terminates, so there is no reset.
 template <int NB>   // bytes of the machine set: ceil(n_machines / 8)
 __global__ __launch_bounds__(BLOCK) void network_steps_quad_kernel(uint32_t *__restrict__ state, int32_t *__restrict__ action,
                                                                    int32_t *__restrict__ ob, float *__restrict__ reward,
@@ -1492,7 +1492,7 @@ __global__ __launch_bounds__(BLOCK) void network_steps_quad_kernel(uint32_t *__r
             if (near[j] < 32u) {                                               // a draw decided by its low word: the exact per-lane form
                 Env::State e{st[j]};
                 int d;
-                Env::step(sh, p, e, a_cur[j], key, glane0 + (uint32_t)j, o, r, d);
+                Env::step_exact(sh, p, e, a_cur[j], key, glane0 + (uint32_t)j, o, r, d);
                 st[j] = e.w;
             } else {                                                           // network.py:101-112
                 const int a = a_cur[j], machine = (a >> 1) & 31;
@@ -1590,14 +1590,14 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_generic_kernel(uint32_t *__r
 // 2^17 / 2^18 / 2^19 / 2^20 lanes (profiles/r02_small_shards_gates.txt, r02c_small_shards.txt): RockSample(7,8) quad 1.50 /
 // 1.52 / 1.82 / 2.89 against 1.25 / 1.39 / 1.99 with one or two lanes per thread; Tag (table-driven) 1.59 / 1.61 / 1.83 /
 // 2.67 against 0.96 / 1.43 / 2.00; Tiger 0.67 / 0.72 / 1.26 / 2.82 against 0.55 / 0.83 / 1.52; Network 2.30 / 2.30 / 2.91 /
-// 4.72 against 2.01 / 2.67 / 4.53 — below these sizes every kernel is bound by the latency of one wave's step
+// 4.72 against 1.45 / 1.94 / 3.32 / 5.99 — below these sizes every kernel is bound by the latency of one wave's step
 // (1.1-2.3 us), and more, lighter waves hide it better than fewer, heavier ones.
 // POMDP_QUAD_MIN_LANES overrides all of them at build time for same-box A/B runs (tools/ab_build.sh lib ... -D...).
 #ifdef POMDP_QUAD_MIN_LANES
 constexpr int64_t QUAD_MIN_ROCK = POMDP_QUAD_MIN_LANES, QUAD_MIN_TAG = POMDP_QUAD_MIN_LANES, QUAD_MIN_GENERIC = POMDP_QUAD_MIN_LANES,
                   QUAD_MIN_NETWORK = POMDP_QUAD_MIN_LANES;
 #else
-constexpr int64_t QUAD_MIN_ROCK = 1 << 19, QUAD_MIN_TAG = 1 << 19, QUAD_MIN_GENERIC = 1 << 18, QUAD_MIN_NETWORK = 1 << 18;
+constexpr int64_t QUAD_MIN_ROCK = 1 << 19, QUAD_MIN_TAG = 1 << 19, QUAD_MIN_GENERIC = 1 << 18, QUAD_MIN_NETWORK = 1 << 19;
 #endif
 
 // which kernel the calling thread's most recent fused launch picked (pomdp_last_fused_kernel: bench.py names the kernel
