@@ -11,6 +11,7 @@ struct TagEnv {
     static constexpr int WORDS = 1;
     static constexpr const char *NAME = "TagEnv";
     static constexpr bool POOLED_LPT2 = true;     // pomdp_kernels.hip: Finisher<TagEnv, 2, .>
+    static constexpr bool QUAD_STEP = false;   // pomdp_kernels.hip: step_quad_kernel
     static constexpr bool POOLED_ANY_LPT = false;
     static constexpr bool QUAD_SENSOR = false;
     // The T-shaped board never changes (tag.py:36-78): two small LDS tables replace the coordinate arithmetic of the

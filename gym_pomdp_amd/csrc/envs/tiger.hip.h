@@ -11,6 +11,7 @@ struct TigerEnv {
     static constexpr int WORDS = 1;
     static constexpr const char *NAME = "TigerEnv";
     static constexpr bool POOLED_LPT2 = false;
+    static constexpr bool QUAD_STEP = false;   // pomdp_kernels.hip: step_quad_kernel
     static constexpr bool POOLED_ANY_LPT = false;
     static constexpr bool QUAD_SENSOR = false;
     static constexpr bool QUAD_FUSED = true;      // pomdp_kernels.hip: steps_quad_generic_kernel

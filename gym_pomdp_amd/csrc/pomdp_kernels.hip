@@ -30,7 +30,18 @@ static inline int grid_for(int64_t n)
 }
 static inline unsigned blocks_for(int64_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
 // below this many lanes one lane per thread is as fast or faster (measured: tools/microbench.hip at 2^16 .. 2^19)
+#ifdef POMDP_DEV_TIMELINE                                      // dev builds only (tools/ab_build.sh): per-workgroup phase stamps
+__device__ uint64_t *g_timeline = nullptr;
+#define TL(k) do { if (threadIdx.x == 0 && g_timeline) g_timeline[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define TL(k) do { } while (0)
+#endif
 constexpr int64_t LPT2_MIN_LANES = 1 << 18;
+#ifdef POMDP_STEP_QUAD_MIN_LANES                              // same-box A/B builds (tools/ab_build.sh)
+constexpr int64_t STEP_QUAD_MIN_LANES = POMDP_STEP_QUAD_MIN_LANES;
+#else
+constexpr int64_t STEP_QUAD_MIN_LANES = 1 << 19;
+#endif
 
 // ---------------------------------------------------------------------------
 // reset: every lane starts a fresh episode from stream RESET of (seed, lane, t)
@@ -323,6 +334,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(uint32_t *__restrict__ stat
                                                      const typename Env::Params p)   // pointers first: what a wave needs first
 {
     __shared__ typename Env::Shared sh;
+    TL(0);
     const bool auto_reset = flags & POMDP_AUTO_RESET;
     // Addressing: the workgroup's first lane is wave-uniform, so every column gets a per-workgroup base pointer in
     // SGPRs and a thread only ever adds a small 32-bit offset (rel < BLOCK * LPT) — `global_load/store v_off, s[base]`
@@ -362,6 +374,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(uint32_t *__restrict__ stat
         Env::stage(sh, p, (int)threadIdx.x);
     }
     __syncthreads();
+    TL(1);
 
     const int n_act = Env::n_actions(p);
     int o[LPT], d[LPT];
@@ -375,12 +388,20 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(uint32_t *__restrict__ stat
         Fin::lane_step(sh, p, st[j], valid[j] ? a_raw[j] : 0, key, lane0 + idx[j], o[j], r[j], d[j], aux[j]);
         if (!live[j]) { r[j] = 0; d[j] = was_done[j]; }               // step result discarded unless live
     }
+#ifdef POMDP_DEV_TIMELINE
+    { int x = 0; for (int j = 0; j < LPT; ++j) x += d[j] + (int)r[j]; asm volatile("" :: "v"(x)); }
+    TL(2);
+#endif
     bool fresh[LPT];
     uint32_t glane[LPT];
     int a_next[LPT];
 #pragma unroll
     for (int j = 0; j < LPT; ++j) { fresh[j] = live[j] && d[j] && auto_reset; glane[j] = lane0 + idx[j]; a_next[j] = 0; }
     Fin::run(sh, p, st, fresh, key, glane, akey, (uint32_t)n_act, a_next, aux, o);
+#ifdef POMDP_DEV_TIMELINE
+    { int x = 0; for (int j = 0; j < LPT; ++j) x += o[j]; asm volatile("" :: "v"(x)); }
+    TL(3);
+#endif
 #pragma unroll
     for (int j = 0; j < LPT; ++j) {
         if (!live[j]) o[j] = 0;
@@ -394,6 +415,11 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(uint32_t *__restrict__ stat
             if (!valid[j] && !was_done[j] && err) atomicAdd(err, 1u);
         }
     }
+#ifdef POMDP_DEV_TIMELINE
+    TL(4);
+    __builtin_amdgcn_s_waitcnt(0);
+    TL(5);
+#endif
 }
 
 // k consecutive chained steps in ONE launch: exactly the memory state k launches of step_kernel<Env, LPT, true> leave —
@@ -1056,6 +1082,11 @@ static int launch_reset(const typename Env::Params &p, uint32_t *state, int32_t 
     return (int)hipGetLastError();
 }
 
+template <class Env>   // defined with the other quad-per-thread kernels below
+__global__ void step_quad_kernel(uint32_t *__restrict__ state, const int32_t *__restrict__ action, int32_t *__restrict__ ob,
+                                 int32_t *__restrict__ reward, uint8_t *__restrict__ done, uint32_t *__restrict__ err, int64_t n,
+                                 RngKey key, uint32_t lane0, int flags, const typename Env::Params p);
+
 template <class Env>
 static int launch_step(const typename Env::Params &p, uint32_t *state, const int32_t *action, int32_t *ob,
                        typename Env::Reward *reward, uint8_t *done, uint32_t *err, int64_t n, uint64_t seed,
@@ -1066,6 +1097,16 @@ static int launch_step(const typename Env::Params &p, uint32_t *state, const int
     // Two lanes per thread where the env pools work across a wave's two 64-lane sub-batches (RockSample: the
     // Finisher specialisation above) and the batch still gives every CU several workgroups; one lane per thread
     // otherwise (measured equal within 2 % for the generic envs, tools/microbench.hip).
+    if constexpr (Env::QUAD_STEP) {
+        // a quad of lanes per thread (step_quad_kernel) once the batch fills the chip with such workgroups
+        const bool cols16 = ((reinterpret_cast<uintptr_t>(state) | reinterpret_cast<uintptr_t>(action) | reinterpret_cast<uintptr_t>(ob) |
+                              reinterpret_cast<uintptr_t>(reward)) & 15u) == 0 && (reinterpret_cast<uintptr_t>(done) & 3u) == 0;
+        if (n >= STEP_QUAD_MIN_LANES && n % (4 * BLOCK) == 0 && (lane0 & 3u) == 0 && cols16) {
+            hipLaunchKernelGGL(step_quad_kernel<Env>, dim3((unsigned)(n / (4 * BLOCK))), dim3(BLOCK), 0, (hipStream_t)stream, state,
+                               action, ob, reward, done, err, n, make_key(seed, t), lane0, flags, p);
+            return (int)hipGetLastError();
+        }
+    }
     if constexpr (Env::POOLED_LPT2) {
         if (n >= LPT2_MIN_LANES) {
             hipLaunchKernelGGL((step_kernel<Env, 2>), dim3((unsigned)((n + 2 * BLOCK - 1) / (2 * BLOCK))), dim3(BLOCK), 0,
@@ -1117,7 +1158,9 @@ static __device__ __forceinline__ u32x4 first_actions4(uint32_t *action_row0, in
 // thread's own: two Philox blocks per thread-step straight into registers, lane j taking element j — no exchange through LDS,
 // no selects.  A thread's outputs are four consecutive elements of each column: one 16-byte store per int32 column and one
 // 4-byte store of the packed done bytes per step instead of twenty scalar stores; state and first actions come in the
-// same way.  The lane step is the table-driven one; resets are pooled per wave as in Finisher<RockEnv>.  Full workgroups
+// same way.  The lane step is the table-driven one; resets are pooled per wave as in Finisher<RockEnv> (pooling them over the workgroup's four
+// waves instead — one pass at 80 % of its width where four run at 20 % — costs two barriers per step and measured 3.21 against
+// 2.85 us per step: the loop lives on its waves drifting apart).  Full workgroups
 // of 1024 lanes and auto-reset only (the launcher's SIMPLE conditions).  Same results as steps_kernel: the mapping of lanes
 // to threads is invisible to a lane's random words.
 template <class Env>
@@ -1225,6 +1268,109 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
     if (W == 2)
         st_stream4(state + n + l0, (uint32_t)((uint64_t)st[0].s >> 32), (uint32_t)((uint64_t)st[1].s >> 32),
                    (uint32_t)((uint64_t)st[2].s >> 32), (uint32_t)((uint64_t)st[3].s >> 32));
+}
+
+// ONE step of RockSample with the caller's actions (env.step()) and a quad of consecutive lanes per thread: the quad's
+// STEP block is the thread's own (one Philox block for four lane-steps, computed under the latency of the loads, no
+// exchange through LDS), state / action / ob / reward move as 16-byte accesses and the four done bytes as one word —
+// 105 VALU instructions per lane-step where step_kernel<Env, 2> issues 187; 7.8 against 8.3 us per step of 2^20 lanes for
+// RockSample(7,8), 7.5 against 8.8 for StochasticRock (whose step_kernel runs one lane per thread), inside a python loop
+// (DESIGN.md §5 has the timeline of such a launch).  Same contract as step_kernel: a lane whose action is out of range is left untouched and counted in
+// *err, without auto-reset a done lane stays frozen.  Full workgroups of 1024 lanes on 16-byte column boundaries only
+// (launch_step); anything else takes step_kernel.
+template <class Env>
+__global__ __launch_bounds__(BLOCK) void step_quad_kernel(uint32_t *__restrict__ state, const int32_t *__restrict__ action,
+                                                          int32_t *__restrict__ ob, int32_t *__restrict__ reward,
+                                                          uint8_t *__restrict__ done, uint32_t *__restrict__ err, int64_t n,
+                                                          RngKey key, uint32_t lane0, int flags, const typename Env::Params p)
+{
+    constexpr int W = Env::WORDS;
+    using S = typename Env::S;
+    __shared__ typename Env::Shared sh;
+    __shared__ uint8_t src_lds[BLOCK / 64][256];             // reset rank -> lane within the wave's 256
+    __shared__ uint32_t res_lds[BLOCK / 64][256];            // reset rank -> the fresh episode's rock codes
+    const int wv = (int)(threadIdx.x >> 6), me = (int)(threadIdx.x & 63u);
+    TL(0);
+    const bool auto_reset = flags & POMDP_AUTO_RESET;
+    const uint32_t l0 = blockIdx.x * (uint32_t)(4 * BLOCK) + 4u * threadIdx.x;
+    const uint32_t glane0 = lane0 + l0, wave0 = glane0 - 4u * (uint32_t)me;
+    uint32_t *const done_w = reinterpret_cast<uint32_t *>(done + l0);
+    const u32x4 s_lo = ld_stream4(state + l0);
+    u32x4 s_hi = {0, 0, 0, 0};
+    if (W == 2) s_hi = ld_stream4(state + n + l0);
+    const u32x4 a4 = ld_stream4(reinterpret_cast<const uint32_t *>(action) + l0);
+    const uint32_t dn = auto_reset ? 0u : ld_stream(done_w);                       // frozen lanes (the reference would assert)
+    const auto staged = Env::stage_load(p, (int)threadIdx.x);
+    // the quad's words depend on lane ids only: Philox under the load latency
+    constexpr uint32_t SENSOR_BLOCK = Env::STOCHASTIC ? 2u : 0u;
+    const uint4 sw = Env::quad_block(key, glane0, SENSOR_BLOCK);
+    const uint32_t H[4] = {sw.x, sw.y, sw.z, sw.w};
+    uint32_t G[4] = {0, 0, 0, 0};
+    if constexpr (Env::STOCHASTIC) { const uint4 gw = Env::quad_block(key, glane0, 0u); G[0] = gw.x; G[1] = gw.y; G[2] = gw.z; G[3] = gw.w; }
+    Env::stage_store(sh, staged, (int)threadIdx.x);
+    __syncthreads();
+#ifdef POMDP_DEV_TIMELINE
+    TL(1);
+    asm volatile("" :: "v"(s_lo[0] + a4[0]));
+    TL(2);
+#endif
+    const uint32_t n_act = (uint32_t)Env::n_actions(p);
+    typename Env::State st[4];
+    typename Env::Aux aux[4];
+    int r[4], d[4], rank[4], nres = 0;
+    bool live[4];
+    uint32_t n_bad = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bool valid = a4[j] < n_act, was_done = ((dn >> (8 * j)) & 0xFFu) != 0u;
+        live[j] = valid && !was_done;
+        n_bad += (uint32_t)(!valid && !was_done);
+        st[j].s = (S)((uint64_t)s_lo[j] | ((uint64_t)s_hi[j] << 32));
+        typename Env::State nx = st[j];
+        Env::step_pre(sh, p, nx, valid ? (int)a4[j] : 0, r[j], d[j], aux[j]);
+        bool acts = live[j];
+        if constexpr (Env::STOCHASTIC)                                             // applied iff binomial(1, p_move) says so (rock.py:443)
+            acts = acts && Env::k53_le(G[j], (uint32_t)(p.act_thr >> 26), (uint32_t)p.act_thr & Env::LO_MASK,
+                                       [&]() { return Env::elem(Env::quad_block(key, glane0, 1u), (uint32_t)j); });
+        if (acts) st[j] = nx; else { r[j] = 0; d[j] = live[j] ? 0 : (int)was_done; aux[j].want = false; }
+        const uint64_t m = __ballot(acts && d[j] != 0 && auto_reset);              // done lanes start a new episode
+        rank[j] = nres + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        nres += __popcll(m);
+        if (acts && d[j] && auto_reset) src_lds[wv][rank[j]] = (uint8_t)(4 * me + j);
+    }
+    // everything but the state is known before the resets: those stores drain under the reset pass.  (A CHECK neither moves
+    // the agent nor ends the episode: the sensor reads the state the step left.)
+    uint32_t o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        o[j] = (uint32_t)Env::sensor_ob(sh, st[j], aux[j], H[j], [&]() { return Env::elem(Env::quad_block(key, glane0, SENSOR_BLOCK + 1u), (uint32_t)j); });
+    st_stream4(reinterpret_cast<uint32_t *>(ob) + l0, o[0], o[1], o[2], o[3]);
+    st_stream4(reinterpret_cast<uint32_t *>(reward) + l0, (uint32_t)r[0], (uint32_t)r[1], (uint32_t)r[2], (uint32_t)r[3]);
+    st_stream(done_w, (uint32_t)d[0] | ((uint32_t)d[1] << 8) | ((uint32_t)d[2] << 16) | ((uint32_t)d[3] << 24));
+    TL(3);
+    const int K = p.num_rocks;
+    for (int base = 0; base < nres; base += 64) {            // one RESET block per resetting lane, 64 per pass
+        const int q = base + me;
+        if (q < nres) {
+            const uint32_t src_lane = wave0 + (uint32_t)src_lds[wv][q & 255];
+            const uint4 w = philox4x32_10(src_lane, key.t_lo, key.t_hi, (uint32_t)POMDP_STREAM_RESET << 24, key.k0, key.k1);
+            res_lds[wv][q & 255] = Env::reset_codes(w, key, src_lane, K);
+        }
+    }
+    const uint32_t start = (uint32_t)p.start_x | ((uint32_t)p.start_y << 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (live[j] && d[j] && auto_reset) st[j].s = (S)((uint64_t)start | ((uint64_t)res_lds[wv][rank[j] & 255] << 8));
+    st_stream4(state + l0, (uint32_t)st[0].s, (uint32_t)st[1].s, (uint32_t)st[2].s, (uint32_t)st[3].s);
+    if (W == 2)
+        st_stream4(state + n + l0, (uint32_t)((uint64_t)st[0].s >> 32), (uint32_t)((uint64_t)st[1].s >> 32),
+                   (uint32_t)((uint64_t)st[2].s >> 32), (uint32_t)((uint64_t)st[3].s >> 32));
+    if (n_bad && err) atomicAdd(err, n_bad);
+#ifdef POMDP_DEV_TIMELINE
+    TL(4);
+    __builtin_amdgcn_s_waitcnt(0);
+    TL(5);
+#endif
 }
 
 // Tag (one opponent) with a quad per thread: the policy's ACTION block is the thread's own, the flights of failed TAGs
@@ -1868,6 +2014,9 @@ static int dispatch_env(int env, const void *params, F &&f)
 }
 
 extern "C" {
+#ifdef POMDP_DEV_TIMELINE
+int pomdp_dev_timeline(uint64_t *buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_timeline), &buf, sizeof(buf)); }
+#endif
 
 int pomdp_abi_version(void) { return POMDP_ABI_VERSION; }
 

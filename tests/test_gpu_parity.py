@@ -1051,14 +1051,19 @@ def test_collect_row_pitch_through_the_c_abi(env, n, pitch, steps):
     assert bad == -1                                        # POMDP_E_BADARG: pitch < n
 
 
-@pytest.mark.parametrize("kw,auto", [({}, False), ({}, True), (dict(board_size=15, num_rocks=15), False)],
-                         ids=["rock_7_8-frozen", "rock_7_8-auto", "rock_15_15-frozen"])
-def test_step_contract_over_a_whole_2_20_batch(oracle_lib, kw, auto):
-    """env.step() at 2^20 lanes against the oracle over the WHOLE batch, with caller-supplied actions of which a few are out
-    of range and, without auto-reset, with lanes freezing as their episodes end."""
+@pytest.mark.parametrize("env,kw,auto,offset", [
+    ("rock", {}, False, 0), ("rock", {}, True, 0), ("rock", dict(board_size=15, num_rocks=15), False, 0),
+    ("rock", dict(board_size=15, num_rocks=15), True, 0), ("stochrock", {}, True, 0), ("stochrock", {}, False, 0),
+    ("rock", {}, True, 1)],
+    ids=["rock_7_8-frozen", "rock_7_8-auto", "rock_15_15-frozen", "rock_15_15-auto", "stochrock-auto", "stochrock-frozen",
+         "rock_7_8-auto-actions_off_16_bytes"])
+def test_step_contract_over_a_whole_2_20_batch(oracle_lib, env, kw, auto, offset):
+    """env.step() at 2^20 lanes (step_quad_kernel; with an action tensor that does not start on a 16-byte boundary the
+    general step_kernel) against the oracle over the WHOLE batch, with caller-supplied actions of which a few are out of
+    range and, without auto-reset, with lanes freezing as their episodes end."""
     n, seed, lane0 = 1 << 20, 606, 1 << 12
-    e = make_env("rock", kw, batch_size=n, seed=seed, lane_offset=lane0, auto_reset=auto, reuse_buffers=True)
-    o = oracle_lib.OracleEnv("rock", **kw)
+    e = make_env(env, kw, batch_size=n, seed=seed, lane_offset=lane0, auto_reset=auto, reuse_buffers=True)
+    o = oracle_lib.OracleEnv(env, **kw)
     st = o.new_state(n)
     assert np.array_equal(np_(e.reset()), o.batch_reset(st, seed, lane0, 0, nthreads=8))
     rs = np.random.RandomState(5)
@@ -1070,7 +1075,10 @@ def test_step_contract_over_a_whole_2_20_batch(oracle_lib, kw, auto):
         a[idx] = rs.choice([-1, o.n_actions, 1 << 20], size=len(idx))
         ob, rew, done, bad = o.batch_step(st, a, seed, lane0, t, auto_reset=auto, done=done, nthreads=8)
         bad_total += bad
-        ob_g, rew_g, done_g, _ = e.step(torch.as_tensor(a, device="cuda"))
+        a_g = torch.zeros(n + offset, dtype=torch.int32, device="cuda")[offset:]
+        a_g.copy_(torch.as_tensor(a))
+        assert a_g.data_ptr() % 16 == 4 * offset
+        ob_g, rew_g, done_g, _ = e.step(a_g)
         assert np.array_equal(np_(ob_g), ob) and np.array_equal(np_(rew_g), rew), t
         assert np.array_equal(np_(done_g), done.astype(bool)), t
         assert np.array_equal(np_(e.state).view(np.uint32), st), t

@@ -11,10 +11,17 @@ import time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import torch  # noqa: E402
+from gym_pomdp_amd import _native  # noqa: E402
+if len(sys.argv) > 1 and sys.argv[1] != "-":                 # a variant library built by tools/ab_build.sh
+    _native.LIB_PATH = os.path.abspath(sys.argv[1])
 import gym_pomdp_amd as gpa  # noqa: E402
 
-n = 1 << 20
-for name, env_id, kw in (("rock", "Rock-v0", {}), ("tag", "Tag-v0", {}), ("tiger", "Tiger-v0", {}), ("network", "Network-v0", {})):
+n = 1 << (int(sys.argv[2]) if len(sys.argv) > 2 else 20)
+print("library: %s, %d lanes" % (_native.LIB_PATH, n))
+for name, env_id, kw in (("rock", "Rock-v0", {}), ("rock15", "Rock-v0", dict(board_size=15, num_rocks=15)),
+                         ("stochrock", "StochasticRock-v0", {}), ("tag", "Tag-v0", {}), ("tiger", "Tiger-v0", {}), ("network", "Network-v0", {})):
+    if len(sys.argv) > 3 and name not in sys.argv[3].split(","):
+        continue
     e = gpa.make(env_id, batch_size=n, seed=0, reuse_buffers=True, **kw)
     e.reset()
     ring = []
