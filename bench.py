@@ -319,6 +319,8 @@ def measured_traffic(env_key, chained=False, fused=False):
     with open(path) as f:
         t = json.load(f)
     key = "fused" if fused and "fused" in t else ("chain" if chained and "chain" in t else "plain")
+    if key not in t:
+        return None, None
     return t[key]["hbm_bytes_per_launch"], "recorded, not measured in this run: profiles/%s [%s]" % (name, key)
 
 

@@ -13,6 +13,7 @@ struct BattleShipEnv {
     static constexpr const char *NAME = MW == 1 ? "BattleShipEnv<1>" : MW == 2 ? "BattleShipEnv<2>" : MW == 3 ? "BattleShipEnv<3>" : "BattleShipEnv<4>";
     static constexpr bool POOLED_LPT2 = false;
     static constexpr bool QUAD_STEP = false;   // pomdp_kernels.hip: step_quad_kernel
+    static constexpr bool HAS_ROCKS = false;   // a bounded History keeps a window of transitions for this env (history_push)
     static constexpr bool POOLED_ANY_LPT = false;
     static constexpr bool QUAD_SENSOR = false;
     struct Shared { int unused; };

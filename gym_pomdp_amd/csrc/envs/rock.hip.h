@@ -30,6 +30,7 @@ struct RockEnv {
     static constexpr const char *NAME = STOCH ? (W == 1 ? "StochasticRockEnv<1>" : "StochasticRockEnv<2>") : (W == 1 ? "RockEnv<1>" : "RockEnv<2>");
     static constexpr bool POOLED_LPT2 = !STOCH;   // pomdp_kernels.hip: Finisher<RockEnv, 2, .>
     static constexpr bool QUAD_STEP = true;   // pomdp_kernels.hip: step_quad_kernel
+    static constexpr bool HAS_ROCKS = true;   // a bounded History keeps a window of transitions for this env (history_push)
     static constexpr bool POOLED_ANY_LPT = !STOCH; // ... and for any other number of lanes per thread >= 2
     static constexpr bool STOCHASTIC = STOCH;
     static constexpr bool QUAD_TAB = true;        // pomdp_kernels.hip: steps_quad_kernel (RockEnv and StochasticRockEnv)

@@ -12,6 +12,7 @@ struct TagEnv {
     static constexpr const char *NAME = "TagEnv";
     static constexpr bool POOLED_LPT2 = true;     // pomdp_kernels.hip: Finisher<TagEnv, 2, .>
     static constexpr bool QUAD_STEP = false;   // pomdp_kernels.hip: step_quad_kernel
+    static constexpr bool HAS_ROCKS = false;   // a bounded History keeps a window of transitions for this env (history_push)
     static constexpr bool POOLED_ANY_LPT = false;
     static constexpr bool QUAD_SENSOR = false;
     // The T-shaped board never changes (tag.py:36-78): two small LDS tables replace the coordinate arithmetic of the

@@ -12,6 +12,7 @@ struct TigerEnv {
     static constexpr const char *NAME = "TigerEnv";
     static constexpr bool POOLED_LPT2 = false;
     static constexpr bool QUAD_STEP = false;   // pomdp_kernels.hip: step_quad_kernel
+    static constexpr bool HAS_ROCKS = false;   // a bounded History keeps a window of transitions for this env (history_push)
     static constexpr bool POOLED_ANY_LPT = false;
     static constexpr bool QUAD_SENSOR = false;
     static constexpr bool QUAD_FUSED = true;      // pomdp_kernels.hip: steps_quad_generic_kernel

@@ -695,11 +695,14 @@ static __device__ __forceinline__ void history_check_sums(const pomdp_history &h
 // max_size + 1 rows, `head` = the row the next transition goes to, which holds the OLDEST one once the ring is full:
 // the reference pops element 0 when size > max_size and then appends, so the list settles at max_size + 1 records) and,
 // for RockSample (K > 0), the two per-rock sums kept current as transitions enter and leave the window.
+// RING = false: the caller knows there is no window to keep (an unbounded history, or an env without rocks) — the
+// heuristic loop is instantiated both ways so that the unbounded history does not carry the window's registers and branches.
+template <bool RING = true>
 static __device__ __forceinline__ void history_push(const pomdp_history &h, int K, int a, int next_ob, int prev_ob, int64_t n,
                                                     uint32_t i, int &hsize, int &head, uint32_t &mv)
 {
     const int W = h.max_size + 1;                                              // 0: unbounded
-    if (W > 0 && K > 0) {
+    if (RING && W > 0 && K > 0) {
         uint8_t *slot = h.ring + (int64_t)head * n + i;
         if (hsize == W) {                                                      // self._history.pop(0)
             const uint32_t old = *slot;
@@ -833,7 +836,7 @@ static __device__ __forceinline__ uint32_t quad_bcast(uint32_t v)     // v of la
 // state, its history words (size, last action / observation, prev_ob), the two derived words and the running return stay
 // in registers and are written back once; the per-rock arrays are read and written in place when a CHECK touches them;
 // every step's action / ob / reward / done (and state) is written as the single-step launches write them.
-template <class Env>
+template <class Env, bool RING>   // RING: a bounded RockSample history (history_push keeps its window)
 __global__ __launch_bounds__(BLOCK) void heuristic_steps_kernel(const typename Env::Params p, uint32_t *__restrict__ state,
                                                                 pomdp_rock_belief b, pomdp_history h, int K, pomdp_returns R,
                                                                 int32_t *__restrict__ prev_ob, int32_t *__restrict__ action,
@@ -851,7 +854,7 @@ __global__ __launch_bounds__(BLOCK) void heuristic_steps_kernel(const typename E
     // every per-lane word first (one memory latency), then the tables
     typename Env::State st;
     Env::load(st, state, n, i);
-    int hsize = ld_stream(h.size + i), pob = ld_stream(prev_ob + i), head = h.head ? ld_stream(h.head + i) : 0;
+    int hsize = ld_stream(h.size + i), pob = ld_stream(prev_ob + i), head = RING ? ld_stream(h.head + i) : 0;
     int la = ld_stream(h.last_action + i), lo = ld_stream(h.last_ob + i);
     uint32_t ck = K ? ld_stream(b.check_ok + i) : 0u, mv = K ? ld_stream(h.move_ok + i) : 0u;
     bool was_done = auto_reset ? false : (ld_stream(done + i) != 0);
@@ -860,6 +863,7 @@ __global__ __launch_bounds__(BLOCK) void heuristic_steps_kernel(const typename E
     stage_policy_tables<Env>(sh, p);
     __syncthreads();
     bool ever_fresh = false;
+    const int hcap = h.max_size >= 0 ? h.max_size + 1 : 0x7FFFFFFF;            // len(history) stops there (rock.py:541-544)
     const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo;
     const uint32_t e = lane & 3u;
     // Random words four steps at a time, as in the rollout kernel: the policy's ACTION block is shared by the four lanes
@@ -923,10 +927,17 @@ __global__ __launch_bounds__(BLOCK) void heuristic_steps_kernel(const typename E
                     hsize = 0; la = -1; lo = -1; head = 0;
                     pob = Env::reset_ob(p, st);
                 } else {
-                    history_push(h, K, a, o, pob, n, i, hsize, head, mv);      // a terminal transition is recorded too
-                    la = a; lo = o;
-                    if (a >= 5 && a < 5 + K && o != 0 && !d)                   // K > 0: RockSample CHECK
-                        heuristic_belief_update<Env>(sh, p, st, a, o, b, n, i, ck);
+                    la = a; lo = o;                                            // a terminal transition is recorded too
+                    if constexpr (RING) {
+                        history_push<true>(h, K, a, o, pob, n, i, hsize, head, mv);
+                        if (a >= 5 && a < 5 + K && o != 0 && !d) heuristic_belief_update<Env>(sh, p, st, a, o, b, n, i, ck);
+                    } else {                                                   // no window: history_push<false>, one CHECK branch
+                        hsize += (int)(hsize != hcap);
+                        if (a >= 5 && a < 5 + K) {                             // K > 0: RockSample CHECK
+                            history_check_sums(h, a - 5, o, pob == 1, n, i, mv);
+                            if (o != 0 && !d) heuristic_belief_update<Env>(sh, p, st, a, o, b, n, i, ck);
+                        }
+                    }
                     pob = o;
                 }
                 was_done = auto_reset ? false : (d != 0);
@@ -942,7 +953,7 @@ __global__ __launch_bounds__(BLOCK) void heuristic_steps_kernel(const typename E
     st_stream(h.size + i, (int32_t)hsize); st_stream(h.last_action + i, (int32_t)la); st_stream(h.last_ob + i, (int32_t)lo);
     st_stream(prev_ob + i, (int32_t)pob);
     if (K) { st_stream(b.check_ok + i, ck); st_stream(h.move_ok + i, mv); }
-    if (h.head) st_stream(h.head + i, (int32_t)head);
+    if (RING) st_stream(h.head + i, (int32_t)head);                            // without a window `head` never moves
     if (R.ret) { R.ret[i] = ret; R.disc[i] = disc; }
 }
 
@@ -1733,7 +1744,7 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_generic_kernel(uint32_t *__r
 }
 
 // Smallest batch each quad-per-thread loop takes (1024 lanes per workgroup).  Measured on MI355X, us per fused step at
-// 2^17 / 2^18 / 2^19 / 2^20 lanes (profiles/r02_small_shards_gates.txt, r02c_small_shards.txt): RockSample(7,8) quad 1.50 /
+// 2^17 / 2^18 / 2^19 / 2^20 lanes (profiles/r02_small_shards_gates.txt, r02e_small_shards.txt): RockSample(7,8) quad 1.50 /
 // 1.52 / 1.82 / 2.89 against 1.25 / 1.39 / 1.99 with one or two lanes per thread; Tag (table-driven) 1.59 / 1.61 / 1.83 /
 // 2.67 against 0.96 / 1.43 / 2.00; Tiger 0.67 / 0.72 / 1.26 / 2.82 against 0.55 / 0.83 / 1.52; Network 2.30 / 2.30 / 2.91 /
 // 4.72 against 1.45 / 1.94 / 3.32 / 5.99 — below these sizes every kernel is bound by the latency of one wave's step
@@ -1963,9 +1974,18 @@ static int launch_heuristic_steps(const typename Env::Params &p, uint32_t *state
     constexpr int64_t FUSE_MAX = 64;                      // steps per launch
     for (int64_t s = 0; s < k_steps; s += FUSE_MAX) {
         const int c = (int)(k_steps - s < FUSE_MAX ? k_steps - s : FUSE_MAX);
-        hipLaunchKernelGGL(heuristic_steps_kernel<Env>, dim3(blocks_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, p, state,
-                           b ? *b : NO_BELIEF, *h, K, returns ? *returns : NO_RETURNS, prev_ob, action, ob,
-                           (typename Env::Reward *)reward, done, n, make_key(seed, t0 + (uint64_t)s), lane0, flags, c);
+        bool ring = false;
+        if constexpr (Env::HAS_ROCKS) ring = h->max_size >= 0 && K > 0 && h->ring && h->head;
+        if constexpr (Env::HAS_ROCKS) {
+            if (ring)
+                hipLaunchKernelGGL((heuristic_steps_kernel<Env, true>), dim3(blocks_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, p,
+                                   state, b ? *b : NO_BELIEF, *h, K, returns ? *returns : NO_RETURNS, prev_ob, action, ob,
+                                   (typename Env::Reward *)reward, done, n, make_key(seed, t0 + (uint64_t)s), lane0, flags, c);
+        }
+        if (!ring)
+            hipLaunchKernelGGL((heuristic_steps_kernel<Env, false>), dim3(blocks_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, p,
+                               state, b ? *b : NO_BELIEF, *h, K, returns ? *returns : NO_RETURNS, prev_ob, action, ob,
+                               (typename Env::Reward *)reward, done, n, make_key(seed, t0 + (uint64_t)s), lane0, flags, c);
         const int rc = (int)hipGetLastError();
         if (rc) return rc;
     }

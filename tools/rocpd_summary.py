@@ -46,12 +46,13 @@ def traffic_json(root, out_path, workload):
            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of `python bench.py --prewarm 0 "
                      "--warmup 64 --steps 640 --no-cpu-baseline` (tools/gpu_profile_round.sh); `fused` = one 64-step "
                      "steps_quad_kernel / steps_kernel launch, `chain` / `plain` = one single-step launch"}
-    for key, pat in (("plain", "%step_kernel<%>, _, false>(%"), ("chain", "%step_kernel<%>, _, true>(%"),
-                     ("fused", "%steps%kernel<%")):
+    # `plain`: what env.step() launches — step_quad_kernel for the RockSample family at this size, else step_kernel<., ., false>
+    for key, pat, pat2 in (("plain", "%step_kernel<%>, _, false>(%", "%step_quad_kernel<%"),
+                           ("chain", "%step_kernel<%>, _, true>(%", ""), ("fused", "%steps%kernel<%", "")):
         vals = []
         for db, cn in ((f, "FETCH_SIZE"), (w, "WRITE_SIZE")):
             r = sqlite3.connect(db).execute("select avg(value), count(*) from counters_collection where counter_name=? "
-                                            "and kernel_name like ?", (cn, pat)).fetchone()
+                                            "and (kernel_name like ? or kernel_name like ?)", (cn, pat, pat2)).fetchone()
             vals.append(r)
         if vals[0][0] is None:
             continue
