@@ -1171,7 +1171,8 @@ static __device__ __forceinline__ u32x4 first_actions4(uint32_t *action_row0, in
 // 4-byte store of the packed done bytes per step instead of twenty scalar stores; state and first actions come in the
 // same way.  The lane step is the table-driven one; resets are pooled per wave as in Finisher<RockEnv> (pooling them over the workgroup's four
 // waves instead — one pass at 80 % of its width where four run at 20 % — costs two barriers per step and measured 3.21 against
-// 2.85 us per step: the loop lives on its waves drifting apart).  Full workgroups
+// 2.85 us per step: the loop lives on its waves drifting apart; two quads per thread — half as many waves, each reset pass
+// twice as full — 3.58 against 2.80).  Full workgroups
 // of 1024 lanes and auto-reset only (the launcher's SIMPLE conditions).  Same results as steps_kernel: the mapping of lanes
 // to threads is invisible to a lane's random words.
 template <class Env>
