@@ -553,7 +553,9 @@ def main():
                              "kernel": "step_kernel<%s, chain> (the same steps, one launch each)" % args.env,
                              "kernel_ms": chain1_ms, "achieved": bytes_per_step * n / (chain1_ms * 1e-3) / 1e9,
                              "frac": bytes_per_step * n / (chain1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-                         "plain_step_kernel": {"kernel": "step_kernel<%s> (what env.step() launches)" % args.env,
+                         "plain_step_kernel": {"kernel": "%s<%s> (what env.step() launches)" % (
+                             "step_quad_kernel" if args.env in ("rock", "rock15", "stochrock") and n >= (1 << 19) and n % 1024 == 0
+                             else "step_kernel", args.env),
                                                "kernel_ms": plain_ms, "achieved": plain_achieved,
                                                "frac": plain_achieved / HBM_PEAK_GBS},
                          "note": "kernel_ms: HIP events on the launch stream around each timed region of %d back-to-back "
