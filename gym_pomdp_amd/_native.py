@@ -15,7 +15,7 @@ SOURCES = [os.path.join(_PKG, "csrc", f) for f in ("pomdp_kernels.hip", "envs.hi
                                                    "envs/rock.hip.h", "envs/tag.hip.h", "envs/battleship.hip.h",
                                                    "envs/tiger.hip.h", "envs/network.hip.h")]
 HEADER = os.path.join(_REPO, "include", "pomdp_hip.h")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 POMDP_AUTO_RESET = 1
 POMDP_FUSE_STEPS = 2
@@ -27,7 +27,7 @@ SYMBOLS = [
     "pomdp_abi_version", "pomdp_error_string", "pomdp_last_fused_kernel",
     "pomdp_rock_reset", "pomdp_rock_step", "pomdp_tag_reset", "pomdp_tag_step",
     "pomdp_battleship_reset", "pomdp_battleship_step", "pomdp_tiger_reset", "pomdp_tiger_step",
-    "pomdp_network_reset", "pomdp_network_step", "pomdp_step", "pomdp_step_sync", "pomdp_stream_sync", "pomdp_synthetic_actions", "pomdp_philox_blocks",
+    "pomdp_network_reset", "pomdp_network_step", "pomdp_step", "pomdp_step_sync", "pomdp_reset_sync", "pomdp_stream_sync", "pomdp_synthetic_actions", "pomdp_philox_blocks",
     "pomdp_rollout_synthetic", "pomdp_collect_synthetic", "pomdp_collect", "pomdp_legal_actions", "pomdp_rollout", "pomdp_compute_prob",
     "pomdp_rock_belief_reset", "pomdp_rock_belief_refresh", "pomdp_rock_belief_update", "pomdp_rock_select_target", "pomdp_history_clear",
     "pomdp_history_append", "pomdp_preferred_actions", "pomdp_pick_actions", "pomdp_heuristic_steps",
@@ -140,6 +140,8 @@ def lib():
     L.pomdp_stream_sync.argtypes = [vp]
     L.pomdp_step_sync.restype = ci
     L.pomdp_step_sync.argtypes = [vp, vp, u64, vp]
+    L.pomdp_reset_sync.restype = ci
+    L.pomdp_reset_sync.argtypes = [ci, vp, vp, vp, i64, u64, u32, u64, vp]
     L.pomdp_synthetic_actions.restype = ci
     L.pomdp_synthetic_actions.argtypes = [vp, i64, u64, u32, u64, u32, vp]
     L.pomdp_rollout_synthetic.restype = ci

@@ -9,6 +9,7 @@
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC (see __graft_entry__.build()).
 #include <hip/hip_runtime.h>
+#include <chrono>
 
 #include "../../include/pomdp_hip.h"
 #include "envs.hip.h"
@@ -48,7 +49,8 @@ constexpr int64_t STEP_QUAD_MIN_LANES = 1 << 19;
 // ---------------------------------------------------------------------------
 template <class Env>
 __global__ __launch_bounds__(BLOCK) void reset_kernel(const typename Env::Params p, uint32_t *__restrict__ state,
-                                                      int32_t *__restrict__ ob, int64_t n, RngKey key, uint32_t lane0)
+                                                      int32_t *__restrict__ ob, int64_t n, RngKey key, uint32_t lane0,
+                                                      uint32_t *__restrict__ host_flag = nullptr, uint32_t flag_value = 0)
 {
     __shared__ typename Env::Shared sh;
     Env::stage(sh, p, (int)threadIdx.x);
@@ -59,6 +61,8 @@ __global__ __launch_bounds__(BLOCK) void reset_kernel(const typename Env::Params
         const int o = Env::reset(sh, p, st, key, lane0 + (uint32_t)i);
         Env::store(st, state, n, i, true);
         if (ob) ob[i] = o;
+        // scalar mode (n == 1, `ob` in pinned host memory): see step_kernel
+        if (host_flag && i == 0) __hip_atomic_store(host_flag, flag_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -331,7 +335,8 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(uint32_t *__restrict__ stat
                                                      int32_t *__restrict__ ob, typename Env::Reward *__restrict__ reward,
                                                      uint8_t *__restrict__ done, uint32_t *__restrict__ err,
                                                      int64_t n, RngKey key, uint32_t lane0, int flags, RngKey akey,
-                                                     const typename Env::Params p)   // pointers first: what a wave needs first
+                                                     const typename Env::Params p,   // pointers first: what a wave needs first
+                                                     uint32_t *__restrict__ host_flag = nullptr, uint32_t flag_value = 0)
 {
     __shared__ typename Env::Shared sh;
     TL(0);
@@ -415,6 +420,10 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(uint32_t *__restrict__ stat
             if (!valid[j] && !was_done[j] && err) atomicAdd(err, 1u);
         }
     }
+    // scalar mode (n == 1, outputs in pinned host memory): lane 0 wrote everything the host reads; publish it with a
+    // system-scope release so that the host can poll `host_flag` instead of waiting for the end-of-kernel signal
+    if (host_flag && blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_store(host_flag, flag_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 #ifdef POMDP_DEV_TIMELINE
     TL(4);
     __builtin_amdgcn_s_waitcnt(0);
@@ -1082,14 +1091,21 @@ static inline RngKey make_key(uint64_t seed, uint64_t t)
 
 static inline bool bad_range(int64_t n, uint32_t lane0) { return n < 0 || (uint64_t)lane0 + (uint64_t)n > (1ull << 32); }
 
+// pomdp_step_sync / pomdp_reset_sync (scalar mode): the flag the next one-lane launch publishes its outputs through;
+// the launcher that takes it sets the pointer back to null
+static thread_local uint32_t *tl_host_flag = nullptr;
+static thread_local uint32_t tl_flag_value = 0;
+
 template <class Env>
 static int launch_reset(const typename Env::Params &p, uint32_t *state, int32_t *ob, int64_t n, uint64_t seed,
                         uint32_t lane0, uint64_t t, void *stream)
 {
     if (!state || bad_range(n, lane0)) return POMDP_E_BADARG;
     if (n == 0) return 0;
+    uint32_t *flag = nullptr;
+    if (n == 1 && ob && tl_host_flag) { flag = tl_host_flag; tl_host_flag = nullptr; }
     hipLaunchKernelGGL(reset_kernel<Env>, dim3(blocks_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, p, state, ob, n,
-                       make_key(seed, t), lane0);
+                       make_key(seed, t), lane0, flag, tl_flag_value);
     return (int)hipGetLastError();
 }
 
@@ -1125,8 +1141,10 @@ static int launch_step(const typename Env::Params &p, uint32_t *state, const int
             return (int)hipGetLastError();
         }
     }
+    uint32_t *flag = nullptr;
+    if (n == 1 && tl_host_flag) { flag = tl_host_flag; tl_host_flag = nullptr; }
     hipLaunchKernelGGL((step_kernel<Env, 1>), dim3(blocks_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, state,
-                       action, ob, reward, done, err, n, make_key(seed, t), lane0, flags, RngKey(), p);
+                       action, ob, reward, done, err, n, make_key(seed, t), lane0, flags, RngKey(), p, flag, tl_flag_value);
     return (int)hipGetLastError();
 }
 
@@ -2168,10 +2186,62 @@ int pomdp_step(const pomdp_step_args *a, const int32_t *action, uint64_t t, void
     }
 }
 
+// Scalar mode (one lane, outputs in pinned host memory): the kernel publishes its outputs through a flag in pinned host
+// memory with a system-scope release and the host polls the flag — the wake-up of a blocking synchronisation is most of
+// a scalar step otherwise.  The stream stays ordered, so the next launch needs no wait.  Anything else, or a flag that
+// does not show up within a millisecond (a failed launch), takes hipStreamSynchronize.
+struct ScalarWait {
+    uint32_t *flag = nullptr;
+    uint32_t seq = 0;
+    bool arm(int64_t n)
+    {
+        if (n != 1) return false;
+        if (!flag) {
+            if (hipHostMalloc((void **)&flag, 64, hipHostMallocDefault) != hipSuccess) { flag = nullptr; return false; }
+            *flag = 0;
+        }
+        tl_host_flag = flag; tl_flag_value = ++seq;
+        return true;
+    }
+    int wait(bool armed, int rc, void *stream)
+    {
+        const bool taken = armed && tl_host_flag == nullptr;   // the launcher passed the flag to its kernel
+        tl_host_flag = nullptr;
+        if (rc) return rc;
+        if (taken) {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (uint32_t spins = 0;; ++spins) {
+                if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return 0;
+                if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(1)) break;
+            }
+        }
+        return (int)hipStreamSynchronize((hipStream_t)stream);
+    }
+};
+static thread_local ScalarWait tl_scalar_wait;
+
 int pomdp_step_sync(const pomdp_step_args *a, const int32_t *action, uint64_t t, void *stream)
 {
-    const int rc = pomdp_step(a, action, t, stream);
-    return rc ? rc : (int)hipStreamSynchronize((hipStream_t)stream);
+    const bool armed = a && tl_scalar_wait.arm(a->n);
+    return tl_scalar_wait.wait(armed, pomdp_step(a, action, t, stream), stream);
+}
+
+int pomdp_reset_sync(int env, const void *params, uint32_t *state, int32_t *ob, int64_t n, uint64_t seed, uint32_t lane0,
+                     uint64_t t, void *stream)
+{
+    if (!params) return POMDP_E_BADARG;
+    const bool armed = tl_scalar_wait.arm(n);
+    int rc;
+    switch (env) {
+    case POMDP_ENV_ROCK: rc = pomdp_rock_reset((const pomdp_rock_params *)params, state, ob, n, seed, lane0, t, stream); break;
+    case POMDP_ENV_TAG: rc = pomdp_tag_reset((const pomdp_tag_params *)params, state, ob, n, seed, lane0, t, stream); break;
+    case POMDP_ENV_BATTLESHIP:
+        rc = pomdp_battleship_reset((const pomdp_battleship_params *)params, state, ob, n, seed, lane0, t, stream); break;
+    case POMDP_ENV_TIGER: rc = pomdp_tiger_reset((const pomdp_tiger_params *)params, state, ob, n, seed, lane0, t, stream); break;
+    case POMDP_ENV_NETWORK: rc = pomdp_network_reset((const pomdp_network_params *)params, state, ob, n, seed, lane0, t, stream); break;
+    default: rc = POMDP_E_BADARG;
+    }
+    return tl_scalar_wait.wait(armed, rc, stream);
 }
 
 int pomdp_stream_sync(void *stream) { return (int)hipStreamSynchronize((hipStream_t)stream); }

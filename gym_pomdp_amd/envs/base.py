@@ -180,10 +180,10 @@ class BatchedEnv(object):
         t = self._t
         self._t += 1
         if self.batch_size == 1 and torch._C._cuda_getDevice() == self._dev_index:
-            # scalar mode: the observation goes straight to pinned host memory; launch, wait, read
-            stream = torch._C._cuda_getCurrentRawStream(self._dev_index)
-            rc = self._reset_fn(self._params_ref, self._ptrs[0], self._host_ptrs[0], 1, self._seed, self.lane_offset, t, stream)
-            _native.check(rc or self._lib.pomdp_stream_sync(stream), "pomdp_%s_reset" % self.env_name)
+            # scalar mode: the observation goes straight to pinned host memory; launch and wait in one FFI call, read
+            rc = self._lib.pomdp_reset_sync(self._step_args.env, self._params_ref, self._ptrs[0], self._host_ptrs[0], 1, self._seed,
+                                            self.lane_offset, t, torch._C._cuda_getCurrentRawStream(self._dev_index))
+            _native.check(rc, "pomdp_%s_reset" % self.env_name)
             self._host_out[2] = 0
             if self._tracker is not None:
                 self._tracker.on_reset()

@@ -13,7 +13,7 @@
  *
  * Conventions
  *   - every pointer marked "device" is HBM the caller owns (e.g. a torch tensor's
- *     data_ptr()); the library never allocates or frees, and never synchronises (pomdp_step_sync, which exists to do so, aside);
+ *     data_ptr()); the library never allocates or frees, and never synchronises (pomdp_step_sync / pomdp_reset_sync / pomdp_stream_sync, which exist to do so, aside);
  *   - `state` is struct-of-arrays: uint32 [words][n], word-major, lane i at state[w*n + i];
  *   - params structs are read on the host at call time and passed to the kernel
  *     by value (kernarg) — they may live on the caller's stack;
@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define POMDP_ABI_VERSION 8
+#define POMDP_ABI_VERSION 9
 
 enum {
     POMDP_E_BADARG = -1,     /* NULL pointer, n < 0, n + lane0 > 2^32 */
@@ -183,11 +183,18 @@ typedef struct pomdp_step_args {
     uint32_t  reserved;
 } pomdp_step_args;
 int pomdp_step(const pomdp_step_args *args, const int32_t *action, uint64_t t, void *stream);
-/* pomdp_step followed by hipStreamSynchronize(stream) — the ONE entry point of this library that blocks.  For hosts that
- * step a single env the way the reference is used (python scalars in and out, batch of 1, ob / reward / done pointing at
- * pinned host memory): launch and wait cost one FFI call instead of two plus a stream object. */
+/* pomdp_step, then wait until its outputs can be read by the host — with pomdp_reset_sync / pomdp_stream_sync the only
+ * entry points of this library that block.  For hosts that step a single env the way the reference is used (python
+ * scalars in and out, batch of 1, ob / reward / done pointing at PINNED HOST memory): launch and wait cost one FFI call.
+ * With n == 1 the kernel publishes its outputs through a flag in pinned host memory (system-scope release) that the host
+ * polls, so the call returns as soon as the outputs are visible; the stream stays ordered and later launches need no
+ * further wait.  With n != 1 it is pomdp_step followed by hipStreamSynchronize(stream). */
 int pomdp_step_sync(const pomdp_step_args *args, const int32_t *action, uint64_t t, void *stream);
-/* hipStreamSynchronize(stream) by itself, for the same hosts (after a pomdp_<env>_reset whose `ob` points at host memory) */
+/* pomdp_<env>_reset (env: POMDP_ENV_*, params: its pomdp_<env>_params) followed by the same wait; `ob` in pinned host
+ * memory when n == 1 */
+int pomdp_reset_sync(int env, const void *params, uint32_t *state, int32_t *ob, int64_t n, uint64_t seed, uint32_t lane0,
+                     uint64_t t, void *stream);
+/* hipStreamSynchronize(stream) by itself */
 int pomdp_stream_sync(void *stream);
 
 /* ---- helpers ---------------------------------------------------------------- */

@@ -401,6 +401,40 @@ def test_network_ansi_render(capsys):
     assert out.startswith("N: ") and out.endswith("M: 2 A: 1")
 
 
+@pytest.mark.parametrize("env", ["rock", "tag", "battleship", "tiger", "network"])
+def test_scalar_loop_equals_the_batched_path_and_sync_entry_points(env, oracle_lib):
+    """batch_size=1 (pomdp_step_sync / pomdp_reset_sync: outputs in pinned host memory, published through a polled flag) over
+    a few hundred steps with resets in between against the oracle, step for step; and pomdp_reset_sync on a batch (n != 1:
+    launch + hipStreamSynchronize) against reset()."""
+    from gym_pomdp_amd import _native
+    seed = 41
+    e = make_env(env, {}, seed=seed)
+    o = oracle_lib.OracleEnv(env)
+    st = o.new_state(1)
+    rs = np.random.RandomState(3)
+    t = 0
+    assert e.reset() == int(o.batch_reset(st, seed, 0, t)[0])
+    for _ in range(300):
+        t += 1
+        a = int(rs.randint(o.n_actions))
+        ob, rew, done, bad = o.batch_step(st, np.array([a], np.int32), seed, 0, t, auto_reset=False, done=np.zeros(1, np.uint8))
+        ob_g, rew_g, done_g, _ = e.step(a)
+        assert (ob_g, float(rew_g), bool(done_g)) == (int(ob[0]), float(rew[0]), bool(done[0])), (env, t)
+        if done_g:
+            t += 1
+            assert e.reset() == int(o.batch_reset(st, seed, 0, t)[0]), (env, t)
+    n = 4096
+    b = make_env(env, {}, batch_size=n, seed=seed, reuse_buffers=True)
+    ob_ref = b.reset().clone()
+    st_ref = b.state.clone()
+    b.state.zero_()
+    ob2 = torch.full((n,), -7, dtype=torch.int32, device="cuda")
+    rc = _native.lib().pomdp_reset_sync(_native.ENV_KIND[env], b._params_ref, b._state.data_ptr(), ob2.data_ptr(), n, seed, 0, 0, None)
+    _native.check(rc, "pomdp_reset_sync")
+    assert torch.equal(ob2, ob_ref) and torch.equal(b.state, st_ref)
+    assert _native.lib().pomdp_reset_sync(99, b._params_ref, b._state.data_ptr(), ob2.data_ptr(), n, seed, 0, 0, None) == -1
+
+
 def test_scalar_planner_hooks():
     e = make_env("rock", {}, seed=5)
     e.reset()
