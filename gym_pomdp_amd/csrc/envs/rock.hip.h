@@ -260,15 +260,26 @@ struct RockEnv {
         alive = (uint32_t)spread;                                      // K <= 16 rocks: 32 bits
         return n_pre + __popc(alive);
     }
-    static __device__ __forceinline__ int legal_nth(const Shared &sh, const Params &p, const State &st, int idx)
+    // the legal list in the form both its length and its idx-th entry come from: computed once per step by the loops that
+    // need both (the rollout kernel)
+    struct Legal { uint32_t pre, alive; int n_pre, count; };
+    static __device__ __forceinline__ Legal legal_set(const Shared &sh, const Params &p, const State &st)
     {
-        uint32_t pre, alive; int n_pre;
-        legal_count(sh, p, st, pre, n_pre, alive);
-        if (idx < n_pre) return (int)((pre >> (3 * idx)) & 7u);
+        Legal L;
+        L.count = legal_count(sh, p, st, L.pre, L.n_pre, L.alive);
+        return L;
+    }
+    static __device__ __forceinline__ int legal_pick(const Shared &sh, const Legal &L, int idx)
+    {
+        if (idx < L.n_pre) return (int)((L.pre >> (3 * idx)) & 7u);
         // rock j sits at bit 2 j of `alive`: the (idx - n_pre)-th set bit, without a data-dependent loop
-        const int j = nth_set_bit(alive, idx - n_pre) >> 1;
+        const int j = nth_set_bit(L.alive, idx - L.n_pre) >> 1;
         const uint32_t rxy = sh.rxy[j & 15];
         return 5 + sh.grid[(rxy & 15u) * 16 + (rxy >> 4)];
+    }
+    static __device__ __forceinline__ int legal_nth(const Shared &sh, const Params &p, const State &st, int idx)
+    {
+        return legal_pick(sh, legal_set(sh, p, st), idx);
     }
     static __device__ __forceinline__ int legal_count(const Shared &sh, const Params &p, const State &st)
     {

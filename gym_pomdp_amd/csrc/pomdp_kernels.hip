@@ -838,6 +838,25 @@ static __device__ __forceinline__ uint32_t quad_bcast(uint32_t v)     // v of la
 {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, J * 0x55, 0xF, 0xF, false);
 }
+// 4 x 4 transpose within a quad: lane e of the quad passes the four words of ITS block and gets word e of the blocks of
+// lanes 0, 1, 2, 3 (t.x .. t.w).  The fused rollout and heuristic loops let lane e of a quad compute the quad-shared block
+// of step base + e; step base + J then reads component J of the result — compile-time — where four broadcasts and a
+// per-lane select per step cost twice as much.  Two butterfly stages (partner e ^ 1, then e ^ 2): each lane first
+// selects the two words its partner lacks, so a stage is 2 selects + 2 DPP moves + 4 selects.
+static __device__ __forceinline__ uint4 quad_transpose4(const uint4 &v, uint32_t e)
+{
+    const bool b0 = e & 1u, b1 = e & 2u;
+    const uint32_t s0 = b0 ? v.x : v.y, s1 = b0 ? v.z : v.w;
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s0, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+    const uint32_t r1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s1, 0xB1, 0xF, 0xF, false);
+    // column (e & 1) / 2 + (e & 1) of the rows (e & ~1, e | 1)
+    const uint32_t p0 = b0 ? r0 : v.x, p1 = b0 ? v.y : r0, q0 = b0 ? r1 : v.z, q1 = b0 ? v.w : r1;
+    const uint32_t u0 = b1 ? p0 : q0, u1 = b1 ? p1 : q1;
+    const uint32_t w0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)u0, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    const uint32_t w1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)u1, 0x4E, 0xF, 0xF, false);
+    return make_uint4(b1 ? w0 : p0, b1 ? w1 : p1, b1 ? q0 : w0, b1 ? q1 : w1);
+}
+template <int J> static __device__ __forceinline__ uint32_t comp(const uint4 &v) { return J == 0 ? v.x : J == 1 ? v.y : J == 2 ? v.z : v.w; }
 
 // k heuristic-policy steps in one launch: per step choice(_generate_preferred(history)) -> step -> side statistics ->
 // history.append, i.e. preferred_kernel + pick_actions_kernel + step_kernel + belief_update_kernel +
@@ -882,9 +901,9 @@ __global__ __launch_bounds__(BLOCK) void heuristic_steps_kernel(const typename E
         const uint64_t te = t0 + (uint64_t)base + (uint64_t)e;
         RngKey ke = key0;
         ke.t_lo = (uint32_t)te; ke.t_hi = (uint32_t)(te >> 32);
-        const uint4 aq = stream_block(ke, lane >> 2, POMDP_STREAM_ACTION, 0u);
+        const uint4 aq = quad_transpose4(stream_block(ke, lane >> 2, POMDP_STREAM_ACTION, 0u), e);   // .J: this lane's word of step base + J
         uint4 sq = make_uint4(0, 0, 0, 0);
-        if constexpr (Env::QUAD_SENSOR) sq = Env::quad_block(ke, lane, 0u);
+        if constexpr (Env::QUAD_SENSOR) sq = quad_transpose4(Env::quad_block(ke, lane, 0u), e);
         auto one_step = [&](auto jc) {
             constexpr int J = decltype(jc)::value;
             const int s = base + J;
@@ -892,8 +911,7 @@ __global__ __launch_bounds__(BLOCK) void heuristic_steps_kernel(const typename E
             RngKey key = key0;
             key.t_lo = (uint32_t)(t0 + (uint64_t)s); key.t_hi = (uint32_t)((t0 + (uint64_t)s) >> 32);
             // the policy: a = list[(w * len(list)) >> 32] over the preferred list (ascending mask order) or the legal list
-            const uint32_t ax = quad_bcast<J>(aq.x), ay = quad_bcast<J>(aq.y), az = quad_bcast<J>(aq.z), aw = quad_bcast<J>(aq.w);
-            const uint32_t word = e == 0 ? ax : e == 1 ? ay : e == 2 ? az : aw;
+            const uint32_t word = comp<J>(aq);
             const uint32_t m = Env::preferred_mask(sh, p, st, h, n, i, ck, mv, hsize, la, lo);
             int a;
             if (m) a = nth_set_bit(m, (int)__umulhi(word, (uint32_t)__popc(m)));
@@ -903,8 +921,7 @@ __global__ __launch_bounds__(BLOCK) void heuristic_steps_kernel(const typename E
             int o, d;
             typename Env::Reward r;
             if constexpr (Env::QUAD_SENSOR) {
-                const uint32_t hx = quad_bcast<J>(sq.x), hy = quad_bcast<J>(sq.y), hz = quad_bcast<J>(sq.z), hw = quad_bcast<J>(sq.w);
-                Env::step_with_H(sh, p, st, a, key, lane, e == 0 ? hx : e == 1 ? hy : e == 2 ? hz : hw, o, r, d);
+                Env::step_with_H(sh, p, st, a, key, lane, comp<J>(sq), o, r, d);
             } else {
                 Env::step(sh, p, st, a, key, lane, o, r, d);
             }
@@ -966,6 +983,37 @@ __global__ __launch_bounds__(BLOCK) void heuristic_steps_kernel(const typename E
     if (R.ret) { R.ret[i] = ret; R.disc[i] = disc; }
 }
 
+// _generate_legal() as the rollout loop uses it — the list's length, then its idx-th entry: envs that derive both from one
+// intermediate form (Env::Legal, Env::legal_set, Env::legal_pick) compute it once per step, the others go through
+// legal_count / legal_nth
+template <class Env, class = void> struct LegalOf {
+    struct Set { int count; };
+    static __device__ __forceinline__ Set make(const typename Env::Shared &sh, const typename Env::Params &p,
+                                               const typename Env::State &st, bool skip)
+    {
+        return Set{skip ? 0 : Env::legal_count(sh, p, st)};
+    }
+    static __device__ __forceinline__ int pick(const typename Env::Shared &sh, const typename Env::Params &p,
+                                               const typename Env::State &st, const Set &, int idx)
+    {
+        return Env::legal_nth(sh, p, st, idx);
+    }
+};
+template <class Env> struct LegalOf<Env, std::void_t<typename Env::Legal>> {
+    using Set = typename Env::Legal;
+    static __device__ __forceinline__ Set make(const typename Env::Shared &sh, const typename Env::Params &p,
+                                               const typename Env::State &st, bool skip)
+    {
+        if (skip) return Set{};
+        return Env::legal_set(sh, p, st);
+    }
+    static __device__ __forceinline__ int pick(const typename Env::Shared &sh, const typename Env::Params &,
+                                               const typename Env::State &, const Set &L, int idx)
+    {
+        return Env::legal_pick(sh, L, idx);
+    }
+};
+
 // Lane i simulates from root state column i / sims_per_root for up to `depth` steps: the state lives in registers
 // and nothing is written but the per-lane results.  Random words, four steps at a time:
 //   - the policy pick of step k is word k of the lane's ROLLOUT stream at t0: one Philox block per four steps;
@@ -1005,13 +1053,14 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(const typename Env::Para
             const uint64_t te = t0 + (uint64_t)base + (uint64_t)(lane & 3u);
             RngKey ke = key0;
             ke.t_lo = (uint32_t)te; ke.t_hi = (uint32_t)(te >> 32);
-            sq = Env::quad_block(ke, lane, 0u);
+            sq = quad_transpose4(Env::quad_block(ke, lane, 0u), lane & 3u);   // .J: this lane's word of step base + J
         }
         auto one_step = [&](auto jc) {
             constexpr int J = decltype(jc)::value;
             const int step = base + J;
             if (step >= depth || !live_wave) return;
-            const int count = all_actions ? n_act : Env::legal_count(sh, p, st);
+            const auto L = LegalOf<Env>::make(sh, p, st, all_actions != 0);
+            const int count = all_actions ? n_act : L.count;
             active = active && !d && count > 0;
             if (!__any(active)) { live_wave = false; return; }           // wave-uniform exit
             const uint64_t t = t0 + (uint64_t)step;
@@ -1019,14 +1068,12 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(const typename Env::Para
             key.t_lo = (uint32_t)t; key.t_hi = (uint32_t)(t >> 32);
             const uint32_t w = J == 0 ? pw.x : J == 1 ? pw.y : J == 2 ? pw.z : pw.w;
             const int idx = (int)__umulhi(w, (uint32_t)(count > 0 ? count : 1));
-            const int a = all_actions ? idx : Env::legal_nth(sh, p, st, idx);
+            const int a = all_actions ? idx : LegalOf<Env>::pick(sh, p, st, L, idx);
             typename Env::State nx = st;
             int o2, d2;
             double r;
             if constexpr (Env::QUAD_SENSOR) {      // every lane runs it (the broadcasts need the whole quad); inactive lanes discard
-                const uint32_t e = lane & 3u;
-                const uint32_t hx = quad_bcast<J>(sq.x), hy = quad_bcast<J>(sq.y), hz = quad_bcast<J>(sq.z), hw = quad_bcast<J>(sq.w);
-                Env::step_with_H(sh, p, nx, a, key, lane, e == 0 ? hx : e == 1 ? hy : e == 2 ? hz : hw, o2, r, d2);
+                Env::step_with_H(sh, p, nx, a, key, lane, comp<J>(sq), o2, r, d2);
             } else {
                 Env::step(sh, p, nx, a, key, lane, o2, r, d2);
             }

@@ -1,23 +1,13 @@
-#!/bin/bash
-# PMC counters for the fused rollout kernel (dev aid). usage: tools/gpu_pmc_rollout.sh [bench args]
 export TMPDIR=/tmp
 REPO=$PWD
-mkdir -p /tmp/pmc
-cd /tmp
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -d /tmp/pmc/p1 -o p1 -- python $REPO/bench.py --mode rollout --steps 5 --warmup 1 "$@" > /tmp/pmc/p1.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE -d /tmp/pmc/p2 -o p2 -- python $REPO/bench.py --mode rollout --steps 5 --warmup 1 "$@" > /tmp/pmc/p2.log 2>&1
+rm -rf /tmp/pmcr; mkdir -p /tmp/pmcr; cd /tmp
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY -d /tmp/pmcr/p1 -o p1 -- python $REPO/bench.py --env rock15 --mode rollout --lanes-per-gpu 2097152 --steps 20 --warmup 10 > /tmp/pmcr/p1.log 2>&1
 cd $REPO
-tail -1 /tmp/pmc/p1.log | cut -c1-600
 python - <<'PY'
 import sqlite3,glob
-for sub in ('p1','p2'):
-    db=glob.glob(f'/tmp/pmc/{sub}/**/*_results.db',recursive=True)
-    if not db: print('no db',sub); continue
-    c=sqlite3.connect(db[0])
-    rows=c.execute("select kernel_name, counter_name, count(*), avg(value), avg(duration) from counters_collection where kernel_name like '%rollout_kernel%' group by kernel_name, counter_name").fetchall()
-    ks={}
-    for k,cn,n,a,d in rows: ks.setdefault(k,{})[cn]=(n,a,d)
-    for k,v in ks.items():
-        print(k[:110])
-        for cn,(n,a,d) in sorted(v.items()): print('    %-22s n=%d avg=%.1f dur_ns=%.0f'%(cn,n,a,d))
+db=glob.glob('/tmp/pmcr/p1/**/*_results.db',recursive=True)
+c=sqlite3.connect(db[0])
+rows=c.execute("select kernel_name, counter_name, count(*), avg(value), avg(duration) from counters_collection where kernel_name like '%rollout%' group by kernel_name, counter_name").fetchall()
+for k,cn,n,a,d in rows: print(k[:50], cn, n, "%.1f"%a, "dur %.1f us"%(d/1e3))
 PY
+tail -1 /tmp/pmcr/p1.log | cut -c1-300
