@@ -273,7 +273,7 @@ struct RockEnv {
     {
         if (idx < L.n_pre) return (int)((L.pre >> (3 * idx)) & 7u);
         // rock j sits at bit 2 j of `alive`: the (idx - n_pre)-th set bit, without a data-dependent loop
-        const int j = nth_set_bit(L.alive, idx - L.n_pre) >> 1;
+        const int j = nth_set_bit<2>(L.alive, idx - L.n_pre) >> 1;
         const uint32_t rxy = sh.rxy[j & 15];
         return 5 + sh.grid[(rxy & 15u) * 16 + (rxy >> 4)];
     }

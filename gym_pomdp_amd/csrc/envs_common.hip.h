@@ -39,12 +39,14 @@ __device__ __forceinline__ void reset_where_chain_default(const typename Env::Sh
     next_action = synthetic_action(akey, lane, n_actions);
 }
 
-// index of the n-th (0-based) set bit of m, branch-free: a binary search on popcounts (n < popc(m))
+// index of the n-th (0-based) set bit of m, branch-free: a binary search on popcounts (n < popc(m)).  MINW = 2: m has
+// bits at even positions only (RockSample's spread rock sets), so the search stops at windows of two.
+template <int MINW = 1>
 __device__ __forceinline__ int nth_set_bit(uint32_t m, int n)
 {
     int pos = 0;
 #pragma unroll
-    for (int w = 16; w >= 1; w >>= 1) {
+    for (int w = 16; w >= MINW; w >>= 1) {
         const int c = __popc(m & ((1u << w) - 1u));
         const bool up = n >= c;
         n -= up ? c : 0;
