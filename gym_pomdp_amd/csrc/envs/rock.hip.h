@@ -527,6 +527,18 @@ struct RockEnv {
         ob = sensor_ob(sh, st, aux, H, [&]() { return elem(quad_block(key, lane, 1u), lane & 3u); });
     }
 
+    // the same from the (position, action) table (kernels that run enough steps per launch to build one: the rollouts)
+    template <class RT>
+    static __device__ __forceinline__ void step_with_H_tab(const Shared &sh, const StepTab &tab, State &st, int a, const RngKey &key,
+                                                           uint32_t lane, uint32_t H, int &ob, RT &rew, int &done)
+    {
+        Aux aux;
+        int rw;
+        step_tab(tab, st, a, rw, done, aux);
+        rew = (RT)rw;
+        ob = sensor_ob(sh, st, aux, H, [&]() { return elem(quad_block(key, lane, 1u), lane & 3u); });
+    }
+
     // The whole step for one lane (launches that do not pool the quad's sensor block: one lane per thread, rollouts).
     template <class RT>
     static __device__ __forceinline__ void step(const Shared &sh, const Params &p, State &st, int a,
