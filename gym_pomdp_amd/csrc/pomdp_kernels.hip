@@ -858,6 +858,37 @@ static __device__ __forceinline__ uint4 quad_transpose4(const uint4 &v, uint32_t
 }
 template <int J> static __device__ __forceinline__ uint32_t comp(const uint4 &v) { return J == 0 ? v.x : J == 1 ? v.y : J == 2 ? v.z : v.w; }
 
+// _generate_legal() as the rollout loop uses it — the list's length, then its idx-th entry: envs that derive both from one
+// intermediate form (Env::Legal, Env::legal_set, Env::legal_pick) compute it once per step, the others go through
+// legal_count / legal_nth
+template <class Env, class = void> struct LegalOf {
+    struct Set { int count; };
+    static __device__ __forceinline__ Set make(const typename Env::Shared &sh, const typename Env::Params &p,
+                                               const typename Env::State &st, bool skip)
+    {
+        return Set{skip ? 0 : Env::legal_count(sh, p, st)};
+    }
+    static __device__ __forceinline__ int pick(const typename Env::Shared &sh, const typename Env::Params &p,
+                                               const typename Env::State &st, const Set &, int idx)
+    {
+        return Env::legal_nth(sh, p, st, idx);
+    }
+};
+template <class Env> struct LegalOf<Env, std::void_t<typename Env::Legal>> {
+    using Set = typename Env::Legal;
+    static __device__ __forceinline__ Set make(const typename Env::Shared &sh, const typename Env::Params &p,
+                                               const typename Env::State &st, bool skip)
+    {
+        if (skip) return Set{};
+        return Env::legal_set(sh, p, st);
+    }
+    static __device__ __forceinline__ int pick(const typename Env::Shared &sh, const typename Env::Params &,
+                                               const typename Env::State &, const Set &L, int idx)
+    {
+        return Env::legal_pick(sh, L, idx);
+    }
+};
+
 // k heuristic-policy steps in one launch: per step choice(_generate_preferred(history)) -> step -> side statistics ->
 // history.append, i.e. preferred_kernel + pick_actions_kernel + step_kernel + belief_update_kernel +
 // history_append_kernel on the same call counter, with the lists never leaving registers.  Across the k steps a lane's
@@ -915,7 +946,10 @@ __global__ __launch_bounds__(BLOCK) void heuristic_steps_kernel(const typename E
             const uint32_t m = Env::preferred_mask(sh, p, st, h, n, i, ck, mv, hsize, la, lo);
             int a;
             if (m) a = nth_set_bit(m, (int)__umulhi(word, (uint32_t)__popc(m)));
-            else a = Env::legal_nth(sh, p, st, (int)__umulhi(word, (uint32_t)Env::legal_count(sh, p, st)));
+            else {
+                const auto L = LegalOf<Env>::make(sh, p, st, false);
+                a = LegalOf<Env>::pick(sh, p, st, L, (int)__umulhi(word, (uint32_t)L.count));
+            }
             const bool live = in_range && !was_done;
             const typename Env::State before = st;
             int o, d;
@@ -982,37 +1016,6 @@ __global__ __launch_bounds__(BLOCK) void heuristic_steps_kernel(const typename E
     if (RING) st_stream(h.head + i, (int32_t)head);                            // without a window `head` never moves
     if (R.ret) { R.ret[i] = ret; R.disc[i] = disc; }
 }
-
-// _generate_legal() as the rollout loop uses it — the list's length, then its idx-th entry: envs that derive both from one
-// intermediate form (Env::Legal, Env::legal_set, Env::legal_pick) compute it once per step, the others go through
-// legal_count / legal_nth
-template <class Env, class = void> struct LegalOf {
-    struct Set { int count; };
-    static __device__ __forceinline__ Set make(const typename Env::Shared &sh, const typename Env::Params &p,
-                                               const typename Env::State &st, bool skip)
-    {
-        return Set{skip ? 0 : Env::legal_count(sh, p, st)};
-    }
-    static __device__ __forceinline__ int pick(const typename Env::Shared &sh, const typename Env::Params &p,
-                                               const typename Env::State &st, const Set &, int idx)
-    {
-        return Env::legal_nth(sh, p, st, idx);
-    }
-};
-template <class Env> struct LegalOf<Env, std::void_t<typename Env::Legal>> {
-    using Set = typename Env::Legal;
-    static __device__ __forceinline__ Set make(const typename Env::Shared &sh, const typename Env::Params &p,
-                                               const typename Env::State &st, bool skip)
-    {
-        if (skip) return Set{};
-        return Env::legal_set(sh, p, st);
-    }
-    static __device__ __forceinline__ int pick(const typename Env::Shared &sh, const typename Env::Params &,
-                                               const typename Env::State &, const Set &L, int idx)
-    {
-        return Env::legal_pick(sh, L, idx);
-    }
-};
 
 // RockSample's rollouts read the lane step from the (position, action) table of the fused loops, built once per launch
 // (2.61 -> 2.73e11 steps/s on (15,15), 2.72 -> 2.80e11 on (7,8))
