@@ -322,7 +322,8 @@ struct RockEnv {
     // rock.py:293-374 _generate_preferred with use_heuristic=True, as a bitmask over actions: every list the
     // heuristic builds is in ascending action order ([SAMPLE], [EAST], or N/E/S/W then the CHECKs by rock index);
     // 0 = the heuristic produced nothing and the caller falls back to _generate_legal() (rock.py:374-375).
-    // Per-rock tests come from the two derived words b.check_ok / h.move_ok: 16 bytes per lane, whatever K is.
+    // Per-rock tests come from the two derived words b.check_ok / h.move_ok (bit j: total_move[j] >= 0, bit 16 + j:
+    // total_sample[j] > 0): 16 bytes per lane, whatever K is.
     static __device__ __forceinline__ uint32_t preferred_mask(const Shared &sh, const Params &p, const State &st,
                                                               const pomdp_rock_belief &b, const pomdp_history &h,
                                                               int64_t n, uint32_t i)
@@ -343,8 +344,10 @@ struct RockEnv {
         const S s = st.s;
         const int x = (int)(s & 15u), y = (int)((s >> 4) & 15u), K = p.num_rocks;
         const int id = sh.grid[x * 16 + y];
-        if (id >= 0 && id < K && ((uint32_t)(s >> (8 + 2 * (id & 15))) & 3u) != 1u && hsize != 0)
-            if (h.total_sample[(int64_t)id * n + i] > 0) return 1u << 4;                          // rock.py:300-313
+        // rock.py:300-313: SAMPLE when the CHECKs of the rock underfoot sum to > 0 — bit 16 + id of the derived word, no
+        // load of total_sample inside the step loop (a load there waits for every store the loop has in flight)
+        if (id >= 0 && id < K && ((uint32_t)(s >> (8 + 2 * (id & 15))) & 3u) != 1u && hsize != 0 && ((mv >> (16 + (id & 15))) & 1u))
+            return 1u << 4;
         // uncollected rocks (code != 1), bit j = rock j: spread form as in legal_count, then the even bits squeezed together
         const uint64_t r = (uint64_t)s >> 8;
         uint32_t alive = (uint32_t)(~(r & ~(r >> 1)) & 0x5555555555555555ull & ((1ull << (2 * K)) - 1ull));
@@ -352,7 +355,7 @@ struct RockEnv {
         alive = (alive | (alive >> 2)) & 0x0F0F0F0Fu;
         alive = (alive | (alive >> 4)) & 0x00FF00FFu;
         alive = (alive | (alive >> 8)) & 0x0000FFFFu;
-        const uint32_t am = alive & mv;                                                           // rock.py:335: total >= 0
+        const uint32_t am = alive & mv & 0xFFFFu;                                                 // rock.py:335: total >= 0
         if (!am) return 1u << 1;                                                                  // all_bad: rock.py:347-349
         // rock.py:338-345, per rock: north if above, else south if below, else (same row) west if left, else east if right
         const uint32_t dy = sh.dir_y[y], dx = sh.dir_x[x], same = am & sh.row[y];

@@ -681,7 +681,7 @@ __global__ __launch_bounds__(BLOCK) void select_target_kernel(const typename Env
     target[i] = Env::select_target(sh, p, st, b, n, (uint32_t)i);
 }
 
-// the two sums over CHECK-j transitions (rock.py:303-310, 327-334) and the derived bit j of move_ok: the contribution of
+// the two sums over CHECK-j transitions (rock.py:303-310, 327-334) and the derived bits j and 16 + j of move_ok: the contribution of
 // one transition (action CHECK j, next observation, observation before it) is added (sign = 1) or, when a bounded history
 // drops the transition, taken out again (sign = -1)
 static __device__ __forceinline__ void history_check_sums(const pomdp_history &h, int j, int next_ob, bool prev_bad, int64_t n,
@@ -690,7 +690,12 @@ static __device__ __forceinline__ void history_check_sums(const pomdp_history &h
     const int64_t k = (int64_t)j * n + i;
     const int ds = sign * ((next_ob == 2) - (next_ob == 1));
     const int dm = sign * (next_ob == 2 ? 1 : (prev_bad ? -1 : 0));
-    if (ds) h.total_sample[k] += ds;
+    if (ds) {                                                                  // bit 16 + j: total_sample[j] > 0 (rock.py:311)
+        const int ts = h.total_sample[k] + ds;
+        h.total_sample[k] = ts;
+        const uint32_t sbit = 0x10000u << j;
+        mv = ts > 0 ? (mv | sbit) : (mv & ~sbit);
+    }
     if (dm) {
         const int tm = h.total_move[k] + dm;
         h.total_move[k] = tm;
@@ -962,12 +967,6 @@ __global__ __launch_bounds__(BLOCK) void heuristic_steps_kernel(const typename E
             if (!live) { o = 0; r = 0; d = was_done; st = before; }
             const bool fresh = live && d && auto_reset;
             Env::reset_where(sh, p, st, fresh, key, lane);                     // wave-cooperative: every lane calls it
-            if (in_range) {
-                st_stream(action + i, (int32_t)(live ? a : -1));
-                st_stream(ob + i, (int32_t)o);
-                st_stream(reward + i, r);
-                st_stream(done + i, (uint8_t)d);
-            }
             ever_fresh |= fresh;
             if (live) {
                 if (R.ret) {                                                   // r += rw * discount; discount *= _discount
@@ -1000,8 +999,17 @@ __global__ __launch_bounds__(BLOCK) void heuristic_steps_kernel(const typename E
                     }
                     pob = o;
                 }
-                was_done = auto_reset ? false : (d != 0);
             }
+            // the step's outputs leave LAST: the per-rock sums and side statistics above are read-modify-writes, and a load
+            // waits for every store issued before it (one counter for both on gfx9) — behind these four it waited for their
+            // acknowledgements every step
+            if (in_range) {
+                st_stream(action + i, (int32_t)(live ? a : -1));
+                st_stream(ob + i, (int32_t)o);
+                st_stream(reward + i, r);
+                st_stream(done + i, (uint8_t)d);
+            }
+            if (live) was_done = auto_reset ? false : (d != 0);
         };
         one_step(std::integral_constant<int, 0>{});
         one_step(std::integral_constant<int, 1>{});

@@ -43,7 +43,7 @@ class History(object):
         from .envs.base import staggered           # one allocation, column starts spread over the HBM channels
         (self._size, self.last_action, self.last_ob, self.total_sample, self.total_move, self.move_ok) = staggered(
             [((n,), torch.int32), ((n,), torch.int32), ((n,), torch.int32), ((k, n), torch.int32), ((k, n), torch.int32),
-             ((n if k else 0,), torch.int32)], dev)                                # move_ok: derived, bit j = total_move[j] >= 0
+             ((n if k else 0,), torch.int32)], dev)                                # move_ok: derived, bit j = total_move[j] >= 0, bit 16 + j = total_sample[j] > 0
         bounded = self._max_size is not None
         self.ring = torch.zeros((self._max_size + 1, n) if bounded and k else (0, n), dtype=torch.uint8, device=dev)
         self.head = torch.zeros(n if bounded else 0, dtype=torch.int32, device=dev)

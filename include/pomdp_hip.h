@@ -328,8 +328,9 @@ int pomdp_rock_select_target(const pomdp_rock_params *p, const uint32_t *state, 
 typedef struct pomdp_history {
     int32_t *size, *last_action, *last_ob;
     int32_t *total_sample, *total_move;
-    uint32_t *move_ok;      /* [n] derived, RockSample only: bit j = total_move[j] >= 0 (the test of rock.py:335),
-                               maintained by pomdp_history_clear / _append / pomdp_heuristic_steps */
+    uint32_t *move_ok;      /* [n] derived, RockSample only: bit j = total_move[j] >= 0 (the test of rock.py:335), bit 16 + j
+                               = total_sample[j] > 0 (rock.py:311); maintained by pomdp_history_clear / _append /
+                               pomdp_heuristic_steps — _generate_preferred reads this word, not the sums */
     /* History(max_size=k) of rock.py:533-544: append() pops the oldest record once the list holds more than k, so the
      * list settles at k + 1 records and the sums above cover that window only.  max_size = -1: unbounded (the reference's
      * default; ring and head may be NULL).  0 <= max_size <= 62: `size` stops at max_size + 1; for RockSample the window

@@ -788,10 +788,10 @@ def test_heuristic_vs_oracle_at_scale(env, kw, n, T, max_size):
             w = (1 << np.arange(K, dtype=np.int64))[:, None]
             ok = (bc["measured"] < 5) & (np.abs(bc["count"]) < 2) & (bc["prob_valuable"] > 0) & (bc["prob_valuable"] < 1)
             assert np.array_equal((ok * w).sum(axis=0), np_(gpu.e._tracker.check_ok).astype(np.int64) & 0xFFFFFFFF), t
-            if max_size is None:
-                assert np.array_equal(((cpu.h.total_move >= 0) * w).sum(axis=0), np_(gpu.h.move_ok).astype(np.int64) & 0xFFFFFFFF), t
-            else:
-                assert np.array_equal(((np_(gpu.h.total_move) >= 0) * w).sum(axis=0), np_(gpu.h.move_ok).astype(np.int64) & 0xFFFFFFFF), t
+            mo = np_(gpu.h.move_ok).astype(np.int64) & 0xFFFFFFFF        # bit j: total_move[j] >= 0, bit 16 + j: total_sample[j] > 0
+            tm, ts = (cpu.h.total_move, cpu.h.total_sample) if max_size is None else (np_(gpu.h.total_move), np_(gpu.h.total_sample))
+            assert np.array_equal(((tm >= 0) * w).sum(axis=0), mo & 0xFFFF), t
+            assert np.array_equal(((ts > 0) * w).sum(axis=0), mo >> 16), t
     # (a policy that forgets its old CHECKs keeps re-measuring: with a short window no episode need end inside T steps)
     assert n_done > 0 or max_size is not None
 
