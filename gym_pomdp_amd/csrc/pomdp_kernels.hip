@@ -1348,10 +1348,12 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
                 res_lds[wv][q & 255] = Env::reset_codes(w, key, src_lane, K);
             }
         }
-        uint32_t o[4], a_next[4];
+        uint32_t o[4], a_next[4], fresh_codes[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fresh_codes[j] = res_lds[wv][rank[j] & 255];   // four reads in flight, one wait; used where d[j]
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (d[j]) st[j].s = (S)((uint64_t)start | ((uint64_t)res_lds[wv][rank[j] & 255] << 8));
+            st[j].s = d[j] ? (S)((uint64_t)start | ((uint64_t)fresh_codes[j] << 8)) : st[j].s;
             const uint32_t lane = glane0 + (uint32_t)j;
             o[j] = (uint32_t)Env::sensor_ob(sh, st[j], aux[j], H[j], [&]() { return Env::elem(Env::quad_block(key, lane, SENSOR_BLOCK + 1u), (uint32_t)j); });
             a_next[j] = __umulhi(P[j], n_act);
