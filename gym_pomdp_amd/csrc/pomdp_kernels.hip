@@ -1721,15 +1721,17 @@ __global__ __launch_bounds__(BLOCK) void network_steps_quad_kernel(uint32_t *__r
                     t[0] = kl; t[1] = (uint32_t)tr | (nr < 32u ? 2u : 0u);
                 }
             }
+            uint32_t tk[4], tf[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                                      // all four reads in flight, one wait; used where more[j]
+                const uint32_t *t = task_lds[wv][rank[j] & 255];
+                tk[j] = t[0]; tf[j] = t[1];
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (more[j]) {
-                    const uint32_t *t = task_lds[wv][rank[j] & 255];
-                    const uint32_t fl = t[1];
-                    kill[j] |= t[0];
-                    if (act_pending[j]) truthful[j] = fl & 1u;
-                    if (fl & 2u) near[j] = 0u;
-                }
+                kill[j] |= more[j] ? tk[j] : 0u;
+                truthful[j] = (more[j] && act_pending[j]) ? (tf[j] & 1u) != 0u : truthful[j];
+                near[j] = (more[j] && (tf[j] & 2u)) ? 0u : near[j];
             }
         }
         uint32_t o4[4], r4[4], a_next[4];
