@@ -1557,13 +1557,17 @@ __global__ __launch_bounds__(BLOCK) void tag_steps_quad_kernel(uint32_t *__restr
             }
         }
         uint32_t a_next[4];
+        uint4 rb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                                          // all four blocks in flight, one wait; used by the lanes with a task
+            const uint32_t *res = res_lds[wv][rank[j] & 255];
+            rb[j] = make_uint4(res[0], res[1], res[2], res[3]);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const uint32_t *res = res_lds[wv][rank[j] & 255];
-            if (f[j].need) Env::flee(sh, p, st[j], f[j], res[0], res[1], res[2]);
+            if (f[j].need) Env::flee(sh, p, st[j], f[j], rb[j].x, rb[j].y, rb[j].z);
             if (d[j]) {
-                const uint4 b = make_uint4(res[0], res[1], res[2], res[3]);
-                if (!Env::reset_from_block(p, st[j], b)) Env::reset(sh, p, st[j], key, glane0 + (uint32_t)j);   // rejections ran past the block
+                if (!Env::reset_from_block(p, st[j], rb[j])) Env::reset(sh, p, st[j], key, glane0 + (uint32_t)j);   // rejections ran past the block
             }
             a_next[j] = __umulhi(P[j], n_act);
             a_cur[j] = (int)a_next[j];
