@@ -236,9 +236,12 @@ struct Finisher<RockEnv<W, false>, LPT, CHAIN, typename std::enable_if<(LPT >= 2
             }
         }
         const uint32_t start = (uint32_t)p.start_x | ((uint32_t)p.start_y << 4);
+        uint32_t fresh_codes[LPT];
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) fresh_codes[j] = res_lds[wv][rank[j] & (64 * LPT - 1)];   // reads in flight together, one wait
 #pragma unroll
         for (int j = 0; j < LPT; ++j) {
-            if (fresh[j]) st[j].s = (typename Env::S)((uint64_t)start | ((uint64_t)res_lds[wv][rank[j] & (64 * LPT - 1)] << 8));
+            st[j].s = fresh[j] ? (typename Env::S)((uint64_t)start | ((uint64_t)fresh_codes[j] << 8)) : st[j].s;
             const uint32_t H = blk_lds()[wv][16 * j + (me >> 2)][me & 3];
             ob[j] = Env::sensor_ob(sh, st[j], aux[j], H, [&]() { return Env::elem(Env::quad_block(key, lane[j], 1u), lane[j] & 3u); });
             if (CHAIN) a_next[j] = (int)__umulhi(blk_lds()[wv][NQ + 16 * j + (me >> 2)][me & 3], n_act);
@@ -313,13 +316,17 @@ struct Finisher<TagEnv, 2, CHAIN, void> {
                 dst[0] = w.x; dst[1] = w.y; dst[2] = w.z; dst[3] = w.w;
             }
         }
+        uint4 rb[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {                                          // both blocks in flight, one wait
+            const uint32_t *res = res_lds[wv][32 + (rank[j] & 127)];
+            rb[j] = make_uint4(res[0], res[1], res[2], res[3]);
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const uint32_t *res = res_lds[wv][32 + (rank[j] & 127)];
-            if (aux[j].need) Env::flee(sh, p, st[j], aux[j], res[0], res[1], res[2]);
+            if (aux[j].need) Env::flee(sh, p, st[j], aux[j], rb[j].x, rb[j].y, rb[j].z);
             if (fresh[j]) {
-                const uint4 b = make_uint4(res[0], res[1], res[2], res[3]);
-                if (!Env::reset_from_block(p, st[j], b)) Env::reset(sh, p, st[j], key, lane[j]);   // rejections ran past the block
+                if (!Env::reset_from_block(p, st[j], rb[j])) Env::reset(sh, p, st[j], key, lane[j]);   // rejections ran past the block
             }
             if (CHAIN) a_next[j] = (int)__umulhi(res_lds[wv][16 * j + (me >> 2)][me & 3], n_act);
         }
@@ -1460,9 +1467,12 @@ __global__ __launch_bounds__(BLOCK) void step_quad_kernel(uint32_t *__restrict__
         }
     }
     const uint32_t start = (uint32_t)p.start_x | ((uint32_t)p.start_y << 4);
+    uint32_t fresh_codes[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fresh_codes[j] = res_lds[wv][rank[j] & 255];       // four reads in flight, one wait
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-        if (live[j] && d[j] && auto_reset) st[j].s = (S)((uint64_t)start | ((uint64_t)res_lds[wv][rank[j] & 255] << 8));
+        st[j].s = (live[j] && d[j] && auto_reset) ? (S)((uint64_t)start | ((uint64_t)fresh_codes[j] << 8)) : st[j].s;
     st_stream4(state + l0, (uint32_t)st[0].s, (uint32_t)st[1].s, (uint32_t)st[2].s, (uint32_t)st[3].s);
     if (W == 2)
         st_stream4(state + n + l0, (uint32_t)((uint64_t)st[0].s >> 32), (uint32_t)((uint64_t)st[1].s >> 32),
