@@ -447,6 +447,31 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(uint32_t *__restrict__ stat
 // no lane is ever out of range or frozen, and the actions are the driver's own (always valid): the bookkeeping for those
 // cases is compiled out.
 // Finishers that take the fused loop's policy words from quad-multiplexed blocks (generic form, one lane per thread)
+template <int J>
+static __device__ __forceinline__ uint32_t quad_bcast(uint32_t v)     // v of lane J of the caller's quad
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, J * 0x55, 0xF, 0xF, false);
+}
+// 4 x 4 transpose within a quad: lane e of the quad passes the four words of ITS block and gets word e of the blocks of
+// lanes 0, 1, 2, 3 (t.x .. t.w).  The fused rollout and heuristic loops let lane e of a quad compute the quad-shared block
+// of step base + e; step base + J then reads component J of the result — compile-time — where four broadcasts and a
+// per-lane select per step cost twice as much.  Two butterfly stages (partner e ^ 1, then e ^ 2): each lane first
+// selects the two words its partner lacks, so a stage is 2 selects + 2 DPP moves + 4 selects.
+static __device__ __forceinline__ uint4 quad_transpose4(const uint4 &v, uint32_t e)
+{
+    const bool b0 = e & 1u, b1 = e & 2u;
+    const uint32_t s0 = b0 ? v.x : v.y, s1 = b0 ? v.z : v.w;
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s0, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+    const uint32_t r1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s1, 0xB1, 0xF, 0xF, false);
+    // column (e & 1) / 2 + (e & 1) of the rows (e & ~1, e | 1)
+    const uint32_t p0 = b0 ? r0 : v.x, p1 = b0 ? v.y : r0, q0 = b0 ? r1 : v.z, q1 = b0 ? v.w : r1;
+    const uint32_t u0 = b1 ? p0 : q0, u1 = b1 ? p1 : q1;
+    const uint32_t w0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)u0, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    const uint32_t w1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)u1, 0x4E, 0xF, 0xF, false);
+    return make_uint4(b1 ? w0 : p0, b1 ? w1 : p1, b1 ? q0 : w0, b1 ? q1 : w1);
+}
+template <int J> static __device__ __forceinline__ uint32_t comp(const uint4 &v) { return J == 0 ? v.x : J == 1 ? v.y : J == 2 ? v.z : v.w; }
+
 template <class Fin, class = void> struct quad_policy_of : std::false_type {};
 template <class Fin> struct quad_policy_of<Fin, std::enable_if_t<Fin::QUAD_POLICY>> : std::true_type {};
 
@@ -544,16 +569,16 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
         }
         if constexpr (quad_policy) {
             const uint32_t e = glane[0] & 3u;
-            if ((s & 3) == 0) {                                              // this lane's block: the policy of step s + e
+            if ((s & 3) == 0) {                                              // this lane's block: the policy of step s + e ...
                 const uint64_t te = ta0 + (uint64_t)s + (uint64_t)e;
-                aq = philox4x32_10(glane[0] >> 2, (uint32_t)te, (uint32_t)(te >> 32), (uint32_t)POMDP_STREAM_ACTION << 24,
-                                   akey0.k0, akey0.k1);
+                // ... transposed within the quad: component J is then THIS lane's word of step s + J
+                aq = quad_transpose4(philox4x32_10(glane[0] >> 2, (uint32_t)te, (uint32_t)(te >> 32),
+                                                   (uint32_t)POMDP_STREAM_ACTION << 24, akey0.k0, akey0.k1), e);
             }
             Fin::resets_only(sh, p, st, fresh, key, glane);
-            const int src = (int)((threadIdx.x & 60u) | (uint32_t)(s & 3));  // the lane of my quad that holds step s's block
-            const uint32_t wx = (uint32_t)__shfl((int)aq.x, src, 64), wy = (uint32_t)__shfl((int)aq.y, src, 64);
-            const uint32_t wz = (uint32_t)__shfl((int)aq.z, src, 64), ww = (uint32_t)__shfl((int)aq.w, src, 64);
-            a_next[0] = (int)__umulhi(e == 0 ? wx : e == 1 ? wy : e == 2 ? wz : ww, (uint32_t)n_act);
+            const int sj = s & 3;                                            // wave-uniform selects
+            const uint32_t word = sj == 0 ? aq.x : sj == 1 ? aq.y : sj == 2 ? aq.z : aq.w;
+            a_next[0] = (int)__umulhi(word, (uint32_t)n_act);
         } else {
             Fin::run(sh, p, st, fresh, key, glane, akey, (uint32_t)n_act, a_next, aux, o);
         }
@@ -845,30 +870,6 @@ static __device__ __forceinline__ void heuristic_belief_update(const typename En
     BeliefOps<Env>::update(sh, p, st, a, o, b, n, i, ck);
 }
 
-template <int J>
-static __device__ __forceinline__ uint32_t quad_bcast(uint32_t v)     // v of lane J of the caller's quad
-{
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, J * 0x55, 0xF, 0xF, false);
-}
-// 4 x 4 transpose within a quad: lane e of the quad passes the four words of ITS block and gets word e of the blocks of
-// lanes 0, 1, 2, 3 (t.x .. t.w).  The fused rollout and heuristic loops let lane e of a quad compute the quad-shared block
-// of step base + e; step base + J then reads component J of the result — compile-time — where four broadcasts and a
-// per-lane select per step cost twice as much.  Two butterfly stages (partner e ^ 1, then e ^ 2): each lane first
-// selects the two words its partner lacks, so a stage is 2 selects + 2 DPP moves + 4 selects.
-static __device__ __forceinline__ uint4 quad_transpose4(const uint4 &v, uint32_t e)
-{
-    const bool b0 = e & 1u, b1 = e & 2u;
-    const uint32_t s0 = b0 ? v.x : v.y, s1 = b0 ? v.z : v.w;
-    const uint32_t r0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s0, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
-    const uint32_t r1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s1, 0xB1, 0xF, 0xF, false);
-    // column (e & 1) / 2 + (e & 1) of the rows (e & ~1, e | 1)
-    const uint32_t p0 = b0 ? r0 : v.x, p1 = b0 ? v.y : r0, q0 = b0 ? r1 : v.z, q1 = b0 ? v.w : r1;
-    const uint32_t u0 = b1 ? p0 : q0, u1 = b1 ? p1 : q1;
-    const uint32_t w0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)u0, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
-    const uint32_t w1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)u1, 0x4E, 0xF, 0xF, false);
-    return make_uint4(b1 ? w0 : p0, b1 ? w1 : p1, b1 ? q0 : w0, b1 ? q1 : w1);
-}
-template <int J> static __device__ __forceinline__ uint32_t comp(const uint4 &v) { return J == 0 ? v.x : J == 1 ? v.y : J == 2 ? v.z : v.w; }
 
 // _generate_legal() as the rollout loop uses it — the list's length, then its idx-th entry: envs that derive both from one
 // intermediate form (Env::Legal, Env::legal_set, Env::legal_pick) compute it once per step, the others go through
