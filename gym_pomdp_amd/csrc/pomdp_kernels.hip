@@ -517,7 +517,7 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
     }
     using Fin = Finisher<Env, LPT, true>;
     constexpr bool quad_policy = quad_policy_of<Fin>::value;
-    uint4 aq = make_uint4(0, 0, 0, 0);
+    uint4 aq = make_uint4(0, 0, 0, 0), sq = make_uint4(0, 0, 0, 0);
     const int n_act = Env::n_actions(p);
     const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo, ta0 = ((uint64_t)akey0.t_hi << 32) | akey0.t_lo;
     if (flags & FLAG_GEN_FIRST) {                        // wave-uniform: the policy's actions of the first call counter
@@ -562,6 +562,20 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
             valid[j] = SIMPLE || (unsigned)a_cur[j] < (unsigned)n_act;
             live[j] = SIMPLE || (in_range[j] && valid[j] && !was_done[j]);
             if constexpr (TAB) Fin::lane_step_tab(tab, st[j], a_cur[j], o[j], r[j], d[j], aux[j]);
+            else if constexpr (quad_policy && Env::QUAD_SENSOR) {
+                // one lane per thread, the sensor block shared by the quad (RockSample shards below the pooled kernels' gates):
+                // lane e computes the block of step s + e once per four steps and the words reach their lanes by the same
+                // transpose as the policy's — one Philox block per lane per four steps instead of one per step
+                if ((s & 3) == 0) {
+                    const uint64_t te = t0 + (uint64_t)s + (uint64_t)(glane[0] & 3u);
+                    RngKey ke = key0;
+                    ke.t_lo = (uint32_t)te; ke.t_hi = (uint32_t)(te >> 32);
+                    sq = quad_transpose4(Env::quad_block(ke, glane[0], 0u), glane[0] & 3u);
+                }
+                const int sj = s & 3;                                            // wave-uniform selects
+                const uint32_t H = sj == 0 ? sq.x : sj == 1 ? sq.y : sj == 2 ? sq.z : sq.w;
+                Env::step_with_H(sh, p, st[j], valid[j] ? a_cur[j] : 0, key, glane[j], H, o[j], r[j], d[j]);
+            }
             else Fin::lane_step(sh, p, st[j], valid[j] ? a_cur[j] : 0, key, glane[j], o[j], r[j], d[j], aux[j]);
             if (!live[j]) { r[j] = 0; d[j] = was_done[j]; }
             fresh[j] = live[j] && d[j] && auto_reset;
