@@ -561,8 +561,7 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
             before[j] = st[j];
             valid[j] = SIMPLE || (unsigned)a_cur[j] < (unsigned)n_act;
             live[j] = SIMPLE || (in_range[j] && valid[j] && !was_done[j]);
-            if constexpr (TAB) Fin::lane_step_tab(tab, st[j], a_cur[j], o[j], r[j], d[j], aux[j]);
-            else if constexpr (quad_policy && Env::QUAD_SENSOR) {
+            if constexpr (quad_policy && Env::QUAD_SENSOR) {
                 // one lane per thread, the sensor block shared by the quad (RockSample shards below the pooled kernels' gates):
                 // lane e computes the block of step s + e once per four steps and the words reach their lanes by the same
                 // transpose as the policy's — one Philox block per lane per four steps instead of one per step
@@ -574,8 +573,10 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
                 }
                 const int sj = s & 3;                                            // wave-uniform selects
                 const uint32_t H = sj == 0 ? sq.x : sj == 1 ? sq.y : sj == 2 ? sq.z : sq.w;
-                Env::step_with_H(sh, p, st[j], valid[j] ? a_cur[j] : 0, key, glane[j], H, o[j], r[j], d[j]);
+                if constexpr (TAB) Env::step_with_H_tab(sh, tab, st[j], a_cur[j], key, glane[j], H, o[j], r[j], d[j]);
+                else Env::step_with_H(sh, p, st[j], valid[j] ? a_cur[j] : 0, key, glane[j], H, o[j], r[j], d[j]);
             }
+            else if constexpr (TAB) Fin::lane_step_tab(tab, st[j], a_cur[j], o[j], r[j], d[j], aux[j]);
             else Fin::lane_step(sh, p, st[j], valid[j] ? a_cur[j] : 0, key, glane[j], o[j], r[j], d[j], aux[j]);
             if (!live[j]) { r[j] = 0; d[j] = was_done[j]; }
             fresh[j] = live[j] && d[j] && auto_reset;
@@ -1977,6 +1978,15 @@ static int launch_steps_fused(const typename Env::Params &p, uint32_t *state, in
     if constexpr (Env::POOLED_LPT2) {
         if (!launched && lpt2) {
             if (simple) POMDP_LAUNCH_STEPS(2, true, grid); else POMDP_LAUNCH_STEPS(2, false, grid);
+            launched = true;
+        }
+    }
+    if constexpr (quad_tab<Env>::value && Env::QUAD_SENSOR) {
+        // RockSample's small shards, one lane per thread: the table-driven lane step from 16 steps per launch on
+        if (!launched && simple && k >= 16 && p.num_rocks + 5 <= Env::TAB_ACTIONS) {
+            note_fused("steps_kernel", Env::NAME, ", 1, true, true");
+            hipLaunchKernelGGL((steps_kernel<Env, 1, true, true>), grid, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob, reward,
+                               done, err, n, make_key(seed, t), lane0, kflags, make_key(action_seed, t + 1), k, rec, p);
             launched = true;
         }
     }

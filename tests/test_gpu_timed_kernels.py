@@ -227,7 +227,7 @@ def test_launcher_picks_the_documented_kernel_per_shard_size():
     from gym_pomdp_amd import _native
     L = _native.lib()
     want = [("rock", {}, 1 << 20, 64, "steps_quad_kernel<RockEnv<1>>"), ("rock", {}, 1 << 19, 64, "steps_quad_kernel<RockEnv<1>>"),
-            ("rock", {}, 1 << 18, 64, "steps_kernel<RockEnv<1>, 2, true>"), ("rock", {}, 1 << 17, 64, "steps_kernel<RockEnv<1>, 1, true>"),
+            ("rock", {}, 1 << 18, 64, "steps_kernel<RockEnv<1>, 2, true>"), ("rock", {}, 1 << 17, 64, "steps_kernel<RockEnv<1>, 1, true, true>"), ("rock", {}, 1 << 17, 8, "steps_kernel<RockEnv<1>, 1, true>"),
             ("rock", {}, 1 << 20, 5, "steps_kernel<RockEnv<1>, 4, true>"), ("rock", dict(board_size=15, num_rocks=15), 1 << 20, 64, "steps_quad_kernel<RockEnv<2>>"),
             ("rock", {}, (1 << 19) + 4, 64, "steps_kernel<RockEnv<1>, 2, false>"),
             ("tag", {}, 1 << 19, 64, "tag_steps_quad_kernel<true>"), ("tag", {}, 1 << 19, 8, "tag_steps_quad_kernel<false>"),
