@@ -1867,7 +1867,7 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_generic_kernel(uint32_t *__r
 }
 
 // Smallest batch each quad-per-thread loop takes (1024 lanes per workgroup).  Measured on MI355X, us per fused step at
-// 2^17 / 2^18 / 2^19 / 2^20 lanes (profiles/r02_small_shards_gates.txt, r02j_small_shards.txt): RockSample(7,8) quad 1.50 /
+// 2^17 / 2^18 / 2^19 / 2^20 lanes (profiles/r02_small_shards_gates.txt, r02k_small_shards.txt): RockSample(7,8) quad 1.50 /
 // 1.52 / 1.82 / 2.89 against 1.25 / 1.39 / 1.99 with one or two lanes per thread; Tag (table-driven) 1.59 / 1.61 / 1.83 /
 // 2.67 against 0.96 / 1.43 / 2.00; Tiger 0.67 / 0.67 / 1.21 / 2.51 against 0.44 / 0.85 / 1.41 / 2.66; Network 2.30 / 2.30 / 2.91 /
 // 4.72 against 1.45 / 1.94 / 3.32 / 5.99 — below these sizes every kernel is bound by the latency of one wave's step
