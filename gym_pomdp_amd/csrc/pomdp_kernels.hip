@@ -37,7 +37,11 @@ __device__ uint64_t *g_timeline = nullptr;
 #else
 #define TL(k) do { } while (0)
 #endif
+#ifdef POMDP_LPT2_MIN_LANES                                   // same-box A/B builds (tools/ab_build.sh)
+constexpr int64_t LPT2_MIN_LANES = POMDP_LPT2_MIN_LANES;
+#else
 constexpr int64_t LPT2_MIN_LANES = 1 << 18;
+#endif
 #ifdef POMDP_STEP_QUAD_MIN_LANES                              // same-box A/B builds (tools/ab_build.sh)
 constexpr int64_t STEP_QUAD_MIN_LANES = POMDP_STEP_QUAD_MIN_LANES;
 #else
@@ -1898,7 +1902,9 @@ static int launch_steps_fused(const typename Env::Params &p, uint32_t *state, in
 {
     if (!state || !action || !ob || !reward || !done || bad_range(n, lane0) || (lane0 & 3u) || k < 1) return POMDP_E_BADARG;
     if (n == 0) return 0;
-    const bool lpt2 = Env::POOLED_LPT2 && n >= LPT2_MIN_LANES;
+    // two lanes per thread from 2^18 lanes (RockSample) / 2^19 (Tag: at 2^18 its one-lane-per-thread loop takes 1.20 us per
+    // step against 1.35)
+    const bool lpt2 = Env::POOLED_LPT2 && n >= (std::is_same<Env, TagEnv>::value ? 2 * LPT2_MIN_LANES : LPT2_MIN_LANES);
     const bool simple = (flags & POMDP_AUTO_RESET) && n % (lpt2 ? 2 * BLOCK : BLOCK) == 0;
     const dim3 grid(lpt2 ? (unsigned)((n + 2 * BLOCK - 1) / (2 * BLOCK)) : blocks_for(n));
     const int kflags = (flags & POMDP_AUTO_RESET) | (gen_first ? FLAG_GEN_FIRST : 0);
