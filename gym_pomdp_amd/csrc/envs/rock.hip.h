@@ -6,19 +6,18 @@
 namespace pomdp {
 
 // Word contract of the RockSample envs ("split layout").  Every draw RockSample makes is a numpy double
-// = (high word H, low word L) -> k53 = (H >> 5) * 2^26 + (L >> 6).  H and L live in DIFFERENT Philox blocks:
-//   reset  (stream RESET, counter word 0 = lane):      double j = rock j = 4 q + e:  H = element e of block 2 (j >> 4)
-//                                                       rotated right by 8 q + 8 bits, L = the same element of block
-//                                                       2 (j >> 4) + 1 under the same rotation — reset() only uses
-//                                                       sign(U - .5), the top bit of H, so ONE block's bits 7, 15, 23, 31
-//                                                       of its four words are sixteen rocks' statuses;
-//   step   (stream STEP,  counter word 0 = lane >> 2): double j (RockEnv: j = 0 the sensor; StochasticRockEnv:
-//                                                       j = 0 the action gate, j = 1 the sensor): H = block 2 j,
-//                                                       L = block 2 j + 1, element lane & 3 — one block serves the four
-//                                                       lanes of a quad.
+// = (high word H, low word L) -> k53 = (H >> 5) * 2^26 + (L >> 6).  H and L live in DIFFERENT Philox blocks, and every
+// stream is shared by the four lanes of a quad: counter word 0 = lane >> 2, lane L uses element L & 3 of each block.
+//   reset  (stream RESET): rock j of the lane: H = the lane's element of block 0 rotated right by 2 j + 2 bits, L = its
+//                          element of block 1 under the same rotation — reset() only uses sign(U - .5), the top bit of H,
+//                          i.e. bit 2 j + 1 of the element: ONE 32-bit word carries the statuses of all K <= 16 rocks,
+//                          already at the upper bit of each rock's 2-bit code (codes = word & 0xAAAAAAAA);
+//   step   (stream STEP):  double j (RockEnv: j = 0 the sensor; StochasticRockEnv: j = 0 the action gate, j = 1 the
+//                          sensor): H = block 2 j, L = block 2 j + 1.
 // A comparison k53 <= thr is decided by H alone unless (H >> 5) == (thr >> 26), which happens with probability 2^-27
-// per draw; only then is the L block generated.  So a reset costs ONE block instead of ceil(K / 2), a
-// quad's sensor draws cost one block instead of four, and a wave's whole step fits one pooled Philox pass.
+// per draw; only then is the L block generated.  So a quad's resets cost ONE block, like its sensor draws and its policy
+// words: a thread that owns a quad has all three thread-local (steps_quad_kernel), a lane of a one-lane-per-thread loop
+// computes each of them once per four steps (quad_transpose4).
 //
 // STOCH selects StochasticRockEnv (rock.py:428-504).
 template <int W, bool STOCH = false> // W = state words per lane: 1 (K <= 12) or 2
@@ -123,31 +122,32 @@ struct RockEnv {
         return kh > HALF_HI ? 2u : (kh < HALF_HI ? 0u : 3u);
     }
     static __device__ __forceinline__ uint32_t rock_code_lo(uint32_t L) { return (L >> 6) ? 2u : 1u; }   // kh == 2^26 exactly
-    // The 2-bit codes of all K <= 16 rocks (bit pair j = rock j) of lane `lane`'s fresh episode from its RESET block.
-    // Rock j = 4 q + e reads element e rotated right by 8 q + 8: its top bit is bit 8 q + 7 of the element, and the code
-    // (status + 1) is twice that bit unless the rotated word lies in the 32 values just above 2^31 — the tie the low
-    // word decides.  Bit 8 q + 7 of element e belongs at bit 2 j + 1 = 8 q + 2 e + 1: a shift by 6 - 2 e for all q at once.
+    // block `j2` (0 = high words, 1 = low words) of the RESET stream of lane's quad
+    static __device__ __forceinline__ uint4 reset_block(const RngKey &key, uint32_t lane, uint32_t j2)
+    {
+        return philox4x32_10(lane >> 2, key.t_lo, key.t_hi, ((uint32_t)POMDP_STREAM_RESET << 24) | j2, key.k0, key.k1);
+    }
+    // The 2-bit codes of all K <= 16 rocks (bit pair j = rock j) of lane `lane`'s fresh episode from its RESET word `w`
+    // (element lane & 3 of reset_block(key, lane, 0)).  Rock j reads the word rotated right by 2 j + 2: its top bit is bit
+    // 2 j + 1 of the word, and the code (status + 1) is twice that bit — the word masked to its odd bits IS the code
+    // word — unless the rotated word lies in the 32 values just above 2^31: the tie the low word decides.
     static __device__ __forceinline__ uint32_t reset_codes(const RngKey &key, uint32_t lane, int K)
     {
-        return reset_codes(stream_block(key, lane, POMDP_STREAM_RESET, 0u), key, lane, K);
+        return reset_codes(elem(reset_block(key, lane, 0u), lane & 3u), key, lane, K);
     }
-    static __device__ __forceinline__ uint32_t reset_codes(const uint4 &h, const RngKey &key, uint32_t lane, int K)
+    static __device__ __forceinline__ uint32_t reset_codes(uint32_t w, const RngKey &key, uint32_t lane, int K)
     {
-        const uint32_t M = 0x80808080u;
-        uint32_t codes = ((h.x & M) >> 6) | ((h.y & M) >> 4) | ((h.z & M) >> 2) | (h.w & M);
-        // A tied rotation is 1, twenty-six zeros, five free bits: at most six bits set in the element (2.7e-4 per element);
+        uint32_t codes = w & 0xAAAAAAAAu;
+        // A tied rotation is 1, twenty-six zeros, five free bits: at most six bits set in the word (2.7e-4 per word);
         // only then look closer
-        if (min(min(__popc(h.x), __popc(h.y)), min(__popc(h.z), __popc(h.w))) <= 6) {
-            const uint32_t w[4] = {h.x, h.y, h.z, h.w};
+        if (__popc(w) <= 6) {
             bool have_lo = false;
-            uint4 l = make_uint4(0, 0, 0, 0);
+            uint32_t l = 0;
             for (int j = 0; j < K; ++j) {
-                const int e = j & 3, rot = (8 * ((j >> 2) & 3) + 8) & 31;
-                const uint32_t H = __builtin_rotateright32(w[e], (uint32_t)rot);
-                if (rock_code_hi(H) != 3u) continue;
-                if (!have_lo) { l = stream_block(key, lane, POMDP_STREAM_RESET, 1u); have_lo = true; }
-                const uint32_t lw[4] = {l.x, l.y, l.z, l.w};
-                const uint32_t c = rock_code_lo(__builtin_rotateright32(lw[e], (uint32_t)rot));
+                const uint32_t rot = (uint32_t)(2 * j + 2) & 31u;
+                if (rock_code_hi(__builtin_rotateright32(w, rot)) != 3u) continue;
+                if (!have_lo) { l = elem(reset_block(key, lane, 1u), lane & 3u); have_lo = true; }
+                const uint32_t c = rock_code_lo(__builtin_rotateright32(l, rot));
                 codes = (codes & ~(3u << (2 * j))) | (c << (2 * j));
             }
         }
@@ -159,6 +159,18 @@ struct RockEnv {
         return philox4x32_10(lane >> 2, key.t_lo, key.t_hi, ((uint32_t)POMDP_STREAM_STEP << 24) | j2, key.k0, key.k1);
     }
 
+    // the same for the four lanes of a quad from its RESET block (R[e] = lane first + e's word): ONE branch for the ties
+    static __device__ __forceinline__ void reset_codes4(const uint32_t (&R)[4], const RngKey &key, uint32_t first, int K,
+                                                        uint32_t (&codes)[4])
+    {
+        const uint32_t exist = K >= 16 ? 0xFFFFFFFFu : ((1u << (2 * K)) - 1u);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) codes[e] = R[e] & 0xAAAAAAAAu & exist;
+        if (min(min(__popc(R[0]), __popc(R[1])), min(__popc(R[2]), __popc(R[3]))) <= 6) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) codes[e] = reset_codes(R[e], key, first + (uint32_t)e, K);
+        }
+    }
     // rock.py:236-241 reset -> 266-271 _get_init_state -> 78-86 Rock.__init__:
     // status_j = sign(U_j - .5), rocks in index order, one double each.
     static __device__ __forceinline__ int reset(const Shared &, const Params &p, State &st, const RngKey &key,
@@ -170,72 +182,27 @@ struct RockEnv {
     }
     static __device__ __forceinline__ int reset_ob(const Params &, const State &) { return 0; }   // what reset() returned
 
-    // Wave-cooperative reset (one lane per thread launches).  A fresh episode needs one block, only ~1/8 of a wave's
-    // lanes reset in a given step while nearly every wave has at least one: done per lane, the whole wave would pay a
-    // block per step for eight resets.  Instead the resetting lanes' blocks are dealt out across the 64 lanes — with the
-    // chained policy's blocks in the same pass — and the rock codes travel back through ds_bpermute.
-    static __device__ __forceinline__ void reset_where(const Shared &sh, const Params &p, State &st, bool fresh,
+    // Called convergently by every lane of the wave; `fresh` marks the lanes that start a new episode.  ~1/8 of a wave's
+    // lanes reset in a given step under a random policy, so nearly every wave-step computes the block; the quads' four
+    // lanes each derive their quad's block themselves (the kernels that own or time-share a quad do better: see above).
+    static __device__ __forceinline__ void reset_where(const Shared &, const Params &p, State &st, bool fresh,
                                                        const RngKey &key, uint32_t lane)
     {
-        int unused;
-        reset_core<false>(sh, p, st, fresh, key, lane, key, 1u, unused);
+        if (!__any(fresh)) return;                                     // wave-uniform
+        const uint32_t codes = reset_codes(key, lane, p.num_rocks);
+        if (fresh) st.s = (S)((uint64_t)((uint32_t)p.start_x | ((uint32_t)p.start_y << 4)) | ((uint64_t)codes << 8));
     }
-    // Same pass, plus the synthetic policy's actions for the NEXT call counter (C-side rollout driver, policy and
-    // env sharing the Philox key): the wave's 16 action blocks ride in lanes 0-15 of the first pass.
+    // ... plus the synthetic policy's action for the NEXT call counter (C-side rollout driver)
     static __device__ __forceinline__ void reset_where_chain(const Shared &sh, const Params &p, State &st, bool fresh,
                                                              const RngKey &key, uint32_t lane, const RngKey &akey,
                                                              uint32_t n_actions, int &next_action)
     {
-        reset_core<true>(sh, p, st, fresh, key, lane, akey, n_actions, next_action);
+        reset_where_chain_default<RockEnv>(sh, p, st, fresh, key, lane, akey, n_actions, next_action);
     }
-
-    template <bool CHAIN>
-    static __device__ __forceinline__ void reset_core(const Shared &, const Params &p, State &st, bool fresh,
-                                                      const RngKey &key, uint32_t lane, const RngKey &akey,
-                                                      uint32_t n_actions, int &next_action)
+    // the fresh episode's state from its RESET word
+    static __device__ __forceinline__ S fresh_state(const Params &p, uint32_t w, const RngKey &key, uint32_t lane)
     {
-        const uint64_t mask = __ballot(fresh);
-        if (!CHAIN && mask == 0ull) return;                            // wave-uniform
-        const int K = p.num_rocks;
-        const int lid = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-        const int me = (int)(threadIdx.x & 63u);
-        const int nreset = __popcll(mask);
-        // stable partition: resetting lanes first; lane r (< nreset) learns who the r-th resetting lane is
-        const int dst = fresh ? lid : nreset + (me - lid);
-        const int src_of_rank = __builtin_amdgcn_ds_permute(dst << 2, me);
-        constexpr int NA = CHAIN ? 16 : 0;                             // task list: [16 policy blocks] ++ [one per reset]
-        const int ntask = NA + nreset;                                 // <= 80: two passes at most
-        uint32_t bits = 0;
-        uint4 aw = make_uint4(0, 0, 0, 0);
-        for (int base = 0; base < ntask; base += 64) {
-            const int tid = base + me;
-            const bool is_act = CHAIN && tid < NA;
-            const int r = tid < NA ? 0 : tid - NA;
-            const int srcl = __shfl(src_of_rank, r & 63, 64);
-            uint32_t codes = 0;
-            if (tid < ntask) {
-                // ONE Philox instance for both task kinds: the counter words are per-lane selects
-                const uint32_t src_lane = lane - (uint32_t)me + (uint32_t)srcl;
-                const uint32_t c0 = is_act ? ((lane - (uint32_t)me) >> 2) + (uint32_t)tid : src_lane;
-                const uint32_t c1 = is_act ? akey.t_lo : key.t_lo, c2 = is_act ? akey.t_hi : key.t_hi;
-                const uint32_t c3 = (uint32_t)(is_act ? POMDP_STREAM_ACTION : POMDP_STREAM_RESET) << 24;
-                const uint4 w = philox4x32_10(c0, c1, c2, c3, key.k0, key.k1);
-                if (CHAIN && base == 0) aw = w;                        // lanes >= 16 hold words nobody reads
-                if (!is_act) codes = reset_codes(w, key, src_lane, K);
-            }
-            const int t = NA + lid - base;                             // where this lane's own reset task ran
-            const uint32_t got = (uint32_t)__shfl((int)codes, t & 63, 64);
-            if (t >= 0 && t < 64) bits = got;
-            if (CHAIN && base == 0) {
-                // lane l takes word (l & 3) of the policy block computed by lane l >> 2
-                const int q = me >> 2;
-                const uint32_t x = (uint32_t)__shfl((int)aw.x, q, 64), y = (uint32_t)__shfl((int)aw.y, q, 64);
-                const uint32_t z = (uint32_t)__shfl((int)aw.z, q, 64), ww = (uint32_t)__shfl((int)aw.w, q, 64);
-                const int b = me & 3;
-                next_action = (int)__umulhi(b == 0 ? x : b == 1 ? y : b == 2 ? z : ww, n_actions);
-            }
-        }
-        if (fresh) st.s = (S)((uint64_t)((uint32_t)p.start_x | ((uint32_t)p.start_y << 4)) | ((uint64_t)bits << 8));
+        return (S)((uint64_t)((uint32_t)p.start_x | ((uint32_t)p.start_y << 4)) | ((uint64_t)reset_codes(w, key, lane, p.num_rocks) << 8));
     }
 
     // rock.py:273-291 _generate_legal, in the reference's list order: EAST, then NORTH / SOUTH / WEST when

@@ -137,21 +137,24 @@ struct Finisher {
     }
 };
 
-// RockSample with two lanes per thread: ONE task list per wave (128 lanes) holds
-//   - the 32 sensor blocks of its quads (stream STEP is shared by the four lanes of a quad),
-//   - for CHAIN launches the 32 policy blocks of the next call counter,
-//   - one reset block per resetting lane (the rotated layout: a block's four words carry sixteen rocks' statuses),
-// i.e. ~48 (CHAIN: ~80) Philox blocks for 128 lane-steps, dealt out 64 per pass.  The lane step therefore runs
-// WITHOUT its sensor draw (Env::step_pre) and the observation is completed here from the pooled words.  Tasks and
-// results are exchanged through a wave-private LDS scratch; LDS operations of one wave complete in order, so no
-// barrier is involved.  Low words (needed with probability 2^-27 per draw) are generated per lane on demand.
+// RockSample with two or more lanes per thread: every random word of the step comes from a quad-shared block (DESIGN.md
+// §2) that depends on lane ids and the call counter only, so ONE task list per wave (64 * LPT lanes) holds
+//   - the 16 * LPT sensor blocks of its quads (stream STEP),
+//   - their 16 * LPT RESET blocks (a quad's four lanes take one word each: the statuses of all rocks of a fresh episode),
+//   - for CHAIN launches the 16 * LPT policy blocks of the next call counter,
+// i.e. 64 (CHAIN: 96) Philox blocks for 128 lane-steps, dealt out 64 per pass BEFORE the lane step: the kernel runs the
+// passes right after issuing its HBM loads.  The lane step therefore runs WITHOUT its sensor draw (Env::step_pre) and
+// the observation and the fresh episodes are completed here from the pooled words.  Tasks and results are exchanged
+// through a wave-private LDS scratch; LDS operations of one wave complete in order, so no barrier is involved.  Low
+// words (needed with probability 2^-27 per draw) are generated per lane on demand.
 template <int W, int LPT, bool CHAIN>
 struct Finisher<RockEnv<W, false>, LPT, CHAIN, typename std::enable_if<(LPT >= 2)>::type> {
     using Env = RockEnv<W, false>;
     using Aux = typename Env::Aux;
     static constexpr bool LOOP_BARRIER = false;              // every scratch array is wave-private
-    static constexpr int NQ = 16 * LPT;                      // quads (sensor blocks) of the wave's 64 * LPT lanes
+    static constexpr int NQ = 16 * LPT;                      // quads of the wave's 64 * LPT lanes: sensor blocks, reset blocks
     static constexpr int NA = CHAIN ? 16 * LPT : 0;          // policy blocks of the next call counter
+    static constexpr int NT = 2 * NQ + NA;
     template <class RT>
     static __device__ __forceinline__ void lane_step(const typename Env::Shared &sh, const typename Env::Params &p,
                                                      typename Env::State &st, int a, const RngKey &, uint32_t, int &ob,
@@ -168,44 +171,28 @@ struct Finisher<RockEnv<W, false>, LPT, CHAIN, typename std::enable_if<(LPT >= 2
         Env::step_tab(tab, st, a, rew, done, aux);
         ob = 0;
     }
-    // wave-private LDS scratch (one instance each: function-local statics of these accessors)
-    static __device__ __forceinline__ uint32_t (&blk_lds())[BLOCK / 64][32 * LPT][4]
+    // wave-private LDS scratch (one instance: function-local static of this accessor)
+    static __device__ __forceinline__ uint32_t (&blk_lds())[BLOCK / 64][NT][4]
     {
-        __shared__ uint32_t a[BLOCK / 64][32 * LPT][4];      // [0, NQ): sensor blocks, [NQ, 2 NQ): policy blocks; (sub-batch, quad)
+        __shared__ uint32_t a[BLOCK / 64][NT][4];            // [0, NQ): sensor, [NQ, 2 NQ): reset, [2 NQ, NT): policy; (sub-batch, quad)
         return a;
     }
-    // The data-independent part of the task list — the wave's sensor blocks and, for CHAIN launches, the policy blocks
-    // of the next call counter — depends on lane ids only, so the kernel runs it right after issuing its HBM loads:
-    // Philox passes hidden under the load latency.  Sub-batch j of a thread is 256 j lanes further on.
     static constexpr bool HAS_PREPASS = true;
-    // Plain launches at two lanes per thread have only 32 such blocks per wave — half a pass.  There the waves of a
-    // workgroup pair up: one wave of each pair computes both waves' 32 sensor blocks in one full pass, the other skips
-    // the pre-pass; which of the two works alternates with the workgroup index so that the SIMDs stay balanced.  The
-    // blocks are first read after the table-staging barrier, which makes them visible across the pair at no extra cost.
-    static constexpr bool PAIRED = !CHAIN && LPT == 2;
+    // Sub-batch j of a thread is 256 j lanes further on.
     static __device__ __forceinline__ void prepass(const RngKey &key, const uint32_t (&lane)[LPT], const RngKey &akey)
     {
         const int wv = (int)(threadIdx.x >> 6), me = (int)(threadIdx.x & 63u);
         const uint32_t first0 = lane[0] - (uint32_t)me;                        // first lane of the wave's sub-batch 0
-        if (PAIRED) {
-            if ((wv & 1) != (int)(blockIdx.x & 1u)) return;                    // the pair's other wave does it (wave-uniform)
-            const int tw = (wv & ~1) + (me >> 5), tt = me & 31;                // target wave, its (sub-batch, quad) index
-            const uint32_t tfirst = first0 + (uint32_t)(tw - wv) * 64u;
-            const uint32_t quad = ((tfirst + (uint32_t)(tt >> 4) * BLOCK) >> 2) + (uint32_t)(tt & 15);
-            const uint4 w = philox4x32_10(quad, key.t_lo, key.t_hi, (uint32_t)POMDP_STREAM_STEP << 24, key.k0, key.k1);
-            uint32_t *dst = blk_lds()[tw][tt];
-            dst[0] = w.x; dst[1] = w.y; dst[2] = w.z; dst[3] = w.w;
-            return;
-        }
 #pragma unroll
-        for (int base = 0; base < NQ + NA; base += 64) {
+        for (int base = 0; base < NT; base += 64) {
             const int tid = base + me;
-            if (tid < NQ + NA) {
-                const bool is_act = tid >= NQ;
-                const int qt = is_act ? tid - NQ : tid;                        // (sub-batch, quad) index
+            if (tid < NT) {
+                // ONE Philox instance for the three task kinds: the counter words are per-lane selects
+                const int kind = tid < NQ ? 0 : (tid < 2 * NQ ? 1 : 2);
+                const int qt = tid - kind * NQ;                                // (sub-batch, quad) index
                 const uint32_t quad = ((first0 + (uint32_t)(qt >> 4) * BLOCK) >> 2) + (uint32_t)(qt & 15);
-                const uint32_t c1 = is_act ? akey.t_lo : key.t_lo, c2 = is_act ? akey.t_hi : key.t_hi;
-                const uint32_t c3 = (uint32_t)(is_act ? POMDP_STREAM_ACTION : POMDP_STREAM_STEP) << 24;
+                const uint32_t c1 = kind == 2 ? akey.t_lo : key.t_lo, c2 = kind == 2 ? akey.t_hi : key.t_hi;
+                const uint32_t c3 = (uint32_t)(kind == 0 ? POMDP_STREAM_STEP : kind == 1 ? POMDP_STREAM_RESET : POMDP_STREAM_ACTION) << 24;
                 const uint4 w = philox4x32_10(quad, c1, c2, c3, key.k0, key.k1);
                 uint32_t *dst = blk_lds()[wv][tid];
                 dst[0] = w.x; dst[1] = w.y; dst[2] = w.z; dst[3] = w.w;
@@ -214,41 +201,22 @@ struct Finisher<RockEnv<W, false>, LPT, CHAIN, typename std::enable_if<(LPT >= 2
     }
     static __device__ __forceinline__ void run(const typename Env::Shared &sh, const typename Env::Params &p,
                                                typename Env::State (&st)[LPT], const bool (&fresh)[LPT], const RngKey &key,
-                                               const uint32_t (&lane)[LPT], const RngKey &akey, uint32_t n_act,
+                                               const uint32_t (&lane)[LPT], const RngKey &, uint32_t n_act,
                                                int (&a_next)[LPT], const Aux (&aux)[LPT], int (&ob)[LPT])
     {
-        __shared__ uint8_t src_lds[BLOCK / 64][64 * LPT];    // reset rank -> virtual lane (me + 64 * sub-batch)
-        __shared__ uint32_t res_lds[BLOCK / 64][64 * LPT];   // reset rank -> the 2-bit codes of the fresh episode's rocks
         const int wv = (int)(threadIdx.x >> 6), me = (int)(threadIdx.x & 63u);
-        const int K = p.num_rocks;
-        int rank[LPT], nres = 0;
+        uint32_t H[LPT], Rw[LPT], P[LPT];
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) {                                         // every read in flight together, one wait
+            H[j] = blk_lds()[wv][16 * j + (me >> 2)][me & 3];
+            Rw[j] = blk_lds()[wv][NQ + 16 * j + (me >> 2)][me & 3];
+            P[j] = CHAIN ? blk_lds()[wv][2 * NQ + 16 * j + (me >> 2)][me & 3] : 0u;
+        }
 #pragma unroll
         for (int j = 0; j < LPT; ++j) {
-            const uint64_t m = __ballot(fresh[j]);
-            rank[j] = nres + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            nres += __popcll(m);
-            if (fresh[j]) src_lds[wv][rank[j]] = (uint8_t)(me + 64 * j);
-        }
-        const uint32_t first0 = lane[0] - (uint32_t)me;
-        for (int base = 0; base < nres; base += 64) {        // one RESET block per resetting lane, 64 per pass
-            const int r = base + me;
-            if (r < nres) {
-                const int v = (int)src_lds[wv][r & (64 * LPT - 1)];
-                const uint32_t src_lane = first0 + (uint32_t)(v >> 6) * BLOCK + (uint32_t)(v & 63);
-                const uint4 w = philox4x32_10(src_lane, key.t_lo, key.t_hi, (uint32_t)POMDP_STREAM_RESET << 24, key.k0, key.k1);
-                res_lds[wv][r & (64 * LPT - 1)] = Env::reset_codes(w, key, src_lane, K);
-            }
-        }
-        const uint32_t start = (uint32_t)p.start_x | ((uint32_t)p.start_y << 4);
-        uint32_t fresh_codes[LPT];
-#pragma unroll
-        for (int j = 0; j < LPT; ++j) fresh_codes[j] = res_lds[wv][rank[j] & (64 * LPT - 1)];   // reads in flight together, one wait
-#pragma unroll
-        for (int j = 0; j < LPT; ++j) {
-            st[j].s = fresh[j] ? (typename Env::S)((uint64_t)start | ((uint64_t)fresh_codes[j] << 8)) : st[j].s;
-            const uint32_t H = blk_lds()[wv][16 * j + (me >> 2)][me & 3];
-            ob[j] = Env::sensor_ob(sh, st[j], aux[j], H, [&]() { return Env::elem(Env::quad_block(key, lane[j], 1u), lane[j] & 3u); });
-            if (CHAIN) a_next[j] = (int)__umulhi(blk_lds()[wv][NQ + 16 * j + (me >> 2)][me & 3], n_act);
+            st[j].s = fresh[j] ? Env::fresh_state(p, Rw[j], key, lane[j]) : st[j].s;
+            ob[j] = Env::sensor_ob(sh, st[j], aux[j], H[j], [&]() { return Env::elem(Env::quad_block(key, lane[j], 1u), lane[j] & 3u); });
+            if (CHAIN) a_next[j] = (int)__umulhi(P[j], n_act);
         }
     }
 };
@@ -521,7 +489,7 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
     }
     using Fin = Finisher<Env, LPT, true>;
     constexpr bool quad_policy = quad_policy_of<Fin>::value;
-    uint4 aq = make_uint4(0, 0, 0, 0), sq = make_uint4(0, 0, 0, 0);
+    uint4 aq = make_uint4(0, 0, 0, 0), sq = make_uint4(0, 0, 0, 0), rq = make_uint4(0, 0, 0, 0);
     const int n_act = Env::n_actions(p);
     const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo, ta0 = ((uint64_t)akey0.t_hi << 32) | akey0.t_lo;
     if (flags & FLAG_GEN_FIRST) {                        // wave-uniform: the policy's actions of the first call counter
@@ -534,26 +502,28 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
         }
     }
     action_w += rec;
+    // Tables once, BEFORE the loop; the first pre-pass rides under the load latency.  The staging reads the kernarg-resident
+    // tables with vector loads, and a loop that contains any load keeps the compiler from settling the loads above in the
+    // loop's pre-header: it then waits on vmcnt(0) in EVERY iteration for a register that arrived long ago — and stores
+    // count on that counter too (gfx9), so every step waited for the acknowledgement of the previous step's stores
+    // (round 3: 0.70 -> 0.45 us per step of a lone wave).  The loop below has no load.
+    if constexpr (Fin::HAS_PREPASS) {
+        const auto staged = Env::stage_load(p, (int)threadIdx.x);
+        Fin::prepass(key0, glane, akey0);
+        Env::stage_store(sh, staged, (int)threadIdx.x);
+    } else {
+        Env::stage(sh, p, (int)threadIdx.x);
+    }
+    __syncthreads();
+    if constexpr (TAB) {                                 // BLOCK threads = the 256 position bytes
+        Env::build_tab(tab, sh, p, (int)threadIdx.x);
+        __syncthreads();
+    }
     for (int s = 0; s < k_steps; ++s) {
         RngKey key = key0, akey = akey0;
         key.t_lo = (uint32_t)(t0 + (uint64_t)s); key.t_hi = (uint32_t)((t0 + (uint64_t)s) >> 32);
         akey.t_lo = (uint32_t)(ta0 + (uint64_t)s); akey.t_hi = (uint32_t)((ta0 + (uint64_t)s) >> 32);
-        if (s == 0) {                                    // tables once; the first pre-pass rides under the load latency
-            if constexpr (Fin::HAS_PREPASS) {
-                const auto staged = Env::stage_load(p, (int)threadIdx.x);
-                Fin::prepass(key, glane, akey);
-                Env::stage_store(sh, staged, (int)threadIdx.x);
-            } else {
-                Env::stage(sh, p, (int)threadIdx.x);
-            }
-            __syncthreads();
-            if constexpr (TAB) {                         // BLOCK threads = the 256 position bytes
-                Env::build_tab(tab, sh, p, (int)threadIdx.x);
-                __syncthreads();
-            }
-        } else {
-            if constexpr (Fin::HAS_PREPASS) Fin::prepass(key, glane, akey);
-        }
+        if constexpr (Fin::HAS_PREPASS) { if (s > 0) Fin::prepass(key, glane, akey); }
         int o[LPT], d[LPT];
         typename Env::Reward r[LPT];
         typename Fin::Aux aux[LPT];
@@ -574,6 +544,7 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
                     RngKey ke = key0;
                     ke.t_lo = (uint32_t)te; ke.t_hi = (uint32_t)(te >> 32);
                     sq = quad_transpose4(Env::quad_block(ke, glane[0], 0u), glane[0] & 3u);
+                    rq = quad_transpose4(Env::reset_block(ke, glane[0], 0u), glane[0] & 3u);   // the quad's RESET words likewise
                 }
                 const int sj = s & 3;                                            // wave-uniform selects
                 const uint32_t H = sj == 0 ? sq.x : sj == 1 ? sq.y : sj == 2 ? sq.z : sq.w;
@@ -594,8 +565,13 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
                 aq = quad_transpose4(philox4x32_10(glane[0] >> 2, (uint32_t)te, (uint32_t)(te >> 32),
                                                    (uint32_t)POMDP_STREAM_ACTION << 24, akey0.k0, akey0.k1), e);
             }
-            Fin::resets_only(sh, p, st, fresh, key, glane);
             const int sj = s & 3;                                            // wave-uniform selects
+            if constexpr (Env::QUAD_SENSOR) {                                // RockSample: this lane's RESET word of step s
+                const uint32_t rword = sj == 0 ? rq.x : sj == 1 ? rq.y : sj == 2 ? rq.z : rq.w;
+                st[0].s = fresh[0] ? Env::fresh_state(p, rword, key, glane[0]) : st[0].s;
+            } else {
+                Fin::resets_only(sh, p, st, fresh, key, glane);
+            }
             const uint32_t word = sj == 0 ? aq.x : sj == 1 ? aq.y : sj == 2 ? aq.z : aq.w;
             a_next[0] = (int)__umulhi(word, (uint32_t)n_act);
         } else {
@@ -1280,16 +1256,14 @@ static __device__ __forceinline__ u32x4 first_actions4(uint32_t *action_row0, in
 }
 
 // The fused RockSample loop with a thread owning four CONSECUTIVE lanes — a quad.  RockSample's word contract shares the
-// STEP block and the policy's ACTION block among the four lanes of a quad, so with this mapping both blocks are the
-// thread's own: two Philox blocks per thread-step straight into registers, lane j taking element j — no exchange through LDS,
-// no selects.  A thread's outputs are four consecutive elements of each column: one 16-byte store per int32 column and one
-// 4-byte store of the packed done bytes per step instead of twenty scalar stores; state and first actions come in the
-// same way.  The lane step is the table-driven one; resets are pooled per wave as in Finisher<RockEnv> (pooling them over the workgroup's four
-// waves instead — one pass at 80 % of its width where four run at 20 % — costs two barriers per step and measured 3.21 against
-// 2.85 us per step: the loop lives on its waves drifting apart; two quads per thread — half as many waves, each reset pass
-// twice as full — 3.58 against 2.80).  Full workgroups
-// of 1024 lanes and auto-reset only (the launcher's SIMPLE conditions).  Same results as steps_kernel: the mapping of lanes
-// to threads is invisible to a lane's random words.
+// STEP block, the RESET block and the policy's ACTION block among the four lanes of a quad, so with this mapping all
+// three are the thread's own: three Philox blocks per thread-step straight into registers, lane j taking element j — no
+// exchange through LDS, no ballots, no task lists, and no dependence on the lane step: the compiler interleaves the three
+// chains with the table lookups.  A thread's outputs are four consecutive elements of each column: one 16-byte store per
+// int32 column and one 4-byte store of the packed done bytes per step instead of twenty scalar stores; state and first
+// actions come in the same way.  The lane step is the table-driven one.  Full workgroups of 1024 lanes and auto-reset
+// only (the launcher's SIMPLE conditions).  Same results as steps_kernel: the mapping of lanes to threads is invisible
+// to a lane's random words.
 template <class Env>
 __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict__ state, int32_t *__restrict__ action,
                                                            int32_t *__restrict__ ob, int32_t *__restrict__ reward,
@@ -1301,12 +1275,8 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
     using S = typename Env::S;
     __shared__ typename Env::Shared sh;
     __shared__ typename Env::StepTab tab;
-    __shared__ uint8_t src_lds[BLOCK / 64][256];             // reset rank -> lane within the wave's 256
-    __shared__ uint32_t res_lds[BLOCK / 64][256];            // reset rank -> the fresh episode's rock codes
-    const int wv = (int)(threadIdx.x >> 6), me = (int)(threadIdx.x & 63u);
     const uint32_t l0 = blockIdx.x * (uint32_t)(4 * BLOCK) + 4u * threadIdx.x;   // this thread's first lane within the shard
     const uint32_t glane0 = lane0 + l0;                                          // ... and its global lane id (a multiple of 4)
-    const uint32_t wave0 = glane0 - 4u * (uint32_t)me;                           // global lane id of the wave's first lane
     uint32_t *action_w = reinterpret_cast<uint32_t *>(action) + l0, *ob_w = reinterpret_cast<uint32_t *>(ob) + l0;
     uint32_t *reward_w = reinterpret_cast<uint32_t *>(reward) + l0;
     uint32_t *done_w = reinterpret_cast<uint32_t *>(done + l0);
@@ -1336,12 +1306,13 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
         RngKey key = key0;
         key.t_lo = (uint32_t)(t0 + (uint64_t)s); key.t_hi = (uint32_t)((t0 + (uint64_t)s) >> 32);
         const uint64_t ta = ta0 + (uint64_t)s;
-        // the quad's sensor words of this step (StochasticRock: block 2 of the stream — block 0 gates the actions, rock.py:443)
-        // and its policy words of the next call counter
+        // the quad's sensor words of this step (StochasticRock: block 2 of the stream — block 0 gates the actions, rock.py:443),
+        // the words its fresh episodes start from, and its policy words of the next call counter
         constexpr uint32_t SENSOR_BLOCK = Env::STOCHASTIC ? 2u : 0u;
         const uint4 sw = philox4x32_10(glane0 >> 2, key.t_lo, key.t_hi, ((uint32_t)POMDP_STREAM_STEP << 24) | SENSOR_BLOCK, key.k0, key.k1);
+        const uint4 rw = Env::reset_block(key, glane0, 0u);
         const uint4 pw = philox4x32_10(glane0 >> 2, (uint32_t)ta, (uint32_t)(ta >> 32), (uint32_t)POMDP_STREAM_ACTION << 24, key.k0, key.k1);
-        const uint32_t H[4] = {sw.x, sw.y, sw.z, sw.w}, P[4] = {pw.x, pw.y, pw.z, pw.w};
+        const uint32_t H[4] = {sw.x, sw.y, sw.z, sw.w}, P[4] = {pw.x, pw.y, pw.z, pw.w}, R[4] = {rw.x, rw.y, rw.z, rw.w};
         bool acts[4] = {true, true, true, true};
         if constexpr (Env::STOCHASTIC) {                                       // the action is applied iff binomial(1, p_move) says so
             const uint4 gw = Env::quad_block(key, glane0, 0u);
@@ -1351,38 +1322,22 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
                 acts[j] = Env::k53_le(G[j], (uint32_t)(p.act_thr >> 26), (uint32_t)p.act_thr & Env::LO_MASK,
                                       [&]() { return Env::elem(Env::quad_block(key, glane0, 1u), (uint32_t)j); });
         }
-        int r[4], d[4], rank[4], nres = 0;
-        typename Env::Aux aux[4];
+        int r[4], d[4];
+        uint32_t o[4], a_next[4], codes[4];
+        Env::reset_codes4(R, key, glane0, K, codes);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+            typename Env::Aux aux;
             if constexpr (Env::STOCHASTIC) {
                 typename Env::State nx = st[j];
-                Env::step_tab(tab, nx, a_cur[j], r[j], d[j], aux[j]);
-                if (acts[j]) st[j] = nx; else { r[j] = 0; d[j] = 0; aux[j].want = false; }
+                Env::step_tab(tab, nx, a_cur[j], r[j], d[j], aux);
+                if (acts[j]) st[j] = nx; else { r[j] = 0; d[j] = 0; aux.want = false; }
             } else {
-                Env::step_tab(tab, st[j], a_cur[j], r[j], d[j], aux[j]);
+                Env::step_tab(tab, st[j], a_cur[j], r[j], d[j], aux);
             }
-            const uint64_t m = __ballot(d[j] != 0);                            // done lanes start a new episode
-            rank[j] = nres + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            nres += __popcll(m);
-            if (d[j]) src_lds[wv][rank[j]] = (uint8_t)(4 * me + j);
-        }
-        for (int base = 0; base < nres; base += 64) {        // one RESET block per resetting lane, 64 per pass
-            const int q = base + me;
-            if (q < nres) {
-                const uint32_t src_lane = wave0 + (uint32_t)src_lds[wv][q & 255];
-                const uint4 w = philox4x32_10(src_lane, key.t_lo, key.t_hi, (uint32_t)POMDP_STREAM_RESET << 24, key.k0, key.k1);
-                res_lds[wv][q & 255] = Env::reset_codes(w, key, src_lane, K);
-            }
-        }
-        uint32_t o[4], a_next[4], fresh_codes[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) fresh_codes[j] = res_lds[wv][rank[j] & 255];   // four reads in flight, one wait; used where d[j]
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            st[j].s = d[j] ? (S)((uint64_t)start | ((uint64_t)fresh_codes[j] << 8)) : st[j].s;
             const uint32_t lane = glane0 + (uint32_t)j;
-            o[j] = (uint32_t)Env::sensor_ob(sh, st[j], aux[j], H[j], [&]() { return Env::elem(Env::quad_block(key, lane, SENSOR_BLOCK + 1u), (uint32_t)j); });
+            st[j].s = d[j] ? (S)((uint64_t)start | ((uint64_t)codes[j] << 8)) : st[j].s;   // done lanes start a new episode
+            o[j] = (uint32_t)Env::sensor_ob(sh, st[j], aux, H[j], [&]() { return Env::elem(Env::quad_block(key, lane, SENSOR_BLOCK + 1u), (uint32_t)j); });
             a_next[j] = __umulhi(P[j], n_act);
             a_cur[j] = (int)a_next[j];
         }
@@ -1416,13 +1371,10 @@ __global__ __launch_bounds__(BLOCK) void step_quad_kernel(uint32_t *__restrict__
     constexpr int W = Env::WORDS;
     using S = typename Env::S;
     __shared__ typename Env::Shared sh;
-    __shared__ uint8_t src_lds[BLOCK / 64][256];             // reset rank -> lane within the wave's 256
-    __shared__ uint32_t res_lds[BLOCK / 64][256];            // reset rank -> the fresh episode's rock codes
-    const int wv = (int)(threadIdx.x >> 6), me = (int)(threadIdx.x & 63u);
     TL(0);
     const bool auto_reset = flags & POMDP_AUTO_RESET;
     const uint32_t l0 = blockIdx.x * (uint32_t)(4 * BLOCK) + 4u * threadIdx.x;
-    const uint32_t glane0 = lane0 + l0, wave0 = glane0 - 4u * (uint32_t)me;
+    const uint32_t glane0 = lane0 + l0;
     uint32_t *const done_w = reinterpret_cast<uint32_t *>(done + l0);
     const u32x4 s_lo = ld_stream4(state + l0);
     u32x4 s_hi = {0, 0, 0, 0};
@@ -1432,8 +1384,8 @@ __global__ __launch_bounds__(BLOCK) void step_quad_kernel(uint32_t *__restrict__
     const auto staged = Env::stage_load(p, (int)threadIdx.x);
     // the quad's words depend on lane ids only: Philox under the load latency
     constexpr uint32_t SENSOR_BLOCK = Env::STOCHASTIC ? 2u : 0u;
-    const uint4 sw = Env::quad_block(key, glane0, SENSOR_BLOCK);
-    const uint32_t H[4] = {sw.x, sw.y, sw.z, sw.w};
+    const uint4 sw = Env::quad_block(key, glane0, SENSOR_BLOCK), rw = Env::reset_block(key, glane0, 0u);
+    const uint32_t H[4] = {sw.x, sw.y, sw.z, sw.w}, R[4] = {rw.x, rw.y, rw.z, rw.w};
     uint32_t G[4] = {0, 0, 0, 0};
     if constexpr (Env::STOCHASTIC) { const uint4 gw = Env::quad_block(key, glane0, 0u); G[0] = gw.x; G[1] = gw.y; G[2] = gw.z; G[3] = gw.w; }
     Env::stage_store(sh, staged, (int)threadIdx.x);
@@ -1446,8 +1398,8 @@ __global__ __launch_bounds__(BLOCK) void step_quad_kernel(uint32_t *__restrict__
     const uint32_t n_act = (uint32_t)Env::n_actions(p);
     typename Env::State st[4];
     typename Env::Aux aux[4];
-    int r[4], d[4], rank[4], nres = 0;
-    bool live[4];
+    int r[4], d[4];
+    bool live[4], fresh[4];
     uint32_t n_bad = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -1462,13 +1414,9 @@ __global__ __launch_bounds__(BLOCK) void step_quad_kernel(uint32_t *__restrict__
             acts = acts && Env::k53_le(G[j], (uint32_t)(p.act_thr >> 26), (uint32_t)p.act_thr & Env::LO_MASK,
                                        [&]() { return Env::elem(Env::quad_block(key, glane0, 1u), (uint32_t)j); });
         if (acts) st[j] = nx; else { r[j] = 0; d[j] = live[j] ? 0 : (int)was_done; aux[j].want = false; }
-        const uint64_t m = __ballot(acts && d[j] != 0 && auto_reset);              // done lanes start a new episode
-        rank[j] = nres + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        nres += __popcll(m);
-        if (acts && d[j] && auto_reset) src_lds[wv][rank[j]] = (uint8_t)(4 * me + j);
+        fresh[j] = acts && d[j] != 0 && auto_reset;                                // done lanes start a new episode
     }
-    // everything but the state is known before the resets: those stores drain under the reset pass.  (A CHECK neither moves
-    // the agent nor ends the episode: the sensor reads the state the step left.)
+    // (A CHECK neither moves the agent nor ends the episode: the sensor reads the state the step left.)
     uint32_t o[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -1477,22 +1425,9 @@ __global__ __launch_bounds__(BLOCK) void step_quad_kernel(uint32_t *__restrict__
     st_stream4(reinterpret_cast<uint32_t *>(reward) + l0, (uint32_t)r[0], (uint32_t)r[1], (uint32_t)r[2], (uint32_t)r[3]);
     st_stream(done_w, (uint32_t)d[0] | ((uint32_t)d[1] << 8) | ((uint32_t)d[2] << 16) | ((uint32_t)d[3] << 24));
     TL(3);
-    const int K = p.num_rocks;
-    for (int base = 0; base < nres; base += 64) {            // one RESET block per resetting lane, 64 per pass
-        const int q = base + me;
-        if (q < nres) {
-            const uint32_t src_lane = wave0 + (uint32_t)src_lds[wv][q & 255];
-            const uint4 w = philox4x32_10(src_lane, key.t_lo, key.t_hi, (uint32_t)POMDP_STREAM_RESET << 24, key.k0, key.k1);
-            res_lds[wv][q & 255] = Env::reset_codes(w, key, src_lane, K);
-        }
-    }
-    const uint32_t start = (uint32_t)p.start_x | ((uint32_t)p.start_y << 4);
-    uint32_t fresh_codes[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) fresh_codes[j] = res_lds[wv][rank[j] & 255];       // four reads in flight, one wait
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-        st[j].s = (live[j] && d[j] && auto_reset) ? (S)((uint64_t)start | ((uint64_t)fresh_codes[j] << 8)) : st[j].s;
+        st[j].s = fresh[j] ? Env::fresh_state(p, R[j], key, glane0 + (uint32_t)j) : st[j].s;
     st_stream4(state + l0, (uint32_t)st[0].s, (uint32_t)st[1].s, (uint32_t)st[2].s, (uint32_t)st[3].s);
     if (W == 2)
         st_stream4(state + n + l0, (uint32_t)((uint64_t)st[0].s >> 32), (uint32_t)((uint64_t)st[1].s >> 32),

@@ -30,6 +30,23 @@ def _random_seed():
     return int.from_bytes(os.urandom(8), "little")
 
 
+def _public_raw_stream(dev_index):
+    return torch.cuda.current_stream(dev_index).cuda_stream
+
+
+def _resolve_fast_handles(c_module=None):
+    """(raw hipStream_t of torch's current stream on a device, current device index) as plain callables.  torch keeps
+    both as private C functions (no Stream object built, no device query through python); they are not a stable API, so
+    they are looked up ONCE here and anything missing falls back to the public calls (tests/test_host_logic.py)."""
+    c_module = torch._C if c_module is None else c_module
+    raw = getattr(c_module, "_cuda_getCurrentRawStream", None)
+    cur = getattr(c_module, "_cuda_getDevice", None)
+    return (raw if callable(raw) else _public_raw_stream), (cur if callable(cur) else torch.cuda.current_device)
+
+
+_raw_stream, _current_device = _resolve_fast_handles()
+
+
 STAGGER_BYTES = 4096
 
 
@@ -114,6 +131,8 @@ class BatchedEnv(object):
         self._has_reset = False
         self._last_reset = None
         self._scalar_done = False
+        self._dev_flags_used = False    # a C-side driver wrote the device-side ob / done of a scalar env (see reset())
+        self._collect_cache = {}        # collect_synthetic: bound argument structs by (buffer pointers, steps)
         self._tracker = None          # per-step side effects beyond (state, ob, reward, done): RockSample's side statistics
         self._done_bool = self._done.view(torch.bool)
         self._ptrs = (self._state.data_ptr(), self._ob.data_ptr(), self._reward.data_ptr(), self._done.data_ptr(),
@@ -173,16 +192,19 @@ class BatchedEnv(object):
 
     def _stream(self):
         """hipStream_t of torch's current stream on this env's device (the raw handle: no Stream object is built)."""
-        return torch._C._cuda_getCurrentRawStream(self._dev_index)
+        return _raw_stream(self._dev_index)
 
     def reset(self):
         """All lanes start a new episode.  Returns ob: int32[N] tensor (python int if batch_size == 1)."""
         t = self._t
         self._t += 1
-        if self.batch_size == 1 and torch._C._cuda_getDevice() == self._dev_index:
-            # scalar mode: the observation goes straight to pinned host memory; launch and wait in one FFI call, read
+        if self.batch_size == 1 and not self._dev_flags_used and _current_device() == self._dev_index:
+            # scalar mode: the observation goes straight to pinned host memory; launch and wait in one FFI call, read.
+            # Only while nothing has written the DEVICE-side ob / done of this env: heuristic_steps() and
+            # rollout_synthetic() take the device done flag as an in/out freeze flag, so after them the general path
+            # below runs once (it clears that flag and refreshes the device-side observation)
             rc = self._lib.pomdp_reset_sync(self._step_args.env, self._params_ref, self._ptrs[0], self._host_ptrs[0], 1, self._seed,
-                                            self.lane_offset, t, torch._C._cuda_getCurrentRawStream(self._dev_index))
+                                            self.lane_offset, t, _raw_stream(self._dev_index))
             _native.check(rc, "pomdp_%s_reset" % self.env_name)
             self._host_out[2] = 0
             if self._tracker is not None:
@@ -203,6 +225,7 @@ class BatchedEnv(object):
                 self._tracker.on_reset()
         self._has_reset = True
         self._scalar_done = False
+        self._dev_flags_used = False
         self._last_reset = (ob, t)      # History() picks the current observation up from here
         self.done = False if self.batch_size == 1 else self._done.view(torch.bool)
         if self.batch_size == 1:
@@ -226,10 +249,10 @@ class BatchedEnv(object):
             action = self._as_action_tensor(action)           # slow path: convert / validate
         t = self._t
         self._t = t + 1
-        if self.reuse_buffers and torch._C._cuda_getDevice() == self._dev_index:
+        if self.reuse_buffers and _current_device() == self._dev_index:
             # hot path: one FFI call with four arguments (the rest is bound in self._step_args), no allocation, no
             # device-context switch, the raw stream handle
-            rc = self._bound_step(self._step_args_ref, action.data_ptr(), t, torch._C._cuda_getCurrentRawStream(self._dev_index))
+            rc = self._bound_step(self._step_args_ref, action.data_ptr(), t, _raw_stream(self._dev_index))
             if rc:
                 _native.check(rc, "pomdp_%s_step" % self.env_name)
             if self._tracker is not None:
@@ -259,9 +282,9 @@ class BatchedEnv(object):
         FFI call (pomdp_step_sync) — python scalars out."""
         t = self._t
         self._t = t + 1
-        if self._tracker is None and torch._C._cuda_getDevice() == self._dev_index:
+        if self._tracker is None and _current_device() == self._dev_index:
             rc = self._bound_step_sync(self._scalar_args_ref, self._action_base + 4 * action, t,
-                                       torch._C._cuda_getCurrentRawStream(self._dev_index))
+                                       _raw_stream(self._dev_index))
             if rc:
                 _native.check(rc, "pomdp_%s_step" % self.env_name)
         else:
@@ -444,6 +467,7 @@ class BatchedEnv(object):
             self._action_scratch = torch.empty(self.batch_size, dtype=torch.int32, device=self.device)
         t0 = self._t
         self._t += int(steps)
+        self._dev_flags_used = True
         with torch.cuda.device(self.device):
             rc = self._lib.pomdp_heuristic_steps(
                 _native.ENV_KIND[self.env_name], self._params_ref, self._state.data_ptr(),
@@ -526,6 +550,7 @@ class BatchedEnv(object):
             actions = self._action_scratch
         t0 = self._t
         self._t += int(steps)
+        self._dev_flags_used = True
         with torch.cuda.device(self.device):
             rc = self._lib.pomdp_rollout_synthetic(
                 _native.ENV_KIND[self.env_name], self._params_ref, self._state.data_ptr(), actions.data_ptr(),
@@ -570,21 +595,28 @@ class BatchedEnv(object):
         steps, n = int(steps), self.batch_size
         if out is None:
             out = self.trajectory_buffers(steps)
-        bound = out.get("_bound")
-        if bound is None or bound[2] != steps:
-            # the call's per-buffer arguments, bound once per `out` (include/pomdp_hip.h: pomdp_collect_args)
-            assert out["action"].shape == (steps + 1, n) and out["ob"].shape == (steps, n)
+        if not (out["action"].shape == (steps + 1, n) and out["ob"].shape == (steps, n) and out["reward"].shape == (steps, n)
+                and out["done_u8"].shape == (steps, n)):
+            raise ValueError("collect_synthetic: `out` does not have the shapes of trajectory_buffers(%d)" % steps)
+        # the call's per-buffer arguments (include/pomdp_hip.h: pomdp_collect_args), bound once per set of buffers: the
+        # cache lives on the env and is keyed by the buffers' addresses, so a dict handed to another env, or one whose
+        # tensors were replaced, never meets a stale struct
+        key = (out["action"].data_ptr(), out["ob"].data_ptr(), out["reward"].data_ptr(), out["done_u8"].data_ptr(), steps)
+        bound = self._collect_cache.get(key)
+        if bound is None:
+            if len(self._collect_cache) >= 64:
+                self._collect_cache.clear()
             a = _native.CollectArgs(env=_native.ENV_KIND[self.env_name], flags=_native.POMDP_AUTO_RESET,
-                                    params=C.addressof(self._params), state=self._ptrs[0], action=out["action"].data_ptr(),
-                                    ob=out["ob"].data_ptr(), reward=out["reward"].data_ptr(), done=out["done_u8"].data_ptr(),
+                                    params=C.addressof(self._params), state=self._ptrs[0], action=key[0],
+                                    ob=key[1], reward=key[2], done=key[3],
                                     err=self._ptrs[4], n=n, pitch=n, seed=self._seed,
                                     lane0=self.lane_offset, reserved=0)
-            bound = out["_bound"] = (a, C.byref(a), steps)
+            bound = self._collect_cache[key] = (a, C.byref(a), steps)
         bound[0].seed = self._seed
         t0 = self._t
         self._t = t0 + steps
-        if torch._C._cuda_getDevice() == self._dev_index:         # no device-context switch on the common path
-            rc = self._lib.pomdp_collect(bound[1], t0, steps, torch._C._cuda_getCurrentRawStream(self._dev_index))
+        if _current_device() == self._dev_index:         # no device-context switch on the common path
+            rc = self._lib.pomdp_collect(bound[1], t0, steps, _raw_stream(self._dev_index))
         else:
             with torch.cuda.device(self.device):
                 rc = self._lib.pomdp_collect(bound[1], t0, steps, self._stream())

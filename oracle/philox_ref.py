@@ -84,7 +84,7 @@ def split_words(seed, lane, t, stream, n_doubles):
     """Per-lane *split layout* of a stream whose draws are all doubles: double j takes its high word from element
     j & 3 of block 2 (j >> 2) and its low word from the same element of block 2 (j >> 2) + 1; the kernels generate
     the odd ("low") blocks only when a high word leaves a comparison undecided.  Returns the 2 * n_doubles words
-    numpy consumes, in order.  Used by RockSample's RESET stream and Network's STEP stream."""
+    numpy consumes, in order.  Used by Network's STEP stream."""
     out = []
     for j in range(n_doubles):
         hi = _block(seed, lane, t, stream, 2 * (j >> 2))[j & 3]
@@ -99,20 +99,21 @@ def rotr32(w, r):
 
 
 def rock_reset_words(seed, lane, t, n_rocks):
-    """RockSample's RESET stream ("rotated split layout").  reset() draws one double per rock and only
-    uses sign(U - .5), i.e. the top bit of the double's high word (the rest matters only when the top 27 bits are
-    exactly 2^26: a tie, probability 2^-27).  One Philox block therefore serves SIXTEEN rocks: rock j = 4 q + e
-    (e = j & 3, q = (j >> 2) & 3) takes as its high word element e of block 2 (j >> 4) rotated right by 8 q + 8 bits
-    (q = 3: unrotated), and as its low word the same element of block 2 (j >> 4) + 1 under the same rotation.  The
-    top bits of the four rotations are bits 7, 15, 23, 31 of the element — independent fair bits — so the rock
-    statuses are independent Bernoulli(1/2) exactly as in the reference.  The kernels generate the low block only on a
-    tie.  Returns the 2 * n_rocks words numpy consumes, in order."""
+    """RockSample's RESET stream ("rotated split layout", shared by the four lanes of a quad like the
+    STEP stream).  reset() draws one double per rock and only uses sign(U - .5), i.e. the top bit of the double's high
+    word (the rest matters only when the top 27 bits are exactly 2^26: a tie, probability 2^-27).  ONE 32-bit word
+    therefore serves all K <= 16 rocks of a lane: the Philox counter carries lane >> 2, lane L uses element L & 3, and
+    rock j takes as its high word that element of block 0 rotated right by 2 j + 2 bits (j = 15: unrotated) and as its
+    low word the same element of block 1 under the same rotation.  The top bits of the rotations are bits 1, 3, ..., 31
+    of the element — independent fair bits — so the rock statuses are independent Bernoulli(1/2) exactly as in the
+    reference, and they sit where the packed state keeps the upper bit of each rock's 2-bit code.  The kernels
+    generate the low block only on a tie.  Returns the 2 * n_rocks words numpy consumes, in order."""
+    hi_w = int(_block(seed, lane >> 2, t, STREAM_RESET, 0)[lane & 3])
+    lo_w = int(_block(seed, lane >> 2, t, STREAM_RESET, 1)[lane & 3])
     out = []
     for j in range(n_rocks):
-        e, rot = j & 3, 8 * ((j >> 2) & 3) + 8
-        hi = rotr32(_block(seed, lane, t, STREAM_RESET, 2 * (j >> 4))[e], rot)
-        lo = rotr32(_block(seed, lane, t, STREAM_RESET, 2 * (j >> 4) + 1)[e], rot)
-        out += [int(hi), int(lo)]
+        rot = (2 * j + 2) & 31
+        out += [rotr32(hi_w, rot), rotr32(lo_w, rot)]
     return np.array(out, dtype=np.uint32)
 
 

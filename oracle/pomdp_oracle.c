@@ -76,12 +76,12 @@ void or_ws_philox(or_ws *ws, uint64_t seed, uint32_t lane, uint64_t t, uint32_t 
 }
 
 /* RockSample: every draw is a double, double j = (high word, low word) with the two halves in different Philox
- * blocks (split layout); the STEP stream is additionally shared by the four lanes of a quad.  See
+ * blocks (split layout); both streams are shared by the four lanes of a quad (counter word 0 = lane >> 2).  See
  * oracle/philox_ref.py rock_reset_words / rock_step_words for the normative statement. */
 void or_ws_philox_env(or_ws *ws, int env_kind, uint64_t seed, uint32_t lane, uint64_t t, uint32_t stream)
 {
     or_ws_philox(ws, seed, lane, t, stream);
-    if (env_kind == OR_ENV_ROCK && stream == OR_STREAM_RESET) ws->layout = 3;   /* rotated: one block, sixteen rocks */
+    if (env_kind == OR_ENV_ROCK && stream == OR_STREAM_RESET) { ws->layout = 3; ws->ctr[0] = lane >> 2; }   /* quad-shared, rotated */
     if (env_kind == OR_ENV_ROCK && stream == OR_STREAM_STEP) { ws->layout = 2; ws->ctr[0] = lane >> 2; }
     /* Network: every draw of step() is a double too (one per up machine, one for the action): per-lane split layout */
     if (env_kind == OR_ENV_NETWORK && stream == OR_STREAM_STEP) ws->layout = 1;
@@ -102,10 +102,11 @@ uint32_t or_ws_next32(or_ws *ws)
     if (ws->layout != 0) {
         const uint32_t i = ws->widx++, j = i >> 1, half = i & 1u;        /* word i = half `half` of double j */
         /* layout 1: per-lane split (four doubles per block pair); 2: quad-shared split (one double per lane per pair);
-         * 3: RockSample reset — double j = element j & 3 of block pair j >> 4, rotated right by 8 ((j >> 2) & 3) + 8 */
-        const uint32_t block = ws->layout == 1 ? 2u * (j >> 2) + half : ws->layout == 3 ? 2u * (j >> 4) + half : 2u * j + half;
-        const uint32_t elem = ws->layout == 2 ? (ws->lane & 3u) : (j & 3u);
-        const uint32_t rot = ws->layout == 3 ? ((8u * ((j >> 2) & 3u) + 8u) & 31u) : 0u;
+         * 3: RockSample reset — quad-shared like 2, ONE block pair: double j (rock j) = the lane's element of block
+         *    `half` rotated right by 2 j + 2 bits (its top bit is bit 2 j + 1 of the element) */
+        const uint32_t block = ws->layout == 1 ? 2u * (j >> 2) + half : ws->layout == 3 ? half : 2u * j + half;
+        const uint32_t elem = ws->layout == 1 ? (j & 3u) : (ws->lane & 3u);
+        const uint32_t rot = ws->layout == 3 ? ((2u * j + 2u) & 31u) : 0u;
         if (!ws->half_have[half] || ws->half_idx[half] != block) {
             uint32_t c[4] = { ws->ctr[0], ws->ctr[1], ws->ctr[2], ws->ctr[3] | block };
             or_philox4x32_10(c, ws->key, ws->half_blk[half]);

@@ -42,13 +42,13 @@ def main(n_reset=6, n_sensor=8):
     lane = 0
     while len(reset_ties) < n_reset or len(sensor_ties) < n_sensor:
         c0 = np.arange(lane, lane + CHUNK, dtype=np.uint64)
-        if len(reset_ties) < n_reset:                                    # reset at t = 0: block 0 per lane, rotated layout
+        if len(reset_ties) < n_reset:                                    # reset at t = 0: block 0 of quad c0, element e = lane c0 * 4 + e
             blk = blocks(c0, 0, px.STREAM_RESET, 0).astype(np.uint64)
-            for q in (0, 1):                                             # rocks 4 q + e: element e rotated right by 8 q + 8
-                r = np.uint64(8 * q + 8)
+            for j in range(8):                                           # rock j: the lane's word rotated right by 2 j + 2
+                r = np.uint64(2 * j + 2)
                 kh = (((blk >> r) | (blk << (np.uint64(32) - r))) & np.uint64(0xFFFFFFFF)) >> np.uint64(5)
-                for li, e in zip(*np.nonzero(kh == (1 << 26))):
-                    reset_ties.append((int(c0[li]), 4 * q + int(e)))
+                for qi, e in zip(*np.nonzero(kh == (1 << 26))):
+                    reset_ties.append((int(c0[qi]) * 4 + int(e), j))
         if len(sensor_ties) < n_sensor:                                  # first step at t = 1: block 0 of quad c0
             kh = blocks(c0, 1, px.STREAM_STEP, 0) >> np.uint32(5)
             for d, th in thr_hi.items():

@@ -330,16 +330,25 @@ def main():
         da = gen_mode_a(case, env, kwargs, TA)
         db, mw = gen_mode_b(case, env, kwargs, L, TB)
         print("%-18s modeA dones=%4d  modeB dones=%5d  max words/call=%d" % (case, da, db, mw), flush=True)
+    wanted = lambda case: not only or any(case.startswith(o) for o in only)   # noqa: E731  (--only=<case prefix>, repeatable)
     for case, env, kwargs, L, T in PROB_CASES:
+        if not wanted(case):
+            continue
         gen_prob(case, env, kwargs, L, T)
         print("compute_prob %-14s ok" % case, flush=True)
     for case, env, kwargs, R, S, depth, alla in ROLLOUT_CASES:
+        if not wanted(case):
+            continue
         nt, ms = gen_rollout(case, env, kwargs, R, S, depth, alla)
         print("rollout %-18s terminated=%4d / %d  mean steps=%.1f" % (case, nt, R * S, ms), flush=True)
     for case, env, kwargs, L, T in HEUR_CASES:
+        if not wanted(case):
+            continue
         nd, ml, tries = gen_heuristic(case, env, kwargs, L, T)
         print("heuristic %-16s dones=%4d  mean preferred-list length=%.2f  (seed retries %d)" % (case, nd, ml, tries), flush=True)
     for case, env, kwargs, L, T, ms in HEUR_BOUNDED:
+        if not wanted(case):
+            continue
         nd, ml, tries = gen_heuristic(case, env, kwargs, L, T, max_size=ms)
         print("heuristic %-16s dones=%4d  mean preferred-list length=%.2f  (seed retries %d)" % (case, nd, ml, tries), flush=True)
     with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:

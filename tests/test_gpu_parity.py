@@ -1161,3 +1161,80 @@ def test_collect_into_columns_that_are_not_16_byte_aligned():
     assert torch.equal(act.view(steps + 1, n), ref["action"]) and torch.equal(ob.view(steps, n), ref["ob"])
     assert torch.equal(rew.view(steps, n), ref["reward"]) and torch.equal(done.view(steps, n), ref["done_u8"])
     assert torch.equal(a.state, b.state)
+
+
+@pytest.mark.parametrize("env,kw,how", [("rock", dict(use_heuristic=True), "heuristic"), ("tiger", {}, "heuristic"),
+                                        ("tiger", {}, "rollout"), ("rock", {}, "rollout")],
+                         ids=["rock-heuristic", "tiger-heuristic", "tiger-rollout", "rock-rollout"])
+def test_scalar_env_keeps_stepping_through_the_c_side_drivers_after_a_reset(env, kw, how):
+    """A batch_size=1 env whose episode ended inside heuristic_steps() / rollout_synthetic() — both take the DEVICE-side
+    done flag as an in/out freeze flag — must be live again after reset(): lane L of a scalar env == lane L of a frozen
+    batch (auto_reset=False; itself checked against the oracle above), call for call, across several resets."""
+    from gym_pomdp_amd import History
+    seed, lane0, n = 77, 4096, 64
+    # a lane whose first episode is short (RockSample's heuristic policy can keep CHECKing for hundreds of steps): scout with
+    # a frozen batch, then pair the scalar env with a batch that starts at that lane
+    scout = make_env(env, kw, batch_size=256, seed=seed, lane_offset=lane0, auto_reset=False)
+    scout.reset()
+    if how == "heuristic":
+        scout.heuristic_steps(History(scout), 200)
+    else:
+        scout.rollout_synthetic(200)
+    ended = torch.nonzero(scout._done).flatten()
+    assert len(ended) > 0
+    lane0 += int(ended[0]) & ~3
+    pick = int(ended[0]) & 3
+    s = make_env(env, kw, seed=seed, lane_offset=lane0 + pick)
+    b = make_env(env, kw, batch_size=n, seed=seed, lane_offset=lane0, auto_reset=False)
+    assert s.reset() == int(b.reset()[pick])
+    hs, hb = (History(s), History(b)) if how == "heuristic" else (None, None)
+    resets = 0
+    for i in range(1500):
+        if how == "heuristic":
+            outs_s, outs_b = s.heuristic_steps(hs, 1), b.heuristic_steps(hb, 1)
+        else:
+            outs_s, outs_b = s.rollout_synthetic(1), b.rollout_synthetic(1)
+            outs_s = (s._action_scratch,) + tuple(outs_s)
+            outs_b = (b._action_scratch,) + tuple(outs_b)
+        row_s, row_b = [x[0].item() for x in outs_s], [x[pick].item() for x in outs_b]
+        assert row_s == row_b, (env, how, i, row_s, row_b)
+        assert torch.equal(s.state[:, 0], b.state[:, pick]), (env, how, i)
+        if row_s[-1]:                                  # done: the reference's caller resets and goes on
+            resets += 1
+            assert s.reset() == int(b.reset()[pick])
+            if how == "heuristic":
+                hs, hb = History(s), History(b)
+            if resets == 3:
+                break
+    assert resets >= 1, resets                         # (later episodes of the same lane may be long ones)
+
+
+def test_collect_buffers_are_bound_per_env_and_per_buffer():
+    """collect_synthetic caches the bound argument struct by the buffers' addresses ON THE ENV: a dict handed to a second
+    env steps that env (not the first), replaced tensors are picked up, the dict holds tensors only, and a dict of the
+    wrong shape is refused."""
+    n, k = 4096, 12
+    a = make_env("rock", {}, batch_size=n, seed=5, reuse_buffers=True)
+    b = make_env("rock", {}, batch_size=n, seed=6, reuse_buffers=True)
+    ref = make_env("rock", {}, batch_size=n, seed=6, reuse_buffers=True)
+    for e in (a, b, ref):
+        e.reset()
+    tr = a.collect_synthetic(k)
+    assert all(isinstance(v, torch.Tensor) for v in tr.values())
+    state_a = a.state.clone()
+    want = ref.collect_synthetic(k)
+    got = b.collect_synthetic(k, out=tr)               # the same dict, another env
+    assert torch.equal(a.state, state_a) and a.call_counter == 1 + k
+    assert torch.equal(b.state, ref.state) and b.call_counter == 1 + k
+    for name in ("action", "ob", "reward", "done"):
+        assert torch.equal(got[name], want[name]), name
+    # replaced tensors: the next call writes the new ones
+    fresh = b.trajectory_buffers(k)
+    old_ob = tr["ob"].clone()
+    tr["ob"], tr["reward"] = fresh["ob"], fresh["reward"]
+    want2 = ref.collect_synthetic(k)
+    got2 = b.collect_synthetic(k, out=tr)
+    assert torch.equal(got2["ob"], want2["ob"]) and torch.equal(got2["reward"], want2["reward"])
+    assert got2["ob"].data_ptr() == fresh["ob"].data_ptr() and old_ob.shape == got2["ob"].shape
+    with pytest.raises(ValueError):
+        b.collect_synthetic(k + 1, out=tr)

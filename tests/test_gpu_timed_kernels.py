@@ -34,7 +34,13 @@ FULL = [("rock", {}, 1 << 20, 70), ("rock", dict(board_size=15, num_rocks=15), 1
         ("battleship", dict(board_size=(10, 10), max_len=5), 1 << 20, 20),
         # batches that are not a multiple of 4 (the last shard of an odd total): ragged last workgroup, scalar tail of the first actions
         ("rock", {}, 4099, 70), ("tag", {}, (1 << 18) + 5, 20), ("network", {}, 777, 70), ("tiger", {}, 3, 70),
-        ("battleship", {}, 259, 70)]
+        ("battleship", {}, 259, 70),
+        # the non-default configs inside the fused kernels (until round 3 they met the oracle only through HIP-vs-HIP tests):
+        # several opponents in steps_kernel<TagEnv, 2, true> (tag.py:119-130 loops over them), the other table sizes of
+        # steps_quad_kernel (rock.py:43-64: an odd K, a table of 8 actions), and the driver's exact 20-step launch
+        ("tag", dict(num_opponents=2), 1 << 20, 40), ("tag", dict(num_opponents=4), 1 << 20, 40),
+        ("rock", dict(board_size=11, num_rocks=11), 1 << 20, 66), ("rock", dict(board_size=7, num_rocks=7), 1 << 20, 66),
+        ("rock", dict(board_size=4, num_rocks=3), 1 << 20, 66), ("rock", {}, 1 << 20, 20)]
 
 
 @pytest.mark.parametrize("env,kw,n,steps", FULL, ids=["%s%s-%d" % (c[0], "-".join(str(v) for v in c[1].values()), c[2]) for c in FULL])

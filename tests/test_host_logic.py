@@ -191,3 +191,26 @@ def test_ids_register_with_gym_when_importable():
             "assert r['Network-v0'][0] == 'gym_pomdp_amd.envs:NetworkEnv'; print('ok')") % (stubs, REPO)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-1500:]
+
+
+def test_stream_and_device_handles_fall_back_to_the_public_api():
+    """The hot paths take torch's raw stream handle and current device through two private C functions; they are resolved
+    once at import and anything missing falls back to torch.cuda.current_stream(dev).cuda_stream / current_device()."""
+    import torch
+    from gym_pomdp_amd.envs import base
+
+    class Nothing(object):
+        pass
+
+    raw, cur = base._resolve_fast_handles(Nothing())
+    assert raw is base._public_raw_stream and cur is torch.cuda.current_device
+
+    class Half(object):
+        _cuda_getDevice = staticmethod(lambda: 3)
+        _cuda_getCurrentRawStream = "not callable"
+
+    raw, cur = base._resolve_fast_handles(Half())
+    assert raw is base._public_raw_stream and cur() == 3
+    assert callable(base._raw_stream) and callable(base._current_device)
+    src = open(os.path.join(REPO, "gym_pomdp_amd", "envs", "base.py")).read()
+    assert src.count("torch._C") == 1, "private torch internals are touched in _resolve_fast_handles only"

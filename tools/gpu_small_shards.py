@@ -23,7 +23,10 @@ def one(lib_path):
     import gym_pomdp_amd as gpa
     L = _native.lib()
     print("library: %s" % _native.LIB_PATH)
+    only = [x for x in os.environ.get("SHARD_ENVS", "").split(",") if x]
     for name, env_id, kw in ENVS:
+        if only and name not in only:
+            continue
         for lg in (14, 16, 17, 18, 19, 20):
             n = 1 << lg
             e = gpa.make(env_id, batch_size=n, seed=0, reuse_buffers=True, **kw)
