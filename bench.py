@@ -39,6 +39,9 @@ import time
 # by the HIP runtime when it initialises, so it has to be in the environment before torch touches the GPU.  Measured:
 # 7.2 us per chained step with it, 7.5-7.7 without, 9.0 with the arguments in host memory (tools/drv_probe.py)
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+# the cpu_baseline's OpenMP threads stay on their cores (read when the OpenMP runtime loads, i.e. with torch)
+os.environ.setdefault("OMP_PROC_BIND", "close")
+os.environ.setdefault("OMP_PLACES", "cores")
 
 import torch  # noqa: E402
 
@@ -47,6 +50,39 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SIMD_HZ = 256 * 4 * 2.4e9  # VALU issue: 256 CUs x 4 SIMDs x 2.4 GHz cycles per second
+
+
+def _latest(pattern):
+    import glob
+    f = sorted(glob.glob(os.path.join(REPO, "profiles", pattern)))
+    return f[-1] if f else None
+
+
+def valu_roofline(workload, kernel_prefix, lanes, launch_ms):
+    """The VALU-issue roofline of one launch ("report int-op rate" for the compute-bound kernels):
+    achieved = vector instructions the launch issues (SQ_INSTS_VALU per launch, RECORDED by the committed rocprofv3 --pmc
+    pass of the same command, profiles/*_pmc_valu.json) / the launch time measured in this run; peak = SIMD cycles per
+    second / the average issue cycles per instruction of the kernel's hot loop (profiles/*_isa_mix.json: its static
+    instruction mix priced with tools/valu_microbench's measured costs — 2 cycles for v_add / v_and / shifts / v_mov,
+    4 for the rest).  None when no recorded pass matches this workload."""
+    pmc, mix = _latest("*_pmc_valu.json"), _latest("*_isa_mix.json")
+    if not pmc or not mix:
+        return None
+    w = json.load(open(pmc))["workloads"].get(workload)
+    if not w or (w.get("bench_line_under_pmc") or {}).get("config", {}).get("lanes_per_gpu") not in (None, lanes):
+        return None
+    name = next((k for k in w["kernels"] if k.startswith(kernel_prefix)), None)
+    m = json.load(open(mix))["kernels"].get(name) if name else None
+    if not m:
+        return None
+    insts, cpi = w["kernels"][name]["valu_per_launch"], m["avg_cycles_per_instruction"]
+    achieved = insts / (launch_ms * 1e-3)
+    return {"bound": "valu", "achieved": achieved, "peak": SIMD_HZ / cpi, "unit": "wave-instructions/s",
+            "frac": achieved * cpi / SIMD_HZ, "insts_per_launch": insts, "launch_ms": launch_ms,
+            "cycles_per_instruction": cpi, "lane_ops_per_s": achieved * 64, "kernel": name,
+            "source": "instructions per launch recorded (not measured in this run): profiles/%s [%s]; issue cost of the "
+                      "kernel's instruction mix: profiles/%s" % (os.path.basename(pmc), workload, os.path.basename(mix))}
 
 # env -> (make id, ctor kwargs, workload label, algorithmic bytes per env-step [SURVEY.md §8d], dtype)
 WORKLOADS = {
@@ -167,7 +203,8 @@ def self_launch(args):
 def cpu_baseline(env_key, kwargs, seed, budget_s):
     """The C oracle (a port of the reference's step()/reset(), pinned to reference traces) on the host
     cores this process may use, same workload shape (2^20 lanes, synthetic policy, auto-reset), the loop
-    entirely in C (oracle/pomdp_oracle.c: or_bench_loop), bounded sample."""
+    entirely in C (oracle/pomdp_oracle.c: or_bench_loop — every thread owns a chunk of lanes for the whole run, no
+    barrier between steps), bounded sample, every thread count tried is in the line."""
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")     # never spin: the box may expose more CPUs than it grants
     from oracle import oracle_lib as ol
     usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -176,25 +213,50 @@ def cpu_baseline(env_key, kwargs, seed, budget_s):
     t1 = o.bench_loop(1 << 16, 8, seed, 1)
     one_core = (1 << 16) * 8 / t1
     # strictly wall-clock bounded: small chunks of steps until this thread count's share of the budget is spent
-    cands = sorted({c for c in (usable, usable // 2, 32, 16, 8) if 1 <= c <= usable}, reverse=True)
+    cands = sorted({c for c in (usable, usable // 2, 128, 64, 32, 16, 8) if 1 <= c <= usable}, reverse=True)
     share = budget_s / len(cands)
-    best = None
+    best, table = None, []
     for threads in cands:
         steps, el, t0 = 0, 0.0, time.perf_counter()
+        k = 8
         while time.perf_counter() - t0 < share:
-            el += o.bench_loop(n, 4, seed + steps, threads)
-            steps += 4
+            el += o.bench_loop(n, k, seed + steps, threads)
+            steps += k
         rate = n * steps / el
+        table.append({"threads": threads, "value": rate, "steps": steps, "seconds": el})
         if best is None or rate > best[0]:
             best = (rate, threads, steps, el)
     rate, threads, steps, el = best
+    quota = None
+    try:                                                   # a cgroup CPU quota explains a curve that flattens early
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q = f.read().split()
+            quota = None if q[0] == "max" else float(q[0]) / float(q[1])
+    except Exception:  # noqa: BLE001
+        pass
     return {"value": rate, "unit": "env-steps/s", "cores": threads, "kind": "port",
-            "sample": "%d lanes x %d steps of the same workload on the C oracle (OpenMP, %d threads, %.1f s; "
-                      "%d CPUs usable by this process)" % (n, steps, threads, el, usable),
+            "sample": "%d lanes x %d steps of the same workload on the C oracle (OpenMP, %d threads pinned with "
+                      "OMP_PROC_BIND=%s OMP_PLACES=%s, %.1f s; %d CPUs usable by this process; best of the thread counts in "
+                      "by_threads)" % (n, steps, threads, os.environ.get("OMP_PROC_BIND"), os.environ.get("OMP_PLACES"), el, usable),
+            "by_threads": table, "cgroup_cpu_quota": quota,
             "single_core": {"value": one_core, "unit": "env-steps/s", "cores": 1},
             "reference_python_recorded": {"value": 6.0e4, "unit": "env-steps/s", "cores": 1,
                                           "note": "reference's own Python loop, RockSample(7,8), measured in the "
                                                   "build container (BASELINE.md); it cannot travel to this box"}}
+
+
+def rollout_roofline(args, lanes, launch_ms, hbm_achieved, alg_per_sim):
+    """The fused rollout is compute-bound by construction (the state lives in registers for the whole simulation): its
+    roofline is VALU issue; the HBM figure is kept beside it to show how far from memory-bound the launch is."""
+    hbm = {"bound": "hbm", "achieved": hbm_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_achieved / HBM_PEAK_GBS,
+           "traffic": None, "algorithmic_bytes_per_simulation": alg_per_sim}
+    v = valu_roofline("rollout_%s" % args.env, "rollout_kernel<", lanes, launch_ms)
+    if v is None:
+        return dict(hbm, kernel="rollout_kernel<%s>" % args.env, kernel_ms=launch_ms,
+                    note="no recorded VALU counters for this workload (profiles/*_pmc_valu.json): HBM figure only")
+    return dict(v, traffic=None, kernel_ms=launch_ms, hbm=hbm,
+                note="kernel_ms = HIP events over the timed region / launches (the step count's reduction included, "
+                     "~5 % of it); lane-steps per second is `value`")
 
 
 def rollout_mode(args, env, cp, dev, rank, world, label):
@@ -249,13 +311,18 @@ def rollout_mode(args, env, cp, dev, rank, world, label):
                                    "_generate_legal(), one fused rollout launch per step" % (label, roots_n, sims, args.depth),
                        "lanes_per_gpu": roots_n * sims, "mean_steps_per_simulation": steps_done / (args.steps * roots_n * sims * world),
                        "parallelism": "lane-shard x%d, no collectives" % world},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "rollout_kernel<%s>" % args.env,
-                         "kernel_ms": launch_ms, "algorithmic_bytes_per_simulation": alg_per_sim,
-                         "note": "compute-bound by construction: the state lives in registers for the whole simulation; "
-                                 "kernel_ms = HIP events over the timed region / launches (the step count's reduction "
-                                 "included); lane-steps per second is `value`"}}), flush=True)
+            "roofline": rollout_roofline(args, roots_n * sims, launch_ms, achieved, alg_per_sim)}), flush=True)
     cp.close()
+
+
+def heuristic_roofline(args, n, kern_ms, hbm_achieved, alg):
+    hbm = {"bound": "hbm", "achieved": hbm_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_achieved / HBM_PEAK_GBS,
+           "traffic": None, "algorithmic_bytes_per_step": alg}
+    v = valu_roofline("heuristic_%s" % args.env, "heuristic_steps_kernel<", n, kern_ms * 64)
+    if v is None:
+        return dict(hbm, kernel="heuristic_steps_kernel (up to 64 steps per launch)", kernel_ms=kern_ms)
+    return dict(v, traffic=None, kernel_ms=kern_ms, steps_per_launch=64, hbm=hbm,
+                note="the tighter of the two bounds is reported first; launch_ms = kernel_ms x 64 steps per launch")
 
 
 def heuristic_mode(args, gpa, env_id, kwargs, cp, dev, rank, world, label, n, lane_offset):
@@ -302,10 +369,21 @@ def heuristic_mode(args, gpa, env_id, kwargs, cp, dev, rank, world, label, n, la
                                    "(use_heuristic=True), auto-reset, up to 64 steps per fused launch" % (label, n),
                        "lanes_per_gpu": n, "mean_history_size": float(hist._size.float().mean().item()),
                        "parallelism": "lane-shard x%d, no collectives" % world},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "heuristic_steps_kernel (up to 64 steps per launch)",
-                         "kernel_ms": kern_ms, "algorithmic_bytes_per_step": alg}}), flush=True)
+            "roofline": heuristic_roofline(args, n, kern_ms, achieved, alg)}), flush=True)
     cp.close()
+
+
+def recorded_traffic_20(env_key, kernel_prefix):
+    """HBM bytes of the driver's 20-step launch, from the FETCH_SIZE / WRITE_SIZE passes of tools/gpu_pmc_valu.sh."""
+    pmc = _latest("*_pmc_valu.json")
+    if not pmc:
+        return None, None
+    w = json.load(open(pmc))["workloads"].get("step20_%s" % env_key, {})
+    for k, v in (w.get("traffic") or {}).items():
+        if k.startswith(kernel_prefix):
+            return v["hbm_bytes_per_launch"], "recorded, not measured in this run: profiles/%s [step20_%s: %s]" % (
+                os.path.basename(pmc), env_key, k)
+    return None, None
 
 
 def measured_traffic(env_key, chained=False, fused=False):
@@ -493,6 +571,11 @@ def main():
 
     # the recorded PMC figure belongs to a launch of the recorded shape only: 2^20 lanes, 64 steps per fused launch
     traffic, traffic_src = measured_traffic(args.env, chained, fused) if (n == 1 << 20 and spl in (1, 64)) else (None, None)
+    kprefix = (fused_kernel or "").split("<")[0] + "<" if fused else "step_kernel<"
+    if fused and n == 1 << 20 and spl == 20:               # the driver's invocation: one 20-step launch per region
+        traffic, traffic_src = recorded_traffic_20(args.env, kprefix)
+    valu = valu_roofline("step%d_%s" % (spl, args.env), kprefix, n, kern_ms * spl) if fused else None
+    rank_kernel_ms = cp.gather(timed_kernel_ms)            # a slow GPU shows in the one line the driver keeps
     if rank == 0:
         total_lanes = n * world
         metric = "env steps/sec (whole node)"
@@ -542,7 +625,10 @@ def main():
                        "host_cpus": os.cpu_count(),
                        "host_cpus_usable": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per 64-step launch" if fused else "bytes per launch",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per %d-step launch" % spl if fused else "bytes per launch",
+                         "valu": valu,
+                         "tighter_bound": None if valu is None else ("valu" if valu["frac"] > achieved / HBM_PEAK_GBS else "hbm"),
+                         "kernel_ms_by_rank": rank_kernel_ms,
                          "traffic_source": traffic_src,
                          "kernel": kernel_name,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_step": alg_bytes,

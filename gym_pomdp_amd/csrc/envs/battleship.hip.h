@@ -9,7 +9,8 @@ template <int MW> // mask words: ceil((cells + 6) / 32)
 struct BattleShipEnv {
     using Params = pomdp_battleship_params;
     using Reward = int32_t;
-    static constexpr int WORDS = 2 * MW;
+    static constexpr int WORDS = 3 * MW;       // occupied, visited (+ remaining), the NEXT episode's occupied mask
+    static constexpr bool HAS_NEXT = true;     // pomdp_kernels.hip: the kernels fetch `next` where a lane may need it (load_next)
     static constexpr const char *NAME = MW == 1 ? "BattleShipEnv<1>" : MW == 2 ? "BattleShipEnv<2>" : MW == 3 ? "BattleShipEnv<3>" : "BattleShipEnv<4>";
     static constexpr bool POOLED_LPT2 = false;
     static constexpr bool QUAD_STEP = false;   // pomdp_kernels.hip: step_quad_kernel
@@ -28,7 +29,12 @@ struct BattleShipEnv {
             if (j < 2) lo = (lo & ~m) | v; else hi = (hi & ~m) | v;
         }
     };
-    struct State { Mask occ, vis; };
+    // Board contract: a lane always holds the board of its NEXT episode as well.  Whenever a board is
+    // dealt at call counter t — by reset() (from stream RESET of (lane, t)) or by the auto-reset of a step at t (the cached
+    // board moves in) — the following board is drawn from stream NEXT of (lane, t).  An episode's end therefore costs a
+    // few selects inside a fused loop, and the rejection loops of all the boards a wave used up during a launch run
+    // afterwards, 64 of them side by side (battleship_steps_quad_kernel).  `next` is only loaded where it can be needed.
+    struct State { Mask occ, vis, next; };
 
     static __device__ __forceinline__ void stage(Shared &, const Params &, int) {}
     static __device__ __forceinline__ int n_actions(const Params &p) { return p.x_size * p.y_size; }
@@ -40,16 +46,34 @@ struct BattleShipEnv {
         for (int j = 0; j < MW; ++j) { o[j] = ld_stream(state + (int64_t)j * n + i); v[j] = ld_stream(state + (int64_t)(MW + j) * n + i); }
         st.occ.lo = o[0] | ((uint64_t)o[1] << 32); st.occ.hi = o[2] | ((uint64_t)o[3] << 32);
         st.vis.lo = v[0] | ((uint64_t)v[1] << 32); st.vis.hi = v[2] | ((uint64_t)v[3] << 32);
+        st.next.lo = st.next.hi = 0;
     }
-    // a step only changes the visited half; the occupied half is rewritten on reset
+    static __device__ __forceinline__ void load_next(State &st, const uint32_t *state, int64_t n, uint32_t i)
+    {
+        uint32_t o[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < MW; ++j) o[j] = ld_stream(state + (int64_t)(2 * MW + j) * n + i);
+        st.next.lo = o[0] | ((uint64_t)o[1] << 32); st.next.hi = o[2] | ((uint64_t)o[3] << 32);
+    }
+    // a step only changes the visited half; the occupied half and the next board are rewritten on reset
     static __device__ __forceinline__ void store(const State &st, uint32_t *state, int64_t n, uint32_t i, bool was_reset)
     {
 #pragma unroll
         for (int j = 0; j < MW; ++j) st_stream(state + (int64_t)(MW + j) * n + i, (uint32_t)st.vis.word(j));
         if (was_reset) {
 #pragma unroll
-            for (int j = 0; j < MW; ++j) st_stream(state + (int64_t)j * n + i, (uint32_t)st.occ.word(j));
+            for (int j = 0; j < MW; ++j) {
+                st_stream(state + (int64_t)j * n + i, (uint32_t)st.occ.word(j));
+                st_stream(state + (int64_t)(2 * MW + j) * n + i, (uint32_t)st.next.word(j));
+            }
         }
+    }
+    // the cached board moves in: a fresh episode (battleship.py:131-137: nothing visited, every ship cell remaining)
+    static __device__ __forceinline__ void swap_in(State &st)
+    {
+        st.occ = st.next;
+        st.vis.lo = 0; st.vis.hi = 0;
+        st.vis.set_word(MW - 1, (uint32_t)(__popcll(st.occ.lo) + __popcll(st.occ.hi)) << 26);
     }
     static __device__ __forceinline__ bool bit(const Mask &m, int a) { return ((a < 64 ? m.lo : m.hi) >> (a & 63)) & 1ull; }
     static __device__ __forceinline__ void set_bit(Mask &m, int a)
@@ -64,7 +88,7 @@ struct BattleShipEnv {
     }
 
     // battleship.py:131-137 reset, 167-180 _get_init_state, 195-211 collision, 182-193 mark_ship,
-    // coord.py:122-123 Grid.sample, battleship.py:33-37 Ship.__init__ (position word(s) before direction word).
+    // coord.py:68-69 Grid.sample, battleship.py:33-37 Ship.__init__ (position word(s) before direction word).
     //
     // The reference's collision() walks L+1 cells from pos and, for each, looks at the cell itself and
     // its N, E, S, W, NE, SE, SW neighbours (Compass[0..7]; NW is never looked at).  Here that is one
@@ -72,16 +96,15 @@ struct BattleShipEnv {
     // (7 shifted copies of the occupancy mask, column-wrap guarded), against the L+1 ship cells; the
     // "pos + dir stays inside for i = 0..L" test reduces to the far end pos + (L+1) dir being inside.
     typedef unsigned __int128 u128;
-    static __device__ __forceinline__ int reset(const Shared &, const Params &p, State &st, const RngKey &key,
-                                                uint32_t lane)
+    // one board from the word stream `stream` of (lane, key's call counter), exactly as the reference's loop consumes it
+    static __device__ __forceinline__ u128 board(const Params &p, const RngKey &key, uint32_t lane, uint32_t stream)
     {
-        WordStream ws(key, lane, POMDP_STREAM_RESET);
+        WordStream ws(key, lane, stream);
         const int X = p.x_size, Y = p.y_size;
         u128 col0 = 0;                                     // cells with x == 0
         for (int y = 0; y < Y; ++y) col0 |= (u128)1 << (y * X);
         const u128 colL = col0 << (X - 1);                 // cells with x == X - 1
         u128 occ = 0;
-        int remaining = 0;
         for (int len = p.max_len; len >= 2; --len) {
             const u128 e = occ & ~col0, w = occ & ~colL;   // sources that may shift one column west / east
             const u128 blocked = occ | (occ >> X) | (occ << X) | (e >> 1) | (w << 1) | (e >> (X + 1)) | (e << (X - 1)) |
@@ -103,19 +126,28 @@ struct BattleShipEnv {
             }
             const int stride = dy * X + dx;
             for (int i = 0; i < len; ++i) occ |= (u128)1 << (a0 + i * stride);     // mark_ship: L cells from pos
-            remaining += len;
         }
-        st.occ.lo = (uint64_t)occ; st.occ.hi = (uint64_t)(occ >> 64);
-        st.vis.lo = 0; st.vis.hi = 0;
-        st.vis.set_word(MW - 1, (uint32_t)remaining << 26);
+        return occ;
+    }
+    // reset() at call counter t: this episode's board from stream RESET, the next episode's from stream NEXT
+    static __device__ __forceinline__ int reset(const Shared &, const Params &p, State &st, const RngKey &key,
+                                                uint32_t lane)
+    {
+        const u128 nx = board(p, key, lane, POMDP_STREAM_RESET);
+        st.next.lo = (uint64_t)nx; st.next.hi = (uint64_t)(nx >> 64);
+        swap_in(st);
+        const u128 n2 = board(p, key, lane, POMDP_STREAM_NEXT);
+        st.next.lo = (uint64_t)n2; st.next.hi = (uint64_t)(n2 >> 64);
         return 0;
     }
 
-    // Wave-cooperative reset.  A BattleShip reset is a long sequential rejection loop (about 20 attempts on
+    // Wave-cooperative auto-reset (the single-step kernels and the one-lane-per-thread loops): a lane whose episode ended
+    // takes its cached board (swap_in) and the wave builds the board after it, from stream NEXT of (lane, t).
+    // A BattleShip board is a long sequential rejection loop (about 20 attempts on
     // 10x10, 42 on 5x5) and roughly one wave in five holds a lane that needs one; run per lane it stalls 63
     // other lanes behind ~2000 divergent instructions.  Here the whole wave serves one resetting lane at a
     // time and evaluates up to 64 candidate placements at once:
-    //   1. one Philox pass gives a 64-word window of that lane's RESET stream (lane l holds word c + l);
+    //   1. one Philox pass gives a 64-word window of that lane's NEXT stream (lane l holds word c + l);
     //   2. the reference consumes the stream as [position words until one is < n_tiles][direction word],
     //      repeated.  With A = ballot(word is an acceptable position), word l is a *direction* word iff
     //      word l-1 is an accepted position word, i.e. D[l] = A[l-1] & ~D[l-1]: inside every run of ones of
@@ -125,7 +157,7 @@ struct BattleShipEnv {
     //   3. every candidate lane tests its placement with 128-bit mask arithmetic against `blocked`; the
     //      lowest successful lane is the ship the reference would have placed, and the cursor moves just
     //      past its direction word.  No success: the cursor moves past the last fully parsed word.
-    // Same words in the same order as reset() above, hence the same boards.
+    // Same words in the same order as board() above, hence the same boards.
     static __device__ __forceinline__ u128 u128_of4(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3)
     {
         return (u128)(w0 | ((uint64_t)w1 << 32)) | ((u128)(w2 | ((uint64_t)w3 << 32)) << 64);
@@ -154,6 +186,76 @@ struct BattleShipEnv {
             return (M)((u128)((lo >> s) | (hi << (64 - s))) | ((u128)(hi >> s) << 64));
         }
     }
+    // ---- the same boards, many lanes at once (pomdp_kernels.hip: battleship_steps_quad_kernel) -----------------------------
+    // board() reshaped for lanes that run it in lockstep: ONE loop in which every lane consumes exactly one word of its
+    // stream per iteration — so the Philox blocks are generated under a wave-uniform condition, four iterations per block —
+    // and a two-state machine per lane says what the word is: a position word (accepted when <= n_tiles - 1,
+    // np.random.randint's masked rejection) or the direction word that follows an accepted position (battleship.py:33-37,
+    // 171-176).  The placement test and mark_ship are the mask arithmetic of reset_where(); the column patterns come from
+    // `vp` (LDS copy of p.vpat: one 16-byte read per lane whatever its ship length).  Lanes with go == false idle through.
+    // Every lane brings its own key (the call counter at which its previous board was dealt).
+    struct SeqTables { uint32_t vp[12][4]; };
+    static __device__ __forceinline__ void stage_seq(SeqTables &t, const Params &p, int tid)
+    {
+        if (tid < 48) t.vp[tid >> 2][tid & 3] = p.vpat[(tid >> 2) % 12][tid & 3];
+    }
+    static __device__ __forceinline__ M blocked_of(M occ, M col0, M colL, int X)
+    {
+        // occ and its N, E, S, W, NE, SE, SW shifts (NW excluded): h = {self, E, W}; south side = h << X; north = {self, E} >> X
+        const M e1 = (M)((occ & ~col0) >> 1), h = (M)(occ | e1 | (M)((occ & ~colL) << 1));
+        return (M)(h | shr_small((M)(occ | e1), X) | shl_small(h, X));
+    }
+    // the two-state word consumer of one board under construction
+    struct Builder {
+        M occ, blocked;
+        int len, a0;                                                           // len < 2: nothing (left) to place
+        bool want_dir;
+        __device__ __forceinline__ void start(int max_len) { occ = 0; blocked = 0; len = max_len; a0 = 0; want_dir = false; }
+        __device__ __forceinline__ void idle() { occ = 0; blocked = 0; len = 1; a0 = 0; want_dir = false; }
+        __device__ __forceinline__ bool busy() const { return len >= 2; }
+    };
+    struct BuildConsts { int X, Y, cells; uint32_t rmask, inv_x; M col0, colL; };
+    static __device__ __forceinline__ BuildConsts build_consts(const Params &p)
+    {
+        BuildConsts c;
+        c.X = p.x_size; c.Y = p.y_size; c.cells = c.X * c.Y;
+        __builtin_assume(c.X >= 1 && c.X <= 16 && c.Y >= 1 && c.Y <= 16);
+        c.rmask = 0xFFFFFFFFu >> __clz((uint32_t)(c.cells - 1) | 1u);
+        c.inv_x = (65536u + (uint32_t)c.X - 1u) / (uint32_t)c.X;               // a / X == (a * inv_x) >> 16 for a < 128, X <= 16
+        c.col0 = mask_of(p.col0); c.colL = (M)(c.col0 << (c.X - 1));
+        return c;
+    }
+    // one word of the board's stream: as a direction word it completes the placement from a0, as a position word it is
+    // accepted when it is a tile (the lane's state says which of the two it is)
+    static __device__ __forceinline__ void feed(Builder &b, const SeqTables &t, const BuildConsts &c, uint32_t w)
+    {
+        const int X = c.X, len = b.len, a0 = b.a0;
+        const bool live = len >= 2;
+        const uint32_t dir = w & 3u;                                           // Compass N E S W
+        const int dx = (dir == 1u) - (dir == 3u), dy = (dir == 0u) - (dir == 2u);
+        const int py = (int)(((uint32_t)a0 * c.inv_x) >> 16), px = a0 - py * X;
+        const int ex = px + (len + 1) * dx, ey = py + (len + 1) * dy, stride = dy * X + dx;
+        const bool inside = (unsigned)ex < (unsigned)X && (unsigned)ey < (unsigned)c.Y;
+        const int lo = stride > 0 ? a0 : a0 + len * stride;
+        const uint32_t *v1 = t.vp[(len + 1) % 12], *v0 = t.vp[len % 12];
+        const uint32_t w1[4] = {v1[0], v1[1], v1[2], v1[3]}, w0[4] = {v0[0], v0[1], v0[2], v0[3]};
+        const M vpat1 = mask_of(w1), vpat0 = mask_of(w0);
+        const M test = (M)((dx != 0 ? (M)((1ull << (len + 1)) - 1ull) : vpat1) << (lo & (MBITS - 1)));
+        const bool place = live && b.want_dir && inside && (test & b.blocked) == 0;
+        if (__any(place)) {                                                    // wave-uniform: skip the marking when nobody places
+            if (place) {
+                const int low = stride > 0 ? a0 : a0 + (len - 1) * stride;
+                b.occ |= (M)((dx != 0 ? (M)((1ull << len) - 1ull) : vpat0) << (low & (MBITS - 1)));
+                b.len = len - 1;
+                b.blocked = blocked_of(b.occ, c.col0, c.colL, X);
+            }
+        }
+        const uint32_t v = w & c.rmask;
+        const bool accept = live && !b.want_dir && v <= (uint32_t)(c.cells - 1);
+        b.a0 = accept ? (int)v : a0;
+        b.want_dir = accept;                                                   // a direction word is always consumed: back to positions
+    }
+
     static __device__ __forceinline__ uint64_t direction_words(uint64_t a)
     {
         const uint64_t even = 0x5555555555555555ull;
@@ -167,6 +269,7 @@ struct BattleShipEnv {
     {
         uint64_t todo = __ballot(fresh);
         if (todo == 0ull) return;                                            // wave-uniform
+        if (fresh) swap_in(st);                                              // the cached board; below: the one after it, stream NEXT
         const int me = (int)(threadIdx.x & 63u);
         const int X = p.x_size, Y = p.y_size, cells = X * Y;
         __builtin_assume(X >= 1 && X <= 16 && Y >= 1 && Y <= 16);          // bs_mask_words(): what the launchers let through —
@@ -185,7 +288,6 @@ struct BattleShipEnv {
             int c0 = -64;
             uint32_t wword = 0;
             M occ = 0;
-            int remaining = 0;
             for (int len = p.max_len; len >= 2; --len) {
                 __builtin_assume(len <= 10);
                 // blocked = occ and its N, E, S, W, NE, SE, SW shifts (NW excluded) in four 128-bit shifts:
@@ -198,7 +300,7 @@ struct BattleShipEnv {
                 for (;;) {
                     if (c - c0 > 32) {                                        // wave-uniform: refill the window at the cursor
                         const uint32_t wi = (uint32_t)(c + me);
-                        const uint4 blk = stream_block(key, glane, POMDP_STREAM_RESET, (wi >> 2) & 0xFFFFFFu);
+                        const uint4 blk = stream_block(key, glane, POMDP_STREAM_NEXT, (wi >> 2) & 0xFFFFFFu);
                         const uint32_t sel = wi & 3u;
                         wword = sel == 0 ? blk.x : sel == 1 ? blk.y : sel == 2 ? blk.z : blk.w;
                         c0 = c;
@@ -226,7 +328,6 @@ struct BattleShipEnv {
                         // mark_ship: L cells from pos = the L-cell pattern shifted to its lowest cell
                         const int low = sw > 0 ? a0w : a0w + (len - 1) * sw;
                         occ |= (M)(((sw == 1 || sw == -1) ? (M)((1ull << len) - 1ull) : vship) << (low & (MBITS - 1)));
-                        remaining += len;
                         c += r + 2;
                         break;
                     }
@@ -235,11 +336,7 @@ struct BattleShipEnv {
                     c += (((A & ~D) >> (nv - 1)) & 1ull) ? nv - 1 : nv;
                 }
             }
-            if (me == src) {
-                st.occ.lo = (uint64_t)occ; st.occ.hi = MW > 2 ? (uint64_t)((u128)occ >> 64) : 0ull;
-                st.vis.lo = 0; st.vis.hi = 0;
-                st.vis.set_word(MW - 1, (uint32_t)remaining << 26);
-            }
+            if (me == src) { st.next.lo = (uint64_t)occ; st.next.hi = MW > 2 ? (uint64_t)((u128)occ >> 64) : 0ull; }
         }
     }
     static __device__ __forceinline__ void reset_where_chain(const Shared &sh, const Params &p, State &st, bool fresh,

@@ -376,7 +376,7 @@ struct RockEnv {
         const S s = st.s;
         const uint32_t x = (uint32_t)s & 15u, y = ((uint32_t)s >> 4) & 15u;
         const uint32_t size = (uint32_t)p.size, K = (uint32_t)p.num_rocks;
-        // CHECK rock a-5 (rock.py:171-175, 401-407, 383-387; coord.py:133-135: L1 distance = sum of absolute byte differences)
+        // CHECK rock a-5 (rock.py:171-175, 401-407, 383-387; coord.py:79-81: L1 distance = sum of absolute byte differences)
         const int r = (a - 5) & 15;
         const uint32_t rp = sh.rpos[r];
         const uint32_t d = __builtin_amdgcn_sad_u8(x | (y << 8), rp, 0u);
@@ -390,7 +390,7 @@ struct RockEnv {
         const int sh_ = 8 + 2 * (id & 15);
         const uint32_t code = (uint32_t)(s >> sh_) & 3u;
         const bool sample_ok = ((uint32_t)id < K) & (code != 1u);
-        // move: 0 N (0,+1)  1 E (+1,0)  2 S (0,-1)  3 W (-1,0)   (coord.py:155-160, rock.py:134-158): the steps are
+        // move: 0 N (0,+1)  1 E (+1,0)  2 S (0,-1)  3 W (-1,0)   (coord.py:101-110, rock.py:134-158): the steps are
         // 2-bit signed fields of two constants, zero for every other action (a < 16; is_move masks the rest)
         const uint32_t a2 = (uint32_t)a << 1;
         const uint32_t nx = x + (uint32_t)__builtin_amdgcn_sbfe(0xC4, a2, 2u), ny = y + (uint32_t)__builtin_amdgcn_sbfe(0x31, a2, 2u);

@@ -48,6 +48,10 @@ constexpr int64_t STEP_QUAD_MIN_LANES = POMDP_STEP_QUAD_MIN_LANES;
 constexpr int64_t STEP_QUAD_MIN_LANES = 1 << 19;
 #endif
 
+// envs whose lanes carry the board of their next episode (BattleShip): `next` is loaded only where a lane may need it
+template <class Env, class = void> struct has_next : std::false_type {};
+template <class Env> struct has_next<Env, std::enable_if_t<Env::HAS_NEXT>> : std::true_type {};
+
 // ---------------------------------------------------------------------------
 // reset: every lane starts a fresh episode from stream RESET of (seed, lane, t)
 // ---------------------------------------------------------------------------
@@ -380,7 +384,10 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(uint32_t *__restrict__ stat
     uint32_t glane[LPT];
     int a_next[LPT];
 #pragma unroll
-    for (int j = 0; j < LPT; ++j) { fresh[j] = live[j] && d[j] && auto_reset; glane[j] = lane0 + idx[j]; a_next[j] = 0; }
+    for (int j = 0; j < LPT; ++j) {
+        fresh[j] = live[j] && d[j] && auto_reset; glane[j] = lane0 + idx[j]; a_next[j] = 0;
+        if constexpr (has_next<Env>::value) { if (fresh[j]) Env::load_next(st[j], state_w, n, rel[j]); }   // the cached board moves in
+    }
     Fin::run(sh, p, st, fresh, key, glane, akey, (uint32_t)n_act, a_next, aux, o);
 #ifdef POMDP_DEV_TIMELINE
     { int x = 0; for (int j = 0; j < LPT; ++j) x += o[j]; asm volatile("" :: "v"(x)); }
@@ -485,6 +492,7 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
         __builtin_assume(rc < (uint32_t)(BLOCK * LPT));
         a_cur[j] = (flags & FLAG_GEN_FIRST) ? 0 : ld_stream(action_w + rc);
         Env::load(st[j], state_w, n, rc);
+        if constexpr (has_next<Env>::value) Env::load_next(st[j], state_w, n, rc);   // once per launch, with the other words
         was_done[j] = auto_reset ? false : (ld_stream(done_w + rc) != 0);
     }
     using Fin = Finisher<Env, LPT, true>;
@@ -921,6 +929,7 @@ __global__ __launch_bounds__(BLOCK) void heuristic_steps_kernel(const typename E
     // every per-lane word first (one memory latency), then the tables
     typename Env::State st;
     Env::load(st, state, n, i);
+    if constexpr (has_next<Env>::value) Env::load_next(st, state, n, i);
     int hsize = ld_stream(h.size + i), pob = ld_stream(prev_ob + i), head = RING ? ld_stream(h.head + i) : 0;
     int la = ld_stream(h.last_action + i), lo = ld_stream(h.last_ob + i);
     uint32_t ck = K ? ld_stream(b.check_ok + i) : 0u, mv = K ? ld_stream(h.move_ok + i) : 0u;
@@ -1737,6 +1746,151 @@ __global__ __launch_bounds__(BLOCK) void network_steps_quad_kernel(uint32_t *__r
     st_stream4(state + l0, st[0], st[1], st[2], st[3]);
 }
 
+// BattleShip with a quad per thread.  A board is a long sequential rejection loop (battleship.py:167-180: about 23 words of a
+// lane's stream on 10x10, 42 on 5x5) that one lane in ~285 needs per step; built when it comes up — by the whole wave, one
+// lane at a time (BattleShipEnv::reset_where) — it is two thirds of all instructions steps_kernel<BattleShipEnv> issues.
+// Under the board contract (include/pomdp_hip.h) a lane carries the board of its NEXT episode, drawn from
+// stream NEXT at the call counter at which its current board was dealt; so inside the loop the end of an episode is a
+// handful of selects (the cached board moves in, the lane remembers the step), and the boards the wave's lanes used up
+// are built AFTER the loop, dealt out one per thread and 64 side by side (board_lockstep).  A lane that finishes a second
+// episode before its next board exists triggers that pass early, for every lane of the wave that is waiting.  The state
+// that reaches memory is the same whichever kernel ran: current board, visited mask, next board.
+template <int MW>
+__global__ __launch_bounds__(BLOCK) void battleship_steps_quad_kernel(uint32_t *__restrict__ state, int32_t *__restrict__ action,
+                                                                      int32_t *__restrict__ ob, int32_t *__restrict__ reward,
+                                                                      uint8_t *__restrict__ done, int64_t n, RngKey key0,
+                                                                      uint32_t lane0, RngKey akey0, int k_steps, int64_t rec,
+                                                                      int gen_first, const pomdp_battleship_params p)
+{
+    using Env = BattleShipEnv<MW>;
+    __shared__ typename Env::Shared sh;
+    __shared__ uint8_t task_lds[BLOCK / 64][256];            // task rank -> lane within the wave's 256
+    __shared__ uint8_t ts_lds[BLOCK / 64][256];              // ... and the step at which that lane's current board was dealt
+    __shared__ uint32_t res_lds[BLOCK / 64][256][MW];        // task rank -> the board built for it
+    __shared__ typename Env::SeqTables seq;                  // the column patterns of the board builder
+    Env::stage_seq(seq, p, (int)threadIdx.x);
+    const int wv = (int)(threadIdx.x >> 6), me = (int)(threadIdx.x & 63u);
+    const uint32_t l0 = blockIdx.x * (uint32_t)(4 * BLOCK) + 4u * threadIdx.x;
+    const uint32_t glane0 = lane0 + l0, wave0 = glane0 - 4u * (uint32_t)me;
+    uint32_t *action_w = reinterpret_cast<uint32_t *>(action) + l0, *ob_w = reinterpret_cast<uint32_t *>(ob) + l0;
+    uint32_t *reward_w = reinterpret_cast<uint32_t *>(reward) + l0;
+    uint32_t *done_w = reinterpret_cast<uint32_t *>(done + l0);
+    const uint32_t n_act = (uint32_t)Env::n_actions(p);
+    typename Env::State st[4];
+    int a_cur[4];
+    {
+        uint32_t w[3 * MW][4];
+#pragma unroll
+        for (int q = 0; q < 3 * MW; ++q) {
+            const u32x4 v = ld_stream4(state + (int64_t)q * n + l0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[q][j] = v[j];
+        }
+        const u32x4 a4 = first_actions4(action_w, gen_first, glane0, akey0, n_act);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a_cur[j] = (int)a4[j];
+            st[j].occ.lo = st[j].occ.hi = st[j].vis.lo = st[j].vis.hi = st[j].next.lo = st[j].next.hi = 0;
+#pragma unroll
+            for (int q = 0; q < MW; ++q) { st[j].occ.set_word(q, w[q][j]); st[j].vis.set_word(q, w[MW + q][j]); st[j].next.set_word(q, w[2 * MW + q][j]); }
+        }
+    }
+    action_w += rec;
+    __syncthreads();
+    const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo, ta0 = ((uint64_t)akey0.t_hi << 32) | akey0.t_lo;
+    int pend[4] = {-1, -1, -1, -1};                          // >= 0: the step at which the lane's board was dealt; its `next` is yet to be built
+    // the boards of every waiting lane of the wave, 64 per pass (wave-uniform control flow; the scratch is wave-private)
+    auto build_boards = [&]() {
+        int rank[4], ntask = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint64_t m = __ballot(pend[j] >= 0);
+            rank[j] = ntask + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            ntask += __popcll(m);
+            if (pend[j] >= 0) { task_lds[wv][rank[j] & 255] = (uint8_t)(4 * me + j); ts_lds[wv][rank[j] & 255] = (uint8_t)pend[j]; }
+        }
+        if (ntask == 0) return;                                                // wave-uniform
+        // A pool of 64 builders works the task list off: every lane feeds its board one word of its stream per iteration
+        // (four iterations per Philox block, the blocks computed by all lanes at once, each with its own counter), and a
+        // lane whose board is complete takes the next unclaimed task at the following block boundary instead of idling
+        // until the slowest board of its batch is done (a 5x5 board takes 42 words on average and over a hundred at worst).
+        const typename Env::BuildConsts bc = Env::build_consts(p);
+        typename Env::Builder bld;
+        int my = me < ntask ? me : -1, next_task = ntask < 64 ? ntask : 64;    // this lane's task; the first unclaimed one
+        uint32_t blane = 0, bt_lo = 0, bt_hi = 0, blk = 0;
+        auto take = [&](int q) {                                               // lanes with q >= 0 start on task q
+            const int idx = q >= 0 ? (int)task_lds[wv][q & 255] : 0, s0 = q >= 0 ? (int)ts_lds[wv][q & 255] : 0;
+            const uint64_t td = t0 + (uint64_t)s0;                             // battleship.py:131-137 on stream NEXT of that step's call counter
+            if (q >= 0) { blane = wave0 + (uint32_t)idx; bt_lo = (uint32_t)td; bt_hi = (uint32_t)(td >> 32); blk = 0; bld.start(p.max_len); }
+        };
+        bld.idle();
+        take(my);
+        while (__any(my >= 0)) {
+            const uint4 b4 = philox4x32_10(blane, bt_lo, bt_hi, ((uint32_t)POMDP_STREAM_NEXT << 24) | (blk & 0xFFFFFFu), key0.k0, key0.k1);
+            ++blk;
+            Env::feed(bld, seq, bc, b4.x);
+            Env::feed(bld, seq, bc, b4.y);
+            Env::feed(bld, seq, bc, b4.z);
+            Env::feed(bld, seq, bc, b4.w);
+            const bool fin = my >= 0 && !bld.busy();
+            const uint64_t fm = __ballot(fin);
+            if (fm != 0ull) {                                                  // wave-uniform
+                if (fin) {
+#pragma unroll
+                    for (int w = 0; w < MW; ++w) res_lds[wv][my & 255][w] = (uint32_t)(bld.occ >> (32 * w));
+                }
+                const int r = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
+                if (fin) { my = next_task + r < ntask ? next_task + r : -1; bld.idle(); take(my); }
+                next_task += __popcll(fm);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                                          // four reads in flight, one wait
+            const uint32_t *res = res_lds[wv][rank[j] & 255];
+            if (pend[j] >= 0) {
+                st[j].next.lo = st[j].next.hi = 0;
+#pragma unroll
+                for (int w = 0; w < MW; ++w) st[j].next.set_word(w, res[w]);
+                pend[j] = -1;
+            }
+        }
+    };
+    for (int s = 0; s < k_steps; ++s) {
+        const uint64_t ta = ta0 + (uint64_t)s;
+        const uint4 pw = philox4x32_10(glane0 >> 2, (uint32_t)ta, (uint32_t)(ta >> 32), (uint32_t)POMDP_STREAM_ACTION << 24, akey0.k0, akey0.k1);
+        const uint32_t P[4] = {pw.x, pw.y, pw.z, pw.w};
+        uint32_t o4[4], r4[4], a_next[4], dpack = 0;
+        int d[4];
+        bool again = false;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int o, r;
+            Env::step(sh, p, st[j], a_cur[j], key0, 0u, o, r, d[j]);              // battleship.py:91-122: draws nothing
+            again |= d[j] && pend[j] >= 0;
+            o4[j] = (uint32_t)o; r4[j] = (uint32_t)r;
+            dpack |= (uint32_t)(d[j] != 0) << (8 * j);
+            a_next[j] = __umulhi(P[j], n_act);
+            a_cur[j] = (int)a_next[j];
+        }
+        st_stream4(action_w, a_next[0], a_next[1], a_next[2], a_next[3]);
+        st_stream4(ob_w, o4[0], o4[1], o4[2], o4[3]);
+        st_stream4(reward_w, r4[0], r4[1], r4[2], r4[3]);
+        st_stream(done_w, dpack);
+        action_w += rec; ob_w += rec; reward_w += rec; done_w += rec / 4;
+        if (__any(again)) build_boards();                                      // a second episode ended before the lane's next board exists
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (d[j]) { Env::swap_in(st[j]); pend[j] = s; }
+    }
+    build_boards();
+#pragma unroll
+    for (int q = 0; q < MW; ++q) {
+        st_stream4(state + (int64_t)q * n + l0, st[0].occ.word(q), st[1].occ.word(q), st[2].occ.word(q), st[3].occ.word(q));
+        st_stream4(state + (int64_t)(MW + q) * n + l0, st[0].vis.word(q), st[1].vis.word(q), st[2].vis.word(q), st[3].vis.word(q));
+        st_stream4(state + (int64_t)(2 * MW + q) * n + l0, st[0].next.word(q), st[1].next.word(q), st[2].next.word(q), st[3].next.word(q));
+    }
+}
+
 // The generic fused loop with a quad per thread, for envs whose lane step is light enough that four of them fit a thread
 // (Env::QUAD_FUSED; one state word): the policy's ACTION block is the thread's own, Env::step / Env::reset_where run per
 // lane as in steps_kernel, the outputs leave as 16-byte stores.  Full workgroups of 1024 lanes, auto-reset.  Only for envs
@@ -1814,9 +1968,10 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_generic_kernel(uint32_t *__r
 // POMDP_QUAD_MIN_LANES overrides all of them at build time for same-box A/B runs (tools/ab_build.sh lib ... -D...).
 #ifdef POMDP_QUAD_MIN_LANES
 constexpr int64_t QUAD_MIN_ROCK = POMDP_QUAD_MIN_LANES, QUAD_MIN_TAG = POMDP_QUAD_MIN_LANES, QUAD_MIN_GENERIC = POMDP_QUAD_MIN_LANES,
-                  QUAD_MIN_NETWORK = POMDP_QUAD_MIN_LANES;
+                  QUAD_MIN_NETWORK = POMDP_QUAD_MIN_LANES, QUAD_MIN_BATTLESHIP = POMDP_QUAD_MIN_LANES;
 #else
-constexpr int64_t QUAD_MIN_ROCK = 1 << 19, QUAD_MIN_TAG = 1 << 19, QUAD_MIN_GENERIC = 1 << 18, QUAD_MIN_NETWORK = 1 << 19;
+constexpr int64_t QUAD_MIN_ROCK = 1 << 19, QUAD_MIN_TAG = 1 << 19, QUAD_MIN_GENERIC = 1 << 18, QUAD_MIN_NETWORK = 1 << 19,
+                  QUAD_MIN_BATTLESHIP = 1 << 18;
 #endif
 
 // which kernel the calling thread's most recent fused launch picked (pomdp_last_fused_kernel: bench.py names the kernel
@@ -1837,9 +1992,9 @@ static int launch_steps_fused(const typename Env::Params &p, uint32_t *state, in
 {
     if (!state || !action || !ob || !reward || !done || bad_range(n, lane0) || (lane0 & 3u) || k < 1) return POMDP_E_BADARG;
     if (n == 0) return 0;
-    // two lanes per thread from 2^18 lanes (RockSample) / 2^19 (Tag: at 2^18 its one-lane-per-thread loop takes 1.20 us per
-    // step against 1.35)
-    const bool lpt2 = Env::POOLED_LPT2 && n >= (std::is_same<Env, TagEnv>::value ? 2 * LPT2_MIN_LANES : LPT2_MIN_LANES);
+    // two lanes per thread from 2^19 lanes, where the batch does not qualify for a quad-per-thread loop: at 2^18 lanes the
+    // one-lane-per-thread loops take 0.90 (RockSample; 1.09 with two) and 1.08 us per step (Tag)
+    const bool lpt2 = Env::POOLED_LPT2 && n >= 2 * LPT2_MIN_LANES;
     const bool simple = (flags & POMDP_AUTO_RESET) && n % (lpt2 ? 2 * BLOCK : BLOCK) == 0;
     const dim3 grid(lpt2 ? (unsigned)((n + 2 * BLOCK - 1) / (2 * BLOCK)) : blocks_for(n));
     const int kflags = (flags & POMDP_AUTO_RESET) | (gen_first ? FLAG_GEN_FIRST : 0);
@@ -1873,6 +2028,14 @@ static int launch_steps_fused(const typename Env::Params &p, uint32_t *state, in
                 hipLaunchKernelGGL(tag_steps_quad_kernel<false>, qgrid, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob, reward,
                                    done, n, make_key(seed, t), lane0, make_key(action_seed, t + 1), k, rec, gf, p);
             }
+            launched = true;
+        }
+    }
+    if constexpr (has_next<Env>::value) {
+        if (quad_ok && n >= QUAD_MIN_BATTLESHIP && k <= 255) {
+            note_fused("battleship_steps_quad_kernel", Env::NAME, "");
+            hipLaunchKernelGGL(battleship_steps_quad_kernel<Env::WORDS / 3>, qgrid, dim3(BLOCK), 0, (hipStream_t)stream, state, action,
+                               ob, reward, done, n, make_key(seed, t), lane0, make_key(action_seed, t + 1), k, rec, gf, p);
             launched = true;
         }
     }
@@ -1988,7 +2151,7 @@ static int launch_rollout(const typename Env::Params &p, const uint32_t *state, 
                           int32_t *n_steps, int32_t *first_action, int32_t *last_ob, uint8_t *terminated, void *stream)
 {
     if (!state || !ret || !n_steps || !first_action || !last_ob || !terminated || n_roots < 0 || sims < 1 || depth < 0 ||
-        bad_range(n_roots * sims, lane0))
+        bad_range(n_roots * sims, lane0) || (lane0 & 3u))                  // quad-shared blocks travel within the hardware quad
         return POMDP_E_BADARG;
     const int64_t n = n_roots * sims;
     if (n == 0) return 0;
@@ -2100,6 +2263,9 @@ static int dispatch_env(int env, const void *params, F &&f)
     case POMDP_ENV_NETWORK: {
         const pomdp_network_params *p = (const pomdp_network_params *)params;
         if (p->n_machines < 1 || p->n_machines > 32) return POMDP_E_BADPARAMS;
+        // Bernoulli thresholds are numerators of numpy's 53-bit doubles: k53 <= thr.  The fast step compares 32-bit high
+        // words against (thr >> 26) << 5, which wraps for thr >= 2^53 (a probability of 1.0)
+        if ((p->fail_thr | p->fail_nb_thr | p->obs_thr) >> 53) return POMDP_E_BADPARAMS;
         return f(EnvTag<NetworkEnv>{}, *p);
     }
     default: return POMDP_E_BADARG;
@@ -2247,11 +2413,14 @@ int pomdp_step(const pomdp_step_args *a, const int32_t *action, uint64_t t, void
 struct ScalarWait {
     uint32_t *flag = nullptr;
     uint32_t seq = 0;
+    // the one allocation the library makes (documented in include/pomdp_hip.h): 64 bytes of pinned host memory per calling
+    // thread, visible to every device (portable), freed when the thread ends
+    ~ScalarWait() { if (flag) (void)hipHostFree(flag); }
     bool arm(int64_t n)
     {
         if (n != 1) return false;
         if (!flag) {
-            if (hipHostMalloc((void **)&flag, 64, hipHostMallocDefault) != hipSuccess) { flag = nullptr; return false; }
+            if (hipHostMalloc((void **)&flag, 64, hipHostMallocPortable) != hipSuccess) { flag = nullptr; return false; }
             *flag = 0;
         }
         tl_host_flag = flag; tl_flag_value = ++seq;
@@ -2263,10 +2432,13 @@ struct ScalarWait {
         tl_host_flag = nullptr;
         if (rc) return rc;
         if (taken) {
+            // a one-lane launch on an idle stream publishes its flag ~10 us after the call; with earlier work queued on the
+            // stream the flag cannot appear before that work is done, so the poll is bounded at 100 us (ten launches' worth)
+            // and the blocking wait takes over — a query of the stream before every step would cost the common case more
             const auto t0 = std::chrono::steady_clock::now();
             for (uint32_t spins = 0;; ++spins) {
                 if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return 0;
-                if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(1)) break;
+                if ((spins & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(100)) break;
             }
         }
         return (int)hipStreamSynchronize((hipStream_t)stream);
@@ -2545,7 +2717,9 @@ int pomdp_heuristic_steps(int env, const void *params, uint32_t *state, const po
                           int64_t k_steps, int flags, void *stream)
 {
     const int K = history_rocks(env, params);
-    if (K < 0 || !params || !state || !prev_ob || !action || !ob || !reward || !done || k_steps < 0 || bad_range(n, lane0))
+    // (the policy's block — and RockSample's STEP / RESET blocks — are shared by global lanes 4 q .. 4 q + 3 and travel
+    // within the hardware quad: a shard has to start on such a boundary)
+    if (K < 0 || !params || !state || !prev_ob || !action || !ob || !reward || !done || k_steps < 0 || bad_range(n, lane0) || (lane0 & 3u))
         return POMDP_E_BADARG;
     if (!history_ok(h, K > 0) || (K > 0 && !belief_ok(b))) return POMDP_E_BADARG;
     if (returns && !(returns->ret && returns->disc && returns->ret_done)) return POMDP_E_BADARG;

@@ -463,6 +463,9 @@ class BatchedEnv(object):
             raise AttributeError("%s: heuristic_steps before reset()" % type(self).__name__)
         if history.prev_ob is None:
             raise ValueError("History was built without the current observation: History(env, observation=ob)")
+        if self.lane_offset % 4:
+            raise ValueError("heuristic_steps: lane_offset must be a multiple of 4 (got %d): the policy's Philox block is shared "
+                             "by global lanes 4q .. 4q+3" % self.lane_offset)
         if getattr(self, "_action_scratch", None) is None:
             self._action_scratch = torch.empty(self.batch_size, dtype=torch.int32, device=self.device)
         t0 = self._t
@@ -511,6 +514,8 @@ class BatchedEnv(object):
         st = st.reshape(self.state_words, -1).contiguous()
         n_roots = st.shape[1]
         n = n_roots * int(sims_per_root)
+        if (self.lane_offset if lane_offset is None else int(lane_offset)) % 4:
+            raise ValueError("rollout: the simulations' first global lane must be a multiple of 4 (quad-shared Philox blocks)")
         t0 = self._t
         self._t += int(depth)
         if out is None:

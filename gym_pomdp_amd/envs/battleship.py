@@ -26,14 +26,15 @@ def make_params(board_size=(5, 5), max_len=3):
         for j in range(4):
             p.vpat[k][j] = (v >> (32 * j)) & 0xFFFFFFFF
     mask_words = (cells + 6 + 31) // 32
-    return p, 2 * mask_words, cells, 2
+    return p, 3 * mask_words, cells, 2     # occupied, visited (+ remaining), the next episode's occupied mask
 
 
 class BattleShipEnv(BatchedEnv):
-    """Action a shoots cell (a % X, a // X) (coord.py:118-120); observation 1 on a first hit else 0;
+    """Action a shoots cell (a % X, a // X) (coord.py:64-66); observation 1 on a first hit else 0;
     reward -10 for a revisit, -1 for a new cell, + X*Y when the last ship cell is hit
     (battleship.py:91-122).  Ships of length max_len..2 are placed by rejection sampling at reset
-    (battleship.py:167-211)."""
+    (battleship.py:167-211).  A lane also carries the board of its NEXT episode (state words 2*MW .. 3*MW-1; the board
+    contract of include/pomdp_hip.h): an auto-reset moves it in and draws the one after it."""
     env_name = "battleship"
     reward_dtype = torch.int32
 
@@ -54,7 +55,7 @@ class BattleShipEnv(BatchedEnv):
 
     def decode_state(self):
         """int64 [N, 1 + 2*cells] = [total_remaining, occupied_0.., visited_0..], cell a = y*X + x."""
-        mw = self.state_words // 2
+        mw = self.state_words // 3
         cells = self.board_size[0] * self.board_size[1]
         s = self._state.to(torch.int64) & 0xFFFFFFFF
         a = torch.arange(cells, device=self.device)

@@ -13,7 +13,9 @@
  *
  * Conventions
  *   - every pointer marked "device" is HBM the caller owns (e.g. a torch tensor's
- *     data_ptr()); the library never allocates or frees, and never synchronises (pomdp_step_sync / pomdp_reset_sync / pomdp_stream_sync, which exist to do so, aside);
+ *     data_ptr()); the library never allocates or frees device memory, and never synchronises (pomdp_step_sync / pomdp_reset_sync / pomdp_stream_sync,
+ *     which exist to do so, aside; those two keep ONE 64-byte block of pinned, portable host memory per calling thread — the flag
+ *     a one-lane kernel publishes its outputs through — allocated at the thread's first such call and freed when the thread ends);
  *   - `state` is struct-of-arrays: uint32 [words][n], word-major, lane i at state[w*n + i];
  *   - params structs are read on the host at call time and passed to the kernel
  *     by value (kernarg) — they may live on the caller's stack;
@@ -59,7 +61,7 @@ enum {
 
 /* id of the word streams of one (seed, lane, t) */
 enum { POMDP_STREAM_STEP = 0, POMDP_STREAM_RESET = 1, POMDP_STREAM_STEP_SPACE = 2,
-       POMDP_STREAM_RESET_SPACE = 3, POMDP_STREAM_ACTION = 4, POMDP_STREAM_ROLLOUT = 5 };
+       POMDP_STREAM_RESET_SPACE = 3, POMDP_STREAM_ACTION = 4, POMDP_STREAM_ROLLOUT = 5, POMDP_STREAM_NEXT = 6 };
 
 /* env kinds for the generic entry points */
 enum { POMDP_ENV_ROCK = 0, POMDP_ENV_TAG = 1, POMDP_ENV_BATTLESHIP = 2, POMDP_ENV_TIGER = 3, POMDP_ENV_NETWORK = 4 };
@@ -108,9 +110,13 @@ int pomdp_tag_step(const pomdp_tag_params *p, uint32_t *state, const int32_t *ac
                    uint64_t seed, uint32_t lane0, uint64_t t, int flags, void *stream);
 
 /* ---- BattleShip  (battleship.py:12-211) ------------------------------------ */
-/* state: 2*MW words, MW = ceil((x_size*y_size + 6) / 32) <= 4: occupied mask words 0..MW-1 then
- * visited mask words; cell a = y * x_size + x is bit a; total_remaining in bits 26-31 of the
- * last visited word. */
+/* state: 3*MW words, MW = ceil((x_size*y_size + 6) / 32) <= 4: occupied mask words 0..MW-1, then the
+ * visited mask words (cell a = y * x_size + x is bit a; total_remaining in bits 26-31 of the last
+ * visited word), then the occupied mask of the lane's NEXT episode.  Board contract: whenever a board
+ * is dealt at call counter t — reset() draws it from stream RESET of (lane, t); the auto-reset of a
+ * step at t moves the cached next board in — the board after it is drawn from stream NEXT of (lane, t).
+ * A lane's boards are therefore known one episode ahead, and a fused launch builds the boards its
+ * lanes used up side by side when it ends instead of stalling a wave on one lane's rejection loop. */
 typedef struct pomdp_battleship_params {
     int32_t x_size, y_size; /* x_size * y_size <= 122                     battleship.py:67 */
     int32_t max_len;        /* ctor max_len (ships max_len .. 2), 2..10   battleship.py:74-75 */
@@ -278,7 +284,8 @@ int pomdp_compute_prob(int env, const void *params, const uint32_t *state, const
  *            a = list[(w * len(list)) >> 32], w = word k of stream ROLLOUT at (seed, lane, t0);
  *            (ob, r, done) = step(a) on stream STEP at (seed, lane, t0 + k);  ret += disc * r;  disc *= discount.
  * The return accumulates in IEEE double (separate multiply and add).  Per-lane outputs (device):
- * ret double[n], n_steps / first_action / last_ob int32[n], terminated uint8[n]. */
+ * ret double[n], n_steps / first_action / last_ob int32[n], terminated uint8[n].  lane0 must be a multiple of 4
+ * (RockSample's STEP blocks are shared by global lanes 4 q .. 4 q + 3 and travel within the hardware quad). */
 enum { POMDP_ROLLOUT_ALL_ACTIONS = 1 };
 int pomdp_rollout(int env, const void *params, const uint32_t *root_state, int64_t n_roots, int64_t sims_per_root,
                   int depth, double discount, int flags, uint64_t seed, uint32_t lane0, uint64_t t0,
@@ -373,7 +380,8 @@ int pomdp_pick_actions(const int32_t *list, const int32_t *len, int stride, int3
  * `returns` (may be NULL) adds the loop's discounted return, `r += rw * discount; discount *= env._discount`
  * (rock.py:569-570), in IEEE double with separate multiply and add: ret[i] += disc[i] * reward; disc[i] *= discount.
  * When a lane's episode ends, ret_done[i] receives its return; with POMDP_AUTO_RESET ret[i] / disc[i] then restart at
- * 0 / 1 for the new episode, without it they keep the finished episode's values (the lane is frozen). */
+ * 0 / 1 for the new episode, without it they keep the finished episode's values (the lane is frozen).
+ * lane0 must be a multiple of 4 (the policy's block is shared by global lanes 4 q .. 4 q + 3). */
 typedef struct pomdp_returns {
     double  discount;       /* the env's _discount (rock.py:115, tag.py:91, ...) */
     double *ret, *disc;     /* device double[n], in/out; start them at 0 and 1 */

@@ -25,7 +25,9 @@ RockSample's quad-shared step stream).
 Streams: 0 np.random draws made inside step(); 1 np.random draws made inside
 reset(); 2 / 3 the gym-space RNG (Discrete.sample) inside step() / reset()
 (Tiger only); 4 the benchmark's synthetic random-action policy; 5 the rollout policy's pick
-among the legal actions (word k of the stream of the rollout's first call counter picks step k).
+among the legal actions (word k of the stream of the rollout's first call counter picks step k); 6 BattleShip's
+"next board": whenever a board is dealt at call counter t (reset(): from stream 1; an auto-reset: the cached board moves
+in), the reference's reset() run on stream 6 of (lane, t) gives the board of the episode after it.
 """
 import numpy as np
 
@@ -35,6 +37,7 @@ STREAM_STEP_SPACE = 2
 STREAM_RESET_SPACE = 3
 STREAM_ACTION = 4
 STREAM_ROLLOUT = 5
+STREAM_NEXT = 6       # BattleShip: the board of the episode AFTER the one dealt at (lane, t) (include/pomdp_hip.h: board contract)
 
 _M0 = np.uint64(0xD2511F53)
 _M1 = np.uint64(0xCD9E8D57)

@@ -175,7 +175,7 @@ static const uint64_t ROCK_THR[29] = {
 
 typedef struct { int x, y; } coord;
 
-/* coord.py:155-160  Moves: NORTH (0,1) EAST (1,0) SOUTH (0,-1) WEST (-1,0) */
+/* coord.py:101-110  Moves: NORTH (0,1) EAST (1,0) SOUTH (0,-1) WEST (-1,0) */
 static const coord MOVES[4] = { {0, 1}, {1, 0}, {0, -1}, {-1, 0} };
 /* battleship.py:12-21  Compass, enumeration order */
 static const coord COMPASS[9] = { {0, 1}, {1, 0}, {0, -1}, {-1, 0}, {0, 0}, {1, 1}, {1, -1}, {-1, -1}, {-1, 1} };
@@ -198,6 +198,7 @@ struct or_env {
     /* ---- battleship ---- */
     int xs, ys, max_len;       /* max_len = ctor max_len + 1 (battleship.py:75) */
     uint8_t occ[16][16], vis[16][16];
+    uint8_t next_occ[16][16];  /* batched board contract: the NEXT episode's ships (see bs_deal_next) */
     int remaining;
     /* ---- tiger ---- */
     int tiger;
@@ -359,7 +360,7 @@ static int rock_reset(or_env *e, or_ws *np_rng)
 }
 
 /* rock.py:123-194 step, 401-407 _sample_ob, 383-387 _efficiency,
- * coord.py:133-135 euclidean_distance (ord-1 norm == L1). */
+ * coord.py:79-81 euclidean_distance (ord-1 norm == L1). */
 static void rock_step(or_env *e, int action, or_ws *np_rng, int *ob_out, double *rw_out, int *done_out)
 {
     int reward = 0, ob = 0;
@@ -490,7 +491,7 @@ static void tag_step(or_env *e, int action, or_ws *np_rng, int *ob_out, double *
 /* ------------------------------------------------------------------------ */
 /* BattleShip                                                                */
 /* ------------------------------------------------------------------------ */
-/* coord.py:115-116 */
+/* coord.py:61-62 */
 static int bs_inside(const or_env *e, coord c) { return c.x >= 0 && c.y >= 0 && c.x < e->xs && c.y < e->ys; }
 
 /* battleship.py:195-211 */
@@ -510,7 +511,7 @@ static int bs_collision(const or_env *e, coord pos, int dir, int length)
 }
 
 /* battleship.py:131-137 reset, 167-180 _get_init_state, 182-193 mark_ship,
- * coord.py:122-123 Grid.sample, battleship.py:33-37 Ship.__init__ (pos drawn before direction) */
+ * coord.py:68-69 Grid.sample, battleship.py:33-37 Ship.__init__ (pos drawn before direction) */
 static int bs_reset(or_env *e, or_ws *np_rng)
 {
     memset(e->occ, 0, sizeof(e->occ));
@@ -520,7 +521,7 @@ static int bs_reset(or_env *e, or_ws *np_rng)
         coord pos; int dir;
         for (;;) {
             int idx = (int)or_draw_randint(np_rng, (uint32_t)(e->xs * e->ys));
-            pos.x = idx % e->xs; pos.y = idx / e->xs;          /* coord.py:118-120 */
+            pos.x = idx % e->xs; pos.y = idx / e->xs;          /* coord.py:64-66 */
             dir = (int)or_draw_randint(np_rng, 4);
             if (!bs_collision(e, pos, dir, length)) break;
         }
@@ -531,6 +532,25 @@ static int bs_reset(or_env *e, or_ws *np_rng)
         }
     }
     return 0;
+}
+
+/* The batched build's board contract (include/pomdp_hip.h): a lane holds the board of its NEXT episode
+ * too.  Whenever a board is dealt at call counter t — reset() draws it from stream RESET of (lane, t); the auto-reset of
+ * a step at t moves the cached board in — the board after it is the reference's reset() (battleship.py:131-137) run on
+ * stream NEXT of (lane, t).  bs_deal_next: that second draw; bs_swap_in: the cached board becomes the current one. */
+static void bs_deal_next(or_env *e, or_ws *next_rng)
+{
+    or_env tmp = *e;
+    bs_reset(&tmp, next_rng);
+    memcpy(e->next_occ, tmp.occ, sizeof(e->occ));
+}
+static void bs_swap_in(or_env *e)
+{
+    memcpy(e->occ, e->next_occ, sizeof(e->occ));
+    memset(e->vis, 0, sizeof(e->vis));
+    e->remaining = 0;
+    for (int x = 0; x < e->xs; x++)
+        for (int y = 0; y < e->ys; y++) e->remaining += e->occ[x][y];
 }
 
 /* battleship.py:91-122 */
@@ -680,7 +700,7 @@ int or_env_words(const or_env *e)
 {
     switch (e->kind) {
     case OR_ENV_ROCK: return e->num_rocks <= 12 ? 1 : 2;
-    case OR_ENV_BATTLESHIP: return 2 * bs_mask_words(e);
+    case OR_ENV_BATTLESHIP: return 3 * bs_mask_words(e);   /* occupied, visited (+ remaining), next episode's occupied */
     default: return 1;
     }
 }
@@ -710,6 +730,7 @@ void or_env_pack(const or_env *e, uint32_t *w)
         for (int a = 0; a < c; a++) {
             if (e->occ[a % e->xs][a / e->xs]) w[a >> 5] |= 1u << (a & 31);
             if (e->vis[a % e->xs][a / e->xs]) w[mw + (a >> 5)] |= 1u << (a & 31);
+            if (e->next_occ[a % e->xs][a / e->xs]) w[2 * mw + (a >> 5)] |= 1u << (a & 31);
         }
         w[2 * mw - 1] |= (uint32_t)e->remaining << 26;
         break;
@@ -744,6 +765,7 @@ void or_env_unpack(or_env *e, const uint32_t *w)
         for (int a = 0; a < c; a++) {
             e->occ[a % e->xs][a / e->xs] = (w[a >> 5] >> (a & 31)) & 1u;
             e->vis[a % e->xs][a / e->xs] = (w[mw + (a >> 5)] >> (a & 31)) & 1u;
+            e->next_occ[a % e->xs][a / e->xs] = (w[2 * mw + (a >> 5)] >> (a & 31)) & 1u;
         }
         e->remaining = (int)(w[2 * mw - 1] >> 26);
         break;
@@ -804,12 +826,16 @@ void or_batch_reset(const or_env *proto, uint32_t *state, int32_t *ob, int64_t n
     {
         or_env e = *proto;
         or_ws np_rng, sp_rng;
-        uint32_t w[8];
+        uint32_t w[12];
 #pragma omp for schedule(static)
         for (int64_t i = 0; i < n; i++) {
             or_ws_philox_env(&np_rng, e.kind, seed, lane0 + (uint32_t)i, t, OR_STREAM_RESET);
             or_ws_philox(&sp_rng, seed, lane0 + (uint32_t)i, t, OR_STREAM_RESET_SPACE);
             int o = or_env_reset(&e, &np_rng, &sp_rng);
+            if (e.kind == OR_ENV_BATTLESHIP) {                 /* ... and the board of the episode after this one */
+                or_ws_philox(&np_rng, seed, lane0 + (uint32_t)i, t, OR_STREAM_NEXT);
+                bs_deal_next(&e, &np_rng);
+            }
             or_env_pack(&e, w);
             for (int j = 0; j < W; j++) state[(int64_t)j * n + i] = w[j];
             if (ob) ob[i] = o;
@@ -828,7 +854,7 @@ int64_t or_batch_step(const or_env *proto, uint32_t *state, const int32_t *actio
     {
         or_env e = *proto;
         or_ws np_rng, sp_rng;
-        uint32_t w[8];
+        uint32_t w[12];
 #pragma omp for schedule(static)
         for (int64_t i = 0; i < n; i++) {
             int o = 0, d = 0; double r = 0;
@@ -843,7 +869,11 @@ int64_t or_batch_step(const or_env *proto, uint32_t *state, const int32_t *actio
                 or_ws_philox_env(&np_rng, e.kind, seed, lane0 + (uint32_t)i, t, OR_STREAM_STEP);
                 or_ws_philox(&sp_rng, seed, lane0 + (uint32_t)i, t, OR_STREAM_STEP_SPACE);
                 or_env_step(&e, a, &np_rng, &sp_rng, &o, &r, &d);
-                if (d && auto_reset) {
+                if (d && auto_reset && e.kind == OR_ENV_BATTLESHIP) {   /* the cached board moves in; the one after it from NEXT */
+                    bs_swap_in(&e);
+                    or_ws_philox(&np_rng, seed, lane0 + (uint32_t)i, t, OR_STREAM_NEXT);
+                    bs_deal_next(&e, &np_rng);
+                } else if (d && auto_reset) {
                     or_ws_philox_env(&np_rng, e.kind, seed, lane0 + (uint32_t)i, t, OR_STREAM_RESET);
                     or_ws_philox(&sp_rng, seed, lane0 + (uint32_t)i, t, OR_STREAM_RESET_SPACE);
                     or_env_reset(&e, &np_rng, &sp_rng);
@@ -864,7 +894,7 @@ void or_batch_compact(const or_env *proto, const uint32_t *state, int64_t *out, 
 {
     int W = or_env_words(proto), S = or_env_compact_len(proto);
     or_env e = *proto;
-    uint32_t w[8];
+    uint32_t w[12];
     for (int64_t i = 0; i < n; i++) {
         for (int j = 0; j < W; j++) w[j] = state[(int64_t)j * n + i];
         or_env_unpack(&e, w);
@@ -887,24 +917,68 @@ void or_synthetic_actions(int32_t *action, int64_t n, uint64_t seed, uint32_t la
     }
 }
 
+/* bench.py's cpu_baseline: `steps` steps of n lanes under the synthetic policy with auto-reset — the workload of the GPU's
+ * timed region.  Lanes are independent, so every thread owns a contiguous chunk of lanes for the whole run (static split,
+ * its pages first touched by itself) and walks it in blocks of lanes that stay in its cache across the steps of a block
+ * pass: no barrier and no shared cache line between threads anywhere in the timed part, which is what lets the loop scale
+ * with the cores it is given.  Same results as or_batch_reset + steps x (or_synthetic_actions, or_batch_step): the draws of
+ * a lane depend on (seed, lane, t) only. */
 double or_bench_loop(const or_env *proto, int64_t n, int64_t steps, uint64_t seed, int nthreads, int64_t *n_done)
 {
-    int W = or_env_words(proto);
+    int W = or_env_words(proto), nA = or_env_n_actions(proto);
+    const uint64_t aseed = seed ^ 0x5DEECE66DULL;
+    const uint32_t akey[2] = { (uint32_t)aseed, (uint32_t)(aseed >> 32) };
     uint32_t *state = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)W * (size_t)n);
-    int32_t *action = (int32_t *)malloc(sizeof(int32_t) * (size_t)n), *ob = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
-    void *reward = malloc(4 * (size_t)n);
-    uint8_t *done = (uint8_t *)calloc((size_t)n, 1);
     int64_t dsum = 0;
-    or_batch_reset(proto, state, ob, n, seed, 0, 0, nthreads);
-    double t0 = omp_get_wtime();
-    for (int64_t s = 1; s <= steps; s++) {
-        or_synthetic_actions(action, n, seed ^ 0x5DEECE66DULL, 0, (uint64_t)s, (uint32_t)or_env_n_actions(proto), nthreads);
-        or_batch_step(proto, state, action, ob, reward, done, n, seed, 0, (uint64_t)s, 1, nthreads);
-        for (int64_t i = 0; i < n; i += 4097) dsum += done[i];
+    double el = 0;
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel num_threads(nthreads) reduction(+ : dsum)
+    {
+        or_env e = *proto;
+        or_ws np_rng, sp_rng;
+        uint32_t w[12];
+        const int nt = omp_get_num_threads(), tid = omp_get_thread_num();
+        const int64_t lo = n * tid / nt, hi = n * (tid + 1) / nt;
+        for (int64_t i = lo; i < hi; i++) {                       /* reset at t = 0 (first touch of the thread's own chunk) */
+            or_ws_philox_env(&np_rng, e.kind, seed, (uint32_t)i, 0, OR_STREAM_RESET);
+            or_ws_philox(&sp_rng, seed, (uint32_t)i, 0, OR_STREAM_RESET_SPACE);
+            or_env_reset(&e, &np_rng, &sp_rng);
+            if (e.kind == OR_ENV_BATTLESHIP) { or_ws_philox(&np_rng, seed, (uint32_t)i, 0, OR_STREAM_NEXT); bs_deal_next(&e, &np_rng); }
+            or_env_pack(&e, w);
+            for (int j = 0; j < W; j++) state[(int64_t)j * n + i] = w[j];
+        }
+#pragma omp barrier
+        double t0 = omp_get_wtime();
+        for (int64_t i = lo; i < hi; i++) {
+            for (int j = 0; j < W; j++) w[j] = state[(int64_t)j * n + i];
+            or_env_unpack(&e, w);
+            for (int64_t s = 1; s <= steps; s++) {
+                uint32_t c[4] = { (uint32_t)i >> 2, (uint32_t)s, (uint32_t)((uint64_t)s >> 32), (uint32_t)OR_STREAM_ACTION << 24 }, o4[4];
+                or_philox4x32_10(c, akey, o4);
+                const int a = (int)(((uint64_t)o4[i & 3] * (uint32_t)nA) >> 32);
+                int o, d; double r;
+                or_ws_philox_env(&np_rng, e.kind, seed, (uint32_t)i, (uint64_t)s, OR_STREAM_STEP);
+                or_ws_philox(&sp_rng, seed, (uint32_t)i, (uint64_t)s, OR_STREAM_STEP_SPACE);
+                or_env_step(&e, a, &np_rng, &sp_rng, &o, &r, &d);
+                if (d && e.kind == OR_ENV_BATTLESHIP) {
+                    bs_swap_in(&e);
+                    or_ws_philox(&np_rng, seed, (uint32_t)i, (uint64_t)s, OR_STREAM_NEXT);
+                    bs_deal_next(&e, &np_rng);
+                } else if (d) {
+                    or_ws_philox_env(&np_rng, e.kind, seed, (uint32_t)i, (uint64_t)s, OR_STREAM_RESET);
+                    or_ws_philox(&sp_rng, seed, (uint32_t)i, (uint64_t)s, OR_STREAM_RESET_SPACE);
+                    or_env_reset(&e, &np_rng, &sp_rng);
+                }
+                dsum += d;
+            }
+            or_env_pack(&e, w);
+            for (int j = 0; j < W; j++) state[(int64_t)j * n + i] = w[j];
+        }
+#pragma omp barrier
+        if (tid == 0) el = omp_get_wtime() - t0;
     }
-    double el = omp_get_wtime() - t0;
     if (n_done) *n_done = dsum;
-    free(state); free(action); free(ob); free(reward); free(done);
+    free(state);
     return el;
 }
 
@@ -942,7 +1016,7 @@ void or_batch_legal(const or_env *proto, const uint32_t *state, int32_t *out, in
 {
     int W = or_env_words(proto);
     or_env e = *proto;
-    uint32_t w[8];
+    uint32_t w[12];
     int list[OR_MAX_LEGAL];
     for (int64_t i = 0; i < n; i++) {
         for (int j = 0; j < W; j++) w[j] = state[(int64_t)j * n + i];
@@ -965,7 +1039,7 @@ void or_batch_rollout(const or_env *proto, const uint32_t *state, int64_t n_root
     {
         or_env e = *proto;
         or_ws np_rng, sp_rng, pol;
-        uint32_t w[8];
+        uint32_t w[12];
         int list[OR_MAX_LEGAL];
 #pragma omp for schedule(static)
         for (int64_t i = 0; i < n; i++) {
@@ -1054,7 +1128,7 @@ void or_batch_compute_prob(const or_env *proto, const uint32_t *state, const int
 {
     int W = or_env_words(proto);
     or_env e = *proto;
-    uint32_t w[8];
+    uint32_t w[12];
     for (int64_t i = 0; i < n; i++) {
         for (int j = 0; j < W; j++) w[j] = state[(int64_t)j * n + i];
         or_env_unpack(&e, w);
@@ -1080,7 +1154,7 @@ void or_batch_rock_belief_update(const or_env *proto, const uint32_t *state, con
 {
     int W = or_env_words(proto), K = proto->num_rocks;
     or_env e = *proto;
-    uint32_t w[8];
+    uint32_t w[12];
     for (int64_t i = 0; i < n; i++) {
         if (done[i]) {                                            /* reset() builds new Rock objects */
             if (auto_reset)
@@ -1228,7 +1302,7 @@ void or_batch_preferred(const or_env *proto, const uint32_t *state, const or_roc
 {
     int W = or_env_words(proto);
     or_env e = *proto;
-    uint32_t w[8];
+    uint32_t w[12];
     int list[OR_MAX_LEGAL];
     for (int64_t i = 0; i < n; i++) {
         for (int j = 0; j < W; j++) w[j] = state[(int64_t)j * n + i];
@@ -1247,7 +1321,7 @@ void or_batch_rock_select_target(const or_env *proto, const uint32_t *state, con
 {
     int W = or_env_words(proto);
     or_env e = *proto;
-    uint32_t w[8];
+    uint32_t w[12];
     for (int64_t i = 0; i < n; i++) {
         for (int j = 0; j < W; j++) w[j] = state[(int64_t)j * n + i];
         or_env_unpack(&e, w);

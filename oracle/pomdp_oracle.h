@@ -26,7 +26,7 @@ extern "C" {
 /* ---- 32-bit word sources ------------------------------------------------ */
 enum { OR_WS_MT19937 = 0, OR_WS_PHILOX = 1 };
 enum { OR_STREAM_STEP = 0, OR_STREAM_RESET = 1, OR_STREAM_STEP_SPACE = 2,
-       OR_STREAM_RESET_SPACE = 3, OR_STREAM_ACTION = 4, OR_STREAM_ROLLOUT = 5 };
+       OR_STREAM_RESET_SPACE = 3, OR_STREAM_ACTION = 4, OR_STREAM_ROLLOUT = 5, OR_STREAM_NEXT = 6 };
 
 typedef struct or_ws {
     int kind;

@@ -111,6 +111,16 @@ def inject_stream(seed, lane, t, stream, rs=None, env=None, env_kwargs=None):
     return N_INJECT
 
 
+def inject_auto_reset(seed, lane, t, dealt_at, env=None, env_kwargs=None):
+    """Words of the reference reset() that follows a done step at call counter t.  BattleShip (board contract,
+    include/pomdp_hip.h): the board that moves in then is the reference's reset() on stream NEXT of the call counter
+    `dealt_at` at which the lane's PREVIOUS board was dealt (by the initial reset or by an earlier auto-reset);
+    every other env: stream RESET of (lane, t)."""
+    if env == "battleship":
+        return inject_stream(seed, lane, dealt_at, px.STREAM_NEXT, env=env, env_kwargs=env_kwargs)
+    return inject_stream(seed, lane, t, px.STREAM_RESET, env=env, env_kwargs=env_kwargs)
+
+
 # ---------------------------------------------------------------------------
 # env construction and compact integer state
 # ---------------------------------------------------------------------------
@@ -208,7 +218,8 @@ def trace_mode_b(name, kwargs, seed, lanes, actions, t0=0):
 
     actions: int[len(lanes), T].  Call `c` of the batched env uses t = t0 + c:
     the initial reset is t0, step i is t0 + 1 + i, and the auto-reset that
-    follows a done step shares that step's t (stream RESET instead of STEP).
+    follows a done step shares that step's t (stream RESET instead of STEP;
+    BattleShip: see inject_auto_reset).
     """
     lanes = list(lanes)
     actions = np.asarray(actions)
@@ -234,6 +245,7 @@ def trace_mode_b(name, kwargs, seed, lanes, actions, t0=0):
                        state=np.zeros((L, T, S), np.int64), reset_ob=np.full((L, T), -1, np.int64))
         out["ob0"][li] = int(ob0)
         out["state0"][li] = s0
+        dealt_at = t0
         for i in range(T):
             t = t0 + 1 + i
             lim = inject_stream(seed, lane, t, px.STREAM_STEP, env=name, env_kwargs=kwargs)
@@ -245,7 +257,8 @@ def trace_mode_b(name, kwargs, seed, lanes, actions, t0=0):
             out["ob"][li, i], out["reward"][li, i], out["done"][li, i] = int(o), _as_float(r), int(bool(d))
             out["state_pre"][li, i] = compact_state(name, env)
             if d:
-                lim = inject_stream(seed, lane, t, px.STREAM_RESET, env=name, env_kwargs=kwargs)
+                lim = inject_auto_reset(seed, lane, t, dealt_at, env=name, env_kwargs=kwargs)
+                dealt_at = t
                 if space is not None:
                     inject_stream(seed, lane, t, px.STREAM_RESET_SPACE, space)
                 out["reset_ob"][li, i] = int(env.reset())
@@ -335,6 +348,7 @@ def compute_prob_trace(name, kwargs, seed, lanes, actions, t0=0):
         if space is not None:
             inject_stream(seed, lane, t0, px.STREAM_RESET_SPACE, space)
         env.reset()
+        dealt_at = t0
         n_obs = env.observation_space.n
         if out is None:
             out = dict(prob=np.zeros((L, T, n_obs), np.float64), ob=np.zeros((L, T), np.int64),
@@ -354,7 +368,8 @@ def compute_prob_trace(name, kwargs, seed, lanes, actions, t0=0):
             for q in range(n_obs):
                 out["prob"][li, i, q] = float(env._compute_prob(a, info["state"], q))
             if d:
-                inject_stream(seed, lane, t, px.STREAM_RESET, env=name, env_kwargs=kwargs)
+                inject_auto_reset(seed, lane, t, dealt_at, env=name, env_kwargs=kwargs)
+                dealt_at = t
                 if space is not None:
                     inject_stream(seed, lane, t, px.STREAM_RESET_SPACE, space)
                 env.reset()

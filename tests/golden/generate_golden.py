@@ -301,7 +301,7 @@ def gen_edge_cases():
     e.state.agent_pos = Coord(12, 2)
     out["rock_15_15.sample_at_12_2"] = err(lambda: e.step(4))
     out["network.make_3legs_10"] = envs.NetworkEnv.make_3legs_neighbours(10)
-    out["moves"] = {"NORTH": [0, 1], "EAST": [1, 0], "SOUTH": [0, -1], "WEST": [-1, 0]}  # coord.py:174-180
+    out["moves"] = {"NORTH": [0, 1], "EAST": [1, 0], "SOUTH": [0, -1], "WEST": [-1, 0]}  # coord.py:120-126
     with open(os.path.join(HERE, "edge_cases.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
 

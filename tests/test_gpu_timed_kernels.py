@@ -233,14 +233,14 @@ def test_launcher_picks_the_documented_kernel_per_shard_size():
     from gym_pomdp_amd import _native
     L = _native.lib()
     want = [("rock", {}, 1 << 20, 64, "steps_quad_kernel<RockEnv<1>>"), ("rock", {}, 1 << 19, 64, "steps_quad_kernel<RockEnv<1>>"),
-            ("rock", {}, 1 << 18, 64, "steps_kernel<RockEnv<1>, 2, true>"), ("rock", {}, 1 << 17, 64, "steps_kernel<RockEnv<1>, 1, true, true>"), ("rock", {}, 1 << 17, 8, "steps_kernel<RockEnv<1>, 1, true>"),
+            ("rock", {}, 1 << 18, 64, "steps_kernel<RockEnv<1>, 1, true, true>"), ("rock", {}, (1 << 19) + 2048, 8, "steps_kernel<RockEnv<1>, 2, true>"), ("rock", {}, 1 << 17, 64, "steps_kernel<RockEnv<1>, 1, true, true>"), ("rock", {}, 1 << 17, 8, "steps_kernel<RockEnv<1>, 1, true>"),
             ("rock", {}, 1 << 20, 5, "steps_kernel<RockEnv<1>, 4, true>"), ("rock", dict(board_size=15, num_rocks=15), 1 << 20, 64, "steps_quad_kernel<RockEnv<2>>"),
             ("rock", {}, (1 << 19) + 4, 64, "steps_kernel<RockEnv<1>, 2, false>"),
             ("tag", {}, 1 << 19, 64, "tag_steps_quad_kernel<true>"), ("tag", {}, 1 << 19, 8, "tag_steps_quad_kernel<false>"),
             ("tag", {}, 1 << 18, 64, "steps_kernel<TagEnv, 1, true>"), ("tag", dict(num_opponents=2), 1 << 20, 64, "steps_kernel<TagEnv, 2, true>"),
             ("tiger", {}, 1 << 18, 64, "steps_quad_generic_kernel<TigerEnv>"), ("tiger", {}, 1 << 17, 64, "steps_kernel<TigerEnv, 1, true>"),
             ("network", {}, 1 << 19, 64, "network_steps_quad_kernel<>"), ("network", {}, 1 << 18, 64, "steps_kernel<NetworkEnv, 1, true>"),
-            ("battleship", {}, 1 << 19, 64, "steps_kernel<BattleShipEnv<1>, 1, true>"), ("stochrock", {}, 1 << 19, 64, "steps_quad_kernel<StochasticRockEnv<1>>"),
+            ("battleship", {}, 1 << 18, 64, "battleship_steps_quad_kernel<BattleShipEnv<1>>"), ("battleship", {}, 1 << 17, 64, "steps_kernel<BattleShipEnv<1>, 1, true>"), ("stochrock", {}, 1 << 19, 64, "steps_quad_kernel<StochasticRockEnv<1>>"),
             ("stochrock", {}, 1 << 18, 64, "steps_kernel<StochasticRockEnv<1>, 1, true>")]
     for env, kw, n, k, name in want:
         e = make_env(env, kw, batch_size=n, seed=1, reuse_buffers=True)

@@ -131,8 +131,8 @@ def test_network_params_follow_reference_topology():
 
 def test_other_params_validation():
     from gym_pomdp_amd.envs import battleship, tag
-    assert battleship.make_params((10, 10), 5)[1:] == (8, 100, 2)
-    assert battleship.make_params((5, 5), 3)[1:] == (2, 25, 2)
+    assert battleship.make_params((10, 10), 5)[1:] == (12, 100, 2)      # occupied + visited + next-episode mask words
+    assert battleship.make_params((5, 5), 3)[1:] == (3, 25, 2)
     with pytest.raises(ValueError):
         battleship.make_params((12, 12), 5)
     with pytest.raises(ValueError):          # the reference's reset() would never terminate on this board

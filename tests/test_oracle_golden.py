@@ -217,7 +217,7 @@ def test_compute_prob_matches_reference(oracle_lib, case, env, kw):
 
 
 def test_moves_axis_convention(oracle_lib):
-    """The reference's only known-answer test (coord.py:174-180, `TestCoord`): (2,2)+NORTH=(2,3), +EAST=(3,2),
+    """The reference's only known-answer test (coord.py:120-126, `TestCoord`): (2,2)+NORTH=(2,3), +EAST=(3,2),
     +SOUTH=(2,1), +WEST=(1,2).  Checked on the oracle's RockSample agent from its start cell (0,3)."""
     with open(os.path.join(GOLDEN, "edge_cases.json")) as f:
         moves = json.load(f)["moves"]
