@@ -39,9 +39,6 @@ import time
 # by the HIP runtime when it initialises, so it has to be in the environment before torch touches the GPU.  Measured:
 # 7.2 us per chained step with it, 7.5-7.7 without, 9.0 with the arguments in host memory (tools/drv_probe.py)
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
-# the cpu_baseline's OpenMP threads stay on their cores (read when the OpenMP runtime loads, i.e. with torch)
-os.environ.setdefault("OMP_PROC_BIND", "close")
-os.environ.setdefault("OMP_PLACES", "cores")
 
 import torch  # noqa: E402
 
@@ -200,33 +197,44 @@ def self_launch(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+CPU_BASELINE_CHILD = r"""
+import json, os, sys, time
+sys.path.insert(0, sys.argv[1])
+from oracle import oracle_lib as ol
+env_key, kwargs, seed, budget_s = sys.argv[2], json.loads(sys.argv[3]), int(sys.argv[4]), float(sys.argv[5])
+usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+o = ol.OracleEnv(env_key, **kwargs)
+n = 1 << 20
+t1 = o.bench_loop(1 << 16, 8, seed, 1)
+cands = sorted({c for c in (usable, usable // 2, 128, 64, 32, 16, 8, 4) if 1 <= c <= usable}, reverse=True)
+share = budget_s / len(cands)
+table = []
+for threads in cands:                      # strictly wall-clock bounded: chunks of steps until this count's share is spent
+    steps, el, t0 = 0, 0.0, time.perf_counter()
+    while time.perf_counter() - t0 < share:
+        el += o.bench_loop(n, 8, seed + steps, threads)
+        steps += 8
+    table.append({"threads": threads, "value": n * steps / el, "steps": steps, "seconds": el})
+print(json.dumps({"usable": usable, "one_core": (1 << 16) * 8 / t1, "table": table}))
+"""
+
+
 def cpu_baseline(env_key, kwargs, seed, budget_s):
     """The C oracle (a port of the reference's step()/reset(), pinned to reference traces) on the host
     cores this process may use, same workload shape (2^20 lanes, synthetic policy, auto-reset), the loop
     entirely in C (oracle/pomdp_oracle.c: or_bench_loop — every thread owns a chunk of lanes for the whole run, no
-    barrier between steps), bounded sample, every thread count tried is in the line."""
-    os.environ.setdefault("OMP_WAIT_POLICY", "passive")     # never spin: the box may expose more CPUs than it grants
-    from oracle import oracle_lib as ol
-    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    o = ol.OracleEnv(ORACLE_NAME[env_key], **kwargs)
-    n = 1 << 20
-    t1 = o.bench_loop(1 << 16, 8, seed, 1)
-    one_core = (1 << 16) * 8 / t1
-    # strictly wall-clock bounded: small chunks of steps until this thread count's share of the budget is spent
-    cands = sorted({c for c in (usable, usable // 2, 128, 64, 32, 16, 8) if 1 <= c <= usable}, reverse=True)
-    share = budget_s / len(cands)
-    best, table = None, []
-    for threads in cands:
-        steps, el, t0 = 0, 0.0, time.perf_counter()
-        k = 8
-        while time.perf_counter() - t0 < share:
-            el += o.bench_loop(n, k, seed + steps, threads)
-            steps += k
-        rate = n * steps / el
-        table.append({"threads": threads, "value": rate, "steps": steps, "seconds": el})
-        if best is None or rate > best[0]:
-            best = (rate, threads, steps, el)
-    rate, threads, steps, el = best
+    barrier between steps), bounded sample, every thread count tried is in the line.  Runs in a child process so that
+    its OpenMP runtime starts with its own settings (threads pinned to cores, passive waits) and torch's is left alone."""
+    import subprocess
+    env = dict(os.environ, OMP_PROC_BIND="close", OMP_PLACES="cores", OMP_WAIT_POLICY="passive")
+    env.pop("OMP_NUM_THREADS", None)
+    out = subprocess.run([sys.executable, "-c", CPU_BASELINE_CHILD, REPO, ORACLE_NAME[env_key], json.dumps(kwargs), str(seed),
+                          str(budget_s)], capture_output=True, text=True, env=env, timeout=60 + 4 * budget_s)
+    if out.returncode:
+        raise RuntimeError("cpu_baseline child failed: %s" % out.stderr[-2000:])
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    table, usable = r["table"], r["usable"]
+    best = max(table, key=lambda t: t["value"])
     quota = None
     try:                                                   # a cgroup CPU quota explains a curve that flattens early
         with open("/sys/fs/cgroup/cpu.max") as f:
@@ -234,12 +242,13 @@ def cpu_baseline(env_key, kwargs, seed, budget_s):
             quota = None if q[0] == "max" else float(q[0]) / float(q[1])
     except Exception:  # noqa: BLE001
         pass
-    return {"value": rate, "unit": "env-steps/s", "cores": threads, "kind": "port",
+    return {"value": best["value"], "unit": "env-steps/s", "cores": best["threads"], "kind": "port",
             "sample": "%d lanes x %d steps of the same workload on the C oracle (OpenMP, %d threads pinned with "
-                      "OMP_PROC_BIND=%s OMP_PLACES=%s, %.1f s; %d CPUs usable by this process; best of the thread counts in "
-                      "by_threads)" % (n, steps, threads, os.environ.get("OMP_PROC_BIND"), os.environ.get("OMP_PLACES"), el, usable),
+                      "OMP_PROC_BIND=close OMP_PLACES=cores, %.1f s; %d CPUs usable by this process%s; best of the thread counts "
+                      "in by_threads)" % (1 << 20, best["steps"], best["threads"], best["seconds"], usable,
+                                          "" if quota is None else ", cgroup quota %.0f CPUs" % quota),
             "by_threads": table, "cgroup_cpu_quota": quota,
-            "single_core": {"value": one_core, "unit": "env-steps/s", "cores": 1},
+            "single_core": {"value": r["one_core"], "unit": "env-steps/s", "cores": 1},
             "reference_python_recorded": {"value": 6.0e4, "unit": "env-steps/s", "cores": 1,
                                           "note": "reference's own Python loop, RockSample(7,8), measured in the "
                                                   "build container (BASELINE.md); it cannot travel to this box"}}

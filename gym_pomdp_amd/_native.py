@@ -11,9 +11,12 @@ import subprocess
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _REPO = os.path.dirname(_PKG)
 LIB_PATH = os.path.join(_PKG, "_lib", "libpomdp_hip.so")
-SOURCES = [os.path.join(_PKG, "csrc", f) for f in ("pomdp_kernels.hip", "envs.hip.h", "envs_common.hip.h", "philox.hip.h",
-                                                   "envs/rock.hip.h", "envs/tag.hip.h", "envs/battleship.hip.h",
-                                                   "envs/tiger.hip.h", "envs/network.hip.h")]
+# one object per translation unit (built in parallel), linked into one shared library
+UNITS = ["api.hip", "step_rock.hip", "step_other.hip", "fused_rock.hip", "fused_stochrock.hip", "fused_tag.hip",
+         "fused_battleship.hip", "fused_misc.hip", "planner.hip"]
+HEADERS = ["kernels_common.hip.h", "step_impl.hip.h", "fused_impl.hip.h", "envs.hip.h", "envs_common.hip.h", "philox.hip.h",
+           "envs/rock.hip.h", "envs/tag.hip.h", "envs/battleship.hip.h", "envs/tiger.hip.h", "envs/network.hip.h"]
+SOURCES = [os.path.join(_PKG, "csrc", f) for f in UNITS + HEADERS]
 HEADER = os.path.join(_REPO, "include", "pomdp_hip.h")
 ABI_VERSION = 9
 
@@ -88,19 +91,39 @@ def hipcc_path():
     return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
-def build(force=False, verbose=False):
-    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
+
+
+def build(force=False, verbose=False, defines=(), out=None, jobs=None):
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU): every translation unit of
+    csrc/ to its own object, in parallel, then one link.  `defines` (-DNAME=VALUE strings) and `out` build same-box A/B
+    variants (tools/ab_build.sh)."""
+    from concurrent.futures import ThreadPoolExecutor
+    lib_path = out or LIB_PATH
     deps = SOURCES + [HEADER]
-    if (not force and os.path.exists(LIB_PATH)
-            and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps)):
-        return LIB_PATH
-    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC",
-           "-o", LIB_PATH, SOURCES[0]]
+    if (not force and not defines and os.path.exists(lib_path)
+            and all(os.path.getmtime(lib_path) >= os.path.getmtime(d) for d in deps)):
+        return lib_path
+    os.makedirs(os.path.dirname(lib_path), exist_ok=True)
+    obj_dir = os.path.join(os.path.dirname(lib_path), "obj_" + os.path.splitext(os.path.basename(lib_path))[0])
+    os.makedirs(obj_dir, exist_ok=True)
+    hipcc = hipcc_path()
+
+    def compile_one(unit):
+        obj = os.path.join(obj_dir, os.path.splitext(unit)[0] + ".o")
+        cmd = [hipcc] + HIPCC_FLAGS + list(defines) + ["-c", "-o", obj, os.path.join(_PKG, "csrc", unit)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=jobs or min(len(UNITS), os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, UNITS))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + objs
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB_PATH
+    return lib_path
 
 
 _lib = None

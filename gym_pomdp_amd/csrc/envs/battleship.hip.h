@@ -1,4 +1,4 @@
-// envs/battleship.hip.h — BattleShip (gym_pomdp/envs/battleship.py): the lane functions the generic kernels of pomdp_kernels.hip call.
+// envs/battleship.hip.h — BattleShip (gym_pomdp/envs/battleship.py): the lane functions the generic kernels of step_impl.hip.h / fused_impl.hip.h / planner.hip call.
 // Included by envs.hip.h (which holds the Env interface description and the shared helpers).
 #pragma once
 #include "../envs_common.hip.h"
@@ -10,10 +10,10 @@ struct BattleShipEnv {
     using Params = pomdp_battleship_params;
     using Reward = int32_t;
     static constexpr int WORDS = 3 * MW;       // occupied, visited (+ remaining), the NEXT episode's occupied mask
-    static constexpr bool HAS_NEXT = true;     // pomdp_kernels.hip: the kernels fetch `next` where a lane may need it (load_next)
+    static constexpr bool HAS_NEXT = true;     // step_impl.hip.h, fused_impl.hip.h: the kernels fetch `next` where a lane may need it (load_next)
     static constexpr const char *NAME = MW == 1 ? "BattleShipEnv<1>" : MW == 2 ? "BattleShipEnv<2>" : MW == 3 ? "BattleShipEnv<3>" : "BattleShipEnv<4>";
     static constexpr bool POOLED_LPT2 = false;
-    static constexpr bool QUAD_STEP = false;   // pomdp_kernels.hip: step_quad_kernel
+    static constexpr bool QUAD_STEP = false;   // step_impl.hip.h: step_quad_kernel
     static constexpr bool HAS_ROCKS = false;   // a bounded History keeps a window of transitions for this env (history_push)
     static constexpr bool POOLED_ANY_LPT = false;
     static constexpr bool QUAD_SENSOR = false;
@@ -186,7 +186,7 @@ struct BattleShipEnv {
             return (M)((u128)((lo >> s) | (hi << (64 - s))) | ((u128)(hi >> s) << 64));
         }
     }
-    // ---- the same boards, many lanes at once (pomdp_kernels.hip: battleship_steps_quad_kernel) -----------------------------
+    // ---- the same boards, many lanes at once (fused_impl.hip.h: battleship_steps_quad_kernel) -----------------------------
     // board() reshaped for lanes that run it in lockstep: ONE loop in which every lane consumes exactly one word of its
     // stream per iteration — so the Philox blocks are generated under a wave-uniform condition, four iterations per block —
     // and a two-state machine per lane says what the word is: a position word (accepted when <= n_tiles - 1,

@@ -1,4 +1,4 @@
-// envs/network.hip.h — Network (gym_pomdp/envs/network.py): the lane functions the generic kernels of pomdp_kernels.hip call.
+// envs/network.hip.h — Network (gym_pomdp/envs/network.py): the lane functions the generic kernels of step_impl.hip.h / fused_impl.hip.h / planner.hip call.
 // Included by envs.hip.h (which holds the Env interface description and the shared helpers).
 #pragma once
 #include "../envs_common.hip.h"
@@ -11,7 +11,7 @@ struct NetworkEnv {
     static constexpr int WORDS = 1;
     static constexpr const char *NAME = "NetworkEnv";
     static constexpr bool POOLED_LPT2 = false;
-    static constexpr bool QUAD_STEP = false;   // pomdp_kernels.hip: step_quad_kernel
+    static constexpr bool QUAD_STEP = false;   // step_impl.hip.h: step_quad_kernel
     static constexpr bool HAS_ROCKS = false;   // a bounded History keeps a window of transitions for this env (history_push)
     static constexpr bool POOLED_ANY_LPT = false;
     static constexpr bool QUAD_SENSOR = false;
@@ -73,7 +73,7 @@ struct NetworkEnv {
         return ob == 2 ? 1.0 : 0.0;
     }
 
-    // ---- pieces of the step for the quad-per-thread fused loop (pomdp_kernels.hip: network_steps_quad_kernel) ----------
+    // ---- pieces of the step for the quad-per-thread fused loop (fused_impl.hip.h: network_steps_quad_kernel) ----------
     // Thresholds against the draw's HIGH word itself: k53 <= thr is decided by (H >> 5) < (thr >> 26), i.e. H < T with
     // T = (thr >> 26) << 5, unless H lies in [T, T + 32) — the tie (probability 2^-27) that asks for the low word.
     struct Thr { uint32_t fail, nb, obs; };

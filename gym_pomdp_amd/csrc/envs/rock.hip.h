@@ -1,4 +1,4 @@
-// envs/rock.hip.h — RockSample / StochasticRock (gym_pomdp/envs/rock.py): the lane functions the generic kernels of pomdp_kernels.hip call.
+// envs/rock.hip.h — RockSample / StochasticRock (gym_pomdp/envs/rock.py): the lane functions the generic kernels of step_impl.hip.h / fused_impl.hip.h / planner.hip call.
 // Included by envs.hip.h (which holds the Env interface description and the shared helpers).
 #pragma once
 #include "../envs_common.hip.h"
@@ -27,12 +27,12 @@ struct RockEnv {
     using S = typename std::conditional<W == 1, uint32_t, uint64_t>::type; // 32-bit ALU when one word is enough
     static constexpr int WORDS = W;
     static constexpr const char *NAME = STOCH ? (W == 1 ? "StochasticRockEnv<1>" : "StochasticRockEnv<2>") : (W == 1 ? "RockEnv<1>" : "RockEnv<2>");
-    static constexpr bool POOLED_LPT2 = !STOCH;   // pomdp_kernels.hip: Finisher<RockEnv, 2, .>
-    static constexpr bool QUAD_STEP = true;   // pomdp_kernels.hip: step_quad_kernel
+    static constexpr bool POOLED_LPT2 = !STOCH;   // kernels_common.hip.h: Finisher<RockEnv, 2, .>
+    static constexpr bool QUAD_STEP = true;   // step_impl.hip.h: step_quad_kernel
     static constexpr bool HAS_ROCKS = true;   // a bounded History keeps a window of transitions for this env (history_push)
     static constexpr bool POOLED_ANY_LPT = !STOCH; // ... and for any other number of lanes per thread >= 2
     static constexpr bool STOCHASTIC = STOCH;
-    static constexpr bool QUAD_TAB = true;        // pomdp_kernels.hip: steps_quad_kernel (RockEnv and StochasticRockEnv)
+    static constexpr bool QUAD_TAB = true;        // fused_impl.hip.h: steps_quad_kernel (RockEnv and StochasticRockEnv)
     struct Shared {
         uint2 thr[32];         // sensor threshold by L1 distance: .x = thr >> 26 (compared with H >> 5),
                                // .y = thr & (2^26 - 1) (compared with L >> 6 on a tie) — one 8-byte LDS read

@@ -1,4 +1,4 @@
-// envs/tag.hip.h — Tag (gym_pomdp/envs/tag.py): the lane functions the generic kernels of pomdp_kernels.hip call.
+// envs/tag.hip.h — Tag (gym_pomdp/envs/tag.py): the lane functions the generic kernels of step_impl.hip.h / fused_impl.hip.h / planner.hip call.
 // Included by envs.hip.h (which holds the Env interface description and the shared helpers).
 #pragma once
 #include "../envs_common.hip.h"
@@ -10,8 +10,8 @@ struct TagEnv {
     using Reward = float;
     static constexpr int WORDS = 1;
     static constexpr const char *NAME = "TagEnv";
-    static constexpr bool POOLED_LPT2 = true;     // pomdp_kernels.hip: Finisher<TagEnv, 2, .>
-    static constexpr bool QUAD_STEP = false;   // pomdp_kernels.hip: step_quad_kernel
+    static constexpr bool POOLED_LPT2 = true;     // kernels_common.hip.h: Finisher<TagEnv, 2, .>
+    static constexpr bool QUAD_STEP = false;   // step_impl.hip.h: step_quad_kernel
     static constexpr bool HAS_ROCKS = false;   // a bounded History keeps a window of transitions for this env (history_push)
     static constexpr bool POOLED_ANY_LPT = false;
     static constexpr bool QUAD_SENSOR = false;

@@ -1,4 +1,4 @@
-// envs/tiger.hip.h — Tiger (gym_pomdp/envs/tiger.py): the lane functions the generic kernels of pomdp_kernels.hip call.
+// envs/tiger.hip.h — Tiger (gym_pomdp/envs/tiger.py): the lane functions the generic kernels of step_impl.hip.h / fused_impl.hip.h / planner.hip call.
 // Included by envs.hip.h (which holds the Env interface description and the shared helpers).
 #pragma once
 #include "../envs_common.hip.h"
@@ -11,11 +11,11 @@ struct TigerEnv {
     static constexpr int WORDS = 1;
     static constexpr const char *NAME = "TigerEnv";
     static constexpr bool POOLED_LPT2 = false;
-    static constexpr bool QUAD_STEP = false;   // pomdp_kernels.hip: step_quad_kernel
+    static constexpr bool QUAD_STEP = false;   // step_impl.hip.h: step_quad_kernel
     static constexpr bool HAS_ROCKS = false;   // a bounded History keeps a window of transitions for this env (history_push)
     static constexpr bool POOLED_ANY_LPT = false;
     static constexpr bool QUAD_SENSOR = false;
-    static constexpr bool QUAD_FUSED = true;      // pomdp_kernels.hip: steps_quad_generic_kernel
+    static constexpr bool QUAD_FUSED = true;      // fused_impl.hip.h: steps_quad_generic_kernel
     struct Shared { int unused; };
     // w: the tiger's door (what is stored).  rs: registers only — the fresh episode's door when this step ended the
     // episode (see step()), NO_RS otherwise.

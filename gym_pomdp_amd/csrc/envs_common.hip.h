@@ -1,7 +1,7 @@
 // envs_common.hip.h — what the five env headers share (envs.hip.h includes them all).
 // The envs are per-lane transition / observation / reward functions of the five envs,
 // written against the packed int32 lane state documented in include/pomdp_hip.h.
-// Each Env type plugs into the generic kernels in pomdp_kernels.hip:
+// Each Env type plugs into the generic kernels in step_impl.hip.h, fused_impl.hip.h and planner.hip:
 //
 //   Params   plain-C params struct (kernarg, wave-uniform)
 //   Shared   lookup tables staged into LDS once per workgroup

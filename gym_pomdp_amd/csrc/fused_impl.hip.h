@@ -1,0 +1,907 @@
+// fused_impl.hip.h — the fused multi-step kernels (steps_kernel and the quad-per-thread loops of every env family) and
+// launch_steps_fused, which picks among them.  Included by the translation units that instantiate it for their env types
+// (fused_rock.hip, fused_stochrock.hip, fused_tag.hip, fused_battleship.hip, fused_misc.hip).
+#pragma once
+#include "kernels_common.hip.h"
+
+namespace pomdp {
+
+// k consecutive chained steps in ONE launch: exactly the memory state k launches of step_kernel<Env, LPT, true> leave —
+// every step's ob / reward / done / state / next action is computed and written — but a lane's state and action stay in
+// registers from one step to the next (nothing is re-read) and there is one launch ramp per k steps instead of per
+// step.  Possible because a lane's step t+1 depends only on its own step t and all cooperation (pooled Philox passes,
+// cooperative resets) is wave- or workgroup-local: no grid-wide synchronisation is involved.
+// SIMPLE: every thread's lanes exist (n is a multiple of the workgroup's BLOCK * LPT lanes) and done lanes auto-reset, so
+// no lane is ever out of range or frozen, and the actions are the driver's own (always valid): the bookkeeping for those
+// cases is compiled out.
+
+template <class Env, int LPT, bool SIMPLE, bool TAB = false>
+__global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ state, int32_t *__restrict__ action,
+                                                      int32_t *__restrict__ ob, typename Env::Reward *__restrict__ reward,
+                                                      uint8_t *__restrict__ done, uint32_t *__restrict__ err, int64_t n,
+                                                      RngKey key0, uint32_t lane0, int flags, RngKey akey0, int k_steps,
+                                                      int64_t rec, const typename Env::Params p)
+{
+    __shared__ typename Env::Shared sh;
+    __shared__ typename step_tab_of<Env, TAB>::type tab;   // TAB: the lane step reads a (position, action) table built below
+    static_assert(!TAB || SIMPLE, "the table-driven step serves the SIMPLE instantiation");
+    const bool auto_reset = SIMPLE || (flags & POMDP_AUTO_RESET);
+    const uint32_t wg0 = blockIdx.x * (uint32_t)(BLOCK * LPT);
+    const uint32_t last = SIMPLE ? (uint32_t)(BLOCK * LPT - 1) : (uint32_t)((uint64_t)(n - 1) - wg0);
+    // rec = 0: every step overwrites the same n-element outputs (what the per-step launches do); rec = row pitch in
+    // elements: step s writes row s of ob / reward / done and row s + 1 of action (row s being the actions it took)
+    int32_t *action_w = action + wg0;
+    uint32_t *const state_w = state + wg0;
+    int32_t *ob_w = ob + wg0;
+    typename Env::Reward *reward_w = reward + wg0;
+    uint8_t *done_w = done + wg0;
+    uint32_t rel[LPT], glane[LPT];
+    bool in_range[LPT], was_done[LPT], ever_fresh[LPT];
+    int a_cur[LPT];
+    typename Env::State st[LPT];
+#pragma unroll
+    for (int j = 0; j < LPT; ++j) {
+        rel[j] = threadIdx.x + (uint32_t)(j * BLOCK);
+        glane[j] = lane0 + wg0 + rel[j];
+        ever_fresh[j] = false;
+        in_range[j] = SIMPLE || rel[j] <= last;
+        const uint32_t rc = in_range[j] ? rel[j] : last;
+        __builtin_assume(rc < (uint32_t)(BLOCK * LPT));
+        a_cur[j] = (flags & FLAG_GEN_FIRST) ? 0 : ld_stream(action_w + rc);
+        Env::load(st[j], state_w, n, rc);
+        if constexpr (has_next<Env>::value) Env::load_next(st[j], state_w, n, rc);   // once per launch, with the other words
+        was_done[j] = auto_reset ? false : (ld_stream(done_w + rc) != 0);
+    }
+    using Fin = Finisher<Env, LPT, true>;
+    constexpr bool quad_policy = quad_policy_of<Fin>::value;
+    uint4 aq = make_uint4(0, 0, 0, 0), sq = make_uint4(0, 0, 0, 0), rq = make_uint4(0, 0, 0, 0);
+    const int n_act = Env::n_actions(p);
+    const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo, ta0 = ((uint64_t)akey0.t_hi << 32) | akey0.t_lo;
+    if (flags & FLAG_GEN_FIRST) {                        // wave-uniform: the policy's actions of the first call counter
+        RngKey fkey = akey0;
+        fkey.t_lo = (uint32_t)(ta0 - 1ull); fkey.t_hi = (uint32_t)((ta0 - 1ull) >> 32);
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) {
+            a_cur[j] = synthetic_action(fkey, glane[j], (uint32_t)n_act);
+            if (in_range[j]) st_stream(action_w + rel[j], (int32_t)a_cur[j]);
+        }
+    }
+    action_w += rec;
+    // Tables once, BEFORE the loop; the first pre-pass rides under the load latency.  The staging reads the kernarg-resident
+    // tables with vector loads, and a loop that contains any load keeps the compiler from settling the loads above in the
+    // loop's pre-header: it then waits on vmcnt(0) in EVERY iteration for a register that arrived long ago — and stores
+    // count on that counter too (gfx9), so every step waited for the acknowledgement of the previous step's stores
+    // (round 3: 0.70 -> 0.45 us per step of a lone wave).  The loop below has no load.
+    if constexpr (Fin::HAS_PREPASS) {
+        const auto staged = Env::stage_load(p, (int)threadIdx.x);
+        Fin::prepass(key0, glane, akey0);
+        Env::stage_store(sh, staged, (int)threadIdx.x);
+    } else {
+        Env::stage(sh, p, (int)threadIdx.x);
+    }
+    __syncthreads();
+    if constexpr (TAB) {                                 // BLOCK threads = the 256 position bytes
+        Env::build_tab(tab, sh, p, (int)threadIdx.x);
+        __syncthreads();
+    }
+    for (int s = 0; s < k_steps; ++s) {
+        RngKey key = key0, akey = akey0;
+        key.t_lo = (uint32_t)(t0 + (uint64_t)s); key.t_hi = (uint32_t)((t0 + (uint64_t)s) >> 32);
+        akey.t_lo = (uint32_t)(ta0 + (uint64_t)s); akey.t_hi = (uint32_t)((ta0 + (uint64_t)s) >> 32);
+        if constexpr (Fin::HAS_PREPASS) { if (s > 0) Fin::prepass(key, glane, akey); }
+        int o[LPT], d[LPT];
+        typename Env::Reward r[LPT];
+        typename Fin::Aux aux[LPT];
+        bool live[LPT], valid[LPT], fresh[LPT];
+        int a_next[LPT];
+        typename Env::State before[LPT];
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) {
+            before[j] = st[j];
+            valid[j] = SIMPLE || (unsigned)a_cur[j] < (unsigned)n_act;
+            live[j] = SIMPLE || (in_range[j] && valid[j] && !was_done[j]);
+            if constexpr (quad_policy && Env::QUAD_SENSOR) {
+                // one lane per thread, the sensor block shared by the quad (RockSample shards below the pooled kernels' gates):
+                // lane e computes the block of step s + e once per four steps and the words reach their lanes by the same
+                // transpose as the policy's — one Philox block per lane per four steps instead of one per step
+                if ((s & 3) == 0) {
+                    const uint64_t te = t0 + (uint64_t)s + (uint64_t)(glane[0] & 3u);
+                    RngKey ke = key0;
+                    ke.t_lo = (uint32_t)te; ke.t_hi = (uint32_t)(te >> 32);
+                    sq = quad_transpose4(Env::quad_block(ke, glane[0], 0u), glane[0] & 3u);
+                    rq = quad_transpose4(Env::reset_block(ke, glane[0], 0u), glane[0] & 3u);   // the quad's RESET words likewise
+                }
+                const int sj = s & 3;                                            // wave-uniform selects
+                const uint32_t H = sj == 0 ? sq.x : sj == 1 ? sq.y : sj == 2 ? sq.z : sq.w;
+                if constexpr (TAB) Env::step_with_H_tab(sh, tab, st[j], a_cur[j], key, glane[j], H, o[j], r[j], d[j]);
+                else Env::step_with_H(sh, p, st[j], valid[j] ? a_cur[j] : 0, key, glane[j], H, o[j], r[j], d[j]);
+            }
+            else if constexpr (TAB) Fin::lane_step_tab(tab, st[j], a_cur[j], o[j], r[j], d[j], aux[j]);
+            else Fin::lane_step(sh, p, st[j], valid[j] ? a_cur[j] : 0, key, glane[j], o[j], r[j], d[j], aux[j]);
+            if (!live[j]) { r[j] = 0; d[j] = was_done[j]; }
+            fresh[j] = live[j] && d[j] && auto_reset;
+            a_next[j] = 0;
+        }
+        if constexpr (quad_policy) {
+            const uint32_t e = glane[0] & 3u;
+            if ((s & 3) == 0) {                                              // this lane's block: the policy of step s + e ...
+                const uint64_t te = ta0 + (uint64_t)s + (uint64_t)e;
+                // ... transposed within the quad: component J is then THIS lane's word of step s + J
+                aq = quad_transpose4(philox4x32_10(glane[0] >> 2, (uint32_t)te, (uint32_t)(te >> 32),
+                                                   (uint32_t)POMDP_STREAM_ACTION << 24, akey0.k0, akey0.k1), e);
+            }
+            const int sj = s & 3;                                            // wave-uniform selects
+            if constexpr (Env::QUAD_SENSOR) {                                // RockSample: this lane's RESET word of step s
+                const uint32_t rword = sj == 0 ? rq.x : sj == 1 ? rq.y : sj == 2 ? rq.z : rq.w;
+                st[0].s = fresh[0] ? Env::fresh_state(p, rword, key, glane[0]) : st[0].s;
+            } else {
+                Fin::resets_only(sh, p, st, fresh, key, glane);
+            }
+            const uint32_t word = sj == 0 ? aq.x : sj == 1 ? aq.y : sj == 2 ? aq.z : aq.w;
+            a_next[0] = (int)__umulhi(word, (uint32_t)n_act);
+        } else {
+            Fin::run(sh, p, st, fresh, key, glane, akey, (uint32_t)n_act, a_next, aux, o);
+        }
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) {
+            if (!live[j]) { o[j] = 0; st[j] = before[j]; }                  // a lane that did not step keeps its state
+            if (in_range[j]) st_stream(action_w + rel[j], (int32_t)a_next[j]);
+            ever_fresh[j] |= fresh[j];
+            if (in_range[j]) {
+                st_stream(ob_w + rel[j], (int32_t)o[j]);
+                st_stream(reward_w + rel[j], r[j]);
+                st_stream(done_w + rel[j], (uint8_t)d[j]);
+                if (!valid[j] && !was_done[j] && err) atomicAdd(err, 1u);
+            }
+            a_cur[j] = a_next[j];
+            was_done[j] = auto_reset ? false : (d[j] != 0);
+        }
+        action_w += rec; ob_w += rec; reward_w += rec; done_w += rec;
+        if constexpr (Fin::LOOP_BARRIER && !quad_policy) __syncthreads();
+    }
+    // the state is the loop's carry: it lived in registers and reaches memory once (a lane that never stepped writes back
+    // what it read; BattleShip's ship words only if some step of the launch dealt a new board)
+#pragma unroll
+    for (int j = 0; j < LPT; ++j)
+        if (in_range[j]) Env::store(st[j], state_w, n, rel[j], ever_fresh[j]);
+}
+
+// The fused RockSample loop with a thread owning four CONSECUTIVE lanes — a quad.  RockSample's word contract shares the
+// STEP block, the RESET block and the policy's ACTION block among the four lanes of a quad, so with this mapping all
+// three are the thread's own: three Philox blocks per thread-step straight into registers, lane j taking element j — no
+// exchange through LDS, no ballots, no task lists, and no dependence on the lane step: the compiler interleaves the three
+// chains with the table lookups.  A thread's outputs are four consecutive elements of each column: one 16-byte store per
+// int32 column and one 4-byte store of the packed done bytes per step instead of twenty scalar stores; state and first
+// actions come in the same way.  The lane step is the table-driven one.  Full workgroups of 1024 lanes and auto-reset
+// only (the launcher's SIMPLE conditions).  Same results as steps_kernel: the mapping of lanes to threads is invisible
+// to a lane's random words.
+template <class Env>
+__global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict__ state, int32_t *__restrict__ action,
+                                                           int32_t *__restrict__ ob, int32_t *__restrict__ reward,
+                                                           uint8_t *__restrict__ done, int64_t n, RngKey key0, uint32_t lane0,
+                                                           RngKey akey0, int k_steps, int64_t rec, int gen_first,
+                                                           const typename Env::Params p)
+{
+    constexpr int W = Env::WORDS;
+    using S = typename Env::S;
+    __shared__ typename Env::Shared sh;
+    __shared__ typename Env::StepTab tab;
+    const uint32_t l0 = blockIdx.x * (uint32_t)(4 * BLOCK) + 4u * threadIdx.x;   // this thread's first lane within the shard
+    const uint32_t glane0 = lane0 + l0;                                          // ... and its global lane id (a multiple of 4)
+    uint32_t *action_w = reinterpret_cast<uint32_t *>(action) + l0, *ob_w = reinterpret_cast<uint32_t *>(ob) + l0;
+    uint32_t *reward_w = reinterpret_cast<uint32_t *>(reward) + l0;
+    uint32_t *done_w = reinterpret_cast<uint32_t *>(done + l0);
+    typename Env::State st[4];
+    int a_cur[4];
+    const uint32_t n_act = (uint32_t)Env::n_actions(p);
+    {
+        const u32x4 s_lo = ld_stream4(state + l0);
+        u32x4 s_hi = {0, 0, 0, 0};
+        if (W == 2) s_hi = ld_stream4(state + n + l0);
+        const u32x4 a4 = first_actions4(action_w, gen_first, glane0, akey0, n_act);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a_cur[j] = (int)a4[j];
+            st[j].s = (S)((uint64_t)s_lo[j] | ((uint64_t)s_hi[j] << 32));
+        }
+    }
+    action_w += rec;
+    Env::stage(sh, p, (int)threadIdx.x);
+    __syncthreads();
+    Env::build_tab(tab, sh, p, (int)threadIdx.x);
+    __syncthreads();
+    const int K = p.num_rocks;
+    const uint32_t start = (uint32_t)p.start_x | ((uint32_t)p.start_y << 4);
+    const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo, ta0 = ((uint64_t)akey0.t_hi << 32) | akey0.t_lo;
+    for (int s = 0; s < k_steps; ++s) {
+        RngKey key = key0;
+        key.t_lo = (uint32_t)(t0 + (uint64_t)s); key.t_hi = (uint32_t)((t0 + (uint64_t)s) >> 32);
+        const uint64_t ta = ta0 + (uint64_t)s;
+        // the quad's sensor words of this step (StochasticRock: block 2 of the stream — block 0 gates the actions, rock.py:443),
+        // the words its fresh episodes start from, and its policy words of the next call counter
+        constexpr uint32_t SENSOR_BLOCK = Env::STOCHASTIC ? 2u : 0u;
+        const uint4 sw = philox4x32_10(glane0 >> 2, key.t_lo, key.t_hi, ((uint32_t)POMDP_STREAM_STEP << 24) | SENSOR_BLOCK, key.k0, key.k1);
+        const uint4 rw = Env::reset_block(key, glane0, 0u);
+        const uint4 pw = philox4x32_10(glane0 >> 2, (uint32_t)ta, (uint32_t)(ta >> 32), (uint32_t)POMDP_STREAM_ACTION << 24, key.k0, key.k1);
+        const uint32_t H[4] = {sw.x, sw.y, sw.z, sw.w}, P[4] = {pw.x, pw.y, pw.z, pw.w}, R[4] = {rw.x, rw.y, rw.z, rw.w};
+        bool acts[4] = {true, true, true, true};
+        if constexpr (Env::STOCHASTIC) {                                       // the action is applied iff binomial(1, p_move) says so
+            const uint4 gw = Env::quad_block(key, glane0, 0u);
+            const uint32_t G[4] = {gw.x, gw.y, gw.z, gw.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acts[j] = Env::k53_le(G[j], (uint32_t)(p.act_thr >> 26), (uint32_t)p.act_thr & Env::LO_MASK,
+                                      [&]() { return Env::elem(Env::quad_block(key, glane0, 1u), (uint32_t)j); });
+        }
+        int r[4], d[4];
+        uint32_t o[4], a_next[4], codes[4];
+        Env::reset_codes4(R, key, glane0, K, codes);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            typename Env::Aux aux;
+            if constexpr (Env::STOCHASTIC) {
+                typename Env::State nx = st[j];
+                Env::step_tab(tab, nx, a_cur[j], r[j], d[j], aux);
+                if (acts[j]) st[j] = nx; else { r[j] = 0; d[j] = 0; aux.want = false; }
+            } else {
+                Env::step_tab(tab, st[j], a_cur[j], r[j], d[j], aux);
+            }
+            const uint32_t lane = glane0 + (uint32_t)j;
+            st[j].s = d[j] ? (S)((uint64_t)start | ((uint64_t)codes[j] << 8)) : st[j].s;   // done lanes start a new episode
+            o[j] = (uint32_t)Env::sensor_ob(sh, st[j], aux, H[j], [&]() { return Env::elem(Env::quad_block(key, lane, SENSOR_BLOCK + 1u), (uint32_t)j); });
+            a_next[j] = __umulhi(P[j], n_act);
+            a_cur[j] = (int)a_next[j];
+        }
+        st_stream4(action_w, a_next[0], a_next[1], a_next[2], a_next[3]);
+        st_stream4(ob_w, o[0], o[1], o[2], o[3]);
+        st_stream4(reward_w, (uint32_t)r[0], (uint32_t)r[1], (uint32_t)r[2], (uint32_t)r[3]);
+        st_stream(done_w, (uint32_t)d[0] | ((uint32_t)d[1] << 8) | ((uint32_t)d[2] << 16) | ((uint32_t)d[3] << 24));
+        action_w += rec; ob_w += rec; reward_w += rec; done_w += rec / 4;
+    }
+    // the state is the loop's carry: it reaches memory once
+    st_stream4(state + l0, (uint32_t)st[0].s, (uint32_t)st[1].s, (uint32_t)st[2].s, (uint32_t)st[3].s);
+    if (W == 2)
+        st_stream4(state + n + l0, (uint32_t)((uint64_t)st[0].s >> 32), (uint32_t)((uint64_t)st[1].s >> 32),
+                   (uint32_t)((uint64_t)st[2].s >> 32), (uint32_t)((uint64_t)st[3].s >> 32));
+}
+
+// Tag (one opponent) with a quad per thread: the policy's ACTION block is the thread's own, the flights of failed TAGs
+// (about a fifth of the lanes) and the rare resets are pooled per wave of 256 lanes — one Philox pass instead of the two per
+// 256 lanes that Finisher<TagEnv, 2> needs with the policy blocks in its task list — and the outputs leave as 16-byte stores.
+template <bool TAB>   // TAB: the lane step reads the (cells, action) table built when the launch starts (from 16 steps per launch)
+__global__ __launch_bounds__(BLOCK) void tag_steps_quad_kernel(uint32_t *__restrict__ state, int32_t *__restrict__ action,
+                                                               int32_t *__restrict__ ob, float *__restrict__ reward,
+                                                               uint8_t *__restrict__ done, int64_t n, RngKey key0,
+                                                               uint32_t lane0, RngKey akey0, int k_steps, int64_t rec,
+                                                               int gen_first, const TagEnv::Params p)
+{
+    using Env = TagEnv;
+    __shared__ Env::Shared sh;
+    __shared__ typename std::conditional<TAB, Env::StepTab, NoTab>::type tab;
+    __shared__ uint8_t src_lds[BLOCK / 64][256];             // task rank -> lane within the wave's 256
+    __shared__ uint32_t res_lds[BLOCK / 64][256][4];         // task rank -> its Philox block
+    const int wv = (int)(threadIdx.x >> 6), me = (int)(threadIdx.x & 63u);
+    const uint32_t l0 = blockIdx.x * (uint32_t)(4 * BLOCK) + 4u * threadIdx.x;
+    const uint32_t glane0 = lane0 + l0, wave0 = glane0 - 4u * (uint32_t)me;
+    uint32_t *action_w = reinterpret_cast<uint32_t *>(action) + l0, *ob_w = reinterpret_cast<uint32_t *>(ob) + l0;
+    uint32_t *reward_w = reinterpret_cast<uint32_t *>(reward) + l0;
+    uint32_t *done_w = reinterpret_cast<uint32_t *>(done + l0);
+    Env::State st[4];
+    int a_cur[4];
+    const uint32_t n_act = (uint32_t)Env::n_actions(p);
+    {
+        const u32x4 s4 = ld_stream4(state + l0);
+        const u32x4 a4 = first_actions4(action_w, gen_first, glane0, akey0, n_act);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a_cur[j] = (int)a4[j]; st[j].w = s4[j]; }
+    }
+    action_w += rec;
+    Env::stage(sh, p, (int)threadIdx.x);
+    __syncthreads();
+    if constexpr (TAB) {
+        Env::build_tab(tab, sh, p, (int)threadIdx.x);
+        __syncthreads();
+    }
+    const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo, ta0 = ((uint64_t)akey0.t_hi << 32) | akey0.t_lo;
+    for (int s = 0; s < k_steps; ++s) {
+        RngKey key = key0;
+        key.t_lo = (uint32_t)(t0 + (uint64_t)s); key.t_hi = (uint32_t)((t0 + (uint64_t)s) >> 32);
+        const uint64_t ta = ta0 + (uint64_t)s;
+        const uint4 pw = philox4x32_10(glane0 >> 2, (uint32_t)ta, (uint32_t)(ta >> 32), (uint32_t)POMDP_STREAM_ACTION << 24, key.k0, key.k1);
+        const uint32_t P[4] = {pw.x, pw.y, pw.z, pw.w};
+        int o[4], d[4];
+        float r[4];
+        Env::Flight f[4];
+        uint64_t fm[4], rm[4];
+        int nfl = 0, nrs = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if constexpr (TAB) Env::step_one_opponent_tab(tab, st[j], a_cur[j], o[j], r[j], d[j], f[j]);
+            else Env::step_one_opponent_pre(sh, p, st[j], a_cur[j], o[j], r[j], d[j], f[j]);
+            fm[j] = __ballot(f[j].need);
+            rm[j] = __ballot(d[j] != 0);
+            nfl += __popcll(fm[j]);
+            nrs += __popcll(rm[j]);
+        }
+        // task list: the flights, then the resets (a lane is never both: a failed TAG does not end the episode)
+        auto below = [&](uint64_t m) {
+            return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        };
+        int rank[4], cf = 0, cr = nfl;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            rank[j] = f[j].need ? cf + below(fm[j]) : cr + below(rm[j]);
+            cf += __popcll(fm[j]);
+            cr += __popcll(rm[j]);
+            if (f[j].need || d[j]) src_lds[wv][rank[j] & 255] = (uint8_t)(4 * me + j);
+        }
+        const int ntask = nfl + nrs;
+        for (int base = 0; base < ntask; base += 64) {
+            const int q = base + me;
+            if (q < ntask) {
+                const uint32_t src_lane = wave0 + (uint32_t)src_lds[wv][q & 255];
+                const uint32_t strm = q < nfl ? POMDP_STREAM_STEP : POMDP_STREAM_RESET;
+                const uint4 w = philox4x32_10(src_lane, key.t_lo, key.t_hi, strm << 24, key.k0, key.k1);
+                uint32_t *dst = res_lds[wv][q & 255];
+                dst[0] = w.x; dst[1] = w.y; dst[2] = w.z; dst[3] = w.w;
+            }
+        }
+        uint32_t a_next[4];
+        uint4 rb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                                          // all four blocks in flight, one wait; used by the lanes with a task
+            const uint32_t *res = res_lds[wv][rank[j] & 255];
+            rb[j] = make_uint4(res[0], res[1], res[2], res[3]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (f[j].need) Env::flee(sh, p, st[j], f[j], rb[j].x, rb[j].y, rb[j].z);
+            if (d[j]) {
+                if (!Env::reset_from_block(p, st[j], rb[j])) Env::reset(sh, p, st[j], key, glane0 + (uint32_t)j);   // rejections ran past the block
+            }
+            a_next[j] = __umulhi(P[j], n_act);
+            a_cur[j] = (int)a_next[j];
+        }
+        st_stream4(action_w, a_next[0], a_next[1], a_next[2], a_next[3]);
+        st_stream4(ob_w, (uint32_t)o[0], (uint32_t)o[1], (uint32_t)o[2], (uint32_t)o[3]);
+        st_stream4(reward_w, __float_as_uint(r[0]), __float_as_uint(r[1]), __float_as_uint(r[2]), __float_as_uint(r[3]));
+        st_stream(done_w, (uint32_t)d[0] | ((uint32_t)d[1] << 8) | ((uint32_t)d[2] << 16) | ((uint32_t)d[3] << 24));
+        action_w += rec; ob_w += rec; reward_w += rec; done_w += rec / 4;
+    }
+    st_stream4(state + l0, st[0].w, st[1].w, st[2].w, st[3].w);
+}
+
+// Network with a quad per thread.  The reference draws one double per UP machine and one for the action (network.py:94-109),
+// from the lane's own stream, four high words per Philox block (split layout).  Under a random policy a lane
+// has 1.4 machines up on average (12 % of the lanes have three or more, 2 % four or more), so almost every lane-step is
+// served by the FIRST block of its stream: each of the thread's four lanes computes that block and applies its first two
+// words to its first two up machines straight-line (NetworkEnv::draws), the action's draw being the word after the last
+// machine — no loop to the wave's largest draw count, which is what steps_kernel<NetworkEnv> pays for every lane.  Lanes
+// with more draws to make (a third machine, or the action's draw behind three) hand (machines left, failed-neighbour set,
+// the block's other two words) to a per-wave task list; one pooled pass per 64 such lanes continues their streams — the
+// two words, then block by block — and returns the machines that fail and the action's draw.  The policy's ACTION block
+// is the thread's own, the outputs leave as 16-byte stores, the reward comes from a table of the float32(float64) values
+// the reference's arithmetic gives.  A draw decided by its low word (2^-27 per draw) sends the lane through
+// NetworkEnv::step_exact, the exact per-lane form.  Network never terminates, so there is no reset.
+template <int NB>   // bytes of the machine set: ceil(n_machines / 8)
+__global__ __launch_bounds__(BLOCK) void network_steps_quad_kernel(uint32_t *__restrict__ state, int32_t *__restrict__ action,
+                                                                   int32_t *__restrict__ ob, float *__restrict__ reward,
+                                                                   uint8_t *__restrict__ done, int64_t n, RngKey key0,
+                                                                   uint32_t lane0, RngKey akey0, int k_steps, int64_t rec,
+                                                                   int gen_first, const NetworkEnv::Params p)
+{
+    using Env = NetworkEnv;
+    __shared__ Env::Shared sh;                               // the nibble tables of the exact per-lane form (ties only)
+    __shared__ uint32_t nbf8[NB][256];                       // nbf8[k][v]: machines that see a failed neighbour when the down
+                                                             // machines among 8 k .. 8 k + 7 are the set v (network.py:82-85)
+    __shared__ float rtab[3][68];                            // reward by (no action / ping / reboot, 2 per up machine with > 2
+                                                             // neighbours + 1 per other up machine): network.py:87-92, 103, 110
+    __shared__ uint32_t task_lds[BLOCK / 64][256][6];        // task rank -> {lane within the wave's 256 | has_action << 8, machines
+                                                             // left, failed-neighbour set, words 2 and 3 of the lane's first
+                                                             // block}; overwritten with {machines that fail, flags}
+    const int wv = (int)(threadIdx.x >> 6), me = (int)(threadIdx.x & 63u);
+    const uint32_t l0 = blockIdx.x * (uint32_t)(4 * BLOCK) + 4u * threadIdx.x;
+    const uint32_t glane0 = lane0 + l0, wave0 = glane0 - 4u * (uint32_t)me;
+    uint32_t *action_w = reinterpret_cast<uint32_t *>(action) + l0, *ob_w = reinterpret_cast<uint32_t *>(ob) + l0;
+    uint32_t *reward_w = reinterpret_cast<uint32_t *>(reward) + l0;
+    uint32_t *done_w = reinterpret_cast<uint32_t *>(done + l0);
+    const uint32_t n_act = (uint32_t)Env::n_actions(p);
+    uint32_t st[4];
+    int a_cur[4];
+    {
+        const u32x4 s4 = ld_stream4(state + l0);
+        const u32x4 a4 = first_actions4(action_w, gen_first, glane0, akey0, n_act);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a_cur[j] = (int)a4[j]; st[j] = s4[j]; }
+    }
+    action_w += rec;
+    Env::stage(sh, p, (int)threadIdx.x);
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb) {                        // BLOCK threads = the 256 values of a byte
+        uint32_t m = 0;
+        for (int i = 0; i < p.n_machines; ++i) m |= (((p.nb_mask[i] >> (8 * kb)) & threadIdx.x) != 0u ? 1u : 0u) << i;
+        nbf8[kb][threadIdx.x] = m;
+    }
+    if (threadIdx.x < 3 * 68) {                              // r = float32(float64(base) - cost), as the reference computes it
+        const int kind = (int)threadIdx.x / 68, b = (int)threadIdx.x % 68;
+        double r = (double)b;
+        if (kind == 1) r -= .1;
+        if (kind == 2) r -= 2.5;
+        rtab[kind][b] = (float)r;
+    }
+    __syncthreads();
+    const Env::Thr T = Env::thresholds(p);
+    const uint32_t all_up = p.n_machines >= 32 ? 0xFFFFFFFFu : ((1u << p.n_machines) - 1u);
+    const int M2 = 2 * p.n_machines;
+    const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo, ta0 = ((uint64_t)akey0.t_hi << 32) | akey0.t_lo;
+    for (int s = 0; s < k_steps; ++s) {
+        RngKey key = key0;
+        key.t_lo = (uint32_t)(t0 + (uint64_t)s); key.t_hi = (uint32_t)((t0 + (uint64_t)s) >> 32);
+        const uint64_t ta = ta0 + (uint64_t)s;
+        const uint4 pw = philox4x32_10(glane0 >> 2, (uint32_t)ta, (uint32_t)(ta >> 32), (uint32_t)POMDP_STREAM_ACTION << 24, key.k0, key.k1);
+        const uint32_t P[4] = {pw.x, pw.y, pw.z, pw.w};
+        uint32_t kill[4], todo[4], nbf[4], near[4], hz[4], hw[4];
+        int base[4];
+        bool truthful[4], more[4], act_pending[4];
+        uint64_t mm[4];
+        int ntask = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t s0 = st[j];
+            const uint4 h = stream_block(key, glane0 + (uint32_t)j, POMDP_STREAM_STEP, 0u);
+            const int n_up = __popc(s0);
+            base[j] = n_up + __popc(s0 & p.deg_gt2_mask);                      // network.py:87-92
+            {
+                const uint32_t down = ~s0 & all_up;
+                uint32_t f = nbf8[0][down & 255u];
+#pragma unroll
+                for (int kb = 1; kb < NB; ++kb) f |= nbf8[kb][(down >> (8 * kb)) & 255u];
+                nbf[j] = f;
+            }
+            todo[j] = s0;
+            near[j] = 0xFFFFFFFFu;
+            const uint32_t H2[2] = {h.x, h.y};
+            kill[j] = Env::draws<2>(H2, todo[j], nbf[j], T, near[j]);
+            hz[j] = h.z; hw[j] = h.w;
+            const bool has_action = a_cur[j] < M2;
+            uint32_t aw = n_up == 1 ? h.y : h.x;                                // word n_up of the block (n_up < 3), as selects
+            aw = n_up >= 2 ? h.z : aw;
+            uint32_t near_a = 0xFFFFFFFFu;
+            const bool tr = Env::truthful_of(aw, T, near_a);
+            const bool here = has_action && n_up < 3;                           // the action's draw is one of these three words
+            truthful[j] = here && tr;
+            near[j] = min(near[j], here ? near_a : 0xFFFFFFFFu);
+            act_pending[j] = has_action && !here;
+            more[j] = todo[j] != 0u || act_pending[j];
+            mm[j] = __ballot(more[j]);
+            ntask += __popcll(mm[j]);
+        }
+        if (ntask) {                                                           // wave-uniform
+            int rank[4], c = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                rank[j] = c + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm[j], 0u));
+                c += __popcll(mm[j]);
+                if (more[j]) {
+                    uint32_t *t = task_lds[wv][rank[j] & 255];
+                    t[0] = (uint32_t)(4 * me + j) | ((uint32_t)act_pending[j] << 8); t[1] = todo[j]; t[2] = nbf[j];
+                    t[3] = hz[j]; t[4] = hw[j];
+                }
+            }
+            for (int b0 = 0; b0 < ntask; b0 += 64) {
+                const int q = b0 + me;
+                if (q < ntask) {
+                    uint32_t *t = task_lds[wv][q & 255];
+                    const uint32_t w0 = t[0], src_lane = wave0 + (w0 & 255u), nb = t[2];
+                    uint32_t td = t[1], nr = 0xFFFFFFFFu;
+                    bool pend = (w0 >> 8) & 1u, tr = false;
+                    // words 2 and 3 of the first block, then the stream's following blocks
+                    const uint32_t H2[2] = {t[3], t[4]};
+                    int left = __popc(td);
+                    uint32_t kl = Env::draws<2>(H2, td, nb, T, nr);
+                    if (pend && left < 2) { tr = Env::truthful_of(left == 0 ? H2[0] : H2[1], T, nr); pend = false; }
+                    for (uint32_t blk = 1; td != 0u || pend; ++blk) {
+                        const uint4 h = stream_block(key, src_lane, POMDP_STREAM_STEP, 2u * blk);
+                        left = __popc(td);
+                        kl |= Env::draw4(h, td, nb, T, nr);
+                        if (pend && left < 4) {
+                            uint32_t w = left == 1 ? h.y : h.x;
+                            w = left == 2 ? h.z : w;
+                            w = left == 3 ? h.w : w;
+                            tr = Env::truthful_of(w, T, nr);
+                            pend = false;
+                        }
+                    }
+                    t[0] = kl; t[1] = (uint32_t)tr | (nr < 32u ? 2u : 0u);
+                }
+            }
+            uint32_t tk[4], tf[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                                      // all four reads in flight, one wait; used where more[j]
+                const uint32_t *t = task_lds[wv][rank[j] & 255];
+                tk[j] = t[0]; tf[j] = t[1];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                kill[j] |= more[j] ? tk[j] : 0u;
+                truthful[j] = (more[j] && act_pending[j]) ? (tf[j] & 1u) != 0u : truthful[j];
+                near[j] = (more[j] && (tf[j] & 2u)) ? 0u : near[j];
+            }
+        }
+        uint32_t o4[4], r4[4], a_next[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int o;
+            float r;
+            if (near[j] < 32u) {                                               // a draw decided by its low word: the exact per-lane form
+                Env::State e{st[j]};
+                int d;
+                Env::step_exact(sh, p, e, a_cur[j], key, glane0 + (uint32_t)j, o, r, d);
+                st[j] = e.w;
+            } else {                                                           // network.py:101-112
+                const int a = a_cur[j], machine = (a >> 1) & 31;
+                const bool has_action = a < M2, reboot = has_action && (a & 1);
+                uint32_t sn = st[j] & ~kill[j];
+                sn |= reboot ? 1u << machine : 0u;
+                const int up = (int)((sn >> machine) & 1u);                    // a rebooted machine is up: ob = truthful either way
+                o = has_action ? (truthful[j] ? up : 1 - up) : 2;
+                r = rtab[has_action ? 1 + (a & 1) : 0][base[j]];
+                st[j] = sn;
+            }
+            o4[j] = (uint32_t)o;
+            r4[j] = __float_as_uint(r);
+            a_next[j] = __umulhi(P[j], n_act);
+            a_cur[j] = (int)a_next[j];
+        }
+        st_stream4(action_w, a_next[0], a_next[1], a_next[2], a_next[3]);
+        st_stream4(ob_w, o4[0], o4[1], o4[2], o4[3]);
+        st_stream4(reward_w, r4[0], r4[1], r4[2], r4[3]);
+        st_stream(done_w, 0u);                                                 // network.py:113: never done
+        action_w += rec; ob_w += rec; reward_w += rec; done_w += rec / 4;
+    }
+    st_stream4(state + l0, st[0], st[1], st[2], st[3]);
+}
+
+// BattleShip with a quad per thread.  A board is a long sequential rejection loop (battleship.py:167-180: about 23 words of a
+// lane's stream on 10x10, 42 on 5x5) that one lane in ~285 needs per step; built when it comes up — by the whole wave, one
+// lane at a time (BattleShipEnv::reset_where) — it is two thirds of all instructions steps_kernel<BattleShipEnv> issues.
+// Under the board contract (include/pomdp_hip.h) a lane carries the board of its NEXT episode, drawn from
+// stream NEXT at the call counter at which its current board was dealt; so inside the loop the end of an episode is a
+// handful of selects (the cached board moves in, the lane remembers the step), and the boards the wave's lanes used up
+// are built AFTER the loop, dealt out one per thread and 64 side by side (board_lockstep).  A lane that finishes a second
+// episode before its next board exists triggers that pass early, for every lane of the wave that is waiting.  The state
+// that reaches memory is the same whichever kernel ran: current board, visited mask, next board.
+template <int MW>
+__global__ __launch_bounds__(BLOCK) void battleship_steps_quad_kernel(uint32_t *__restrict__ state, int32_t *__restrict__ action,
+                                                                      int32_t *__restrict__ ob, int32_t *__restrict__ reward,
+                                                                      uint8_t *__restrict__ done, int64_t n, RngKey key0,
+                                                                      uint32_t lane0, RngKey akey0, int k_steps, int64_t rec,
+                                                                      int gen_first, const pomdp_battleship_params p)
+{
+    using Env = BattleShipEnv<MW>;
+    using Mask = typename Env::Mask;
+    // The two masks a step only READS — the ships of this episode and of the next — live in LDS, [word][lane of the quad]
+    // [thread] (conflict-free: a wave reads one word of lane j of each of its threads); the visited mask, which every step
+    // updates, stays in registers.  A shot tests ONE word of the ship mask (an LDS read issued when the step begins), and
+    // with eight mask words per lane out of the register file the 10x10 kernel fits four waves per SIMD.
+    __shared__ uint32_t occ_lds[MW][4][BLOCK], next_lds[MW][4][BLOCK];
+    __shared__ uint8_t task_lds[BLOCK / 64][256];            // task rank -> lane within the wave's 256
+    __shared__ uint8_t ts_lds[BLOCK / 64][256];              // ... and the step at which that lane's current board was dealt
+    __shared__ typename Env::SeqTables seq;                  // the column patterns of the board builder
+    Env::stage_seq(seq, p, (int)threadIdx.x);
+    const int wv = (int)(threadIdx.x >> 6), me = (int)(threadIdx.x & 63u), tid = (int)threadIdx.x;
+    const uint32_t l0 = blockIdx.x * (uint32_t)(4 * BLOCK) + 4u * threadIdx.x;
+    const uint32_t glane0 = lane0 + l0, wave0 = glane0 - 4u * (uint32_t)me;
+    uint32_t *action_w = reinterpret_cast<uint32_t *>(action) + l0, *ob_w = reinterpret_cast<uint32_t *>(ob) + l0;
+    uint32_t *reward_w = reinterpret_cast<uint32_t *>(reward) + l0;
+    uint32_t *done_w = reinterpret_cast<uint32_t *>(done + l0);
+    const uint32_t n_act = (uint32_t)Env::n_actions(p);
+    Mask vis[4];
+    int a_cur[4];
+    {
+        u32x4 w[3 * MW];
+#pragma unroll
+        for (int q = 0; q < 3 * MW; ++q) w[q] = ld_stream4(state + (int64_t)q * n + l0);
+        const u32x4 a4 = first_actions4(action_w, gen_first, glane0, akey0, n_act);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a_cur[j] = (int)a4[j];
+            vis[j].lo = vis[j].hi = 0;
+#pragma unroll
+            for (int q = 0; q < MW; ++q) { occ_lds[q][j][tid] = w[q][j]; vis[j].set_word(q, w[MW + q][j]); next_lds[q][j][tid] = w[2 * MW + q][j]; }
+        }
+    }
+    action_w += rec;
+    __syncthreads();
+    const int cells = p.x_size * p.y_size;
+    const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo, ta0 = ((uint64_t)akey0.t_hi << 32) | akey0.t_lo;
+    int pend[4] = {-1, -1, -1, -1};                          // >= 0: the step at which the lane's board was dealt; its `next` is yet to be built
+    // the boards of every waiting lane of the wave (wave-uniform control flow; the scratch and the mask slots are the wave's own)
+    auto build_boards = [&]() {
+        int ntask = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint64_t m = __ballot(pend[j] >= 0);
+            const int rank = ntask + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            ntask += __popcll(m);
+            if (pend[j] >= 0) { task_lds[wv][rank & 255] = (uint8_t)(4 * me + j); ts_lds[wv][rank & 255] = (uint8_t)pend[j]; }
+            pend[j] = -1;
+        }
+        if (ntask == 0) return;                                                // wave-uniform
+        // A pool of 64 builders works the task list off: every lane feeds its board one word of its stream per iteration
+        // (four iterations per Philox block, the blocks computed by all lanes at once, each with its own counter), and a
+        // lane whose board is complete takes the next unclaimed task at the following block boundary instead of idling
+        // until the slowest board of its batch is done (a 5x5 board takes 42 words on average and over a hundred at worst).
+        const typename Env::BuildConsts bc = Env::build_consts(p);
+        typename Env::Builder bld;
+        int my = me < ntask ? me : -1, next_task = ntask < 64 ? ntask : 64;    // this lane's task; the first unclaimed one
+        int bidx = 0;
+        uint32_t bt_lo = 0, bt_hi = 0, blk = 0;
+        auto take = [&](int q) {                                               // lanes with q >= 0 start on task q
+            const int idx = q >= 0 ? (int)task_lds[wv][q & 255] : 0, s0 = q >= 0 ? (int)ts_lds[wv][q & 255] : 0;
+            const uint64_t td = t0 + (uint64_t)s0;                             // battleship.py:131-137 on stream NEXT of that step's call counter
+            if (q >= 0) { bidx = idx; bt_lo = (uint32_t)td; bt_hi = (uint32_t)(td >> 32); blk = 0; bld.start(p.max_len); }
+        };
+        bld.idle();
+        take(my);
+        while (__any(my >= 0)) {
+            const uint4 b4 = philox4x32_10(wave0 + (uint32_t)bidx, bt_lo, bt_hi, ((uint32_t)POMDP_STREAM_NEXT << 24) | (blk & 0xFFFFFFu), key0.k0, key0.k1);
+            ++blk;
+            Env::feed(bld, seq, bc, b4.x);
+            Env::feed(bld, seq, bc, b4.y);
+            Env::feed(bld, seq, bc, b4.z);
+            Env::feed(bld, seq, bc, b4.w);
+            const bool fin = my >= 0 && !bld.busy();
+            const uint64_t fm = __ballot(fin);
+            if (fm != 0ull) {                                                  // wave-uniform
+                if (fin) {                                                     // straight into the owner's slot: lane bidx & 3 of thread bidx >> 2
+#pragma unroll
+                    for (int w = 0; w < MW; ++w) next_lds[w][bidx & 3][64 * wv + (bidx >> 2)] = (uint32_t)(bld.occ >> (32 * w));
+                }
+                const int r = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
+                if (fin) { my = next_task + r < ntask ? next_task + r : -1; bld.idle(); take(my); }
+                next_task += __popcll(fm);
+            }
+        }
+    };
+    for (int s = 0; s < k_steps; ++s) {
+        uint32_t ow[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ow[j] = occ_lds[a_cur[j] >> 5][j][tid];   // the ship-mask word this shot tests
+        const uint64_t ta = ta0 + (uint64_t)s;
+        const uint4 pw = philox4x32_10(glane0 >> 2, (uint32_t)ta, (uint32_t)(ta >> 32), (uint32_t)POMDP_STREAM_ACTION << 24, akey0.k0, akey0.k1);
+        const uint32_t P[4] = {pw.x, pw.y, pw.z, pw.w};
+        uint32_t o4[4], r4[4], a_next[4], dpack = 0;
+        bool d[4], again = false;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                                          // battleship.py:91-122: draws nothing
+            const int a = a_cur[j];
+            const uint32_t last = vis[j].word(MW - 1);
+            int remaining = (int)(last >> 26), r;
+            const bool visited = Env::bit(vis[j], a), hit = (ow[j] >> (a & 31)) & 1u;
+            if (visited) r = -10;
+            else { r = -1; remaining -= (int)hit; Env::set_bit(vis[j], a); }
+            d[j] = remaining == 0;
+            if (d[j]) r += cells;
+            vis[j].set_word(MW - 1, (vis[j].word(MW - 1) & 0x03FFFFFFu) | ((uint32_t)remaining << 26));
+            again |= d[j] && pend[j] >= 0;
+            o4[j] = (uint32_t)(!visited && hit); r4[j] = (uint32_t)r;
+            dpack |= (uint32_t)d[j] << (8 * j);
+            a_next[j] = __umulhi(P[j], n_act);
+            a_cur[j] = (int)a_next[j];
+        }
+        st_stream4(action_w, a_next[0], a_next[1], a_next[2], a_next[3]);
+        st_stream4(ob_w, o4[0], o4[1], o4[2], o4[3]);
+        st_stream4(reward_w, r4[0], r4[1], r4[2], r4[3]);
+        st_stream(done_w, dpack);
+        action_w += rec; ob_w += rec; reward_w += rec; done_w += rec / 4;
+        if (__any(again)) build_boards();                                      // a second episode ended before the lane's next board exists
+        if (__any(d[0] || d[1] || d[2] || d[3])) {                             // wave-uniform: the cached boards move in
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (d[j]) {
+                    int ships = 0;
+#pragma unroll
+                    for (int q = 0; q < MW; ++q) { const uint32_t x = next_lds[q][j][tid]; occ_lds[q][j][tid] = x; ships += __popc(x); }
+                    vis[j].lo = vis[j].hi = 0;
+                    vis[j].set_word(MW - 1, (uint32_t)ships << 26);
+                    pend[j] = s;
+                }
+            }
+        }
+    }
+    build_boards();
+#pragma unroll
+    for (int q = 0; q < MW; ++q) {
+        st_stream4(state + (int64_t)q * n + l0, occ_lds[q][0][tid], occ_lds[q][1][tid], occ_lds[q][2][tid], occ_lds[q][3][tid]);
+        st_stream4(state + (int64_t)(MW + q) * n + l0, vis[0].word(q), vis[1].word(q), vis[2].word(q), vis[3].word(q));
+        st_stream4(state + (int64_t)(2 * MW + q) * n + l0, next_lds[q][0][tid], next_lds[q][1][tid], next_lds[q][2][tid], next_lds[q][3][tid]);
+    }
+}
+
+// The generic fused loop with a quad per thread, for envs whose lane step is light enough that four of them fit a thread
+// (Env::QUAD_FUSED; one state word): the policy's ACTION block is the thread's own, Env::step / Env::reset_where run per
+// lane as in steps_kernel, the outputs leave as 16-byte stores.  Full workgroups of 1024 lanes, auto-reset.  Only for envs
+// whose reset_where does not assume that a wave's 64 lanes are consecutive (RockSample's cooperative reset does).
+template <class Env, class = void> struct quad_tab : std::false_type {};
+template <class Env> struct quad_tab<Env, std::enable_if_t<Env::QUAD_TAB>> : std::true_type {};
+template <class Env, class = void> struct quad_fused : std::false_type {};
+template <class Env> struct quad_fused<Env, std::enable_if_t<Env::QUAD_FUSED>> : std::true_type {};
+
+template <class Env>
+__global__ __launch_bounds__(BLOCK) void steps_quad_generic_kernel(uint32_t *__restrict__ state, int32_t *__restrict__ action,
+                                                                   int32_t *__restrict__ ob,
+                                                                   typename Env::Reward *__restrict__ reward,
+                                                                   uint8_t *__restrict__ done, int64_t n, RngKey key0,
+                                                                   uint32_t lane0, RngKey akey0, int k_steps, int64_t rec,
+                                                                   int gen_first, const typename Env::Params p)
+{
+    static_assert(Env::WORDS == 1 && sizeof(typename Env::Reward) == 4, "one state word, 4-byte rewards");
+    __shared__ typename Env::Shared sh;
+    const uint32_t l0 = blockIdx.x * (uint32_t)(4 * BLOCK) + 4u * threadIdx.x;
+    const uint32_t glane0 = lane0 + l0;
+    uint32_t *action_w = reinterpret_cast<uint32_t *>(action) + l0, *ob_w = reinterpret_cast<uint32_t *>(ob) + l0;
+    uint32_t *reward_w = reinterpret_cast<uint32_t *>(reward) + l0;
+    uint32_t *done_w = reinterpret_cast<uint32_t *>(done + l0);
+    typename Env::State st[4];
+    int a_cur[4];
+    const uint32_t n_act = (uint32_t)Env::n_actions(p);
+    {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Env::load(st[j], state, n, l0 + (uint32_t)j);
+        const u32x4 a4 = first_actions4(action_w, gen_first, glane0, akey0, n_act);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a_cur[j] = (int)a4[j];
+    }
+    action_w += rec;
+    Env::stage(sh, p, (int)threadIdx.x);
+    __syncthreads();
+    const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo, ta0 = ((uint64_t)akey0.t_hi << 32) | akey0.t_lo;
+    for (int s = 0; s < k_steps; ++s) {
+        RngKey key = key0;
+        key.t_lo = (uint32_t)(t0 + (uint64_t)s); key.t_hi = (uint32_t)((t0 + (uint64_t)s) >> 32);
+        const uint64_t ta = ta0 + (uint64_t)s;
+        const uint4 pw = philox4x32_10(glane0 >> 2, (uint32_t)ta, (uint32_t)(ta >> 32), (uint32_t)POMDP_STREAM_ACTION << 24, key.k0, key.k1);
+        const uint32_t P[4] = {pw.x, pw.y, pw.z, pw.w};
+        uint32_t o4[4], r4[4], a_next[4], dpack = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int o, d;
+            typename Env::Reward r;
+            const uint32_t lane = glane0 + (uint32_t)j;
+            Env::step(sh, p, st[j], a_cur[j], key, lane, o, r, d);
+            Env::reset_where(sh, p, st[j], d != 0, key, lane);                 // wave-convergent: every lane calls it
+            o4[j] = (uint32_t)o;
+            __builtin_memcpy(&r4[j], &r, 4);
+            dpack |= (uint32_t)(d != 0) << (8 * j);
+            a_next[j] = __umulhi(P[j], n_act);
+            a_cur[j] = (int)a_next[j];
+        }
+        st_stream4(action_w, a_next[0], a_next[1], a_next[2], a_next[3]);
+        st_stream4(ob_w, o4[0], o4[1], o4[2], o4[3]);
+        st_stream4(reward_w, r4[0], r4[1], r4[2], r4[3]);
+        st_stream(done_w, dpack);
+        action_w += rec; ob_w += rec; reward_w += rec; done_w += rec / 4;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Env::store(st[j], state, n, l0 + (uint32_t)j, true);
+}
+
+// the same as k launch_step_chain calls at t, t + 1, ..., in one launch.  gen_first: the launch derives the actions of
+// call counter t itself (and writes them to `action`) instead of reading them — the caller skips the policy launch.
+template <class Env>
+int launch_steps_fused(const typename Env::Params &p, uint32_t *state, int32_t *action, int32_t *ob,
+                              typename Env::Reward *reward, uint8_t *done, uint32_t *err, int64_t n, uint64_t seed,
+                              uint64_t action_seed, uint32_t lane0, uint64_t t, int k, int flags, int64_t rec, bool gen_first,
+                              void *stream)
+{
+    if (!state || !action || !ob || !reward || !done || bad_range(n, lane0) || (lane0 & 3u) || k < 1) return POMDP_E_BADARG;
+    if (n == 0) return 0;
+    // two lanes per thread from 2^19 lanes, where the batch does not qualify for a quad-per-thread loop: at 2^18 lanes the
+    // one-lane-per-thread loops take 0.90 (RockSample; 1.09 with two) and 1.08 us per step (Tag)
+    const bool lpt2 = Env::POOLED_LPT2 && n >= 2 * LPT2_MIN_LANES;
+    const bool simple = (flags & POMDP_AUTO_RESET) && n % (lpt2 ? 2 * BLOCK : BLOCK) == 0;
+    const dim3 grid(lpt2 ? (unsigned)((n + 2 * BLOCK - 1) / (2 * BLOCK)) : blocks_for(n));
+    const int kflags = (flags & POMDP_AUTO_RESET) | (gen_first ? FLAG_GEN_FIRST : 0);
+    const int gf = gen_first ? 1 : 0;
+#define POMDP_LAUNCH_STEPS(LPT_, SIMPLE_, GRID_)                                                                       \
+    do {                                                                                                                 \
+        note_fused("steps_kernel", Env::NAME, ", " #LPT_ ", " #SIMPLE_);                                                 \
+        hipLaunchKernelGGL((steps_kernel<Env, LPT_, SIMPLE_>), GRID_, dim3(BLOCK), 0, (hipStream_t)stream, state, action, \
+                           ob, reward, done, err, n, make_key(seed, t), lane0, kflags, make_key(action_seed, t + 1), k,   \
+                           rec, p);                                                                                      \
+    } while (0)
+    // RockSample's pooled passes exist for any number of lanes per thread; in the fused loop (no load latency to hide)
+    // four per thread, with fuller passes, beat two by 5 % from 2^20 lanes up (3.97 vs 4.16 us per step) when the state
+    // is one word; with two state words (K > 12) the extra registers cost more (5.04 vs 4.74 us).  Only the geometries
+    // an env can take are instantiated.
+    // the quad-per-thread loops move 16 bytes at a time (4 for the done bytes): columns that start on such a boundary
+    // only, full workgroups of 1024 lanes, auto-reset, policy and env on one Philox key
+    const bool quad_ok = ((reinterpret_cast<uintptr_t>(state) | reinterpret_cast<uintptr_t>(action) | reinterpret_cast<uintptr_t>(ob) |
+                           reinterpret_cast<uintptr_t>(reward)) & 15u) == 0 && (reinterpret_cast<uintptr_t>(done) & 3u) == 0 &&
+                         rec % 4 == 0 && action_seed == seed && (flags & POMDP_AUTO_RESET) && n % (4 * BLOCK) == 0;
+    const dim3 qgrid((unsigned)(n / (4 * BLOCK)));
+    bool launched = false;
+    if constexpr (std::is_same<Env, TagEnv>::value) {
+        if (quad_ok && n >= QUAD_MIN_TAG && p.num_opponents == 1) {
+            if (k >= 16 && TagEnv::tab_ok(p)) {
+                note_fused("tag_steps_quad_kernel", "true", "");
+                hipLaunchKernelGGL(tag_steps_quad_kernel<true>, qgrid, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob, reward,
+                                   done, n, make_key(seed, t), lane0, make_key(action_seed, t + 1), k, rec, gf, p);
+            } else {
+                note_fused("tag_steps_quad_kernel", "false", "");
+                hipLaunchKernelGGL(tag_steps_quad_kernel<false>, qgrid, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob, reward,
+                                   done, n, make_key(seed, t), lane0, make_key(action_seed, t + 1), k, rec, gf, p);
+            }
+            launched = true;
+        }
+    }
+    if constexpr (has_next<Env>::value) {
+        if (quad_ok && n >= QUAD_MIN_BATTLESHIP && k <= 255) {
+            note_fused("battleship_steps_quad_kernel", Env::NAME, "");
+            hipLaunchKernelGGL(battleship_steps_quad_kernel<Env::WORDS / 3>, qgrid, dim3(BLOCK), 0, (hipStream_t)stream, state, action,
+                               ob, reward, done, n, make_key(seed, t), lane0, make_key(action_seed, t + 1), k, rec, gf, p);
+            launched = true;
+        }
+    }
+    if constexpr (std::is_same<Env, NetworkEnv>::value) {
+        if (quad_ok && n >= QUAD_MIN_NETWORK) {
+            note_fused("network_steps_quad_kernel", "", "");
+#define POMDP_LAUNCH_NET(NB_)                                                                                            \
+    hipLaunchKernelGGL(network_steps_quad_kernel<NB_>, qgrid, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob, reward, \
+                       done, n, make_key(seed, t), lane0, make_key(action_seed, t + 1), k, rec, gf, p)
+            switch ((p.n_machines + 7) / 8) {
+            case 1: POMDP_LAUNCH_NET(1); break;
+            case 2: POMDP_LAUNCH_NET(2); break;
+            case 3: POMDP_LAUNCH_NET(3); break;
+            default: POMDP_LAUNCH_NET(4); break;
+            }
+#undef POMDP_LAUNCH_NET
+            launched = true;
+        }
+    }
+    if constexpr (quad_fused<Env>::value) {
+        if (quad_ok && n >= QUAD_MIN_GENERIC) {
+            note_fused("steps_quad_generic_kernel", Env::NAME, "");
+            hipLaunchKernelGGL((steps_quad_generic_kernel<Env>), qgrid, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob,
+                               reward, done, n, make_key(seed, t), lane0, make_key(action_seed, t + 1), k, rec, gf, p);
+            launched = true;
+        }
+    }
+    if constexpr (quad_tab<Env>::value) {
+        // from 16 steps per launch on the lane step reads the (position, action) table the workgroup builds first and a
+        // thread owns a quad of consecutive lanes (steps_quad_kernel: RockSample and StochasticRock)
+        if (quad_ok && n >= QUAD_MIN_ROCK && k >= 16 && p.num_rocks + 5 <= Env::TAB_ACTIONS) {
+            note_fused("steps_quad_kernel", Env::NAME, "");
+            hipLaunchKernelGGL((steps_quad_kernel<Env>), qgrid, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob, reward,
+                               done, n, make_key(seed, t), lane0, make_key(action_seed, t + 1), k, rec, gf, p);
+            launched = true;
+        }
+    }
+    if constexpr (Env::POOLED_ANY_LPT) {
+        if (!launched && lpt2 && (flags & POMDP_AUTO_RESET) && n % (4 * BLOCK) == 0 && n >= (1 << 20) && Env::WORDS == 1) {
+            POMDP_LAUNCH_STEPS(4, true, qgrid);
+            launched = true;
+        }
+    }
+    if constexpr (Env::POOLED_LPT2) {
+        if (!launched && lpt2) {
+            if (simple) POMDP_LAUNCH_STEPS(2, true, grid); else POMDP_LAUNCH_STEPS(2, false, grid);
+            launched = true;
+        }
+    }
+    if constexpr (quad_tab<Env>::value && Env::QUAD_SENSOR) {
+        // RockSample's small shards, one lane per thread: the table-driven lane step from 16 steps per launch on
+        if (!launched && simple && k >= 16 && p.num_rocks + 5 <= Env::TAB_ACTIONS) {
+            note_fused("steps_kernel", Env::NAME, ", 1, true, true");
+            hipLaunchKernelGGL((steps_kernel<Env, 1, true, true>), grid, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob, reward,
+                               done, err, n, make_key(seed, t), lane0, kflags, make_key(action_seed, t + 1), k, rec, p);
+            launched = true;
+        }
+    }
+    if (!launched) { if (simple) POMDP_LAUNCH_STEPS(1, true, grid); else POMDP_LAUNCH_STEPS(1, false, grid); }
+#undef POMDP_LAUNCH_STEPS
+    return (int)hipGetLastError();
+}
+
+} // namespace pomdp

@@ -1,0 +1,487 @@
+#pragma once
+// kernels_common.hip.h — what the translation units of libpomdp_hip.so share (gfx950 kernels + the C ABI of include/pomdp_hip.h).
+//
+// One wavefront lane advances one env instance.  State, action, ob, reward and done
+// are struct-of-arrays columns in HBM, so every access of a wave is one coalesced
+// 256-byte (int32) or 64-byte (done) segment.  Lookup tables (RockSample's rock-id
+// grid, rock coordinates and sensor thresholds) are staged from the kernarg segment
+// into LDS once per workgroup.  No MFMA: the path is integer / branch work, bounded
+// by HBM traffic (21 B per RockSample step) and by Philox ALU throughput.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC (see __graft_entry__.build()).
+#include <hip/hip_runtime.h>
+#include <chrono>
+
+#include "../../include/pomdp_hip.h"
+#include "envs.hip.h"
+#include "philox.hip.h"
+#include <cstdio>
+
+namespace pomdp {
+
+constexpr int BLOCK = 256;        // 4 waves: one per SIMD
+// launcher -> fused kernels only (never part of the ABI's flags): the launch derives the actions of its first step from
+// the synthetic policy itself and writes them to row 0 of `action`, instead of reading what a policy launch left there
+constexpr int FLAG_GEN_FIRST = 1 << 8;
+constexpr int MAX_BLOCKS = 256 * 8; // helper kernels: 256 CUs x 8 resident workgroups, grid-stride beyond
+
+static inline int grid_for(int64_t n)
+{
+    const int64_t b = (n + BLOCK - 1) / BLOCK;
+    return (int)(b < 1 ? 1 : (b > MAX_BLOCKS ? MAX_BLOCKS : b));
+}
+static inline unsigned blocks_for(int64_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
+// below this many lanes one lane per thread is as fast or faster (measured: tools/microbench.hip at 2^16 .. 2^19)
+#ifdef POMDP_DEV_TIMELINE                                      // dev builds only (tools/ab_build.sh): per-workgroup phase stamps
+__device__ uint64_t *g_timeline = nullptr;
+#define TL(k) do { if (threadIdx.x == 0 && g_timeline) g_timeline[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define TL(k) do { } while (0)
+#endif
+#ifdef POMDP_LPT2_MIN_LANES                                   // same-box A/B builds (tools/ab_build.sh)
+constexpr int64_t LPT2_MIN_LANES = POMDP_LPT2_MIN_LANES;
+#else
+constexpr int64_t LPT2_MIN_LANES = 1 << 18;
+#endif
+#ifdef POMDP_STEP_QUAD_MIN_LANES                              // same-box A/B builds (tools/ab_build.sh)
+constexpr int64_t STEP_QUAD_MIN_LANES = POMDP_STEP_QUAD_MIN_LANES;
+#else
+constexpr int64_t STEP_QUAD_MIN_LANES = 1 << 19;
+#endif
+
+// envs whose lanes carry the board of their next episode (BattleShip): `next` is loaded only where a lane may need it
+template <class Env, class = void> struct has_next : std::false_type {};
+template <class Env> struct has_next<Env, std::enable_if_t<Env::HAS_NEXT>> : std::true_type {};
+
+// ---------------------------------------------------------------------------
+// step: transition + observation + reward (+ same-call auto-reset of done lanes)
+//
+// One workgroup = 256 threads = LPT x 256 consecutive lanes; thread `tid` owns lanes
+// base + tid + 256 * j (j < LPT), so every wave access is still one coalesced segment.
+// All HBM loads of all of a thread's lanes (action, state words, done flag) are issued
+// unconditionally before the table staging and its barrier: a wave pays one memory latency for
+// LPT x 64 lanes, and the independent per-lane chains (LDS lookups, Philox, cross-lane reset)
+// overlap.  Lanes past n read lane n-1 and have their stores predicated off.  Every lane of a
+// wave reaches Env::reset_where (wave-cooperative reset).
+// ---------------------------------------------------------------------------
+// ---------------------------------------------------------------------------
+// Finisher: the lane step of a thread's lanes and what follows it — auto-reset of the done lanes and, for
+// CHAIN launches, the synthetic policy's actions of the next call counter.  Generic form: Env::step per lane,
+// one Env::reset_where[_chain] per 64-lane sub-batch.
+// ---------------------------------------------------------------------------
+template <class Env, int LPT, bool CHAIN, class = void>
+struct Finisher {
+    struct Aux {};
+    static constexpr bool HAS_PREPASS = false;
+    static constexpr bool LOOP_BARRIER = CHAIN;      // run() shares `pol` across waves: a fused multi-step loop must fence its reuse
+    // The fused multi-step loop does not use `pol` at one lane per thread: lane e of a quad computes the quad's policy
+    // block of step s + e once per four steps and the words travel by ds_bpermute (steps_kernel), so the loop has no
+    // barrier at all and a wave that runs a long cooperative reset (BattleShip) no longer stalls the other three.
+    static constexpr bool QUAD_POLICY = CHAIN && LPT == 1;
+    static __device__ __forceinline__ void resets_only(const typename Env::Shared &sh, const typename Env::Params &p,
+                                                       typename Env::State (&st)[LPT], const bool (&fresh)[LPT],
+                                                       const RngKey &key, const uint32_t (&lane)[LPT])
+    {
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) Env::reset_where(sh, p, st[j], fresh[j], key, lane[j]);
+    }
+    template <class RT>
+    static __device__ __forceinline__ void lane_step(const typename Env::Shared &sh, const typename Env::Params &p,
+                                                     typename Env::State &st, int a, const RngKey &key, uint32_t lane,
+                                                     int &ob, RT &rew, int &done, Aux &)
+    {
+        Env::step(sh, p, st, a, key, lane, ob, rew, done);
+    }
+    static __device__ __forceinline__ void run(const typename Env::Shared &sh, const typename Env::Params &p,
+                                               typename Env::State (&st)[LPT], const bool (&fresh)[LPT],
+                                               const RngKey &key, const uint32_t (&lane)[LPT], const RngKey &akey,
+                                               uint32_t n_act, int (&a_next)[LPT], const Aux (&)[LPT], int (&)[LPT])
+    {
+        // CHAIN: the workgroup's BLOCK * LPT consecutive lanes share BLOCK * LPT / 4 policy blocks (one per quad); its
+        // first wave(s) compute each once, the others pick their word up from LDS, instead of every lane computing
+        // its quad's block itself
+        constexpr int NQ = BLOCK * LPT / 4;
+        __shared__ uint32_t pol[CHAIN ? NQ : 1][4];
+        if (CHAIN && (int)threadIdx.x < NQ) {                                  // whole waves: NQ is a multiple of 64
+            const uint32_t quad = ((lane[0] - threadIdx.x) >> 2) + threadIdx.x;
+            const uint4 w = philox4x32_10(quad, akey.t_lo, akey.t_hi, (uint32_t)POMDP_STREAM_ACTION << 24, akey.k0, akey.k1);
+            pol[threadIdx.x][0] = w.x; pol[threadIdx.x][1] = w.y; pol[threadIdx.x][2] = w.z; pol[threadIdx.x][3] = w.w;
+        }
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) Env::reset_where(sh, p, st[j], fresh[j], key, lane[j]);
+        if (CHAIN) {
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < LPT; ++j) {
+                const uint32_t rel = threadIdx.x + (uint32_t)(j * BLOCK);
+                a_next[j] = (int)__umulhi(pol[rel >> 2][rel & 3], n_act);
+            }
+        }
+    }
+};
+
+// RockSample with two or more lanes per thread: every random word of the step comes from a quad-shared block (DESIGN.md
+// §2) that depends on lane ids and the call counter only, so ONE task list per wave (64 * LPT lanes) holds
+//   - the 16 * LPT sensor blocks of its quads (stream STEP),
+//   - their 16 * LPT RESET blocks (a quad's four lanes take one word each: the statuses of all rocks of a fresh episode),
+//   - for CHAIN launches the 16 * LPT policy blocks of the next call counter,
+// i.e. 64 (CHAIN: 96) Philox blocks for 128 lane-steps, dealt out 64 per pass BEFORE the lane step: the kernel runs the
+// passes right after issuing its HBM loads.  The lane step therefore runs WITHOUT its sensor draw (Env::step_pre) and
+// the observation and the fresh episodes are completed here from the pooled words.  Tasks and results are exchanged
+// through a wave-private LDS scratch; LDS operations of one wave complete in order, so no barrier is involved.  Low
+// words (needed with probability 2^-27 per draw) are generated per lane on demand.
+template <int W, int LPT, bool CHAIN>
+struct Finisher<RockEnv<W, false>, LPT, CHAIN, typename std::enable_if<(LPT >= 2)>::type> {
+    using Env = RockEnv<W, false>;
+    using Aux = typename Env::Aux;
+    static constexpr bool LOOP_BARRIER = false;              // every scratch array is wave-private
+    static constexpr int NQ = 16 * LPT;                      // quads of the wave's 64 * LPT lanes: sensor blocks, reset blocks
+    static constexpr int NA = CHAIN ? 16 * LPT : 0;          // policy blocks of the next call counter
+    static constexpr int NT = 2 * NQ + NA;
+    template <class RT>
+    static __device__ __forceinline__ void lane_step(const typename Env::Shared &sh, const typename Env::Params &p,
+                                                     typename Env::State &st, int a, const RngKey &, uint32_t, int &ob,
+                                                     RT &rew, int &done, Aux &aux)
+    {
+        Env::step_pre(sh, p, st, a, rew, done, aux);
+        ob = 0;
+    }
+    // the same from the (position, action) table of a multi-step launch (RockEnv::StepTab)
+    template <class Tab, class RT>
+    static __device__ __forceinline__ void lane_step_tab(const Tab &tab, typename Env::State &st, int a, int &ob, RT &rew,
+                                                         int &done, Aux &aux)
+    {
+        Env::step_tab(tab, st, a, rew, done, aux);
+        ob = 0;
+    }
+    // wave-private LDS scratch (one instance: function-local static of this accessor)
+    static __device__ __forceinline__ uint32_t (&blk_lds())[BLOCK / 64][NT][4]
+    {
+        __shared__ uint32_t a[BLOCK / 64][NT][4];            // [0, NQ): sensor, [NQ, 2 NQ): reset, [2 NQ, NT): policy; (sub-batch, quad)
+        return a;
+    }
+    static constexpr bool HAS_PREPASS = true;
+    // Sub-batch j of a thread is 256 j lanes further on.
+    static __device__ __forceinline__ void prepass(const RngKey &key, const uint32_t (&lane)[LPT], const RngKey &akey)
+    {
+        const int wv = (int)(threadIdx.x >> 6), me = (int)(threadIdx.x & 63u);
+        const uint32_t first0 = lane[0] - (uint32_t)me;                        // first lane of the wave's sub-batch 0
+#pragma unroll
+        for (int base = 0; base < NT; base += 64) {
+            const int tid = base + me;
+            if (tid < NT) {
+                // ONE Philox instance for the three task kinds: the counter words are per-lane selects
+                const int kind = tid < NQ ? 0 : (tid < 2 * NQ ? 1 : 2);
+                const int qt = tid - kind * NQ;                                // (sub-batch, quad) index
+                const uint32_t quad = ((first0 + (uint32_t)(qt >> 4) * BLOCK) >> 2) + (uint32_t)(qt & 15);
+                const uint32_t c1 = kind == 2 ? akey.t_lo : key.t_lo, c2 = kind == 2 ? akey.t_hi : key.t_hi;
+                const uint32_t c3 = (uint32_t)(kind == 0 ? POMDP_STREAM_STEP : kind == 1 ? POMDP_STREAM_RESET : POMDP_STREAM_ACTION) << 24;
+                const uint4 w = philox4x32_10(quad, c1, c2, c3, key.k0, key.k1);
+                uint32_t *dst = blk_lds()[wv][tid];
+                dst[0] = w.x; dst[1] = w.y; dst[2] = w.z; dst[3] = w.w;
+            }
+        }
+    }
+    static __device__ __forceinline__ void run(const typename Env::Shared &sh, const typename Env::Params &p,
+                                               typename Env::State (&st)[LPT], const bool (&fresh)[LPT], const RngKey &key,
+                                               const uint32_t (&lane)[LPT], const RngKey &, uint32_t n_act,
+                                               int (&a_next)[LPT], const Aux (&aux)[LPT], int (&ob)[LPT])
+    {
+        const int wv = (int)(threadIdx.x >> 6), me = (int)(threadIdx.x & 63u);
+        uint32_t H[LPT], Rw[LPT], P[LPT];
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) {                                         // every read in flight together, one wait
+            H[j] = blk_lds()[wv][16 * j + (me >> 2)][me & 3];
+            Rw[j] = blk_lds()[wv][NQ + 16 * j + (me >> 2)][me & 3];
+            P[j] = CHAIN ? blk_lds()[wv][2 * NQ + 16 * j + (me >> 2)][me & 3] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) {
+            st[j].s = fresh[j] ? Env::fresh_state(p, Rw[j], key, lane[j]) : st[j].s;
+            ob[j] = Env::sensor_ob(sh, st[j], aux[j], H[j], [&]() { return Env::elem(Env::quad_block(key, lane[j], 1u), lane[j] & 3u); });
+            if (CHAIN) a_next[j] = (int)__umulhi(P[j], n_act);
+        }
+    }
+};
+
+// Tag with two lanes per thread: only a failed TAG on a live opponent draws (about a fifth of the lanes under a random
+// policy) and resets are rare (episodes last hundreds of steps), so per-lane Philox blocks would be mostly wasted.
+// ONE task list per wave (128 lanes): for CHAIN launches the 32 policy blocks of the next call counter, one STEP block
+// per lane whose opponent may flee, one RESET block per resetting lane — ~58 blocks for 128 lane-steps instead of 256
+// (512 chained), dealt out 64 per pass through a wave-private LDS scratch like RockSample's.  The lane step runs
+// without the flight (TagEnv::step_one_opponent_pre) and TagEnv::flee completes it from the pooled words.
+// More than one opponent (wave-uniform, from the params): the general per-lane path.
+template <bool CHAIN>
+struct Finisher<TagEnv, 2, CHAIN, void> {
+    using Env = TagEnv;
+    using Aux = typename Env::Flight;
+    static constexpr bool HAS_PREPASS = false;
+    static constexpr bool LOOP_BARRIER = false;
+    template <class RT>
+    static __device__ __forceinline__ void lane_step(const typename Env::Shared &sh, const typename Env::Params &p,
+                                                     typename Env::State &st, int a, const RngKey &key, uint32_t lane,
+                                                     int &ob, RT &rew, int &done, Aux &aux)
+    {
+        if (p.num_opponents == 1) Env::step_one_opponent_pre(sh, p, st, a, ob, rew, done, aux);
+        else { aux.need = false; Env::step(sh, p, st, a, key, lane, ob, rew, done); }
+    }
+    static __device__ __forceinline__ void run(const typename Env::Shared &sh, const typename Env::Params &p,
+                                               typename Env::State (&st)[2], const bool (&fresh)[2], const RngKey &key,
+                                               const uint32_t (&lane)[2], const RngKey &akey, uint32_t n_act,
+                                               int (&a_next)[2], const Aux (&aux)[2], int (&)[2])
+    {
+        if (p.num_opponents != 1) {                                            // wave-uniform
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (CHAIN) Env::reset_where_chain(sh, p, st[j], fresh[j], key, lane[j], akey, n_act, a_next[j]);
+                else Env::reset_where(sh, p, st[j], fresh[j], key, lane[j]);
+            }
+            return;
+        }
+        __shared__ uint8_t src_lds[BLOCK / 64][128];         // task rank -> virtual lane (me + 64 * sub-batch)
+        __shared__ uint32_t res_lds[BLOCK / 64][32 + 128][4];   // [0,32): policy blocks (sub-batch, quad); then task results
+        const int wv = (int)(threadIdx.x >> 6), me = (int)(threadIdx.x & 63u);
+        // flights first, resets after them: a lane is never both (a failed TAG does not end the episode)
+        const uint64_t f0 = __ballot(aux[0].need), f1 = __ballot(aux[1].need);
+        const uint64_t r0 = __ballot(fresh[0]), r1 = __ballot(fresh[1]);
+        const int nf0 = __popcll(f0), nfl = nf0 + __popcll(f1), nr0 = __popcll(r0), ntsk = nfl + nr0 + __popcll(r1);
+        auto below = [&](uint64_t m) {
+            return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        };
+        const int rank[2] = {aux[0].need ? below(f0) : nfl + below(r0),
+                             aux[1].need ? nf0 + below(f1) : nfl + nr0 + below(r1)};
+        if (aux[0].need || fresh[0]) src_lds[wv][rank[0]] = (uint8_t)me;
+        if (aux[1].need || fresh[1]) src_lds[wv][rank[1]] = (uint8_t)(me + 64);
+        constexpr int NA = CHAIN ? 32 : 0;
+        const int ntask = NA + ntsk;
+        const uint32_t first0 = lane[0] - (uint32_t)me, first1 = lane[1] - (uint32_t)me;   // first lane of each sub-batch
+        for (int base = 0; base < ntask; base += 64) {
+            const int tid = base + me;
+            if (tid < ntask) {
+                const bool is_act = tid < NA;
+                const int r = is_act ? 0 : tid - NA;
+                const int v = (int)src_lds[wv][r & 127];
+                const uint32_t src_lane = ((v >> 6) ? first1 : first0) + (uint32_t)(v & 63);
+                const uint32_t quad = (((tid >> 4) ? first1 : first0) >> 2) + (uint32_t)(tid & 15);
+                const uint32_t c0 = is_act ? quad : src_lane;
+                const uint32_t c1 = is_act ? akey.t_lo : key.t_lo, c2 = is_act ? akey.t_hi : key.t_hi;
+                const uint32_t strm = is_act ? POMDP_STREAM_ACTION : (r < nfl ? POMDP_STREAM_STEP : POMDP_STREAM_RESET);
+                const uint4 w = philox4x32_10(c0, c1, c2, strm << 24, key.k0, key.k1);
+                uint32_t *dst = res_lds[wv][is_act ? tid : 32 + (r & 127)];
+                dst[0] = w.x; dst[1] = w.y; dst[2] = w.z; dst[3] = w.w;
+            }
+        }
+        uint4 rb[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {                                          // both blocks in flight, one wait
+            const uint32_t *res = res_lds[wv][32 + (rank[j] & 127)];
+            rb[j] = make_uint4(res[0], res[1], res[2], res[3]);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (aux[j].need) Env::flee(sh, p, st[j], aux[j], rb[j].x, rb[j].y, rb[j].z);
+            if (fresh[j]) {
+                if (!Env::reset_from_block(p, st[j], rb[j])) Env::reset(sh, p, st[j], key, lane[j]);   // rejections ran past the block
+            }
+            if (CHAIN) a_next[j] = (int)__umulhi(res_lds[wv][16 * j + (me >> 2)][me & 3], n_act);
+        }
+    }
+};
+
+// Finishers that take the fused loop's policy words from quad-multiplexed blocks (generic form, one lane per thread)
+template <int J>
+static __device__ __forceinline__ uint32_t quad_bcast(uint32_t v)     // v of lane J of the caller's quad
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, J * 0x55, 0xF, 0xF, false);
+}
+// 4 x 4 transpose within a quad: lane e of the quad passes the four words of ITS block and gets word e of the blocks of
+// lanes 0, 1, 2, 3 (t.x .. t.w).  The fused rollout and heuristic loops let lane e of a quad compute the quad-shared block
+// of step base + e; step base + J then reads component J of the result — compile-time — where four broadcasts and a
+// per-lane select per step cost twice as much.  Two butterfly stages (partner e ^ 1, then e ^ 2): each lane first
+// selects the two words its partner lacks, so a stage is 2 selects + 2 DPP moves + 4 selects.
+static __device__ __forceinline__ uint4 quad_transpose4(const uint4 &v, uint32_t e)
+{
+    const bool b0 = e & 1u, b1 = e & 2u;
+    const uint32_t s0 = b0 ? v.x : v.y, s1 = b0 ? v.z : v.w;
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s0, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+    const uint32_t r1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s1, 0xB1, 0xF, 0xF, false);
+    // column (e & 1) / 2 + (e & 1) of the rows (e & ~1, e | 1)
+    const uint32_t p0 = b0 ? r0 : v.x, p1 = b0 ? v.y : r0, q0 = b0 ? r1 : v.z, q1 = b0 ? v.w : r1;
+    const uint32_t u0 = b1 ? p0 : q0, u1 = b1 ? p1 : q1;
+    const uint32_t w0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)u0, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    const uint32_t w1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)u1, 0x4E, 0xF, 0xF, false);
+    return make_uint4(b1 ? w0 : p0, b1 ? w1 : p1, b1 ? q0 : w0, b1 ? q1 : w1);
+}
+template <int J> static __device__ __forceinline__ uint32_t comp(const uint4 &v) { return J == 0 ? v.x : J == 1 ? v.y : J == 2 ? v.z : v.w; }
+
+template <class Fin, class = void> struct quad_policy_of : std::false_type {};
+template <class Fin> struct quad_policy_of<Fin, std::enable_if_t<Fin::QUAD_POLICY>> : std::true_type {};
+
+struct NoTab {};
+template <class Env, bool ON> struct step_tab_of { using type = NoTab; };
+template <class Env> struct step_tab_of<Env, true> { using type = typename Env::StepTab; };
+
+static inline RngKey make_key(uint64_t seed, uint64_t t)
+{
+    RngKey k;
+    k.k0 = (uint32_t)seed; k.k1 = (uint32_t)(seed >> 32);
+    k.t_lo = (uint32_t)t; k.t_hi = (uint32_t)(t >> 32);
+    return k;
+}
+
+static inline bool bad_range(int64_t n, uint32_t lane0) { return n < 0 || (uint64_t)lane0 + (uint64_t)n > (1ull << 32); }
+
+// pomdp_step_sync / pomdp_reset_sync (scalar mode): the flag the next one-lane launch publishes its outputs through;
+// the launcher that takes it sets the pointer back to null (defined in api.hip)
+extern thread_local uint32_t *tl_host_flag;
+extern thread_local uint32_t tl_flag_value;
+
+// The actions of a quad-per-thread launch's first step: read from row 0 of `action`, or (gen_first, wave-uniform) the
+// quad's block of the synthetic policy at the call counter before akey0's — computed here and written to that row.
+static __device__ __forceinline__ u32x4 first_actions4(uint32_t *action_row0, int gen_first, uint32_t glane0, const RngKey &akey0,
+                                                       uint32_t n_act)
+{
+    if (!gen_first) return ld_stream4(action_row0);
+    const uint64_t tf = (((uint64_t)akey0.t_hi << 32) | akey0.t_lo) - 1ull;
+    const uint4 w = philox4x32_10(glane0 >> 2, (uint32_t)tf, (uint32_t)(tf >> 32), (uint32_t)POMDP_STREAM_ACTION << 24, akey0.k0, akey0.k1);
+    const u32x4 a = {__umulhi(w.x, n_act), __umulhi(w.y, n_act), __umulhi(w.z, n_act), __umulhi(w.w, n_act)};
+    st_stream4(action_row0, a[0], a[1], a[2], a[3]);
+    return a;
+}
+
+// Smallest batch each quad-per-thread loop takes (1024 lanes per workgroup).  Measured on MI355X, us per fused step at
+// 2^17 / 2^18 / 2^19 / 2^20 lanes (profiles/r02_small_shards_gates.txt, r02k_small_shards.txt): RockSample(7,8) quad 1.50 /
+// 1.52 / 1.82 / 2.89 against 1.25 / 1.39 / 1.99 with one or two lanes per thread; Tag (table-driven) 1.59 / 1.61 / 1.83 /
+// 2.67 against 0.96 / 1.43 / 2.00; Tiger 0.67 / 0.67 / 1.21 / 2.51 against 0.44 / 0.85 / 1.41 / 2.66; Network 2.30 / 2.30 / 2.91 /
+// 4.72 against 1.45 / 1.94 / 3.32 / 5.99 — below these sizes every kernel is bound by the latency of one wave's step
+// (1.1-2.3 us), and more, lighter waves hide it better than fewer, heavier ones.
+// POMDP_QUAD_MIN_LANES overrides all of them at build time for same-box A/B runs (tools/ab_build.sh lib ... -D...).
+#ifdef POMDP_QUAD_MIN_LANES
+constexpr int64_t QUAD_MIN_ROCK = POMDP_QUAD_MIN_LANES, QUAD_MIN_TAG = POMDP_QUAD_MIN_LANES, QUAD_MIN_GENERIC = POMDP_QUAD_MIN_LANES,
+                  QUAD_MIN_NETWORK = POMDP_QUAD_MIN_LANES, QUAD_MIN_BATTLESHIP = POMDP_QUAD_MIN_LANES;
+#else
+constexpr int64_t QUAD_MIN_ROCK = 1 << 19, QUAD_MIN_TAG = 1 << 19, QUAD_MIN_GENERIC = 1 << 18, QUAD_MIN_NETWORK = 1 << 19,
+                  QUAD_MIN_BATTLESHIP = 1 << 18;
+#endif
+
+// which kernel the calling thread's most recent fused launch picked (pomdp_last_fused_kernel: bench.py names the kernel
+// it timed from this instead of guessing the launcher's choice; defined in api.hip)
+extern thread_local char g_last_fused[96];
+static inline void note_fused(const char *kernel, const char *env, const char *variant)
+{
+    snprintf(g_last_fused, sizeof g_last_fused, "%s<%s%s>", kernel, env, variant);
+}
+
+using StochRock1 = RockEnv<1, true>;   // StochasticRockEnv, one / two state words
+using StochRock2 = RockEnv<2, true>;
+
+static inline bool rock_ok(const pomdp_rock_params *p)
+{
+    if (!(p && p->size >= 1 && p->size <= 15 && p->num_rocks >= 1 && p->num_rocks <= 16 &&
+          (unsigned)p->start_x < (unsigned)p->size && (unsigned)p->start_y < (unsigned)p->size))
+        return false;
+    for (int i = 0; i < p->num_rocks; ++i)     // rock coordinates index the LDS tables: keep them on the board
+        if ((unsigned)p->rock_x[i] >= (unsigned)p->size || (unsigned)p->rock_y[i] >= (unsigned)p->size) return false;
+    for (int i = 0; i < 256; ++i)
+        if (p->grid[i] < -1 || p->grid[i] > 15) return false;
+    return true;
+}
+static inline int bs_mask_words(const pomdp_battleship_params *p)
+{
+    if (!p || p->x_size < 1 || p->y_size < 1 || p->x_size > 16 || p->y_size > 16) return 0;
+    const int cells = p->x_size * p->y_size;
+    if (cells > 122 || p->max_len < 2 || p->max_len > 10) return 0;
+    // a ship of length L needs L + 2 cells in a line (battleship.py:199-201): on a board where the longest ship
+    // cannot be placed the reference's rejection loop never ends, and neither would the kernel's
+    const int longest = p->x_size > p->y_size ? p->x_size : p->y_size;
+    if (longest < p->max_len + 2) return 0;
+    return (cells + 6 + 31) / 32;
+}
+
+// ---- the launchers: one function template per kind of launch, defined in step_impl.hip.h / fused_impl.hip.h and
+// instantiated for its env types by exactly one translation unit each (the family files); everybody else sees the
+// declarations below and links against them
+template <class Env>
+int launch_reset(const typename Env::Params &p, uint32_t *state, int32_t *ob, int64_t n, uint64_t seed, uint32_t lane0, uint64_t t,
+                 void *stream);
+template <class Env>
+int launch_step(const typename Env::Params &p, uint32_t *state, const int32_t *action, int32_t *ob, typename Env::Reward *reward,
+                uint8_t *done, uint32_t *err, int64_t n, uint64_t seed, uint32_t lane0, uint64_t t, int flags, void *stream);
+template <class Env>
+int launch_step_chain(const typename Env::Params &p, uint32_t *state, int32_t *action, int32_t *ob, typename Env::Reward *reward,
+                      uint8_t *done, uint32_t *err, int64_t n, uint64_t seed, uint64_t action_seed, uint32_t lane0, uint64_t t,
+                      int flags, void *stream);
+template <class Env>
+int launch_steps_fused(const typename Env::Params &p, uint32_t *state, int32_t *action, int32_t *ob, typename Env::Reward *reward,
+                       uint8_t *done, uint32_t *err, int64_t n, uint64_t seed, uint64_t action_seed, uint32_t lane0, uint64_t t,
+                       int k, int flags, int64_t rec, bool gen_first, void *stream);
+
+using Rock1 = RockEnv<1>;
+using Rock2 = RockEnv<2>;
+using BattleShip1 = BattleShipEnv<1>;
+using BattleShip2 = BattleShipEnv<2>;
+using BattleShip3 = BattleShipEnv<3>;
+using BattleShip4 = BattleShipEnv<4>;
+#define POMDP_STEP_LAUNCHERS(X, E)                                                                                          \
+    X template int launch_reset<E>(const E::Params &, uint32_t *, int32_t *, int64_t, uint64_t, uint32_t, uint64_t, void *);  \
+    X template int launch_step<E>(const E::Params &, uint32_t *, const int32_t *, int32_t *, E::Reward *, uint8_t *,          \
+                                  uint32_t *, int64_t, uint64_t, uint32_t, uint64_t, int, void *);                           \
+    X template int launch_step_chain<E>(const E::Params &, uint32_t *, int32_t *, int32_t *, E::Reward *, uint8_t *,          \
+                                        uint32_t *, int64_t, uint64_t, uint64_t, uint32_t, uint64_t, int, void *);
+#define POMDP_FUSED_LAUNCHER(X, E)                                                                                            \
+    X template int launch_steps_fused<E>(const E::Params &, uint32_t *, int32_t *, int32_t *, E::Reward *, uint8_t *,          \
+                                         uint32_t *, int64_t, uint64_t, uint64_t, uint32_t, uint64_t, int, int, int64_t,     \
+                                         bool, void *);
+#define POMDP_EACH_ENV(M, X)                                                                                                  \
+    M(X, Rock1) M(X, Rock2) M(X, StochRock1) M(X, StochRock2) M(X, TagEnv) M(X, BattleShip1) M(X, BattleShip2)                  \
+    M(X, BattleShip3) M(X, BattleShip4) M(X, TigerEnv) M(X, NetworkEnv)
+#ifndef POMDP_NO_EXTERN_LAUNCHERS
+POMDP_EACH_ENV(POMDP_STEP_LAUNCHERS, extern)
+POMDP_EACH_ENV(POMDP_FUSED_LAUNCHER, extern)
+#endif
+
+} // namespace pomdp
+
+using namespace pomdp;
+
+// Resolve (env kind, params) to the env type the kernels are instantiated for, validate the params against what the
+// packed layouts support, and call f(EnvTag<Env>{}, typed params).
+template <class E> struct EnvTag { using Env = E; };
+template <class F>
+static inline int dispatch_env(int env, const void *params, F &&f)
+{
+    switch (env) {
+    case POMDP_ENV_ROCK: {
+        const pomdp_rock_params *p = (const pomdp_rock_params *)params;
+        if (!rock_ok(p)) return POMDP_E_BADPARAMS;
+        if (p->stochastic) return p->num_rocks <= 12 ? f(EnvTag<StochRock1>{}, *p) : f(EnvTag<StochRock2>{}, *p);
+        return p->num_rocks <= 12 ? f(EnvTag<RockEnv<1>>{}, *p) : f(EnvTag<RockEnv<2>>{}, *p);
+    }
+    case POMDP_ENV_TAG: {
+        const pomdp_tag_params *p = (const pomdp_tag_params *)params;
+        if (p->num_opponents < 1 || p->num_opponents > 4) return POMDP_E_BADPARAMS;
+        return f(EnvTag<TagEnv>{}, *p);
+    }
+    case POMDP_ENV_BATTLESHIP: {
+        const pomdp_battleship_params *p = (const pomdp_battleship_params *)params;
+        switch (bs_mask_words(p)) {
+        case 1: return f(EnvTag<BattleShipEnv<1>>{}, *p);
+        case 2: return f(EnvTag<BattleShipEnv<2>>{}, *p);
+        case 3: return f(EnvTag<BattleShipEnv<3>>{}, *p);
+        case 4: return f(EnvTag<BattleShipEnv<4>>{}, *p);
+        default: return POMDP_E_BADPARAMS;
+        }
+    }
+    case POMDP_ENV_TIGER: return f(EnvTag<TigerEnv>{}, *(const pomdp_tiger_params *)params);
+    case POMDP_ENV_NETWORK: {
+        const pomdp_network_params *p = (const pomdp_network_params *)params;
+        if (p->n_machines < 1 || p->n_machines > 32) return POMDP_E_BADPARAMS;
+        // Bernoulli thresholds are numerators of numpy's 53-bit doubles: k53 <= thr.  The fast step compares 32-bit high
+        // words against (thr >> 26) << 5, which wraps for thr >= 2^53 (a probability of 1.0)
+        if ((p->fail_thr | p->fail_nb_thr | p->obs_thr) >> 53) return POMDP_E_BADPARAMS;
+        return f(EnvTag<NetworkEnv>{}, *p);
+    }
+    default: return POMDP_E_BADARG;
+    }
+}
+

@@ -1088,12 +1088,13 @@ def test_collect_row_pitch_through_the_c_abi(env, n, pitch, steps):
 @pytest.mark.parametrize("env,kw,auto,offset", [
     ("rock", {}, False, 0), ("rock", {}, True, 0), ("rock", dict(board_size=15, num_rocks=15), False, 0),
     ("rock", dict(board_size=15, num_rocks=15), True, 0), ("stochrock", {}, True, 0), ("stochrock", {}, False, 0),
-    ("rock", {}, True, 1)],
+    ("rock", {}, True, 1), ("network", {}, True, 0), ("network", {}, False, 0), ("network", dict(n_machines=31, problem_type=3), True, 0),
+    ("network", {}, True, 2)],
     ids=["rock_7_8-frozen", "rock_7_8-auto", "rock_15_15-frozen", "rock_15_15-auto", "stochrock-auto", "stochrock-frozen",
-         "rock_7_8-auto-actions_off_16_bytes"])
+         "rock_7_8-auto-actions_off_16_bytes", "network-auto", "network-frozen", "network_31-auto", "network-auto-actions_off_16_bytes"])
 def test_step_contract_over_a_whole_2_20_batch(oracle_lib, env, kw, auto, offset):
-    """env.step() at 2^20 lanes (step_quad_kernel; with an action tensor that does not start on a 16-byte boundary the
-    general step_kernel) against the oracle over the WHOLE batch, with caller-supplied actions of which a few are out of
+    """env.step() at 2^20 lanes (step_quad_kernel / network_step_quad_kernel; with an action tensor that does not start on
+    a 16-byte boundary the general step_kernel) against the oracle over the WHOLE batch, with caller-supplied actions of which a few are out of
     range and, without auto-reset, with lanes freezing as their episodes end."""
     n, seed, lane0 = 1 << 20, 606, 1 << 12
     e = make_env(env, kw, batch_size=n, seed=seed, lane_offset=lane0, auto_reset=auto, reuse_buffers=True)

@@ -203,12 +203,34 @@ def test_bench_line_as_the_driver_runs_it():
         assert k in r, k
     assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert r["kernel"].startswith("steps_quad_kernel<RockEnv<1>>"), r["kernel"]
-    assert r["kernel_ms"] < 4.0e-3 and r["frac"] > 0.45, r             # profiles: 2.95-3.0 us per step, 0.58-0.60
-    assert d["ms_per_step"] < 5e-3, d["ms_per_step"]                   # by wall clock, launch + sync wake-up included
+    assert r["kernel_ms"] < 3.6e-3 and r["frac"] > 0.5, r              # profiles: 2.85-2.9 us per step of a 20-step launch, 0.62
+    assert d["ms_per_step"] < 4.5e-3, d["ms_per_step"]                 # by wall clock, launch + sync wake-up included
+    # the recorded HBM bytes of THIS launch shape (20 steps) and the VALU-issue roofline beside the HBM one
+    assert r["traffic"] is not None and 0.95 < r["traffic"] / (r["algorithmic_bytes_per_step"] * (1 << 20) * 20) < 1.1, r["traffic"]
+    v = r["valu"]
+    assert v["bound"] == "valu" and v["unit"] == "wave-instructions/s" and abs(v["frac"] - v["achieved"] / v["peak"]) < 1e-9
+    assert 0.4 < v["frac"] <= 1.0 and r["tighter_bound"] in ("valu", "hbm"), v
+    assert len(r["kernel_ms_by_rank"]) == 1
     c = d["cpu_baseline"]
-    for k in ("value", "unit", "cores", "kind", "sample"):
+    for k in ("value", "unit", "cores", "kind", "sample", "by_threads"):
         assert k in c, k
+    assert c["cores"] == max(c["by_threads"], key=lambda t: t["value"])["threads"] and c["value"] > 1e6
     assert d["value"] > 1e8          # the north star's single-GPU target, by a wide margin
+
+
+@pytest.mark.parametrize("mode,env,extra", [("rollout", "rock15", ["--lanes-per-gpu", 2097152, "--steps", 10, "--warmup", 5]),
+                                            ("heuristic", "tag", ["--steps", 128, "--warmup", 64, "--prewarm", 0.5])],
+                         ids=["rollout-c5", "heuristic-tag"])
+def test_compute_bound_modes_report_a_valu_roofline(mode, env, extra):
+    """the fused rollout (configs[4]) and the heuristic-policy loop are bound by instruction issue, not by
+    bytes: their line's roofline is VALU issue — recorded instructions per launch / the launch time of this run, against
+    the SIMDs' issue cycles priced with the kernel's instruction mix — with frac <= 1, and the HBM figure beside it."""
+    d = _bench("--env", env, "--mode", mode, *extra)
+    r = d["roofline"]
+    assert r["bound"] == "valu" and r["unit"] == "wave-instructions/s", r
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.2 < r["frac"] <= 1.0, r
+    assert r["hbm"]["bound"] == "hbm" and r["hbm"]["frac"] < 0.5
+    assert "profiles/" in r["source"] and d["value"] > 1e10
 
 
 def test_bench_self_launches_two_ranks_on_the_one_gpu():
@@ -224,6 +246,9 @@ def test_bench_self_launches_two_ranks_on_the_one_gpu():
     assert d["value"] > 1e8 and "cpu_baseline" not in d
     s = d["strong_scaling"]
     assert s["total_lanes"] == 1 << 20 and s["lanes_per_gpu"] == 1 << 19 and s["value"] > 1e8
+    # two 2^19-lane shards keep up with two 2^20-lane ones (the small-shard kernels of round 3; both ranks share this GPU)
+    assert s["value"] > 0.9 * d["value"], (s["value"], d["value"])
+    assert len(d["roofline"]["kernel_ms_by_rank"]) == 2
 
 
 def test_launcher_picks_the_documented_kernel_per_shard_size():

@@ -4,23 +4,32 @@
 #       working tree with extra defines (e.g. -DPOMDP_QUAD_MIN_LANES=4096); tools/gpu_small_shards.py and
 #       tools/gpu_ab_bench.py take such variants by path
 #   tools/ab_build.sh rev <revA> [revB=working tree] -> gym_pomdp_amd/_lib/libpomdp_hip_a.so / _b.so from two git revisions
+#       (revisions from round 3 on: the library is built by gym_pomdp_amd/_native.py, one object per translation unit)
 set -e
-HIPCC="/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -shared -fPIC"
 mode=$1; shift
+build() {  # <source tree> <output .so> [defines...]
+  local src=$1 out=$2; shift 2
+  (cd $src && python - "$out" "$@" <<'PY'
+import sys
+sys.path.insert(0, ".")
+from gym_pomdp_amd import _native
+print(_native.build(force=True, out=sys.argv[1], defines=sys.argv[2:]))
+PY
+  )
+}
 if [ "$mode" = lib ]; then
   tag=$1; shift
-  $HIPCC "$@" -o gym_pomdp_amd/_lib/libpomdp_hip_$tag.so gym_pomdp_amd/csrc/pomdp_kernels.hip
-  ls -la gym_pomdp_amd/_lib/libpomdp_hip_$tag.so
+  build $PWD $PWD/gym_pomdp_amd/_lib/libpomdp_hip_$tag.so "$@"
 elif [ "$mode" = rev ]; then
   A=$1; B=${2:-WORK}
-  build() {  # <rev> <tag>
+  one() {  # <rev> <tag>
     if [ "$1" = WORK ]; then SRC=$PWD; else SRC=/tmp/ab_$2; rm -rf $SRC; git worktree add -f $SRC $1 >/dev/null 2>&1; fi
-    (cd $SRC && $HIPCC -o $OLDPWD/gym_pomdp_amd/_lib/libpomdp_hip_$2.so gym_pomdp_amd/csrc/pomdp_kernels.hip)
+    build $SRC $PWD/gym_pomdp_amd/_lib/libpomdp_hip_$2.so
     if [ "$1" != WORK ]; then git worktree remove --force $SRC; fi
   }
-  build $A a
-  build $B b
-  ls -la gym_pomdp_amd/_lib/libpomdp_hip_a.so gym_pomdp_amd/_lib/libpomdp_hip_b.so
+  one $A a
+  one $B b
 else
   echo "usage: tools/ab_build.sh lib <tag> [-D...] | rev <revA> [revB]"; exit 1
 fi
+ls -la gym_pomdp_amd/_lib/*.so

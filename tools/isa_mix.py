@@ -3,7 +3,7 @@
 
     python tools/isa_mix.py [--costs profiles/<tag>_valu_microbench.json] [--json out.json] [kernel-name-substring ...]
 
-Compiles gym_pomdp_amd/csrc/pomdp_kernels.hip for gfx950 to assembly text (hipcc --cuda-device-only -S), finds each
+Compiles the translation units of gym_pomdp_amd/csrc/ for gfx950 to assembly text (hipcc --cuda-device-only -S), finds each
 requested kernel, takes its outermost loop with the most instructions (the step loop of the fused kernels, the four-step
 loop of the rollout / heuristic kernels) without the loops nested inside it (they are the 2^-27 tie paths and the
 continuation passes), and counts its VALU instructions by mnemonic.  With a cost table (tools/valu_microbench: shader cycles
@@ -21,12 +21,13 @@ import subprocess
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(REPO, "gym_pomdp_amd", "csrc", "pomdp_kernels.hip")
+CSRC = os.path.join(REPO, "gym_pomdp_amd", "csrc")
+UNITS = ["fused_rock.hip", "fused_tag.hip", "fused_battleship.hip", "fused_misc.hip", "planner.hip"]   # where the kernels of interest live
 DEFAULT = ["steps_quad_kernel<pomdp::RockEnv<1, false>", "steps_quad_kernel<pomdp::RockEnv<2, false>", "rollout_kernel<pomdp::RockEnv<2, false>",
            "rollout_kernel<pomdp::RockEnv<1, false>", "rollout_kernel<pomdp::TagEnv", "heuristic_steps_kernel<pomdp::RockEnv<1, false>, false",
            "heuristic_steps_kernel<pomdp::RockEnv<2, false>, false", "heuristic_steps_kernel<pomdp::TagEnv, false",
            "tag_steps_quad_kernel<true", "network_steps_quad_kernel<2", "steps_quad_generic_kernel<pomdp::TigerEnv",
-           "steps_kernel<pomdp::RockEnv<1, false>, 1, true, true", "steps_kernel<pomdp::BattleShipEnv<4>, 1, true, false"]
+           "steps_kernel<pomdp::RockEnv<1, false>, 1, true, true", "battleship_steps_quad_kernel<4", "battleship_steps_quad_kernel<1"]
 
 # mnemonic -> the measured class that prices it (tools/valu_microbench.hip op names); anything else: DEFAULT_COST
 ALIAS = {
@@ -49,12 +50,22 @@ DEFAULT_COST = 4.0
 
 
 def assembly(path=None):
-    if path and os.path.exists(path):
-        return open(path).read()
-    out = path or "/tmp/pomdp_kernels_gfx950.s"
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "--cuda-device-only",
-                           "-S", "-o", out, SRC], stderr=subprocess.DEVNULL)
-    return open(out).read()
+    """The device assembly of the units (concatenated); `path`: a directory to keep / reuse the .s files in."""
+    from concurrent.futures import ThreadPoolExecutor
+    d = path or "/tmp/pomdp_isa"
+    os.makedirs(d, exist_ok=True)
+
+    def one(u):
+        out = os.path.join(d, u + ".s")
+        src = os.path.join(CSRC, u)
+        if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC)
+                                                                  if f.endswith((".hip", ".h"))):
+            subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+                                   "--cuda-device-only", "-S", "-o", out, src], stderr=subprocess.DEVNULL)
+        return open(out).read()
+
+    with ThreadPoolExecutor(max_workers=len(UNITS)) as ex:
+        return "\n".join(ex.map(one, UNITS))
 
 
 def demangle(names):
@@ -211,7 +222,7 @@ def main():
     ks = kernels_of(assembly(asm))
     names = demangle(list(ks))
     res = {"source": "tools/isa_mix.py: static mix of the hot loop (outermost loop with the most instructions, nested loops left out) of "
-                     "hipcc --offload-arch=gfx950 -O3 -S gym_pomdp_amd/csrc/pomdp_kernels.hip",
+                     "hipcc --offload-arch=gfx950 -O3 -S gym_pomdp_amd/csrc/{fused_*,planner}.hip",
            "costs": costs_path and os.path.relpath(costs_path, REPO), "cost_column": "W4 (four waves per SIMD), rounded to 2 or 4 cycles", "kernels": {}}
     for pat in pats:
         for mangled, lines in ks.items():
