@@ -124,6 +124,9 @@ def parse():
     ap.add_argument("--prewarm", type=float, default=2.0,
                     help="seconds of untimed launches before the W warm-up steps: a GPU coming out of idle runs its first "
                          "~0.1-1 s below full clock (a compute-only kernel like the fused rollout is up to 1.4x slower there)")
+    ap.add_argument("--phase-steps", type=int, default=4096,
+                    help="heuristic mode: untimed steps between reset() and the warm-up, so that the timed region is a fixed "
+                         "stretch of the process with the lanes spread over their episodes")
     ap.add_argument("--fuse", type=int, default=1, choices=[0, 1],
                     help="1: the C driver may run up to 64 consecutive steps inside one launch (steps_kernel: every step's "
                          "outputs still computed and written, state in registers between steps); 0: one launch per step")
@@ -338,18 +341,32 @@ def heuristic_mode(args, gpa, env_id, kwargs, cp, dev, rank, world, label, n, la
     """Every lane runs the reference's heuristic rollout loop (rock.py:557-573): choice(_generate_preferred(history)),
     step, side statistics, history.append — one pomdp_heuristic_steps launch per step."""
     is_rock = env_id == "Rock-v0"
-    env = gpa.make(env_id, batch_size=n, device=dev, seed=args.seed, lane_offset=lane_offset, reuse_buffers=True,
-                   **dict(kwargs, **(dict(use_heuristic=True) if is_rock else {})))
-    env.reset()
-    hist = gpa.History(env)
 
-    def run(k):
-        while k > 0:
-            c = min(k, 128)                  # up to 64 steps per launch
-            env.heuristic_steps(hist, c)
-            k -= c
+    def make():
+        e = gpa.make(env_id, batch_size=n, device=dev, seed=args.seed, lane_offset=lane_offset, reuse_buffers=True,
+                     **dict(kwargs, **(dict(use_heuristic=True) if is_rock else {})))
+        e.reset()
+        return e, gpa.History(e)
 
-    prewarm(args, run, dev)
+    def stepper(e, h):
+        def run(k):
+            while k > 0:
+                c = min(k, 128)              # up to 64 steps per launch
+                e.heuristic_steps(h, c)
+                k -= c
+        return run
+
+    # The cost of a step depends on where the lanes are in their episodes (the first hundred steps after a reset are
+    # CHECK-heavy and cost several times more), so the timed region is a FIXED stretch of the process: reset, --phase-steps
+    # untimed steps (default 4096: lanes are spread over their episodes by then), W warm-up steps, K timed steps — the same
+    # launches whether or not a profiler slows the run down (tools/gpu_pmc_valu.sh records the instruction counters of
+    # exactly these launches).  The clock spin-up (--prewarm seconds) therefore runs on a scratch env.
+    scratch = make()
+    prewarm(args, stepper(*scratch), dev)
+    del scratch
+    env, hist = make()
+    run = stepper(env, hist)
+    run(args.phase_steps)
     run(args.warmup)
     torch.cuda.synchronize(dev)
     cp.barrier()
@@ -376,7 +393,7 @@ def heuristic_mode(args, gpa, env_id, kwargs, cp, dev, rank, world, label, n, la
             "vs_baseline": None, "dtype": "int32 (+ f64 side statistics)", "data": "synthetic",
             "config": {"workload": "%s batch=%d lanes per GPU, every lane follows _generate_preferred(history) "
                                    "(use_heuristic=True), auto-reset, up to 64 steps per fused launch" % (label, n),
-                       "lanes_per_gpu": n, "mean_history_size": float(hist._size.float().mean().item()),
+                       "lanes_per_gpu": n, "phase_steps": args.phase_steps, "mean_history_size": float(hist._size.float().mean().item()),
                        "parallelism": "lane-shard x%d, no collectives" % world},
             "roofline": heuristic_roofline(args, n, kern_ms, achieved, alg)}), flush=True)
     cp.close()

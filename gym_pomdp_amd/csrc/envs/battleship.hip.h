@@ -194,7 +194,7 @@ struct BattleShipEnv {
     // 171-176).  The placement test and mark_ship are the mask arithmetic of reset_where(); the column patterns come from
     // `vp` (LDS copy of p.vpat: one 16-byte read per lane whatever its ship length).  Lanes with go == false idle through.
     // Every lane brings its own key (the call counter at which its previous board was dealt).
-    struct SeqTables { uint32_t vp[12][4]; };
+    struct SeqTables { uint32_t vp[16][4]; };   // rows 0 .. 11 hold p.vpat
     static __device__ __forceinline__ void stage_seq(SeqTables &t, const Params &p, int tid)
     {
         if (tid < 48) t.vp[tid >> 2][tid & 3] = p.vpat[(tid >> 2) % 12][tid & 3];
@@ -231,13 +231,13 @@ struct BattleShipEnv {
     {
         const int X = c.X, len = b.len, a0 = b.a0;
         const bool live = len >= 2;
-        const uint32_t dir = w & 3u;                                           // Compass N E S W
-        const int dx = (dir == 1u) - (dir == 3u), dy = (dir == 0u) - (dir == 2u);
+        const uint32_t dir2 = (w & 3u) << 1;                                   // Compass N E S W: (dx, dy) = (0,1) (1,0) (0,-1) (-1,0),
+        const int dx = __builtin_amdgcn_sbfe(0xC4, dir2, 2u), dy = __builtin_amdgcn_sbfe(0x31, dir2, 2u);   // 2-bit signed fields of two constants
         const int py = (int)(((uint32_t)a0 * c.inv_x) >> 16), px = a0 - py * X;
         const int ex = px + (len + 1) * dx, ey = py + (len + 1) * dy, stride = dy * X + dx;
         const bool inside = (unsigned)ex < (unsigned)X && (unsigned)ey < (unsigned)c.Y;
         const int lo = stride > 0 ? a0 : a0 + len * stride;
-        const uint32_t *v1 = t.vp[(len + 1) % 12], *v0 = t.vp[len % 12];
+        const uint32_t *v1 = t.vp[(len + 1) & 15], *v0 = t.vp[len & 15];         // len <= max_len <= 10 (bs_mask_words)
         const uint32_t w1[4] = {v1[0], v1[1], v1[2], v1[3]}, w0[4] = {v0[0], v0[1], v0[2], v0[3]};
         const M vpat1 = mask_of(w1), vpat0 = mask_of(w0);
         const M test = (M)((dx != 0 ? (M)((1ull << (len + 1)) - 1ull) : vpat1) << (lo & (MBITS - 1)));

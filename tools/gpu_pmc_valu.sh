@@ -23,9 +23,9 @@ run() {   # name, bench args...
 run rollout_rock15 --env rock15 --mode rollout --lanes-per-gpu 2097152 --steps 20 --warmup 10
 run rollout_rock --env rock --mode rollout --lanes-per-gpu 2097152 --steps 20 --warmup 10
 run rollout_tag --env tag --mode rollout --lanes-per-gpu 2097152 --steps 20 --warmup 10
-run heuristic_rock --env rock --mode heuristic --prewarm 0 --warmup 128 --steps 512
-run heuristic_rock15 --env rock15 --mode heuristic --prewarm 0 --warmup 128 --steps 512
-run heuristic_tag --env tag --mode heuristic --prewarm 0 --warmup 128 --steps 512
+run heuristic_rock --env rock --mode heuristic --prewarm 0 --warmup 128 --steps 1024
+run heuristic_rock15 --env rock15 --mode heuristic --prewarm 0 --warmup 128 --steps 1024
+run heuristic_tag --env tag --mode heuristic --prewarm 0 --warmup 128 --steps 1024
 for e in rock rock15 tag tiger network battleship; do
   run step64_$e --env $e --prewarm 0 --warmup 64 --steps 640 --seeds 0 --repeats 1 --no-cpu-baseline
 done

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One call that produces everything kept under profiles/ for a round (text only; the rocpd databases stay in /tmp).
-# usage: tools/gpu_profile_round.sh <tag>      -> gpurun_out/<tag>/{headline.txt,headline_steps20.txt,traffic.json,pmc_valu.txt,pmc_envs.txt,envs.txt,bench*.json,small_shards.txt}
+# usage: tools/gpu_profile_round.sh <tag>      -> gpurun_out/<tag>/{headline.txt,headline_steps20.txt,traffic.json,pmc_rock.txt,pmc_envs.txt,envs.txt,bench*.json(l),small_shards.txt,single_step.txt,valu_microbench.json,pmc_valu.json,pmc_valu.txt}
 TAG=${1:-round}
 export TMPDIR=/tmp
 REPO=$PWD
@@ -22,10 +22,10 @@ python $REPO/tools/rocpd_summary.py $W --traffic $OUT/traffic.json "RockSample(7
 cd $REPO
 (echo "# rocprofv3 --pmc passes over 'python bench.py --env rock --prewarm 0 --warmup 64 --steps 640 --no-cpu-baseline' (tools/gpu_pmc_env.sh rock), MI355X";
  echo "# divide SQ_INSTS_* by SQ_WAVES for per-wave counts (128 lanes at two lanes per thread, 256 at four); steps_kernel launches are 64 steps each";
- bash tools/gpu_pmc_env.sh rock 2>/dev/null) > $OUT/pmc_valu.txt
+ bash tools/gpu_pmc_env.sh rock 2>/dev/null) > $OUT/pmc_rock.txt
 # 2b. instructions per wave-step of every env's fused launch (one PMC pass each)
 : > $OUT/pmc_envs.txt
-for e in rock rock15 tag battleship tiger network; do
+for e in rock rock15 tag battleship battleship5 tiger network; do
   (echo "##### tools/gpu_pmc_quick.sh $e"; bash tools/gpu_pmc_quick.sh $e 2>/dev/null) >> $OUT/pmc_envs.txt
 done
 # 3. every env, the fused rollouts and the heuristic policy: kernel traces
@@ -52,6 +52,16 @@ timeout 600 python bench.py 2>/dev/null | tail -1 > $OUT/bench.json
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 > $OUT/bench_steps20.json
 timeout 600 python bench.py --gpus 2 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_gpus2.json
 : > $OUT/bench_envs.jsonl
-for e in rock15 tag battleship tiger network; do timeout 600 python bench.py --env $e --no-cpu-baseline 2>/dev/null | tail -1 >> $OUT/bench_envs.jsonl; done
+for e in rock15 stochrock tag battleship battleship5 tiger network; do timeout 600 python bench.py --env $e --no-cpu-baseline 2>/dev/null | tail -1 >> $OUT/bench_envs.jsonl; done
+: > $OUT/bench_modes.jsonl
+timeout 600 python bench.py --env rock15 --mode rollout --lanes-per-gpu 2097152 --steps 200 --warmup 100 2>/dev/null | tail -1 >> $OUT/bench_modes.jsonl
+timeout 600 python bench.py --env rock --mode rollout --lanes-per-gpu 2097152 --steps 200 --warmup 100 2>/dev/null | tail -1 >> $OUT/bench_modes.jsonl
+for e in rock rock15 tag; do timeout 600 python bench.py --env $e --mode heuristic --steps 1024 --warmup 128 2>/dev/null | tail -1 >> $OUT/bench_modes.jsonl; done
 timeout 600 python tools/gpu_small_shards.py - 2>/dev/null > $OUT/small_shards.txt
+timeout 600 python tools/gpu_single_step_probe.py - 20 2>/dev/null > $OUT/single_step.txt
+# 5. the VALU-issue counters of the compute-bound kernels and of both timed launch shapes (tools/gpu_pmc_valu.sh), and the
+#    instruction costs they are priced with
+tools/valu_microbench > $OUT/valu_microbench.json 2>/dev/null
+bash tools/gpu_pmc_valu.sh ${TAG}_valu > $OUT/pmc_valu.log 2>&1
+cp $REPO/gpurun_out/${TAG}_valu/pmc_valu.json $REPO/gpurun_out/${TAG}_valu/pmc_valu.txt $OUT/ 2>/dev/null
 ls -la $OUT

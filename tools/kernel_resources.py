@@ -9,9 +9,19 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 flt = [a for a in sys.argv[1:] if not a.startswith("-D")]
 defs = [a for a in sys.argv[1:] if a.startswith("-D")]
-cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-c", "-o", "/dev/null",
-       os.path.join(REPO, "gym_pomdp_amd/csrc/pomdp_kernels.hip"), "-Rpass-analysis=kernel-resource-usage"] + defs
-out = subprocess.run(cmd, capture_output=True, text=True).stderr
+sys.path.insert(0, REPO)
+from gym_pomdp_amd import _native  # noqa: E402
+from concurrent.futures import ThreadPoolExecutor  # noqa: E402
+
+
+def remarks(unit):
+    cmd = ["/opt/rocm/bin/hipcc"] + _native.HIPCC_FLAGS + ["-c", "-o", "/dev/null", os.path.join(REPO, "gym_pomdp_amd/csrc", unit),
+                                                          "-Rpass-analysis=kernel-resource-usage"] + defs
+    return subprocess.run(cmd, capture_output=True, text=True).stderr
+
+
+with ThreadPoolExecutor(max_workers=len(_native.UNITS)) as ex:
+    out = "\n".join(ex.map(remarks, _native.UNITS))
 cur, rows = None, []
 for line in out.splitlines():
     m = re.search(r"remark: +(.*?) \[-Rpass", line)

@@ -1,6 +1,9 @@
 // microbench.hip — standalone A/B harness for the RockSample step kernel (not part of the product).
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o /tmp/microbench tools/microbench.hip
-#include "../gym_pomdp_amd/csrc/pomdp_kernels.hip"
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -o tools/microbench tools/microbench.hip \
+//        -Lgym_pomdp_amd/_lib -lpomdp_hip -Wl,-rpath,'$ORIGIN/../gym_pomdp_amd/_lib'
+// (the product's kernel templates come from its headers, its launchers and C ABI from the library it links against)
+#include "../gym_pomdp_amd/csrc/step_impl.hip.h"
+#include "../gym_pomdp_amd/csrc/fused_impl.hip.h"
 #include <cstdio>
 #include <cstdlib>
 #include <vector>

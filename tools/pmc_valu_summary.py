@@ -31,14 +31,22 @@ def db_of(d):
     return f[0] if f else None
 
 
-def counters(db):
-    """-> {kernel: {counter: (dispatches, avg value, avg duration ns)}} for the kernels of interest."""
+def counters(db, last=None):
+    """-> {kernel: {counter: (dispatches, avg value, avg duration ns)}} for the kernels of interest; `last`: only the last
+    that many dispatches of each kernel (the timed region of a run whose earlier launches are in another phase)."""
     c = sqlite3.connect(db)
     out = {}
     for pat in KERNELS:
-        for k, cn, n, a, d in c.execute("select kernel_name, counter_name, count(*), avg(value), avg(duration) from "
-                                        "counters_collection where kernel_name like ? group by kernel_name, counter_name",
-                                        (pat,)):
+        if last is None:
+            rows = c.execute("select kernel_name, counter_name, count(*), avg(value), avg(duration) from "
+                             "counters_collection where kernel_name like ? group by kernel_name, counter_name", (pat,)).fetchall()
+        else:
+            rows = []
+            for k, cn in c.execute("select distinct kernel_name, counter_name from counters_collection where kernel_name like ?", (pat,)):
+                v = c.execute("select value, duration from counters_collection where kernel_name=? and counter_name=? "
+                              "order by start desc limit ?", (k, cn, last)).fetchall()
+                rows.append((k, cn, len(v), sum(x[0] for x in v) / len(v), sum(x[1] for x in v) / len(v)))
+        for k, cn, n, a, d in rows:
             out.setdefault(k, {})[cn] = (n, a, d)
     return out
 
@@ -67,11 +75,16 @@ def main():
             continue
         name = os.path.basename(wd)
         merged = {}
+        last = None
+        if name.startswith("heuristic_"):          # the timed region = the last ceil(K / 64) launches of the run (bench.py: heuristic_mode)
+            import re
+            m = re.search(r"--steps (\d+)", cmds.get(name, ""))
+            last = -(-int(m.group(1)) // 64) if m else None
         for sub in ("p1", "p2"):
             db = db_of(os.path.join(wd, sub))
             if not db:
                 continue
-            for k, v in counters(db).items():
+            for k, v in counters(db, last).items():
                 merged.setdefault(k, {}).update({cn: (n, a, d, sub) for cn, (n, a, d) in v.items()})
         entry = {"command": cmds.get(name), "kernels": {}}
         for k, v in merged.items():
