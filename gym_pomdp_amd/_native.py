@@ -10,7 +10,8 @@ import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _REPO = os.path.dirname(_PKG)
-LIB_PATH = os.path.join(_PKG, "_lib", "libpomdp_hip.so")
+# GYM_POMDP_AMD_LIB: another build of the same library (tools/ab_build.sh variants for same-box A/B runs)
+LIB_PATH = os.environ.get("GYM_POMDP_AMD_LIB") or os.path.join(_PKG, "_lib", "libpomdp_hip.so")
 # one object per translation unit (built in parallel), linked into one shared library
 UNITS = ["api.hip", "step_rock.hip", "step_other.hip", "fused_rock.hip", "fused_stochrock.hip", "fused_tag.hip",
          "fused_battleship.hip", "fused_misc.hip", "planner.hip"]

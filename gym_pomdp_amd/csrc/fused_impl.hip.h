@@ -84,7 +84,11 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
         Env::build_tab(tab, sh, p, (int)threadIdx.x);
         __syncthreads();
     }
-    for (int s = 0; s < k_steps; ++s) {
+    wait_loads();
+    const LoopPrio prio(k_steps);
+    #pragma unroll 1
+    for (int seg = 0, s = 0; seg < 4; ++seg)                               // four priority segments (LoopPrio)
+    for (const int seg_end = prio.segment(seg); s < seg_end; ++s) {
         RngKey key = key0, akey = akey0;
         key.t_lo = (uint32_t)(t0 + (uint64_t)s); key.t_hi = (uint32_t)((t0 + (uint64_t)s) >> 32);
         akey.t_lo = (uint32_t)(ta0 + (uint64_t)s); akey.t_hi = (uint32_t)((ta0 + (uint64_t)s) >> 32);
@@ -186,6 +190,8 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
     using S = typename Env::S;
     __shared__ typename Env::Shared sh;
     __shared__ typename Env::StepTab tab;
+    TL(0);
+    TL_HW();
     const uint32_t l0 = blockIdx.x * (uint32_t)(4 * BLOCK) + 4u * threadIdx.x;   // this thread's first lane within the shard
     const uint32_t glane0 = lane0 + l0;                                          // ... and its global lane id (a multiple of 4)
     uint32_t *action_w = reinterpret_cast<uint32_t *>(action) + l0, *ob_w = reinterpret_cast<uint32_t *>(ob) + l0;
@@ -208,12 +214,18 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
     action_w += rec;
     Env::stage(sh, p, (int)threadIdx.x);
     __syncthreads();
+    TL(1);
     Env::build_tab(tab, sh, p, (int)threadIdx.x);
     __syncthreads();
+    TL(2);
     const int K = p.num_rocks;
     const uint32_t start = (uint32_t)p.start_x | ((uint32_t)p.start_y << 4);
     const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo, ta0 = ((uint64_t)akey0.t_hi << 32) | akey0.t_lo;
-    for (int s = 0; s < k_steps; ++s) {
+    wait_loads();
+    const LoopPrio prio(k_steps);
+    #pragma unroll 1
+    for (int seg = 0, s = 0; seg < 4; ++seg)                               // four priority segments (LoopPrio)
+    for (const int seg_end = prio.segment(seg); s < seg_end; ++s) {
         RngKey key = key0;
         key.t_lo = (uint32_t)(t0 + (uint64_t)s); key.t_hi = (uint32_t)((t0 + (uint64_t)s) >> 32);
         const uint64_t ta = ta0 + (uint64_t)s;
@@ -259,10 +271,16 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
         action_w += rec; ob_w += rec; reward_w += rec; done_w += rec / 4;
     }
     // the state is the loop's carry: it reaches memory once
+    TL(3);
     st_stream4(state + l0, (uint32_t)st[0].s, (uint32_t)st[1].s, (uint32_t)st[2].s, (uint32_t)st[3].s);
     if (W == 2)
         st_stream4(state + n + l0, (uint32_t)((uint64_t)st[0].s >> 32), (uint32_t)((uint64_t)st[1].s >> 32),
                    (uint32_t)((uint64_t)st[2].s >> 32), (uint32_t)((uint64_t)st[3].s >> 32));
+#ifdef POMDP_DEV_TIMELINE
+    TL(4);
+    __builtin_amdgcn_s_waitcnt(0);
+    TL(5);
+#endif
 }
 
 // Tag (one opponent) with a quad per thread: the policy's ACTION block is the thread's own, the flights of failed TAGs
@@ -303,7 +321,11 @@ __global__ __launch_bounds__(BLOCK) void tag_steps_quad_kernel(uint32_t *__restr
         __syncthreads();
     }
     const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo, ta0 = ((uint64_t)akey0.t_hi << 32) | akey0.t_lo;
-    for (int s = 0; s < k_steps; ++s) {
+    wait_loads();
+    const LoopPrio prio(k_steps);
+    #pragma unroll 1
+    for (int seg = 0, s = 0; seg < 4; ++seg)                               // four priority segments (LoopPrio)
+    for (const int seg_end = prio.segment(seg); s < seg_end; ++s) {
         RngKey key = key0;
         key.t_lo = (uint32_t)(t0 + (uint64_t)s); key.t_hi = (uint32_t)((t0 + (uint64_t)s) >> 32);
         const uint64_t ta = ta0 + (uint64_t)s;
@@ -434,7 +456,11 @@ __global__ __launch_bounds__(BLOCK) void network_steps_quad_kernel(uint32_t *__r
     const uint32_t all_up = p.n_machines >= 32 ? 0xFFFFFFFFu : ((1u << p.n_machines) - 1u);
     const int M2 = 2 * p.n_machines;
     const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo, ta0 = ((uint64_t)akey0.t_hi << 32) | akey0.t_lo;
-    for (int s = 0; s < k_steps; ++s) {
+    wait_loads();
+    const LoopPrio prio(k_steps);
+    #pragma unroll 1
+    for (int seg = 0, s = 0; seg < 4; ++seg)                               // four priority segments (LoopPrio)
+    for (const int seg_end = prio.segment(seg); s < seg_end; ++s) {
         RngKey key = key0;
         key.t_lo = (uint32_t)(t0 + (uint64_t)s); key.t_hi = (uint32_t)((t0 + (uint64_t)s) >> 32);
         const uint64_t ta = ta0 + (uint64_t)s;
@@ -664,7 +690,14 @@ __global__ __launch_bounds__(BLOCK) void battleship_steps_quad_kernel(uint32_t *
             }
         }
     };
-    for (int s = 0; s < k_steps; ++s) {
+    wait_loads();
+    // The ladder from 32 steps per launch only: the board builders that follow the loop are instruction-bound where the loop
+    // is store-bound, and waves that leave the loop at different times build their boards under the others' stores (10x10,
+    // 20 steps per launch: 5.8 us per step without the ladder, 6.3 with it; 5x5 at 64 steps: 5.0 without, 4.3 with).
+    const LoopPrio prio(k_steps, k_steps >= 32);
+    #pragma unroll 1
+    for (int seg = 0, s = 0; seg < 4; ++seg)                               // four priority segments (LoopPrio)
+    for (const int seg_end = prio.segment(seg); s < seg_end; ++s) {
         uint32_t ow[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) ow[j] = occ_lds[a_cur[j] >> 5][j][tid];   // the ship-mask word this shot tests
@@ -757,7 +790,11 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_generic_kernel(uint32_t *__r
     Env::stage(sh, p, (int)threadIdx.x);
     __syncthreads();
     const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo, ta0 = ((uint64_t)akey0.t_hi << 32) | akey0.t_lo;
-    for (int s = 0; s < k_steps; ++s) {
+    wait_loads();
+    const LoopPrio prio(k_steps);
+    #pragma unroll 1
+    for (int seg = 0, s = 0; seg < 4; ++seg)                               // four priority segments (LoopPrio)
+    for (const int seg_end = prio.segment(seg); s < seg_end; ++s) {
         RngKey key = key0;
         key.t_lo = (uint32_t)(t0 + (uint64_t)s); key.t_hi = (uint32_t)((t0 + (uint64_t)s) >> 32);
         const uint64_t ta = ta0 + (uint64_t)s;

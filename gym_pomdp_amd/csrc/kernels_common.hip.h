@@ -33,10 +33,16 @@ static inline int grid_for(int64_t n)
 static inline unsigned blocks_for(int64_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
 // below this many lanes one lane per thread is as fast or faster (measured: tools/microbench.hip at 2^16 .. 2^19)
 #ifdef POMDP_DEV_TIMELINE                                      // dev builds only (tools/ab_build.sh): per-workgroup phase stamps
-__device__ uint64_t *g_timeline = nullptr;
+static __device__ uint64_t *g_timeline = nullptr;           // one copy per translation unit: each exports its own setter
 #define TL(k) do { if (threadIdx.x == 0 && g_timeline) g_timeline[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+// slot 6: HW_REG_HW_ID (wave / SIMD / CU / SH / SE ids), slot 7: HW_REG_XCC_ID — which CU of which XCD ran the workgroup
+#define TL_HW() do { if (threadIdx.x == 0 && g_timeline) { g_timeline[blockIdx.x * 8 + 6] = __builtin_amdgcn_s_getreg((31 << 11) | 4); \
+                                                             g_timeline[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_getreg((31 << 11) | 20); } } while (0)
+#define POMDP_DEV_TIMELINE_SETTER(name) \
+    extern "C" int name(uint64_t *buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(pomdp::g_timeline), &buf, sizeof(buf)); }
 #else
 #define TL(k) do { } while (0)
+#define TL_HW() do { } while (0)
 #endif
 #ifdef POMDP_LPT2_MIN_LANES                                   // same-box A/B builds (tools/ab_build.sh)
 constexpr int64_t LPT2_MIN_LANES = POMDP_LPT2_MIN_LANES;
@@ -312,6 +318,58 @@ static __device__ __forceinline__ uint4 quad_transpose4(const uint4 &v, uint32_t
     const uint32_t w1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)u1, 0x4E, 0xF, 0xF, false);
     return make_uint4(b1 ? w0 : p0, b1 ? w1 : p1, b1 ? q0 : w0, b1 ? q1 : w1);
 }
+// Every load issued so far has landed.  Placed in front of a storing loop: gfx9 counts loads and stores on one counter, and
+// a compiler that cannot prove the pre-loop loads settled waits on vmcnt(0) INSIDE the loop — i.e. for the previous step's
+// stores, every step.  (It settles them in the pre-header by itself only when the loop has a single entry; the priority
+// ladder below gives it two.)  s_waitcnt vmcnt(0) expcnt(7) lgkmcnt(15) on gfx9.
+static __device__ __forceinline__ void wait_loads() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+
+// Issue priority of a wave inside a fused step loop (round 3, profiles/r03_prio_timeline.txt).  A SIMD's arbiter serves its
+// OLDEST wave first: of the four workgroups a CU holds, the first ran its 64 steps almost as if alone (1.3 us per step, done
+// after 83 us) and the last one finished at 191 us; once the early workgroups are gone the SIMDs run with three, two, one
+// wave and lose throughput — the launch took 159 us where the median workgroup needed 130.  s_setprio outranks age, so a
+// wave lowers its priority as it nears the end of the launch: with `rem` steps to go it runs at priority 3 above 7k/16
+// steps, 2 above 3k/16, 1 above k/16, else 0.  The waves that are ahead wait at each threshold (still filling the issue
+// slots the others leave) until the others are as close to the end, and a SIMD's waves finish within a step or two of
+// each other: RockSample 159 -> 141 us per 64-step launch, 59 -> 54 per 20-step launch (thresholds measured at k = 16 ..
+// 64: the geometric ladder beats quartiles, and it scales with k).
+#ifndef POMDP_PRIO_MIN_WGS                                     // same-box A/B builds (tools/ab_build.sh)
+#define POMDP_PRIO_MIN_WGS (2 * 256)
+#endif
+struct LoopPrio {
+    int k, t0, t1, t2;
+    bool on;
+    // Only where a SIMD holds two or more of the launch's waves (256-thread workgroups: from two per CU; measured at 2^17
+    // lanes with one lane per thread and at 2^19 with a quad: 3-8 % either way); a lone wave has nobody to yield to.
+    __device__ __forceinline__ explicit LoopPrio(int k_steps, bool enable = true)
+        : k(k_steps), t0(k_steps >> 4 > 0 ? k_steps >> 4 : 1), t1((3 * k_steps) >> 4), t2((7 * k_steps) >> 4)
+    {
+#ifdef POMDP_NO_LOOP_PRIO                                     // same-box A/B builds (tools/ab_build.sh)
+        on = false;
+#else
+        on = enable && gridDim.x >= (unsigned)POMDP_PRIO_MIN_WGS;
+#endif
+    }
+    // The step loop runs as four consecutive segments, one per priority: segment `seg` sets its priority and returns the
+    // step at which it ends (`unit`: the loop's stride — the heuristic loop advances four steps at a time).  The ladder
+    // lives OUTSIDE the step loop on purpose: as a compare-and-branch chain inside it, it cost a lone wave five taken
+    // branches per step (Tiger, 2^14 lanes: 0.26 -> 0.34 us per step) and gave the loop a second entry, after which the
+    // compiler waited for the pre-loop loads inside the loop (wait_loads above).
+    template <int UNIT = 1>
+    __device__ __forceinline__ int segment(int seg) const
+    {
+        if (!on) return k;                                 // one segment, the dispatch priority
+        int end;
+        switch (seg) {
+        case 0: __builtin_amdgcn_s_setprio(3); end = k - t2; break;
+        case 1: __builtin_amdgcn_s_setprio(2); end = k - t1; break;
+        case 2: __builtin_amdgcn_s_setprio(1); end = k - t0; break;
+        default: __builtin_amdgcn_s_setprio(0); return k;
+        }
+        return UNIT == 1 ? end : (end + UNIT - 1) / UNIT * UNIT;
+    }
+};
+
 template <int J> static __device__ __forceinline__ uint32_t comp(const uint4 &v) { return J == 0 ? v.x : J == 1 ? v.y : J == 2 ? v.z : v.w; }
 
 template <class Fin, class = void> struct quad_policy_of : std::false_type {};

@@ -214,3 +214,21 @@ def test_stream_and_device_handles_fall_back_to_the_public_api():
     assert callable(base._raw_stream) and callable(base._current_device)
     src = open(os.path.join(REPO, "gym_pomdp_amd", "envs", "base.py")).read()
     assert src.count("torch._C") == 1, "private torch internals are touched in _resolve_fast_handles only"
+
+
+def test_fused_step_loops_never_wait_for_their_own_stores():
+    """Static property of the compiled kernels (tools/check_loop_waits.py, no GPU needed): inside the step loop of the
+    headline kernel and of its small-shard sibling there is no `s_waitcnt vmcnt` — gfx9 counts loads and stores on one
+    counter, so such a wait would stall every step on the previous step's stores — and the priority ladder (LoopPrio:
+    four s_setprio, one per segment) is compiled in, outside the step loop."""
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import check_loop_waits as clw
+    res = clw.loop_waits(clw.assembly("fused_rock.hip"))
+    seen = 0
+    for name, (waits, prio) in res.items():
+        if "steps_quad_kernel<pomdp::RockEnv<1, false>" in name or "steps_kernel<pomdp::RockEnv<1, false>, 1, true, true>" in name:
+            seen += 1
+            assert waits == [], (name, waits)
+            assert prio == 4, (name, prio)
+    assert seen == 2, sorted(res)
