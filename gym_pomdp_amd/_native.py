@@ -19,7 +19,7 @@ HEADERS = ["kernels_common.hip.h", "step_impl.hip.h", "fused_impl.hip.h", "envs.
            "envs/rock.hip.h", "envs/tag.hip.h", "envs/battleship.hip.h", "envs/tiger.hip.h", "envs/network.hip.h"]
 SOURCES = [os.path.join(_PKG, "csrc", f) for f in UNITS + HEADERS]
 HEADER = os.path.join(_REPO, "include", "pomdp_hip.h")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 POMDP_AUTO_RESET = 1
 POMDP_FUSE_STEPS = 2

@@ -13,11 +13,15 @@ namespace pomdp {
 //                          i.e. bit 2 j + 1 of the element: ONE 32-bit word carries the statuses of all K <= 16 rocks,
 //                          already at the upper bit of each rock's 2-bit code (codes = word & 0xAAAAAAAA);
 //   step   (stream STEP):  double j (RockEnv: j = 0 the sensor; StochasticRockEnv: j = 0 the action gate, j = 1 the
-//                          sensor): H = block 2 j, L = block 2 j + 1.
+//                          sensor): H = block 2 j, L = block 2 j + 1;
+//   auto-reset (the reset that follows a done step inside that step's call counter): the same rotated pair, taken from
+//                          the step's own SENSOR blocks — stream STEP, blocks b and b + 1, b = SENSOR_BLOCK — instead of
+//                          stream RESET.  A step never makes both draws (a CHECK does not end the episode, rock.py:171-175,
+//                          193), so the word is consumed exactly once either way.
 // A comparison k53 <= thr is decided by H alone unless (H >> 5) == (thr >> 26), which happens with probability 2^-27
-// per draw; only then is the L block generated.  So a quad's resets cost ONE block, like its sensor draws and its policy
-// words: a thread that owns a quad has all three thread-local (steps_quad_kernel), a lane of a one-lane-per-thread loop
-// computes each of them once per four steps (quad_transpose4).
+// per draw; only then is the L block generated.  So a quad's step — sensor draws AND the fresh episodes of its done lanes —
+// costs ONE block besides its policy words: a thread that owns a quad has both thread-local (steps_quad_kernel), a lane of
+// a one-lane-per-thread loop computes each once per four steps (quad_transpose4).
 //
 // STOCH selects StochasticRockEnv (rock.py:428-504).
 template <int W, bool STOCH = false> // W = state words per lane: 1 (K <= 12) or 2
@@ -48,6 +52,7 @@ struct RockEnv {
     // what the lane step leaves for the deferred sensor draw (pooled launches fetch H from the wave's task pass)
     struct Aux { uint32_t th; uint8_t r; bool good, want; };   // th: sensor threshold (high 27 bits) of a CHECK of rock r
 
+    static constexpr uint32_t SENSOR_BLOCK = STOCH ? 2u : 0u;   // high words of the sensor draw (StochasticRock: block 0 gates the action)
     static constexpr uint32_t LO_MASK = (1u << 26) - 1u;
     static constexpr uint32_t HALF_HI = 1u << 26;            // 2^52 >> 26: the reset's "U > .5" threshold
 
@@ -122,19 +127,24 @@ struct RockEnv {
         return kh > HALF_HI ? 2u : (kh < HALF_HI ? 0u : 3u);
     }
     static __device__ __forceinline__ uint32_t rock_code_lo(uint32_t L) { return (L >> 6) ? 2u : 1u; }   // kh == 2^26 exactly
-    // block `j2` (0 = high words, 1 = low words) of the RESET stream of lane's quad
+    // block `j2` (0 = high words, 1 = low words) of the rotated pair a reset of lane's quad reads: stream RESET for a
+    // reset() call of its own; AUTO (the reset inside a done step's call counter): the step's sensor blocks
+    template <bool AUTO = false>
     static __device__ __forceinline__ uint4 reset_block(const RngKey &key, uint32_t lane, uint32_t j2)
     {
-        return philox4x32_10(lane >> 2, key.t_lo, key.t_hi, ((uint32_t)POMDP_STREAM_RESET << 24) | j2, key.k0, key.k1);
+        const uint32_t c3 = AUTO ? (((uint32_t)POMDP_STREAM_STEP << 24) | (SENSOR_BLOCK + j2)) : (((uint32_t)POMDP_STREAM_RESET << 24) | j2);
+        return philox4x32_10(lane >> 2, key.t_lo, key.t_hi, c3, key.k0, key.k1);
     }
     // The 2-bit codes of all K <= 16 rocks (bit pair j = rock j) of lane `lane`'s fresh episode from its RESET word `w`
     // (element lane & 3 of reset_block(key, lane, 0)).  Rock j reads the word rotated right by 2 j + 2: its top bit is bit
     // 2 j + 1 of the word, and the code (status + 1) is twice that bit — the word masked to its odd bits IS the code
     // word — unless the rotated word lies in the 32 values just above 2^31: the tie the low word decides.
+    template <bool AUTO>
     static __device__ __forceinline__ uint32_t reset_codes(const RngKey &key, uint32_t lane, int K)
     {
-        return reset_codes(elem(reset_block(key, lane, 0u), lane & 3u), key, lane, K);
+        return reset_codes<AUTO>(elem(reset_block<AUTO>(key, lane, 0u), lane & 3u), key, lane, K);
     }
+    template <bool AUTO>
     static __device__ __forceinline__ uint32_t reset_codes(uint32_t w, const RngKey &key, uint32_t lane, int K)
     {
         uint32_t codes = w & 0xAAAAAAAAu;
@@ -146,7 +156,16 @@ struct RockEnv {
             for (int j = 0; j < K; ++j) {
                 const uint32_t rot = (uint32_t)(2 * j + 2) & 31u;
                 if (rock_code_hi(__builtin_rotateright32(w, rot)) != 3u) continue;
-                if (!have_lo) { l = elem(reset_block(key, lane, 1u), lane & 3u); have_lo = true; }
+                if (!have_lo) {
+                    // The low-word block of an auto-reset IS the block a sensor tie of the same step reads: left as one
+                    // expression, the compiler merges the two 2^-27 paths' Philox calls and computes the block
+                    // unconditionally, every step (one lane per thread, 2^18 lanes: 0.79 -> 0.97 us per step).  The lane id
+                    // passes through an opaque register move, so this call stays where it is needed.
+                    uint32_t lane_ = lane;
+                    asm volatile("" : "+v"(lane_));
+                    l = elem(reset_block<AUTO>(key, lane_, 1u), lane & 3u);
+                    have_lo = true;
+                }
                 const uint32_t c = rock_code_lo(__builtin_rotateright32(l, rot));
                 codes = (codes & ~(3u << (2 * j))) | (c << (2 * j));
             }
@@ -159,7 +178,8 @@ struct RockEnv {
         return philox4x32_10(lane >> 2, key.t_lo, key.t_hi, ((uint32_t)POMDP_STREAM_STEP << 24) | j2, key.k0, key.k1);
     }
 
-    // the same for the four lanes of a quad from its RESET block (R[e] = lane first + e's word): ONE branch for the ties
+    // the same for the four lanes of a quad inside a step (auto-reset) from its sensor block (R[e] = lane first + e's word):
+    // ONE branch for the ties
     static __device__ __forceinline__ void reset_codes4(const uint32_t (&R)[4], const RngKey &key, uint32_t first, int K,
                                                         uint32_t (&codes)[4])
     {
@@ -168,7 +188,7 @@ struct RockEnv {
         for (int e = 0; e < 4; ++e) codes[e] = R[e] & 0xAAAAAAAAu & exist;
         if (min(min(__popc(R[0]), __popc(R[1])), min(__popc(R[2]), __popc(R[3]))) <= 6) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) codes[e] = reset_codes(R[e], key, first + (uint32_t)e, K);
+            for (int e = 0; e < 4; ++e) codes[e] = reset_codes<true>(R[e], key, first + (uint32_t)e, K);
         }
     }
     // rock.py:236-241 reset -> 266-271 _get_init_state -> 78-86 Rock.__init__:
@@ -177,19 +197,20 @@ struct RockEnv {
                                                 uint32_t lane)
     {
         const uint64_t s = (uint32_t)p.start_x | ((uint32_t)p.start_y << 4);
-        st.s = (S)(s | ((uint64_t)reset_codes(key, lane, p.num_rocks) << 8));
+        st.s = (S)(s | ((uint64_t)reset_codes<false>(key, lane, p.num_rocks) << 8));
         return 0; // Obs.NULL
     }
     static __device__ __forceinline__ int reset_ob(const Params &, const State &) { return 0; }   // what reset() returned
 
-    // Called convergently by every lane of the wave; `fresh` marks the lanes that start a new episode.  ~1/8 of a wave's
-    // lanes reset in a given step under a random policy, so nearly every wave-step computes the block; the quads' four
-    // lanes each derive their quad's block themselves (the kernels that own or time-share a quad do better: see above).
+    // The auto-reset of a step: called convergently by every lane of the wave; `fresh` marks the lanes that start a new
+    // episode.  ~1/8 of a wave's lanes reset in a given step under a random policy, so nearly every wave-step computes the
+    // block; the quads' four lanes each derive it themselves — it is the block the step's sensor draw came from, and the
+    // kernels that own or time-share a quad hand that one over instead (steps_quad_kernel, steps_kernel, fresh_state).
     static __device__ __forceinline__ void reset_where(const Shared &, const Params &p, State &st, bool fresh,
                                                        const RngKey &key, uint32_t lane)
     {
         if (!__any(fresh)) return;                                     // wave-uniform
-        const uint32_t codes = reset_codes(key, lane, p.num_rocks);
+        const uint32_t codes = reset_codes<true>(key, lane, p.num_rocks);
         if (fresh) st.s = (S)((uint64_t)((uint32_t)p.start_x | ((uint32_t)p.start_y << 4)) | ((uint64_t)codes << 8));
     }
     // ... plus the synthetic policy's action for the NEXT call counter (C-side rollout driver)
@@ -199,10 +220,10 @@ struct RockEnv {
     {
         reset_where_chain_default<RockEnv>(sh, p, st, fresh, key, lane, akey, n_actions, next_action);
     }
-    // the fresh episode's state from its RESET word
+    // the fresh episode's state inside a step from the lane's word of the step's sensor block (auto-reset)
     static __device__ __forceinline__ S fresh_state(const Params &p, uint32_t w, const RngKey &key, uint32_t lane)
     {
-        return (S)((uint64_t)((uint32_t)p.start_x | ((uint32_t)p.start_y << 4)) | ((uint64_t)reset_codes(w, key, lane, p.num_rocks) << 8));
+        return (S)((uint64_t)((uint32_t)p.start_x | ((uint32_t)p.start_y << 4)) | ((uint64_t)reset_codes<true>(w, key, lane, p.num_rocks) << 8));
     }
 
     // rock.py:273-291 _generate_legal, in the reference's list order: EAST, then NORTH / SOUTH / WEST when

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
                     RngKey ke = key0;
                     ke.t_lo = (uint32_t)te; ke.t_hi = (uint32_t)(te >> 32);
                     sq = quad_transpose4(Env::quad_block(ke, glane[0], 0u), glane[0] & 3u);
-                    rq = quad_transpose4(Env::reset_block(ke, glane[0], 0u), glane[0] & 3u);   // the quad's RESET words likewise
+                    rq = sq;                       // ... and the fresh episodes of the steps' done lanes start from the same words
                 }
                 const int sj = s & 3;                                            // wave-uniform selects
                 const uint32_t H = sj == 0 ? sq.x : sj == 1 ? sq.y : sj == 2 ? sq.z : sq.w;
@@ -229,11 +229,11 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
         RngKey key = key0;
         key.t_lo = (uint32_t)(t0 + (uint64_t)s); key.t_hi = (uint32_t)((t0 + (uint64_t)s) >> 32);
         const uint64_t ta = ta0 + (uint64_t)s;
-        // the quad's sensor words of this step (StochasticRock: block 2 of the stream — block 0 gates the actions, rock.py:443),
-        // the words its fresh episodes start from, and its policy words of the next call counter
-        constexpr uint32_t SENSOR_BLOCK = Env::STOCHASTIC ? 2u : 0u;
+        // the quad's sensor words of this step (StochasticRock: block 2 of the stream — block 0 gates the actions, rock.py:443)
+        // — the words its fresh episodes start from as well — and its policy words of the next call counter
+        constexpr uint32_t SENSOR_BLOCK = Env::SENSOR_BLOCK;
         const uint4 sw = philox4x32_10(glane0 >> 2, key.t_lo, key.t_hi, ((uint32_t)POMDP_STREAM_STEP << 24) | SENSOR_BLOCK, key.k0, key.k1);
-        const uint4 rw = Env::reset_block(key, glane0, 0u);
+        const uint4 rw = sw;                                   // a lane's step draws EITHER its sensor reading OR its next episode
         const uint4 pw = philox4x32_10(glane0 >> 2, (uint32_t)ta, (uint32_t)(ta >> 32), (uint32_t)POMDP_STREAM_ACTION << 24, key.k0, key.k1);
         const uint32_t H[4] = {sw.x, sw.y, sw.z, sw.w}, P[4] = {pw.x, pw.y, pw.z, pw.w}, R[4] = {rw.x, rw.y, rw.z, rw.w};
         bool acts[4] = {true, true, true, true};

@@ -128,10 +128,10 @@ struct Finisher {
 
 // RockSample with two or more lanes per thread: every random word of the step comes from a quad-shared block (DESIGN.md
 // §2) that depends on lane ids and the call counter only, so ONE task list per wave (64 * LPT lanes) holds
-//   - the 16 * LPT sensor blocks of its quads (stream STEP),
-//   - their 16 * LPT RESET blocks (a quad's four lanes take one word each: the statuses of all rocks of a fresh episode),
+//   - the 16 * LPT sensor blocks of its quads (stream STEP) — a done lane's fresh episode starts from the same word its
+//     sensor draw would have come from (a step never makes both: rock.hip.h, auto-reset),
 //   - for CHAIN launches the 16 * LPT policy blocks of the next call counter,
-// i.e. 64 (CHAIN: 96) Philox blocks for 128 lane-steps, dealt out 64 per pass BEFORE the lane step: the kernel runs the
+// i.e. 32 (CHAIN: 64) Philox blocks for 128 lane-steps, dealt out 64 per pass BEFORE the lane step: the kernel runs the
 // passes right after issuing its HBM loads.  The lane step therefore runs WITHOUT its sensor draw (Env::step_pre) and
 // the observation and the fresh episodes are completed here from the pooled words.  Tasks and results are exchanged
 // through a wave-private LDS scratch; LDS operations of one wave complete in order, so no barrier is involved.  Low
@@ -141,9 +141,9 @@ struct Finisher<RockEnv<W, false>, LPT, CHAIN, typename std::enable_if<(LPT >= 2
     using Env = RockEnv<W, false>;
     using Aux = typename Env::Aux;
     static constexpr bool LOOP_BARRIER = false;              // every scratch array is wave-private
-    static constexpr int NQ = 16 * LPT;                      // quads of the wave's 64 * LPT lanes: sensor blocks, reset blocks
+    static constexpr int NQ = 16 * LPT;                      // quads of the wave's 64 * LPT lanes: sensor blocks
     static constexpr int NA = CHAIN ? 16 * LPT : 0;          // policy blocks of the next call counter
-    static constexpr int NT = 2 * NQ + NA;
+    static constexpr int NT = NQ + NA;
     template <class RT>
     static __device__ __forceinline__ void lane_step(const typename Env::Shared &sh, const typename Env::Params &p,
                                                      typename Env::State &st, int a, const RngKey &, uint32_t, int &ob,
@@ -163,7 +163,7 @@ struct Finisher<RockEnv<W, false>, LPT, CHAIN, typename std::enable_if<(LPT >= 2
     // wave-private LDS scratch (one instance: function-local static of this accessor)
     static __device__ __forceinline__ uint32_t (&blk_lds())[BLOCK / 64][NT][4]
     {
-        __shared__ uint32_t a[BLOCK / 64][NT][4];            // [0, NQ): sensor, [NQ, 2 NQ): reset, [2 NQ, NT): policy; (sub-batch, quad)
+        __shared__ uint32_t a[BLOCK / 64][NT][4];            // [0, NQ): sensor, [NQ, NT): policy; (sub-batch, quad)
         return a;
     }
     static constexpr bool HAS_PREPASS = true;
@@ -176,12 +176,12 @@ struct Finisher<RockEnv<W, false>, LPT, CHAIN, typename std::enable_if<(LPT >= 2
         for (int base = 0; base < NT; base += 64) {
             const int tid = base + me;
             if (tid < NT) {
-                // ONE Philox instance for the three task kinds: the counter words are per-lane selects
-                const int kind = tid < NQ ? 0 : (tid < 2 * NQ ? 1 : 2);
-                const int qt = tid - kind * NQ;                                // (sub-batch, quad) index
+                // ONE Philox instance for the two task kinds: the counter words are per-lane selects
+                const bool pol = tid >= NQ;
+                const int qt = pol ? tid - NQ : tid;                           // (sub-batch, quad) index
                 const uint32_t quad = ((first0 + (uint32_t)(qt >> 4) * BLOCK) >> 2) + (uint32_t)(qt & 15);
-                const uint32_t c1 = kind == 2 ? akey.t_lo : key.t_lo, c2 = kind == 2 ? akey.t_hi : key.t_hi;
-                const uint32_t c3 = (uint32_t)(kind == 0 ? POMDP_STREAM_STEP : kind == 1 ? POMDP_STREAM_RESET : POMDP_STREAM_ACTION) << 24;
+                const uint32_t c1 = pol ? akey.t_lo : key.t_lo, c2 = pol ? akey.t_hi : key.t_hi;
+                const uint32_t c3 = (uint32_t)(pol ? POMDP_STREAM_ACTION : POMDP_STREAM_STEP) << 24;
                 const uint4 w = philox4x32_10(quad, c1, c2, c3, key.k0, key.k1);
                 uint32_t *dst = blk_lds()[wv][tid];
                 dst[0] = w.x; dst[1] = w.y; dst[2] = w.z; dst[3] = w.w;
@@ -198,8 +198,8 @@ struct Finisher<RockEnv<W, false>, LPT, CHAIN, typename std::enable_if<(LPT >= 2
 #pragma unroll
         for (int j = 0; j < LPT; ++j) {                                         // every read in flight together, one wait
             H[j] = blk_lds()[wv][16 * j + (me >> 2)][me & 3];
-            Rw[j] = blk_lds()[wv][NQ + 16 * j + (me >> 2)][me & 3];
-            P[j] = CHAIN ? blk_lds()[wv][2 * NQ + 16 * j + (me >> 2)][me & 3] : 0u;
+            Rw[j] = H[j];                                                       // auto-reset: the sensor block's word
+            P[j] = CHAIN ? blk_lds()[wv][NQ + 16 * j + (me >> 2)][me & 3] : 0u;
         }
 #pragma unroll
         for (int j = 0; j < LPT; ++j) {

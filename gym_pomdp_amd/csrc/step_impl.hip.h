@@ -164,9 +164,10 @@ __global__ __launch_bounds__(BLOCK) void step_quad_kernel(uint32_t *__restrict__
     const uint32_t dn = auto_reset ? 0u : ld_stream(done_w);                       // frozen lanes (the reference would assert)
     const auto staged = Env::stage_load(p, (int)threadIdx.x);
     // the quad's words depend on lane ids only: Philox under the load latency
-    constexpr uint32_t SENSOR_BLOCK = Env::STOCHASTIC ? 2u : 0u;
-    const uint4 sw = Env::quad_block(key, glane0, SENSOR_BLOCK), rw = Env::reset_block(key, glane0, 0u);
-    const uint32_t H[4] = {sw.x, sw.y, sw.z, sw.w}, R[4] = {rw.x, rw.y, rw.z, rw.w};
+    constexpr uint32_t SENSOR_BLOCK = Env::SENSOR_BLOCK;
+    const uint4 sw = Env::quad_block(key, glane0, SENSOR_BLOCK);
+    // a lane's step draws EITHER its sensor reading OR (done) its next episode: both from this one block
+    const uint32_t H[4] = {sw.x, sw.y, sw.z, sw.w}, R[4] = {sw.x, sw.y, sw.z, sw.w};
     uint32_t G[4] = {0, 0, 0, 0};
     if constexpr (Env::STOCHASTIC) { const uint4 gw = Env::quad_block(key, glane0, 0u); G[0] = gw.x; G[1] = gw.y; G[2] = gw.z; G[3] = gw.w; }
     Env::stage_store(sh, staged, (int)threadIdx.x);

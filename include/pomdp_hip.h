@@ -31,9 +31,14 @@
  * ctr = (lane, t lo, t hi, stream_id << 24 | block); numpy legacy constructions on
  * top (res53 doubles, masked-rejection randint).  RockSample / StochasticRock lay their doubles out
  * "split": the high word of a double in one block, its low word in the following block, generated only when the
- * high word leaves a comparison undecided.  step: block 2j for the step's double j, counter word 0 = lane / 4,
- * element lane % 4 (one block serves a quad).  reset: rock j = 4q + e reads element e of block 2(j/16) rotated right
- * by 8q + 8 bits (reset() only uses the top bit of the double: one block serves sixteen rocks).
+ * high word leaves a comparison undecided.  Both RockSample streams are shared by the four lanes of a quad: counter
+ * word 0 = lane / 4, lane L reads element L % 4 of every block.  step: block 2j for the step's double j (RockEnv: j = 0
+ * the sensor; StochasticRock: j = 0 the action gate, j = 1 the sensor).  reset: rock j reads the lane's element of block 0
+ * of stream RESET rotated right by 2j + 2 bits (reset() only uses the top bit of the double: one word serves the lane's
+ * sixteen rocks), its low word the element of block 1 under the same rotation.  The reset that follows a done step inside
+ * that step's call (POMDP_AUTO_RESET) reads the same rotated pair from the step's own SENSOR blocks — stream STEP, blocks
+ * b and b + 1, b = 0 (RockEnv) / 2 (StochasticRock) — instead: a step never makes both draws (a CHECK does not end the
+ * episode), so each word is consumed once either way and a quad's step costs one Philox block (ABI 10).
  * Network's step uses the per-lane form (block 2(j/4), element j % 4) for its one-double-per-machine draws.
  */
 #ifndef POMDP_HIP_H
@@ -45,7 +50,7 @@
 extern "C" {
 #endif
 
-#define POMDP_ABI_VERSION 9
+#define POMDP_ABI_VERSION 10
 
 enum {
     POMDP_E_BADARG = -1,     /* NULL pointer, n < 0, n + lane0 > 2^32 */
@@ -54,8 +59,9 @@ enum {
 
 /* flags for *_step */
 enum {
-    POMDP_AUTO_RESET = 1,    /* done lanes get a fresh episode in the same call (stream RESET of the same t);
-                                without it `done` is in/out and done lanes freeze: (ob, reward, done) = (0, 0, 1) */
+    POMDP_AUTO_RESET = 1,    /* done lanes get a fresh episode in the same call (stream RESET of the same t; RockSample:
+                                the step's own sensor blocks, BattleShip: the cached board — see the contracts above and
+                                below); without it `done` is in/out and done lanes freeze: (ob, reward, done) = (0, 0, 1) */
     POMDP_FUSE_STEPS = 2,    /* pomdp_rollout_synthetic only: consecutive steps may share a launch (see there) */
 };
 

@@ -101,7 +101,7 @@ def rotr32(w, r):
     return ((w >> r) | (w << (32 - r))) & 0xFFFFFFFF
 
 
-def rock_reset_words(seed, lane, t, n_rocks):
+def rock_reset_words(seed, lane, t, n_rocks, auto_step_block=None):
     """RockSample's RESET stream ("rotated split layout", shared by the four lanes of a quad like the
     STEP stream).  reset() draws one double per rock and only uses sign(U - .5), i.e. the top bit of the double's high
     word (the rest matters only when the top 27 bits are exactly 2^26: a tie, probability 2^-27).  ONE 32-bit word
@@ -110,9 +110,16 @@ def rock_reset_words(seed, lane, t, n_rocks):
     low word the same element of block 1 under the same rotation.  The top bits of the rotations are bits 1, 3, ..., 31
     of the element — independent fair bits — so the rock statuses are independent Bernoulli(1/2) exactly as in the
     reference, and they sit where the packed state keeps the upper bit of each rock's 2-bit code.  The kernels
-    generate the low block only on a tie.  Returns the 2 * n_rocks words numpy consumes, in order."""
-    hi_w = int(_block(seed, lane >> 2, t, STREAM_RESET, 0)[lane & 3])
-    lo_w = int(_block(seed, lane >> 2, t, STREAM_RESET, 1)[lane & 3])
+    generate the low block only on a tie.  Returns the 2 * n_rocks words numpy consumes, in order.
+
+    `auto_step_block`: None for a reset() call of its own (stream RESET, blocks 0 and 1).  The reset that follows a done
+    step INSIDE that step's call counter (auto-reset) takes the same rotated pair from the step's own SENSOR blocks
+    instead — stream STEP, blocks b and b + 1 with b = 0 (RockEnv) or 2 (StochasticRockEnv: block 0 gates the action):
+    a step never makes both draws (a CHECK does not end the episode, rock.py:171-175 / 193), so the word is consumed
+    exactly once either way and a quad's step costs one Philox block, not two."""
+    stream, b = (STREAM_RESET, 0) if auto_step_block is None else (STREAM_STEP, int(auto_step_block))
+    hi_w = int(_block(seed, lane >> 2, t, stream, b)[lane & 3])
+    lo_w = int(_block(seed, lane >> 2, t, stream, b + 1)[lane & 3])
     out = []
     for j in range(n_rocks):
         rot = (2 * j + 2) & 31

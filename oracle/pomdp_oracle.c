@@ -71,6 +71,7 @@ void or_ws_philox(or_ws *ws, uint64_t seed, uint32_t lane, uint64_t t, uint32_t 
     ws->widx = 0;
     ws->n_drawn = 0;
     ws->layout = 0;
+    ws->blk_base = 0;
     ws->lane = lane;
     ws->half_have[0] = ws->half_have[1] = 0;
 }
@@ -104,7 +105,7 @@ uint32_t or_ws_next32(or_ws *ws)
         /* layout 1: per-lane split (four doubles per block pair); 2: quad-shared split (one double per lane per pair);
          * 3: RockSample reset — quad-shared like 2, ONE block pair: double j (rock j) = the lane's element of block
          *    `half` rotated right by 2 j + 2 bits (its top bit is bit 2 j + 1 of the element) */
-        const uint32_t block = ws->layout == 1 ? 2u * (j >> 2) + half : ws->layout == 3 ? half : 2u * j + half;
+        const uint32_t block = ws->layout == 1 ? 2u * (j >> 2) + half : ws->layout == 3 ? ws->blk_base + half : 2u * j + half;
         const uint32_t elem = ws->layout == 1 ? (j & 3u) : (ws->lane & 3u);
         const uint32_t rot = ws->layout == 3 ? ((2u * j + 2u) & 31u) : 0u;
         if (!ws->half_have[half] || ws->half_idx[half] != block) {
@@ -639,6 +640,21 @@ static void network_step(or_env *e, int action, or_ws *np_rng, int *ob_out, doub
 /* ------------------------------------------------------------------------ */
 /* dispatch                                                                  */
 /* ------------------------------------------------------------------------ */
+/* The reset that follows a done step inside the step's own call counter.  RockSample / StochasticRock: the rotated pair
+ * (layout 3) of the step's SENSOR blocks — stream STEP, blocks b, b + 1 with b = 0 (RockEnv) or 2 (StochasticRockEnv,
+ * whose block 0 gates the action) — instead of stream RESET: a step never draws both (a CHECK does not end the episode,
+ * rock.py:171-175, 193), so the word is consumed once either way (oracle/philox_ref.py rock_reset_words).  Every other env:
+ * stream RESET of (lane, t).  (BattleShip's cached board is the caller's business.) */
+void or_ws_philox_auto_reset(or_ws *ws, const or_env *e, uint64_t seed, uint32_t lane, uint64_t t)
+{
+    if (e->kind == OR_ENV_ROCK) {
+        or_ws_philox(ws, seed, lane, t, OR_STREAM_STEP);
+        ws->layout = 3; ws->ctr[0] = lane >> 2; ws->blk_base = e->stochastic ? 2u : 0u;
+        return;
+    }
+    or_ws_philox_env(ws, e->kind, seed, lane, t, OR_STREAM_RESET);
+}
+
 int or_env_reset(or_env *e, or_ws *np_rng, or_ws *space_rng)
 {
     switch (e->kind) {
@@ -874,7 +890,7 @@ int64_t or_batch_step(const or_env *proto, uint32_t *state, const int32_t *actio
                     or_ws_philox(&np_rng, seed, lane0 + (uint32_t)i, t, OR_STREAM_NEXT);
                     bs_deal_next(&e, &np_rng);
                 } else if (d && auto_reset) {
-                    or_ws_philox_env(&np_rng, e.kind, seed, lane0 + (uint32_t)i, t, OR_STREAM_RESET);
+                    or_ws_philox_auto_reset(&np_rng, &e, seed, lane0 + (uint32_t)i, t);
                     or_ws_philox(&sp_rng, seed, lane0 + (uint32_t)i, t, OR_STREAM_RESET_SPACE);
                     or_env_reset(&e, &np_rng, &sp_rng);
                 }
@@ -965,7 +981,7 @@ double or_bench_loop(const or_env *proto, int64_t n, int64_t steps, uint64_t see
                     or_ws_philox(&np_rng, seed, (uint32_t)i, (uint64_t)s, OR_STREAM_NEXT);
                     bs_deal_next(&e, &np_rng);
                 } else if (d) {
-                    or_ws_philox_env(&np_rng, e.kind, seed, (uint32_t)i, (uint64_t)s, OR_STREAM_RESET);
+                    or_ws_philox_auto_reset(&np_rng, &e, seed, (uint32_t)i, (uint64_t)s);
                     or_ws_philox(&sp_rng, seed, (uint32_t)i, (uint64_t)s, OR_STREAM_RESET_SPACE);
                     or_env_reset(&e, &np_rng, &sp_rng);
                 }

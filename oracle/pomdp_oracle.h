@@ -42,6 +42,7 @@ typedef struct or_ws {
     /* RockSample's split layout (oracle/philox_ref.py: rock_reset_words / rock_step_words):
      * 0 = plain sequential stream, 1 = per-lane split (RESET), 2 = quad-shared split (STEP) */
     int layout;
+    uint32_t blk_base;                      /* layout 3: first block of the rotated pair (auto-reset: the step's sensor block) */
     uint32_t lane;
     uint32_t half_blk[2][4], half_idx[2];   /* one cached block per half (high / low words) */
     int half_have[2];
@@ -63,6 +64,8 @@ enum { OR_ENV_ROCK = 0, OR_ENV_TAG = 1, OR_ENV_BATTLESHIP = 2, OR_ENV_TIGER = 3,
 enum { OR_REWARD_I32 = 0, OR_REWARD_F32 = 1 };
 
 typedef struct or_env or_env;
+/* word source of the reset that follows a done step inside that step's call counter t (batch auto-reset) */
+void     or_ws_philox_auto_reset(or_ws *ws, const or_env *e, uint64_t seed, uint32_t lane, uint64_t t);
 
 /* args: rock (board_size, num_rocks[, stochastic, act_thr_lo, act_thr_hi])  stochastic = StochasticRockEnv
  *       tag (num_opponents, obs_cells, move_thr_lo, move_thr_hi)  thr==0 -> captured value for 0.8

@@ -91,13 +91,15 @@ def consumed_words(rs=None):
     return int(st[2])
 
 
-def inject_stream(seed, lane, t, stream, rs=None, env=None, env_kwargs=None):
+def inject_stream(seed, lane, t, stream, rs=None, env=None, env_kwargs=None, auto_reset=False):
     """Inject the words of (seed, lane, t, stream).  RockSample / StochasticRock use the split, quad-shared layout
     of oracle/philox_ref.py (rock_reset_words / rock_step_words), Network's step() the per-lane split layout
     (split_words); everything else the plain sequential stream."""
     if env in ("rock", "stochrock") and stream in (px.STREAM_STEP, px.STREAM_RESET):
         if stream == px.STREAM_RESET:
-            w = px.rock_reset_words(seed, lane, t, (env_kwargs or {}).get("num_rocks", 8))
+            # an auto-reset draws from the step's own sensor blocks (philox_ref.rock_reset_words)
+            w = px.rock_reset_words(seed, lane, t, (env_kwargs or {}).get("num_rocks", 8),
+                                    auto_step_block=(2 if env == "stochrock" else 0) if auto_reset else None)
         else:
             w = px.rock_step_words(seed, lane, t, 2 if env == "stochrock" else 1)
         # pad with a recognisable filler: consuming more words than the layout defines must be noticed
@@ -115,10 +117,11 @@ def inject_auto_reset(seed, lane, t, dealt_at, env=None, env_kwargs=None):
     """Words of the reference reset() that follows a done step at call counter t.  BattleShip (board contract,
     include/pomdp_hip.h): the board that moves in then is the reference's reset() on stream NEXT of the call counter
     `dealt_at` at which the lane's PREVIOUS board was dealt (by the initial reset or by an earlier auto-reset);
-    every other env: stream RESET of (lane, t)."""
+    RockSample / StochasticRock: the rotated pair of the step's own sensor blocks (stream STEP of (lane, t): a step never
+    draws both); every other env: stream RESET of (lane, t)."""
     if env == "battleship":
         return inject_stream(seed, lane, dealt_at, px.STREAM_NEXT, env=env, env_kwargs=env_kwargs)
-    return inject_stream(seed, lane, t, px.STREAM_RESET, env=env, env_kwargs=env_kwargs)
+    return inject_stream(seed, lane, t, px.STREAM_RESET, env=env, env_kwargs=env_kwargs, auto_reset=True)
 
 
 # ---------------------------------------------------------------------------
@@ -454,7 +457,7 @@ def heuristic_trace(name, kwargs, seed, lanes, T, t0=0, max_size=None):
             out["action"][li, i], out["ob"][li, i] = a, int(o)
             out["reward"][li, i], out["done"][li, i] = float(r), int(bool(d))
             if d:
-                inject_stream(seed, lane, t, px.STREAM_RESET, env=name, env_kwargs=kwargs)
+                inject_auto_reset(seed, lane, t, t, env=name, env_kwargs=kwargs)   # (no BattleShip here: dealt_at unused)
                 ob_prev = int(env.reset())
                 hist = rk.History(max_size) if is_rock else _TagHistory()
             else:

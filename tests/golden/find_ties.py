@@ -104,8 +104,38 @@ def main_network(n_ties=5):
     print("network ties (lane, draw):", ties)
 
 
+def main_auto(n_ties=4):
+    """Auto-reset ties (fixture ties_rock_auto.npz).  The reset that follows a done step inside the step's call counter takes
+    its rotated word pair from the step's own sensor blocks (stream STEP, blocks 0 / 1; philox_ref.rock_reset_words): find
+    lanes whose element of block 0 at t = 1 puts some rock of the NEW episode on the 2^52 boundary, and end their first
+    episode there — WEST from the start cell (0, 3) of RockSample(7,8) leaves the grid (-100, done)."""
+    ties, lane = [], 0
+    while len(ties) < n_ties:
+        c0 = np.arange(lane, lane + CHUNK, dtype=np.uint64)
+        blk = blocks(c0, 1, px.STREAM_STEP, 0).astype(np.uint64)
+        for j in range(8):
+            r = np.uint64(2 * j + 2)
+            kh = (((blk >> r) | (blk << (np.uint64(32) - r))) & np.uint64(0xFFFFFFFF)) >> np.uint64(5)
+            for qi, e in zip(*np.nonzero(kh == (1 << 26))):
+                ties.append((int(c0[qi]) * 4 + int(e), j))
+        lane += CHUNK
+        print("searched", lane, "found", len(ties), flush=True)
+    ties = ties[:n_ties]
+    lanes = [ln for ln, _ in ties]
+    tr = h.trace_mode_b("rock", {}, SEED, lanes, np.full((len(lanes), 1), 3, np.int64), t0=0)
+    assert tr["done"][:, 0].all()
+    np.savez_compressed(os.path.join(HERE, "ties_rock_auto.npz"), seed=np.int64(SEED), lanes=np.array(lanes, np.int64),
+                        actions=np.full(len(lanes), 3, np.int64), tied_rock=np.array([r for _, r in ties], np.int64),
+                        state0=tr["state0"], ob=tr["ob"][:, 0], reward=tr["reward"][:, 0], done=tr["done"][:, 0],
+                        state=tr["state"][:, 0])
+    print("auto-reset ties (lane, rock):", ties)
+    print("new episode's status of the tied rocks:", [int(tr["state"][i, 0][1 + r]) for i, (_, r) in enumerate(ties)])
+
+
 if __name__ == "__main__":
     if "--network" in sys.argv:
         main_network()
+    elif "--auto" in sys.argv:
+        main_auto()
     else:
         main()

@@ -650,6 +650,30 @@ def test_split_layout_ties():
             assert (int(ob[col]), int(rew[col]), int(done[col])) == (int(g["ob"][i]), int(g["reward"][i]), int(g["done"][i])), (lane, n)
 
 
+def test_auto_reset_ties():
+    """A done step's auto-reset starts the new episode from the step's own sensor block; fixture ties_rock_auto.npz holds
+    lanes (found by tests/golden/find_ties.py --auto) where a rock of that new episode is decided by the LOW word, with the
+    reference's outcome.  Through the one-lane-per-thread step kernel, the pooled two-lanes-per-thread one and the
+    quad-per-thread one (2^19 lanes)."""
+    import os
+    from conftest import GOLDEN
+    g = dict(np.load(os.path.join(GOLDEN, "ties_rock_auto.npz")))
+    seed = int(g["seed"])
+    for i, lane in enumerate(g["lanes"]):
+        lane = int(lane)
+        for n in (4, 1 << 18, 1 << 19):
+            base = lane & ~3 if n == 4 else max(0, (lane & ~3) - (n // 2))
+            col = lane - base
+            e = make_env("rock", {}, batch_size=n, seed=seed, lane_offset=base)
+            e.reset()
+            assert np.array_equal(np_(e.decode_state()[col]), g["state0"][i]), (lane, n)
+            a = torch.full((n,), 5, dtype=torch.int32, device="cuda")            # everybody else CHECKs rock 0
+            a[col] = int(g["actions"][i])
+            ob, rew, done, _ = e.step(a)
+            assert (int(ob[col]), int(rew[col]), int(done[col])) == (int(g["ob"][i]), int(g["reward"][i]), 1), (lane, n)
+            assert np.array_equal(np_(e.decode_state()[col]), g["state"][i]), (lane, n)
+
+
 def test_network_split_layout_ties():
     """The 2^-27 path of Network's split word layout (fixture ties_network.npz: the reference on lanes where a failure
     or observation draw is undecided by its high word)."""

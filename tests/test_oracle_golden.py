@@ -254,6 +254,28 @@ def test_split_layout_ties_oracle(oracle_lib):
         assert int(w[2 * int(g["tied_rock"][i])]) >> 5 == 1 << 26
 
 
+def test_auto_reset_ties_oracle(oracle_lib):
+    """The reset that follows a done step inside the step's call counter reads the step's own sensor blocks (stream STEP,
+    rotated pair; oracle/philox_ref.py rock_reset_words): lanes whose new episode has a rock on the 2^52 boundary of its high
+    word (fixture ties_rock_auto.npz, tests/golden/find_ties.py --auto: the reference, ending its first episode with WEST)."""
+    g = dict(np.load(os.path.join(GOLDEN, "ties_rock_auto.npz")))
+    o = oracle_lib.OracleEnv("rock")
+    seed = int(g["seed"])
+    from oracle import philox_ref as px
+    for i, lane in enumerate(g["lanes"]):
+        st = o.new_state(1)
+        o.batch_reset(st, seed, int(lane), 0)
+        assert np.array_equal(o.batch_compact(st)[0], g["state0"][i])
+        ob, rew, done, _ = o.batch_step(st, [int(g["actions"][i])], seed, int(lane), 1)
+        assert (int(ob[0]), int(rew[0]), int(done[0])) == (int(g["ob"][i]), int(g["reward"][i]), 1)
+        assert np.array_equal(o.batch_compact(st)[0], g["state"][i])                    # the episode the auto-reset dealt
+        w = px.rock_reset_words(seed, int(lane), 1, 8, auto_step_block=0)
+        assert int(w[2 * int(g["tied_rock"][i])]) >> 5 == 1 << 26
+        # ... and it is NOT what stream RESET would have dealt at that call counter
+    assert any(not np.array_equal(px.rock_reset_words(seed, int(l), 1, 8), px.rock_reset_words(seed, int(l), 1, 8, auto_step_block=0))
+               for l in g["lanes"])
+
+
 def test_network_split_layout_ties_oracle(oracle_lib):
     """Network draws decided by the low word (fixture ties_network.npz from tests/golden/find_ties.py --network)."""
     import json
