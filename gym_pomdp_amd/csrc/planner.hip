@@ -375,7 +375,14 @@ __global__ __launch_bounds__(BLOCK) void heuristic_steps_kernel(const typename E
             }
             if (!live) { o = 0; r = 0; d = was_done; st = before; }
             const bool fresh = live && d && auto_reset;
-            Env::reset_where(sh, p, st, fresh, key, lane);                     // wave-cooperative: every lane calls it
+            if constexpr (Env::QUAD_SENSOR) {
+                // RockSample: the fresh episode starts from the word the step's sensor draw would have read (auto-reset
+                // contract, rock.hip.h) — this lane's word of the quad's block is already here; reset_where would compute
+                // that block again, per lane, in every wave-step in which some lane's episode ends
+                st.s = fresh ? Env::fresh_state(p, comp<J>(sq), key, lane) : st.s;
+            } else {
+                Env::reset_where(sh, p, st, fresh, key, lane);                 // wave-cooperative: every lane calls it
+            }
             ever_fresh |= fresh;
             if (live) {
                 if (R.ret) {                                                   // r += rw * discount; discount *= _discount

@@ -4,7 +4,7 @@
     python tools/isa_mix.py [--costs profiles/<tag>_valu_microbench.json] [--json out.json] [kernel-name-substring ...]
 
 Compiles the translation units of gym_pomdp_amd/csrc/ for gfx950 to assembly text (hipcc --cuda-device-only -S), finds each
-requested kernel, takes its outermost loop with the most instructions (the step loop of the fused kernels, the four-step
+requested kernel, takes its loop with the most instructions of its own (the step loop of the fused kernels, the four-step
 loop of the rollout / heuristic kernels) without the loops nested inside it (they are the 2^-27 tie paths and the
 continuation passes), and counts its VALU instructions by mnemonic.  With a cost table (tools/valu_microbench: shader cycles
 per wave64 instruction per SIMD) the mix gives the average issue cost of the loop's vector instructions — what turns a
@@ -136,15 +136,16 @@ def is_tie_path(prev, b):
 
 
 def hot_loop(blocks):
-    """The depth-1 loop with the most instructions in its own (depth-1) blocks; nested loops and tie-path blocks left out.
+    """The loop (of any depth: the fused step loops sit inside the four-segment priority loop, LoopPrio) with the most
+    instructions in its OWN blocks; the loops nested inside it and tie-path blocks left out.
     -> (loop header, instructions of the common path, VALU instructions left out as tie paths)"""
     loops, cold = {}, {}
     prev = None
     for b in blocks:
         key = None
-        if b["header_depth"] == 1:
+        if b["header_depth"] is not None:
             key = b["label"].lstrip(".L")
-        elif b["in_loop"] and b["in_loop"][1] == 1:
+        elif b["in_loop"]:
             key = b["in_loop"][0]
         if key:
             if is_tie_path(prev, b):
