@@ -232,3 +232,18 @@ def test_fused_step_loops_never_wait_for_their_own_stores():
             assert waits == [], (name, waits)
             assert prio == 4, (name, prio)
     assert seen == 2, sorted(res)
+
+
+def test_library_override_by_environment_variable():
+    """GYM_POMDP_AMD_LIB points the package at another build of the library (tools/ab_build.sh variants for same-box A/B
+    runs); unset, the in-tree product library is what loads."""
+    import subprocess
+    import sys
+    from gym_pomdp_amd import _native
+    code = "from gym_pomdp_amd import _native; print(_native.LIB_PATH)"
+    env = dict(os.environ, GYM_POMDP_AMD_LIB="/nonexistent/libpomdp_hip_x.so")
+    out = subprocess.run([sys.executable, "-c", code], cwd=REPO, env=env, capture_output=True, text=True).stdout.strip()
+    assert out == "/nonexistent/libpomdp_hip_x.so"
+    env.pop("GYM_POMDP_AMD_LIB")
+    out = subprocess.run([sys.executable, "-c", code], cwd=REPO, env=env, capture_output=True, text=True).stdout.strip()
+    assert out == os.path.join(REPO, "gym_pomdp_amd", "_lib", "libpomdp_hip.so") == _native.LIB_PATH or os.environ.get("GYM_POMDP_AMD_LIB")
