@@ -171,10 +171,10 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
 }
 
 // The fused RockSample loop with a thread owning four CONSECUTIVE lanes — a quad.  RockSample's word contract shares the
-// STEP block, the RESET block and the policy's ACTION block among the four lanes of a quad, so with this mapping all
-// three are the thread's own: three Philox blocks per thread-step straight into registers, lane j taking element j — no
-// exchange through LDS, no ballots, no task lists, and no dependence on the lane step: the compiler interleaves the three
-// chains with the table lookups.  A thread's outputs are four consecutive elements of each column: one 16-byte store per
+// STEP block — which a done step's auto-reset reads as well (rock.hip.h) — and the policy's ACTION block among the four
+// lanes of a quad, so with this mapping both are the thread's own: two Philox blocks per thread-step straight into
+// registers, lane j taking element j — no exchange through LDS, no ballots, no task lists, and no dependence on the lane
+// step: the compiler interleaves the chains with the table lookups.  A thread's outputs are four consecutive elements of each column: one 16-byte store per
 // int32 column and one 4-byte store of the packed done bytes per step instead of twenty scalar stores; state and first
 // actions come in the same way.  The lane step is the table-driven one.  Full workgroups of 1024 lanes and auto-reset
 // only (the launcher's SIMPLE conditions).  Same results as steps_kernel: the mapping of lanes to threads is invisible
