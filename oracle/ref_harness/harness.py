@@ -222,7 +222,8 @@ def trace_mode_b(name, kwargs, seed, lanes, actions, t0=0):
     actions: int[len(lanes), T].  Call `c` of the batched env uses t = t0 + c:
     the initial reset is t0, step i is t0 + 1 + i, and the auto-reset that
     follows a done step shares that step's t (stream RESET instead of STEP;
-    BattleShip: see inject_auto_reset).
+    RockSample: the step's own sensor blocks, BattleShip: the cached board — see
+    inject_auto_reset).
     """
     lanes = list(lanes)
     actions = np.asarray(actions)
