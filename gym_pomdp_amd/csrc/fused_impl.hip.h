@@ -908,7 +908,7 @@ int launch_steps_fused(const typename Env::Params &p, uint32_t *state, int32_t *
     if constexpr (quad_tab<Env>::value) {
         // from 16 steps per launch on the lane step reads the (position, action) table the workgroup builds first and a
         // thread owns a quad of consecutive lanes (steps_quad_kernel: RockSample and StochasticRock)
-        if (quad_ok && n >= QUAD_MIN_ROCK && k >= 16 && p.num_rocks + 5 <= Env::TAB_ACTIONS) {
+        if (quad_ok && n >= (Env::STOCHASTIC ? QUAD_MIN_STOCHROCK : QUAD_MIN_ROCK) && k >= 16 && p.num_rocks + 5 <= Env::TAB_ACTIONS) {
             note_fused("steps_quad_kernel", Env::NAME, "");
             hipLaunchKernelGGL((steps_quad_kernel<Env>), qgrid, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob, reward,
                                done, n, make_key(seed, t), lane0, make_key(action_seed, t + 1), k, rec, gf, p);

@@ -413,13 +413,18 @@ static __device__ __forceinline__ u32x4 first_actions4(uint32_t *action_row0, in
 // 2.67 against 0.96 / 1.43 / 2.00; Tiger 0.67 / 0.67 / 1.21 / 2.51 against 0.44 / 0.85 / 1.41 / 2.66; Network 2.30 / 2.30 / 2.91 /
 // 4.72 against 1.45 / 1.94 / 3.32 / 5.99 — below these sizes every kernel is bound by the latency of one wave's step
 // (1.1-2.3 us), and more, lighter waves hide it better than fewer, heavier ones.
+// Re-measured at the end of round 3 (priority ladder, RockSample's auto-reset from the sensor block; profiles/
+// r03b_gates.txt): RockSample between 2^19 and 3 * 2^18 lanes is faster with the pooled two-lanes-per-thread loop (four waves
+// per SIMD instead of two or two and a half; (15,15) at 2^19 lanes 1.25 against 1.46 us per step, (7,8) at 5 * 2^17 lanes
+// 1.50 against 1.65) and from 3 * 2^18 lanes — three workgroups per CU — with the quad loop; Tiger at 2^18 lanes with one
+// lane per thread (0.66 against 0.72).  StochasticRock has no pooled loop and keeps 2^19.
 // POMDP_QUAD_MIN_LANES overrides all of them at build time for same-box A/B runs (tools/ab_build.sh lib ... -D...).
 #ifdef POMDP_QUAD_MIN_LANES
-constexpr int64_t QUAD_MIN_ROCK = POMDP_QUAD_MIN_LANES, QUAD_MIN_TAG = POMDP_QUAD_MIN_LANES, QUAD_MIN_GENERIC = POMDP_QUAD_MIN_LANES,
-                  QUAD_MIN_NETWORK = POMDP_QUAD_MIN_LANES, QUAD_MIN_BATTLESHIP = POMDP_QUAD_MIN_LANES;
+constexpr int64_t QUAD_MIN_ROCK = POMDP_QUAD_MIN_LANES, QUAD_MIN_STOCHROCK = POMDP_QUAD_MIN_LANES, QUAD_MIN_TAG = POMDP_QUAD_MIN_LANES,
+                  QUAD_MIN_GENERIC = POMDP_QUAD_MIN_LANES, QUAD_MIN_NETWORK = POMDP_QUAD_MIN_LANES, QUAD_MIN_BATTLESHIP = POMDP_QUAD_MIN_LANES;
 #else
-constexpr int64_t QUAD_MIN_ROCK = 1 << 19, QUAD_MIN_TAG = 1 << 19, QUAD_MIN_GENERIC = 1 << 18, QUAD_MIN_NETWORK = 1 << 19,
-                  QUAD_MIN_BATTLESHIP = 1 << 18;
+constexpr int64_t QUAD_MIN_ROCK = 3 << 18, QUAD_MIN_STOCHROCK = 1 << 19, QUAD_MIN_TAG = 1 << 19, QUAD_MIN_GENERIC = 1 << 19,
+                  QUAD_MIN_NETWORK = 1 << 19, QUAD_MIN_BATTLESHIP = 1 << 18;
 #endif
 
 // which kernel the calling thread's most recent fused launch picked (pomdp_last_fused_kernel: bench.py names the kernel

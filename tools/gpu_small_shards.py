@@ -27,8 +27,9 @@ def one(lib_path):
     for name, env_id, kw in ENVS:
         if only and name not in only:
             continue
-        for lg in (14, 16, 17, 18, 19, 20):
-            n = 1 << lg
+        sizes = [int(x) for x in os.environ["SHARD_SIZES"].split(",")] if os.environ.get("SHARD_SIZES") else [1 << lg for lg in (14, 16, 17, 18, 19, 20)]
+        for n in sizes:
+            lg = n.bit_length() - 1
             e = gpa.make(env_id, batch_size=n, seed=0, reuse_buffers=True, **kw)
             e.reset()
             tr = e.collect_synthetic(64)
@@ -44,7 +45,7 @@ def one(lib_path):
                 e1.record()
                 torch.cuda.synchronize()
                 best = min(best, e0.elapsed_time(e1) / 640 * 1e3)
-            print("%-10s 2^%d lanes: %7.3f us/step  %8.3e lane-steps/s  %s" % (name, lg, best, n / best * 1e6,
+            print("%-10s %s lanes: %7.3f us/step  %8.3e lane-steps/s  %s" % (name, ("2^%d" % lg) if n == 1 << lg else str(n), best, n / best * 1e6,
                                                                                L.pomdp_last_fused_kernel().decode()), flush=True)
             del e, tr
 
