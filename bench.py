@@ -594,6 +594,23 @@ def main():
         torch.cuda.synchronize(dev)
         chain1_ms = ev0.elapsed_time(ev1) / k1
     invalid = env.invalid_action_count()
+    # What a write stream reaches on THIS device into THIS buffer (measured here, after the timed regions): a plain fill of the
+    # trajectory's ob column — one 16-byte store stream over the very pages the timed launches wrote.  The fused launch's own
+    # rate depends on where its buffer lies; the fill shows the ceiling the placement leaves.
+    store_ceiling = None
+    if collect:
+        col = wl.traj["ob"].view(-1)
+        for _ in range(3):
+            col.fill_(0)
+        torch.cuda.synchronize(dev)
+        ev0.record()
+        for _ in range(10):
+            col.fill_(0)
+        ev1.record()
+        torch.cuda.synchronize(dev)
+        store_ceiling = {"value": col.numel() * col.element_size() * 10 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9, "unit": "GB/s",
+                         "how": "torch fill over the trajectory buffer's ob column (%d MB, one 16-byte store stream), HIP events; "
+                                "untimed, after the regions" % (col.numel() * col.element_size() >> 20)}
 
     # the recorded PMC figure belongs to a launch of the recorded shape only: 2^20 lanes, 64 steps per fused launch
     traffic, traffic_src = measured_traffic(args.env, chained, fused) if (n == 1 << 20 and spl in (1, 64)) else (None, None)
@@ -653,6 +670,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per %d-step launch" % spl if fused else "bytes per launch",
                          "valu": valu,
+                         "store_ceiling": store_ceiling,
                          "tighter_bound": None if valu is None else ("valu" if valu["frac"] > achieved / HBM_PEAK_GBS else "hbm"),
                          "kernel_ms_by_rank": rank_kernel_ms,
                          "traffic_source": traffic_src,
