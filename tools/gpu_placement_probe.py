@@ -52,7 +52,7 @@ def fill_rate(t):
 
 from gym_pomdp_amd.envs import base as _base  # noqa: E402
 print("(a) fresh allocations of trajectory_buffers(%d), earlier ones kept alive, by column stagger" % K)
-for round_ in range(2):
+for round_ in range(int(os.environ.get('PP_ROUNDS', '2'))):
     for stg in [int(x) for x in os.environ.get("PP_ALLOC_STAGGERS", "4096,2048").split(",")]:
         _base.STAGGER_BYTES = stg
         keep, ts = [], []
