@@ -245,7 +245,10 @@ def cpu_baseline(env_key, kwargs, seed, budget_s):
             quota = None if q[0] == "max" else float(q[0]) / float(q[1])
     except Exception:  # noqa: BLE001
         pass
-    return {"value": best["value"], "unit": "env-steps/s", "cores": best["threads"], "kind": "port",
+    usable_cpus = usable if quota is None else min(usable, int(quota))
+    return {"value": best["value"], "unit": "env-steps/s", "cores": best["threads"], "usable_cpus": usable_cpus, "kind": "port",
+            "cores_note": "`cores` = the OpenMP threads of the best row of by_threads; `usable_cpus` = the CPUs this process can "
+                          "actually run on at once (min of its affinity mask and the cgroup quota) — threads beyond that time-share",
             "sample": "%d lanes x %d steps of the same workload on the C oracle (OpenMP, %d threads pinned with "
                       "OMP_PROC_BIND=close OMP_PLACES=cores, %.1f s; %d CPUs usable by this process%s; best of the thread counts "
                       "in by_threads)" % (1 << 20, best["steps"], best["threads"], best["seconds"], usable,

@@ -10,20 +10,23 @@ import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _REPO = os.path.dirname(_PKG)
-# GYM_POMDP_AMD_LIB: another build of the same library (tools/ab_build.sh variants for same-box A/B runs)
-LIB_PATH = os.environ.get("GYM_POMDP_AMD_LIB") or os.path.join(_PKG, "_lib", "libpomdp_hip.so")
+INTREE_LIB_PATH = os.path.join(_PKG, "_lib", "libpomdp_hip.so")
+# GYM_POMDP_AMD_LIB: another build of the same library (tools/ab_build.sh variants for same-box A/B runs).  It redirects
+# what lib() LOADS; build() writes the in-tree path unless it is given `out` (a rebuild never overwrites a variant).
+LIB_PATH = os.environ.get("GYM_POMDP_AMD_LIB") or INTREE_LIB_PATH
 # one object per translation unit (built in parallel), linked into one shared library
 UNITS = ["api.hip", "step_rock.hip", "step_other.hip", "fused_rock.hip", "fused_stochrock.hip", "fused_tag.hip",
          "fused_battleship.hip", "fused_misc.hip", "planner.hip"]
-HEADERS = ["kernels_common.hip.h", "step_impl.hip.h", "fused_impl.hip.h", "envs.hip.h", "envs_common.hip.h", "philox.hip.h",
+HEADERS = ["kernels_common.hip.h", "traj_out.hip.h", "step_impl.hip.h", "fused_impl.hip.h", "envs.hip.h", "envs_common.hip.h", "philox.hip.h",
            "envs/rock.hip.h", "envs/tag.hip.h", "envs/battleship.hip.h", "envs/tiger.hip.h", "envs/network.hip.h"]
 SOURCES = [os.path.join(_PKG, "csrc", f) for f in UNITS + HEADERS]
 HEADER = os.path.join(_REPO, "include", "pomdp_hip.h")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 POMDP_AUTO_RESET = 1
 POMDP_FUSE_STEPS = 2
 POMDP_ROLLOUT_ALL_ACTIONS = 1
+LAYOUTS = {"columns": 0, "blocked": 1, "packed": 2}     # POMDP_LAYOUT_*
 ENV_KIND = {"rock": 0, "tag": 1, "battleship": 2, "tiger": 3, "network": 4}
 
 # every symbol include/pomdp_hip.h declares
@@ -32,7 +35,7 @@ SYMBOLS = [
     "pomdp_rock_reset", "pomdp_rock_step", "pomdp_tag_reset", "pomdp_tag_step",
     "pomdp_battleship_reset", "pomdp_battleship_step", "pomdp_tiger_reset", "pomdp_tiger_step",
     "pomdp_network_reset", "pomdp_network_step", "pomdp_step", "pomdp_step_sync", "pomdp_reset_sync", "pomdp_stream_sync", "pomdp_synthetic_actions", "pomdp_philox_blocks",
-    "pomdp_rollout_synthetic", "pomdp_collect_synthetic", "pomdp_collect", "pomdp_legal_actions", "pomdp_rollout", "pomdp_compute_prob",
+    "pomdp_rollout_synthetic", "pomdp_collect_synthetic", "pomdp_collect", "pomdp_collect_layout", "pomdp_collect_traj", "pomdp_packed_reward", "pomdp_legal_actions", "pomdp_rollout", "pomdp_compute_prob",
     "pomdp_rock_belief_reset", "pomdp_rock_belief_refresh", "pomdp_rock_belief_update", "pomdp_rock_select_target", "pomdp_history_clear",
     "pomdp_history_append", "pomdp_preferred_actions", "pomdp_pick_actions", "pomdp_heuristic_steps",
 ]
@@ -75,6 +78,12 @@ class CollectArgs(C.Structure):     # pomdp_collect_args
                 ("pitch", C.c_int64), ("seed", C.c_uint64), ("lane0", C.c_uint32), ("reserved", C.c_uint32)]
 
 
+class TrajArgs(C.Structure):        # pomdp_traj_args
+    _fields_ = [("env", C.c_int32), ("flags", C.c_int32), ("layout", C.c_int32), ("reserved", C.c_int32), ("params", C.c_void_p),
+                ("state", C.c_void_p), ("traj", C.c_void_p), ("err", C.c_void_p), ("n", C.c_int64), ("pitch", C.c_int64),
+                ("seed", C.c_uint64), ("lane0", C.c_uint32), ("reserved2", C.c_uint32)]
+
+
 class RockBelief(C.Structure):      # pomdp_rock_belief: device pointers, [num_rocks][n]
     _fields_ = [(k, C.c_void_p) for k in ("count", "measured", "lkv", "lkw", "prob_valuable", "check_ok")]
 
@@ -100,7 +109,7 @@ def build(force=False, verbose=False, defines=(), out=None, jobs=None):
     csrc/ to its own object, in parallel, then one link.  `defines` (-DNAME=VALUE strings) and `out` build same-box A/B
     variants (tools/ab_build.sh)."""
     from concurrent.futures import ThreadPoolExecutor
-    lib_path = out or LIB_PATH
+    lib_path = out or INTREE_LIB_PATH
     deps = SOURCES + [HEADER]
     if (not force and not defines and os.path.exists(lib_path)
             and all(os.path.getmtime(lib_path) >= os.path.getmtime(d) for d in deps)):
@@ -138,6 +147,9 @@ def lib():
         raise RuntimeError(
             "gym_pomdp_amd: HIP library %s is missing — build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` (hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+    if LIB_PATH != INTREE_LIB_PATH:
+        import sys
+        print("gym_pomdp_amd: loading the library variant GYM_POMDP_AMD_LIB=%s" % LIB_PATH, file=sys.stderr)
     L = C.CDLL(LIB_PATH)
     missing = [s for s in SYMBOLS if not hasattr(L, s)]
     if missing:
@@ -174,6 +186,12 @@ def lib():
     L.pomdp_collect_synthetic.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, i64, u64, u32, u64, i64, i64, ci, vp]
     L.pomdp_collect.restype = ci
     L.pomdp_collect.argtypes = [vp, u64, i64, vp]
+    L.pomdp_collect_layout.restype = ci
+    L.pomdp_collect_layout.argtypes = [ci, vp, vp, vp, vp, i64, u64, u32, u64, i64, i64, ci, ci, vp]
+    L.pomdp_collect_traj.restype = ci
+    L.pomdp_collect_traj.argtypes = [vp, u64, i64, vp]
+    L.pomdp_packed_reward.restype = C.c_double
+    L.pomdp_packed_reward.argtypes = [ci, u32]
     L.pomdp_legal_actions.restype = ci
     L.pomdp_legal_actions.argtypes = [ci, vp, vp, vp, vp, i64, ci, vp]
     L.pomdp_compute_prob.restype = ci

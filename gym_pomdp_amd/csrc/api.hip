@@ -302,7 +302,7 @@ int pomdp_rollout_synthetic(int env, const void *params, uint32_t *state, int32_
             rc = dispatch_env(env, params, [&](auto tag, const auto &p) {
                 using E = typename decltype(tag)::Env;
                 return launch_steps_fused<E>(p, state, action, ob, (typename E::Reward *)reward, done, err, n, seed,
-                                             action_seed, lane0, t, c, flags, 0, s == 0, stream);
+                                             action_seed, lane0, t, c, flags, 0, s == 0, POMDP_LAYOUT_COLUMNS, stream);
             });
             if (rc) return rc;
         }
@@ -353,7 +353,7 @@ int pomdp_collect_synthetic(int env, const void *params, uint32_t *state, int32_
             using R = typename E::Reward;
             return launch_steps_fused<E>(p, state, action + s * pitch, ob + s * pitch, (R *)reward + s * pitch,
                                          done + s * pitch, err, n, seed, seed, lane0, t0 + (uint64_t)s, c, flags, pitch,
-                                         s == 0, stream);
+                                         s == 0, POMDP_LAYOUT_COLUMNS, stream);
         });
         if (rc) return rc;
     }
@@ -365,6 +365,54 @@ int pomdp_collect(const pomdp_collect_args *a, uint64_t t0, int64_t k_steps, voi
     if (!a) return POMDP_E_BADARG;
     return pomdp_collect_synthetic(a->env, a->params, a->state, a->action, a->ob, a->reward, a->done, a->err, a->n, a->seed,
                                    a->lane0, t0, k_steps, a->pitch, a->flags, stream);
+}
+
+// Trajectory collection into one of the single-stream layouts (include/pomdp_hip.h: POMDP_LAYOUT_BLOCKED / _PACKED): the
+// launches of pomdp_collect_synthetic with another sink (traj_out.hip.h).
+int pomdp_collect_layout(int env, const void *params, uint32_t *state, void *traj, uint32_t *err, int64_t n, uint64_t seed,
+                         uint32_t lane0, uint64_t t0, int64_t k_steps, int64_t pitch, int layout, int flags, void *stream)
+{
+    if (layout != POMDP_LAYOUT_BLOCKED && layout != POMDP_LAYOUT_PACKED) return POMDP_E_BADARG;
+    int rc = check_driver_args(env, params, state, traj, traj, traj, traj, n, lane0, k_steps);
+    if (rc) return rc;
+    if (pitch < n || !(flags & POMDP_AUTO_RESET)) return POMDP_E_BADARG;
+    if (layout == POMDP_LAYOUT_BLOCKED && pitch % 256 != 0) return POMDP_E_BADARG;
+    // a Packed record keeps action and observation in a byte each: every env's fit by construction except Tag's
+    // "opponent seen" value, which is a constructor argument (tag.py:94)
+    if (layout == POMDP_LAYOUT_PACKED && env == POMDP_ENV_TAG && (uint32_t)((const pomdp_tag_params *)params)->obs_cells > 255u)
+        return POMDP_E_BADPARAMS;
+    if (k_steps == 0 || n == 0) return 0;
+    const int64_t row_bytes = layout == POMDP_LAYOUT_BLOCKED ? pitch * 13 : pitch * 4;
+    constexpr int64_t FUSE_MAX = 64;
+    for (int64_t s = 0; s < k_steps; s += FUSE_MAX) {
+        const int c = (int)(k_steps - s < FUSE_MAX ? k_steps - s : FUSE_MAX);
+        int32_t *base = reinterpret_cast<int32_t *>(reinterpret_cast<uint8_t *>(traj) + s * row_bytes);
+        rc = dispatch_env(env, params, [&](auto tag, const auto &p) {
+            using E = typename decltype(tag)::Env;
+            return launch_steps_fused<E>(p, state, base, nullptr, nullptr, nullptr, err, n, seed, seed, lane0, t0 + (uint64_t)s, c,
+                                         flags, pitch, true, layout, stream);
+        });
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int pomdp_collect_traj(const pomdp_traj_args *a, uint64_t t0, int64_t k_steps, void *stream)
+{
+    if (!a) return POMDP_E_BADARG;
+    return pomdp_collect_layout(a->env, a->params, a->state, a->traj, a->err, a->n, a->seed, a->lane0, t0, k_steps, a->pitch,
+                                a->layout, a->flags, stream);
+}
+
+double pomdp_packed_reward(int env, uint32_t code)
+{
+    code &= 0xFFu;
+    if (env != POMDP_ENV_NETWORK) return (double)(int8_t)code;       // the reward itself
+    const int kind = (int)code / NetworkEnv::REWARD_BASES, base = (int)code % NetworkEnv::REWARD_BASES;
+    double r = (double)base;                                           // network.py:87-92, 103, 110 — as the kernels' rtab
+    if (kind == 1) r -= .1;
+    if (kind == 2) r -= 2.5;
+    return (double)(float)r;
 }
 
 int pomdp_philox_blocks(const uint32_t *ctr_key, uint32_t *out, int64_t n_blocks, void *stream)

@@ -29,6 +29,18 @@ struct NetworkEnv {
         sh.nbf[k][v] = m;
     }
     static __device__ __forceinline__ int n_actions(const Params &p) { return 2 * p.n_machines + 1; }
+    // The reward byte of a Packed trajectory record (traj_out.hip.h).  Network's reward is float32(base - cost) with base =
+    // 2 per up machine with more than two neighbours + 1 per other up machine (<= 64) and cost 0 (no action), .1 (ping) or 2.5
+    // (reboot): network.py:87-92, 103, 110.  code = kind * 68 + base, kind 0 / 1 / 2 in that order; pomdp_packed_reward() and
+    // the host's table turn it back into the same float.  From the float itself: the fractional part names the kind.
+    static constexpr int REWARD_BASES = 68;
+    static __device__ __forceinline__ uint32_t reward_code(int kind, int base) { return (uint32_t)(kind * REWARD_BASES + base); }
+    static __device__ __forceinline__ uint32_t reward_code(Reward r)
+    {
+        const float f = floorf(r), frac = r - f;                                // 0 | .9 (base - .1) | .5 (base - 2.5)
+        const int kind = frac == 0.f ? 0 : (frac == .5f ? 2 : 1);
+        return reward_code(kind, (int)f + (kind == 0 ? 0 : kind == 1 ? 1 : 3));
+    }
     static __device__ __forceinline__ void load(State &st, const uint32_t *state, int64_t, uint32_t i) { st.w = ld_stream(state + i); }
     static __device__ __forceinline__ void store(const State &st, uint32_t *state, int64_t, uint32_t i, bool) { st_stream(state + i, st.w); }
 

@@ -79,6 +79,8 @@ struct RockEnv {
     }
     static __device__ __forceinline__ void stage(Shared &sh, const Params &p, int tid) { stage_store(sh, stage_load(p, tid), tid); }
     static __device__ __forceinline__ int n_actions(const Params &p) { return 5 + p.num_rocks; }
+    // the reward byte of a Packed trajectory record (traj_out.hip.h): the reward itself, an int8
+    static __device__ __forceinline__ uint32_t reward_code(Reward r) { return (uint32_t)(int)r; }
     // the position tables preferred_mask reads; kernels that call it run this next to stage()
     static __device__ __forceinline__ void stage_policy(Shared &sh, const Params &p, int tid)
     {

@@ -24,6 +24,8 @@ struct TigerEnv {
 
     static __device__ __forceinline__ void stage(Shared &, const Params &, int) {}
     static __device__ __forceinline__ int n_actions(const Params &) { return 3; }
+    // the reward byte of a Packed trajectory record (traj_out.hip.h): the reward itself, an int8
+    static __device__ __forceinline__ uint32_t reward_code(Reward r) { return (uint32_t)(int)r; }
     static __device__ __forceinline__ void load(State &st, const uint32_t *state, int64_t, uint32_t i) { st.w = ld_stream(state + i); }
     static __device__ __forceinline__ void store(const State &st, uint32_t *state, int64_t, uint32_t i, bool) { st_stream(state + i, st.w); }
 

@@ -15,7 +15,9 @@ namespace pomdp {
 // no lane is ever out of range or frozen, and the actions are the driver's own (always valid): the bookkeeping for those
 // cases is compiled out.
 
-template <class Env, int LPT, bool SIMPLE, bool TAB = false>
+// L: the trajectory layout the steps are written in (traj_out.hip.h).  Blocked / Packed: `action` is the trajectory's base,
+// ob / reward / done are not used, and the launch derives its first actions itself (FLAG_GEN_FIRST is always set).
+template <class Env, int LPT, bool SIMPLE, bool TAB = false, class L = Columns>
 __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ state, int32_t *__restrict__ action,
                                                       int32_t *__restrict__ ob, typename Env::Reward *__restrict__ reward,
                                                       uint8_t *__restrict__ done, uint32_t *__restrict__ err, int64_t n,
@@ -30,11 +32,9 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
     const uint32_t last = SIMPLE ? (uint32_t)(BLOCK * LPT - 1) : (uint32_t)((uint64_t)(n - 1) - wg0);
     // rec = 0: every step overwrites the same n-element outputs (what the per-step launches do); rec = row pitch in
     // elements: step s writes row s of ob / reward / done and row s + 1 of action (row s being the actions it took)
-    int32_t *action_w = action + wg0;
+    LaneOut<L, typename Env::Reward> out(action, ob, reward, done, rec, wg0);
     uint32_t *const state_w = state + wg0;
-    int32_t *ob_w = ob + wg0;
-    typename Env::Reward *reward_w = reward + wg0;
-    uint8_t *done_w = done + wg0;
+    constexpr bool COLS = L::ID == POMDP_LAYOUT_COLUMNS;     // only the column layout has a row of first actions / done flags to read
     uint32_t rel[LPT], glane[LPT];
     bool in_range[LPT], was_done[LPT], ever_fresh[LPT];
     int a_cur[LPT];
@@ -47,26 +47,27 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
         in_range[j] = SIMPLE || rel[j] <= last;
         const uint32_t rc = in_range[j] ? rel[j] : last;
         __builtin_assume(rc < (uint32_t)(BLOCK * LPT));
-        a_cur[j] = (flags & FLAG_GEN_FIRST) ? 0 : ld_stream(action_w + rc);
+        a_cur[j] = (!COLS || (flags & FLAG_GEN_FIRST)) ? 0 : out.load_first(rc);
         Env::load(st[j], state_w, n, rc);
         if constexpr (has_next<Env>::value) Env::load_next(st[j], state_w, n, rc);   // once per launch, with the other words
-        was_done[j] = auto_reset ? false : (ld_stream(done_w + rc) != 0);
+        if constexpr (COLS) was_done[j] = auto_reset ? false : (ld_stream(done + wg0 + rc) != 0);
+        else was_done[j] = false;
     }
     using Fin = Finisher<Env, LPT, true>;
     constexpr bool quad_policy = quad_policy_of<Fin>::value;
     uint4 aq = make_uint4(0, 0, 0, 0), sq = make_uint4(0, 0, 0, 0), rq = make_uint4(0, 0, 0, 0);
     const int n_act = Env::n_actions(p);
     const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo, ta0 = ((uint64_t)akey0.t_hi << 32) | akey0.t_lo;
-    if (flags & FLAG_GEN_FIRST) {                        // wave-uniform: the policy's actions of the first call counter
+    if (!COLS || (flags & FLAG_GEN_FIRST)) {             // wave-uniform: the policy's actions of the first call counter
         RngKey fkey = akey0;
         fkey.t_lo = (uint32_t)(ta0 - 1ull); fkey.t_hi = (uint32_t)((ta0 - 1ull) >> 32);
 #pragma unroll
         for (int j = 0; j < LPT; ++j) {
             a_cur[j] = synthetic_action(fkey, glane[j], (uint32_t)n_act);
-            if (in_range[j]) st_stream(action_w + rel[j], (int32_t)a_cur[j]);
+            if (in_range[j]) out.store_first(rel[j], a_cur[j]);
         }
     }
-    action_w += rec;
+    out.first_done();
     // Tables once, BEFORE the loop; the first pre-pass rides under the load latency.  The staging reads the kernarg-resident
     // tables with vector loads, and a loop that contains any load keeps the compiler from settling the loads above in the
     // loop's pre-header: it then waits on vmcnt(0) in EVERY iteration for a register that arrived long ago — and stores
@@ -149,18 +150,18 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
 #pragma unroll
         for (int j = 0; j < LPT; ++j) {
             if (!live[j]) { o[j] = 0; st[j] = before[j]; }                  // a lane that did not step keeps its state
-            if (in_range[j]) st_stream(action_w + rel[j], (int32_t)a_next[j]);
+            if (in_range[j]) out.put_next_action(rel[j], a_next[j]);
             ever_fresh[j] |= fresh[j];
             if (in_range[j]) {
-                st_stream(ob_w + rel[j], (int32_t)o[j]);
-                st_stream(reward_w + rel[j], r[j]);
-                st_stream(done_w + rel[j], (uint8_t)d[j]);
+                uint32_t rcode = 0;
+                if constexpr (L::ID == POMDP_LAYOUT_PACKED) rcode = Env::reward_code(r[j]);
+                out.put(rel[j], a_cur[j], o[j], r[j], rcode, d[j]);
                 if (!valid[j] && !was_done[j] && err) atomicAdd(err, 1u);
             }
             a_cur[j] = a_next[j];
             was_done[j] = auto_reset ? false : (d[j] != 0);
         }
-        action_w += rec; ob_w += rec; reward_w += rec; done_w += rec;
+        out.next_row();
         if constexpr (Fin::LOOP_BARRIER && !quad_policy) __syncthreads();
     }
     // the state is the loop's carry: it lived in registers and reaches memory once (a lane that never stepped writes back
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
 // actions come in the same way.  The lane step is the table-driven one.  Full workgroups of 1024 lanes and auto-reset
 // only (the launcher's SIMPLE conditions).  Same results as steps_kernel: the mapping of lanes to threads is invisible
 // to a lane's random words.
-template <class Env>
+template <class Env, class L = Columns>
 __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict__ state, int32_t *__restrict__ action,
                                                            int32_t *__restrict__ ob, int32_t *__restrict__ reward,
                                                            uint8_t *__restrict__ done, int64_t n, RngKey key0, uint32_t lane0,
@@ -194,9 +195,7 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
     TL_HW();
     const uint32_t l0 = blockIdx.x * (uint32_t)(4 * BLOCK) + 4u * threadIdx.x;   // this thread's first lane within the shard
     const uint32_t glane0 = lane0 + l0;                                          // ... and its global lane id (a multiple of 4)
-    uint32_t *action_w = reinterpret_cast<uint32_t *>(action) + l0, *ob_w = reinterpret_cast<uint32_t *>(ob) + l0;
-    uint32_t *reward_w = reinterpret_cast<uint32_t *>(reward) + l0;
-    uint32_t *done_w = reinterpret_cast<uint32_t *>(done + l0);
+    QuadOut<L> out(action, ob, reward, done, rec, l0);
     typename Env::State st[4];
     int a_cur[4];
     const uint32_t n_act = (uint32_t)Env::n_actions(p);
@@ -204,14 +203,13 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
         const u32x4 s_lo = ld_stream4(state + l0);
         u32x4 s_hi = {0, 0, 0, 0};
         if (W == 2) s_hi = ld_stream4(state + n + l0);
-        const u32x4 a4 = first_actions4(action_w, gen_first, glane0, akey0, n_act);
+        const u32x4 a4 = out.first(gen_first, glane0, akey0, n_act);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             a_cur[j] = (int)a4[j];
             st[j].s = (S)((uint64_t)s_lo[j] | ((uint64_t)s_hi[j] << 32));
         }
     }
-    action_w += rec;
     Env::stage(sh, p, (int)threadIdx.x);
     __syncthreads();
     TL(1);
@@ -247,6 +245,7 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
         }
         int r[4], d[4];
         uint32_t o[4], a_next[4], codes[4];
+        const uint32_t a_taken[4] = {(uint32_t)a_cur[0], (uint32_t)a_cur[1], (uint32_t)a_cur[2], (uint32_t)a_cur[3]};
         Env::reset_codes4(R, key, glane0, K, codes);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -264,11 +263,9 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
             a_next[j] = __umulhi(P[j], n_act);
             a_cur[j] = (int)a_next[j];
         }
-        st_stream4(action_w, a_next[0], a_next[1], a_next[2], a_next[3]);
-        st_stream4(ob_w, o[0], o[1], o[2], o[3]);
-        st_stream4(reward_w, (uint32_t)r[0], (uint32_t)r[1], (uint32_t)r[2], (uint32_t)r[3]);
-        st_stream(done_w, (uint32_t)d[0] | ((uint32_t)d[1] << 8) | ((uint32_t)d[2] << 16) | ((uint32_t)d[3] << 24));
-        action_w += rec; ob_w += rec; reward_w += rec; done_w += rec / 4;
+        const uint32_t r4[4] = {(uint32_t)r[0], (uint32_t)r[1], (uint32_t)r[2], (uint32_t)r[3]};   // the int8 reward IS its code
+        const uint32_t d4[4] = {(uint32_t)d[0], (uint32_t)d[1], (uint32_t)d[2], (uint32_t)d[3]};
+        out.put(a_taken, a_next, o, r4, r4, d4);
     }
     // the state is the loop's carry: it reaches memory once
     TL(3);
@@ -286,7 +283,7 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
 // Tag (one opponent) with a quad per thread: the policy's ACTION block is the thread's own, the flights of failed TAGs
 // (about a fifth of the lanes) and the rare resets are pooled per wave of 256 lanes — one Philox pass instead of the two per
 // 256 lanes that Finisher<TagEnv, 2> needs with the policy blocks in its task list — and the outputs leave as 16-byte stores.
-template <bool TAB>   // TAB: the lane step reads the (cells, action) table built when the launch starts (from 16 steps per launch)
+template <bool TAB, class L = Columns>   // TAB: the lane step reads the (cells, action) table built when the launch starts (from 16 steps per launch)
 __global__ __launch_bounds__(BLOCK) void tag_steps_quad_kernel(uint32_t *__restrict__ state, int32_t *__restrict__ action,
                                                                int32_t *__restrict__ ob, float *__restrict__ reward,
                                                                uint8_t *__restrict__ done, int64_t n, RngKey key0,
@@ -301,19 +298,16 @@ __global__ __launch_bounds__(BLOCK) void tag_steps_quad_kernel(uint32_t *__restr
     const int wv = (int)(threadIdx.x >> 6), me = (int)(threadIdx.x & 63u);
     const uint32_t l0 = blockIdx.x * (uint32_t)(4 * BLOCK) + 4u * threadIdx.x;
     const uint32_t glane0 = lane0 + l0, wave0 = glane0 - 4u * (uint32_t)me;
-    uint32_t *action_w = reinterpret_cast<uint32_t *>(action) + l0, *ob_w = reinterpret_cast<uint32_t *>(ob) + l0;
-    uint32_t *reward_w = reinterpret_cast<uint32_t *>(reward) + l0;
-    uint32_t *done_w = reinterpret_cast<uint32_t *>(done + l0);
+    QuadOut<L> out(action, ob, reward, done, rec, l0);
     Env::State st[4];
     int a_cur[4];
     const uint32_t n_act = (uint32_t)Env::n_actions(p);
     {
         const u32x4 s4 = ld_stream4(state + l0);
-        const u32x4 a4 = first_actions4(action_w, gen_first, glane0, akey0, n_act);
+        const u32x4 a4 = out.first(gen_first, glane0, akey0, n_act);
 #pragma unroll
         for (int j = 0; j < 4; ++j) { a_cur[j] = (int)a4[j]; st[j].w = s4[j]; }
     }
-    action_w += rec;
     Env::stage(sh, p, (int)threadIdx.x);
     __syncthreads();
     if constexpr (TAB) {
@@ -335,6 +329,7 @@ __global__ __launch_bounds__(BLOCK) void tag_steps_quad_kernel(uint32_t *__restr
         float r[4];
         Env::Flight f[4];
         uint64_t fm[4], rm[4];
+        const uint32_t a_taken[4] = {(uint32_t)a_cur[0], (uint32_t)a_cur[1], (uint32_t)a_cur[2], (uint32_t)a_cur[3]};
         int nfl = 0, nrs = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -384,11 +379,15 @@ __global__ __launch_bounds__(BLOCK) void tag_steps_quad_kernel(uint32_t *__restr
             a_next[j] = __umulhi(P[j], n_act);
             a_cur[j] = (int)a_next[j];
         }
-        st_stream4(action_w, a_next[0], a_next[1], a_next[2], a_next[3]);
-        st_stream4(ob_w, (uint32_t)o[0], (uint32_t)o[1], (uint32_t)o[2], (uint32_t)o[3]);
-        st_stream4(reward_w, __float_as_uint(r[0]), __float_as_uint(r[1]), __float_as_uint(r[2]), __float_as_uint(r[3]));
-        st_stream(done_w, (uint32_t)d[0] | ((uint32_t)d[1] << 8) | ((uint32_t)d[2] << 16) | ((uint32_t)d[3] << 24));
-        action_w += rec; ob_w += rec; reward_w += rec; done_w += rec / 4;
+        const uint32_t o4[4] = {(uint32_t)o[0], (uint32_t)o[1], (uint32_t)o[2], (uint32_t)o[3]};
+        const uint32_t r4[4] = {__float_as_uint(r[0]), __float_as_uint(r[1]), __float_as_uint(r[2]), __float_as_uint(r[3])};
+        const uint32_t d4[4] = {(uint32_t)d[0], (uint32_t)d[1], (uint32_t)d[2], (uint32_t)d[3]};
+        uint32_t rc[4] = {0, 0, 0, 0};
+        if constexpr (L::ID == POMDP_LAYOUT_PACKED) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rc[j] = Env::reward_code(r[j]);
+        }
+        out.put(a_taken, a_next, o4, r4, rc, d4);
     }
     st_stream4(state + l0, st[0].w, st[1].w, st[2].w, st[3].w);
 }
@@ -405,7 +404,7 @@ __global__ __launch_bounds__(BLOCK) void tag_steps_quad_kernel(uint32_t *__restr
 // is the thread's own, the outputs leave as 16-byte stores, the reward comes from a table of the float32(float64) values
 // the reference's arithmetic gives.  A draw decided by its low word (2^-27 per draw) sends the lane through
 // NetworkEnv::step_exact, the exact per-lane form.  Network never terminates, so there is no reset.
-template <int NB>   // bytes of the machine set: ceil(n_machines / 8)
+template <int NB, class L = Columns>   // NB: bytes of the machine set, ceil(n_machines / 8)
 __global__ __launch_bounds__(BLOCK) void network_steps_quad_kernel(uint32_t *__restrict__ state, int32_t *__restrict__ action,
                                                                    int32_t *__restrict__ ob, float *__restrict__ reward,
                                                                    uint8_t *__restrict__ done, int64_t n, RngKey key0,
@@ -424,19 +423,16 @@ __global__ __launch_bounds__(BLOCK) void network_steps_quad_kernel(uint32_t *__r
     const int wv = (int)(threadIdx.x >> 6), me = (int)(threadIdx.x & 63u);
     const uint32_t l0 = blockIdx.x * (uint32_t)(4 * BLOCK) + 4u * threadIdx.x;
     const uint32_t glane0 = lane0 + l0, wave0 = glane0 - 4u * (uint32_t)me;
-    uint32_t *action_w = reinterpret_cast<uint32_t *>(action) + l0, *ob_w = reinterpret_cast<uint32_t *>(ob) + l0;
-    uint32_t *reward_w = reinterpret_cast<uint32_t *>(reward) + l0;
-    uint32_t *done_w = reinterpret_cast<uint32_t *>(done + l0);
+    QuadOut<L> out(action, ob, reward, done, rec, l0);
     const uint32_t n_act = (uint32_t)Env::n_actions(p);
     uint32_t st[4];
     int a_cur[4];
     {
         const u32x4 s4 = ld_stream4(state + l0);
-        const u32x4 a4 = first_actions4(action_w, gen_first, glane0, akey0, n_act);
+        const u32x4 a4 = out.first(gen_first, glane0, akey0, n_act);
 #pragma unroll
         for (int j = 0; j < 4; ++j) { a_cur[j] = (int)a4[j]; st[j] = s4[j]; }
     }
-    action_w += rec;
     Env::stage(sh, p, (int)threadIdx.x);
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb) {                        // BLOCK threads = the 256 values of a byte
@@ -554,7 +550,8 @@ __global__ __launch_bounds__(BLOCK) void network_steps_quad_kernel(uint32_t *__r
                 near[j] = (more[j] && (tf[j] & 2u)) ? 0u : near[j];
             }
         }
-        uint32_t o4[4], r4[4], a_next[4];
+        uint32_t o4[4], r4[4], a_next[4], rc[4] = {0, 0, 0, 0};
+        const uint32_t a_taken[4] = {(uint32_t)a_cur[0], (uint32_t)a_cur[1], (uint32_t)a_cur[2], (uint32_t)a_cur[3]};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             int o;
@@ -564,6 +561,7 @@ __global__ __launch_bounds__(BLOCK) void network_steps_quad_kernel(uint32_t *__r
                 int d;
                 Env::step_exact(sh, p, e, a_cur[j], key, glane0 + (uint32_t)j, o, r, d);
                 st[j] = e.w;
+                if constexpr (L::ID == POMDP_LAYOUT_PACKED) rc[j] = Env::reward_code(r);
             } else {                                                           // network.py:101-112
                 const int a = a_cur[j], machine = (a >> 1) & 31;
                 const bool has_action = a < M2, reboot = has_action && (a & 1);
@@ -572,6 +570,7 @@ __global__ __launch_bounds__(BLOCK) void network_steps_quad_kernel(uint32_t *__r
                 const int up = (int)((sn >> machine) & 1u);                    // a rebooted machine is up: ob = truthful either way
                 o = has_action ? (truthful[j] ? up : 1 - up) : 2;
                 r = rtab[has_action ? 1 + (a & 1) : 0][base[j]];
+                if constexpr (L::ID == POMDP_LAYOUT_PACKED) rc[j] = Env::reward_code(has_action ? 1 + (a & 1) : 0, base[j]);
                 st[j] = sn;
             }
             o4[j] = (uint32_t)o;
@@ -579,11 +578,8 @@ __global__ __launch_bounds__(BLOCK) void network_steps_quad_kernel(uint32_t *__r
             a_next[j] = __umulhi(P[j], n_act);
             a_cur[j] = (int)a_next[j];
         }
-        st_stream4(action_w, a_next[0], a_next[1], a_next[2], a_next[3]);
-        st_stream4(ob_w, o4[0], o4[1], o4[2], o4[3]);
-        st_stream4(reward_w, r4[0], r4[1], r4[2], r4[3]);
-        st_stream(done_w, 0u);                                                 // network.py:113: never done
-        action_w += rec; ob_w += rec; reward_w += rec; done_w += rec / 4;
+        const uint32_t d4[4] = {0u, 0u, 0u, 0u};                               // network.py:113: never done
+        out.put(a_taken, a_next, o4, r4, rc, d4);
     }
     st_stream4(state + l0, st[0], st[1], st[2], st[3]);
 }
@@ -597,7 +593,7 @@ __global__ __launch_bounds__(BLOCK) void network_steps_quad_kernel(uint32_t *__r
 // are built AFTER the loop, dealt out one per thread and 64 side by side (board_lockstep).  A lane that finishes a second
 // episode before its next board exists triggers that pass early, for every lane of the wave that is waiting.  The state
 // that reaches memory is the same whichever kernel ran: current board, visited mask, next board.
-template <int MW>
+template <int MW, class L = Columns>
 __global__ __launch_bounds__(BLOCK) void battleship_steps_quad_kernel(uint32_t *__restrict__ state, int32_t *__restrict__ action,
                                                                       int32_t *__restrict__ ob, int32_t *__restrict__ reward,
                                                                       uint8_t *__restrict__ done, int64_t n, RngKey key0,
@@ -618,9 +614,7 @@ __global__ __launch_bounds__(BLOCK) void battleship_steps_quad_kernel(uint32_t *
     const int wv = (int)(threadIdx.x >> 6), me = (int)(threadIdx.x & 63u), tid = (int)threadIdx.x;
     const uint32_t l0 = blockIdx.x * (uint32_t)(4 * BLOCK) + 4u * threadIdx.x;
     const uint32_t glane0 = lane0 + l0, wave0 = glane0 - 4u * (uint32_t)me;
-    uint32_t *action_w = reinterpret_cast<uint32_t *>(action) + l0, *ob_w = reinterpret_cast<uint32_t *>(ob) + l0;
-    uint32_t *reward_w = reinterpret_cast<uint32_t *>(reward) + l0;
-    uint32_t *done_w = reinterpret_cast<uint32_t *>(done + l0);
+    QuadOut<L> out(action, ob, reward, done, rec, l0);
     const uint32_t n_act = (uint32_t)Env::n_actions(p);
     Mask vis[4];
     int a_cur[4];
@@ -628,7 +622,7 @@ __global__ __launch_bounds__(BLOCK) void battleship_steps_quad_kernel(uint32_t *
         u32x4 w[3 * MW];
 #pragma unroll
         for (int q = 0; q < 3 * MW; ++q) w[q] = ld_stream4(state + (int64_t)q * n + l0);
-        const u32x4 a4 = first_actions4(action_w, gen_first, glane0, akey0, n_act);
+        const u32x4 a4 = out.first(gen_first, glane0, akey0, n_act);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             a_cur[j] = (int)a4[j];
@@ -637,7 +631,6 @@ __global__ __launch_bounds__(BLOCK) void battleship_steps_quad_kernel(uint32_t *
             for (int q = 0; q < MW; ++q) { occ_lds[q][j][tid] = w[q][j]; vis[j].set_word(q, w[MW + q][j]); next_lds[q][j][tid] = w[2 * MW + q][j]; }
         }
     }
-    action_w += rec;
     __syncthreads();
     const int cells = p.x_size * p.y_size;
     const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo, ta0 = ((uint64_t)akey0.t_hi << 32) | akey0.t_lo;
@@ -654,6 +647,10 @@ __global__ __launch_bounds__(BLOCK) void battleship_steps_quad_kernel(uint32_t *
             pend[j] = -1;
         }
         if (ntask == 0) return;                                                // wave-uniform
+        // the task list is read by OTHER lanes of this wave (take): pin the LDS order the hand-off relies on — no
+        // instruction on hardware (a wave's LDS operations execute in order), but the compiler may not move the reads up
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         // A pool of 64 builders works the task list off: every lane feeds its board one word of its stream per iteration
         // (four iterations per Philox block, the blocks computed by all lanes at once, each with its own counter), and a
         // lane whose board is complete takes the next unclaimed task at the following block boundary instead of idling
@@ -689,6 +686,9 @@ __global__ __launch_bounds__(BLOCK) void battleship_steps_quad_kernel(uint32_t *
                 next_task += __popcll(fm);
             }
         }
+        // the builders wrote next_lds slots that their OWNERS read (swap-in, final store): same hand-off, same pin
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     };
     wait_loads();
     // The ladder from 32 steps per launch only: the board builders that follow the loop are instruction-bound where the loop
@@ -704,7 +704,8 @@ __global__ __launch_bounds__(BLOCK) void battleship_steps_quad_kernel(uint32_t *
         const uint64_t ta = ta0 + (uint64_t)s;
         const uint4 pw = philox4x32_10(glane0 >> 2, (uint32_t)ta, (uint32_t)(ta >> 32), (uint32_t)POMDP_STREAM_ACTION << 24, akey0.k0, akey0.k1);
         const uint32_t P[4] = {pw.x, pw.y, pw.z, pw.w};
-        uint32_t o4[4], r4[4], a_next[4], dpack = 0;
+        uint32_t o4[4], r4[4], a_next[4], d4[4];
+        const uint32_t a_taken[4] = {(uint32_t)a_cur[0], (uint32_t)a_cur[1], (uint32_t)a_cur[2], (uint32_t)a_cur[3]};
         bool d[4], again = false;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {                                          // battleship.py:91-122: draws nothing
@@ -719,15 +720,11 @@ __global__ __launch_bounds__(BLOCK) void battleship_steps_quad_kernel(uint32_t *
             vis[j].set_word(MW - 1, (vis[j].word(MW - 1) & 0x03FFFFFFu) | ((uint32_t)remaining << 26));
             again |= d[j] && pend[j] >= 0;
             o4[j] = (uint32_t)(!visited && hit); r4[j] = (uint32_t)r;
-            dpack |= (uint32_t)d[j] << (8 * j);
+            d4[j] = (uint32_t)d[j];
             a_next[j] = __umulhi(P[j], n_act);
             a_cur[j] = (int)a_next[j];
         }
-        st_stream4(action_w, a_next[0], a_next[1], a_next[2], a_next[3]);
-        st_stream4(ob_w, o4[0], o4[1], o4[2], o4[3]);
-        st_stream4(reward_w, r4[0], r4[1], r4[2], r4[3]);
-        st_stream(done_w, dpack);
-        action_w += rec; ob_w += rec; reward_w += rec; done_w += rec / 4;
+        out.put(a_taken, a_next, o4, r4, r4, d4);                              // the int8 reward IS its code
         if (__any(again)) build_boards();                                      // a second episode ended before the lane's next board exists
         if (__any(d[0] || d[1] || d[2] || d[3])) {                             // wave-uniform: the cached boards move in
 #pragma unroll
@@ -761,7 +758,7 @@ template <class Env> struct quad_tab<Env, std::enable_if_t<Env::QUAD_TAB>> : std
 template <class Env, class = void> struct quad_fused : std::false_type {};
 template <class Env> struct quad_fused<Env, std::enable_if_t<Env::QUAD_FUSED>> : std::true_type {};
 
-template <class Env>
+template <class Env, class L = Columns>
 __global__ __launch_bounds__(BLOCK) void steps_quad_generic_kernel(uint32_t *__restrict__ state, int32_t *__restrict__ action,
                                                                    int32_t *__restrict__ ob,
                                                                    typename Env::Reward *__restrict__ reward,
@@ -773,20 +770,17 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_generic_kernel(uint32_t *__r
     __shared__ typename Env::Shared sh;
     const uint32_t l0 = blockIdx.x * (uint32_t)(4 * BLOCK) + 4u * threadIdx.x;
     const uint32_t glane0 = lane0 + l0;
-    uint32_t *action_w = reinterpret_cast<uint32_t *>(action) + l0, *ob_w = reinterpret_cast<uint32_t *>(ob) + l0;
-    uint32_t *reward_w = reinterpret_cast<uint32_t *>(reward) + l0;
-    uint32_t *done_w = reinterpret_cast<uint32_t *>(done + l0);
+    QuadOut<L> out(action, ob, reward, done, rec, l0);
     typename Env::State st[4];
     int a_cur[4];
     const uint32_t n_act = (uint32_t)Env::n_actions(p);
     {
 #pragma unroll
         for (int j = 0; j < 4; ++j) Env::load(st[j], state, n, l0 + (uint32_t)j);
-        const u32x4 a4 = first_actions4(action_w, gen_first, glane0, akey0, n_act);
+        const u32x4 a4 = out.first(gen_first, glane0, akey0, n_act);
 #pragma unroll
         for (int j = 0; j < 4; ++j) a_cur[j] = (int)a4[j];
     }
-    action_w += rec;
     Env::stage(sh, p, (int)threadIdx.x);
     __syncthreads();
     const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo, ta0 = ((uint64_t)akey0.t_hi << 32) | akey0.t_lo;
@@ -800,7 +794,8 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_generic_kernel(uint32_t *__r
         const uint64_t ta = ta0 + (uint64_t)s;
         const uint4 pw = philox4x32_10(glane0 >> 2, (uint32_t)ta, (uint32_t)(ta >> 32), (uint32_t)POMDP_STREAM_ACTION << 24, key.k0, key.k1);
         const uint32_t P[4] = {pw.x, pw.y, pw.z, pw.w};
-        uint32_t o4[4], r4[4], a_next[4], dpack = 0;
+        uint32_t o4[4], r4[4], a_next[4], d4[4], rc[4] = {0, 0, 0, 0};
+        const uint32_t a_taken[4] = {(uint32_t)a_cur[0], (uint32_t)a_cur[1], (uint32_t)a_cur[2], (uint32_t)a_cur[3]};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             int o, d;
@@ -810,15 +805,12 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_generic_kernel(uint32_t *__r
             Env::reset_where(sh, p, st[j], d != 0, key, lane);                 // wave-convergent: every lane calls it
             o4[j] = (uint32_t)o;
             __builtin_memcpy(&r4[j], &r, 4);
-            dpack |= (uint32_t)(d != 0) << (8 * j);
+            if constexpr (L::ID == POMDP_LAYOUT_PACKED) rc[j] = Env::reward_code(r);
+            d4[j] = (uint32_t)(d != 0);
             a_next[j] = __umulhi(P[j], n_act);
             a_cur[j] = (int)a_next[j];
         }
-        st_stream4(action_w, a_next[0], a_next[1], a_next[2], a_next[3]);
-        st_stream4(ob_w, o4[0], o4[1], o4[2], o4[3]);
-        st_stream4(reward_w, r4[0], r4[1], r4[2], r4[3]);
-        st_stream(done_w, dpack);
-        action_w += rec; ob_w += rec; reward_w += rec; done_w += rec / 4;
+        out.put(a_taken, a_next, o4, r4, rc, d4);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) Env::store(st[j], state, n, l0 + (uint32_t)j, true);
@@ -826,14 +818,27 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_generic_kernel(uint32_t *__r
 
 // the same as k launch_step_chain calls at t, t + 1, ..., in one launch.  gen_first: the launch derives the actions of
 // call counter t itself (and writes them to `action`) instead of reading them — the caller skips the policy launch.
-template <class Env>
-int launch_steps_fused(const typename Env::Params &p, uint32_t *state, int32_t *action, int32_t *ob,
-                              typename Env::Reward *reward, uint8_t *done, uint32_t *err, int64_t n, uint64_t seed,
-                              uint64_t action_seed, uint32_t lane0, uint64_t t, int k, int flags, int64_t rec, bool gen_first,
-                              void *stream)
+// L: the trajectory layout (traj_out.hip.h).  Blocked / Packed (trajectory collection only): `action` is the trajectory's
+// base — row-major, `rec` lanes per row —, ob / reward / done are ignored, auto-reset and the shared policy key are
+// required and every launch derives its first actions itself.
+template <class Env, class L>
+static int launch_steps_fused_l(const typename Env::Params &p, uint32_t *state, int32_t *action, int32_t *ob,
+                                typename Env::Reward *reward, uint8_t *done, uint32_t *err, int64_t n, uint64_t seed,
+                                uint64_t action_seed, uint32_t lane0, uint64_t t, int k, int flags, int64_t rec, bool gen_first,
+                                void *stream)
 {
-    if (!state || !action || !ob || !reward || !done || bad_range(n, lane0) || (lane0 & 3u) || k < 1) return POMDP_E_BADARG;
+    constexpr bool COLS = L::ID == POMDP_LAYOUT_COLUMNS;
+    if (!state || !action || bad_range(n, lane0) || (lane0 & 3u) || k < 1) return POMDP_E_BADARG;
+    if (COLS && (!ob || !reward || !done)) return POMDP_E_BADARG;
+    if (!COLS) {
+        if (!(flags & POMDP_AUTO_RESET) || action_seed != seed || rec < n) return POMDP_E_BADARG;
+        if (L::ID == POMDP_LAYOUT_BLOCKED && rec % TRAJ_BLOCK_LANES != 0) return POMDP_E_BADARG;
+        gen_first = true;
+        ob = nullptr; reward = nullptr; done = nullptr;
+    }
     if (n == 0) return 0;
+    char lname[24] = "";
+    if (!COLS) snprintf(lname, sizeof lname, ", %s", L::NAME);
     // two lanes per thread from 2^19 lanes, where the batch does not qualify for a quad-per-thread loop: at 2^18 lanes the
     // one-lane-per-thread loops take 0.90 (RockSample; 1.09 with two) and 1.08 us per step (Tag)
     const bool lpt2 = Env::POOLED_LPT2 && n >= 2 * LPT2_MIN_LANES;
@@ -841,12 +846,14 @@ int launch_steps_fused(const typename Env::Params &p, uint32_t *state, int32_t *
     const dim3 grid(lpt2 ? (unsigned)((n + 2 * BLOCK - 1) / (2 * BLOCK)) : blocks_for(n));
     const int kflags = (flags & POMDP_AUTO_RESET) | (gen_first ? FLAG_GEN_FIRST : 0);
     const int gf = gen_first ? 1 : 0;
+    char variant[64];
 #define POMDP_LAUNCH_STEPS(LPT_, SIMPLE_, GRID_)                                                                       \
     do {                                                                                                                 \
-        note_fused("steps_kernel", Env::NAME, ", " #LPT_ ", " #SIMPLE_);                                                 \
-        hipLaunchKernelGGL((steps_kernel<Env, LPT_, SIMPLE_>), GRID_, dim3(BLOCK), 0, (hipStream_t)stream, state, action, \
-                           ob, reward, done, err, n, make_key(seed, t), lane0, kflags, make_key(action_seed, t + 1), k,   \
-                           rec, p);                                                                                      \
+        snprintf(variant, sizeof variant, ", " #LPT_ ", " #SIMPLE_ "%s%s", COLS ? "" : ", false", lname);                 \
+        note_fused("steps_kernel", Env::NAME, variant);                                                                  \
+        hipLaunchKernelGGL((steps_kernel<Env, LPT_, SIMPLE_, false, L>), GRID_, dim3(BLOCK), 0, (hipStream_t)stream, state, \
+                           action, ob, reward, done, err, n, make_key(seed, t), lane0, kflags, make_key(action_seed, t + 1), \
+                           k, rec, p);                                                                                   \
     } while (0)
     // RockSample's pooled passes exist for any number of lanes per thread; in the fused loop (no load latency to hide)
     // four per thread, with fuller passes, beat two by 5 % from 2^20 lanes up (3.97 vs 4.16 us per step) when the state
@@ -854,20 +861,24 @@ int launch_steps_fused(const typename Env::Params &p, uint32_t *state, int32_t *
     // an env can take are instantiated.
     // the quad-per-thread loops move 16 bytes at a time (4 for the done bytes): columns that start on such a boundary
     // only, full workgroups of 1024 lanes, auto-reset, policy and env on one Philox key
-    const bool quad_ok = ((reinterpret_cast<uintptr_t>(state) | reinterpret_cast<uintptr_t>(action) | reinterpret_cast<uintptr_t>(ob) |
-                           reinterpret_cast<uintptr_t>(reward)) & 15u) == 0 && (reinterpret_cast<uintptr_t>(done) & 3u) == 0 &&
-                         rec % 4 == 0 && action_seed == seed && (flags & POMDP_AUTO_RESET) && n % (4 * BLOCK) == 0;
+    bool quad_ok = (reinterpret_cast<uintptr_t>(state) & 15u) == 0 && rec % 4 == 0 && action_seed == seed &&
+                   (flags & POMDP_AUTO_RESET) && n % (4 * BLOCK) == 0;
+    if (COLS)
+        quad_ok = quad_ok && ((reinterpret_cast<uintptr_t>(action) | reinterpret_cast<uintptr_t>(ob) | reinterpret_cast<uintptr_t>(reward)) & 15u) == 0 &&
+                  (reinterpret_cast<uintptr_t>(done) & 3u) == 0;
+    else
+        quad_ok = quad_ok && (reinterpret_cast<uintptr_t>(action) & 15u) == 0;
     const dim3 qgrid((unsigned)(n / (4 * BLOCK)));
     bool launched = false;
     if constexpr (std::is_same<Env, TagEnv>::value) {
         if (quad_ok && n >= QUAD_MIN_TAG && p.num_opponents == 1) {
             if (k >= 16 && TagEnv::tab_ok(p)) {
-                note_fused("tag_steps_quad_kernel", "true", "");
-                hipLaunchKernelGGL(tag_steps_quad_kernel<true>, qgrid, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob, reward,
+                note_fused("tag_steps_quad_kernel", "true", lname);
+                hipLaunchKernelGGL((tag_steps_quad_kernel<true, L>), qgrid, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob, reward,
                                    done, n, make_key(seed, t), lane0, make_key(action_seed, t + 1), k, rec, gf, p);
             } else {
-                note_fused("tag_steps_quad_kernel", "false", "");
-                hipLaunchKernelGGL(tag_steps_quad_kernel<false>, qgrid, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob, reward,
+                note_fused("tag_steps_quad_kernel", "false", lname);
+                hipLaunchKernelGGL((tag_steps_quad_kernel<false, L>), qgrid, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob, reward,
                                    done, n, make_key(seed, t), lane0, make_key(action_seed, t + 1), k, rec, gf, p);
             }
             launched = true;
@@ -875,17 +886,17 @@ int launch_steps_fused(const typename Env::Params &p, uint32_t *state, int32_t *
     }
     if constexpr (has_next<Env>::value) {
         if (quad_ok && n >= QUAD_MIN_BATTLESHIP && k <= 255) {
-            note_fused("battleship_steps_quad_kernel", Env::NAME, "");
-            hipLaunchKernelGGL(battleship_steps_quad_kernel<Env::WORDS / 3>, qgrid, dim3(BLOCK), 0, (hipStream_t)stream, state, action,
+            note_fused("battleship_steps_quad_kernel", Env::NAME, lname);
+            hipLaunchKernelGGL((battleship_steps_quad_kernel<Env::WORDS / 3, L>), qgrid, dim3(BLOCK), 0, (hipStream_t)stream, state, action,
                                ob, reward, done, n, make_key(seed, t), lane0, make_key(action_seed, t + 1), k, rec, gf, p);
             launched = true;
         }
     }
     if constexpr (std::is_same<Env, NetworkEnv>::value) {
         if (quad_ok && n >= QUAD_MIN_NETWORK) {
-            note_fused("network_steps_quad_kernel", "", "");
+            note_fused("network_steps_quad_kernel", "", COLS ? "" : lname + 2);
 #define POMDP_LAUNCH_NET(NB_)                                                                                            \
-    hipLaunchKernelGGL(network_steps_quad_kernel<NB_>, qgrid, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob, reward, \
+    hipLaunchKernelGGL((network_steps_quad_kernel<NB_, L>), qgrid, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob, reward, \
                        done, n, make_key(seed, t), lane0, make_key(action_seed, t + 1), k, rec, gf, p)
             switch ((p.n_machines + 7) / 8) {
             case 1: POMDP_LAUNCH_NET(1); break;
@@ -899,8 +910,8 @@ int launch_steps_fused(const typename Env::Params &p, uint32_t *state, int32_t *
     }
     if constexpr (quad_fused<Env>::value) {
         if (quad_ok && n >= QUAD_MIN_GENERIC) {
-            note_fused("steps_quad_generic_kernel", Env::NAME, "");
-            hipLaunchKernelGGL((steps_quad_generic_kernel<Env>), qgrid, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob,
+            note_fused("steps_quad_generic_kernel", Env::NAME, lname);
+            hipLaunchKernelGGL((steps_quad_generic_kernel<Env, L>), qgrid, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob,
                                reward, done, n, make_key(seed, t), lane0, make_key(action_seed, t + 1), k, rec, gf, p);
             launched = true;
         }
@@ -909,8 +920,8 @@ int launch_steps_fused(const typename Env::Params &p, uint32_t *state, int32_t *
         // from 16 steps per launch on the lane step reads the (position, action) table the workgroup builds first and a
         // thread owns a quad of consecutive lanes (steps_quad_kernel: RockSample and StochasticRock)
         if (quad_ok && n >= (Env::STOCHASTIC ? QUAD_MIN_STOCHROCK : QUAD_MIN_ROCK) && k >= 16 && p.num_rocks + 5 <= Env::TAB_ACTIONS) {
-            note_fused("steps_quad_kernel", Env::NAME, "");
-            hipLaunchKernelGGL((steps_quad_kernel<Env>), qgrid, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob, reward,
+            note_fused("steps_quad_kernel", Env::NAME, lname);
+            hipLaunchKernelGGL((steps_quad_kernel<Env, L>), qgrid, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob, reward,
                                done, n, make_key(seed, t), lane0, make_key(action_seed, t + 1), k, rec, gf, p);
             launched = true;
         }
@@ -930,8 +941,9 @@ int launch_steps_fused(const typename Env::Params &p, uint32_t *state, int32_t *
     if constexpr (quad_tab<Env>::value && Env::QUAD_SENSOR) {
         // RockSample's small shards, one lane per thread: the table-driven lane step from 16 steps per launch on
         if (!launched && simple && k >= 16 && p.num_rocks + 5 <= Env::TAB_ACTIONS) {
-            note_fused("steps_kernel", Env::NAME, ", 1, true, true");
-            hipLaunchKernelGGL((steps_kernel<Env, 1, true, true>), grid, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob, reward,
+            snprintf(variant, sizeof variant, ", 1, true, true%s", lname);
+            note_fused("steps_kernel", Env::NAME, variant);
+            hipLaunchKernelGGL((steps_kernel<Env, 1, true, true, L>), grid, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob, reward,
                                done, err, n, make_key(seed, t), lane0, kflags, make_key(action_seed, t + 1), k, rec, p);
             launched = true;
         }
@@ -939,6 +951,23 @@ int launch_steps_fused(const typename Env::Params &p, uint32_t *state, int32_t *
     if (!launched) { if (simple) POMDP_LAUNCH_STEPS(1, true, grid); else POMDP_LAUNCH_STEPS(1, false, grid); }
 #undef POMDP_LAUNCH_STEPS
     return (int)hipGetLastError();
+}
+
+template <class Env>
+int launch_steps_fused(const typename Env::Params &p, uint32_t *state, int32_t *action, int32_t *ob,
+                       typename Env::Reward *reward, uint8_t *done, uint32_t *err, int64_t n, uint64_t seed,
+                       uint64_t action_seed, uint32_t lane0, uint64_t t, int k, int flags, int64_t rec, bool gen_first,
+                       int layout, void *stream)
+{
+    switch (layout) {
+    case POMDP_LAYOUT_COLUMNS:
+        return launch_steps_fused_l<Env, Columns>(p, state, action, ob, reward, done, err, n, seed, action_seed, lane0, t, k, flags, rec, gen_first, stream);
+    case POMDP_LAYOUT_BLOCKED:
+        return launch_steps_fused_l<Env, Blocked>(p, state, action, ob, reward, done, err, n, seed, action_seed, lane0, t, k, flags, rec, gen_first, stream);
+    case POMDP_LAYOUT_PACKED:
+        return launch_steps_fused_l<Env, Packed>(p, state, action, ob, reward, done, err, n, seed, action_seed, lane0, t, k, flags, rec, gen_first, stream);
+    default: return POMDP_E_BADARG;
+    }
 }
 
 } // namespace pomdp

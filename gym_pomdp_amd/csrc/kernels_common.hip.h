@@ -15,6 +15,7 @@
 #include "../../include/pomdp_hip.h"
 #include "envs.hip.h"
 #include "philox.hip.h"
+#include "traj_out.hip.h"
 #include <cstdio>
 
 namespace pomdp {
@@ -366,7 +367,9 @@ struct LoopPrio {
         case 2: __builtin_amdgcn_s_setprio(1); end = k - t0; break;
         default: __builtin_amdgcn_s_setprio(0); return k;
         }
-        return UNIT == 1 ? end : (end + UNIT - 1) / UNIT * UNIT;
+        if (UNIT == 1) return end;
+        const int up = (end + UNIT - 1) / UNIT * UNIT;     // a stride's boundary, but never past the launch's last step
+        return up < k ? up : k;
     }
 };
 
@@ -393,19 +396,6 @@ static inline bool bad_range(int64_t n, uint32_t lane0) { return n < 0 || (uint6
 // the launcher that takes it sets the pointer back to null (defined in api.hip)
 extern thread_local uint32_t *tl_host_flag;
 extern thread_local uint32_t tl_flag_value;
-
-// The actions of a quad-per-thread launch's first step: read from row 0 of `action`, or (gen_first, wave-uniform) the
-// quad's block of the synthetic policy at the call counter before akey0's — computed here and written to that row.
-static __device__ __forceinline__ u32x4 first_actions4(uint32_t *action_row0, int gen_first, uint32_t glane0, const RngKey &akey0,
-                                                       uint32_t n_act)
-{
-    if (!gen_first) return ld_stream4(action_row0);
-    const uint64_t tf = (((uint64_t)akey0.t_hi << 32) | akey0.t_lo) - 1ull;
-    const uint4 w = philox4x32_10(glane0 >> 2, (uint32_t)tf, (uint32_t)(tf >> 32), (uint32_t)POMDP_STREAM_ACTION << 24, akey0.k0, akey0.k1);
-    const u32x4 a = {__umulhi(w.x, n_act), __umulhi(w.y, n_act), __umulhi(w.z, n_act), __umulhi(w.w, n_act)};
-    st_stream4(action_row0, a[0], a[1], a[2], a[3]);
-    return a;
-}
 
 // Smallest batch each quad-per-thread loop takes (1024 lanes per workgroup).  Measured on MI355X, us per fused step at
 // 2^17 / 2^18 / 2^19 / 2^20 lanes (profiles/r02_small_shards_gates.txt, r02k_small_shards.txt): RockSample(7,8) quad 1.50 /
@@ -477,7 +467,7 @@ int launch_step_chain(const typename Env::Params &p, uint32_t *state, int32_t *a
 template <class Env>
 int launch_steps_fused(const typename Env::Params &p, uint32_t *state, int32_t *action, int32_t *ob, typename Env::Reward *reward,
                        uint8_t *done, uint32_t *err, int64_t n, uint64_t seed, uint64_t action_seed, uint32_t lane0, uint64_t t,
-                       int k, int flags, int64_t rec, bool gen_first, void *stream);
+                       int k, int flags, int64_t rec, bool gen_first, int layout, void *stream);
 
 using Rock1 = RockEnv<1>;
 using Rock2 = RockEnv<2>;
@@ -494,7 +484,7 @@ using BattleShip4 = BattleShipEnv<4>;
 #define POMDP_FUSED_LAUNCHER(X, E)                                                                                            \
     X template int launch_steps_fused<E>(const E::Params &, uint32_t *, int32_t *, int32_t *, E::Reward *, uint8_t *,          \
                                          uint32_t *, int64_t, uint64_t, uint64_t, uint32_t, uint64_t, int, int, int64_t,     \
-                                         bool, void *);
+                                         bool, int, void *);
 #define POMDP_EACH_ENV(M, X)                                                                                                  \
     M(X, Rock1) M(X, Rock2) M(X, StochRock1) M(X, StochRock2) M(X, TagEnv) M(X, BattleShip1) M(X, BattleShip2)                  \
     M(X, BattleShip3) M(X, BattleShip4) M(X, TigerEnv) M(X, NetworkEnv)

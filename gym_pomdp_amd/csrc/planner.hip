@@ -319,8 +319,11 @@ __global__ __launch_bounds__(BLOCK) void heuristic_steps_kernel(const typename E
     const bool auto_reset = flags & POMDP_AUTO_RESET;
     const uint32_t idx = blockIdx.x * (uint32_t)BLOCK + threadIdx.x;
     const bool in_range = (uint64_t)idx < (uint64_t)n;
-    const uint32_t i = in_range ? idx : (uint32_t)(n - 1);
-    const uint32_t lane = lane0 + i;
+    const uint32_t i = in_range ? idx : (uint32_t)(n - 1);     // memory index only: threads past n read lane n - 1's words
+    // the lane id — and with it the quad element e that picks which step's quad-shared block this thread computes — comes
+    // from the UNCLAMPED index, as in rollout_kernel / steps_kernel: the padding threads of a ragged last quad (n % 4 != 0)
+    // still supply the blocks of steps base + 1 .. 3 to the quad's in-range lanes through quad_transpose4
+    const uint32_t lane = lane0 + idx;
     // every per-lane word first (one memory latency), then the tables
     typename Env::State st;
     Env::load(st, state, n, i);

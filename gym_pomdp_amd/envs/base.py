@@ -308,11 +308,17 @@ class BatchedEnv(object):
         if isinstance(action, torch.Tensor):
             if action.dtype.is_floating_point or action.dtype == torch.bool:
                 raise AssertionError("actions must be integers")
+            if action.dtype != torch.int32:
+                # a wider value must not wrap into a valid action (2^32 + 1 -> 1): anything outside the action space
+                # becomes -1, which the kernels count as invalid and ignore (the reference asserts, rock.py:125)
+                action = torch.where((action < 0) | (action >= self.action_space.n), torch.full_like(action, -1), action)
             a = action.to(device=self.device, dtype=torch.int32)
         else:
             arr = np.asarray(action)
             if arr.dtype.kind not in "iu":
                 raise AssertionError("actions must be integers")
+            if arr.dtype != np.int32:
+                arr = np.where((arr < 0) | (arr >= self.action_space.n), -1, arr)
             a = torch.as_tensor(arr.astype(np.int32), device=self.device)
         if a.shape != (self.batch_size,):
             raise AssertionError("actions must have shape (%d,), got %s" % (self.batch_size, tuple(a.shape)))
@@ -333,8 +339,10 @@ class BatchedEnv(object):
         return self._state
 
     def set_state(self, state):
-        """Overwrite the packed lane state (planner hook `_set_state`; tensor copy)."""
-        self._state.copy_(torch.as_tensor(state, dtype=torch.int32, device=self.device).reshape(self._state.shape))
+        """Overwrite the packed lane state (planner hook `_set_state`; tensor copy).  `state` is int32
+        [state_words, N] (or [N] / a scalar-mode [state_words] for one-word layouts): anything else is rejected, so a
+        state saved under another layout (BattleShip had 2 * MW words before ABI 10) cannot be misread."""
+        self._state.copy_(self._checked_state(state, self.batch_size, "set_state", validate=True))
         self._done.zero_()
         if self.batch_size == 1:
             self._host_out[2] = 0
@@ -345,6 +353,23 @@ class BatchedEnv(object):
             self._tracker.on_reset()
 
     _set_state = set_state
+
+    def _checked_state(self, state, lanes, what, validate=False):
+        """`state` as an int32 [state_words, lanes or -1] device tensor, shape-checked (lanes=None: any lane count);
+        validate: also the env's own sanity check of a state that is going to be stepped."""
+        st = torch.as_tensor(state, dtype=torch.int32, device=self.device)
+        if st.dim() == 1 and (self.state_words == 1 or (lanes == 1 and st.numel() == self.state_words)):
+            st = st.reshape(self.state_words, -1)
+        if st.dim() != 2 or st.shape[0] != self.state_words or (lanes is not None and st.shape[1] != lanes):
+            raise ValueError("%s: expected a packed state of shape (%d, %s), got %s" % (
+                what, self.state_words, "N" if lanes is None else lanes, tuple(st.shape)))
+        if validate:
+            self._validate_state(st, what)
+        return st.contiguous()
+
+    def _validate_state(self, st, what):
+        """env-specific sanity of a caller-supplied packed state (BattleShip: the cached next board)"""
+        return
 
     def invalid_action_count(self):
         """Lanes that were handed an out-of-range action since construction (they were left
@@ -388,8 +413,7 @@ class BatchedEnv(object):
     def legal_actions(self, state=None):
         """`_generate_legal()` of every lane: (list int32 [N, n_actions] in the reference's order, padded
         with -1; length int32 [N]).  `state` defaults to the live state."""
-        st = self._state if state is None else torch.as_tensor(state, dtype=torch.int32, device=self.device)
-        st = st.reshape(self.state_words, -1).contiguous()
+        st = self._state if state is None else self._checked_state(state, None, "legal_actions")
         n = st.shape[1]
         stride = self.action_space.n
         lst = torch.empty((n, stride), dtype=torch.int32, device=self.device)
@@ -410,8 +434,7 @@ class BatchedEnv(object):
     def preferred_actions(self, history, state=None):
         """`_generate_preferred(history)` of every lane, in the shape of legal_actions(): (list int32 [N, n_actions]
         padded with -1, length int32 [N]).  `history` is a gym_pomdp_amd.history.History of this env."""
-        st = self._state if state is None else torch.as_tensor(state, dtype=torch.int32, device=self.device)
-        st = st.reshape(self.state_words, -1).contiguous()
+        st = self._state if state is None else self._checked_state(state, None, "preferred_actions")
         n = st.shape[1]
         if n != self.batch_size:
             raise ValueError("preferred_actions: the history and side statistics cover exactly batch_size lanes")
@@ -484,8 +507,7 @@ class BatchedEnv(object):
     def compute_prob(self, action, ob, state=None):
         """`_compute_prob(action, next_state, ob)` per lane -> float64[N]: the likelihood of `ob` given that
         `action` led to `state` (default: the live state)."""
-        st = self._state if state is None else torch.as_tensor(state, dtype=torch.int32, device=self.device)
-        st = st.reshape(self.state_words, -1).contiguous()
+        st = self._state if state is None else self._checked_state(state, None, "compute_prob")
         n = st.shape[1]
         a = torch.as_tensor(action, device=self.device).to(torch.int32).reshape(n).contiguous()
         o = torch.as_tensor(ob, device=self.device).to(torch.int32).reshape(n).contiguous()
@@ -510,8 +532,7 @@ class BatchedEnv(object):
         `depth`.  Returns a dict of per-simulation tensors: ret float64, n_steps, first_action, last_ob
         int32, terminated bool — simulation i belongs to root i // sims_per_root.  `out`: the dict of an earlier
         call of the same shape, to reuse its buffers."""
-        st = self._state if roots is None else torch.as_tensor(roots, dtype=torch.int32, device=self.device)
-        st = st.reshape(self.state_words, -1).contiguous()
+        st = self._state if roots is None else self._checked_state(roots, None, "rollout")
         n_roots = st.shape[1]
         n = n_roots * int(sims_per_root)
         if (self.lane_offset if lane_offset is None else int(lane_offset)) % 4:
@@ -566,13 +587,55 @@ class BatchedEnv(object):
             _native.check(rc, "pomdp_rollout_synthetic")
         return self._ob, self._reward, self._done.view(torch.bool)
 
-    def trajectory_buffers(self, steps):
-        """The `out` dict of collect_synthetic(steps): action int32 [steps + 1, N], ob int32 [steps, N], reward [steps, N],
-        done bool [steps, N] (and its uint8 view "done_u8"), carved from one allocation with staggered column starts."""
+    def trajectory_buffers(self, steps, layout="columns"):
+        """The `out` dict of collect_synthetic(steps, layout=...).
+        "columns" (the default ABI): action int32 [steps + 1, N], ob int32 [steps, N], reward [steps, N], done bool
+        [steps, N] (and its uint8 view "done_u8"), carved from one allocation with staggered column starts.
+        "blocked" / "packed" (include/pomdp_hip.h: POMDP_LAYOUT_*; one write stream per step): {"layout", "traj": the raw
+        rows — uint8 [steps, pitch * 13] / int32 [steps, pitch] —, "pitch"}; decode_trajectory() gives the four columns."""
         n = self.batch_size
-        a, o, r, d = staggered([((steps + 1, n), torch.int32), ((steps, n), torch.int32), ((steps, n), self._reward.dtype),
-                                ((steps, n), torch.uint8)], self.device)
-        return {"action": a, "ob": o, "reward": r, "done_u8": d, "done": d.view(torch.bool)}
+        if layout == "columns":
+            a, o, r, d = staggered([((steps + 1, n), torch.int32), ((steps, n), torch.int32), ((steps, n), self._reward.dtype),
+                                    ((steps, n), torch.uint8)], self.device)
+            return {"action": a, "ob": o, "reward": r, "done_u8": d, "done": d.view(torch.bool)}       # no "layout" key = columns
+        if layout == "blocked":
+            pitch = -(-n // 256) * 256
+            return {"layout": "blocked", "pitch": pitch, "traj": torch.zeros((steps, pitch * 13), dtype=torch.uint8, device=self.device)}
+        if layout == "packed":
+            pitch = -(-n // 4) * 4
+            return {"layout": "packed", "pitch": pitch, "traj": torch.zeros((steps, pitch), dtype=torch.int32, device=self.device)}
+        raise ValueError("unknown trajectory layout %r (columns, blocked, packed)" % (layout,))
+
+    def packed_reward_table(self):
+        """reward_code byte of a packed record -> the reward the columns hold (pomdp_packed_reward), as a [256] tensor of
+        this env's reward dtype."""
+        t = getattr(self, "_packed_reward_table", None)
+        if t is None:
+            kind = _native.ENV_KIND[self.env_name]
+            vals = [self._lib.pomdp_packed_reward(kind, c) for c in range(256)]
+            t = self._packed_reward_table = torch.tensor(vals, dtype=torch.float64).to(self._reward.dtype).to(self.device)
+        return t
+
+    def decode_trajectory(self, out, steps=None):
+        """The four columns of a collected trajectory whatever its layout: {"action": int32 [steps, N] (the action taken at
+        each step), "ob": int32, "reward": this env's reward dtype, "done": bool}.  Blocked: strided views of the rows (no
+        copy); packed: unpacked into new tensors (the reward through packed_reward_table())."""
+        layout = out.get("layout", "columns")
+        n = self.batch_size
+        if layout == "columns":
+            k = out["ob"].shape[0] if steps is None else steps
+            return {"action": out["action"][:k], "ob": out["ob"][:k], "reward": out["reward"][:k], "done": out["done"][:k]}
+        traj = out["traj"] if steps is None else out["traj"][:steps]
+        k = traj.shape[0]
+        if layout == "blocked":
+            b = traj.view(k, out["pitch"] // 256, 13 * 256)
+            col = lambda lo, dt: b[:, :, lo:lo + 1024].view(dt).reshape(k, -1)[:, :n]                     # noqa: E731
+            return {"action": col(0, torch.int32), "ob": col(1024, torch.int32), "reward": col(2048, self._reward.dtype),
+                    "done": b[:, :, 3072:].reshape(k, -1)[:, :n].view(torch.bool)}
+        w = traj[:, :n]
+        code = (w >> 16) & 0xFF
+        return {"action": w & 0xFF, "ob": (w >> 8) & 0xFF, "reward": self.packed_reward_table()[code.long()],
+                "done": ((w >> 24) & 1).to(torch.bool)}
 
     def _check_driver_use(self, what):
         """The C-side episode loops advance the packed state only: they know nothing of RockSample's side statistics
@@ -585,21 +648,28 @@ class BatchedEnv(object):
             raise ValueError("%s: lane_offset must be a multiple of 4 (got %d): the synthetic policy's Philox block is "
                              "shared by global lanes 4q .. 4q+3" % (what, self.lane_offset))
 
-    def collect_synthetic(self, steps, out=None):
+    def collect_synthetic(self, steps, out=None, layout=None):
         """`steps` consecutive step() calls under the synthetic uniform policy with every step's results KEPT
         (pomdp_collect_synthetic): returns {"action": int32 [steps + 1, N] (row s = the actions of step s, last row = the
         next call's), "ob": int32 [steps, N], "reward": [steps, N], "done": bool [steps, N]} — row s equals what
         synthetic_actions() + step() return at that call.  The batched form of the reference callers' episode
         loops (rock.py:553-575); up to 64 steps per launch, auto_reset envs only.  `out`: a dict from an earlier call
-        to write into.  Asynchronous."""
+        to write into.  `layout` (default: `out`'s, else "columns"): "blocked" / "packed" write the same information as one
+        stream per step (pomdp_collect_layout; trajectory_buffers, decode_trajectory).  Asynchronous."""
         if not self._has_reset:
             raise AttributeError("%s: collect before reset()" % type(self).__name__)
         if not self.auto_reset:
             raise ValueError("collect_synthetic needs auto_reset=True")
         self._check_driver_use("collect_synthetic")
         steps, n = int(steps), self.batch_size
+        if layout is None:
+            layout = "columns" if out is None else out.get("layout", "columns")
         if out is None:
-            out = self.trajectory_buffers(steps)
+            out = self.trajectory_buffers(steps, layout)
+        if out.get("layout", "columns") != layout:
+            raise ValueError("collect_synthetic: `out` was built for layout %r, not %r" % (out.get("layout", "columns"), layout))
+        if layout != "columns":
+            return self._collect_traj(steps, out, layout)
         if not (out["action"].shape == (steps + 1, n) and out["ob"].shape == (steps, n) and out["reward"].shape == (steps, n)
                 and out["done_u8"].shape == (steps, n)):
             raise ValueError("collect_synthetic: `out` does not have the shapes of trajectory_buffers(%d)" % steps)
@@ -627,6 +697,34 @@ class BatchedEnv(object):
                 rc = self._lib.pomdp_collect(bound[1], t0, steps, self._stream())
         if rc:
             _native.check(rc, "pomdp_collect_synthetic")
+        return out
+
+    def _collect_traj(self, steps, out, layout):
+        """collect_synthetic into a blocked / packed trajectory: pomdp_collect_traj with its arguments bound per buffer."""
+        n, traj, pitch = self.batch_size, out["traj"], int(out["pitch"])
+        row = pitch * 13 if layout == "blocked" else pitch
+        if not (traj.dim() == 2 and traj.shape[0] >= steps and traj.shape[1] == row and traj.is_contiguous() and pitch >= n
+                and traj.dtype == (torch.uint8 if layout == "blocked" else torch.int32)):
+            raise ValueError("collect_synthetic: `out` does not have the shape of trajectory_buffers(%d, %r)" % (steps, layout))
+        key = (traj.data_ptr(), layout, pitch)
+        bound = self._collect_cache.get(key)
+        if bound is None:
+            if len(self._collect_cache) >= 64:
+                self._collect_cache.clear()
+            a = _native.TrajArgs(env=_native.ENV_KIND[self.env_name], flags=_native.POMDP_AUTO_RESET, layout=_native.LAYOUTS[layout],
+                                 reserved=0, params=C.addressof(self._params), state=self._ptrs[0], traj=key[0], err=self._ptrs[4],
+                                 n=n, pitch=pitch, seed=self._seed, lane0=self.lane_offset, reserved2=0)
+            bound = self._collect_cache[key] = (a, C.byref(a), steps)
+        bound[0].seed = self._seed
+        t0 = self._t
+        self._t = t0 + steps
+        if _current_device() == self._dev_index:
+            rc = self._lib.pomdp_collect_traj(bound[1], t0, steps, _raw_stream(self._dev_index))
+        else:
+            with torch.cuda.device(self.device):
+                rc = self._lib.pomdp_collect_traj(bound[1], t0, steps, self._stream())
+        if rc:
+            _native.check(rc, "pomdp_collect_layout")
         return out
 
     def __repr__(self):

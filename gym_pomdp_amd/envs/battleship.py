@@ -53,6 +53,19 @@ class BattleShipEnv(BatchedEnv):
     def _build_params(self):
         return make_params(self.board_size, self._max_len)
 
+    def _validate_state(self, st, what):
+        """A caller-supplied state must carry a real next board: with an empty one the lane's next auto-reset deals an episode
+        whose `remaining` starts at 0 and can never reach done again (every shot a miss)."""
+        mw = self.state_words // 3
+        ships = sum(range(2, self._max_len + 1))
+        nxt = st[2 * mw:].to(torch.int64) & 0xFFFFFFFF
+        pop = torch.zeros(st.shape[1], dtype=torch.int64, device=st.device)
+        for b in range(32):
+            pop += ((nxt >> b) & 1).sum(dim=0)
+        if bool((pop != ships).any()):
+            raise ValueError("%s: state words %d..%d (the board of the lane's NEXT episode) must hold %d ship cells per lane; "
+                             "take them from reset() / _get_init_state()" % (what, 2 * mw, 3 * mw - 1, ships))
+
     def decode_state(self):
         """int64 [N, 1 + 2*cells] = [total_remaining, occupied_0.., visited_0..], cell a = y*X + x."""
         mw = self.state_words // 3

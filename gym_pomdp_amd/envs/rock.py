@@ -130,8 +130,7 @@ class RockEnv(BatchedEnv):
     def select_target(self, state=None):
         """`_select_target` (rock.py:389-399) per lane: index of the nearest uncollected rock whose count is >= 0
         (straight-line distance, lowest index on ties), -1 if none -> int32[N]."""
-        st = self._state if state is None else torch.as_tensor(state, dtype=torch.int32, device=self.device)
-        st = st.reshape(self.state_words, -1).contiguous()
+        st = self._state if state is None else self._checked_state(state, self.batch_size, "select_target")
         out = torch.empty(self.batch_size, dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):
             rc = self._lib.pomdp_rock_select_target(self._params_ref, st.data_ptr(), self._belief_ref(), out.data_ptr(),

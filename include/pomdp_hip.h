@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define POMDP_ABI_VERSION 10
+#define POMDP_ABI_VERSION 11
 
 enum {
     POMDP_E_BADARG = -1,     /* NULL pointer, n < 0, n + lane0 > 2^32 */
@@ -269,6 +269,44 @@ typedef struct pomdp_collect_args {
     uint32_t  lane0, reserved;
 } pomdp_collect_args;
 int pomdp_collect(const pomdp_collect_args *args, uint64_t t0, int64_t k_steps, void *stream);
+
+/* ---- trajectory layouts (ABI 11) ------------------------------------------------ */
+/* pomdp_collect_synthetic writes the default layout, COLUMNS: four separate [step][pitch] arrays, the values the reference's
+ * `ob, rw, done, info = env.step(action)` returns (rock.py:553-575) as int32 / float / uint8 columns.  A fused step then
+ * feeds four write streams that lie whole columns apart, and how fast they drain depends on where the allocation's pages
+ * happen to lie.  The two layouts below keep exactly the same information in ONE write stream:
+ *
+ * POMDP_LAYOUT_BLOCKED — same types, same 13 bytes per lane-step.  traj: uint8 [k_steps][pitch * 13], pitch a multiple of
+ *   256 lanes; row s = pitch / 256 blocks of 3328 bytes, block q holding lanes 256 q .. 256 q + 255 of step s as
+ *       action int32[256] | ob int32[256] | reward (int32 | float)[256] | done uint8[256]
+ *   (action = the action TAKEN at step s; there is no row of "next actions").
+ * POMDP_LAYOUT_PACKED — 4 bytes per lane-step.  traj: uint32 [k_steps][pitch]; record of (step s, lane i):
+ *       action | ob << 8 | reward_code << 16 | done << 24
+ *   Actions and observations of every env fit a byte (Tag's obs_cells <= 255 is checked).  reward_code: the reward itself as
+ *   an int8 for RockSample / StochasticRock (-100, -10, 0, 10), Tag (-1, -10, 10), BattleShip (-10 .. cells - 1) and Tiger
+ *   (-100, -1, 10); Network: kind * 68 + base for reward = float32(base - cost), cost = 0 / .1 / 2.5 for kind 0 (no action) /
+ *   1 (ping) / 2 (reboot) (network.py:87-92, 103, 110).  pomdp_packed_reward() decodes either to the value COLUMNS holds.
+ * Both: POMDP_AUTO_RESET required, lane0 a multiple of 4; rows on 16-byte boundaries and n a multiple of 1024 take the
+ * launches that store 16 bytes per thread, anything else the general ones; `state` ends as after the last step; the next
+ * call derives its first actions from (seed, lane, t) again, so nothing else carries over. */
+enum { POMDP_LAYOUT_COLUMNS = 0, POMDP_LAYOUT_BLOCKED = 1, POMDP_LAYOUT_PACKED = 2 };
+int pomdp_collect_layout(int env, const void *params, uint32_t *state, void *traj, uint32_t *err, int64_t n, uint64_t seed,
+                         uint32_t lane0, uint64_t t0, int64_t k_steps, int64_t pitch, int layout, int flags, void *stream);
+/* the same with the per-batch arguments bound once (see pomdp_step_args) */
+typedef struct pomdp_traj_args {
+    int32_t   env, flags;
+    int32_t   layout, reserved;
+    const void *params;
+    uint32_t *state;
+    void     *traj;
+    uint32_t *err;
+    int64_t   n, pitch;
+    uint64_t  seed;
+    uint32_t  lane0, reserved2;
+} pomdp_traj_args;
+int pomdp_collect_traj(const pomdp_traj_args *args, uint64_t t0, int64_t k_steps, void *stream);
+/* host-side: the reward a PACKED record's reward_code byte stands for (exactly the value the COLUMNS layout stores) */
+double pomdp_packed_reward(int env, uint32_t reward_code);
 
 /* ---- planner hooks ------------------------------------- */
 /* replaces <Env>._generate_legal (rock.py:273-291, tag.py:228-229, battleship.py:157-165, tiger.py:111-112,

@@ -60,6 +60,7 @@ def lib():
         L.or_batch_preferred.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int64]
         L.or_batch_rock_select_target.argtypes = [vp, vp, vp, vp, C.c_int64]
         L.or_batch_pick.argtypes = [vp, vp, C.c_int, vp, C.c_int64, C.c_uint64, C.c_uint32, C.c_uint64]
+        L.or_batch_heuristic_steps.argtypes = [vp] * 10 + [C.c_int64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_int64, C.c_int, C.c_int]
         _lib = L
     return _lib
 
@@ -287,6 +288,21 @@ def pick(lists, lens, seed, lane0, t):
     return a
 
 
+def _batch_heuristic_steps(self, state, history, belief, prev_ob, k, seed, lane0, t0, auto_reset=True, done_in=None, nthreads=1):
+    """k steps of the heuristic rollout loop (rock.py:557-573) for every lane, in C, lane-major (or_batch_heuristic_steps):
+    -> rows action, ob, reward, done [k, n]; `state`, `history`, `belief`, `prev_ob` (int32 [n]) are updated in place."""
+    n = state.shape[1]
+    out = dict(action=np.zeros((k, n), np.int32), ob=np.zeros((k, n), np.int32), reward=np.zeros((k, n), self.reward_dtype),
+               done=np.zeros((k, n), np.uint8))
+    assert prev_ob.dtype == np.int32 and prev_ob.flags.c_contiguous and state.flags.c_contiguous
+    di = None if done_in is None else np.ascontiguousarray(done_in, np.uint8)
+    lib().or_batch_heuristic_steps(self._h, _ptr(state), belief._ptrs() if belief is not None else None, history._ptrs(),
+                                   _ptr(prev_ob), None if di is None else _ptr(di), _ptr(out["action"]), _ptr(out["ob"]),
+                                   _ptr(out["reward"]), _ptr(out["done"]), n, seed, lane0, t0, k, int(auto_reset), nthreads)
+    return out
+
+
+OracleEnv.batch_heuristic_steps = _batch_heuristic_steps
 OracleEnv.batch_preferred = _batch_preferred
 OracleEnv.batch_compute_prob = _batch_compute_prob
 OracleEnv.bench_loop = _bench_loop

@@ -1155,48 +1155,64 @@ void or_batch_compute_prob(const or_env *proto, const uint32_t *state, const int
 /* ======================================================================== */
 /* heuristic-policy support: side statistics, history sums, preferred lists  */
 /* ======================================================================== */
+/* fresh Rock objects for one lane (rock.py:81-86) */
+static void belief_fresh_lane(const or_rock_belief *b, int K, int64_t i, int64_t n)
+{
+    for (int j = 0; j < K; j++) {
+        int64_t k = (int64_t)j * n + i;
+        b->count[k] = 0; b->measured[k] = 0; b->lkv[k] = 1.; b->lkw[k] = 1.; b->prob_valuable[k] = .5;
+    }
+}
+
 void or_batch_rock_belief_reset(const or_env *proto, const or_rock_belief *b, const uint8_t *where, int64_t n)
 {
-    for (int j = 0; j < proto->num_rocks; j++)
-        for (int64_t i = 0; i < n; i++) {
-            if (where && !where[i]) continue;
-            int64_t k = (int64_t)j * n + i;                       /* rock.py:81-86 */
-            b->count[k] = 0; b->measured[k] = 0; b->lkv[k] = 1.; b->lkw[k] = 1.; b->prob_valuable[k] = .5;
-        }
+    for (int64_t i = 0; i < n; i++) {
+        if (where && !where[i]) continue;
+        belief_fresh_lane(b, proto->num_rocks, i, n);
+    }
+}
+
+/* one lane of or_batch_rock_belief_update: `e` is the lane's unpacked stored (post auto-reset) state */
+static void belief_update_lane(const or_env *e, const or_rock_belief *b, int64_t i, int64_t n, int a, int ob, int done,
+                               int auto_reset)
+{
+    int K = e->num_rocks;
+    if (done) {                                               /* reset() builds new Rock objects */
+        if (auto_reset) belief_fresh_lane(b, K, i, n);
+        return;
+    }
+    if (a <= 4 || a >= 5 + K || ob == 0) return;              /* not an executed CHECK */
+    int rock = a - 5;
+    int64_t k = (int64_t)rock * n + i;
+    int dx = e->agent.x - e->rock_pos[rock].x, dy = e->agent.y - e->rock_pos[rock].y;
+    double eff = ROCK_EFF[(dx < 0 ? -dx : dx) + (dy < 0 ? -dy : dy)];          /* rock.py:180 */
+    b->measured[k] += 1;                                      /* rock.py:178 */
+    if (ob == 2) {                                            /* rock.py:182-185 */
+        b->count[k] += 1; b->lkv[k] *= eff; b->lkw[k] *= (1 - eff);
+    } else {                                                  /* rock.py:186-189 */
+        b->count[k] -= 1; b->lkw[k] *= eff; b->lkv[k] *= (1 - eff);
+    }
+    double denom = (.5 * b->lkv[k]) + (.5 * b->lkw[k]);       /* rock.py:190-191 */
+    b->prob_valuable[k] = (.5 * b->lkv[k]) / denom;
 }
 
 void or_batch_rock_belief_update(const or_env *proto, const uint32_t *state, const int32_t *action, const int32_t *ob,
                                  const uint8_t *done, int auto_reset, const or_rock_belief *b, int64_t n)
 {
-    int W = or_env_words(proto), K = proto->num_rocks;
+    int W = or_env_words(proto);
     or_env e = *proto;
     uint32_t w[12];
     for (int64_t i = 0; i < n; i++) {
-        if (done[i]) {                                            /* reset() builds new Rock objects */
-            if (auto_reset)
-                for (int j = 0; j < K; j++) {
-                    int64_t k = (int64_t)j * n + i;
-                    b->count[k] = 0; b->measured[k] = 0; b->lkv[k] = 1.; b->lkw[k] = 1.; b->prob_valuable[k] = .5;
-                }
-            continue;
-        }
-        int a = action[i];
-        if (a <= 4 || a >= 5 + K || ob[i] == 0) continue;         /* not an executed CHECK */
         for (int j = 0; j < W; j++) w[j] = state[(int64_t)j * n + i];
         or_env_unpack(&e, w);
-        int rock = a - 5;
-        int64_t k = (int64_t)rock * n + i;
-        int dx = e.agent.x - e.rock_pos[rock].x, dy = e.agent.y - e.rock_pos[rock].y;
-        double eff = ROCK_EFF[(dx < 0 ? -dx : dx) + (dy < 0 ? -dy : dy)];          /* rock.py:180 */
-        b->measured[k] += 1;                                      /* rock.py:178 */
-        if (ob[i] == 2) {                                         /* rock.py:182-185 */
-            b->count[k] += 1; b->lkv[k] *= eff; b->lkw[k] *= (1 - eff);
-        } else {                                                  /* rock.py:186-189 */
-            b->count[k] -= 1; b->lkw[k] *= eff; b->lkv[k] *= (1 - eff);
-        }
-        double denom = (.5 * b->lkv[k]) + (.5 * b->lkw[k]);       /* rock.py:190-191 */
-        b->prob_valuable[k] = (.5 * b->lkv[k]) / denom;
+        belief_update_lane(&e, b, i, n, action[i], ob[i], done[i], auto_reset);
     }
+}
+
+static void history_clear_lane(const or_history *h, int K, int64_t i, int64_t n)
+{
+    h->size[i] = 0; h->last_action[i] = -1; h->last_ob[i] = -1;
+    for (int j = 0; j < K; j++) { h->total_sample[(int64_t)j * n + i] = 0; h->total_move[(int64_t)j * n + i] = 0; }
 }
 
 void or_batch_history_clear(const or_env *proto, const or_history *h, const uint8_t *where, int64_t n)
@@ -1204,8 +1220,41 @@ void or_batch_history_clear(const or_env *proto, const or_history *h, const uint
     int K = proto->kind == OR_ENV_ROCK ? proto->num_rocks : 0;
     for (int64_t i = 0; i < n; i++) {
         if (where && !where[i]) continue;
-        h->size[i] = 0; h->last_action[i] = -1; h->last_ob[i] = -1;
-        for (int j = 0; j < K; j++) { h->total_sample[(int64_t)j * n + i] = 0; h->total_move[(int64_t)j * n + i] = 0; }
+        history_clear_lane(h, K, i, n);
+    }
+}
+
+/* one lane of or_batch_history_append */
+static void history_append_lane(const or_history *h, int K, int64_t i, int64_t n, int observation, int a, int o, int done,
+                                int auto_reset)
+{
+    if (done && auto_reset) {                                 /* next episode: a new, empty History */
+        history_clear_lane(h, K, i, n);
+        return;
+    }
+    if (h->max_size >= 0) {                                   /* rock.py:541-544: the records themselves */
+        int sz = h->size[i];
+        if (sz > h->max_size) {                               /* self._history.pop(0) */
+            for (int r = 1; r < sz; r++) {
+                h->rec_obs[(int64_t)(r - 1) * n + i] = h->rec_obs[(int64_t)r * n + i];
+                h->rec_act[(int64_t)(r - 1) * n + i] = h->rec_act[(int64_t)r * n + i];
+                h->rec_next[(int64_t)(r - 1) * n + i] = h->rec_next[(int64_t)r * n + i];
+            }
+            sz -= 1;
+        }
+        h->rec_obs[(int64_t)sz * n + i] = observation;        /* self._history.append(transition) */
+        h->rec_act[(int64_t)sz * n + i] = a;
+        h->rec_next[(int64_t)sz * n + i] = o;
+        h->size[i] = sz + 1; h->last_action[i] = a; h->last_ob[i] = o;
+        return;
+    }
+    h->size[i] += 1; h->last_action[i] = a; h->last_ob[i] = o;
+    if (a >= 5 && a < 5 + K) {
+        int64_t k = (int64_t)(a - 5) * n + i;
+        if (o == 2) h->total_sample[k] += 1;                  /* rock.py:305-309 */
+        else if (o == 1) h->total_sample[k] -= 1;
+        if (o == 2) h->total_move[k] += 1;                    /* rock.py:329-333: elif on transition.observation */
+        else if (observation == 1) h->total_move[k] -= 1;
     }
 }
 
@@ -1214,38 +1263,8 @@ void or_batch_history_append(const or_env *proto, const or_history *h, const int
                              int auto_reset, int64_t n)
 {
     int K = proto->kind == OR_ENV_ROCK ? proto->num_rocks : 0;
-    for (int64_t i = 0; i < n; i++) {
-        if (done[i] && auto_reset) {                              /* next episode: a new, empty History */
-            h->size[i] = 0; h->last_action[i] = -1; h->last_ob[i] = -1;
-            for (int j = 0; j < K; j++) { h->total_sample[(int64_t)j * n + i] = 0; h->total_move[(int64_t)j * n + i] = 0; }
-            continue;
-        }
-        int a = action[i], o = next_observation[i];
-        if (h->max_size >= 0) {                                   /* rock.py:541-544: the records themselves */
-            int sz = h->size[i];
-            if (sz > h->max_size) {                               /* self._history.pop(0) */
-                for (int r = 1; r < sz; r++) {
-                    h->rec_obs[(int64_t)(r - 1) * n + i] = h->rec_obs[(int64_t)r * n + i];
-                    h->rec_act[(int64_t)(r - 1) * n + i] = h->rec_act[(int64_t)r * n + i];
-                    h->rec_next[(int64_t)(r - 1) * n + i] = h->rec_next[(int64_t)r * n + i];
-                }
-                sz -= 1;
-            }
-            h->rec_obs[(int64_t)sz * n + i] = observation[i];    /* self._history.append(transition) */
-            h->rec_act[(int64_t)sz * n + i] = a;
-            h->rec_next[(int64_t)sz * n + i] = o;
-            h->size[i] = sz + 1; h->last_action[i] = a; h->last_ob[i] = o;
-            continue;
-        }
-        h->size[i] += 1; h->last_action[i] = a; h->last_ob[i] = o;
-        if (a >= 5 && a < 5 + K) {
-            int64_t k = (int64_t)(a - 5) * n + i;
-            if (o == 2) h->total_sample[k] += 1;                  /* rock.py:305-309 */
-            else if (o == 1) h->total_sample[k] -= 1;
-            if (o == 2) h->total_move[k] += 1;                    /* rock.py:329-333: elif on transition.observation */
-            else if (observation[i] == 1) h->total_move[k] -= 1;
-        }
-    }
+    for (int64_t i = 0; i < n; i++)
+        history_append_lane(h, K, i, n, observation[i], action[i], next_observation[i], done[i], auto_reset);
 }
 
 /* the two per-rock sums over the history's transitions: rock.py:303-310 (sample) and rock.py:327-334 (move) */
@@ -1313,6 +1332,14 @@ static int tag_preferred(const or_env *e, const or_history *h, int64_t i, int *l
     return cnt;
 }
 
+/* `_generate_preferred(history)` of one lane whose state is unpacked in `e` */
+static int preferred_lane(const or_env *e, const or_rock_belief *b, const or_history *h, int64_t i, int64_t n, int *list)
+{
+    if (e->kind == OR_ENV_ROCK) return rock_preferred(e, b, h, i, n, list);
+    if (e->kind == OR_ENV_TAG) return tag_preferred(e, h, i, list);
+    return or_env_legal(e, list);
+}
+
 void or_batch_preferred(const or_env *proto, const uint32_t *state, const or_rock_belief *b, const or_history *h,
                         int32_t *out, int32_t *len, int64_t n)
 {
@@ -1323,10 +1350,7 @@ void or_batch_preferred(const or_env *proto, const uint32_t *state, const or_roc
     for (int64_t i = 0; i < n; i++) {
         for (int j = 0; j < W; j++) w[j] = state[(int64_t)j * n + i];
         or_env_unpack(&e, w);
-        int l;
-        if (e.kind == OR_ENV_ROCK) l = rock_preferred(&e, b, h, i, n, list);
-        else if (e.kind == OR_ENV_TAG) l = tag_preferred(&e, h, i, list);
-        else l = or_env_legal(&e, list);
+        int l = preferred_lane(&e, b, h, i, n, list);
         len[i] = l;
         for (int j = 0; j < OR_MAX_LEGAL; j++) out[i * OR_MAX_LEGAL + j] = j < l ? list[j] : -1;
     }
@@ -1362,5 +1386,79 @@ void or_batch_pick(const int32_t *list, const int32_t *len, int stride, int32_t 
         uint32_t c[4] = { lane >> 2, (uint32_t)t, (uint32_t)(t >> 32), (uint32_t)OR_STREAM_ACTION << 24 }, o[4];
         or_philox4x32_10(c, key, o);
         action[i] = len[i] > 0 ? list[i * stride + (int32_t)(((uint64_t)o[lane & 3u] * (uint32_t)len[i]) >> 32)] : -1;
+    }
+}
+
+/* The reference's heuristic rollout loop (rock.py:557-573) for a batch, k steps of every lane in one call — what
+ * pomdp_heuristic_steps fuses on the device — composed from the SAME per-lane pieces the per-step batch functions
+ * above are made of (preferred_lane, the pick of or_batch_pick, the step + auto-reset of or_batch_step,
+ * belief_update_lane, history_append_lane), lane-major so that no [n][OR_MAX_LEGAL] list array is ever materialised
+ * (tests/test_oracle_golden.py checks it against the per-step call sequence).  Step s of a lane, at call counter t0 + s:
+ *   list = _generate_preferred(history); a = list[(w * len) >> 32], w = the synthetic policy's word of (seed, lane, t)
+ *   (ob, reward, done) = step(a), auto-reset as in or_batch_step; side statistics; history.append(Transition(prev_ob,
+ *   a, reward, ob, done)); prev_ob <- ob, or what reset() returned on a lane that auto-reset.
+ * Outputs: rows [k][n] of action / ob / reward / done; state, b, h, prev_ob are updated in place.  Without auto_reset,
+ * done_in (uint8 [n], may be NULL) marks the lanes that are already frozen; frozen lane-steps write (-1, 0, 0, 1). */
+void or_batch_heuristic_steps(const or_env *proto, uint32_t *state, const or_rock_belief *b, const or_history *h,
+                              int32_t *prev_ob, const uint8_t *done_in, int32_t *action, int32_t *ob, void *reward,
+                              uint8_t *done, int64_t n, uint64_t seed, uint32_t lane0, uint64_t t0, int64_t k,
+                              int auto_reset, int nthreads)
+{
+    int W = or_env_words(proto), nA = or_env_n_actions(proto), rk = or_env_reward_kind(proto);
+    int K = proto->kind == OR_ENV_ROCK ? proto->num_rocks : 0;
+    const uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel num_threads(nthreads)
+    {
+        or_env e = *proto;
+        or_ws np_rng, sp_rng;
+        uint32_t w[12];
+        int list[OR_MAX_LEGAL];
+#pragma omp for schedule(static)
+        for (int64_t i = 0; i < n; i++) {
+            const uint32_t lane = lane0 + (uint32_t)i;
+            int was_done = (!auto_reset && done_in) ? done_in[i] != 0 : 0;
+            for (int j = 0; j < W; j++) w[j] = state[(int64_t)j * n + i];
+            or_env_unpack(&e, w);
+            int pob = prev_ob[i];
+            for (int64_t s = 0; s < k; s++) {
+                const uint64_t t = t0 + (uint64_t)s;
+                const int64_t row = s * n + i;
+                int a = -1, o = 0, d = 0; double r = 0;
+                if (was_done) {
+                    d = 1;
+                } else {
+                    int l = preferred_lane(&e, b, h, i, n, list);
+                    uint32_t c[4] = { lane >> 2, (uint32_t)t, (uint32_t)(t >> 32), (uint32_t)OR_STREAM_ACTION << 24 }, o4[4];
+                    or_philox4x32_10(c, key, o4);
+                    a = l > 0 ? list[(int32_t)(((uint64_t)o4[lane & 3u] * (uint32_t)l) >> 32)] : -1;
+                    int fresh_ob = 0;
+                    if (a >= 0 && a < nA) {
+                        or_ws_philox_env(&np_rng, e.kind, seed, lane, t, OR_STREAM_STEP);
+                        or_ws_philox(&sp_rng, seed, lane, t, OR_STREAM_STEP_SPACE);
+                        or_env_step(&e, a, &np_rng, &sp_rng, &o, &r, &d);
+                        if (d && auto_reset && e.kind == OR_ENV_BATTLESHIP) {
+                            bs_swap_in(&e);
+                            or_ws_philox(&np_rng, seed, lane, t, OR_STREAM_NEXT);
+                            bs_deal_next(&e, &np_rng);
+                        } else if (d && auto_reset) {
+                            or_ws_philox_auto_reset(&np_rng, &e, seed, lane, t);
+                            or_ws_philox(&sp_rng, seed, lane, t, OR_STREAM_RESET_SPACE);
+                            fresh_ob = or_env_reset(&e, &np_rng, &sp_rng);
+                        }
+                    }
+                    if (K) belief_update_lane(&e, b, i, n, a, o, d, auto_reset);
+                    history_append_lane(h, K, i, n, pob, a, o, d, auto_reset);
+                    pob = (d && auto_reset) ? fresh_ob : o;
+                    if (!auto_reset) was_done = d;
+                }
+                action[row] = a; ob[row] = o; done[row] = (uint8_t)d;
+                if (rk == OR_REWARD_I32) ((int32_t *)reward)[row] = (int32_t)r;
+                else ((float *)reward)[row] = (float)r;
+            }
+            or_env_pack(&e, w);
+            for (int j = 0; j < W; j++) state[(int64_t)j * n + i] = w[j];
+            prev_ob[i] = pob;
+        }
     }
 }

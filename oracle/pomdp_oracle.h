@@ -189,6 +189,13 @@ void or_batch_rock_select_target(const or_env *proto, const uint32_t *state, con
 void or_batch_pick(const int32_t *list, const int32_t *len, int stride, int32_t *action, int64_t n, uint64_t seed,
                    uint32_t lane0, uint64_t t);
 
+/* k steps of the reference's heuristic rollout loop (rock.py:557-573) for every lane in one call, lane-major, built from
+ * the per-lane pieces of the batch functions above; rows [k][n] out, state / b / h / prev_ob updated in place */
+void or_batch_heuristic_steps(const or_env *proto, uint32_t *state, const or_rock_belief *b, const or_history *h,
+                              int32_t *prev_ob, const uint8_t *done_in, int32_t *action, int32_t *ob, void *reward,
+                              uint8_t *done, int64_t n, uint64_t seed, uint32_t lane0, uint64_t t0, int64_t k,
+                              int auto_reset, int nthreads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,7 +54,16 @@ def test_golden_mode_b(case, env, kw):
         envb.call_counter = t0
         ob0 = envb.reset()
         if n == 1:
-            pytest.skip("single-lane run")
+            # an isolated lane runs through the scalar API (python scalars in and out, as the reference is used): the same
+            # fixture rows, never a skip — a fixture regenerated with single-lane runs must not silently stop being checked
+            assert ob0 == int(g["ob0"][s])
+            assert np.array_equal(np_(envb.decode_state()), saturate_tag_compact(env, g["state0"][s:e]))
+            for i in range(T):
+                ob, rew, done, info = envb.step(int(g["actions"][s, i]))
+                want_rew = float(np.float32(g["reward"][s, i])) if isinstance(rew, float) else int(g["reward"][s, i])
+                assert (ob, rew, bool(done)) == (int(g["ob"][s, i]), want_rew, bool(g["done"][s, i])), (case, i)
+                assert np.array_equal(np_(envb.decode_state()), saturate_tag_compact(env, g["state"][s:e, i])), (case, i)
+            continue
         assert np.array_equal(np_(ob0), g["ob0"][s:e])
         assert np.array_equal(np_(envb.decode_state()), saturate_tag_compact(env, g["state0"][s:e]))
         for i in range(T):
@@ -990,7 +999,9 @@ def test_fused_steps_leave_what_per_step_launches_leave(env, kw, n, auto):
     assert a.call_counter == b.call_counter
 
 
-HEUR_FUSE_CASES = [("rock", {}, 8192 + 12, True), ("rock", {}, 4096, False), ("rock", dict(board_size=15, num_rocks=15), 4096, True),
+HEUR_FUSE_CASES = [("rock", {}, 4096 + 1, True), ("rock", dict(board_size=15, num_rocks=15), 2048 + 2, True), ("tag", {}, 4096 + 3, True),   # n % 4 != 0:
+                   ("stochrock", {}, 1024 + 3, False),                               # the padding threads of the last quad supply blocks
+                   ("rock", {}, 8192 + 12, True), ("rock", {}, 4096, False), ("rock", dict(board_size=15, num_rocks=15), 4096, True),
                    ("stochrock", {}, 4096, True), ("tag", {}, 8192, True), ("tag", dict(num_opponents=2), 4096, False),
                    ("battleship", {}, 4096, True), ("tiger", {}, 4096, True), ("network", {}, 4096, True),
                    ("rock", dict(hist=5), 4096 + 12, True), ("rock", dict(board_size=15, num_rocks=15, hist=40), 4096, True)]
@@ -1263,3 +1274,52 @@ def test_collect_buffers_are_bound_per_env_and_per_buffer():
     assert got2["ob"].data_ptr() == fresh["ob"].data_ptr() and old_ob.shape == got2["ob"].shape
     with pytest.raises(ValueError):
         b.collect_synthetic(k + 1, out=tr)
+
+
+def test_wide_integer_actions_never_wrap_into_valid_ones():
+    """An int64 action such as 2^32 + 1 must not become action 1 through the int32 cast (the reference asserts on it,
+    rock.py:125): it is counted invalid and the lane is left untouched, like any other out-of-range action."""
+    n = 1024
+    e = make_env("rock", {}, batch_size=n, seed=9)
+    ref = make_env("rock", {}, batch_size=n, seed=9)
+    e.reset()
+    ref.reset()
+    a64 = torch.ones(n, dtype=torch.int64, device="cuda")
+    a64[::2] += 1 << 32                       # would wrap to the valid action 1
+    a64[1] = -(1 << 32) + 2                   # would wrap to 2
+    a32 = torch.where((a64 < 0) | (a64 >= e.action_space.n), torch.full_like(a64, -1), a64).to(torch.int32)
+    ob, rew, done, _ = e.step(a64)
+    ob2, rew2, done2, _ = ref.step(a32)
+    assert torch.equal(ob, ob2) and torch.equal(rew, rew2) and torch.equal(done, done2) and torch.equal(e.state, ref.state)
+    bad = int(((a64 < 0) | (a64 >= e.action_space.n)).sum())
+    assert e.invalid_action_count() == ref.invalid_action_count() == bad == n // 2 + 1
+    e.step(np.full(n, (1 << 32) + 3, dtype=np.int64))           # the numpy path
+    assert e.invalid_action_count() == bad + n
+    e.step(np.full(n, 3, dtype=np.uint8))
+    assert e.invalid_action_count() == bad + n
+
+
+def test_set_state_rejects_states_of_another_layout():
+    """set_state / the planner hooks take int32 [state_words, N] only: a BattleShip state saved with 2 * MW words per lane
+    (before the next-board contract) whose element count happens to divide by 3 * MW is not silently misread, and a
+    hand-built state without a next board (its lanes could never finish a second episode) is rejected."""
+    n = 96
+    e = make_env("battleship", {}, batch_size=n, seed=1)
+    e.reset()
+    good = e.state.clone()
+    assert e.state_words == 3
+    with pytest.raises(ValueError):
+        e.set_state(torch.zeros((2, n * 3 // 2), dtype=torch.int32))          # 2 * MW words per lane, same element count
+    with pytest.raises(ValueError):
+        e.set_state(good[:, : n // 2])
+    empty_next = good.clone()
+    empty_next[2] = 0
+    with pytest.raises(ValueError):
+        e.set_state(empty_next)
+    e.set_state(good)
+    assert torch.equal(e.state, good)
+    r = make_env("rock", {}, batch_size=n, seed=1)
+    r.reset()
+    r.set_state(r.state.clone().reshape(-1))                                   # one-word layouts: [N] is unambiguous
+    with pytest.raises(ValueError):
+        r.legal_actions(torch.zeros((2, n), dtype=torch.int32))

@@ -296,3 +296,199 @@ def test_bound_argument_entry_points_equal_the_plain_ones():
             act = b.synthetic_actions()
             ra, rb = a.step(act), b.step(act)
             assert all(torch.equal(x, y) for x, y in zip(ra[:3], rb[:3])) and torch.equal(a.state, b.state), env
+
+
+def _heuristic_fused_vs_oracle(oracle_lib, env, kw, n, ks, seed, lane0, max_size=None, auto=True):
+    """The launches `bench.py --mode heuristic` times — heuristic_steps_kernel, up to 64 steps each — against the oracle's
+    lane-major restatement of the reference's rollout loop (rock.py:557-573; or_batch_heuristic_steps, pinned on CPU to the
+    per-step batch functions the heur_* fixtures pin to the reference): after every launch the outputs it leaves (the LAST
+    step's action / ob / reward / done — the fused loop overwrites one row), the state, prev_ob, the history words and
+    sums and, for RockSample, the float64 side statistics bit for bit and the two derived words."""
+    from gym_pomdp_amd import History
+    ol = oracle_lib
+    nt = ol.max_threads()
+    is_rock = env in ("rock", "stochrock")
+    o = ol.OracleEnv(env, **kw)
+    e = make_env(env, dict(kw, **(dict(use_heuristic=True) if is_rock else {})), batch_size=n, seed=seed, lane_offset=lane0,
+                 auto_reset=auto, reuse_buffers=True)
+    st = o.new_state(n)
+    prev = o.batch_reset(st, seed, lane0, 0, nthreads=nt).astype(np.int32)
+    assert np.array_equal(np_(e.reset()), prev)
+    h = History(e, max_size=max_size)
+    b = ol.Belief(o, n) if is_rock else None
+    hs = ol.HistorySums(o, n, max_size=max_size)
+    frozen = np.zeros(n, np.uint8)
+    t, n_done = 1, 0
+    for k in ks:
+        fa, fo, fr, fd = e.heuristic_steps(h, k)
+        want = o.batch_heuristic_steps(st, hs, b, prev, k, seed, lane0, t, auto_reset=auto, done_in=frozen, nthreads=nt)
+        t += k
+        ctx = (env, kw, n, k, t)
+        assert np.array_equal(np_(fa), want["action"][-1]), ctx
+        assert np.array_equal(np_(fo), want["ob"][-1]) and np.array_equal(np_(fr), want["reward"][-1]), ctx
+        assert np.array_equal(np_(fd), want["done"][-1].astype(bool)), ctx
+        assert np.array_equal(np_(e.state).view(np.uint32), st), ctx
+        if not auto:
+            frozen = want["done"][-1].copy()
+        live = frozen == 0
+        assert np.array_equal(np_(h.prev_ob)[live], prev[live]), ctx
+        for name in ("size", "last_action", "last_ob") + (("total_sample", "total_move") if is_rock and max_size is None else ()):
+            got = np_(getattr(h, "_size" if name == "size" else name))
+            assert np.array_equal(got[..., live], getattr(hs, name)[..., live]), ctx + (name,)
+        if is_rock:
+            gb = {k_: np_(v) for k_, v in e.belief.items()}
+            for k_, _ in ol.Belief.FIELDS:
+                x, y = gb[k_], getattr(b, k_)
+                same = (x.view(np.uint64) == y.view(np.uint64)) if x.dtype == np.float64 else (x == y)
+                assert (same | ((x != x) & (y != y))).all(), ctx + (k_,)
+            K = o.n_actions - 5
+            w = (1 << np.arange(K, dtype=np.int64))[:, None]
+            ok = (b.measured < 5) & (np.abs(b.count) < 2) & (b.prob_valuable > 0) & (b.prob_valuable < 1)
+            assert np.array_equal((ok * w).sum(axis=0), np_(e._tracker.check_ok).astype(np.int64) & 0xFFFFFFFF), ctx
+            if max_size is None:
+                mo = np_(h.move_ok).astype(np.int64) & 0xFFFFFFFF
+                assert np.array_equal(((hs.total_move >= 0) * w).sum(axis=0), mo & 0xFFFF), ctx
+                assert np.array_equal(((hs.total_sample > 0) * w).sum(axis=0), mo >> 16), ctx
+        n_done += int(want["done"].sum())
+    return n_done
+
+
+@pytest.mark.parametrize("env,kw", [("rock", {}), ("rock", dict(board_size=15, num_rocks=15)), ("tag", {})],
+                         ids=["rock_7_8", "rock_15_15", "tag"])
+def test_heuristic_steps_fused_vs_oracle(oracle_lib, env, kw):
+    """2^20 lanes, heuristic_steps(h, 64) twice (then a short launch that ends off a multiple of four steps)."""
+    n_done = _heuristic_fused_vs_oracle(oracle_lib, env, kw, 1 << 20, (64, 64, 7), seed=0xBEEF, lane0=1 << 21)
+    assert n_done > 0
+
+
+@pytest.mark.parametrize("env,kw,n,max_size,auto", [("rock", {}, 4096 + 1, None, True), ("rock", {}, 4096 + 2, 6, True),
+                                                    ("rock", dict(board_size=15, num_rocks=15), 2048 + 3, None, True),
+                                                    ("tag", {}, 4096 + 3, None, True), ("stochrock", {}, 1024 + 1, None, False),
+                                                    ("tiger", {}, 259, None, True), ("battleship", {}, 1021, None, True)],
+                         ids=["rock+1", "rock+2-hist6", "rock15+3", "tag+3", "stochrock+1-frozen", "tiger+3", "battleship+1"])
+def test_heuristic_multi_step_launches_on_ragged_batches_vs_oracle(oracle_lib, env, kw, n, max_size, auto):
+    """n % 4 != 0 with several steps per launch: the padding threads of the last quad take part in the quad transposes that
+    hand the policy's (and RockSample's sensor) blocks of steps base + 1 .. 3 to the quad's in-range lanes, so their lane
+    ids must be the unclamped ones (round 3's advisor finding: they used lane n - 1's)."""
+    _heuristic_fused_vs_oracle(oracle_lib, env, kw, n, (64, 5, 64, 2), seed=4242, lane0=1 << 10, max_size=max_size, auto=auto)
+
+
+# ---- the single-stream trajectory layouts (include/pomdp_hip.h: POMDP_LAYOUT_BLOCKED / _PACKED; csrc/traj_out.hip.h) --------
+LAYOUT_FULL = [("rock", {}, 1 << 20, 70), ("rock", {}, 1 << 20, 20), ("rock", dict(board_size=15, num_rocks=15), 1 << 20, 66),
+               ("rock", dict(board_size=4, num_rocks=3), 1 << 20, 40), ("stochrock", {}, 1 << 19, 70), ("tag", {}, 1 << 20, 70),
+               ("tag", dict(num_opponents=3), 1 << 20, 40), ("tiger", {}, 1 << 20, 70), ("network", {}, 1 << 20, 70),
+               ("network", dict(n_machines=31, problem_type=3), 1 << 19, 40),
+               ("battleship", dict(board_size=(10, 10), max_len=5), 1 << 19, 70), ("battleship", {}, 1 << 20, 130),
+               # the shards a 2^20-lane batch leaves per GPU at 2 / 4 / 8 GPUs (the one- and two-lanes-per-thread loops)
+               ("rock", {}, 1 << 19, 66), ("rock", {}, 1 << 18, 66), ("rock", {}, 1 << 17, 66), ("tag", {}, 1 << 18, 66),
+               ("tiger", {}, 1 << 17, 66), ("network", {}, 1 << 18, 66), ("battleship", {}, 1 << 17, 66),
+               # ragged batches: rows padded to the layout's pitch, the general (not SIMPLE) loop
+               ("rock", {}, 4099, 70), ("tag", {}, (1 << 18) + 5, 20), ("network", {}, 777, 70), ("tiger", {}, 3, 70),
+               ("battleship", {}, 259, 70), ("rock", dict(board_size=15, num_rocks=15), (1 << 19) + 4, 30)]
+
+
+@pytest.mark.parametrize("layout", ["blocked", "packed"])
+@pytest.mark.parametrize("env,kw,n,steps", LAYOUT_FULL, ids=["%s%s-%d-%d" % (c[0], "-".join(str(v) for v in c[1].values()), c[2], c[3]) for c in LAYOUT_FULL])
+def test_single_stream_layouts_equal_the_oracle(oracle_lib, env, kw, n, steps, layout):
+    """collect_synthetic(steps, layout=...) — the blocked (13 B per lane-step, int32 / float values, one contiguous block
+    per wave-step) and packed (one 32-bit record per lane-step) trajectories — decoded and compared with the oracle row by
+    row over the whole batch, across the 64-step launch boundary, then the state: the same information as the four
+    columns of the default ABI (rock.py:553-575: `ob, rw, done, info = env.step(action)` per step)."""
+    seed, lane0, t0 = 20260930, 1 << 22, (1 << 33) + 9
+    nt = oracle_lib.max_threads()
+    e = make_env(env, kw, batch_size=n, seed=seed, lane_offset=lane0, reuse_buffers=True)
+    e.call_counter = t0
+    o = oracle_lib.OracleEnv(env, **kw)
+    st = o.new_state(n)
+    assert np.array_equal(np_(e.reset()), o.batch_reset(st, seed, lane0, t0, nthreads=nt))
+    tr = e.collect_synthetic(steps, layout=layout)
+    assert tr["layout"] == layout and e.call_counter == t0 + 1 + steps and "layout" not in e.trajectory_buffers(1)
+    dec = e.decode_trajectory(tr)
+    done = np.zeros(n, np.uint8)
+    for k in range(steps):
+        t = t0 + 1 + k
+        a = oracle_lib.synthetic_actions(n, seed, lane0, t, o.n_actions, nthreads=nt)
+        ob, rew, done, bad = o.batch_step(st, a, seed, lane0, t, auto_reset=True, done=done, nthreads=nt)
+        ctx = (env, kw, n, k, layout)
+        assert bad == 0, ctx
+        assert np.array_equal(np_(dec["action"][k]), a), ctx
+        assert np.array_equal(np_(dec["ob"][k]), ob), ctx
+        got_r = np_(dec["reward"][k])
+        assert got_r.dtype == rew.dtype and np.array_equal(got_r, rew), ctx
+        assert np.array_equal(np_(dec["done"][k]), done.astype(bool)), ctx
+    assert np.array_equal(np_(e.state).view(np.uint32), st)
+    assert e.invalid_action_count() == 0
+    # the next call continues the same trajectory (it derives its first actions from (seed, lane, t) again)
+    tr2 = e.collect_synthetic(3, layout=layout)
+    d2 = e.decode_trajectory(tr2)
+    for k in range(3):
+        t = t0 + 1 + steps + k
+        a = oracle_lib.synthetic_actions(n, seed, lane0, t, o.n_actions, nthreads=nt)
+        ob, rew, done, bad = o.batch_step(st, a, seed, lane0, t, auto_reset=True, done=done, nthreads=nt)
+        assert np.array_equal(np_(d2["action"][k]), a) and np.array_equal(np_(d2["ob"][k]), ob) and np.array_equal(np_(d2["reward"][k]), rew)
+    assert np.array_equal(np_(e.state).view(np.uint32), st)
+
+
+def test_layout_kernels_are_the_quad_loops_with_another_sink():
+    """pomdp_last_fused_kernel() names the layout the launch wrote (as a profiler shows the template argument)."""
+    from gym_pomdp_amd import _native
+    L = _native.lib()
+    want = [("rock", {}, 1 << 20, 64, "packed", "steps_quad_kernel<RockEnv<1>, Packed>"),
+            ("rock", {}, 1 << 20, 64, "blocked", "steps_quad_kernel<RockEnv<1>, Blocked>"),
+            ("rock", {}, 1 << 18, 64, "packed", "steps_kernel<RockEnv<1>, 1, true, true, Packed>"),
+            ("rock", {}, 1 << 19, 64, "blocked", "steps_kernel<RockEnv<1>, 2, true, false, Blocked>"),
+            ("tag", {}, 1 << 20, 64, "packed", "tag_steps_quad_kernel<true, Packed>"),
+            ("tiger", {}, 1 << 20, 64, "blocked", "steps_quad_generic_kernel<TigerEnv, Blocked>"),
+            ("network", {}, 1 << 20, 64, "packed", "network_steps_quad_kernel<Packed>"),
+            ("battleship", {}, 1 << 18, 64, "packed", "battleship_steps_quad_kernel<BattleShipEnv<1>, Packed>"),
+            ("tiger", {}, 1000, 64, "packed", "steps_kernel<TigerEnv, 1, false, false, Packed>")]
+    for env, kw, n, k, layout, name in want:
+        e = make_env(env, kw, batch_size=n, seed=1, reuse_buffers=True)
+        e.reset()
+        e.collect_synthetic(k, layout=layout)
+        assert L.pomdp_last_fused_kernel().decode() == name, (env, kw, n, k, layout, L.pomdp_last_fused_kernel())
+        del e
+
+
+def test_collect_layout_through_the_c_abi():
+    """pomdp_collect_layout called directly: a row pitch larger than n in both layouts (the padding is never written),
+    equality with the column layout's values, and the argument checks."""
+    import ctypes as C
+    from gym_pomdp_amd import _native
+    L = _native.lib()
+    n, steps, seed = 5000, 67, 77
+    ref = make_env("rock", {}, batch_size=n, seed=seed, lane_offset=8, reuse_buffers=True)
+    ref.reset()
+    cols = ref.collect_synthetic(steps)
+    s = torch.cuda.current_stream().cuda_stream
+    for layout, pitch, row, dt in ((1, 5120, 5120 * 13, torch.uint8), (2, 5008, 5008, torch.int32)):
+        e = make_env("rock", {}, batch_size=n, seed=seed, lane_offset=8, reuse_buffers=True)
+        e.reset()
+        traj = torch.full((steps, row), 0x5A if layout == 1 else 0x5A5A5A5A, dtype=dt, device="cuda")
+        rc = L.pomdp_collect_layout(_native.ENV_KIND["rock"], C.byref(e._params), e._state.data_ptr(), traj.data_ptr(), e._err.data_ptr(),
+                                    n, seed, 8, e.call_counter, steps, pitch, layout, _native.POMDP_AUTO_RESET, s)
+        assert rc == 0
+        torch.cuda.synchronize()
+        d = e.decode_trajectory({"layout": "blocked" if layout == 1 else "packed", "pitch": pitch, "traj": traj})
+        assert torch.equal(d["action"], cols["action"][:steps]) and torch.equal(d["ob"], cols["ob"])
+        assert torch.equal(d["reward"], cols["reward"]) and torch.equal(d["done"], cols["done"])
+        assert torch.equal(e.state, ref.state)
+        if layout == 2:                                     # the padding lanes of every row are untouched
+            assert bool((traj[:, n:] == 0x5A5A5A5A).all())
+        else:
+            blocks = traj.view(steps, pitch // 256, 13 * 256)
+            assert bool((blocks[:, -1, 4 * (n % 256):1024] == 0x5A).all()) and bool((blocks[:, -1, 3072 + n % 256:] == 0x5A).all())
+        bad = lambda *a: L.pomdp_collect_layout(*a)        # noqa: E731
+        args = [_native.ENV_KIND["rock"], C.byref(e._params), e._state.data_ptr(), traj.data_ptr(), e._err.data_ptr(), n, seed, 8, 0, 4, pitch,
+                layout, _native.POMDP_AUTO_RESET, s]
+        assert bad(*args[:11], 0, *args[12:]) == -1         # POMDP_LAYOUT_COLUMNS has its own entry point
+        assert bad(*args[:12], 0, s) == -1                  # auto-reset is required
+        assert bad(*args[:10], n - 1, *args[11:]) == -1     # pitch < n
+        if layout == 1:
+            assert bad(*args[:10], pitch + 4, *args[11:]) == -1   # blocked rows are whole 256-lane blocks
+    t = make_env("tag", dict(obs_cells=300), batch_size=1024, seed=1, reuse_buffers=True)
+    t.reset()
+    with pytest.raises(RuntimeError):
+        t.collect_synthetic(4, layout="packed")             # "opponent seen" = 300 does not fit the record's ob byte
+    t.collect_synthetic(4, layout="blocked")
+    assert L.pomdp_packed_reward(_native.ENV_KIND["rock"], 0x9C) == -100.0 and L.pomdp_packed_reward(_native.ENV_KIND["network"], 68 + 7) == float(np.float32(6.9))

@@ -227,11 +227,11 @@ def test_fused_step_loops_never_wait_for_their_own_stores():
     res = clw.loop_waits(clw.assembly("fused_rock.hip"))
     seen = 0
     for name, (waits, prio) in res.items():
-        if "steps_quad_kernel<pomdp::RockEnv<1, false>" in name or "steps_kernel<pomdp::RockEnv<1, false>, 1, true, true>" in name:
+        if "steps_quad_kernel<pomdp::RockEnv<1, false>, " in name or "steps_kernel<pomdp::RockEnv<1, false>, 1, true, true, " in name:
             seen += 1
             assert waits == [], (name, waits)
             assert prio == 4, (name, prio)
-    assert seen == 2, sorted(res)
+    assert seen == 6, sorted(res)           # both kernels in each of the three trajectory layouts (traj_out.hip.h)
 
 
 def test_library_override_by_environment_variable():

@@ -305,3 +305,74 @@ def test_heuristic_policy_support(oracle_lib, case, env, kw):
     use_heuristic=True on injected Philox words (tests/golden/heur_*.npz)."""
     o = oracle_lib.OracleEnv(env, **kw)
     heuristic_replay(case, env, o, OracleHeuristicOps(oracle_lib, o))
+
+
+@pytest.mark.parametrize("env,kw,n,max_size,auto", [("rock", {}, 1001, None, True), ("rock", dict(board_size=15, num_rocks=15), 515, None, True),
+                                                    ("stochrock", {}, 402, None, True), ("tag", {}, 999, None, True),
+                                                    ("rock", {}, 600, 8, True), ("rock", dict(board_size=11, num_rocks=11), 300, 0, True),
+                                                    ("tag", {}, 500, 2, True), ("rock", {}, 700, None, False), ("tag", dict(num_opponents=2), 300, None, False),
+                                                    ("tiger", {}, 400, None, True), ("battleship", {}, 300, None, True),
+                                                    ("network", {}, 300, None, True)],
+                         ids=["rock_7_8", "rock_15_15", "stochrock", "tag", "rock-hist8", "rock_11_11-hist0", "tag-hist2", "rock-frozen",
+                              "tag_2-frozen", "tiger", "battleship", "network"])
+def test_lane_major_heuristic_driver_equals_the_per_step_call_sequence(oracle_lib, env, kw, n, max_size, auto):
+    """or_batch_heuristic_steps (k steps of every lane in one call, what the GPU tests at 2^20 lanes compare the fused
+    pomdp_heuristic_steps launches with) == the per-step sequence preferred -> pick -> step -> side statistics ->
+    history.append of the batch functions that the heur_* fixtures pin to the reference: every output row, the state, the
+    statistics, the history (sums or records) and prev_ob, across two calls."""
+    from conftest import OracleHeuristicOps
+    ol = oracle_lib
+    o = ol.OracleEnv(env, **kw)
+    seed, lane0, T1, T2 = 0xC0FFEE, (1 << 20) - 256, 37, 20
+    is_rock = env in ("rock", "stochrock")
+    ref = OracleHeuristicOps(ol, o)
+    ref.max_size = max_size
+    prev = ref.reset(n, seed, lane0, 5)
+    st = o.new_state(n)
+    prev_d = o.batch_reset(st, seed, lane0, 5).astype(np.int32)
+    assert np.array_equal(prev, prev_d)
+    b = ol.Belief(o, n) if is_rock else None
+    h = ol.HistorySums(o, n, max_size=max_size)
+    frozen = np.zeros(n, np.uint8)
+    t = 6
+    for k in (T1, T2):
+        got = o.batch_heuristic_steps(st, h, b, prev_d, k, seed, lane0, t, auto_reset=auto, done_in=frozen, nthreads=4)
+        for s in range(k):
+            lc, nc = ref.preferred()
+            a = ref.pick(lc, nc, t)
+            ref._pre = ref.st.copy()
+            ob, rew, done, bad = o.batch_step(ref.st, a, seed, lane0, t, auto_reset=auto, done=frozen.copy() if not auto else None)
+            live = frozen == 0
+            if ref.b is not None:
+                ref.b.update(ref.st, np.where(live, a, 0), ob, np.where(live, done, 1) if not auto else done, auto_reset=auto)
+            if auto:
+                ref.h.append(prev, a, ob, done)
+            else:                                  # frozen lanes append nothing: replay only the live ones' records
+                keep = {k_: getattr(ref.h, k_).copy() for k_ in ("size", "last_action", "last_ob", "total_sample", "total_move")}
+                recs = [r.copy() for r in ref.h.rec]
+                ref.h.append(prev, a, ob, done, auto_reset=False)
+                for k_, v in keep.items():
+                    cur = getattr(ref.h, k_)
+                    cur[..., ~live] = v[..., ~live]
+                for r, v in zip(ref.h.rec, recs):
+                    r[..., ~live] = v[..., ~live]
+            want_a = np.where(live, a, -1)
+            assert np.array_equal(got["action"][s], want_a), (s, "action")
+            assert np.array_equal(got["ob"][s], ob) and np.array_equal(got["reward"][s], rew), s
+            assert np.array_equal(got["done"][s], done), s
+            reset_ob = 0 if is_rock or env in ("battleship", "network") else (2 if env == "tiger" else ref.reset_ob())
+            prev = np.where(live, np.where((done != 0) & auto, reset_ob, ob), prev).astype(np.int32)
+            if not auto:
+                frozen = done.copy()
+            t += 1
+        assert np.array_equal(st, ref.st) and np.array_equal(prev_d, prev)
+        for k_ in ("size", "last_action", "last_ob") + (("total_sample", "total_move") if max_size is None else ()):
+            assert np.array_equal(getattr(h, k_), getattr(ref.h, k_)), k_
+        if max_size is not None:
+            for r, v in zip(h.rec, ref.h.rec):
+                rows = np.arange(r.shape[0])[:, None] < h.size[None, :]
+                assert np.array_equal(np.where(rows, r, 0), np.where(rows, v, 0))
+        if is_rock:
+            for k_, _ in ol.Belief.FIELDS:
+                x, y = getattr(b, k_), getattr(ref.b, k_)
+                assert ((x == y) | ((x != x) & (y != y))).all(), k_
