@@ -52,8 +52,37 @@ SIMD_HZ = 256 * 4 * 2.4e9  # VALU issue: 256 CUs x 4 SIMDs x 2.4 GHz cycles per 
 
 def _latest(pattern):
     import glob
-    f = sorted(glob.glob(os.path.join(REPO, "profiles", pattern)))
+    f = sorted(glob.glob(os.path.join(REPO, "profiles", pattern)), key=lambda x: (os.path.getmtime(x), x))
     return f[-1] if f else None
+
+
+def csrc_sha():
+    """sha256 over the kernel sources (gym_pomdp_amd/csrc/**, include/pomdp_hip.h), name-sorted: what a recorded PMC pass is
+    tied to.  tools/pmc_valu_summary.py writes it into profiles/*_pmc_valu.json when the counters are recorded; a tree that
+    differs makes every figure derived from those counters `counters_stale` (and tests/test_host_logic.py fail)."""
+    import hashlib
+    h = hashlib.sha256()
+    root = os.path.join(REPO, "gym_pomdp_amd", "csrc")
+    files = [os.path.join(d, f) for d, _, fs in os.walk(root) for f in fs if f.endswith((".hip", ".h"))]
+    for f in sorted(files) + [os.path.join(REPO, "include", "pomdp_hip.h")]:
+        h.update(os.path.relpath(f, REPO).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def counters_stale(pmc_path, workload=None):
+    """True when the recorded counters (of one workload of the file: each entry carries the hash it was recorded under, so a
+    partial re-recording can be merged into an older file) were taken from other kernel sources than this tree's, or carry
+    no hash at all."""
+    try:
+        d = json.load(open(pmc_path))
+        sha = d.get("csrc_sha256")
+        if workload is not None:
+            sha = d["workloads"][workload].get("csrc_sha256", sha)
+        return sha != csrc_sha()
+    except Exception:  # noqa: BLE001
+        return True
 
 
 def valu_roofline(workload, kernel_prefix, lanes, launch_ms):
@@ -78,6 +107,7 @@ def valu_roofline(workload, kernel_prefix, lanes, launch_ms):
     return {"bound": "valu", "achieved": achieved, "peak": SIMD_HZ / cpi, "unit": "wave-instructions/s",
             "frac": achieved * cpi / SIMD_HZ, "insts_per_launch": insts, "launch_ms": launch_ms,
             "cycles_per_instruction": cpi, "lane_ops_per_s": achieved * 64, "kernel": name,
+            "counters_stale": counters_stale(pmc, workload) or json.load(open(mix)).get("csrc_sha256") != csrc_sha(),
             "source": "instructions per launch recorded (not measured in this run): profiles/%s [%s]; issue cost of the "
                       "kernel's instruction mix: profiles/%s" % (os.path.basename(pmc), workload, os.path.basename(mix))}
 
@@ -134,6 +164,15 @@ def parse():
                     help="step mode, fused launches: 1 = keep every step's action / ob / reward / done in [128][N] "
                          "trajectory buffers (env.collect_synthetic); 0 = every step overwrites the same N-element "
                          "outputs, as per-step launches do (env.rollout_synthetic).  Same bytes written either way")
+    ap.add_argument("--layout", default="packed", choices=["columns", "blocked", "packed"],
+                    help="trajectory layout of the collected steps (include/pomdp_hip.h: POMDP_LAYOUT_*).  packed (default): one "
+                         "32-bit record per lane-step (action | ob << 8 | reward code << 16 | done << 24), 4 B instead of 13 — the fused "
+                         "loop is then bound by instruction issue; columns: the default ABI's four int32 / float / uint8 columns "
+                         "(four write streams); blocked: the columns' 13 bytes as one stream (256-lane blocks).  The line carries "
+                         "all three under `layouts`")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the `layouts` and `configs` blocks (the other layouts of this workload; Tag / BattleShip / the C5 "
+                         "rollout) that the default single-GPU run appends after its timed regions")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline sample")
     return ap.parse_args()
@@ -402,16 +441,18 @@ def heuristic_mode(args, gpa, env_id, kwargs, cp, dev, rank, world, label, n, la
     cp.close()
 
 
-def recorded_traffic_20(env_key, kernel_prefix):
-    """HBM bytes of the driver's 20-step launch, from the FETCH_SIZE / WRITE_SIZE passes of tools/gpu_pmc_valu.sh."""
+def recorded_traffic(env_key, layout, spl, kernel_prefix):
+    """HBM bytes of one fused launch of `spl` steps in `layout`, from the FETCH_SIZE / WRITE_SIZE passes of
+    tools/gpu_pmc_valu.sh (2 x FETCH_SIZE + WRITE_SIZE, the guide's gfx950 correction) — recorded, not measured in this run."""
     pmc = _latest("*_pmc_valu.json")
     if not pmc:
         return None, None
-    w = json.load(open(pmc))["workloads"].get("step20_%s" % env_key, {})
+    key = valu_workload_key(env_key, spl, layout)
+    w = json.load(open(pmc))["workloads"].get(key, {})
     for k, v in (w.get("traffic") or {}).items():
         if k.startswith(kernel_prefix):
-            return v["hbm_bytes_per_launch"], "recorded, not measured in this run: profiles/%s [step20_%s: %s]" % (
-                os.path.basename(pmc), env_key, k)
+            return v["hbm_bytes_per_launch"], "recorded, not measured in this run%s: profiles/%s [%s: %s]" % (
+                " (STALE: the kernel sources changed since)" if counters_stale(pmc, key) else "", os.path.basename(pmc), key, k)
     return None, None
 
 
@@ -431,13 +472,105 @@ def measured_traffic(env_key, chained=False, fused=False):
     return t[key]["hbm_bytes_per_launch"], "recorded, not measured in this run: profiles/%s [%s]" % (name, key)
 
 
+def fused_alg_bytes(bytes_per_step, spl, layout):
+    """Algorithmic bytes per lane-step of a fused launch of `spl` steps: the layout's output bytes per step (action, ob,
+    reward: 4 B each + done: 1 B = 13; packed: one 4-byte record) + what the launch moves once — the state in and out
+    (SURVEY.md §8d's per-step figure minus its 13 B of per-step columns ... minus the action it READS, which a fused launch
+    generates) and, columns only, the row of first actions it writes."""
+    out_b = 4.0 if layout == "packed" else 13.0
+    once = bytes_per_step - 9 - (0 if layout == "columns" else 4)
+    return out_b + once / float(spl)
+
+
+def valu_workload_key(env_key, spl, layout):
+    return "step%d_%s%s" % (spl, env_key, "" if layout == "columns" else "_" + layout)
+
+
+def step_rooflines(env_key, bytes_per_step, layout, n, kern_ms, spl, fused, fused_kernel):
+    """Both rooflines of the timed step kernel: HBM (algorithmic bytes / live kernel time) and, when the kernel's VALU count
+    is on record, VALU issue.  `primary` = the tighter one (HBM when there is no usable VALU record)."""
+    alg = fused_alg_bytes(bytes_per_step, spl, layout) if fused else float(bytes_per_step)
+    achieved = alg * n / (kern_ms * 1e-3) / 1e9
+    hbm = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS}
+    valu = None
+    if fused and fused_kernel:
+        valu = valu_roofline(valu_workload_key(env_key, spl, layout), fused_kernel.split("<")[0] + "<", n, kern_ms * spl)
+    primary = hbm
+    if valu is not None and not valu["counters_stale"] and valu["frac"] > hbm["frac"]:
+        primary = {k: valu[k] for k in ("bound", "achieved", "peak", "unit", "frac")}
+    return {"alg_bytes": alg, "hbm": hbm, "valu": valu, "primary": primary}
+
+
+def quick_step_config(args, gpa, _native, cp, dev, env_key, n, lane_offset, seed, layout):
+    """One workload measured briefly with the headline's protocol (reseed + reset, W warm-up steps, an untimed pass, then 9
+    regions of K steps bracketed by device syncs: even ones by wall clock, odd ones by HIP events) -> a `configs` / `layouts`
+    entry.  K = --steps, at most 128."""
+    env_id, kwargs, label, bytes_per_step, _ = WORKLOADS[env_key]
+    k = min(args.steps, 128)
+    wl = StepWorkload(args, gpa, env_id, kwargs, dev, n, lane_offset, seed, layout=layout)
+    wl.reseed(seed)
+    wl.run(args.warmup)
+    wl.run(k)
+    walls, evs = timed_regions(wl.run, k, 9, dev, cp)
+    kernel = _native.lib().pomdp_last_fused_kernel().decode()
+    spl = min(64, k)
+    kern_ms = median(evs) / k
+    rf = step_rooflines(env_key, bytes_per_step, layout, n, kern_ms, spl, True, kernel)
+    del wl
+    torch.cuda.empty_cache()
+    return {"workload": "%s batch=%d, %s layout, %d steps per region" % (label, n, layout, k),
+            "value": n * k / median(walls), "unit": "env-steps/s", "ms_per_step": median(walls) / k * 1e3,
+            "kernel": kernel, "kernel_ms": kern_ms, "steps_per_launch": spl, "bytes_per_lane_step": rf["alg_bytes"],
+            "roofline": {"bound": rf["primary"]["bound"], "frac": rf["primary"]["frac"], "hbm_frac": rf["hbm"]["frac"],
+                         "valu_frac": None if rf["valu"] is None else rf["valu"]["frac"],
+                         "counters_stale": None if rf["valu"] is None else rf["valu"]["counters_stale"]}}
+
+
+def quick_rollout_config(args, gpa, dev, env_key, roots_n, sims, depth, seed):
+    """BASELINE.json configs[4] per GPU: roots_n x sims random rollouts of <= depth steps in one fused launch, 10 timed
+    launches (HIP events) after 5 untimed ones."""
+    env_id, kwargs, label, _, _ = WORKLOADS[env_key]
+    e = gpa.make(env_id, batch_size=roots_n, device=dev, seed=seed, reuse_buffers=True, **kwargs)
+    e.reset()
+    for _ in range(4):
+        e.step(e.synthetic_actions())
+    roots = e.state.clone()
+    out, total = None, torch.zeros((), dtype=torch.int64, device=dev)
+    for _ in range(5):                     # the step count's reduction too: torch loads that kernel at its first use (~0.1 s)
+        out = e.rollout(depth, sims_per_root=sims, roots=roots, out=out)
+        total.add_(out["n_steps"].sum())
+    total.zero_()
+    torch.cuda.synchronize(dev)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(10):
+        out = e.rollout(depth, sims_per_root=sims, roots=roots, out=out)
+        total.add_(out["n_steps"].sum())
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    launch_ms = ev0.elapsed_time(ev1) / 10
+    steps_done = int(total.item())
+    v = valu_roofline("rollout_%s" % env_key, "rollout_kernel<", roots_n * sims, launch_ms)
+    del e, out
+    torch.cuda.empty_cache()
+    return {"workload": "%s: %d roots x %d simulations, depth <= %d, uniform policy over _generate_legal(), one fused rollout "
+                        "launch per step" % (label, roots_n, sims, depth),
+            "value": steps_done / wall, "unit": "env-steps/s (lane-steps of the simulations)", "kernel": "rollout_kernel<%s>" % env_key,
+            "kernel_ms": launch_ms, "mean_steps_per_simulation": steps_done / (10.0 * roots_n * sims),
+            "roofline": {"bound": "valu" if v else None, "frac": v["frac"] if v else None,
+                         "counters_stale": v["counters_stale"] if v else None}}
+
+
 class StepWorkload(object):
     """K consecutive steps of one env shard under the synthetic policy, every buffer allocated up front."""
 
     CHUNK = 128          # steps per C-driver call (two full 64-step launches when fused)
 
-    def __init__(self, args, gpa, env_id, kwargs, dev, n, lane_offset, seed):
+    def __init__(self, args, gpa, env_id, kwargs, dev, n, lane_offset, seed, layout=None):
         self.args, self.dev, self.n = args, dev, n
+        self.layout = layout or args.layout
         self.env = gpa.make(env_id, batch_size=n, device=dev, seed=seed, lane_offset=lane_offset, reuse_buffers=True, **kwargs)
         self.actions = torch.empty(n, dtype=torch.int32, device=dev)
         self.shared_key = args.action_seed is None
@@ -448,16 +581,25 @@ class StepWorkload(object):
         if self.collect:
             # one [CHUNK + 1][n] trajectory buffer per column; a call of c steps writes the first c (+ 1) rows
             c = min(self.CHUNK, max(args.steps, args.warmup, 1))
-            self.traj = self.env.trajectory_buffers(c)      # one allocation, column starts staggered (envs/base.py: staggered)
+            self.traj = self.env.trajectory_buffers(c, self.layout)    # one allocation (columns: starts staggered, envs/base.py)
+        else:
+            self.layout = "columns"
 
     def _view(self, c):
         v = self.views.get(c)
         if v is None:
             t = self.traj
-            v = {"action": t["action"][:c + 1], "ob": t["ob"][:c], "reward": t["reward"][:c], "done_u8": t["done_u8"][:c]}
-            v["done"] = v["done_u8"].view(torch.bool)
+            if self.layout == "columns":
+                v = {"action": t["action"][:c + 1], "ob": t["ob"][:c], "reward": t["reward"][:c], "done_u8": t["done_u8"][:c]}
+                v["done"] = v["done_u8"].view(torch.bool)
+            else:
+                v = dict(t, traj=t["traj"][:c])
             self.views[c] = v
         return v
+
+    def traj_tensor(self):
+        """a flat view of (one column of) the trajectory buffer the timed launches write: what store_ceiling fills"""
+        return (self.traj["ob"] if self.layout == "columns" else self.traj["traj"]).view(-1)
 
     def reseed(self, seed):
         self.env.seed(seed)
@@ -579,14 +721,9 @@ def main():
     plain_ms = ev0.elapsed_time(ev1) / k1
     plain_achieved = bytes_per_step * n / (plain_ms * 1e-3) / 1e9
     kern_ms = timed_kernel_ms if chained else plain_ms
-    # Algorithmic bytes per lane-step.  One launch per step moves SURVEY.md §8d's figure: state in + state out + action
-    # in 4 + ob 4 + reward 4 + done 1.  A fused launch of up to 64 steps has to write each step's action, ob, reward and
-    # done (13 B) but reads the state once, writes it once and writes the first actions: 13 + (figure - 9) / steps per
-    # launch.  Pricing the fused launch at the per-step figure would credit it with bytes it never has to move
-    # (BattleShip: 61 vs 13.8).
     spl = min(64, args.steps) if fused else 1
-    alg_bytes = 13.0 + (bytes_per_step - 9) / float(spl) if fused else float(bytes_per_step)
-    achieved = alg_bytes * n / (kern_ms * 1e-3) / 1e9
+    layout = wl.layout
+    rf = step_rooflines(args.env, bytes_per_step, layout, n, kern_ms, spl, fused, fused_kernel)
     chain1_ms = None
     if fused:      # the same chained steps launched one by one (step_kernel<., chain>), for reference
         env.rollout_synthetic(64, action_seed=action_seed, actions=wl.actions, fuse=False)
@@ -598,11 +735,10 @@ def main():
         chain1_ms = ev0.elapsed_time(ev1) / k1
     invalid = env.invalid_action_count()
     # What a write stream reaches on THIS device into THIS buffer (measured here, after the timed regions): a plain fill of the
-    # trajectory's ob column — one 16-byte store stream over the very pages the timed launches wrote.  The fused launch's own
-    # rate depends on where its buffer lies; the fill shows the ceiling the placement leaves.
+    # trajectory buffer (columns: its ob column) — one 16-byte store stream over the very pages the timed launches wrote.
     store_ceiling = None
     if collect:
-        col = wl.traj["ob"].view(-1)
+        col = wl.traj_tensor()
         for _ in range(3):
             col.fill_(0)
         torch.cuda.synchronize(dev)
@@ -612,15 +748,36 @@ def main():
         ev1.record()
         torch.cuda.synchronize(dev)
         store_ceiling = {"value": col.numel() * col.element_size() * 10 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9, "unit": "GB/s",
-                         "how": "torch fill over the trajectory buffer's ob column (%d MB, one 16-byte store stream), HIP events; "
-                                "untimed, after the regions" % (col.numel() * col.element_size() >> 20)}
+                         "how": "torch fill over the trajectory buffer%s (%d MB, one 16-byte store stream), HIP events; "
+                                "untimed, after the regions" % ("'s ob column" if layout == "columns" else "", col.numel() * col.element_size() >> 20)}
 
-    # the recorded PMC figure belongs to a launch of the recorded shape only: 2^20 lanes, 64 steps per fused launch
-    traffic, traffic_src = measured_traffic(args.env, chained, fused) if (n == 1 << 20 and spl in (1, 64)) else (None, None)
+    # ---- the same workload in the other trajectory layouts, and BASELINE.json's configs[2..4] at their per-GPU sizes --------
+    # (single-GPU default runs only; short HIP-event measurements of the same protocol, after the headline's timed regions)
+    layouts_block = configs_block = None
+    extras = world == 1 and not args.no_extras and collect
+    if extras:
+        layouts_block = {}
+        for lay in ("columns", "blocked", "packed"):
+            if lay == layout:
+                layouts_block[lay] = {"value": n * args.steps / elapsed, "ms_per_step": elapsed / args.steps * 1e3, "kernel": fused_kernel,
+                                      "kernel_ms": kern_ms, "bytes_per_lane_step": rf["alg_bytes"],
+                                      "roofline": {"bound": rf["primary"]["bound"], "frac": rf["primary"]["frac"], "hbm_frac": rf["hbm"]["frac"],
+                                                   "valu_frac": None if rf["valu"] is None else rf["valu"]["frac"]}, "headline": True}
+            else:
+                layouts_block[lay] = quick_step_config(args, gpa, _native, cp, dev, args.env, n, lane_offset, seeds[0], lay)
+    if extras and args.env == "rock":
+        configs_block = {
+            "tag": quick_step_config(args, gpa, _native, cp, dev, "tag", 1 << 20, 0, seeds[0], layout),            # configs[2]
+            "battleship": quick_step_config(args, gpa, _native, cp, dev, "battleship", 1 << 19, 0, seeds[0], layout),   # configs[3]: 2^22 / 8 GPUs
+            "rollout_rock15": quick_rollout_config(args, gpa, dev, "rock15", 2048, 1024, 64, seeds[0])}                 # configs[4]: 2^24 / 8 GPUs
+
+    # the recorded PMC figure belongs to a launch of the recorded shape only: 2^20 lanes, 64 or 20 steps per fused launch
+    traffic, traffic_src = (None, None)
     kprefix = (fused_kernel or "").split("<")[0] + "<" if fused else "step_kernel<"
-    if fused and n == 1 << 20 and spl == 20:               # the driver's invocation: one 20-step launch per region
-        traffic, traffic_src = recorded_traffic_20(args.env, kprefix)
-    valu = valu_roofline("step%d_%s" % (spl, args.env), kprefix, n, kern_ms * spl) if fused else None
+    if layout == "columns" and n == 1 << 20 and spl in (1, 64):
+        traffic, traffic_src = measured_traffic(args.env, chained, fused)
+    if fused and n == 1 << 20 and traffic is None:
+        traffic, traffic_src = recorded_traffic(args.env, layout, spl, kprefix)
     rank_kernel_ms = cp.gather(timed_kernel_ms)            # a slow GPU shows in the one line the driver keeps
     if rank == 0:
         total_lanes = n * world
@@ -635,11 +792,43 @@ def main():
         if fused:
             kernel_name = "%s — %d chained steps per launch: step + next-step policy, every step's outputs written%s, " \
                           "state in registers between steps; the only kernel of the timed region" % (
-                              fused_kernel, spl, " to its own trajectory row" if collect else " over the previous step's")
+                              fused_kernel, spl, (" to its own trajectory row (%s layout)" % layout) if collect else " over the previous step's")
         elif chained:
             kernel_name = "step_kernel<%s, chain> (step + next-step policy, the launch of the timed region)" % args.env
         else:
             kernel_name = "step_kernel<%s>" % args.env
+        primary, hbm, valu = rf["primary"], rf["hbm"], rf["valu"]
+        roof = dict(primary)
+        roof.update({
+            "traffic": traffic, "traffic_unit": "bytes per %d-step launch" % spl if fused else "bytes per launch",
+            "traffic_source": traffic_src,
+            "hbm": hbm, "valu": valu,
+            "tighter_bound": None if valu is None else ("valu" if valu["frac"] > hbm["frac"] else "hbm"),
+            "counters_stale": None if valu is None else valu["counters_stale"],
+            "store_ceiling": store_ceiling,
+            "kernel_ms_by_rank": rank_kernel_ms,
+            "kernel": kernel_name,
+            "kernel_ms": kern_ms, "algorithmic_bytes_per_step": rf["alg_bytes"],
+            "algorithmic_bytes_per_step_unfused": bytes_per_step,
+            "steps_per_launch": spl,
+            "launch_ms": kern_ms * spl,
+            "chained_step_kernel": None if chain1_ms is None else {
+                "kernel": "step_kernel<%s, chain> (the same steps, one launch each)" % args.env,
+                "kernel_ms": chain1_ms, "achieved": bytes_per_step * n / (chain1_ms * 1e-3) / 1e9,
+                "frac": bytes_per_step * n / (chain1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "plain_step_kernel": {"kernel": "%s<%s> (what env.step() launches)" % (
+                "step_quad_kernel" if args.env in ("rock", "rock15", "stochrock") and n >= (1 << 19) and n % 1024 == 0
+                else "step_kernel", args.env),
+                                  "kernel_ms": plain_ms, "achieved": plain_achieved,
+                                  "frac": plain_achieved / HBM_PEAK_GBS},
+            "note": "kernel_ms: HIP events on the launch stream around each timed region of %d back-to-back "
+                    "steps (median over regions and seeds) / steps; launch_ms = kernel_ms x steps_per_launch; "
+                    "algorithmic bytes: the layout's bytes of outputs per lane-step (13, packed: 4) + state in/out (columns: "
+                    "and the first actions) once per fused launch, the full per-step figure for the single-step kernels; the "
+                    "object's own bound/achieved/peak/frac are the TIGHTER of the two rooflines when the VALU counters of this "
+                    "kernel are on record (profiles/*_pmc_valu.json, csrc hash checked), else HBM; both are kept under "
+                    "`hbm` / `valu`; plain_step_kernel: env.step() on a ring of 16 pre-generated action batches"
+                    % args.steps})
         out = {
             "metric": metric,
             "value": total_lanes * args.steps / elapsed,
@@ -654,10 +843,12 @@ def main():
             "dtype": dtype,
             "data": "synthetic",
             "config": {"workload": "%s batch=%d lanes per GPU (%d total, %s scaling), uniform random actions from the "
-                                   "synthetic policy (generated inside the timed launches), auto-reset"
-                                   % (label, n, total_lanes, args.scaling),
+                                   "synthetic policy (generated inside the timed launches), auto-reset, every step's "
+                                   "action / ob / reward / done kept in the %s trajectory layout"
+                                   % (label, n, total_lanes, args.scaling, layout),
                        "lanes_per_gpu": n, "total_lanes": total_lanes, "host_loop": args.host_loop, "visible_gpus": n_dev,
-                       "steps_per_launch": spl, "trajectories_kept": collect,
+                       "steps_per_launch": spl, "trajectories_kept": collect, "trajectory_layout": layout if collect else None,
+                       "trajectory_bytes_per_lane_step": (4 if layout == "packed" else 13) if collect else None,
                        "seeds": seeds, "repeats": repeats,
                        "protocol": "per seed: reseed + reset, W warm-up steps, one untimed pass of K steps, then `repeats` "
                                    "timed regions of exactly K steps (barrier + device sync on both sides, max over ranks); "
@@ -670,35 +861,13 @@ def main():
                        "shards": [{"rank": r, "lane_offset": s[0], "lanes": s[1], "device": s[2]} for r, s in enumerate(shards)],
                        "host_cpus": os.cpu_count(),
                        "host_cpus_usable": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per %d-step launch" % spl if fused else "bytes per launch",
-                         "valu": valu,
-                         "store_ceiling": store_ceiling,
-                         "tighter_bound": None if valu is None else ("valu" if valu["frac"] > achieved / HBM_PEAK_GBS else "hbm"),
-                         "kernel_ms_by_rank": rank_kernel_ms,
-                         "traffic_source": traffic_src,
-                         "kernel": kernel_name,
-                         "kernel_ms": kern_ms, "algorithmic_bytes_per_step": alg_bytes,
-                         "algorithmic_bytes_per_step_unfused": bytes_per_step,
-                         "steps_per_launch": spl,
-                         "launch_ms": kern_ms * spl,
-                         "chained_step_kernel": None if chain1_ms is None else {
-                             "kernel": "step_kernel<%s, chain> (the same steps, one launch each)" % args.env,
-                             "kernel_ms": chain1_ms, "achieved": bytes_per_step * n / (chain1_ms * 1e-3) / 1e9,
-                             "frac": bytes_per_step * n / (chain1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-                         "plain_step_kernel": {"kernel": "%s<%s> (what env.step() launches)" % (
-                             "step_quad_kernel" if args.env in ("rock", "rock15", "stochrock") and n >= (1 << 19) and n % 1024 == 0
-                             else "step_kernel", args.env),
-                                               "kernel_ms": plain_ms, "achieved": plain_achieved,
-                                               "frac": plain_achieved / HBM_PEAK_GBS},
-                         "note": "kernel_ms: HIP events on the launch stream around each timed region of %d back-to-back "
-                                 "steps (median over regions and seeds) / steps; launch_ms = kernel_ms x steps_per_launch; "
-                                 "algorithmic bytes: 13 B of outputs per step + state in/out and first actions once "
-                                 "per fused launch, the full per-step figure for the single-step kernels; "
-                                 "plain_step_kernel: env.step() on a ring of 16 pre-generated action batches"
-                                 % args.steps},
+            "roofline": roof,
             "invalid_actions": invalid,
         }
+        if layouts_block is not None:
+            out["layouts"] = layouts_block
+        if configs_block is not None:
+            out["configs"] = configs_block
         if strong is not None:
             out["strong_scaling"] = strong
         if world == 1 and not args.no_cpu_baseline:

@@ -498,6 +498,72 @@ struct RockEnv {
         done = STOCH ? exit_east : (left | missed);                            // penalties never terminate there (rock.py:503)
     }
 
+    // ---- the lane step as one packed record (one state word; steps_quad_kernel) -------------------------------------------
+    // Round 4: with 4-byte trajectory records the fused loop is bound by instruction issue, and step_tab + sensor_ob + the
+    // reward / done selects cost ~49 vector instructions per lane-step.  step_rec produces the lane's Packed record
+    // (traj_out.hip.h: action | ob << 8 | reward code << 16 | done << 24) and its new state in ~31, from a table whose
+    // entries already hold, per (action, position), everything that does not depend on the rocks' codes:
+    //   every entry: bits 28-30 = the OUTCOME CODE the step has when no uncollected rock is sampled ("fallback"), bit 31 =
+    //                a rock with an id < K lies under a SAMPLE;
+    //   a <  4: bits 0-7 = position byte XOR new position byte (0 if the move leaves); fallback 6 inside, 3 leaving east,
+    //           1 leaving elsewhere (StochasticRock: 6, rock.py:432, 503);
+    //   a == 4: bits 0-4 = bit offset of the cell's rock code in the state; fallback 1 (StochasticRock: 6);
+    //   a >= 5: bits 0-27 = the sensor threshold's high bits (thr >> 26 <= 2^27: a sensor that is always right at distance 0
+    //           has thr = 2^53) at this distance; fallback 6 — the kernel compares against (H >> 5) | 6 << 28 (one
+    //           v_alignbit_b32), so the threshold test and the tie test read the entry as it is.
+    // Outcome codes: 0 = bad rock sampled (-10), 1 = penalty (-100, done), 2 = good rock sampled (+10), 3 = east exit (+10,
+    // done), 6 = nothing (0) — a sampled rock's own code IS its outcome code, done is bit 0, and the reward byte is one
+    // v_perm_b32 lookup in an 8-byte constant.
+    static constexpr bool FAST_REC = W == 1;
+    static constexpr uint32_t REC_LUT_LO = 0x0A0A9CF6u, REC_LUT_HI = 0x00000000u;   // reward byte by outcome code 0..7
+    struct RecTab { uint32_t e[TAB_ACTIONS][256]; };
+    static __device__ __forceinline__ void build_rec_tab(RecTab &tab, const Shared &sh, const Params &p, int pos)
+    {
+        const uint32_t x = (uint32_t)pos & 15u, y = (uint32_t)pos >> 4, size = (uint32_t)p.size, K = (uint32_t)p.num_rocks;
+        const int id = sh.grid[x * 16 + y];
+        const uint32_t NOTHING = 6u << 28, PENALTY = (STOCH ? 6u : 1u) << 28, EXIT_EAST = 3u << 28;
+        for (int a = 0; a < 5 + (int)K && a < TAB_ACTIONS; ++a) {
+            uint32_t e;
+            if (a < 4) {
+                const uint32_t nx = x + (uint32_t)((a == 1) - (a == 3)), ny = y + (uint32_t)((a == 0) - (a == 2));
+                const bool inside = max(nx, ny) < size;
+                e = inside ? (((uint32_t)pos ^ (nx | (ny << 4))) | NOTHING) : (a == 1 ? EXIT_EAST : PENALTY);
+            } else if (a == 4) {
+                const bool rock = (uint32_t)id < K;
+                e = (rock ? ((8u + 2u * (uint32_t)id) | 0x80000000u) : 0u) | PENALTY;
+            } else {
+                e = sh.thr[__builtin_amdgcn_sad_u8(x | (y << 8), sh.rpos[a - 5], 0u) & 31u].x | NOTHING;
+            }
+            tab.e[a][pos] = e;
+        }
+    }
+    // rock.py:123-194 for one lane: s -> s' (the fresh episode `fresh` if the step ends this one), rec = the step's record.
+    // H: the lane's sensor high word; `lo` yields its low word (a tie, 2^-27 per CHECK).
+    template <class LowWord>
+    static __device__ __forceinline__ void step_rec(const Shared &sh, const RecTab &tab, uint32_t &s, uint32_t a, uint32_t H,
+                                                    uint32_t fresh, uint32_t &rec, LowWord lo)
+    {
+        const uint32_t e = tab.e[a][s & 0xFFu];
+        // SAMPLE (rock.py:160-169): the cell's rock code, read at the entry's offset (entries of the other classes: the
+        // sign bit is clear, so whatever this reads is never used)
+        const uint32_t code = __builtin_amdgcn_ubfe(s, e, 2u);
+        const bool ok = ((int32_t)e < 0) & (code != 1u);                        // an uncollected rock with an id < K is underfoot
+        const uint32_t collect = (code ^ 1u) << (e & 31u);                      // its code -> 1
+        // moves (rock.py:134-158): the position delta, for that class only
+        const uint32_t delta = ok ? collect : ((a < 4u ? e : 0u) & 0xFFu);
+        const uint32_t oc = ok ? code : __builtin_amdgcn_ubfe(e, 28u, 3u);      // outcome code
+        const uint32_t rbyte = __builtin_amdgcn_perm(REC_LUT_HI, REC_LUT_LO, (oc << 16) | 0x0C000C0Cu);   // reward byte << 16
+        const uint32_t done = oc & 1u;
+        // CHECK rock a - 5 (rock.py:171-175, 401-407): its code sits at bits 2a-2, 2a-1 of the state; good = the upper one
+        const bool good = __builtin_amdgcn_ubfe(s, 2u * a - 1u, 1u) != 0u;
+        const uint32_t kh = __builtin_amdgcn_alignbit(12u, H, 5u);              // (H >> 5) | 6 << 28: compares with the entry itself
+        bool correct = kh < e;
+        if (a > 4u && kh == e) correct = (lo() >> 6) <= thr_lo_of(sh, State{(S)s}, (int)a - 5);   // probability 2^-27
+        const uint32_t ob = a > 4u ? ((good == correct) ? 2u << 8 : 1u << 8) : 0u;
+        rec = rbyte | (done << 24) | ob | a;
+        s = done ? fresh : (s ^ delta);
+    }
+
     // observation of a CHECK from the sensor's high word (rock.py:404-407); `lo` yields the low word on a tie
     template <class LowWord>
     static __device__ __forceinline__ int sensor_ob(const Shared &sh, const State &st, const Aux &aux, uint32_t H, LowWord lo)

@@ -190,7 +190,10 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
     constexpr int W = Env::WORDS;
     using S = typename Env::S;
     __shared__ typename Env::Shared sh;
-    __shared__ typename Env::StepTab tab;
+    // one state word: the lane step yields the lane's packed record straight from RecTab (RockEnv::step_rec, ~31 instead of ~49
+    // vector instructions per lane-step); two state words: the (position, action) table of step_tab
+    constexpr bool FAST = Env::FAST_REC;
+    __shared__ typename std::conditional<FAST, typename Env::RecTab, typename Env::StepTab>::type tab;
     TL(0);
     TL_HW();
     const uint32_t l0 = blockIdx.x * (uint32_t)(4 * BLOCK) + 4u * threadIdx.x;   // this thread's first lane within the shard
@@ -213,7 +216,8 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
     Env::stage(sh, p, (int)threadIdx.x);
     __syncthreads();
     TL(1);
-    Env::build_tab(tab, sh, p, (int)threadIdx.x);
+    if constexpr (FAST) Env::build_rec_tab(tab, sh, p, (int)threadIdx.x);
+    else Env::build_tab(tab, sh, p, (int)threadIdx.x);
     __syncthreads();
     TL(2);
     const int K = p.num_rocks;
@@ -247,6 +251,24 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
         uint32_t o[4], a_next[4], codes[4];
         const uint32_t a_taken[4] = {(uint32_t)a_cur[0], (uint32_t)a_cur[1], (uint32_t)a_cur[2], (uint32_t)a_cur[3]};
         Env::reset_codes4(R, key, glane0, K, codes);
+        if constexpr (FAST) {
+            uint32_t rec[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t lane = glane0 + (uint32_t)j;
+                uint32_t sj = (uint32_t)st[j].s;
+                Env::step_rec(sh, tab, sj, a_taken[j], H[j], start | (codes[j] << 8), rec[j],
+                              [&]() { return Env::elem(Env::quad_block(key, lane, SENSOR_BLOCK + 1u), (uint32_t)j); });
+                if constexpr (Env::STOCHASTIC) {                                // the gate said no (rock.py:443): nothing happens
+                    sj = acts[j] ? sj : (uint32_t)st[j].s;
+                    rec[j] = acts[j] ? rec[j] : a_taken[j];
+                }
+                st[j].s = (S)sj;
+                a_next[j] = __umulhi(P[j], n_act);
+                a_cur[j] = (int)a_next[j];
+            }
+            out.put_records(rec, a_next);
+        } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             typename Env::Aux aux;
@@ -266,6 +288,7 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
         const uint32_t r4[4] = {(uint32_t)r[0], (uint32_t)r[1], (uint32_t)r[2], (uint32_t)r[3]};   // the int8 reward IS its code
         const uint32_t d4[4] = {(uint32_t)d[0], (uint32_t)d[1], (uint32_t)d[2], (uint32_t)d[3]};
         out.put(a_taken, a_next, o, r4, r4, d4);
+        }
     }
     // the state is the loop's carry: it reaches memory once
     TL(3);

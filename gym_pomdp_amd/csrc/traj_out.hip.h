@@ -79,6 +79,20 @@ template <> struct QuadOut<Columns> {
         st_stream(done_w, d[0] | (d[1] << 8) | (d[2] << 16) | (d[3] << 24));
         action_w += rec; ob_w += rec; reward_w += rec; done_w += rec / 4;
     }
+    // the same from the lanes' packed records (a lane step that produces the record directly: RockEnv::step_rec) — unpacked
+    // here; valid for the envs whose reward code is the int8 reward itself
+    __device__ __forceinline__ void put_records(const uint32_t (&rec)[4], const uint32_t (&a_next)[4])
+    {
+        uint32_t a[4], o[4], r[4], d[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a[j] = rec[j] & 0xFFu;
+            o[j] = __builtin_amdgcn_ubfe(rec[j], 8u, 8u);
+            r[j] = (uint32_t)__builtin_amdgcn_sbfe(rec[j], 16u, 8u);
+            d[j] = rec[j] >> 24;
+        }
+        put(a, a_next, o, r, r, d);
+    }
 };
 
 template <> struct QuadOut<Blocked> {
@@ -98,6 +112,20 @@ template <> struct QuadOut<Blocked> {
         st_stream(reinterpret_cast<uint32_t *>(wd), d[0] | (d[1] << 8) | (d[2] << 16) | (d[3] << 24));
         w += row_bytes; wd += row_bytes;
     }
+    // the same from the lanes' packed records (a lane step that produces the record directly: RockEnv::step_rec) — unpacked
+    // here; valid for the envs whose reward code is the int8 reward itself
+    __device__ __forceinline__ void put_records(const uint32_t (&rec)[4], const uint32_t (&a_next)[4])
+    {
+        uint32_t a[4], o[4], r[4], d[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a[j] = rec[j] & 0xFFu;
+            o[j] = __builtin_amdgcn_ubfe(rec[j], 8u, 8u);
+            r[j] = (uint32_t)__builtin_amdgcn_sbfe(rec[j], 16u, 8u);
+            d[j] = rec[j] >> 24;
+        }
+        put(a, a_next, o, r, r, d);
+    }
 };
 
 template <> struct QuadOut<Packed> {
@@ -111,6 +139,11 @@ template <> struct QuadOut<Packed> {
     {
         st_stream4(w, pack_record(a_cur[0], o[0], rc[0], d[0]), pack_record(a_cur[1], o[1], rc[1], d[1]),
                    pack_record(a_cur[2], o[2], rc[2], d[2]), pack_record(a_cur[3], o[3], rc[3], d[3]));
+        w += rec;
+    }
+    __device__ __forceinline__ void put_records(const uint32_t (&r)[4], const uint32_t (&)[4])
+    {
+        st_stream4(w, r[0], r[1], r[2], r[3]);
         w += rec;
     }
 };

@@ -191,31 +191,49 @@ def _bench(*argv, timeout=900):
 def test_bench_line_as_the_driver_runs_it():
     """`python bench.py --gpus 1 --steps 20 --warmup 5`: ONE JSON line with the contract's keys, and the figures of the
     timed region — no allocation inside it, the fused kernel named as a profiler shows it, the per-step time and roofline
-    fraction of the committed profiles (within the spread of a short region)."""
+    fraction of the committed profiles (within the spread of a short region); the other trajectory layouts and
+    BASELINE.json's configs[2..4] measured in the same run."""
     d = _bench("--gpus", 1, "--steps", 20, "--warmup", 5, "--cpu-seconds", 2)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "layouts", "configs"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["scaling"] == "weak"
     assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
     assert d["config"]["seeds"] == [0, 1, 2] and d["config"]["repeats"] >= 30 and len(d["config"]["seed_values"]["per_seed"]) == 3
+    assert d["config"]["trajectories_kept"] is True and d["config"]["trajectory_layout"] == "packed"
     r = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "hbm", "valu"):
         assert k in r, k
-    assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
-    assert r["kernel"].startswith("steps_quad_kernel<RockEnv<1>>"), r["kernel"]
-    assert r["kernel_ms"] < 3.6e-3 and r["frac"] > 0.5, r              # profiles: 2.85-2.9 us per step of a 20-step launch, 0.62
-    assert d["ms_per_step"] < 4.5e-3, d["ms_per_step"]                 # by wall clock, launch + sync wake-up included
-    # the recorded HBM bytes of THIS launch shape (20 steps) and the VALU-issue roofline beside the HBM one
-    assert r["traffic"] is not None and 0.95 < r["traffic"] / (r["algorithmic_bytes_per_step"] * (1 << 20) * 20) < 1.1, r["traffic"]
+    assert r["bound"] in ("hbm", "valu") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["frac"] <= 1.0
+    assert r["kernel"].startswith("steps_quad_kernel<RockEnv<1>, Packed>"), r["kernel"]
+    assert r["kernel_ms"] < 2.6e-3, r                                  # profiles: 2.1-2.2 us per step of a 20-step launch
+    assert d["ms_per_step"] < 3.6e-3, d["ms_per_step"]                 # by wall clock, launch + sync wake-up included
+    h = r["hbm"]
+    assert h["bound"] == "hbm" and abs(h["frac"] - h["achieved"] / h["peak"]) < 1e-9 and abs(r["algorithmic_bytes_per_step"] - 4.4) < 1e-9
     v = r["valu"]
-    assert v["bound"] == "valu" and v["unit"] == "wave-instructions/s" and abs(v["frac"] - v["achieved"] / v["peak"]) < 1e-9
-    assert 0.4 < v["frac"] <= 1.0 and r["tighter_bound"] in ("valu", "hbm"), v
+    if v is not None:       # the kernel's VALU count is on record: instructions per launch / this run's launch time, and its staleness
+        assert v["bound"] == "valu" and v["unit"] == "wave-instructions/s" and abs(v["frac"] - v["achieved"] / v["peak"]) < 1e-9
+        assert 0.4 < v["frac"] <= 1.0 and r["tighter_bound"] in ("valu", "hbm") and isinstance(r["counters_stale"], bool), v
+        if not r["counters_stale"]:
+            assert r["bound"] == r["tighter_bound"]
+            # the recorded HBM bytes of THIS launch shape (20 steps, packed records)
+            assert r["traffic"] is not None and 0.9 < r["traffic"] / (r["algorithmic_bytes_per_step"] * (1 << 20) * 20) < 1.25, r["traffic"]
     assert len(r["kernel_ms_by_rank"]) == 1
+    lay = d["layouts"]
+    assert set(lay) == {"columns", "blocked", "packed"} and lay["packed"]["headline"] is True
+    assert lay["columns"]["kernel"] == "steps_quad_kernel<RockEnv<1>>" and lay["blocked"]["kernel"] == "steps_quad_kernel<RockEnv<1>, Blocked>"
+    for k in ("columns", "blocked"):
+        assert lay[k]["value"] > 1e8 and 0.3 < lay[k]["roofline"]["hbm_frac"] < 1.0 and lay[k]["kernel_ms"] < 3.6e-3, lay[k]
+    assert lay["packed"]["kernel_ms"] < min(lay["columns"]["kernel_ms"], lay["blocked"]["kernel_ms"])
+    cfg = d["configs"]
+    assert set(cfg) == {"tag", "battleship", "rollout_rock15"}
+    assert cfg["tag"]["kernel"].startswith("tag_steps_quad_kernel<true") and cfg["battleship"]["kernel"].startswith("battleship_steps_quad_kernel<BattleShipEnv<4>")
+    for k in cfg:
+        assert cfg[k]["value"] > 1e10 and cfg[k]["kernel_ms"] > 0 and "frac" in cfg[k]["roofline"], (k, cfg[k])
     c = d["cpu_baseline"]
-    for k in ("value", "unit", "cores", "kind", "sample", "by_threads"):
+    for k in ("value", "unit", "cores", "usable_cpus", "kind", "sample", "by_threads"):
         assert k in c, k
-    assert c["cores"] == max(c["by_threads"], key=lambda t: t["value"])["threads"] and c["value"] > 1e6
+    assert c["cores"] == max(c["by_threads"], key=lambda t: t["value"])["threads"] and c["value"] > 1e6 and c["usable_cpus"] >= 1
     assert d["value"] > 1e8          # the north star's single-GPU target, by a wide margin
 
 
@@ -247,10 +265,11 @@ def test_bench_self_launches_two_ranks_on_the_one_gpu():
     assert d["value"] > 1e8 and "cpu_baseline" not in d
     s = d["strong_scaling"]
     assert s["total_lanes"] == 1 << 20 and s["lanes_per_gpu"] == 1 << 19 and s["value"] > 1e8
-    # two 2^19-lane shards keep up with two 2^20-lane ones (the small-shard kernels of round 3).  Both ranks share this one
-    # GPU, so the two figures are how two processes' launches interleave on a device, not what a GPU per rank gives: 0.87-1.05
-    # over the runs of round 3 (the 2^20-lane launch gained more from the priority ladder than the 2^19-lane one)
-    assert s["value"] > 0.8 * d["value"], (s["value"], d["value"])
+    # Both ranks share this one GPU, so the two figures are how two processes' launches interleave on a device, not what a
+    # GPU per rank gives.  Round 3 (13 B per lane-step, store-bound at 2^20 lanes): 0.87-1.05.  Round 4 (packed records,
+    # issue-bound): a 2^19-lane shard runs 1.12 us per step against 1.54 for 2^20 lanes (profiles/r04*_small_shards*.txt), so two
+    # of them deliver ~0.7 of what two 2^20-lane shards do
+    assert s["value"] > 0.55 * d["value"], (s["value"], d["value"])
     assert len(d["roofline"]["kernel_ms_by_rank"]) == 2
 
 

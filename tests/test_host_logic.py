@@ -247,3 +247,27 @@ def test_library_override_by_environment_variable():
     env.pop("GYM_POMDP_AMD_LIB")
     out = subprocess.run([sys.executable, "-c", code], cwd=REPO, env=env, capture_output=True, text=True).stdout.strip()
     assert out == os.path.join(REPO, "gym_pomdp_amd", "_lib", "libpomdp_hip.so") == _native.LIB_PATH or os.environ.get("GYM_POMDP_AMD_LIB")
+
+
+def test_recorded_counters_belong_to_this_tree():
+    """bench.py's VALU roofline and `traffic` divide / quote counters RECORDED by tools/gpu_pmc_valu.sh (profiles/*_pmc_valu.json)
+    and an instruction mix compiled by tools/isa_mix.py (profiles/*_isa_mix.json).  Both files carry the sha256 of the kernel
+    sources they were taken from; a tree whose sources differ makes `roofline.counters_stale` true in the bench line — and
+    fails here, for the workloads the driver's line is built from (the headline kernel in both timed launch shapes)."""
+    import json
+    import sys
+    sys.path.insert(0, REPO)
+    import bench
+    sha = bench.csrc_sha()
+    assert len(sha) == 64 and sha == bench.csrc_sha()
+    pmc, mix = bench._latest("*_pmc_valu.json"), bench._latest("*_isa_mix.json")
+    assert pmc and mix
+    assert json.load(open(mix)).get("csrc_sha256") == sha, "re-run tools/isa_mix.py --json profiles/<tag>_isa_mix.json"
+    for wl in ("step20_rock_packed", "step64_rock_packed"):
+        assert not bench.counters_stale(pmc, wl), "kernel sources changed since %s [%s] was recorded: re-run tools/gpu_pmc_valu.sh <tag> headline" % (pmc, wl)
+        v = bench.valu_roofline(wl, "steps_quad_kernel<", 1 << 20, 0.04 if wl.startswith("step20") else 0.1)
+        assert v is not None and v["counters_stale"] is False and v["kernel"] == "steps_quad_kernel<RockEnv<1, false>, Packed>" and 0.3 < v["frac"] < 1.0, v
+    # a changed source file flips the flag (the hash covers every file under csrc/ and the C header)
+    assert bench.counters_stale(pmc, "no_such_workload")
+    t, _ = bench.recorded_traffic("rock", "packed", 20, "steps_quad_kernel<")
+    assert t is not None and 0.9 < t / (4.4 * (1 << 20) * 20) < 1.25, t

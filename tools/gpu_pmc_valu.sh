@@ -1,10 +1,15 @@
 #!/bin/bash
 # VALU-issue counters of the kernels whose bound is instruction issue ("report int-op rate"): the fused
 # rollout (configs[4]), the heuristic-policy loop, and the fused step launches in both timed shapes (64 and 20 steps per
-# launch), plus the HBM byte counters of the 20-step shape.  One rocprofv3 --pmc pass per counter group (never combined
-# with other trace domains), summaries into gpurun_out/<tag>/.
-# usage: tools/gpu_pmc_valu.sh <tag>     -> gpurun_out/<tag>/{pmc_valu.json, pmc_valu.txt}
+# launch) and every trajectory layout, plus the HBM byte counters of the headline's shapes.  One rocprofv3 --pmc pass per
+# counter group (never combined with other trace domains), summaries into gpurun_out/<tag>/.
+# usage: tools/gpu_pmc_valu.sh <tag> [sets]    -> gpurun_out/<tag>/{pmc_valu.json, pmc_valu.txt}
+#   sets (default "planners headline envs"): planners = rollouts + heuristic loops; headline = RockSample(7,8) in the three
+#   layouts x (64, 20) steps per launch + HBM byte passes; envs = the other envs' fused launches (packed and columns).
+#   Workloads that are not re-recorded are carried over from the newest profiles/*_pmc_valu.json, each with the source hash
+#   it was recorded under (bench.py: counters_stale).
 TAG=${1:-pmcv}
+SETS=${2:-"planners headline envs"}
 export TMPDIR=/tmp
 REPO=$PWD
 OUT=$REPO/gpurun_out/$TAG
@@ -20,20 +25,39 @@ run() {   # name, bench args...
   timeout 600 rocprofv3 --kernel-trace --pmc $SQ2 -d $W/$name/p2 -o p2 -- python $REPO/bench.py "$@" > $W/$name/p2.log 2>&1
   echo "$name: $*" >> $W/commands.txt
 }
-run rollout_rock15 --env rock15 --mode rollout --lanes-per-gpu 2097152 --steps 20 --warmup 10
-run rollout_rock --env rock --mode rollout --lanes-per-gpu 2097152 --steps 20 --warmup 10
-run rollout_tag --env tag --mode rollout --lanes-per-gpu 2097152 --steps 20 --warmup 10
-run heuristic_rock --env rock --mode heuristic --prewarm 0 --warmup 128 --steps 1024
-run heuristic_rock15 --env rock15 --mode heuristic --prewarm 0 --warmup 128 --steps 1024
-run heuristic_tag --env tag --mode heuristic --prewarm 0 --warmup 128 --steps 1024
-for e in rock rock15 tag tiger network battleship; do
-  run step64_$e --env $e --prewarm 0 --warmup 64 --steps 640 --seeds 0 --repeats 1 --no-cpu-baseline
+traffic() {   # name, bench args...: FETCH_SIZE and WRITE_SIZE in separate passes
+  local name=$1; shift
+  mkdir -p $W/$name/pmc_fetch $W/$name/pmc_write
+  timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $W/$name/pmc_fetch -o f -- python $REPO/bench.py "$@" > $W/$name/f.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $W/$name/pmc_write -o w -- python $REPO/bench.py "$@" > $W/$name/w.log 2>&1
+}
+sfx() { if [ "$1" = columns ]; then echo ""; else echo "_$1"; fi; }
+S64="--prewarm 0 --warmup 64 --steps 640 --seeds 0 --repeats 1 --no-cpu-baseline --no-extras"
+S20="--gpus 1 --steps 20 --warmup 5 --prewarm 0 --seeds 0 --no-cpu-baseline --no-extras"
+for set in $SETS; do
+  case $set in
+  planners)
+    run rollout_rock15 --env rock15 --mode rollout --lanes-per-gpu 2097152 --steps 20 --warmup 10
+    run rollout_rock --env rock --mode rollout --lanes-per-gpu 2097152 --steps 20 --warmup 10
+    run rollout_tag --env tag --mode rollout --lanes-per-gpu 2097152 --steps 20 --warmup 10
+    run heuristic_rock --env rock --mode heuristic --prewarm 0 --warmup 128 --steps 1024
+    run heuristic_rock15 --env rock15 --mode heuristic --prewarm 0 --warmup 128 --steps 1024
+    run heuristic_tag --env tag --mode heuristic --prewarm 0 --warmup 128 --steps 1024 ;;
+  headline)
+    for l in packed columns blocked; do
+      run step64_rock$(sfx $l) --env rock --layout $l $S64
+      run step20_rock$(sfx $l) --env rock --layout $l $S20
+      traffic step20_rock$(sfx $l) --env rock --layout $l $S20
+    done
+    traffic step64_rock_packed --env rock --layout packed $S64 ;;
+  envs)
+    for e in rock15 tag tiger network battleship battleship5; do
+      run step64_${e}_packed --env $e --layout packed $S64
+      run step20_${e}_packed --env $e --layout packed $S20
+    done
+    for e in tag network battleship; do run step64_$e --env $e --layout columns $S64; done ;;
+  esac
 done
-run step20_rock --env rock --gpus 1 --steps 20 --warmup 5 --prewarm 0 --seeds 0 --no-cpu-baseline
-# HBM bytes of the driver's 20-step launch: FETCH_SIZE and WRITE_SIZE in separate passes
-mkdir -p $W/step20_rock/pmc_fetch $W/step20_rock/pmc_write
-timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $W/step20_rock/pmc_fetch -o f -- python $REPO/bench.py --gpus 1 --steps 20 --warmup 5 --prewarm 0 --seeds 0 --no-cpu-baseline > $W/step20_rock/f.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $W/step20_rock/pmc_write -o w -- python $REPO/bench.py --gpus 1 --steps 20 --warmup 5 --prewarm 0 --seeds 0 --no-cpu-baseline > $W/step20_rock/w.log 2>&1
 cd $REPO
-python tools/pmc_valu_summary.py $W $OUT
+python tools/pmc_valu_summary.py $W $OUT "$(ls -t profiles/*_pmc_valu.json 2>/dev/null | head -1)"
 ls -la $OUT

@@ -2,7 +2,7 @@
 """Fused-launch time per step at the shard sizes a 2^20-lane batch leaves per GPU (2^17 .. 2^20, and below), for every
 library variant given: python tools/gpu_small_shards.py [libA.so libB.so ...]   (default: the product library).
 Variants come from tools/ab_build.sh (e.g. -DPOMDP_QUAD_MIN_LANES=4096: the quad-per-thread loops from 4096 lanes up).
-Prints us per step of collect_synthetic(64) by HIP events, and the kernel the launcher picked."""
+Prints us per step of collect_synthetic(64, layout=$SHARD_LAYOUT or "packed") by HIP events, and the kernel the launcher picked."""
 import os
 import subprocess
 import sys
@@ -32,7 +32,7 @@ def one(lib_path):
             lg = n.bit_length() - 1
             e = gpa.make(env_id, batch_size=n, seed=0, reuse_buffers=True, **kw)
             e.reset()
-            tr = e.collect_synthetic(64)
+            tr = e.collect_synthetic(64, layout=os.environ.get("SHARD_LAYOUT", "packed"))
             for _ in range(20):
                 e.collect_synthetic(64, out=tr)
             torch.cuda.synchronize()

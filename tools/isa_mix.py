@@ -23,11 +23,11 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(REPO, "gym_pomdp_amd", "csrc")
 UNITS = ["fused_rock.hip", "fused_tag.hip", "fused_battleship.hip", "fused_misc.hip", "planner.hip"]   # where the kernels of interest live
-DEFAULT = ["steps_quad_kernel<pomdp::RockEnv<1, false>", "steps_quad_kernel<pomdp::RockEnv<2, false>", "rollout_kernel<pomdp::RockEnv<2, false>",
+DEFAULT = ["steps_quad_kernel<pomdp::RockEnv<1, false>, ", "steps_quad_kernel<pomdp::RockEnv<2, false>, ", "rollout_kernel<pomdp::RockEnv<2, false>",
            "rollout_kernel<pomdp::RockEnv<1, false>", "rollout_kernel<pomdp::TagEnv", "heuristic_steps_kernel<pomdp::RockEnv<1, false>, false",
            "heuristic_steps_kernel<pomdp::RockEnv<2, false>, false", "heuristic_steps_kernel<pomdp::TagEnv, false",
-           "tag_steps_quad_kernel<true", "network_steps_quad_kernel<2", "steps_quad_generic_kernel<pomdp::TigerEnv",
-           "steps_kernel<pomdp::RockEnv<1, false>, 1, true, true", "battleship_steps_quad_kernel<4", "battleship_steps_quad_kernel<1"]
+           "tag_steps_quad_kernel<true, ", "network_steps_quad_kernel<2, ", "steps_quad_generic_kernel<pomdp::TigerEnv, ",
+           "steps_kernel<pomdp::RockEnv<1, false>, 1, true, true, ", "battleship_steps_quad_kernel<4, ", "battleship_steps_quad_kernel<1, "]
 
 # mnemonic -> the measured class that prices it (tools/valu_microbench.hip op names); anything else: DEFAULT_COST
 ALIAS = {
@@ -245,6 +245,9 @@ def main():
             if m["unpriced_at_4_cycles"]:
                 print("    unpriced (4 cycles assumed): %s" % m["unpriced_at_4_cycles"])
     if out_json:
+        sys.path.insert(0, REPO)
+        from bench import csrc_sha                      # the sources this mix was compiled from (bench.py: counters_stale)
+        res["csrc_sha256"] = csrc_sha()
         json.dump(res, open(out_json, "w"), indent=1)
 
 

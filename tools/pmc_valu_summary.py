@@ -58,14 +58,18 @@ def short(k):
 
 def main():
     root, out_dir = sys.argv[1], sys.argv[2]
+    merge_from = sys.argv[3] if len(sys.argv) > 3 else None      # an earlier pmc_valu.json: its other workloads are carried over
     cmds = {}
     cf = os.path.join(root, "commands.txt")
     if os.path.exists(cf):
         for line in open(cf):
             name, _, cmd = line.partition(": ")
             cmds[name] = "python bench.py " + cmd.strip()
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import csrc_sha
     res = {"source": "tools/gpu_pmc_valu.sh: rocprofv3 --kernel-trace --pmc <one counter group per pass> -- python bench.py ...; "
                      "averages over the dispatches of each kernel (MI355X)",
+           "csrc_sha256": csrc_sha(),      # the kernel sources these counters were recorded from (bench.py: counters_stale)
            "issue_peak_wave_insts_per_s": ISSUE_PEAK,
            "issue_peak_formula": "256 CUs x 4 SIMDs x 2.4e9 Hz / 4 cycles per wave64 VALU instruction",
            "workloads": {}}
@@ -143,7 +147,14 @@ def main():
                                                                     if k in j.get("config", {})}}
                     except Exception:  # noqa: BLE001
                         pass
+        entry["csrc_sha256"] = res["csrc_sha256"]
         res["workloads"][name] = entry
+    if merge_from and os.path.exists(merge_from):
+        old = json.load(open(merge_from))
+        for name, entry in old.get("workloads", {}).items():
+            if name not in res["workloads"]:
+                entry.setdefault("csrc_sha256", old.get("csrc_sha256"))
+                res["workloads"][name] = entry
     os.makedirs(out_dir, exist_ok=True)
     json.dump(res, open(os.path.join(out_dir, "pmc_valu.json"), "w"), indent=1)
     with open(os.path.join(out_dir, "pmc_valu.txt"), "w") as fo:
