@@ -25,7 +25,10 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
                                                       int64_t rec, const typename Env::Params p)
 {
     __shared__ typename Env::Shared sh;
-    __shared__ typename step_tab_of<Env, TAB>::type tab;   // TAB: the lane step reads a (position, action) table built below
+    // TAB: the lane step reads a (position, action) table built below; REC: ... the table of RockEnv::step_rec, whose lane step
+    // yields the lane's packed record and its new state (fresh episode included) in one go
+    constexpr bool REC = TAB && LPT == 1 && fast_rec_of<Env>::value;
+    __shared__ typename step_tab_of<Env, TAB, REC>::type tab;
     static_assert(!TAB || SIMPLE, "the table-driven step serves the SIMPLE instantiation");
     const bool auto_reset = SIMPLE || (flags & POMDP_AUTO_RESET);
     const uint32_t wg0 = blockIdx.x * (uint32_t)(BLOCK * LPT);
@@ -82,7 +85,8 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
     }
     __syncthreads();
     if constexpr (TAB) {                                 // BLOCK threads = the 256 position bytes
-        Env::build_tab(tab, sh, p, (int)threadIdx.x);
+        if constexpr (REC) Env::build_rec_tab(tab, sh, p, (int)threadIdx.x);
+        else Env::build_tab(tab, sh, p, (int)threadIdx.x);
         __syncthreads();
     }
     wait_loads();
@@ -95,6 +99,7 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
         akey.t_lo = (uint32_t)(ta0 + (uint64_t)s); akey.t_hi = (uint32_t)((ta0 + (uint64_t)s) >> 32);
         if constexpr (Fin::HAS_PREPASS) { if (s > 0) Fin::prepass(key, glane, akey); }
         int o[LPT], d[LPT];
+        uint32_t recv[LPT];                              // REC: the lanes' packed records
         typename Env::Reward r[LPT];
         typename Fin::Aux aux[LPT];
         bool live[LPT], valid[LPT], fresh[LPT];
@@ -118,7 +123,18 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
                 }
                 const int sj = s & 3;                                            // wave-uniform selects
                 const uint32_t H = sj == 0 ? sq.x : sj == 1 ? sq.y : sj == 2 ? sq.z : sq.w;
-                if constexpr (TAB) Env::step_with_H_tab(sh, tab, st[j], a_cur[j], key, glane[j], H, o[j], r[j], d[j]);
+                if constexpr (REC) {
+                    // the step and, where it ends the episode, the fresh one (which starts from the same word H: auto-reset contract)
+                    uint32_t sj = (uint32_t)st[j].s;
+                    const uint32_t lane_ = glane[j];
+                    Env::step_rec(sh, tab, sj, (uint32_t)a_cur[j], H, (uint32_t)Env::fresh_state(p, H, key, lane_), recv[j],
+                                  [&]() { return Env::elem(Env::quad_block(key, lane_, 1u), lane_ & 3u); });
+                    st[j].s = sj;
+                    o[j] = (int)__builtin_amdgcn_ubfe(recv[j], 8u, 8u);
+                    r[j] = (typename Env::Reward)__builtin_amdgcn_sbfe(recv[j], 16u, 8u);
+                    d[j] = (int)(recv[j] >> 24);
+                }
+                else if constexpr (TAB) Env::step_with_H_tab(sh, tab, st[j], a_cur[j], key, glane[j], H, o[j], r[j], d[j]);
                 else Env::step_with_H(sh, p, st[j], valid[j] ? a_cur[j] : 0, key, glane[j], H, o[j], r[j], d[j]);
             }
             else if constexpr (TAB) Fin::lane_step_tab(tab, st[j], a_cur[j], o[j], r[j], d[j], aux[j]);
@@ -136,7 +152,9 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
                                                    (uint32_t)POMDP_STREAM_ACTION << 24, akey0.k0, akey0.k1), e);
             }
             const int sj = s & 3;                                            // wave-uniform selects
-            if constexpr (Env::QUAD_SENSOR) {                                // RockSample: this lane's RESET word of step s
+            if constexpr (REC) {
+                // step_rec already moved the fresh episode in
+            } else if constexpr (Env::QUAD_SENSOR) {                         // RockSample: this lane's RESET word of step s
                 const uint32_t rword = sj == 0 ? rq.x : sj == 1 ? rq.y : sj == 2 ? rq.z : rq.w;
                 st[0].s = fresh[0] ? Env::fresh_state(p, rword, key, glane[0]) : st[0].s;
             } else {
@@ -155,7 +173,8 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
             if (in_range[j]) {
                 uint32_t rcode = 0;
                 if constexpr (L::ID == POMDP_LAYOUT_PACKED) rcode = Env::reward_code(r[j]);
-                out.put(rel[j], a_cur[j], o[j], r[j], rcode, d[j]);
+                if constexpr (REC && L::ID == POMDP_LAYOUT_PACKED) out.put_record(rel[j], recv[j]);
+                else out.put(rel[j], a_cur[j], o[j], r[j], rcode, d[j]);
                 if (!valid[j] && !was_done[j] && err) atomicAdd(err, 1u);
             }
             a_cur[j] = a_next[j];

@@ -379,8 +379,12 @@ template <class Fin, class = void> struct quad_policy_of : std::false_type {};
 template <class Fin> struct quad_policy_of<Fin, std::enable_if_t<Fin::QUAD_POLICY>> : std::true_type {};
 
 struct NoTab {};
-template <class Env, bool ON> struct step_tab_of { using type = NoTab; };
-template <class Env> struct step_tab_of<Env, true> { using type = typename Env::StepTab; };
+// envs whose table-driven lane step yields the lane's packed record directly (RockEnv<1, .>::step_rec)
+template <class Env, class = void> struct fast_rec_of : std::false_type {};
+template <class Env> struct fast_rec_of<Env, std::enable_if_t<Env::FAST_REC>> : std::true_type {};
+template <class Env, bool ON, bool REC = false> struct step_tab_of { using type = NoTab; };
+template <class Env> struct step_tab_of<Env, true, false> { using type = typename Env::StepTab; };
+template <class Env> struct step_tab_of<Env, true, true> { using type = typename Env::RecTab; };
 
 static inline RngKey make_key(uint64_t seed, uint64_t t)
 {

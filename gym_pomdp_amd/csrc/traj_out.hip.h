@@ -210,6 +210,7 @@ template <class RT> struct LaneOut<Packed, RT> {
     {
         st_stream(w + rel, pack_record((uint32_t)a_cur & 0xFFu, (uint32_t)o & 0xFFu, rcode, (uint32_t)(d != 0)));
     }
+    __device__ __forceinline__ void put_record(uint32_t rel, uint32_t record) const { st_stream(w + rel, record); }
     __device__ __forceinline__ void next_row() { w += rec; }
 };
 
