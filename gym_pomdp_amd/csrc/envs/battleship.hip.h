@@ -258,6 +258,47 @@ struct BattleShipEnv {
         b.want_dir = accept;                                                   // a direction word is always consumed: back to positions
     }
 
+    // Two consecutive words of the board's stream at once — exactly feed(w0) then feed(w1), with ONE placement test: a lane
+    // tests a placement at most once per two words whatever its state (waiting for a direction: w0 completes the pending
+    // position, then w1 is a position word; waiting for a position: w0 accepted -> w1 is its direction word and completes it,
+    // w0 rejected -> w1 is the next position word), and the test — coordinates, bounds, two LDS pattern rows, the mask shift
+    // and the `blocked` recomputation behind it — is most of what a word costs (round 4: the builder pool is 60 % of the 5x5
+    // board's launch; 4.2 -> 3.x us per step).
+    static __device__ __forceinline__ void feed2(Builder &b, const SeqTables &t, const BuildConsts &c, uint32_t w0, uint32_t w1)
+    {
+        const int X = c.X, len = b.len;
+        const bool live = len >= 2, D = b.want_dir;
+        const uint32_t v0 = w0 & c.rmask, v1 = w1 & c.rmask;
+        const bool acc0 = v0 <= (uint32_t)(c.cells - 1), acc1 = v1 <= (uint32_t)(c.cells - 1);
+        const bool test_now = live && (D || acc0);                             // a (position, direction) pair is complete
+        const int a0 = D ? b.a0 : (int)v0;
+        const uint32_t dir2 = ((D ? w0 : w1) & 3u) << 1;                       // Compass N E S W: (dx, dy) = (0,1) (1,0) (0,-1) (-1,0)
+        const int dx = __builtin_amdgcn_sbfe(0xC4, dir2, 2u), dy = __builtin_amdgcn_sbfe(0x31, dir2, 2u);
+        const int py = (int)(((uint32_t)a0 * c.inv_x) >> 16), px = a0 - py * X;
+        const int ex = px + (len + 1) * dx, ey = py + (len + 1) * dy, stride = dy * X + dx;
+        const bool inside = (unsigned)ex < (unsigned)X && (unsigned)ey < (unsigned)c.Y;
+        const int lo = stride > 0 ? a0 : a0 + len * stride;
+        const uint32_t *v1p = t.vp[(len + 1) & 15], *v0p = t.vp[len & 15];       // len <= max_len <= 10 (bs_mask_words)
+        const uint32_t p1[4] = {v1p[0], v1p[1], v1p[2], v1p[3]}, p0[4] = {v0p[0], v0p[1], v0p[2], v0p[3]};
+        const M vpat1 = mask_of(p1), vpat0 = mask_of(p0);
+        const M test = (M)((dx != 0 ? (M)((1ull << (len + 1)) - 1ull) : vpat1) << (lo & (MBITS - 1)));
+        const bool place = test_now && inside && (test & b.blocked) == 0;
+        int len_after = len;
+        if (__any(place)) {                                                    // wave-uniform: skip the marking when nobody places
+            if (place) {
+                const int low = stride > 0 ? a0 : a0 + (len - 1) * stride;
+                b.occ |= (M)((dx != 0 ? (M)((1ull << len) - 1ull) : vpat0) << (low & (MBITS - 1)));
+                len_after = len - 1;
+                b.len = len_after;
+                b.blocked = blocked_of(b.occ, c.col0, c.colL, X);
+            }
+        }
+        // w1 as a position word: after a completed direction (D), or after a rejected w0
+        const bool accept1 = len_after >= 2 && (D || !acc0) && acc1;
+        b.a0 = accept1 ? (int)v1 : a0;
+        b.want_dir = accept1;
+    }
+
     static __device__ __forceinline__ uint64_t direction_words(uint64_t a)
     {
         const uint64_t even = 0x5555555555555555ull;

@@ -712,10 +712,8 @@ __global__ __launch_bounds__(BLOCK) void battleship_steps_quad_kernel(uint32_t *
         while (__any(my >= 0)) {
             const uint4 b4 = philox4x32_10(wave0 + (uint32_t)bidx, bt_lo, bt_hi, ((uint32_t)POMDP_STREAM_NEXT << 24) | (blk & 0xFFFFFFu), key0.k0, key0.k1);
             ++blk;
-            Env::feed(bld, seq, bc, b4.x);
-            Env::feed(bld, seq, bc, b4.y);
-            Env::feed(bld, seq, bc, b4.z);
-            Env::feed(bld, seq, bc, b4.w);
+            Env::feed2(bld, seq, bc, b4.x, b4.y);                             // == feed(x), feed(y): one placement test per pair
+            Env::feed2(bld, seq, bc, b4.z, b4.w);
             const bool fin = my >= 0 && !bld.busy();
             const uint64_t fm = __ballot(fin);
             if (fm != 0ull) {                                                  // wave-uniform
