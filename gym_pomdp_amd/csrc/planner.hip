@@ -337,6 +337,11 @@ __global__ __launch_bounds__(BLOCK) void heuristic_steps_kernel(const typename E
     stage_policy_tables<Env>(sh, p);
     __syncthreads();
     bool ever_fresh = false;
+    // what the launch's LAST step returns: every step overwrites the same n-element outputs, so only the last one's values
+    // are ever visible — they are written once, after the loop (round 4).  Inside the loop they were four stores per step
+    // that every CHECK's read-modify-write of the side statistics then waited behind (loads and stores share one counter).
+    int out_a = -1, out_o = 0, out_d = 0;
+    typename Env::Reward out_r = 0;
     const int hcap = h.max_size >= 0 ? h.max_size + 1 : 0x7FFFFFFF;            // len(history) stops there (rock.py:541-544)
     const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo;
     const uint32_t e = lane & 3u;
@@ -419,15 +424,7 @@ __global__ __launch_bounds__(BLOCK) void heuristic_steps_kernel(const typename E
                     pob = o;
                 }
             }
-            // the step's outputs leave LAST: the per-rock sums and side statistics above are read-modify-writes, and a load
-            // waits for every store issued before it (one counter for both on gfx9) — behind these four it waited for their
-            // acknowledgements every step
-            if (in_range) {
-                st_stream(action + i, (int32_t)(live ? a : -1));
-                st_stream(ob + i, (int32_t)o);
-                st_stream(reward + i, r);
-                st_stream(done + i, (uint8_t)d);
-            }
+            out_a = live ? a : -1; out_o = o; out_r = r; out_d = d;
             if (live) was_done = auto_reset ? false : (d != 0);
         };
         one_step(std::integral_constant<int, 0>{});
@@ -436,6 +433,10 @@ __global__ __launch_bounds__(BLOCK) void heuristic_steps_kernel(const typename E
         one_step(std::integral_constant<int, 3>{});
     }
     if (!in_range) return;
+    st_stream(action + i, (int32_t)out_a);
+    st_stream(ob + i, (int32_t)out_o);
+    st_stream(reward + i, out_r);
+    st_stream(done + i, (uint8_t)out_d);
     Env::store(st, state, n, i, ever_fresh);                                   // the loop's carry, written once
     st_stream(h.size + i, (int32_t)hsize); st_stream(h.last_action + i, (int32_t)la); st_stream(h.last_ob + i, (int32_t)lo);
     st_stream(prev_ob + i, (int32_t)pob);
