@@ -507,14 +507,15 @@ struct RockEnv {
     //                a rock with an id < K lies under a SAMPLE;
     //   a <  4: bits 0-7 = position byte XOR new position byte (0 if the move leaves); fallback 6 inside, 3 leaving east,
     //           1 leaving elsewhere (StochasticRock: 6, rock.py:432, 503);
-    //   a == 4: bits 0-4 = bit offset of the cell's rock code in the state; fallback 1 (StochasticRock: 6);
+    //   a == 4: bits 0-5 = bit offset of the cell's rock code in the state (bit 5: it lies in the upper word); fallback 1
+    //           (StochasticRock: 6);
     //   a >= 5: bits 0-27 = the sensor threshold's high bits (thr >> 26 <= 2^27: a sensor that is always right at distance 0
     //           has thr = 2^53) at this distance; fallback 6 — the kernel compares against (H >> 5) | 6 << 28 (one
     //           v_alignbit_b32), so the threshold test and the tie test read the entry as it is.
     // Outcome codes: 0 = bad rock sampled (-10), 1 = penalty (-100, done), 2 = good rock sampled (+10), 3 = east exit (+10,
     // done), 6 = nothing (0) — a sampled rock's own code IS its outcome code, done is bit 0, and the reward byte is one
     // v_perm_b32 lookup in an 8-byte constant.
-    static constexpr bool FAST_REC = W == 1;
+    static constexpr bool FAST_REC = true;
     static constexpr uint32_t REC_LUT_LO = 0x0A0A9CF6u, REC_LUT_HI = 0x00000000u;   // reward byte by outcome code 0..7
     struct RecTab { uint32_t e[TAB_ACTIONS][256]; };
     static __device__ __forceinline__ void build_rec_tab(RecTab &tab, const Shared &sh, const Params &p, int pos)
@@ -538,30 +539,37 @@ struct RockEnv {
         }
     }
     // rock.py:123-194 for one lane: s -> s' (the fresh episode `fresh` if the step ends this one), rec = the step's record.
-    // H: the lane's sensor high word; `lo` yields its low word (a tie, 2^-27 per CHECK).
+    // H: the lane's sensor high word; `lo` yields its low word (a tie, 2^-27 per CHECK).  Two state words (K > 12): the rock
+    // codes run on into the upper word (rock j at bits 8 + 2 j), a code never straddles the words, and the word a SAMPLE or
+    // a CHECK reads is a select on bit 5 of its bit offset.
     template <class LowWord>
-    static __device__ __forceinline__ void step_rec(const Shared &sh, const RecTab &tab, uint32_t &s, uint32_t a, uint32_t H,
-                                                    uint32_t fresh, uint32_t &rec, LowWord lo)
+    static __device__ __forceinline__ void step_rec(const Shared &sh, const RecTab &tab, S &s, uint32_t a, uint32_t H, S fresh,
+                                                    uint32_t &rec, LowWord lo)
     {
-        const uint32_t e = tab.e[a][s & 0xFFu];
+        const uint32_t s_lo = (uint32_t)s, s_hi = W == 2 ? (uint32_t)((uint64_t)s >> 32) : 0u;
+        const uint32_t e = tab.e[a][s_lo & 0xFFu];
         // SAMPLE (rock.py:160-169): the cell's rock code, read at the entry's offset (entries of the other classes: the
         // sign bit is clear, so whatever this reads is never used)
-        const uint32_t code = __builtin_amdgcn_ubfe(s, e, 2u);
+        const bool up_s = W == 2 && (e & 32u) != 0u;                            // the code lies in the upper word
+        const uint32_t code = __builtin_amdgcn_ubfe(up_s ? s_hi : s_lo, e, 2u);
         const bool ok = ((int32_t)e < 0) & (code != 1u);                        // an uncollected rock with an id < K is underfoot
         const uint32_t collect = (code ^ 1u) << (e & 31u);                      // its code -> 1
         // moves (rock.py:134-158): the position delta, for that class only
-        const uint32_t delta = ok ? collect : ((a < 4u ? e : 0u) & 0xFFu);
+        const uint32_t move = (a < 4u ? e : 0u) & 0xFFu;
+        const uint32_t d_lo = (ok & !up_s) ? collect : move, d_hi = (ok & up_s) ? collect : 0u;
         const uint32_t oc = ok ? code : __builtin_amdgcn_ubfe(e, 28u, 3u);      // outcome code
         const uint32_t rbyte = __builtin_amdgcn_perm(REC_LUT_HI, REC_LUT_LO, (oc << 16) | 0x0C000C0Cu);   // reward byte << 16
         const uint32_t done = oc & 1u;
         // CHECK rock a - 5 (rock.py:171-175, 401-407): its code sits at bits 2a-2, 2a-1 of the state; good = the upper one
-        const bool good = __builtin_amdgcn_ubfe(s, 2u * a - 1u, 1u) != 0u;
+        const uint32_t gi = 2u * a - 1u;
+        const bool good = __builtin_amdgcn_ubfe((W == 2 && (gi & 32u)) ? s_hi : s_lo, gi, 1u) != 0u;
         const uint32_t kh = __builtin_amdgcn_alignbit(12u, H, 5u);              // (H >> 5) | 6 << 28: compares with the entry itself
         bool correct = kh < e;
-        if (a > 4u && kh == e) correct = (lo() >> 6) <= thr_lo_of(sh, State{(S)s}, (int)a - 5);   // probability 2^-27
+        if (a > 4u && kh == e) correct = (lo() >> 6) <= thr_lo_of(sh, State{s}, (int)a - 5);   // probability 2^-27
         const uint32_t ob = a > 4u ? ((good == correct) ? 2u << 8 : 1u << 8) : 0u;
         rec = rbyte | (done << 24) | ob | a;
-        s = done ? fresh : (s ^ delta);
+        if constexpr (W == 2) s = done ? fresh : (S)(((uint64_t)(s_hi ^ d_hi) << 32) | (s_lo ^ d_lo));
+        else s = done ? fresh : (S)(s_lo ^ d_lo);
     }
 
     // observation of a CHECK from the sensor's high word (rock.py:404-407); `lo` yields the low word on a tie

@@ -125,9 +125,9 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
                 const uint32_t H = sj == 0 ? sq.x : sj == 1 ? sq.y : sj == 2 ? sq.z : sq.w;
                 if constexpr (REC) {
                     // the step and, where it ends the episode, the fresh one (which starts from the same word H: auto-reset contract)
-                    uint32_t sj = (uint32_t)st[j].s;
+                    typename Env::S sj = st[j].s;
                     const uint32_t lane_ = glane[j];
-                    Env::step_rec(sh, tab, sj, (uint32_t)a_cur[j], H, (uint32_t)Env::fresh_state(p, H, key, lane_), recv[j],
+                    Env::step_rec(sh, tab, sj, (uint32_t)a_cur[j], H, Env::fresh_state(p, H, key, lane_), recv[j],
                                   [&]() { return Env::elem(Env::quad_block(key, lane_, 1u), lane_ & 3u); });
                     st[j].s = sj;
                     o[j] = (int)__builtin_amdgcn_ubfe(recv[j], 8u, 8u);
@@ -209,8 +209,8 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
     constexpr int W = Env::WORDS;
     using S = typename Env::S;
     __shared__ typename Env::Shared sh;
-    // one state word: the lane step yields the lane's packed record straight from RecTab (RockEnv::step_rec, ~31 instead of ~49
-    // vector instructions per lane-step); two state words: the (position, action) table of step_tab
+    // the lane step yields the lane's packed record straight from RecTab (RockEnv::step_rec, ~31 instead of ~49 vector
+    // instructions per lane-step with one state word); the step_tab form is kept for envs without one
     constexpr bool FAST = Env::FAST_REC;
     __shared__ typename std::conditional<FAST, typename Env::RecTab, typename Env::StepTab>::type tab;
     TL(0);
@@ -275,14 +275,14 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const uint32_t lane = glane0 + (uint32_t)j;
-                uint32_t sj = (uint32_t)st[j].s;
-                Env::step_rec(sh, tab, sj, a_taken[j], H[j], start | (codes[j] << 8), rec[j],
+                S sj = st[j].s;
+                Env::step_rec(sh, tab, sj, a_taken[j], H[j], (S)((uint64_t)start | ((uint64_t)codes[j] << 8)), rec[j],
                               [&]() { return Env::elem(Env::quad_block(key, lane, SENSOR_BLOCK + 1u), (uint32_t)j); });
                 if constexpr (Env::STOCHASTIC) {                                // the gate said no (rock.py:443): nothing happens
-                    sj = acts[j] ? sj : (uint32_t)st[j].s;
+                    sj = acts[j] ? sj : st[j].s;
                     rec[j] = acts[j] ? rec[j] : a_taken[j];
                 }
-                st[j].s = (S)sj;
+                st[j].s = sj;
                 a_next[j] = __umulhi(P[j], n_act);
                 a_cur[j] = (int)a_next[j];
             }

@@ -469,11 +469,13 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(const typename Env::Para
 #pragma clang fp contract(off) // the discounted return must not be fused into FMAs (hipcc defaults to contract=fast)
     __shared__ typename Env::Shared sh;
     constexpr bool TAB = ROLLOUT_TAB<Env>::value;            // RockSample: the (position, action) table of the fused loops
-    __shared__ typename step_tab_of<Env, TAB>::type tab;
+    constexpr bool REC = TAB && fast_rec_of<Env>::value;     // ... in the form whose lane step yields the packed record (step_rec)
+    __shared__ typename step_tab_of<Env, TAB, REC>::type tab;
     Env::stage(sh, p, (int)threadIdx.x);
     __syncthreads();
     if constexpr (TAB) {
-        Env::build_tab(tab, sh, p, (int)threadIdx.x);
+        if constexpr (REC) Env::build_rec_tab(tab, sh, p, (int)threadIdx.x);
+        else Env::build_tab(tab, sh, p, (int)threadIdx.x);
         __syncthreads();
     }
     const int64_t n = n_roots * sims_per_root;
@@ -515,7 +517,16 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(const typename Env::Para
             int o2, d2;
             double r;
             if constexpr (Env::QUAD_SENSOR) {      // every lane runs it (the broadcasts need the whole quad); inactive lanes discard
-                if constexpr (TAB) Env::step_with_H_tab(sh, tab, nx, a, key, lane, comp<J>(sq), o2, r, d2);
+                if constexpr (REC) {
+                    // a simulation stops at its terminal step, so the state after one is never read: no fresh episode to pass
+                    uint32_t rec;
+                    Env::step_rec(sh, tab, nx.s, (uint32_t)a, comp<J>(sq), nx.s, rec,
+                                  [&]() { return Env::elem(Env::quad_block(key, lane, 1u), lane & 3u); });
+                    o2 = (int)__builtin_amdgcn_ubfe(rec, 8u, 8u);
+                    r = (double)(int32_t)__builtin_amdgcn_sbfe(rec, 16u, 8u);
+                    d2 = (int)(rec >> 24);
+                }
+                else if constexpr (TAB) Env::step_with_H_tab(sh, tab, nx, a, key, lane, comp<J>(sq), o2, r, d2);
                 else Env::step_with_H(sh, p, nx, a, key, lane, comp<J>(sq), o2, r, d2);
             } else {
                 Env::step(sh, p, nx, a, key, lane, o2, r, d2);
