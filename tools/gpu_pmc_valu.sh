@@ -5,7 +5,8 @@
 # counter group (never combined with other trace domains), summaries into gpurun_out/<tag>/.
 # usage: tools/gpu_pmc_valu.sh <tag> [sets]    -> gpurun_out/<tag>/{pmc_valu.json, pmc_valu.txt}
 #   sets (default "planners headline envs"): planners = rollouts + heuristic loops; headline = RockSample(7,8) in the three
-#   layouts x (64, 20) steps per launch + HBM byte passes; envs = the other envs' fused launches (packed and columns).
+#   layouts x (64, 20) steps per launch + HBM byte passes; envs = the other envs' fused launches (packed and columns);
+#   shards = RockSample(7,8) at 2^17 / 2^18 lanes.
 #   Workloads that are not re-recorded are carried over from the newest profiles/*_pmc_valu.json, each with the source hash
 #   it was recorded under (bench.py: counters_stale).
 TAG=${1:-pmcv}
@@ -56,6 +57,9 @@ for set in $SETS; do
       run step20_${e}_packed --env $e --layout packed $S20
     done
     for e in tag network battleship; do run step64_$e --env $e --layout columns $S64; done ;;
+  shards)   # the shards a 2^20-lane batch leaves per GPU at 8 / 4 GPUs (strong scaling: DESIGN.md §7)
+    run step64_rock_packed_2e17 --env rock --layout packed --lanes-per-gpu 131072 $S64
+    run step64_rock_packed_2e18 --env rock --layout packed --lanes-per-gpu 262144 $S64 ;;
   esac
 done
 cd $REPO
