@@ -98,7 +98,9 @@ def valu_roofline(workload, kernel_prefix, lanes, launch_ms):
     w = json.load(open(pmc))["workloads"].get(workload)
     if not w or (w.get("bench_line_under_pmc") or {}).get("config", {}).get("lanes_per_gpu") not in (None, lanes):
         return None
-    name = next((k for k in w["kernels"] if k.startswith(kernel_prefix)), None)
+    # the workload's dominant kernel of that family (a run's warm-up launches may be another instantiation of it)
+    cands = [k for k in w["kernels"] if k.startswith(kernel_prefix)]
+    name = max(cands, key=lambda k: w["kernels"][k].get("dispatches", 0)) if cands else None
     m = json.load(open(mix))["kernels"].get(name) if name else None
     if not m:
         return None
@@ -447,7 +449,7 @@ def recorded_traffic(env_key, layout, spl, kernel_prefix):
     pmc = _latest("*_pmc_valu.json")
     if not pmc:
         return None, None
-    key = valu_workload_key(env_key, spl, layout)
+    key = valu_workload_key(env_key, spl, layout)            # (recorded at 2^20 lanes only)
     w = json.load(open(pmc))["workloads"].get(key, {})
     for k, v in (w.get("traffic") or {}).items():
         if k.startswith(kernel_prefix):
@@ -482,8 +484,11 @@ def fused_alg_bytes(bytes_per_step, spl, layout):
     return out_b + once / float(spl)
 
 
-def valu_workload_key(env_key, spl, layout):
-    return "step%d_%s%s" % (spl, env_key, "" if layout == "columns" else "_" + layout)
+def valu_workload_key(env_key, spl, layout, n=1 << 20):
+    """name of the recorded PMC workload (tools/gpu_pmc_valu.sh) of a fused step launch: steps per launch, env, layout and —
+    when it is not the metric's 2^20 — the shard size"""
+    size = "" if n == 1 << 20 else ("_2e%d" % (n.bit_length() - 1) if n & (n - 1) == 0 else "_%d" % n)
+    return "step%d_%s%s%s" % (spl, env_key, "" if layout == "columns" else "_" + layout, size)
 
 
 def step_rooflines(env_key, bytes_per_step, layout, n, kern_ms, spl, fused, fused_kernel):
@@ -494,7 +499,7 @@ def step_rooflines(env_key, bytes_per_step, layout, n, kern_ms, spl, fused, fuse
     hbm = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS}
     valu = None
     if fused and fused_kernel:
-        valu = valu_roofline(valu_workload_key(env_key, spl, layout), fused_kernel.split("<")[0] + "<", n, kern_ms * spl)
+        valu = valu_roofline(valu_workload_key(env_key, spl, layout, n), fused_kernel.split("<")[0] + "<", n, kern_ms * spl)
     primary = hbm
     if valu is not None and not valu["counters_stale"] and valu["frac"] > hbm["frac"]:
         primary = {k: valu[k] for k in ("bound", "achieved", "peak", "unit", "frac")}

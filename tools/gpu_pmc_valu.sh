@@ -56,7 +56,10 @@ for set in $SETS; do
       run step64_${e}_packed --env $e --layout packed $S64
       run step20_${e}_packed --env $e --layout packed $S20
     done
-    for e in tag network battleship; do run step64_$e --env $e --layout columns $S64; done ;;
+    for e in tag network battleship; do run step64_$e --env $e --layout columns $S64; done
+    # BASELINE.json configs[3] per GPU: BattleShip 10x10 at 2^19 lanes (bench.py: configs.battleship)
+    run step64_battleship_packed_2e19 --env battleship --layout packed --lanes-per-gpu 524288 $S64
+    run step20_battleship_packed_2e19 --env battleship --layout packed --lanes-per-gpu 524288 $S20 ;;
   shards)   # the shards a 2^20-lane batch leaves per GPU at 8 / 4 GPUs (strong scaling: DESIGN.md §7)
     run step64_rock_packed_2e17 --env rock --layout packed --lanes-per-gpu 131072 $S64
     run step64_rock_packed_2e18 --env rock --layout packed --lanes-per-gpu 262144 $S64 ;;
