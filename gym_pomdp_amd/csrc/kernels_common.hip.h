@@ -412,13 +412,15 @@ extern thread_local uint32_t tl_flag_value;
 // per SIMD instead of two or two and a half; (15,15) at 2^19 lanes 1.25 against 1.46 us per step, (7,8) at 5 * 2^17 lanes
 // 1.50 against 1.65) and from 3 * 2^18 lanes — three workgroups per CU — with the quad loop; Tiger at 2^18 lanes with one
 // lane per thread (0.66 against 0.72).  StochasticRock has no pooled loop and keeps 2^19.
+// Round 4: BattleShip's quad loop from 2^16 lanes (feed2 halved what its board pool costs, the one-lane loop builds boards on
+// the spot with the wave-cooperative builder: 2^16 / 2^17 lanes 0.995 / 1.036 against 1.074 / 1.209 us per step).
 // POMDP_QUAD_MIN_LANES overrides all of them at build time for same-box A/B runs (tools/ab_build.sh lib ... -D...).
 #ifdef POMDP_QUAD_MIN_LANES
 constexpr int64_t QUAD_MIN_ROCK = POMDP_QUAD_MIN_LANES, QUAD_MIN_STOCHROCK = POMDP_QUAD_MIN_LANES, QUAD_MIN_TAG = POMDP_QUAD_MIN_LANES,
                   QUAD_MIN_GENERIC = POMDP_QUAD_MIN_LANES, QUAD_MIN_NETWORK = POMDP_QUAD_MIN_LANES, QUAD_MIN_BATTLESHIP = POMDP_QUAD_MIN_LANES;
 #else
 constexpr int64_t QUAD_MIN_ROCK = 3 << 18, QUAD_MIN_STOCHROCK = 1 << 19, QUAD_MIN_TAG = 1 << 19, QUAD_MIN_GENERIC = 1 << 19,
-                  QUAD_MIN_NETWORK = 1 << 19, QUAD_MIN_BATTLESHIP = 1 << 18;
+                  QUAD_MIN_NETWORK = 1 << 19, QUAD_MIN_BATTLESHIP = 1 << 16;
 #endif
 
 // which kernel the calling thread's most recent fused launch picked (pomdp_last_fused_kernel: bench.py names the kernel

@@ -596,7 +596,7 @@ static bool belief_ok(const pomdp_rock_belief *b)
 static bool history_ok(const pomdp_history *h, bool rock)
 {
     if (!(h && h->size && h->last_action && h->last_ob && (!rock || (h->total_sample && h->total_move && h->move_ok)))) return false;
-    if (h->max_size < -1 || h->max_size > 62) return false;                    // window of at most 63 transitions
+    if (h->max_size < -1 || h->max_size > 0x7FFFFFFE) return false;           // any window the caller has a (max_size + 1) x n byte ring for
     return h->max_size < 0 || !rock || (h->ring && h->head);                   // a bounded RockSample history keeps its window
 }
 static const pomdp_rock_belief NO_BELIEF = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};

@@ -29,8 +29,8 @@ class History(object):
     def __init__(self, env, max_size=None, observation=None):
         """`observation`: what the agent currently sees (int32[N]); only env.heuristic_steps() needs it, as the
         `observation` field of the next transition.  Defaults to what env.reset() just returned."""
-        if max_size is not None and not 0 <= int(max_size) <= 62:
-            raise ValueError("History: max_size must be None or in [0, 62] (a window of at most 63 transitions per lane)")
+        if max_size is not None and not 0 <= int(max_size) < (1 << 31) - 1:
+            raise ValueError("History: max_size must be None or a non-negative int (rock.py:533-544)")
         self._max_size = None if max_size is None else int(max_size)
         self._env = env
         n, dev = env.batch_size, env.device

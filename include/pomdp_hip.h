@@ -384,7 +384,7 @@ typedef struct pomdp_history {
                                pomdp_heuristic_steps — _generate_preferred reads this word, not the sums */
     /* History(max_size=k) of rock.py:533-544: append() pops the oldest record once the list holds more than k, so the
      * list settles at k + 1 records and the sums above cover that window only.  max_size = -1: unbounded (the reference's
-     * default; ring and head may be NULL).  0 <= max_size <= 62: `size` stops at max_size + 1; for RockSample the window
+     * default; ring and head may be NULL).  max_size >= 0: `size` stops at max_size + 1; for RockSample the window
      * itself is kept so that a record's contribution can leave the sums again: ring uint8 [max_size + 1][n], one byte per
      * kept transition (action | next_ob << 5 | (observation == BAD) << 7), head int32 [n] = the row the next transition
      * goes to (the oldest one once the ring is full).  Both may be NULL for the other envs. */

@@ -774,9 +774,10 @@ def test_heuristic_golden(case, env, kw):
 @pytest.mark.parametrize("env,kw,n,T,max_size", [("rock", {}, 16384, 96, None), ("rock", dict(board_size=15, num_rocks=15), 8192, 96, None),
                                                  ("stochrock", {}, 4096, 128, None), ("tag", {}, 8192, 128, None),
                                                  ("rock", {}, 8192, 96, 8), ("rock", dict(board_size=11, num_rocks=11), 4096, 96, 0),
-                                                 ("rock", dict(board_size=15, num_rocks=15), 4096, 128, 30), ("tag", {}, 4096, 64, 2)],
+                                                 ("rock", dict(board_size=15, num_rocks=15), 4096, 128, 30), ("tag", {}, 4096, 64, 2),
+                                                 ("rock", {}, 2048, 160, 100), ("tag", {}, 1024, 96, 300)],
                          ids=["rock_7_8", "rock_15_15", "stochrock_7_8", "tag_1", "rock_7_8-hist8", "rock_11_11-hist0",
-                              "rock_15_15-hist30", "tag_1-hist2"])
+                              "rock_15_15-hist30", "tag_1-hist2", "rock_7_8-hist100", "tag_1-hist300"])
 def test_heuristic_vs_oracle_at_scale(env, kw, n, T, max_size):
     """A device-resident heuristic-policy loop (preferred -> pick -> step -> statistics -> history) against the oracle's
     restatement, every lane following its own preferred list; with max_size the planner's history is History(max_size)
@@ -999,7 +1000,8 @@ def test_fused_steps_leave_what_per_step_launches_leave(env, kw, n, auto):
     assert a.call_counter == b.call_counter
 
 
-HEUR_FUSE_CASES = [("rock", {}, 4096 + 1, True), ("rock", dict(board_size=15, num_rocks=15), 2048 + 2, True), ("tag", {}, 4096 + 3, True),   # n % 4 != 0:
+HEUR_FUSE_CASES = [("rock", dict(hist=90), 2048, True),              # a window longer than a launch (any max_size since round 4)
+                   ("rock", {}, 4096 + 1, True), ("rock", dict(board_size=15, num_rocks=15), 2048 + 2, True), ("tag", {}, 4096 + 3, True),   # n % 4 != 0:
                    ("stochrock", {}, 1024 + 3, False),                               # the padding threads of the last quad supply blocks
                    ("rock", {}, 8192 + 12, True), ("rock", {}, 4096, False), ("rock", dict(board_size=15, num_rocks=15), 4096, True),
                    ("stochrock", {}, 4096, True), ("tag", {}, 8192, True), ("tag", dict(num_opponents=2), 4096, False),

@@ -22,7 +22,7 @@ FULL = [("rock", {}, 1 << 20, 70), ("rock", dict(board_size=15, num_rocks=15), 1
         ("tiger", {}, 1 << 20, 70), ("network", {}, 1 << 20, 70),
         ("battleship", dict(board_size=(10, 10), max_len=5), 1 << 19, 70),            # C4: 2^22 lanes over 8 GPUs
         ("stochrock", {}, 1 << 18, 70), ("stochrock", {}, 1 << 19, 70), ("stochrock", dict(board_size=15, num_rocks=15), 1 << 19, 40),
-        ("battleship", {}, 1 << 18, 70),
+        ("battleship", {}, 1 << 18, 70), ("battleship", {}, 1 << 16, 70), ("battleship", dict(board_size=(10, 10), max_len=5), 1 << 16, 70),   # the quad loop's gate (2^16)
         # the shards a 2^20-lane batch leaves per GPU at 2, 4 and 8 GPUs
         ("rock", {}, 1 << 19, 66), ("rock", {}, 1 << 18, 66), ("rock", {}, 1 << 17, 66),
         ("rock", {}, 3 << 18, 66), ("rock", dict(board_size=15, num_rocks=15), 1 << 19, 66),   # either side of RockSample's quad gate (3 * 2^18 lanes)
@@ -275,8 +275,8 @@ def test_bench_self_launches_two_ranks_on_the_one_gpu():
 
 def test_launcher_picks_the_documented_kernel_per_shard_size():
     """pomdp_last_fused_kernel() after a fused call: the quad-per-thread loops from the shard sizes DESIGN.md §5 lists
-    (RockSample 3 * 2^18, StochasticRock 2^19, Tag 2^19, Tiger 2^19, Network 2^19), the one- / two-lanes-per-thread loops below, the generic loop
-    for BattleShip, and the arithmetic lane step for launches shorter than 16 steps."""
+    (RockSample 3 * 2^18, StochasticRock 2^19, Tag 2^19, Tiger 2^19, Network 2^19, BattleShip 2^16), the one- / two-lanes-per-thread
+    loops below, and the arithmetic lane step for launches shorter than 16 steps."""
     from gym_pomdp_amd import _native
     L = _native.lib()
     want = [("rock", {}, 1 << 20, 64, "steps_quad_kernel<RockEnv<1>>"), ("rock", {}, 3 << 18, 64, "steps_quad_kernel<RockEnv<1>>"),
@@ -288,7 +288,7 @@ def test_launcher_picks_the_documented_kernel_per_shard_size():
             ("tag", {}, 1 << 18, 64, "steps_kernel<TagEnv, 1, true>"), ("tag", dict(num_opponents=2), 1 << 20, 64, "steps_kernel<TagEnv, 2, true>"),
             ("tiger", {}, 1 << 19, 64, "steps_quad_generic_kernel<TigerEnv>"), ("tiger", {}, 1 << 18, 64, "steps_kernel<TigerEnv, 1, true>"),
             ("network", {}, 1 << 19, 64, "network_steps_quad_kernel<>"), ("network", {}, 1 << 18, 64, "steps_kernel<NetworkEnv, 1, true>"),
-            ("battleship", {}, 1 << 18, 64, "battleship_steps_quad_kernel<BattleShipEnv<1>>"), ("battleship", {}, 1 << 17, 64, "steps_kernel<BattleShipEnv<1>, 1, true>"), ("stochrock", {}, 1 << 19, 64, "steps_quad_kernel<StochasticRockEnv<1>>"),
+            ("battleship", {}, 1 << 16, 64, "battleship_steps_quad_kernel<BattleShipEnv<1>>"), ("battleship", {}, 1 << 15, 64, "steps_kernel<BattleShipEnv<1>, 1, true>"), ("stochrock", {}, 1 << 19, 64, "steps_quad_kernel<StochasticRockEnv<1>>"),
             ("stochrock", {}, 1 << 18, 64, "steps_kernel<StochasticRockEnv<1>, 1, true>")]
     for env, kw, n, k, name in want:
         e = make_env(env, kw, batch_size=n, seed=1, reuse_buffers=True)
@@ -383,8 +383,9 @@ def test_heuristic_steps_fused_vs_oracle(oracle_lib, env, kw):
 @pytest.mark.parametrize("env,kw,n,max_size,auto", [("rock", {}, 4096 + 1, None, True), ("rock", {}, 4096 + 2, 6, True),
                                                     ("rock", dict(board_size=15, num_rocks=15), 2048 + 3, None, True),
                                                     ("tag", {}, 4096 + 3, None, True), ("stochrock", {}, 1024 + 1, None, False),
-                                                    ("tiger", {}, 259, None, True), ("battleship", {}, 1021, None, True)],
-                         ids=["rock+1", "rock+2-hist6", "rock15+3", "tag+3", "stochrock+1-frozen", "tiger+3", "battleship+1"])
+                                                    ("tiger", {}, 259, None, True), ("battleship", {}, 1021, None, True),
+                                                    ("rock", {}, 2048, 80, True)],
+                         ids=["rock+1", "rock+2-hist6", "rock15+3", "tag+3", "stochrock+1-frozen", "tiger+3", "battleship+1", "rock-hist80"])
 def test_heuristic_multi_step_launches_on_ragged_batches_vs_oracle(oracle_lib, env, kw, n, max_size, auto):
     """n % 4 != 0 with several steps per launch: the padding threads of the last quad take part in the quad transposes that
     hand the policy's (and RockSample's sensor) blocks of steps base + 1 .. 3 to the quad's in-range lanes, so their lane

@@ -14,6 +14,8 @@ trace() {   # <out file> <header> bench args...: kernel trace of one bench comma
   (cd /tmp && rocprofv3 --kernel-trace --stats -d $W/t/trace -o t -- python $REPO/bench.py "$@" > $W/t/bench_traced.log 2>&1)
   (echo "##### python bench.py $* under rocprofv3 --kernel-trace --stats (MI355X)$hdr"; python $REPO/tools/rocpd_summary.py $W/t | awk '{ if (substr($0,1,1)=="{") print; else print substr($0,1,280) }'; tail -1 $W/t/bench_traced.log) >> $out
 }
+# (the whole GPU suite first: the profiles belong to a tree whose parity is green)
+timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 > $OUT/pytest_gpu.log
 # 0. the bench exactly as the driver runs it (one 20-step launch per timed region), then the default (64-step launches)
 : > $OUT/headline_steps20.txt; trace $OUT/headline_steps20.txt "" --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline
 : > $OUT/headline.txt; trace $OUT/headline.txt "" --steps 2000 --no-cpu-baseline --no-extras
@@ -23,8 +25,14 @@ for l in columns blocked; do trace $OUT/headline.txt " — layout $l" --steps 20
 for e in rock15 stochrock tag battleship battleship5 tiger network; do trace $OUT/envs.txt "" --env $e --steps 1500 --warmup 300 --no-cpu-baseline --no-extras; done
 for e in rock15 rock; do trace $OUT/envs.txt "" --env $e --mode rollout --lanes-per-gpu 2097152 --steps 200 --warmup 100; done
 for e in rock rock15 tag; do trace $OUT/envs.txt "" --env $e --mode heuristic --steps 1024 --warmup 128; done
-# 2. the bench lines, unprofiled: default, as the driver runs it, two ranks on the one GPU, the other envs and layouts
+# 2. the counters first (step 4 below used to come last): the bench lines then read THIS tree's counters from profiles/
 cd $REPO
+(cd tools && hipcc --offload-arch=gfx950 -O3 -o /tmp/valu_microbench valu_microbench.hip 2>/dev/null); /tmp/valu_microbench > $OUT/valu_microbench.json 2>/dev/null
+python tools/isa_mix.py --costs $OUT/valu_microbench.json --json $OUT/isa_mix.json > $OUT/isa_mix.txt 2>/dev/null
+bash tools/gpu_pmc_valu.sh ${TAG}_valu "planners headline envs shards" > $OUT/pmc_valu.log 2>&1
+cp $REPO/gpurun_out/${TAG}_valu/pmc_valu.json $REPO/gpurun_out/${TAG}_valu/pmc_valu.txt $OUT/ 2>/dev/null
+cp $OUT/pmc_valu.json profiles/${TAG}_pmc_valu.json; cp $OUT/isa_mix.json profiles/${TAG}_isa_mix.json      # (on the box's copy of the tree)
+# 2b. the bench lines, unprofiled: default, as the driver runs it, two ranks on the one GPU, the other envs and layouts
 timeout 600 python bench.py 2>/dev/null | tail -1 > $OUT/bench.json
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 > $OUT/bench_steps20.json
 timeout 600 python bench.py --gpus 2 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_gpus2.json
@@ -42,9 +50,4 @@ timeout 600 python tools/gpu_layout_probe.py 20 rock > $OUT/layout_probe_20.txt 
 timeout 900 python tools/gpu_small_shards.py - 2>/dev/null > $OUT/small_shards_packed.txt
 SHARD_LAYOUT=columns SHARD_ENVS=rock,tag,battleship timeout 900 python tools/gpu_small_shards.py - 2>/dev/null > $OUT/small_shards_columns.txt
 timeout 600 python tools/gpu_single_step_probe.py - 20 2>/dev/null > $OUT/single_step.txt
-# 4. the VALU-issue counters (tools/gpu_pmc_valu.sh: every set), the instruction costs and mixes they are priced with
-(cd tools && hipcc --offload-arch=gfx950 -O3 -o /tmp/valu_microbench valu_microbench.hip 2>/dev/null); /tmp/valu_microbench > $OUT/valu_microbench.json 2>/dev/null
-python tools/isa_mix.py --costs $OUT/valu_microbench.json --json $OUT/isa_mix.json > $OUT/isa_mix.txt 2>/dev/null
-bash tools/gpu_pmc_valu.sh ${TAG}_valu > $OUT/pmc_valu.log 2>&1
-cp $REPO/gpurun_out/${TAG}_valu/pmc_valu.json $REPO/gpurun_out/${TAG}_valu/pmc_valu.txt $OUT/ 2>/dev/null
 ls -la $OUT
