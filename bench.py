@@ -506,13 +506,15 @@ def step_rooflines(env_key, bytes_per_step, layout, n, kern_ms, spl, fused, fuse
     return {"alg_bytes": alg, "hbm": hbm, "valu": valu, "primary": primary}
 
 
-def quick_step_config(args, gpa, _native, cp, dev, env_key, n, lane_offset, seed, layout):
+def quick_step_config(args, gpa, _native, cp, dev, env_key, n, lane_offset, seed, layout, k=None):
     """One workload measured briefly with the headline's protocol (reseed + reset, W warm-up steps, an untimed pass, then 9
     regions of K steps bracketed by device syncs: even ones by wall clock, odd ones by HIP events) -> a `configs` / `layouts`
-    entry.  K = --steps, at most 128."""
+    entry.  K = --steps, at most 128 (`layouts`: like for like with the headline); `configs` pass K = 512 — eight 64-step
+    launches per region, whatever --steps is — so that their figures are those of the stand-alone runs of the same workloads
+    (profiles/*_bench_envs.jsonl) and not a function of how the driver sliced the headline."""
     env_id, kwargs, label, bytes_per_step, _ = WORKLOADS[env_key]
-    k = min(args.steps, 128)
-    wl = StepWorkload(args, gpa, env_id, kwargs, dev, n, lane_offset, seed, layout=layout)
+    k = min(args.steps, 128) if k is None else k
+    wl = StepWorkload(args, gpa, env_id, kwargs, dev, n, lane_offset, seed, layout=layout, max_steps=k)
     wl.reseed(seed)
     wl.run(args.warmup)
     wl.run(k)
@@ -532,7 +534,7 @@ def quick_step_config(args, gpa, _native, cp, dev, env_key, n, lane_offset, seed
 
 
 def quick_rollout_config(args, gpa, dev, env_key, roots_n, sims, depth, seed):
-    """BASELINE.json configs[4] per GPU: roots_n x sims random rollouts of <= depth steps in one fused launch, 10 timed
+    """BASELINE.json configs[4] per GPU: roots_n x sims random rollouts of <= depth steps in one fused launch, 40 timed
     launches (HIP events) after 5 untimed ones."""
     env_id, kwargs, label, _, _ = WORKLOADS[env_key]
     e = gpa.make(env_id, batch_size=roots_n, device=dev, seed=seed, reuse_buffers=True, **kwargs)
@@ -549,13 +551,13 @@ def quick_rollout_config(args, gpa, dev, env_key, roots_n, sims, depth, seed):
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
-    for _ in range(10):
+    for _ in range(40):
         out = e.rollout(depth, sims_per_root=sims, roots=roots, out=out)
         total.add_(out["n_steps"].sum())
     ev1.record()
     torch.cuda.synchronize(dev)
     wall = time.perf_counter() - t0
-    launch_ms = ev0.elapsed_time(ev1) / 10
+    launch_ms = ev0.elapsed_time(ev1) / 40
     steps_done = int(total.item())
     v = valu_roofline("rollout_%s" % env_key, "rollout_kernel<", roots_n * sims, launch_ms)
     del e, out
@@ -563,7 +565,7 @@ def quick_rollout_config(args, gpa, dev, env_key, roots_n, sims, depth, seed):
     return {"workload": "%s: %d roots x %d simulations, depth <= %d, uniform policy over _generate_legal(), one fused rollout "
                         "launch per step" % (label, roots_n, sims, depth),
             "value": steps_done / wall, "unit": "env-steps/s (lane-steps of the simulations)", "kernel": "rollout_kernel<%s>" % env_key,
-            "kernel_ms": launch_ms, "mean_steps_per_simulation": steps_done / (10.0 * roots_n * sims),
+            "kernel_ms": launch_ms, "mean_steps_per_simulation": steps_done / (40.0 * roots_n * sims),
             "roofline": {"bound": "valu" if v else None, "frac": v["frac"] if v else None,
                          "counters_stale": v["counters_stale"] if v else None}}
 
@@ -573,7 +575,7 @@ class StepWorkload(object):
 
     CHUNK = 128          # steps per C-driver call (two full 64-step launches when fused)
 
-    def __init__(self, args, gpa, env_id, kwargs, dev, n, lane_offset, seed, layout=None):
+    def __init__(self, args, gpa, env_id, kwargs, dev, n, lane_offset, seed, layout=None, max_steps=0):
         self.args, self.dev, self.n = args, dev, n
         self.layout = layout or args.layout
         self.env = gpa.make(env_id, batch_size=n, device=dev, seed=seed, lane_offset=lane_offset, reuse_buffers=True, **kwargs)
@@ -585,7 +587,7 @@ class StepWorkload(object):
         self.views = {}
         if self.collect:
             # one [CHUNK + 1][n] trajectory buffer per column; a call of c steps writes the first c (+ 1) rows
-            c = min(self.CHUNK, max(args.steps, args.warmup, 1))
+            c = min(self.CHUNK, max(args.steps, args.warmup, max_steps, 1))
             self.traj = self.env.trajectory_buffers(c, self.layout)    # one allocation (columns: starts staggered, envs/base.py)
         else:
             self.layout = "columns"
@@ -772,8 +774,8 @@ def main():
                 layouts_block[lay] = quick_step_config(args, gpa, _native, cp, dev, args.env, n, lane_offset, seeds[0], lay)
     if extras and args.env == "rock":
         configs_block = {
-            "tag": quick_step_config(args, gpa, _native, cp, dev, "tag", 1 << 20, 0, seeds[0], layout),            # configs[2]
-            "battleship": quick_step_config(args, gpa, _native, cp, dev, "battleship", 1 << 19, 0, seeds[0], layout),   # configs[3]: 2^22 / 8 GPUs
+            "tag": quick_step_config(args, gpa, _native, cp, dev, "tag", 1 << 20, 0, seeds[0], layout, k=512),            # configs[2]
+            "battleship": quick_step_config(args, gpa, _native, cp, dev, "battleship", 1 << 19, 0, seeds[0], layout, k=512),   # configs[3]: 2^22 / 8 GPUs
             "rollout_rock15": quick_rollout_config(args, gpa, dev, "rock15", 2048, 1024, 64, seeds[0])}                 # configs[4]: 2^24 / 8 GPUs
 
     # the recorded PMC figure belongs to a launch of the recorded shape only: 2^20 lanes, 64 or 20 steps per fused launch

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised parity sweep (dev aid, GPU box): random env configs, batch sizes (both launch geometries), lane offsets,
 call counters, auto-reset on/off, valid and invalid actions — HIP path vs the oracle, word for word; one case in eight
-is a trajectory collection (fused launches, up to 2^20 + 2048 lanes) checked row by row against the oracle.
+is a trajectory collection (fused launches, up to 2^20 + 2048 lanes, a random trajectory layout; FUZZ_COLLECT sets the
+share) checked row by row against the oracle.
 usage: python tools/gpu_fuzz.py [seconds]"""
 import os
 import sys
@@ -48,13 +49,14 @@ def collect_case(rs):
     st = o.new_state(n)
     ob_o = o.batch_reset(st, seed, lane0, t0, nthreads=8)
     assert np.array_equal(e.reset().cpu().numpy(), ob_o), (name, kw, n, "reset ob")
-    tr = e.collect_synthetic(steps)
+    layout = ("columns", "blocked", "packed")[rs.randint(3)]             # round 4: the trajectory layout too
+    tr = e.decode_trajectory(e.collect_synthetic(steps, layout=layout))
     done = np.zeros(n, np.uint8)
     for k in range(steps):
         t = t0 + 1 + k
         a = px.synthetic_actions(seed, lane0, n, t, o.n_actions)
         ob_o, rew_o, done, bad = o.batch_step(st, a, seed, lane0, t, auto_reset=True, done=done, nthreads=8)
-        ctx = ("collect", name, kw, n, lane0, seed, t0, steps, k)
+        ctx = ("collect", layout, name, kw, n, lane0, seed, t0, steps, k)
         assert bad == 0, ctx
         assert np.array_equal(tr["action"][k].cpu().numpy(), a), ctx
         assert np.array_equal(tr["ob"][k].cpu().numpy(), ob_o), ctx
@@ -67,7 +69,7 @@ def main(budget):
     rs = np.random.RandomState(int(time.time()) & 0xFFFFFF)
     t_end, cases = time.time() + budget, 0
     while time.time() < t_end:
-        if rs.rand() < 0.12:
+        if rs.rand() < float(os.environ.get("FUZZ_COLLECT", "0.12")):
             collect_case(rs)
             cases += 1
             continue
