@@ -446,7 +446,13 @@ __global__ __launch_bounds__(BLOCK) void tag_steps_quad_kernel(uint32_t *__restr
 // is the thread's own, the outputs leave as 16-byte stores, the reward comes from a table of the float32(float64) values
 // the reference's arithmetic gives.  A draw decided by its low word (2^-27 per draw) sends the lane through
 // NetworkEnv::step_exact, the exact per-lane form.  Network never terminates, so there is no reset.
-template <int NB, class L = Columns>   // NB: bytes of the machine set, ceil(n_machines / 8)
+// SMALL (round 4; n_machines <= 10, the reference's default): everything the first two draws need that depends on the
+// machine set alone comes from ONE lookup in a 2^n_machines-entry table the workgroup builds when the launch starts —
+// the two lowest up machines (the ones draws 0 and 1 belong to), which of the two thresholds each is compared with (as
+// the byte offset of a two-entry threshold table) and the reward base — instead of two popcounts, two byte-table lookups
+// and two rounds of "isolate the lowest set bit, test its failed-neighbour bit, select the threshold": 33 -> 16 vector
+// instructions per lane-step of a loop that runs at 0.96 of VALU issue.
+template <int NB, class L = Columns, bool SMALL = false>   // NB: bytes of the machine set, ceil(n_machines / 8)
 __global__ __launch_bounds__(BLOCK) void network_steps_quad_kernel(uint32_t *__restrict__ state, int32_t *__restrict__ action,
                                                                    int32_t *__restrict__ ob, float *__restrict__ reward,
                                                                    uint8_t *__restrict__ done, int64_t n, RngKey key0,
@@ -455,8 +461,11 @@ __global__ __launch_bounds__(BLOCK) void network_steps_quad_kernel(uint32_t *__r
 {
     using Env = NetworkEnv;
     __shared__ Env::Shared sh;                               // the nibble tables of the exact per-lane form (ties only)
-    __shared__ uint32_t nbf8[NB][256];                       // nbf8[k][v]: machines that see a failed neighbour when the down
+    __shared__ uint32_t nbf8[SMALL ? 1 : NB][SMALL ? 1 : 256];   // nbf8[k][v]: machines that see a failed neighbour when the down
                                                              // machines among 8 k .. 8 k + 7 are the set v (network.py:82-85)
+    // SMALL, by machine set v: stab = lb0 | lb1 << 10 | (4 * nbf(lb0)) << 20 | (4 * nbf(lb1)) << 23 | base << 26 (lb0 / lb1: the lowest
+    // / second lowest up machine as a bit, 0 if none); nbft = the failed-neighbour set itself (the pooled continuation's)
+    __shared__ uint32_t stab[SMALL ? 1024 : 1], nbft[SMALL ? 1024 : 1], thr2[2];
     __shared__ float rtab[3][68];                            // reward by (no action / ping / reboot, 2 per up machine with > 2
                                                              // neighbours + 1 per other up machine): network.py:87-92, 103, 110
     __shared__ uint32_t task_lds[BLOCK / 64][256][6];        // task rank -> {lane within the wave's 256 | has_action << 8, machines
@@ -476,11 +485,25 @@ __global__ __launch_bounds__(BLOCK) void network_steps_quad_kernel(uint32_t *__r
         for (int j = 0; j < 4; ++j) { a_cur[j] = (int)a4[j]; st[j] = s4[j]; }
     }
     Env::stage(sh, p, (int)threadIdx.x);
+    if constexpr (SMALL) {
+        const uint32_t up_all = (1u << p.n_machines) - 1u;
+        for (uint32_t v = threadIdx.x; v <= up_all; v += BLOCK) {
+            const uint32_t down = ~v & up_all;
+            uint32_t m = 0;
+            for (int i = 0; i < p.n_machines; ++i) m |= ((p.nb_mask[i] & down) != 0u ? 1u : 0u) << i;
+            const uint32_t lb0 = v & (0u - v), r1 = v ^ lb0, lb1 = r1 & (0u - r1);
+            const uint32_t base = (uint32_t)(__popc(v) + __popc(v & p.deg_gt2_mask));          // network.py:87-92
+            stab[v] = lb0 | (lb1 << 10) | ((m & lb0) ? 4u << 20 : 0u) | ((m & lb1) ? 4u << 23 : 0u) | (base << 26);
+            nbft[v] = m;
+        }
+        if (threadIdx.x == 0) { const Env::Thr T0 = Env::thresholds(p); thr2[0] = T0.fail; thr2[1] = T0.nb; }
+    } else {
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb) {                        // BLOCK threads = the 256 values of a byte
         uint32_t m = 0;
         for (int i = 0; i < p.n_machines; ++i) m |= (((p.nb_mask[i] >> (8 * kb)) & threadIdx.x) != 0u ? 1u : 0u) << i;
         nbf8[kb][threadIdx.x] = m;
+    }
     }
     if (threadIdx.x < 3 * 68) {                              // r = float32(float64(base) - cost), as the reference computes it
         const int kind = (int)threadIdx.x / 68, b = (int)threadIdx.x % 68;
@@ -514,6 +537,19 @@ __global__ __launch_bounds__(BLOCK) void network_steps_quad_kernel(uint32_t *__r
             const uint32_t s0 = st[j];
             const uint4 h = stream_block(key, glane0 + (uint32_t)j, POMDP_STREAM_STEP, 0u);
             const int n_up = __popc(s0);
+            if constexpr (SMALL) {
+                const uint32_t e = stab[s0];
+                nbf[j] = nbft[s0];
+                const uint32_t lb0 = e & 1023u, lb1 = __builtin_amdgcn_ubfe(e, 10u, 10u);
+                // the threshold of draw 0 / 1: entry 0 (no failed neighbour) or 1 of thr2, addressed by the byte offset in e
+                const uint32_t t0 = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(thr2) + __builtin_amdgcn_ubfe(e, 20u, 3u));
+                const uint32_t t1 = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(thr2) + __builtin_amdgcn_ubfe(e, 23u, 3u));
+                base[j] = (int)(e >> 26);
+                kill[j] = (h.x < t0 ? 0u : lb0) | (h.y < t1 ? 0u : lb1);           // fails iff k53 > thr (network.py:94-99)
+                near[j] = min(h.x - t0, h.y - t1);                                 // a tie has H - T < 32 (a slot without a machine: a
+                                                                                    // false alarm costs the exact path, 2^-27 of the time)
+                todo[j] = s0 & ~(lb0 | lb1);
+            } else {
             base[j] = n_up + __popc(s0 & p.deg_gt2_mask);                      // network.py:87-92
             {
                 const uint32_t down = ~s0 & all_up;
@@ -526,6 +562,7 @@ __global__ __launch_bounds__(BLOCK) void network_steps_quad_kernel(uint32_t *__r
             near[j] = 0xFFFFFFFFu;
             const uint32_t H2[2] = {h.x, h.y};
             kill[j] = Env::draws<2>(H2, todo[j], nbf[j], T, near[j]);
+            }
             hz[j] = h.z; hw[j] = h.w;
             const bool has_action = a_cur[j] < M2;
             uint32_t aw = n_up == 1 ? h.y : h.x;                                // word n_up of the block (n_up < 3), as selects
@@ -938,6 +975,10 @@ static int launch_steps_fused_l(const typename Env::Params &p, uint32_t *state, 
 #define POMDP_LAUNCH_NET(NB_)                                                                                            \
     hipLaunchKernelGGL((network_steps_quad_kernel<NB_, L>), qgrid, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob, reward, \
                        done, n, make_key(seed, t), lane0, make_key(action_seed, t + 1), k, rec, gf, p)
+            if (p.n_machines <= 10) {        // the state-table form (the reference's default has 10 machines)
+                hipLaunchKernelGGL((network_steps_quad_kernel<2, L, true>), qgrid, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob,
+                                   reward, done, n, make_key(seed, t), lane0, make_key(action_seed, t + 1), k, rec, gf, p);
+            } else
             switch ((p.n_machines + 7) / 8) {
             case 1: POMDP_LAUNCH_NET(1); break;
             case 2: POMDP_LAUNCH_NET(2); break;

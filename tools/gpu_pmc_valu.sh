@@ -43,7 +43,10 @@ for set in $SETS; do
     run rollout_tag --env tag --mode rollout --lanes-per-gpu 2097152 --steps 20 --warmup 10
     run heuristic_rock --env rock --mode heuristic --prewarm 0 --warmup 128 --steps 1024
     run heuristic_rock15 --env rock15 --mode heuristic --prewarm 0 --warmup 128 --steps 1024
-    run heuristic_tag --env tag --mode heuristic --prewarm 0 --warmup 128 --steps 1024 ;;
+    run heuristic_tag --env tag --mode heuristic --prewarm 0 --warmup 128 --steps 1024
+    # what the heuristic loop's CHECKs move: the side statistics are seven [K][N] arrays read-modify-written per CHECK
+    traffic heuristic_rock15 --env rock15 --mode heuristic --prewarm 0 --warmup 128 --steps 1024
+    traffic heuristic_rock --env rock --mode heuristic --prewarm 0 --warmup 128 --steps 1024 ;;
   headline)
     for l in packed columns blocked; do
       run step64_rock$(sfx $l) --env rock --layout $l $S64
