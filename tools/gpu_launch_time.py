@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """us per fused launch of k steps (HIP events, best of 7 x 20 launches) for the library in $POMDP_LIB (dev aid for
-tools/ab_build.sh variants).  env: LT_ENV (rock), LT_LG (20), LT_KS (20,64)."""
+tools/ab_build.sh variants).  env: LT_ENV (rock), LT_LG (20), LT_KS (20,64), LT_LAYOUT (packed)."""
 import os
 import sys
 
@@ -25,7 +25,7 @@ for name in os.environ.get("LT_ENV", "rock").split(","):
     e = gpa.make(env_id, batch_size=1 << int(os.environ.get("LT_LG", "20")), seed=0, reuse_buffers=True, **kw)
     e.reset()
     for k in [int(x) for x in os.environ.get("LT_KS", "20,64").split(",")]:
-        tr = e.collect_synthetic(k)
+        tr = e.collect_synthetic(k, layout=os.environ.get("LT_LAYOUT", "packed"))
         for _ in range(30):
             e.collect_synthetic(k, out=tr)
         torch.cuda.synchronize()
