@@ -306,8 +306,14 @@ template <class Env> struct LegalOf<Env, std::void_t<typename Env::Legal>> {
 // state, its history words (size, last action / observation, prev_ob), the two derived words and the running return stay
 // in registers and are written back once; the per-rock arrays are read and written in place when a CHECK touches them;
 // every step's action / ob / reward / done (and state) is written as the single-step launches write them.
+// Six waves per SIMD (at most 80 registers) where the compiler's own choice was five (81-86): the loop's CHECK / fresh-episode
+// branches stall on memory, and the sixth wave fills those slots — RockSample(7,8) 4.64 -> 4.52, (15,15) 5.98 -> 5.85, Tag
+// 4.35 -> 4.15 us per step at 2^20 lanes; four waves: 4.95 / 6.42 / 4.69, eight (spilling): 5.17 / 6.58 / 4.22.  BattleShip's
+// large boards (three and four state words) keep the compiler's choice: they would spill 100+ bytes per lane.
+template <class Env> struct heur_waves { static constexpr int value = Env::WORDS <= 2 ? 6 : 4; };
 template <class Env, bool RING>   // RING: a bounded RockSample history (history_push keeps its window)
-__global__ __launch_bounds__(BLOCK) void heuristic_steps_kernel(const typename Env::Params p, uint32_t *__restrict__ state,
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(heur_waves<Env>::value)))
+void heuristic_steps_kernel(const typename Env::Params p, uint32_t *__restrict__ state,
                                                                 pomdp_rock_belief b, pomdp_history h, int K, pomdp_returns R,
                                                                 int32_t *__restrict__ prev_ob, int32_t *__restrict__ action,
                                                                 int32_t *__restrict__ ob, typename Env::Reward *__restrict__ reward,
