@@ -704,6 +704,18 @@ def main():
         strong = {"total_lanes": args.lanes_per_gpu, "lanes_per_gpu": n_s, "value": args.lanes_per_gpu * args.steps / rows_s[0][1],
                   "unit": "env-steps/s", "ms_per_step": rows_s[0][1] / args.steps * 1e3, "seed": seeds[0],
                   "kernel": _native.lib().pomdp_last_fused_kernel().decode() if wl_s.fused else None}
+        # How far the shard's launch is from its floor: a small shard has two to four waves per SIMD and is
+        # bound by instruction issue at best — floor = the launch's recorded vector instructions x the cycles its mix costs
+        # / the SIMDs' cycles, i.e. frac_of_floor is the VALU-issue fraction of the shard's kernel (None: no recorded pass
+        # for this shard size and launch length, tools/gpu_pmc_valu.sh shards).
+        strong["frac_of_floor"] = strong["floor_source"] = None
+        if wl_s.fused and strong["kernel"]:
+            spl_s = min(64, args.steps)
+            v = valu_roofline(valu_workload_key(args.env, spl_s, wl_s.layout, n_s), strong["kernel"].split("<")[0] + "<", n_s,
+                              rows_s[0][4] / args.steps * spl_s)
+            if v is not None:
+                strong.update({"frac_of_floor": v["frac"], "kernel_ms": rows_s[0][4] / args.steps, "floor_ms_per_step": v["frac"] * rows_s[0][4] / args.steps,
+                               "counters_stale": v["counters_stale"], "floor_source": v["source"]})
         del wl_s
 
     # ---- the single-step kernels, for reference: HIP events on their stream ------------------------------------------

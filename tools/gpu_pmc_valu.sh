@@ -63,9 +63,11 @@ for set in $SETS; do
     # BASELINE.json configs[3] per GPU: BattleShip 10x10 at 2^19 lanes (bench.py: configs.battleship)
     run step64_battleship_packed_2e19 --env battleship --layout packed --lanes-per-gpu 524288 $S64
     run step20_battleship_packed_2e19 --env battleship --layout packed --lanes-per-gpu 524288 $S20 ;;
-  shards)   # the shards a 2^20-lane batch leaves per GPU at 8 / 4 GPUs (strong scaling: DESIGN.md §7)
-    run step64_rock_packed_2e17 --env rock --layout packed --lanes-per-gpu 131072 $S64
-    run step64_rock_packed_2e18 --env rock --layout packed --lanes-per-gpu 262144 $S64 ;;
+  shards)   # the shards a 2^20-lane batch leaves per GPU at 8 / 4 / 2 GPUs (strong scaling: DESIGN.md §7)
+    for lg in 17 18 19; do       # both launch shapes: bench.py's strong_scaling.frac_of_floor looks the shard up by size and length
+      run step64_rock_packed_2e$lg --env rock --layout packed --lanes-per-gpu $((1 << lg)) $S64
+      run step20_rock_packed_2e$lg --env rock --layout packed --lanes-per-gpu $((1 << lg)) $S20
+    done ;;
   esac
 done
 cd $REPO

@@ -27,7 +27,7 @@ DEFAULT = ["steps_quad_kernel<pomdp::RockEnv<1, false>, ", "steps_quad_kernel<po
            "rollout_kernel<pomdp::RockEnv<1, false>", "rollout_kernel<pomdp::TagEnv", "heuristic_steps_kernel<pomdp::RockEnv<1, false>, false",
            "heuristic_steps_kernel<pomdp::RockEnv<2, false>, false", "heuristic_steps_kernel<pomdp::TagEnv, false",
            "tag_steps_quad_kernel<true, ", "network_steps_quad_kernel<2, ", "steps_quad_generic_kernel<pomdp::TigerEnv, ",
-           "steps_kernel<pomdp::RockEnv<1, false>, 1, true, true, ", "battleship_steps_quad_kernel<4, ", "battleship_steps_quad_kernel<1, "]
+           "steps_kernel<pomdp::RockEnv<1, false>, 1, true, true, ", "steps_kernel<pomdp::RockEnv<1, false>, 2, true, false, ", "battleship_steps_quad_kernel<4, ", "battleship_steps_quad_kernel<1, "]
 
 # mnemonic -> the measured class that prices it (tools/valu_microbench.hip op names); anything else: DEFAULT_COST
 ALIAS = {
