@@ -267,6 +267,14 @@ def test_recorded_counters_belong_to_this_tree():
         assert not bench.counters_stale(pmc, wl), "kernel sources changed since %s [%s] was recorded: re-run tools/gpu_pmc_valu.sh <tag> headline" % (pmc, wl)
         v = bench.valu_roofline(wl, "steps_quad_kernel<", 1 << 20, 0.04 if wl.startswith("step20") else 0.1)
         assert v is not None and v["counters_stale"] is False and v["kernel"] == "steps_quad_kernel<RockEnv<1, false>, Packed>" and 0.3 < v["frac"] < 1.0, v
+    # the shards of a 2^20-lane batch over 8 / 4 / 2 GPUs, in the default and the driver's launch shape: what
+    # `strong_scaling.frac_of_floor` of a multi-GPU line is computed from
+    for lg, launch_us in ((17, (12.0, 28.0)), (18, (16.0, 38.0)), (19, (26.0, 72.0))):
+        for spl, us in zip((20, 64), launch_us):
+            key = bench.valu_workload_key("rock", spl, "packed", 1 << lg)
+            assert key == "step%d_rock_packed_2e%d" % (spl, lg)
+            v = bench.valu_roofline(key, "steps_kernel<", 1 << lg, us * 1e-3)
+            assert v is not None and v["counters_stale"] is False and 0.3 < v["frac"] < 1.0, (key, v)
     # a changed source file flips the flag (the hash covers every file under csrc/ and the C header)
     assert bench.counters_stale(pmc, "no_such_workload")
     t, _ = bench.recorded_traffic("rock", "packed", 20, "steps_quad_kernel<")
