@@ -14,7 +14,7 @@ import os
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 from . import spaces  # noqa: F401
-from .history import History, Returns, Transition  # noqa: F401
+from .history import EpisodeStats, History, Returns, Transition  # noqa: F401
 from .envs import BattleShipEnv, NetworkEnv, RockEnv, StochasticRockEnv, TagEnv, TigerEnv  # noqa: F401
 
 __version__ = "0.1.0"

@@ -21,12 +21,13 @@ HEADERS = ["kernels_common.hip.h", "traj_out.hip.h", "step_impl.hip.h", "fused_i
            "envs/rock.hip.h", "envs/tag.hip.h", "envs/battleship.hip.h", "envs/tiger.hip.h", "envs/network.hip.h"]
 SOURCES = [os.path.join(_PKG, "csrc", f) for f in UNITS + HEADERS]
 HEADER = os.path.join(_REPO, "include", "pomdp_hip.h")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 POMDP_AUTO_RESET = 1
 POMDP_FUSE_STEPS = 2
 POMDP_ROLLOUT_ALL_ACTIONS = 1
-LAYOUTS = {"columns": 0, "blocked": 1, "packed": 2}     # POMDP_LAYOUT_*
+LAYOUTS = {"columns": 0, "blocked": 1, "packed": 2, "narrow": 3}     # POMDP_LAYOUT_*
+FUSE_MAX_DEFAULT = 64
 ENV_KIND = {"rock": 0, "tag": 1, "battleship": 2, "tiger": 3, "network": 4}
 
 # every symbol include/pomdp_hip.h declares
@@ -35,7 +36,7 @@ SYMBOLS = [
     "pomdp_rock_reset", "pomdp_rock_step", "pomdp_tag_reset", "pomdp_tag_step",
     "pomdp_battleship_reset", "pomdp_battleship_step", "pomdp_tiger_reset", "pomdp_tiger_step",
     "pomdp_network_reset", "pomdp_network_step", "pomdp_step", "pomdp_step_sync", "pomdp_reset_sync", "pomdp_stream_sync", "pomdp_synthetic_actions", "pomdp_philox_blocks",
-    "pomdp_rollout_synthetic", "pomdp_collect_synthetic", "pomdp_collect", "pomdp_collect_layout", "pomdp_collect_traj", "pomdp_packed_reward", "pomdp_legal_actions", "pomdp_rollout", "pomdp_compute_prob",
+    "pomdp_rollout_synthetic", "pomdp_collect_synthetic", "pomdp_collect", "pomdp_collect_layout", "pomdp_collect_traj", "pomdp_packed_reward", "pomdp_decode_packed", "pomdp_collect_returns", "pomdp_fuse_max", "pomdp_legal_actions", "pomdp_rollout", "pomdp_compute_prob",
     "pomdp_rock_belief_reset", "pomdp_rock_belief_refresh", "pomdp_rock_belief_update", "pomdp_rock_select_target", "pomdp_history_clear",
     "pomdp_history_append", "pomdp_preferred_actions", "pomdp_pick_actions", "pomdp_heuristic_steps",
 ]
@@ -91,6 +92,10 @@ class RockBelief(C.Structure):      # pomdp_rock_belief: device pointers, [num_r
 class HistoryPtrs(C.Structure):     # pomdp_history: device pointers + the window size of a bounded history
     _fields_ = [(k, C.c_void_p) for k in ("size", "last_action", "last_ob", "total_sample", "total_move", "move_ok", "ring", "head")] + \
                [("max_size", C.c_int32), ("reserved", C.c_int32)]
+
+
+class ReturnStats(C.Structure):     # pomdp_return_stats
+    _fields_ = [("discount", C.c_double), ("acc", C.c_void_p), ("cnt", C.c_void_p), ("pitch", C.c_int64)]
 
 
 class Returns(C.Structure):         # pomdp_returns
@@ -192,6 +197,12 @@ def lib():
     L.pomdp_collect_traj.argtypes = [vp, u64, i64, vp]
     L.pomdp_packed_reward.restype = C.c_double
     L.pomdp_packed_reward.argtypes = [ci, u32]
+    L.pomdp_decode_packed.restype = ci
+    L.pomdp_decode_packed.argtypes = [ci, vp, i64, i64, i64, vp, vp, vp, vp, i64, vp]
+    L.pomdp_collect_returns.restype = ci
+    L.pomdp_collect_returns.argtypes = [ci, vp, vp, vp, vp, i64, u64, u32, u64, i64, ci, vp]
+    L.pomdp_fuse_max.restype = ci
+    L.pomdp_fuse_max.argtypes = [ci]
     L.pomdp_legal_actions.restype = ci
     L.pomdp_legal_actions.argtypes = [ci, vp, vp, vp, vp, i64, ci, vp]
     L.pomdp_compute_prob.restype = ci

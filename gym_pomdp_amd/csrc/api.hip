@@ -1,12 +1,14 @@
 // api.hip — the C ABI of include/pomdp_hip.h: per-env reset / step, bound-argument and scalar-mode entry points, the synthetic policy, the C-side episode loops.
 // Part of libpomdp_hip.so; built by gym_pomdp_amd/_native.py (hipcc --offload-arch=gfx950 -O3 -std=c++17 -c, one object per file).
 #include "kernels_common.hip.h"
+#include <cstring>
 
 namespace pomdp {
 
 thread_local uint32_t *tl_host_flag = nullptr;
 thread_local uint32_t tl_flag_value = 0;
 thread_local char g_last_fused[96] = "";
+int g_fuse_max = POMDP_FUSE_MAX_DEFAULT;
 
 // ---------------------------------------------------------------------------
 // helpers
@@ -33,6 +35,48 @@ __global__ void philox_blocks_kernel(const uint32_t *__restrict__ ck, uint32_t *
     if (i < n) {
         const uint4 w = philox4x32_10(ck[6 * i], ck[6 * i + 1], ck[6 * i + 2], ck[6 * i + 3], ck[6 * i + 4], ck[6 * i + 5]);
         out[4 * i] = w.x; out[4 * i + 1] = w.y; out[4 * i + 2] = w.z; out[4 * i + 3] = w.w;
+    }
+}
+
+// PACKED records -> the default ABI's columns (pomdp_decode_packed).  One thread = four consecutive records of one row:
+// a 16-byte load, three 16-byte stores and the four done bytes.  The reward column's bit patterns come from a 256-entry
+// table in LDS (int32 of the int8 code; float for Tag; Network's float32(base - cost)) built once per workgroup.
+static __device__ __forceinline__ uint32_t decoded_reward_bits(int env, uint32_t code)
+{
+    if (env == POMDP_ENV_NETWORK) return __float_as_uint((float)NetworkEnv::code_reward(code));
+    const int r = (int)(int8_t)code;
+    return env == POMDP_ENV_TAG ? __float_as_uint((float)r) : (uint32_t)r;
+}
+template <bool VEC>
+__global__ __launch_bounds__(BLOCK) void decode_packed_kernel(const uint32_t *__restrict__ records, int64_t n, int64_t k_steps,
+                                                             int64_t pitch_in, uint32_t *__restrict__ action,
+                                                             uint32_t *__restrict__ ob, uint32_t *__restrict__ reward,
+                                                             uint8_t *__restrict__ done, int64_t pitch_out, int env)
+{
+    __shared__ uint32_t rtab[256];
+    rtab[threadIdx.x] = decoded_reward_bits(env, threadIdx.x);
+    __syncthreads();
+    const int64_t per_row = VEC ? (n + 3) >> 2 : n, total = per_row * k_steps, stride = (int64_t)gridDim.x * BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < total; i += stride) {
+        const int64_t s = i / per_row, q = i - s * per_row;
+        if (VEC && 4 * q + 4 <= n) {
+            const int64_t in = s * pitch_in + 4 * q, o = s * pitch_out + 4 * q;
+            const u32x4 r = ld_stream4(records + in);
+            st_stream4(action + o, r[0] & 0xFFu, r[1] & 0xFFu, r[2] & 0xFFu, r[3] & 0xFFu);
+            st_stream4(ob + o, __builtin_amdgcn_ubfe(r[0], 8u, 8u), __builtin_amdgcn_ubfe(r[1], 8u, 8u), __builtin_amdgcn_ubfe(r[2], 8u, 8u),
+                       __builtin_amdgcn_ubfe(r[3], 8u, 8u));
+            st_stream4(reward + o, rtab[__builtin_amdgcn_ubfe(r[0], 16u, 8u)], rtab[__builtin_amdgcn_ubfe(r[1], 16u, 8u)],
+                       rtab[__builtin_amdgcn_ubfe(r[2], 16u, 8u)], rtab[__builtin_amdgcn_ubfe(r[3], 16u, 8u)]);
+            // done bytes 0 / 1 of the four records -> four consecutive bytes
+            st_stream(reinterpret_cast<uint32_t *>(done + o), (r[0] >> 24) | ((r[1] >> 24) << 8) | ((r[2] >> 24) << 16) | (r[3] & 0xFF000000u));
+        } else {
+            const int64_t l0 = VEC ? 4 * q : q, l1 = VEC ? n : q + 1;                    // the ragged tail of a row, or one lane
+            for (int64_t l = l0; l < l1; ++l) {
+                const uint32_t r = records[s * pitch_in + l];
+                const int64_t o = s * pitch_out + l;
+                action[o] = r & 0xFFu; ob[o] = (r >> 8) & 0xFFu; reward[o] = rtab[(r >> 16) & 0xFFu]; done[o] = (uint8_t)(r >> 24);
+            }
+        }
     }
 }
 
@@ -295,7 +339,7 @@ int pomdp_rollout_synthetic(int env, const void *params, uint32_t *state, int32_
         // chained and fused: up to FUSE_MAX consecutive steps share one launch (steps_kernel and its quad-per-thread
         // forms); every step also leaves the actions of the following call counter in `action`; the first launch
         // derives the actions of t0 itself
-        constexpr int64_t FUSE_MAX = 64;
+        const int64_t FUSE_MAX = fuse_max();
         for (int64_t s = 0; s < k_steps; s += FUSE_MAX) {
             const int c = (int)(k_steps - s < FUSE_MAX ? k_steps - s : FUSE_MAX);
             const uint64_t t = t0 + (uint64_t)s;
@@ -345,7 +389,7 @@ int pomdp_collect_synthetic(int env, const void *params, uint32_t *state, int32_
     if (rc) return rc;
     if (pitch < n || !(flags & POMDP_AUTO_RESET)) return POMDP_E_BADARG;
     if (k_steps == 0 || n == 0) return 0;
-    constexpr int64_t FUSE_MAX = 64;
+    const int64_t FUSE_MAX = fuse_max();
     for (int64_t s = 0; s < k_steps; s += FUSE_MAX) {      // the first launch writes row 0 (the actions of t0) itself
         const int c = (int)(k_steps - s < FUSE_MAX ? k_steps - s : FUSE_MAX);
         rc = dispatch_env(env, params, [&](auto tag, const auto &p) {
@@ -372,18 +416,19 @@ int pomdp_collect(const pomdp_collect_args *a, uint64_t t0, int64_t k_steps, voi
 int pomdp_collect_layout(int env, const void *params, uint32_t *state, void *traj, uint32_t *err, int64_t n, uint64_t seed,
                          uint32_t lane0, uint64_t t0, int64_t k_steps, int64_t pitch, int layout, int flags, void *stream)
 {
-    if (layout != POMDP_LAYOUT_BLOCKED && layout != POMDP_LAYOUT_PACKED) return POMDP_E_BADARG;
+    if (layout != POMDP_LAYOUT_BLOCKED && layout != POMDP_LAYOUT_PACKED && layout != POMDP_LAYOUT_NARROW) return POMDP_E_BADARG;
     int rc = check_driver_args(env, params, state, traj, traj, traj, traj, n, lane0, k_steps);
     if (rc) return rc;
     if (pitch < n || !(flags & POMDP_AUTO_RESET)) return POMDP_E_BADARG;
     if (layout == POMDP_LAYOUT_BLOCKED && pitch % 256 != 0) return POMDP_E_BADARG;
-    // a Packed record keeps action and observation in a byte each: every env's fit by construction except Tag's
-    // "opponent seen" value, which is a constructor argument (tag.py:94)
-    if (layout == POMDP_LAYOUT_PACKED && env == POMDP_ENV_TAG && (uint32_t)((const pomdp_tag_params *)params)->obs_cells > 255u)
+    if (layout == POMDP_LAYOUT_NARROW && pitch % 4 != 0) return POMDP_E_BADARG;
+    // a Packed record (and a Narrow plane) keeps action and observation in a byte each: every env's fit by construction
+    // except Tag's "opponent seen" value, which is a constructor argument (tag.py:94)
+    if (layout != POMDP_LAYOUT_BLOCKED && env == POMDP_ENV_TAG && (uint32_t)((const pomdp_tag_params *)params)->obs_cells > 255u)
         return POMDP_E_BADPARAMS;
     if (k_steps == 0 || n == 0) return 0;
     const int64_t row_bytes = layout == POMDP_LAYOUT_BLOCKED ? pitch * 13 : pitch * 4;
-    constexpr int64_t FUSE_MAX = 64;
+    const int64_t FUSE_MAX = fuse_max();
     for (int64_t s = 0; s < k_steps; s += FUSE_MAX) {
         const int c = (int)(k_steps - s < FUSE_MAX ? k_steps - s : FUSE_MAX);
         int32_t *base = reinterpret_cast<int32_t *>(reinterpret_cast<uint8_t *>(traj) + s * row_bytes);
@@ -402,6 +447,60 @@ int pomdp_collect_traj(const pomdp_traj_args *a, uint64_t t0, int64_t k_steps, v
     if (!a) return POMDP_E_BADARG;
     return pomdp_collect_layout(a->env, a->params, a->state, a->traj, a->err, a->n, a->seed, a->lane0, t0, k_steps, a->pitch,
                                 a->layout, a->flags, stream);
+}
+
+int pomdp_collect_returns(int env, const void *params, uint32_t *state, const pomdp_return_stats *stats, uint32_t *err,
+                          int64_t n, uint64_t seed, uint32_t lane0, uint64_t t0, int64_t k_steps, int flags, void *stream)
+{
+    if (!stats || !stats->acc || !stats->cnt) return POMDP_E_BADARG;
+    int rc = check_driver_args(env, params, state, stats->acc, stats->cnt, stats->acc, stats->acc, n, lane0, k_steps);
+    if (rc) return rc;
+    if (stats->pitch < n || !(flags & POMDP_AUTO_RESET) || !(stats->discount == stats->discount)) return POMDP_E_BADARG;
+    if (k_steps == 0 || n == 0) return 0;
+    // the launches of pomdp_collect_synthetic with the Returns sink (traj_out.hip.h); the discount travels as its bit pattern
+    uint64_t bits;
+    memcpy(&bits, &stats->discount, 8);
+    const int64_t FUSE_MAX = fuse_max();
+    for (int64_t s = 0; s < k_steps; s += FUSE_MAX) {
+        const int c = (int)(k_steps - s < FUSE_MAX ? k_steps - s : FUSE_MAX);
+        rc = dispatch_env(env, params, [&](auto tag, const auto &p) {
+            using E = typename decltype(tag)::Env;
+            return launch_steps_fused<E>(p, state, reinterpret_cast<int32_t *>(stats->acc), stats->cnt,
+                                         reinterpret_cast<typename E::Reward *>(bits), nullptr, err, n, seed, seed, lane0,
+                                         t0 + (uint64_t)s, c, flags, stats->pitch, true, LAYOUT_RETURNS, stream);
+        });
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int pomdp_decode_packed(int env, const uint32_t *records, int64_t n, int64_t k_steps, int64_t pitch_in, int32_t *action,
+                        int32_t *ob, void *reward, uint8_t *done, int64_t pitch_out, void *stream)
+{
+    if (!records || !action || !ob || !reward || !done || n < 0 || k_steps < 0 || pitch_in < n || pitch_out < n ||
+        env < POMDP_ENV_ROCK || env > POMDP_ENV_NETWORK)
+        return POMDP_E_BADARG;
+    if (n == 0 || k_steps == 0) return 0;
+    const bool vec = ((reinterpret_cast<uintptr_t>(records) | reinterpret_cast<uintptr_t>(action) | reinterpret_cast<uintptr_t>(ob) |
+                       reinterpret_cast<uintptr_t>(reward)) & 15u) == 0 && (reinterpret_cast<uintptr_t>(done) & 3u) == 0 &&
+                     pitch_in % 4 == 0 && pitch_out % 4 == 0;
+    const int64_t items = (vec ? (n + 3) / 4 : n) * k_steps;
+    const int64_t b = (items + BLOCK - 1) / BLOCK;
+    const dim3 grid((unsigned)(b > 256 * 16 ? 256 * 16 : b));                   // 16 workgroups per CU, grid-stride beyond
+    if (vec)
+        hipLaunchKernelGGL(decode_packed_kernel<true>, grid, dim3(BLOCK), 0, (hipStream_t)stream, records, n, k_steps, pitch_in,
+                           (uint32_t *)action, (uint32_t *)ob, (uint32_t *)reward, done, pitch_out, env);
+    else
+        hipLaunchKernelGGL(decode_packed_kernel<false>, grid, dim3(BLOCK), 0, (hipStream_t)stream, records, n, k_steps, pitch_in,
+                           (uint32_t *)action, (uint32_t *)ob, (uint32_t *)reward, done, pitch_out, env);
+    return (int)hipGetLastError();
+}
+
+int pomdp_fuse_max(int v)
+{
+    const int old = g_fuse_max;
+    if (v >= 1) g_fuse_max = v > FUSE_MAX_LIMIT ? FUSE_MAX_LIMIT : v;
+    return old;
 }
 
 double pomdp_packed_reward(int env, uint32_t code)

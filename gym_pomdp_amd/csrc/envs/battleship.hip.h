@@ -40,6 +40,8 @@ struct BattleShipEnv {
     static __device__ __forceinline__ int n_actions(const Params &p) { return p.x_size * p.y_size; }
     // the reward byte of a Packed trajectory record (traj_out.hip.h): the reward itself (-10 .. cells - 1 <= 121), an int8
     static __device__ __forceinline__ uint32_t reward_code(Reward r) { return (uint32_t)(int)r; }
+    // ... and back, as the float64 the reference's callers add up (traj_out.hip.h: the Returns sink)
+    static __device__ __forceinline__ double code_reward(uint32_t code) { return (double)(int8_t)code; }
     static __device__ __forceinline__ int reset_ob(const Params &, const State &) { return 0; }   // battleship.py:131-137
     static __device__ __forceinline__ void load(State &st, const uint32_t *state, int64_t n, uint32_t i)
     {

@@ -41,6 +41,17 @@ struct NetworkEnv {
         const int kind = frac == 0.f ? 0 : (frac == .5f ? 2 : 1);
         return reward_code(kind, (int)f + (kind == 0 ? 0 : kind == 1 ? 1 : 3));
     }
+    // ... and back, as the float64 the reference computes — `reward -= .1` / `reward -= 2.5` on the integer base
+    // (network.py:87-92, 103, 110) — which is what its callers add up (traj_out.hip.h: the Returns sink); the reward
+    // COLUMN holds the float32 of this value
+    static __device__ __forceinline__ double code_reward(uint32_t code)
+    {
+        const int kind = (int)code / REWARD_BASES;
+        double r = (double)((int)code % REWARD_BASES);
+        if (kind == 1) r -= .1;
+        if (kind == 2) r -= 2.5;
+        return r;
+    }
     static __device__ __forceinline__ void load(State &st, const uint32_t *state, int64_t, uint32_t i) { st.w = ld_stream(state + i); }
     static __device__ __forceinline__ void store(const State &st, uint32_t *state, int64_t, uint32_t i, bool) { st_stream(state + i, st.w); }
 

@@ -81,6 +81,8 @@ struct RockEnv {
     static __device__ __forceinline__ int n_actions(const Params &p) { return 5 + p.num_rocks; }
     // the reward byte of a Packed trajectory record (traj_out.hip.h): the reward itself, an int8
     static __device__ __forceinline__ uint32_t reward_code(Reward r) { return (uint32_t)(int)r; }
+    // ... and back, as the float64 the reference's callers add up (traj_out.hip.h: the Returns sink)
+    static __device__ __forceinline__ double code_reward(uint32_t code) { return (double)(int8_t)code; }
     // the position tables preferred_mask reads; kernels that call it run this next to stage()
     static __device__ __forceinline__ void stage_policy(Shared &sh, const Params &p, int tid)
     {

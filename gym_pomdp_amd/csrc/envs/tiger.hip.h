@@ -26,6 +26,8 @@ struct TigerEnv {
     static __device__ __forceinline__ int n_actions(const Params &) { return 3; }
     // the reward byte of a Packed trajectory record (traj_out.hip.h): the reward itself, an int8
     static __device__ __forceinline__ uint32_t reward_code(Reward r) { return (uint32_t)(int)r; }
+    // ... and back, as the float64 the reference's callers add up (traj_out.hip.h: the Returns sink)
+    static __device__ __forceinline__ double code_reward(uint32_t code) { return (double)(int8_t)code; }
     static __device__ __forceinline__ void load(State &st, const uint32_t *state, int64_t, uint32_t i) { st.w = ld_stream(state + i); }
     static __device__ __forceinline__ void store(const State &st, uint32_t *state, int64_t, uint32_t i, bool) { st_stream(state + i, st.w); }
 

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
     const uint32_t last = SIMPLE ? (uint32_t)(BLOCK * LPT - 1) : (uint32_t)((uint64_t)(n - 1) - wg0);
     // rec = 0: every step overwrites the same n-element outputs (what the per-step launches do); rec = row pitch in
     // elements: step s writes row s of ob / reward / done and row s + 1 of action (row s being the actions it took)
-    LaneOut<L, typename Env::Reward> out(action, ob, reward, done, rec, wg0);
+    LaneOut<L, typename Env::Reward, LPT> out(action, ob, reward, done, rec, wg0);
     uint32_t *const state_w = state + wg0;
     constexpr bool COLS = L::ID == POMDP_LAYOUT_COLUMNS;     // only the column layout has a row of first actions / done flags to read
     uint32_t rel[LPT], glane[LPT];
@@ -55,6 +55,7 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
         if constexpr (has_next<Env>::value) Env::load_next(st[j], state_w, n, rc);   // once per launch, with the other words
         if constexpr (COLS) was_done[j] = auto_reset ? false : (ld_stream(done + wg0 + rc) != 0);
         else was_done[j] = false;
+        out.begin(j, rc);                                    // Returns: the lane's running statistics
     }
     using Fin = Finisher<Env, LPT, true>;
     constexpr bool quad_policy = quad_policy_of<Fin>::value;
@@ -172,9 +173,9 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
             ever_fresh[j] |= fresh[j];
             if (in_range[j]) {
                 uint32_t rcode = 0;
-                if constexpr (L::ID == POMDP_LAYOUT_PACKED) rcode = Env::reward_code(r[j]);
-                if constexpr (REC && L::ID == POMDP_LAYOUT_PACKED) out.put_record(rel[j], recv[j]);
-                else out.put(rel[j], a_cur[j], o[j], r[j], rcode, d[j]);
+                if constexpr (L::CODES && !REC) rcode = Env::reward_code(r[j]);
+                if constexpr (REC && L::CODES) out.put_record(j, rel[j], recv[j]);
+                else out.put(j, rel[j], a_cur[j], o[j], r[j], rcode, d[j]);
                 if (!valid[j] && !was_done[j] && err) atomicAdd(err, 1u);
             }
             a_cur[j] = a_next[j];
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
     // what it read; BattleShip's ship words only if some step of the launch dealt a new board)
 #pragma unroll
     for (int j = 0; j < LPT; ++j)
-        if (in_range[j]) Env::store(st[j], state_w, n, rel[j], ever_fresh[j]);
+        if (in_range[j]) { Env::store(st[j], state_w, n, rel[j], ever_fresh[j]); out.finish(j, rel[j], k_steps); }
 }
 
 // The fused RockSample loop with a thread owning four CONSECUTIVE lanes — a quad.  RockSample's word contract shares the
@@ -311,6 +312,7 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
     }
     // the state is the loop's carry: it reaches memory once
     TL(3);
+    out.finish(k_steps);
     st_stream4(state + l0, (uint32_t)st[0].s, (uint32_t)st[1].s, (uint32_t)st[2].s, (uint32_t)st[3].s);
     if (W == 2)
         st_stream4(state + n + l0, (uint32_t)((uint64_t)st[0].s >> 32), (uint32_t)((uint64_t)st[1].s >> 32),
@@ -425,12 +427,13 @@ __global__ __launch_bounds__(BLOCK) void tag_steps_quad_kernel(uint32_t *__restr
         const uint32_t r4[4] = {__float_as_uint(r[0]), __float_as_uint(r[1]), __float_as_uint(r[2]), __float_as_uint(r[3])};
         const uint32_t d4[4] = {(uint32_t)d[0], (uint32_t)d[1], (uint32_t)d[2], (uint32_t)d[3]};
         uint32_t rc[4] = {0, 0, 0, 0};
-        if constexpr (L::ID == POMDP_LAYOUT_PACKED) {
+        if constexpr (L::CODES) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) rc[j] = Env::reward_code(r[j]);
         }
         out.put(a_taken, a_next, o4, r4, rc, d4);
     }
+    out.finish(k_steps);
     st_stream4(state + l0, st[0].w, st[1].w, st[2].w, st[3].w);
 }
 
@@ -538,8 +541,8 @@ __global__ __launch_bounds__(BLOCK) void network_steps_quad_kernel(uint32_t *__r
             const uint4 h = stream_block(key, glane0 + (uint32_t)j, POMDP_STREAM_STEP, 0u);
             const int n_up = __popc(s0);
             if constexpr (SMALL) {
-                const uint32_t e = stab[s0];
-                nbf[j] = nbft[s0];
+                const uint32_t e = stab[s0 & all_up];                            // only 2^n_machines entries exist: a state from
+                nbf[j] = nbft[s0 & all_up];                                      // set_state() with stray upper bits stays inside
                 const uint32_t lb0 = e & 1023u, lb1 = __builtin_amdgcn_ubfe(e, 10u, 10u);
                 // the threshold of draw 0 / 1: entry 0 (no failed neighbour) or 1 of thr2, addressed by the byte offset in e
                 const uint32_t t0 = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(thr2) + __builtin_amdgcn_ubfe(e, 20u, 3u));
@@ -640,7 +643,7 @@ __global__ __launch_bounds__(BLOCK) void network_steps_quad_kernel(uint32_t *__r
                 int d;
                 Env::step_exact(sh, p, e, a_cur[j], key, glane0 + (uint32_t)j, o, r, d);
                 st[j] = e.w;
-                if constexpr (L::ID == POMDP_LAYOUT_PACKED) rc[j] = Env::reward_code(r);
+                if constexpr (L::CODES) rc[j] = Env::reward_code(r);
             } else {                                                           // network.py:101-112
                 const int a = a_cur[j], machine = (a >> 1) & 31;
                 const bool has_action = a < M2, reboot = has_action && (a & 1);
@@ -649,7 +652,7 @@ __global__ __launch_bounds__(BLOCK) void network_steps_quad_kernel(uint32_t *__r
                 const int up = (int)((sn >> machine) & 1u);                    // a rebooted machine is up: ob = truthful either way
                 o = has_action ? (truthful[j] ? up : 1 - up) : 2;
                 r = rtab[has_action ? 1 + (a & 1) : 0][base[j]];
-                if constexpr (L::ID == POMDP_LAYOUT_PACKED) rc[j] = Env::reward_code(has_action ? 1 + (a & 1) : 0, base[j]);
+                if constexpr (L::CODES) rc[j] = Env::reward_code(has_action ? 1 + (a & 1) : 0, base[j]);
                 st[j] = sn;
             }
             o4[j] = (uint32_t)o;
@@ -660,6 +663,7 @@ __global__ __launch_bounds__(BLOCK) void network_steps_quad_kernel(uint32_t *__r
         const uint32_t d4[4] = {0u, 0u, 0u, 0u};                               // network.py:113: never done
         out.put(a_taken, a_next, o4, r4, rc, d4);
     }
+    out.finish(k_steps);
     st_stream4(state + l0, st[0], st[1], st[2], st[3]);
 }
 
@@ -818,6 +822,7 @@ __global__ __launch_bounds__(BLOCK) void battleship_steps_quad_kernel(uint32_t *
         }
     }
     build_boards();
+    out.finish(k_steps);
 #pragma unroll
     for (int q = 0; q < MW; ++q) {
         st_stream4(state + (int64_t)q * n + l0, occ_lds[q][0][tid], occ_lds[q][1][tid], occ_lds[q][2][tid], occ_lds[q][3][tid]);
@@ -882,22 +887,24 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_generic_kernel(uint32_t *__r
             Env::reset_where(sh, p, st[j], d != 0, key, lane);                 // wave-convergent: every lane calls it
             o4[j] = (uint32_t)o;
             __builtin_memcpy(&r4[j], &r, 4);
-            if constexpr (L::ID == POMDP_LAYOUT_PACKED) rc[j] = Env::reward_code(r);
+            if constexpr (L::CODES) rc[j] = Env::reward_code(r);
             d4[j] = (uint32_t)(d != 0);
             a_next[j] = __umulhi(P[j], n_act);
             a_cur[j] = (int)a_next[j];
         }
         out.put(a_taken, a_next, o4, r4, rc, d4);
     }
+    out.finish(k_steps);
 #pragma unroll
     for (int j = 0; j < 4; ++j) Env::store(st[j], state, n, l0 + (uint32_t)j, true);
 }
 
 // the same as k launch_step_chain calls at t, t + 1, ..., in one launch.  gen_first: the launch derives the actions of
 // call counter t itself (and writes them to `action`) instead of reading them — the caller skips the policy launch.
-// L: the trajectory layout (traj_out.hip.h).  Blocked / Packed (trajectory collection only): `action` is the trajectory's
-// base — row-major, `rec` lanes per row —, ob / reward / done are ignored, auto-reset and the shared policy key are
-// required and every launch derives its first actions itself.
+// L: the trajectory layout (traj_out.hip.h).  Blocked / Packed / Narrow (trajectory collection only): `action` is the
+// trajectory's base — row-major, `rec` lanes per row —, ob / reward / done are ignored, auto-reset and the shared policy key
+// are required and every launch derives its first actions itself.  Returns<Env> (pomdp_collect_returns): `action` = the
+// statistics' double rows, `ob` = their int32 rows, `reward` = the discount's bit pattern, `rec` = their pitch.
 template <class Env, class L>
 static int launch_steps_fused_l(const typename Env::Params &p, uint32_t *state, int32_t *action, int32_t *ob,
                                 typename Env::Reward *reward, uint8_t *done, uint32_t *err, int64_t n, uint64_t seed,
@@ -907,11 +914,15 @@ static int launch_steps_fused_l(const typename Env::Params &p, uint32_t *state, 
     constexpr bool COLS = L::ID == POMDP_LAYOUT_COLUMNS;
     if (!state || !action || bad_range(n, lane0) || (lane0 & 3u) || k < 1) return POMDP_E_BADARG;
     if (COLS && (!ob || !reward || !done)) return POMDP_E_BADARG;
+    constexpr bool RETS = L::ID == LAYOUT_RETURNS;
     if (!COLS) {
         if (!(flags & POMDP_AUTO_RESET) || action_seed != seed || rec < n) return POMDP_E_BADARG;
         if (L::ID == POMDP_LAYOUT_BLOCKED && rec % TRAJ_BLOCK_LANES != 0) return POMDP_E_BADARG;
+        if (L::ID == POMDP_LAYOUT_NARROW && rec % 4 != 0) return POMDP_E_BADARG;
+        if (RETS && !ob) return POMDP_E_BADARG;
         gen_first = true;
-        ob = nullptr; reward = nullptr; done = nullptr;
+        if (!RETS) { ob = nullptr; reward = nullptr; }
+        done = nullptr;
     }
     if (n == 0) return 0;
     char lname[24] = "";
@@ -944,7 +955,7 @@ static int launch_steps_fused_l(const typename Env::Params &p, uint32_t *state, 
         quad_ok = quad_ok && ((reinterpret_cast<uintptr_t>(action) | reinterpret_cast<uintptr_t>(ob) | reinterpret_cast<uintptr_t>(reward)) & 15u) == 0 &&
                   (reinterpret_cast<uintptr_t>(done) & 3u) == 0;
     else
-        quad_ok = quad_ok && (reinterpret_cast<uintptr_t>(action) & 15u) == 0;
+        quad_ok = quad_ok && (reinterpret_cast<uintptr_t>(action) & 15u) == 0 && (!RETS || (reinterpret_cast<uintptr_t>(ob) & 15u) == 0);
     const dim3 qgrid((unsigned)(n / (4 * BLOCK)));
     bool launched = false;
     if constexpr (std::is_same<Env, TagEnv>::value) {
@@ -962,7 +973,7 @@ static int launch_steps_fused_l(const typename Env::Params &p, uint32_t *state, 
         }
     }
     if constexpr (has_next<Env>::value) {
-        if (quad_ok && n >= QUAD_MIN_BATTLESHIP && k <= 255) {
+        if (quad_ok && n >= QUAD_MIN_BATTLESHIP && k <= 256) {   // the pool keeps a lane's deal step in a byte
             note_fused("battleship_steps_quad_kernel", Env::NAME, lname);
             hipLaunchKernelGGL((battleship_steps_quad_kernel<Env::WORDS / 3, L>), qgrid, dim3(BLOCK), 0, (hipStream_t)stream, state, action,
                                ob, reward, done, n, make_key(seed, t), lane0, make_key(action_seed, t + 1), k, rec, gf, p);
@@ -971,11 +982,14 @@ static int launch_steps_fused_l(const typename Env::Params &p, uint32_t *state, 
     }
     if constexpr (std::is_same<Env, NetworkEnv>::value) {
         if (quad_ok && n >= QUAD_MIN_NETWORK) {
-            note_fused("network_steps_quad_kernel", "", COLS ? "" : lname + 2);
+            // named as a profiler shows the instantiation: <bytes of the machine set, layout, state-table form>
+            const bool small = p.n_machines <= 10;
+            snprintf(variant, sizeof variant, "%d, %s, %s", small ? 2 : (p.n_machines + 7) / 8, L::NAME, small ? "true" : "false");
+            note_fused("network_steps_quad_kernel", variant, "");
 #define POMDP_LAUNCH_NET(NB_)                                                                                            \
     hipLaunchKernelGGL((network_steps_quad_kernel<NB_, L>), qgrid, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob, reward, \
                        done, n, make_key(seed, t), lane0, make_key(action_seed, t + 1), k, rec, gf, p)
-            if (p.n_machines <= 10) {        // the state-table form (the reference's default has 10 machines)
+            if (small) {                     // the state-table form (the reference's default has 10 machines)
                 hipLaunchKernelGGL((network_steps_quad_kernel<2, L, true>), qgrid, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob,
                                    reward, done, n, make_key(seed, t), lane0, make_key(action_seed, t + 1), k, rec, gf, p);
             } else
@@ -1047,6 +1061,10 @@ int launch_steps_fused(const typename Env::Params &p, uint32_t *state, int32_t *
         return launch_steps_fused_l<Env, Blocked>(p, state, action, ob, reward, done, err, n, seed, action_seed, lane0, t, k, flags, rec, gen_first, stream);
     case POMDP_LAYOUT_PACKED:
         return launch_steps_fused_l<Env, Packed>(p, state, action, ob, reward, done, err, n, seed, action_seed, lane0, t, k, flags, rec, gen_first, stream);
+    case POMDP_LAYOUT_NARROW:
+        return launch_steps_fused_l<Env, Narrow>(p, state, action, ob, reward, done, err, n, seed, action_seed, lane0, t, k, flags, rec, gen_first, stream);
+    case LAYOUT_RETURNS:
+        return launch_steps_fused_l<Env, Returns<Env>>(p, state, action, ob, reward, done, err, n, seed, action_seed, lane0, t, k, flags, rec, gen_first, stream);
     default: return POMDP_E_BADARG;
     }
 }

@@ -5,8 +5,11 @@
 // are struct-of-arrays columns in HBM, so every access of a wave is one coalesced
 // 256-byte (int32) or 64-byte (done) segment.  Lookup tables (RockSample's rock-id
 // grid, rock coordinates and sensor thresholds) are staged from the kernarg segment
-// into LDS once per workgroup.  No MFMA: the path is integer / branch work, bounded
-// by HBM traffic (21 B per RockSample step) and by Philox ALU throughput.
+// into LDS once per workgroup.  No MFMA: the path is integer / branch work.  What bounds
+// a launch depends on what it writes: one step per launch moves 21 B per RockSample
+// lane (HBM latency / bandwidth); a fused launch writing int32 columns 13 B per
+// lane-step (the store stream); one writing 4-byte records or only per-lane returns
+// is bound by VALU issue — Philox and the lane step.
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC (see __graft_entry__.build()).
 #include <hip/hip_runtime.h>
@@ -422,6 +425,12 @@ constexpr int64_t QUAD_MIN_ROCK = POMDP_QUAD_MIN_LANES, QUAD_MIN_STOCHROCK = POM
 constexpr int64_t QUAD_MIN_ROCK = 3 << 18, QUAD_MIN_STOCHROCK = 1 << 19, QUAD_MIN_TAG = 1 << 19, QUAD_MIN_GENERIC = 1 << 19,
                   QUAD_MIN_NETWORK = 1 << 19, QUAD_MIN_BATTLESHIP = 1 << 16;
 #endif
+
+// steps per fused launch of the C-side drivers (pomdp_fuse_max; defined in api.hip).  One place instead of a constant per
+// driver; a launch's fixed cost is paid once per this many steps, results never depend on it
+extern int g_fuse_max;
+constexpr int FUSE_MAX_LIMIT = 256;                            // BattleShip's board pool keeps a lane's deal step in a byte
+static inline int64_t fuse_max() { return (int64_t)g_fuse_max; }
 
 // which kernel the calling thread's most recent fused launch picked (pomdp_last_fused_kernel: bench.py names the kernel
 // it timed from this instead of guessing the launcher's choice; defined in api.hip)

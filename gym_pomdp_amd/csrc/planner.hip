@@ -642,7 +642,7 @@ static int launch_heuristic_steps(const typename Env::Params &p, uint32_t *state
 {
     if (n == 0) return 0;
     static const pomdp_returns NO_RETURNS = {0.0, nullptr, nullptr, nullptr};
-    constexpr int64_t FUSE_MAX = 64;                      // steps per launch
+    const int64_t FUSE_MAX = fuse_max();                  // steps per launch
     for (int64_t s = 0; s < k_steps; s += FUSE_MAX) {
         const int c = (int)(k_steps - s < FUSE_MAX ? k_steps - s : FUSE_MAX);
         bool ring = false;

@@ -16,17 +16,30 @@
 //            4 bytes per lane-step instead of 13: one 16-byte store per thread-step of a quad-per-thread loop, and the
 //            fused loops become bound by instruction issue instead of by the write stream.
 //
-// Blocked and Packed rows hold the action TAKEN at step s (row s of every field belongs to step s); they have no row of
-// "next actions" — a launch derives its first actions from the synthetic policy itself (they are a function of (seed,
+//   Narrow   the Packed record's four bytes as four typed planes: row s = action uint8[pitch] | ob uint8[pitch] | reward code
+//            (u)int8[pitch] | done uint8[pitch].  The same 4 bytes per lane-step, and every plane of every step is an array a
+//            consumer reads in place — nothing to decode.  A quad-per-thread loop transposes its four records (eight
+//            v_perm_b32) and stores four bytes per plane: four 256-byte pieces per wave-step instead of one 1 KB piece.
+//   Returns  no trajectory at all: the reduction the reference's callers apply to the stream — r += discount * rw; discount
+//            *= .95 per step, one return per episode (network.py:175-191, rock.py:553-575) — kept per lane in registers
+//            across the launch and written once when it ends (include/pomdp_hip.h: pomdp_collect_returns).
+//
+// Blocked, Packed and Narrow rows hold the action TAKEN at step s (row s of every field belongs to step s); they have no row
+// of "next actions" — a launch derives its first actions from the synthetic policy itself (they are a function of (seed,
 // lane, t) only), which is what the Columns layout's gen_first launches do as well.
 #pragma once
 #include "envs.hip.h"
 
 namespace pomdp {
 
-struct Columns { static constexpr int ID = POMDP_LAYOUT_COLUMNS; static constexpr const char *NAME = "Columns"; };
-struct Blocked { static constexpr int ID = POMDP_LAYOUT_BLOCKED; static constexpr const char *NAME = "Blocked"; };
-struct Packed  { static constexpr int ID = POMDP_LAYOUT_PACKED;  static constexpr const char *NAME = "Packed"; };
+// CODES: the sink reads the step's reward code (Env::reward_code) — the loops compute it only then
+constexpr int LAYOUT_RETURNS = 100;                         // launcher-internal: not a trajectory layout of the ABI
+struct Columns { static constexpr int ID = POMDP_LAYOUT_COLUMNS; static constexpr const char *NAME = "Columns"; static constexpr bool CODES = false; };
+struct Blocked { static constexpr int ID = POMDP_LAYOUT_BLOCKED; static constexpr const char *NAME = "Blocked"; static constexpr bool CODES = false; };
+struct Packed  { static constexpr int ID = POMDP_LAYOUT_PACKED;  static constexpr const char *NAME = "Packed";  static constexpr bool CODES = true; };
+struct Narrow  { static constexpr int ID = POMDP_LAYOUT_NARROW;  static constexpr const char *NAME = "Narrow";  static constexpr bool CODES = true; };
+// Env: whose reward codes the sink turns back into the reference's float64 rewards (Env::code_reward)
+template <class Env> struct Returns { static constexpr int ID = LAYOUT_RETURNS; static constexpr const char *NAME = "Returns"; static constexpr bool CODES = true; using E = Env; };
 
 constexpr int TRAJ_BLOCK_LANES = 256;                       // lanes per block of the Blocked layout = one wave's four per thread
 constexpr int TRAJ_BLOCK_BYTES = 13 * TRAJ_BLOCK_LANES;     // 3 x 1024 bytes of int32 / float + 256 done bytes
@@ -93,6 +106,7 @@ template <> struct QuadOut<Columns> {
         }
         put(a, a_next, o, r, r, d);
     }
+    __device__ __forceinline__ void finish(int) {}
 };
 
 template <> struct QuadOut<Blocked> {
@@ -126,6 +140,7 @@ template <> struct QuadOut<Blocked> {
         }
         put(a, a_next, o, r, r, d);
     }
+    __device__ __forceinline__ void finish(int) {}
 };
 
 template <> struct QuadOut<Packed> {
@@ -146,45 +161,153 @@ template <> struct QuadOut<Packed> {
         st_stream4(w, r[0], r[1], r[2], r[3]);
         w += rec;
     }
+    __device__ __forceinline__ void finish(int) {}
 };
 
-// ---- a thread whose lanes are 256 apart (steps_kernel: lane j of a thread is base + tid + 256 j) ------------------------
-// wg0: the workgroup's first lane within the shard (a multiple of 256); rel = tid + 256 j.
-template <class L, class RT> struct LaneOut;
+template <> struct QuadOut<Narrow> {
+    uint32_t *w;                                            // the thread's four bytes of the row's action plane
+    int64_t plane, row;                                     // in 32-bit words: a plane is `pitch` bytes, a row four planes
+    __device__ __forceinline__ QuadOut(void *base, void *, void *, void *, int64_t rec_, uint32_t l0)
+        : w(reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(base) + l0)), plane(rec_ / 4), row(rec_) {}
+    __device__ __forceinline__ u32x4 first(int, uint32_t glane0, const RngKey &akey0, uint32_t n_act) { return gen_actions4(glane0, akey0, n_act); }
+    // 4 x 4 byte transpose: byte b of record j -> byte j of plane b (v_perm_b32: selector 0-3 = bytes of the second
+    // operand, 4-7 = bytes of the first)
+    __device__ __forceinline__ void put_records(const uint32_t (&r)[4], const uint32_t (&)[4])
+    {
+        const uint32_t t0 = __builtin_amdgcn_perm(r[1], r[0], 0x05010400u), t1 = __builtin_amdgcn_perm(r[1], r[0], 0x07030602u);
+        const uint32_t t2 = __builtin_amdgcn_perm(r[3], r[2], 0x05010400u), t3 = __builtin_amdgcn_perm(r[3], r[2], 0x07030602u);
+        st_stream(w, __builtin_amdgcn_perm(t2, t0, 0x05040100u));
+        st_stream(w + plane, __builtin_amdgcn_perm(t2, t0, 0x07060302u));
+        st_stream(w + 2 * plane, __builtin_amdgcn_perm(t3, t1, 0x05040100u));
+        st_stream(w + 3 * plane, __builtin_amdgcn_perm(t3, t1, 0x07060302u));
+        w += row;
+    }
+    __device__ __forceinline__ void put(const uint32_t (&a_cur)[4], const uint32_t (&)[4], const uint32_t (&o)[4],
+                                        const uint32_t (&)[4], const uint32_t (&rc)[4], const uint32_t (&d)[4])
+    {
+        st_stream(w, a_cur[0] | (a_cur[1] << 8) | (a_cur[2] << 16) | (a_cur[3] << 24));
+        st_stream(w + plane, o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24));
+        st_stream(w + 2 * plane, (rc[0] & 0xFFu) | ((rc[1] & 0xFFu) << 8) | ((rc[2] & 0xFFu) << 16) | (rc[3] << 24));
+        st_stream(w + 3 * plane, d[0] | (d[1] << 8) | (d[2] << 16) | (d[3] << 24));
+        w += row;
+    }
+    __device__ __forceinline__ void finish(int) {}
+};
 
-template <class RT> struct LaneOut<Columns, RT> {
+// The workgroup's table of the rewards its env's codes stand for, as the float64 values the reference's callers add up
+// (Env::code_reward).  Filled by the sinks' constructors — every fused loop constructs its sink before the barrier that
+// follows its table staging, and reads it only inside the step loop.
+template <class Env>
+static __device__ __forceinline__ double (&reward_f64_lds())[256]
+{
+    __shared__ double t[256];
+    return t;
+}
+
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+template <class Env> struct QuadOut<Returns<Env>> {
+    double *acc_w;
+    uint32_t *cnt_w;
+    int64_t pitch;
+    double discount;
+    double ret[4], disc[4], ret_done[4], ret_sum[4];
+    uint32_t episodes[4];
+    // acc: double [4][pitch], cnt: int32 [2][pitch] (include/pomdp_hip.h: pomdp_return_stats); the discount rides in the slot
+    // of the reward pointer as its bit pattern (the kernels' signatures are the trajectory sinks')
+    __device__ __forceinline__ QuadOut(void *acc, void *cnt, void *discount_bits, void *, int64_t pitch_, uint32_t l0)
+        : acc_w(reinterpret_cast<double *>(acc) + l0), cnt_w(reinterpret_cast<uint32_t *>(cnt) + l0), pitch(pitch_)
+    {
+        const uint64_t bits = reinterpret_cast<uint64_t>(discount_bits);
+        __builtin_memcpy(&discount, &bits, 8);
+        reward_f64_lds<Env>()[threadIdx.x & 255u] = Env::code_reward(threadIdx.x & 255u);
+        auto row = [&](int q, double (&v)[4]) {
+            const f64x2 lo = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(acc_w + q * pitch));
+            const f64x2 hi = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(acc_w + q * pitch) + 1);
+            v[0] = lo[0]; v[1] = lo[1]; v[2] = hi[0]; v[3] = hi[1];
+        };
+        row(0, ret); row(1, disc); row(2, ret_done); row(3, ret_sum);
+        const u32x4 e = ld_stream4(cnt_w);
+        episodes[0] = e[0]; episodes[1] = e[1]; episodes[2] = e[2]; episodes[3] = e[3];
+    }
+    __device__ __forceinline__ u32x4 first(int, uint32_t glane0, const RngKey &akey0, uint32_t n_act) { return gen_actions4(glane0, akey0, n_act); }
+    // r += discount * rw; discount *= _discount (rock.py:569-570, network.py:186-187) — separate multiply and add; a done step
+    // banks the episode's return and the next one starts at 0 / 1
+    __device__ __forceinline__ void add(int j, uint32_t rcode, bool done)
+    {
+#pragma clang fp contract(off)
+        const double term = disc[j] * reward_f64_lds<Env>()[rcode & 0xFFu];
+        const double total = ret[j] + term;
+        const double banked = ret_sum[j] + total;
+        ret_done[j] = done ? total : ret_done[j];
+        ret_sum[j] = done ? banked : ret_sum[j];
+        ret[j] = done ? 0.0 : total;
+        disc[j] = done ? 1.0 : disc[j] * discount;
+        episodes[j] += (uint32_t)done;
+    }
+    __device__ __forceinline__ void put_records(const uint32_t (&r)[4], const uint32_t (&)[4])
+    {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) add(j, r[j] >> 16, r[j] > 0x00FFFFFFu);     // the done byte is 0 or 1
+    }
+    __device__ __forceinline__ void put(const uint32_t (&)[4], const uint32_t (&)[4], const uint32_t (&)[4],
+                                        const uint32_t (&)[4], const uint32_t (&rc)[4], const uint32_t (&d)[4])
+    {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) add(j, rc[j], d[j] != 0u);
+    }
+    __device__ __forceinline__ void finish(int k_steps)
+    {
+        auto row = [&](int q, const double (&v)[4]) {
+            __builtin_nontemporal_store(f64x2{v[0], v[1]}, reinterpret_cast<f64x2 *>(acc_w + q * pitch));
+            __builtin_nontemporal_store(f64x2{v[2], v[3]}, reinterpret_cast<f64x2 *>(acc_w + q * pitch) + 1);
+        };
+        row(0, ret); row(1, disc); row(2, ret_done); row(3, ret_sum);
+        st_stream4(cnt_w, episodes[0], episodes[1], episodes[2], episodes[3]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)                          // steps += k: no value comes back, nothing to wait for
+            (void)__hip_atomic_fetch_add(cnt_w + pitch + j, (uint32_t)k_steps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+};
+
+// ---- a thread whose lanes are 256 apart (steps_kernel: lane j of a thread is base + tid + 256 j, j < LPT) ----------------
+// wg0: the workgroup's first lane within the shard (a multiple of 256); rel = tid + 256 j.  begin(j, rel): before the loop,
+// with the lane's (clamped) index; put(j, rel, ...): one step's results of an in-range lane; finish(j, rel, k): after the loop.
+template <class L, class RT, int LPT> struct LaneOut;
+
+template <class RT, int LPT> struct LaneOut<Columns, RT, LPT> {
     int32_t *action_w, *ob_w;
     RT *reward_w;
     uint8_t *done_w;
     int64_t rec;
-    static constexpr bool HAS_ACTION_ROWS = true;
     __device__ __forceinline__ LaneOut(void *action, void *ob, void *reward, void *done, int64_t rec_, uint32_t wg0)
         : action_w(reinterpret_cast<int32_t *>(action) + wg0), ob_w(reinterpret_cast<int32_t *>(ob) + wg0),
           reward_w(reinterpret_cast<RT *>(reward) + wg0), done_w(reinterpret_cast<uint8_t *>(done) + wg0), rec(rec_) {}
+    __device__ __forceinline__ void begin(int, uint32_t) {}
     __device__ __forceinline__ int load_first(uint32_t rel) const { return ld_stream(action_w + rel); }
     __device__ __forceinline__ void store_first(uint32_t rel, int a) const { st_stream(action_w + rel, (int32_t)a); }
     __device__ __forceinline__ void first_done() { action_w += rec; }                  // row 0 of `action` is behind us
     __device__ __forceinline__ void put_next_action(uint32_t rel, int a_next) const { st_stream(action_w + rel, (int32_t)a_next); }
-    __device__ __forceinline__ void put(uint32_t rel, int, int o, RT r, uint32_t, int d) const
+    __device__ __forceinline__ void put(int, uint32_t rel, int, int o, RT r, uint32_t, int d)
     {
         st_stream(ob_w + rel, (int32_t)o);
         st_stream(reward_w + rel, r);
         st_stream(done_w + rel, (uint8_t)d);
     }
     __device__ __forceinline__ void next_row() { action_w += rec; ob_w += rec; reward_w += rec; done_w += rec; }
+    __device__ __forceinline__ void finish(int, uint32_t, int) {}
 };
 
-template <class RT> struct LaneOut<Blocked, RT> {
+template <class RT, int LPT> struct LaneOut<Blocked, RT, LPT> {
     uint8_t *w;                                             // block of the workgroup's sub-batch 0, action section
     int64_t row_bytes;
-    static constexpr bool HAS_ACTION_ROWS = false;
     __device__ __forceinline__ LaneOut(void *base, void *, void *, void *, int64_t rec_, uint32_t wg0)
         : w(reinterpret_cast<uint8_t *>(base) + (int64_t)(wg0 >> 8) * TRAJ_BLOCK_BYTES), row_bytes(rec_ * 13) {}
+    __device__ __forceinline__ void begin(int, uint32_t) {}
     __device__ __forceinline__ int load_first(uint32_t) const { return 0; }
     __device__ __forceinline__ void store_first(uint32_t, int) const {}
     __device__ __forceinline__ void first_done() {}
     __device__ __forceinline__ void put_next_action(uint32_t, int) const {}
-    __device__ __forceinline__ void put(uint32_t rel, int a_cur, int o, RT r, uint32_t, int d) const
+    __device__ __forceinline__ void put(int, uint32_t rel, int a_cur, int o, RT r, uint32_t, int d)
     {
         uint8_t *b = w + (rel >> 8) * (uint32_t)TRAJ_BLOCK_BYTES;                      // sub-batch j's block
         const uint32_t i = rel & 255u;
@@ -194,24 +317,99 @@ template <class RT> struct LaneOut<Blocked, RT> {
         st_stream(b + 3072 + i, (uint8_t)d);
     }
     __device__ __forceinline__ void next_row() { w += row_bytes; }
+    __device__ __forceinline__ void finish(int, uint32_t, int) {}
 };
 
-template <class RT> struct LaneOut<Packed, RT> {
+template <class RT, int LPT> struct LaneOut<Packed, RT, LPT> {
     uint32_t *w;
     int64_t rec;
-    static constexpr bool HAS_ACTION_ROWS = false;
     __device__ __forceinline__ LaneOut(void *base, void *, void *, void *, int64_t rec_, uint32_t wg0)
         : w(reinterpret_cast<uint32_t *>(base) + wg0), rec(rec_) {}
+    __device__ __forceinline__ void begin(int, uint32_t) {}
     __device__ __forceinline__ int load_first(uint32_t) const { return 0; }
     __device__ __forceinline__ void store_first(uint32_t, int) const {}
     __device__ __forceinline__ void first_done() {}
     __device__ __forceinline__ void put_next_action(uint32_t, int) const {}
-    __device__ __forceinline__ void put(uint32_t rel, int a_cur, int o, RT, uint32_t rcode, int d) const
+    __device__ __forceinline__ void put(int, uint32_t rel, int a_cur, int o, RT, uint32_t rcode, int d)
     {
         st_stream(w + rel, pack_record((uint32_t)a_cur & 0xFFu, (uint32_t)o & 0xFFu, rcode, (uint32_t)(d != 0)));
     }
-    __device__ __forceinline__ void put_record(uint32_t rel, uint32_t record) const { st_stream(w + rel, record); }
+    __device__ __forceinline__ void put_record(int, uint32_t rel, uint32_t record) { st_stream(w + rel, record); }
     __device__ __forceinline__ void next_row() { w += rec; }
+    __device__ __forceinline__ void finish(int, uint32_t, int) {}
+};
+
+template <class RT, int LPT> struct LaneOut<Narrow, RT, LPT> {
+    uint8_t *w;                                             // the workgroup's first byte of the row's action plane
+    int64_t pitch;
+    __device__ __forceinline__ LaneOut(void *base, void *, void *, void *, int64_t rec_, uint32_t wg0)
+        : w(reinterpret_cast<uint8_t *>(base) + wg0), pitch(rec_) {}
+    __device__ __forceinline__ void begin(int, uint32_t) {}
+    __device__ __forceinline__ int load_first(uint32_t) const { return 0; }
+    __device__ __forceinline__ void store_first(uint32_t, int) const {}
+    __device__ __forceinline__ void first_done() {}
+    __device__ __forceinline__ void put_next_action(uint32_t, int) const {}
+    __device__ __forceinline__ void put(int, uint32_t rel, int a_cur, int o, RT, uint32_t rcode, int d)
+    {
+        st_stream(w + rel, (uint8_t)a_cur);
+        st_stream(w + pitch + rel, (uint8_t)o);
+        st_stream(w + 2 * pitch + rel, (uint8_t)rcode);
+        st_stream(w + 3 * pitch + rel, (uint8_t)(d != 0));
+    }
+    __device__ __forceinline__ void put_record(int j, uint32_t rel, uint32_t record)
+    {
+        put(j, rel, (int)(record & 0xFFu), (int)((record >> 8) & 0xFFu), RT(0), record >> 16, (int)(record >> 24));
+    }
+    __device__ __forceinline__ void next_row() { w += 4 * pitch; }
+    __device__ __forceinline__ void finish(int, uint32_t, int) {}
+};
+
+template <class Env, class RT, int LPT> struct LaneOut<Returns<Env>, RT, LPT> {
+    double *acc_w;
+    uint32_t *cnt_w;
+    int64_t pitch;
+    double discount;
+    double ret[LPT], disc[LPT], ret_done[LPT], ret_sum[LPT];
+    uint32_t episodes[LPT];
+    __device__ __forceinline__ LaneOut(void *acc, void *cnt, void *discount_bits, void *, int64_t pitch_, uint32_t wg0)
+        : acc_w(reinterpret_cast<double *>(acc) + wg0), cnt_w(reinterpret_cast<uint32_t *>(cnt) + wg0), pitch(pitch_)
+    {
+        const uint64_t bits = reinterpret_cast<uint64_t>(discount_bits);
+        __builtin_memcpy(&discount, &bits, 8);
+        reward_f64_lds<Env>()[threadIdx.x & 255u] = Env::code_reward(threadIdx.x & 255u);
+    }
+    __device__ __forceinline__ void begin(int j, uint32_t rel)
+    {
+        ret[j] = ld_stream(acc_w + rel); disc[j] = ld_stream(acc_w + pitch + rel);
+        ret_done[j] = ld_stream(acc_w + 2 * pitch + rel); ret_sum[j] = ld_stream(acc_w + 3 * pitch + rel);
+        episodes[j] = ld_stream(cnt_w + rel);
+    }
+    __device__ __forceinline__ int load_first(uint32_t) const { return 0; }
+    __device__ __forceinline__ void store_first(uint32_t, int) const {}
+    __device__ __forceinline__ void first_done() {}
+    __device__ __forceinline__ void put_next_action(uint32_t, int) const {}
+    __device__ __forceinline__ void put(int j, uint32_t, int, int, RT, uint32_t rcode, int d)
+    {
+#pragma clang fp contract(off)
+        const bool done = d != 0;
+        const double term = disc[j] * reward_f64_lds<Env>()[rcode & 0xFFu];
+        const double total = ret[j] + term;
+        const double banked = ret_sum[j] + total;
+        ret_done[j] = done ? total : ret_done[j];
+        ret_sum[j] = done ? banked : ret_sum[j];
+        ret[j] = done ? 0.0 : total;
+        disc[j] = done ? 1.0 : disc[j] * discount;
+        episodes[j] += (uint32_t)done;
+    }
+    __device__ __forceinline__ void put_record(int j, uint32_t rel, uint32_t record) { put(j, rel, 0, 0, RT(0), record >> 16, (int)(record >> 24)); }
+    __device__ __forceinline__ void next_row() {}
+    __device__ __forceinline__ void finish(int j, uint32_t rel, int k_steps)
+    {
+        st_stream(acc_w + rel, ret[j]); st_stream(acc_w + pitch + rel, disc[j]);
+        st_stream(acc_w + 2 * pitch + rel, ret_done[j]); st_stream(acc_w + 3 * pitch + rel, ret_sum[j]);
+        st_stream(cnt_w + rel, episodes[j]);
+        (void)__hip_atomic_fetch_add(cnt_w + pitch + rel, (uint32_t)k_steps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 };
 
 } // namespace pomdp

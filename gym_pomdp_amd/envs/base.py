@@ -591,8 +591,9 @@ class BatchedEnv(object):
         """The `out` dict of collect_synthetic(steps, layout=...).
         "columns" (the default ABI): action int32 [steps + 1, N], ob int32 [steps, N], reward [steps, N], done bool
         [steps, N] (and its uint8 view "done_u8"), carved from one allocation with staggered column starts.
-        "blocked" / "packed" (include/pomdp_hip.h: POMDP_LAYOUT_*; one write stream per step): {"layout", "traj": the raw
-        rows — uint8 [steps, pitch * 13] / int32 [steps, pitch] —, "pitch"}; decode_trajectory() gives the four columns."""
+        "blocked" / "packed" / "narrow" (include/pomdp_hip.h: POMDP_LAYOUT_*; one write stream per step): {"layout", "traj":
+        the raw rows — uint8 [steps, pitch * 13] / int32 [steps, pitch] / uint8 [steps, 4, pitch] —, "pitch"};
+        decode_trajectory() gives the four columns (narrow: its typed planes, in place)."""
         n = self.batch_size
         if layout == "columns":
             a, o, r, d = staggered([((steps + 1, n), torch.int32), ((steps, n), torch.int32), ((steps, n), self._reward.dtype),
@@ -604,7 +605,10 @@ class BatchedEnv(object):
         if layout == "packed":
             pitch = -(-n // 4) * 4
             return {"layout": "packed", "pitch": pitch, "traj": torch.zeros((steps, pitch), dtype=torch.int32, device=self.device)}
-        raise ValueError("unknown trajectory layout %r (columns, blocked, packed)" % (layout,))
+        if layout == "narrow":
+            pitch = -(-n // 16) * 16
+            return {"layout": "narrow", "pitch": pitch, "traj": torch.zeros((steps, 4, pitch), dtype=torch.uint8, device=self.device)}
+        raise ValueError("unknown trajectory layout %r (columns, blocked, packed, narrow)" % (layout,))
 
     def packed_reward_table(self):
         """reward_code byte of a packed record -> the reward the columns hold (pomdp_packed_reward), as a [256] tensor of
@@ -616,10 +620,14 @@ class BatchedEnv(object):
             t = self._packed_reward_table = torch.tensor(vals, dtype=torch.float64).to(self._reward.dtype).to(self.device)
         return t
 
-    def decode_trajectory(self, out, steps=None):
-        """The four columns of a collected trajectory whatever its layout: {"action": int32 [steps, N] (the action taken at
-        each step), "ob": int32, "reward": this env's reward dtype, "done": bool}.  Blocked: strided views of the rows (no
-        copy); packed: unpacked into new tensors (the reward through packed_reward_table())."""
+    def decode_trajectory(self, out, steps=None, into=None):
+        """The four columns of a collected trajectory whatever its layout: {"action" (the action taken at each step), "ob",
+        "reward", "done"}, each [steps, N].
+        columns: the buffers themselves.  blocked: int32 / reward-dtype / bool COPIES gathered from the 256-lane blocks.
+        packed: int32 / reward-dtype / bool columns written by ONE device pass over the records (pomdp_decode_packed: 4 bytes
+        read, 13 written per lane-step) — into `into` (a trajectory_buffers(steps) dict; rows 0 .. steps - 1 of its
+        "action") when given.  narrow: the planes themselves, no copy — action / ob uint8, done bool, reward int8 (the
+        reward itself; Network: its values through packed_reward_table(), a gather)."""
         layout = out.get("layout", "columns")
         n = self.batch_size
         if layout == "columns":
@@ -632,10 +640,46 @@ class BatchedEnv(object):
             col = lambda lo, dt: b[:, :, lo:lo + 1024].view(dt).reshape(k, -1)[:, :n]                     # noqa: E731
             return {"action": col(0, torch.int32), "ob": col(1024, torch.int32), "reward": col(2048, self._reward.dtype),
                     "done": b[:, :, 3072:].reshape(k, -1)[:, :n].view(torch.bool)}
-        w = traj[:, :n]
-        code = (w >> 16) & 0xFF
-        return {"action": w & 0xFF, "ob": (w >> 8) & 0xFF, "reward": self.packed_reward_table()[code.long()],
-                "done": ((w >> 24) & 1).to(torch.bool)}
+        if layout == "narrow":
+            rw = traj[:, 2, :n]
+            rw = self.packed_reward_table()[rw.long()] if self.env_name == "network" else rw.view(torch.int8)
+            return {"action": traj[:, 0, :n], "ob": traj[:, 1, :n], "reward": rw, "done": traj[:, 3, :n].view(torch.bool)}
+        if into is None:
+            into = self.trajectory_buffers(k)
+        if into["ob"].shape[0] < k or into["ob"].shape[1] != n:
+            raise ValueError("decode_trajectory: `into` does not have the shapes of trajectory_buffers(%d)" % k)
+        with torch.cuda.device(self.device):
+            rc = self._lib.pomdp_decode_packed(_native.ENV_KIND[self.env_name], traj.data_ptr(), n, k, int(out["pitch"]),
+                                               into["action"].data_ptr(), into["ob"].data_ptr(), into["reward"].data_ptr(),
+                                               into["done_u8"].data_ptr(), n, self._stream())
+            _native.check(rc, "pomdp_decode_packed")
+        return {"action": into["action"][:k], "ob": into["ob"][:k], "reward": into["reward"][:k], "done": into["done"][:k]}
+
+    def collect_returns(self, steps, stats=None, discount=None):
+        """`steps` consecutive step() calls under the synthetic uniform policy with NOTHING kept per step but the reduction
+        the reference's callers apply to the stream (pomdp_collect_returns): per lane `r += discount * rw; discount *=
+        _discount`, the return of every finished episode banked (network.py:175-191, rock.py:553-575).  Same policy, same
+        draws and same final state as collect_synthetic(steps).  `stats`: a gym_pomdp_amd.EpisodeStats to continue
+        (default: a fresh one with the env's `_discount`).  Returns it.  Asynchronous."""
+        if not self._has_reset:
+            raise AttributeError("%s: collect before reset()" % type(self).__name__)
+        if not self.auto_reset:
+            raise ValueError("collect_returns needs auto_reset=True")
+        self._check_driver_use("collect_returns")
+        if stats is None:
+            from ..history import EpisodeStats
+            stats = EpisodeStats(self, discount)
+        elif stats._n != self.batch_size or stats.acc.device != self.device:
+            raise ValueError("collect_returns: `stats` belongs to another batch")
+        steps = int(steps)
+        t0 = self._t
+        self._t = t0 + steps
+        with torch.cuda.device(self.device):
+            rc = self._lib.pomdp_collect_returns(_native.ENV_KIND[self.env_name], self._params_ref, self._ptrs[0], stats._ref,
+                                                 self._ptrs[4], self.batch_size, self._seed, self.lane_offset, t0, steps,
+                                                 _native.POMDP_AUTO_RESET, self._stream())
+            _native.check(rc, "pomdp_collect_returns")
+        return stats
 
     def _check_driver_use(self, what):
         """The C-side episode loops advance the packed state only: they know nothing of RockSample's side statistics
@@ -654,8 +698,8 @@ class BatchedEnv(object):
         next call's), "ob": int32 [steps, N], "reward": [steps, N], "done": bool [steps, N]} — row s equals what
         synthetic_actions() + step() return at that call.  The batched form of the reference callers' episode
         loops (rock.py:553-575); up to 64 steps per launch, auto_reset envs only.  `out`: a dict from an earlier call
-        to write into.  `layout` (default: `out`'s, else "columns"): "blocked" / "packed" write the same information as one
-        stream per step (pomdp_collect_layout; trajectory_buffers, decode_trajectory).  Asynchronous."""
+        to write into.  `layout` (default: `out`'s, else "columns"): "blocked" / "packed" / "narrow" write the same
+        information as one stream per step (pomdp_collect_layout; trajectory_buffers, decode_trajectory).  Asynchronous."""
         if not self._has_reset:
             raise AttributeError("%s: collect before reset()" % type(self).__name__)
         if not self.auto_reset:
@@ -700,11 +744,11 @@ class BatchedEnv(object):
         return out
 
     def _collect_traj(self, steps, out, layout):
-        """collect_synthetic into a blocked / packed trajectory: pomdp_collect_traj with its arguments bound per buffer."""
+        """collect_synthetic into a blocked / packed / narrow trajectory: pomdp_collect_traj with its arguments bound per buffer."""
         n, traj, pitch = self.batch_size, out["traj"], int(out["pitch"])
-        row = pitch * 13 if layout == "blocked" else pitch
-        if not (traj.dim() == 2 and traj.shape[0] >= steps and traj.shape[1] == row and traj.is_contiguous() and pitch >= n
-                and traj.dtype == (torch.uint8 if layout == "blocked" else torch.int32)):
+        row = {"blocked": (pitch * 13,), "packed": (pitch,), "narrow": (4, pitch)}[layout]
+        if not (traj.shape[0] >= steps and tuple(traj.shape[1:]) == row and traj.is_contiguous() and pitch >= n
+                and traj.dtype == (torch.int32 if layout == "packed" else torch.uint8)):
             raise ValueError("collect_synthetic: `out` does not have the shape of trajectory_buffers(%d, %r)" % (steps, layout))
         key = (traj.data_ptr(), layout, pitch)
         bound = self._collect_cache.get(key)

@@ -16,6 +16,9 @@ import torch
 from . import _native
 
 
+RING_MAX_BYTES = 64 << 30        # a bounded RockSample history's window, (max_size + 1) x N bytes: refuse what cannot fit beside the env
+
+
 class Transition(NamedTuple):
     """rock.py:525-530, same field order.  Fields are int32[N] / uint8[N] tensors (python scalars when N == 1)."""
     observation: object
@@ -45,6 +48,11 @@ class History(object):
             [((n,), torch.int32), ((n,), torch.int32), ((n,), torch.int32), ((k, n), torch.int32), ((k, n), torch.int32),
              ((n if k else 0,), torch.int32)], dev)                                # move_ok: derived, bit j = total_move[j] >= 0, bit 16 + j = total_sample[j] > 0
         bounded = self._max_size is not None
+        if bounded and k and (self._max_size + 1) * n > RING_MAX_BYTES:
+            # the window is one byte per kept transition and lane (action in bits 0-4 — RockSample has at most 21 actions —
+            # next observation in bits 5-6, "observation was BAD" in bit 7), allocated up front
+            raise ValueError("History(max_size=%d) for %d lanes needs a %.1f GB window (one byte per transition and lane); "
+                             "the limit is %d GB" % (self._max_size, n, (self._max_size + 1) * n / 1e9, RING_MAX_BYTES >> 30))
         self.ring = torch.zeros((self._max_size + 1, n) if bounded and k else (0, n), dtype=torch.uint8, device=dev)
         self.head = torch.zeros(n if bounded else 0, dtype=torch.int32, device=dev)
         self._ptrs = _native.HistoryPtrs(self._size.data_ptr(), self.last_action.data_ptr(), self.last_ob.data_ptr(),
@@ -110,3 +118,37 @@ class Returns(object):
         self.ret_done = torch.full((n,), float("nan"), dtype=torch.float64, device=dev)
         self._ptrs = _native.Returns(self.discount, self.ret.data_ptr(), self.disc.data_ptr(), self.ret_done.data_ptr())
         self._ref = C.byref(self._ptrs)
+
+
+class EpisodeStats(object):
+    """What the reference's callers keep of a rollout under the random policy — `r += discount * rw; discount *= .95` per
+    step, one return per episode, `sum(eps) / len(eps)` over episodes (network.py:175-191, rock.py:553-575) — per lane and
+    device-resident, accumulated by env.collect_returns(steps, stats) with nothing written per step
+    (include/pomdp_hip.h: pomdp_return_stats).  Views of the two buffers: `ret`, `disc` (running, float64[N]), `ret_done`
+    (return of the lane's last finished episode; NaN until one finishes), `ret_sum` (sum of the returns of its finished
+    episodes), `episodes`, `steps` (int32[N]).  The reward is the reference's own float64 value (Network: base - .1 /
+    base - 2.5, not the float32 the reward column holds)."""
+
+    def __init__(self, env, discount=None):
+        n, dev = env.batch_size, env.device
+        self.discount = float(env._discount if discount is None else discount)
+        self.pitch = -(-n // 4) * 4
+        self.acc = torch.zeros((4, self.pitch), dtype=torch.float64, device=dev)
+        self.cnt = torch.zeros((2, self.pitch), dtype=torch.int32, device=dev)
+        self.ret, self.disc, self.ret_done, self.ret_sum = (self.acc[q, :n] for q in range(4))
+        self.episodes, self.steps = self.cnt[0, :n], self.cnt[1, :n]
+        self._n = n
+        self.reset()
+        self._ptrs = _native.ReturnStats(self.discount, self.acc.data_ptr(), self.cnt.data_ptr(), self.pitch)
+        self._ref = C.byref(self._ptrs)
+
+    def reset(self):
+        self.acc.zero_()
+        self.acc[1].fill_(1.0)
+        self.acc[2].fill_(float("nan"))
+        self.cnt.zero_()
+
+    def mean_return(self):
+        """sum(eps) / len(eps) over every finished episode of every lane (network.py:189) -> python float.  Synchronises."""
+        e = int(self.episodes.sum().item())
+        return float(self.ret_sum.sum().item()) / e if e else float("nan")

@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define POMDP_ABI_VERSION 11
+#define POMDP_ABI_VERSION 12
 
 enum {
     POMDP_E_BADARG = -1,     /* NULL pointer, n < 0, n + lane0 > 2^32 */
@@ -284,12 +284,16 @@ int pomdp_collect(const pomdp_collect_args *args, uint64_t t0, int64_t k_steps, 
  *       action | ob << 8 | reward_code << 16 | done << 24
  *   Actions and observations of every env fit a byte (Tag's obs_cells <= 255 is checked).  reward_code: the reward itself as
  *   an int8 for RockSample / StochasticRock (-100, -10, 0, 10), Tag (-1, -10, 10), BattleShip (-10 .. cells - 1) and Tiger
- *   (-100, -1, 10); Network: kind * 68 + base for reward = float32(base - cost), cost = 0 / .1 / 2.5 for kind 0 (no action) /
+ *   (-20, -1, 10: tiger.py:165-172); Network: kind * 68 + base for reward = float32(base - cost), cost = 0 / .1 / 2.5 for kind 0 (no action) /
  *   1 (ping) / 2 (reboot) (network.py:87-92, 103, 110).  pomdp_packed_reward() decodes either to the value COLUMNS holds.
- * Both: POMDP_AUTO_RESET required, lane0 a multiple of 4; rows on 16-byte boundaries and n a multiple of 1024 take the
+ * POMDP_LAYOUT_NARROW (ABI 12) — the PACKED record's four bytes as four typed planes, 4 bytes per lane-step and nothing to
+ *   decode.  traj: uint8 [k_steps][4][pitch], pitch a multiple of 4; plane 0 action uint8, 1 ob uint8, 2 reward_code (int8
+ *   reward; Network: the code above, an index for a 204-entry table), 3 done uint8 — each plane of each step a typed array
+ *   a consumer reads in place (plane p of step s starts (4 s + p) * pitch bytes into traj).
+ * All three: POMDP_AUTO_RESET required, lane0 a multiple of 4; rows on 16-byte boundaries and n a multiple of 1024 take the
  * launches that store 16 bytes per thread, anything else the general ones; `state` ends as after the last step; the next
  * call derives its first actions from (seed, lane, t) again, so nothing else carries over. */
-enum { POMDP_LAYOUT_COLUMNS = 0, POMDP_LAYOUT_BLOCKED = 1, POMDP_LAYOUT_PACKED = 2 };
+enum { POMDP_LAYOUT_COLUMNS = 0, POMDP_LAYOUT_BLOCKED = 1, POMDP_LAYOUT_PACKED = 2, POMDP_LAYOUT_NARROW = 3 };
 int pomdp_collect_layout(int env, const void *params, uint32_t *state, void *traj, uint32_t *err, int64_t n, uint64_t seed,
                          uint32_t lane0, uint64_t t0, int64_t k_steps, int64_t pitch, int layout, int flags, void *stream);
 /* the same with the per-batch arguments bound once (see pomdp_step_args) */
@@ -307,6 +311,47 @@ typedef struct pomdp_traj_args {
 int pomdp_collect_traj(const pomdp_traj_args *args, uint64_t t0, int64_t k_steps, void *stream);
 /* host-side: the reward a PACKED record's reward_code byte stands for (exactly the value the COLUMNS layout stores) */
 double pomdp_packed_reward(int env, uint32_t reward_code);
+
+/* PACKED records -> the default ABI's four columns, on the device (ABI 12): row s of `records` (uint32 [k_steps][pitch_in])
+ * becomes row s of action int32 / ob int32 / reward (int32 | float per env: pomdp_packed_reward of the code) / done uint8,
+ * each [k_steps][pitch_out], n lanes per row — the values pomdp_collect_synthetic writes into ob / reward / done and the
+ * action TAKEN at each step (its rows 0 .. k_steps - 1).  One pass, 4 bytes read and 13 written per lane-step; rows and
+ * columns on 16-byte boundaries (done: 4) with pitches that are multiples of 4 take the 16-byte accesses. */
+int pomdp_decode_packed(int env, const uint32_t *records, int64_t n, int64_t k_steps, int64_t pitch_in, int32_t *action,
+                        int32_t *ob, void *reward, uint8_t *done, int64_t pitch_out, void *stream);
+
+/* ---- episode returns without a trajectory (ABI 12) ------------------------------- */
+/* What the reference's callers do with the stream of `ob, rw, done, info = env.step(action)`: reduce it on the fly,
+ *     r += discount * rw; discount *= .95          per step      (network.py:186-187, rock.py:569-570)
+ *     eps.append(r) ... sum(eps) / len(eps)        per episode   (network.py:188-189)
+ * pomdp_collect_returns runs the k_steps steps of pomdp_collect_synthetic (same policy, same draws, same final state, the
+ * same launches) and keeps, per lane, only that reduction — nothing is written per step:
+ *     acc  double [4][pitch]   row 0 ret       running return of the lane's current episode   (start at 0)
+ *                              row 1 disc      its running discount                             (start at 1)
+ *                              row 2 ret_done  return of the lane's last finished episode       (untouched until one ends)
+ *                              row 3 ret_sum   sum of the returns of its finished episodes, added in the order they ended
+ *     cnt  int32  [2][pitch]   row 0 episodes  number of finished episodes;  row 1 steps  number of steps taken
+ * all in/out, so consecutive calls continue the same statistics.  Per step: ret += disc * reward; disc *= discount, in IEEE
+ * double with separate multiply and add; a done step banks ret (ret_done = ret; ret_sum += ret; ++episodes) and the fresh
+ * episode starts at ret = 0, disc = 1.  `reward` is the reference's own value: the integer rewards of RockSample / Tag /
+ * BattleShip / Tiger, and for Network the float64 `base - .1` / `base - 2.5` of network.py:103, 110 (NOT the float32 the
+ * reward column rounds it to).  POMDP_AUTO_RESET required; lane0 a multiple of 4; acc and cnt on 16-byte boundaries with a
+ * pitch that is a multiple of 4 take the quad-per-thread launches. */
+typedef struct pomdp_return_stats {
+    double   discount;      /* the env's _discount (rock.py:115, tag.py:91, ...) */
+    double  *acc;           /* device double [4][pitch] */
+    int32_t *cnt;           /* device int32 [2][pitch] */
+    int64_t  pitch;         /* >= n */
+} pomdp_return_stats;
+int pomdp_collect_returns(int env, const void *params, uint32_t *state, const pomdp_return_stats *stats, uint32_t *err,
+                          int64_t n, uint64_t seed, uint32_t lane0, uint64_t t0, int64_t k_steps, int flags, void *stream);
+
+/* Steps per fused launch of the C-side drivers above (pomdp_rollout_synthetic with POMDP_FUSE_STEPS, pomdp_collect_*,
+ * pomdp_heuristic_steps): a launch's fixed cost (kernel start, table build, drain) is paid once per this many steps.
+ * pomdp_fuse_max(v) sets it for the calling process (1 <= v <= 256; v <= 0 only reads) and returns the previous value;
+ * the default is POMDP_FUSE_MAX_DEFAULT.  Results never depend on it. */
+#define POMDP_FUSE_MAX_DEFAULT 64
+int pomdp_fuse_max(int v);
 
 /* ---- planner hooks ------------------------------------- */
 /* replaces <Env>._generate_legal (rock.py:273-291, tag.py:228-229, battleship.py:157-165, tiger.py:111-112,

@@ -52,6 +52,9 @@ def lib():
         L.or_bench_loop.restype = C.c_double
         L.or_bench_loop.argtypes = [vp, C.c_int64, C.c_int64, C.c_uint64, C.c_int, vp]
         L.or_max_threads.restype = C.c_int
+        L.or_batch_collect_returns.restype = C.c_int64
+        L.or_batch_collect_returns.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_double, vp, C.c_int64, C.c_uint64, C.c_uint32,
+                                               C.c_uint64, C.c_int64, C.c_int]
         L.or_philox4x32_10.argtypes = [vp, vp, vp]
         L.or_batch_rock_belief_reset.argtypes = [vp, vp, vp, C.c_int64]
         L.or_batch_rock_belief_update.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp, C.c_int64]
@@ -302,6 +305,30 @@ def _batch_heuristic_steps(self, state, history, belief, prev_ob, k, seed, lane0
     return out
 
 
+def new_return_stats(n, pitch=None):
+    """(acc float64 [4, pitch], cnt int32 [2, pitch]) as a fresh gym_pomdp_amd.EpisodeStats holds them: ret 0, disc 1,
+    ret_done NaN, ret_sum 0; episodes 0, steps 0."""
+    pitch = n if pitch is None else pitch
+    acc = np.zeros((4, pitch), np.float64)
+    acc[1] = 1.0
+    acc[2] = np.nan
+    return acc, np.zeros((2, pitch), np.int32)
+
+
+def _batch_collect_returns(self, state, acc, cnt, discount, seed, lane0, t0, k, nthreads=1, actions=None):
+    """k random-policy steps of every lane (or the tape `actions`, int32 [k, n]) reduced to the reference callers'
+    per-episode discounted returns (or_batch_collect_returns); state, acc, cnt updated in place.  -> number of done steps."""
+    if actions is not None:
+        actions = np.ascontiguousarray(actions, np.int32)
+        assert actions.shape == (k, state.shape[1])
+    assert acc.dtype == np.float64 and cnt.dtype == np.int32 and acc.flags.c_contiguous and cnt.flags.c_contiguous
+    assert acc.shape[1] == cnt.shape[1] >= state.shape[1] and state.flags.c_contiguous
+    return int(lib().or_batch_collect_returns(self._h, _ptr(state), _ptr(acc), _ptr(cnt), acc.shape[1], float(discount),
+                                              None if actions is None else _ptr(actions), state.shape[1], seed, lane0, t0, k,
+                                              nthreads))
+
+
+OracleEnv.batch_collect_returns = _batch_collect_returns
 OracleEnv.batch_heuristic_steps = _batch_heuristic_steps
 OracleEnv.batch_preferred = _batch_preferred
 OracleEnv.batch_compute_prob = _batch_compute_prob

@@ -998,6 +998,73 @@ double or_bench_loop(const or_env *proto, int64_t n, int64_t steps, uint64_t see
     return el;
 }
 
+/* The reduction the reference's callers apply to the stream of step() results under a random policy — `r += discount * rw;
+ * discount *= .95` per step, `eps.append(r)` per episode, `sum(eps)` over them (network.py:175-191; rock.py:553-575 has the
+ * same two lines with the factors swapped) — for every lane, lane-major, over the k steps of or_synthetic_actions +
+ * or_batch_step(auto_reset) at call counters t0 .. t0 + k - 1 (`actions`, int32 [k][n], replaces the policy when not NULL: the
+ * fixtures' tapes).  acc: double [4][pitch] = ret, disc, ret_done, ret_sum; cnt:
+ * int32 [2][pitch] = episodes, steps; all in/out (include/pomdp_hip.h: pomdp_collect_returns).  The reward is or_env_step's
+ * double — the reference's own value (Network: base - .1, not its float32).  Returns the number of done steps. */
+int64_t or_batch_collect_returns(const or_env *proto, uint32_t *state, double *acc, int32_t *cnt, int64_t pitch, double discount,
+                                 const int32_t *actions, int64_t n, uint64_t seed, uint32_t lane0, uint64_t t0, int64_t k,
+                                 int nthreads)
+{
+    int W = or_env_words(proto), nA = or_env_n_actions(proto);
+    const uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
+    int64_t dsum = 0;
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel num_threads(nthreads) reduction(+ : dsum)
+    {
+        or_env e = *proto;
+        or_ws np_rng, sp_rng;
+        uint32_t w[12];
+#pragma omp for schedule(static)
+        for (int64_t i = 0; i < n; i++) {
+            const uint32_t lane = lane0 + (uint32_t)i;
+            double ret = acc[i], disc = acc[pitch + i], ret_done = acc[2 * pitch + i], ret_sum = acc[3 * pitch + i];
+            int32_t episodes = cnt[i];
+            for (int j = 0; j < W; j++) w[j] = state[(int64_t)j * n + i];
+            or_env_unpack(&e, w);
+            for (int64_t s = 0; s < k; s++) {
+                const uint64_t t = t0 + (uint64_t)s;
+                uint32_t c[4] = { lane >> 2, (uint32_t)t, (uint32_t)(t >> 32), (uint32_t)OR_STREAM_ACTION << 24 }, o4[4];
+                or_philox4x32_10(c, key, o4);
+                const int a = actions ? actions[s * n + i] : (int)(((uint64_t)o4[lane & 3u] * (uint32_t)nA) >> 32);
+                int o, d; double r;
+                or_ws_philox_env(&np_rng, e.kind, seed, lane, t, OR_STREAM_STEP);
+                or_ws_philox(&sp_rng, seed, lane, t, OR_STREAM_STEP_SPACE);
+                or_env_step(&e, a, &np_rng, &sp_rng, &o, &r, &d);
+                {   /* r += discount * rw; discount *= .95 (network.py:186-187) — separate multiply and add */
+                    const double term = disc * r;
+                    ret = ret + term;
+                    disc = disc * discount;
+                }
+                if (d) {                                    /* eps.append(r) (network.py:188); the next episode starts at 0 / 1 */
+                    ret_done = ret;
+                    ret_sum = ret_sum + ret;
+                    episodes++;
+                    ret = 0.0; disc = 1.0;
+                    dsum++;
+                    if (e.kind == OR_ENV_BATTLESHIP) {
+                        bs_swap_in(&e);
+                        or_ws_philox(&np_rng, seed, lane, t, OR_STREAM_NEXT);
+                        bs_deal_next(&e, &np_rng);
+                    } else {
+                        or_ws_philox_auto_reset(&np_rng, &e, seed, lane, t);
+                        or_ws_philox(&sp_rng, seed, lane, t, OR_STREAM_RESET_SPACE);
+                        or_env_reset(&e, &np_rng, &sp_rng);
+                    }
+                }
+            }
+            or_env_pack(&e, w);
+            for (int j = 0; j < W; j++) state[(int64_t)j * n + i] = w[j];
+            acc[i] = ret; acc[pitch + i] = disc; acc[2 * pitch + i] = ret_done; acc[3 * pitch + i] = ret_sum;
+            cnt[i] = episodes; cnt[pitch + i] += (int32_t)k;
+        }
+    }
+    return dsum;
+}
+
 /* ======================================================================== */
 /* planner hooks: _generate_legal and random rollouts                        */
 /* ======================================================================== */

@@ -114,6 +114,15 @@ int  or_max_threads(void);
  * lanes seen (so the work cannot be optimised away). */
 double or_bench_loop(const or_env *proto, int64_t n, int64_t steps, uint64_t seed, int nthreads, int64_t *n_done);
 
+/* The reference callers' reduction of a random-policy rollout (network.py:175-191, rock.py:553-575): per lane and step
+ * ret += disc * reward; disc *= discount (IEEE double, separate multiply and add); a done step banks ret — ret_done = ret,
+ * ret_sum += ret, episodes++ — and the fresh episode starts at 0 / 1.  k steps of or_synthetic_actions + or_batch_step
+ * (auto_reset) from call counter t0; `actions` (int32 [k][n], may be NULL) replaces the policy's.  acc: double [4][pitch] (ret, disc, ret_done, ret_sum), cnt: int32 [2][pitch]
+ * (episodes, steps), in/out.  The reward is the reference's float64 value.  Returns the number of done steps. */
+int64_t or_batch_collect_returns(const or_env *proto, uint32_t *state, double *acc, int32_t *cnt, int64_t pitch, double discount,
+                                 const int32_t *actions, int64_t n, uint64_t seed, uint32_t lane0, uint64_t t0, int64_t k,
+                                 int nthreads);
+
 /* ---- planner hooks ---------------------------------- */
 /* `_generate_legal()` of the current state, in the reference's list order (duplicates kept);
  * returns the list length (<= OR_MAX_LEGAL). */

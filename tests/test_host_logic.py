@@ -231,7 +231,7 @@ def test_fused_step_loops_never_wait_for_their_own_stores():
             seen += 1
             assert waits == [], (name, waits)
             assert prio == 4, (name, prio)
-    assert seen == 6, sorted(res)           # both kernels in each of the three trajectory layouts (traj_out.hip.h)
+    assert seen == 10, sorted(res)          # both kernels with each of the five sinks (traj_out.hip.h: three layouts of round 4, Narrow, Returns)
 
 
 def test_library_override_by_environment_variable():

@@ -376,3 +376,47 @@ def test_lane_major_heuristic_driver_equals_the_per_step_call_sequence(oracle_li
             for k_, _ in ol.Belief.FIELDS:
                 x, y = getattr(b, k_), getattr(ref.b, k_)
                 assert ((x == y) | ((x != x) & (y != y))).all(), k_
+
+
+@pytest.mark.parametrize("case,env,kw", CASES, ids=[c[0] for c in CASES])
+def test_collect_returns_is_the_callers_loop_over_the_reference_rewards(oracle_lib, case, env, kw):
+    """or_batch_collect_returns (what the GPU's returns-only sink is held to) against the reference callers' two lines —
+    `r += discount * rw; discount *= .95` per step, `eps.append(r)` per episode, `sum(eps)` (network.py:175-191,
+    rock.py:569-570) — run in python floats over the REFERENCE's own rewards and done flags of the mode-B fixtures
+    (float64, so Network's `base - .1` unrounded): running return and discount, last finished return, the sequential sum
+    over finished episodes, bit for bit; counts; the state."""
+    g = load_golden("B", case)
+    o = oracle_lib.OracleEnv(env, **kw)
+    seed, t0, lanes = int(g["seed"]), int(g["t0"]), g["lanes"]
+    L, T = g["actions"].shape
+    discount = 1.0 if env == "battleship" else .95            # battleship.py:73, else rock.py:115 / tag.py:91 / tiger.py:55 / network.py:35
+    starts = [0] + [i for i in range(1, L) if lanes[i] != lanes[i - 1] + 1] + [L]
+    for s, e in zip(starts[:-1], starts[1:]):
+        n, lane0 = e - s, int(lanes[s])
+        st, st2 = o.new_state(n), o.new_state(n)
+        o.batch_reset(st, seed, lane0, t0)
+        o.batch_reset(st2, seed, lane0, t0)
+        acc, cnt = oracle_lib.new_return_stats(n, pitch=n + 3)
+        half = T // 2                                          # two calls: the statistics carry over
+        o.batch_collect_returns(st, acc, cnt, discount, seed, lane0, t0 + 1, half, actions=g["actions"][s:e, :half].T)
+        o.batch_collect_returns(st, acc, cnt, discount, seed, lane0, t0 + 1 + half, T - half, actions=g["actions"][s:e, half:].T)
+        for i in range(T):
+            o.batch_step(st2, g["actions"][s:e, i], seed, lane0, t0 + 1 + i)
+        assert np.array_equal(st, st2)
+        for li in range(n):
+            r, disc, eps, last = 0, 1., [], float("nan")
+            for i in range(T):
+                rw = float(g["reward"][s + li, i])
+                r += disc * rw
+                disc *= discount
+                if g["done"][s + li, i]:
+                    eps.append(r)
+                    last, r, disc = r, 0, 1.
+            tot = 0.                                           # sum(eps), left to right (python >= 3.12 compensates inside sum())
+            for x in eps:
+                tot += x
+            want = np.array([float(r), disc, last, tot], np.float64)
+            assert np.array_equal(acc[:, li].view(np.uint64), want.view(np.uint64)), (case, li, acc[:, li], want)
+            assert cnt[0, li] == len(eps) and cnt[1, li] == T
+        assert np.all(acc[0, n:] == 0) and np.all(acc[1, n:] == 1) and np.all(np.isnan(acc[2, n:])) and np.all(acc[3, n:] == 0)   # padding untouched
+        assert np.all(cnt[:, n:] == 0)
