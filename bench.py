@@ -6,9 +6,9 @@
 Workload (BASELINE.json metric): RockSample(7,8), 2^20 lanes per GPU, i.i.d. uniform random
 actions from the synthetic policy (its kernel is inside the timed region), auto-reset on done.
 A "step" is one pass of the hot path over the whole batch.  The steps are issued by the library's C-side
-drivers, by default as trajectory collection (pomdp_collect_synthetic): up to 64 consecutive steps inside one
-launch, every step's action / ob / reward / done written to its own [step][lane] row, a lane's state in
-registers between its steps.  `--collect 0` runs the same fused launches with every step overwriting the same
+drivers, by default as trajectory collection (pomdp_collect_layout): up to pomdp_fuse_max() (256) consecutive steps
+inside one launch, every step's action / ob / reward / done written to its own [step][lane] row in the layout --layout
+names (packed 4-byte records by default), a lane's state in registers between its steps.  `--collect 0` runs the same fused launches with every step overwriting the same
 N-element outputs (pomdp_rollout_synthetic; what per-step launches leave), `--fuse 0` launches every step
 separately, `--host-loop python` times the same steps through env.step() instead.
 N > 1: one process per GPU, lanes sharded by global lane id, no data-path collective — only the timing
@@ -25,9 +25,11 @@ line's `value` / `ms_per_step` the median over the seeds (config.seed_values has
 Every buffer the timed steps write is allocated, and touched by the same chunking of K, before the first timed
 region.
 
-Prints ONE JSON line on rank 0 with the driver's contract keys plus `roofline` (algorithmic
-bytes / HIP-event time of the step kernel alone) and `cpu_baseline` (the C oracle, OpenMP, on
-this box's host cores, N == 1 only).
+Prints ONE JSON line on rank 0 with the driver's contract keys plus `roofline` (the tighter of HBM — algorithmic bytes /
+HIP-event time of the timed kernel — and VALU issue — recorded instructions per launch / the same time), `layouts`
+(the other sinks of the same workload, and what a consumer of int32 columns gets from the records: packed_plus_decode),
+`configs` (BASELINE.json's other configs at their per-GPU sizes, and the returns-only reduction of the headline workload)
+and `cpu_baseline` (the C oracle, OpenMP, on this box's host cores, N == 1 only).
 """
 import argparse
 import json
@@ -51,9 +53,20 @@ SIMD_HZ = 256 * 4 * 2.4e9  # VALU issue: 256 CUs x 4 SIMDs x 2.4 GHz cycles per 
 
 
 def _latest(pattern):
+    """The newest profiles/<pattern>: the one recorded from THIS tree's kernel sources if there is one (its csrc_sha256),
+    else the last by name (round tags sort: r04q < r05a) — never by mtime, which a fresh checkout scrambles."""
     import glob
-    f = sorted(glob.glob(os.path.join(REPO, "profiles", pattern)), key=lambda x: (os.path.getmtime(x), x))
-    return f[-1] if f else None
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", pattern)))
+    if not files:
+        return None
+    sha = csrc_sha()
+    for f in reversed(files):
+        try:
+            if json.load(open(f)).get("csrc_sha256") == sha:
+                return f
+        except Exception:  # noqa: BLE001
+            pass
+    return files[-1]
 
 
 def csrc_sha():
@@ -149,7 +162,7 @@ def parse():
                     help="step: the headline metric.  rollout: BASELINE.json configs[4] shape — every launch runs "
                          "sims-per-root random rollouts of --depth steps from each root (fused kernel, state in registers).  "
                          "heuristic: every lane follows the env's own _generate_preferred(history) policy "
-                         "(use_heuristic=True; rock / rock15 / tag), up to 64 steps per fused launch")
+                         "(use_heuristic=True; rock / rock15 / tag), up to pomdp_fuse_max() steps per fused launch")
     ap.add_argument("--depth", type=int, default=64)
     ap.add_argument("--sims-per-root", type=int, default=1024)
     ap.add_argument("--action-seed", type=int, default=None, help="policy key (default: the env seed)")
@@ -166,16 +179,21 @@ def parse():
                     help="step mode, fused launches: 1 = keep every step's action / ob / reward / done in [128][N] "
                          "trajectory buffers (env.collect_synthetic); 0 = every step overwrites the same N-element "
                          "outputs, as per-step launches do (env.rollout_synthetic).  Same bytes written either way")
-    ap.add_argument("--layout", default="packed", choices=["columns", "blocked", "packed"],
+    ap.add_argument("--layout", default="packed", choices=["columns", "blocked", "packed", "narrow", "returns"],
                     help="trajectory layout of the collected steps (include/pomdp_hip.h: POMDP_LAYOUT_*).  packed (default): one "
                          "32-bit record per lane-step (action | ob << 8 | reward code << 16 | done << 24), 4 B instead of 13 — the fused "
                          "loop is then bound by instruction issue; columns: the default ABI's four int32 / float / uint8 columns "
-                         "(four write streams); blocked: the columns' 13 bytes as one stream (256-lane blocks).  The line carries "
-                         "all three under `layouts`")
+                         "(four write streams); blocked: the columns' 13 bytes as one stream (256-lane blocks); narrow: the record's "
+                         "four bytes as four typed planes (uint8 / int8 tensors, nothing to decode); returns: NO trajectory — per lane "
+                         "the reference callers' reduction r += discount * rw, one return per episode (pomdp_collect_returns).  The "
+                         "line carries all of them under `layouts` / `configs.returns_only`")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the `layouts` and `configs` blocks (the other layouts of this workload; Tag / BattleShip / the C5 "
                          "rollout) that the default single-GPU run appends after its timed regions")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--share-gpus", action="store_true",
+                    help="allow fewer visible GPUs than ranks (ranks then share devices: a development aid, e.g. two ranks on a "
+                         "one-GPU box); without it such a run is an error, so a line that says n_gpus: N ran on N GPUs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline sample")
     return ap.parse_args()
 
@@ -249,7 +267,11 @@ env_key, kwargs, seed, budget_s = sys.argv[2], json.loads(sys.argv[3]), int(sys.
 usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
 o = ol.OracleEnv(env_key, **kwargs)
 n = 1 << 20
-t1 = o.bench_loop(1 << 16, 8, seed, 1)
+t1, s1, t0 = 0.0, 0, time.perf_counter()          # one core: at least half a second of it (a cold first pass reads low)
+o.bench_loop(1 << 16, 8, seed, 1)
+while time.perf_counter() - t0 < 0.6:
+    t1 += o.bench_loop(1 << 16, 8, seed + s1, 1)
+    s1 += 8
 cands = sorted({c for c in (usable, usable // 2, 128, 64, 32, 16, 8, 4) if 1 <= c <= usable}, reverse=True)
 share = budget_s / len(cands)
 table = []
@@ -259,7 +281,7 @@ for threads in cands:                      # strictly wall-clock bounded: chunks
         el += o.bench_loop(n, 8, seed + steps, threads)
         steps += 8
     table.append({"threads": threads, "value": n * steps / el, "steps": steps, "seconds": el})
-print(json.dumps({"usable": usable, "one_core": (1 << 16) * 8 / t1, "table": table}))
+print(json.dumps({"usable": usable, "one_core": (1 << 16) * s1 / t1, "table": table}))
 """
 
 
@@ -374,11 +396,12 @@ def rollout_mode(args, env, cp, dev, rank, world, label):
 def heuristic_roofline(args, n, kern_ms, hbm_achieved, alg):
     hbm = {"bound": "hbm", "achieved": hbm_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_achieved / HBM_PEAK_GBS,
            "traffic": None, "algorithmic_bytes_per_step": alg}
-    v = valu_roofline("heuristic_%s" % args.env, "heuristic_steps_kernel<", n, kern_ms * 64)
+    spl = fuse_max()
+    v = valu_roofline("heuristic_%s" % args.env, "heuristic_steps_kernel<", n, kern_ms * spl)
     if v is None:
-        return dict(hbm, kernel="heuristic_steps_kernel (up to 64 steps per launch)", kernel_ms=kern_ms)
-    return dict(v, traffic=None, kernel_ms=kern_ms, steps_per_launch=64, hbm=hbm,
-                note="the tighter of the two bounds is reported first; launch_ms = kernel_ms x 64 steps per launch")
+        return dict(hbm, kernel="heuristic_steps_kernel (up to %d steps per launch)" % spl, kernel_ms=kern_ms)
+    return dict(v, traffic=None, kernel_ms=kern_ms, steps_per_launch=spl, hbm=hbm,
+                note="the tighter of the two bounds is reported first; launch_ms = kernel_ms x %d steps per launch" % spl)
 
 
 def heuristic_mode(args, gpa, env_id, kwargs, cp, dev, rank, world, label, n, lane_offset):
@@ -392,10 +415,12 @@ def heuristic_mode(args, gpa, env_id, kwargs, cp, dev, rank, world, label, n, la
         e.reset()
         return e, gpa.History(e)
 
+    chunk = fuse_max()
+
     def stepper(e, h):
         def run(k):
             while k > 0:
-                c = min(k, 128)              # up to 64 steps per launch
+                c = min(k, chunk)            # whole launches of pomdp_fuse_max() steps
                 e.heuristic_steps(h, c)
                 k -= c
         return run
@@ -423,11 +448,11 @@ def heuristic_mode(args, gpa, env_id, kwargs, cp, dev, rank, world, label, n, la
     elapsed = cp.max(time.perf_counter() - t0)
     cp.barrier()
     kern_ms = ev0.elapsed_time(ev1) / args.steps
-    # algorithmic bytes per lane-step: with up to 64 steps per launch the lane's state and history words
+    # algorithmic bytes per lane-step: with many steps per launch the lane's state and history words
     # stay in registers, so a step must write action, ob, reward, done = 13 B; state in / out once per launch (a CHECK's
     # statistics update — one rock's five fields and two sums — is not counted, nor the 40 B of history words per lane
     # read and written once per launch)
-    alg = 13.0 + 8.0 * env.state_words / 64.0
+    alg = 13.0 + 8.0 * env.state_words / float(chunk)
     achieved = alg * n / (kern_ms * 1e-3) / 1e9
     if rank == 0:
         print(json.dumps({
@@ -436,7 +461,7 @@ def heuristic_mode(args, gpa, env_id, kwargs, cp, dev, rank, world, label, n, la
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "int32 (+ f64 side statistics)", "data": "synthetic",
             "config": {"workload": "%s batch=%d lanes per GPU, every lane follows _generate_preferred(history) "
-                                   "(use_heuristic=True), auto-reset, up to 64 steps per fused launch" % (label, n),
+                                   "(use_heuristic=True), auto-reset, up to %d steps per fused launch" % (label, n, chunk),
                        "lanes_per_gpu": n, "phase_steps": args.phase_steps, "mean_history_size": float(hist._size.float().mean().item()),
                        "parallelism": "lane-shard x%d, no collectives" % world},
             "roofline": heuristic_roofline(args, n, kern_ms, achieved, alg)}), flush=True)
@@ -458,30 +483,21 @@ def recorded_traffic(env_key, layout, spl, kernel_prefix):
     return None, None
 
 
-def measured_traffic(env_key, chained=False, fused=False):
-    """HBM bytes per step-kernel launch RECORDED by the committed PMC passes (profiles/traffic_*.json, produced by
-    tools/gpu_profile_round.sh: separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this command) — not
-    measured in this run."""
-    name = {"rock": "traffic_rock_7_8.json"}.get(env_key)
-    path = os.path.join(REPO, "profiles", name) if name else None
-    if not path or not os.path.exists(path):
-        return None, None
-    with open(path) as f:
-        t = json.load(f)
-    key = "fused" if fused and "fused" in t else ("chain" if chained and "chain" in t else "plain")
-    if key not in t:
-        return None, None
-    return t[key]["hbm_bytes_per_launch"], "recorded, not measured in this run: profiles/%s [%s]" % (name, key)
-
-
 def fused_alg_bytes(bytes_per_step, spl, layout):
-    """Algorithmic bytes per lane-step of a fused launch of `spl` steps: the layout's output bytes per step (action, ob,
-    reward: 4 B each + done: 1 B = 13; packed: one 4-byte record) + what the launch moves once — the state in and out
-    (SURVEY.md §8d's per-step figure minus its 13 B of per-step columns ... minus the action it READS, which a fused launch
-    generates) and, columns only, the row of first actions it writes."""
-    out_b = 4.0 if layout == "packed" else 13.0
-    once = bytes_per_step - 9 - (0 if layout == "columns" else 4)
+    """Algorithmic bytes per lane-step of a fused launch of `spl` steps: the sink's output bytes per step (action, ob,
+    reward: 4 B each + done: 1 B = 13; packed / narrow: 4; returns: none) + what the launch moves once — the state in and
+    out (SURVEY.md §8d's per-step figure minus its 13 B of per-step columns ... minus the action it READS, which a fused
+    launch generates), columns only: the row of first actions it writes, returns only: the lane's statistics in and out
+    (three float64 and two int32 rows: 64 B)."""
+    out_b = {"packed": 4.0, "narrow": 4.0, "returns": 0.0}.get(layout, 13.0)
+    once = bytes_per_step - 9 - (0 if layout == "columns" else 4) + (64 if layout == "returns" else 0)
     return out_b + once / float(spl)
+
+
+def fuse_max():
+    """steps per fused launch of the library's C-side drivers (include/pomdp_hip.h: pomdp_fuse_max)"""
+    from gym_pomdp_amd import _native
+    return int(_native.lib().pomdp_fuse_max(0))
 
 
 def valu_workload_key(env_key, spl, layout, n=1 << 20):
@@ -509,23 +525,51 @@ def step_rooflines(env_key, bytes_per_step, layout, n, kern_ms, spl, fused, fuse
 def quick_step_config(args, gpa, _native, cp, dev, env_key, n, lane_offset, seed, layout, k=None):
     """One workload measured briefly with the headline's protocol (reseed + reset, W warm-up steps, an untimed pass, then 9
     regions of K steps bracketed by device syncs: even ones by wall clock, odd ones by HIP events) -> a `configs` / `layouts`
-    entry.  K = --steps, at most 128 (`layouts`: like for like with the headline); `configs` pass K = 512 — eight 64-step
-    launches per region, whatever --steps is — so that their figures are those of the stand-alone runs of the same workloads
-    (profiles/*_bench_envs.jsonl) and not a function of how the driver sliced the headline."""
+    entry.  K = --steps, at most one launch's worth (`layouts`: like for like with the headline); `configs` pass K = 512 — two
+    256-step launches per region, whatever --steps is — so that their figures are those of the stand-alone runs of the same
+    workloads (profiles/*_bench_envs.jsonl) and not a function of how the driver sliced the headline.  layout "returns": the
+    returns-only sink (collect_returns); "packed_plus_decode": packed records, then pomdp_decode_packed into int32 columns."""
     env_id, kwargs, label, bytes_per_step, _ = WORKLOADS[env_key]
-    k = min(args.steps, 128) if k is None else k
+    k = min(args.steps, StepWorkload.CHUNK) if k is None else k
     wl = StepWorkload(args, gpa, env_id, kwargs, dev, n, lane_offset, seed, layout=layout, max_steps=k)
     wl.reseed(seed)
     wl.run(args.warmup)
     wl.run(k)
     walls, evs = timed_regions(wl.run, k, 9, dev, cp)
     kernel = _native.lib().pomdp_last_fused_kernel().decode()
-    spl = min(64, k)
+    spl = min(fuse_max(), StepWorkload.CHUNK, k)
     kern_ms = median(evs) / k
+    if layout == "packed_plus_decode":
+        # two kernels per chunk: the packed producer and the decode pass (4 B read + 13 B written per lane-step); the pass is
+        # timed by itself as well — it is a pure stream, so its roofline is HBM at 17 B
+        c = min(k, StepWorkload.CHUNK)
+        view = wl._view(c)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        wl.env.decode_trajectory(view, into=wl.cols)
+        torch.cuda.synchronize(dev)
+        e0.record()
+        for _ in range(5):
+            wl.env.decode_trajectory(view, into=wl.cols)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        dec_ms = e0.elapsed_time(e1) / (5 * c)
+        del wl
+        torch.cuda.empty_cache()
+        alg = fused_alg_bytes(bytes_per_step, spl, "packed") + 17.0
+        hbm = alg * n / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        return {"workload": "%s batch=%d, packed records then pomdp_decode_packed into the default int32 columns, %d steps per region"
+                            % (label, n, k),
+                "value": n * k / median(walls), "unit": "env-steps/s", "ms_per_step": median(walls) / k * 1e3,
+                "kernel": "%s + decode_packed_kernel<true>" % kernel, "kernel_ms": kern_ms, "steps_per_launch": spl, "bytes_per_lane_step": alg,
+                "decode_kernel_ms": dec_ms, "decode_hbm_frac": 17.0 * n / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "roofline": {"bound": "hbm", "frac": hbm, "hbm_frac": hbm, "valu_frac": None, "counters_stale": None},
+                "note": "what a consumer that needs int32 / float tensors gets FROM RECORDS; writing the columns directly "
+                        "(layouts.columns) is faster, reading the narrow layout's typed planes in place (layouts.narrow) faster still"}
     rf = step_rooflines(env_key, bytes_per_step, layout, n, kern_ms, spl, True, kernel)
     del wl
     torch.cuda.empty_cache()
-    return {"workload": "%s batch=%d, %s layout, %d steps per region" % (label, n, layout, k),
+    return {"workload": "%s batch=%d, %s, %d steps per region" % (label, n, "returns-only sink (per-lane episode statistics, no "
+                                                                   "trajectory)" if layout == "returns" else layout + " layout", k),
             "value": n * k / median(walls), "unit": "env-steps/s", "ms_per_step": median(walls) / k * 1e3,
             "kernel": kernel, "kernel_ms": kern_ms, "steps_per_launch": spl, "bytes_per_lane_step": rf["alg_bytes"],
             "roofline": {"bound": rf["primary"]["bound"], "frac": rf["primary"]["frac"], "hbm_frac": rf["hbm"]["frac"],
@@ -573,7 +617,7 @@ def quick_rollout_config(args, gpa, dev, env_key, roots_n, sims, depth, seed):
 class StepWorkload(object):
     """K consecutive steps of one env shard under the synthetic policy, every buffer allocated up front."""
 
-    CHUNK = 128          # steps per C-driver call (two full 64-step launches when fused)
+    CHUNK = 256          # steps per C-driver call = one full launch when fused (pomdp_fuse_max)
 
     def __init__(self, args, gpa, env_id, kwargs, dev, n, lane_offset, seed, layout=None, max_steps=0):
         self.args, self.dev, self.n = args, dev, n
@@ -585,10 +629,16 @@ class StepWorkload(object):
         self.chained = args.host_loop == "c" and self.shared_key
         self.fused = self.chained and bool(args.fuse)
         self.views = {}
+        self.stats = self.cols = None
         if self.collect:
             # one [CHUNK + 1][n] trajectory buffer per column; a call of c steps writes the first c (+ 1) rows
             c = min(self.CHUNK, max(args.steps, args.warmup, max_steps, 1))
-            self.traj = self.env.trajectory_buffers(c, self.layout)    # one allocation (columns: starts staggered, envs/base.py)
+            if self.layout == "returns":                               # nothing per step: the lanes' episode statistics only
+                self.stats, self.traj = gpa.EpisodeStats(self.env), None
+            elif self.layout == "packed_plus_decode":                  # records, then one device pass into int32 columns
+                self.traj, self.cols = self.env.trajectory_buffers(c, "packed"), self.env.trajectory_buffers(c)
+            else:
+                self.traj = self.env.trajectory_buffers(c, self.layout)    # one allocation (columns: starts staggered, envs/base.py)
         else:
             self.layout = "columns"
 
@@ -605,7 +655,9 @@ class StepWorkload(object):
         return v
 
     def traj_tensor(self):
-        """a flat view of (one column of) the trajectory buffer the timed launches write: what store_ceiling fills"""
+        """a flat view of (one column of) the buffer the timed launches write: what store_ceiling fills"""
+        if self.stats is not None:
+            return self.stats.acc.view(-1)
         return (self.traj["ob"] if self.layout == "columns" else self.traj["traj"]).view(-1)
 
     def reseed(self, seed):
@@ -620,7 +672,12 @@ class StepWorkload(object):
         if self.collect:
             while left > 0:
                 c = min(left, self.CHUNK)
-                env.collect_synthetic(c, out=self._view(c))
+                if self.stats is not None:
+                    env.collect_returns(c, self.stats)
+                else:
+                    env.collect_synthetic(c, out=self._view(c))
+                    if self.cols is not None:
+                        env.decode_trajectory(self._view(c), into=self.cols)
                 left -= c
         elif self.args.host_loop == "python":
             for _ in range(k):
@@ -660,7 +717,10 @@ def main():
     seeds = [args.seed] if args.seed is not None else [int(x) for x in args.seeds.split(",") if x != ""]
     args.seed = seeds[0]
     n_dev = torch.cuda.device_count()
-    dev_index = local_rank % max(n_dev, 1)      # fewer GPUs than ranks (1-GPU dev box): ranks share devices
+    if n_dev < world and not args.share_gpus:
+        raise SystemExit("bench.py: %d ranks but %d visible GPU(s) — one GPU per rank, or --share-gpus to let ranks share "
+                         "devices (development only: the line would still say n_gpus: %d)" % (world, n_dev, world))
+    dev_index = local_rank % max(n_dev, 1)      # --share-gpus: fewer GPUs than ranks, ranks share devices
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     import gym_pomdp_amd as gpa
@@ -710,7 +770,7 @@ def main():
         # for this shard size and launch length, tools/gpu_pmc_valu.sh shards).
         strong["frac_of_floor"] = strong["floor_source"] = None
         if wl_s.fused and strong["kernel"]:
-            spl_s = min(64, args.steps)
+            spl_s = min(fuse_max(), StepWorkload.CHUNK, args.steps)
             v = valu_roofline(valu_workload_key(args.env, spl_s, wl_s.layout, n_s), strong["kernel"].split("<")[0] + "<", n_s,
                               rows_s[0][4] / args.steps * spl_s)
             if v is not None:
@@ -740,7 +800,7 @@ def main():
     plain_ms = ev0.elapsed_time(ev1) / k1
     plain_achieved = bytes_per_step * n / (plain_ms * 1e-3) / 1e9
     kern_ms = timed_kernel_ms if chained else plain_ms
-    spl = min(64, args.steps) if fused else 1
+    spl = min(fuse_max(), StepWorkload.CHUNK, args.steps) if fused else 1
     layout = wl.layout
     rf = step_rooflines(args.env, bytes_per_step, layout, n, kern_ms, spl, fused, fused_kernel)
     chain1_ms = None
@@ -776,7 +836,7 @@ def main():
     extras = world == 1 and not args.no_extras and collect
     if extras:
         layouts_block = {}
-        for lay in ("columns", "blocked", "packed"):
+        for lay in ("columns", "blocked", "packed", "narrow", "packed_plus_decode"):
             if lay == layout:
                 layouts_block[lay] = {"value": n * args.steps / elapsed, "ms_per_step": elapsed / args.steps * 1e3, "kernel": fused_kernel,
                                       "kernel_ms": kern_ms, "bytes_per_lane_step": rf["alg_bytes"],
@@ -788,14 +848,14 @@ def main():
         configs_block = {
             "tag": quick_step_config(args, gpa, _native, cp, dev, "tag", 1 << 20, 0, seeds[0], layout, k=512),            # configs[2]
             "battleship": quick_step_config(args, gpa, _native, cp, dev, "battleship", 1 << 19, 0, seeds[0], layout, k=512),   # configs[3]: 2^22 / 8 GPUs
-            "rollout_rock15": quick_rollout_config(args, gpa, dev, "rock15", 2048, 1024, 64, seeds[0])}                 # configs[4]: 2^24 / 8 GPUs
+            "rollout_rock15": quick_rollout_config(args, gpa, dev, "rock15", 2048, 1024, 64, seeds[0]),                 # configs[4]: 2^24 / 8 GPUs
+            # the headline workload reduced on the fly to what the reference's callers keep of it (network.py:175-191): no trajectory
+            "returns_only": quick_step_config(args, gpa, _native, cp, dev, "rock", 1 << 20, 0, seeds[0], "returns", k=512)}
 
-    # the recorded PMC figure belongs to a launch of the recorded shape only: 2^20 lanes, 64 or 20 steps per fused launch
+    # the recorded PMC figure belongs to a launch of the recorded shape only (2^20 lanes, this many steps per fused launch)
     traffic, traffic_src = (None, None)
     kprefix = (fused_kernel or "").split("<")[0] + "<" if fused else "step_kernel<"
-    if layout == "columns" and n == 1 << 20 and spl in (1, 64):
-        traffic, traffic_src = measured_traffic(args.env, chained, fused)
-    if fused and n == 1 << 20 and traffic is None:
+    if fused and n == 1 << 20:
         traffic, traffic_src = recorded_traffic(args.env, layout, spl, kprefix)
     rank_kernel_ms = cp.gather(timed_kernel_ms)            # a slow GPU shows in the one line the driver keeps
     if rank == 0:
@@ -867,7 +927,7 @@ def main():
                                    % (label, n, total_lanes, args.scaling, layout),
                        "lanes_per_gpu": n, "total_lanes": total_lanes, "host_loop": args.host_loop, "visible_gpus": n_dev,
                        "steps_per_launch": spl, "trajectories_kept": collect, "trajectory_layout": layout if collect else None,
-                       "trajectory_bytes_per_lane_step": (4 if layout == "packed" else 13) if collect else None,
+                       "trajectory_bytes_per_lane_step": {"packed": 4, "narrow": 4, "returns": 0}.get(layout, 13) if collect else None,
                        "seeds": seeds, "repeats": repeats,
                        "protocol": "per seed: reseed + reset, W warm-up steps, one untimed pass of K steps, then `repeats` "
                                    "timed regions of exactly K steps (barrier + device sync on both sides, max over ranks); "

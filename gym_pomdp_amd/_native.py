@@ -27,7 +27,7 @@ POMDP_AUTO_RESET = 1
 POMDP_FUSE_STEPS = 2
 POMDP_ROLLOUT_ALL_ACTIONS = 1
 LAYOUTS = {"columns": 0, "blocked": 1, "packed": 2, "narrow": 3}     # POMDP_LAYOUT_*
-FUSE_MAX_DEFAULT = 64
+FUSE_MAX_DEFAULT = 256
 ENV_KIND = {"rock": 0, "tag": 1, "battleship": 2, "tiger": 3, "network": 4}
 
 # every symbol include/pomdp_hip.h declares
@@ -50,7 +50,8 @@ class RockParams(C.Structure):
 
 
 class TagParams(C.Structure):
-    _fields_ = [("num_opponents", C.c_int32), ("obs_cells", C.c_int32), ("move_thr", C.c_uint64)]
+    _fields_ = [("num_opponents", C.c_int32), ("obs_cells", C.c_int32), ("move_thr", C.c_uint64), ("move_gt", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class BattleShipParams(C.Structure):

@@ -15,6 +15,7 @@ struct NetworkEnv {
     static constexpr bool HAS_ROCKS = false;   // a bounded History keeps a window of transitions for this env (history_push)
     static constexpr bool POOLED_ANY_LPT = false;
     static constexpr bool QUAD_SENSOR = false;
+    static constexpr bool NEVER_DONE = true;   // network.py:113 — the Returns sink banks nothing (traj_out.hip.h)
     // nbf[k][v]: the machines that see a failed neighbour when the down machines among 4 k .. 4 k + 3 are the set v
     // (network.py:82-85) — the OR over the nibbles of ~state replaces a loop over the machines
     struct Shared { uint32_t nbf[8][16]; };

@@ -445,64 +445,15 @@ struct RockEnv {
         const uint32_t x = (uint32_t)st.s & 15u, y = ((uint32_t)st.s >> 4) & 15u;
         return sh.thr[__builtin_amdgcn_sad_u8(x | (y << 8), sh.rpos[r & 15], 0u)].y;
     }
-    // ---- the lane step from a (position, action) -> outcome table ----------------------------------------------
-    // Everything step_pre derives from the agent's cell and the action alone — where a move leads and whether it leaves
-    // the board, which rock lies under a SAMPLE, the sensor threshold of a CHECK from here — is one 32-bit entry, built
-    // in LDS by the workgroup when a multi-step launch starts (one thread per cell, one pass over the actions) and read
-    // with a single lookup per lane-step instead of two dependent ones plus the arithmetic.
-    //   a <  4: bits 0-7 = position byte XOR the new position byte (0 if the move leaves), bit 8 = leaves, bit 9 = leaves east
-    //   a == 4: bits 0-5 = bit offset of the cell's rock code in the state (8 if none), bit 6 = a rock id < K lies here
-    //   a >= 5: the sensor threshold's high 27 bits at this distance
     static constexpr int TAB_ACTIONS = W == 1 ? 17 : 21;                    // 5 + K: K <= 12 in one state word, <= 16 in two
-    struct StepTab { uint32_t e[TAB_ACTIONS][256]; };
-    static __device__ __forceinline__ void build_tab(StepTab &tab, const Shared &sh, const Params &p, int pos)
-    {
-        const uint32_t x = (uint32_t)pos & 15u, y = (uint32_t)pos >> 4, size = (uint32_t)p.size, K = (uint32_t)p.num_rocks;
-        const int id = sh.grid[x * 16 + y];                                     // grid is indexed [x][y], pos is x | y << 4
-        for (int a = 0; a < 5 + (int)K && a < TAB_ACTIONS; ++a) {
-            uint32_t e;
-            if (a < 4) {
-                const uint32_t nx = x + (uint32_t)((a == 1) - (a == 3)), ny = y + (uint32_t)((a == 0) - (a == 2));
-                const bool inside = max(nx, ny) < size;
-                e = inside ? ((uint32_t)pos ^ (nx | (ny << 4))) : (0x100u | (a == 1 ? 0x200u : 0u));
-            } else if (a == 4) {
-                const bool rock = (uint32_t)id < K;
-                e = rock ? ((8u + 2u * (uint32_t)id) | 0x40u) : 8u;
-            } else {
-                e = sh.thr[__builtin_amdgcn_sad_u8(x | (y << 8), sh.rpos[a - 5], 0u) & 31u].x;
-            }
-            tab.e[a][pos] = e;
-        }
-    }
-    template <class RT>
-    static __device__ __forceinline__ void step_tab(const StepTab &tab, State &st, int a, RT &rew, int &done, Aux &aux)
-    {
-        const S s = st.s;
-        const uint32_t e = tab.e[a][(uint32_t)s & 0xFFu];
-        const bool is_move = a < 4, is_sample = a == 4;
-        // CHECK rock a - 5: its code sits at bits 2 a - 2, 2 a - 1 of the state; good = the upper one (codes are 0, 1, 2)
-        aux.th = e;
-        aux.r = (uint8_t)((a - 5) & 15);
-        aux.good = ((uint32_t)(s >> ((2 * a - 1) & (8 * (int)sizeof(S) - 1))) & 1u) != 0u;
-        aux.want = a > 4;
-        // SAMPLE
-        const uint32_t sh_ = e & 63u, code = (uint32_t)(s >> sh_) & 3u;
-        const bool sample_ok = ((e & 0x40u) != 0u) & (code != 1u);
-        const bool sampled = is_sample & sample_ok, missed = is_sample & !sample_ok;
-        // move
-        const bool left = is_move & ((e & 0x100u) != 0u), exit_east = is_move & ((e & 0x200u) != 0u);
-        st.s = s ^ (is_move ? (S)(e & 0xFFu) : (sampled ? (S)(code ^ 1u) << sh_ : (S)0));
-        const bool good_rock = code == 2u;
-        int rw = (exit_east | (sampled & good_rock)) ? 10 : 0;
-        rw = (sampled & !good_rock) ? -10 : rw;
-        rw = ((left & !exit_east) | missed) ? (STOCH ? 0 : -100) : rw;          // rock.py:117 / rock.py:432
-        rew = rw;
-        done = STOCH ? exit_east : (left | missed);                            // penalties never terminate there (rock.py:503)
-    }
 
-    // ---- the lane step as one packed record (one state word; steps_quad_kernel) -------------------------------------------
-    // Round 4: with 4-byte trajectory records the fused loop is bound by instruction issue, and step_tab + sensor_ob + the
-    // reward / done selects cost ~49 vector instructions per lane-step.  step_rec produces the lane's Packed record
+    // ---- the lane step from a (position, action) -> outcome table, as one packed record -------------------------------------
+    // Everything a step derives from the agent's cell and the action alone — where a move leads and whether it leaves the
+    // board, which rock lies under a SAMPLE, the sensor threshold of a CHECK from here — is one 32-bit entry, built in LDS by
+    // the workgroup when a multi-step launch starts (one thread per cell, one pass over the actions) and read with a single
+    // lookup per lane-step.  With 4-byte trajectory records the fused loops are bound by instruction issue; a lane step that
+    // fills (reward, done, aux) for a separate sensor / select stage cost ~49 vector instructions (round 3's step_tab, gone
+    // since every table-driven launch takes this form).  step_rec produces the lane's Packed record
     // (traj_out.hip.h: action | ob << 8 | reward code << 16 | done << 24) and its new state in ~31, from a table whose
     // entries already hold, per (action, position), everything that does not depend on the rocks' codes:
     //   every entry: bits 28-30 = the OUTCOME CODE the step has when no uncollected rock is sampled ("fallback"), bit 31 =
@@ -517,7 +468,6 @@ struct RockEnv {
     // Outcome codes: 0 = bad rock sampled (-10), 1 = penalty (-100, done), 2 = good rock sampled (+10), 3 = east exit (+10,
     // done), 6 = nothing (0) — a sampled rock's own code IS its outcome code, done is bit 0, and the reward byte is one
     // v_perm_b32 lookup in an 8-byte constant.
-    static constexpr bool FAST_REC = true;
     static constexpr uint32_t REC_LUT_LO = 0x0A0A9CF6u, REC_LUT_HI = 0x00000000u;   // reward byte by outcome code 0..7
     struct RecTab { uint32_t e[TAB_ACTIONS][256]; };
     static __device__ __forceinline__ void build_rec_tab(RecTab &tab, const Shared &sh, const Params &p, int pos)
@@ -593,18 +543,6 @@ struct RockEnv {
     {
         Aux aux;
         step_pre(sh, p, st, a, rew, done, aux);
-        ob = sensor_ob(sh, st, aux, H, [&]() { return elem(quad_block(key, lane, 1u), lane & 3u); });
-    }
-
-    // the same from the (position, action) table (kernels that run enough steps per launch to build one: the rollouts)
-    template <class RT>
-    static __device__ __forceinline__ void step_with_H_tab(const Shared &sh, const StepTab &tab, State &st, int a, const RngKey &key,
-                                                           uint32_t lane, uint32_t H, int &ob, RT &rew, int &done)
-    {
-        Aux aux;
-        int rw;
-        step_tab(tab, st, a, rw, done, aux);
-        rew = (RT)rw;
         ob = sensor_ob(sh, st, aux, H, [&]() { return elem(quad_block(key, lane, 1u), lane & 3u); });
     }
 

@@ -224,13 +224,16 @@ struct TagEnv {
         f.need = tag && !colocated && no > 0;
     }
 
+    // binomial(1, move_prob) of tag.py:204 from the double's numerator: numpy's inversion gives [U <= thr] for p > .5 and
+    // [U > thr] for p <= .5 — the sense is a flag of the params (wave-uniform)
+    static __device__ __forceinline__ bool moves(const Params &p, uint64_t k) { return (k <= p.move_thr) != (p.move_gt != 0); }
     // the opponent's flight from words 0-2 of the lane's STEP block (tag.py:201-207)
     static __device__ __forceinline__ void flee(const Shared &sh, const Params &p, State &st, const Flight &f, uint32_t w0,
                                                 uint32_t w1, uint32_t w2)
     {
         const uint32_t pick = (f.list >> (2 * (w2 & 3u))) & 3u;       // np.random.choice: randint(2 or 4), exact mask
         const uint32_t to = sh.mv[4 * f.oi + (int)pick];               // the cell itself if the square does not exist
-        if (f.need && k53(w0, w1) <= p.move_thr) st.w = (st.w & ~(31u << 5)) | (to << 5);
+        if (f.need && moves(p, k53(w0, w1))) st.w = (st.w & ~(31u << 5)) | (to << 5);
     }
     template <class RT>
     static __device__ __forceinline__ void step_one_opponent(const Shared &sh, const Params &p, State &st, int a,
@@ -292,7 +295,7 @@ struct TagEnv {
                     if (oy == ay && ox > ax) { list |= 1u << (2 * cnt); ++cnt; }
                     if (ox == ax && oy < ay) { list |= 2u << (2 * cnt); ++cnt; }
                     if (oy == ay && ox < ax) { list |= 3u << (2 * cnt); ++cnt; }
-                    if (ws.next_k53() <= p.move_thr) {                    // binomial(1, move_prob)
+                    if (moves(p, ws.next_k53())) {                        // binomial(1, move_prob)
                         const uint32_t pick = (list >> (2 * ws.randint((uint32_t)cnt))) & 3u; // np.random.choice
                         const int nx = ox + (pick == 1u) - (pick == 3u), ny = oy + (pick == 0u) - (pick == 2u);
                         if (inside(nx, ny)) w = (w & ~(31u << sh)) | ((uint32_t)index(nx, ny) << sh);

@@ -25,11 +25,11 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
                                                       int64_t rec, const typename Env::Params p)
 {
     __shared__ typename Env::Shared sh;
-    // TAB: the lane step reads a (position, action) table built below; REC: ... the table of RockEnv::step_rec, whose lane step
-    // yields the lane's packed record and its new state (fresh episode included) in one go
-    constexpr bool REC = TAB && LPT == 1 && fast_rec_of<Env>::value;
-    __shared__ typename step_tab_of<Env, TAB, REC>::type tab;
-    static_assert(!TAB || SIMPLE, "the table-driven step serves the SIMPLE instantiation");
+    // TAB: the lane step reads the (position, action) table built below (RockEnv::step_rec: the lane's packed record and its
+    // new state, fresh episode included, in one go); one lane per thread, the quad's blocks time-shared
+    constexpr bool REC = TAB;
+    __shared__ typename step_tab_of<Env, TAB>::type tab;
+    static_assert(!TAB || (SIMPLE && LPT == 1), "the table-driven step serves the SIMPLE one-lane-per-thread instantiation");
     const bool auto_reset = SIMPLE || (flags & POMDP_AUTO_RESET);
     const uint32_t wg0 = blockIdx.x * (uint32_t)(BLOCK * LPT);
     const uint32_t last = SIMPLE ? (uint32_t)(BLOCK * LPT - 1) : (uint32_t)((uint64_t)(n - 1) - wg0);
@@ -86,8 +86,7 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
     }
     __syncthreads();
     if constexpr (TAB) {                                 // BLOCK threads = the 256 position bytes
-        if constexpr (REC) Env::build_rec_tab(tab, sh, p, (int)threadIdx.x);
-        else Env::build_tab(tab, sh, p, (int)threadIdx.x);
+        Env::build_rec_tab(tab, sh, p, (int)threadIdx.x);
         __syncthreads();
     }
     wait_loads();
@@ -135,10 +134,8 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
                     r[j] = (typename Env::Reward)__builtin_amdgcn_sbfe(recv[j], 16u, 8u);
                     d[j] = (int)(recv[j] >> 24);
                 }
-                else if constexpr (TAB) Env::step_with_H_tab(sh, tab, st[j], a_cur[j], key, glane[j], H, o[j], r[j], d[j]);
                 else Env::step_with_H(sh, p, st[j], valid[j] ? a_cur[j] : 0, key, glane[j], H, o[j], r[j], d[j]);
             }
-            else if constexpr (TAB) Fin::lane_step_tab(tab, st[j], a_cur[j], o[j], r[j], d[j], aux[j]);
             else Fin::lane_step(sh, p, st[j], valid[j] ? a_cur[j] : 0, key, glane[j], o[j], r[j], d[j], aux[j]);
             if (!live[j]) { r[j] = 0; d[j] = was_done[j]; }
             fresh[j] = live[j] && d[j] && auto_reset;
@@ -210,10 +207,9 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
     constexpr int W = Env::WORDS;
     using S = typename Env::S;
     __shared__ typename Env::Shared sh;
-    // the lane step yields the lane's packed record straight from RecTab (RockEnv::step_rec, ~31 instead of ~49 vector
-    // instructions per lane-step with one state word); the step_tab form is kept for envs without one
-    constexpr bool FAST = Env::FAST_REC;
-    __shared__ typename std::conditional<FAST, typename Env::RecTab, typename Env::StepTab>::type tab;
+    // the lane step yields the lane's packed record straight from RecTab (RockEnv::step_rec, ~31 vector instructions per
+    // lane-step with one state word)
+    __shared__ typename Env::RecTab tab;
     TL(0);
     TL_HW();
     const uint32_t l0 = blockIdx.x * (uint32_t)(4 * BLOCK) + 4u * threadIdx.x;   // this thread's first lane within the shard
@@ -236,8 +232,7 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
     Env::stage(sh, p, (int)threadIdx.x);
     __syncthreads();
     TL(1);
-    if constexpr (FAST) Env::build_rec_tab(tab, sh, p, (int)threadIdx.x);
-    else Env::build_tab(tab, sh, p, (int)threadIdx.x);
+    Env::build_rec_tab(tab, sh, p, (int)threadIdx.x);
     __syncthreads();
     TL(2);
     const int K = p.num_rocks;
@@ -267,48 +262,24 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
                 acts[j] = Env::k53_le(G[j], (uint32_t)(p.act_thr >> 26), (uint32_t)p.act_thr & Env::LO_MASK,
                                       [&]() { return Env::elem(Env::quad_block(key, glane0, 1u), (uint32_t)j); });
         }
-        int r[4], d[4];
-        uint32_t o[4], a_next[4], codes[4];
+        uint32_t a_next[4], codes[4], rec[4];
         const uint32_t a_taken[4] = {(uint32_t)a_cur[0], (uint32_t)a_cur[1], (uint32_t)a_cur[2], (uint32_t)a_cur[3]};
         Env::reset_codes4(R, key, glane0, K, codes);
-        if constexpr (FAST) {
-            uint32_t rec[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t lane = glane0 + (uint32_t)j;
-                S sj = st[j].s;
-                Env::step_rec(sh, tab, sj, a_taken[j], H[j], (S)((uint64_t)start | ((uint64_t)codes[j] << 8)), rec[j],
-                              [&]() { return Env::elem(Env::quad_block(key, lane, SENSOR_BLOCK + 1u), (uint32_t)j); });
-                if constexpr (Env::STOCHASTIC) {                                // the gate said no (rock.py:443): nothing happens
-                    sj = acts[j] ? sj : st[j].s;
-                    rec[j] = acts[j] ? rec[j] : a_taken[j];
-                }
-                st[j].s = sj;
-                a_next[j] = __umulhi(P[j], n_act);
-                a_cur[j] = (int)a_next[j];
-            }
-            out.put_records(rec, a_next);
-        } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            typename Env::Aux aux;
-            if constexpr (Env::STOCHASTIC) {
-                typename Env::State nx = st[j];
-                Env::step_tab(tab, nx, a_cur[j], r[j], d[j], aux);
-                if (acts[j]) st[j] = nx; else { r[j] = 0; d[j] = 0; aux.want = false; }
-            } else {
-                Env::step_tab(tab, st[j], a_cur[j], r[j], d[j], aux);
-            }
             const uint32_t lane = glane0 + (uint32_t)j;
-            st[j].s = d[j] ? (S)((uint64_t)start | ((uint64_t)codes[j] << 8)) : st[j].s;   // done lanes start a new episode
-            o[j] = (uint32_t)Env::sensor_ob(sh, st[j], aux, H[j], [&]() { return Env::elem(Env::quad_block(key, lane, SENSOR_BLOCK + 1u), (uint32_t)j); });
+            S sj = st[j].s;
+            Env::step_rec(sh, tab, sj, a_taken[j], H[j], (S)((uint64_t)start | ((uint64_t)codes[j] << 8)), rec[j],
+                          [&]() { return Env::elem(Env::quad_block(key, lane, SENSOR_BLOCK + 1u), (uint32_t)j); });
+            if constexpr (Env::STOCHASTIC) {                                // the gate said no (rock.py:443): nothing happens
+                sj = acts[j] ? sj : st[j].s;
+                rec[j] = acts[j] ? rec[j] : a_taken[j];
+            }
+            st[j].s = sj;
             a_next[j] = __umulhi(P[j], n_act);
             a_cur[j] = (int)a_next[j];
         }
-        const uint32_t r4[4] = {(uint32_t)r[0], (uint32_t)r[1], (uint32_t)r[2], (uint32_t)r[3]};   // the int8 reward IS its code
-        const uint32_t d4[4] = {(uint32_t)d[0], (uint32_t)d[1], (uint32_t)d[2], (uint32_t)d[3]};
-        out.put(a_taken, a_next, o, r4, r4, d4);
-        }
+        out.put_records(rec, a_next);
     }
     // the state is the loop's carry: it reaches memory once
     TL(3);
@@ -676,8 +647,12 @@ __global__ __launch_bounds__(BLOCK) void network_steps_quad_kernel(uint32_t *__r
 // are built AFTER the loop, dealt out one per thread and 64 side by side (board_lockstep).  A lane that finishes a second
 // episode before its next board exists triggers that pass early, for every lane of the wave that is waiting.  The state
 // that reaches memory is the same whichever kernel ran: current board, visited mask, next board.
+// The Returns sink keeps ten more registers per lane across the loop (traj_out.hip.h); with three or four mask words that is
+// 137-143 registers by the compiler's own choice — three waves per SIMD, where a 2^20-lane launch has four workgroups per CU
+// to place.  waves_per_eu(4) holds it to 128 (1 = no constraint, for the trajectory sinks).
+template <class L, int MW> struct quad_waves { static constexpr int value = (L::ID == LAYOUT_RETURNS && MW >= 3) ? 4 : 1; };
 template <int MW, class L = Columns>
-__global__ __launch_bounds__(BLOCK) void battleship_steps_quad_kernel(uint32_t *__restrict__ state, int32_t *__restrict__ action,
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(quad_waves<L, MW>::value))) void battleship_steps_quad_kernel(uint32_t *__restrict__ state, int32_t *__restrict__ action,
                                                                       int32_t *__restrict__ ob, int32_t *__restrict__ reward,
                                                                       uint8_t *__restrict__ done, int64_t n, RngKey key0,
                                                                       uint32_t lane0, RngKey akey0, int k_steps, int64_t rec,

@@ -156,14 +156,6 @@ struct Finisher<RockEnv<W, false>, LPT, CHAIN, typename std::enable_if<(LPT >= 2
         Env::step_pre(sh, p, st, a, rew, done, aux);
         ob = 0;
     }
-    // the same from the (position, action) table of a multi-step launch (RockEnv::StepTab)
-    template <class Tab, class RT>
-    static __device__ __forceinline__ void lane_step_tab(const Tab &tab, typename Env::State &st, int a, int &ob, RT &rew,
-                                                         int &done, Aux &aux)
-    {
-        Env::step_tab(tab, st, a, rew, done, aux);
-        ob = 0;
-    }
     // wave-private LDS scratch (one instance: function-local static of this accessor)
     static __device__ __forceinline__ uint32_t (&blk_lds())[BLOCK / 64][NT][4]
     {
@@ -382,12 +374,10 @@ template <class Fin, class = void> struct quad_policy_of : std::false_type {};
 template <class Fin> struct quad_policy_of<Fin, std::enable_if_t<Fin::QUAD_POLICY>> : std::true_type {};
 
 struct NoTab {};
-// envs whose table-driven lane step yields the lane's packed record directly (RockEnv<1, .>::step_rec)
-template <class Env, class = void> struct fast_rec_of : std::false_type {};
-template <class Env> struct fast_rec_of<Env, std::enable_if_t<Env::FAST_REC>> : std::true_type {};
-template <class Env, bool ON, bool REC = false> struct step_tab_of { using type = NoTab; };
-template <class Env> struct step_tab_of<Env, true, false> { using type = typename Env::StepTab; };
-template <class Env> struct step_tab_of<Env, true, true> { using type = typename Env::RecTab; };
+// the (position, action) table of a table-driven launch: RockEnv::RecTab, whose lane step (step_rec) yields the lane's
+// packed record and its new state in one go
+template <class Env, bool ON> struct step_tab_of { using type = NoTab; };
+template <class Env> struct step_tab_of<Env, true> { using type = typename Env::RecTab; };
 
 static inline RngKey make_key(uint64_t seed, uint64_t t)
 {

@@ -308,9 +308,11 @@ template <class Env> struct LegalOf<Env, std::void_t<typename Env::Legal>> {
 // every step's action / ob / reward / done (and state) is written as the single-step launches write them.
 // Six waves per SIMD (at most 80 registers) where the compiler's own choice was five (81-86): the loop's CHECK / fresh-episode
 // branches stall on memory, and the sixth wave fills those slots — RockSample(7,8) 4.64 -> 4.52, (15,15) 5.98 -> 5.85, Tag
-// 4.35 -> 4.15 us per step at 2^20 lanes; four waves: 4.95 / 6.42 / 4.69, eight (spilling): 5.17 / 6.58 / 4.22.  BattleShip's
-// large boards (three and four state words) keep the compiler's choice: they would spill 100+ bytes per lane.
-template <class Env> struct heur_waves { static constexpr int value = Env::WORDS <= 2 ? 6 : 4; };
+// 4.35 -> 4.15 us per step at 2^20 lanes; four waves: 4.95 / 6.42 / 4.69, eight (spilling): 5.17 / 6.58 / 4.22.  BattleShip
+// (three state words and more) keeps the compiler's own choice — waves_per_eu(1) constrains nothing: 81-105 registers, five
+// or four waves; six would spill 100+ bytes per lane.  Every launch runs at least one step (the launcher's k >= 1): the
+// outputs written after the loop are those of the launch's last step.
+template <class Env> struct heur_waves { static constexpr int value = Env::WORDS <= 2 ? 6 : 1; };
 template <class Env, bool RING>   // RING: a bounded RockSample history (history_push keeps its window)
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(heur_waves<Env>::value)))
 void heuristic_steps_kernel(const typename Env::Params p, uint32_t *__restrict__ state,
@@ -474,14 +476,13 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(const typename Env::Para
 {
 #pragma clang fp contract(off) // the discounted return must not be fused into FMAs (hipcc defaults to contract=fast)
     __shared__ typename Env::Shared sh;
-    constexpr bool TAB = ROLLOUT_TAB<Env>::value;            // RockSample: the (position, action) table of the fused loops
-    constexpr bool REC = TAB && fast_rec_of<Env>::value;     // ... in the form whose lane step yields the packed record (step_rec)
-    __shared__ typename step_tab_of<Env, TAB, REC>::type tab;
+    constexpr bool TAB = ROLLOUT_TAB<Env>::value;            // RockSample: the (position, action) table of the fused loops,
+    constexpr bool REC = TAB;                                // whose lane step yields the packed record (step_rec)
+    __shared__ typename step_tab_of<Env, TAB>::type tab;
     Env::stage(sh, p, (int)threadIdx.x);
     __syncthreads();
     if constexpr (TAB) {
-        if constexpr (REC) Env::build_rec_tab(tab, sh, p, (int)threadIdx.x);
-        else Env::build_tab(tab, sh, p, (int)threadIdx.x);
+        Env::build_rec_tab(tab, sh, p, (int)threadIdx.x);
         __syncthreads();
     }
     const int64_t n = n_roots * sims_per_root;
@@ -532,7 +533,6 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(const typename Env::Para
                     r = (double)(int32_t)__builtin_amdgcn_sbfe(rec, 16u, 8u);
                     d2 = (int)(rec >> 24);
                 }
-                else if constexpr (TAB) Env::step_with_H_tab(sh, tab, nx, a, key, lane, comp<J>(sq), o2, r, d2);
                 else Env::step_with_H(sh, p, nx, a, key, lane, comp<J>(sq), o2, r, d2);
             } else {
                 Env::step(sh, p, nx, a, key, lane, o2, r, d2);

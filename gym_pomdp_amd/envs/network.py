@@ -45,6 +45,12 @@ class NetworkEnv(BatchedEnv):
     def _build_params(self):
         return make_params(self._n_machines, self.problem_type)
 
+    def _validate_state(self, st, what):
+        """bit i = machine i: a bit at or above n_machines names no machine (the kernels index per-machine-set tables with
+        the word)"""
+        if self._n_machines < 32 and bool(((st[0].to(torch.int64) & 0xFFFFFFFF) >> self._n_machines).any()):
+            raise ValueError("%s: Network state words may only have bits 0 .. %d set" % (what, self._n_machines - 1))
+
     def decode_state(self):
         w = self._state[0].to(torch.int64) & 0xFFFFFFFF
         return torch.stack([(w >> i) & 1 for i in range(self._n_machines)], dim=1)

@@ -14,12 +14,12 @@ def make_params(num_opponents=1, move_prob=.8, obs_cells=29, board_size=(10, 5))
     p = _native.TagParams()
     p.num_opponents, p.obs_cells = num_opponents, obs_cells
     if move_prob == .8:
-        p.move_thr = tables.TAG_MOVE_THR
+        p.move_thr, p.move_gt = tables.TAG_MOVE_THR, 0
     else:
+        if not 0. < move_prob < 1.:
+            raise ValueError("Tag: move_prob must lie in (0, 1)")
         thr, sense = tables.bernoulli_threshold(move_prob)
-        if sense != "le":
-            raise ValueError("Tag: move_prob <= 0.5 is not supported by the packed threshold compare")
-        p.move_thr = thr
+        p.move_thr, p.move_gt = thr, int(sense == "gt")     # numpy's binomial(1, p): [U > thr] for p <= .5 (tag.py:204)
     return p, 1, 5, obs_cells + 1
 
 

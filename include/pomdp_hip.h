@@ -105,6 +105,8 @@ typedef struct pomdp_tag_params {
     int32_t  num_opponents; /* 1..4                                       tag.py:87 */
     int32_t  obs_cells;     /* "opponent seen" observation value          tag.py:94 */
     uint64_t move_thr;      /* opponent moves iff k53 <= move_thr         tag.py:204 */
+    int32_t  move_gt;       /* 1: ... iff k53 > move_thr instead — numpy's binomial(1, p) for p <= .5 (ABI 12) */
+    int32_t  reserved;
 } pomdp_tag_params;
 
 /* replaces TagEnv.reset (tag.py:97-102, 181-193) */
@@ -226,10 +228,10 @@ int pomdp_philox_blocks(const uint32_t *ctr_key, uint32_t *out, int64_t n_blocks
  * policy kernel runs once, for t0, and every step launch also leaves the policy's actions for the
  * following call counter in `action` (on RockSample they ride in the cooperative reset pass); with a
  * distinct action_seed each step is a policy launch plus a step launch.  With POMDP_FUSE_STEPS in `flags` (shared key
- * only) up to 64 consecutive steps run inside one launch: every step's ob / reward / done / next action is still
+ * only) up to pomdp_fuse_max() (256) consecutive steps run inside one launch: every step's ob / reward / done / next action is still
  * computed and written, in the same order, and the state when the launch ends, so every buffer holds what the per-step
  * launches leave, but a lane's state and action stay in registers between its steps and the launch ramp is paid once
- * per 64 steps; the first launch derives the actions of t0 itself, so there is no policy launch at all.  Either way
+ * per launch; the first launch derives the actions of t0 itself, so there is no policy launch at all.  Either way
  * `action` holds the actions of t0 + k_steps on return.  The caller's call counter advances by k_steps.  `params` points
  * at the env's pomdp_<env>_params; `reward` is int32 or float per env.  lane0 must be a multiple of 4 (the policy's
  * Philox block is shared by global lanes 4q .. 4q+3); n is arbitrary.  Params and pointers are checked before anything
@@ -244,7 +246,7 @@ int pomdp_rollout_synthetic(int env, const void *params, uint32_t *state, int32_
  * elements) instead of overwriting one row, and `action` (device, int32 [k_steps + 1][pitch]) receives the actions of
  * call counter t0 + s in row s (row k_steps = the actions the next call would take).  Row s of every output equals what
  * pomdp_synthetic_actions + pomdp_<env>_step at t0 + s leave in their n-element buffers; `state` ends as after the last
- * step.  This is the batched form of the reference callers' episode loops (rock.py:553-575): one launch per 64 steps,
+ * step.  This is the batched form of the reference callers' episode loops (rock.py:553-575): one launch per 256 steps,
  * each lane's state in registers, 13 bytes per lane-step written, state and first actions read once per launch.  Any
  * alignment and pitch >= n is accepted; columns on 16-byte boundaries (done: 4) with a pitch that is a multiple of 4 take the
  * launches that store 16 bytes per thread. */
@@ -350,7 +352,7 @@ int pomdp_collect_returns(int env, const void *params, uint32_t *state, const po
  * pomdp_heuristic_steps): a launch's fixed cost (kernel start, table build, drain) is paid once per this many steps.
  * pomdp_fuse_max(v) sets it for the calling process (1 <= v <= 256; v <= 0 only reads) and returns the previous value;
  * the default is POMDP_FUSE_MAX_DEFAULT.  Results never depend on it. */
-#define POMDP_FUSE_MAX_DEFAULT 64
+#define POMDP_FUSE_MAX_DEFAULT 256
 int pomdp_fuse_max(int v);
 
 /* ---- planner hooks ------------------------------------- */

@@ -80,8 +80,14 @@ def env_args(name, **kw):
         thr = int(kw.get("act_thr", 0))
         return [kw.get("board_size", 7), kw.get("num_rocks", 8), 1, thr & 0xFFFFFFFF, thr >> 32]
     if name == "tag":
-        thr = int(kw.get("move_thr", 0))
-        return [kw.get("num_opponents", 1), kw.get("obs_cells", 29), thr & 0xFFFFFFFF, thr >> 32]
+        thr, gt = int(kw.get("move_thr", 0)), 0
+        p = kw.get("move_prob", .8)
+        if p != .8:          # numpy legacy binomial(1, p), distributions.c: [U > qn] for p <= .5, 1 - [U > qn] above; qn = exp(log(q))
+            import math
+            gt = int(p <= .5)
+            q = 1.0 - p if gt else 1.0 - (1.0 - p)
+            thr = math.floor(math.exp(math.log(q)) * 2 ** 53)
+        return [kw.get("num_opponents", 1), kw.get("obs_cells", 29), thr & 0xFFFFFFFF, thr >> 32, gt]
     if name == "battleship":
         bs = kw.get("board_size", (5, 5))
         return [bs[0], bs[1], kw.get("max_len", 3)]

@@ -194,6 +194,7 @@ struct or_env {
     /* ---- tag ---- */
     int n_opponents, obs_cells;
     uint64_t move_thr;
+    int move_gt;            /* numpy's binomial(1, p) is [U > thr] for p <= .5, [U <= thr] for p > .5 */
     coord opp[MAX_OPP];
     int num_opp;
     /* ---- battleship ---- */
@@ -278,6 +279,7 @@ or_env *or_env_new(int kind, const int64_t *a, int nargs)
         e->obs_cells = nargs >= 2 ? (int)a[1] : 29;
         e->move_thr = nargs >= 4 ? ((uint64_t)(uint32_t)a[2] | ((uint64_t)(uint32_t)a[3] << 32)) : 0;
         if (e->move_thr == 0) e->move_thr = TAG_MOVE_THR;
+        e->move_gt = nargs >= 5 ? (int)a[4] : 0;
         if (e->n_opponents < 1 || e->n_opponents > MAX_OPP) rc = -1;
         break;
     case OR_ENV_BATTLESHIP:
@@ -458,7 +460,7 @@ static void tag_move_opponent(or_env *e, int i, or_ws *np_rng)
     if (o.x == a.x && o.y < a.y) acts[n++] = 2;
     if (o.y == a.y && o.x < a.x) acts[n++] = 3;
     uint64_t k = or_draw_k53(np_rng);                  /* binomial(1, move_prob) */
-    if (k <= e->move_thr) {
+    if ((k <= e->move_thr) != (e->move_gt != 0)) {     /* numpy: 1 - [U > q] for p > .5, [U > q] for p <= .5 */
         int pick = acts[or_draw_randint(np_rng, (uint32_t)n)];   /* np.random.choice(actions) */
         coord nx = { o.x + MOVES[pick].x, o.y + MOVES[pick].y };
         if (tag_inside(nx)) e->opp[i] = nx;

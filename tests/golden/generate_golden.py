@@ -40,6 +40,8 @@ CASES = [
     ("tag_1", "tag", {}, 4000, 512, 64),
     ("tag_2", "tag", dict(num_opponents=2), 4000, 256, 64),
     ("tag_4", "tag", dict(num_opponents=4), 2000, 128, 64),
+    ("tag_1_p03", "tag", dict(move_prob=.3), 2000, 128, 64),      # binomial(1, p <= .5): the other sense of numpy's inversion
+    ("tag_2_p06", "tag", dict(num_opponents=2, move_prob=.6), 1000, 64, 64),
     ("battleship_5_5", "battleship", {}, 1500, 512, 48),
     ("battleship_10_10", "battleship", dict(board_size=(10, 10), max_len=5), 2000, 48, 400),
     ("battleship_8_6", "battleship", dict(board_size=(8, 6), max_len=4), 1000, 128, 64),

@@ -1325,3 +1325,18 @@ def test_set_state_rejects_states_of_another_layout():
     r.set_state(r.state.clone().reshape(-1))                                   # one-word layouts: [N] is unambiguous
     with pytest.raises(ValueError):
         r.legal_actions(torch.zeros((2, n), dtype=torch.int32))
+
+
+def test_randomised_sweep_on_a_fixed_seed(monkeypatch):
+    """tools/gpu_fuzz.py as part of the suite: 45 seconds of random env configs, batch sizes (both launch geometries), lane
+    offsets up to 2^32, call counters up to 2^40, auto-reset on and off, invalid actions, and — one case in four here —
+    trajectory collections in a random sink (columns / blocked / packed / narrow / returns-only), each compared word for
+    word with the oracle.  The seed is fixed, so a failure reproduces; the builder's longer sweeps on fresh seeds are
+    logged under profiles/."""
+    import os
+    import sys
+    from conftest import REPO
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    monkeypatch.setenv("FUZZ_COLLECT", "0.25")
+    import gpu_fuzz
+    assert gpu_fuzz.main(45.0, seed=20261001) >= 20

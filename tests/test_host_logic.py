@@ -50,7 +50,7 @@ def test_bad_arguments_are_rejected_without_a_gpu():
 def test_struct_sizes_match_header_layout():
     from gym_pomdp_amd import _native as n
     assert C.sizeof(n.RockParams) == 16 + 16 + 16 + 256 + 32 * 8 + 32 * 8 + 16
-    assert C.sizeof(n.TagParams) == 16
+    assert C.sizeof(n.TagParams) == 24
     assert C.sizeof(n.BattleShipParams) == 16 + 16 + 12 * 16
     assert C.sizeof(n.TigerParams) == 8
     assert C.sizeof(n.NetworkParams) == 8 + 32 * 4 + 3 * 8
@@ -65,7 +65,7 @@ def test_ctypes_structs_match_the_header_as_gcc_lays_it_out(tmp_path):
     pairs = {"pomdp_rock_params": n.RockParams, "pomdp_tag_params": n.TagParams, "pomdp_battleship_params": n.BattleShipParams,
              "pomdp_tiger_params": n.TigerParams, "pomdp_network_params": n.NetworkParams, "pomdp_step_args": n.StepArgs,
              "pomdp_collect_args": n.CollectArgs, "pomdp_rock_belief": n.RockBelief, "pomdp_history": n.HistoryPtrs,
-             "pomdp_returns": n.Returns}
+             "pomdp_returns": n.Returns, "pomdp_traj_args": n.TrajArgs, "pomdp_return_stats": n.ReturnStats}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "pomdp_hip.h"', 'int main(void) {']
     for cname, cls in pairs.items():
         lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))

@@ -12,7 +12,7 @@ REF = os.environ.get("GYM_POMDP_REFERENCE", "/root/reference")
 pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "gym_pomdp")), reason="reference not present")
 
 CASES = [("rock", {}), ("rock", dict(board_size=11, num_rocks=11)), ("stochrock", {}), ("tag", {}),
-         ("tag", dict(num_opponents=3)), ("battleship", {}), ("battleship", dict(board_size=(7, 9), max_len=4)),
+         ("tag", dict(num_opponents=3)), ("tag", dict(move_prob=.3)), ("tag", dict(num_opponents=2, move_prob=.55)), ("battleship", {}), ("battleship", dict(board_size=(7, 9), max_len=4)),
          ("tiger", {}), ("network", {}), ("network", dict(n_machines=13, problem_type=3)),
          ("network", dict(n_machines=7, problem_type=2))]
 

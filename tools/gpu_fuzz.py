@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Randomised parity sweep (dev aid, GPU box): random env configs, batch sizes (both launch geometries), lane offsets,
 call counters, auto-reset on/off, valid and invalid actions — HIP path vs the oracle, word for word; one case in eight
-is a trajectory collection (fused launches, up to 2^20 + 2048 lanes, a random trajectory layout; FUZZ_COLLECT sets the
-share) checked row by row against the oracle.
-usage: python tools/gpu_fuzz.py [seconds]"""
+is a trajectory collection (fused launches, up to 2^20 + 2048 lanes, a random trajectory layout or the returns-only sink;
+FUZZ_COLLECT sets the share) checked row by row against the oracle.
+usage: python tools/gpu_fuzz.py [seconds [seed]]      (tests/test_gpu_parity.py runs a 45-second sweep on a fixed seed)"""
 import os
 import sys
 import time
@@ -21,6 +21,7 @@ CONFIGS = [
     ("rock", "Rock-v0", dict(board_size=11, num_rocks=11)), ("rock", "Rock-v0", dict(board_size=15, num_rocks=15)),
     ("rock", "Rock-v0", dict(board_size=4, num_rocks=3)), ("stochrock", "StochasticRock-v0", {}),
     ("tag", "Tag-v0", {}), ("tag", "Tag-v0", dict(num_opponents=2)), ("tag", "Tag-v0", dict(num_opponents=4)),
+    ("tag", "Tag-v0", dict(move_prob=.3)), ("tag", "Tag-v0", dict(num_opponents=3, move_prob=.6)),
     ("battleship", "Battleship-v0", {}), ("battleship", "Battleship-v0", dict(board_size=(10, 10), max_len=5)),
     ("battleship", "Battleship-v0", dict(board_size=(8, 6), max_len=4)),
     ("tiger", "Tiger-v0", {}), ("network", "Network-v0", {}), ("network", "Network-v0", dict(n_machines=16, problem_type=1)),
@@ -49,7 +50,16 @@ def collect_case(rs):
     st = o.new_state(n)
     ob_o = o.batch_reset(st, seed, lane0, t0, nthreads=8)
     assert np.array_equal(e.reset().cpu().numpy(), ob_o), (name, kw, n, "reset ob")
-    layout = ("columns", "blocked", "packed")[rs.randint(3)]             # round 4: the trajectory layout too
+    layout = ("columns", "blocked", "packed", "narrow", "returns")[rs.randint(5)]    # the sink too
+    if layout == "returns":                               # no trajectory: the per-lane episode statistics (pomdp_collect_returns)
+        stats = e.collect_returns(steps)
+        acc, cnt = ol.new_return_stats(n)
+        o.batch_collect_returns(st, acc, cnt, e._discount, seed, lane0, t0 + 1, steps, nthreads=8)
+        ctx = ("returns", name, kw, n, lane0, seed, t0, steps)
+        assert np.array_equal(stats.acc[:, :n].cpu().numpy().view(np.uint64), acc.view(np.uint64)), ctx
+        assert np.array_equal(stats.cnt[:, :n].cpu().numpy(), cnt), ctx
+        assert np.array_equal(e.state.cpu().numpy().view(np.uint32), st), ctx
+        return
     tr = e.decode_trajectory(e.collect_synthetic(steps, layout=layout))
     done = np.zeros(n, np.uint8)
     for k in range(steps):
@@ -65,8 +75,8 @@ def collect_case(rs):
     assert np.array_equal(e.state.cpu().numpy().view(np.uint32), st), ("collect", name, kw, n, "state")
 
 
-def main(budget):
-    rs = np.random.RandomState(int(time.time()) & 0xFFFFFF)
+def main(budget, seed=None):
+    rs = np.random.RandomState(int(time.time()) & 0xFFFFFF if seed is None else seed)
     t_end, cases = time.time() + budget, 0
     while time.time() < t_end:
         if rs.rand() < float(os.environ.get("FUZZ_COLLECT", "0.12")):
@@ -111,7 +121,8 @@ def main(budget):
         cases += 1
         del e
     print("fuzz ok: %d random cases in %.0f s" % (cases, budget))
+    return cases
 
 
 if __name__ == "__main__":
-    main(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0)
+    main(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0, int(sys.argv[2]) if len(sys.argv) > 2 else None)

@@ -1,12 +1,12 @@
 #!/bin/bash
 # VALU-issue counters of the kernels whose bound is instruction issue ("report int-op rate"): the fused
-# rollout (configs[4]), the heuristic-policy loop, and the fused step launches in both timed shapes (64 and 20 steps per
-# launch) and every trajectory layout, plus the HBM byte counters of the headline's shapes.  One rocprofv3 --pmc pass per
+# rollout (configs[4]), the heuristic-policy loop, and the fused step launches in both timed shapes (256 and 20 steps per
+# launch) and every sink, plus the HBM byte counters of the headline's shapes.  One rocprofv3 --pmc pass per
 # counter group (never combined with other trace domains), summaries into gpurun_out/<tag>/.
 # usage: tools/gpu_pmc_valu.sh <tag> [sets]    -> gpurun_out/<tag>/{pmc_valu.json, pmc_valu.txt}
-#   sets (default "planners headline envs"): planners = rollouts + heuristic loops; headline = RockSample(7,8) in the three
-#   layouts x (64, 20) steps per launch + HBM byte passes; envs = the other envs' fused launches (packed and columns);
-#   shards = RockSample(7,8) at 2^17 / 2^18 lanes.
+#   sets (default "planners headline envs"): planners = rollouts + heuristic loops; headline = RockSample(7,8) in every sink
+#   (packed, columns, blocked, narrow, returns) x (256, 20) steps per launch + HBM byte passes; envs = the other envs' fused
+#   launches (packed and columns); shards = RockSample(7,8) at 2^17 / 2^18 / 2^19 lanes.
 #   Workloads that are not re-recorded are carried over from the newest profiles/*_pmc_valu.json, each with the source hash
 #   it was recorded under (bench.py: counters_stale).
 TAG=${1:-pmcv}
@@ -33,7 +33,7 @@ traffic() {   # name, bench args...: FETCH_SIZE and WRITE_SIZE in separate passe
   timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $W/$name/pmc_write -o w -- python $REPO/bench.py "$@" > $W/$name/w.log 2>&1
 }
 sfx() { if [ "$1" = columns ]; then echo ""; else echo "_$1"; fi; }
-S64="--prewarm 0 --warmup 64 --steps 640 --seeds 0 --repeats 1 --no-cpu-baseline --no-extras"
+S256="--prewarm 0 --warmup 256 --steps 1024 --seeds 0 --repeats 1 --no-cpu-baseline --no-extras"
 S20="--gpus 1 --steps 20 --warmup 5 --prewarm 0 --seeds 0 --no-cpu-baseline --no-extras"
 for set in $SETS; do
   case $set in
@@ -48,24 +48,27 @@ for set in $SETS; do
     traffic heuristic_rock15 --env rock15 --mode heuristic --prewarm 0 --warmup 128 --steps 1024
     traffic heuristic_rock --env rock --mode heuristic --prewarm 0 --warmup 128 --steps 1024 ;;
   headline)
-    for l in packed columns blocked; do
-      run step64_rock$(sfx $l) --env rock --layout $l $S64
+    for l in packed columns blocked narrow returns; do
+      run step256_rock$(sfx $l) --env rock --layout $l $S256
       run step20_rock$(sfx $l) --env rock --layout $l $S20
       traffic step20_rock$(sfx $l) --env rock --layout $l $S20
     done
-    traffic step64_rock_packed --env rock --layout packed $S64 ;;
+    traffic step256_rock_packed --env rock --layout packed $S256
+    traffic step256_rock_columns --env rock --layout columns $S256 ;;
+  sinks)    # the headline workload's sinks at 256 steps per launch only (a quick A/B of what a sink costs)
+    for l in packed narrow returns; do run step256_rock$(sfx $l) --env rock --layout $l $S256; done ;;
   envs)
     for e in rock15 tag tiger network battleship battleship5; do
-      run step64_${e}_packed --env $e --layout packed $S64
+      run step256_${e}_packed --env $e --layout packed $S256
       run step20_${e}_packed --env $e --layout packed $S20
     done
-    for e in tag network battleship; do run step64_$e --env $e --layout columns $S64; done
+    for e in tag network battleship; do run step256_$e --env $e --layout columns $S256; done
     # BASELINE.json configs[3] per GPU: BattleShip 10x10 at 2^19 lanes (bench.py: configs.battleship)
-    run step64_battleship_packed_2e19 --env battleship --layout packed --lanes-per-gpu 524288 $S64
+    run step256_battleship_packed_2e19 --env battleship --layout packed --lanes-per-gpu 524288 $S256
     run step20_battleship_packed_2e19 --env battleship --layout packed --lanes-per-gpu 524288 $S20 ;;
   shards)   # the shards a 2^20-lane batch leaves per GPU at 8 / 4 / 2 GPUs (strong scaling: DESIGN.md §7)
     for lg in 17 18 19; do       # both launch shapes: bench.py's strong_scaling.frac_of_floor looks the shard up by size and length
-      run step64_rock_packed_2e$lg --env rock --layout packed --lanes-per-gpu $((1 << lg)) $S64
+      run step256_rock_packed_2e$lg --env rock --layout packed --lanes-per-gpu $((1 << lg)) $S256
       run step20_rock_packed_2e$lg --env rock --layout packed --lanes-per-gpu $((1 << lg)) $S20
     done ;;
   esac

@@ -80,10 +80,11 @@ def main():
         name = os.path.basename(wd)
         merged = {}
         last = None
-        if name.startswith("heuristic_"):          # the timed region = the last ceil(K / 64) launches of the run (bench.py: heuristic_mode)
+        if name.startswith("heuristic_"):          # the timed region = the last ceil(K / steps per launch) launches of the run (bench.py: heuristic_mode)
             import re
+            from gym_pomdp_amd._native import FUSE_MAX_DEFAULT
             m = re.search(r"--steps (\d+)", cmds.get(name, ""))
-            last = -(-int(m.group(1)) // 64) if m else None
+            last = -(-int(m.group(1)) // FUSE_MAX_DEFAULT) if m else None
         for sub in ("p1", "p2"):
             db = db_of(os.path.join(wd, sub))
             if not db:
