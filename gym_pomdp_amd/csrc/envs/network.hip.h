@@ -97,13 +97,26 @@ struct NetworkEnv {
         return ob == 2 ? 1.0 : 0.0;
     }
 
-    // ---- pieces of the step for the quad-per-thread fused loop (fused_impl.hip.h: network_steps_quad_kernel) ----------
-    // Thresholds against the draw's HIGH word itself: k53 <= thr is decided by (H >> 5) < (thr >> 26), i.e. H < T with
-    // T = (thr >> 26) << 5, unless H lies in [T, T + 32) — the tie (probability 2^-27) that asks for the low word.
+    // ---- the step's random words (ABI 12) ------------------------------------------------------------------------
+    // step() draws one double per UP machine, in index order, then one for the action (network.py:94-109), each compared with
+    // a threshold.  16 random bits decide such a comparison unless they EQUAL the threshold's top 16 bits (2^-16 per draw), so
+    // the top 16 bits of double j are a half — upper for even j, lower for odd j — of the lane's element of a block shared
+    // by the four lanes of a quad (stream STEP, counter word 0 = lane >> 2, block j >> 1): one Philox block serves two draws
+    // of each of four lanes.  The 37 bits below them come from the lane's own stream STEP_LO (block j >> 1, elements 2 (j & 1)
+    // and 2 (j & 1) + 1) and are generated on a tie only.
+    static constexpr uint32_t STREAM_STEP_LO = POMDP_STREAM_STEP_LO;
+    static constexpr uint32_t TIE = 1u << 16;               // H - T < TIE: the 16 bits equal the threshold's
+    static __device__ __forceinline__ uint4 quad_block(const RngKey &key, uint32_t lane, uint32_t b)
+    {
+        return stream_block(key, lane >> 2, POMDP_STREAM_STEP, b);
+    }
+    static __device__ __forceinline__ uint32_t elem(const uint4 &w, uint32_t e) { return e == 0 ? w.x : e == 1 ? w.y : e == 2 ? w.z : w.w; }
+    // Thresholds against a draw's 16 bits held in the TOP half of a 32-bit word H (whatever lies below): k53 <= thr is
+    // decided by H < T with T = (thr >> 37) << 16, unless H - T < TIE.
     struct Thr { uint32_t fail, nb, obs; };
     static __device__ __forceinline__ Thr thresholds(const Params &p)
     {
-        return Thr{(uint32_t)(p.fail_thr >> 26) << 5, (uint32_t)(p.fail_nb_thr >> 26) << 5, (uint32_t)(p.obs_thr >> 26) << 5};
+        return Thr{(uint32_t)(p.fail_thr >> 37) << 16, (uint32_t)(p.fail_nb_thr >> 37) << 16, (uint32_t)(p.obs_thr >> 37) << 16};
     }
     // machines that see a failed neighbour (network.py:82-85), from the nibble tables
     static __device__ __forceinline__ uint32_t nb_failed_of(const Shared &sh, const Params &p, uint32_t s0)
@@ -114,17 +127,16 @@ struct NetworkEnv {
         for (int k = 0; 4 * k < M; ++k) nbf |= sh.nbf[k][(down >> (4 * k)) & 15u];          // wave-uniform trip count
         return nbf;
     }
-    // N consecutive draws of a lane's STEP stream (high words of one Philox block) applied to the next N up machines of
-    // `todo` (network.py:94-99, index order): returns the machines that fail, removes the N from `todo`, and folds "some
-    // draw was a tie" into `near` (the minimum of H - T over the draws; a tie has H - T < 32 — the caller then takes the
-    // exact per-lane form, so a false alarm from a slot without a machine costs time, 2^-27 of the time, and nothing
-    // else).  A slot without a machine (todo ran out) kills nothing.
-    template <int N>
-    static __device__ __forceinline__ uint32_t draws(const uint32_t (&H)[N], uint32_t &todo, uint32_t nbf, const Thr &T, uint32_t &near)
+    // The two draws of one word W of the lane (upper half: the earlier draw) applied to the next two up machines of `todo`
+    // (network.py:94-99, index order): returns the machines that fail, removes the two from `todo`, and folds "some draw
+    // was a tie" into `near` (the minimum of H - T over the draws; a tie has H - T < TIE — the caller then takes the exact
+    // per-lane form, so a false alarm from a slot without a machine costs time, 2^-16 of the time, and nothing else).
+    static __device__ __forceinline__ uint32_t draw2(uint32_t W, uint32_t &todo, uint32_t nbf, const Thr &T, uint32_t &near)
     {
         uint32_t kill = 0;
+        const uint32_t H[2] = {W, W << 16};
 #pragma unroll
-        for (int k = 0; k < N; ++k) {
+        for (int k = 0; k < 2; ++k) {
             const uint32_t lb = todo & (0u - todo);                              // this draw's machine; 0 = none left
             todo ^= lb;
             const uint32_t t = (nbf & lb) ? T.nb : T.fail;
@@ -133,16 +145,12 @@ struct NetworkEnv {
         }
         return kill;
     }
-    static __device__ __forceinline__ uint32_t draw4(const uint4 &h, uint32_t &todo, uint32_t nbf, const Thr &T, uint32_t &near)
+    // the action's draw (network.py:106-109) when it is draw `slot` (0 or 1) of word W; truthful iff k53 <= obs_thr
+    static __device__ __forceinline__ bool truthful_of(uint32_t W, int slot, const Thr &T, uint32_t &near)
     {
-        const uint32_t H[4] = {h.x, h.y, h.z, h.w};
-        return draws<4>(H, todo, nbf, T, near);
-    }
-    // the action's draw (network.py:106-109): word `w` of the same stream; truthful iff k53 <= obs_thr
-    static __device__ __forceinline__ bool truthful_of(uint32_t w, const Thr &T, uint32_t &near)
-    {
-        near = min(near, w - T.obs);
-        return w < T.obs;
+        const uint32_t H = slot ? W << 16 : W;
+        near = min(near, H - T.obs);
+        return H < T.obs;
     }
     // reward, observation and the reboot (network.py:87-92, 101-112) once the machine draws are in: s = state after the
     // failures, base = reward before the action's cost
@@ -159,17 +167,30 @@ struct NetworkEnv {
         rew = (RT)r;
     }
 
-    // network.py:71-114.  The reference draws one double per *up* machine in index order, then one for
-    // the action.  Lanes iterate over the draws (j = 0, 1, ...), not over the machines: j is
-    // wave-uniform, so the Philox block that feeds doubles 2q and 2q+1 is generated under a uniform
-    // condition and the only divergence left is the per-lane number of up machines.
-    // The step as the single-step kernels, the rollouts and the generic fused loop run it: the FIRST block of the lane's
-    // stream is computed unconditionally and its four words applied straight-line (draw4) — under a random policy 98 % of the
-    // lanes need no more — then the wave loops, block by block, only while some lane still has machines to draw for or its
-    // action's draw ahead.  A draw decided by its low word (2^-27) sends the lane through step_exact.
+    // network.py:71-114 for one lane, as the single-step kernels, the rollouts, the heuristic loop and the generic fused
+    // loop run it: the lane takes its words from its quad's blocks, two draws per block, and the wave loops block by block
+    // while some lane still has machines to draw for or its action's draw ahead (j is wave-uniform; under a random policy a
+    // lane has 1.4 machines up, so two blocks serve 98 % of the lanes).  A tie (2^-16 per draw) sends the lane through
+    // step_exact.
     template <class RT>
     static __device__ __forceinline__ void step(const Shared &sh, const Params &p, State &st, int a,
                                                 const RngKey &key, uint32_t lane, int &ob, RT &rew, int &done)
+    {
+        step_from<0>(sh, p, st, a, key, lane, 0u, 0u, 0u, ob, rew, done);
+    }
+    // The same with the lane's words of the quad's first QUAD_WORDS blocks handed in: the one-lane-per-thread fused loop lets
+    // lane e of a quad compute the blocks of step s + e once per four steps and passes the words round by DPP transposes
+    // (steps_kernel) — three blocks per lane per four steps instead of per step.
+    static constexpr int QUAD_WORDS = 3;
+    template <class RT>
+    static __device__ __forceinline__ void step_words(const Shared &sh, const Params &p, State &st, int a, const RngKey &key,
+                                                      uint32_t lane, uint32_t W0, uint32_t W1, uint32_t W2, int &ob, RT &rew, int &done)
+    {
+        step_from<QUAD_WORDS>(sh, p, st, a, key, lane, W0, W1, W2, ob, rew, done);
+    }
+    template <int GIVEN, class RT>
+    static __device__ __forceinline__ void step_from(const Shared &sh, const Params &p, State &st, int a, const RngKey &key,
+                                                     uint32_t lane, uint32_t W0, uint32_t W1, uint32_t W2, int &ob, RT &rew, int &done)
     {
         const uint32_t s0 = st.w;
         const int n_up = __popc(s0), base = n_up + __popc(s0 & p.deg_gt2_mask);       // network.py:87-92
@@ -178,29 +199,22 @@ struct NetworkEnv {
         const bool has_action = a < 2 * p.n_machines;
         uint32_t todo = s0, near = 0xFFFFFFFFu, kill = 0;
         bool pend = has_action, truthful = false;
-        int left = n_up;
-        uint4 h = stream_block(key, lane, POMDP_STREAM_STEP, 0u);
-        for (uint32_t blk = 1;; ++blk) {
-            kill |= draw4(h, todo, nbf, T, near);
-            if (pend && left < 4) {                                              // the action's draw: the word after the last machine's
-                uint32_t w = left == 1 ? h.y : h.x;
-                w = left == 2 ? h.z : w;
-                w = left == 3 ? h.w : w;
-                truthful = truthful_of(w, T, near);
-                pend = false;
-            }
-            if (!__any(todo != 0u || pend)) break;                               // wave-uniform
-            left = __popc(todo);
-            h = stream_block(key, lane, POMDP_STREAM_STEP, 2u * blk);
-        }
-        if (near < 32u) { step_exact(sh, p, st, a, key, lane, ob, rew, done); return; }
+        auto word = [&](uint32_t W) {
+            const int left = __popc(todo);
+            kill |= draw2(W, todo, nbf, T, near);
+            if (pend && left < 2) { truthful = truthful_of(W, left, T, near); pend = false; }   // the draw after the last machine's
+        };
+        if constexpr (GIVEN == 3) { word(W0); word(W1); word(W2); }
+        for (uint32_t b = (uint32_t)GIVEN; __any(todo != 0u || pend); ++b)      // wave-uniform
+            word(elem(quad_block(key, lane, b), lane & 3u));
+        if (near < TIE) { step_exact(sh, p, st, a, key, lane, ob, rew, done); return; }
         uint32_t s = s0 & ~kill;
         finish(p, s, a, base, truthful, ob, rew);
         done = 0;
         st.w = s;
     }
 
-    // the same, one draw at a time with the low words at hand: the exact form (ties; and what the fast forms are checked against)
+    // the same, one draw at a time with all 53 bits at hand: the exact form (ties; and what the fast forms are checked against)
     template <class RT>
     static __device__ __forceinline__ void step_exact(const Shared &sh, const Params &p, State &st, int a,
                                                       const RngKey &key, uint32_t lane, int &ob, RT &rew, int &done)
@@ -211,36 +225,26 @@ struct NetworkEnv {
         const int n_up = __popc(s0);
         double r = (double)(n_up + __popc(s0 & p.deg_gt2_mask));
         // machines whose neighbourhood has a failure, from the pre-update state    network.py:82-85
-        const uint32_t down = ~s0 & (M >= 32 ? 0xFFFFFFFFu : ((1u << M) - 1u));
-        uint32_t nb_failed = 0;
-        for (int k = 0; 4 * k < M; ++k) nb_failed |= sh.nbf[k][(down >> (4 * k)) & 15u];      // wave-uniform trip count
+        const uint32_t nb_failed = nb_failed_of(sh, p, s0);
         const bool has_action = a < 2 * M;
         const int n_draws = n_up + (has_action ? 1 : 0);
-        // Split word layout: double j compares by its high word — element j & 3 of block 2 (j >> 2) —
-        // and needs its low word (same element of the next block) only on a tie, probability 2^-27 per draw.  One
-        // Philox block therefore serves four draws instead of two.  Thresholds as (high 27 bits, low 26 bits).
-        // Draw j belongs to the j-th up machine (lowest set bit of `todo`), draw n_up to the action.
-        constexpr uint32_t LO = (1u << 26) - 1u;
-        const uint32_t th_fail = (uint32_t)(p.fail_thr >> 26), tl_fail = (uint32_t)p.fail_thr & LO;
-        const uint32_t th_nb = (uint32_t)(p.fail_nb_thr >> 26), tl_nb = (uint32_t)p.fail_nb_thr & LO;
-        const uint32_t th_obs = (uint32_t)(p.obs_thr >> 26), tl_obs = (uint32_t)p.obs_thr & LO;
+        // Draw j belongs to the j-th up machine (lowest set bit of `todo`), draw n_up to the action.  Its double, as numpy
+        // builds it from two words: a = Q << 16 | X >> 16, b = Y, k53 = (a >> 5) << 26 | b >> 6 (network_step_words).
         uint32_t todo = s0, s = s0;
-        uint4 blk = make_uint4(0, 0, 0, 0);
+        uint4 qb = make_uint4(0, 0, 0, 0);
         bool truthful = false;
         for (int j = 0; __any(j < n_draws); ++j) {                               // j is wave-uniform
-            if ((j & 3) == 0) blk = stream_block(key, lane, POMDP_STREAM_STEP, 2u * (uint32_t)(j >> 2));
-            const uint32_t H = (j & 3) == 0 ? blk.x : (j & 3) == 1 ? blk.y : (j & 3) == 2 ? blk.z : blk.w;
+            if ((j & 1) == 0) qb = quad_block(key, lane, (uint32_t)(j >> 1));
+            const uint32_t W = elem(qb, lane & 3u), Q = (j & 1) ? (W & 0xFFFFu) : (W >> 16);
             const uint32_t lb = todo & (0u - todo);                              // this draw's machine; 0 = none left
             const bool machine_draw = lb != 0u;                                  // network.py:94-99, else the action's draw
-            const bool nbf = (nb_failed & lb) != 0u;
-            const uint32_t th = machine_draw ? (nbf ? th_nb : th_fail) : th_obs;
-            const uint32_t kh = H >> 5;
-            bool le = kh < th;                                                   // k53 <= thr, decided by the high word
-            if (kh == th && j < n_draws) {                                       // tie: fetch the low word
-                const uint32_t tl = machine_draw ? (nbf ? tl_nb : tl_fail) : tl_obs;
-                const uint4 lo = stream_block(key, lane, POMDP_STREAM_STEP, 2u * (uint32_t)(j >> 2) + 1u);
-                const uint32_t L = (j & 3) == 0 ? lo.x : (j & 3) == 1 ? lo.y : (j & 3) == 2 ? lo.z : lo.w;
-                le = (L >> 6) <= tl;
+            const uint64_t thr = machine_draw ? ((nb_failed & lb) ? p.fail_nb_thr : p.fail_thr) : p.obs_thr;
+            const uint32_t t16 = (uint32_t)(thr >> 37);
+            bool le = Q < t16;                                                   // k53 <= thr, decided by the top 16 bits
+            if (Q == t16 && j < n_draws) {                                       // tie: the lane's own low words
+                const uint4 lo = stream_block(key, lane, STREAM_STEP_LO, (uint32_t)(j >> 1));
+                const uint32_t X = (j & 1) ? lo.z : lo.x, Y = (j & 1) ? lo.w : lo.y;
+                le = k53((Q << 16) | (X >> 16), Y) <= thr;
             }
             s &= le ? 0xFFFFFFFFu : ~lb;                                         // fails iff k > thr (lb == 0: nothing)
             truthful = (j == n_up) ? le : truthful;                              // only read when the action draws

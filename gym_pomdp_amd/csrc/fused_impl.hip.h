@@ -60,6 +60,7 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
     using Fin = Finisher<Env, LPT, true>;
     constexpr bool quad_policy = quad_policy_of<Fin>::value;
     uint4 aq = make_uint4(0, 0, 0, 0), sq = make_uint4(0, 0, 0, 0), rq = make_uint4(0, 0, 0, 0);
+    uint4 nq0 = make_uint4(0, 0, 0, 0), nq1 = nq0, nq2 = nq0;        // Network: this lane's words of the quad's blocks 0 .. 2 of steps s .. s + 3
     const int n_act = Env::n_actions(p);
     const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo, ta0 = ((uint64_t)akey0.t_hi << 32) | akey0.t_lo;
     if (!COLS || (flags & FLAG_GEN_FIRST)) {             // wave-uniform: the policy's actions of the first call counter
@@ -135,6 +136,22 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
                     d[j] = (int)(recv[j] >> 24);
                 }
                 else Env::step_with_H(sh, p, st[j], valid[j] ? a_cur[j] : 0, key, glane[j], H, o[j], r[j], d[j]);
+            }
+            else if constexpr (quad_policy && quad_words_of<Env>::value == 3) {
+                // the step's quad-shared blocks, time-shared: lane e of a quad computes the three blocks of step s + e once per
+                // four steps, three 4 x 4 transposes hand every lane its own word of each block of each step
+                if ((s & 3) == 0) {
+                    const uint32_t e = glane[0] & 3u;
+                    const uint64_t te = t0 + (uint64_t)s + (uint64_t)e;
+                    RngKey ke = key0;
+                    ke.t_lo = (uint32_t)te; ke.t_hi = (uint32_t)(te >> 32);
+                    nq0 = quad_transpose4(Env::quad_block(ke, glane[0], 0u), e);
+                    nq1 = quad_transpose4(Env::quad_block(ke, glane[0], 1u), e);
+                    nq2 = quad_transpose4(Env::quad_block(ke, glane[0], 2u), e);
+                }
+                const int sj = s & 3;                                            // wave-uniform selects
+                auto pick = [&](const uint4 &q) { return sj == 0 ? q.x : sj == 1 ? q.y : sj == 2 ? q.z : q.w; };
+                Env::step_words(sh, p, st[j], valid[j] ? a_cur[j] : 0, key, glane[j], pick(nq0), pick(nq1), pick(nq2), o[j], r[j], d[j]);
             }
             else Fin::lane_step(sh, p, st[j], valid[j] ? a_cur[j] : 0, key, glane[j], o[j], r[j], d[j], aux[j]);
             if (!live[j]) { r[j] = 0; d[j] = was_done[j]; }
@@ -408,24 +425,28 @@ __global__ __launch_bounds__(BLOCK) void tag_steps_quad_kernel(uint32_t *__restr
     st_stream4(state + l0, st[0].w, st[1].w, st[2].w, st[3].w);
 }
 
-// Network with a quad per thread.  The reference draws one double per UP machine and one for the action (network.py:94-109),
-// from the lane's own stream, four high words per Philox block (split layout).  Under a random policy a lane
-// has 1.4 machines up on average (12 % of the lanes have three or more, 2 % four or more), so almost every lane-step is
-// served by the FIRST block of its stream: each of the thread's four lanes computes that block and applies its first two
-// words to its first two up machines straight-line (NetworkEnv::draws), the action's draw being the word after the last
-// machine — no loop to the wave's largest draw count, which is what steps_kernel<NetworkEnv> pays for every lane.  Lanes
-// with more draws to make (a third machine, or the action's draw behind three) hand (machines left, failed-neighbour set,
-// the block's other two words) to a per-wave task list; one pooled pass per 64 such lanes continues their streams — the
-// two words, then block by block — and returns the machines that fail and the action's draw.  The policy's ACTION block
-// is the thread's own, the outputs leave as 16-byte stores, the reward comes from a table of the float32(float64) values
-// the reference's arithmetic gives.  A draw decided by its low word (2^-27 per draw) sends the lane through
-// NetworkEnv::step_exact, the exact per-lane form.  Network never terminates, so there is no reset.
-// SMALL (round 4; n_machines <= 10, the reference's default): everything the first two draws need that depends on the
-// machine set alone comes from ONE lookup in a 2^n_machines-entry table the workgroup builds when the launch starts —
-// the two lowest up machines (the ones draws 0 and 1 belong to), which of the two thresholds each is compared with (as
-// the byte offset of a two-entry threshold table) and the reward base — instead of two popcounts, two byte-table lookups
-// and two rounds of "isolate the lowest set bit, test its failed-neighbour bit, select the threshold": 33 -> 16 vector
-// instructions per lane-step of a loop that runs at 0.96 of VALU issue.
+// Network with a quad per thread.  The reference draws one double per UP machine and one for the action (network.py:94-109);
+// the top 16 bits of those doubles come from blocks shared by the quad, two draws per word (network.hip.h), so the thread's
+// own three blocks — twelve 32-bit words — hold draws 0 .. 5 of each of its four lanes.  Under a random policy a lane has 1.4
+// machines up (2 % of the lanes four or more, 0.01 % six or more), so draws 0 .. 5 serve all but one lane-step in 10^4,
+// straight-line: the machines they belong to, which of the two thresholds each is compared with and the reward base come
+// from a table indexed by the machine set (SMALL: n_machines <= 10, the reference's default — three 32-bit entries per set,
+// built when the launch starts), the six comparisons are three packed 16-bit saturating subtractions, the action's draw is
+// the half-word after the last machine's.  A thread with a lane that has more to draw runs on, block by block (the whole
+// wave does, a few lanes wide: 3 % of the wave-steps; with two inline blocks it was every wave-step, and 40 % of the loop).  A tie (a draw's 16 bits equal its threshold's, 2^-16 per draw) sends the lane
+// through NetworkEnv::step_exact, the exact per-lane form.  The policy's ACTION block is the thread's own, the outputs
+// leave as 16-byte stores, the reward comes from a table of the float32(float64) values the reference's arithmetic gives.
+// Network never terminates, so there is no reset.
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ uint32_t pk_sub_sat_u16(uint32_t a, uint32_t b)       // per half: max(a - b, 0)  (v_pk_sub_u16 clamp)
+{
+    u16x2 x, y;
+    __builtin_memcpy(&x, &a, 4); __builtin_memcpy(&y, &b, 4);
+    const u16x2 d = __builtin_elementwise_sub_sat(x, y);
+    uint32_t r;
+    __builtin_memcpy(&r, &d, 4);
+    return r;
+}
 template <int NB, class L = Columns, bool SMALL = false>   // NB: bytes of the machine set, ceil(n_machines / 8)
 __global__ __launch_bounds__(BLOCK) void network_steps_quad_kernel(uint32_t *__restrict__ state, int32_t *__restrict__ action,
                                                                    int32_t *__restrict__ ob, float *__restrict__ reward,
@@ -437,17 +458,17 @@ __global__ __launch_bounds__(BLOCK) void network_steps_quad_kernel(uint32_t *__r
     __shared__ Env::Shared sh;                               // the nibble tables of the exact per-lane form (ties only)
     __shared__ uint32_t nbf8[SMALL ? 1 : NB][SMALL ? 1 : 256];   // nbf8[k][v]: machines that see a failed neighbour when the down
                                                              // machines among 8 k .. 8 k + 7 are the set v (network.py:82-85)
-    // SMALL, by machine set v: stab = lb0 | lb1 << 10 | (4 * nbf(lb0)) << 20 | (4 * nbf(lb1)) << 23 | base << 26 (lb0 / lb1: the lowest
-    // / second lowest up machine as a bit, 0 if none); nbft = the failed-neighbour set itself (the pooled continuation's)
-    __shared__ uint32_t stab[SMALL ? 1024 : 1], nbft[SMALL ? 1024 : 1], thr2[2];
+    // SMALL, by machine set v (lbK: the K-th lowest up machine as a bit, 0 if none; selX: byte offset into tp of the pair's
+    // packed thresholds — bit 2: the first of the pair sees a failed neighbour, bit 3: the second):
+    //   sta = lb0 | lb1 << 10 | selA << 20 | base << 24      stb = lb2 | lb3 << 10 | selB << 20      stc = lb4 | lb5 << 10 | selC << 20
+    //   nbft = the failed-neighbour set itself (the continuation's)
+    //   tp[s] = (T16 of the pair's first draw - 1) << 16 | (T16 of its second - 1): d = sat(W - tp) per half is 0 where the
+    //   draw leaves the machine up, 1 on a tie, >= 1 where it fails (fails iff k53 > thr, network.py:94-99)
+    __shared__ uint32_t sta[SMALL ? 1024 : 1], stb[SMALL ? 1024 : 1], stc[SMALL ? 1024 : 1], nbft[SMALL ? 1024 : 1], tp[4];
     __shared__ float rtab[3][68];                            // reward by (no action / ping / reboot, 2 per up machine with > 2
                                                              // neighbours + 1 per other up machine): network.py:87-92, 103, 110
-    __shared__ uint32_t task_lds[BLOCK / 64][256][6];        // task rank -> {lane within the wave's 256 | has_action << 8, machines
-                                                             // left, failed-neighbour set, words 2 and 3 of the lane's first
-                                                             // block}; overwritten with {machines that fail, flags}
-    const int wv = (int)(threadIdx.x >> 6), me = (int)(threadIdx.x & 63u);
     const uint32_t l0 = blockIdx.x * (uint32_t)(4 * BLOCK) + 4u * threadIdx.x;
-    const uint32_t glane0 = lane0 + l0, wave0 = glane0 - 4u * (uint32_t)me;
+    const uint32_t glane0 = lane0 + l0;
     QuadOut<L> out(action, ob, reward, done, rec, l0);
     const uint32_t n_act = (uint32_t)Env::n_actions(p);
     uint32_t st[4];
@@ -459,18 +480,26 @@ __global__ __launch_bounds__(BLOCK) void network_steps_quad_kernel(uint32_t *__r
         for (int j = 0; j < 4; ++j) { a_cur[j] = (int)a4[j]; st[j] = s4[j]; }
     }
     Env::stage(sh, p, (int)threadIdx.x);
+    const Env::Thr T = Env::thresholds(p);
     if constexpr (SMALL) {
         const uint32_t up_all = (1u << p.n_machines) - 1u;
         for (uint32_t v = threadIdx.x; v <= up_all; v += BLOCK) {
             const uint32_t down = ~v & up_all;
             uint32_t m = 0;
             for (int i = 0; i < p.n_machines; ++i) m |= ((p.nb_mask[i] & down) != 0u ? 1u : 0u) << i;
-            const uint32_t lb0 = v & (0u - v), r1 = v ^ lb0, lb1 = r1 & (0u - r1);
+            uint32_t r = v, lb[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { lb[k] = r & (0u - r); r ^= lb[k]; }
             const uint32_t base = (uint32_t)(__popc(v) + __popc(v & p.deg_gt2_mask));          // network.py:87-92
-            stab[v] = lb0 | (lb1 << 10) | ((m & lb0) ? 4u << 20 : 0u) | ((m & lb1) ? 4u << 23 : 0u) | (base << 26);
+            sta[v] = lb[0] | (lb[1] << 10) | ((m & lb[0]) ? 4u << 20 : 0u) | ((m & lb[1]) ? 8u << 20 : 0u) | (base << 24);
+            stb[v] = lb[2] | (lb[3] << 10) | ((m & lb[2]) ? 4u << 20 : 0u) | ((m & lb[3]) ? 8u << 20 : 0u);
+            stc[v] = lb[4] | (lb[5] << 10) | ((m & lb[4]) ? 4u << 20 : 0u) | ((m & lb[5]) ? 8u << 20 : 0u);
             nbft[v] = m;
         }
-        if (threadIdx.x == 0) { const Env::Thr T0 = Env::thresholds(p); thr2[0] = T0.fail; thr2[1] = T0.nb; }
+        if (threadIdx.x < 4) {
+            const uint32_t f = (T.fail >> 16) - 1u, nb = (T.nb >> 16) - 1u;     // the launcher checked both thresholds' top 16 bits >= 1
+            tp[threadIdx.x] = (((threadIdx.x & 1u) ? nb : f) << 16) | ((threadIdx.x & 2u) ? nb : f);
+        }
     } else {
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb) {                        // BLOCK threads = the 256 values of a byte
@@ -487,7 +516,6 @@ __global__ __launch_bounds__(BLOCK) void network_steps_quad_kernel(uint32_t *__r
         rtab[kind][b] = (float)r;
     }
     __syncthreads();
-    const Env::Thr T = Env::thresholds(p);
     const uint32_t all_up = p.n_machines >= 32 ? 0xFFFFFFFFu : ((1u << p.n_machines) - 1u);
     const int M2 = 2 * p.n_machines;
     const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo, ta0 = ((uint64_t)akey0.t_hi << 32) | akey0.t_lo;
@@ -500,107 +528,84 @@ __global__ __launch_bounds__(BLOCK) void network_steps_quad_kernel(uint32_t *__r
         key.t_lo = (uint32_t)(t0 + (uint64_t)s); key.t_hi = (uint32_t)((t0 + (uint64_t)s) >> 32);
         const uint64_t ta = ta0 + (uint64_t)s;
         const uint4 pw = philox4x32_10(glane0 >> 2, (uint32_t)ta, (uint32_t)(ta >> 32), (uint32_t)POMDP_STREAM_ACTION << 24, key.k0, key.k1);
-        const uint32_t P[4] = {pw.x, pw.y, pw.z, pw.w};
-        uint32_t kill[4], todo[4], nbf[4], near[4], hz[4], hw[4];
+        const uint4 q0 = Env::quad_block(key, glane0, 0u), q1 = Env::quad_block(key, glane0, 1u), q2 = Env::quad_block(key, glane0, 2u);
+        const uint32_t P[4] = {pw.x, pw.y, pw.z, pw.w}, W0[4] = {q0.x, q0.y, q0.z, q0.w}, W1[4] = {q1.x, q1.y, q1.z, q1.w};
+        const uint32_t W2[4] = {q2.x, q2.y, q2.z, q2.w};
+        uint32_t kill[4], todo[4], near[4], tie16[4];
         int base[4];
-        bool truthful[4], more[4], act_pending[4];
-        uint64_t mm[4];
-        int ntask = 0;
+        bool truthful[4], pend[4], need[4];
+        bool any_need = false;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const uint32_t s0 = st[j];
-            const uint4 h = stream_block(key, glane0 + (uint32_t)j, POMDP_STREAM_STEP, 0u);
+            const uint32_t s0 = st[j] & all_up;                                // set_state() may have handed in stray upper bits
             const int n_up = __popc(s0);
+            near[j] = 0xFFFFFFFFu;
             if constexpr (SMALL) {
-                const uint32_t e = stab[s0 & all_up];                            // only 2^n_machines entries exist: a state from
-                nbf[j] = nbft[s0 & all_up];                                      // set_state() with stray upper bits stays inside
-                const uint32_t lb0 = e & 1023u, lb1 = __builtin_amdgcn_ubfe(e, 10u, 10u);
-                // the threshold of draw 0 / 1: entry 0 (no failed neighbour) or 1 of thr2, addressed by the byte offset in e
-                const uint32_t t0 = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(thr2) + __builtin_amdgcn_ubfe(e, 20u, 3u));
-                const uint32_t t1 = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(thr2) + __builtin_amdgcn_ubfe(e, 23u, 3u));
-                base[j] = (int)(e >> 26);
-                kill[j] = (h.x < t0 ? 0u : lb0) | (h.y < t1 ? 0u : lb1);           // fails iff k53 > thr (network.py:94-99)
-                near[j] = min(h.x - t0, h.y - t1);                                 // a tie has H - T < 32 (a slot without a machine: a
-                                                                                    // false alarm costs the exact path, 2^-27 of the time)
-                todo[j] = s0 & ~(lb0 | lb1);
+                const uint32_t ea = sta[s0], eb = stb[s0], ec = stc[s0];
+                const uint32_t lb0 = ea & 1023u, lb1 = __builtin_amdgcn_ubfe(ea, 10u, 10u), lb2 = eb & 1023u, lb3 = __builtin_amdgcn_ubfe(eb, 10u, 10u);
+                const uint32_t lb4 = ec & 1023u, lb5 = __builtin_amdgcn_ubfe(ec, 10u, 10u);
+                const uint32_t ta_ = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(tp) + __builtin_amdgcn_ubfe(ea, 20u, 4u));
+                const uint32_t tb_ = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(tp) + __builtin_amdgcn_ubfe(eb, 20u, 4u));
+                const uint32_t tc_ = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(tp) + __builtin_amdgcn_ubfe(ec, 20u, 4u));
+                const uint32_t d0 = pk_sub_sat_u16(W0[j], ta_), d1 = pk_sub_sat_u16(W1[j], tb_), d2 = pk_sub_sat_u16(W2[j], tc_);
+                base[j] = (int)(ea >> 24);
+                kill[j] = (d0 > 0xFFFFu ? lb0 : 0u) | ((d0 & 0xFFFFu) ? lb1 : 0u) | (d1 > 0xFFFFu ? lb2 : 0u) | ((d1 & 0xFFFFu) ? lb3 : 0u) |
+                          (d2 > 0xFFFFu ? lb4 : 0u) | ((d2 & 0xFFFFu) ? lb5 : 0u);
+                // a tie: some half of d is exactly 1 (a slot without a machine may raise a false alarm: the exact path, 2^-16 of the time)
+                tie16[j] = ((d0 >> 16) == 1u) | ((d0 & 0xFFFFu) == 1u) | ((d1 >> 16) == 1u) | ((d1 & 0xFFFFu) == 1u) |
+                           ((d2 >> 16) == 1u) | ((d2 & 0xFFFFu) == 1u);
+                todo[j] = s0 & ~(lb0 | lb1 | lb2 | lb3 | lb4 | lb5);
             } else {
-            base[j] = n_up + __popc(s0 & p.deg_gt2_mask);                      // network.py:87-92
-            {
+                base[j] = n_up + __popc(s0 & p.deg_gt2_mask);                  // network.py:87-92
                 const uint32_t down = ~s0 & all_up;
                 uint32_t f = nbf8[0][down & 255u];
 #pragma unroll
                 for (int kb = 1; kb < NB; ++kb) f |= nbf8[kb][(down >> (8 * kb)) & 255u];
-                nbf[j] = f;
+                todo[j] = s0;
+                kill[j] = Env::draw2(W0[j], todo[j], f, T, near[j]);
+                kill[j] |= Env::draw2(W1[j], todo[j], f, T, near[j]);
+                kill[j] |= Env::draw2(W2[j], todo[j], f, T, near[j]);
+                tie16[j] = 0u;
             }
-            todo[j] = s0;
-            near[j] = 0xFFFFFFFFu;
-            const uint32_t H2[2] = {h.x, h.y};
-            kill[j] = Env::draws<2>(H2, todo[j], nbf[j], T, near[j]);
-            }
-            hz[j] = h.z; hw[j] = h.w;
             const bool has_action = a_cur[j] < M2;
-            uint32_t aw = n_up == 1 ? h.y : h.x;                                // word n_up of the block (n_up < 3), as selects
-            aw = n_up >= 2 ? h.z : aw;
+            const uint32_t aw = n_up < 2 ? W0[j] : (n_up < 4 ? W1[j] : W2[j]);   // the action's draw: half-word n_up of the twelve (n_up < 6)
             uint32_t near_a = 0xFFFFFFFFu;
-            const bool tr = Env::truthful_of(aw, T, near_a);
-            const bool here = has_action && n_up < 3;                           // the action's draw is one of these three words
+            const bool tr = Env::truthful_of(aw, n_up & 1, T, near_a);
+            const bool here = has_action && n_up < 6;
             truthful[j] = here && tr;
             near[j] = min(near[j], here ? near_a : 0xFFFFFFFFu);
-            act_pending[j] = has_action && !here;
-            more[j] = todo[j] != 0u || act_pending[j];
-            mm[j] = __ballot(more[j]);
-            ntask += __popcll(mm[j]);
+            pend[j] = has_action && !here;
+            need[j] = todo[j] != 0u || pend[j];
+            any_need |= need[j];
         }
-        if (ntask) {                                                           // wave-uniform
-            int rank[4], c = 0;
+        if (any_need) {                                                        // this thread's quad has more to draw: block by block
+            uint32_t nbf[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                rank[j] = c + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm[j], 0u));
-                c += __popcll(mm[j]);
-                if (more[j]) {
-                    uint32_t *t = task_lds[wv][rank[j] & 255];
-                    t[0] = (uint32_t)(4 * me + j) | ((uint32_t)act_pending[j] << 8); t[1] = todo[j]; t[2] = nbf[j];
-                    t[3] = hz[j]; t[4] = hw[j];
+                const uint32_t s0 = st[j] & all_up;
+                if constexpr (SMALL) nbf[j] = nbft[s0];
+                else {
+                    const uint32_t down = ~s0 & all_up;
+                    uint32_t f = nbf8[0][down & 255u];
+#pragma unroll
+                    for (int kb = 1; kb < NB; ++kb) f |= nbf8[kb][(down >> (8 * kb)) & 255u];
+                    nbf[j] = f;
                 }
             }
-            for (int b0 = 0; b0 < ntask; b0 += 64) {
-                const int q = b0 + me;
-                if (q < ntask) {
-                    uint32_t *t = task_lds[wv][q & 255];
-                    const uint32_t w0 = t[0], src_lane = wave0 + (w0 & 255u), nb = t[2];
-                    uint32_t td = t[1], nr = 0xFFFFFFFFu;
-                    bool pend = (w0 >> 8) & 1u, tr = false;
-                    // words 2 and 3 of the first block, then the stream's following blocks
-                    const uint32_t H2[2] = {t[3], t[4]};
-                    int left = __popc(td);
-                    uint32_t kl = Env::draws<2>(H2, td, nb, T, nr);
-                    if (pend && left < 2) { tr = Env::truthful_of(left == 0 ? H2[0] : H2[1], T, nr); pend = false; }
-                    for (uint32_t blk = 1; td != 0u || pend; ++blk) {
-                        const uint4 h = stream_block(key, src_lane, POMDP_STREAM_STEP, 2u * blk);
-                        left = __popc(td);
-                        kl |= Env::draw4(h, td, nb, T, nr);
-                        if (pend && left < 4) {
-                            uint32_t w = left == 1 ? h.y : h.x;
-                            w = left == 2 ? h.z : w;
-                            w = left == 3 ? h.w : w;
-                            tr = Env::truthful_of(w, T, nr);
-                            pend = false;
-                        }
+            for (uint32_t b = 3; any_need; ++b) {
+                const uint4 qb = Env::quad_block(key, glane0, b);
+                const uint32_t Wb[4] = {qb.x, qb.y, qb.z, qb.w};
+                any_need = false;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (need[j]) {
+                        const int left = __popc(todo[j]);
+                        kill[j] |= Env::draw2(Wb[j], todo[j], nbf[j], T, near[j]);
+                        if (pend[j] && left < 2) { truthful[j] = Env::truthful_of(Wb[j], left, T, near[j]); pend[j] = false; }
+                        need[j] = todo[j] != 0u || pend[j];
+                        any_need |= need[j];
                     }
-                    t[0] = kl; t[1] = (uint32_t)tr | (nr < 32u ? 2u : 0u);
                 }
-            }
-            uint32_t tk[4], tf[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {                                      // all four reads in flight, one wait; used where more[j]
-                const uint32_t *t = task_lds[wv][rank[j] & 255];
-                tk[j] = t[0]; tf[j] = t[1];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                kill[j] |= more[j] ? tk[j] : 0u;
-                truthful[j] = (more[j] && act_pending[j]) ? (tf[j] & 1u) != 0u : truthful[j];
-                near[j] = (more[j] && (tf[j] & 2u)) ? 0u : near[j];
             }
         }
         uint32_t o4[4], r4[4], a_next[4], rc[4] = {0, 0, 0, 0};
@@ -609,8 +614,8 @@ __global__ __launch_bounds__(BLOCK) void network_steps_quad_kernel(uint32_t *__r
         for (int j = 0; j < 4; ++j) {
             int o;
             float r;
-            if (near[j] < 32u) {                                               // a draw decided by its low word: the exact per-lane form
-                Env::State e{st[j]};
+            if (tie16[j] != 0u || near[j] < Env::TIE) {                        // a draw decided below its top 16 bits: the exact per-lane form
+                Env::State e{st[j] & all_up};
                 int d;
                 Env::step_exact(sh, p, e, a_cur[j], key, glane0 + (uint32_t)j, o, r, d);
                 st[j] = e.w;
@@ -618,7 +623,7 @@ __global__ __launch_bounds__(BLOCK) void network_steps_quad_kernel(uint32_t *__r
             } else {                                                           // network.py:101-112
                 const int a = a_cur[j], machine = (a >> 1) & 31;
                 const bool has_action = a < M2, reboot = has_action && (a & 1);
-                uint32_t sn = st[j] & ~kill[j];
+                uint32_t sn = st[j] & all_up & ~kill[j];
                 sn |= reboot ? 1u << machine : 0u;
                 const int up = (int)((sn >> machine) & 1u);                    // a rebooted machine is up: ob = truthful either way
                 o = has_action ? (truthful[j] ? up : 1 - up) : 2;
@@ -958,7 +963,8 @@ static int launch_steps_fused_l(const typename Env::Params &p, uint32_t *state, 
     if constexpr (std::is_same<Env, NetworkEnv>::value) {
         if (quad_ok && n >= QUAD_MIN_NETWORK) {
             // named as a profiler shows the instantiation: <bytes of the machine set, layout, state-table form>
-            const bool small = p.n_machines <= 10;
+            // the state-table form: the reference's default has 10 machines; its packed thresholds are T16 - 1
+            const bool small = p.n_machines <= 10 && (p.fail_thr >> 37) != 0 && (p.fail_nb_thr >> 37) != 0;
             snprintf(variant, sizeof variant, "%d, %s, %s", small ? 2 : (p.n_machines + 7) / 8, L::NAME, small ? "true" : "false");
             note_fused("network_steps_quad_kernel", variant, "");
 #define POMDP_LAUNCH_NET(NB_)                                                                                            \

@@ -373,6 +373,10 @@ template <int J> static __device__ __forceinline__ uint32_t comp(const uint4 &v)
 template <class Fin, class = void> struct quad_policy_of : std::false_type {};
 template <class Fin> struct quad_policy_of<Fin, std::enable_if_t<Fin::QUAD_POLICY>> : std::true_type {};
 
+// envs whose step takes its words from QUAD_WORDS quad-shared blocks that a one-lane-per-thread loop can time-share (Network)
+template <class Env, class = void> struct quad_words_of { static constexpr int value = 0; };
+template <class Env> struct quad_words_of<Env, std::enable_if_t<(Env::QUAD_WORDS > 0)>> { static constexpr int value = Env::QUAD_WORDS; };
+
 struct NoTab {};
 // the (position, action) table of a table-driven launch: RockEnv::RecTab, whose lane step (step_rec) yields the lane's
 // packed record and its new state in one go

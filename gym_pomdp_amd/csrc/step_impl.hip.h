@@ -223,13 +223,12 @@ __global__ __launch_bounds__(BLOCK) void step_quad_kernel(uint32_t *__restrict__
 }
 
 // ONE step of Network with the caller's actions and a quad of consecutive lanes per thread (env.step() from 2^19 lanes).
-// The one-lane-per-thread kernel runs every lane to its wave's largest draw count — two to three Philox blocks and as many
-// loop iterations per lane-step, although 98 % of the lanes need one block (under a random policy a lane has 1.4 machines
-// up).  Here, as in network_steps_quad_kernel: each lane computes the FIRST block of its stream and applies its first two
-// words straight-line, the action's draw being the word after the last machine; lanes with more to draw go through one
-// pooled pass per wave (64 such lanes at a time); state, action, ob and reward move as 16-byte accesses.  Same contract as
-// step_kernel: an out-of-range action leaves the lane untouched and is counted in *err; without auto-reset a lane whose
-// done flag is set stays frozen (Network itself never sets it).
+// The top 16 bits of a step's doubles come from blocks shared by the quad, two draws per word (network.hip.h): the thread's
+// own three blocks — computed under the latency of its loads — hold draws 0 .. 5 of each of its four lanes, which serve all
+// but one lane-step in 10^4 under a random policy; a thread with a lane that has more to draw runs on block by block.  State,
+// action, ob and reward move as 16-byte accesses.  Same contract as step_kernel: an out-of-range action leaves the lane
+// untouched and is counted in *err; without auto-reset a lane whose done flag is set stays frozen (Network itself never
+// sets it).
 template <class Env>   // NetworkEnv (a template so that the header may be included by several translation units)
 __global__ __launch_bounds__(BLOCK) void network_step_quad_kernel(uint32_t *__restrict__ state, const int32_t *__restrict__ action,
                                                                   int32_t *__restrict__ ob, float *__restrict__ reward,
@@ -237,19 +236,16 @@ __global__ __launch_bounds__(BLOCK) void network_step_quad_kernel(uint32_t *__re
                                                                   RngKey key, uint32_t lane0, int flags, const typename Env::Params p)
 {
     __shared__ typename Env::Shared sh;
-    __shared__ uint32_t task_lds[BLOCK / 64][256][6];        // as in network_steps_quad_kernel
-    const int wv = (int)(threadIdx.x >> 6), me = (int)(threadIdx.x & 63u);
     const bool auto_reset = flags & POMDP_AUTO_RESET;
     const uint32_t l0 = blockIdx.x * (uint32_t)(4 * BLOCK) + 4u * threadIdx.x;
-    const uint32_t glane0 = lane0 + l0, wave0 = glane0 - 4u * (uint32_t)me;
+    const uint32_t glane0 = lane0 + l0;
     uint32_t *const done_w = reinterpret_cast<uint32_t *>(done + l0);
     const u32x4 s4 = ld_stream4(state + l0);
     const u32x4 a4 = ld_stream4(reinterpret_cast<const uint32_t *>(action) + l0);
     const uint32_t dn = auto_reset ? 0u : ld_stream(done_w);
-    // the lanes' first blocks depend on lane ids only: Philox under the load latency
-    uint4 h[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) h[j] = stream_block(key, glane0 + (uint32_t)j, POMDP_STREAM_STEP, 0u);
+    // the quad's blocks depend on lane ids only: Philox under the load latency
+    const uint4 q0 = Env::quad_block(key, glane0, 0u), q1 = Env::quad_block(key, glane0, 1u), q2 = Env::quad_block(key, glane0, 2u);
+    const uint32_t W0[4] = {q0.x, q0.y, q0.z, q0.w}, W1[4] = {q1.x, q1.y, q1.z, q1.w}, W2[4] = {q2.x, q2.y, q2.z, q2.w};
     Env::stage(sh, p, (int)threadIdx.x);
     __syncthreads();
     const typename Env::Thr T = Env::thresholds(p);
@@ -257,87 +253,56 @@ __global__ __launch_bounds__(BLOCK) void network_step_quad_kernel(uint32_t *__re
     const uint32_t n_act = (uint32_t)Env::n_actions(p);
     uint32_t st[4], kill[4], todo[4], nbf[4], near[4];
     int base[4], a_eff[4];
-    bool truthful[4], more[4], act_pending[4], live[4];
-    uint64_t mm[4];
-    int ntask = 0;
+    bool truthful[4], pend[4], need[4], live[4];
+    bool any_need = false;
     uint32_t n_bad = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t s0 = s4[j];
+        st[j] = s0;
+        nbf[j] = Env::nb_failed_of(sh, p, s0);
+        todo[j] = s0;
+        near[j] = 0xFFFFFFFFu;
+        kill[j] = Env::draw2(W0[j], todo[j], nbf[j], T, near[j]);
+        kill[j] |= Env::draw2(W1[j], todo[j], nbf[j], T, near[j]);
+    }
+    // draws 4 and 5 belong to a fifth and sixth up machine: 0.2 % of the lanes have one, four wave-steps in ten some lane
+    if (__any((todo[0] | todo[1] | todo[2] | todo[3]) != 0u)) {                // wave-uniform
+#pragma unroll
+        for (int j = 0; j < 4; ++j) kill[j] |= Env::draw2(W2[j], todo[j], nbf[j], T, near[j]);
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const bool valid = a4[j] < n_act, was_done = ((dn >> (8 * j)) & 0xFFu) != 0u;
         live[j] = valid && !was_done;
         n_bad += (uint32_t)(!valid && !was_done);
         a_eff[j] = valid ? (int)a4[j] : M2;                                    // an invalid action draws like "no action"; the lane is discarded
-        const uint32_t s0 = s4[j];
-        st[j] = s0;
+        const uint32_t s0 = st[j];
         const int n_up = __popc(s0);
         base[j] = n_up + __popc(s0 & p.deg_gt2_mask);                          // network.py:87-92
-        nbf[j] = Env::nb_failed_of(sh, p, s0);
-        todo[j] = s0;
-        near[j] = 0xFFFFFFFFu;
-        const uint32_t H2[2] = {h[j].x, h[j].y};
-        kill[j] = Env::template draws<2>(H2, todo[j], nbf[j], T, near[j]);
         const bool has_action = a_eff[j] < M2;
-        uint32_t aw = n_up == 1 ? h[j].y : h[j].x;                             // word n_up of the block (n_up < 3), as selects
-        aw = n_up >= 2 ? h[j].z : aw;
         uint32_t near_a = 0xFFFFFFFFu;
-        const bool tr = Env::truthful_of(aw, T, near_a);
-        const bool here = has_action && n_up < 3;
+        const bool tr = Env::truthful_of(n_up < 2 ? W0[j] : (n_up < 4 ? W1[j] : W2[j]), n_up & 1, T, near_a);   // half-word n_up of the twelve (n_up < 6)
+        const bool here = has_action && n_up < 6;
         truthful[j] = here && tr;
         near[j] = min(near[j], here ? near_a : 0xFFFFFFFFu);
-        act_pending[j] = has_action && !here;
-        more[j] = live[j] && (todo[j] != 0u || act_pending[j]);
-        mm[j] = __ballot(more[j]);
-        ntask += __popcll(mm[j]);
+        pend[j] = has_action && !here;
+        need[j] = live[j] && (todo[j] != 0u || pend[j]);
+        any_need |= need[j];
     }
-    if (ntask) {                                                               // wave-uniform
-        int rank[4], c = 0;
+    for (uint32_t b = 3; any_need; ++b) {                                      // this thread's quad has more to draw: block by block
+        const uint4 qb = Env::quad_block(key, glane0, b);
+        const uint32_t Wb[4] = {qb.x, qb.y, qb.z, qb.w};
+        any_need = false;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            rank[j] = c + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm[j], 0u));
-            c += __popcll(mm[j]);
-            if (more[j]) {
-                uint32_t *t = task_lds[wv][rank[j] & 255];
-                t[0] = (uint32_t)(4 * me + j) | ((uint32_t)act_pending[j] << 8); t[1] = todo[j]; t[2] = nbf[j];
-                t[3] = h[j].z; t[4] = h[j].w;
+            if (need[j]) {
+                const int left = __popc(todo[j]);
+                kill[j] |= Env::draw2(Wb[j], todo[j], nbf[j], T, near[j]);
+                if (pend[j] && left < 2) { truthful[j] = Env::truthful_of(Wb[j], left, T, near[j]); pend[j] = false; }
+                need[j] = todo[j] != 0u || pend[j];
+                any_need |= need[j];
             }
-        }
-        for (int b0 = 0; b0 < ntask; b0 += 64) {
-            const int q = b0 + me;
-            if (q < ntask) {
-                uint32_t *t = task_lds[wv][q & 255];
-                const uint32_t w0 = t[0], src_lane = wave0 + (w0 & 255u), nb = t[2];
-                uint32_t td = t[1], nr = 0xFFFFFFFFu;
-                bool pend = (w0 >> 8) & 1u, tr = false;
-                const uint32_t H2[2] = {t[3], t[4]};                            // words 2 and 3 of the first block, then the following blocks
-                int left = __popc(td);
-                uint32_t kl = Env::template draws<2>(H2, td, nb, T, nr);
-                if (pend && left < 2) { tr = Env::truthful_of(left == 0 ? H2[0] : H2[1], T, nr); pend = false; }
-                for (uint32_t blk = 1; td != 0u || pend; ++blk) {
-                    const uint4 hb = stream_block(key, src_lane, POMDP_STREAM_STEP, 2u * blk);
-                    left = __popc(td);
-                    kl |= Env::draw4(hb, td, nb, T, nr);
-                    if (pend && left < 4) {
-                        uint32_t w = left == 1 ? hb.y : hb.x;
-                        w = left == 2 ? hb.z : w;
-                        w = left == 3 ? hb.w : w;
-                        tr = Env::truthful_of(w, T, nr);
-                        pend = false;
-                    }
-                }
-                t[0] = kl; t[1] = (uint32_t)tr | (nr < 32u ? 2u : 0u);
-            }
-        }
-        uint32_t tk[4], tf[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {                                          // all four reads in flight, one wait; used where more[j]
-            const uint32_t *t = task_lds[wv][rank[j] & 255];
-            tk[j] = t[0]; tf[j] = t[1];
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            kill[j] |= more[j] ? tk[j] : 0u;
-            truthful[j] = (more[j] && act_pending[j]) ? (tf[j] & 1u) != 0u : truthful[j];
-            near[j] = (more[j] && (tf[j] & 2u)) ? 0u : near[j];
         }
     }
     uint32_t o4[4], r4[4], dpack = 0;
@@ -346,7 +311,7 @@ __global__ __launch_bounds__(BLOCK) void network_step_quad_kernel(uint32_t *__re
         int o = 0;
         float r = 0.f;
         if (live[j]) {
-            if (near[j] < 32u) {                                               // a draw decided by its low word: the exact per-lane form
+            if (near[j] < Env::TIE) {                                          // a draw decided below its top 16 bits: the exact per-lane form
                 typename Env::State e{st[j]};
                 int d;
                 Env::step_exact(sh, p, e, a_eff[j], key, glane0 + (uint32_t)j, o, r, d);
@@ -404,7 +369,7 @@ int launch_step(const typename Env::Params &p, uint32_t *state, const int32_t *a
     if constexpr (std::is_same<Env, NetworkEnv>::value) {
         const bool cols16 = ((reinterpret_cast<uintptr_t>(state) | reinterpret_cast<uintptr_t>(action) | reinterpret_cast<uintptr_t>(ob) |
                               reinterpret_cast<uintptr_t>(reward)) & 15u) == 0 && (reinterpret_cast<uintptr_t>(done) & 3u) == 0;
-        if (n >= STEP_QUAD_MIN_LANES && n % (4 * BLOCK) == 0 && cols16) {
+        if (n >= STEP_QUAD_MIN_LANES && n % (4 * BLOCK) == 0 && (lane0 & 3u) == 0 && cols16) {    // a thread's quad = a quad of the word contract
             hipLaunchKernelGGL(network_step_quad_kernel<Env>, dim3((unsigned)(n / (4 * BLOCK))), dim3(BLOCK), 0, (hipStream_t)stream, state,
                                action, ob, reward, done, err, n, make_key(seed, t), lane0, flags, p);
             return (int)hipGetLastError();

@@ -39,7 +39,11 @@
  * that step's call (POMDP_AUTO_RESET) reads the same rotated pair from the step's own SENSOR blocks — stream STEP, blocks
  * b and b + 1, b = 0 (RockEnv) / 2 (StochasticRock) — instead: a step never makes both draws (a CHECK does not end the
  * episode), so each word is consumed once either way and a quad's step costs one Philox block (ABI 10).
- * Network's step uses the per-lane form (block 2(j/4), element j % 4) for its one-double-per-machine draws.
+ * Network's step (ABI 12): one double per up machine, then one for the action (network.py:94-109).  16 bits decide a
+ * comparison with a threshold unless they equal the threshold's top 16 bits, so the TOP 16 bits of double j are a half —
+ * upper for even j, lower for odd j — of element lane % 4 of block j / 2 of the QUAD's stream STEP (counter word 0 =
+ * lane / 4): one block serves two draws of each of four lanes.  The 37 bits below them come from the lane's own stream
+ * STEP_LO (block j / 2, elements 2 (j % 2) and 2 (j % 2) + 1) and are generated on such a tie (2^-16 per draw) only.
  */
 #ifndef POMDP_HIP_H
 #define POMDP_HIP_H
@@ -67,7 +71,8 @@ enum {
 
 /* id of the word streams of one (seed, lane, t) */
 enum { POMDP_STREAM_STEP = 0, POMDP_STREAM_RESET = 1, POMDP_STREAM_STEP_SPACE = 2,
-       POMDP_STREAM_RESET_SPACE = 3, POMDP_STREAM_ACTION = 4, POMDP_STREAM_ROLLOUT = 5, POMDP_STREAM_NEXT = 6 };
+       POMDP_STREAM_RESET_SPACE = 3, POMDP_STREAM_ACTION = 4, POMDP_STREAM_ROLLOUT = 5, POMDP_STREAM_NEXT = 6,
+       POMDP_STREAM_STEP_LO = 7 };
 
 /* env kinds for the generic entry points */
 enum { POMDP_ENV_ROCK = 0, POMDP_ENV_TAG = 1, POMDP_ENV_BATTLESHIP = 2, POMDP_ENV_TIGER = 3, POMDP_ENV_NETWORK = 4 };

@@ -37,6 +37,7 @@ STREAM_STEP_SPACE = 2
 STREAM_RESET_SPACE = 3
 STREAM_ACTION = 4
 STREAM_ROLLOUT = 5
+STREAM_STEP_LO = 7    # Network: the per-lane low parts of step()'s doubles (network_step_words), generated on ties only
 STREAM_NEXT = 6       # BattleShip: the board of the episode AFTER the one dealt at (lane, t) (include/pomdp_hip.h: board contract)
 
 _M0 = np.uint64(0xD2511F53)
@@ -87,12 +88,32 @@ def split_words(seed, lane, t, stream, n_doubles):
     """Per-lane *split layout* of a stream whose draws are all doubles: double j takes its high word from element
     j & 3 of block 2 (j >> 2) and its low word from the same element of block 2 (j >> 2) + 1; the kernels generate
     the odd ("low") blocks only when a high word leaves a comparison undecided.  Returns the 2 * n_doubles words
-    numpy consumes, in order.  Used by Network's STEP stream."""
+    numpy consumes, in order.  (Network's STEP stream until ABI 11; network_step_words since.)"""
     out = []
     for j in range(n_doubles):
         hi = _block(seed, lane, t, stream, 2 * (j >> 2))[j & 3]
         lo = _block(seed, lane, t, stream, 2 * (j >> 2) + 1)[j & 3]
         out += [int(hi), int(lo)]
+    return np.array(out, dtype=np.uint32)
+
+
+def network_step_words(seed, lane, t, n_doubles):
+    """Network's STEP stream (ABI 12): every draw of step() is a double — one per up machine in index order,
+    then one for the action (network.py:94-109) — compared with a threshold, and 16 random bits decide such a comparison
+    unless they equal the threshold's top 16 bits (probability 2^-16).  So the TOP 16 bits of double j come from a block
+    shared by the four lanes of a quad — counter (lane >> 2, t, STEP, block j >> 1), element lane & 3, upper half of the word
+    for even j, lower half for odd j: one Philox block serves two draws of each of four lanes — and the 37 bits below them
+    from the lane's own stream STEP_LO — counter (lane, t, STEP_LO, block j >> 1), elements 2 (j & 1) and 2 (j & 1) + 1 —
+    which the kernels generate on a tie only.  numpy builds the double from two words (a >> 5, b >> 6):
+        a_j = Q_j << 16 | X_j >> 16,   b_j = Y_j.
+    Returns the 2 * n_doubles words numpy consumes, in order."""
+    out = []
+    for j in range(n_doubles):
+        w = int(_block(seed, lane >> 2, t, STREAM_STEP, j >> 1)[lane & 3])
+        q = (w >> 16) if (j & 1) == 0 else (w & 0xFFFF)
+        lo = _block(seed, lane, t, STREAM_STEP_LO, j >> 1)
+        x, y = int(lo[2 * (j & 1)]), int(lo[2 * (j & 1) + 1])
+        out += [(q << 16) | (x >> 16), y]
     return np.array(out, dtype=np.uint32)
 
 

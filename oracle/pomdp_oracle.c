@@ -84,8 +84,9 @@ void or_ws_philox_env(or_ws *ws, int env_kind, uint64_t seed, uint32_t lane, uin
     or_ws_philox(ws, seed, lane, t, stream);
     if (env_kind == OR_ENV_ROCK && stream == OR_STREAM_RESET) { ws->layout = 3; ws->ctr[0] = lane >> 2; }   /* quad-shared, rotated */
     if (env_kind == OR_ENV_ROCK && stream == OR_STREAM_STEP) { ws->layout = 2; ws->ctr[0] = lane >> 2; }
-    /* Network: every draw of step() is a double too (one per up machine, one for the action): per-lane split layout */
-    if (env_kind == OR_ENV_NETWORK && stream == OR_STREAM_STEP) ws->layout = 1;
+    /* Network: every draw of step() is a double too (one per up machine, one for the action): the top 16 bits of double j
+     * from a quad-shared block, the rest from the lane's own STEP_LO stream (oracle/philox_ref.py network_step_words) */
+    if (env_kind == OR_ENV_NETWORK && stream == OR_STREAM_STEP) ws->layout = 4;
 }
 
 uint32_t or_ws_next32(or_ws *ws)
@@ -99,6 +100,23 @@ uint32_t or_ws_next32(or_ws *ws)
         y ^= (y << 15) & 0xefc60000u;
         y ^= y >> 18;
         return y;
+    }
+    if (ws->layout == 4) {
+        /* word 2 j = Q_j << 16 | X_j >> 16, word 2 j + 1 = Y_j: Q_j = the upper (j even) / lower (j odd) half of element
+         * lane & 3 of block j >> 1 of the QUAD's STEP stream; X_j, Y_j = elements 2 (j & 1), 2 (j & 1) + 1 of block j >> 1
+         * of the lane's STEP_LO stream.  half_blk[0] caches the quad block, half_blk[1] the lane's. */
+        const uint32_t i = ws->widx++, j = i >> 1, second = i & 1u, block = j >> 1;
+        if (!ws->half_have[0] || ws->half_idx[0] != block) {
+            uint32_t c[4] = { ws->lane >> 2, ws->ctr[1], ws->ctr[2], ((uint32_t)OR_STREAM_STEP << 24) | block };
+            or_philox4x32_10(c, ws->key, ws->half_blk[0]);
+            uint32_t c2[4] = { ws->lane, ws->ctr[1], ws->ctr[2], ((uint32_t)OR_STREAM_STEP_LO << 24) | block };
+            or_philox4x32_10(c2, ws->key, ws->half_blk[1]);
+            ws->half_idx[0] = block;
+            ws->half_have[0] = 1;
+        }
+        const uint32_t w = ws->half_blk[0][ws->lane & 3u], q = (j & 1u) ? (w & 0xFFFFu) : (w >> 16);
+        const uint32_t x = ws->half_blk[1][2u * (j & 1u)], y = ws->half_blk[1][2u * (j & 1u) + 1u];
+        return second ? y : ((q << 16) | (x >> 16));
     }
     if (ws->layout != 0) {
         const uint32_t i = ws->widx++, j = i >> 1, half = i & 1u;        /* word i = half `half` of double j */

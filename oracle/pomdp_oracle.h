@@ -26,7 +26,7 @@ extern "C" {
 /* ---- 32-bit word sources ------------------------------------------------ */
 enum { OR_WS_MT19937 = 0, OR_WS_PHILOX = 1 };
 enum { OR_STREAM_STEP = 0, OR_STREAM_RESET = 1, OR_STREAM_STEP_SPACE = 2,
-       OR_STREAM_RESET_SPACE = 3, OR_STREAM_ACTION = 4, OR_STREAM_ROLLOUT = 5, OR_STREAM_NEXT = 6 };
+       OR_STREAM_RESET_SPACE = 3, OR_STREAM_ACTION = 4, OR_STREAM_ROLLOUT = 5, OR_STREAM_NEXT = 6, OR_STREAM_STEP_LO = 7 };
 
 typedef struct or_ws {
     int kind;
@@ -40,7 +40,8 @@ typedef struct or_ws {
     uint32_t widx;
     uint64_t n_drawn;
     /* RockSample's split layout (oracle/philox_ref.py: rock_reset_words / rock_step_words):
-     * 0 = plain sequential stream, 1 = per-lane split (RESET), 2 = quad-shared split (STEP) */
+     * 0 = plain sequential stream, 1 = per-lane split, 2 = quad-shared split (STEP), 3 = rotated pair (RESET), 4 = Network's
+     * STEP: top 16 bits of double j from the quad's block j >> 1, the rest from the lane's STEP_LO block j >> 1 */
     int layout;
     uint32_t blk_base;                      /* layout 3: first block of the rotated pair (auto-reset: the step's sensor block) */
     uint32_t lane;

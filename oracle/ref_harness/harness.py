@@ -93,8 +93,8 @@ def consumed_words(rs=None):
 
 def inject_stream(seed, lane, t, stream, rs=None, env=None, env_kwargs=None, auto_reset=False):
     """Inject the words of (seed, lane, t, stream).  RockSample / StochasticRock use the split, quad-shared layout
-    of oracle/philox_ref.py (rock_reset_words / rock_step_words), Network's step() the per-lane split layout
-    (split_words); everything else the plain sequential stream."""
+    of oracle/philox_ref.py (rock_reset_words / rock_step_words), Network's step() the quad-shared 16-bit layout
+    (network_step_words); everything else the plain sequential stream."""
     if env in ("rock", "stochrock") and stream in (px.STREAM_STEP, px.STREAM_RESET):
         if stream == px.STREAM_RESET:
             # an auto-reset draws from the step's own sensor blocks (philox_ref.rock_reset_words)
@@ -106,7 +106,7 @@ def inject_stream(seed, lane, t, stream, rs=None, env=None, env_kwargs=None, aut
         inject_words(np.concatenate([w, np.full(8, 0xDEADBEEF, np.uint32)]), rs)
         return len(w)
     if env == "network" and stream == px.STREAM_STEP:
-        w = px.split_words(seed, lane, t, stream, (env_kwargs or {}).get("n_machines", 10) + 1)
+        w = px.network_step_words(seed, lane, t, (env_kwargs or {}).get("n_machines", 10) + 1)
         inject_words(np.concatenate([w, np.full(8, 0xDEADBEEF, np.uint32)]), rs)
         return len(w)
     inject_words(px.stream_words(seed, lane, t, stream, N_INJECT), rs)

@@ -76,26 +76,31 @@ def main(n_reset=6, n_sensor=8):
     print("state0 of tied rocks:", [int(tr["state0"][i][2 + r]) for i, (_, r) in enumerate(reset_ties)])
 
 
-def main_network(n_ties=5):
+def main_network(n_ties=11):
     """Network-v0 (10 machines): after reset every machine is up, so the first step draws doubles 0..9 against the
-    p = .1 failure threshold and double 10 (action 0 = ping machine 0) against the .95 observation threshold — split
-    layout, high words in elements of blocks 0, 2, 4 of the lane's STEP stream.  Ties on any of them."""
+    p = .1 failure threshold and double 10 (action 0 = ping machine 0) against the .95 observation threshold.  The top 16
+    bits of double j are a half of the quad's STEP block j >> 1 (philox_ref.network_step_words): a tie is a half that
+    equals the threshold's top 16 bits, the low 37 bits from the lane's STEP_LO stream then decide.  One tie per draw
+    index 0 .. 10 (both halves of blocks 0 .. 5: the inline blocks and the continuation of the kernels)."""
     thr = json.load(open(os.path.join(HERE, "thresholds.json")))
-    th_fail, th_obs = thr["net_fail"]["thr"] >> 26, thr["net_obs"]["thr"] >> 26
-    ties, lane = [], 0
-    while len(ties) < n_ties:
-        c0 = np.arange(lane, lane + CHUNK, dtype=np.uint64)
-        for g in (0, 1, 2):
-            kh = blocks(c0, 1, px.STREAM_STEP, 2 * g) >> np.uint32(5)
-            for li, e in zip(*np.nonzero(kh == th_fail)):
-                if 4 * g + int(e) < 10:
-                    ties.append((int(c0[li]), 4 * g + int(e)))
-            if g == 2:
-                for li in np.nonzero(kh[:, 2] == th_obs)[0]:
-                    ties.append((int(c0[li]), 10))
-        lane += CHUNK
-        print("searched", lane, "found", len(ties), flush=True)
-    ties = ties[:n_ties]
+    t16_fail, t16_obs = thr["net_fail"]["thr"] >> 37, thr["net_obs"]["thr"] >> 37
+    found, quad = {}, 0
+    chunk = 1 << 16
+    while len(found) < n_ties:
+        cq = np.arange(quad, quad + chunk, dtype=np.uint64)
+        for b in range(6):
+            blk = blocks(cq, 1, px.STREAM_STEP, b)
+            for half in (0, 1):
+                j = 2 * b + half
+                if j > 10 or j in found:
+                    continue
+                q16 = (blk >> np.uint32(16)) if half == 0 else (blk & np.uint32(0xFFFF))
+                hit = np.nonzero(q16 == (t16_fail if j < 10 else t16_obs))
+                if len(hit[0]):
+                    found[j] = int(cq[hit[0][0]]) * 4 + int(hit[1][0])
+        quad += chunk
+        print("searched quads", quad, "found", sorted(found), flush=True)
+    ties = sorted((ln, j) for j, ln in found.items())
     lanes = [ln for ln, _ in ties]
     tr = h.trace_mode_b("network", {}, SEED, lanes, np.zeros((len(lanes), 1), np.int64), t0=0)
     np.savez_compressed(os.path.join(HERE, "ties_network.npz"), seed=np.int64(SEED), lanes=np.array(lanes, np.int64),

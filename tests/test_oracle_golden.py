@@ -277,7 +277,8 @@ def test_auto_reset_ties_oracle(oracle_lib):
 
 
 def test_network_split_layout_ties_oracle(oracle_lib):
-    """Network draws decided by the low word (fixture ties_network.npz from tests/golden/find_ties.py --network)."""
+    """Network draws whose quad-shared top 16 bits equal the threshold's (fixture ties_network.npz from tests/golden/
+    find_ties.py --network: one lane per draw index 0 .. 10), decided by the lane's own STEP_LO words."""
     import json
     g = dict(np.load(os.path.join(GOLDEN, "ties_network.npz")))
     thr = json.load(open(os.path.join(GOLDEN, "thresholds.json")))
@@ -292,7 +293,8 @@ def test_network_split_layout_ties_oracle(oracle_lib):
         assert np.array_equal(o.batch_compact(st)[0], g["state"][i])
         j = int(g["tied_draw"][i])
         want = thr["net_obs"]["thr"] if j == 10 else thr["net_fail"]["thr"]
-        assert int(px.split_words(seed, int(lane), 1, px.STREAM_STEP, 11)[2 * j]) >> 5 == want >> 26   # really a tie
+        # really a tie of the quad-shared 16 bits (philox_ref.network_step_words), decided by the lane's STEP_LO words
+        assert int(px.network_step_words(seed, int(lane), 1, 11)[2 * j]) >> 16 == want >> 37
 
 
 # ---- heuristic policy support -------------------------------------------------------
