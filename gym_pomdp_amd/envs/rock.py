@@ -146,6 +146,12 @@ class RockEnv(BatchedEnv):
     def _build_params(self):
         return make_params(self.board_size, self.num_rocks)
 
+    def _validate_state(self, st, what):
+        """the agent stands on the board: the kernels' (position, action) tables hold the board's cells only"""
+        w = st[0].to(torch.int64)
+        if bool((((w & 15) >= self.board_size) | (((w >> 4) & 15) >= self.board_size)).any()):
+            raise ValueError("%s: RockSample state with the agent off the %d x %d board" % (what, self.board_size, self.board_size))
+
     def decode_state(self):
         """Reference-format view: int64 [N, 2 + K] = [x, y, status_0..status_{K-1}], status in {-1,0,+1}."""
         s = self._state.to(torch.int64) & 0xFFFFFFFF
