@@ -10,8 +10,11 @@ import os
 
 # The kernels take their parameter tables by value (~1 KB of kernel arguments per launch); with the arguments in device
 # memory a 2^20-lane step launch is 0.3-1.8 us shorter (bench.py).  Only effective if set before the HIP runtime
-# initialises, hence setdefault at import; harmless otherwise.
-os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+# initialises, hence at import — as a DEFAULT: a value the process already has is kept, and GYM_POMDP_AMD_KEEP_ENV=1 leaves
+# the environment alone altogether (the setting is process-wide: it changes where every HIP kernel of the process finds its
+# arguments, not only this package's).
+if not os.environ.get("GYM_POMDP_AMD_KEEP_ENV"):
+    os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 from . import spaces  # noqa: F401
 from .history import EpisodeStats, History, Returns, Transition  # noqa: F401

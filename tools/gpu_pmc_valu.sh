@@ -26,6 +26,16 @@ run() {   # name, bench args...
   timeout 600 rocprofv3 --kernel-trace --pmc $SQ2 -d $W/$name/p2 -o p2 -- python $REPO/bench.py "$@" > $W/$name/p2.log 2>&1
   echo "$name: $*" >> $W/commands.txt
 }
+SQ3="TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_STALL_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WR_UNCACHED_32B_sum"
+SQ4="TCP_PENDING_STALL_CYCLES_sum TCP_TCC_WRITE_REQ_sum TCP_TA_TCP_STATE_READ_sum TCP_GATE_EN2_sum"
+stalls() {   # name, bench args...: what the store path waits for (L2 write requests towards the fabric and their stalls, the
+             # vector cache's pending stalls) — two more passes, kept apart so that a counter this build of rocprofv3 does not
+             # know costs one pass, not all
+  local name=$1; shift
+  mkdir -p $W/$name
+  timeout 600 rocprofv3 --kernel-trace --pmc $SQ3 -d $W/$name/p3 -o p3 -- python $REPO/bench.py "$@" > $W/$name/p3.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $SQ4 -d $W/$name/p4 -o p4 -- python $REPO/bench.py "$@" > $W/$name/p4.log 2>&1
+}
 traffic() {   # name, bench args...: FETCH_SIZE and WRITE_SIZE in separate passes
   local name=$1; shift
   mkdir -p $W/$name/pmc_fetch $W/$name/pmc_write
@@ -54,7 +64,8 @@ for set in $SETS; do
       traffic step20_rock$(sfx $l) --env rock --layout $l $S20
     done
     traffic step256_rock_packed --env rock --layout packed $S256
-    traffic step256_rock_columns --env rock --layout columns $S256 ;;
+    traffic step256_rock_columns --env rock --layout columns $S256
+    for l in packed columns blocked narrow; do stalls step256_rock$(sfx $l) --env rock --layout $l $S256; done ;;
   sinks)    # the headline workload's sinks at 256 steps per launch only (a quick A/B of what a sink costs)
     for l in packed narrow returns; do run step256_rock$(sfx $l) --env rock --layout $l $S256; done ;;
   envs)

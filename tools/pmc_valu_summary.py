@@ -85,7 +85,7 @@ def main():
             from gym_pomdp_amd._native import FUSE_MAX_DEFAULT
             m = re.search(r"--steps (\d+)", cmds.get(name, ""))
             last = -(-int(m.group(1)) // FUSE_MAX_DEFAULT) if m else None
-        for sub in ("p1", "p2"):
+        for sub in ("p1", "p2", "p3", "p4"):          # p3 / p4: the store-path stall counters (headline set only)
             db = db_of(os.path.join(wd, sub))
             if not db:
                 continue
