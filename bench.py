@@ -39,7 +39,7 @@ import time
 
 # kernel arguments in device memory (the step kernels take their parameter tables by value, ~1 KB per launch): read
 # by the HIP runtime when it initialises, so it has to be in the environment before torch touches the GPU.  Measured:
-# 7.2 us per chained step with it, 7.5-7.7 without, 9.0 with the arguments in host memory (tools/drv_probe.py)
+# 7.2 us per chained step with it, 7.5-7.7 without, 9.0 with the arguments in host memory (round 2's probe)
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 import torch  # noqa: E402

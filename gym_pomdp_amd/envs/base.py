@@ -55,7 +55,7 @@ def staggered(specs, device):
     column starting k * 4 KB past a 4 KB boundary of its own.  Why: separate allocations of this size all start on the same
     2 MB boundary, a kernel that touches element i of every column at the same time (every step kernel does) then keeps
     hitting the same HBM channel, and the store stream of a fused launch runs 6 % (RockSample) to 14 % (Tiger) slower than
-    with the columns spread (tools/gpu_store_layout_probe.py, profiles/r02d_store_layout.txt)."""
+    with the columns spread (profiles/r02d_store_layout.txt)."""
     offs, total = [], 0
     for k, (shape, dtype) in enumerate(specs):
         nbytes = int(torch.Size(shape).numel()) * torch.empty((), dtype=dtype).element_size()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Round 4: the fused launch's time by TRAJECTORY LAYOUT and by where the buffer lies (dev aid; the successor of
-gpu_placement_probe.py's part (a)).  One process, one env per workload (2^20 lanes); for each layout (columns = four write
+round 3's placement probe, profiles/r03b_placement.txt).  One process, one env per workload (2^20 lanes); for each layout (columns = four write
 streams, blocked = the same 13 B per lane-step in one stream, packed = 4 B records) PP_ALLOCS fresh trajectory buffers are
 allocated with the earlier ones kept alive (fresh physical pages each time) and a K-step launch is timed into each (HIP
 events, best of 5 x 10 launches).  Prints us per launch per buffer, min / median / max, the spread, and the fill rate of
