@@ -494,10 +494,13 @@ def fused_alg_bytes(bytes_per_step, spl, layout):
     return out_b + once / float(spl)
 
 
-def fuse_max():
-    """steps per fused launch of the library's C-side drivers (include/pomdp_hip.h: pomdp_fuse_max)"""
+def fuse_max(env_key=None, layout=None):
+    """steps per fused launch of the library's C-side drivers (include/pomdp_hip.h: pomdp_fuse_max; for a trajectory
+    collection of `env_key` in `layout`: pomdp_fuse_steps — the 13-byte layouts of the store-bound envs stay at 64)"""
     from gym_pomdp_amd import _native
-    return int(_native.lib().pomdp_fuse_max(0))
+    if env_key is None or layout not in _native.LAYOUTS:
+        return int(_native.lib().pomdp_fuse_max(0))
+    return int(_native.lib().pomdp_fuse_steps(_native.ENV_KIND[ORACLE_NAME[env_key].replace("stochrock", "rock")], _native.LAYOUTS[layout]))
 
 
 def valu_workload_key(env_key, spl, layout, n=1 << 20):
@@ -537,7 +540,7 @@ def quick_step_config(args, gpa, _native, cp, dev, env_key, n, lane_offset, seed
     wl.run(k)
     walls, evs = timed_regions(wl.run, k, 9, dev, cp)
     kernel = _native.lib().pomdp_last_fused_kernel().decode()
-    spl = min(fuse_max(), StepWorkload.CHUNK, k)
+    spl = min(fuse_max(env_key, layout), StepWorkload.CHUNK, k)
     kern_ms = median(evs) / k
     if layout == "packed_plus_decode":
         # two kernels per chunk: the packed producer and the decode pass (4 B read + 13 B written per lane-step); the pass is
@@ -770,7 +773,7 @@ def main():
         # for this shard size and launch length, tools/gpu_pmc_valu.sh shards).
         strong["frac_of_floor"] = strong["floor_source"] = None
         if wl_s.fused and strong["kernel"]:
-            spl_s = min(fuse_max(), StepWorkload.CHUNK, args.steps)
+            spl_s = min(fuse_max(args.env, wl_s.layout), StepWorkload.CHUNK, args.steps)
             v = valu_roofline(valu_workload_key(args.env, spl_s, wl_s.layout, n_s), strong["kernel"].split("<")[0] + "<", n_s,
                               rows_s[0][4] / args.steps * spl_s)
             if v is not None:
@@ -800,7 +803,7 @@ def main():
     plain_ms = ev0.elapsed_time(ev1) / k1
     plain_achieved = bytes_per_step * n / (plain_ms * 1e-3) / 1e9
     kern_ms = timed_kernel_ms if chained else plain_ms
-    spl = min(fuse_max(), StepWorkload.CHUNK, args.steps) if fused else 1
+    spl = min(fuse_max(args.env, wl.layout if collect else None), StepWorkload.CHUNK, args.steps) if fused else 1
     layout = wl.layout
     rf = step_rooflines(args.env, bytes_per_step, layout, n, kern_ms, spl, fused, fused_kernel)
     chain1_ms = None

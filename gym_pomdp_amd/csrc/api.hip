@@ -389,7 +389,7 @@ int pomdp_collect_synthetic(int env, const void *params, uint32_t *state, int32_
     if (rc) return rc;
     if (pitch < n || !(flags & POMDP_AUTO_RESET)) return POMDP_E_BADARG;
     if (k_steps == 0 || n == 0) return 0;
-    const int64_t FUSE_MAX = fuse_max();
+    const int64_t FUSE_MAX = pomdp_fuse_steps(env, POMDP_LAYOUT_COLUMNS);
     for (int64_t s = 0; s < k_steps; s += FUSE_MAX) {      // the first launch writes row 0 (the actions of t0) itself
         const int c = (int)(k_steps - s < FUSE_MAX ? k_steps - s : FUSE_MAX);
         rc = dispatch_env(env, params, [&](auto tag, const auto &p) {
@@ -428,7 +428,7 @@ int pomdp_collect_layout(int env, const void *params, uint32_t *state, void *tra
         return POMDP_E_BADPARAMS;
     if (k_steps == 0 || n == 0) return 0;
     const int64_t row_bytes = layout == POMDP_LAYOUT_BLOCKED ? pitch * 13 : pitch * 4;
-    const int64_t FUSE_MAX = fuse_max();
+    const int64_t FUSE_MAX = pomdp_fuse_steps(env, layout);
     for (int64_t s = 0; s < k_steps; s += FUSE_MAX) {
         const int c = (int)(k_steps - s < FUSE_MAX ? k_steps - s : FUSE_MAX);
         int32_t *base = reinterpret_cast<int32_t *>(reinterpret_cast<uint8_t *>(traj) + s * row_bytes);
@@ -494,6 +494,14 @@ int pomdp_decode_packed(int env, const uint32_t *records, int64_t n, int64_t k_s
         hipLaunchKernelGGL(decode_packed_kernel<false>, grid, dim3(BLOCK), 0, (hipStream_t)stream, records, n, k_steps, pitch_in,
                            (uint32_t *)action, (uint32_t *)ob, (uint32_t *)reward, done, pitch_out, env);
     return (int)hipGetLastError();
+}
+
+int pomdp_fuse_steps(int env, int layout)
+{
+    const bool wide = layout == POMDP_LAYOUT_COLUMNS || layout == POMDP_LAYOUT_BLOCKED;
+    const bool store_bound = env == POMDP_ENV_ROCK || env == POMDP_ENV_TAG || env == POMDP_ENV_TIGER;
+    const int f = g_fuse_max;
+    return (wide && store_bound && f > 64) ? 64 : f;
 }
 
 int pomdp_fuse_max(int v)

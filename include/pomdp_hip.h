@@ -359,6 +359,11 @@ int pomdp_collect_returns(int env, const void *params, uint32_t *state, const po
  * the default is POMDP_FUSE_MAX_DEFAULT.  Results never depend on it. */
 #define POMDP_FUSE_MAX_DEFAULT 256
 int pomdp_fuse_max(int v);
+/* ... and what a trajectory collection of `env` in `layout` really runs per launch: pomdp_fuse_max(), except that the 13-byte
+ * layouts (POMDP_LAYOUT_COLUMNS, _BLOCKED) of RockSample, Tag and Tiger stay at 64 — their launches are bound by the store
+ * stream, and in a longer launch the waves drift further apart in the rows they write (RockSample 2.09 -> 2.55 us per step of
+ * 2^20 lanes at 256 steps per launch); BattleShip and Network gain from the longer launch in every layout. */
+int pomdp_fuse_steps(int env, int layout);
 
 /* ---- planner hooks ------------------------------------- */
 /* replaces <Env>._generate_legal (rock.py:273-291, tag.py:228-229, battleship.py:157-165, tiger.py:111-112,

@@ -422,47 +422,57 @@ LAYOUT_FULL = [("rock", {}, 1 << 20, 70), ("rock", {}, 1 << 20, 20), ("rock", di
                ("battleship", {}, 259, 70), ("rock", dict(board_size=15, num_rocks=15), (1 << 19) + 4, 30)]
 
 
-@pytest.mark.parametrize("layout", ["blocked", "packed", "narrow"])
+LAYOUTS = ("blocked", "packed", "narrow")
+
+
 @pytest.mark.parametrize("env,kw,n,steps", LAYOUT_FULL, ids=["%s%s-%d-%d" % (c[0], "-".join(str(v) for v in c[1].values()), c[2], c[3]) for c in LAYOUT_FULL])
-def test_single_stream_layouts_equal_the_oracle(oracle_lib, env, kw, n, steps, layout):
+def test_single_stream_layouts_equal_the_oracle(oracle_lib, env, kw, n, steps):
     """collect_synthetic(steps, layout=...) — the blocked (13 B per lane-step, int32 / float values, one contiguous block
-    per wave-step) and packed (one 32-bit record per lane-step) trajectories — decoded and compared with the oracle row by
-    row over the whole batch, across the 64-step launch boundary, then the state: the same information as the four
-    columns of the default ABI (rock.py:553-575: `ob, rw, done, info = env.step(action)` per step)."""
+    per wave-step), packed (one 32-bit record per lane-step, decoded by pomdp_decode_packed) and narrow (the record's bytes
+    as four typed planes) trajectories — compared with the oracle row by row over the whole batch, then the state: the same
+    information as the four columns of the default ABI (rock.py:553-575: `ob, rw, done, info = env.step(action)` per
+    step).  One oracle pass per case; one env per layout, all on the same seed."""
     seed, lane0, t0 = 20260930, 1 << 22, (1 << 33) + 9
     nt = oracle_lib.max_threads()
-    e = make_env(env, kw, batch_size=n, seed=seed, lane_offset=lane0, reuse_buffers=True)
-    e.call_counter = t0
     o = oracle_lib.OracleEnv(env, **kw)
     st = o.new_state(n)
-    assert np.array_equal(np_(e.reset()), o.batch_reset(st, seed, lane0, t0, nthreads=nt))
-    tr = e.collect_synthetic(steps, layout=layout)
-    assert tr["layout"] == layout and e.call_counter == t0 + 1 + steps and "layout" not in e.trajectory_buffers(1)
-    dec = e.decode_trajectory(tr)
+    ob0 = o.batch_reset(st, seed, lane0, t0, nthreads=nt)
+    envs, decs = {}, {}
+    for layout in LAYOUTS:
+        e = envs[layout] = make_env(env, kw, batch_size=n, seed=seed, lane_offset=lane0, reuse_buffers=True)
+        e.call_counter = t0
+        assert np.array_equal(np_(e.reset()), ob0)
+        tr = e.collect_synthetic(steps, layout=layout)
+        assert tr["layout"] == layout and e.call_counter == t0 + 1 + steps and "layout" not in e.trajectory_buffers(1)
+        decs[layout] = e.decode_trajectory(tr)
     done = np.zeros(n, np.uint8)
     for k in range(steps):
         t = t0 + 1 + k
         a = oracle_lib.synthetic_actions(n, seed, lane0, t, o.n_actions, nthreads=nt)
         ob, rew, done, bad = o.batch_step(st, a, seed, lane0, t, auto_reset=True, done=done, nthreads=nt)
-        ctx = (env, kw, n, k, layout)
-        assert bad == 0, ctx
-        assert np.array_equal(np_(dec["action"][k]), a), ctx
-        assert np.array_equal(np_(dec["ob"][k]), ob), ctx
-        got_r = np_(dec["reward"][k])
-        # narrow: the reward plane is the int8 reward itself (Network: gathered through the table, float32)
-        assert got_r.dtype == (np.int8 if layout == "narrow" and env != "network" else rew.dtype) and np.array_equal(got_r, rew), ctx
-        assert np.array_equal(np_(dec["done"][k]), done.astype(bool)), ctx
-    assert np.array_equal(np_(e.state).view(np.uint32), st)
-    assert e.invalid_action_count() == 0
+        assert bad == 0, (env, kw, n, k)
+        for layout in LAYOUTS:
+            dec, ctx = decs[layout], (env, kw, n, k, layout)
+            assert np.array_equal(np_(dec["action"][k]), a), ctx
+            assert np.array_equal(np_(dec["ob"][k]), ob), ctx
+            got_r = np_(dec["reward"][k])
+            # narrow: the reward plane is the int8 reward itself (Network: gathered through the table, float32)
+            assert got_r.dtype == (np.int8 if layout == "narrow" and env != "network" else rew.dtype) and np.array_equal(got_r, rew), ctx
+            assert np.array_equal(np_(dec["done"][k]), done.astype(bool)), ctx
+    for layout in LAYOUTS:
+        assert np.array_equal(np_(envs[layout].state).view(np.uint32), st), layout
+        assert envs[layout].invalid_action_count() == 0
     # the next call continues the same trajectory (it derives its first actions from (seed, lane, t) again)
-    tr2 = e.collect_synthetic(3, layout=layout)
-    d2 = e.decode_trajectory(tr2)
+    d2 = {layout: envs[layout].decode_trajectory(envs[layout].collect_synthetic(3, layout=layout)) for layout in LAYOUTS}
     for k in range(3):
         t = t0 + 1 + steps + k
         a = oracle_lib.synthetic_actions(n, seed, lane0, t, o.n_actions, nthreads=nt)
         ob, rew, done, bad = o.batch_step(st, a, seed, lane0, t, auto_reset=True, done=done, nthreads=nt)
-        assert np.array_equal(np_(d2["action"][k]), a) and np.array_equal(np_(d2["ob"][k]), ob) and np.array_equal(np_(d2["reward"][k]), rew)
-    assert np.array_equal(np_(e.state).view(np.uint32), st)
+        for layout in LAYOUTS:
+            d = d2[layout]
+            assert np.array_equal(np_(d["action"][k]), a) and np.array_equal(np_(d["ob"][k]), ob) and np.array_equal(np_(d["reward"][k]), rew), layout
+    for layout in LAYOUTS:
+        assert np.array_equal(np_(envs[layout].state).view(np.uint32), st), layout
 
 
 def test_layout_kernels_are_the_quad_loops_with_another_sink():

@@ -59,13 +59,15 @@ for set in $SETS; do
     traffic heuristic_rock --env rock --mode heuristic --prewarm 0 --warmup 128 --steps 1024 ;;
   headline)
     for l in packed columns blocked narrow returns; do
-      run step256_rock$(sfx $l) --env rock --layout $l $S256
+      k=256; if [ $l = columns ] || [ $l = blocked ]; then k=64; fi      # pomdp_fuse_steps: RockSample's 13-byte layouts stay at 64
+      run step${k}_rock$(sfx $l) --env rock --layout $l $S256
       run step20_rock$(sfx $l) --env rock --layout $l $S20
       traffic step20_rock$(sfx $l) --env rock --layout $l $S20
     done
     traffic step256_rock_packed --env rock --layout packed $S256
-    traffic step256_rock_columns --env rock --layout columns $S256
-    for l in packed columns blocked narrow; do stalls step256_rock$(sfx $l) --env rock --layout $l $S256; done ;;
+    traffic step64_rock --env rock --layout columns $S256
+    stalls step256_rock_packed --env rock --layout packed $S256; stalls step256_rock_narrow --env rock --layout narrow $S256
+    stalls step64_rock --env rock --layout columns $S256; stalls step64_rock_blocked --env rock --layout blocked $S256 ;;
   sinks)    # the headline workload's sinks at 256 steps per launch only (a quick A/B of what a sink costs)
     for l in packed narrow returns; do run step256_rock$(sfx $l) --env rock --layout $l $S256; done ;;
   envs)
@@ -73,7 +75,8 @@ for set in $SETS; do
       run step256_${e}_packed --env $e --layout packed $S256
       run step20_${e}_packed --env $e --layout packed $S20
     done
-    for e in tag network battleship; do run step256_$e --env $e --layout columns $S256; done
+    run step64_tag --env tag --layout columns $S256
+    for e in network battleship; do run step256_$e --env $e --layout columns $S256; done
     # BASELINE.json configs[3] per GPU: BattleShip 10x10 at 2^19 lanes (bench.py: configs.battleship)
     run step256_battleship_packed_2e19 --env battleship --layout packed --lanes-per-gpu 524288 $S256
     run step20_battleship_packed_2e19 --env battleship --layout packed --lanes-per-gpu 524288 $S20 ;;

@@ -2,7 +2,8 @@
 """Fused-launch time per step at the shard sizes a 2^20-lane batch leaves per GPU (2^17 .. 2^20, and below), for every
 library variant given: python tools/gpu_small_shards.py [libA.so libB.so ...]   (default: the product library).
 Variants come from tools/ab_build.sh (e.g. -DPOMDP_QUAD_MIN_LANES=4096: the quad-per-thread loops from 4096 lanes up).
-Prints us per step of collect_synthetic(64, layout=$SHARD_LAYOUT or "packed") by HIP events, and the kernel the launcher picked."""
+Prints us per step of collect_synthetic($SHARD_K or 256, layout=$SHARD_LAYOUT or "packed") by HIP events, and the kernel the launcher
+picked."""
 import os
 import subprocess
 import sys
@@ -32,19 +33,20 @@ def one(lib_path):
             lg = n.bit_length() - 1
             e = gpa.make(env_id, batch_size=n, seed=0, reuse_buffers=True, **kw)
             e.reset()
-            tr = e.collect_synthetic(64, layout=os.environ.get("SHARD_LAYOUT", "packed"))
-            for _ in range(20):
-                e.collect_synthetic(64, out=tr)
+            K = int(os.environ.get("SHARD_K", "256"))
+            tr = e.collect_synthetic(K, layout=os.environ.get("SHARD_LAYOUT", "packed"))
+            for _ in range(8):
+                e.collect_synthetic(K, out=tr)
             torch.cuda.synchronize()
             best = 1e9
             for _ in range(5):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                for _ in range(10):
-                    e.collect_synthetic(64, out=tr)
+                for _ in range(4):
+                    e.collect_synthetic(K, out=tr)
                 e1.record()
                 torch.cuda.synchronize()
-                best = min(best, e0.elapsed_time(e1) / 640 * 1e3)
+                best = min(best, e0.elapsed_time(e1) / (4 * K) * 1e3)
             print("%-10s %s lanes: %7.3f us/step  %8.3e lane-steps/s  %s" % (name, ("2^%d" % lg) if n == 1 << lg else str(n), best, n / best * 1e6,
                                                                                L.pomdp_last_fused_kernel().decode()), flush=True)
             del e, tr
