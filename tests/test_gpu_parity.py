@@ -1328,7 +1328,7 @@ def test_set_state_rejects_states_of_another_layout():
 
 
 def test_randomised_sweep_on_a_fixed_seed(monkeypatch):
-    """tools/gpu_fuzz.py as part of the suite: 45 seconds of random env configs, batch sizes (both launch geometries), lane
+    """tools/gpu_fuzz.py as part of the suite: 30 seconds of random env configs, batch sizes (both launch geometries), lane
     offsets up to 2^32, call counters up to 2^40, auto-reset on and off, invalid actions, and — one case in four here —
     trajectory collections in a random sink (columns / blocked / packed / narrow / returns-only), each compared word for
     word with the oracle.  The seed is fixed, so a failure reproduces; the builder's longer sweeps on fresh seeds are
@@ -1339,4 +1339,4 @@ def test_randomised_sweep_on_a_fixed_seed(monkeypatch):
     sys.path.insert(0, os.path.join(REPO, "tools"))
     monkeypatch.setenv("FUZZ_COLLECT", "0.25")
     import gpu_fuzz
-    assert gpu_fuzz.main(45.0, seed=20261001) >= 20
+    assert gpu_fuzz.main(30.0, seed=20261001) >= 12

@@ -3,7 +3,7 @@
 call counters, auto-reset on/off, valid and invalid actions — HIP path vs the oracle, word for word; one case in eight
 is a trajectory collection (fused launches, up to 2^20 + 2048 lanes, a random trajectory layout or the returns-only sink;
 FUZZ_COLLECT sets the share) checked row by row against the oracle.
-usage: python tools/gpu_fuzz.py [seconds [seed]]      (tests/test_gpu_parity.py runs a 45-second sweep on a fixed seed)"""
+usage: python tools/gpu_fuzz.py [seconds [seed]]      (tests/test_gpu_parity.py runs a 30-second sweep on a fixed seed)"""
 import os
 import sys
 import time
