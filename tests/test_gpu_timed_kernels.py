@@ -332,7 +332,7 @@ def test_bound_argument_entry_points_equal_the_plain_ones():
             assert all(torch.equal(x, y) for x, y in zip(ra[:3], rb[:3])) and torch.equal(a.state, b.state), env
 
 
-def _heuristic_fused_vs_oracle(oracle_lib, env, kw, n, ks, seed, lane0, max_size=None, auto=True):
+def _heuristic_fused_vs_oracle(oracle_lib, env, kw, n, ks, seed, lane0, max_size=None, auto=True, preset=None):
     """The launches `bench.py --mode heuristic` times — heuristic_steps_kernel, up to 64 steps each — against the oracle's
     lane-major restatement of the reference's rollout loop (rock.py:557-573; or_batch_heuristic_steps, pinned on CPU to the
     per-step batch functions the heur_* fixtures pin to the reference): after every launch the outputs it leaves (the LAST
@@ -353,6 +353,8 @@ def _heuristic_fused_vs_oracle(oracle_lib, env, kw, n, ks, seed, lane0, max_size
     hs = ol.HistorySums(o, n, max_size=max_size)
     frozen = np.zeros(n, np.uint8)
     t, n_done = 1, 0
+    if preset is not None:
+        preset(e, h, b, hs)
     for k in ks:
         fa, fo, fr, fd = e.heuristic_steps(h, k)
         want = o.batch_heuristic_steps(st, hs, b, prev, k, seed, lane0, t, auto_reset=auto, done_in=frozen, nthreads=nt)
@@ -406,6 +408,45 @@ def test_heuristic_multi_step_launches_on_ragged_batches_vs_oracle(oracle_lib, e
     hand the policy's (and RockSample's sensor) blocks of steps base + 1 .. 3 to the quad's in-range lanes, so their lane
     ids must be the unclamped ones (round 3's advisor finding: they used lane n - 1's)."""
     _heuristic_fused_vs_oracle(oracle_lib, env, kw, n, (64, 5, 64, 2), seed=4242, lane0=1 << 10, max_size=max_size, auto=auto)
+
+
+def test_heuristic_loop_over_many_launches_with_lanes_that_keep_checking(oracle_lib):
+    """RockSample(15,15) past the phase in which the rocks get measured: most lanes never CHECK again, one in 500 stands on a
+    rock it cannot decide about and CHECKs in three steps of four (the legal fallback of rock.py:374: ~190 CHECKs per 256
+    steps, `measured` far past 5) — every array after every launch.  1 280 steps, six launches."""
+    n_done = _heuristic_fused_vs_oracle(oracle_lib, "rock", dict(board_size=15, num_rocks=15), 8192 + 3, (256, 256, 256, 256, 255, 1),
+                                        seed=77, lane0=12)
+    assert n_done > 0
+
+
+@pytest.mark.parametrize("env,kw,max_size", [("rock", dict(board_size=15, num_rocks=15), None), ("rock", {}, None), ("rock", {}, 9),
+                                             ("stochrock", {}, None)], ids=["rock15", "rock", "rock-hist9", "stochrock"])
+def test_heuristic_loop_from_statistics_far_from_fresh(oracle_lib, env, kw, max_size):
+    """The heuristic loop started from statistics far from a fresh episode's: sums and counts of thousands either sign, rocks
+    measured hundreds of times, rocks whose prob_valuable is already closed (a likelihood of exactly 0) — every array, bit
+    for bit, after every launch (a loop that kept narrow copies of them, docs/HISTORY.md §A round 5, was checked with these)."""
+    def preset(e, h, b, hs):
+        K, n = b.count.shape
+        rng = np.random.default_rng(5)
+        edge = np.array([-70000, -2049, -2048, -2047, -2046, -300, -2, -1, 0, 0, 0, 1, 2, 300, 2046, 2047, 2048, 2049, 70000], np.int32)
+        hs.total_sample[:] = rng.choice(edge, size=(K, n))
+        hs.total_move[:] = rng.choice(edge, size=(K, n))
+        far = rng.random((K, n)) < .3                                    # rocks measured out long ago
+        b.measured[:] = np.where(far, rng.choice(np.array([5, 14, 15, 16, 250, 70000]), size=(K, n)), rng.integers(0, 5, size=(K, n)))
+        b.count[:] = np.where(far, rng.choice(np.array([-130, -9, -8, -7, -6, 6, 7, 8, 9, 130]), size=(K, n)),
+                              rng.integers(-2, 3, size=(K, n)))
+        closed = rng.random((K, n)) < .2                                 # a CHECK from distance 0 came first
+        b.lkw[:] = np.where(closed, 0., 1.)
+        b.prob_valuable[:] = np.where(closed, 1., .5)
+        if max_size is None:                                             # (a bounded history's sums are its window's: left at 0)
+            h.total_sample.copy_(torch.as_tensor(hs.total_sample)); h.total_move.copy_(torch.as_tensor(hs.total_move))
+            w = (1 << np.arange(K, dtype=np.int64))[:, None]
+            mo = ((hs.total_move >= 0) * w).sum(axis=0) | (((hs.total_sample > 0) * w).sum(axis=0) << 16)
+            h.move_ok.copy_(torch.as_tensor(mo.astype(np.uint32).view(np.int32)))
+        else:
+            hs.total_sample[:] = 0; hs.total_move[:] = 0
+        e.set_belief({k_: torch.as_tensor(getattr(b, k_)) for k_, _ in type(b).FIELDS})
+    _heuristic_fused_vs_oracle(oracle_lib, env, kw, 4096 + 1, (64, 256, 7), seed=99, lane0=8, max_size=max_size, preset=preset)
 
 
 # ---- the single-stream trajectory layouts (include/pomdp_hip.h: POMDP_LAYOUT_BLOCKED / _PACKED; csrc/traj_out.hip.h) --------
