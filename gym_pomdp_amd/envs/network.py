@@ -60,6 +60,13 @@ class NetworkEnv(BatchedEnv):
             self.last_action = int(action)           # network.py:80, used by render
         return super().step(action)
 
+    def sample_action(self):
+        """network.py:141-142 `np.random.choice(self._generate_legal())` — every action is legal (network.py:129-130), so this is
+        the synthetic policy's draw at the current call counter: element `(w * n_actions) >> 32` of the list, stream ACTION
+        (include/pomdp_hip.h: pomdp_synthetic_actions).  int32[N]; a python int when batch_size == 1."""
+        a = self.synthetic_actions()
+        return int(a.item()) if self.batch_size == 1 else a
+
     def reset(self):
         self.last_action = self._n_machines * 2       # network.py:65
         self._server = 0                              # network.py:68

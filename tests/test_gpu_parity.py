@@ -145,6 +145,21 @@ def test_no_auto_reset_freezes(oracle_lib, env, kw):
     assert done.sum() > 0
 
 
+def test_network_sample_action_is_the_uniform_choice_over_the_legal_list(oracle_lib):
+    """network.py:141-142: np.random.choice(_generate_legal()) with every action legal — the synthetic policy's draw at the
+    env's call counter (a python int for one lane, as the reference returns)."""
+    n, seed = 1000, 11
+    e = make_env("network", {}, batch_size=n, seed=seed)
+    e.reset()
+    for t in (1, 2):
+        a = e.sample_action()
+        assert np.array_equal(np_(a), oracle_lib.synthetic_actions(n, seed, 0, t, 21))
+        e.step(a)
+    one = make_env("network", {}, batch_size=1, seed=seed)
+    one.reset()
+    assert one.sample_action() == int(oracle_lib.synthetic_actions(1, seed, 0, 1, 21)[0])
+
+
 def test_odd_batch_sizes_without_synthetic_policy(oracle_lib):
     """batch sizes 1, 2, 3, 63, 65, 257 with host-provided actions (no multiple-of-4 requirement)."""
     for n in (1, 2, 3, 63, 65, 257):
