@@ -21,7 +21,7 @@ HEADERS = ["kernels_common.hip.h", "traj_out.hip.h", "step_impl.hip.h", "fused_i
            "envs/rock.hip.h", "envs/tag.hip.h", "envs/battleship.hip.h", "envs/tiger.hip.h", "envs/network.hip.h"]
 SOURCES = [os.path.join(_PKG, "csrc", f) for f in UNITS + HEADERS]
 HEADER = os.path.join(_REPO, "include", "pomdp_hip.h")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 POMDP_AUTO_RESET = 1
 POMDP_FUSE_STEPS = 2

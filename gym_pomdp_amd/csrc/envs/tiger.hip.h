@@ -31,11 +31,22 @@ struct TigerEnv {
     static __device__ __forceinline__ void load(State &st, const uint32_t *state, int64_t, uint32_t i) { st.w = ld_stream(state + i); }
     static __device__ __forceinline__ void store(const State &st, uint32_t *state, int64_t, uint32_t i, bool) { st_stream(state + i, st.w); }
 
-    // tiger.py:60-66: state = state_space.sample() (gym-space RNG -> stream RESET_SPACE); ob = NULL
+    // Word contract (ABI 13, include/pomdp_hip.h): whatever a call with counter t draws — LISTEN's uniform(), the door a wrong
+    // guess resamples, the door of the episode that reset() or the auto-reset after a right guess starts — it reads from the
+    // QUAD's STEP stream (counter word 0 = lane >> 2, lane L element L & 3): the double's high word / the door's word from
+    // block 0, the double's low word (a tie of the top 27 bits: 2^-27) from block 1.  One block serves four lanes.
+    static constexpr int QUAD_WORD = 1;                                        // fused_impl.hip.h: steps_quad_generic_kernel shares the block
+    static __device__ __forceinline__ uint4 quad_block(const RngKey &key, uint32_t lane, uint32_t block)
+    {
+        return stream_block(key, lane >> 2, POMDP_STREAM_STEP, block);
+    }
+    static __device__ __forceinline__ uint32_t elem(const uint4 &b, uint32_t e) { return e == 0 ? b.x : e == 1 ? b.y : e == 2 ? b.z : b.w; }
+    static __device__ __forceinline__ uint32_t word(const RngKey &key, uint32_t lane) { return elem(quad_block(key, lane, 0u), lane & 3u); }
+    // tiger.py:60-66: state = state_space.sample(); ob = NULL
     static __device__ __forceinline__ int reset(const Shared &, const Params &, State &st, const RngKey &key,
                                                 uint32_t lane)
     {
-        st.w = stream_block(key, lane, POMDP_STREAM_RESET_SPACE, 0u).x & 1u; // randint(2): mask 1, never rejects
+        st.w = word(key, lane) & 1u;                                            // randint(2): mask 1, never rejects
         return 2;
     }
     static __device__ __forceinline__ int reset_ob(const Params &, const State &) { return 2; }
@@ -81,26 +92,31 @@ struct TigerEnv {
     }
 
     // tiger.py:72-88 step, 117-119 _sample_state, 140-149 _sample_ob, 155-172.
-    // A step draws from exactly one place: LISTEN one double of stream STEP; the wrong door one word of stream STEP_SPACE
-    // (the state is resampled); the tiger's door nothing — but the auto-reset that follows draws one word of stream
-    // RESET_SPACE at the same call counter.  So the lane computes ONE Philox block whose stream id is a per-lane select,
-    // instead of the wave walking through three divergent blocks; the fresh episode's door is parked in st.rs.
-    template <class RT>
-    static __device__ __forceinline__ void step(const Shared &, const Params &p, State &st, int a,
-                                                const RngKey &key, uint32_t lane, int &ob, RT &rew, int &done)
+    // A step draws from exactly one place that matters: LISTEN one double; the wrong door one word (the state is resampled;
+    // the uniform() drawn there affects nothing); the tiger's door nothing — but the auto-reset that follows draws the fresh
+    // episode's door at the same call counter, parked in st.rs.  All of them read W, the lane's word of the quad's block.
+    // lo(): the double's low word (block 1), asked for on a tie of the top 27 bits only.
+    template <class RT, class LowWord>
+    static __device__ __forceinline__ void step_word(const Params &p, State &st, int a, uint32_t W, LowWord lo, int &ob, RT &rew,
+                                                     int &done)
     {
         const int tiger = (int)(st.w & 1u);
         const bool listen = a == 2, right = !listen && a == tiger;               // right: terminal, ob is the state
-        const uint32_t stream = listen ? (uint32_t)POMDP_STREAM_STEP
-                                       : (right ? (uint32_t)POMDP_STREAM_RESET_SPACE : (uint32_t)POMDP_STREAM_STEP_SPACE);
-        const uint4 w = stream_block(key, lane, stream, 0u);
-        const uint32_t door = w.x & 1u;                                          // randint(2): mask 1, never rejects
-        const bool flip = k53(w.x, w.y) > p.listen_thr;                          // p > .85
+        const uint32_t door = W & 1u;                                            // randint(2): mask 1, never rejects
+        const uint32_t kh = W >> 5, th = (uint32_t)(p.listen_thr >> 26);         // k53 > thr: the top 27 bits decide, but for a tie
+        bool flip = kh > th;                                                     // p > .85
+        if (listen && kh == th) flip = (lo() >> 6) > (uint32_t)(p.listen_thr & 0x3FFFFFFu);
         ob = right ? tiger : (listen ? (tiger ^ (int)flip) : 2);
         rew = right ? -20 : (listen ? -1 : 10);
         done = right;
         st.rs = right ? door : NO_RS;
-        st.w = (listen | right) ? st.w : door;     // wrong door: state resampled (the uniform() drawn there affects nothing)
+        st.w = (listen | right) ? st.w : door;     // wrong door: state resampled
+    }
+    template <class RT>
+    static __device__ __forceinline__ void step(const Shared &, const Params &p, State &st, int a,
+                                                const RngKey &key, uint32_t lane, int &ob, RT &rew, int &done)
+    {
+        step_word(p, st, a, word(key, lane), [&]() { return elem(quad_block(key, lane, 1u), lane & 3u); }, ob, rew, done);
     }
 };
 

@@ -820,6 +820,9 @@ template <class Env> struct quad_tab<Env, std::enable_if_t<Env::QUAD_TAB>> : std
 template <class Env, class = void> struct quad_fused : std::false_type {};
 template <class Env> struct quad_fused<Env, std::enable_if_t<Env::QUAD_FUSED>> : std::true_type {};
 
+template <class Env, class = void> struct quad_word_env : std::false_type {};
+template <class Env> struct quad_word_env<Env, std::enable_if_t<(Env::QUAD_WORD > 0)>> : std::true_type {};
+
 template <class Env, class L = Columns>
 __global__ __launch_bounds__(BLOCK) void steps_quad_generic_kernel(uint32_t *__restrict__ state, int32_t *__restrict__ action,
                                                                    int32_t *__restrict__ ob,
@@ -858,12 +861,20 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_generic_kernel(uint32_t *__r
         const uint32_t P[4] = {pw.x, pw.y, pw.z, pw.w};
         uint32_t o4[4], r4[4], a_next[4], d4[4], rc[4] = {0, 0, 0, 0};
         const uint32_t a_taken[4] = {(uint32_t)a_cur[0], (uint32_t)a_cur[1], (uint32_t)a_cur[2], (uint32_t)a_cur[3]};
+        uint32_t W[4] = {0, 0, 0, 0};                                          // Tiger: the quad's STEP block IS the thread's four words
+        if constexpr (quad_word_env<Env>::value) {
+            const uint4 qw = Env::quad_block(key, glane0, 0u);
+            W[0] = qw.x; W[1] = qw.y; W[2] = qw.z; W[3] = qw.w;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             int o, d;
             typename Env::Reward r;
             const uint32_t lane = glane0 + (uint32_t)j;
-            Env::step(sh, p, st[j], a_cur[j], key, lane, o, r, d);
+            if constexpr (quad_word_env<Env>::value)
+                Env::step_word(p, st[j], a_cur[j], W[j], [&]() { return Env::elem(Env::quad_block(key, lane, 1u), (uint32_t)j); }, o, r, d);
+            else
+                Env::step(sh, p, st[j], a_cur[j], key, lane, o, r, d);
             Env::reset_where(sh, p, st[j], d != 0, key, lane);                 // wave-convergent: every lane calls it
             o4[j] = (uint32_t)o;
             __builtin_memcpy(&r4[j], &r, 4);

@@ -411,12 +411,14 @@ extern thread_local uint32_t tl_flag_value;
 // lane per thread (0.66 against 0.72).  StochasticRock has no pooled loop and keeps 2^19.
 // Round 4: BattleShip's quad loop from 2^16 lanes (feed2 halved what its board pool costs, the one-lane loop builds boards on
 // the spot with the wave-cooperative builder: 2^16 / 2^17 lanes 0.995 / 1.036 against 1.074 / 1.209 us per step).
+// Round 5: Tiger's quad loop from 2^18 lanes (ABI 13: the quad's STEP block is the thread's four words; 2^18 / 2^17 lanes 0.531 /
+// 0.529 against 0.561 / 0.385 us per step with one lane per thread).
 // POMDP_QUAD_MIN_LANES overrides all of them at build time for same-box A/B runs (tools/ab_build.sh lib ... -D...).
 #ifdef POMDP_QUAD_MIN_LANES
 constexpr int64_t QUAD_MIN_ROCK = POMDP_QUAD_MIN_LANES, QUAD_MIN_STOCHROCK = POMDP_QUAD_MIN_LANES, QUAD_MIN_TAG = POMDP_QUAD_MIN_LANES,
                   QUAD_MIN_GENERIC = POMDP_QUAD_MIN_LANES, QUAD_MIN_NETWORK = POMDP_QUAD_MIN_LANES, QUAD_MIN_BATTLESHIP = POMDP_QUAD_MIN_LANES;
 #else
-constexpr int64_t QUAD_MIN_ROCK = 3 << 18, QUAD_MIN_STOCHROCK = 1 << 19, QUAD_MIN_TAG = 1 << 19, QUAD_MIN_GENERIC = 1 << 19,
+constexpr int64_t QUAD_MIN_ROCK = 3 << 18, QUAD_MIN_STOCHROCK = 1 << 19, QUAD_MIN_TAG = 1 << 19, QUAD_MIN_GENERIC = 1 << 18,
                   QUAD_MIN_NETWORK = 1 << 19, QUAD_MIN_BATTLESHIP = 1 << 16;
 #endif
 

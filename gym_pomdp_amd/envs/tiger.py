@@ -18,7 +18,8 @@ class TigerEnv(BatchedEnv):
     observation (tiger.py:81-83); opening the other door: +10, not done, tiger re-placed; listen: -1,
     correct w.p. .85.  `correct_prob` is stored but unused, as in the reference (tiger.py:86, 141).
     The hidden state comes from the gym-space RNG in the reference (tiger.py:64, 119), which
-    np.random.seed does not control: here it has its own word streams (RESET_SPACE / STEP_SPACE)."""
+    np.random.seed does not control: here both generators read the lane's word of the quad's STEP block of the
+    call counter (include/pomdp_hip.h, ABI 13: a call makes at most one draw that matters)."""
     env_name = "tiger"
     reward_dtype = torch.int32
 

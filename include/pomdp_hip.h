@@ -44,6 +44,11 @@
  * upper for even j, lower for odd j — of element lane % 4 of block j / 2 of the QUAD's stream STEP (counter word 0 =
  * lane / 4): one block serves two draws of each of four lanes.  The 37 bits below them come from the lane's own stream
  * STEP_LO (block j / 2, elements 2 (j % 2) and 2 (j % 2) + 1) and are generated on such a tie (2^-16 per draw) only.
+ * Tiger (ABI 13): a call with counter t makes at most one draw that matters — LISTEN's uniform() (tiger.py:140-149), the door
+ * a wrong guess resamples (tiger.py:117-119), the door of the episode that reset() or the auto-reset after a right guess
+ * starts (tiger.py:60-66) — and reads it from the QUAD's stream STEP (counter word 0 = lane / 4, lane L element L % 4): the
+ * double's high word, or the door (bit 0), from block 0; the double's low word (a tie of the top 27 bits only) from block
+ * 1.  One block serves four lanes.  (Streams STEP_SPACE / RESET_SPACE — the gym-space RNG's own — are no longer read.)
  */
 #ifndef POMDP_HIP_H
 #define POMDP_HIP_H
@@ -54,7 +59,7 @@
 extern "C" {
 #endif
 
-#define POMDP_ABI_VERSION 12
+#define POMDP_ABI_VERSION 13
 
 enum {
     POMDP_E_BADARG = -1,     /* NULL pointer, n < 0, n + lane0 > 2^32 */
@@ -154,7 +159,7 @@ typedef struct pomdp_tiger_params {
     uint64_t listen_thr;    /* listen is wrong iff k53 > listen_thr       tiger.py:141-148 */
 } pomdp_tiger_params;
 
-/* replaces TigerEnv.reset (tiger.py:60-66); the hidden state comes from stream RESET_SPACE */
+/* replaces TigerEnv.reset (tiger.py:60-66); the hidden state is bit 0 of the lane's word of the quad's STEP block */
 int pomdp_tiger_reset(const pomdp_tiger_params *p, uint32_t *state, int32_t *ob, int64_t n,
                       uint64_t seed, uint32_t lane0, uint64_t t, void *stream);
 /* replaces TigerEnv.step (tiger.py:72-88) */

@@ -18,13 +18,13 @@ oracle/pomdp_oracle.c and gym_pomdp_amd/csrc/philox.hip.h):
     randint n: mask = bit-smear(n - 1); draw words until (w & mask) <= n - 1
     binomial(1, p): one double, compared against a captured integer threshold.
 
-RockSample / StochasticRock and Network's step() deviate from "strictly sequential" in how the words are laid out (not
-in how numpy consumes them): see split_words / rock_reset_words / rock_step_words below (split high / low blocks,
-RockSample's quad-shared step stream).
+RockSample / StochasticRock, Network's step() and Tiger deviate from "strictly sequential" in how the words are laid out (not
+in how numpy consumes them): see split_words / rock_reset_words / rock_step_words / network_step_words / tiger_words below
+(split high / low blocks, quad-shared streams).
 
 Streams: 0 np.random draws made inside step(); 1 np.random draws made inside
 reset(); 2 / 3 the gym-space RNG (Discrete.sample) inside step() / reset()
-(Tiger only); 4 the benchmark's synthetic random-action policy; 5 the rollout policy's pick
+(Tiger only — since ABI 13 both read the words of stream 0, tiger_words); 4 the benchmark's synthetic random-action policy; 5 the rollout policy's pick
 among the legal actions (word k of the stream of the rollout's first call counter picks step k); 6 BattleShip's
 "next board": whenever a board is dealt at call counter t (reset(): from stream 1; an auto-reset: the cached board moves
 in), the reference's reset() run on stream 6 of (lane, t) gives the board of the episode after it.
@@ -159,6 +159,17 @@ def rock_step_words(seed, lane, t, n_doubles=1):
         lo = _block(seed, lane >> 2, t, STREAM_STEP, 2 * j + 1)[lane & 3]
         out += [int(hi), int(lo)]
     return np.array(out, dtype=np.uint32)
+
+
+def tiger_words(seed, lane, t):
+    """Tiger (ABI 13): whatever a call with counter t draws — LISTEN's uniform() (tiger.py:140-149), the door a wrong guess
+    resamples (state_space.sample(), tiger.py:117-119), the door of the episode that reset() or the auto-reset after a
+    right guess starts (tiger.py:60-66) — it reads from the QUAD's STEP stream, like RockSample's sensor: the Philox counter
+    carries lane >> 2, lane L uses element L & 3; the double's high word from block 0, its low word (a tie of the top 27 bits
+    only: 2^-27) from block 1; a door is bit 0 of the block-0 word (randint(2): mask 1, never rejects).  A call makes at most
+    one of these draws that matters (the uniform() a non-LISTEN step draws decides nothing), so one block serves four lanes.
+    -> [high word, low word]: the words of np.random for stream STEP, and of the gym-space RNG for STEP_SPACE / RESET_SPACE."""
+    return rock_step_words(seed, lane, t, 1)
 
 
 def synthetic_actions(seed, lane0, n, t, n_actions):

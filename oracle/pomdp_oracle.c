@@ -87,6 +87,16 @@ void or_ws_philox_env(or_ws *ws, int env_kind, uint64_t seed, uint32_t lane, uin
     /* Network: every draw of step() is a double too (one per up machine, one for the action): the top 16 bits of double j
      * from a quad-shared block, the rest from the lane's own STEP_LO stream (oracle/philox_ref.py network_step_words) */
     if (env_kind == OR_ENV_NETWORK && stream == OR_STREAM_STEP) ws->layout = 4;
+    if (env_kind == OR_ENV_TIGER && stream == OR_STREAM_STEP) { ws->layout = 2; ws->ctr[0] = lane >> 2; }
+}
+
+/* Tiger's gym-space RNG (state_space.sample(): tiger.py:62, 118) — ABI 13: it reads what LISTEN's uniform() reads, the
+ * quad's STEP blocks of the call counter (oracle/philox_ref.py tiger_words); `stream` (STEP_SPACE / RESET_SPACE) only says
+ * which call site draws */
+void or_ws_space(or_ws *ws, uint64_t seed, uint32_t lane, uint64_t t, uint32_t stream)
+{
+    (void)stream;
+    or_ws_philox_env(ws, OR_ENV_TIGER, seed, lane, t, OR_STREAM_STEP);
 }
 
 uint32_t or_ws_next32(or_ws *ws)
@@ -866,7 +876,7 @@ void or_batch_reset(const or_env *proto, uint32_t *state, int32_t *ob, int64_t n
 #pragma omp for schedule(static)
         for (int64_t i = 0; i < n; i++) {
             or_ws_philox_env(&np_rng, e.kind, seed, lane0 + (uint32_t)i, t, OR_STREAM_RESET);
-            or_ws_philox(&sp_rng, seed, lane0 + (uint32_t)i, t, OR_STREAM_RESET_SPACE);
+            or_ws_space(&sp_rng, seed, lane0 + (uint32_t)i, t, OR_STREAM_RESET_SPACE);
             int o = or_env_reset(&e, &np_rng, &sp_rng);
             if (e.kind == OR_ENV_BATTLESHIP) {                 /* ... and the board of the episode after this one */
                 or_ws_philox(&np_rng, seed, lane0 + (uint32_t)i, t, OR_STREAM_NEXT);
@@ -903,7 +913,7 @@ int64_t or_batch_step(const or_env *proto, uint32_t *state, const int32_t *actio
                 for (int j = 0; j < W; j++) w[j] = state[(int64_t)j * n + i];
                 or_env_unpack(&e, w);
                 or_ws_philox_env(&np_rng, e.kind, seed, lane0 + (uint32_t)i, t, OR_STREAM_STEP);
-                or_ws_philox(&sp_rng, seed, lane0 + (uint32_t)i, t, OR_STREAM_STEP_SPACE);
+                or_ws_space(&sp_rng, seed, lane0 + (uint32_t)i, t, OR_STREAM_STEP_SPACE);
                 or_env_step(&e, a, &np_rng, &sp_rng, &o, &r, &d);
                 if (d && auto_reset && e.kind == OR_ENV_BATTLESHIP) {   /* the cached board moves in; the one after it from NEXT */
                     bs_swap_in(&e);
@@ -911,7 +921,7 @@ int64_t or_batch_step(const or_env *proto, uint32_t *state, const int32_t *actio
                     bs_deal_next(&e, &np_rng);
                 } else if (d && auto_reset) {
                     or_ws_philox_auto_reset(&np_rng, &e, seed, lane0 + (uint32_t)i, t);
-                    or_ws_philox(&sp_rng, seed, lane0 + (uint32_t)i, t, OR_STREAM_RESET_SPACE);
+                    or_ws_space(&sp_rng, seed, lane0 + (uint32_t)i, t, OR_STREAM_RESET_SPACE);
                     or_env_reset(&e, &np_rng, &sp_rng);
                 }
                 or_env_pack(&e, w);
@@ -977,7 +987,7 @@ double or_bench_loop(const or_env *proto, int64_t n, int64_t steps, uint64_t see
         const int64_t lo = n * tid / nt, hi = n * (tid + 1) / nt;
         for (int64_t i = lo; i < hi; i++) {                       /* reset at t = 0 (first touch of the thread's own chunk) */
             or_ws_philox_env(&np_rng, e.kind, seed, (uint32_t)i, 0, OR_STREAM_RESET);
-            or_ws_philox(&sp_rng, seed, (uint32_t)i, 0, OR_STREAM_RESET_SPACE);
+            or_ws_space(&sp_rng, seed, (uint32_t)i, 0, OR_STREAM_RESET_SPACE);
             or_env_reset(&e, &np_rng, &sp_rng);
             if (e.kind == OR_ENV_BATTLESHIP) { or_ws_philox(&np_rng, seed, (uint32_t)i, 0, OR_STREAM_NEXT); bs_deal_next(&e, &np_rng); }
             or_env_pack(&e, w);
@@ -994,7 +1004,7 @@ double or_bench_loop(const or_env *proto, int64_t n, int64_t steps, uint64_t see
                 const int a = (int)(((uint64_t)o4[i & 3] * (uint32_t)nA) >> 32);
                 int o, d; double r;
                 or_ws_philox_env(&np_rng, e.kind, seed, (uint32_t)i, (uint64_t)s, OR_STREAM_STEP);
-                or_ws_philox(&sp_rng, seed, (uint32_t)i, (uint64_t)s, OR_STREAM_STEP_SPACE);
+                or_ws_space(&sp_rng, seed, (uint32_t)i, (uint64_t)s, OR_STREAM_STEP_SPACE);
                 or_env_step(&e, a, &np_rng, &sp_rng, &o, &r, &d);
                 if (d && e.kind == OR_ENV_BATTLESHIP) {
                     bs_swap_in(&e);
@@ -1002,7 +1012,7 @@ double or_bench_loop(const or_env *proto, int64_t n, int64_t steps, uint64_t see
                     bs_deal_next(&e, &np_rng);
                 } else if (d) {
                     or_ws_philox_auto_reset(&np_rng, &e, seed, (uint32_t)i, (uint64_t)s);
-                    or_ws_philox(&sp_rng, seed, (uint32_t)i, (uint64_t)s, OR_STREAM_RESET_SPACE);
+                    or_ws_space(&sp_rng, seed, (uint32_t)i, (uint64_t)s, OR_STREAM_RESET_SPACE);
                     or_env_reset(&e, &np_rng, &sp_rng);
                 }
                 dsum += d;
@@ -1052,7 +1062,7 @@ int64_t or_batch_collect_returns(const or_env *proto, uint32_t *state, double *a
                 const int a = actions ? actions[s * n + i] : (int)(((uint64_t)o4[lane & 3u] * (uint32_t)nA) >> 32);
                 int o, d; double r;
                 or_ws_philox_env(&np_rng, e.kind, seed, lane, t, OR_STREAM_STEP);
-                or_ws_philox(&sp_rng, seed, lane, t, OR_STREAM_STEP_SPACE);
+                or_ws_space(&sp_rng, seed, lane, t, OR_STREAM_STEP_SPACE);
                 or_env_step(&e, a, &np_rng, &sp_rng, &o, &r, &d);
                 {   /* r += discount * rw; discount *= .95 (network.py:186-187) — separate multiply and add */
                     const double term = disc * r;
@@ -1071,7 +1081,7 @@ int64_t or_batch_collect_returns(const or_env *proto, uint32_t *state, double *a
                         bs_deal_next(&e, &np_rng);
                     } else {
                         or_ws_philox_auto_reset(&np_rng, &e, seed, lane, t);
-                        or_ws_philox(&sp_rng, seed, lane, t, OR_STREAM_RESET_SPACE);
+                        or_ws_space(&sp_rng, seed, lane, t, OR_STREAM_RESET_SPACE);
                         or_env_reset(&e, &np_rng, &sp_rng);
                     }
                 }
@@ -1161,7 +1171,7 @@ void or_batch_rollout(const or_env *proto, const uint32_t *state, int64_t n_root
                 int a = list[((uint64_t)or_ws_next32(&pol) * (uint64_t)len) >> 32];
                 if (k == 0) first = a;
                 or_ws_philox_env(&np_rng, e.kind, seed, lane, t0 + (uint64_t)k, OR_STREAM_STEP);
-                or_ws_philox(&sp_rng, seed, lane, t0 + (uint64_t)k, OR_STREAM_STEP_SPACE);
+                or_ws_space(&sp_rng, seed, lane, t0 + (uint64_t)k, OR_STREAM_STEP_SPACE);
                 double r;
                 or_env_step(&e, a, &np_rng, &sp_rng, &o, &r, &d);
                 double term = disc * r;
@@ -1522,7 +1532,7 @@ void or_batch_heuristic_steps(const or_env *proto, uint32_t *state, const or_roc
                     int fresh_ob = 0;
                     if (a >= 0 && a < nA) {
                         or_ws_philox_env(&np_rng, e.kind, seed, lane, t, OR_STREAM_STEP);
-                        or_ws_philox(&sp_rng, seed, lane, t, OR_STREAM_STEP_SPACE);
+                        or_ws_space(&sp_rng, seed, lane, t, OR_STREAM_STEP_SPACE);
                         or_env_step(&e, a, &np_rng, &sp_rng, &o, &r, &d);
                         if (d && auto_reset && e.kind == OR_ENV_BATTLESHIP) {
                             bs_swap_in(&e);
@@ -1530,7 +1540,7 @@ void or_batch_heuristic_steps(const or_env *proto, uint32_t *state, const or_roc
                             bs_deal_next(&e, &np_rng);
                         } else if (d && auto_reset) {
                             or_ws_philox_auto_reset(&np_rng, &e, seed, lane, t);
-                            or_ws_philox(&sp_rng, seed, lane, t, OR_STREAM_RESET_SPACE);
+                            or_ws_space(&sp_rng, seed, lane, t, OR_STREAM_RESET_SPACE);
                             fresh_ob = or_env_reset(&e, &np_rng, &sp_rng);
                         }
                     }

@@ -53,6 +53,8 @@ void     or_ws_seed_mt(or_ws *ws, uint32_t seed);
 void     or_ws_philox(or_ws *ws, uint64_t seed, uint32_t lane, uint64_t t, uint32_t stream);
 /* word source of one env call: RockSample envs get the split layout for streams STEP / RESET */
 void     or_ws_philox_env(or_ws *ws, int env_kind, uint64_t seed, uint32_t lane, uint64_t t, uint32_t stream);
+/* Tiger's gym-space RNG at call counter t: the quad's STEP blocks (oracle/philox_ref.py tiger_words) */
+void     or_ws_space(or_ws *ws, uint64_t seed, uint32_t lane, uint64_t t, uint32_t stream);
 uint32_t or_ws_next32(or_ws *ws);
 void     or_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 

@@ -94,7 +94,8 @@ def consumed_words(rs=None):
 def inject_stream(seed, lane, t, stream, rs=None, env=None, env_kwargs=None, auto_reset=False):
     """Inject the words of (seed, lane, t, stream).  RockSample / StochasticRock use the split, quad-shared layout
     of oracle/philox_ref.py (rock_reset_words / rock_step_words), Network's step() the quad-shared 16-bit layout
-    (network_step_words); everything else the plain sequential stream."""
+    (network_step_words), Tiger the quad's STEP blocks for all three of its streams (tiger_words); everything else the plain
+    sequential stream."""
     if env in ("rock", "stochrock") and stream in (px.STREAM_STEP, px.STREAM_RESET):
         if stream == px.STREAM_RESET:
             # an auto-reset draws from the step's own sensor blocks (philox_ref.rock_reset_words)
@@ -103,6 +104,11 @@ def inject_stream(seed, lane, t, stream, rs=None, env=None, env_kwargs=None, aut
         else:
             w = px.rock_step_words(seed, lane, t, 2 if env == "stochrock" else 1)
         # pad with a recognisable filler: consuming more words than the layout defines must be noticed
+        inject_words(np.concatenate([w, np.full(8, 0xDEADBEEF, np.uint32)]), rs)
+        return len(w)
+    if stream in (px.STREAM_STEP_SPACE, px.STREAM_RESET_SPACE) or (env == "tiger" and stream == px.STREAM_STEP):
+        # Tiger (the only env with a gym-space RNG): every draw of call counter t reads the quad's STEP blocks
+        w = px.tiger_words(seed, lane, t)
         inject_words(np.concatenate([w, np.full(8, 0xDEADBEEF, np.uint32)]), rs)
         return len(w)
     if env == "network" and stream == px.STREAM_STEP:
