@@ -80,11 +80,47 @@ struct TagEnv {
     }
     static __device__ __forceinline__ int reset_ob(const Params &p, const State &st) { return sample_ob(p, st.w, 0); }
 
-    // Called convergently by every lane of the wave; `fresh` marks the lanes that start a new episode.
+    // ---- word contract of the one-opponent game (ABI 13, include/pomdp_hip.h) ------------------------------------------------
+    // A step draws only when a TAG fails (the opponent's flight: binomial(1, move_prob), then np.random.choice over 2 or 4
+    // moves, tag.py:201-207) or succeeds (the auto-reset that follows: randint(29) per cell, tag.py:181-193) — never both, and
+    // a fifth of the lane-steps at most.  Both read ONE word W: the lane's element (lane % 4) of block 0 of the QUAD's STEP
+    // stream (counter word 0 = lane / 4).  Flight: the double's high word is W (its low word, read on a tie of the top 27 bits
+    // only, the element of block 1); the choice's word is W again — it uses bits 0-1, the double bits 5-31.  Auto-reset:
+    // attempt i of the masked-rejection draws reads bits 5 i .. 5 i + 4 of W (i < 6), later attempts the lane's own RESET stream
+    // from its first word on (4 x 10^-5 of the resets).  One block serves four lanes; reset() itself (pomdp_tag_reset) and
+    // games with more opponents keep the sequential per-lane streams.
+    static __device__ __forceinline__ uint4 quad_block(const RngKey &key, uint32_t lane, uint32_t block)
+    {
+        return stream_block(key, lane >> 2, POMDP_STREAM_STEP, block);
+    }
+    static __device__ __forceinline__ uint32_t elem(const uint4 &b, uint32_t e) { return e == 0 ? b.x : e == 1 ? b.y : e == 2 ? b.z : b.w; }
+    static __device__ __forceinline__ void auto_reset_word(const Params &p, State &st, uint32_t W, const RngKey &key, uint32_t lane)
+    {
+        uint32_t w = 0; int have = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const uint32_t v = (W >> (5 * i)) & 31u;
+            if (have < 2 && v <= 28u) { w |= v << (5 * have); ++have; }
+        }
+        if (have < 2) {                                                        // five of six attempts rejected
+            WordStream ws(key, lane, POMDP_STREAM_RESET);
+            while (have < 2) {
+                const uint32_t v = ws.next32() & 31u;
+                if (v <= 28u) { w |= v << (5 * have); ++have; }
+            }
+        }
+        st.w = with_num_opp(w, 1);
+    }
+    // Called convergently by every lane of the wave; `fresh` marks the lanes that start a new episode inside a step's call.
     static __device__ __forceinline__ void reset_where(const Shared &sh, const Params &p, State &st, bool fresh,
                                                        const RngKey &key, uint32_t lane)
     {
-        if (fresh) reset(sh, p, st, key, lane);
+        if (p.num_opponents == 1) {                                            // wave-uniform
+            if (__any(fresh)) {
+                const uint32_t W = elem(quad_block(key, lane, 0u), lane & 3u);
+                if (fresh) auto_reset_word(p, st, W, key, lane);
+            }
+        } else if (fresh) reset(sh, p, st, key, lane);
     }
     static __device__ __forceinline__ void reset_where_chain(const Shared &sh, const Params &p, State &st, bool fresh,
                                                              const RngKey &key, uint32_t lane, const RngKey &akey,
@@ -143,10 +179,10 @@ struct TagEnv {
 
     // tag.py:108-143 with one opponent (the default and the benchmark configuration), branch-free: under a random
     // policy every wave holds both moves and TAGs, so both outcomes are evaluated and selected.  Only a failed TAG
-    // on a live opponent draws random numbers — words 0-2 of block 0 of the lane's STEP stream: binomial(1,
-    // move_prob) on (w0, w1), then np.random.choice over a list whose length is 2 or 4, i.e. randint with an exact
-    // mask (one word, no rejection).  The step is therefore split: `pre` does everything but the opponent's flight
-    // and says whether the draw is needed, `flee` applies it; launches that pool Philox work call them separately.
+    // on a live opponent draws random numbers: binomial(1, move_prob), then np.random.choice over a list whose length is 2
+    // or 4, i.e. randint with an exact mask (one word, no rejection) — from the lane's word of the quad's block (above).  The
+    // step is therefore split: `pre` does everything but the opponent's flight and says whether the draw is needed,
+    // `flee_word` applies it.
     struct Flight { uint32_t list; int oi; bool need; };
     // tag.py:260-280 `_admissable_actions`: the list the eight appends build depends only on the signs of
     // (opponent - agent) in x and y.  Entry k = 3 (sign dx + 1) + (sign dy + 1), four 2-bit moves each (N0 E1 S2 W3,
@@ -227,13 +263,16 @@ struct TagEnv {
     // binomial(1, move_prob) of tag.py:204 from the double's numerator: numpy's inversion gives [U <= thr] for p > .5 and
     // [U > thr] for p <= .5 — the sense is a flag of the params (wave-uniform)
     static __device__ __forceinline__ bool moves(const Params &p, uint64_t k) { return (k <= p.move_thr) != (p.move_gt != 0); }
-    // the opponent's flight from words 0-2 of the lane's STEP block (tag.py:201-207)
-    static __device__ __forceinline__ void flee(const Shared &sh, const Params &p, State &st, const Flight &f, uint32_t w0,
-                                                uint32_t w1, uint32_t w2)
+    // the one-opponent game's flight from the lane's word W of the quad's block (lo(): the double's low word, a tie only)
+    template <class LowWord>
+    static __device__ __forceinline__ void flee_word(const Shared &sh, const Params &p, State &st, const Flight &f, uint32_t W, LowWord lo)
     {
-        const uint32_t pick = (f.list >> (2 * (w2 & 3u))) & 3u;       // np.random.choice: randint(2 or 4), exact mask
+        const uint32_t pick = (f.list >> (2 * (W & 3u))) & 3u;        // np.random.choice: randint(2 or 4), exact mask
         const uint32_t to = sh.mv[4 * f.oi + (int)pick];               // the cell itself if the square does not exist
-        if (f.need && moves(p, k53(w0, w1))) st.w = (st.w & ~(31u << 5)) | (to << 5);
+        const uint32_t kh = W >> 5, th = (uint32_t)(p.move_thr >> 26);
+        bool le = kh < th;                                             // k53 <= move_thr: the top 27 bits decide, but for a tie
+        if (f.need && kh == th) le = (lo() >> 6) <= (uint32_t)(p.move_thr & 0x3FFFFFFu);
+        if (f.need && (le != (p.move_gt != 0))) st.w = (st.w & ~(31u << 5)) | (to << 5);
     }
     template <class RT>
     static __device__ __forceinline__ void step_one_opponent(const Shared &sh, const Params &p, State &st, int a,
@@ -242,28 +281,10 @@ struct TagEnv {
         Flight f;
         step_one_opponent_pre(sh, p, st, a, ob, rew, done, f);
         if (__any(f.need)) {                             // a policy that rarely tags (the heuristic one) rarely pays for the block
-            const uint4 blk = stream_block(key, lane, POMDP_STREAM_STEP, 0u);
-            flee(sh, p, st, f, blk.x, blk.y, blk.z);
+            const uint32_t W = elem(quad_block(key, lane, 0u), lane & 3u);
+            flee_word(sh, p, st, f, W, [&]() { return elem(quad_block(key, lane, 1u), lane & 3u); });
         }
     }
-    // reset() from the four words of block 0 of the lane's RESET stream (tag.py:181-193: randint(29) per cell, each a
-    // masked-rejection loop); false when the rejections ran past the block (probability < 1e-3) — the caller then
-    // takes the general path
-    static __device__ __forceinline__ bool reset_from_block(const Params &p, State &st, const uint4 &b)
-    {
-        const uint32_t wd[4] = {b.x, b.y, b.z, b.w};
-        uint32_t w = 0; int have = 0;
-        const int want = 1 + p.num_opponents;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t v = wd[j] & 31u;
-            if (have < want && v <= 28u) { w |= v << (5 * have); ++have; }
-        }
-        if (have < want) return false;
-        st.w = with_num_opp(w, p.num_opponents);
-        return true;
-    }
-
     // tag.py:108-143 step, 201-207 move_opponent, 260-280 _admissable_actions
     template <class RT>
     static __device__ __forceinline__ void step(const Shared &sh, const Params &p, State &st, int a,

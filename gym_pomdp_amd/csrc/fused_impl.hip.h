@@ -312,9 +312,11 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
 #endif
 }
 
-// Tag (one opponent) with a quad per thread: the policy's ACTION block is the thread's own, the flights of failed TAGs
-// (about a fifth of the lanes) and the rare resets are pooled per wave of 256 lanes — one Philox pass instead of the two per
-// 256 lanes that Finisher<TagEnv, 2> needs with the policy blocks in its task list — and the outputs leave as 16-byte stores.
+// Tag (one opponent) with a quad per thread: the policy's ACTION block is the thread's own, and so is the quad's STEP block —
+// its four words are the four lanes' (ABI 13, tag.hip.h): a failed TAG's flight and the auto-reset after a successful one read
+// them where they stand.  (Until round 5 both had per-lane blocks, pooled per wave of 256 lanes through LDS: two ballots, a rank
+// and an LDS round trip per lane for one Philox pass — 70 of the loop's 273 vector instructions per thread-step.)  The outputs
+// leave as 16-byte stores.
 template <bool TAB, class L = Columns>   // TAB: the lane step reads the (cells, action) table built when the launch starts (from 16 steps per launch)
 __global__ __launch_bounds__(BLOCK) void tag_steps_quad_kernel(uint32_t *__restrict__ state, int32_t *__restrict__ action,
                                                                int32_t *__restrict__ ob, float *__restrict__ reward,
@@ -325,11 +327,8 @@ __global__ __launch_bounds__(BLOCK) void tag_steps_quad_kernel(uint32_t *__restr
     using Env = TagEnv;
     __shared__ Env::Shared sh;
     __shared__ typename std::conditional<TAB, Env::StepTab, NoTab>::type tab;
-    __shared__ uint8_t src_lds[BLOCK / 64][256];             // task rank -> lane within the wave's 256
-    __shared__ uint32_t res_lds[BLOCK / 64][256][4];         // task rank -> its Philox block
-    const int wv = (int)(threadIdx.x >> 6), me = (int)(threadIdx.x & 63u);
     const uint32_t l0 = blockIdx.x * (uint32_t)(4 * BLOCK) + 4u * threadIdx.x;
-    const uint32_t glane0 = lane0 + l0, wave0 = glane0 - 4u * (uint32_t)me;
+    const uint32_t glane0 = lane0 + l0;
     QuadOut<L> out(action, ob, reward, done, rec, l0);
     Env::State st[4];
     int a_cur[4];
@@ -359,55 +358,18 @@ __global__ __launch_bounds__(BLOCK) void tag_steps_quad_kernel(uint32_t *__restr
         const uint32_t P[4] = {pw.x, pw.y, pw.z, pw.w};
         int o[4], d[4];
         float r[4];
-        Env::Flight f[4];
-        uint64_t fm[4], rm[4];
         const uint32_t a_taken[4] = {(uint32_t)a_cur[0], (uint32_t)a_cur[1], (uint32_t)a_cur[2], (uint32_t)a_cur[3]};
-        int nfl = 0, nrs = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if constexpr (TAB) Env::step_one_opponent_tab(tab, st[j], a_cur[j], o[j], r[j], d[j], f[j]);
-            else Env::step_one_opponent_pre(sh, p, st[j], a_cur[j], o[j], r[j], d[j], f[j]);
-            fm[j] = __ballot(f[j].need);
-            rm[j] = __ballot(d[j] != 0);
-            nfl += __popcll(fm[j]);
-            nrs += __popcll(rm[j]);
-        }
-        // task list: the flights, then the resets (a lane is never both: a failed TAG does not end the episode)
-        auto below = [&](uint64_t m) {
-            return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        };
-        int rank[4], cf = 0, cr = nfl;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            rank[j] = f[j].need ? cf + below(fm[j]) : cr + below(rm[j]);
-            cf += __popcll(fm[j]);
-            cr += __popcll(rm[j]);
-            if (f[j].need || d[j]) src_lds[wv][rank[j] & 255] = (uint8_t)(4 * me + j);
-        }
-        const int ntask = nfl + nrs;
-        for (int base = 0; base < ntask; base += 64) {
-            const int q = base + me;
-            if (q < ntask) {
-                const uint32_t src_lane = wave0 + (uint32_t)src_lds[wv][q & 255];
-                const uint32_t strm = q < nfl ? POMDP_STREAM_STEP : POMDP_STREAM_RESET;
-                const uint4 w = philox4x32_10(src_lane, key.t_lo, key.t_hi, strm << 24, key.k0, key.k1);
-                uint32_t *dst = res_lds[wv][q & 255];
-                dst[0] = w.x; dst[1] = w.y; dst[2] = w.z; dst[3] = w.w;
-            }
-        }
+        const uint4 qw = Env::quad_block(key, glane0, 0u);
+        const uint32_t W[4] = {qw.x, qw.y, qw.z, qw.w};
         uint32_t a_next[4];
-        uint4 rb[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {                                          // all four blocks in flight, one wait; used by the lanes with a task
-            const uint32_t *res = res_lds[wv][rank[j] & 255];
-            rb[j] = make_uint4(res[0], res[1], res[2], res[3]);
-        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (f[j].need) Env::flee(sh, p, st[j], f[j], rb[j].x, rb[j].y, rb[j].z);
-            if (d[j]) {
-                if (!Env::reset_from_block(p, st[j], rb[j])) Env::reset(sh, p, st[j], key, glane0 + (uint32_t)j);   // rejections ran past the block
-            }
+            Env::Flight f;
+            if constexpr (TAB) Env::step_one_opponent_tab(tab, st[j], a_cur[j], o[j], r[j], d[j], f);
+            else Env::step_one_opponent_pre(sh, p, st[j], a_cur[j], o[j], r[j], d[j], f);
+            const uint32_t lane = glane0 + (uint32_t)j;
+            Env::flee_word(sh, p, st[j], f, W[j], [&]() { return Env::elem(Env::quad_block(key, lane, 1u), (uint32_t)j); });
+            if (d[j]) Env::auto_reset_word(p, st[j], W[j], key, lane);
             a_next[j] = __umulhi(P[j], n_act);
             a_cur[j] = (int)a_next[j];
         }

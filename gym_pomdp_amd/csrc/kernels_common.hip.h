@@ -208,9 +208,10 @@ struct Finisher<RockEnv<W, false>, LPT, CHAIN, typename std::enable_if<(LPT >= 2
 
 // Tag with two lanes per thread: only a failed TAG on a live opponent draws (about a fifth of the lanes under a random
 // policy) and resets are rare (episodes last hundreds of steps), so per-lane Philox blocks would be mostly wasted.
-// ONE task list per wave (128 lanes): for CHAIN launches the 32 policy blocks of the next call counter, one STEP block
-// per lane whose opponent may flee, one RESET block per resetting lane — ~58 blocks for 128 lane-steps instead of 256
-// (512 chained), dealt out 64 per pass through a wave-private LDS scratch like RockSample's.  The lane step runs
+// ONE task list per wave (128 lanes): for CHAIN launches the 32 policy blocks of the next call counter, and the quad's STEP
+// block for every lane whose opponent may flee or whose episode ended (ABI 13: both read the lane's element of it) — ~58
+// blocks for 128 lane-steps instead of 256 (512 chained), dealt out 64 per pass through a wave-private LDS scratch like
+// RockSample's.  The lane step runs
 // without the flight (TagEnv::step_one_opponent_pre) and TagEnv::flee completes it from the pooled words.
 // More than one opponent (wave-uniform, from the params): the general per-lane path.
 template <bool CHAIN>
@@ -265,9 +266,9 @@ struct Finisher<TagEnv, 2, CHAIN, void> {
                 const int v = (int)src_lds[wv][r & 127];
                 const uint32_t src_lane = ((v >> 6) ? first1 : first0) + (uint32_t)(v & 63);
                 const uint32_t quad = (((tid >> 4) ? first1 : first0) >> 2) + (uint32_t)(tid & 15);
-                const uint32_t c0 = is_act ? quad : src_lane;
+                const uint32_t c0 = is_act ? quad : (src_lane >> 2);           // flights and auto-resets: the QUAD's STEP block (tag.hip.h)
                 const uint32_t c1 = is_act ? akey.t_lo : key.t_lo, c2 = is_act ? akey.t_hi : key.t_hi;
-                const uint32_t strm = is_act ? POMDP_STREAM_ACTION : (r < nfl ? POMDP_STREAM_STEP : POMDP_STREAM_RESET);
+                const uint32_t strm = is_act ? POMDP_STREAM_ACTION : POMDP_STREAM_STEP;
                 const uint4 w = philox4x32_10(c0, c1, c2, strm << 24, key.k0, key.k1);
                 uint32_t *dst = res_lds[wv][is_act ? tid : 32 + (r & 127)];
                 dst[0] = w.x; dst[1] = w.y; dst[2] = w.z; dst[3] = w.w;
@@ -281,10 +282,9 @@ struct Finisher<TagEnv, 2, CHAIN, void> {
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            if (aux[j].need) Env::flee(sh, p, st[j], aux[j], rb[j].x, rb[j].y, rb[j].z);
-            if (fresh[j]) {
-                if (!Env::reset_from_block(p, st[j], rb[j])) Env::reset(sh, p, st[j], key, lane[j]);   // rejections ran past the block
-            }
+            const uint32_t W = Env::elem(rb[j], lane[j] & 3u);
+            Env::flee_word(sh, p, st[j], aux[j], W, [&]() { return Env::elem(Env::quad_block(key, lane[j], 1u), lane[j] & 3u); });
+            if (fresh[j]) Env::auto_reset_word(p, st[j], W, key, lane[j]);
             if (CHAIN) a_next[j] = (int)__umulhi(res_lds[wv][16 * j + (me >> 2)][me & 3], n_act);
         }
     }

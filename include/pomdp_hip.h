@@ -49,6 +49,13 @@
  * starts (tiger.py:60-66) — and reads it from the QUAD's stream STEP (counter word 0 = lane / 4, lane L element L % 4): the
  * double's high word, or the door (bit 0), from block 0; the double's low word (a tie of the top 27 bits only) from block
  * 1.  One block serves four lanes.  (Streams STEP_SPACE / RESET_SPACE — the gym-space RNG's own — are no longer read.)
+ * Tag with ONE opponent (ABI 13): a step draws only when a TAG fails (the opponent's flight: binomial(1, move_prob), then
+ * np.random.choice over 2 or 4 moves, tag.py:201-207) or succeeds (the reset that follows inside the call: randint(29) per
+ * cell, tag.py:181-193) — never both — and reads the lane's word W of the QUAD's STEP block 0 for either: the flight's double
+ * is (W, the same element of block 1 — a tie of the top 27 bits only), its choice word is W again (bits 0-1; the double uses
+ * bits 5-31); the auto-reset's attempt i < 6 reads bits 5 i .. 5 i + 4 of W, later attempts (4 x 10^-5 of the resets) the
+ * lane's own stream RESET from its first word on.  pomdp_tag_reset itself and games with more opponents keep the
+ * sequential per-lane streams.
  */
 #ifndef POMDP_HIP_H
 #define POMDP_HIP_H

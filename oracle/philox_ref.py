@@ -18,8 +18,9 @@ oracle/pomdp_oracle.c and gym_pomdp_amd/csrc/philox.hip.h):
     randint n: mask = bit-smear(n - 1); draw words until (w & mask) <= n - 1
     binomial(1, p): one double, compared against a captured integer threshold.
 
-RockSample / StochasticRock, Network's step() and Tiger deviate from "strictly sequential" in how the words are laid out (not
-in how numpy consumes them): see split_words / rock_reset_words / rock_step_words / network_step_words / tiger_words below
+RockSample / StochasticRock, Network's step(), Tiger and Tag with one opponent deviate from "strictly sequential" in how the words are laid out (not
+in how numpy consumes them): see split_words / rock_reset_words / rock_step_words / network_step_words / tiger_words /
+tag_step_words / tag_auto_reset_words below
 (split high / low blocks, quad-shared streams).
 
 Streams: 0 np.random draws made inside step(); 1 np.random draws made inside
@@ -170,6 +171,26 @@ def tiger_words(seed, lane, t):
     one of these draws that matters (the uniform() a non-LISTEN step draws decides nothing), so one block serves four lanes.
     -> [high word, low word]: the words of np.random for stream STEP, and of the gym-space RNG for STEP_SPACE / RESET_SPACE."""
     return rock_step_words(seed, lane, t, 1)
+
+
+def tag_step_words(seed, lane, t):
+    """Tag with ONE opponent (ABI 13): a step draws only when a TAG fails — the opponent's flight, binomial(1, move_prob) then
+    np.random.choice over 2 or 4 admissible moves (tag.py:201-207) — and reads the lane's word W of the QUAD's STEP block 0
+    (counter word 0 = lane >> 2, element lane & 3) for both: the double is (W, W') with W' the same element of block 1 (it
+    matters on a tie of the top 27 bits only), the choice's randint word is W again (it uses bits 0-1, the double bits 5-31).
+    -> the three words np.random consumes."""
+    hi, lo = (int(x) for x in rock_step_words(seed, lane, t, 1))
+    return np.array([hi, lo, hi], dtype=np.uint32)
+
+
+def tag_auto_reset_words(seed, lane, t, n_tail=64):
+    """Tag with ONE opponent: the reset() that follows a successful TAG inside the step's call (the step itself drew nothing)
+    draws randint(29) per cell by masked rejection, 5 bits per attempt (tag.py:43-44, 181-193): attempt i < 6 reads bits
+    5 i .. 5 i + 4 of the step's quad word W, later attempts (five of the first six rejected: 4 x 10^-5) the lane's own RESET
+    stream from its first word on."""
+    w = int(rock_step_words(seed, lane, t, 1)[0])
+    head = [(w >> (5 * i)) & 0xFFFFFFFF for i in range(6)]
+    return np.concatenate([np.array(head, dtype=np.uint32), stream_words(seed, lane, t, STREAM_RESET, n_tail)])
 
 
 def synthetic_actions(seed, lane0, n, t, n_actions):

@@ -111,6 +111,29 @@ uint32_t or_ws_next32(or_ws *ws)
         y ^= y >> 18;
         return y;
     }
+    if (ws->layout == 5 || ws->layout == 6) {
+        /* Tag with one opponent (oracle/philox_ref.py tag_step_words / tag_auto_reset_words): W = element lane & 3 of block 0 of
+         * the QUAD's STEP stream, W' the same of block 1.  layout 5 (a step: the flight's binomial double, then the choice's
+         * word): W, W', W.  layout 6 (the auto-reset after a done step): attempt i < 6 reads W >> 5 i, later attempts the
+         * lane's own RESET stream from its first word on. */
+        const uint32_t i = ws->widx++;
+        if (ws->layout == 6 && i >= 6u) {
+            const uint32_t k = i - 6u;
+            if ((k & 3u) == 0 || !ws->half_have[1] || ws->half_idx[1] != (k >> 2)) {
+                uint32_t c[4] = { ws->lane, ws->ctr[1], ws->ctr[2], ((uint32_t)OR_STREAM_RESET << 24) | ((k >> 2) & 0xFFFFFFu) };
+                or_philox4x32_10(c, ws->key, ws->half_blk[1]);
+                ws->half_idx[1] = k >> 2;
+                ws->half_have[1] = 1;
+            }
+            return ws->half_blk[1][k & 3u];
+        }
+        const uint32_t block = (ws->layout == 5 && i == 1u) ? 1u : 0u;
+        if (ws->layout == 5 && i > 2u) return 0xDEADBEEFu;                   /* a flight draws three words */
+        uint32_t c[4] = { ws->lane >> 2, ws->ctr[1], ws->ctr[2], ((uint32_t)OR_STREAM_STEP << 24) | block }, q[4];
+        or_philox4x32_10(c, ws->key, q);
+        const uint32_t w = q[ws->lane & 3u];
+        return ws->layout == 6 ? (w >> (5u * i)) : w;
+    }
     if (ws->layout == 4) {
         /* word 2 j = Q_j << 16 | X_j >> 16, word 2 j + 1 = Y_j: Q_j = the upper (j even) / lower (j odd) half of element
          * lane & 3 of block j >> 1 of the QUAD's STEP stream; X_j, Y_j = elements 2 (j & 1), 2 (j & 1) + 1 of block j >> 1
@@ -673,16 +696,29 @@ static void network_step(or_env *e, int action, or_ws *np_rng, int *ob_out, doub
 /* The reset that follows a done step inside the step's own call counter.  RockSample / StochasticRock: the rotated pair
  * (layout 3) of the step's SENSOR blocks — stream STEP, blocks b, b + 1 with b = 0 (RockEnv) or 2 (StochasticRockEnv,
  * whose block 0 gates the action) — instead of stream RESET: a step never draws both (a CHECK does not end the episode,
- * rock.py:171-175, 193), so the word is consumed once either way (oracle/philox_ref.py rock_reset_words).  Every other env:
+ * rock.py:171-175, 193), so the word is consumed once either way (oracle/philox_ref.py rock_reset_words).  Tag with one
+ * opponent: the 5-bit fields of the step's own quad word (a successful TAG draws nothing else; layout 6).  Every other env:
  * stream RESET of (lane, t).  (BattleShip's cached board is the caller's business.) */
 void or_ws_philox_auto_reset(or_ws *ws, const or_env *e, uint64_t seed, uint32_t lane, uint64_t t)
 {
+    if (e->kind == OR_ENV_TAG && e->n_opponents == 1) {                       /* the fields of the step's own quad word */
+        or_ws_philox(ws, seed, lane, t, OR_STREAM_RESET);
+        ws->layout = 6;
+        return;
+    }
     if (e->kind == OR_ENV_ROCK) {
         or_ws_philox(ws, seed, lane, t, OR_STREAM_STEP);
         ws->layout = 3; ws->ctr[0] = lane >> 2; ws->blk_base = e->stochastic ? 2u : 0u;
         return;
     }
     or_ws_philox_env(ws, e->kind, seed, lane, t, OR_STREAM_RESET);
+}
+
+/* np.random's words inside step() at call counter t */
+void or_ws_philox_step(or_ws *ws, const or_env *e, uint64_t seed, uint32_t lane, uint64_t t)
+{
+    or_ws_philox_env(ws, e->kind, seed, lane, t, OR_STREAM_STEP);
+    if (e->kind == OR_ENV_TAG && e->n_opponents == 1) ws->layout = 5;          /* the one-opponent game: the quad's word */
 }
 
 int or_env_reset(or_env *e, or_ws *np_rng, or_ws *space_rng)
@@ -912,7 +948,7 @@ int64_t or_batch_step(const or_env *proto, uint32_t *state, const int32_t *actio
             } else {
                 for (int j = 0; j < W; j++) w[j] = state[(int64_t)j * n + i];
                 or_env_unpack(&e, w);
-                or_ws_philox_env(&np_rng, e.kind, seed, lane0 + (uint32_t)i, t, OR_STREAM_STEP);
+                or_ws_philox_step(&np_rng, &e, seed, lane0 + (uint32_t)i, t);
                 or_ws_space(&sp_rng, seed, lane0 + (uint32_t)i, t, OR_STREAM_STEP_SPACE);
                 or_env_step(&e, a, &np_rng, &sp_rng, &o, &r, &d);
                 if (d && auto_reset && e.kind == OR_ENV_BATTLESHIP) {   /* the cached board moves in; the one after it from NEXT */
@@ -1003,7 +1039,7 @@ double or_bench_loop(const or_env *proto, int64_t n, int64_t steps, uint64_t see
                 or_philox4x32_10(c, akey, o4);
                 const int a = (int)(((uint64_t)o4[i & 3] * (uint32_t)nA) >> 32);
                 int o, d; double r;
-                or_ws_philox_env(&np_rng, e.kind, seed, (uint32_t)i, (uint64_t)s, OR_STREAM_STEP);
+                or_ws_philox_step(&np_rng, &e, seed, (uint32_t)i, (uint64_t)s);
                 or_ws_space(&sp_rng, seed, (uint32_t)i, (uint64_t)s, OR_STREAM_STEP_SPACE);
                 or_env_step(&e, a, &np_rng, &sp_rng, &o, &r, &d);
                 if (d && e.kind == OR_ENV_BATTLESHIP) {
@@ -1061,7 +1097,7 @@ int64_t or_batch_collect_returns(const or_env *proto, uint32_t *state, double *a
                 or_philox4x32_10(c, key, o4);
                 const int a = actions ? actions[s * n + i] : (int)(((uint64_t)o4[lane & 3u] * (uint32_t)nA) >> 32);
                 int o, d; double r;
-                or_ws_philox_env(&np_rng, e.kind, seed, lane, t, OR_STREAM_STEP);
+                or_ws_philox_step(&np_rng, &e, seed, lane, t);
                 or_ws_space(&sp_rng, seed, lane, t, OR_STREAM_STEP_SPACE);
                 or_env_step(&e, a, &np_rng, &sp_rng, &o, &r, &d);
                 {   /* r += discount * rw; discount *= .95 (network.py:186-187) — separate multiply and add */
@@ -1170,7 +1206,7 @@ void or_batch_rollout(const or_env *proto, const uint32_t *state, int64_t n_root
                 if (k == 0) or_ws_philox(&pol, seed, lane, t0, OR_STREAM_ROLLOUT);   /* word k of this stream picks step k */
                 int a = list[((uint64_t)or_ws_next32(&pol) * (uint64_t)len) >> 32];
                 if (k == 0) first = a;
-                or_ws_philox_env(&np_rng, e.kind, seed, lane, t0 + (uint64_t)k, OR_STREAM_STEP);
+                or_ws_philox_step(&np_rng, &e, seed, lane, t0 + (uint64_t)k);
                 or_ws_space(&sp_rng, seed, lane, t0 + (uint64_t)k, OR_STREAM_STEP_SPACE);
                 double r;
                 or_env_step(&e, a, &np_rng, &sp_rng, &o, &r, &d);
@@ -1531,7 +1567,7 @@ void or_batch_heuristic_steps(const or_env *proto, uint32_t *state, const or_roc
                     a = l > 0 ? list[(int32_t)(((uint64_t)o4[lane & 3u] * (uint32_t)l) >> 32)] : -1;
                     int fresh_ob = 0;
                     if (a >= 0 && a < nA) {
-                        or_ws_philox_env(&np_rng, e.kind, seed, lane, t, OR_STREAM_STEP);
+                        or_ws_philox_step(&np_rng, &e, seed, lane, t);
                         or_ws_space(&sp_rng, seed, lane, t, OR_STREAM_STEP_SPACE);
                         or_env_step(&e, a, &np_rng, &sp_rng, &o, &r, &d);
                         if (d && auto_reset && e.kind == OR_ENV_BATTLESHIP) {

@@ -41,7 +41,8 @@ typedef struct or_ws {
     uint64_t n_drawn;
     /* RockSample's split layout (oracle/philox_ref.py: rock_reset_words / rock_step_words):
      * 0 = plain sequential stream, 1 = per-lane split, 2 = quad-shared split (STEP), 3 = rotated pair (RESET), 4 = Network's
-     * STEP: top 16 bits of double j from the quad's block j >> 1, the rest from the lane's STEP_LO block j >> 1 */
+     * STEP: top 16 bits of double j from the quad's block j >> 1, the rest from the lane's STEP_LO block j >> 1; 5 / 6 = Tag with
+     * one opponent: a step's flight / the auto-reset after it, from the quad's STEP word (pomdp_oracle.c: or_ws_next32) */
     int layout;
     uint32_t blk_base;                      /* layout 3: first block of the rotated pair (auto-reset: the step's sensor block) */
     uint32_t lane;
@@ -69,6 +70,8 @@ enum { OR_REWARD_I32 = 0, OR_REWARD_F32 = 1 };
 typedef struct or_env or_env;
 /* word source of the reset that follows a done step inside that step's call counter t (batch auto-reset) */
 void     or_ws_philox_auto_reset(or_ws *ws, const or_env *e, uint64_t seed, uint32_t lane, uint64_t t);
+/* np.random's word source inside step() at call counter t (Tag with one opponent: the quad's word, layout 5) */
+void     or_ws_philox_step(or_ws *ws, const or_env *e, uint64_t seed, uint32_t lane, uint64_t t);
 
 /* args: rock (board_size, num_rocks[, stochastic, act_thr_lo, act_thr_hi])  stochastic = StochasticRockEnv
  *       tag (num_opponents, obs_cells, move_thr_lo, move_thr_hi[, move_gt])  thr==0 -> captured value for 0.8; move_gt: moves iff k > thr

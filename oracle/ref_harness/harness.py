@@ -94,7 +94,8 @@ def consumed_words(rs=None):
 def inject_stream(seed, lane, t, stream, rs=None, env=None, env_kwargs=None, auto_reset=False):
     """Inject the words of (seed, lane, t, stream).  RockSample / StochasticRock use the split, quad-shared layout
     of oracle/philox_ref.py (rock_reset_words / rock_step_words), Network's step() the quad-shared 16-bit layout
-    (network_step_words), Tiger the quad's STEP blocks for all three of its streams (tiger_words); everything else the plain
+    (network_step_words), Tiger the quad's STEP blocks for all three of its streams (tiger_words), Tag with one opponent the quad's word for a
+    step's flight and for the auto-reset after it (tag_step_words / tag_auto_reset_words); everything else the plain
     sequential stream."""
     if env in ("rock", "stochrock") and stream in (px.STREAM_STEP, px.STREAM_RESET):
         if stream == px.STREAM_RESET:
@@ -110,6 +111,14 @@ def inject_stream(seed, lane, t, stream, rs=None, env=None, env_kwargs=None, aut
         # Tiger (the only env with a gym-space RNG): every draw of call counter t reads the quad's STEP blocks
         w = px.tiger_words(seed, lane, t)
         inject_words(np.concatenate([w, np.full(8, 0xDEADBEEF, np.uint32)]), rs)
+        return len(w)
+    if env == "tag" and (env_kwargs or {}).get("num_opponents", 1) == 1 and (stream == px.STREAM_STEP or (stream == px.STREAM_RESET and auto_reset)):
+        # the one-opponent game: a flight and the auto-reset after a successful TAG read the quad's STEP word
+        if stream == px.STREAM_STEP:
+            w = np.concatenate([px.tag_step_words(seed, lane, t), np.full(8, 0xDEADBEEF, np.uint32)])
+        else:
+            w = px.tag_auto_reset_words(seed, lane, t)
+        inject_words(w, rs)
         return len(w)
     if env == "network" and stream == px.STREAM_STEP:
         w = px.network_step_words(seed, lane, t, (env_kwargs or {}).get("n_machines", 10) + 1)

@@ -137,8 +137,50 @@ def main_auto(n_ties=4):
     print("new episode's status of the tied rocks:", [int(tr["state"][i, 0][1 + r]) for i, (_, r) in enumerate(ties)])
 
 
+def main_tag(n_slow=4, n_tie=2):
+    """Tag with one opponent (fixture ties_tag.npz): a flight and the auto-reset after a successful TAG read the lane's word W of
+    the quad's STEP block (philox_ref.tag_step_words / tag_auto_reset_words).  Rare paths, at call counter 1 with action TAG:
+      slow  — lanes whose reset() at t = 0 puts agent and opponent on one cell (the TAG succeeds) AND whose W has five of its
+              six 5-bit fields above 28 (the auto-reset's draws run on into the lane's RESET stream: 4 x 10^-5 of the resets);
+      tie   — lanes whose TAG fails and whose W >> 5 equals the move threshold's top 27 bits (2^-27: the flight's binomial is
+              decided by the low word, block 1)."""
+    from gym_pomdp_amd import tables
+    thr_hi = int(tables.TAG_MOVE_THR) >> 26
+    slow, tie, lane = [], [], 0
+    while len(slow) < n_slow or len(tie) < n_tie:
+        q = np.arange(lane >> 2, (lane + CHUNK) >> 2, dtype=np.uint64)
+        W = blocks(q, 1, px.STREAM_STEP, 0).astype(np.uint64).reshape(-1)          # lane-major: quad q, element e -> lane 4 q + e
+        lanes = np.arange(lane, lane + CHUNK, dtype=np.uint64)
+        r0 = blocks(lanes, 0, px.STREAM_RESET, 0).astype(np.uint64) & np.uint64(31)   # reset() at t = 0: first two accepted fields
+        ok = r0 <= 28
+        first = np.argmax(ok, axis=1)
+        ok2 = ok.copy(); ok2[np.arange(len(lanes)), first] = False
+        second = np.argmax(ok2, axis=1)
+        both = ok.sum(axis=1) >= 2
+        same = both & (r0[np.arange(len(lanes)), first] == r0[np.arange(len(lanes)), second])
+        acc = sum((((W >> np.uint64(5 * i)) & np.uint64(31)) <= 28).astype(np.int64) for i in range(6))
+        for i in np.nonzero(same & (acc < 2))[0]:
+            if len(slow) < n_slow:
+                slow.append(int(lanes[i]))
+        for i in np.nonzero(both & ~same & ((W >> np.uint64(5)) == thr_hi))[0]:
+            if len(tie) < n_tie:
+                tie.append(int(lanes[i]))
+        lane += CHUNK
+        if (lane // CHUNK) % 8 == 0:
+            print("searched", lane, "slow", len(slow), "ties", len(tie), flush=True)
+    lanes = slow + tie
+    tr = h.trace_mode_b("tag", {}, SEED, lanes, np.full((len(lanes), 1), 4, np.int64), t0=0)
+    assert tr["done"][: len(slow), 0].all() and not tr["done"][len(slow):, 0].any()
+    np.savez_compressed(os.path.join(HERE, "ties_tag.npz"), seed=np.int64(SEED), lanes=np.array(lanes, np.int64),
+                        n_slow=np.int64(len(slow)), state0=tr["state0"], ob=tr["ob"][:, 0], reward=tr["reward"][:, 0],
+                        done=tr["done"][:, 0], state_pre=tr["state_pre"][:, 0], state=tr["state"][:, 0])
+    print("tag: slow auto-resets at lanes", slow, "flight ties at lanes", tie)
+
+
 if __name__ == "__main__":
-    if "--network" in sys.argv:
+    if "--tag" in sys.argv:
+        main_tag()
+    elif "--network" in sys.argv:
         main_network()
     elif "--auto" in sys.argv:
         main_auto()

@@ -629,8 +629,8 @@ def test_ragged_batch_on_the_pooled_path(oracle_lib, env, kw):
 
 def test_tag_pooled_resets_including_the_rejection_fallback(oracle_lib):
     """Every lane of a 2^18-lane Tag batch tags its opponent in the same step, so all of them start a new episode
-    inside the pooled pass: most resets come from the four words of the pooled RESET block, the lanes whose
-    masked-rejection draws run past that block (a few in a thousand) take the general path.  All against the oracle."""
+    inside the pooled pass: the resets read the 5-bit fields of the lanes' words of the pooled quad blocks (ABI 13; the lanes
+    whose masked-rejection draws run past the six fields are pinned by test_tag_quad_word_rare_paths).  All against the oracle."""
     n, seed, lane0 = 1 << 18, 99, 1 << 19
     e = make_env("tag", {}, batch_size=n, seed=seed, lane_offset=lane0)
     e.reset()
@@ -645,11 +645,32 @@ def test_tag_pooled_resets_including_the_rejection_fallback(oracle_lib):
     assert bool(done.all()) and done_o.all()
     assert np.array_equal(np_(ob), ob_o) and np.array_equal(np_(rew), rew_o)
     assert np.array_equal(np_(e.state).view(np.uint32), st)
-    # the fallback was exercised: some lanes' first four RESET words hold fewer than two accepted draws
+    # rejections were exercised: some lanes' quad word has a field above 28 among the first two
     from oracle import philox_ref as px
     lanes = np.arange(lane0, lane0 + 4096)
-    acc = np.array([(px.stream_words(seed, int(l), t, px.STREAM_RESET, 4) & 31 <= 28).sum() for l in lanes])
-    assert (acc < 2).sum() > 0
+    rej = np.array([any(((int(px.tag_step_words(seed, int(l), t)[0]) >> (5 * k)) & 31) > 28 for k in range(2)) for l in lanes])
+    assert rej.sum() > 0
+
+
+def test_tag_quad_word_rare_paths():
+    """Fixture ties_tag.npz (the reference's own results, tests/golden/find_ties.py --tag) on the device: auto-resets whose
+    draws run past the quad word's six fields, flights decided by the double's low word — through the one-lane-per-thread
+    step kernel (n = 4) and the pooled two-lanes-per-thread one (2^18 lanes)."""
+    import os
+    from conftest import GOLDEN
+    g = dict(np.load(os.path.join(GOLDEN, "ties_tag.npz")))
+    seed = int(g["seed"])
+    for i, lane in enumerate(g["lanes"]):
+        lane = int(lane)
+        for n in (4, 1 << 18):
+            base = lane & ~3 if n == 4 else max(0, (lane & ~3) - (n // 2))
+            col = lane - base
+            e = make_env("tag", {}, batch_size=n, seed=seed, lane_offset=base)
+            e.reset()
+            assert np.array_equal(np_(e.decode_state()[col]), g["state0"][i]), (lane, n)
+            ob, rew, done, _ = e.step(torch.full((n,), 4, dtype=torch.int32, device="cuda"))
+            assert (int(ob[col]), float(rew[col]), int(done[col])) == (int(g["ob"][i]), float(g["reward"][i]), int(g["done"][i])), (lane, n)
+            assert np.array_equal(np_(e.decode_state()[col]), g["state"][i]), (lane, n)
 
 
 def test_split_layout_ties():

@@ -276,6 +276,31 @@ def test_auto_reset_ties_oracle(oracle_lib):
                for l in g["lanes"])
 
 
+def test_tag_quad_word_rare_paths_oracle(oracle_lib):
+    """Tag with one opponent: a flight and the auto-reset after a successful TAG read the lane's word of the quad's STEP block
+    (oracle/philox_ref.py tag_step_words / tag_auto_reset_words).  Fixture ties_tag.npz (tests/golden/find_ties.py --tag: the
+    reference): lanes whose auto-reset's rejection draws run past the word's six fields into stream RESET, and lanes whose
+    flight is decided by the double's low word."""
+    g = dict(np.load(os.path.join(GOLDEN, "ties_tag.npz")))
+    o = oracle_lib.OracleEnv("tag")
+    seed, n_slow = int(g["seed"]), int(g["n_slow"])
+    from oracle import philox_ref as px
+    from gym_pomdp_amd import tables
+    for i, lane in enumerate(g["lanes"]):
+        lane = int(lane)
+        st = o.new_state(1)
+        o.batch_reset(st, seed, lane, 0)
+        assert np.array_equal(o.batch_compact(st)[0], g["state0"][i])
+        ob, rew, done, _ = o.batch_step(st, [4], seed, lane, 1)
+        assert (int(ob[0]), float(rew[0]), int(done[0])) == (int(g["ob"][i]), float(g["reward"][i]), int(g["done"][i])), lane
+        assert np.array_equal(o.batch_compact(st)[0], g["state"][i]), lane
+        w = px.tag_step_words(seed, lane, 1)
+        if i < n_slow:
+            assert int(g["done"][i]) == 1 and sum(((int(w[0]) >> (5 * k)) & 31) <= 28 for k in range(6)) < 2
+        else:
+            assert int(g["done"][i]) == 0 and int(w[0]) >> 5 == tables.TAG_MOVE_THR >> 26
+
+
 def test_network_split_layout_ties_oracle(oracle_lib):
     """Network draws whose quad-shared top 16 bits equal the threshold's (fixture ties_network.npz from tests/golden/
     find_ties.py --network: one lane per draw index 0 .. 10), decided by the lane's own STEP_LO words."""
