@@ -89,6 +89,7 @@ struct TagEnv {
     // attempt i of the masked-rejection draws reads bits 5 i .. 5 i + 4 of W (i < 6), later attempts the lane's own RESET stream
     // from its first word on (4 x 10^-5 of the resets).  One block serves four lanes; reset() itself (pomdp_tag_reset) and
     // games with more opponents keep the sequential per-lane streams.
+    static constexpr int QUAD_WORD = 1;                                        // fused_impl.hip.h / planner.hip: the loops that time-share the block
     static __device__ __forceinline__ uint4 quad_block(const RngKey &key, uint32_t lane, uint32_t block)
     {
         return stream_block(key, lane >> 2, POMDP_STREAM_STEP, block);
@@ -284,6 +285,24 @@ struct TagEnv {
             const uint32_t W = elem(quad_block(key, lane, 0u), lane & 3u);
             flee_word(sh, p, st, f, W, [&]() { return elem(quad_block(key, lane, 1u), lane & 3u); });
         }
+    }
+    // the step and the auto-reset given the lane's word W of the quad's block (the loops that time-share it); games with more
+    // opponents (wave-uniform) take the per-lane streams and leave W unread
+    template <class RT>
+    static __device__ __forceinline__ void step_w(const Shared &sh, const Params &p, State &st, int a, const RngKey &key, uint32_t lane,
+                                                  uint32_t W, int &ob, RT &rew, int &done)
+    {
+        if (p.num_opponents != 1) { step(sh, p, st, a, key, lane, ob, rew, done); return; }
+        Flight f;
+        step_one_opponent_pre(sh, p, st, a, ob, rew, done, f);
+        flee_word(sh, p, st, f, W, [&]() { return elem(quad_block(key, lane, 1u), lane & 3u); });
+    }
+    static __device__ __forceinline__ void fresh_w(const Shared &sh, const Params &p, State &st, bool fresh, const RngKey &key,
+                                                   uint32_t lane, uint32_t W)
+    {
+        if (!fresh) return;
+        if (p.num_opponents == 1) auto_reset_word(p, st, W, key, lane);
+        else reset(sh, p, st, key, lane);
     }
     // tag.py:108-143 step, 201-207 move_opponent, 260-280 _admissable_actions
     template <class RT>

@@ -118,6 +118,20 @@ struct TigerEnv {
     {
         step_word(p, st, a, word(key, lane), [&]() { return elem(quad_block(key, lane, 1u), lane & 3u); }, ob, rew, done);
     }
+    // the interface of the loops that time-share the quad's block (one lane per thread: lane e of a quad computes the block of
+    // step s + e once per four steps and a 4 x 4 DPP transpose hands every lane its word of every step): the step and the
+    // auto-reset given the lane's word W
+    template <class RT>
+    static __device__ __forceinline__ void step_w(const Shared &, const Params &p, State &st, int a, const RngKey &key, uint32_t lane,
+                                                  uint32_t W, int &ob, RT &rew, int &done)
+    {
+        step_word(p, st, a, W, [&]() { return elem(quad_block(key, lane, 1u), lane & 3u); }, ob, rew, done);
+    }
+    static __device__ __forceinline__ void fresh_w(const Shared &, const Params &, State &st, bool fresh, const RngKey &, uint32_t, uint32_t W)
+    {
+        if (fresh) st.w = st.rs != NO_RS ? st.rs : (W & 1u);
+        st.rs = NO_RS;
+    }
 };
 
 } // namespace pomdp

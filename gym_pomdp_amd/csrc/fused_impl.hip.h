@@ -137,6 +137,19 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
                 }
                 else Env::step_with_H(sh, p, st[j], valid[j] ? a_cur[j] : 0, key, glane[j], H, o[j], r[j], d[j]);
             }
+            else if constexpr (quad_policy && quad_word_env<Env>::value) {
+                // Tiger, Tag: ONE word per lane-step from the quad's STEP block, time-shared the same way; the auto-reset of a
+                // done lane reads the same word (fresh_w below)
+                if ((s & 3) == 0) {
+                    const uint64_t te = t0 + (uint64_t)s + (uint64_t)(glane[0] & 3u);
+                    RngKey ke = key0;
+                    ke.t_lo = (uint32_t)te; ke.t_hi = (uint32_t)(te >> 32);
+                    sq = quad_transpose4(Env::quad_block(ke, glane[0], 0u), glane[0] & 3u);
+                }
+                const int sj = s & 3;                                            // wave-uniform selects
+                const uint32_t W = sj == 0 ? sq.x : sj == 1 ? sq.y : sj == 2 ? sq.z : sq.w;
+                Env::step_w(sh, p, st[j], valid[j] ? a_cur[j] : 0, key, glane[j], W, o[j], r[j], d[j]);
+            }
             else if constexpr (quad_policy && quad_words_of<Env>::value == 3) {
                 // the step's quad-shared blocks, time-shared: lane e of a quad computes the three blocks of step s + e once per
                 // four steps, three 4 x 4 transposes hand every lane its own word of each block of each step
@@ -172,6 +185,8 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
             } else if constexpr (Env::QUAD_SENSOR) {                         // RockSample: this lane's RESET word of step s
                 const uint32_t rword = sj == 0 ? rq.x : sj == 1 ? rq.y : sj == 2 ? rq.z : rq.w;
                 st[0].s = fresh[0] ? Env::fresh_state(p, rword, key, glane[0]) : st[0].s;
+            } else if constexpr (quad_word_env<Env>::value) {
+                Env::fresh_w(sh, p, st[0], fresh[0], key, glane[0], sj == 0 ? sq.x : sj == 1 ? sq.y : sj == 2 ? sq.z : sq.w);
             } else {
                 Fin::resets_only(sh, p, st, fresh, key, glane);
             }
@@ -781,9 +796,6 @@ template <class Env, class = void> struct quad_tab : std::false_type {};
 template <class Env> struct quad_tab<Env, std::enable_if_t<Env::QUAD_TAB>> : std::true_type {};
 template <class Env, class = void> struct quad_fused : std::false_type {};
 template <class Env> struct quad_fused<Env, std::enable_if_t<Env::QUAD_FUSED>> : std::true_type {};
-
-template <class Env, class = void> struct quad_word_env : std::false_type {};
-template <class Env> struct quad_word_env<Env, std::enable_if_t<(Env::QUAD_WORD > 0)>> : std::true_type {};
 
 template <class Env, class L = Columns>
 __global__ __launch_bounds__(BLOCK) void steps_quad_generic_kernel(uint32_t *__restrict__ state, int32_t *__restrict__ action,

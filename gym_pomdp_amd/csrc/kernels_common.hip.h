@@ -377,6 +377,10 @@ template <class Fin> struct quad_policy_of<Fin, std::enable_if_t<Fin::QUAD_POLIC
 template <class Env, class = void> struct quad_words_of { static constexpr int value = 0; };
 template <class Env> struct quad_words_of<Env, std::enable_if_t<(Env::QUAD_WORDS > 0)>> { static constexpr int value = Env::QUAD_WORDS; };
 
+// envs whose step (and auto-reset) reads ONE word of a quad-shared STEP block (Tiger, Tag: Env::quad_block, step_w, fresh_w)
+template <class Env, class = void> struct quad_word_env : std::false_type {};
+template <class Env> struct quad_word_env<Env, std::enable_if_t<(Env::QUAD_WORD > 0)>> : std::true_type {};
+
 struct NoTab {};
 // the (position, action) table of a table-driven launch: RockEnv::RecTab, whose lane step (step_rec) yields the lane's
 // packed record and its new state in one go
@@ -411,14 +415,16 @@ extern thread_local uint32_t tl_flag_value;
 // lane per thread (0.66 against 0.72).  StochasticRock has no pooled loop and keeps 2^19.
 // Round 4: BattleShip's quad loop from 2^16 lanes (feed2 halved what its board pool costs, the one-lane loop builds boards on
 // the spot with the wave-cooperative builder: 2^16 / 2^17 lanes 0.995 / 1.036 against 1.074 / 1.209 us per step).
-// Round 5: Tiger's quad loop from 2^18 lanes (ABI 13: the quad's STEP block is the thread's four words; 2^18 / 2^17 lanes 0.531 /
-// 0.529 against 0.561 / 0.385 us per step with one lane per thread).
+// Round 5 (ABI 13: Tiger's and Tag's steps read one word of the quad's STEP block): the one-lane loops time-share that block
+// like the policy's, the quad loops have it thread-local — Tiger 2^18 / 2^19 lanes 0.382 / 0.811 us per step with one lane
+// per thread against 0.522 / 0.650 with a quad, Tag 2^18 0.765 against 0.919 (2^19: the pooled two-lane loop 1.74, the quad
+// loop 1.08): the gates stay.
 // POMDP_QUAD_MIN_LANES overrides all of them at build time for same-box A/B runs (tools/ab_build.sh lib ... -D...).
 #ifdef POMDP_QUAD_MIN_LANES
 constexpr int64_t QUAD_MIN_ROCK = POMDP_QUAD_MIN_LANES, QUAD_MIN_STOCHROCK = POMDP_QUAD_MIN_LANES, QUAD_MIN_TAG = POMDP_QUAD_MIN_LANES,
                   QUAD_MIN_GENERIC = POMDP_QUAD_MIN_LANES, QUAD_MIN_NETWORK = POMDP_QUAD_MIN_LANES, QUAD_MIN_BATTLESHIP = POMDP_QUAD_MIN_LANES;
 #else
-constexpr int64_t QUAD_MIN_ROCK = 3 << 18, QUAD_MIN_STOCHROCK = 1 << 19, QUAD_MIN_TAG = 1 << 19, QUAD_MIN_GENERIC = 1 << 18,
+constexpr int64_t QUAD_MIN_ROCK = 3 << 18, QUAD_MIN_STOCHROCK = 1 << 19, QUAD_MIN_TAG = 1 << 19, QUAD_MIN_GENERIC = 1 << 19,
                   QUAD_MIN_NETWORK = 1 << 19, QUAD_MIN_BATTLESHIP = 1 << 16;
 #endif
 

@@ -504,7 +504,7 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(const typename Env::Para
     for (int base = 0; base < depth && live_wave; base += 4) {
         const uint4 pw = stream_block(key0, lane, POMDP_STREAM_ROLLOUT, (uint32_t)(base >> 2));
         uint4 sq = make_uint4(0, 0, 0, 0);
-        if constexpr (Env::QUAD_SENSOR) {            // this lane's share: the quad's STEP block of step base + (lane & 3)
+        if constexpr (Env::QUAD_SENSOR || quad_word_env<Env>::value) {   // this lane's share: the quad's STEP block of step base + (lane & 3)
             const uint64_t te = t0 + (uint64_t)base + (uint64_t)(lane & 3u);
             RngKey ke = key0;
             ke.t_lo = (uint32_t)te; ke.t_hi = (uint32_t)(te >> 32);
@@ -538,6 +538,8 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(const typename Env::Para
                     d2 = (int)(rec >> 24);
                 }
                 else Env::step_with_H(sh, p, nx, a, key, lane, comp<J>(sq), o2, r, d2);
+            } else if constexpr (quad_word_env<Env>::value) {          // Tiger, Tag: the lane's word of the quad's block
+                Env::step_w(sh, p, nx, a, key, lane, comp<J>(sq), o2, r, d2);
             } else {
                 Env::step(sh, p, nx, a, key, lane, o2, r, d2);
             }

@@ -290,7 +290,7 @@ def test_bench_self_launches_two_ranks_on_the_one_gpu():
 
 def test_launcher_picks_the_documented_kernel_per_shard_size():
     """pomdp_last_fused_kernel() after a fused call: the quad-per-thread loops from the shard sizes DESIGN.md §5 lists
-    (RockSample 3 * 2^18, StochasticRock 2^19, Tag 2^19, Tiger 2^18, Network 2^19, BattleShip 2^16), the one- / two-lanes-per-thread
+    (RockSample 3 * 2^18, StochasticRock 2^19, Tag 2^19, Tiger 2^19, Network 2^19, BattleShip 2^16), the one- / two-lanes-per-thread
     loops below, and the arithmetic lane step for launches shorter than 16 steps."""
     from gym_pomdp_amd import _native
     L = _native.lib()
@@ -301,7 +301,7 @@ def test_launcher_picks_the_documented_kernel_per_shard_size():
             ("rock", {}, (1 << 19) + 4, 64, "steps_kernel<RockEnv<1>, 2, false>"),
             ("tag", {}, 1 << 19, 64, "tag_steps_quad_kernel<true>"), ("tag", {}, 1 << 19, 8, "tag_steps_quad_kernel<false>"),
             ("tag", {}, 1 << 18, 64, "steps_kernel<TagEnv, 1, true>"), ("tag", dict(num_opponents=2), 1 << 20, 64, "steps_kernel<TagEnv, 2, true>"),
-            ("tiger", {}, 1 << 18, 64, "steps_quad_generic_kernel<TigerEnv>"), ("tiger", {}, 1 << 17, 64, "steps_kernel<TigerEnv, 1, true>"),
+            ("tiger", {}, 1 << 19, 64, "steps_quad_generic_kernel<TigerEnv>"), ("tiger", {}, 1 << 18, 64, "steps_kernel<TigerEnv, 1, true>"),
             ("network", {}, 1 << 19, 64, "network_steps_quad_kernel<2, Columns, true>"), ("network", dict(n_machines=16, problem_type=1), 1 << 19, 64, "network_steps_quad_kernel<2, Columns, false>"), ("network", {}, 1 << 18, 64, "steps_kernel<NetworkEnv, 1, true>"),
             ("battleship", {}, 1 << 16, 64, "battleship_steps_quad_kernel<BattleShipEnv<1>>"), ("battleship", {}, 1 << 15, 64, "steps_kernel<BattleShipEnv<1>, 1, true>"), ("stochrock", {}, 1 << 19, 64, "steps_quad_kernel<StochasticRockEnv<1>>"),
             ("stochrock", {}, 1 << 18, 64, "steps_kernel<StochasticRockEnv<1>, 1, true>")]

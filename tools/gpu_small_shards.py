@@ -21,6 +21,8 @@ def one(lib_path):
     from gym_pomdp_amd import _native
     if lib_path:
         _native.LIB_PATH = lib_path
+    if os.environ.get("AB_ABI"):        # an older revision's library with the same struct layouts (tools/ab_build.sh rev)
+        _native.ABI_VERSION = int(os.environ["AB_ABI"])
     import gym_pomdp_amd as gpa
     L = _native.lib()
     print("library: %s" % _native.LIB_PATH)
