@@ -839,7 +839,9 @@ def main():
     extras = world == 1 and not args.no_extras and collect
     if extras:
         layouts_block = {}
-        for lay in ("columns", "blocked", "packed", "narrow", "packed_plus_decode"):
+        # (the 4-byte sinks first: the 13-byte layouts are store-heavy launches under which the clock drops to 2.1-2.3 GHz, and an
+        #  instruction-bound launch measured right after them reads 10-15 % slower than it does on its own)
+        for lay in ("packed", "narrow", "columns", "blocked", "packed_plus_decode"):
             if lay == layout:
                 layouts_block[lay] = {"value": n * args.steps / elapsed, "ms_per_step": elapsed / args.steps * 1e3, "kernel": fused_kernel,
                                       "kernel_ms": kern_ms, "bytes_per_lane_step": rf["alg_bytes"],
