@@ -46,16 +46,9 @@ def make(id, **kwargs):
 
 
 def _register_with_gym():
-    for pkg in ("gym", "gymnasium"):
-        try:
-            reg = importlib.import_module(pkg + ".envs.registration")
-        except Exception:  # noqa: BLE001 - not installed
-            continue
-        for env_id, entry in registry.items():
-            try:
-                reg.register(id=env_id, entry_point=entry)
-            except Exception:  # noqa: BLE001 - already registered (e.g. by the reference)
-                pass
+    """gym_pomdp/__init__.py:7-41 for the batched classes: every gym / gymnasium that is importable gets the ids (compat.py)."""
+    from . import compat
+    return compat.register_ids(registry)
 
 
 _register_with_gym()

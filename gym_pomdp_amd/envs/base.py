@@ -22,7 +22,7 @@ import os
 import numpy as np
 import torch
 
-from .. import _native
+from .. import _native, compat
 from ..spaces import Discrete
 
 
@@ -66,9 +66,13 @@ def staggered(specs, device):
     return [pool[o:o + nb].view(dtype).view(shape) for (o, nb), (shape, dtype) in zip(offs, specs)]
 
 
-class BatchedEnv(object):
-    metadata = {"render.modes": ["ansi"]}
+class BatchedEnv(compat.EnvBase):
+    """A `gym.Env` when an old-API gym is importable (compat.EnvBase), so that `gym.make()`'s wrappers and type checks
+    accept it; either way it carries what `gym.make` touches: `unwrapped`, `spec`, `np_random`, `render_mode`, `metadata`."""
+    metadata = {"render.modes": ["ansi"], "render_modes": ["ansi"]}      # gym <= 0.21 / gym >= 0.22 spelling
     reward_range = (-float("inf"), float("inf"))
+    spec = None               # gym.make: `env.unwrapped.spec = spec` (gym/envs/registration.py, EnvSpec.make)
+    render_mode = None
     env_name = None           # "rock", "tag", ... (C-ABI entry-point infix)
     reward_dtype = torch.int32
 
@@ -156,6 +160,24 @@ class BatchedEnv(object):
         self._info = {"state": self._state}
 
     @property
+    def unwrapped(self):
+        """gym.Env.unwrapped: the env under every wrapper — this object."""
+        return self
+
+    @property
+    def np_random(self):
+        """gym.Env.np_random (gym >= 0.22 keeps one per env).  The kernels never draw from it — their words are Philox
+        streams of (seed, lane, t) — it exists for callers and wrappers that expect the attribute."""
+        rng = self.__dict__.get("_np_random")
+        if rng is None:
+            rng = self.__dict__["_np_random"] = np.random.RandomState(getattr(self, "_seed", 0) & 0xFFFFFFFF)
+        return rng
+
+    @np_random.setter
+    def np_random(self, value):
+        self.__dict__["_np_random"] = value
+
+    @property
     def auto_reset(self):
         return self._auto_reset
 
@@ -179,6 +201,7 @@ class BatchedEnv(object):
         if self.batch_size == 1:
             self._scalar_args.seed = self._seed
         self._t = 0
+        self.__dict__.pop("_np_random", None)
         return [self._seed]
 
     @property
@@ -194,8 +217,14 @@ class BatchedEnv(object):
         """hipStream_t of torch's current stream on this env's device (the raw handle: no Stream object is built)."""
         return _raw_stream(self._dev_index)
 
-    def reset(self):
-        """All lanes start a new episode.  Returns ob: int32[N] tensor (python int if batch_size == 1)."""
+    def reset(self, *, seed=None, options=None, return_info=False):
+        """All lanes start a new episode.  Returns ob: int32[N] tensor (python int if batch_size == 1).
+        The reference's reset() takes no arguments; the keywords are what gym 0.22-0.25's `gym.make` wrappers pass through
+        (`seed`: seed(seed) first; `return_info`: (ob, info) instead of ob; `options` is accepted and ignored)."""
+        if seed is not None:
+            self.seed(seed)
+        if return_info:
+            return self.reset(), self._info
         t = self._t
         self._t += 1
         if self.batch_size == 1 and not self._dev_flags_used and _current_device() == self._dev_index:

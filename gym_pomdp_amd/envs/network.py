@@ -67,10 +67,10 @@ class NetworkEnv(BatchedEnv):
         a = self.synthetic_actions()
         return int(a.item()) if self.batch_size == 1 else a
 
-    def reset(self):
+    def reset(self, **kwargs):
         self.last_action = self._n_machines * 2       # network.py:65
         self._server = 0                              # network.py:68
-        return super().reset()
+        return super().reset(**kwargs)
 
     def render(self, mode="ansi", close=False, lane=0):
         """network.py:116-120: prints `N: <machines up>, S: <server>\t<action>` for one lane (the reference's only

@@ -1,6 +1,9 @@
-"""`gym.spaces.Discrete` duck type (the only space the reference uses:
-rock.py:113-114, tag.py:92-94, battleship.py:69-70, tiger.py:52-54, network.py:33-34)."""
+"""`gym.spaces.Discrete` (the only space the reference uses: rock.py:113-114, tag.py:92-94, battleship.py:69-70,
+tiger.py:52-54, network.py:33-34): gym's own class when an old-API `gym` is importable — gym's wrappers and env checker
+test `isinstance(env.action_space, gym.spaces.Space)` — and the duck type below otherwise."""
 import numpy as np
+
+from . import compat
 
 np_random = np.random.RandomState()
 
@@ -9,7 +12,7 @@ def seed(s=None):
     np_random.seed(s)
 
 
-class Discrete(object):
+class _Discrete(object):
     def __init__(self, n):
         assert n >= 0
         self.n = int(n)
@@ -36,4 +39,7 @@ class Discrete(object):
         return "Discrete(%d)" % self.n
 
     def __eq__(self, other):
-        return isinstance(other, Discrete) and self.n == other.n
+        return isinstance(other, _Discrete) and self.n == other.n
+
+
+Discrete = compat.GymDiscrete if compat.GymDiscrete is not None else _Discrete

@@ -14,7 +14,13 @@ def seed(s=None):
     np_random.seed(s)
 
 
-class Discrete(object):
+class Space(object):
+    """base class gym's wrappers and env checker test spaces against"""
+    shape = None
+    dtype = None
+
+
+class Discrete(Space):
     def __init__(self, n):
         self.n = n
         self.shape = ()
