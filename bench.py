@@ -617,6 +617,61 @@ def quick_rollout_config(args, gpa, dev, env_key, roots_n, sims, depth, seed):
                          "counters_stale": v["counters_stale"] if v else None}}
 
 
+def quick_plan_config(args, gpa, dev, env_key, roots_n, sims, depth, seed):
+    """BASELINE.json configs[4] as the caller runs it — "a POMCP-style 1024-simulation rollout PER REAL STEP": every timed step
+    is env.plan_step(): the fused rollout launch from the roots' live state, the on-device reduction of each root's
+    simulations to action values (pomdp_plan_reduce: visits / mean return by first action, argmax) and the real step of the
+    roots with the chosen actions (pomdp_<env>_step).  20 planned steps timed by wall clock and by HIP events after 3 untimed
+    ones; the reduction and the real step are then timed on their own (HIP events) for their share."""
+    env_id, kwargs, label, _, _ = WORKLOADS[env_key]
+    e = gpa.make(env_id, batch_size=roots_n, device=dev, seed=seed, reuse_buffers=True, auto_reset=True, **kwargs)
+    e.reset()
+    for _ in range(4):
+        e.step(e.synthetic_actions())
+    out = None
+    for _ in range(3):
+        out = e.plan_step(depth, sims_per_root=sims, out=out)[4]
+    torch.cuda.synchronize(dev)
+    k = 20
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(k):
+        e.plan_step(depth, sims_per_root=sims, out=out)
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    step_ms = ev0.elapsed_time(ev1) / k
+    from gym_pomdp_amd import _native
+    import ctypes
+    po = ctypes.byref(out["_plan_out"])
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    ev0.record()
+    for _ in range(k):
+        _native.lib().pomdp_plan_reduce(out["sim_ret"].data_ptr(), out["sim_first_action"].data_ptr(), roots_n, sims, e.action_space.n, po, stream)
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    reduce_ms = ev0.elapsed_time(ev1) / k
+    best = out["best"].clone()
+    ev0.record()
+    for _ in range(k):
+        e.step(best)
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    real_ms = ev0.elapsed_time(ev1) / k
+    visited = float((out["visits"] > 0).sum().item()) / roots_n
+    del e, out
+    torch.cuda.empty_cache()
+    return {"workload": "%s: %d roots, each real step planned by %d random rollouts of <= %d steps (uniform over _generate_legal()), "
+                        "action values reduced on the device, roots stepped with the argmax" % (label, roots_n, sims, depth),
+            "value": roots_n * k / wall, "unit": "planned real env-steps/s", "ms_per_planned_step": wall / k * 1e3,
+            "simulations_per_s": roots_n * sims * k / wall, "kernel_ms": step_ms,
+            "kernels": "rollout_kernel<%s> + plan_reduce_kernel + the env's step kernel" % env_key,
+            "share": {"rollout": max(0.0, step_ms - reduce_ms - real_ms) / step_ms, "reduce": reduce_ms / step_ms, "real_step": real_ms / step_ms},
+            "reduce_kernel_ms": reduce_ms, "reduce_hbm_frac": 12.0 * roots_n * sims / (reduce_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "real_step_ms": real_ms, "visited_actions_per_root": visited}
+
+
 class StepWorkload(object):
     """K consecutive steps of one env shard under the synthetic policy, every buffer allocated up front."""
 
@@ -854,6 +909,7 @@ def main():
             "tag": quick_step_config(args, gpa, _native, cp, dev, "tag", 1 << 20, 0, seeds[0], layout, k=512),            # configs[2]
             "battleship": quick_step_config(args, gpa, _native, cp, dev, "battleship", 1 << 19, 0, seeds[0], layout, k=512),   # configs[3]: 2^22 / 8 GPUs
             "rollout_rock15": quick_rollout_config(args, gpa, dev, "rock15", 2048, 1024, 64, seeds[0]),                 # configs[4]: 2^24 / 8 GPUs
+            "plan_rock15": quick_plan_config(args, gpa, dev, "rock15", 2048, 1024, 64, seeds[0]),                      # ... as planned real steps
             # the headline workload reduced on the fly to what the reference's callers keep of it (network.py:175-191): no trajectory
             "returns_only": quick_step_config(args, gpa, _native, cp, dev, "rock", 1 << 20, 0, seeds[0], "returns", k=512)}
 

@@ -21,7 +21,7 @@ HEADERS = ["kernels_common.hip.h", "traj_out.hip.h", "step_impl.hip.h", "fused_i
            "envs/rock.hip.h", "envs/tag.hip.h", "envs/battleship.hip.h", "envs/tiger.hip.h", "envs/network.hip.h"]
 SOURCES = [os.path.join(_PKG, "csrc", f) for f in UNITS + HEADERS]
 HEADER = os.path.join(_REPO, "include", "pomdp_hip.h")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 POMDP_AUTO_RESET = 1
 POMDP_FUSE_STEPS = 2
@@ -36,7 +36,7 @@ SYMBOLS = [
     "pomdp_rock_reset", "pomdp_rock_step", "pomdp_tag_reset", "pomdp_tag_step",
     "pomdp_battleship_reset", "pomdp_battleship_step", "pomdp_tiger_reset", "pomdp_tiger_step",
     "pomdp_network_reset", "pomdp_network_step", "pomdp_step", "pomdp_step_sync", "pomdp_reset_sync", "pomdp_stream_sync", "pomdp_synthetic_actions", "pomdp_philox_blocks",
-    "pomdp_rollout_synthetic", "pomdp_collect_synthetic", "pomdp_collect", "pomdp_collect_layout", "pomdp_collect_traj", "pomdp_packed_reward", "pomdp_decode_packed", "pomdp_collect_returns", "pomdp_fuse_max", "pomdp_fuse_steps", "pomdp_legal_actions", "pomdp_rollout", "pomdp_compute_prob",
+    "pomdp_rollout_synthetic", "pomdp_collect_synthetic", "pomdp_collect", "pomdp_collect_layout", "pomdp_collect_traj", "pomdp_packed_reward", "pomdp_decode_packed", "pomdp_collect_returns", "pomdp_fuse_max", "pomdp_fuse_steps", "pomdp_legal_actions", "pomdp_rollout", "pomdp_plan", "pomdp_plan_reduce", "pomdp_compute_prob",
     "pomdp_rock_belief_reset", "pomdp_rock_belief_refresh", "pomdp_rock_belief_update", "pomdp_rock_select_target", "pomdp_history_clear",
     "pomdp_history_append", "pomdp_preferred_actions", "pomdp_pick_actions", "pomdp_heuristic_steps",
 ]
@@ -97,6 +97,11 @@ class HistoryPtrs(C.Structure):     # pomdp_history: device pointers + the windo
 
 class ReturnStats(C.Structure):     # pomdp_return_stats
     _fields_ = [("discount", C.c_double), ("acc", C.c_void_p), ("cnt", C.c_void_p), ("pitch", C.c_int64)]
+
+
+class PlanOut(C.Structure):         # pomdp_plan_out
+    _fields_ = [("q", C.c_void_p), ("visits", C.c_void_p), ("best", C.c_void_p), ("value", C.c_void_p), ("stride", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class Returns(C.Structure):         # pomdp_returns
@@ -212,6 +217,10 @@ def lib():
     L.pomdp_compute_prob.argtypes = [ci, vp, vp, vp, vp, vp, i64, vp]
     L.pomdp_rollout.restype = ci
     L.pomdp_rollout.argtypes = [ci, vp, vp, i64, i64, ci, C.c_double, ci, u64, u32, u64, vp, vp, vp, vp, vp, vp]
+    L.pomdp_plan.restype = ci
+    L.pomdp_plan.argtypes = [ci, vp, vp, i64, i64, ci, C.c_double, ci, u64, u32, u64, vp, vp, vp, vp]
+    L.pomdp_plan_reduce.restype = ci
+    L.pomdp_plan_reduce.argtypes = [vp, vp, i64, i64, ci, vp, vp]
     L.pomdp_rock_belief_reset.restype = ci
     L.pomdp_rock_belief_reset.argtypes = [vp, vp, vp, i64, vp]
     L.pomdp_rock_belief_refresh.restype = ci

@@ -302,22 +302,6 @@ int pomdp_synthetic_actions(int32_t *action, int64_t n, uint64_t seed, uint32_t 
     return (int)hipGetLastError();
 }
 
-// the env's action count from its params; 0 = unknown env
-static uint32_t env_action_count(int env, const void *params)
-{
-    switch (env) {
-    case POMDP_ENV_ROCK: return 5u + (uint32_t)((const pomdp_rock_params *)params)->num_rocks;
-    case POMDP_ENV_TAG: return 5u;
-    case POMDP_ENV_BATTLESHIP: {
-        const pomdp_battleship_params *p = (const pomdp_battleship_params *)params;
-        return (uint32_t)(p->x_size * p->y_size);
-    }
-    case POMDP_ENV_TIGER: return 3u;
-    case POMDP_ENV_NETWORK: return 2u * (uint32_t)((const pomdp_network_params *)params)->n_machines + 1u;
-    default: return 0u;
-    }
-}
-
 // params and buffers of the C-side episode loops, checked before anything is enqueued
 static int check_driver_args(int env, const void *params, const void *state, const void *action, const void *ob,
                              const void *reward, const void *done, int64_t n, uint32_t lane0, int64_t k_steps)

@@ -514,6 +514,22 @@ POMDP_EACH_ENV(POMDP_FUSED_LAUNCHER, extern)
 
 using namespace pomdp;
 
+// the env's action count from its params; 0 = unknown env
+static inline uint32_t env_action_count(int env, const void *params)
+{
+    switch (env) {
+    case POMDP_ENV_ROCK: return 5u + (uint32_t)((const pomdp_rock_params *)params)->num_rocks;
+    case POMDP_ENV_TAG: return 5u;
+    case POMDP_ENV_BATTLESHIP: {
+        const pomdp_battleship_params *p = (const pomdp_battleship_params *)params;
+        return (uint32_t)(p->x_size * p->y_size);
+    }
+    case POMDP_ENV_TIGER: return 3u;
+    case POMDP_ENV_NETWORK: return 2u * (uint32_t)((const pomdp_network_params *)params)->n_machines + 1u;
+    default: return 0u;
+    }
+}
+
 // Resolve (env kind, params) to the env type the kernels are instantiated for, validate the params against what the
 // packed layouts support, and call f(EnvTag<Env>{}, typed params).
 template <class E> struct EnvTag { using Env = E; };

@@ -559,10 +559,82 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(const typename Env::Para
     }
     if (in_range) {
         ret[i] = acc;
-        n_steps[i] = k;
         first_action[i] = first;
-        last_ob[i] = o;
-        terminated[i] = (uint8_t)d;
+        if (n_steps) n_steps[i] = k;                          // kernel arguments: wave-uniform
+        if (last_ob) last_ob[i] = o;
+        if (terminated) terminated[i] = (uint8_t)d;
+    }
+}
+
+// The planning step's reduction (include/pomdp_hip.h: pomdp_plan): one workgroup per root turns the root's simulations into
+// visits / mean return per first action and picks the best one.  The order of the float64 additions is part of the
+// contract — chunks of 64 simulations by index, simulation-index order within a chunk, chunk order across chunks, each sum
+// starting from +0.0 — so the layout follows it: the root's returns and first actions are staged through LDS a tile of
+// PLAN_TILE = 16 chunks at a time; wave w sums chunks w, w + 4, ... with lane a owning action a (every lane reads the
+// same LDS address: a broadcast, no bank conflict; an addition of nothing leaves the sum alone, which is what skipping the
+// simulation means, and a partial sum that started at +0.0 is never -0.0), the per-chunk sums go through LDS, and thread a
+// adds them in chunk order into its running total across tiles.  No atomics, no cross-workgroup traffic.
+constexpr int PLAN_TILE = 16 * POMDP_PLAN_CHUNK;
+__global__ __launch_bounds__(BLOCK) void plan_reduce_kernel(const double *__restrict__ ret, const int32_t *__restrict__ first_action,
+                                                            int64_t sims, int n_act, pomdp_plan_out out)
+{
+#pragma clang fp contract(off)
+    __shared__ double r_lds[PLAN_TILE];
+    __shared__ uint8_t a_lds[PLAN_TILE];                    // 255: the simulation took no step (or an action out of range)
+    __shared__ double part[PLAN_TILE / POMDP_PLAN_CHUNK][BLOCK];
+    __shared__ uint8_t cnt[PLAN_TILE / POMDP_PLAN_CHUNK][BLOCK];   // <= 64 per chunk
+    __shared__ double q_lds[BLOCK];
+    __shared__ int32_t n_lds[BLOCK];
+    const int64_t root = blockIdx.x;
+    const int tid = (int)threadIdx.x, wv = tid >> 6, me = tid & 63;
+    const double *const rr = ret + root * sims;
+    const int32_t *const fa = first_action + root * sims;
+    double total = 0.0;                                      // thread a < n_act: action a
+    int32_t visits = 0;
+    for (int64_t base = 0; base < sims; base += PLAN_TILE) {
+        const int tile = (int)(sims - base < PLAN_TILE ? sims - base : PLAN_TILE);
+        for (int j = tid; j < tile; j += BLOCK) {
+            r_lds[j] = rr[base + j];
+            const int32_t f = fa[base + j];
+            a_lds[j] = (uint8_t)((uint32_t)f < (uint32_t)n_act ? f : 255);
+        }
+        __syncthreads();
+        const int n_chunks = (tile + POMDP_PLAN_CHUNK - 1) / POMDP_PLAN_CHUNK;
+        for (int c = wv; c < n_chunks; c += BLOCK / 64) {
+            const int j0 = c * POMDP_PLAN_CHUNK, j1 = j0 + POMDP_PLAN_CHUNK < tile ? j0 + POMDP_PLAN_CHUNK : tile;
+            for (int a = me; a < n_act; a += 64) {
+                double p = 0.0;
+                int k = 0;
+                for (int j = j0; j < j1; ++j) {
+                    const bool hit = (int)a_lds[j] == a;
+                    const double with = p + r_lds[j];
+                    p = hit ? with : p;
+                    k += (int)hit;
+                }
+                part[c][a] = p;
+                cnt[c][a] = (uint8_t)k;
+            }
+        }
+        __syncthreads();
+        if (tid < n_act)
+            for (int c = 0; c < n_chunks; ++c) { total = total + part[c][tid]; visits += (int32_t)cnt[c][tid]; }
+        __syncthreads();                                     // the next tile overwrites r_lds / part
+    }
+    if (tid < n_act) {
+        const double q = visits > 0 ? total / (double)visits : 0.0;
+        out.q[root * out.stride + tid] = q;
+        out.visits[root * out.stride + tid] = visits;
+        q_lds[tid] = q;
+        n_lds[tid] = visits;
+    }
+    __syncthreads();
+    if (tid == 0) {                                          // n_act <= 255 values: the first strict maximum among the visited actions
+        int b = -1;
+        double bq = 0.0;
+        for (int a = 0; a < n_act; ++a)
+            if (n_lds[a] > 0 && (b < 0 || q_lds[a] > bq)) { b = a; bq = q_lds[a]; }
+        out.best[root] = b;
+        if (out.value) out.value[root] = b >= 0 ? bq : 0.0;
     }
 }
 
@@ -591,7 +663,7 @@ static int launch_rollout(const typename Env::Params &p, const uint32_t *state, 
                           int depth, double discount, int flags, uint64_t seed, uint32_t lane0, uint64_t t0, double *ret,
                           int32_t *n_steps, int32_t *first_action, int32_t *last_ob, uint8_t *terminated, void *stream)
 {
-    if (!state || !ret || !n_steps || !first_action || !last_ob || !terminated || n_roots < 0 || sims < 1 || depth < 0 ||
+    if (!state || !ret || !first_action || n_roots < 0 || sims < 1 || depth < 0 ||
         bad_range(n_roots * sims, lane0) || (lane0 & 3u))                  // quad-shared blocks travel within the hardware quad
         return POMDP_E_BADARG;
     const int64_t n = n_roots * sims;
@@ -703,6 +775,38 @@ int pomdp_rollout(int env, const void *params, const uint32_t *root_state, int64
         return launch_rollout<E>(p, root_state, n_roots, sims_per_root, depth, discount, flags, seed, lane0, t0, ret, n_steps,
                                  first_action, last_ob, terminated, stream);
     });
+}
+
+static bool plan_out_ok(const pomdp_plan_out *o, int n_act)
+{
+    return o && o->q && o->visits && o->best && n_act >= 1 && n_act <= 255 && o->stride >= n_act;
+}
+
+int pomdp_plan_reduce(const double *ret, const int32_t *first_action, int64_t n_roots, int64_t sims_per_root, int n_actions,
+                      const pomdp_plan_out *out, void *stream)
+{
+    if (!ret || !first_action || n_roots < 0 || n_roots > 0x7FFFFFFF || sims_per_root < 1 || !plan_out_ok(out, n_actions))
+        return POMDP_E_BADARG;
+    if (n_roots == 0) return 0;
+    hipLaunchKernelGGL(plan_reduce_kernel, dim3((unsigned)n_roots), dim3(BLOCK), 0, (hipStream_t)stream, ret, first_action,
+                       sims_per_root, n_actions, *out);
+    return (int)hipGetLastError();
+}
+
+int pomdp_plan(int env, const void *params, const uint32_t *root_state, int64_t n_roots, int64_t sims_per_root, int depth,
+               double discount, int flags, uint64_t seed, uint32_t lane0, uint64_t t0, double *sim_ret,
+               int32_t *sim_first_action, const pomdp_plan_out *out, void *stream)
+{
+    if (!params || !out) return POMDP_E_BADARG;
+    // everything is checked before anything is enqueued
+    int rc = dispatch_env(env, params, [](auto, const auto &) { return 0; });   // POMDP_E_BADPARAMS / unknown env
+    if (rc) return rc;
+    const int n_act = (int)env_action_count(env, params);
+    if (n_roots > 0x7FFFFFFF || !plan_out_ok(out, n_act)) return POMDP_E_BADARG;
+    rc = pomdp_rollout(env, params, root_state, n_roots, sims_per_root, depth, discount, flags, seed, lane0, t0, sim_ret, nullptr,
+                       sim_first_action, nullptr, nullptr, stream);
+    if (rc) return rc;
+    return pomdp_plan_reduce(sim_ret, sim_first_action, n_roots, sims_per_root, n_act, out, stream);
 }
 
 int pomdp_rock_belief_reset(const pomdp_rock_params *p, const pomdp_rock_belief *b, const uint8_t *where, int64_t n,

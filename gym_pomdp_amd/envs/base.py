@@ -588,6 +588,60 @@ class BatchedEnv(compat.EnvBase):
         out["terminated"] = out["terminated"].view(torch.bool)
         return out
 
+    def plan(self, depth, sims_per_root=1024, discount=None, all_actions=False, roots=None, out=None):
+        """One planning pass of a POMCP-style caller over the live state (or `roots`): `sims_per_root` random rollouts of
+        at most `depth` steps from every root (rollout()), reduced ON THE DEVICE to the roots' action values
+        (pomdp_plan): {"q": float64 [R, n_actions] mean return by first action (0 where never tried), "visits": int32
+        [R, n_actions], "best": int32 [R] the visited action with the largest q (lowest index on ties, -1 if no
+        simulation took a step), "value": float64 [R] = q[best], "sim_ret" / "sim_first_action": the R * sims_per_root
+        simulations' returns and first actions}.  The float64 sums follow the order stated in include/pomdp_hip.h, so the
+        CPU restatement reproduces them bit for bit.  Root r is global lane lane_offset + r and its simulation s is
+        global lane (lane_offset + r) * sims_per_root + s: the draws — and with them q / visits / best — do not depend on
+        how the roots are sharded, and whole roots never straddle a shard.  The call counter advances by `depth`.
+        `out`: the dict of an earlier call of the same shape, to reuse its buffers.  Asynchronous."""
+        st = self._state if roots is None else self._checked_state(roots, None, "plan")
+        n_roots, sims, depth = st.shape[1], int(sims_per_root), int(depth)
+        n, n_act = n_roots * sims, self.action_space.n
+        sim_lane0 = self.lane_offset * sims
+        if sims < 1 or sim_lane0 + n > 1 << 32:
+            raise ValueError("plan: the simulations' global lanes (lane_offset + r) * sims_per_root + s must lie in [0, 2^32)")
+        if sim_lane0 % 4:
+            raise ValueError("plan: lane_offset * sims_per_root must be a multiple of 4 (quad-shared Philox blocks)")
+        if out is None:
+            out = dict(q=torch.zeros((n_roots, n_act), dtype=torch.float64, device=self.device),
+                       visits=torch.zeros((n_roots, n_act), dtype=torch.int32, device=self.device),
+                       best=torch.empty(n_roots, dtype=torch.int32, device=self.device),
+                       value=torch.empty(n_roots, dtype=torch.float64, device=self.device),
+                       sim_ret=torch.empty(n, dtype=torch.float64, device=self.device),
+                       sim_first_action=torch.empty(n, dtype=torch.int32, device=self.device))
+        elif out["q"].shape != (n_roots, n_act) or out["sim_ret"].shape != (n,):
+            raise ValueError("plan: `out` was built for another shape")
+        po = out.get("_plan_out")
+        if po is None:
+            po = out["_plan_out"] = _native.PlanOut(q=out["q"].data_ptr(), visits=out["visits"].data_ptr(), best=out["best"].data_ptr(),
+                                                    value=out["value"].data_ptr(), stride=n_act, reserved=0)
+        t0 = self._t
+        self._t += depth
+        with torch.cuda.device(self.device):
+            rc = self._lib.pomdp_plan(
+                _native.ENV_KIND[self.env_name], self._params_ref, st.data_ptr(), n_roots, sims, depth,
+                float(self._discount if discount is None else discount), _native.POMDP_ROLLOUT_ALL_ACTIONS if all_actions else 0,
+                self._seed, sim_lane0, t0, out["sim_ret"].data_ptr(), out["sim_first_action"].data_ptr(), C.byref(po), self._stream())
+            _native.check(rc, "pomdp_plan")
+        return out
+
+    def plan_step(self, depth, sims_per_root=1024, discount=None, all_actions=False, out=None):
+        """One REAL step of every lane, planned: plan() from the live state, then step(best) — BASELINE.json configs[4]'s "1024-
+        simulation rollout per real step".  Returns (ob, reward, done, info, plan dict).  A lane whose simulations took no
+        step (best == -1: nothing legal to do, or depth == 0) is handed -1, which step() counts as an invalid action and
+        leaves untouched.  batch_size == 1: python scalars as step() returns them."""
+        p = self.plan(depth, sims_per_root, discount, all_actions, out=out)
+        if self.batch_size == 1:
+            a = int(p["best"].item())
+            assert a >= 0, "plan_step: no simulation took a step"
+            return self.step(a) + (p,)
+        return self.step(p["best"]) + (p,)
+
     def rollout_synthetic(self, steps, action_seed=None, actions=None, fuse=False):
         """`steps` consecutive step() calls under the synthetic uniform policy, issued from C
         (pomdp_rollout_synthetic): the same launches per step a python loop over synthetic_actions() + step()

@@ -66,7 +66,7 @@
 extern "C" {
 #endif
 
-#define POMDP_ABI_VERSION 13
+#define POMDP_ABI_VERSION 14
 
 enum {
     POMDP_E_BADARG = -1,     /* NULL pointer, n < 0, n + lane0 > 2^32 */
@@ -397,13 +397,51 @@ int pomdp_compute_prob(int env, const void *params, const uint32_t *state, const
  *            a = list[(w * len(list)) >> 32], w = word k of stream ROLLOUT at (seed, lane, t0);
  *            (ob, r, done) = step(a) on stream STEP at (seed, lane, t0 + k);  ret += disc * r;  disc *= discount.
  * The return accumulates in IEEE double (separate multiply and add).  Per-lane outputs (device):
- * ret double[n], n_steps / first_action / last_ob int32[n], terminated uint8[n].  lane0 must be a multiple of 4
+ * ret double[n], n_steps / first_action / last_ob int32[n], terminated uint8[n] (first_action = -1 for a simulation
+ * that took no step; n_steps, last_ob and terminated may be NULL since ABI 14).  lane0 must be a multiple of 4
  * (RockSample's STEP blocks are shared by global lanes 4 q .. 4 q + 3 and travel within the hardware quad). */
 enum { POMDP_ROLLOUT_ALL_ACTIONS = 1 };
 int pomdp_rollout(int env, const void *params, const uint32_t *root_state, int64_t n_roots, int64_t sims_per_root,
                   int depth, double discount, int flags, uint64_t seed, uint32_t lane0, uint64_t t0,
                   double *ret, int32_t *n_steps, int32_t *first_action, int32_t *last_ob, uint8_t *terminated,
                   void *stream);
+
+/* ---- the planning step built on those rollouts (ABI 14; BASELINE.json configs[4]: "a POMCP-style 1024-simulation
+ * rollout per real step") ------------------------------------------------------------------------------------------
+ * What the reference's hooks exist to be driven for (rock.py:243-245 _set_state, 266-291 _get_init_state /
+ * _generate_legal, 115 _discount; readme.md:38-41 credits POMCP): the caller simulates from each root, turns the
+ * simulations into action values and takes the best action in the real env.  Per root r, over its sims_per_root
+ * simulations (simulation s of root r is lane r * sims_per_root + s of pomdp_rollout's outputs):
+ *     visits[r][a] = the number of simulations whose first action was a
+ *     q[r][a]      = (sum of their returns) / visits[r][a]            0.0 where visits == 0
+ *     best[r]      = the action with the largest q among those with visits > 0, the lowest index on ties; -1 if none
+ *     value[r]     = q[r][best[r]]                                     0.0 if best == -1
+ * The reduction stays on the device — one workgroup per root, the root's returns staged through LDS, no atomics — and is
+ * IEEE double with a DEFINED summation order, so that a CPU restatement reproduces it bit for bit: the root's simulations
+ * are cut into chunks of POMDP_PLAN_CHUNK = 64 by simulation index; within a chunk the returns whose first action is a are
+ * added in simulation-index order, starting from +0.0; the chunk sums are then added in chunk order, starting from +0.0;
+ * the mean is one division.  Nothing depends on the launch geometry or on how roots are spread over GPUs: a root's
+ * simulations are consecutive lanes, so whole roots never straddle a shard.
+ * The real step is then pomdp_<env>_step(root_state, action = best, ...) — an ordinary step of n_roots lanes. */
+#define POMDP_PLAN_CHUNK 64
+typedef struct pomdp_plan_out {
+    double  *q;        /* device double [n_roots][stride] */
+    int32_t *visits;   /* device int32  [n_roots][stride] */
+    int32_t *best;     /* device int32  [n_roots] */
+    double  *value;    /* device double [n_roots]; may be NULL */
+    int32_t  stride;   /* >= the env's action count (columns past it are left alone) */
+    int32_t  reserved;
+} pomdp_plan_out;
+/* the reduction alone, over per-simulation returns / first actions the caller already has (n_actions <= 255; a
+ * first_action outside [0, n_actions) — pomdp_rollout's -1 — counts for no action) */
+int pomdp_plan_reduce(const double *ret, const int32_t *first_action, int64_t n_roots, int64_t sims_per_root,
+                      int n_actions, const pomdp_plan_out *out, void *stream);
+/* pomdp_rollout (same arguments, same lanes, same draws) followed by pomdp_plan_reduce: two launches.  sim_ret /
+ * sim_first_action: device double / int32 [n_roots * sims_per_root], the caller's scratch — on return they hold the
+ * simulations' returns and first actions, as pomdp_rollout writes them. */
+int pomdp_plan(int env, const void *params, const uint32_t *root_state, int64_t n_roots, int64_t sims_per_root,
+               int depth, double discount, int flags, uint64_t seed, uint32_t lane0, uint64_t t0,
+               double *sim_ret, int32_t *sim_first_action, const pomdp_plan_out *out, void *stream);
 
 /* ---- heuristic-policy support --------------------------- */
 /* RockSample's per-rock side statistics — the Rock fields count, measured, lkv, lkw, prob_valuable of rock.py:78-86,

@@ -49,6 +49,7 @@ def lib():
         L.or_batch_rollout.argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_int, C.c_double, C.c_int, C.c_uint64,
                                        C.c_uint32, C.c_uint64, vp, vp, vp, vp, vp, C.c_int]
         L.or_batch_compute_prob.argtypes = [vp, vp, vp, vp, vp, C.c_int64]
+        L.or_plan_reduce.argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_int, C.c_int, vp, vp, vp, vp]
         L.or_bench_loop.restype = C.c_double
         L.or_bench_loop.argtypes = [vp, C.c_int64, C.c_int64, C.c_uint64, C.c_int, vp]
         L.or_max_threads.restype = C.c_int
@@ -184,6 +185,19 @@ def _batch_rollout(self, state, sims_per_root, depth, discount, seed, lane0, t0,
     lib().or_batch_rollout(self._h, _ptr(np.ascontiguousarray(state)), roots, sims_per_root, depth, discount,
                            int(all_actions), seed, lane0, t0, _ptr(out["ret"]), _ptr(out["n_steps"]),
                            _ptr(out["first_action"]), _ptr(out["last_ob"]), _ptr(out["terminated"]), nthreads)
+    return out
+
+
+def plan_reduce(ret, first_action, n_roots, sims_per_root, n_actions):
+    """The planner's reduction of a root's simulations to action values (pomdp_oracle.h: or_plan_reduce) ->
+    dict(q float64 [R, A], visits int32 [R, A], best int32 [R], value float64 [R])."""
+    ret = np.ascontiguousarray(ret, np.float64)
+    first_action = np.ascontiguousarray(first_action, np.int32)
+    assert ret.shape == (n_roots * sims_per_root,) and first_action.shape == ret.shape
+    out = dict(q=np.zeros((n_roots, n_actions), np.float64), visits=np.zeros((n_roots, n_actions), np.int32),
+               best=np.zeros(n_roots, np.int32), value=np.zeros(n_roots, np.float64))
+    lib().or_plan_reduce(_ptr(ret), _ptr(first_action), n_roots, sims_per_root, n_actions, n_actions, _ptr(out["q"]),
+                         _ptr(out["visits"]), _ptr(out["best"]), _ptr(out["value"]))
     return out
 
 

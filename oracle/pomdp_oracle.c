@@ -1219,6 +1219,35 @@ void or_batch_rollout(const or_env *proto, const uint32_t *state, int64_t n_root
     }
 }
 
+/* The caller's reduction of those simulations to action values (pomdp_oracle.h: or_plan_reduce). */
+void or_plan_reduce(const double *ret, const int32_t *first_action, int64_t n_roots, int64_t sims_per_root, int n_actions,
+                    int stride, double *q, int32_t *visits, int32_t *best, double *value)
+{
+    for (int64_t r = 0; r < n_roots; r++) {
+        const double *rr = ret + r * sims_per_root;
+        const int32_t *fa = first_action + r * sims_per_root;
+        int b = -1;
+        double bq = 0.0;
+        for (int a = 0; a < n_actions; a++) {
+            double total = 0.0;
+            int32_t cnt = 0;
+            for (int64_t c0 = 0; c0 < sims_per_root; c0 += OR_PLAN_CHUNK) {
+                double part = 0.0;
+                int64_t c1 = c0 + OR_PLAN_CHUNK < sims_per_root ? c0 + OR_PLAN_CHUNK : sims_per_root;
+                for (int64_t j = c0; j < c1; j++)
+                    if (fa[j] == a) { part = part + rr[j]; cnt++; }
+                total = total + part;
+            }
+            double qa = cnt > 0 ? total / (double)cnt : 0.0;
+            q[r * stride + a] = qa;
+            visits[r * stride + a] = cnt;
+            if (cnt > 0 && (b < 0 || qa > bq)) { b = a; bq = qa; }
+        }
+        best[r] = b;
+        if (value) value[r] = b >= 0 ? bq : 0.0;
+    }
+}
+
 /* ======================================================================== */
 /* planner hook: observation likelihood _compute_prob(action, next_state, ob) */
 /* ======================================================================== */

@@ -152,6 +152,21 @@ void or_batch_rollout(const or_env *proto, const uint32_t *state, int64_t n_root
                       uint64_t t0, double *ret, int32_t *n_steps, int32_t *first_action, int32_t *last_ob,
                       uint8_t *terminated, int nthreads);
 
+/* The planning step a POMCP-style caller builds on those rollouts (BASELINE.json configs[4]; the hooks it drives:
+ * rock.py:243-245 _set_state, 266-291 _get_init_state / _generate_legal, 115 _discount): per root,
+ * over its sims_per_root simulations (simulation s of root r = lane r * sims_per_root + s of or_batch_rollout's outputs),
+ *   visits[r][a] = the number of simulations whose first action was a
+ *   q[r][a]      = (sum of their returns) / visits[r][a]           0.0 where visits == 0
+ *   best[r]      = the action with the largest q among those with visits > 0, lowest index on ties; -1 if there is none
+ *   value[r]     = q[r][best[r]]                                    0.0 if best == -1
+ * in IEEE double with this summation order, which the GPU build states in include/pomdp_hip.h (pomdp_plan) and follows:
+ * the root's simulations are cut into chunks of 64 by simulation index; a chunk's returns for action a are added in
+ * simulation-index order starting from +0.0; the chunk sums are then added in chunk order starting from +0.0.
+ * q / visits: [n_roots][stride], stride >= n_actions (columns past n_actions are left alone). */
+#define OR_PLAN_CHUNK 64
+void or_plan_reduce(const double *ret, const int32_t *first_action, int64_t n_roots, int64_t sims_per_root, int n_actions,
+                    int stride, double *q, int32_t *visits, int32_t *best, double *value);
+
 
 /* ---- heuristic-policy support ------------------------ */
 /* RockSample's per-rock side statistics (rock.py:78-86: count, measured, lkw, lkv, prob_valuable), struct of

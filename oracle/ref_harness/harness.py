@@ -303,7 +303,7 @@ def legal_list(env):
 
 
 def rollout_reference(name, kwargs, seed, root_lane0, n_roots, sims_per_root, depth, discount, t_reset, t0,
-                      lane0, all_actions=False):
+                      lane0, all_actions=False, keep_envs=None):
     """Reference-side statement of the build's rollout contract (oracle/pomdp_oracle.h: or_batch_rollout):
     root r is the reference env reset on stream RESET of (seed, root_lane0 + r, t_reset); simulation s of
     root r is a deep copy of it, advanced by the reference's own step() on injected STEP words, the action
@@ -327,6 +327,8 @@ def rollout_reference(name, kwargs, seed, root_lane0, n_roots, sims_per_root, de
         out["root_state"][r] = s0
         out["root_legal"][r], out["root_legal_len"][r] = legal_list(env)
         n_act = env.action_space.n
+        if keep_envs is not None:
+            keep_envs.append(env)          # the root itself is never stepped here: simulations run on deep copies
         for s in range(sims_per_root):
             i = r * sims_per_root + s
             lane = lane0 + i
@@ -350,6 +352,76 @@ def rollout_reference(name, kwargs, seed, root_lane0, n_roots, sims_per_root, de
                 disc = disc * discount
                 k += 1
             out["ret"][i], out["n_steps"][i], out["last_ob"][i], out["terminated"][i] = ret, k, int(ob), int(bool(done))
+    return out
+
+
+PLAN_CHUNK = 64
+
+
+def plan_reduce_python(ret, first_action, n_roots, sims_per_root, n_actions):
+    """The planner's reduction in PYTHON floats, in the order include/pomdp_hip.h states for pomdp_plan: per root and
+    action, chunks of 64 simulations by index; within a chunk the returns whose first action is `a` are added in index
+    order starting from 0.0; the chunk sums are added in chunk order starting from 0.0; the mean is one division.
+    best = the visited action with the largest mean, lowest index on ties (-1: none)."""
+    q = np.zeros((n_roots, n_actions), np.float64)
+    visits = np.zeros((n_roots, n_actions), np.int64)
+    best = np.full(n_roots, -1, np.int64)
+    value = np.zeros(n_roots, np.float64)
+    for r in range(n_roots):
+        rr = [float(v) for v in ret[r * sims_per_root:(r + 1) * sims_per_root]]
+        fa = [int(v) for v in first_action[r * sims_per_root:(r + 1) * sims_per_root]]
+        b, bq = -1, 0.0
+        for a in range(n_actions):
+            total, cnt = 0.0, 0
+            for c0 in range(0, sims_per_root, PLAN_CHUNK):
+                part = 0.0
+                for j in range(c0, min(c0 + PLAN_CHUNK, sims_per_root)):
+                    if fa[j] == a:
+                        part = part + rr[j]
+                        cnt += 1
+                total = total + part
+            qa = total / cnt if cnt else 0.0
+            q[r, a], visits[r, a] = qa, cnt
+            if cnt and (b < 0 or qa > bq):
+                b, bq = a, qa
+        best[r], value[r] = b, (bq if b >= 0 else 0.0)
+    return q, visits, best, value
+
+
+def plan_reference(name, kwargs, seed, root_lane0, n_roots, sims_per_root, depth, discount, t_reset, t0, all_actions=False):
+    """Reference-side statement of the planning step (include/pomdp_hip.h: pomdp_plan, then pomdp_<env>_step with the
+    chosen actions): root r is the reference env reset on stream RESET of (seed, root_lane0 + r, t_reset); its simulation s
+    is lane (root_lane0 + r) * sims_per_root + s of rollout_reference at call counter t0; the simulations' returns —
+    the reference's own float64 arithmetic over its own step() — are reduced in Python floats in the stated order; the
+    root then takes its best action in the reference's own step() at call counter t0 + depth (auto-reset as in
+    trace_mode_b)."""
+    space = _space_rng() if name == "tiger" else None
+    envs = []
+    tr = rollout_reference(name, kwargs, seed, root_lane0, n_roots, sims_per_root, depth, discount, t_reset, t0,
+                           lane0=root_lane0 * sims_per_root, all_actions=all_actions, keep_envs=envs)
+    n_act = envs[0].action_space.n
+    q, visits, best, value = plan_reduce_python(tr["ret"], tr["first_action"], n_roots, sims_per_root, n_act)
+    t_step = t0 + depth
+    S = tr["root_state"].shape[1]
+    out = dict(sim_ret=tr["ret"], sim_first_action=tr["first_action"], root_state=tr["root_state"], q=q, visits=visits, best=best,
+               value=value, ob=np.zeros(n_roots, np.int64), reward=np.zeros(n_roots, np.float64), done=np.zeros(n_roots, np.uint8),
+               state_pre=np.zeros((n_roots, S), np.int64), state=np.zeros((n_roots, S), np.int64))
+    for r, env in enumerate(envs):
+        assert best[r] >= 0
+        lane = root_lane0 + r
+        lim = inject_stream(seed, lane, t_step, px.STREAM_STEP, env=name, env_kwargs=kwargs)
+        if space is not None:
+            inject_stream(seed, lane, t_step, px.STREAM_STEP_SPACE, space)
+        o, rw, d, _ = env.step(int(best[r]))
+        assert consumed_words() <= lim
+        out["ob"][r], out["reward"][r], out["done"][r] = int(o), _as_float(rw), int(bool(d))
+        out["state_pre"][r] = compact_state(name, env)
+        if d:
+            inject_auto_reset(seed, lane, t_step, t_reset, env=name, env_kwargs=kwargs)
+            if space is not None:
+                inject_stream(seed, lane, t_step, px.STREAM_RESET_SPACE, space)
+            env.reset()
+        out["state"][r] = compact_state(name, env)
     return out
 
 

@@ -157,6 +157,36 @@ def gen_rollout(case, env, kwargs, R, S, depth, all_actions):
     return int(tr["terminated"].sum()), float(tr["n_steps"].mean())
 
 
+# the planning step (include/pomdp_hip.h: pomdp_plan + the roots' real step): (case, env, kwargs, roots, sims per root, depth).
+# Simulation counts straddle the reduction's 64-simulation chunks: 160 = two and a half, 100 = a ragged second chunk, 72.
+PLAN_CASES = [
+    ("rock_7_8", "rock", {}, 6, 160, 20),
+    ("rock_15_15", "rock", dict(board_size=15, num_rocks=15), 4, 128, 30),
+    ("stochrock_7_8", "stochrock", {}, 3, 72, 20),
+    ("tag_1", "tag", {}, 4, 100, 20),
+    ("battleship_5_5", "battleship", {}, 3, 80, 25),
+    ("tiger", "tiger", {}, 6, 72, 10),
+    ("network_10", "network", {}, 3, 64, 8),
+]
+PLAN_SEED = 0x9A11CE5EED
+
+
+def gen_plan(case, env, kwargs, R, S, depth):
+    tries = 0
+    while True:
+        try:
+            tr = h.plan_reference(env, kwargs, PLAN_SEED + tries, root_lane0=1000, n_roots=R, sims_per_root=S, depth=depth,
+                                  discount=ROLLOUT_DISCOUNT[env], t_reset=3, t0=10)
+            break
+        except IndexError:      # RockSample crash cells
+            tries += 1
+            assert tries < 50
+    tr.update(seed=np.int64(PLAN_SEED + tries), root_lane0=np.int64(1000), n_roots=np.int64(R), sims_per_root=np.int64(S),
+              depth=np.int64(depth), discount=np.float64(ROLLOUT_DISCOUNT[env]), t_reset=np.int64(3), t0=np.int64(10))
+    np.savez_compressed(os.path.join(HERE, "plan_%s.npz" % case), **tr)
+    return tr
+
+
 PROB_CASES = [("rock_7_8", "rock", {}, 48, 40), ("stochrock_7_8", "stochrock", {}, 24, 40), ("rock_15_15", "rock", dict(board_size=15, num_rocks=15), 24, 40),
               ("tag_1", "tag", {}, 32, 40), ("tag_2", "tag", dict(num_opponents=2), 16, 40),
               ("battleship_5_5", "battleship", {}, 32, 40), ("tiger", "tiger", {}, 32, 30),
@@ -323,6 +353,13 @@ def main():
             nd, ml, tries = gen_heuristic(case, env, kwargs, L, T)
             print("heuristic %-16s dones=%4d  mean preferred-list length=%.2f  (seed retries %d)" % (case, nd, ml, tries), flush=True)
         return
+    if "--plans-only" in sys.argv:
+        for case, env, kwargs, R, S, depth in PLAN_CASES:
+            tr = gen_plan(case, env, kwargs, R, S, depth)
+            print("plan %-16s best=%s visited actions per root=%s done=%d" % (case, tr["best"].tolist(),
+                  (tr["visits"] > 0).sum(axis=1).tolist(), int(tr["done"].sum())), flush=True)
+        write_manifest()
+        return
     if "--rollouts-only" not in sys.argv:
         gen_edge_cases()
     only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--only=")]
@@ -353,6 +390,15 @@ def main():
             continue
         nd, ml, tries = gen_heuristic(case, env, kwargs, L, T, max_size=ms)
         print("heuristic %-16s dones=%4d  mean preferred-list length=%.2f  (seed retries %d)" % (case, nd, ml, tries), flush=True)
+    for case, env, kwargs, R, S, depth in PLAN_CASES:
+        if not wanted(case):
+            continue
+        tr = gen_plan(case, env, kwargs, R, S, depth)
+        print("plan %-16s best=%s" % (case, tr["best"].tolist()), flush=True)
+    write_manifest()
+
+
+def write_manifest():
     with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
         json.dump({"cases": [[c[0], c[1], {k: (list(v) if isinstance(v, tuple) else v) for k, v in c[2].items()}]
                              for c in CASES],
@@ -360,6 +406,8 @@ def main():
                                      for c in ROLLOUT_CASES],
                    "prob_cases": [[c[0], c[1], {k: (list(v) if isinstance(v, tuple) else v) for k, v in c[2].items()}]
                                   for c in PROB_CASES],
+                   "plan_cases": [[c[0], c[1], {k: (list(v) if isinstance(v, tuple) else v) for k, v in c[2].items()}]
+                                  for c in PLAN_CASES],
                    "heuristic_cases": [[c[0], c[1], {k: (list(v) if isinstance(v, tuple) else v) for k, v in c[2].items()}]
                                        for c in HEUR_CASES + HEUR_BOUNDED],
                    "mode_a_seeds": MODE_A_SEEDS, "mode_b_seed": MODE_B_SEED,

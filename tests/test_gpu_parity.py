@@ -366,6 +366,153 @@ def test_rollouts_and_legal_lists_match_reference(case, env, kw):
     assert np.array_equal(np_(r["terminated"]), g["terminated"].astype(bool))
 
 
+def _plan_cases():
+    from conftest import golden_manifest
+    return [(c[0], c[1], {k: (tuple(v) if isinstance(v, list) else v) for k, v in c[2].items()})
+            for c in golden_manifest()["plan_cases"]]
+
+
+PLANS = _plan_cases()
+
+
+@pytest.mark.parametrize("case,env,kw", PLANS, ids=[c[0] for c in PLANS])
+def test_planning_step_matches_reference(case, env, kw):
+    """BASELINE.json configs[4]'s planning step on the HIP path == fixture plan_*.npz: the reference's own step() under every
+    simulation, the returns reduced in Python floats in the order include/pomdp_hip.h states (q / value bit for bit), then the
+    reference's step() of the roots with the chosen actions."""
+    import os
+    from conftest import GOLDEN
+    g = dict(np.load(os.path.join(GOLDEN, "plan_%s.npz" % case)))
+    R, S, depth = int(g["n_roots"]), int(g["sims_per_root"]), int(g["depth"])
+    e = make_env(env, kw, batch_size=R, seed=int(g["seed"]), lane_offset=int(g["root_lane0"]), auto_reset=True)
+    e.call_counter = int(g["t_reset"])
+    e.reset()
+    assert np.array_equal(np_(e.decode_state()), saturate_tag_compact(env, g["root_state"]))
+    e.call_counter = int(g["t0"])
+    before = e.state.clone()
+    p = e.plan(depth, sims_per_root=S, discount=float(g["discount"]))
+    assert torch.equal(e.state, before) and e.call_counter == int(g["t0"]) + depth
+    assert np.array_equal(np_(p["sim_ret"]).view(np.uint64), g["sim_ret"].view(np.uint64))
+    assert np.array_equal(np_(p["sim_first_action"]), g["sim_first_action"])
+    assert np.array_equal(np_(p["visits"]), g["visits"]) and np.array_equal(np_(p["best"]), g["best"])
+    assert np.array_equal(np_(p["q"]).view(np.uint64), g["q"].view(np.uint64))
+    assert np.array_equal(np_(p["value"]).view(np.uint64), g["value"].view(np.uint64))
+    # ... and the same through plan_step(): plan again from the same counter, then the real step
+    e.call_counter = int(g["t0"])
+    ob, rew, done, info, p2 = e.plan_step(depth, sims_per_root=S, discount=float(g["discount"]), out=p)
+    assert p2 is p and np.array_equal(np_(p["best"]), g["best"])
+    assert np.array_equal(np_(ob), g["ob"]) and np.array_equal(np_(done), g["done"].astype(bool))
+    assert np.array_equal(np_(rew).astype(np.float64), g["reward"].astype(np_(rew).dtype).astype(np.float64))
+    assert np.array_equal(np_(e.decode_state()), saturate_tag_compact(env, g["state"]))
+    assert e.invalid_action_count() == 0 and e.call_counter == int(g["t0"]) + depth + 1
+
+
+@pytest.mark.parametrize("env,kw,roots,sims,depth", [
+    ("rock", dict(board_size=15, num_rocks=15), 96, 1024, 48),          # BASELINE.json configs[4] shape, scaled down
+    ("rock", {}, 515, 200, 24),                                         # ragged: 200 = 3 chunks + 8, an odd number of roots
+    ("rock", {}, 64, 2500, 16),                                         # more than two LDS tiles of 1024 simulations
+    ("tag", {}, 300, 65, 30),
+    ("battleship", dict(board_size=(10, 10), max_len=5), 37, 260, 40),  # 100 actions: two passes of 64 per chunk
+    ("network", {}, 130, 96, 10),
+    ("tiger", {}, 1000, 7, 8),
+    ("tiger", {}, 9, 1, 3),
+])
+def test_plan_vs_oracle(oracle_lib, env, kw, roots, sims, depth):
+    """plan() against the oracle's rollouts + or_plan_reduce on roots moved off their start states, float64 bit for bit;
+    then a second planned step from the state the first one left (plan_step)."""
+    seed, lane0 = 777, 4096
+    o = oracle_lib.OracleEnv(env, **kw)
+    e = make_env(env, kw, batch_size=roots, seed=seed, lane_offset=lane0, auto_reset=True)
+    st = o.new_state(roots)
+    o.batch_reset(st, seed, lane0, 0, nthreads=8)
+    e.reset()
+    for _ in range(2):
+        a = oracle_lib.synthetic_actions(roots, 3, lane0, e.call_counter, o.n_actions)
+        o.batch_step(st, a, seed, lane0, e.call_counter, nthreads=8)
+        e.step(torch.as_tensor(a, device="cuda"))
+    out = None
+    for rep in range(2):
+        t0 = e.call_counter
+        r = o.batch_rollout(st, sims, depth, e._discount, seed, lane0 * sims, t0, nthreads=8)
+        want = oracle_lib.plan_reduce(r["ret"], r["first_action"], roots, sims, o.n_actions)
+        ob, rew, done, info, out = e.plan_step(depth, sims_per_root=sims, out=out)
+        assert np.array_equal(np_(out["sim_ret"]).view(np.uint64), r["ret"].view(np.uint64))
+        assert np.array_equal(np_(out["sim_first_action"]), r["first_action"])
+        for k in ("q", "value"):
+            assert np.array_equal(np_(out[k]).view(np.uint64), want[k].view(np.uint64)), (k, rep)
+        for k in ("visits", "best"):
+            assert np.array_equal(np_(out[k]), want[k]), (k, rep)
+        ob_o, rew_o, done_o, bad = o.batch_step(st, want["best"], seed, lane0, t0 + depth, auto_reset=True, nthreads=8)
+        assert np.array_equal(np_(ob), ob_o) and np.array_equal(np_(rew), rew_o) and np.array_equal(np_(done), done_o.astype(bool))
+        assert np.array_equal(np_(e.state).view(np.uint32), st) and e.invalid_action_count() == bad
+    assert (np_(out["visits"]).sum(axis=1) == sims).all()
+
+
+def test_plan_does_not_depend_on_the_sharding_and_handles_no_simulation():
+    """Root r is global lane lane_offset + r and its simulations global lanes (lane_offset + r) * S ..: two shards of a root
+    set reproduce the unsharded plan exactly (whole roots never straddle a shard).  depth = 0: no simulation takes a step —
+    best = -1, value = 0, nothing visited."""
+    kw = dict(board_size=11, num_rocks=11)
+    S, depth = 132, 12
+    whole = make_env("rock", kw, batch_size=24, seed=9, lane_offset=40)
+    whole.reset()
+    p = whole.plan(depth, sims_per_root=S)
+    for lo, hi in ((0, 8), (8, 24)):
+        part = make_env("rock", kw, batch_size=hi - lo, seed=9, lane_offset=40 + lo)
+        part.reset()
+        assert torch.equal(part.state, whole.state[:, lo:hi])
+        q = part.plan(depth, sims_per_root=S)
+        for k in ("q", "visits", "best", "value"):
+            assert torch.equal(q[k], p[k][lo:hi]), k
+        assert torch.equal(q["sim_ret"], p["sim_ret"][lo * S:hi * S])
+    z = whole.plan(0, sims_per_root=S)
+    assert (np_(z["best"]) == -1).all() and (np_(z["value"]) == 0).all() and (np_(z["visits"]) == 0).all() and (np_(z["q"]) == 0).all()
+    assert (np_(z["sim_first_action"]) == -1).all()
+    with pytest.raises(ValueError):
+        make_env("rock", {}, batch_size=4, seed=1, lane_offset=3).plan(4, sims_per_root=5)    # first simulation lane 15: not on a quad
+
+
+def test_plan_through_the_c_abi(oracle_lib):
+    """pomdp_plan / pomdp_plan_reduce called directly: the reduction over caller-supplied simulation results (a wider stride,
+    columns past the action count left alone, value = NULL), and the argument checks."""
+    import ctypes as C
+    from gym_pomdp_amd import _native
+    L = _native.lib()
+    R, S, A, stride = 5, 300, 13, 16
+    rng = np.random.RandomState(3)
+    ret = rng.randn(R * S)
+    fa = rng.randint(-1, A, R * S).astype(np.int32)
+    d_ret, d_fa = torch.as_tensor(ret, device="cuda"), torch.as_tensor(fa, device="cuda")
+    q = torch.full((R, stride), 7.5, dtype=torch.float64, device="cuda")
+    visits = torch.full((R, stride), -3, dtype=torch.int32, device="cuda")
+    best = torch.zeros(R, dtype=torch.int32, device="cuda")
+    po = _native.PlanOut(q=q.data_ptr(), visits=visits.data_ptr(), best=best.data_ptr(), value=None, stride=stride, reserved=0)
+    assert L.pomdp_plan_reduce(d_ret.data_ptr(), d_fa.data_ptr(), R, S, A, C.byref(po), None) == 0
+    torch.cuda.synchronize()
+    want = oracle_lib.plan_reduce(ret, fa, R, S, A)
+    assert np.array_equal(np_(q)[:, :A].view(np.uint64), want["q"].view(np.uint64)) and (np_(q)[:, A:] == 7.5).all()
+    assert np.array_equal(np_(visits)[:, :A], want["visits"]) and (np_(visits)[:, A:] == -3).all()
+    assert np.array_equal(np_(best), want["best"])
+    assert L.pomdp_plan_reduce(d_ret.data_ptr(), d_fa.data_ptr(), R, S, 256, C.byref(po), None) == -1     # actions beyond a byte
+    assert L.pomdp_plan_reduce(d_ret.data_ptr(), d_fa.data_ptr(), R, S, 20, C.byref(po), None) == -1      # stride < n_actions
+    assert L.pomdp_plan_reduce(None, d_fa.data_ptr(), R, S, A, C.byref(po), None) == -1
+    assert L.pomdp_plan_reduce(d_ret.data_ptr(), d_fa.data_ptr(), R, 0, A, C.byref(po), None) == -1
+    assert L.pomdp_plan_reduce(d_ret.data_ptr(), d_fa.data_ptr(), 0, S, A, C.byref(po), None) == 0
+    e = make_env("rock", {}, batch_size=R, seed=1)
+    e.reset()
+    bad = _native.PlanOut(q=q.data_ptr(), visits=visits.data_ptr(), best=None, value=None, stride=stride, reserved=0)
+    args = (_native.ENV_KIND["rock"], e._params_ref, e.state.data_ptr(), R, S, 8, .95, 0, 1, 0, 0, d_ret.data_ptr(), d_fa.data_ptr())
+    assert L.pomdp_plan(*args, C.byref(bad), None) == -1
+    assert L.pomdp_plan(*args, None, None) == -1
+    assert L.pomdp_plan(*args, C.byref(po), None) == 0
+    torch.cuda.synchronize()
+    assert (np_(visits)[:, :A].sum(axis=1) == S).all()
+    # pomdp_rollout's optional outputs (ABI 14): NULL n_steps / last_ob / terminated
+    assert L.pomdp_rollout(_native.ENV_KIND["rock"], e._params_ref, e.state.data_ptr(), R, S, 8, .95, 0, 1, 0, 0, d_ret.data_ptr(), None,
+                           d_fa.data_ptr(), None, None, None) == 0
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("env,kw,roots,sims,depth", [
     ("rock", dict(board_size=15, num_rocks=15), 64, 1024, 48),          # BASELINE.json configs[4] shape, scaled down
     ("rock", {}, 4096, 8, 32),

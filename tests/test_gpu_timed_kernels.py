@@ -240,7 +240,10 @@ def test_bench_line_as_the_driver_runs_it():
     pd = lay["packed_plus_decode"]      # records -> int32 columns costs more than writing the columns in the first place
     assert pd["kernel_ms"] > lay["columns"]["kernel_ms"] and 0.4 < pd["decode_hbm_frac"] < 1.0 and abs(pd["bytes_per_lane_step"] - 21.4) < 1e-9, pd
     cfg = d["configs"]
-    assert set(cfg) == {"tag", "battleship", "rollout_rock15", "returns_only"}
+    assert set(cfg) == {"tag", "battleship", "rollout_rock15", "plan_rock15", "returns_only"}
+    pl = cfg.pop("plan_rock15")          # configs[4] as planned REAL steps: rollout + on-device reduction + the roots' step
+    assert pl["unit"] == "planned real env-steps/s" and pl["value"] > 1e5 and abs(sum(pl["share"].values()) - 1.0) < 1e-6, pl
+    assert pl["share"]["rollout"] > 0.8 and pl["reduce_kernel_ms"] < 0.2 and pl["visited_actions_per_root"] > 3, pl
     assert cfg["returns_only"]["kernel"] == "steps_quad_kernel<RockEnv<1>, Returns>" and cfg["returns_only"]["steps_per_launch"] == 256
     assert cfg["tag"]["kernel"].startswith("tag_steps_quad_kernel<true") and cfg["battleship"]["kernel"].startswith("battleship_steps_quad_kernel<BattleShipEnv<4>")
     for k in cfg:

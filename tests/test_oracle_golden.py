@@ -187,6 +187,75 @@ def test_rollouts_and_legal_lists_match_reference(oracle_lib, case, env, kw):
         assert np.array_equal(r[k], g[k].astype(r[k].dtype)), k
 
 
+def _plan_cases():
+    return [(c[0], c[1], {k: (tuple(v) if isinstance(v, list) else v) for k, v in c[2].items()})
+            for c in golden_manifest()["plan_cases"]]
+
+
+PLANS = _plan_cases()
+
+
+@pytest.mark.parametrize("case,env,kw", PLANS, ids=[c[0] for c in PLANS])
+def test_planning_step_matches_reference(oracle_lib, case, env, kw):
+    """BASELINE.json configs[4]'s planning step (fixture plan_*.npz: the reference's own step() under the simulations, their
+    returns reduced in PYTHON floats in the order include/pomdp_hip.h states, the roots then stepped by the reference): the
+    oracle's rollouts, or_plan_reduce and batch step reproduce every number, the float64 ones bit for bit."""
+    g = dict(np.load(os.path.join(GOLDEN, "plan_%s.npz" % case)))
+    o = oracle_lib.OracleEnv(env, **kw)
+    R, S, depth = int(g["n_roots"]), int(g["sims_per_root"]), int(g["depth"])
+    seed, lane0, t0 = int(g["seed"]), int(g["root_lane0"]), int(g["t0"])
+    roots = o.new_state(R)
+    o.batch_reset(roots, seed, lane0, int(g["t_reset"]))
+    assert np.array_equal(o.batch_compact(roots), saturate_tag_compact(env, g["root_state"]))
+    r = o.batch_rollout(roots, S, depth, float(g["discount"]), seed, lane0 * S, t0, nthreads=2)
+    assert np.array_equal(r["ret"].view(np.uint64), g["sim_ret"].view(np.uint64))
+    assert np.array_equal(r["first_action"], g["sim_first_action"])
+    p = oracle_lib.plan_reduce(r["ret"], r["first_action"], R, S, o.n_actions)
+    assert np.array_equal(p["visits"], g["visits"]) and np.array_equal(p["best"], g["best"])
+    assert np.array_equal(p["q"].view(np.uint64), g["q"].view(np.uint64))             # IEEE double, bit for bit
+    assert np.array_equal(p["value"].view(np.uint64), g["value"].view(np.uint64))
+    assert g["visits"].sum(axis=1).tolist() == [S] * R
+    ob, rew, done, bad = o.batch_step(roots, p["best"], seed, lane0, t0 + depth, auto_reset=True)
+    assert bad == 0 and np.array_equal(ob, g["ob"]) and np.array_equal(done, g["done"])
+    assert np.array_equal(rew.astype(np.float64), g["reward"].astype(rew.dtype).astype(np.float64))
+    assert np.array_equal(o.batch_compact(roots), saturate_tag_compact(env, g["state"]))
+
+
+def test_plan_reduce_order_and_edge_cases(oracle_lib):
+    """or_plan_reduce against the harness's Python-float statement of the order on returns built to expose it (magnitudes 16
+    orders apart: any other association rounds differently), with unvisited actions, simulations that took no step, a root
+    where nothing did, ties, and simulation counts on both sides of the chunk boundaries."""
+    from oracle.ref_harness import harness as h
+    rng = np.random.RandomState(7)
+    for R, S, A in ((3, 1, 3), (2, 63, 5), (2, 64, 5), (2, 65, 20), (3, 200, 7), (2, 1024, 20), (1, 1100, 100)):
+        ret = (rng.randn(R * S) * 10.0 ** rng.randint(-8, 9, R * S)).astype(np.float64)
+        fa = rng.randint(-1, A, R * S).astype(np.int32)
+        fa[fa == 2] = 1                                                     # action 2 is never tried
+        if R > 1:
+            fa[S:2 * S] = -1                                                # root 1: no simulation took a step
+        if R > 2:
+            ret[2 * S:3 * S] = 1.0                                          # root 2: every visited action ties
+        want = h.plan_reduce_python(ret, fa, R, S, A)
+        got = oracle_lib.plan_reduce(ret, fa, R, S, A)
+        for k, w in zip(("q", "visits", "best", "value"), want):
+            assert np.array_equal(got[k].astype(w.dtype).view(np.uint64), w.view(np.uint64)), (R, S, A, k)
+        if A > 2:
+            assert (got["visits"][:, 2] == 0).all() and (got["q"][:, 2] == 0).all()
+        if R > 1:
+            assert got["best"][1] == -1 and got["value"][1] == 0.0
+        if R > 2:
+            assert got["best"][2] == int(np.flatnonzero(got["visits"][2] > 0)[0])
+    # the order matters: chunk 0 = 1e16 + 63 ones (each lost to rounding), chunk 1 = -1e16 + 63 ones: the chunked sum is 0,
+    # a plain left-to-right sum over the 128 simulations keeps chunk 1's ones (63)
+    ret = np.ones(128)
+    ret[0], ret[64] = 1e16, -1e16
+    got = oracle_lib.plan_reduce(ret, np.zeros(128, np.int32), 1, 128, 1)
+    seq = 0.0
+    for v in ret:
+        seq = seq + float(v)
+    assert got["q"][0, 0] == 0.0 and seq == 63.0
+
+
 def _prob_cases():
     return [(c[0], c[1], {k: (tuple(v) if isinstance(v, list) else v) for k, v in c[2].items()})
             for c in golden_manifest()["prob_cases"]]
