@@ -580,6 +580,47 @@ def quick_step_config(args, gpa, _native, cp, dev, env_key, n, lane_offset, seed
                          "counters_stale": None if rf["valu"] is None else rf["valu"]["counters_stale"]}}
 
 
+def quick_tape_config(args, gpa, _native, cp, dev, env_key, n, seed, layout, k=512):
+    """The fused launches on the CALLER's actions (pomdp_collect_tape*: rock.py:562-566, `env.step(action)` with whatever the
+    caller chose): the headline's protocol on a tape of uniform random bytes in [0, n_actions) that torch generated — 256
+    rows, replayed for every 256-step launch of the K-step regions — in the packed sink or the returns-only sink.  What the
+    tape costs against the synthetic policy: one 4-byte load per quad-step instead of one Philox block."""
+    env_id, kwargs, label, bytes_per_step, _ = WORKLOADS[env_key]
+    e = gpa.make(env_id, batch_size=n, device=dev, seed=seed, reuse_buffers=True, **kwargs)
+    e.reset()
+    rows = StepWorkload.CHUNK
+    tape = torch.randint(0, e.action_space.n, (rows, n), dtype=torch.uint8, device=dev)
+    sink = gpa.EpisodeStats(e) if layout == "returns" else e.trajectory_buffers(rows, layout)
+
+    def run(steps):
+        left = steps
+        while left > 0:
+            c = min(left, rows)
+            if layout == "returns":
+                e.collect_tape(tape[:c], stats=sink)
+            else:
+                e.collect_tape(tape[:c], out=sink, layout=layout)
+            left -= c
+
+    run(args.warmup)
+    run(k)
+    walls, evs = timed_regions(run, k, 9, dev, cp)
+    kernel = _native.lib().pomdp_last_fused_kernel().decode()
+    spl = min(fuse_max(env_key, layout), rows, k)
+    kern_ms = median(evs) / k
+    alg = fused_alg_bytes(bytes_per_step, spl, layout) + 1.0          # + the tape's byte
+    hbm = alg * n / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    bad = e.invalid_action_count()
+    del e, tape, sink
+    torch.cuda.empty_cache()
+    return {"workload": "%s batch=%d, actions from a caller's tape (uint8 [steps][lanes] in HBM), %s, %d steps per region"
+                        % (label, n, "returns-only sink" if layout == "returns" else layout + " layout", k),
+            "value": n * k / median(walls), "unit": "env-steps/s", "ms_per_step": median(walls) / k * 1e3, "kernel": kernel,
+            "kernel_ms": kern_ms, "steps_per_launch": spl, "bytes_per_lane_step": alg, "invalid_actions": bad,
+            "roofline": {"bound": "hbm", "frac": hbm, "hbm_frac": hbm, "valu_frac": None, "counters_stale": None,
+                         "note": "no PMC record for the tape kernels: compare kernel_ms with the same sink under the synthetic policy"}}
+
+
 def quick_rollout_config(args, gpa, dev, env_key, roots_n, sims, depth, seed):
     """BASELINE.json configs[4] per GPU: roots_n x sims random rollouts of <= depth steps in one fused launch, 40 timed
     launches (HIP events) after 5 untimed ones."""
@@ -910,6 +951,9 @@ def main():
             "battleship": quick_step_config(args, gpa, _native, cp, dev, "battleship", 1 << 19, 0, seeds[0], layout, k=512),   # configs[3]: 2^22 / 8 GPUs
             "rollout_rock15": quick_rollout_config(args, gpa, dev, "rock15", 2048, 1024, 64, seeds[0]),                 # configs[4]: 2^24 / 8 GPUs
             "plan_rock15": quick_plan_config(args, gpa, dev, "rock15", 2048, 1024, 64, seeds[0]),                      # ... as planned real steps
+            # the headline workload on the CALLER's actions instead of the synthetic policy's (pomdp_collect_tape*)
+            "tape_packed": quick_tape_config(args, gpa, _native, cp, dev, "rock", 1 << 20, seeds[0], "packed"),
+            "tape_returns": quick_tape_config(args, gpa, _native, cp, dev, "rock", 1 << 20, seeds[0], "returns"),
             # the headline workload reduced on the fly to what the reference's callers keep of it (network.py:175-191): no trajectory
             "returns_only": quick_step_config(args, gpa, _native, cp, dev, "rock", 1 << 20, 0, seeds[0], "returns", k=512)}
 

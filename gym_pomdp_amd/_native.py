@@ -36,7 +36,7 @@ SYMBOLS = [
     "pomdp_rock_reset", "pomdp_rock_step", "pomdp_tag_reset", "pomdp_tag_step",
     "pomdp_battleship_reset", "pomdp_battleship_step", "pomdp_tiger_reset", "pomdp_tiger_step",
     "pomdp_network_reset", "pomdp_network_step", "pomdp_step", "pomdp_step_sync", "pomdp_reset_sync", "pomdp_stream_sync", "pomdp_synthetic_actions", "pomdp_philox_blocks",
-    "pomdp_rollout_synthetic", "pomdp_collect_synthetic", "pomdp_collect", "pomdp_collect_layout", "pomdp_collect_traj", "pomdp_packed_reward", "pomdp_decode_packed", "pomdp_collect_returns", "pomdp_fuse_max", "pomdp_fuse_steps", "pomdp_legal_actions", "pomdp_rollout", "pomdp_plan", "pomdp_plan_reduce", "pomdp_compute_prob",
+    "pomdp_rollout_synthetic", "pomdp_collect_synthetic", "pomdp_collect", "pomdp_collect_layout", "pomdp_collect_traj", "pomdp_packed_reward", "pomdp_decode_packed", "pomdp_collect_returns", "pomdp_collect_tape", "pomdp_collect_tape_layout", "pomdp_collect_tape_returns", "pomdp_fuse_max", "pomdp_fuse_steps", "pomdp_legal_actions", "pomdp_rollout", "pomdp_plan", "pomdp_plan_reduce", "pomdp_compute_prob",
     "pomdp_rock_belief_reset", "pomdp_rock_belief_refresh", "pomdp_rock_belief_update", "pomdp_rock_select_target", "pomdp_history_clear",
     "pomdp_history_append", "pomdp_preferred_actions", "pomdp_pick_actions", "pomdp_heuristic_steps",
 ]
@@ -97,6 +97,10 @@ class HistoryPtrs(C.Structure):     # pomdp_history: device pointers + the windo
 
 class ReturnStats(C.Structure):     # pomdp_return_stats
     _fields_ = [("discount", C.c_double), ("acc", C.c_void_p), ("cnt", C.c_void_p), ("pitch", C.c_int64)]
+
+
+class Tape(C.Structure):            # pomdp_tape
+    _fields_ = [("actions", C.c_void_p), ("stride", C.c_int64)]
 
 
 class PlanOut(C.Structure):         # pomdp_plan_out
@@ -207,6 +211,12 @@ def lib():
     L.pomdp_decode_packed.argtypes = [ci, vp, i64, i64, i64, vp, vp, vp, vp, i64, vp]
     L.pomdp_collect_returns.restype = ci
     L.pomdp_collect_returns.argtypes = [ci, vp, vp, vp, vp, i64, u64, u32, u64, i64, ci, vp]
+    L.pomdp_collect_tape.restype = ci
+    L.pomdp_collect_tape.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, i64, u64, u32, u64, i64, i64, ci, vp]
+    L.pomdp_collect_tape_layout.restype = ci
+    L.pomdp_collect_tape_layout.argtypes = [ci, vp, vp, vp, vp, vp, i64, u64, u32, u64, i64, i64, ci, ci, vp]
+    L.pomdp_collect_tape_returns.restype = ci
+    L.pomdp_collect_tape_returns.argtypes = [ci, vp, vp, vp, vp, vp, i64, u64, u32, u64, i64, ci, vp]
     L.pomdp_fuse_max.restype = ci
     L.pomdp_fuse_max.argtypes = [ci]
     L.pomdp_fuse_steps.restype = ci

@@ -330,7 +330,7 @@ int pomdp_rollout_synthetic(int env, const void *params, uint32_t *state, int32_
             rc = dispatch_env(env, params, [&](auto tag, const auto &p) {
                 using E = typename decltype(tag)::Env;
                 return launch_steps_fused<E>(p, state, action, ob, (typename E::Reward *)reward, done, err, n, seed,
-                                             action_seed, lane0, t, c, flags, 0, s == 0, POMDP_LAYOUT_COLUMNS, stream);
+                                             action_seed, lane0, t, c, flags, 0, s == 0, POMDP_LAYOUT_COLUMNS, NO_TAPE, stream);
             });
             if (rc) return rc;
         }
@@ -365,13 +365,22 @@ int pomdp_rollout_synthetic(int env, const void *params, uint32_t *state, int32_
     return pomdp_synthetic_actions(action, n, action_seed, lane0, t0 + (uint64_t)k_steps, n_actions, stream);
 }
 
-int pomdp_collect_synthetic(int env, const void *params, uint32_t *state, int32_t *action, int32_t *ob, void *reward,
-                            uint8_t *done, uint32_t *err, int64_t n, uint64_t seed, uint32_t lane0, uint64_t t0,
-                            int64_t k_steps, int64_t pitch, int flags, void *stream)
+// rows s .. s + c - 1 of a caller's tape as one launch's TapeRef (nullptr: the synthetic policy)
+static TapeRef tape_rows(const pomdp_tape *tape, int64_t s, uint32_t *err)
 {
-    int rc = check_driver_args(env, params, state, action, ob, reward, done, n, lane0, k_steps);
+    if (!tape) return NO_TAPE;
+    return TapeRef{tape->actions + s * tape->stride, tape->stride, err};
+}
+static bool tape_ok(const pomdp_tape *tape, int64_t n) { return tape && tape->actions && tape->stride >= n; }
+
+// pomdp_collect_synthetic (tape == nullptr; `action` = its [k + 1][pitch] rows) / pomdp_collect_tape (no action column)
+static int collect_columns(int env, const void *params, uint32_t *state, const pomdp_tape *tape, int32_t *action, int32_t *ob,
+                           void *reward, uint8_t *done, uint32_t *err, int64_t n, uint64_t seed, uint32_t lane0, uint64_t t0,
+                           int64_t k_steps, int64_t pitch, int flags, void *stream)
+{
+    int rc = check_driver_args(env, params, state, tape ? (const void *)ob : (const void *)action, ob, reward, done, n, lane0, k_steps);
     if (rc) return rc;
-    if (pitch < n || !(flags & POMDP_AUTO_RESET)) return POMDP_E_BADARG;
+    if (pitch < n || !(flags & POMDP_AUTO_RESET) || (tape && !tape_ok(tape, n))) return POMDP_E_BADARG;
     if (k_steps == 0 || n == 0) return 0;
     const int64_t FUSE_MAX = pomdp_fuse_steps(env, POMDP_LAYOUT_COLUMNS);
     for (int64_t s = 0; s < k_steps; s += FUSE_MAX) {      // the first launch writes row 0 (the actions of t0) itself
@@ -379,13 +388,28 @@ int pomdp_collect_synthetic(int env, const void *params, uint32_t *state, int32_
         rc = dispatch_env(env, params, [&](auto tag, const auto &p) {
             using E = typename decltype(tag)::Env;
             using R = typename E::Reward;
-            return launch_steps_fused<E>(p, state, action + s * pitch, ob + s * pitch, (R *)reward + s * pitch,
+            return launch_steps_fused<E>(p, state, tape ? nullptr : action + s * pitch, ob + s * pitch, (R *)reward + s * pitch,
                                          done + s * pitch, err, n, seed, seed, lane0, t0 + (uint64_t)s, c, flags, pitch,
-                                         s == 0, POMDP_LAYOUT_COLUMNS, stream);
+                                         s == 0, POMDP_LAYOUT_COLUMNS, tape_rows(tape, s, err), stream);
         });
         if (rc) return rc;
     }
     return 0;
+}
+
+int pomdp_collect_synthetic(int env, const void *params, uint32_t *state, int32_t *action, int32_t *ob, void *reward,
+                            uint8_t *done, uint32_t *err, int64_t n, uint64_t seed, uint32_t lane0, uint64_t t0,
+                            int64_t k_steps, int64_t pitch, int flags, void *stream)
+{
+    return collect_columns(env, params, state, nullptr, action, ob, reward, done, err, n, seed, lane0, t0, k_steps, pitch, flags, stream);
+}
+
+int pomdp_collect_tape(int env, const void *params, uint32_t *state, const pomdp_tape *tape, int32_t *ob, void *reward,
+                       uint8_t *done, uint32_t *err, int64_t n, uint64_t seed, uint32_t lane0, uint64_t t0, int64_t k_steps,
+                       int64_t pitch, int flags, void *stream)
+{
+    if (!tape) return POMDP_E_BADARG;
+    return collect_columns(env, params, state, tape, nullptr, ob, reward, done, err, n, seed, lane0, t0, k_steps, pitch, flags, stream);
 }
 
 int pomdp_collect(const pomdp_collect_args *a, uint64_t t0, int64_t k_steps, void *stream)
@@ -397,13 +421,13 @@ int pomdp_collect(const pomdp_collect_args *a, uint64_t t0, int64_t k_steps, voi
 
 // Trajectory collection into one of the single-stream layouts (include/pomdp_hip.h: POMDP_LAYOUT_BLOCKED / _PACKED): the
 // launches of pomdp_collect_synthetic with another sink (traj_out.hip.h).
-int pomdp_collect_layout(int env, const void *params, uint32_t *state, void *traj, uint32_t *err, int64_t n, uint64_t seed,
-                         uint32_t lane0, uint64_t t0, int64_t k_steps, int64_t pitch, int layout, int flags, void *stream)
+static int collect_layout(int env, const void *params, uint32_t *state, const pomdp_tape *tape, void *traj, uint32_t *err, int64_t n,
+                          uint64_t seed, uint32_t lane0, uint64_t t0, int64_t k_steps, int64_t pitch, int layout, int flags, void *stream)
 {
     if (layout != POMDP_LAYOUT_BLOCKED && layout != POMDP_LAYOUT_PACKED && layout != POMDP_LAYOUT_NARROW) return POMDP_E_BADARG;
     int rc = check_driver_args(env, params, state, traj, traj, traj, traj, n, lane0, k_steps);
     if (rc) return rc;
-    if (pitch < n || !(flags & POMDP_AUTO_RESET)) return POMDP_E_BADARG;
+    if (pitch < n || !(flags & POMDP_AUTO_RESET) || (tape && !tape_ok(tape, n))) return POMDP_E_BADARG;
     if (layout == POMDP_LAYOUT_BLOCKED && pitch % 256 != 0) return POMDP_E_BADARG;
     if (layout == POMDP_LAYOUT_NARROW && pitch % 4 != 0) return POMDP_E_BADARG;
     // a Packed record (and a Narrow plane) keeps action and observation in a byte each: every env's fit by construction
@@ -419,11 +443,25 @@ int pomdp_collect_layout(int env, const void *params, uint32_t *state, void *tra
         rc = dispatch_env(env, params, [&](auto tag, const auto &p) {
             using E = typename decltype(tag)::Env;
             return launch_steps_fused<E>(p, state, base, nullptr, nullptr, nullptr, err, n, seed, seed, lane0, t0 + (uint64_t)s, c,
-                                         flags, pitch, true, layout, stream);
+                                         flags, pitch, true, layout, tape_rows(tape, s, err), stream);
         });
         if (rc) return rc;
     }
     return 0;
+}
+
+int pomdp_collect_layout(int env, const void *params, uint32_t *state, void *traj, uint32_t *err, int64_t n, uint64_t seed,
+                         uint32_t lane0, uint64_t t0, int64_t k_steps, int64_t pitch, int layout, int flags, void *stream)
+{
+    return collect_layout(env, params, state, nullptr, traj, err, n, seed, lane0, t0, k_steps, pitch, layout, flags, stream);
+}
+
+int pomdp_collect_tape_layout(int env, const void *params, uint32_t *state, const pomdp_tape *tape, void *traj, uint32_t *err,
+                              int64_t n, uint64_t seed, uint32_t lane0, uint64_t t0, int64_t k_steps, int64_t pitch, int layout,
+                              int flags, void *stream)
+{
+    if (!tape) return POMDP_E_BADARG;
+    return collect_layout(env, params, state, tape, traj, err, n, seed, lane0, t0, k_steps, pitch, layout, flags, stream);
 }
 
 int pomdp_collect_traj(const pomdp_traj_args *a, uint64_t t0, int64_t k_steps, void *stream)
@@ -433,13 +471,14 @@ int pomdp_collect_traj(const pomdp_traj_args *a, uint64_t t0, int64_t k_steps, v
                                 a->layout, a->flags, stream);
 }
 
-int pomdp_collect_returns(int env, const void *params, uint32_t *state, const pomdp_return_stats *stats, uint32_t *err,
-                          int64_t n, uint64_t seed, uint32_t lane0, uint64_t t0, int64_t k_steps, int flags, void *stream)
+static int collect_returns(int env, const void *params, uint32_t *state, const pomdp_tape *tape, const pomdp_return_stats *stats,
+                           uint32_t *err, int64_t n, uint64_t seed, uint32_t lane0, uint64_t t0, int64_t k_steps, int flags, void *stream)
 {
     if (!stats || !stats->acc || !stats->cnt) return POMDP_E_BADARG;
     int rc = check_driver_args(env, params, state, stats->acc, stats->cnt, stats->acc, stats->acc, n, lane0, k_steps);
     if (rc) return rc;
-    if (stats->pitch < n || !(flags & POMDP_AUTO_RESET) || !(stats->discount == stats->discount)) return POMDP_E_BADARG;
+    if (stats->pitch < n || !(flags & POMDP_AUTO_RESET) || !(stats->discount == stats->discount) || (tape && !tape_ok(tape, n)))
+        return POMDP_E_BADARG;
     if (k_steps == 0 || n == 0) return 0;
     // the launches of pomdp_collect_synthetic with the Returns sink (traj_out.hip.h); the discount travels as its bit pattern
     uint64_t bits;
@@ -451,11 +490,25 @@ int pomdp_collect_returns(int env, const void *params, uint32_t *state, const po
             using E = typename decltype(tag)::Env;
             return launch_steps_fused<E>(p, state, reinterpret_cast<int32_t *>(stats->acc), stats->cnt,
                                          reinterpret_cast<typename E::Reward *>(bits), nullptr, err, n, seed, seed, lane0,
-                                         t0 + (uint64_t)s, c, flags, stats->pitch, true, LAYOUT_RETURNS, stream);
+                                         t0 + (uint64_t)s, c, flags, stats->pitch, true, LAYOUT_RETURNS, tape_rows(tape, s, err), stream);
         });
         if (rc) return rc;
     }
     return 0;
+}
+
+int pomdp_collect_returns(int env, const void *params, uint32_t *state, const pomdp_return_stats *stats, uint32_t *err,
+                          int64_t n, uint64_t seed, uint32_t lane0, uint64_t t0, int64_t k_steps, int flags, void *stream)
+{
+    return collect_returns(env, params, state, nullptr, stats, err, n, seed, lane0, t0, k_steps, flags, stream);
+}
+
+int pomdp_collect_tape_returns(int env, const void *params, uint32_t *state, const pomdp_tape *tape,
+                               const pomdp_return_stats *stats, uint32_t *err, int64_t n, uint64_t seed, uint32_t lane0,
+                               uint64_t t0, int64_t k_steps, int flags, void *stream)
+{
+    if (!tape) return POMDP_E_BADARG;
+    return collect_returns(env, params, state, tape, stats, err, n, seed, lane0, t0, k_steps, flags, stream);
 }
 
 int pomdp_decode_packed(int env, const uint32_t *records, int64_t n, int64_t k_steps, int64_t pitch_in, int32_t *action,

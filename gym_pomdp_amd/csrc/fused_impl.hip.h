@@ -17,13 +17,16 @@ namespace pomdp {
 
 // L: the trajectory layout the steps are written in (traj_out.hip.h).  Blocked / Packed: `action` is the trajectory's base,
 // ob / reward / done are not used, and the launch derives its first actions itself (FLAG_GEN_FIRST is always set).
-template <class Env, int LPT, bool SIMPLE, bool TAB = false, class L = Columns>
+// TAPE: the actions are the caller's (TapeRef: uint8 [k_steps][stride]) instead of the synthetic policy's — the general
+// one-lane-per-thread form only (any n, out-of-range actions counted); each lane keeps a four-step window of its column.
+template <class Env, int LPT, bool SIMPLE, bool TAB = false, class L = Columns, bool TAPE = false>
 __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ state, int32_t *__restrict__ action,
                                                       int32_t *__restrict__ ob, typename Env::Reward *__restrict__ reward,
                                                       uint8_t *__restrict__ done, uint32_t *__restrict__ err, int64_t n,
                                                       RngKey key0, uint32_t lane0, int flags, RngKey akey0, int k_steps,
-                                                      int64_t rec, const typename Env::Params p)
+                                                      int64_t rec, const typename Env::Params p, TapeRef tape)
 {
+    static_assert(!TAPE || (LPT == 1 && !SIMPLE && !TAB), "a tape drives the general one-lane-per-thread instantiation");
     __shared__ typename Env::Shared sh;
     // TAB: the lane step reads the (position, action) table built below (RockEnv::step_rec: the lane's packed record and its
     // new state, fresh episode included, in one go); one lane per thread, the quad's blocks time-shared
@@ -63,6 +66,10 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
     uint4 nq0 = make_uint4(0, 0, 0, 0), nq1 = nq0, nq2 = nq0;        // Network: this lane's words of the quad's blocks 0 .. 2 of steps s .. s + 3
     const int n_act = Env::n_actions(p);
     const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo, ta0 = ((uint64_t)akey0.t_hi << 32) | akey0.t_lo;
+    // TAPE: this lane's column of the tape (threads past n read lane n - 1's, like every other per-lane word)
+    typename std::conditional<TAPE, TapeColumn<uint8_t>, NoColumn>::type col(tape, wg0 + (in_range[0] ? rel[0] : last), k_steps);
+    if constexpr (TAPE) a_cur[0] = (int)col.first;
+    else
     if (!COLS || (flags & FLAG_GEN_FIRST)) {             // wave-uniform: the policy's actions of the first call counter
         RngKey fkey = akey0;
         fkey.t_lo = (uint32_t)(ta0 - 1ull); fkey.t_hi = (uint32_t)((ta0 - 1ull) >> 32);
@@ -95,6 +102,7 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
     #pragma unroll 1
     for (int seg = 0, s = 0; seg < 4; ++seg)                               // four priority segments (LoopPrio)
     for (const int seg_end = prio.segment(seg); s < seg_end; ++s) {
+        if constexpr (TAPE) col.request(s);                  // the row of step s + 1: first touched after this step's stores
         RngKey key = key0, akey = akey0;
         key.t_lo = (uint32_t)(t0 + (uint64_t)s); key.t_hi = (uint32_t)((t0 + (uint64_t)s) >> 32);
         akey.t_lo = (uint32_t)(ta0 + (uint64_t)s); akey.t_hi = (uint32_t)((ta0 + (uint64_t)s) >> 32);
@@ -173,7 +181,7 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
         }
         if constexpr (quad_policy) {
             const uint32_t e = glane[0] & 3u;
-            if ((s & 3) == 0) {                                              // this lane's block: the policy of step s + e ...
+            if (!TAPE && (s & 3) == 0) {                                     // this lane's block: the policy of step s + e ...
                 const uint64_t te = ta0 + (uint64_t)s + (uint64_t)e;
                 // ... transposed within the quad: component J is then THIS lane's word of step s + J
                 aq = quad_transpose4(philox4x32_10(glane[0] >> 2, (uint32_t)te, (uint32_t)(te >> 32),
@@ -191,7 +199,7 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
                 Fin::resets_only(sh, p, st, fresh, key, glane);
             }
             const uint32_t word = sj == 0 ? aq.x : sj == 1 ? aq.y : sj == 2 ? aq.z : aq.w;
-            a_next[0] = (int)__umulhi(word, (uint32_t)n_act);
+            if constexpr (!TAPE) a_next[0] = (int)__umulhi(word, (uint32_t)n_act);
         } else {
             Fin::run(sh, p, st, fresh, key, glane, akey, (uint32_t)n_act, a_next, aux, o);
         }
@@ -207,6 +215,7 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
                 else out.put(j, rel[j], a_cur[j], o[j], r[j], rcode, d[j]);
                 if (!valid[j] && !was_done[j] && err) atomicAdd(err, 1u);
             }
+            if constexpr (TAPE) a_next[j] = (int)col.nxt;                   // the tape's row of step s + 1, requested when this step began
             a_cur[j] = a_next[j];
             was_done[j] = auto_reset ? false : (d[j] != 0);
         }
@@ -229,12 +238,12 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
 // actions come in the same way.  The lane step is the table-driven one.  Full workgroups of 1024 lanes and auto-reset
 // only (the launcher's SIMPLE conditions).  Same results as steps_kernel: the mapping of lanes to threads is invisible
 // to a lane's random words.
-template <class Env, class L = Columns>
+template <class Env, class L = Columns, class Pol = SyntheticQuad>
 __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict__ state, int32_t *__restrict__ action,
                                                            int32_t *__restrict__ ob, int32_t *__restrict__ reward,
                                                            uint8_t *__restrict__ done, int64_t n, RngKey key0, uint32_t lane0,
                                                            RngKey akey0, int k_steps, int64_t rec, int gen_first,
-                                                           const typename Env::Params p)
+                                                           const typename Env::Params p, TapeRef tape)
 {
     constexpr int W = Env::WORDS;
     using S = typename Env::S;
@@ -250,11 +259,14 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
     typename Env::State st[4];
     int a_cur[4];
     const uint32_t n_act = (uint32_t)Env::n_actions(p);
+    Pol pol(tape, l0, glane0, key0, akey0, n_act, k_steps);        // where the actions come from: the synthetic policy, or the caller's tape
+    uint32_t n_bad = 0;                                      // tape only: out-of-range actions met
     {
+        u32x4 a4;
         const u32x4 s_lo = ld_stream4(state + l0);
         u32x4 s_hi = {0, 0, 0, 0};
         if (W == 2) s_hi = ld_stream4(state + n + l0);
-        const u32x4 a4 = out.first(gen_first, glane0, akey0, n_act);
+        a4 = out.first(pol, gen_first);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             a_cur[j] = (int)a4[j];
@@ -269,7 +281,7 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
     TL(2);
     const int K = p.num_rocks;
     const uint32_t start = (uint32_t)p.start_x | ((uint32_t)p.start_y << 4);
-    const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo, ta0 = ((uint64_t)akey0.t_hi << 32) | akey0.t_lo;
+    const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo;
     wait_loads();
     const LoopPrio prio(k_steps);
     #pragma unroll 1
@@ -277,14 +289,14 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
     for (const int seg_end = prio.segment(seg); s < seg_end; ++s) {
         RngKey key = key0;
         key.t_lo = (uint32_t)(t0 + (uint64_t)s); key.t_hi = (uint32_t)((t0 + (uint64_t)s) >> 32);
-        const uint64_t ta = ta0 + (uint64_t)s;
         // the quad's sensor words of this step (StochasticRock: block 2 of the stream — block 0 gates the actions, rock.py:443)
-        // — the words its fresh episodes start from as well — and its policy words of the next call counter
+        // — the words its fresh episodes start from as well — and the actions of the next call counter
         constexpr uint32_t SENSOR_BLOCK = Env::SENSOR_BLOCK;
         const uint4 sw = philox4x32_10(glane0 >> 2, key.t_lo, key.t_hi, ((uint32_t)POMDP_STREAM_STEP << 24) | SENSOR_BLOCK, key.k0, key.k1);
         const uint4 rw = sw;                                   // a lane's step draws EITHER its sensor reading OR its next episode
-        const uint4 pw = philox4x32_10(glane0 >> 2, (uint32_t)ta, (uint32_t)(ta >> 32), (uint32_t)POMDP_STREAM_ACTION << 24, key.k0, key.k1);
-        const uint32_t H[4] = {sw.x, sw.y, sw.z, sw.w}, P[4] = {pw.x, pw.y, pw.z, pw.w}, R[4] = {rw.x, rw.y, rw.z, rw.w};
+        uint32_t a_next[4];
+        pol.begin(s, a_next);
+        const uint32_t H[4] = {sw.x, sw.y, sw.z, sw.w}, R[4] = {rw.x, rw.y, rw.z, rw.w};
         bool acts[4] = {true, true, true, true};
         if constexpr (Env::STOCHASTIC) {                                       // the action is applied iff binomial(1, p_move) says so
             const uint4 gw = Env::quad_block(key, glane0, 0u);
@@ -294,27 +306,36 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
                 acts[j] = Env::k53_le(G[j], (uint32_t)(p.act_thr >> 26), (uint32_t)p.act_thr & Env::LO_MASK,
                                       [&]() { return Env::elem(Env::quad_block(key, glane0, 1u), (uint32_t)j); });
         }
-        uint32_t a_next[4], codes[4], rec[4];
+        uint32_t codes[4], rec[4];
         const uint32_t a_taken[4] = {(uint32_t)a_cur[0], (uint32_t)a_cur[1], (uint32_t)a_cur[2], (uint32_t)a_cur[3]};
         Env::reset_codes4(R, key, glane0, K, codes);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint32_t lane = glane0 + (uint32_t)j;
             S sj = st[j].s;
-            Env::step_rec(sh, tab, sj, a_taken[j], H[j], (S)((uint64_t)start | ((uint64_t)codes[j] << 8)), rec[j],
+            // a tape may hold anything: an out-of-range action leaves the lane untouched, (ob, reward, done) = (0, 0, 0), and is counted
+            const bool valid = !Pol::TAPE || a_taken[j] < n_act;
+            Env::step_rec(sh, tab, sj, valid ? a_taken[j] : 0u, H[j], (S)((uint64_t)start | ((uint64_t)codes[j] << 8)), rec[j],
                           [&]() { return Env::elem(Env::quad_block(key, lane, SENSOR_BLOCK + 1u), (uint32_t)j); });
             if constexpr (Env::STOCHASTIC) {                                // the gate said no (rock.py:443): nothing happens
                 sj = acts[j] ? sj : st[j].s;
                 rec[j] = acts[j] ? rec[j] : a_taken[j];
             }
+            if constexpr (Pol::TAPE) {
+                sj = valid ? sj : st[j].s;
+                rec[j] = valid ? rec[j] : a_taken[j];
+                n_bad += (uint32_t)!valid;
+            }
             st[j].s = sj;
-            a_next[j] = __umulhi(P[j], n_act);
-            a_cur[j] = (int)a_next[j];
         }
         out.put_records(rec, a_next);
+        pol.end(s, a_next);                                  // the actions of step s + 1 (a tape's row arrives here)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a_cur[j] = (int)a_next[j];
     }
     // the state is the loop's carry: it reaches memory once
     TL(3);
+    pol.count_bad(n_bad);
     out.finish(k_steps);
     st_stream4(state + l0, (uint32_t)st[0].s, (uint32_t)st[1].s, (uint32_t)st[2].s, (uint32_t)st[3].s);
     if (W == 2)
@@ -332,12 +353,12 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
 // them where they stand.  (Until round 5 both had per-lane blocks, pooled per wave of 256 lanes through LDS: two ballots, a rank
 // and an LDS round trip per lane for one Philox pass — 70 of the loop's 273 vector instructions per thread-step.)  The outputs
 // leave as 16-byte stores.
-template <bool TAB, class L = Columns>   // TAB: the lane step reads the (cells, action) table built when the launch starts (from 16 steps per launch)
+template <bool TAB, class L = Columns, class Pol = SyntheticQuad>   // TAB: the lane step reads the (cells, action) table built when the launch starts (from 16 steps per launch)
 __global__ __launch_bounds__(BLOCK) void tag_steps_quad_kernel(uint32_t *__restrict__ state, int32_t *__restrict__ action,
                                                                int32_t *__restrict__ ob, float *__restrict__ reward,
                                                                uint8_t *__restrict__ done, int64_t n, RngKey key0,
                                                                uint32_t lane0, RngKey akey0, int k_steps, int64_t rec,
-                                                               int gen_first, const TagEnv::Params p)
+                                                               int gen_first, const TagEnv::Params p, TapeRef tape)
 {
     using Env = TagEnv;
     __shared__ Env::Shared sh;
@@ -348,9 +369,11 @@ __global__ __launch_bounds__(BLOCK) void tag_steps_quad_kernel(uint32_t *__restr
     Env::State st[4];
     int a_cur[4];
     const uint32_t n_act = (uint32_t)Env::n_actions(p);
+    Pol pol(tape, l0, glane0, key0, akey0, n_act, k_steps);
+    uint32_t n_bad = 0;
     {
         const u32x4 s4 = ld_stream4(state + l0);
-        const u32x4 a4 = out.first(gen_first, glane0, akey0, n_act);
+        const u32x4 a4 = out.first(pol, gen_first);
 #pragma unroll
         for (int j = 0; j < 4; ++j) { a_cur[j] = (int)a4[j]; st[j].w = s4[j]; }
     }
@@ -360,7 +383,7 @@ __global__ __launch_bounds__(BLOCK) void tag_steps_quad_kernel(uint32_t *__restr
         Env::build_tab(tab, sh, p, (int)threadIdx.x);
         __syncthreads();
     }
-    const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo, ta0 = ((uint64_t)akey0.t_hi << 32) | akey0.t_lo;
+    const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo;
     wait_loads();
     const LoopPrio prio(k_steps);
     #pragma unroll 1
@@ -368,25 +391,26 @@ __global__ __launch_bounds__(BLOCK) void tag_steps_quad_kernel(uint32_t *__restr
     for (const int seg_end = prio.segment(seg); s < seg_end; ++s) {
         RngKey key = key0;
         key.t_lo = (uint32_t)(t0 + (uint64_t)s); key.t_hi = (uint32_t)((t0 + (uint64_t)s) >> 32);
-        const uint64_t ta = ta0 + (uint64_t)s;
-        const uint4 pw = philox4x32_10(glane0 >> 2, (uint32_t)ta, (uint32_t)(ta >> 32), (uint32_t)POMDP_STREAM_ACTION << 24, key.k0, key.k1);
-        const uint32_t P[4] = {pw.x, pw.y, pw.z, pw.w};
+        uint32_t a_next[4];
+        pol.begin(s, a_next);
         int o[4], d[4];
         float r[4];
         const uint32_t a_taken[4] = {(uint32_t)a_cur[0], (uint32_t)a_cur[1], (uint32_t)a_cur[2], (uint32_t)a_cur[3]};
         const uint4 qw = Env::quad_block(key, glane0, 0u);
         const uint32_t W[4] = {qw.x, qw.y, qw.z, qw.w};
-        uint32_t a_next[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             Env::Flight f;
-            if constexpr (TAB) Env::step_one_opponent_tab(tab, st[j], a_cur[j], o[j], r[j], d[j], f);
-            else Env::step_one_opponent_pre(sh, p, st[j], a_cur[j], o[j], r[j], d[j], f);
+            const bool valid = !Pol::TAPE || a_taken[j] < n_act;      // a tape's out-of-range action: the lane is left untouched and counted
+            const Env::State before = st[j];
+            const int a = valid ? a_cur[j] : 0;
+            if constexpr (TAB) Env::step_one_opponent_tab(tab, st[j], a, o[j], r[j], d[j], f);
+            else Env::step_one_opponent_pre(sh, p, st[j], a, o[j], r[j], d[j], f);
             const uint32_t lane = glane0 + (uint32_t)j;
+            if constexpr (Pol::TAPE) { if (!valid) { f.need = false; o[j] = 0; r[j] = 0.f; d[j] = 0; n_bad++; } }
             Env::flee_word(sh, p, st[j], f, W[j], [&]() { return Env::elem(Env::quad_block(key, lane, 1u), (uint32_t)j); });
             if (d[j]) Env::auto_reset_word(p, st[j], W[j], key, lane);
-            a_next[j] = __umulhi(P[j], n_act);
-            a_cur[j] = (int)a_next[j];
+            if constexpr (Pol::TAPE) st[j] = valid ? st[j] : before;
         }
         const uint32_t o4[4] = {(uint32_t)o[0], (uint32_t)o[1], (uint32_t)o[2], (uint32_t)o[3]};
         const uint32_t r4[4] = {__float_as_uint(r[0]), __float_as_uint(r[1]), __float_as_uint(r[2]), __float_as_uint(r[3])};
@@ -397,7 +421,11 @@ __global__ __launch_bounds__(BLOCK) void tag_steps_quad_kernel(uint32_t *__restr
             for (int j = 0; j < 4; ++j) rc[j] = Env::reward_code(r[j]);
         }
         out.put(a_taken, a_next, o4, r4, rc, d4);
+        pol.end(s, a_next);                                  // the actions of step s + 1 (a tape's row arrives here)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a_cur[j] = (int)a_next[j];
     }
+    pol.count_bad(n_bad);
     out.finish(k_steps);
     st_stream4(state + l0, st[0].w, st[1].w, st[2].w, st[3].w);
 }
@@ -424,12 +452,12 @@ static __device__ __forceinline__ uint32_t pk_sub_sat_u16(uint32_t a, uint32_t b
     __builtin_memcpy(&r, &d, 4);
     return r;
 }
-template <int NB, class L = Columns, bool SMALL = false>   // NB: bytes of the machine set, ceil(n_machines / 8)
+template <int NB, class L = Columns, bool SMALL = false, class Pol = SyntheticQuad>   // NB: bytes of the machine set, ceil(n_machines / 8)
 __global__ __launch_bounds__(BLOCK) void network_steps_quad_kernel(uint32_t *__restrict__ state, int32_t *__restrict__ action,
                                                                    int32_t *__restrict__ ob, float *__restrict__ reward,
                                                                    uint8_t *__restrict__ done, int64_t n, RngKey key0,
                                                                    uint32_t lane0, RngKey akey0, int k_steps, int64_t rec,
-                                                                   int gen_first, const NetworkEnv::Params p)
+                                                                   int gen_first, const NetworkEnv::Params p, TapeRef tape)
 {
     using Env = NetworkEnv;
     __shared__ Env::Shared sh;                               // the nibble tables of the exact per-lane form (ties only)
@@ -450,9 +478,11 @@ __global__ __launch_bounds__(BLOCK) void network_steps_quad_kernel(uint32_t *__r
     const uint32_t n_act = (uint32_t)Env::n_actions(p);
     uint32_t st[4];
     int a_cur[4];
+    Pol pol(tape, l0, glane0, key0, akey0, n_act, k_steps);
+    uint32_t n_bad = 0;
     {
         const u32x4 s4 = ld_stream4(state + l0);
-        const u32x4 a4 = out.first(gen_first, glane0, akey0, n_act);
+        const u32x4 a4 = out.first(pol, gen_first);
 #pragma unroll
         for (int j = 0; j < 4; ++j) { a_cur[j] = (int)a4[j]; st[j] = s4[j]; }
     }
@@ -495,7 +525,7 @@ __global__ __launch_bounds__(BLOCK) void network_steps_quad_kernel(uint32_t *__r
     __syncthreads();
     const uint32_t all_up = p.n_machines >= 32 ? 0xFFFFFFFFu : ((1u << p.n_machines) - 1u);
     const int M2 = 2 * p.n_machines;
-    const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo, ta0 = ((uint64_t)akey0.t_hi << 32) | akey0.t_lo;
+    const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo;
     wait_loads();
     const LoopPrio prio(k_steps);
     #pragma unroll 1
@@ -503,11 +533,22 @@ __global__ __launch_bounds__(BLOCK) void network_steps_quad_kernel(uint32_t *__r
     for (const int seg_end = prio.segment(seg); s < seg_end; ++s) {
         RngKey key = key0;
         key.t_lo = (uint32_t)(t0 + (uint64_t)s); key.t_hi = (uint32_t)((t0 + (uint64_t)s) >> 32);
-        const uint64_t ta = ta0 + (uint64_t)s;
-        const uint4 pw = philox4x32_10(glane0 >> 2, (uint32_t)ta, (uint32_t)(ta >> 32), (uint32_t)POMDP_STREAM_ACTION << 24, key.k0, key.k1);
+        uint32_t a_next[4];
+        pol.begin(s, a_next);
         const uint4 q0 = Env::quad_block(key, glane0, 0u), q1 = Env::quad_block(key, glane0, 1u), q2 = Env::quad_block(key, glane0, 2u);
-        const uint32_t P[4] = {pw.x, pw.y, pw.z, pw.w}, W0[4] = {q0.x, q0.y, q0.z, q0.w}, W1[4] = {q1.x, q1.y, q1.z, q1.w};
+        const uint32_t W0[4] = {q0.x, q0.y, q0.z, q0.w}, W1[4] = {q1.x, q1.y, q1.z, q1.w};
         const uint32_t W2[4] = {q2.x, q2.y, q2.z, q2.w};
+        // a tape's out-of-range action draws like "no action" (the same random words are consumed); the lane is then left untouched
+        bool valid[4] = {true, true, true, true};
+        if constexpr (Pol::TAPE) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { valid[j] = (uint32_t)a_cur[j] < n_act; n_bad += (uint32_t)!valid[j]; }
+        }
+        const uint32_t a_taken[4] = {(uint32_t)a_cur[0], (uint32_t)a_cur[1], (uint32_t)a_cur[2], (uint32_t)a_cur[3]};
+        if constexpr (Pol::TAPE) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a_cur[j] = valid[j] ? a_cur[j] : M2;
+        }
         uint32_t kill[4], todo[4], near[4], tie16[4];
         int base[4];
         bool truthful[4], pend[4], need[4];
@@ -585,13 +626,14 @@ __global__ __launch_bounds__(BLOCK) void network_steps_quad_kernel(uint32_t *__r
                 }
             }
         }
-        uint32_t o4[4], r4[4], a_next[4], rc[4] = {0, 0, 0, 0};
-        const uint32_t a_taken[4] = {(uint32_t)a_cur[0], (uint32_t)a_cur[1], (uint32_t)a_cur[2], (uint32_t)a_cur[3]};
+        uint32_t o4[4], r4[4], rc[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             int o;
             float r;
-            if (tie16[j] != 0u || near[j] < Env::TIE) {                        // a draw decided below its top 16 bits: the exact per-lane form
+            if (Pol::TAPE && !valid[j]) {                                      // untouched: (ob, reward, done) = (0, 0, 0)
+                o = 0; r = 0.f;
+            } else if (tie16[j] != 0u || near[j] < Env::TIE) {                 // a draw decided below its top 16 bits: the exact per-lane form
                 Env::State e{st[j] & all_up};
                 int d;
                 Env::step_exact(sh, p, e, a_cur[j], key, glane0 + (uint32_t)j, o, r, d);
@@ -610,12 +652,14 @@ __global__ __launch_bounds__(BLOCK) void network_steps_quad_kernel(uint32_t *__r
             }
             o4[j] = (uint32_t)o;
             r4[j] = __float_as_uint(r);
-            a_next[j] = __umulhi(P[j], n_act);
-            a_cur[j] = (int)a_next[j];
         }
         const uint32_t d4[4] = {0u, 0u, 0u, 0u};                               // network.py:113: never done
         out.put(a_taken, a_next, o4, r4, rc, d4);
+        pol.end(s, a_next);                                  // the actions of step s + 1 (a tape's row arrives here)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a_cur[j] = (int)a_next[j];
     }
+    pol.count_bad(n_bad);
     out.finish(k_steps);
     st_stream4(state + l0, st[0], st[1], st[2], st[3]);
 }
@@ -633,12 +677,12 @@ __global__ __launch_bounds__(BLOCK) void network_steps_quad_kernel(uint32_t *__r
 // 137-143 registers by the compiler's own choice — three waves per SIMD, where a 2^20-lane launch has four workgroups per CU
 // to place.  waves_per_eu(4) holds it to 128 (1 = no constraint, for the trajectory sinks).
 template <class L, int MW> struct quad_waves { static constexpr int value = (L::ID == LAYOUT_RETURNS && MW >= 3) ? 4 : 1; };
-template <int MW, class L = Columns>
+template <int MW, class L = Columns, class Pol = SyntheticQuad>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(quad_waves<L, MW>::value))) void battleship_steps_quad_kernel(uint32_t *__restrict__ state, int32_t *__restrict__ action,
                                                                       int32_t *__restrict__ ob, int32_t *__restrict__ reward,
                                                                       uint8_t *__restrict__ done, int64_t n, RngKey key0,
                                                                       uint32_t lane0, RngKey akey0, int k_steps, int64_t rec,
-                                                                      int gen_first, const pomdp_battleship_params p)
+                                                                      int gen_first, const pomdp_battleship_params p, TapeRef tape)
 {
     using Env = BattleShipEnv<MW>;
     using Mask = typename Env::Mask;
@@ -658,11 +702,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(quad_wave
     const uint32_t n_act = (uint32_t)Env::n_actions(p);
     Mask vis[4];
     int a_cur[4];
+    Pol pol(tape, l0, glane0, key0, akey0, n_act, k_steps);
+    uint32_t n_bad = 0;
     {
         u32x4 w[3 * MW];
 #pragma unroll
         for (int q = 0; q < 3 * MW; ++q) w[q] = ld_stream4(state + (int64_t)q * n + l0);
-        const u32x4 a4 = out.first(gen_first, glane0, akey0, n_act);
+        const u32x4 a4 = out.first(pol, gen_first);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             a_cur[j] = (int)a4[j];
@@ -673,7 +719,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(quad_wave
     }
     __syncthreads();
     const int cells = p.x_size * p.y_size;
-    const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo, ta0 = ((uint64_t)akey0.t_hi << 32) | akey0.t_lo;
+    const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo;
     int pend[4] = {-1, -1, -1, -1};                          // >= 0: the step at which the lane's board was dealt; its `next` is yet to be built
     // the boards of every waiting lane of the wave (wave-uniform control flow; the scratch and the mask slots are the wave's own)
     auto build_boards = [&]() {
@@ -736,18 +782,23 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(quad_wave
     #pragma unroll 1
     for (int seg = 0, s = 0; seg < 4; ++seg)                               // four priority segments (LoopPrio)
     for (const int seg_end = prio.segment(seg); s < seg_end; ++s) {
+        const uint32_t a_taken[4] = {(uint32_t)a_cur[0], (uint32_t)a_cur[1], (uint32_t)a_cur[2], (uint32_t)a_cur[3]};
+        bool valid[4] = {true, true, true, true};
+        if constexpr (Pol::TAPE) {               // a tape's out-of-range shot: the lane is left untouched, (0, 0, 0), and counted
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { valid[j] = a_taken[j] < n_act; n_bad += (uint32_t)!valid[j]; a_cur[j] = valid[j] ? a_cur[j] : 0; }
+        }
         uint32_t ow[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) ow[j] = occ_lds[a_cur[j] >> 5][j][tid];   // the ship-mask word this shot tests
-        const uint64_t ta = ta0 + (uint64_t)s;
-        const uint4 pw = philox4x32_10(glane0 >> 2, (uint32_t)ta, (uint32_t)(ta >> 32), (uint32_t)POMDP_STREAM_ACTION << 24, akey0.k0, akey0.k1);
-        const uint32_t P[4] = {pw.x, pw.y, pw.z, pw.w};
-        uint32_t o4[4], r4[4], a_next[4], d4[4];
-        const uint32_t a_taken[4] = {(uint32_t)a_cur[0], (uint32_t)a_cur[1], (uint32_t)a_cur[2], (uint32_t)a_cur[3]};
+        uint32_t a_next[4];
+        pol.begin(s, a_next);
+        uint32_t o4[4], r4[4], d4[4];
         bool d[4], again = false;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {                                          // battleship.py:91-122: draws nothing
             const int a = a_cur[j];
+            const Mask vis_before = vis[j];
             const uint32_t last = vis[j].word(MW - 1);
             int remaining = (int)(last >> 26), r;
             const bool visited = Env::bit(vis[j], a), hit = (ow[j] >> (a & 31)) & 1u;
@@ -756,13 +807,16 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(quad_wave
             d[j] = remaining == 0;
             if (d[j]) r += cells;
             vis[j].set_word(MW - 1, (vis[j].word(MW - 1) & 0x03FFFFFFu) | ((uint32_t)remaining << 26));
+            uint32_t ob_j = (uint32_t)(!visited && hit);
+            if constexpr (Pol::TAPE) { if (!valid[j]) { vis[j] = vis_before; d[j] = false; r = 0; ob_j = 0; } }
             again |= d[j] && pend[j] >= 0;
-            o4[j] = (uint32_t)(!visited && hit); r4[j] = (uint32_t)r;
+            o4[j] = ob_j; r4[j] = (uint32_t)r;
             d4[j] = (uint32_t)d[j];
-            a_next[j] = __umulhi(P[j], n_act);
-            a_cur[j] = (int)a_next[j];
         }
         out.put(a_taken, a_next, o4, r4, r4, d4);                              // the int8 reward IS its code
+        pol.end(s, a_next);                                  // the actions of step s + 1 (a tape's row arrives here)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a_cur[j] = (int)a_next[j];
         if (__any(again)) build_boards();                                      // a second episode ended before the lane's next board exists
         if (__any(d[0] || d[1] || d[2] || d[3])) {                             // wave-uniform: the cached boards move in
 #pragma unroll
@@ -779,6 +833,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(quad_wave
         }
     }
     build_boards();
+    pol.count_bad(n_bad);
     out.finish(k_steps);
 #pragma unroll
     for (int q = 0; q < MW; ++q) {
@@ -797,13 +852,13 @@ template <class Env> struct quad_tab<Env, std::enable_if_t<Env::QUAD_TAB>> : std
 template <class Env, class = void> struct quad_fused : std::false_type {};
 template <class Env> struct quad_fused<Env, std::enable_if_t<Env::QUAD_FUSED>> : std::true_type {};
 
-template <class Env, class L = Columns>
+template <class Env, class L = Columns, class Pol = SyntheticQuad>
 __global__ __launch_bounds__(BLOCK) void steps_quad_generic_kernel(uint32_t *__restrict__ state, int32_t *__restrict__ action,
                                                                    int32_t *__restrict__ ob,
                                                                    typename Env::Reward *__restrict__ reward,
                                                                    uint8_t *__restrict__ done, int64_t n, RngKey key0,
                                                                    uint32_t lane0, RngKey akey0, int k_steps, int64_t rec,
-                                                                   int gen_first, const typename Env::Params p)
+                                                                   int gen_first, const typename Env::Params p, TapeRef tape)
 {
     static_assert(Env::WORDS == 1 && sizeof(typename Env::Reward) == 4, "one state word, 4-byte rewards");
     __shared__ typename Env::Shared sh;
@@ -813,16 +868,18 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_generic_kernel(uint32_t *__r
     typename Env::State st[4];
     int a_cur[4];
     const uint32_t n_act = (uint32_t)Env::n_actions(p);
+    Pol pol(tape, l0, glane0, key0, akey0, n_act, k_steps);
+    uint32_t n_bad = 0;
     {
 #pragma unroll
         for (int j = 0; j < 4; ++j) Env::load(st[j], state, n, l0 + (uint32_t)j);
-        const u32x4 a4 = out.first(gen_first, glane0, akey0, n_act);
+        const u32x4 a4 = out.first(pol, gen_first);
 #pragma unroll
         for (int j = 0; j < 4; ++j) a_cur[j] = (int)a4[j];
     }
     Env::stage(sh, p, (int)threadIdx.x);
     __syncthreads();
-    const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo, ta0 = ((uint64_t)akey0.t_hi << 32) | akey0.t_lo;
+    const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo;
     wait_loads();
     const LoopPrio prio(k_steps);
     #pragma unroll 1
@@ -830,10 +887,9 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_generic_kernel(uint32_t *__r
     for (const int seg_end = prio.segment(seg); s < seg_end; ++s) {
         RngKey key = key0;
         key.t_lo = (uint32_t)(t0 + (uint64_t)s); key.t_hi = (uint32_t)((t0 + (uint64_t)s) >> 32);
-        const uint64_t ta = ta0 + (uint64_t)s;
-        const uint4 pw = philox4x32_10(glane0 >> 2, (uint32_t)ta, (uint32_t)(ta >> 32), (uint32_t)POMDP_STREAM_ACTION << 24, key.k0, key.k1);
-        const uint32_t P[4] = {pw.x, pw.y, pw.z, pw.w};
-        uint32_t o4[4], r4[4], a_next[4], d4[4], rc[4] = {0, 0, 0, 0};
+        uint32_t a_next[4];
+        pol.begin(s, a_next);
+        uint32_t o4[4], r4[4], d4[4], rc[4] = {0, 0, 0, 0};
         const uint32_t a_taken[4] = {(uint32_t)a_cur[0], (uint32_t)a_cur[1], (uint32_t)a_cur[2], (uint32_t)a_cur[3]};
         uint32_t W[4] = {0, 0, 0, 0};                                          // Tiger: the quad's STEP block IS the thread's four words
         if constexpr (quad_word_env<Env>::value) {
@@ -845,20 +901,26 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_generic_kernel(uint32_t *__r
             int o, d;
             typename Env::Reward r;
             const uint32_t lane = glane0 + (uint32_t)j;
+            const bool valid = !Pol::TAPE || a_taken[j] < n_act;               // a tape's out-of-range action: untouched, (0, 0, 0), counted
+            const typename Env::State before = st[j];
+            const int a = valid ? a_cur[j] : 0;
             if constexpr (quad_word_env<Env>::value)
-                Env::step_word(p, st[j], a_cur[j], W[j], [&]() { return Env::elem(Env::quad_block(key, lane, 1u), (uint32_t)j); }, o, r, d);
+                Env::step_word(p, st[j], a, W[j], [&]() { return Env::elem(Env::quad_block(key, lane, 1u), (uint32_t)j); }, o, r, d);
             else
-                Env::step(sh, p, st[j], a_cur[j], key, lane, o, r, d);
+                Env::step(sh, p, st[j], a, key, lane, o, r, d);
+            if constexpr (Pol::TAPE) { if (!valid) { st[j] = before; o = 0; r = 0; d = 0; n_bad++; } }
             Env::reset_where(sh, p, st[j], d != 0, key, lane);                 // wave-convergent: every lane calls it
             o4[j] = (uint32_t)o;
             __builtin_memcpy(&r4[j], &r, 4);
             if constexpr (L::CODES) rc[j] = Env::reward_code(r);
             d4[j] = (uint32_t)(d != 0);
-            a_next[j] = __umulhi(P[j], n_act);
-            a_cur[j] = (int)a_next[j];
         }
         out.put(a_taken, a_next, o4, r4, rc, d4);
+        pol.end(s, a_next);                                  // the actions of step s + 1 (a tape's row arrives here)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a_cur[j] = (int)a_next[j];
     }
+    pol.count_bad(n_bad);
     out.finish(k_steps);
 #pragma unroll
     for (int j = 0; j < 4; ++j) Env::store(st[j], state, n, l0 + (uint32_t)j, true);
@@ -870,15 +932,21 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_generic_kernel(uint32_t *__r
 // trajectory's base — row-major, `rec` lanes per row —, ob / reward / done are ignored, auto-reset and the shared policy key
 // are required and every launch derives its first actions itself.  Returns<Env> (pomdp_collect_returns): `action` = the
 // statistics' double rows, `ob` = their int32 rows, `reward` = the discount's bit pattern, `rec` = their pitch.
+// tape.base != nullptr (pomdp_collect_tape*): the k steps take the caller's actions, row s of the tape at step s; the
+// column layout then has no `action` column (ColumnsNoAct).  The quad-per-thread loops when the batch qualifies for them
+// (and the tape's rows start on 4-byte boundaries), the general one-lane-per-thread loop otherwise.
 template <class Env, class L>
 static int launch_steps_fused_l(const typename Env::Params &p, uint32_t *state, int32_t *action, int32_t *ob,
                                 typename Env::Reward *reward, uint8_t *done, uint32_t *err, int64_t n, uint64_t seed,
                                 uint64_t action_seed, uint32_t lane0, uint64_t t, int k, int flags, int64_t rec, bool gen_first,
-                                void *stream)
+                                TapeRef tape, void *stream)
 {
     constexpr bool COLS = L::ID == POMDP_LAYOUT_COLUMNS;
-    if (!state || !action || bad_range(n, lane0) || (lane0 & 3u) || k < 1) return POMDP_E_BADARG;
+    const bool taped = tape.base != nullptr;
+    if (!state || (!action && !(COLS && taped)) || bad_range(n, lane0) || (lane0 & 3u) || k < 1) return POMDP_E_BADARG;
     if (COLS && (!ob || !reward || !done)) return POMDP_E_BADARG;
+    if (taped && (std::is_same<L, Columns>::value || tape.stride < n)) return POMDP_E_BADARG;
+    if (taped) action_seed = seed;                          // no policy key is involved
     constexpr bool RETS = L::ID == LAYOUT_RETURNS;
     if (!COLS) {
         if (!(flags & POMDP_AUTO_RESET) || action_seed != seed || rec < n) return POMDP_E_BADARG;
@@ -890,12 +958,12 @@ static int launch_steps_fused_l(const typename Env::Params &p, uint32_t *state, 
         done = nullptr;
     }
     if (n == 0) return 0;
-    char lname[24] = "";
-    if (!COLS) snprintf(lname, sizeof lname, ", %s", L::NAME);
+    char lname[32] = "";
+    snprintf(lname, sizeof lname, "%s%s%s", COLS ? "" : ", ", COLS ? "" : L::NAME, taped ? ", Tape" : "");
     // two lanes per thread from 2^19 lanes, where the batch does not qualify for a quad-per-thread loop: at 2^18 lanes the
     // one-lane-per-thread loops take 0.90 (RockSample; 1.09 with two) and 1.08 us per step (Tag)
-    const bool lpt2 = Env::POOLED_LPT2 && n >= 2 * LPT2_MIN_LANES;
-    const bool simple = (flags & POMDP_AUTO_RESET) && n % (lpt2 ? 2 * BLOCK : BLOCK) == 0;
+    const bool lpt2 = Env::POOLED_LPT2 && n >= 2 * LPT2_MIN_LANES && !taped;
+    const bool simple = (flags & POMDP_AUTO_RESET) && n % (lpt2 ? 2 * BLOCK : BLOCK) == 0 && !taped;
     const dim3 grid(lpt2 ? (unsigned)((n + 2 * BLOCK - 1) / (2 * BLOCK)) : blocks_for(n));
     const int kflags = (flags & POMDP_AUTO_RESET) | (gen_first ? FLAG_GEN_FIRST : 0);
     const int gf = gen_first ? 1 : 0;
@@ -906,7 +974,18 @@ static int launch_steps_fused_l(const typename Env::Params &p, uint32_t *state, 
         note_fused("steps_kernel", Env::NAME, variant);                                                                  \
         hipLaunchKernelGGL((steps_kernel<Env, LPT_, SIMPLE_, false, L>), GRID_, dim3(BLOCK), 0, (hipStream_t)stream, state, \
                            action, ob, reward, done, err, n, make_key(seed, t), lane0, kflags, make_key(action_seed, t + 1), \
-                           k, rec, p);                                                                                   \
+                           k, rec, p, tape);                                                                             \
+    } while (0)
+    // a quad-per-thread loop with the policy the launch asked for: KERNEL<..., L, Pol>
+#define POMDP_QUAD_ARGS state, action, ob, reward, done, n, make_key(seed, t), lane0, make_key(action_seed, t + 1), k, rec, gf, p, tape
+#define POMDP_LAUNCH_QUAD(...)                                                                                           \
+    do {      /* (only the pairs that can occur are instantiated: Columns never rides a tape, ColumnsNoAct always does) */ \
+        if constexpr (!std::is_same<L, Columns>::value) {                                                                \
+            if (taped) hipLaunchKernelGGL((__VA_ARGS__, TapeQuad>), qgrid, dim3(BLOCK), 0, (hipStream_t)stream, POMDP_QUAD_ARGS); \
+        }                                                                                                                \
+        if constexpr (!std::is_same<L, ColumnsNoAct>::value) {                                                           \
+            if (!taped) hipLaunchKernelGGL((__VA_ARGS__, SyntheticQuad>), qgrid, dim3(BLOCK), 0, (hipStream_t)stream, POMDP_QUAD_ARGS); \
+        }                                                                                                                \
     } while (0)
     // RockSample's pooled passes exist for any number of lanes per thread; in the fused loop (no load latency to hide)
     // four per thread, with fuller passes, beat two by 5 % from 2^20 lanes up (3.97 vs 4.16 us per step) when the state
@@ -917,22 +996,21 @@ static int launch_steps_fused_l(const typename Env::Params &p, uint32_t *state, 
     bool quad_ok = (reinterpret_cast<uintptr_t>(state) & 15u) == 0 && rec % 4 == 0 && action_seed == seed &&
                    (flags & POMDP_AUTO_RESET) && n % (4 * BLOCK) == 0;
     if (COLS)
-        quad_ok = quad_ok && ((reinterpret_cast<uintptr_t>(action) | reinterpret_cast<uintptr_t>(ob) | reinterpret_cast<uintptr_t>(reward)) & 15u) == 0 &&
+        quad_ok = quad_ok && ((reinterpret_cast<uintptr_t>(taped ? nullptr : action) | reinterpret_cast<uintptr_t>(ob) | reinterpret_cast<uintptr_t>(reward)) & 15u) == 0 &&
                   (reinterpret_cast<uintptr_t>(done) & 3u) == 0;
     else
         quad_ok = quad_ok && (reinterpret_cast<uintptr_t>(action) & 15u) == 0 && (!RETS || (reinterpret_cast<uintptr_t>(ob) & 15u) == 0);
+    if (taped) quad_ok = quad_ok && (reinterpret_cast<uintptr_t>(tape.base) & 3u) == 0 && tape.stride % 4 == 0;   // a quad's row = one dword
     const dim3 qgrid((unsigned)(n / (4 * BLOCK)));
     bool launched = false;
     if constexpr (std::is_same<Env, TagEnv>::value) {
         if (quad_ok && n >= QUAD_MIN_TAG && p.num_opponents == 1) {
             if (k >= 16 && TagEnv::tab_ok(p)) {
                 note_fused("tag_steps_quad_kernel", "true", lname);
-                hipLaunchKernelGGL((tag_steps_quad_kernel<true, L>), qgrid, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob, reward,
-                                   done, n, make_key(seed, t), lane0, make_key(action_seed, t + 1), k, rec, gf, p);
+                POMDP_LAUNCH_QUAD(tag_steps_quad_kernel<true, L);
             } else {
                 note_fused("tag_steps_quad_kernel", "false", lname);
-                hipLaunchKernelGGL((tag_steps_quad_kernel<false, L>), qgrid, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob, reward,
-                                   done, n, make_key(seed, t), lane0, make_key(action_seed, t + 1), k, rec, gf, p);
+                POMDP_LAUNCH_QUAD(tag_steps_quad_kernel<false, L);
             }
             launched = true;
         }
@@ -940,8 +1018,7 @@ static int launch_steps_fused_l(const typename Env::Params &p, uint32_t *state, 
     if constexpr (has_next<Env>::value) {
         if (quad_ok && n >= QUAD_MIN_BATTLESHIP && k <= 256) {   // the pool keeps a lane's deal step in a byte
             note_fused("battleship_steps_quad_kernel", Env::NAME, lname);
-            hipLaunchKernelGGL((battleship_steps_quad_kernel<Env::WORDS / 3, L>), qgrid, dim3(BLOCK), 0, (hipStream_t)stream, state, action,
-                               ob, reward, done, n, make_key(seed, t), lane0, make_key(action_seed, t + 1), k, rec, gf, p);
+            POMDP_LAUNCH_QUAD(battleship_steps_quad_kernel<Env::WORDS / 3, L);
             launched = true;
         }
     }
@@ -950,30 +1027,24 @@ static int launch_steps_fused_l(const typename Env::Params &p, uint32_t *state, 
             // named as a profiler shows the instantiation: <bytes of the machine set, layout, state-table form>
             // the state-table form: the reference's default has 10 machines; its packed thresholds are T16 - 1
             const bool small = p.n_machines <= 10 && (p.fail_thr >> 37) != 0 && (p.fail_nb_thr >> 37) != 0;
-            snprintf(variant, sizeof variant, "%d, %s, %s", small ? 2 : (p.n_machines + 7) / 8, L::NAME, small ? "true" : "false");
+            snprintf(variant, sizeof variant, "%d, %s, %s%s", small ? 2 : (p.n_machines + 7) / 8, L::NAME, small ? "true" : "false", taped ? ", Tape" : "");
             note_fused("network_steps_quad_kernel", variant, "");
-#define POMDP_LAUNCH_NET(NB_)                                                                                            \
-    hipLaunchKernelGGL((network_steps_quad_kernel<NB_, L>), qgrid, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob, reward, \
-                       done, n, make_key(seed, t), lane0, make_key(action_seed, t + 1), k, rec, gf, p)
             if (small) {                     // the state-table form (the reference's default has 10 machines)
-                hipLaunchKernelGGL((network_steps_quad_kernel<2, L, true>), qgrid, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob,
-                                   reward, done, n, make_key(seed, t), lane0, make_key(action_seed, t + 1), k, rec, gf, p);
+                POMDP_LAUNCH_QUAD(network_steps_quad_kernel<2, L, true);
             } else
             switch ((p.n_machines + 7) / 8) {
-            case 1: POMDP_LAUNCH_NET(1); break;
-            case 2: POMDP_LAUNCH_NET(2); break;
-            case 3: POMDP_LAUNCH_NET(3); break;
-            default: POMDP_LAUNCH_NET(4); break;
+            case 1: POMDP_LAUNCH_QUAD(network_steps_quad_kernel<1, L, false); break;
+            case 2: POMDP_LAUNCH_QUAD(network_steps_quad_kernel<2, L, false); break;
+            case 3: POMDP_LAUNCH_QUAD(network_steps_quad_kernel<3, L, false); break;
+            default: POMDP_LAUNCH_QUAD(network_steps_quad_kernel<4, L, false); break;
             }
-#undef POMDP_LAUNCH_NET
             launched = true;
         }
     }
     if constexpr (quad_fused<Env>::value) {
         if (quad_ok && n >= QUAD_MIN_GENERIC) {
             note_fused("steps_quad_generic_kernel", Env::NAME, lname);
-            hipLaunchKernelGGL((steps_quad_generic_kernel<Env, L>), qgrid, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob,
-                               reward, done, n, make_key(seed, t), lane0, make_key(action_seed, t + 1), k, rec, gf, p);
+            POMDP_LAUNCH_QUAD(steps_quad_generic_kernel<Env, L);
             launched = true;
         }
     }
@@ -982,11 +1053,22 @@ static int launch_steps_fused_l(const typename Env::Params &p, uint32_t *state, 
         // thread owns a quad of consecutive lanes (steps_quad_kernel: RockSample and StochasticRock)
         if (quad_ok && n >= (Env::STOCHASTIC ? QUAD_MIN_STOCHROCK : QUAD_MIN_ROCK) && k >= 16 && p.num_rocks + 5 <= Env::TAB_ACTIONS) {
             note_fused("steps_quad_kernel", Env::NAME, lname);
-            hipLaunchKernelGGL((steps_quad_kernel<Env, L>), qgrid, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob, reward,
-                               done, n, make_key(seed, t), lane0, make_key(action_seed, t + 1), k, rec, gf, p);
+            POMDP_LAUNCH_QUAD(steps_quad_kernel<Env, L);
             launched = true;
         }
     }
+    if (taped) {
+        if constexpr (!std::is_same<L, Columns>::value) {
+            if (!launched) {                                 // any batch, any alignment: one lane per thread, the general form
+                snprintf(variant, sizeof variant, ", 1, false%s%s", COLS ? "" : ", false", lname);
+                note_fused("steps_kernel", Env::NAME, variant);
+                hipLaunchKernelGGL((steps_kernel<Env, 1, false, false, L, true>), grid, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob,
+                                   reward, done, err, n, make_key(seed, t), lane0, kflags, make_key(action_seed, t + 1), k, rec, p, tape);
+            }
+        }
+        return (int)hipGetLastError();
+    }
+    if constexpr (!std::is_same<L, ColumnsNoAct>::value) {  // the synthetic policy's own forms
     if constexpr (Env::POOLED_ANY_LPT) {
         if (!launched && lpt2 && (flags & POMDP_AUTO_RESET) && n % (4 * BLOCK) == 0 && n >= (1 << 20) && Env::WORDS == 1) {
             POMDP_LAUNCH_STEPS(4, true, qgrid);
@@ -1005,12 +1087,15 @@ static int launch_steps_fused_l(const typename Env::Params &p, uint32_t *state, 
             snprintf(variant, sizeof variant, ", 1, true, true%s", lname);
             note_fused("steps_kernel", Env::NAME, variant);
             hipLaunchKernelGGL((steps_kernel<Env, 1, true, true, L>), grid, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob, reward,
-                               done, err, n, make_key(seed, t), lane0, kflags, make_key(action_seed, t + 1), k, rec, p);
+                               done, err, n, make_key(seed, t), lane0, kflags, make_key(action_seed, t + 1), k, rec, p, tape);
             launched = true;
         }
     }
     if (!launched) { if (simple) POMDP_LAUNCH_STEPS(1, true, grid); else POMDP_LAUNCH_STEPS(1, false, grid); }
+    }
 #undef POMDP_LAUNCH_STEPS
+#undef POMDP_LAUNCH_QUAD
+#undef POMDP_QUAD_ARGS
     return (int)hipGetLastError();
 }
 
@@ -1018,21 +1103,18 @@ template <class Env>
 int launch_steps_fused(const typename Env::Params &p, uint32_t *state, int32_t *action, int32_t *ob,
                        typename Env::Reward *reward, uint8_t *done, uint32_t *err, int64_t n, uint64_t seed,
                        uint64_t action_seed, uint32_t lane0, uint64_t t, int k, int flags, int64_t rec, bool gen_first,
-                       int layout, void *stream)
+                       int layout, TapeRef tape, void *stream)
 {
+#define POMDP_FUSED_L(L_) launch_steps_fused_l<Env, L_>(p, state, action, ob, reward, done, err, n, seed, action_seed, lane0, t, k, flags, rec, gen_first, tape, stream)
     switch (layout) {
-    case POMDP_LAYOUT_COLUMNS:
-        return launch_steps_fused_l<Env, Columns>(p, state, action, ob, reward, done, err, n, seed, action_seed, lane0, t, k, flags, rec, gen_first, stream);
-    case POMDP_LAYOUT_BLOCKED:
-        return launch_steps_fused_l<Env, Blocked>(p, state, action, ob, reward, done, err, n, seed, action_seed, lane0, t, k, flags, rec, gen_first, stream);
-    case POMDP_LAYOUT_PACKED:
-        return launch_steps_fused_l<Env, Packed>(p, state, action, ob, reward, done, err, n, seed, action_seed, lane0, t, k, flags, rec, gen_first, stream);
-    case POMDP_LAYOUT_NARROW:
-        return launch_steps_fused_l<Env, Narrow>(p, state, action, ob, reward, done, err, n, seed, action_seed, lane0, t, k, flags, rec, gen_first, stream);
-    case LAYOUT_RETURNS:
-        return launch_steps_fused_l<Env, Returns<Env>>(p, state, action, ob, reward, done, err, n, seed, action_seed, lane0, t, k, flags, rec, gen_first, stream);
+    case POMDP_LAYOUT_COLUMNS: return tape.base ? POMDP_FUSED_L(ColumnsNoAct) : POMDP_FUSED_L(Columns);
+    case POMDP_LAYOUT_BLOCKED: return POMDP_FUSED_L(Blocked);
+    case POMDP_LAYOUT_PACKED: return POMDP_FUSED_L(Packed);
+    case POMDP_LAYOUT_NARROW: return POMDP_FUSED_L(Narrow);
+    case LAYOUT_RETURNS: return POMDP_FUSED_L(Returns<Env>);
     default: return POMDP_E_BADARG;
     }
+#undef POMDP_FUSED_L
 }
 
 } // namespace pomdp

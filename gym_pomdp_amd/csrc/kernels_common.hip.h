@@ -484,7 +484,8 @@ int launch_step_chain(const typename Env::Params &p, uint32_t *state, int32_t *a
 template <class Env>
 int launch_steps_fused(const typename Env::Params &p, uint32_t *state, int32_t *action, int32_t *ob, typename Env::Reward *reward,
                        uint8_t *done, uint32_t *err, int64_t n, uint64_t seed, uint64_t action_seed, uint32_t lane0, uint64_t t,
-                       int k, int flags, int64_t rec, bool gen_first, int layout, void *stream);
+                       int k, int flags, int64_t rec, bool gen_first, int layout, TapeRef tape, void *stream);
+constexpr TapeRef NO_TAPE = {nullptr, 0, nullptr};         // the synthetic policy
 
 using Rock1 = RockEnv<1>;
 using Rock2 = RockEnv<2>;
@@ -501,7 +502,7 @@ using BattleShip4 = BattleShipEnv<4>;
 #define POMDP_FUSED_LAUNCHER(X, E)                                                                                            \
     X template int launch_steps_fused<E>(const E::Params &, uint32_t *, int32_t *, int32_t *, E::Reward *, uint8_t *,          \
                                          uint32_t *, int64_t, uint64_t, uint64_t, uint32_t, uint64_t, int, int, int64_t,     \
-                                         bool, int, void *);
+                                         bool, int, TapeRef, void *);
 #define POMDP_EACH_ENV(M, X)                                                                                                  \
     M(X, Rock1) M(X, Rock2) M(X, StochRock1) M(X, StochRock2) M(X, TagEnv) M(X, BattleShip1) M(X, BattleShip2)                  \
     M(X, BattleShip3) M(X, BattleShip4) M(X, TigerEnv) M(X, NetworkEnv)

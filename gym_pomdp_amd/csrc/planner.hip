@@ -570,23 +570,31 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(const typename Env::Para
 // visits / mean return per first action and picks the best one.  The order of the float64 additions is part of the
 // contract — chunks of 64 simulations by index, simulation-index order within a chunk, chunk order across chunks, each sum
 // starting from +0.0 — so the layout follows it: the root's returns and first actions are staged through LDS a tile of
-// PLAN_TILE = 16 chunks at a time; wave w sums chunks w, w + 4, ... with lane a owning action a (every lane reads the
-// same LDS address: a broadcast, no bank conflict; an addition of nothing leaves the sum alone, which is what skipping the
-// simulation means, and a partial sum that started at +0.0 is never -0.0), the per-chunk sums go through LDS, and thread a
-// adds them in chunk order into its running total across tiles.  No atomics, no cross-workgroup traffic.
-constexpr int PLAN_TILE = 16 * POMDP_PLAN_CHUNK;
+// PLAN_TILE = 16 chunks at a time; the tile's (chunk, action) pairs are dealt out one per thread, each walking its chunk in
+// index order (an addition of nothing leaves the sum alone, which is what skipping a simulation means, and a sum that
+// started at +0.0 is never -0.0); the per-chunk sums go through LDS and thread a adds them in chunk order into its running
+// total across tiles.  No atomics, no cross-workgroup traffic.  LDS is sized by the action count (dynamic: 13 KB for
+// RockSample(15,15)'s 20 actions), so that a CU holds eight roots at once — configs[4]'s 2048 roots are one round of
+// workgroups; a chunk's returns sit 65 doubles apart so that threads on different chunks read different banks.
+constexpr int PLAN_CHUNKS = 16, PLAN_TILE = PLAN_CHUNKS * POMDP_PLAN_CHUNK, PLAN_ROW = POMDP_PLAN_CHUNK + 1;
+static inline size_t plan_lds_bytes(int n_act)
+{
+    return sizeof(double) * (PLAN_CHUNKS * PLAN_ROW + (size_t)PLAN_CHUNKS * n_act + n_act) + sizeof(int32_t) * n_act +
+           PLAN_TILE + (size_t)PLAN_CHUNKS * n_act;
+}
 __global__ __launch_bounds__(BLOCK) void plan_reduce_kernel(const double *__restrict__ ret, const int32_t *__restrict__ first_action,
                                                             int64_t sims, int n_act, pomdp_plan_out out)
 {
 #pragma clang fp contract(off)
-    __shared__ double r_lds[PLAN_TILE];
-    __shared__ uint8_t a_lds[PLAN_TILE];                    // 255: the simulation took no step (or an action out of range)
-    __shared__ double part[PLAN_TILE / POMDP_PLAN_CHUNK][BLOCK];
-    __shared__ uint8_t cnt[PLAN_TILE / POMDP_PLAN_CHUNK][BLOCK];   // <= 64 per chunk
-    __shared__ double q_lds[BLOCK];
-    __shared__ int32_t n_lds[BLOCK];
+    extern __shared__ double plan_lds[];
+    double *const r_lds = plan_lds;                                        // [PLAN_CHUNKS][PLAN_ROW]
+    double *const part = r_lds + PLAN_CHUNKS * PLAN_ROW;                   // [PLAN_CHUNKS][n_act]
+    double *const q_lds = part + PLAN_CHUNKS * n_act;                      // [n_act]
+    int32_t *const n_lds = reinterpret_cast<int32_t *>(q_lds + n_act);     // [n_act]
+    uint8_t *const a_lds = reinterpret_cast<uint8_t *>(n_lds + n_act);     // [PLAN_TILE]; 255: no step taken / out of range
+    uint8_t *const cnt = a_lds + PLAN_TILE;                                // [PLAN_CHUNKS][n_act], <= 64 each
     const int64_t root = blockIdx.x;
-    const int tid = (int)threadIdx.x, wv = tid >> 6, me = tid & 63;
+    const int tid = (int)threadIdx.x;
     const double *const rr = ret + root * sims;
     const int32_t *const fa = first_action + root * sims;
     double total = 0.0;                                      // thread a < n_act: action a
@@ -594,30 +602,31 @@ __global__ __launch_bounds__(BLOCK) void plan_reduce_kernel(const double *__rest
     for (int64_t base = 0; base < sims; base += PLAN_TILE) {
         const int tile = (int)(sims - base < PLAN_TILE ? sims - base : PLAN_TILE);
         for (int j = tid; j < tile; j += BLOCK) {
-            r_lds[j] = rr[base + j];
+            r_lds[(j >> 6) * PLAN_ROW + (j & 63)] = rr[base + j];
             const int32_t f = fa[base + j];
             a_lds[j] = (uint8_t)((uint32_t)f < (uint32_t)n_act ? f : 255);
         }
         __syncthreads();
         const int n_chunks = (tile + POMDP_PLAN_CHUNK - 1) / POMDP_PLAN_CHUNK;
-        for (int c = wv; c < n_chunks; c += BLOCK / 64) {
-            const int j0 = c * POMDP_PLAN_CHUNK, j1 = j0 + POMDP_PLAN_CHUNK < tile ? j0 + POMDP_PLAN_CHUNK : tile;
-            for (int a = me; a < n_act; a += 64) {
-                double p = 0.0;
-                int k = 0;
-                for (int j = j0; j < j1; ++j) {
-                    const bool hit = (int)a_lds[j] == a;
-                    const double with = p + r_lds[j];
-                    p = hit ? with : p;
-                    k += (int)hit;
-                }
-                part[c][a] = p;
-                cnt[c][a] = (uint8_t)k;
+        for (int item = tid; item < n_chunks * n_act; item += BLOCK) {
+            const int c = item / n_act, a = item - c * n_act;
+            const int len = tile - c * POMDP_PLAN_CHUNK < POMDP_PLAN_CHUNK ? tile - c * POMDP_PLAN_CHUNK : POMDP_PLAN_CHUNK;
+            const double *const rc = r_lds + c * PLAN_ROW;
+            const uint8_t *const ac = a_lds + c * POMDP_PLAN_CHUNK;
+            double p = 0.0;
+            int k = 0;
+            for (int j = 0; j < len; ++j) {
+                const bool hit = (int)ac[j] == a;
+                const double with = p + rc[j];
+                p = hit ? with : p;
+                k += (int)hit;
             }
+            part[c * n_act + a] = p;
+            cnt[c * n_act + a] = (uint8_t)k;
         }
         __syncthreads();
         if (tid < n_act)
-            for (int c = 0; c < n_chunks; ++c) { total = total + part[c][tid]; visits += (int32_t)cnt[c][tid]; }
+            for (int c = 0; c < n_chunks; ++c) { total = total + part[c * n_act + tid]; visits += (int32_t)cnt[c * n_act + tid]; }
         __syncthreads();                                     // the next tile overwrites r_lds / part
     }
     if (tid < n_act) {
@@ -788,8 +797,8 @@ int pomdp_plan_reduce(const double *ret, const int32_t *first_action, int64_t n_
     if (!ret || !first_action || n_roots < 0 || n_roots > 0x7FFFFFFF || sims_per_root < 1 || !plan_out_ok(out, n_actions))
         return POMDP_E_BADARG;
     if (n_roots == 0) return 0;
-    hipLaunchKernelGGL(plan_reduce_kernel, dim3((unsigned)n_roots), dim3(BLOCK), 0, (hipStream_t)stream, ret, first_action,
-                       sims_per_root, n_actions, *out);
+    hipLaunchKernelGGL(plan_reduce_kernel, dim3((unsigned)n_roots), dim3(BLOCK), plan_lds_bytes(n_actions), (hipStream_t)stream, ret,
+                       first_action, sims_per_root, n_actions, *out);
     return (int)hipGetLastError();
 }
 

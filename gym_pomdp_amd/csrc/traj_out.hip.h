@@ -34,7 +34,11 @@ namespace pomdp {
 
 // CODES: the sink reads the step's reward code (Env::reward_code) — the loops compute it only then
 constexpr int LAYOUT_RETURNS = 100;                         // launcher-internal: not a trajectory layout of the ABI
-struct Columns { static constexpr int ID = POMDP_LAYOUT_COLUMNS; static constexpr const char *NAME = "Columns"; static constexpr bool CODES = false; };
+// ACT: the columns include `action` (row s + 1 = the policy's next actions).  A tape-driven launch leaves it out — the caller
+// holds the actions already — and writes ob / reward / done only: 9 bytes per lane-step.
+template <bool ACT> struct ColumnsT { static constexpr int ID = POMDP_LAYOUT_COLUMNS; static constexpr const char *NAME = "Columns"; static constexpr bool CODES = false; };
+using Columns = ColumnsT<true>;
+using ColumnsNoAct = ColumnsT<false>;
 struct Blocked { static constexpr int ID = POMDP_LAYOUT_BLOCKED; static constexpr const char *NAME = "Blocked"; static constexpr bool CODES = false; };
 struct Packed  { static constexpr int ID = POMDP_LAYOUT_PACKED;  static constexpr const char *NAME = "Packed";  static constexpr bool CODES = true; };
 struct Narrow  { static constexpr int ID = POMDP_LAYOUT_NARROW;  static constexpr const char *NAME = "Narrow";  static constexpr bool CODES = true; };
@@ -50,13 +54,90 @@ static __device__ __forceinline__ uint32_t pack_record(uint32_t a, uint32_t o, u
     return a | (o << 8) | ((rcode & 0xFFu) << 16) | (d << 24);
 }
 
-// the four policy words of a quad at the call counter BEFORE akey0's, as actions (what pomdp_synthetic_actions would write)
-static __device__ __forceinline__ u32x4 gen_actions4(uint32_t glane0, const RngKey &akey0, uint32_t n_act)
-{
-    const uint64_t tf = (((uint64_t)akey0.t_hi << 32) | akey0.t_lo) - 1ull;
-    const uint4 w = philox4x32_10(glane0 >> 2, (uint32_t)tf, (uint32_t)(tf >> 32), (uint32_t)POMDP_STREAM_ACTION << 24, akey0.k0, akey0.k1);
-    return u32x4{__umulhi(w.x, n_act), __umulhi(w.y, n_act), __umulhi(w.z, n_act), __umulhi(w.w, n_act)};
-}
+// ---- where a fused loop's actions come from ------------------------------------------------------------------------------
+// Synthetic: the bench's uniform random policy — stream ACTION of (seed, quad, t), generated inside the loop (the launches of
+// pomdp_collect_synthetic / _layout / _returns).  Tape: the CALLER's actions (pomdp_collect_tape*), `uint8 [k_steps][stride]`
+// in HBM, row s = the actions of the launch's step s.  gfx9 counts loads and stores on one counter and returns them in
+// order, so waiting for a load also waits for every store issued BEFORE it: the row of step s + 1 is therefore requested at
+// the TOP of step s (begin) — the only older stores are step s - 1's, a whole step old by the time anybody waits — and first
+// touched at the END of step s (end), after the step's own stores have been issued, with the step's arithmetic in between to
+// cover the latency.  Request and use sit in the same loop iteration, so the compiler's own `s_waitcnt vmcnt(n)` counts
+// exactly the stores issued after the load; nothing pending is carried round the loop.
+struct TapeRef {
+    const uint8_t *base;     // row 0 of this launch; nullptr: the synthetic policy
+    int64_t stride;          // bytes from one step's row to the next
+    uint32_t *err;           // device counter of out-of-range actions (may be nullptr)
+};
+
+template <class T>           // T = uint32_t: the four lanes of a quad (one dword per row); uint8_t: one lane
+struct TapeColumn {
+    const uint8_t *p;        // this thread's element of row 0
+    int64_t stride;
+    int last;                // k_steps - 1: rows past it are never requested
+    T first, nxt;
+    __device__ __forceinline__ T row(int r) const
+    {
+        r = r < last ? r : last;
+        return ld_stream(reinterpret_cast<const T *>(p + (int64_t)r * stride));
+    }
+    __device__ __forceinline__ TapeColumn(const TapeRef &t, uint32_t col, int k_steps)
+        : p(t.base + col), stride(t.stride), last(k_steps - 1), nxt(0) { first = row(0); }
+    __device__ __forceinline__ void request(int s) { nxt = row(s + 1); }   // top of step s: the actions of step s + 1
+};
+struct NoColumn {            // the same interface for a loop that is not tape-driven: nothing is loaded
+    uint8_t first, nxt;
+    __device__ __forceinline__ NoColumn(const TapeRef &, uint32_t, int) : first(0), nxt(0) {}
+    __device__ __forceinline__ void request(int) {}
+};
+
+// quad-per-thread loops: l0 = the thread's first lane within the shard, glane0 its global id.  begin(s, a_next) at the top of
+// step s, end(s, a_next) after the step's stores: between them a_next holds the actions of step s + 1 (Synthetic) or nothing yet.
+struct SyntheticQuad {
+    static constexpr bool TAPE = false;
+    uint32_t glane0, n_act, k0, k1;
+    uint64_t ta0;
+    // (the policy shares the env's Philox key in every launch that takes these loops: the key words are the ENV key's, so that
+    // the compiler keeps one copy of them in scalar registers — a second copy made Network's loop spill scalars)
+    __device__ __forceinline__ SyntheticQuad(const TapeRef &, uint32_t, uint32_t glane0_, const RngKey &key0, const RngKey &akey0, uint32_t n_act_, int)
+        : glane0(glane0_), n_act(n_act_), k0(key0.k0), k1(key0.k1), ta0(((uint64_t)akey0.t_hi << 32) | akey0.t_lo) {}
+    __device__ __forceinline__ uint4 block(uint64_t ta) const
+    {
+        return philox4x32_10(glane0 >> 2, (uint32_t)ta, (uint32_t)(ta >> 32), (uint32_t)POMDP_STREAM_ACTION << 24, k0, k1);
+    }
+    // the actions of the call counter BEFORE akey0's: what pomdp_synthetic_actions would have written for the launch's first step
+    __device__ __forceinline__ u32x4 first() const
+    {
+        const uint4 w = block(ta0 - 1ull);
+        return u32x4{__umulhi(w.x, n_act), __umulhi(w.y, n_act), __umulhi(w.z, n_act), __umulhi(w.w, n_act)};
+    }
+    __device__ __forceinline__ void begin(int s, uint32_t (&a)[4]) const
+    {
+        const uint4 pw = block(ta0 + (uint64_t)s);
+        a[0] = __umulhi(pw.x, n_act); a[1] = __umulhi(pw.y, n_act); a[2] = __umulhi(pw.z, n_act); a[3] = __umulhi(pw.w, n_act);
+    }
+    __device__ __forceinline__ void end(int, uint32_t (&)[4]) const {}
+    __device__ __forceinline__ void count_bad(uint32_t) const {}
+};
+struct TapeQuad {
+    static constexpr bool TAPE = true;
+    TapeColumn<uint32_t> col;
+    uint32_t *err;
+    static __device__ __forceinline__ void unpack(uint32_t w, uint32_t (&a)[4])
+    {
+        a[0] = w & 0xFFu; a[1] = __builtin_amdgcn_ubfe(w, 8u, 8u); a[2] = __builtin_amdgcn_ubfe(w, 16u, 8u); a[3] = w >> 24;
+    }
+    __device__ __forceinline__ TapeQuad(const TapeRef &t, uint32_t l0, uint32_t, const RngKey &, const RngKey &, uint32_t, int k_steps)
+        : col(t, l0, k_steps), err(t.err) {}
+    __device__ __forceinline__ u32x4 first() const
+    {
+        uint32_t a[4];
+        unpack(col.first, a);
+        return u32x4{a[0], a[1], a[2], a[3]};
+    }
+    __device__ __forceinline__ void begin(int s, uint32_t (&a)[4]) { col.request(s); a[0] = a[1] = a[2] = a[3] = 0; }
+    __device__ __forceinline__ void end(int, uint32_t (&a)[4]) const { unpack(col.nxt, a); }
+    __device__ __forceinline__ void count_bad(uint32_t n_bad) const { if (n_bad && err) atomicAdd(err, n_bad); }
+};
 
 // ---- a thread that owns a quad of consecutive lanes (the quad-per-thread loops) ------------------------------------
 // l0: the thread's first lane within the shard (a multiple of 4).  first(): the actions of the launch's first step.
@@ -64,20 +145,22 @@ static __device__ __forceinline__ u32x4 gen_actions4(uint32_t glane0, const RngK
 // counter, o / r (raw 32-bit patterns) / rc (reward codes, read by Packed only) / d (0 or 1) — then on to the next row.
 template <class L> struct QuadOut;
 
-template <> struct QuadOut<Columns> {
+template <bool ACT> struct QuadOut<ColumnsT<ACT>> {
     uint32_t *action_w, *ob_w, *reward_w, *done_w;
     int64_t rec;
     __device__ __forceinline__ QuadOut(void *action, void *ob, void *reward, void *done, int64_t rec_, uint32_t l0)
-        : action_w(reinterpret_cast<uint32_t *>(action) + l0), ob_w(reinterpret_cast<uint32_t *>(ob) + l0),
+        : action_w(ACT ? reinterpret_cast<uint32_t *>(action) + l0 : nullptr), ob_w(reinterpret_cast<uint32_t *>(ob) + l0),
           reward_w(reinterpret_cast<uint32_t *>(reward) + l0), done_w(reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(done) + l0)),
           rec(rec_) {}
-    // read from row 0 of `action`, or (gen_first, wave-uniform) the quad's block of the synthetic policy, written to that row
-    __device__ __forceinline__ u32x4 first(int gen_first, uint32_t glane0, const RngKey &akey0, uint32_t n_act)
+    // read from row 0 of `action`, or (gen_first, wave-uniform) the policy's own first actions, written to that row
+    template <class Pol>
+    __device__ __forceinline__ u32x4 first(const Pol &pol, int gen_first)
     {
+        if constexpr (!ACT) return pol.first();
         u32x4 a;
         if (!gen_first) a = ld_stream4(action_w);
         else {
-            a = gen_actions4(glane0, akey0, n_act);
+            a = pol.first();
             st_stream4(action_w, a[0], a[1], a[2], a[3]);
         }
         action_w += rec;
@@ -86,7 +169,7 @@ template <> struct QuadOut<Columns> {
     __device__ __forceinline__ void put(const uint32_t (&)[4], const uint32_t (&a_next)[4], const uint32_t (&o)[4],
                                         const uint32_t (&r)[4], const uint32_t (&)[4], const uint32_t (&d)[4])
     {
-        st_stream4(action_w, a_next[0], a_next[1], a_next[2], a_next[3]);
+        if constexpr (ACT) st_stream4(action_w, a_next[0], a_next[1], a_next[2], a_next[3]);
         st_stream4(ob_w, o[0], o[1], o[2], o[3]);
         st_stream4(reward_w, r[0], r[1], r[2], r[3]);
         st_stream(done_w, d[0] | (d[1] << 8) | (d[2] << 16) | (d[3] << 24));
@@ -116,7 +199,7 @@ template <> struct QuadOut<Blocked> {
         : w(reinterpret_cast<uint8_t *>(base) + (int64_t)(l0 >> 8) * TRAJ_BLOCK_BYTES + (l0 & 255u) * 4u),
           wd(reinterpret_cast<uint8_t *>(base) + (int64_t)(l0 >> 8) * TRAJ_BLOCK_BYTES + 3 * 1024 + (l0 & 255u)),
           row_bytes(rec_ * 13) {}
-    __device__ __forceinline__ u32x4 first(int, uint32_t glane0, const RngKey &akey0, uint32_t n_act) { return gen_actions4(glane0, akey0, n_act); }
+    template <class Pol> __device__ __forceinline__ u32x4 first(const Pol &pol, int) { return pol.first(); }
     __device__ __forceinline__ void put(const uint32_t (&a_cur)[4], const uint32_t (&)[4], const uint32_t (&o)[4],
                                         const uint32_t (&r)[4], const uint32_t (&)[4], const uint32_t (&d)[4])
     {
@@ -148,7 +231,7 @@ template <> struct QuadOut<Packed> {
     int64_t rec;
     __device__ __forceinline__ QuadOut(void *base, void *, void *, void *, int64_t rec_, uint32_t l0)
         : w(reinterpret_cast<uint32_t *>(base) + l0), rec(rec_) {}
-    __device__ __forceinline__ u32x4 first(int, uint32_t glane0, const RngKey &akey0, uint32_t n_act) { return gen_actions4(glane0, akey0, n_act); }
+    template <class Pol> __device__ __forceinline__ u32x4 first(const Pol &pol, int) { return pol.first(); }
     __device__ __forceinline__ void put(const uint32_t (&a_cur)[4], const uint32_t (&)[4], const uint32_t (&o)[4],
                                         const uint32_t (&)[4], const uint32_t (&rc)[4], const uint32_t (&d)[4])
     {
@@ -169,7 +252,7 @@ template <> struct QuadOut<Narrow> {
     int64_t plane, row;                                     // in 32-bit words: a plane is `pitch` bytes, a row four planes
     __device__ __forceinline__ QuadOut(void *base, void *, void *, void *, int64_t rec_, uint32_t l0)
         : w(reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(base) + l0)), plane(rec_ / 4), row(rec_) {}
-    __device__ __forceinline__ u32x4 first(int, uint32_t glane0, const RngKey &akey0, uint32_t n_act) { return gen_actions4(glane0, akey0, n_act); }
+    template <class Pol> __device__ __forceinline__ u32x4 first(const Pol &pol, int) { return pol.first(); }
     // 4 x 4 byte transpose: byte b of record j -> byte j of plane b (v_perm_b32: selector 0-3 = bytes of the second
     // operand, 4-7 = bytes of the first)
     __device__ __forceinline__ void put_records(const uint32_t (&r)[4], const uint32_t (&)[4])
@@ -288,7 +371,7 @@ template <class Env> struct QuadOut<Returns<Env>> {
             episodes[0] = e[0]; episodes[1] = e[1]; episodes[2] = e[2]; episodes[3] = e[3];
         }
     }
-    __device__ __forceinline__ u32x4 first(int, uint32_t glane0, const RngKey &akey0, uint32_t n_act) { return gen_actions4(glane0, akey0, n_act); }
+    template <class Pol> __device__ __forceinline__ u32x4 first(const Pol &pol, int) { return pol.first(); }
     __device__ __forceinline__ void put_records(const uint32_t (&r)[4], const uint32_t (&)[4])
     {
 #pragma unroll
@@ -324,7 +407,7 @@ template <class Env> struct QuadOut<Returns<Env>> {
 // with the lane's (clamped) index; put(j, rel, ...): one step's results of an in-range lane; finish(j, rel, k): after the loop.
 template <class L, class RT, int LPT> struct LaneOut;
 
-template <class RT, int LPT> struct LaneOut<Columns, RT, LPT> {
+template <bool ACT, class RT, int LPT> struct LaneOut<ColumnsT<ACT>, RT, LPT> {
     int32_t *action_w, *ob_w;
     RT *reward_w;
     uint8_t *done_w;
@@ -333,10 +416,10 @@ template <class RT, int LPT> struct LaneOut<Columns, RT, LPT> {
         : action_w(reinterpret_cast<int32_t *>(action) + wg0), ob_w(reinterpret_cast<int32_t *>(ob) + wg0),
           reward_w(reinterpret_cast<RT *>(reward) + wg0), done_w(reinterpret_cast<uint8_t *>(done) + wg0), rec(rec_) {}
     __device__ __forceinline__ void begin(int, uint32_t) {}
-    __device__ __forceinline__ int load_first(uint32_t rel) const { return ld_stream(action_w + rel); }
-    __device__ __forceinline__ void store_first(uint32_t rel, int a) const { st_stream(action_w + rel, (int32_t)a); }
+    __device__ __forceinline__ int load_first(uint32_t rel) const { return ACT ? ld_stream(action_w + rel) : 0; }
+    __device__ __forceinline__ void store_first(uint32_t rel, int a) const { if constexpr (ACT) st_stream(action_w + rel, (int32_t)a); }
     __device__ __forceinline__ void first_done() { action_w += rec; }                  // row 0 of `action` is behind us
-    __device__ __forceinline__ void put_next_action(uint32_t rel, int a_next) const { st_stream(action_w + rel, (int32_t)a_next); }
+    __device__ __forceinline__ void put_next_action(uint32_t rel, int a_next) const { if constexpr (ACT) st_stream(action_w + rel, (int32_t)a_next); }
     __device__ __forceinline__ void put(int, uint32_t rel, int, int o, RT r, uint32_t, int d)
     {
         st_stream(ob_w + rel, (int32_t)o);

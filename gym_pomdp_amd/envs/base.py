@@ -764,6 +764,79 @@ class BatchedEnv(compat.EnvBase):
             _native.check(rc, "pomdp_collect_returns")
         return stats
 
+    def as_tape(self, actions):
+        """`actions` ([steps, N], any integer dtype, any device) as the uint8 tape the fused launches read: a uint8 tensor on
+        this env's device whose rows are contiguous is used in place (e.g. the action plane `traj["traj"][:, 0]` of a narrow
+        trajectory); anything else is converted, an action that does not fit a byte becoming 255 (out of range for every env,
+        so it stays the invalid action it was)."""
+        t = torch.as_tensor(actions, device=self.device) if not isinstance(actions, torch.Tensor) else actions.to(self.device)
+        if t.dim() != 2 or t.shape[1] != self.batch_size:
+            raise ValueError("tape: expected actions of shape (steps, %d), got %s" % (self.batch_size, tuple(t.shape)))
+        if t.dtype.is_floating_point or t.dtype == torch.bool:
+            raise AssertionError("actions must be integers")
+        if t.dtype != torch.uint8:
+            t = torch.where((t < 0) | (t > 255), torch.full_like(t, 255), t).to(torch.uint8)
+        if t.stride(1) != 1 or (t.shape[0] > 1 and t.stride(0) < t.shape[1]):
+            t = t.contiguous()
+        return t
+
+    def collect_tape(self, actions, out=None, layout=None, stats=None):
+        """`steps = len(actions)` consecutive step() calls with the CALLER's actions (pomdp_collect_tape*): row s of `actions`
+        ([steps, N]; see as_tape) is what step() is handed at call counter t + s.  The fused launches of collect_synthetic /
+        collect_returns — a lane's state in registers between its steps, up to 256 steps per launch — on actions the caller
+        chose: a replayed trajectory, a table policy, another model's output.  Same results as a python loop over step(),
+        row for row, including the final state.  layout "columns" (default): {"ob", "reward", "done"} [steps, N] (no action
+        column: the caller holds it); "blocked" / "packed" / "narrow": as collect_synthetic; "returns" (or `stats` given): the
+        episode statistics of collect_returns, returned as the EpisodeStats.  An action outside the env's range leaves the
+        lane untouched for that step and is counted (invalid_action_count()).  auto_reset envs only.  Asynchronous."""
+        if not self._has_reset:
+            raise AttributeError("%s: collect before reset()" % type(self).__name__)
+        if not self.auto_reset:
+            raise ValueError("collect_tape needs auto_reset=True")
+        self._check_driver_use("collect_tape")
+        tape = self.as_tape(actions)
+        steps, n = tape.shape[0], self.batch_size
+        if stats is not None and layout is None:
+            layout = "returns"
+        if layout is None:
+            layout = "columns" if out is None else out.get("layout", "columns")
+        ct = _native.Tape(actions=tape.data_ptr(), stride=tape.stride(0) if steps > 1 else max(tape.stride(0), n))
+        kind, t0 = _native.ENV_KIND[self.env_name], self._t
+        self._t = t0 + steps
+        with torch.cuda.device(self.device):
+            if layout == "returns":
+                if stats is None:
+                    from ..history import EpisodeStats
+                    stats = EpisodeStats(self)
+                elif stats._n != n or stats.acc.device != self.device:
+                    raise ValueError("collect_tape: `stats` belongs to another batch")
+                rc = self._lib.pomdp_collect_tape_returns(kind, self._params_ref, self._ptrs[0], C.byref(ct), stats._ref, self._ptrs[4], n,
+                                                          self._seed, self.lane_offset, t0, steps, _native.POMDP_AUTO_RESET, self._stream())
+                _native.check(rc, "pomdp_collect_tape_returns")
+                return stats
+            if out is None:
+                out = self.trajectory_buffers(steps, layout)
+            if out.get("layout", "columns") != layout:
+                raise ValueError("collect_tape: `out` was built for layout %r, not %r" % (out.get("layout", "columns"), layout))
+            if layout == "columns":
+                if not (out["ob"].shape[0] >= steps and out["ob"].shape[1] == n and out["reward"].shape == out["ob"].shape
+                        and out["done_u8"].shape == out["ob"].shape):
+                    raise ValueError("collect_tape: `out` does not have the shapes of trajectory_buffers(%d)" % steps)
+                rc = self._lib.pomdp_collect_tape(kind, self._params_ref, self._ptrs[0], C.byref(ct), out["ob"].data_ptr(),
+                                                  out["reward"].data_ptr(), out["done_u8"].data_ptr(), self._ptrs[4], n, self._seed,
+                                                  self.lane_offset, t0, steps, n, _native.POMDP_AUTO_RESET, self._stream())
+                _native.check(rc, "pomdp_collect_tape")
+                return out
+            traj, pitch = out["traj"], int(out["pitch"])
+            row = {"blocked": (pitch * 13,), "packed": (pitch,), "narrow": (4, pitch)}[layout]
+            if not (traj.shape[0] >= steps and tuple(traj.shape[1:]) == row and traj.is_contiguous() and pitch >= n):
+                raise ValueError("collect_tape: `out` does not have the shape of trajectory_buffers(%d, %r)" % (steps, layout))
+            rc = self._lib.pomdp_collect_tape_layout(kind, self._params_ref, self._ptrs[0], C.byref(ct), traj.data_ptr(), self._ptrs[4], n,
+                                                     self._seed, self.lane_offset, t0, steps, pitch, _native.LAYOUTS[layout],
+                                                     _native.POMDP_AUTO_RESET, self._stream())
+            _native.check(rc, "pomdp_collect_tape_layout")
+        return out
+
     def _check_driver_use(self, what):
         """The C-side episode loops advance the packed state only: they know nothing of RockSample's side statistics
         (use_heuristic / track_belief envs), and the synthetic policy shares one Philox block among global lanes

@@ -365,6 +365,38 @@ typedef struct pomdp_return_stats {
 int pomdp_collect_returns(int env, const void *params, uint32_t *state, const pomdp_return_stats *stats, uint32_t *err,
                           int64_t n, uint64_t seed, uint32_t lane0, uint64_t t0, int64_t k_steps, int flags, void *stream);
 
+/* ---- fused launches over the CALLER's actions (ABI 14) ----------------------------------------------------------------
+ * The reference's callers hand step() whatever they like (rock.py:562-566, tag.py:310-312, network.py:181-187).  With the
+ * actions of k_steps steps known up front — a replayed trajectory, a table policy evaluated on the device, another model's
+ * output — the fused launches above run on them instead of on the synthetic policy: state in registers between steps, up to
+ * pomdp_fuse_max() steps per launch, every sink.
+ *     tape.actions  device uint8 [k_steps][tape.stride]: row s = the actions of call counter t0 + s, lane i at byte i
+ *                   (tape.stride >= n bytes from one row to the next; the action plane of a POMDP_LAYOUT_NARROW trajectory
+ *                   is such a tape with stride = 4 * pitch).  Every env's actions fit a byte.
+ * A byte outside the env's action range leaves the lane untouched for that step — (ob, reward, done) = (0, 0, 0), the record
+ * keeps the byte as its action, the returns sink books a step with reward 0 — and is counted in *err, as pomdp_<env>_step
+ * does.  Everything else is as in the synthetic-policy entry point of the same sink: same draws (the env's streams at (seed,
+ * lane, t0 + s) do not depend on where the actions come from), same rows, same final state; POMDP_AUTO_RESET required, lane0
+ * a multiple of 4.  Rows on 4-byte boundaries (tape.actions and tape.stride multiples of 4) with n a multiple of 1024 and
+ * 16-byte-aligned sinks take the quad-per-thread loops, anything else the general one.
+ *   pomdp_collect_tape          the default columns WITHOUT `action` (the caller has it): ob int32, reward int32 | float, done
+ *                               uint8, each [k_steps][pitch] — row s what pomdp_<env>_step(action = tape row s) at t0 + s returns
+ *   pomdp_collect_tape_layout   POMDP_LAYOUT_BLOCKED / _PACKED / _NARROW, as pomdp_collect_layout
+ *   pomdp_collect_tape_returns  the episode statistics of pomdp_collect_returns */
+typedef struct pomdp_tape {
+    const uint8_t *actions;
+    int64_t stride;
+} pomdp_tape;
+int pomdp_collect_tape(int env, const void *params, uint32_t *state, const pomdp_tape *tape, int32_t *ob, void *reward,
+                       uint8_t *done, uint32_t *err, int64_t n, uint64_t seed, uint32_t lane0, uint64_t t0, int64_t k_steps,
+                       int64_t pitch, int flags, void *stream);
+int pomdp_collect_tape_layout(int env, const void *params, uint32_t *state, const pomdp_tape *tape, void *traj, uint32_t *err,
+                              int64_t n, uint64_t seed, uint32_t lane0, uint64_t t0, int64_t k_steps, int64_t pitch, int layout,
+                              int flags, void *stream);
+int pomdp_collect_tape_returns(int env, const void *params, uint32_t *state, const pomdp_tape *tape,
+                               const pomdp_return_stats *stats, uint32_t *err, int64_t n, uint64_t seed, uint32_t lane0,
+                               uint64_t t0, int64_t k_steps, int flags, void *stream);
+
 /* Steps per fused launch of the C-side drivers above (pomdp_rollout_synthetic with POMDP_FUSE_STEPS, pomdp_collect_*,
  * pomdp_heuristic_steps): a launch's fixed cost (kernel start, table build, drain) is paid once per this many steps.
  * pomdp_fuse_max(v) sets it for the calling process (1 <= v <= 256; v <= 0 only reads) and returns the previous value;

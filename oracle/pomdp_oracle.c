@@ -1097,9 +1097,14 @@ int64_t or_batch_collect_returns(const or_env *proto, uint32_t *state, double *a
                 or_philox4x32_10(c, key, o4);
                 const int a = actions ? actions[s * n + i] : (int)(((uint64_t)o4[lane & 3u] * (uint32_t)nA) >> 32);
                 int o, d; double r;
-                or_ws_philox_step(&np_rng, &e, seed, lane, t);
-                or_ws_space(&sp_rng, seed, lane, t, OR_STREAM_STEP_SPACE);
-                or_env_step(&e, a, &np_rng, &sp_rng, &o, &r, &d);
+                if (a < 0 || a >= nA) {                     /* a tape's out-of-range action (the reference asserts): the lane is left
+                                                               untouched — a step that returns (0, 0, 0) — as in or_batch_step */
+                    o = 0; d = 0; r = 0.0;
+                } else {
+                    or_ws_philox_step(&np_rng, &e, seed, lane, t);
+                    or_ws_space(&sp_rng, seed, lane, t, OR_STREAM_STEP_SPACE);
+                    or_env_step(&e, a, &np_rng, &sp_rng, &o, &r, &d);
+                }
                 {   /* r += discount * rw; discount *= .95 (network.py:186-187) — separate multiply and add */
                     const double term = disc * r;
                     ret = ret + term;

@@ -84,6 +84,145 @@ def test_collected_rows_equal_the_oracle(oracle_lib, fuse64, env, kw, n, steps):
     assert e.invalid_action_count() == 0
 
 
+# ---- fused launches over the CALLER's actions (pomdp_collect_tape*) ---------------------------------------------------------
+TAPES = [("rock", {}, 1 << 20, 80), ("rock", dict(board_size=15, num_rocks=15), 1 << 20, 40), ("stochrock", {}, 1 << 19, 40),
+         ("tag", {}, 1 << 20, 70), ("tiger", {}, 1 << 20, 70), ("network", {}, 1 << 20, 40),
+         ("battleship", dict(board_size=(10, 10), max_len=5), 1 << 19, 70), ("battleship", {}, 1 << 18, 70),
+         # below the quad gates / ragged / several opponents: the general one-lane-per-thread loop
+         ("rock", {}, 1 << 17, 66), ("rock", {}, 4099, 70), ("tag", dict(num_opponents=2), 1 << 18, 40), ("tiger", {}, 3, 70),
+         ("network", dict(n_machines=16, problem_type=1), 777, 40), ("battleship", {}, 259, 70)]
+
+
+def _tape(rng, n_actions, steps, n, bad_every):
+    """a tape no policy of ours produced: uniform actions from numpy, with an out-of-range byte (n_actions .. 255) on one lane-step in `bad_every`"""
+    tape = rng.randint(0, n_actions, (steps, n)).astype(np.uint8)
+    if bad_every:
+        bad = rng.randint(0, bad_every, (steps, n)) == 0
+        tape[bad] = rng.randint(n_actions, 256, int(bad.sum())).astype(np.uint8)
+    return tape
+
+
+@pytest.mark.parametrize("env,kw,n,steps", TAPES, ids=["%s%s-%d" % (c[0], "-".join(str(v) for v in c[1].values()), c[2]) for c in TAPES])
+@pytest.mark.parametrize("layout", ["packed", "columns"])
+def test_tape_driven_rows_equal_the_oracle(oracle_lib, fuse64, env, kw, n, steps, layout):
+    """collect_tape(actions): the fused launches on the CALLER's actions (rock.py:562-566: `env.step(action)` with whatever the
+    caller chose) against oracle.batch_step fed the same tape — every row over the whole batch, across the 64-step launch
+    boundary, out-of-range bytes included (lane untouched, (0, 0, 0), counted), then the final state."""
+    seed, lane0, t0 = 77001, 1 << 21, (1 << 32) - 9
+    nt = oracle_lib.max_threads()
+    e = make_env(env, kw, batch_size=n, seed=seed, lane_offset=lane0, reuse_buffers=True)
+    e.call_counter = t0
+    o = oracle_lib.OracleEnv(env, **kw)
+    st = o.new_state(n)
+    assert np.array_equal(np_(e.reset()), o.batch_reset(st, seed, lane0, t0, nthreads=nt))
+    tape = _tape(np.random.RandomState(n % 9973 + steps), o.n_actions, steps, n, 4096)
+    tr = e.collect_tape(torch.as_tensor(tape, device="cuda"), layout=layout)
+    cols = e.decode_trajectory(tr, steps)
+    done, n_bad = np.zeros(n, np.uint8), 0
+    for k in range(steps):
+        a = tape[k].astype(np.int32)
+        ob, rew, done, bad = o.batch_step(st, a, seed, lane0, t0 + 1 + k, auto_reset=True, done=done, nthreads=nt)
+        n_bad += bad
+        ctx = (env, kw, n, k, layout)
+        if layout == "packed":
+            assert np.array_equal(np_(cols["action"][k]), a), ctx          # the record keeps the byte it was given
+        assert np.array_equal(np_(cols["ob"][k]), ob), ctx
+        assert np.array_equal(np_(cols["reward"][k]), rew), ctx
+        assert np.array_equal(np_(cols["done"][k]), done.astype(bool)), ctx
+    assert np.array_equal(np_(e.state).view(np.uint32), st)
+    assert e.invalid_action_count() == n_bad == int((tape >= o.n_actions).sum())
+    want_kernel = {"rock": "steps_quad_kernel", "stochrock": "steps_quad_kernel", "tag": "tag_steps_quad_kernel", "tiger": "steps_quad_generic_kernel",
+                   "network": "network_steps_quad_kernel", "battleship": "battleship_steps_quad_kernel"}[env]
+    from gym_pomdp_amd import _native
+    name = _native.lib().pomdp_last_fused_kernel().decode()
+    assert name.endswith(", Tape>") or ", Tape" in name, name
+    if n >= 1 << 19 or (env == "battleship" and n >= 1 << 16):
+        assert name.startswith(want_kernel + "<"), name                    # the quad-per-thread loop took it
+    elif n < 1 << 16 or n % 1024:
+        assert name.startswith("steps_kernel<"), name
+
+
+@pytest.mark.parametrize("env,kw,n", [("rock", {}, 1 << 20), ("tag", {}, 1 << 19), ("network", {}, 1 << 19), ("tiger", {}, 1000),
+                                      ("battleship", dict(board_size=(10, 10), max_len=5), 1 << 17)], ids=["rock", "tag", "network", "tiger-ragged", "battleship"])
+def test_tape_driven_returns_and_other_sinks(oracle_lib, fuse64, env, kw, n):
+    """The returns sink on a tape (float64 statistics bit for bit against or_batch_collect_returns fed the same tape, out-of-range
+    bytes booking a step with reward 0) and the narrow / blocked sinks (== the packed rows); then a replay: the action plane
+    of a narrow trajectory collected under the synthetic policy, fed back as a tape with its 4 * pitch row stride, reproduces
+    that trajectory and its final state."""
+    seed, lane0, steps = 4711, 8192, 150
+    nt = oracle_lib.max_threads()
+    o = oracle_lib.OracleEnv(env, **kw)
+    tape = _tape(np.random.RandomState(5), o.n_actions, steps, n, 1000)
+    d_tape = torch.as_tensor(tape, device="cuda")
+    e = make_env(env, kw, batch_size=n, seed=seed, lane_offset=lane0, reuse_buffers=True)
+    st = o.new_state(n)
+    assert np.array_equal(np_(e.reset()), o.batch_reset(st, seed, lane0, 0, nthreads=nt))
+    stats = e.collect_tape(d_tape, layout="returns")
+    acc, cnt = np.zeros((4, stats.acc.shape[1])), np.zeros((2, stats.acc.shape[1]), np.int32)
+    acc[1] = 1.0
+    o.batch_collect_returns(st, acc, cnt, e._discount, seed, lane0, 1, steps, nthreads=nt, actions=tape.astype(np.int32))
+    assert np.array_equal(np_(stats.acc)[:, :n].view(np.uint64), acc[:, :n].view(np.uint64))
+    assert np.array_equal(np_(stats.cnt)[:, :n], cnt[:, :n]) and np.array_equal(np_(e.state).view(np.uint32), st)
+    want = None
+    for layout in ("packed", "narrow", "blocked"):
+        f = make_env(env, kw, batch_size=n, seed=seed, lane_offset=lane0, reuse_buffers=True)
+        f.reset()
+        cols = f.decode_trajectory(f.collect_tape(d_tape, layout=layout), steps)
+        got = {k: np_(v).astype(np.float64) for k, v in cols.items()}
+        if want is None:
+            want = got
+        for k in want:
+            assert np.array_equal(got[k], want[k]), (layout, k)
+        assert np.array_equal(np_(f.state).view(np.uint32), st)
+    # replay
+    a = make_env(env, kw, batch_size=n, seed=seed + 1, lane_offset=lane0, reuse_buffers=True)
+    b = make_env(env, kw, batch_size=n, seed=seed + 1, lane_offset=lane0, reuse_buffers=True)
+    a.reset(), b.reset()
+    tr = a.collect_synthetic(steps, layout="narrow")
+    plane = tr["traj"][:, 0, :n]                                          # uint8 [steps, n], row stride 4 * pitch: used in place
+    assert b.as_tape(plane).data_ptr() == plane.data_ptr()
+    rp = b.collect_tape(plane, layout="narrow")
+    assert torch.equal(rp["traj"][:, :, :n], tr["traj"][:, :, :n]) and torch.equal(a.state, b.state) and b.invalid_action_count() == 0
+
+
+def test_tape_through_the_c_abi_and_host_checks():
+    """pomdp_collect_tape* called directly: argument checks, an unaligned tape (the general loop), and the host-side conversions."""
+    import ctypes as C
+    from gym_pomdp_amd import _native
+    L = _native.lib()
+    n, k = 2048, 20
+    e = make_env("rock", {}, batch_size=n, seed=3, reuse_buffers=True)
+    e.reset()
+    ref = make_env("rock", {}, batch_size=n, seed=3, reuse_buffers=True)
+    ref.reset()
+    raw = torch.randint(0, 13, (k, n + 3), dtype=torch.uint8, device="cuda")
+    tape = raw[:, 3:]                                                     # rows start 3 bytes off a 4-byte boundary, stride n + 3
+    bufs = e.trajectory_buffers(k)
+    ct = _native.Tape(actions=tape.data_ptr(), stride=n + 3)
+    args = (_native.ENV_KIND["rock"], e._params_ref, e.state.data_ptr())
+    tail = (bufs["ob"].data_ptr(), bufs["reward"].data_ptr(), bufs["done_u8"].data_ptr(), e._err.data_ptr(), n, 3, 0, 1, k, n)
+    assert L.pomdp_collect_tape(*args, None, *tail, 1, None) == -1
+    assert L.pomdp_collect_tape(*args, C.byref(ct), *tail, 0, None) == -1                 # auto-reset is required
+    assert L.pomdp_collect_tape(*args, C.byref(_native.Tape(actions=tape.data_ptr(), stride=n - 1)), *tail, 1, None) == -1
+    assert L.pomdp_collect_tape(*args, C.byref(_native.Tape(actions=None, stride=n)), *tail, 1, None) == -1
+    assert L.pomdp_collect_tape(*args, C.byref(ct), *tail, 1, None) == 0
+    assert _native.lib().pomdp_last_fused_kernel().decode().startswith("steps_kernel<")
+    for s in range(k):
+        ob, rew, done, _ = ref.step(tape[s].to(torch.int32))
+        assert torch.equal(bufs["ob"][s], ob) and torch.equal(bufs["reward"][s], rew) and torch.equal(bufs["done"][s], done), s
+    assert torch.equal(e.state, ref.state)
+    # host side: wide integers, lists, numpy; floats are refused like step() refuses them
+    t = e.as_tape(torch.tensor([[0, 300, -1, 12] + [1] * (n - 4)], dtype=torch.int64))
+    assert t.dtype == torch.uint8 and t[0, :4].tolist() == [0, 255, 255, 12]
+    assert e.as_tape(np.zeros((2, n), np.int32)).shape == (2, n)
+    with pytest.raises(AssertionError):
+        e.as_tape(torch.zeros((2, n)))
+    with pytest.raises(ValueError):
+        e.as_tape(torch.zeros((2, n - 1), dtype=torch.uint8))
+    with pytest.raises(ValueError):
+        make_env("rock", {}, batch_size=n, seed=3, auto_reset=False).collect_tape(tape)
+
+
 @pytest.mark.parametrize("env,kw,n", [("rock", {}, 1 << 20), ("tag", {}, 1 << 20), ("network", {}, 1 << 18), ("network", {}, 1 << 19),
                                       ("battleship", {}, 1 << 19)],
                          ids=["rock", "tag", "network", "network-quad", "battleship"])
@@ -240,7 +379,11 @@ def test_bench_line_as_the_driver_runs_it():
     pd = lay["packed_plus_decode"]      # records -> int32 columns costs more than writing the columns in the first place
     assert pd["kernel_ms"] > lay["columns"]["kernel_ms"] and 0.4 < pd["decode_hbm_frac"] < 1.0 and abs(pd["bytes_per_lane_step"] - 21.4) < 1e-9, pd
     cfg = d["configs"]
-    assert set(cfg) == {"tag", "battleship", "rollout_rock15", "plan_rock15", "returns_only"}
+    assert set(cfg) == {"tag", "battleship", "rollout_rock15", "plan_rock15", "tape_packed", "tape_returns", "returns_only"}
+    # the caller's actions instead of the synthetic policy's: the same loops, one load per quad-step instead of one Philox block
+    assert cfg["tape_packed"]["kernel"] == "steps_quad_kernel<RockEnv<1>, Packed, Tape>" and cfg["tape_packed"]["invalid_actions"] == 0
+    assert cfg["tape_returns"]["kernel"] == "steps_quad_kernel<RockEnv<1>, Returns, Tape>"
+    assert cfg["tape_returns"]["kernel_ms"] < 1.15 * cfg["returns_only"]["kernel_ms"], (cfg["tape_returns"], cfg["returns_only"])
     pl = cfg.pop("plan_rock15")          # configs[4] as planned REAL steps: rollout + on-device reduction + the roots' step
     assert pl["unit"] == "planned real env-steps/s" and pl["value"] > 1e5 and abs(sum(pl["share"].values()) - 1.0) < 1e-6, pl
     assert pl["share"]["rollout"] > 0.8 and pl["reduce_kernel_ms"] < 0.2 and pl["visited_actions_per_root"] > 3, pl
