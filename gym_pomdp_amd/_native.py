@@ -46,7 +46,7 @@ class RockParams(C.Structure):
     _fields_ = [("size", C.c_int32), ("num_rocks", C.c_int32), ("start_x", C.c_int32), ("start_y", C.c_int32),
                 ("rock_x", C.c_int8 * 16), ("rock_y", C.c_int8 * 16), ("grid", C.c_int8 * 256),
                 ("thr", C.c_uint64 * 32), ("eff", C.c_double * 32),
-                ("stochastic", C.c_int32), ("reserved", C.c_int32), ("act_thr", C.c_uint64)]
+                ("stochastic", C.c_int32), ("act_gt", C.c_int32), ("act_thr", C.c_uint64)]
 
 
 class TagParams(C.Structure):

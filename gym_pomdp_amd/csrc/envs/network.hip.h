@@ -172,6 +172,10 @@ struct NetworkEnv {
     // while some lane still has machines to draw for or its action's draw ahead (j is wave-uniform; under a random policy a
     // lane has 1.4 machines up, so two blocks serve 98 % of the lanes).  A tie (2^-16 per draw) sends the lane through
     // step_exact.
+    static __device__ __forceinline__ uint32_t machines_mask(const Params &p)
+    {
+        return p.n_machines >= 32 ? 0xFFFFFFFFu : ((1u << p.n_machines) - 1u);
+    }
     template <class RT>
     static __device__ __forceinline__ void step(const Shared &sh, const Params &p, State &st, int a,
                                                 const RngKey &key, uint32_t lane, int &ob, RT &rew, int &done)
@@ -192,7 +196,7 @@ struct NetworkEnv {
     static __device__ __forceinline__ void step_from(const Shared &sh, const Params &p, State &st, int a, const RngKey &key,
                                                      uint32_t lane, uint32_t W0, uint32_t W1, uint32_t W2, int &ob, RT &rew, int &done)
     {
-        const uint32_t s0 = st.w;
+        const uint32_t s0 = st.w & machines_mask(p);                             // bits at or above n_machines are not machines
         const int n_up = __popc(s0), base = n_up + __popc(s0 & p.deg_gt2_mask);       // network.py:87-92
         const uint32_t nbf = nb_failed_of(sh, p, s0);
         const Thr T = thresholds(p);
@@ -219,7 +223,8 @@ struct NetworkEnv {
     static __device__ __forceinline__ void step_exact(const Shared &sh, const Params &p, State &st, int a,
                                                       const RngKey &key, uint32_t lane, int &ob, RT &rew, int &done)
     {
-        const uint32_t s0 = st.w;
+        const uint32_t s0 = st.w & machines_mask(p);                             // every launch shape reads the same machines (a caller's
+                                                                                 // stray upper bits never become draws)
         const int M = p.n_machines;
         // reward: 2 per up machine with > 2 neighbours, 1 per other up machine   network.py:87-92
         const int n_up = __popc(s0);

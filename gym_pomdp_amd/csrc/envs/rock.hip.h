@@ -556,7 +556,7 @@ struct RockEnv {
             // the first double of the step gates the whole action (rock.py:443), the sensor draw is the second
             const uint4 g = quad_block(key, lane, 0u);
             const bool act = k53_le(elem(g, e), (uint32_t)(p.act_thr >> 26), (uint32_t)p.act_thr & LO_MASK,
-                                    [&]() { return elem(quad_block(key, lane, 1u), e); });
+                                    [&]() { return elem(quad_block(key, lane, 1u), e); }) != (p.act_gt != 0);
             State nx = st;
             Aux aux; RT r2; int d2;
             step_pre(sh, p, nx, a, r2, d2, aux);

@@ -304,7 +304,7 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acts[j] = Env::k53_le(G[j], (uint32_t)(p.act_thr >> 26), (uint32_t)p.act_thr & Env::LO_MASK,
-                                      [&]() { return Env::elem(Env::quad_block(key, glane0, 1u), (uint32_t)j); });
+                                      [&]() { return Env::elem(Env::quad_block(key, glane0, 1u), (uint32_t)j); }) != (p.act_gt != 0);
         }
         uint32_t codes[4], rec[4];
         const uint32_t a_taken[4] = {(uint32_t)a_cur[0], (uint32_t)a_cur[1], (uint32_t)a_cur[2], (uint32_t)a_cur[3]};

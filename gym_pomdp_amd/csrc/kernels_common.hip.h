@@ -59,6 +59,12 @@ constexpr int64_t STEP_QUAD_MIN_LANES = POMDP_STEP_QUAD_MIN_LANES;
 constexpr int64_t STEP_QUAD_MIN_LANES = 1 << 19;
 #endif
 
+#ifdef POMDP_STEP_TILES                                       // same-box A/B builds (tools/ab_build.sh): tiles per thread of the one-step quad kernels
+constexpr int STEP_TILES = POMDP_STEP_TILES;
+#else
+constexpr int STEP_TILES = 1;                                 // measured (round 6): two tiles per thread 7.6 against 6.5 us per call — DESIGN.md §5.2
+#endif
+
 // envs whose lanes carry the board of their next episode (BattleShip): `next` is loaded only where a lane may need it
 template <class Env, class = void> struct has_next : std::false_type {};
 template <class Env> struct has_next<Env, std::enable_if_t<Env::HAS_NEXT>> : std::true_type {};

@@ -135,15 +135,25 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(uint32_t *__restrict__ stat
 #endif
 }
 
-// ONE step of RockSample with the caller's actions (env.step()) and a quad of consecutive lanes per thread: the quad's
+// ONE step of RockSample with the caller's actions (env.step()) and quads of consecutive lanes per thread: a quad's
 // STEP block is the thread's own (one Philox block for four lane-steps, computed under the latency of the loads, no
 // exchange through LDS), state / action / ob / reward move as 16-byte accesses and the four done bytes as one word —
-// 105 VALU instructions per lane-step where step_kernel<Env, 2> issues 187; 7.8 against 8.3 us per step of 2^20 lanes for
-// RockSample(7,8), 7.5 against 8.8 for StochasticRock (whose step_kernel runs one lane per thread), inside a python loop
-// (DESIGN.md §5 has the timeline of such a launch).  Same contract as step_kernel: a lane whose action is out of range is left untouched and counted in
-// *err, without auto-reset a done lane stays frozen.  Full workgroups of 1024 lanes on 16-byte column boundaries only
-// (launch_step); anything else takes step_kernel.
-template <class Env>
+// 105 VALU instructions per lane-step where step_kernel<Env, 2> issues 187.
+// TILES (the product runs 1; -DPOMDP_STEP_TILES=2 builds the B arm): a one-step launch is 9 MB of loads, the lane steps and
+// 13 MB of stores; with one quad per thread every workgroup of the launch is resident at once and in the same phase, so the
+// three run one after the other (round 5's timeline: 1.3 + 2 + 1.2 us).  With TILES > 1 a thread walks TILES
+// tiles of 1024 lanes, software-pipelined: the loads of ALL its tiles are issued first, in tile order — HBM serves them
+// roughly in that order, and gfx9 returns them in order, so `s_waitcnt vmcnt(loads still to come)` releases tile 0 while the
+// later tiles are still streaming in —, then tile by tile the lane steps and the stores: tile i's stores drain under tile
+// i + 1's lane steps (its loads were issued BEFORE those stores, so waiting for them does not wait for the stores).
+// Workgroup w owns tiles w, w + G, ... of a G-workgroup launch.  Measured at 2^20 lanes (profiles/r06_step_tiles.txt): two
+// tiles 7.6 against 6.5 us per call (Network 10.6 against 9.2) — a 2^20-lane batch is 4096 quad-waves, four per SIMD; two
+// tiles per thread leave two, and two waves fill a SIMD's issue slots so much worse during the lane steps (the ~500
+// dependent-heavy instructions of a tile) that the overlap is lost twice over.
+// Same contract as step_kernel: a lane whose action is out of range is left untouched and counted in *err, without
+// auto-reset a done lane stays frozen.  n a multiple of TILES x 1024 lanes on 16-byte column boundaries only (launch_step);
+// anything else takes fewer tiles, or step_kernel.
+template <class Env, int TILES>
 __global__ __launch_bounds__(BLOCK) void step_quad_kernel(uint32_t *__restrict__ state, const int32_t *__restrict__ action,
                                                           int32_t *__restrict__ ob, int32_t *__restrict__ reward,
                                                           uint8_t *__restrict__ done, uint32_t *__restrict__ err, int64_t n,
@@ -154,66 +164,75 @@ __global__ __launch_bounds__(BLOCK) void step_quad_kernel(uint32_t *__restrict__
     __shared__ typename Env::Shared sh;
     TL(0);
     const bool auto_reset = flags & POMDP_AUTO_RESET;
-    const uint32_t l0 = blockIdx.x * (uint32_t)(4 * BLOCK) + 4u * threadIdx.x;
-    const uint32_t glane0 = lane0 + l0;
-    uint32_t *const done_w = reinterpret_cast<uint32_t *>(done + l0);
-    const u32x4 s_lo = ld_stream4(state + l0);
-    u32x4 s_hi = {0, 0, 0, 0};
-    if (W == 2) s_hi = ld_stream4(state + n + l0);
-    const u32x4 a4 = ld_stream4(reinterpret_cast<const uint32_t *>(action) + l0);
-    const uint32_t dn = auto_reset ? 0u : ld_stream(done_w);                       // frozen lanes (the reference would assert)
+    uint32_t l0[TILES];
+    u32x4 s_lo[TILES], s_hi[TILES], a4[TILES];
+    uint32_t dn[TILES];
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+        l0[t] = (blockIdx.x + (uint32_t)t * gridDim.x) * (uint32_t)(4 * BLOCK) + 4u * threadIdx.x;
+        s_lo[t] = ld_stream4(state + l0[t]);
+        s_hi[t] = u32x4{0, 0, 0, 0};
+        if (W == 2) s_hi[t] = ld_stream4(state + n + l0[t]);
+        a4[t] = ld_stream4(reinterpret_cast<const uint32_t *>(action) + l0[t]);
+        dn[t] = auto_reset ? 0u : ld_stream(reinterpret_cast<const uint32_t *>(done + l0[t]));   // frozen lanes (the reference would assert)
+    }
     const auto staged = Env::stage_load(p, (int)threadIdx.x);
-    // the quad's words depend on lane ids only: Philox under the load latency
-    constexpr uint32_t SENSOR_BLOCK = Env::SENSOR_BLOCK;
-    const uint4 sw = Env::quad_block(key, glane0, SENSOR_BLOCK);
-    // a lane's step draws EITHER its sensor reading OR (done) its next episode: both from this one block
-    const uint32_t H[4] = {sw.x, sw.y, sw.z, sw.w}, R[4] = {sw.x, sw.y, sw.z, sw.w};
-    uint32_t G[4] = {0, 0, 0, 0};
-    if constexpr (Env::STOCHASTIC) { const uint4 gw = Env::quad_block(key, glane0, 0u); G[0] = gw.x; G[1] = gw.y; G[2] = gw.z; G[3] = gw.w; }
     Env::stage_store(sh, staged, (int)threadIdx.x);
     __syncthreads();
 #ifdef POMDP_DEV_TIMELINE
     TL(1);
-    asm volatile("" :: "v"(s_lo[0] + a4[0]));
+    asm volatile("" :: "v"(s_lo[0][0] + a4[0][0]));
     TL(2);
 #endif
     const uint32_t n_act = (uint32_t)Env::n_actions(p);
-    typename Env::State st[4];
-    typename Env::Aux aux[4];
-    int r[4], d[4];
-    bool live[4], fresh[4];
     uint32_t n_bad = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const bool valid = a4[j] < n_act, was_done = ((dn >> (8 * j)) & 0xFFu) != 0u;
-        live[j] = valid && !was_done;
-        n_bad += (uint32_t)(!valid && !was_done);
-        st[j].s = (S)((uint64_t)s_lo[j] | ((uint64_t)s_hi[j] << 32));
-        typename Env::State nx = st[j];
-        Env::step_pre(sh, p, nx, valid ? (int)a4[j] : 0, r[j], d[j], aux[j]);
-        bool acts = live[j];
-        if constexpr (Env::STOCHASTIC)                                             // applied iff binomial(1, p_move) says so (rock.py:443)
-            acts = acts && Env::k53_le(G[j], (uint32_t)(p.act_thr >> 26), (uint32_t)p.act_thr & Env::LO_MASK,
-                                       [&]() { return Env::elem(Env::quad_block(key, glane0, 1u), (uint32_t)j); });
-        if (acts) st[j] = nx; else { r[j] = 0; d[j] = live[j] ? 0 : (int)was_done; aux[j].want = false; }
-        fresh[j] = acts && d[j] != 0 && auto_reset;                                // done lanes start a new episode
+    for (int t = 0; t < TILES; ++t) {
+        const uint32_t glane0 = lane0 + l0[t];
+        uint32_t *const done_w = reinterpret_cast<uint32_t *>(done + l0[t]);
+        // the quad's words depend on lane ids only: tile 0's Philox runs under the load latency, tile t's under tile t - 1's stores
+        constexpr uint32_t SENSOR_BLOCK = Env::SENSOR_BLOCK;
+        const uint4 sw = Env::quad_block(key, glane0, SENSOR_BLOCK);
+        // a lane's step draws EITHER its sensor reading OR (done) its next episode: both from this one block
+        const uint32_t H[4] = {sw.x, sw.y, sw.z, sw.w}, R[4] = {sw.x, sw.y, sw.z, sw.w};
+        uint32_t G[4] = {0, 0, 0, 0};
+        if constexpr (Env::STOCHASTIC) { const uint4 gw = Env::quad_block(key, glane0, 0u); G[0] = gw.x; G[1] = gw.y; G[2] = gw.z; G[3] = gw.w; }
+        typename Env::State st[4];
+        typename Env::Aux aux[4];
+        int r[4], d[4];
+        bool live[4], fresh[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool valid = a4[t][j] < n_act, was_done = ((dn[t] >> (8 * j)) & 0xFFu) != 0u;
+            live[j] = valid && !was_done;
+            n_bad += (uint32_t)(!valid && !was_done);
+            st[j].s = (S)((uint64_t)s_lo[t][j] | ((uint64_t)s_hi[t][j] << 32));
+            typename Env::State nx = st[j];
+            Env::step_pre(sh, p, nx, valid ? (int)a4[t][j] : 0, r[j], d[j], aux[j]);
+            bool acts = live[j];
+            if constexpr (Env::STOCHASTIC)                                             // applied iff binomial(1, p_move) says so (rock.py:443)
+                acts = acts && (Env::k53_le(G[j], (uint32_t)(p.act_thr >> 26), (uint32_t)p.act_thr & Env::LO_MASK,
+                                            [&]() { return Env::elem(Env::quad_block(key, glane0, 1u), (uint32_t)j); }) != (p.act_gt != 0));
+            if (acts) st[j] = nx; else { r[j] = 0; d[j] = live[j] ? 0 : (int)was_done; aux[j].want = false; }
+            fresh[j] = acts && d[j] != 0 && auto_reset;                                // done lanes start a new episode
+        }
+        // (A CHECK neither moves the agent nor ends the episode: the sensor reads the state the step left.)
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            o[j] = (uint32_t)Env::sensor_ob(sh, st[j], aux[j], H[j], [&]() { return Env::elem(Env::quad_block(key, glane0, SENSOR_BLOCK + 1u), (uint32_t)j); });
+        st_stream4(reinterpret_cast<uint32_t *>(ob) + l0[t], o[0], o[1], o[2], o[3]);
+        st_stream4(reinterpret_cast<uint32_t *>(reward) + l0[t], (uint32_t)r[0], (uint32_t)r[1], (uint32_t)r[2], (uint32_t)r[3]);
+        st_stream(done_w, (uint32_t)d[0] | ((uint32_t)d[1] << 8) | ((uint32_t)d[2] << 16) | ((uint32_t)d[3] << 24));
+        if (t == 0) TL(3);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            st[j].s = fresh[j] ? Env::fresh_state(p, R[j], key, glane0 + (uint32_t)j) : st[j].s;
+        st_stream4(state + l0[t], (uint32_t)st[0].s, (uint32_t)st[1].s, (uint32_t)st[2].s, (uint32_t)st[3].s);
+        if (W == 2)
+            st_stream4(state + n + l0[t], (uint32_t)((uint64_t)st[0].s >> 32), (uint32_t)((uint64_t)st[1].s >> 32),
+                       (uint32_t)((uint64_t)st[2].s >> 32), (uint32_t)((uint64_t)st[3].s >> 32));
     }
-    // (A CHECK neither moves the agent nor ends the episode: the sensor reads the state the step left.)
-    uint32_t o[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-        o[j] = (uint32_t)Env::sensor_ob(sh, st[j], aux[j], H[j], [&]() { return Env::elem(Env::quad_block(key, glane0, SENSOR_BLOCK + 1u), (uint32_t)j); });
-    st_stream4(reinterpret_cast<uint32_t *>(ob) + l0, o[0], o[1], o[2], o[3]);
-    st_stream4(reinterpret_cast<uint32_t *>(reward) + l0, (uint32_t)r[0], (uint32_t)r[1], (uint32_t)r[2], (uint32_t)r[3]);
-    st_stream(done_w, (uint32_t)d[0] | ((uint32_t)d[1] << 8) | ((uint32_t)d[2] << 16) | ((uint32_t)d[3] << 24));
-    TL(3);
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-        st[j].s = fresh[j] ? Env::fresh_state(p, R[j], key, glane0 + (uint32_t)j) : st[j].s;
-    st_stream4(state + l0, (uint32_t)st[0].s, (uint32_t)st[1].s, (uint32_t)st[2].s, (uint32_t)st[3].s);
-    if (W == 2)
-        st_stream4(state + n + l0, (uint32_t)((uint64_t)st[0].s >> 32), (uint32_t)((uint64_t)st[1].s >> 32),
-                   (uint32_t)((uint64_t)st[2].s >> 32), (uint32_t)((uint64_t)st[3].s >> 32));
     if (n_bad && err) atomicAdd(err, n_bad);
 #ifdef POMDP_DEV_TIMELINE
     TL(4);
@@ -229,7 +248,8 @@ __global__ __launch_bounds__(BLOCK) void step_quad_kernel(uint32_t *__restrict__
 // action, ob and reward move as 16-byte accesses.  Same contract as step_kernel: an out-of-range action leaves the lane
 // untouched and is counted in *err; without auto-reset a lane whose done flag is set stays frozen (Network itself never
 // sets it).
-template <class Env>   // NetworkEnv (a template so that the header may be included by several translation units)
+// TILES: as step_quad_kernel — every tile's loads first, in tile order, then lane steps and stores tile by tile.
+template <class Env, int TILES>   // NetworkEnv (a template so that the header may be included by several translation units)
 __global__ __launch_bounds__(BLOCK) void network_step_quad_kernel(uint32_t *__restrict__ state, const int32_t *__restrict__ action,
                                                                   int32_t *__restrict__ ob, float *__restrict__ reward,
                                                                   uint8_t *__restrict__ done, uint32_t *__restrict__ err, int64_t n,
@@ -237,28 +257,38 @@ __global__ __launch_bounds__(BLOCK) void network_step_quad_kernel(uint32_t *__re
 {
     __shared__ typename Env::Shared sh;
     const bool auto_reset = flags & POMDP_AUTO_RESET;
-    const uint32_t l0 = blockIdx.x * (uint32_t)(4 * BLOCK) + 4u * threadIdx.x;
-    const uint32_t glane0 = lane0 + l0;
-    uint32_t *const done_w = reinterpret_cast<uint32_t *>(done + l0);
-    const u32x4 s4 = ld_stream4(state + l0);
-    const u32x4 a4 = ld_stream4(reinterpret_cast<const uint32_t *>(action) + l0);
-    const uint32_t dn = auto_reset ? 0u : ld_stream(done_w);
-    // the quad's blocks depend on lane ids only: Philox under the load latency
-    const uint4 q0 = Env::quad_block(key, glane0, 0u), q1 = Env::quad_block(key, glane0, 1u), q2 = Env::quad_block(key, glane0, 2u);
-    const uint32_t W0[4] = {q0.x, q0.y, q0.z, q0.w}, W1[4] = {q1.x, q1.y, q1.z, q1.w}, W2[4] = {q2.x, q2.y, q2.z, q2.w};
+    uint32_t l0[TILES], dn_t[TILES];
+    u32x4 s4_t[TILES], a4_t[TILES];
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+        l0[t] = (blockIdx.x + (uint32_t)t * gridDim.x) * (uint32_t)(4 * BLOCK) + 4u * threadIdx.x;
+        s4_t[t] = ld_stream4(state + l0[t]);
+        a4_t[t] = ld_stream4(reinterpret_cast<const uint32_t *>(action) + l0[t]);
+        dn_t[t] = auto_reset ? 0u : ld_stream(reinterpret_cast<const uint32_t *>(done + l0[t]));
+    }
     Env::stage(sh, p, (int)threadIdx.x);
     __syncthreads();
     const typename Env::Thr T = Env::thresholds(p);
     const int M2 = 2 * p.n_machines;
     const uint32_t n_act = (uint32_t)Env::n_actions(p);
+    const uint32_t all_up = p.n_machines >= 32 ? 0xFFFFFFFFu : ((1u << p.n_machines) - 1u);
+    uint32_t n_bad = 0;
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+    const uint32_t glane0 = lane0 + l0[t];
+    uint32_t *const done_w = reinterpret_cast<uint32_t *>(done + l0[t]);
+    const u32x4 s4 = s4_t[t], a4 = a4_t[t];
+    const uint32_t dn = dn_t[t];
+    // the quad's blocks depend on lane ids only: Philox under the load latency (tile 0) / the previous tile's stores
+    const uint4 q0 = Env::quad_block(key, glane0, 0u), q1 = Env::quad_block(key, glane0, 1u), q2 = Env::quad_block(key, glane0, 2u);
+    const uint32_t W0[4] = {q0.x, q0.y, q0.z, q0.w}, W1[4] = {q1.x, q1.y, q1.z, q1.w}, W2[4] = {q2.x, q2.y, q2.z, q2.w};
     uint32_t st[4], kill[4], todo[4], nbf[4], near[4];
     int base[4], a_eff[4];
     bool truthful[4], pend[4], need[4], live[4];
     bool any_need = false;
-    uint32_t n_bad = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const uint32_t s0 = s4[j];
+        const uint32_t s0 = s4[j] & all_up;                                    // bits at or above n_machines are not machines: every launch shape masks them
         st[j] = s0;
         nbf[j] = Env::nb_failed_of(sh, p, s0);
         todo[j] = s0;
@@ -310,26 +340,29 @@ __global__ __launch_bounds__(BLOCK) void network_step_quad_kernel(uint32_t *__re
     for (int j = 0; j < 4; ++j) {
         int o = 0;
         float r = 0.f;
+        uint32_t sn = s4[j];                                                   // a lane that does not step keeps its word as it came
         if (live[j]) {
             if (near[j] < Env::TIE) {                                          // a draw decided below its top 16 bits: the exact per-lane form
                 typename Env::State e{st[j]};
                 int d;
                 Env::step_exact(sh, p, e, a_eff[j], key, glane0 + (uint32_t)j, o, r, d);
-                st[j] = e.w;
+                sn = e.w;
             } else {                                                           // network.py:101-112
                 typename Env::State e{st[j] & ~kill[j]};
                 Env::finish(p, e.w, a_eff[j], base[j], truthful[j], o, r);
-                st[j] = e.w;
+                sn = e.w;
             }
         }
+        st[j] = sn;
         o4[j] = (uint32_t)o;
         r4[j] = __float_as_uint(r);
         dpack |= (((dn >> (8 * j)) & 0xFFu) != 0u ? 1u : 0u) << (8 * j);      // network.py:113: never done; a frozen lane keeps its flag
     }
-    st_stream4(state + l0, st[0], st[1], st[2], st[3]);
-    st_stream4(reinterpret_cast<uint32_t *>(ob) + l0, o4[0], o4[1], o4[2], o4[3]);
-    st_stream4(reinterpret_cast<uint32_t *>(reward) + l0, r4[0], r4[1], r4[2], r4[3]);
+    st_stream4(state + l0[t], st[0], st[1], st[2], st[3]);
+    st_stream4(reinterpret_cast<uint32_t *>(ob) + l0[t], o4[0], o4[1], o4[2], o4[3]);
+    st_stream4(reinterpret_cast<uint32_t *>(reward) + l0[t], r4[0], r4[1], r4[2], r4[3]);
     st_stream(done_w, dpack);
+    }
     if (n_bad && err) atomicAdd(err, n_bad);
 }
 
@@ -357,12 +390,18 @@ int launch_step(const typename Env::Params &p, uint32_t *state, const int32_t *a
     // Finisher specialisation above) and the batch still gives every CU several workgroups; one lane per thread
     // otherwise (measured equal within 2 % for the generic envs, tools/microbench.hip).
     if constexpr (Env::QUAD_STEP) {
-        // a quad of lanes per thread (step_quad_kernel) once the batch fills the chip with such workgroups
+        // quads of lanes per thread (step_quad_kernel) once the batch fills the chip with such workgroups
         const bool cols16 = ((reinterpret_cast<uintptr_t>(state) | reinterpret_cast<uintptr_t>(action) | reinterpret_cast<uintptr_t>(ob) |
                               reinterpret_cast<uintptr_t>(reward)) & 15u) == 0 && (reinterpret_cast<uintptr_t>(done) & 3u) == 0;
         if (n >= STEP_QUAD_MIN_LANES && n % (4 * BLOCK) == 0 && (lane0 & 3u) == 0 && cols16) {
-            hipLaunchKernelGGL(step_quad_kernel<Env>, dim3((unsigned)(n / (4 * BLOCK))), dim3(BLOCK), 0, (hipStream_t)stream, state,
-                               action, ob, reward, done, err, n, make_key(seed, t), lane0, flags, p);
+            // STEP_TILES tiles per thread, software-pipelined, while that leaves every CU two workgroups (see the kernel)
+            const int64_t tiles = n / (4 * BLOCK);
+            if (STEP_TILES >= 2 && tiles % STEP_TILES == 0 && tiles / STEP_TILES >= 2 * 256)
+                hipLaunchKernelGGL((step_quad_kernel<Env, STEP_TILES>), dim3((unsigned)(tiles / STEP_TILES)), dim3(BLOCK), 0, (hipStream_t)stream,
+                                   state, action, ob, reward, done, err, n, make_key(seed, t), lane0, flags, p);
+            else
+                hipLaunchKernelGGL((step_quad_kernel<Env, 1>), dim3((unsigned)tiles), dim3(BLOCK), 0, (hipStream_t)stream, state,
+                                   action, ob, reward, done, err, n, make_key(seed, t), lane0, flags, p);
             return (int)hipGetLastError();
         }
     }
@@ -370,8 +409,13 @@ int launch_step(const typename Env::Params &p, uint32_t *state, const int32_t *a
         const bool cols16 = ((reinterpret_cast<uintptr_t>(state) | reinterpret_cast<uintptr_t>(action) | reinterpret_cast<uintptr_t>(ob) |
                               reinterpret_cast<uintptr_t>(reward)) & 15u) == 0 && (reinterpret_cast<uintptr_t>(done) & 3u) == 0;
         if (n >= STEP_QUAD_MIN_LANES && n % (4 * BLOCK) == 0 && (lane0 & 3u) == 0 && cols16) {    // a thread's quad = a quad of the word contract
-            hipLaunchKernelGGL(network_step_quad_kernel<Env>, dim3((unsigned)(n / (4 * BLOCK))), dim3(BLOCK), 0, (hipStream_t)stream, state,
-                               action, ob, reward, done, err, n, make_key(seed, t), lane0, flags, p);
+            const int64_t tiles = n / (4 * BLOCK);
+            if (STEP_TILES >= 2 && tiles % STEP_TILES == 0 && tiles / STEP_TILES >= 2 * 256)
+                hipLaunchKernelGGL((network_step_quad_kernel<Env, STEP_TILES>), dim3((unsigned)(tiles / STEP_TILES)), dim3(BLOCK), 0,
+                                   (hipStream_t)stream, state, action, ob, reward, done, err, n, make_key(seed, t), lane0, flags, p);
+            else
+                hipLaunchKernelGGL((network_step_quad_kernel<Env, 1>), dim3((unsigned)tiles), dim3(BLOCK), 0, (hipStream_t)stream, state,
+                                   action, ob, reward, done, err, n, make_key(seed, t), lane0, flags, p);
             return (int)hipGetLastError();
         }
     }

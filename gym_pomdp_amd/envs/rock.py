@@ -67,10 +67,10 @@ def make_params(board_size=7, num_rocks=8, stochastic=False, p_move=.8):
         if p_move == .8:
             p.act_thr = tables.TAG_MOVE_THR          # binomial(1, .8): the same captured threshold
         else:
+            if not 0. < p_move < 1.:
+                raise ValueError("StochasticRock: p_move must lie in (0, 1), got %r" % (p_move,))
             thr, sense = tables.bernoulli_threshold(p_move)
-            if sense != "le":
-                raise ValueError("StochasticRock: p_move <= 0.5 is not supported by the packed threshold compare")
-            p.act_thr = thr
+            p.act_thr, p.act_gt = thr, int(sense == "gt")   # numpy's binomial(1, p): [U > thr] for p <= .5 (rock.py:443)
     words = 1 if num_rocks <= 12 else 2
     return p, words, 5 + num_rocks, 3
 

@@ -102,7 +102,7 @@ typedef struct pomdp_rock_params {
     double   eff[32];       /* eff(d) itself, returned by pomdp_compute_prob            rock.py:383-387 */
     int32_t  stochastic;    /* 1 = StochasticRockEnv (rock.py:428-504): the action is applied only when a
                                binomial(1, p_move) draw succeeds, penalties are 0 and do not terminate */
-    int32_t  reserved;
+    int32_t  act_gt;        /* stochastic, 1: act iff k53 > act_thr instead — numpy's binomial(1, p_move) for p_move <= .5 (ABI 14) */
     uint64_t act_thr;       /* stochastic: act iff k53 <= act_thr (first double of stream STEP)  rock.py:443 */
 } pomdp_rock_params;
 

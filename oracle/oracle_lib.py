@@ -78,8 +78,14 @@ def env_args(name, **kw):
     if name == "rock":
         return [kw.get("board_size", 7), kw.get("num_rocks", 8)]
     if name == "stochrock":
-        thr = int(kw.get("act_thr", 0))
-        return [kw.get("board_size", 7), kw.get("num_rocks", 8), 1, thr & 0xFFFFFFFF, thr >> 32]
+        thr, gt = int(kw.get("act_thr", 0)), 0
+        p = kw.get("p_move", .8)
+        if p != .8:          # numpy legacy binomial(1, p), as for Tag's move_prob below
+            import math
+            gt = int(p <= .5)
+            q = 1.0 - p if gt else 1.0 - (1.0 - p)
+            thr = math.floor(math.exp(math.log(q)) * 2 ** 53)
+        return [kw.get("board_size", 7), kw.get("num_rocks", 8), 1, thr & 0xFFFFFFFF, thr >> 32, gt]
     if name == "tag":
         thr, gt = int(kw.get("move_thr", 0)), 0
         p = kw.get("move_prob", .8)

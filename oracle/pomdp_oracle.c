@@ -238,6 +238,7 @@ struct or_env {
     int size, num_rocks, n_listed;
     int stochastic;            /* StochasticRockEnv (rock.py:428-504): action applied w.p. p_move, penalty 0 */
     uint64_t act_thr;          /* binomial(1, p_move) == 1 iff k53 <= act_thr */
+    int act_gt;                /* ... iff k53 > act_thr for p_move <= .5 (numpy's inversion takes the other branch) */
     coord start, rock_pos[MAX_ROCKS];
     int grid[16][16];          /* grid.board[x, y], -1 = empty (rock.py:108-111) */
     coord agent;
@@ -324,6 +325,7 @@ or_env *or_env_new(int kind, const int64_t *a, int nargs)
         e->stochastic = nargs >= 3 ? (int)a[2] : 0;
         e->act_thr = nargs >= 5 ? ((uint64_t)(uint32_t)a[3] | ((uint64_t)(uint32_t)a[4] << 32)) : 0;
         if (e->act_thr == 0) e->act_thr = TAG_MOVE_THR;      /* p_move = .8: the same captured threshold as binomial(1, .8) */
+        e->act_gt = nargs >= 6 ? (int)a[5] : 0;
         break;
     case OR_ENV_TAG:
         e->n_opponents = nargs >= 1 ? (int)a[0] : 1;
@@ -421,7 +423,7 @@ static void rock_step(or_env *e, int action, or_ws *np_rng, int *ob_out, double 
     /* StochasticRockEnv.step (rock.py:434-504): `if np.random.binomial(1, p=self.p_move):` gates the whole
      * action; _penalization is 0 and the `done = penalization == reward` line is commented out (rock.py:503) */
     const int penal = e->stochastic ? 0 : -100;
-    if (e->stochastic && !(or_draw_k53(np_rng) <= e->act_thr)) { *ob_out = 0; *rw_out = 0; *done_out = 0; return; }
+    if (e->stochastic && !((or_draw_k53(np_rng) <= e->act_thr) != (e->act_gt != 0))) { *ob_out = 0; *rw_out = 0; *done_out = 0; return; }
     if (action < 4) {
         if (action == 1) {                                   /* EAST  rock.py:135-141 */
             if (e->agent.x + 1 < e->size) e->agent.x += 1;

@@ -74,6 +74,7 @@ void     or_ws_philox_auto_reset(or_ws *ws, const or_env *e, uint64_t seed, uint
 void     or_ws_philox_step(or_ws *ws, const or_env *e, uint64_t seed, uint32_t lane, uint64_t t);
 
 /* args: rock (board_size, num_rocks[, stochastic, act_thr_lo, act_thr_hi])  stochastic = StochasticRockEnv
+ *       stochrock (board_size, num_rocks, 1, act_thr_lo, act_thr_hi[, act_gt])  thr==0 -> the captured value for 0.8; act_gt: acts iff k > thr
  *       tag (num_opponents, obs_cells, move_thr_lo, move_thr_hi[, move_gt])  thr==0 -> captured value for 0.8; move_gt: moves iff k > thr
  *       battleship (x_size, y_size, max_len)
  *       tiger ()

@@ -40,6 +40,7 @@ CASES = [
     ("tag_1", "tag", {}, 4000, 512, 64),
     ("tag_2", "tag", dict(num_opponents=2), 4000, 256, 64),
     ("tag_4", "tag", dict(num_opponents=4), 2000, 128, 64),
+    ("stochrock_7_8_p04", "stochrock", dict(p_move=.4), 1500, 128, 64),   # ... and StochasticRockEnv(p_move <= .5) (rock.py:431, 443)
     ("tag_1_p03", "tag", dict(move_prob=.3), 2000, 128, 64),      # binomial(1, p <= .5): the other sense of numpy's inversion
     ("tag_2_p06", "tag", dict(num_opponents=2, move_prob=.6), 1000, 64, 64),
     ("battleship_5_5", "battleship", {}, 1500, 512, 48),

@@ -158,8 +158,7 @@ def test_tape_driven_returns_and_other_sinks(oracle_lib, fuse64, env, kw, n):
     st = o.new_state(n)
     assert np.array_equal(np_(e.reset()), o.batch_reset(st, seed, lane0, 0, nthreads=nt))
     stats = e.collect_tape(d_tape, layout="returns")
-    acc, cnt = np.zeros((4, stats.acc.shape[1])), np.zeros((2, stats.acc.shape[1]), np.int32)
-    acc[1] = 1.0
+    acc, cnt = oracle_lib.new_return_stats(n, stats.acc.shape[1])
     o.batch_collect_returns(st, acc, cnt, e._discount, seed, lane0, 1, steps, nthreads=nt, actions=tape.astype(np.int32))
     assert np.array_equal(np_(stats.acc)[:, :n].view(np.uint64), acc[:, :n].view(np.uint64))
     assert np.array_equal(np_(stats.cnt)[:, :n], cnt[:, :n]) and np.array_equal(np_(e.state).view(np.uint32), st)
@@ -219,8 +218,12 @@ def test_tape_through_the_c_abi_and_host_checks():
         e.as_tape(torch.zeros((2, n)))
     with pytest.raises(ValueError):
         e.as_tape(torch.zeros((2, n - 1), dtype=torch.uint8))
+    frozen = make_env("rock", {}, batch_size=n, seed=3, auto_reset=False)
+    with pytest.raises(AttributeError):
+        frozen.collect_tape(tape)                                          # before reset(), like step()
+    frozen.reset()
     with pytest.raises(ValueError):
-        make_env("rock", {}, batch_size=n, seed=3, auto_reset=False).collect_tape(tape)
+        frozen.collect_tape(tape)                                          # auto_reset envs only
 
 
 @pytest.mark.parametrize("env,kw,n", [("rock", {}, 1 << 20), ("tag", {}, 1 << 20), ("network", {}, 1 << 18), ("network", {}, 1 << 19),
