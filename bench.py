@@ -121,6 +121,10 @@ def valu_roofline(workload, kernel_prefix, lanes, launch_ms):
     achieved = insts / (launch_ms * 1e-3)
     return {"bound": "valu", "achieved": achieved, "peak": SIMD_HZ / cpi, "unit": "wave-instructions/s",
             "frac": achieved * cpi / SIMD_HZ, "insts_per_launch": insts, "launch_ms": launch_ms,
+            # the same count against the programming guide's flat figure — every wave64 VALU instruction 2 cycles — beside the
+            # priced one: `frac` says how full the issue slots are for THIS mix as measured, `frac_flat_2cyc` how far the
+            # instruction count is from a machine that issued everything at the guide's rate
+            "frac_flat_2cyc": achieved * 2.0 / SIMD_HZ,
             "cycles_per_instruction": cpi, "lane_ops_per_s": achieved * 64, "kernel": name,
             "counters_stale": counters_stale(pmc, workload) or json.load(open(mix)).get("csrc_sha256") != csrc_sha(),
             "source": "instructions per launch recorded (not measured in this run): profiles/%s [%s]; issue cost of the "

@@ -1,6 +1,7 @@
 // api.hip — the C ABI of include/pomdp_hip.h: per-env reset / step, bound-argument and scalar-mode entry points, the synthetic policy, the C-side episode loops.
 // Part of libpomdp_hip.so; built by gym_pomdp_amd/_native.py (hipcc --offload-arch=gfx950 -O3 -std=c++17 -c, one object per file).
 #include "kernels_common.hip.h"
+#include <atomic>
 #include <cstring>
 
 namespace pomdp {
@@ -8,7 +9,7 @@ namespace pomdp {
 thread_local uint32_t *tl_host_flag = nullptr;
 thread_local uint32_t tl_flag_value = 0;
 thread_local char g_last_fused[96] = "";
-int g_fuse_max = POMDP_FUSE_MAX_DEFAULT;
+std::atomic<int> g_fuse_max{POMDP_FUSE_MAX_DEFAULT};     // process-wide, set and read by any host thread (relaxed: a knob, not a fence)
 
 // ---------------------------------------------------------------------------
 // helpers
@@ -537,14 +538,14 @@ int pomdp_fuse_steps(int env, int layout)
 {
     const bool wide = layout == POMDP_LAYOUT_COLUMNS || layout == POMDP_LAYOUT_BLOCKED;
     const bool store_bound = env == POMDP_ENV_ROCK || env == POMDP_ENV_TAG || env == POMDP_ENV_TIGER;
-    const int f = g_fuse_max;
+    const int f = g_fuse_max.load(std::memory_order_relaxed);
     return (wide && store_bound && f > 64) ? 64 : f;
 }
 
 int pomdp_fuse_max(int v)
 {
-    const int old = g_fuse_max;
-    if (v >= 1) g_fuse_max = v > FUSE_MAX_LIMIT ? FUSE_MAX_LIMIT : v;
+    const int old = g_fuse_max.load(std::memory_order_relaxed);
+    if (v >= 1) g_fuse_max.store(v > FUSE_MAX_LIMIT ? FUSE_MAX_LIMIT : v, std::memory_order_relaxed);
     return old;
 }
 

@@ -55,8 +55,9 @@ struct TigerEnv {
     static __device__ __forceinline__ void reset_where(const Shared &sh, const Params &p, State &st, bool fresh,
                                                        const RngKey &key, uint32_t lane)
     {
-        // a lane is fresh because the step just before (same key, same lane) opened the tiger's door, and that step
-        // already drew the new episode's door from stream RESET_SPACE: no second Philox block
+        // a lane is fresh because the step just before (same key, same lane) opened the tiger's door; step() then left the new
+        // episode's door — bit 0 of the lane's word of the quad's STEP block, which a terminal step does not otherwise read
+        // (tiger.py:81-83 returns before any draw) — in st.rs: no second Philox block
         if (fresh) {
             if (st.rs != NO_RS) st.w = st.rs;
             else reset(sh, p, st, key, lane);

@@ -13,6 +13,7 @@
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC (see __graft_entry__.build()).
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <chrono>
 
 #include "../../include/pomdp_hip.h"
@@ -436,9 +437,9 @@ constexpr int64_t QUAD_MIN_ROCK = 3 << 18, QUAD_MIN_STOCHROCK = 1 << 19, QUAD_MI
 
 // steps per fused launch of the C-side drivers (pomdp_fuse_max; defined in api.hip).  One place instead of a constant per
 // driver; a launch's fixed cost is paid once per this many steps, results never depend on it
-extern int g_fuse_max;
+extern std::atomic<int> g_fuse_max;
 constexpr int FUSE_MAX_LIMIT = 256;                            // BattleShip's board pool keeps a lane's deal step in a byte
-static inline int64_t fuse_max() { return (int64_t)g_fuse_max; }
+static inline int64_t fuse_max() { return (int64_t)g_fuse_max.load(std::memory_order_relaxed); }
 
 // which kernel the calling thread's most recent fused launch picked (pomdp_last_fused_kernel: bench.py names the kernel
 // it timed from this instead of guessing the launcher's choice; defined in api.hip)

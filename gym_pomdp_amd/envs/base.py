@@ -645,8 +645,8 @@ class BatchedEnv(compat.EnvBase):
     def rollout_synthetic(self, steps, action_seed=None, actions=None, fuse=False):
         """`steps` consecutive step() calls under the synthetic uniform policy, issued from C
         (pomdp_rollout_synthetic): the same launches per step a python loop over synthetic_actions() + step()
-        makes, without the interpreter between them.  `fuse=True` (policy key == env key only): up to 64
-        consecutive steps share one launch — every step's outputs are still computed and written, so all
+        makes, without the interpreter between them.  `fuse=True` (policy key == env key only): up to pomdp_fuse_max()
+        (256) consecutive steps share one launch — every step's outputs are still computed and written, so all
         buffers end up exactly as after the per-step launches, but a lane's state stays in registers between
         its steps.  Outputs land in the reusable buffers; returns (ob, reward, done) of the last step.
         Asynchronous."""
@@ -853,7 +853,8 @@ class BatchedEnv(compat.EnvBase):
         (pomdp_collect_synthetic): returns {"action": int32 [steps + 1, N] (row s = the actions of step s, last row = the
         next call's), "ob": int32 [steps, N], "reward": [steps, N], "done": bool [steps, N]} — row s equals what
         synthetic_actions() + step() return at that call.  The batched form of the reference callers' episode
-        loops (rock.py:553-575); up to 64 steps per launch, auto_reset envs only.  `out`: a dict from an earlier call
+        loops (rock.py:553-575); up to pomdp_fuse_steps(env, layout) steps per launch (256; 64 for the 13-byte layouts of RockSample /
+        Tag / Tiger), auto_reset envs only.  `out`: a dict from an earlier call
         to write into.  `layout` (default: `out`'s, else "columns"): "blocked" / "packed" / "narrow" write the same
         information as one stream per step (pomdp_collect_layout; trajectory_buffers, decode_trajectory).  Asynchronous."""
         if not self._has_reset:

@@ -49,6 +49,11 @@
  * starts (tiger.py:60-66) — and reads it from the QUAD's stream STEP (counter word 0 = lane / 4, lane L element L % 4): the
  * double's high word, or the door (bit 0), from block 0; the double's low word (a tie of the top 27 bits only) from block
  * 1.  One block serves four lanes.  (Streams STEP_SPACE / RESET_SPACE — the gym-space RNG's own — are no longer read.)
+ * Consequence for callers: pomdp_tiger_reset and pomdp_tiger_step of the same lanes must not be given the same (seed, t) —
+ * the step's wrong-door resample would redraw the door reset() just dealt.  A call counter that advances with every call
+ * (what the host mirror keeps: reset() is call t, the first step call t + 1) never does; re-seeding with the SAME seed
+ * rewinds it, so follow such a seed() by reset(), as the reference's callers do (network.py:176-177 in the other order is
+ * harmless there: its reset() ran under the previous seed).
  * Tag with ONE opponent (ABI 13): a step draws only when a TAG fails (the opponent's flight: binomial(1, move_prob), then
  * np.random.choice over 2 or 4 moves, tag.py:201-207) or succeeds (the reset that follows inside the call: randint(29) per
  * cell, tag.py:181-193) — never both — and reads the lane's word W of the QUAD's STEP block 0 for either: the flight's double

@@ -13,6 +13,7 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: a minute or more on the GPU box (still part of -m gpu; deselect with -m 'gpu and not slow')")
 
 
 def golden_manifest():

@@ -820,6 +820,59 @@ def test_tag_quad_word_rare_paths():
             assert np.array_equal(np_(e.decode_state()[col]), g["state"][i]), (lane, n)
 
 
+def test_tag_quad_word_rare_paths_in_the_fused_loops():
+    """The same fixture through the FUSED consumers of Tag's word contract, which a tape of the caller's actions can now steer
+    onto the tie lanes: tag_steps_quad_kernel with and without its step table (2^19 lanes; 16 steps / 1 step per launch) and
+    the general one-lane-per-thread loop (8 lanes: step_w / fresh_w on the time-shared quad block).  Row 0 — TAG everywhere, as
+    in the fixture — against the reference's outcome; every row and the final state against a python loop over step()."""
+    import os
+    from conftest import GOLDEN
+    from gym_pomdp_amd import _native
+    g = dict(np.load(os.path.join(GOLDEN, "ties_tag.npz")))
+    seed = int(g["seed"])
+    for i, lane in enumerate(g["lanes"]):
+        lane = int(lane)
+        for n, k, kernel in ((8, 1, "steps_kernel<"), (8, 16, "steps_kernel<"), (1 << 19, 1, "tag_steps_quad_kernel<false"), (1 << 19, 16, "tag_steps_quad_kernel<true")):
+            base = lane & ~7 if n == 8 else max(0, (lane & ~1023) - (n // 2))
+            col = lane - base
+            e = make_env("tag", {}, batch_size=n, seed=seed, lane_offset=base)
+            ref = make_env("tag", {}, batch_size=n, seed=seed, lane_offset=base)
+            e.reset(), ref.reset()
+            tape = torch.randint(0, 5, (k, n), dtype=torch.uint8, device="cuda")
+            tape[0] = 4
+            cols = e.decode_trajectory(e.collect_tape(tape, layout="packed"), k)
+            assert _native.lib().pomdp_last_fused_kernel().decode().startswith(kernel), (n, k)
+            assert (int(cols["ob"][0, col]), float(cols["reward"][0, col]), int(cols["done"][0, col])) == \
+                (int(g["ob"][i]), float(g["reward"][i]), int(g["done"][i])), (lane, n, k)
+            for s in range(k):
+                ob, rew, done, _ = ref.step(tape[s].to(torch.int32))
+                assert torch.equal(cols["ob"][s], ob) and torch.equal(cols["reward"][s], rew) and torch.equal(cols["done"][s], done), (lane, n, k, s)
+                if s == 0:
+                    assert np.array_equal(np_(ref.decode_state()[col]), g["state"][i]), (lane, n)
+            assert torch.equal(e.state, ref.state), (lane, n, k)
+
+
+def test_network_state_words_with_stray_bits_step_alike_in_every_launch_shape():
+    """A Network state word is n_machines bits; set_state() refuses anything above them, but a C caller could hand such a
+    word in.  Every launch shape — the one-lane step kernel, the quad step kernel (2^19 lanes), the fused loops — reads the
+    machines only: the same draws, observation and reward as for the clean word."""
+    for n in (1000, 1 << 19):
+        clean = make_env("network", {}, batch_size=n, seed=11, reuse_buffers=True)
+        dirty = make_env("network", {}, batch_size=n, seed=11, reuse_buffers=True)
+        clean.reset(), dirty.reset()
+        a = clean.synthetic_actions().clone()
+        clean.step(a), dirty.step(a)                                  # some machines down
+        dirty._state.bitwise_or_(torch.tensor(0x7FF << 12, dtype=torch.int32, device="cuda"))     # bits 12 .. 22: no machine of the ten
+        for t in range(3):
+            a = clean.synthetic_actions().clone()
+            want, got = clean.step(a), dirty.step(a)
+            assert torch.equal(want[0], got[0]) and torch.equal(want[1], got[1]), (n, t)
+            assert torch.equal(clean.state & 0x3FF, dirty.state & 0x3FF), (n, t)
+        dirty._state.bitwise_or_(torch.tensor(0x7FF << 12, dtype=torch.int32, device="cuda"))
+        tw, tg = clean.collect_synthetic(20, layout="packed"), dirty.collect_synthetic(20, layout="packed")
+        assert torch.equal(tw["traj"], tg["traj"]) and torch.equal(clean.state & 0x3FF, dirty.state & 0x3FF), n
+
+
 def test_split_layout_ties():
     """The 2^-27 path of RockSample's split word layout: lanes (found by tests/golden/find_ties.py) where a reset or
     sensor draw is undecided by its high word, so the kernel has to generate the low-word block.  Expected values
@@ -1511,15 +1564,28 @@ def test_set_state_rejects_states_of_another_layout():
 
 
 def test_randomised_sweep_on_a_fixed_seed(monkeypatch):
-    """tools/gpu_fuzz.py as part of the suite: 30 seconds of random env configs, batch sizes (both launch geometries), lane
-    offsets up to 2^32, call counters up to 2^40, auto-reset on and off, invalid actions, and — one case in four here —
-    trajectory collections in a random sink (columns / blocked / packed / narrow / returns-only), each compared word for
-    word with the oracle.  The seed is fixed, so a failure reproduces; the builder's longer sweeps on fresh seeds are
-    logged under profiles/."""
+    """tools/gpu_fuzz.py as part of the suite: 16 cases (the same on every machine: fixed seed, fixed count) of random env
+    configs, batch sizes (both launch geometries), lane offsets up to 2^32, call counters up to 2^40, auto-reset on and off,
+    invalid actions, and — one case in four here — trajectory collections in a random sink (columns / blocked / packed /
+    narrow / returns-only), half of them on a random tape of caller's actions, each compared word for word with the
+    oracle.  The builder's longer sweeps on fresh seeds are logged under profiles/."""
     import os
     import sys
     from conftest import REPO
     sys.path.insert(0, os.path.join(REPO, "tools"))
     monkeypatch.setenv("FUZZ_COLLECT", "0.25")
     import gpu_fuzz
-    assert gpu_fuzz.main(30.0, seed=20261001) >= 12
+    assert gpu_fuzz.main(None, seed=20261001, n_cases=16) == 16
+
+
+@pytest.mark.slow
+def test_randomised_sweep_of_the_builders_long_run(monkeypatch):
+    """The first 120 cases of the long sweep logged in profiles/r05_fuzz.txt (seed 777, one case in three a trajectory collection
+    in a random sink — since round 6 half of those on a random tape of caller's actions): a fixed set, about a minute."""
+    import os
+    import sys
+    from conftest import REPO
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    monkeypatch.setenv("FUZZ_COLLECT", "0.33")
+    import gpu_fuzz
+    assert gpu_fuzz.main(None, seed=777, n_cases=120) == 120

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Randomised parity sweep (dev aid, GPU box): random env configs, batch sizes (both launch geometries), lane offsets,
 call counters, auto-reset on/off, valid and invalid actions — HIP path vs the oracle, word for word; one case in eight
-is a trajectory collection (fused launches, up to 2^20 + 2048 lanes, a random trajectory layout or the returns-only sink;
+is a trajectory collection (fused launches, up to 2^20 + 2048 lanes, a random trajectory layout or the returns-only sink,
+half of them driven by a random tape of the caller's actions — out-of-range bytes included — instead of the synthetic policy;
 FUZZ_COLLECT sets the share) checked row by row against the oracle.
-usage: python tools/gpu_fuzz.py [seconds [seed]]      (tests/test_gpu_parity.py runs a 30-second sweep on a fixed seed)"""
+usage: python tools/gpu_fuzz.py [seconds [seed [cases]]]      (tests/test_gpu_parity.py runs a fixed number of cases on a fixed seed)"""
 import os
 import sys
 import time
@@ -20,6 +21,7 @@ CONFIGS = [
     ("rock", "Rock-v0", {}), ("rock", "Rock-v0", dict(board_size=7, num_rocks=7)),
     ("rock", "Rock-v0", dict(board_size=11, num_rocks=11)), ("rock", "Rock-v0", dict(board_size=15, num_rocks=15)),
     ("rock", "Rock-v0", dict(board_size=4, num_rocks=3)), ("stochrock", "StochasticRock-v0", {}),
+    ("stochrock", "StochasticRock-v0", dict(p_move=.4)), ("stochrock", "StochasticRock-v0", dict(board_size=11, num_rocks=11, p_move=.65)),
     ("tag", "Tag-v0", {}), ("tag", "Tag-v0", dict(num_opponents=2)), ("tag", "Tag-v0", dict(num_opponents=4)),
     ("tag", "Tag-v0", dict(move_prob=.3)), ("tag", "Tag-v0", dict(num_opponents=3, move_prob=.6)),
     ("battleship", "Battleship-v0", {}), ("battleship", "Battleship-v0", dict(board_size=(10, 10), max_len=5)),
@@ -51,34 +53,48 @@ def collect_case(rs):
     ob_o = o.batch_reset(st, seed, lane0, t0, nthreads=8)
     assert np.array_equal(e.reset().cpu().numpy(), ob_o), (name, kw, n, "reset ob")
     layout = ("columns", "blocked", "packed", "narrow", "returns")[rs.randint(5)]    # the sink too
+    # ... and where the actions come from: the synthetic policy, or a tape of the caller's (pomdp_collect_tape*), one byte in
+    # ~2000 out of range
+    tape = None
+    if rs.rand() < 0.5:
+        tape = rs.randint(0, o.n_actions, (steps, n)).astype(np.uint8)
+        bad = rs.randint(0, 2000, (steps, n)) == 0
+        tape[bad] = rs.randint(o.n_actions, 256, int(bad.sum())).astype(np.uint8)
+        d_tape = torch.as_tensor(tape, device="cuda")
     if layout == "returns":                               # no trajectory: the per-lane episode statistics (pomdp_collect_returns)
-        stats = e.collect_returns(steps)
+        stats = e.collect_returns(steps) if tape is None else e.collect_tape(d_tape, layout="returns")
         acc, cnt = ol.new_return_stats(n)
-        o.batch_collect_returns(st, acc, cnt, e._discount, seed, lane0, t0 + 1, steps, nthreads=8)
+        o.batch_collect_returns(st, acc, cnt, e._discount, seed, lane0, t0 + 1, steps, nthreads=8,
+                                actions=None if tape is None else tape.astype(np.int32))
         ctx = ("returns", name, kw, n, lane0, seed, t0, steps)
         assert np.array_equal(stats.acc[:, :n].cpu().numpy().view(np.uint64), acc.view(np.uint64)), ctx
         assert np.array_equal(stats.cnt[:, :n].cpu().numpy(), cnt), ctx
         assert np.array_equal(e.state.cpu().numpy().view(np.uint32), st), ctx
         return
-    tr = e.decode_trajectory(e.collect_synthetic(steps, layout=layout))
-    done = np.zeros(n, np.uint8)
+    tr = e.decode_trajectory(e.collect_synthetic(steps, layout=layout) if tape is None else e.collect_tape(d_tape, layout=layout), steps)
+    done, n_bad = np.zeros(n, np.uint8), 0
     for k in range(steps):
         t = t0 + 1 + k
-        a = px.synthetic_actions(seed, lane0, n, t, o.n_actions)
+        a = px.synthetic_actions(seed, lane0, n, t, o.n_actions) if tape is None else tape[k].astype(np.int32)
         ob_o, rew_o, done, bad = o.batch_step(st, a, seed, lane0, t, auto_reset=True, done=done, nthreads=8)
-        ctx = ("collect", layout, name, kw, n, lane0, seed, t0, steps, k)
-        assert bad == 0, ctx
-        assert np.array_equal(tr["action"][k].cpu().numpy(), a), ctx
+        ctx = ("collect", layout, "tape" if tape is not None else "synthetic", name, kw, n, lane0, seed, t0, steps, k)
+        n_bad += bad
+        assert tape is not None or bad == 0, ctx
+        if tape is None or layout != "columns":            # a tape-driven column collection has no action column (the caller holds it)
+            assert np.array_equal(tr["action"][k].cpu().numpy(), a), ctx
         assert np.array_equal(tr["ob"][k].cpu().numpy(), ob_o), ctx
         assert np.array_equal(tr["reward"][k].cpu().numpy(), rew_o), ctx
         assert np.array_equal(tr["done"][k].cpu().numpy(), done.astype(bool)), ctx
     assert np.array_equal(e.state.cpu().numpy().view(np.uint32), st), ("collect", name, kw, n, "state")
+    assert e.invalid_action_count() == n_bad, ("collect", name, kw, n, "invalid actions")
 
 
-def main(budget, seed=None):
+def main(budget, seed=None, n_cases=None):
+    """`budget` seconds of random cases, or — n_cases given — exactly that many, however long they take (what the test suite
+    runs: the same cases on every machine)"""
     rs = np.random.RandomState(int(time.time()) & 0xFFFFFF if seed is None else seed)
-    t_end, cases = time.time() + budget, 0
-    while time.time() < t_end:
+    t_start, cases = time.time(), 0
+    while (cases < n_cases) if n_cases else (time.time() < t_start + budget):
         if rs.rand() < float(os.environ.get("FUZZ_COLLECT", "0.12")):
             collect_case(rs)
             cases += 1
@@ -120,9 +136,10 @@ def main(budget, seed=None):
         assert e.invalid_action_count() == bad_total, (name, kw, n)
         cases += 1
         del e
-    print("fuzz ok: %d random cases in %.0f s" % (cases, budget))
+    print("fuzz ok: %d random cases in %.0f s" % (cases, time.time() - t_start))
     return cases
 
 
 if __name__ == "__main__":
-    main(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0, int(sys.argv[2]) if len(sys.argv) > 2 else None)
+    main(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0, int(sys.argv[2]) if len(sys.argv) > 2 else None,
+         int(sys.argv[3]) if len(sys.argv) > 3 else None)

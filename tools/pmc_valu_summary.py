@@ -9,8 +9,11 @@ from them —
   wave_insts_per_s         valu_per_launch / duration: the integer-op rate SURVEY.md §8d asks for (x 64 = lane-ops/s)
   issue_peak               256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction = 6.144e11 wave-instructions/s
   valu_issue_frac          wave_insts_per_s / issue_peak
-  clock_ghz                GRBM_GUI_ACTIVE / 8 XCDs / duration: the clock the launch really ran at
-  valu_busy_frac           SQ_ACTIVE_INST_VALU (quad-cycles, summed over waves) x 4 / (1024 SIMDs x duration x clock)
+  clock_ghz                GRBM_GUI_ACTIVE / 8 XCDs / duration: the clock the launch really ran at — for launches of at least
+                           MIN_WINDOW_US only: the counter runs over the profiler's sampling window, which is longer than a
+                           short launch (round 5's summary derived 3.7-4.7 "GHz" and a VALU busy of 1.02-1.17 for 35 us launches)
+  valu_busy_frac           SQ_ACTIVE_INST_VALU (quad-cycles, summed over waves) x 4 / (1024 SIMDs x duration x clock), same
+                           launches only; a value above 1 is reported as not derivable, never printed as a fraction
 bench.py reads the JSON (`valu_per_launch`, keyed by workload and kernel) and divides by the kernel time it measures
 live, as it does with the recorded HBM byte counters.
 """
@@ -23,6 +26,7 @@ import sys
 SIMDS = 256 * 4
 NOMINAL_HZ = 2.4e9
 ISSUE_PEAK = SIMDS * NOMINAL_HZ / 4.0
+MIN_WINDOW_US = 150.0        # launches shorter than this do not fill the GRBM counter's window: no clock, no busy fraction
 KERNELS = ("%rollout_kernel%", "%heuristic_steps_kernel%", "%steps%kernel%")
 
 
@@ -107,10 +111,16 @@ def main():
             if "GRBM_GUI_ACTIVE" in v:
                 d2 = v["GRBM_GUI_ACTIVE"][2] * 1e-9
                 clk = v["GRBM_GUI_ACTIVE"][1] / 8.0 / d2
-                ke["clock_ghz"] = clk / 1e9
                 ke["duration_us_pass2"] = d2 * 1e6
-                if "SQ_ACTIVE_INST_VALU" in v:
-                    ke["valu_busy_frac"] = v["SQ_ACTIVE_INST_VALU"][1] * 4.0 / (SIMDS * dur_s * clk)
+                if d2 * 1e6 >= MIN_WINDOW_US and clk <= 1.05 * NOMINAL_HZ:
+                    ke["clock_ghz"] = clk / 1e9
+                    if "SQ_ACTIVE_INST_VALU" in v:
+                        busy = v["SQ_ACTIVE_INST_VALU"][1] * 4.0 / (SIMDS * dur_s * clk)
+                        if busy <= 1.0:
+                            ke["valu_busy_frac"] = busy
+                else:
+                    ke["clock_note"] = "launch shorter than the GRBM counter's window (%.0f us < %.0f us) or clock above nominal: " \
+                                       "clock and VALU busy not derived" % (d2 * 1e6, MIN_WINDOW_US)
             entry["kernels"][short(k)] = ke
             lines.append("%-18s %-58s n=%-5d %9.1f us  VALU/launch %.4e  %.3e wave-insts/s = %.3f of issue peak%s%s"
                          % (name, short(k)[:58], n1, d1 / 1e3, valu, valu / dur_s, valu / dur_s / ISSUE_PEAK,
