@@ -676,9 +676,13 @@ __global__ __launch_bounds__(BLOCK) void network_steps_quad_kernel(uint32_t *__r
 // The Returns sink keeps ten more registers per lane across the loop (traj_out.hip.h); with three or four mask words that is
 // 137-143 registers by the compiler's own choice — three waves per SIMD, where a 2^20-lane launch has four workgroups per CU
 // to place.  waves_per_eu(4) holds it to 128 (1 = no constraint, for the trajectory sinks).
-template <class L, int MW> struct quad_waves { static constexpr int value = (L::ID == LAYOUT_RETURNS && MW >= 3) ? 4 : 1; };
-template <int MW, class L = Columns, class Pol = SyntheticQuad>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(quad_waves<L, MW>::value))) void battleship_steps_quad_kernel(uint32_t *__restrict__ state, int32_t *__restrict__ action,
+template <class L, int MW, bool VIS_LDS = false> struct quad_waves { static constexpr int value = (L::ID == LAYOUT_RETURNS && MW >= 3 && !VIS_LDS) ? 4 : 1; };
+// LPT = 2 (round 6): the same loop with HALF a quad per thread, for the shards that leave the quad loop two waves per SIMD —
+// configs[3]'s 2^19 lanes per GPU ran at 0.64-0.79 of the VALU's issue slots.  Two lanes per thread are four waves per SIMD
+// there; the policy's block is time-shared by the two threads of a quad (SyntheticPair), the ship masks lie [word][lane of
+// the pair][thread], the sinks are the 4-byte ones and the returns sink (PairOut).
+template <int MW, class L = Columns, class Pol = SyntheticQuad, int LPT = 4, bool VIS_LDS = false>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(quad_waves<L, MW, VIS_LDS>::value))) void battleship_steps_quad_kernel(uint32_t *__restrict__ state, int32_t *__restrict__ action,
                                                                       int32_t *__restrict__ ob, int32_t *__restrict__ reward,
                                                                       uint8_t *__restrict__ done, int64_t n, RngKey key0,
                                                                       uint32_t lane0, RngKey akey0, int k_steps, int64_t rec,
@@ -687,49 +691,70 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(quad_wave
     using Env = BattleShipEnv<MW>;
     using Mask = typename Env::Mask;
     // The two masks a step only READS — the ships of this episode and of the next — live in LDS, [word][lane of the quad]
-    // [thread] (conflict-free: a wave reads one word of lane j of each of its threads); the visited mask, which every step
-    // updates, stays in registers.  A shot tests ONE word of the ship mask (an LDS read issued when the step begins), and
-    // with eight mask words per lane out of the register file the 10x10 kernel fits four waves per SIMD.
-    __shared__ uint32_t occ_lds[MW][4][BLOCK], next_lds[MW][4][BLOCK];
-    __shared__ uint8_t task_lds[BLOCK / 64][256];            // task rank -> lane within the wave's 256
-    __shared__ uint8_t ts_lds[BLOCK / 64][256];              // ... and the step at which that lane's current board was dealt
+    // [thread] (conflict-free whatever word a thread asks for: a row is 256 words, so thread t always hits bank t % 64); a
+    // shot tests ONE word of the ship mask (an LDS read issued when the step begins).
+    // VIS_LDS (round 6; shards up to 2^19 lanes): the cells already shot at live there too — one more read, one bit test, one
+    // LDS write of the visited word, about twenty vector instructions per lane-step where picking the word out of a
+    // register-resident 128-bit mask takes fifty; `remaining` (the top six bits of the last visited word in memory) rides
+    // in a register of its own.  48 bytes of LDS per lane: a 2^20-lane batch (4096 lanes per CU) does not fit a CU's 160 KB
+    // at once, so there the visited mask stays in registers (10x10, packed records, 2^20 lanes: 1.59 us per step in
+    // registers, 1.72 in LDS with three workgroups resident instead of four).
+    static_assert(LPT == 4 || LPT == 2, "a quad or half a quad per thread");
+    constexpr int LOG = LPT == 4 ? 2 : 1;
+    __shared__ uint32_t occ_lds[MW][LPT][BLOCK], next_lds[MW][LPT][BLOCK], vis_lds[VIS_LDS ? MW : 1][VIS_LDS ? LPT : 1][VIS_LDS ? BLOCK : 1];
+    __shared__ uint8_t task_lds[BLOCK / 64][64 * LPT];       // task rank -> lane within the wave's 64 * LPT
+    __shared__ uint8_t ts_lds[BLOCK / 64][64 * LPT];         // ... and the step at which that lane's current board was dealt
     __shared__ typename Env::SeqTables seq;                  // the column patterns of the board builder
     Env::stage_seq(seq, p, (int)threadIdx.x);
     const int wv = (int)(threadIdx.x >> 6), me = (int)(threadIdx.x & 63u), tid = (int)threadIdx.x;
-    const uint32_t l0 = blockIdx.x * (uint32_t)(4 * BLOCK) + 4u * threadIdx.x;
-    const uint32_t glane0 = lane0 + l0, wave0 = glane0 - 4u * (uint32_t)me;
-    QuadOut<L> out(action, ob, reward, done, rec, l0);
+    const uint32_t l0 = blockIdx.x * (uint32_t)(LPT * BLOCK) + (uint32_t)LPT * threadIdx.x;
+    const uint32_t glane0 = lane0 + l0, wave0 = glane0 - (uint32_t)LPT * (uint32_t)me;
+    typename lanes_out<L, LPT>::type out(action, ob, reward, done, rec, l0);
     const uint32_t n_act = (uint32_t)Env::n_actions(p);
-    Mask vis[4];
-    int a_cur[4];
-    Pol pol(tape, l0, glane0, key0, akey0, n_act, k_steps);
+    int rem[LPT];                                            // VIS_LDS: total_remaining (battleship.py:100-104)
+    Mask vis[VIS_LDS ? 1 : LPT];                             // !VIS_LDS: the visited mask, remaining in the top bits of its last word
+    int a_cur[LPT];
+    typename lanes_policy<Pol, LPT>::type pol(tape, l0, glane0, key0, akey0, n_act, k_steps);
     uint32_t n_bad = 0;
     {
-        u32x4 w[3 * MW];
+        typename std::conditional<LPT == 4, u32x4, u32x2>::type w[3 * MW];
+        uint32_t a4[LPT];
 #pragma unroll
-        for (int q = 0; q < 3 * MW; ++q) w[q] = ld_stream4(state + (int64_t)q * n + l0);
-        const u32x4 a4 = out.first(pol, gen_first);
+        for (int q = 0; q < 3 * MW; ++q) {
+            if constexpr (LPT == 4) w[q] = ld_stream4(state + (int64_t)q * n + l0);
+            else w[q] = ld_stream2(state + (int64_t)q * n + l0);
+        }
+        if constexpr (LPT == 4) { const u32x4 f = out.first(pol, gen_first); a4[0] = f[0]; a4[1] = f[1]; a4[2] = f[2]; a4[3] = f[3]; }
+        else pol.first(a4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < LPT; ++j) {
             a_cur[j] = (int)a4[j];
-            vis[j].lo = vis[j].hi = 0;
+            rem[j] = (int)(w[2 * MW - 1][j] >> 26);
+            if constexpr (!VIS_LDS) vis[j].lo = vis[j].hi = 0;
 #pragma unroll
-            for (int q = 0; q < MW; ++q) { occ_lds[q][j][tid] = w[q][j]; vis[j].set_word(q, w[MW + q][j]); next_lds[q][j][tid] = w[2 * MW + q][j]; }
+            for (int q = 0; q < MW; ++q) {
+                occ_lds[q][j][tid] = w[q][j];
+                if constexpr (VIS_LDS) vis_lds[q][j][tid] = q == MW - 1 ? (w[MW + q][j] & 0x03FFFFFFu) : w[MW + q][j];
+                else vis[j].set_word(q, w[MW + q][j]);
+                next_lds[q][j][tid] = w[2 * MW + q][j];
+            }
         }
     }
     __syncthreads();
     const int cells = p.x_size * p.y_size;
     const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo;
-    int pend[4] = {-1, -1, -1, -1};                          // >= 0: the step at which the lane's board was dealt; its `next` is yet to be built
+    int pend[LPT];                                           // >= 0: the step at which the lane's board was dealt; its `next` is yet to be built
+#pragma unroll
+    for (int j = 0; j < LPT; ++j) pend[j] = -1;
     // the boards of every waiting lane of the wave (wave-uniform control flow; the scratch and the mask slots are the wave's own)
     auto build_boards = [&]() {
         int ntask = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < LPT; ++j) {
             const uint64_t m = __ballot(pend[j] >= 0);
             const int rank = ntask + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
             ntask += __popcll(m);
-            if (pend[j] >= 0) { task_lds[wv][rank & 255] = (uint8_t)(4 * me + j); ts_lds[wv][rank & 255] = (uint8_t)pend[j]; }
+            if (pend[j] >= 0) { task_lds[wv][rank & (64 * LPT - 1)] = (uint8_t)(LPT * me + j); ts_lds[wv][rank & (64 * LPT - 1)] = (uint8_t)pend[j]; }
             pend[j] = -1;
         }
         if (ntask == 0) return;                                                // wave-uniform
@@ -747,7 +772,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(quad_wave
         int bidx = 0;
         uint32_t bt_lo = 0, bt_hi = 0, blk = 0;
         auto take = [&](int q) {                                               // lanes with q >= 0 start on task q
-            const int idx = q >= 0 ? (int)task_lds[wv][q & 255] : 0, s0 = q >= 0 ? (int)ts_lds[wv][q & 255] : 0;
+            const int idx = q >= 0 ? (int)task_lds[wv][q & (64 * LPT - 1)] : 0, s0 = q >= 0 ? (int)ts_lds[wv][q & (64 * LPT - 1)] : 0;
             const uint64_t td = t0 + (uint64_t)s0;                             // battleship.py:131-137 on stream NEXT of that step's call counter
             if (q >= 0) { bidx = idx; bt_lo = (uint32_t)td; bt_hi = (uint32_t)(td >> 32); blk = 0; bld.start(p.max_len); }
         };
@@ -761,9 +786,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(quad_wave
             const bool fin = my >= 0 && !bld.busy();
             const uint64_t fm = __ballot(fin);
             if (fm != 0ull) {                                                  // wave-uniform
-                if (fin) {                                                     // straight into the owner's slot: lane bidx & 3 of thread bidx >> 2
+                if (fin) {                                                     // straight into the owner's slot: lane bidx % LPT of thread bidx / LPT
 #pragma unroll
-                    for (int w = 0; w < MW; ++w) next_lds[w][bidx & 3][64 * wv + (bidx >> 2)] = (uint32_t)(bld.occ >> (32 * w));
+                    for (int w = 0; w < MW; ++w) next_lds[w][bidx & (LPT - 1)][64 * wv + (bidx >> LOG)] = (uint32_t)(bld.occ >> (32 * w));
                 }
                 const int r = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
                 if (fin) { my = next_task + r < ntask ? next_task + r : -1; bld.idle(); take(my); }
@@ -782,51 +807,77 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(quad_wave
     #pragma unroll 1
     for (int seg = 0, s = 0; seg < 4; ++seg)                               // four priority segments (LoopPrio)
     for (const int seg_end = prio.segment(seg); s < seg_end; ++s) {
-        const uint32_t a_taken[4] = {(uint32_t)a_cur[0], (uint32_t)a_cur[1], (uint32_t)a_cur[2], (uint32_t)a_cur[3]};
-        bool valid[4] = {true, true, true, true};
+        uint32_t a_taken[LPT];
+        bool valid[LPT];
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) { a_taken[j] = (uint32_t)a_cur[j]; valid[j] = true; }
         if constexpr (Pol::TAPE) {               // a tape's out-of-range shot: the lane is left untouched, (0, 0, 0), and counted
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { valid[j] = a_taken[j] < n_act; n_bad += (uint32_t)!valid[j]; a_cur[j] = valid[j] ? a_cur[j] : 0; }
+            for (int j = 0; j < LPT; ++j) { valid[j] = a_taken[j] < n_act; n_bad += (uint32_t)!valid[j]; a_cur[j] = valid[j] ? a_cur[j] : 0; }
         }
-        uint32_t ow[4];
+        uint32_t ow[LPT], vw[LPT];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) ow[j] = occ_lds[a_cur[j] >> 5][j][tid];   // the ship-mask word this shot tests
-        uint32_t a_next[4];
+        for (int j = 0; j < LPT; ++j) {                                         // the word of the ship mask and of the visited mask this shot tests
+            ow[j] = occ_lds[a_cur[j] >> 5][j][tid];
+            vw[j] = VIS_LDS ? vis_lds[a_cur[j] >> 5][j][tid] : 0u;
+        }
+        uint32_t a_next[LPT];
         pol.begin(s, a_next);
-        uint32_t o4[4], r4[4], d4[4];
-        bool d[4], again = false;
+        uint32_t o4[LPT], r4[LPT], d4[LPT];
+        bool d[LPT], again = false, any_d = false;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {                                          // battleship.py:91-122: draws nothing
+        for (int j = 0; j < LPT; ++j) {                                        // battleship.py:91-122: draws nothing
             const int a = a_cur[j];
-            const Mask vis_before = vis[j];
-            const uint32_t last = vis[j].word(MW - 1);
-            int remaining = (int)(last >> 26), r;
-            const bool visited = Env::bit(vis[j], a), hit = (ow[j] >> (a & 31)) & 1u;
-            if (visited) r = -10;
-            else { r = -1; remaining -= (int)hit; Env::set_bit(vis[j], a); }
-            d[j] = remaining == 0;
-            if (d[j]) r += cells;
-            vis[j].set_word(MW - 1, (vis[j].word(MW - 1) & 0x03FFFFFFu) | ((uint32_t)remaining << 26));
-            uint32_t ob_j = (uint32_t)(!visited && hit);
-            if constexpr (Pol::TAPE) { if (!valid[j]) { vis[j] = vis_before; d[j] = false; r = 0; ob_j = 0; } }
+            int r;
+            uint32_t ob_j;
+            if constexpr (VIS_LDS) {
+                const uint32_t m = 1u << (a & 31);
+                const bool visited = (vw[j] & m) != 0u, hit = (ow[j] & m) != 0u;
+                const bool fresh_hit = !visited && hit && valid[j];
+                r = visited ? -10 : -1;
+                rem[j] -= (int)fresh_hit;
+                d[j] = rem[j] == 0 && valid[j];
+                if (d[j]) r += cells;
+                if (valid[j]) vis_lds[a >> 5][j][tid] = vw[j] | m;             // (a cell shot at before: the same word again)
+                ob_j = (uint32_t)fresh_hit;
+                if constexpr (Pol::TAPE) { if (!valid[j]) r = 0; }
+            } else {
+                const Mask vis_before = vis[j];
+                const uint32_t last = vis[j].word(MW - 1);
+                int remaining = (int)(last >> 26);
+                const bool visited = Env::bit(vis[j], a), hit = (ow[j] >> (a & 31)) & 1u;
+                if (visited) r = -10;
+                else { r = -1; remaining -= (int)hit; Env::set_bit(vis[j], a); }
+                d[j] = remaining == 0;
+                if (d[j]) r += cells;
+                vis[j].set_word(MW - 1, (vis[j].word(MW - 1) & 0x03FFFFFFu) | ((uint32_t)remaining << 26));
+                ob_j = (uint32_t)(!visited && hit);
+                if constexpr (Pol::TAPE) { if (!valid[j]) { vis[j] = vis_before; d[j] = false; r = 0; ob_j = 0; } }
+            }
             again |= d[j] && pend[j] >= 0;
+            any_d |= d[j];
             o4[j] = ob_j; r4[j] = (uint32_t)r;
             d4[j] = (uint32_t)d[j];
         }
         out.put(a_taken, a_next, o4, r4, r4, d4);                              // the int8 reward IS its code
         pol.end(s, a_next);                                  // the actions of step s + 1 (a tape's row arrives here)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) a_cur[j] = (int)a_next[j];
+        for (int j = 0; j < LPT; ++j) a_cur[j] = (int)a_next[j];
         if (__any(again)) build_boards();                                      // a second episode ended before the lane's next board exists
-        if (__any(d[0] || d[1] || d[2] || d[3])) {                             // wave-uniform: the cached boards move in
+        if (__any(any_d)) {                                                    // wave-uniform: the cached boards move in
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < LPT; ++j) {
                 if (d[j]) {
                     int ships = 0;
 #pragma unroll
-                    for (int q = 0; q < MW; ++q) { const uint32_t x = next_lds[q][j][tid]; occ_lds[q][j][tid] = x; ships += __popc(x); }
-                    vis[j].lo = vis[j].hi = 0;
-                    vis[j].set_word(MW - 1, (uint32_t)ships << 26);
+                    for (int q = 0; q < MW; ++q) {
+                        const uint32_t x = next_lds[q][j][tid];
+                        occ_lds[q][j][tid] = x;
+                        if constexpr (VIS_LDS) vis_lds[q][j][tid] = 0u;
+                        ships += __popc(x);
+                    }
+                    rem[j] = ships;
+                    if constexpr (!VIS_LDS) { vis[j].lo = vis[j].hi = 0; vis[j].set_word(MW - 1, (uint32_t)ships << 26); }
                     pend[j] = s;
                 }
             }
@@ -837,9 +888,21 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(quad_wave
     out.finish(k_steps);
 #pragma unroll
     for (int q = 0; q < MW; ++q) {
-        st_stream4(state + (int64_t)q * n + l0, occ_lds[q][0][tid], occ_lds[q][1][tid], occ_lds[q][2][tid], occ_lds[q][3][tid]);
-        st_stream4(state + (int64_t)(MW + q) * n + l0, vis[0].word(q), vis[1].word(q), vis[2].word(q), vis[3].word(q));
-        st_stream4(state + (int64_t)(2 * MW + q) * n + l0, next_lds[q][0][tid], next_lds[q][1][tid], next_lds[q][2][tid], next_lds[q][3][tid]);
+        uint32_t vq[LPT];
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) {
+            if constexpr (VIS_LDS) vq[j] = vis_lds[q][j][tid] | (q == MW - 1 ? (uint32_t)rem[j] << 26 : 0u);
+            else vq[j] = vis[j].word(q);
+        }
+        if constexpr (LPT == 4) {
+            st_stream4(state + (int64_t)q * n + l0, occ_lds[q][0][tid], occ_lds[q][1][tid], occ_lds[q][2][tid], occ_lds[q][3][tid]);
+            st_stream4(state + (int64_t)(MW + q) * n + l0, vq[0], vq[1], vq[2], vq[3]);
+            st_stream4(state + (int64_t)(2 * MW + q) * n + l0, next_lds[q][0][tid], next_lds[q][1][tid], next_lds[q][2][tid], next_lds[q][3][tid]);
+        } else {
+            st_stream2(state + (int64_t)q * n + l0, occ_lds[q][0][tid], occ_lds[q][1][tid]);
+            st_stream2(state + (int64_t)(MW + q) * n + l0, vq[0], vq[1]);
+            st_stream2(state + (int64_t)(2 * MW + q) * n + l0, next_lds[q][0][tid], next_lds[q][1][tid]);
+        }
     }
 }
 
@@ -1016,9 +1079,30 @@ static int launch_steps_fused_l(const typename Env::Params &p, uint32_t *state, 
         }
     }
     if constexpr (has_next<Env>::value) {
-        if (quad_ok && n >= QUAD_MIN_BATTLESHIP && k <= 256) {   // the pool keeps a lane's deal step in a byte
+        if constexpr (pair_sink<L>::value) {
+            // half a quad per thread where the quad loop would leave a SIMD two waves or fewer (configs[3]'s 2^19-lane shard)
+            if (quad_ok && n >= BS_PAIR_MIN_LANES && n <= BS_PAIR_MAX_LANES && k <= 256) {
+                char pname[40];
+                snprintf(pname, sizeof pname, "%s, 2", lname);
+                note_fused("battleship_steps_quad_kernel", Env::NAME, pname);
+                const dim3 pgrid((unsigned)(n / (2 * BLOCK)));
+                if (taped) hipLaunchKernelGGL((battleship_steps_quad_kernel<Env::WORDS / 3, L, TapeQuad, 2, true>), pgrid, dim3(BLOCK), 0, (hipStream_t)stream, POMDP_QUAD_ARGS);
+                else hipLaunchKernelGGL((battleship_steps_quad_kernel<Env::WORDS / 3, L, SyntheticQuad, 2, true>), pgrid, dim3(BLOCK), 0, (hipStream_t)stream, POMDP_QUAD_ARGS);
+                launched = true;
+            }
+        }
+        if (!launched && quad_ok && n >= QUAD_MIN_BATTLESHIP && k <= 256) {   // the pool keeps a lane's deal step in a byte
             note_fused("battleship_steps_quad_kernel", Env::NAME, lname);
-            POMDP_LAUNCH_QUAD(battleship_steps_quad_kernel<Env::WORDS / 3, L);
+            // the visited mask in LDS while a CU's share of the batch fits there (see the kernel)
+            if (n * (Env::WORDS / 3) <= BS_VIS_LDS_MAX_LANES * 4) {          // 12 bytes of LDS per mask word and lane: 2^19 lanes of four words,
+                                                                              // 2^20 of two (the reference's 5 x 5 board: 2.39 against 2.73 us per step), ...
+                if constexpr (!std::is_same<L, Columns>::value) {
+                    if (taped) hipLaunchKernelGGL((battleship_steps_quad_kernel<Env::WORDS / 3, L, TapeQuad, 4, true>), qgrid, dim3(BLOCK), 0, (hipStream_t)stream, POMDP_QUAD_ARGS);
+                }
+                if constexpr (!std::is_same<L, ColumnsNoAct>::value) {
+                    if (!taped) hipLaunchKernelGGL((battleship_steps_quad_kernel<Env::WORDS / 3, L, SyntheticQuad, 4, true>), qgrid, dim3(BLOCK), 0, (hipStream_t)stream, POMDP_QUAD_ARGS);
+                }
+            } else POMDP_LAUNCH_QUAD(battleship_steps_quad_kernel<Env::WORDS / 3, L);
             launched = true;
         }
     }

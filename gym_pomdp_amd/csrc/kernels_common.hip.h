@@ -435,6 +435,24 @@ constexpr int64_t QUAD_MIN_ROCK = 3 << 18, QUAD_MIN_STOCHROCK = 1 << 19, QUAD_MI
                   QUAD_MIN_NETWORK = 1 << 19, QUAD_MIN_BATTLESHIP = 1 << 16;
 #endif
 
+// BattleShip with half a quad per thread (battleship_steps_quad_kernel<.., 2>): the shards the quad loop gives two waves per
+// SIMD or fewer.  -DPOMDP_BS_PAIR_MAX_LANES=0 builds the A arm (quad loop everywhere).
+#ifdef POMDP_BS_PAIR_MAX_LANES
+constexpr int64_t BS_PAIR_MAX_LANES = POMDP_BS_PAIR_MAX_LANES;
+#else
+constexpr int64_t BS_PAIR_MAX_LANES = 1 << 19;
+#endif
+#ifdef POMDP_BS_VIS_LDS_MAX_LANES                             // the visited mask in LDS up to this many lanes (48 B of LDS per lane)
+constexpr int64_t BS_VIS_LDS_MAX_LANES = POMDP_BS_VIS_LDS_MAX_LANES;
+#else
+constexpr int64_t BS_VIS_LDS_MAX_LANES = 1 << 19;
+#endif
+#ifdef POMDP_BS_PAIR_MIN_LANES
+constexpr int64_t BS_PAIR_MIN_LANES = POMDP_BS_PAIR_MIN_LANES;
+#else
+constexpr int64_t BS_PAIR_MIN_LANES = 1 << 17;
+#endif
+
 // steps per fused launch of the C-side drivers (pomdp_fuse_max; defined in api.hip).  One place instead of a constant per
 // driver; a launch's fixed cost is paid once per this many steps, results never depend on it
 extern std::atomic<int> g_fuse_max;

@@ -40,6 +40,14 @@ __device__ __forceinline__ void st_stream4(uint32_t *p, uint32_t a, uint32_t b, 
     __builtin_nontemporal_store(u32x4{a, b, c, d}, reinterpret_cast<u32x4 *>(p));
 }
 
+// ... and two (the two-lanes-per-thread loops)
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32x2 ld_stream2(const uint32_t *p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(p)); }
+__device__ __forceinline__ void st_stream2(uint32_t *p, uint32_t a, uint32_t b)
+{
+    __builtin_nontemporal_store(u32x2{a, b}, reinterpret_cast<u32x2 *>(p));
+}
+
 struct RngKey {          // wave-uniform part of the counter/key
     uint32_t k0, k1;     // seed lo, hi
     uint32_t t_lo, t_hi; // call counter of the batched env

@@ -139,6 +139,57 @@ struct TapeQuad {
     __device__ __forceinline__ void count_bad(uint32_t n_bad) const { if (n_bad && err) atomicAdd(err, n_bad); }
 };
 
+// ---- two lanes per thread: half a quad (BattleShip's small shards, fused_impl.hip.h) ----------------------------------------
+// The policy's block belongs to a quad, i.e. to a PAIR of neighbouring threads: thread e (0 / 1: lanes 0-1 / 2-3 of the quad)
+// computes the block of step s + e at every even s, and the pair swaps the halves the partner needs (two DPP moves) — one
+// Philox block per thread per two steps, as many per lane-step as in the quad-per-thread loops.
+static __device__ __forceinline__ uint32_t pair_swap(uint32_t v)      // v of the neighbouring thread (lanes 2 i <-> 2 i + 1 of the wave)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+}
+struct SyntheticPair {
+    static constexpr bool TAPE = false;
+    uint32_t glane0, n_act, k0, k1, odd[2];
+    uint64_t ta0;
+    bool hi;                 // this thread holds lanes 2, 3 of its quad
+    __device__ __forceinline__ SyntheticPair(const TapeRef &, uint32_t, uint32_t glane0_, const RngKey &key0, const RngKey &akey0, uint32_t n_act_, int)
+        : glane0(glane0_), n_act(n_act_), k0(key0.k0), k1(key0.k1), odd{0, 0}, ta0(((uint64_t)akey0.t_hi << 32) | akey0.t_lo), hi((glane0_ & 2u) != 0u) {}
+    __device__ __forceinline__ uint4 block(uint64_t ta) const
+    {
+        return philox4x32_10(glane0 >> 2, (uint32_t)ta, (uint32_t)(ta >> 32), (uint32_t)POMDP_STREAM_ACTION << 24, k0, k1);
+    }
+    __device__ __forceinline__ void first(uint32_t (&a)[2]) const
+    {
+        const uint4 w = block(ta0 - 1ull);
+        a[0] = __umulhi(hi ? w.z : w.x, n_act); a[1] = __umulhi(hi ? w.w : w.y, n_act);
+    }
+    __device__ __forceinline__ void begin(int s, uint32_t (&a)[2])
+    {
+        if ((s & 1) == 0) {                                   // wave-uniform: this thread's block is step s + hi's
+            const uint4 w = block(ta0 + (uint64_t)s + (hi ? 1ull : 0ull));
+            const uint32_t r0 = pair_swap(hi ? w.x : w.z), r1 = pair_swap(hi ? w.y : w.w);   // what the partner lacks <-> what it sends
+            a[0] = __umulhi(hi ? r0 : w.x, n_act); a[1] = __umulhi(hi ? r1 : w.y, n_act);     // step s: the low thread's block
+            odd[0] = __umulhi(hi ? w.z : r0, n_act); odd[1] = __umulhi(hi ? w.w : r1, n_act); // step s + 1: the high thread's
+        } else { a[0] = odd[0]; a[1] = odd[1]; }
+    }
+    __device__ __forceinline__ void end(int, uint32_t (&)[2]) const {}
+    __device__ __forceinline__ void count_bad(uint32_t) const {}
+};
+struct TapePair {
+    static constexpr bool TAPE = true;
+    TapeColumn<uint16_t> col;
+    uint32_t *err;
+    __device__ __forceinline__ TapePair(const TapeRef &t, uint32_t l0, uint32_t, const RngKey &, const RngKey &, uint32_t, int k_steps)
+        : col(t, l0, k_steps), err(t.err) {}
+    __device__ __forceinline__ void first(uint32_t (&a)[2]) const { a[0] = col.first & 0xFFu; a[1] = (uint32_t)col.first >> 8; }
+    __device__ __forceinline__ void begin(int s, uint32_t (&a)[2]) { col.request(s); a[0] = a[1] = 0; }
+    __device__ __forceinline__ void end(int, uint32_t (&a)[2]) const { a[0] = col.nxt & 0xFFu; a[1] = (uint32_t)col.nxt >> 8; }
+    __device__ __forceinline__ void count_bad(uint32_t n_bad) const { if (n_bad && err) atomicAdd(err, n_bad); }
+};
+template <class Pol, int LPT> struct lanes_policy { using type = Pol; };
+template <> struct lanes_policy<SyntheticQuad, 2> { using type = SyntheticPair; };
+template <> struct lanes_policy<TapeQuad, 2> { using type = TapePair; };
+
 // ---- a thread that owns a quad of consecutive lanes (the quad-per-thread loops) ------------------------------------
 // l0: the thread's first lane within the shard (a multiple of 4).  first(): the actions of the launch's first step.
 // put(): one step's results of the four lanes — a_cur the actions taken, a_next the policy's actions of the next call
@@ -401,6 +452,89 @@ template <class Env> struct QuadOut<Returns<Env>> {
             (void)__hip_atomic_fetch_add(cnt_w + pitch + j, (uint32_t)k_steps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 };
+
+// ---- a thread that owns TWO consecutive lanes: the 4-byte sinks and the returns sink (the 13-byte layouts are bound by their
+// store stream whatever the geometry: they keep the quad-per-thread loops).  put(): as QuadOut's, two lanes wide.
+template <class L> struct PairOut;
+template <> struct PairOut<Packed> {
+    uint32_t *w;
+    int64_t rec;
+    __device__ __forceinline__ PairOut(void *base, void *, void *, void *, int64_t rec_, uint32_t l0) : w(reinterpret_cast<uint32_t *>(base) + l0), rec(rec_) {}
+    __device__ __forceinline__ void put(const uint32_t (&a_cur)[2], const uint32_t (&)[2], const uint32_t (&o)[2], const uint32_t (&)[2],
+                                        const uint32_t (&rc)[2], const uint32_t (&d)[2])
+    {
+        st_stream2(w, pack_record(a_cur[0], o[0], rc[0], d[0]), pack_record(a_cur[1], o[1], rc[1], d[1]));
+        w += rec;
+    }
+    __device__ __forceinline__ void finish(int) {}
+};
+template <> struct PairOut<Narrow> {
+    uint16_t *w;                                            // the thread's two bytes of the row's action plane
+    int64_t plane, row;                                     // in 16-bit units
+    __device__ __forceinline__ PairOut(void *base, void *, void *, void *, int64_t rec_, uint32_t l0)
+        : w(reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(base) + l0)), plane(rec_ / 2), row(2 * rec_) {}
+    __device__ __forceinline__ void put(const uint32_t (&a_cur)[2], const uint32_t (&)[2], const uint32_t (&o)[2], const uint32_t (&)[2],
+                                        const uint32_t (&rc)[2], const uint32_t (&d)[2])
+    {
+        st_stream(w, (uint16_t)(a_cur[0] | (a_cur[1] << 8)));
+        st_stream(w + plane, (uint16_t)(o[0] | (o[1] << 8)));
+        st_stream(w + 2 * plane, (uint16_t)((rc[0] & 0xFFu) | ((rc[1] & 0xFFu) << 8)));
+        st_stream(w + 3 * plane, (uint16_t)(d[0] | (d[1] << 8)));
+        w += row;
+    }
+    __device__ __forceinline__ void finish(int) {}
+};
+template <class Env> struct PairOut<Returns<Env>> {
+    static constexpr bool BANK = !never_done<Env>::value;
+    double *acc_w;
+    uint32_t *cnt_w;
+    int64_t pitch;
+    double discount;
+    double ret[2], disc[2], ret_done[2], ret_sum[2];
+    uint32_t episodes[2];
+    __device__ __forceinline__ PairOut(void *acc, void *cnt, void *discount_bits, void *, int64_t pitch_, uint32_t l0)
+        : acc_w(reinterpret_cast<double *>(acc) + l0), cnt_w(reinterpret_cast<uint32_t *>(cnt) + l0), pitch(pitch_)
+    {
+        const uint64_t bits = reinterpret_cast<uint64_t>(discount_bits);
+        __builtin_memcpy(&discount, &bits, 8);
+        reward_f64_lds<Env>()[threadIdx.x & 255u] = Env::code_reward(threadIdx.x & 255u);
+        auto row = [&](int q, double (&v)[2]) {
+            const f64x2 x = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(acc_w + q * pitch));
+            v[0] = x[0]; v[1] = x[1];
+        };
+        row(0, ret); row(1, disc);
+        if constexpr (BANK) {
+            row(2, ret_done); row(3, ret_sum);
+            const u32x2 e = ld_stream2(cnt_w);
+            episodes[0] = e[0]; episodes[1] = e[1];
+        }
+    }
+    __device__ __forceinline__ void put(const uint32_t (&)[2], const uint32_t (&)[2], const uint32_t (&)[2], const uint32_t (&)[2],
+                                        const uint32_t (&rc)[2], const uint32_t (&d)[2])
+    {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            returns_step<Env>(ret[j], disc[j], ret_sum[j], episodes[j], ret_done[j], discount, rc[j], BANK ? mask_of_bit(d[j], 0) : 0u);
+    }
+    __device__ __forceinline__ void finish(int k_steps)
+    {
+        auto row = [&](int q, const double (&v)[2]) { __builtin_nontemporal_store(f64x2{v[0], v[1]}, reinterpret_cast<f64x2 *>(acc_w + q * pitch)); };
+        row(0, ret); row(1, disc);
+        if constexpr (BANK) {
+            row(2, ret_done); row(3, ret_sum);
+            st_stream2(cnt_w, episodes[0], episodes[1]);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            (void)__hip_atomic_fetch_add(cnt_w + pitch + j, (uint32_t)k_steps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+};
+template <class L> struct pair_sink : std::false_type {};               // the sinks PairOut exists for
+template <> struct pair_sink<Packed> : std::true_type {};
+template <> struct pair_sink<Narrow> : std::true_type {};
+template <class Env> struct pair_sink<Returns<Env>> : std::true_type {};
+template <class L, int LPT> struct lanes_out { using type = QuadOut<L>; };
+template <class L> struct lanes_out<L, 2> { using type = PairOut<L>; };
 
 // ---- a thread whose lanes are 256 apart (steps_kernel: lane j of a thread is base + tid + 256 j, j < LPT) ----------------
 // wg0: the workgroup's first lane within the shard (a multiple of 256); rel = tid + 256 j.  begin(j, rel): before the loop,

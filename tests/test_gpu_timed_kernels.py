@@ -677,7 +677,7 @@ def test_layout_kernels_are_the_quad_loops_with_another_sink():
             ("tiger", {}, 1 << 20, 64, "blocked", "steps_quad_generic_kernel<TigerEnv, Blocked>"),
             ("network", {}, 1 << 20, 64, "packed", "network_steps_quad_kernel<2, Packed, true>"),
             ("rock", {}, 1 << 20, 64, "narrow", "steps_quad_kernel<RockEnv<1>, Narrow>"), ("tag", {}, 1 << 18, 64, "narrow", "steps_kernel<TagEnv, 1, true, false, Narrow>"),
-            ("battleship", {}, 1 << 18, 64, "packed", "battleship_steps_quad_kernel<BattleShipEnv<1>, Packed>"),
+            ("battleship", {}, 1 << 18, 64, "packed", "battleship_steps_quad_kernel<BattleShipEnv<1>, Packed, 2>"),
             ("tiger", {}, 1000, 64, "packed", "steps_kernel<TigerEnv, 1, false, false, Packed>")]
     for env, kw, n, k, layout, name in want:
         e = make_env(env, kw, batch_size=n, seed=1, reuse_buffers=True)
@@ -787,7 +787,7 @@ def test_returns_kernels_are_the_fused_loops_with_the_returns_sink():
     L = _native.lib()
     want = [("rock", {}, 1 << 20, "steps_quad_kernel<RockEnv<1>, Returns>"), ("rock", {}, 1 << 17, "steps_kernel<RockEnv<1>, 1, true, true, Returns>"),
             ("tag", {}, 1 << 20, "tag_steps_quad_kernel<true, Returns>"), ("network", {}, 1 << 20, "network_steps_quad_kernel<2, Returns, true>"),
-            ("battleship", {}, 1 << 18, "battleship_steps_quad_kernel<BattleShipEnv<1>, Returns>"),
+            ("battleship", {}, 1 << 18, "battleship_steps_quad_kernel<BattleShipEnv<1>, Returns, 2>"),
             ("tiger", {}, 1000, "steps_kernel<TigerEnv, 1, false, false, Returns>")]
     for env, kw, n, name in want:
         e = make_env(env, kw, batch_size=n, seed=1, reuse_buffers=True)
