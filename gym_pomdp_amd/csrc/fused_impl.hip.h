@@ -6,6 +6,63 @@
 
 namespace pomdp {
 
+// ---- what every quad-per-thread loop shares ------------------------------------------------------------------------------
+// The thread's place in the batch, its sink and its policy; the prologue around the first actions; the per-step key; the
+// epilogue of a step (the policy's next actions become the current ones) and of the launch.  LPT lanes per thread: 4, or 2
+// for BattleShip's small shards.  A contract change touches this and the env's own lane step, not six loops.
+template <class L, class Pol, int LPT = 4>
+struct FusedCtx {
+    uint32_t l0, glane0;                                     // the thread's first lane within the shard / its global id
+    uint64_t t0;                                             // call counter of the launch's first step
+    typename lanes_out<L, LPT>::type out;
+    typename lanes_policy<Pol, LPT>::type pol;
+    uint32_t n_bad;                                          // tape only: out-of-range actions met
+    __device__ __forceinline__ FusedCtx(int32_t *action, int32_t *ob, void *reward, uint8_t *done, int64_t rec, uint32_t lane0,
+                                        const RngKey &key0, const RngKey &akey0, uint32_t n_act, int k_steps, const TapeRef &tape)
+        : l0(blockIdx.x * (uint32_t)(LPT * BLOCK) + (uint32_t)LPT * threadIdx.x), glane0(lane0 + l0),
+          t0(((uint64_t)key0.t_hi << 32) | key0.t_lo), out(action, ob, reward, done, rec, l0),
+          pol(tape, l0, glane0, key0, akey0, n_act, k_steps), n_bad(0) {}
+    // the actions of the launch's first step: the policy's own (the column sink keeps them in row 0, or reads them from there)
+    __device__ __forceinline__ void first(int gen_first, int (&a_cur)[LPT])
+    {
+        if constexpr (LPT == 4) {
+            const u32x4 a4 = out.first(pol, gen_first);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a_cur[j] = (int)a4[j];
+        } else {
+            uint32_t a2[LPT];
+            pol.first(a2);
+#pragma unroll
+            for (int j = 0; j < LPT; ++j) a_cur[j] = (int)a2[j];
+        }
+    }
+    // the env's Philox key at step s of the launch
+    __device__ __forceinline__ RngKey key(const RngKey &key0, int s) const
+    {
+        RngKey k = key0;
+        k.t_lo = (uint32_t)(t0 + (uint64_t)s); k.t_hi = (uint32_t)((t0 + (uint64_t)s) >> 32);
+        return k;
+    }
+    // end of step s, after its stores: the actions of step s + 1 (a tape's row arrives here) become the current ones
+    __device__ __forceinline__ void advance(int s, uint32_t (&a_next)[LPT], int (&a_cur)[LPT])
+    {
+        pol.end(s, a_next);
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) a_cur[j] = (int)a_next[j];
+    }
+    __device__ __forceinline__ void finish(int k_steps)
+    {
+        pol.count_bad(n_bad);
+        out.finish(k_steps);
+    }
+};
+// The step loop of a fused launch: every load issued so far has landed (wait_loads: a storing loop may not wait on vmcnt), then
+// four consecutive segments of falling issue priority (LoopPrio).  `s` runs over the launch's steps.
+#define POMDP_FUSED_STEP_LOOP(prio_, s_)                                                                              \
+    wait_loads();                                                                                                      \
+    _Pragma("unroll 1") for (int seg_ = 0, s_ = 0; seg_ < 4; ++seg_)                                                   \
+        for (const int seg_end_ = (prio_).segment(seg_); s_ < seg_end_; ++s_)
+
 // k consecutive chained steps in ONE launch: exactly the memory state k launches of step_kernel<Env, LPT, true> leave —
 // every step's ob / reward / done / state / next action is computed and written — but a lane's state and action stay in
 // registers from one step to the next (nothing is re-read) and there is one launch ramp per k steps instead of per
@@ -253,25 +310,18 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
     __shared__ typename Env::RecTab tab;
     TL(0);
     TL_HW();
-    const uint32_t l0 = blockIdx.x * (uint32_t)(4 * BLOCK) + 4u * threadIdx.x;   // this thread's first lane within the shard
-    const uint32_t glane0 = lane0 + l0;                                          // ... and its global lane id (a multiple of 4)
-    QuadOut<L> out(action, ob, reward, done, rec, l0);
+    const uint32_t n_act = (uint32_t)Env::n_actions(p);
+    FusedCtx<L, Pol> cx(action, ob, reward, done, rec, lane0, key0, akey0, n_act, k_steps, tape);
+    const uint32_t l0 = cx.l0, glane0 = cx.glane0;           // the thread's first lane within the shard; its global id (a multiple of 4)
     typename Env::State st[4];
     int a_cur[4];
-    const uint32_t n_act = (uint32_t)Env::n_actions(p);
-    Pol pol(tape, l0, glane0, key0, akey0, n_act, k_steps);        // where the actions come from: the synthetic policy, or the caller's tape
-    uint32_t n_bad = 0;                                      // tape only: out-of-range actions met
     {
-        u32x4 a4;
         const u32x4 s_lo = ld_stream4(state + l0);
         u32x4 s_hi = {0, 0, 0, 0};
         if (W == 2) s_hi = ld_stream4(state + n + l0);
-        a4 = out.first(pol, gen_first);
+        cx.first(gen_first, a_cur);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            a_cur[j] = (int)a4[j];
-            st[j].s = (S)((uint64_t)s_lo[j] | ((uint64_t)s_hi[j] << 32));
-        }
+        for (int j = 0; j < 4; ++j) st[j].s = (S)((uint64_t)s_lo[j] | ((uint64_t)s_hi[j] << 32));
     }
     Env::stage(sh, p, (int)threadIdx.x);
     __syncthreads();
@@ -281,21 +331,16 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
     TL(2);
     const int K = p.num_rocks;
     const uint32_t start = (uint32_t)p.start_x | ((uint32_t)p.start_y << 4);
-    const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo;
-    wait_loads();
     const LoopPrio prio(k_steps);
-    #pragma unroll 1
-    for (int seg = 0, s = 0; seg < 4; ++seg)                               // four priority segments (LoopPrio)
-    for (const int seg_end = prio.segment(seg); s < seg_end; ++s) {
-        RngKey key = key0;
-        key.t_lo = (uint32_t)(t0 + (uint64_t)s); key.t_hi = (uint32_t)((t0 + (uint64_t)s) >> 32);
+    POMDP_FUSED_STEP_LOOP(prio, s) {
+        const RngKey key = cx.key(key0, s);
         // the quad's sensor words of this step (StochasticRock: block 2 of the stream — block 0 gates the actions, rock.py:443)
         // — the words its fresh episodes start from as well — and the actions of the next call counter
         constexpr uint32_t SENSOR_BLOCK = Env::SENSOR_BLOCK;
         const uint4 sw = philox4x32_10(glane0 >> 2, key.t_lo, key.t_hi, ((uint32_t)POMDP_STREAM_STEP << 24) | SENSOR_BLOCK, key.k0, key.k1);
         const uint4 rw = sw;                                   // a lane's step draws EITHER its sensor reading OR its next episode
         uint32_t a_next[4];
-        pol.begin(s, a_next);
+        cx.pol.begin(s, a_next);
         const uint32_t H[4] = {sw.x, sw.y, sw.z, sw.w}, R[4] = {rw.x, rw.y, rw.z, rw.w};
         bool acts[4] = {true, true, true, true};
         if constexpr (Env::STOCHASTIC) {                                       // the action is applied iff binomial(1, p_move) says so
@@ -324,19 +369,16 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
             if constexpr (Pol::TAPE) {
                 sj = valid ? sj : st[j].s;
                 rec[j] = valid ? rec[j] : a_taken[j];
-                n_bad += (uint32_t)!valid;
+                cx.n_bad += (uint32_t)!valid;
             }
             st[j].s = sj;
         }
-        out.put_records(rec, a_next);
-        pol.end(s, a_next);                                  // the actions of step s + 1 (a tape's row arrives here)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) a_cur[j] = (int)a_next[j];
+        cx.out.put_records(rec, a_next);
+        cx.advance(s, a_next, a_cur);
     }
     // the state is the loop's carry: it reaches memory once
     TL(3);
-    pol.count_bad(n_bad);
-    out.finish(k_steps);
+    cx.finish(k_steps);
     st_stream4(state + l0, (uint32_t)st[0].s, (uint32_t)st[1].s, (uint32_t)st[2].s, (uint32_t)st[3].s);
     if (W == 2)
         st_stream4(state + n + l0, (uint32_t)((uint64_t)st[0].s >> 32), (uint32_t)((uint64_t)st[1].s >> 32),
@@ -363,19 +405,16 @@ __global__ __launch_bounds__(BLOCK) void tag_steps_quad_kernel(uint32_t *__restr
     using Env = TagEnv;
     __shared__ Env::Shared sh;
     __shared__ typename std::conditional<TAB, Env::StepTab, NoTab>::type tab;
-    const uint32_t l0 = blockIdx.x * (uint32_t)(4 * BLOCK) + 4u * threadIdx.x;
-    const uint32_t glane0 = lane0 + l0;
-    QuadOut<L> out(action, ob, reward, done, rec, l0);
+    const uint32_t n_act = (uint32_t)Env::n_actions(p);
+    FusedCtx<L, Pol> cx(action, ob, reward, done, rec, lane0, key0, akey0, n_act, k_steps, tape);
+    const uint32_t l0 = cx.l0, glane0 = cx.glane0;
     Env::State st[4];
     int a_cur[4];
-    const uint32_t n_act = (uint32_t)Env::n_actions(p);
-    Pol pol(tape, l0, glane0, key0, akey0, n_act, k_steps);
-    uint32_t n_bad = 0;
     {
         const u32x4 s4 = ld_stream4(state + l0);
-        const u32x4 a4 = out.first(pol, gen_first);
+        cx.first(gen_first, a_cur);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { a_cur[j] = (int)a4[j]; st[j].w = s4[j]; }
+        for (int j = 0; j < 4; ++j) st[j].w = s4[j];
     }
     Env::stage(sh, p, (int)threadIdx.x);
     __syncthreads();
@@ -383,16 +422,11 @@ __global__ __launch_bounds__(BLOCK) void tag_steps_quad_kernel(uint32_t *__restr
         Env::build_tab(tab, sh, p, (int)threadIdx.x);
         __syncthreads();
     }
-    const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo;
-    wait_loads();
     const LoopPrio prio(k_steps);
-    #pragma unroll 1
-    for (int seg = 0, s = 0; seg < 4; ++seg)                               // four priority segments (LoopPrio)
-    for (const int seg_end = prio.segment(seg); s < seg_end; ++s) {
-        RngKey key = key0;
-        key.t_lo = (uint32_t)(t0 + (uint64_t)s); key.t_hi = (uint32_t)((t0 + (uint64_t)s) >> 32);
+    POMDP_FUSED_STEP_LOOP(prio, s) {
+        const RngKey key = cx.key(key0, s);
         uint32_t a_next[4];
-        pol.begin(s, a_next);
+        cx.pol.begin(s, a_next);
         int o[4], d[4];
         float r[4];
         const uint32_t a_taken[4] = {(uint32_t)a_cur[0], (uint32_t)a_cur[1], (uint32_t)a_cur[2], (uint32_t)a_cur[3]};
@@ -407,7 +441,7 @@ __global__ __launch_bounds__(BLOCK) void tag_steps_quad_kernel(uint32_t *__restr
             if constexpr (TAB) Env::step_one_opponent_tab(tab, st[j], a, o[j], r[j], d[j], f);
             else Env::step_one_opponent_pre(sh, p, st[j], a, o[j], r[j], d[j], f);
             const uint32_t lane = glane0 + (uint32_t)j;
-            if constexpr (Pol::TAPE) { if (!valid) { f.need = false; o[j] = 0; r[j] = 0.f; d[j] = 0; n_bad++; } }
+            if constexpr (Pol::TAPE) { if (!valid) { f.need = false; o[j] = 0; r[j] = 0.f; d[j] = 0; cx.n_bad++; } }
             Env::flee_word(sh, p, st[j], f, W[j], [&]() { return Env::elem(Env::quad_block(key, lane, 1u), (uint32_t)j); });
             if (d[j]) Env::auto_reset_word(p, st[j], W[j], key, lane);
             if constexpr (Pol::TAPE) st[j] = valid ? st[j] : before;
@@ -420,13 +454,10 @@ __global__ __launch_bounds__(BLOCK) void tag_steps_quad_kernel(uint32_t *__restr
 #pragma unroll
             for (int j = 0; j < 4; ++j) rc[j] = Env::reward_code(r[j]);
         }
-        out.put(a_taken, a_next, o4, r4, rc, d4);
-        pol.end(s, a_next);                                  // the actions of step s + 1 (a tape's row arrives here)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) a_cur[j] = (int)a_next[j];
+        cx.out.put(a_taken, a_next, o4, r4, rc, d4);
+        cx.advance(s, a_next, a_cur);
     }
-    pol.count_bad(n_bad);
-    out.finish(k_steps);
+    cx.finish(k_steps);
     st_stream4(state + l0, st[0].w, st[1].w, st[2].w, st[3].w);
 }
 
@@ -472,19 +503,16 @@ __global__ __launch_bounds__(BLOCK) void network_steps_quad_kernel(uint32_t *__r
     __shared__ uint32_t sta[SMALL ? 1024 : 1], stb[SMALL ? 1024 : 1], stc[SMALL ? 1024 : 1], nbft[SMALL ? 1024 : 1], tp[4];
     __shared__ float rtab[3][68];                            // reward by (no action / ping / reboot, 2 per up machine with > 2
                                                              // neighbours + 1 per other up machine): network.py:87-92, 103, 110
-    const uint32_t l0 = blockIdx.x * (uint32_t)(4 * BLOCK) + 4u * threadIdx.x;
-    const uint32_t glane0 = lane0 + l0;
-    QuadOut<L> out(action, ob, reward, done, rec, l0);
     const uint32_t n_act = (uint32_t)Env::n_actions(p);
+    FusedCtx<L, Pol> cx(action, ob, reward, done, rec, lane0, key0, akey0, n_act, k_steps, tape);
+    const uint32_t l0 = cx.l0, glane0 = cx.glane0;
     uint32_t st[4];
     int a_cur[4];
-    Pol pol(tape, l0, glane0, key0, akey0, n_act, k_steps);
-    uint32_t n_bad = 0;
     {
         const u32x4 s4 = ld_stream4(state + l0);
-        const u32x4 a4 = out.first(pol, gen_first);
+        cx.first(gen_first, a_cur);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { a_cur[j] = (int)a4[j]; st[j] = s4[j]; }
+        for (int j = 0; j < 4; ++j) st[j] = s4[j];
     }
     Env::stage(sh, p, (int)threadIdx.x);
     const Env::Thr T = Env::thresholds(p);
@@ -525,16 +553,11 @@ __global__ __launch_bounds__(BLOCK) void network_steps_quad_kernel(uint32_t *__r
     __syncthreads();
     const uint32_t all_up = p.n_machines >= 32 ? 0xFFFFFFFFu : ((1u << p.n_machines) - 1u);
     const int M2 = 2 * p.n_machines;
-    const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo;
-    wait_loads();
     const LoopPrio prio(k_steps);
-    #pragma unroll 1
-    for (int seg = 0, s = 0; seg < 4; ++seg)                               // four priority segments (LoopPrio)
-    for (const int seg_end = prio.segment(seg); s < seg_end; ++s) {
-        RngKey key = key0;
-        key.t_lo = (uint32_t)(t0 + (uint64_t)s); key.t_hi = (uint32_t)((t0 + (uint64_t)s) >> 32);
+    POMDP_FUSED_STEP_LOOP(prio, s) {
+        const RngKey key = cx.key(key0, s);
         uint32_t a_next[4];
-        pol.begin(s, a_next);
+        cx.pol.begin(s, a_next);
         const uint4 q0 = Env::quad_block(key, glane0, 0u), q1 = Env::quad_block(key, glane0, 1u), q2 = Env::quad_block(key, glane0, 2u);
         const uint32_t W0[4] = {q0.x, q0.y, q0.z, q0.w}, W1[4] = {q1.x, q1.y, q1.z, q1.w};
         const uint32_t W2[4] = {q2.x, q2.y, q2.z, q2.w};
@@ -542,7 +565,7 @@ __global__ __launch_bounds__(BLOCK) void network_steps_quad_kernel(uint32_t *__r
         bool valid[4] = {true, true, true, true};
         if constexpr (Pol::TAPE) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { valid[j] = (uint32_t)a_cur[j] < n_act; n_bad += (uint32_t)!valid[j]; }
+            for (int j = 0; j < 4; ++j) { valid[j] = (uint32_t)a_cur[j] < n_act; cx.n_bad += (uint32_t)!valid[j]; }
         }
         const uint32_t a_taken[4] = {(uint32_t)a_cur[0], (uint32_t)a_cur[1], (uint32_t)a_cur[2], (uint32_t)a_cur[3]};
         if constexpr (Pol::TAPE) {
@@ -654,13 +677,10 @@ __global__ __launch_bounds__(BLOCK) void network_steps_quad_kernel(uint32_t *__r
             r4[j] = __float_as_uint(r);
         }
         const uint32_t d4[4] = {0u, 0u, 0u, 0u};                               // network.py:113: never done
-        out.put(a_taken, a_next, o4, r4, rc, d4);
-        pol.end(s, a_next);                                  // the actions of step s + 1 (a tape's row arrives here)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) a_cur[j] = (int)a_next[j];
+        cx.out.put(a_taken, a_next, o4, r4, rc, d4);
+        cx.advance(s, a_next, a_cur);
     }
-    pol.count_bad(n_bad);
-    out.finish(k_steps);
+    cx.finish(k_steps);
     st_stream4(state + l0, st[0], st[1], st[2], st[3]);
 }
 
@@ -707,28 +727,22 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(quad_wave
     __shared__ typename Env::SeqTables seq;                  // the column patterns of the board builder
     Env::stage_seq(seq, p, (int)threadIdx.x);
     const int wv = (int)(threadIdx.x >> 6), me = (int)(threadIdx.x & 63u), tid = (int)threadIdx.x;
-    const uint32_t l0 = blockIdx.x * (uint32_t)(LPT * BLOCK) + (uint32_t)LPT * threadIdx.x;
-    const uint32_t glane0 = lane0 + l0, wave0 = glane0 - (uint32_t)LPT * (uint32_t)me;
-    typename lanes_out<L, LPT>::type out(action, ob, reward, done, rec, l0);
     const uint32_t n_act = (uint32_t)Env::n_actions(p);
+    FusedCtx<L, Pol, LPT> cx(action, ob, reward, done, rec, lane0, key0, akey0, n_act, k_steps, tape);
+    const uint32_t l0 = cx.l0, glane0 = cx.glane0, wave0 = glane0 - (uint32_t)LPT * (uint32_t)me;
     int rem[LPT];                                            // VIS_LDS: total_remaining (battleship.py:100-104)
     Mask vis[VIS_LDS ? 1 : LPT];                             // !VIS_LDS: the visited mask, remaining in the top bits of its last word
     int a_cur[LPT];
-    typename lanes_policy<Pol, LPT>::type pol(tape, l0, glane0, key0, akey0, n_act, k_steps);
-    uint32_t n_bad = 0;
     {
         typename std::conditional<LPT == 4, u32x4, u32x2>::type w[3 * MW];
-        uint32_t a4[LPT];
 #pragma unroll
         for (int q = 0; q < 3 * MW; ++q) {
             if constexpr (LPT == 4) w[q] = ld_stream4(state + (int64_t)q * n + l0);
             else w[q] = ld_stream2(state + (int64_t)q * n + l0);
         }
-        if constexpr (LPT == 4) { const u32x4 f = out.first(pol, gen_first); a4[0] = f[0]; a4[1] = f[1]; a4[2] = f[2]; a4[3] = f[3]; }
-        else pol.first(a4);
+        cx.first(gen_first, a_cur);
 #pragma unroll
         for (int j = 0; j < LPT; ++j) {
-            a_cur[j] = (int)a4[j];
             rem[j] = (int)(w[2 * MW - 1][j] >> 26);
             if constexpr (!VIS_LDS) vis[j].lo = vis[j].hi = 0;
 #pragma unroll
@@ -742,7 +756,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(quad_wave
     }
     __syncthreads();
     const int cells = p.x_size * p.y_size;
-    const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo;
+    const uint64_t t0 = cx.t0;
     int pend[LPT];                                           // >= 0: the step at which the lane's board was dealt; its `next` is yet to be built
 #pragma unroll
     for (int j = 0; j < LPT; ++j) pend[j] = -1;
@@ -799,21 +813,18 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(quad_wave
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     };
-    wait_loads();
     // The ladder from 32 steps per launch only: the board builders that follow the loop are instruction-bound where the loop
     // is store-bound, and waves that leave the loop at different times build their boards under the others' stores (10x10,
     // 20 steps per launch: 5.8 us per step without the ladder, 6.3 with it; 5x5 at 64 steps: 5.0 without, 4.3 with).
     const LoopPrio prio(k_steps, k_steps >= 32);
-    #pragma unroll 1
-    for (int seg = 0, s = 0; seg < 4; ++seg)                               // four priority segments (LoopPrio)
-    for (const int seg_end = prio.segment(seg); s < seg_end; ++s) {
+    POMDP_FUSED_STEP_LOOP(prio, s) {
         uint32_t a_taken[LPT];
         bool valid[LPT];
 #pragma unroll
         for (int j = 0; j < LPT; ++j) { a_taken[j] = (uint32_t)a_cur[j]; valid[j] = true; }
         if constexpr (Pol::TAPE) {               // a tape's out-of-range shot: the lane is left untouched, (0, 0, 0), and counted
 #pragma unroll
-            for (int j = 0; j < LPT; ++j) { valid[j] = a_taken[j] < n_act; n_bad += (uint32_t)!valid[j]; a_cur[j] = valid[j] ? a_cur[j] : 0; }
+            for (int j = 0; j < LPT; ++j) { valid[j] = a_taken[j] < n_act; cx.n_bad += (uint32_t)!valid[j]; a_cur[j] = valid[j] ? a_cur[j] : 0; }
         }
         uint32_t ow[LPT], vw[LPT];
 #pragma unroll
@@ -822,7 +833,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(quad_wave
             vw[j] = VIS_LDS ? vis_lds[a_cur[j] >> 5][j][tid] : 0u;
         }
         uint32_t a_next[LPT];
-        pol.begin(s, a_next);
+        cx.pol.begin(s, a_next);
         uint32_t o4[LPT], r4[LPT], d4[LPT];
         bool d[LPT], again = false, any_d = false;
 #pragma unroll
@@ -859,10 +870,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(quad_wave
             o4[j] = ob_j; r4[j] = (uint32_t)r;
             d4[j] = (uint32_t)d[j];
         }
-        out.put(a_taken, a_next, o4, r4, r4, d4);                              // the int8 reward IS its code
-        pol.end(s, a_next);                                  // the actions of step s + 1 (a tape's row arrives here)
-#pragma unroll
-        for (int j = 0; j < LPT; ++j) a_cur[j] = (int)a_next[j];
+        cx.out.put(a_taken, a_next, o4, r4, r4, d4);                           // the int8 reward IS its code
+        cx.advance(s, a_next, a_cur);
         if (__any(again)) build_boards();                                      // a second episode ended before the lane's next board exists
         if (__any(any_d)) {                                                    // wave-uniform: the cached boards move in
 #pragma unroll
@@ -884,8 +893,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(quad_wave
         }
     }
     build_boards();
-    pol.count_bad(n_bad);
-    out.finish(k_steps);
+    cx.finish(k_steps);
 #pragma unroll
     for (int q = 0; q < MW; ++q) {
         uint32_t vq[LPT];
@@ -925,33 +933,23 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_generic_kernel(uint32_t *__r
 {
     static_assert(Env::WORDS == 1 && sizeof(typename Env::Reward) == 4, "one state word, 4-byte rewards");
     __shared__ typename Env::Shared sh;
-    const uint32_t l0 = blockIdx.x * (uint32_t)(4 * BLOCK) + 4u * threadIdx.x;
-    const uint32_t glane0 = lane0 + l0;
-    QuadOut<L> out(action, ob, reward, done, rec, l0);
+    const uint32_t n_act = (uint32_t)Env::n_actions(p);
+    FusedCtx<L, Pol> cx(action, ob, reward, done, rec, lane0, key0, akey0, n_act, k_steps, tape);
+    const uint32_t l0 = cx.l0, glane0 = cx.glane0;
     typename Env::State st[4];
     int a_cur[4];
-    const uint32_t n_act = (uint32_t)Env::n_actions(p);
-    Pol pol(tape, l0, glane0, key0, akey0, n_act, k_steps);
-    uint32_t n_bad = 0;
     {
 #pragma unroll
         for (int j = 0; j < 4; ++j) Env::load(st[j], state, n, l0 + (uint32_t)j);
-        const u32x4 a4 = out.first(pol, gen_first);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) a_cur[j] = (int)a4[j];
+        cx.first(gen_first, a_cur);
     }
     Env::stage(sh, p, (int)threadIdx.x);
     __syncthreads();
-    const uint64_t t0 = ((uint64_t)key0.t_hi << 32) | key0.t_lo;
-    wait_loads();
     const LoopPrio prio(k_steps);
-    #pragma unroll 1
-    for (int seg = 0, s = 0; seg < 4; ++seg)                               // four priority segments (LoopPrio)
-    for (const int seg_end = prio.segment(seg); s < seg_end; ++s) {
-        RngKey key = key0;
-        key.t_lo = (uint32_t)(t0 + (uint64_t)s); key.t_hi = (uint32_t)((t0 + (uint64_t)s) >> 32);
+    POMDP_FUSED_STEP_LOOP(prio, s) {
+        const RngKey key = cx.key(key0, s);
         uint32_t a_next[4];
-        pol.begin(s, a_next);
+        cx.pol.begin(s, a_next);
         uint32_t o4[4], r4[4], d4[4], rc[4] = {0, 0, 0, 0};
         const uint32_t a_taken[4] = {(uint32_t)a_cur[0], (uint32_t)a_cur[1], (uint32_t)a_cur[2], (uint32_t)a_cur[3]};
         uint32_t W[4] = {0, 0, 0, 0};                                          // Tiger: the quad's STEP block IS the thread's four words
@@ -971,20 +969,17 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_generic_kernel(uint32_t *__r
                 Env::step_word(p, st[j], a, W[j], [&]() { return Env::elem(Env::quad_block(key, lane, 1u), (uint32_t)j); }, o, r, d);
             else
                 Env::step(sh, p, st[j], a, key, lane, o, r, d);
-            if constexpr (Pol::TAPE) { if (!valid) { st[j] = before; o = 0; r = 0; d = 0; n_bad++; } }
+            if constexpr (Pol::TAPE) { if (!valid) { st[j] = before; o = 0; r = 0; d = 0; cx.n_bad++; } }
             Env::reset_where(sh, p, st[j], d != 0, key, lane);                 // wave-convergent: every lane calls it
             o4[j] = (uint32_t)o;
             __builtin_memcpy(&r4[j], &r, 4);
             if constexpr (L::CODES) rc[j] = Env::reward_code(r);
             d4[j] = (uint32_t)(d != 0);
         }
-        out.put(a_taken, a_next, o4, r4, rc, d4);
-        pol.end(s, a_next);                                  // the actions of step s + 1 (a tape's row arrives here)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) a_cur[j] = (int)a_next[j];
+        cx.out.put(a_taken, a_next, o4, r4, rc, d4);
+        cx.advance(s, a_next, a_cur);
     }
-    pol.count_bad(n_bad);
-    out.finish(k_steps);
+    cx.finish(k_steps);
 #pragma unroll
     for (int j = 0; j < 4; ++j) Env::store(st[j], state, n, l0 + (uint32_t)j, true);
 }
