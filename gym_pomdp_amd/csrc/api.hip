@@ -84,18 +84,6 @@ __global__ __launch_bounds__(BLOCK) void decode_packed_kernel(const uint32_t *__
 } // namespace pomdp
 
 extern "C" {
-#ifdef POMDP_DEV_TIMELINE
-int pomdp_dev_timeline_step_rock(uint64_t *buf);
-int pomdp_dev_timeline_step_other(uint64_t *buf);
-int pomdp_dev_timeline_fused_rock(uint64_t *buf);
-int pomdp_dev_timeline(uint64_t *buf)       // every translation unit that stamps has its own pointer
-{
-    int rc = pomdp_dev_timeline_step_rock(buf);
-    if (!rc) rc = pomdp_dev_timeline_step_other(buf);
-    if (!rc) rc = pomdp_dev_timeline_fused_rock(buf);
-    return rc;
-}
-#endif
 
 int pomdp_abi_version(void) { return POMDP_ABI_VERSION; }
 

@@ -308,8 +308,6 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
     // the lane step yields the lane's packed record straight from RecTab (RockEnv::step_rec, ~31 vector instructions per
     // lane-step with one state word)
     __shared__ typename Env::RecTab tab;
-    TL(0);
-    TL_HW();
     const uint32_t n_act = (uint32_t)Env::n_actions(p);
     FusedCtx<L, Pol> cx(action, ob, reward, done, rec, lane0, key0, akey0, n_act, k_steps, tape);
     const uint32_t l0 = cx.l0, glane0 = cx.glane0;           // the thread's first lane within the shard; its global id (a multiple of 4)
@@ -325,10 +323,8 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
     }
     Env::stage(sh, p, (int)threadIdx.x);
     __syncthreads();
-    TL(1);
     Env::build_rec_tab(tab, sh, p, (int)threadIdx.x);
     __syncthreads();
-    TL(2);
     const int K = p.num_rocks;
     const uint32_t start = (uint32_t)p.start_x | ((uint32_t)p.start_y << 4);
     const LoopPrio prio(k_steps);
@@ -377,17 +373,11 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
         cx.advance(s, a_next, a_cur);
     }
     // the state is the loop's carry: it reaches memory once
-    TL(3);
     cx.finish(k_steps);
     st_stream4(state + l0, (uint32_t)st[0].s, (uint32_t)st[1].s, (uint32_t)st[2].s, (uint32_t)st[3].s);
     if (W == 2)
         st_stream4(state + n + l0, (uint32_t)((uint64_t)st[0].s >> 32), (uint32_t)((uint64_t)st[1].s >> 32),
                    (uint32_t)((uint64_t)st[2].s >> 32), (uint32_t)((uint64_t)st[3].s >> 32));
-#ifdef POMDP_DEV_TIMELINE
-    TL(4);
-    __builtin_amdgcn_s_waitcnt(0);
-    TL(5);
-#endif
 }
 
 // Tag (one opponent) with a quad per thread: the policy's ACTION block is the thread's own, and so is the quad's STEP block —

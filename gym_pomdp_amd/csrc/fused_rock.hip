@@ -5,6 +5,3 @@ namespace pomdp {
 POMDP_FUSED_LAUNCHER(, Rock1)
 POMDP_FUSED_LAUNCHER(, Rock2)
 }
-#ifdef POMDP_DEV_TIMELINE
-POMDP_DEV_TIMELINE_SETTER(pomdp_dev_timeline_fused_rock)
-#endif

@@ -37,18 +37,6 @@ static inline int grid_for(int64_t n)
 }
 static inline unsigned blocks_for(int64_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
 // below this many lanes one lane per thread is as fast or faster (measured: tools/microbench.hip at 2^16 .. 2^19)
-#ifdef POMDP_DEV_TIMELINE                                      // dev builds only (tools/ab_build.sh): per-workgroup phase stamps
-static __device__ uint64_t *g_timeline = nullptr;           // one copy per translation unit: each exports its own setter
-#define TL(k) do { if (threadIdx.x == 0 && g_timeline) g_timeline[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
-// slot 6: HW_REG_HW_ID (wave / SIMD / CU / SH / SE ids), slot 7: HW_REG_XCC_ID — which CU of which XCD ran the workgroup
-#define TL_HW() do { if (threadIdx.x == 0 && g_timeline) { g_timeline[blockIdx.x * 8 + 6] = __builtin_amdgcn_s_getreg((31 << 11) | 4); \
-                                                             g_timeline[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_getreg((31 << 11) | 20); } } while (0)
-#define POMDP_DEV_TIMELINE_SETTER(name) \
-    extern "C" int name(uint64_t *buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(pomdp::g_timeline), &buf, sizeof(buf)); }
-#else
-#define TL(k) do { } while (0)
-#define TL_HW() do { } while (0)
-#endif
 #ifdef POMDP_LPT2_MIN_LANES                                   // same-box A/B builds (tools/ab_build.sh)
 constexpr int64_t LPT2_MIN_LANES = POMDP_LPT2_MIN_LANES;
 #else

@@ -40,7 +40,6 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(uint32_t *__restrict__ stat
                                                      uint32_t *__restrict__ host_flag = nullptr, uint32_t flag_value = 0)
 {
     __shared__ typename Env::Shared sh;
-    TL(0);
     const bool auto_reset = flags & POMDP_AUTO_RESET;
     // Addressing: the workgroup's first lane is wave-uniform, so every column gets a per-workgroup base pointer in
     // SGPRs and a thread only ever adds a small 32-bit offset (rel < BLOCK * LPT) — `global_load/store v_off, s[base]`
@@ -80,7 +79,6 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(uint32_t *__restrict__ stat
         Env::stage(sh, p, (int)threadIdx.x);
     }
     __syncthreads();
-    TL(1);
 
     const int n_act = Env::n_actions(p);
     int o[LPT], d[LPT];
@@ -94,10 +92,6 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(uint32_t *__restrict__ stat
         Fin::lane_step(sh, p, st[j], valid[j] ? a_raw[j] : 0, key, lane0 + idx[j], o[j], r[j], d[j], aux[j]);
         if (!live[j]) { r[j] = 0; d[j] = was_done[j]; }               // step result discarded unless live
     }
-#ifdef POMDP_DEV_TIMELINE
-    { int x = 0; for (int j = 0; j < LPT; ++j) x += d[j] + (int)r[j]; asm volatile("" :: "v"(x)); }
-    TL(2);
-#endif
     bool fresh[LPT];
     uint32_t glane[LPT];
     int a_next[LPT];
@@ -107,10 +101,6 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(uint32_t *__restrict__ stat
         if constexpr (has_next<Env>::value) { if (fresh[j]) Env::load_next(st[j], state_w, n, rel[j]); }   // the cached board moves in
     }
     Fin::run(sh, p, st, fresh, key, glane, akey, (uint32_t)n_act, a_next, aux, o);
-#ifdef POMDP_DEV_TIMELINE
-    { int x = 0; for (int j = 0; j < LPT; ++j) x += o[j]; asm volatile("" :: "v"(x)); }
-    TL(3);
-#endif
 #pragma unroll
     for (int j = 0; j < LPT; ++j) {
         if (!live[j]) o[j] = 0;
@@ -128,11 +118,6 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(uint32_t *__restrict__ stat
     // system-scope release so that the host can poll `host_flag` instead of waiting for the end-of-kernel signal
     if (host_flag && blockIdx.x == 0 && threadIdx.x == 0)
         __hip_atomic_store(host_flag, flag_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-#ifdef POMDP_DEV_TIMELINE
-    TL(4);
-    __builtin_amdgcn_s_waitcnt(0);
-    TL(5);
-#endif
 }
 
 // ONE step of RockSample with the caller's actions (env.step()) and quads of consecutive lanes per thread: a quad's
@@ -162,7 +147,6 @@ __global__ __launch_bounds__(BLOCK) void step_quad_kernel(uint32_t *__restrict__
     constexpr int W = Env::WORDS;
     using S = typename Env::S;
     __shared__ typename Env::Shared sh;
-    TL(0);
     const bool auto_reset = flags & POMDP_AUTO_RESET;
     uint32_t l0[TILES];
     u32x4 s_lo[TILES], s_hi[TILES], a4[TILES];
@@ -179,11 +163,6 @@ __global__ __launch_bounds__(BLOCK) void step_quad_kernel(uint32_t *__restrict__
     const auto staged = Env::stage_load(p, (int)threadIdx.x);
     Env::stage_store(sh, staged, (int)threadIdx.x);
     __syncthreads();
-#ifdef POMDP_DEV_TIMELINE
-    TL(1);
-    asm volatile("" :: "v"(s_lo[0][0] + a4[0][0]));
-    TL(2);
-#endif
     const uint32_t n_act = (uint32_t)Env::n_actions(p);
     uint32_t n_bad = 0;
 #pragma unroll
@@ -224,7 +203,6 @@ __global__ __launch_bounds__(BLOCK) void step_quad_kernel(uint32_t *__restrict__
         st_stream4(reinterpret_cast<uint32_t *>(ob) + l0[t], o[0], o[1], o[2], o[3]);
         st_stream4(reinterpret_cast<uint32_t *>(reward) + l0[t], (uint32_t)r[0], (uint32_t)r[1], (uint32_t)r[2], (uint32_t)r[3]);
         st_stream(done_w, (uint32_t)d[0] | ((uint32_t)d[1] << 8) | ((uint32_t)d[2] << 16) | ((uint32_t)d[3] << 24));
-        if (t == 0) TL(3);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             st[j].s = fresh[j] ? Env::fresh_state(p, R[j], key, glane0 + (uint32_t)j) : st[j].s;
@@ -234,11 +212,6 @@ __global__ __launch_bounds__(BLOCK) void step_quad_kernel(uint32_t *__restrict__
                        (uint32_t)((uint64_t)st[2].s >> 32), (uint32_t)((uint64_t)st[3].s >> 32));
     }
     if (n_bad && err) atomicAdd(err, n_bad);
-#ifdef POMDP_DEV_TIMELINE
-    TL(4);
-    __builtin_amdgcn_s_waitcnt(0);
-    TL(5);
-#endif
 }
 
 // ONE step of Network with the caller's actions and a quad of consecutive lanes per thread (env.step() from 2^19 lanes).

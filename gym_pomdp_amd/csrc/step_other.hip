@@ -10,6 +10,3 @@ POMDP_STEP_LAUNCHERS(, BattleShip4)
 POMDP_STEP_LAUNCHERS(, TigerEnv)
 POMDP_STEP_LAUNCHERS(, NetworkEnv)
 }
-#ifdef POMDP_DEV_TIMELINE
-POMDP_DEV_TIMELINE_SETTER(pomdp_dev_timeline_step_other)
-#endif

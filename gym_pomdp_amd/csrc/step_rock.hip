@@ -7,6 +7,3 @@ POMDP_STEP_LAUNCHERS(, Rock2)
 POMDP_STEP_LAUNCHERS(, StochRock1)
 POMDP_STEP_LAUNCHERS(, StochRock2)
 }
-#ifdef POMDP_DEV_TIMELINE
-POMDP_DEV_TIMELINE_SETTER(pomdp_dev_timeline_step_rock)
-#endif
