@@ -125,6 +125,9 @@ def valu_roofline(workload, kernel_prefix, lanes, launch_ms):
             # priced one: `frac` says how full the issue slots are for THIS mix as measured, `frac_flat_2cyc` how far the
             # instruction count is from a machine that issued everything at the guide's rate
             "frac_flat_2cyc": achieved * 2.0 / SIMD_HZ,
+            # the recorded pass's own measure of how busy the vector ALUs were (SQ_ACTIVE_INST_VALU x 4 / SIMD cycles at the measured
+            # clock; launches of at least 150 us only — tools/pmc_valu_summary.py), for kernels whose static mix prices badly
+            "valu_busy_recorded": w["kernels"][name].get("valu_busy_frac"),
             "cycles_per_instruction": cpi, "lane_ops_per_s": achieved * 64, "kernel": name,
             "counters_stale": counters_stale(pmc, workload) or json.load(open(mix)).get("csrc_sha256") != csrc_sha(),
             "source": "instructions per launch recorded (not measured in this run): profiles/%s [%s]; issue cost of the "
@@ -581,6 +584,7 @@ def quick_step_config(args, gpa, _native, cp, dev, env_key, n, lane_offset, seed
             "kernel": kernel, "kernel_ms": kern_ms, "steps_per_launch": spl, "bytes_per_lane_step": rf["alg_bytes"],
             "roofline": {"bound": rf["primary"]["bound"], "frac": rf["primary"]["frac"], "hbm_frac": rf["hbm"]["frac"],
                          "valu_frac": None if rf["valu"] is None else rf["valu"]["frac"],
+                         "valu_busy_recorded": None if rf["valu"] is None else rf["valu"].get("valu_busy_recorded"),
                          "counters_stale": None if rf["valu"] is None else rf["valu"]["counters_stale"]}}
 
 

@@ -255,7 +255,7 @@ def test_recorded_counters_belong_to_this_tree():
     for wl in ("step20_rock_packed", "step256_rock_packed"):
         assert not bench.counters_stale(pmc, wl), "kernel sources changed since %s [%s] was recorded: re-run tools/gpu_pmc_valu.sh <tag> headline" % (pmc, wl)
         v = bench.valu_roofline(wl, "steps_quad_kernel<", 1 << 20, 0.04 if wl.startswith("step20") else 0.38)
-        assert v is not None and v["counters_stale"] is False and v["kernel"] == "steps_quad_kernel<RockEnv<1, false>, Packed>" and 0.3 < v["frac"] < 1.0, v
+        assert v is not None and v["counters_stale"] is False and v["kernel"] == "steps_quad_kernel<RockEnv<1, false>, Packed, SyntheticQuad>" and 0.3 < v["frac"] < 1.0, v
     # the shards of a 2^20-lane batch over 8 / 4 / 2 GPUs, in the default and the driver's launch shape: what
     # `strong_scaling.frac_of_floor` of a multi-GPU line is computed from
     for lg, launch_us in ((17, (12.0, 100.0)), (18, (16.0, 140.0)), (19, (26.0, 290.0))):
