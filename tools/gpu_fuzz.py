@@ -105,6 +105,7 @@ def main(budget, seed=None, n_cases=None):
         lane0 = int(rs.randint(0, 1 << 30)) * 4 % ((1 << 32) - n - 8)
         if big and rs.rand() < 0.4:             # full 1024-lane workgroups from 2^19 lanes: env.step()'s quad-per-thread kernel
             n = (1 << 19) + 1024 * int(rs.randint(0, 40))
+            lane0 = min(lane0, (1 << 32) - n - 8)               # (n grew after lane0 was drawn)
             lane0 = lane0 // 4 * 4 if rs.rand() < 0.8 else lane0
         seed = int(rs.randint(1 << 62))
         t0 = int(rs.randint(1 << 40)) if rs.rand() < 0.5 else int(rs.randint(100))

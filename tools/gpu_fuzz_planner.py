@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity sweep of the planner hooks (dev aid, GPU box): _generate_legal, _compute_prob and the fused rollouts
-(random depths incl. non-multiples of 4, sims per root, all-actions policy, lane offsets, call counters) — HIP vs oracle.
+(random depths incl. non-multiples of 4, sims per root, all-actions policy, lane offsets, call counters) and the planning step on
+top of them (pomdp_plan: action values bit for bit, argmax, the roots' real step) — HIP vs oracle.
 usage: python tools/gpu_fuzz_planner.py [seconds]"""
 import os
 import sys
@@ -54,6 +55,25 @@ def main(budget):
         for k in ("ret", "n_steps", "first_action", "last_ob"):
             assert np.array_equal(g[k].cpu().numpy(), w[k]), ctx + (k, depth, sims, alla)
         assert np.array_equal(g["terminated"].cpu().numpy(), w["terminated"].astype(bool)), ctx
+        # ... and the planning step built on them (pomdp_plan): per-root action values in the stated float64 order, argmax, the
+        # roots' real step — simulation counts on both sides of the 64-simulation chunks and of the 1024-simulation LDS tile
+        sims_p = int(rs.choice([1, 3, 63, 64, 65, 100, 130, 1030])) if n <= 64 else int(rs.randint(1, 70))
+        if (lane0 * sims_p) % 4 == 0 and (lane0 + n) * sims_p < 1 << 32:
+            tc = e.call_counter
+            r = o.batch_rollout(st, sims_p, depth, disc, seed, lane0 * sims_p, tc, all_actions=alla, nthreads=4)
+            want = ol.plan_reduce(r["ret"], r["first_action"], n, sims_p, o.n_actions)
+            if (want["best"] >= 0).all():
+                e.auto_reset = True
+                ob_g, rew_g, done_g, _, p = e.plan_step(depth, sims_per_root=sims_p, discount=disc, all_actions=alla)
+                ob_o, rew_o, done_o, bad = o.batch_step(st, want["best"], seed, lane0, tc + depth, auto_reset=True, nthreads=4)
+                assert np.array_equal(ob_g.cpu().numpy(), ob_o) and np.array_equal(rew_g.cpu().numpy(), rew_o), ctx + ("plan step",)
+                assert np.array_equal(e.state.cpu().numpy().view(np.uint32), st), ctx + ("plan state",)
+            else:
+                p = e.plan(depth, sims_per_root=sims_p, discount=disc, all_actions=alla)
+            for k in ("q", "value"):
+                assert np.array_equal(p[k].cpu().numpy().view(np.uint64), want[k].view(np.uint64)), ctx + ("plan", k, depth, sims_p)
+            for k in ("visits", "best"):
+                assert np.array_equal(p[k].cpu().numpy(), want[k]), ctx + ("plan", k, depth, sims_p)
         cases += 1
         del e
     print("planner fuzz ok: %d random cases in %.0f s" % (cases, budget))
