@@ -295,13 +295,20 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
 // actions come in the same way.  The lane step is the table-driven one.  Full workgroups of 1024 lanes and auto-reset
 // only (the launcher's SIMPLE conditions).  Same results as steps_kernel: the mapping of lanes to threads is invisible
 // to a lane's random words.
-template <class Env, class L = Columns, class Pol = SyntheticQuad>
+// LPT = 2 (round 6): HALF a quad per thread, for the shards that leave the quad loop two waves per SIMD or fewer (2^19 lanes
+// — half of a 2^20-lane batch — ran the pooled two-lanes-per-thread steps_kernel at 0.46 of its issue floor).  The quad's
+// STEP block (and StochasticRock's gate block) is time-shared by the quad's two threads exactly like the policy's block
+// (pair_shared: thread e computes the block of step s + e at every even s, two DPP moves swap the halves): one block of each
+// stream per thread per two steps — as many per lane-step as with a quad per thread — and twice the waves.  4-byte sinks and
+// the returns sink (PairOut).
+template <class Env, class L = Columns, class Pol = SyntheticQuad, int LPT = 4>
 __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict__ state, int32_t *__restrict__ action,
                                                            int32_t *__restrict__ ob, int32_t *__restrict__ reward,
                                                            uint8_t *__restrict__ done, int64_t n, RngKey key0, uint32_t lane0,
                                                            RngKey akey0, int k_steps, int64_t rec, int gen_first,
                                                            const typename Env::Params p, TapeRef tape)
 {
+    static_assert(LPT == 4 || LPT == 2, "a quad or half a quad per thread");
     constexpr int W = Env::WORDS;
     using S = typename Env::S;
     __shared__ typename Env::Shared sh;
@@ -309,17 +316,30 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
     // lane-step with one state word)
     __shared__ typename Env::RecTab tab;
     const uint32_t n_act = (uint32_t)Env::n_actions(p);
-    FusedCtx<L, Pol> cx(action, ob, reward, done, rec, lane0, key0, akey0, n_act, k_steps, tape);
-    const uint32_t l0 = cx.l0, glane0 = cx.glane0;           // the thread's first lane within the shard; its global id (a multiple of 4)
-    typename Env::State st[4];
-    int a_cur[4];
+    FusedCtx<L, Pol, LPT> cx(action, ob, reward, done, rec, lane0, key0, akey0, n_act, k_steps, tape);
+    const uint32_t l0 = cx.l0, glane0 = cx.glane0;           // the thread's first lane within the shard; its global id (a multiple of LPT)
+    const uint32_t e0 = LPT == 4 ? 0u : (glane0 & 2u);       // ... and that lane's element of its quad's blocks (LPT = 2: 0 or 2)
+    typename Env::State st[LPT];
+    int a_cur[LPT];
+    uint32_t sp0 = 0, sp1 = 0, gp0 = 0, gp1 = 0;             // LPT = 2: the odd step's words of the quad's time-shared STEP / gate blocks
     {
-        const u32x4 s_lo = ld_stream4(state + l0);
-        u32x4 s_hi = {0, 0, 0, 0};
-        if (W == 2) s_hi = ld_stream4(state + n + l0);
+        uint32_t s_lo[LPT], s_hi[LPT];
+        if constexpr (LPT == 4) {
+            const u32x4 lo = ld_stream4(state + l0);
+            u32x4 hi = {0, 0, 0, 0};
+            if (W == 2) hi = ld_stream4(state + n + l0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s_lo[j] = lo[j]; s_hi[j] = hi[j]; }
+        } else {
+            const u32x2 lo = ld_stream2(state + l0);
+            u32x2 hi = {0, 0};
+            if (W == 2) hi = ld_stream2(state + n + l0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { s_lo[j] = lo[j]; s_hi[j] = hi[j]; }
+        }
         cx.first(gen_first, a_cur);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) st[j].s = (S)((uint64_t)s_lo[j] | ((uint64_t)s_hi[j] << 32));
+        for (int j = 0; j < LPT; ++j) st[j].s = (S)((uint64_t)s_lo[j] | ((uint64_t)s_hi[j] << 32));
     }
     Env::stage(sh, p, (int)threadIdx.x);
     __syncthreads();
@@ -333,31 +353,47 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
         // the quad's sensor words of this step (StochasticRock: block 2 of the stream — block 0 gates the actions, rock.py:443)
         // — the words its fresh episodes start from as well — and the actions of the next call counter
         constexpr uint32_t SENSOR_BLOCK = Env::SENSOR_BLOCK;
-        const uint4 sw = philox4x32_10(glane0 >> 2, key.t_lo, key.t_hi, ((uint32_t)POMDP_STREAM_STEP << 24) | SENSOR_BLOCK, key.k0, key.k1);
-        const uint4 rw = sw;                                   // a lane's step draws EITHER its sensor reading OR its next episode
-        uint32_t a_next[4];
-        cx.pol.begin(s, a_next);
-        const uint32_t H[4] = {sw.x, sw.y, sw.z, sw.w}, R[4] = {rw.x, rw.y, rw.z, rw.w};
-        bool acts[4] = {true, true, true, true};
-        if constexpr (Env::STOCHASTIC) {                                       // the action is applied iff binomial(1, p_move) says so
-            const uint4 gw = Env::quad_block(key, glane0, 0u);
-            const uint32_t G[4] = {gw.x, gw.y, gw.z, gw.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acts[j] = Env::k53_le(G[j], (uint32_t)(p.act_thr >> 26), (uint32_t)p.act_thr & Env::LO_MASK,
-                                      [&]() { return Env::elem(Env::quad_block(key, glane0, 1u), (uint32_t)j); }) != (p.act_gt != 0);
+        uint32_t H[LPT], G[LPT];
+        if constexpr (LPT == 4) {
+            const uint4 sw = philox4x32_10(glane0 >> 2, key.t_lo, key.t_hi, ((uint32_t)POMDP_STREAM_STEP << 24) | SENSOR_BLOCK, key.k0, key.k1);
+            H[0] = sw.x; H[1] = sw.y; H[2] = sw.z; H[3] = sw.w;
+        } else {
+            pair_shared(s, e0 != 0u, [&](int sb) { return Env::quad_block(cx.key(key0, sb), glane0, SENSOR_BLOCK); }, H, sp0, sp1);
         }
-        uint32_t codes[4], rec[4];
-        const uint32_t a_taken[4] = {(uint32_t)a_cur[0], (uint32_t)a_cur[1], (uint32_t)a_cur[2], (uint32_t)a_cur[3]};
-        Env::reset_codes4(R, key, glane0, K, codes);
+        uint32_t a_next[LPT];
+        cx.pol.begin(s, a_next);
+        // (a lane's step draws EITHER its sensor reading OR its next episode: the fresh episodes start from the same words, R = H)
+        bool acts[LPT];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < LPT; ++j) acts[j] = true;
+        if constexpr (Env::STOCHASTIC) {                                       // the action is applied iff binomial(1, p_move) says so
+            if constexpr (LPT == 4) {
+                const uint4 gw = Env::quad_block(key, glane0, 0u);
+                G[0] = gw.x; G[1] = gw.y; G[2] = gw.z; G[3] = gw.w;
+            } else {
+                pair_shared(s, e0 != 0u, [&](int sb) { return Env::quad_block(cx.key(key0, sb), glane0, 0u); }, G, gp0, gp1);
+            }
+#pragma unroll
+            for (int j = 0; j < LPT; ++j)
+                acts[j] = Env::k53_le(G[j], (uint32_t)(p.act_thr >> 26), (uint32_t)p.act_thr & Env::LO_MASK,
+                                      [&]() { return Env::elem(Env::quad_block(key, glane0, 1u), e0 + (uint32_t)j); }) != (p.act_gt != 0);
+        }
+        uint32_t codes[LPT], rec[LPT], a_taken[LPT];
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) a_taken[j] = (uint32_t)a_cur[j];
+        if constexpr (LPT == 4) Env::reset_codes4(H, key, glane0, K, codes);
+        else {
+#pragma unroll
+            for (int j = 0; j < LPT; ++j) codes[j] = Env::template reset_codes<true>(H[j], key, glane0 + (uint32_t)j, K);
+        }
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) {
             const uint32_t lane = glane0 + (uint32_t)j;
             S sj = st[j].s;
             // a tape may hold anything: an out-of-range action leaves the lane untouched, (ob, reward, done) = (0, 0, 0), and is counted
             const bool valid = !Pol::TAPE || a_taken[j] < n_act;
             Env::step_rec(sh, tab, sj, valid ? a_taken[j] : 0u, H[j], (S)((uint64_t)start | ((uint64_t)codes[j] << 8)), rec[j],
-                          [&]() { return Env::elem(Env::quad_block(key, lane, SENSOR_BLOCK + 1u), (uint32_t)j); });
+                          [&]() { return Env::elem(Env::quad_block(key, lane, SENSOR_BLOCK + 1u), e0 + (uint32_t)j); });
             if constexpr (Env::STOCHASTIC) {                                // the gate said no (rock.py:443): nothing happens
                 sj = acts[j] ? sj : st[j].s;
                 rec[j] = acts[j] ? rec[j] : a_taken[j];
@@ -374,10 +410,15 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
     }
     // the state is the loop's carry: it reaches memory once
     cx.finish(k_steps);
-    st_stream4(state + l0, (uint32_t)st[0].s, (uint32_t)st[1].s, (uint32_t)st[2].s, (uint32_t)st[3].s);
-    if (W == 2)
-        st_stream4(state + n + l0, (uint32_t)((uint64_t)st[0].s >> 32), (uint32_t)((uint64_t)st[1].s >> 32),
-                   (uint32_t)((uint64_t)st[2].s >> 32), (uint32_t)((uint64_t)st[3].s >> 32));
+    if constexpr (LPT == 4) {
+        st_stream4(state + l0, (uint32_t)st[0].s, (uint32_t)st[1].s, (uint32_t)st[2].s, (uint32_t)st[3].s);
+        if (W == 2)
+            st_stream4(state + n + l0, (uint32_t)((uint64_t)st[0].s >> 32), (uint32_t)((uint64_t)st[1].s >> 32),
+                       (uint32_t)((uint64_t)st[2].s >> 32), (uint32_t)((uint64_t)st[3].s >> 32));
+    } else {
+        st_stream2(state + l0, (uint32_t)st[0].s, (uint32_t)st[1].s);
+        if (W == 2) st_stream2(state + n + l0, (uint32_t)((uint64_t)st[0].s >> 32), (uint32_t)((uint64_t)st[1].s >> 32));
+    }
 }
 
 // Tag (one opponent) with a quad per thread: the policy's ACTION block is the thread's own, and so is the quad's STEP block —
@@ -1120,7 +1161,20 @@ static int launch_steps_fused_l(const typename Env::Params &p, uint32_t *state, 
     if constexpr (quad_tab<Env>::value) {
         // from 16 steps per launch on the lane step reads the (position, action) table the workgroup builds first and a
         // thread owns a quad of consecutive lanes (steps_quad_kernel: RockSample and StochasticRock)
-        if (quad_ok && n >= (Env::STOCHASTIC ? QUAD_MIN_STOCHROCK : QUAD_MIN_ROCK) && k >= 16 && p.num_rocks + 5 <= Env::TAB_ACTIONS) {
+        if constexpr (pair_sink<L>::value && !RETS) {
+            // half a quad per thread where a quad per thread would leave a SIMD two waves or fewer (the shards of a 2^20-lane batch)
+            if (quad_ok && n >= (Env::STOCHASTIC ? STOCHROCK_PAIR_MIN_LANES : ROCK_PAIR_MIN_LANES) &&
+                n <= (Env::STOCHASTIC ? STOCHROCK_PAIR_MAX_LANES : ROCK_PAIR_MAX_LANES) && k >= 16 && p.num_rocks + 5 <= Env::TAB_ACTIONS) {
+                char pname[40];
+                snprintf(pname, sizeof pname, "%s, 2", lname);
+                note_fused("steps_quad_kernel", Env::NAME, pname);
+                const dim3 pgrid((unsigned)(n / (2 * BLOCK)));
+                if (taped) hipLaunchKernelGGL((steps_quad_kernel<Env, L, TapeQuad, 2>), pgrid, dim3(BLOCK), 0, (hipStream_t)stream, POMDP_QUAD_ARGS);
+                else hipLaunchKernelGGL((steps_quad_kernel<Env, L, SyntheticQuad, 2>), pgrid, dim3(BLOCK), 0, (hipStream_t)stream, POMDP_QUAD_ARGS);
+                launched = true;
+            }
+        }
+        if (!launched && quad_ok && n >= (Env::STOCHASTIC ? QUAD_MIN_STOCHROCK : QUAD_MIN_ROCK) && k >= 16 && p.num_rocks + 5 <= Env::TAB_ACTIONS) {
             note_fused("steps_quad_kernel", Env::NAME, lname);
             POMDP_LAUNCH_QUAD(steps_quad_kernel<Env, L);
             launched = true;

@@ -430,6 +430,22 @@ constexpr int64_t BS_PAIR_MAX_LANES = POMDP_BS_PAIR_MAX_LANES;
 #else
 constexpr int64_t BS_PAIR_MAX_LANES = 1 << 19;
 #endif
+// RockSample / StochasticRock with half a quad per thread (steps_quad_kernel<.., 2>), records and typed planes only.  Measured
+// against both neighbours (profiles/r06_rock_pair_ab.txt, us per step, Packed): RockSample(7,8) at 3 * 2^17 lanes level with
+// the pooled kernel (0.80 / 0.81), 13 * 2^15 .. 5 * 2^17 ahead (2^19: 1.07 -> 0.87), at 3 * 2^18 level with the quad loop;
+// StochasticRock ahead of the pooled kernel from 3 * 2^17 (1.47 -> 1.11; 7 * 2^16: 2.06 -> 1.35) and behind the quad loop from
+// 2^19 (1.32 / 1.36).  The returns sink loses at 2^19 (1.01 / 1.05: its float64 chain wants the quad's four independent
+// lanes) and is not built in this form.  -DPOMDP_ROCK_PAIR_MAX_LANES=0: the A arm; with _MIN_LANES: one gate for both envs.
+#ifdef POMDP_ROCK_PAIR_MAX_LANES
+constexpr int64_t ROCK_PAIR_MAX_LANES = POMDP_ROCK_PAIR_MAX_LANES, STOCHROCK_PAIR_MAX_LANES = POMDP_ROCK_PAIR_MAX_LANES;
+#else
+constexpr int64_t ROCK_PAIR_MAX_LANES = (3 << 18) - 1, STOCHROCK_PAIR_MAX_LANES = (1 << 19) - 1;
+#endif
+#ifdef POMDP_ROCK_PAIR_MIN_LANES
+constexpr int64_t ROCK_PAIR_MIN_LANES = POMDP_ROCK_PAIR_MIN_LANES, STOCHROCK_PAIR_MIN_LANES = POMDP_ROCK_PAIR_MIN_LANES;
+#else
+constexpr int64_t ROCK_PAIR_MIN_LANES = (3 << 17) + 1, STOCHROCK_PAIR_MIN_LANES = 3 << 17;
+#endif
 #ifdef POMDP_BS_VIS_LDS_MAX_LANES                             // the visited mask in LDS up to this many lanes (48 B of LDS per lane)
 constexpr int64_t BS_VIS_LDS_MAX_LANES = POMDP_BS_VIS_LDS_MAX_LANES;
 #else

@@ -147,6 +147,18 @@ static __device__ __forceinline__ uint32_t pair_swap(uint32_t v)      // v of th
 {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
 }
+// the two words of a quad-shared block stream that belong to this thread's two lanes, at step s: at every even s thread `hi`
+// (lanes 2, 3 of the quad) computes the block of step s + 1, its neighbour the block of step s, and they swap the halves
+template <class BlockOfStep>
+static __device__ __forceinline__ void pair_shared(int s, bool hi, BlockOfStep block_of_step, uint32_t (&w)[2], uint32_t &odd0, uint32_t &odd1)
+{
+    if ((s & 1) == 0) {                                       // wave-uniform
+        const uint4 b = block_of_step(s + (hi ? 1 : 0));
+        const uint32_t r0 = pair_swap(hi ? b.x : b.z), r1 = pair_swap(hi ? b.y : b.w);
+        w[0] = hi ? r0 : b.x; w[1] = hi ? r1 : b.y;
+        odd0 = hi ? b.z : r0; odd1 = hi ? b.w : r1;           // kept by the caller for step s + 1
+    } else { w[0] = odd0; w[1] = odd1; }
+}
 struct SyntheticPair {
     static constexpr bool TAPE = false;
     uint32_t glane0, n_act, k0, k1, odd[2];
@@ -466,6 +478,11 @@ template <> struct PairOut<Packed> {
         st_stream2(w, pack_record(a_cur[0], o[0], rc[0], d[0]), pack_record(a_cur[1], o[1], rc[1], d[1]));
         w += rec;
     }
+    __device__ __forceinline__ void put_records(const uint32_t (&r)[2], const uint32_t (&)[2])
+    {
+        st_stream2(w, r[0], r[1]);
+        w += rec;
+    }
     __device__ __forceinline__ void finish(int) {}
 };
 template <> struct PairOut<Narrow> {
@@ -480,6 +497,15 @@ template <> struct PairOut<Narrow> {
         st_stream(w + plane, (uint16_t)(o[0] | (o[1] << 8)));
         st_stream(w + 2 * plane, (uint16_t)((rc[0] & 0xFFu) | ((rc[1] & 0xFFu) << 8)));
         st_stream(w + 3 * plane, (uint16_t)(d[0] | (d[1] << 8)));
+        w += row;
+    }
+    __device__ __forceinline__ void put_records(const uint32_t (&r)[2], const uint32_t (&)[2])
+    {
+        // byte b of record j -> byte j of plane b
+        st_stream(w, (uint16_t)__builtin_amdgcn_perm(r[1], r[0], 0x0C0C0400u));
+        st_stream(w + plane, (uint16_t)__builtin_amdgcn_perm(r[1], r[0], 0x0C0C0501u));
+        st_stream(w + 2 * plane, (uint16_t)__builtin_amdgcn_perm(r[1], r[0], 0x0C0C0602u));
+        st_stream(w + 3 * plane, (uint16_t)__builtin_amdgcn_perm(r[1], r[0], 0x0C0C0703u));
         w += row;
     }
     __device__ __forceinline__ void finish(int) {}
@@ -515,6 +541,12 @@ template <class Env> struct PairOut<Returns<Env>> {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
             returns_step<Env>(ret[j], disc[j], ret_sum[j], episodes[j], ret_done[j], discount, rc[j], BANK ? mask_of_bit(d[j], 0) : 0u);
+    }
+    __device__ __forceinline__ void put_records(const uint32_t (&r)[2], const uint32_t (&)[2])
+    {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)                           // the done byte of a record is 0 or 1
+            returns_step<Env>(ret[j], disc[j], ret_sum[j], episodes[j], ret_done[j], discount, r[j] >> 16, mask_of_bit(r[j], 24));
     }
     __device__ __forceinline__ void finish(int k_steps)
     {

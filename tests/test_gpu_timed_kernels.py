@@ -90,7 +90,9 @@ TAPES = [("rock", {}, 1 << 20, 80), ("rock", dict(board_size=15, num_rocks=15), 
          ("battleship", dict(board_size=(10, 10), max_len=5), 1 << 19, 70), ("battleship", {}, 1 << 18, 70),
          # below the quad gates / ragged / several opponents: the general one-lane-per-thread loop
          ("rock", {}, 1 << 17, 66), ("rock", {}, 4099, 70), ("tag", dict(num_opponents=2), 1 << 18, 40), ("tiger", {}, 3, 70),
-         ("network", dict(n_machines=16, problem_type=1), 777, 40), ("battleship", {}, 259, 70)]
+         ("network", dict(n_machines=16, problem_type=1), 777, 40), ("battleship", {}, 259, 70),
+         # RockSample's half-quad-per-thread loop (7 * 2^16 .. 3 * 2^18 lanes)
+         ("rock", {}, 1 << 19, 80), ("rock", dict(board_size=15, num_rocks=15), 5 << 17, 40)]
 
 
 def _tape(rng, n_actions, steps, n, bad_every):
@@ -611,7 +613,11 @@ LAYOUT_FULL = [("rock", {}, 1 << 20, 70), ("rock", {}, 1 << 20, 20), ("rock", di
                ("tiger", {}, 1 << 17, 66), ("network", {}, 1 << 18, 66), ("battleship", {}, 1 << 17, 66),
                # ragged batches: rows padded to the layout's pitch, the general (not SIMPLE) loop
                ("rock", {}, 4099, 70), ("tag", {}, (1 << 18) + 5, 20), ("network", {}, 777, 70), ("tiger", {}, 3, 70),
-               ("battleship", {}, 259, 70), ("rock", dict(board_size=15, num_rocks=15), (1 << 19) + 4, 30)]
+               ("battleship", {}, 259, 70), ("rock", dict(board_size=15, num_rocks=15), (1 << 19) + 4, 30),
+               # RockSample's half-quad-per-thread loop (above 3 * 2^17, below 3 * 2^18 lanes; 2^19 is above) and StochasticRock's
+               # (3 * 2^17 .. 2^19 - 1)
+               ("rock", {}, 7 << 16, 40), ("rock", dict(board_size=15, num_rocks=15), 5 << 17, 40), ("rock", {}, (3 << 18) - 1024, 20),
+               ("stochrock", dict(board_size=11, num_rocks=11), 3 << 17, 30), ("stochrock", {}, (1 << 19) - 1024, 40)]
 
 
 LAYOUTS = ("blocked", "packed", "narrow")
@@ -680,6 +686,10 @@ def test_layout_kernels_are_the_quad_loops_with_another_sink():
             ("network", {}, 1 << 20, 64, "packed", "network_steps_quad_kernel<2, Packed, true>"),
             ("rock", {}, 1 << 20, 64, "narrow", "steps_quad_kernel<RockEnv<1>, Narrow>"), ("tag", {}, 1 << 18, 64, "narrow", "steps_kernel<TagEnv, 1, true, false, Narrow>"),
             ("battleship", {}, 1 << 18, 64, "packed", "battleship_steps_quad_kernel<BattleShipEnv<1>, Packed, 2>"),
+            ("rock", {}, 1 << 19, 64, "packed", "steps_quad_kernel<RockEnv<1>, Packed, 2>"), ("rock", {}, 3 << 17, 64, "narrow", "steps_kernel<RockEnv<1>, 1, true, true, Narrow>"),
+            ("rock", {}, (3 << 17) + 1024, 64, "narrow", "steps_quad_kernel<RockEnv<1>, Narrow, 2>"), ("rock", {}, 3 << 18, 64, "packed", "steps_quad_kernel<RockEnv<1>, Packed>"),
+            ("rock", dict(board_size=15, num_rocks=15), 5 << 17, 64, "narrow", "steps_quad_kernel<RockEnv<2>, Narrow, 2>"), ("rock", {}, 1 << 19, 8, "packed", "steps_kernel<RockEnv<1>, 2, true, false, Packed>"),
+            ("stochrock", {}, 1 << 19, 64, "packed", "steps_quad_kernel<StochasticRockEnv<1>, Packed>"), ("stochrock", {}, 3 << 17, 64, "packed", "steps_quad_kernel<StochasticRockEnv<1>, Packed, 2>"),
             ("tiger", {}, 1000, 64, "packed", "steps_kernel<TigerEnv, 1, false, false, Packed>")]
     for env, kw, n, k, layout, name in want:
         e = make_env(env, kw, batch_size=n, seed=1, reuse_buffers=True)
@@ -743,7 +753,8 @@ RETURNS_FULL = [("rock", {}, 1 << 20, (70, 20)), ("rock", dict(board_size=15, nu
                 ("rock", {}, 1 << 19, (66, 4)), ("rock", {}, 1 << 18, (66, 4)), ("rock", {}, 1 << 17, (66, 4)), ("tag", {}, 1 << 18, (66, 4)),
                 ("tiger", {}, 1 << 17, (66, 4)), ("network", {}, 1 << 18, (66, 4)), ("battleship", {}, 1 << 17, (66, 4)),
                 ("rock", {}, 4099, (70, 9)), ("tag", {}, (1 << 18) + 5, (20, 9)), ("network", {}, 777, (70, 9)), ("tiger", {}, 3, (70, 9)),
-                ("battleship", {}, 259, (70, 9)), ("rock", dict(board_size=15, num_rocks=15), (1 << 19) + 4, (30, 9))]
+                ("battleship", {}, 259, (70, 9)), ("rock", dict(board_size=15, num_rocks=15), (1 << 19) + 4, (30, 9)),
+                ("rock", dict(board_size=15, num_rocks=15), 5 << 17, (40, 9)), ("stochrock", dict(board_size=11, num_rocks=11), 7 << 16, (30, 9))]   # between the gates
 
 
 @pytest.mark.parametrize("env,kw,n,ks", RETURNS_FULL, ids=["%s%s-%d" % (c[0], "-".join(str(v) for v in c[1].values()), c[2]) for c in RETURNS_FULL])

@@ -219,8 +219,10 @@ def test_fused_step_loops_never_wait_for_their_own_stores():
                 continue
             seen += 1
             assert waits == [], (name, waits)
-    assert seen == 10, sorted(res)          # both kernels with each of the five sinks (traj_out.hip.h: three layouts of round 4, Narrow, Returns)
-    assert taped == 5, sorted(res)          # the quad loop on a tape, each sink
+    # the quad kernel and the pooled one with each of the five sinks (traj_out.hip.h: three layouts of round 4, Narrow, Returns),
+    # the half-quad-per-thread form of the quad kernel (the shards between 3 * 2^17 and 3 * 2^18 lanes) with Packed / Narrow
+    assert seen == 12, sorted(res)
+    assert taped == 7, sorted(res)          # the quad loop on a tape, each sink; its half-quad form, two sinks
 
 
 def test_library_override_by_environment_variable():

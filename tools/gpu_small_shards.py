@@ -2,8 +2,8 @@
 """Fused-launch time per step at the shard sizes a 2^20-lane batch leaves per GPU (2^17 .. 2^20, and below), for every
 library variant given: python tools/gpu_small_shards.py [libA.so libB.so ...]   (default: the product library).
 Variants come from tools/ab_build.sh (e.g. -DPOMDP_QUAD_MIN_LANES=4096: the quad-per-thread loops from 4096 lanes up).
-Prints us per step of collect_synthetic($SHARD_K or 256, layout=$SHARD_LAYOUT or "packed") by HIP events, and the kernel the launcher
-picked."""
+Prints us per step of collect_synthetic($SHARD_K or 256, layout=$SHARD_LAYOUT or "packed"; "returns": collect_returns) by HIP
+events, and the kernel the launcher picked."""
 import os
 import subprocess
 import sys
@@ -11,7 +11,7 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 
-ENVS = [("rock", "Rock-v0", {}), ("rock15", "Rock-v0", dict(board_size=15, num_rocks=15)), ("tag", "Tag-v0", {}),
+ENVS = [("rock", "Rock-v0", {}), ("rock15", "Rock-v0", dict(board_size=15, num_rocks=15)), ("stochrock", "StochasticRock-v0", {}), ("tag", "Tag-v0", {}),
         ("tiger", "Tiger-v0", {}), ("network", "Network-v0", {}),
         ("battleship", "Battleship-v0", dict(board_size=(10, 10), max_len=5))]
 
@@ -36,16 +36,22 @@ def one(lib_path):
             e = gpa.make(env_id, batch_size=n, seed=0, reuse_buffers=True, **kw)
             e.reset()
             K = int(os.environ.get("SHARD_K", "256"))
-            tr = e.collect_synthetic(K, layout=os.environ.get("SHARD_LAYOUT", "packed"))
+            layout = os.environ.get("SHARD_LAYOUT", "packed")
+            if layout == "returns":                    # no trajectory: the episode-return reduction (pomdp_collect_returns)
+                tr = e.collect_returns(K)
+                run = lambda: e.collect_returns(K, stats=tr)
+            else:
+                tr = e.collect_synthetic(K, layout=layout)
+                run = lambda: e.collect_synthetic(K, out=tr)
             for _ in range(8):
-                e.collect_synthetic(K, out=tr)
+                run()
             torch.cuda.synchronize()
             best = 1e9
             for _ in range(5):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(4):
-                    e.collect_synthetic(K, out=tr)
+                    run()
                 e1.record()
                 torch.cuda.synchronize()
                 best = min(best, e0.elapsed_time(e1) / (4 * K) * 1e3)
