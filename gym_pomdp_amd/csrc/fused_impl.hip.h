@@ -171,6 +171,18 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
         bool live[LPT], valid[LPT], fresh[LPT];
         int a_next[LPT];
         typename Env::State before[LPT];
+        // this lane's block of the policy: that of step s + e, transposed within the quad — component J is then THIS lane's word
+        // of step s + J.  Drawn in the same branch as the step's own time-shared blocks (POLICY_WITH_STEP): the chains are
+        // independent and a shard this loop serves has two to four waves per SIMD — one block after the other costs it twice
+        // the latency of both together.
+        auto policy_quarter = [&]() {
+            const uint32_t e = glane[0] & 3u;
+            const uint64_t te = ta0 + (uint64_t)s + (uint64_t)e;
+            aq = quad_transpose4(philox4x32_10(glane[0] >> 2, (uint32_t)te, (uint32_t)(te >> 32),
+                                               (uint32_t)POMDP_STREAM_ACTION << 24, akey0.k0, akey0.k1), e);
+        };
+        constexpr bool POLICY_WITH_STEP = quad_policy && !TAPE && POLICY_WITH_STEP_BLOCKS &&
+                                          (Env::QUAD_SENSOR || quad_word_env<Env>::value || quad_words_of<Env>::value == 3);
 #pragma unroll
         for (int j = 0; j < LPT; ++j) {
             before[j] = st[j];
@@ -186,6 +198,7 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
                     ke.t_lo = (uint32_t)te; ke.t_hi = (uint32_t)(te >> 32);
                     sq = quad_transpose4(Env::quad_block(ke, glane[0], 0u), glane[0] & 3u);
                     rq = sq;                       // ... and the fresh episodes of the steps' done lanes start from the same words
+                    if constexpr (POLICY_WITH_STEP) policy_quarter();
                 }
                 const int sj = s & 3;                                            // wave-uniform selects
                 const uint32_t H = sj == 0 ? sq.x : sj == 1 ? sq.y : sj == 2 ? sq.z : sq.w;
@@ -210,6 +223,7 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
                     RngKey ke = key0;
                     ke.t_lo = (uint32_t)te; ke.t_hi = (uint32_t)(te >> 32);
                     sq = quad_transpose4(Env::quad_block(ke, glane[0], 0u), glane[0] & 3u);
+                    if constexpr (POLICY_WITH_STEP) policy_quarter();
                 }
                 const int sj = s & 3;                                            // wave-uniform selects
                 const uint32_t W = sj == 0 ? sq.x : sj == 1 ? sq.y : sj == 2 ? sq.z : sq.w;
@@ -226,6 +240,7 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
                     nq0 = quad_transpose4(Env::quad_block(ke, glane[0], 0u), e);
                     nq1 = quad_transpose4(Env::quad_block(ke, glane[0], 1u), e);
                     nq2 = quad_transpose4(Env::quad_block(ke, glane[0], 2u), e);
+                    if constexpr (POLICY_WITH_STEP) policy_quarter();
                 }
                 const int sj = s & 3;                                            // wave-uniform selects
                 auto pick = [&](const uint4 &q) { return sj == 0 ? q.x : sj == 1 ? q.y : sj == 2 ? q.z : q.w; };
@@ -237,13 +252,7 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
             a_next[j] = 0;
         }
         if constexpr (quad_policy) {
-            const uint32_t e = glane[0] & 3u;
-            if (!TAPE && (s & 3) == 0) {                                     // this lane's block: the policy of step s + e ...
-                const uint64_t te = ta0 + (uint64_t)s + (uint64_t)e;
-                // ... transposed within the quad: component J is then THIS lane's word of step s + J
-                aq = quad_transpose4(philox4x32_10(glane[0] >> 2, (uint32_t)te, (uint32_t)(te >> 32),
-                                                   (uint32_t)POMDP_STREAM_ACTION << 24, akey0.k0, akey0.k1), e);
-            }
+            if constexpr (!TAPE && !POLICY_WITH_STEP) { if ((s & 3) == 0) policy_quarter(); }
             const int sj = s & 3;                                            // wave-uniform selects
             if constexpr (REC) {
                 // step_rec already moved the fresh episode in

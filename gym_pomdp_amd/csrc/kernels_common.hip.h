@@ -446,6 +446,11 @@ constexpr int64_t ROCK_PAIR_MIN_LANES = POMDP_ROCK_PAIR_MIN_LANES, STOCHROCK_PAI
 #else
 constexpr int64_t ROCK_PAIR_MIN_LANES = (3 << 17) + 1, STOCHROCK_PAIR_MIN_LANES = 3 << 17;
 #endif
+#ifdef POMDP_POLICY_AFTER_STEP                                 // the A arm: the policy's block drawn after the lane step (until round 6)
+constexpr bool POLICY_WITH_STEP_BLOCKS = false;
+#else
+constexpr bool POLICY_WITH_STEP_BLOCKS = true;
+#endif
 #ifdef POMDP_BS_VIS_LDS_MAX_LANES                             // the visited mask in LDS up to this many lanes (48 B of LDS per lane)
 constexpr int64_t BS_VIS_LDS_MAX_LANES = POMDP_BS_VIS_LDS_MAX_LANES;
 #else

@@ -138,7 +138,9 @@ def test_tape_driven_rows_equal_the_oracle(oracle_lib, fuse64, env, kw, n, steps
     from gym_pomdp_amd import _native
     name = _native.lib().pomdp_last_fused_kernel().decode()
     assert name.endswith(", Tape>") or ", Tape" in name, name
-    if n >= 1 << 19 or (env == "battleship" and n >= 1 << 16):
+    # the quad-per-thread loops' gates (kernels_common.hip.h); RockSample's records ride the half-quad form from above 3 * 2^17 lanes
+    quad_from = {"battleship": 1 << 16, "rock": (3 << 17) + 1 if layout == "packed" else 3 << 18}.get(env, 1 << 19)
+    if n >= quad_from:
         assert name.startswith(want_kernel + "<"), name                    # the quad-per-thread loop took it
     elif n < 1 << 16 or n % 1024:
         assert name.startswith("steps_kernel<"), name
@@ -754,7 +756,7 @@ RETURNS_FULL = [("rock", {}, 1 << 20, (70, 20)), ("rock", dict(board_size=15, nu
                 ("tiger", {}, 1 << 17, (66, 4)), ("network", {}, 1 << 18, (66, 4)), ("battleship", {}, 1 << 17, (66, 4)),
                 ("rock", {}, 4099, (70, 9)), ("tag", {}, (1 << 18) + 5, (20, 9)), ("network", {}, 777, (70, 9)), ("tiger", {}, 3, (70, 9)),
                 ("battleship", {}, 259, (70, 9)), ("rock", dict(board_size=15, num_rocks=15), (1 << 19) + 4, (30, 9)),
-                ("rock", dict(board_size=15, num_rocks=15), 5 << 17, (40, 9)), ("stochrock", dict(board_size=11, num_rocks=11), 7 << 16, (30, 9))]   # between the gates
+                ("rock", dict(board_size=15, num_rocks=15), 5 << 17, (40, 9)), ("stochrock", {}, 7 << 16, (30, 9))]   # between the gates
 
 
 @pytest.mark.parametrize("env,kw,n,ks", RETURNS_FULL, ids=["%s%s-%d" % (c[0], "-".join(str(v) for v in c[1].values()), c[2]) for c in RETURNS_FULL])

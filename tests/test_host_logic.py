@@ -257,14 +257,15 @@ def test_recorded_counters_belong_to_this_tree():
     for wl in ("step20_rock_packed", "step256_rock_packed"):
         assert not bench.counters_stale(pmc, wl), "kernel sources changed since %s [%s] was recorded: re-run tools/gpu_pmc_valu.sh <tag> headline" % (pmc, wl)
         v = bench.valu_roofline(wl, "steps_quad_kernel<", 1 << 20, 0.04 if wl.startswith("step20") else 0.38)
-        assert v is not None and v["counters_stale"] is False and v["kernel"] == "steps_quad_kernel<RockEnv<1, false>, Packed, SyntheticQuad>" and 0.3 < v["frac"] < 1.0, v
+        assert v is not None and v["counters_stale"] is False and v["kernel"] == "steps_quad_kernel<RockEnv<1, false>, Packed, SyntheticQuad, 4>" and 0.3 < v["frac"] < 1.0, v
     # the shards of a 2^20-lane batch over 8 / 4 / 2 GPUs, in the default and the driver's launch shape: what
     # `strong_scaling.frac_of_floor` of a multi-GPU line is computed from
-    for lg, launch_us in ((17, (12.0, 100.0)), (18, (16.0, 140.0)), (19, (26.0, 290.0))):
+    # (2^19 lanes: the half-quad-per-thread form of the quad loop since round 6; below, the one-lane-per-thread loop)
+    for lg, launch_us, family in ((17, (12.0, 100.0), "steps_kernel<"), (18, (16.0, 140.0), "steps_kernel<"), (19, (26.0, 240.0), "steps_quad_kernel<")):
         for spl, us in zip((20, 256), launch_us):
             key = bench.valu_workload_key("rock", spl, "packed", 1 << lg)
             assert key == "step%d_rock_packed_2e%d" % (spl, lg)
-            v = bench.valu_roofline(key, "steps_kernel<", 1 << lg, us * 1e-3)
+            v = bench.valu_roofline(key, family, 1 << lg, us * 1e-3)
             assert v is not None and v["counters_stale"] is False and 0.3 < v["frac"] < 1.0, (key, v)
     # a changed source file flips the flag (the hash covers every file under csrc/ and the C header)
     assert bench.counters_stale(pmc, "no_such_workload")

@@ -37,11 +37,12 @@ def collect_case(rs):
     from oracle import philox_ref as px
     name, env_id, kw = CONFIGS[rs.randint(len(CONFIGS))]
     pick = rs.rand()
-    # full workgroups at and above the gates of the quad-per-thread loops (2^18: Tiger, Network; 2^19: RockSample, Tag), ragged
-    # batches around 2^18, small batches (any size: the fused drivers generate their own first actions)
+    # full workgroups at and above the gates of the quad-per-thread loops (2^18: Tiger, Network; 2^19: RockSample, Tag), across
+    # the half-quad-per-thread gates (3 * 2^17 .. 3 * 2^18 lanes), ragged batches around 2^18, small batches (any size: the fused drivers generate their own first actions)
     n = (1 << 20) + 1024 * int(rs.randint(0, 3)) if pick < 0.3 else \
         (1 << int(rs.randint(18, 20))) + 1024 * int(rs.randint(0, 3)) if pick < 0.5 else \
-        int(rs.randint(1 << 18, (1 << 18) + 3000)) if pick < 0.65 else int(rs.randint(2, 6000))   # 1 is scalar mode
+        1024 * int(rs.randint(384, 769)) if pick < 0.58 else \
+        int(rs.randint(1 << 18, (1 << 18) + 3000)) if pick < 0.7 else int(rs.randint(2, 6000))   # 1 is scalar mode
     lane0 = int(rs.randint(0, 1 << 30)) * 4 % ((1 << 32) - n - 8) // 4 * 4
     seed = int(rs.randint(1 << 62))
     t0 = int(rs.randint(1 << 40)) if rs.rand() < 0.5 else int(rs.randint(100))
