@@ -156,9 +156,11 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
     }
     wait_loads();
     const LoopPrio prio(k_steps);
-    #pragma unroll 1
-    for (int seg = 0, s = 0; seg < 4; ++seg)                               // four priority segments (LoopPrio)
-    for (const int seg_end = prio.segment(seg); s < seg_end; ++s) {
+    // One step.  `sj_`: the step's place in its group of four (s & 3) — the time-shared blocks are drawn at place 0 and every
+    // step picks its words by place: a run-time, wave-uniform select in the plain loop, a compile-time constant in the loop
+    // unrolled by four (UNROLL4 below).
+    auto step_body = [&](const int s, const auto sj_) __attribute__((always_inline)) {
+        const int sj = sj_;
         if constexpr (TAPE) col.request(s);                  // the row of step s + 1: first touched after this step's stores
         RngKey key = key0, akey = akey0;
         key.t_lo = (uint32_t)(t0 + (uint64_t)s); key.t_hi = (uint32_t)((t0 + (uint64_t)s) >> 32);
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
                 // one lane per thread, the sensor block shared by the quad (RockSample shards below the pooled kernels' gates):
                 // lane e computes the block of step s + e once per four steps and the words reach their lanes by the same
                 // transpose as the policy's — one Philox block per lane per four steps instead of one per step
-                if ((s & 3) == 0) {
+                if (sj == 0) {
                     const uint64_t te = t0 + (uint64_t)s + (uint64_t)(glane[0] & 3u);
                     RngKey ke = key0;
                     ke.t_lo = (uint32_t)te; ke.t_hi = (uint32_t)(te >> 32);
@@ -200,7 +202,6 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
                     rq = sq;                       // ... and the fresh episodes of the steps' done lanes start from the same words
                     if constexpr (POLICY_WITH_STEP) policy_quarter();
                 }
-                const int sj = s & 3;                                            // wave-uniform selects
                 const uint32_t H = sj == 0 ? sq.x : sj == 1 ? sq.y : sj == 2 ? sq.z : sq.w;
                 if constexpr (REC) {
                     // the step and, where it ends the episode, the fresh one (which starts from the same word H: auto-reset contract)
@@ -218,21 +219,20 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
             else if constexpr (quad_policy && quad_word_env<Env>::value) {
                 // Tiger, Tag: ONE word per lane-step from the quad's STEP block, time-shared the same way; the auto-reset of a
                 // done lane reads the same word (fresh_w below)
-                if ((s & 3) == 0) {
+                if (sj == 0) {
                     const uint64_t te = t0 + (uint64_t)s + (uint64_t)(glane[0] & 3u);
                     RngKey ke = key0;
                     ke.t_lo = (uint32_t)te; ke.t_hi = (uint32_t)(te >> 32);
                     sq = quad_transpose4(Env::quad_block(ke, glane[0], 0u), glane[0] & 3u);
                     if constexpr (POLICY_WITH_STEP) policy_quarter();
                 }
-                const int sj = s & 3;                                            // wave-uniform selects
                 const uint32_t W = sj == 0 ? sq.x : sj == 1 ? sq.y : sj == 2 ? sq.z : sq.w;
                 Env::step_w(sh, p, st[j], valid[j] ? a_cur[j] : 0, key, glane[j], W, o[j], r[j], d[j]);
             }
             else if constexpr (quad_policy && quad_words_of<Env>::value == 3) {
                 // the step's quad-shared blocks, time-shared: lane e of a quad computes the three blocks of step s + e once per
                 // four steps, three 4 x 4 transposes hand every lane its own word of each block of each step
-                if ((s & 3) == 0) {
+                if (sj == 0) {
                     const uint32_t e = glane[0] & 3u;
                     const uint64_t te = t0 + (uint64_t)s + (uint64_t)e;
                     RngKey ke = key0;
@@ -242,7 +242,6 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
                     nq2 = quad_transpose4(Env::quad_block(ke, glane[0], 2u), e);
                     if constexpr (POLICY_WITH_STEP) policy_quarter();
                 }
-                const int sj = s & 3;                                            // wave-uniform selects
                 auto pick = [&](const uint4 &q) { return sj == 0 ? q.x : sj == 1 ? q.y : sj == 2 ? q.z : q.w; };
                 Env::step_words(sh, p, st[j], valid[j] ? a_cur[j] : 0, key, glane[j], pick(nq0), pick(nq1), pick(nq2), o[j], r[j], d[j]);
             }
@@ -252,8 +251,7 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
             a_next[j] = 0;
         }
         if constexpr (quad_policy) {
-            if constexpr (!TAPE && !POLICY_WITH_STEP) { if ((s & 3) == 0) policy_quarter(); }
-            const int sj = s & 3;                                            // wave-uniform selects
+            if constexpr (!TAPE && !POLICY_WITH_STEP) { if (sj == 0) policy_quarter(); }
             if constexpr (REC) {
                 // step_rec already moved the fresh episode in
             } else if constexpr (Env::QUAD_SENSOR) {                         // RockSample: this lane's RESET word of step s
@@ -287,6 +285,28 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
         }
         out.next_row();
         if constexpr (Fin::LOOP_BARRIER && !quad_policy) __syncthreads();
+    };
+    // The one-lane-per-thread loops with time-shared blocks serve the small shards (2^14 .. 2^18 lanes: one to four waves per
+    // SIMD, a step is one wave's dependent chain).  Unrolled by four, a step's picks are register names instead of three
+    // selects each and the every-fourth-step branch is straight-line code.
+    constexpr bool UNROLL4 = quad_policy && LPT == 1 && !TAPE && STEP_LOOP_UNROLL4;
+    if constexpr (UNROLL4) {
+        #pragma unroll 1
+        for (int seg = 0, s = 0; seg < 4; ++seg)                           // four priority segments (LoopPrio), ending at multiples of four
+        for (const int seg_end = prio.template segment<4>(seg); s < seg_end; s += 4) {
+            step_body(s, std::integral_constant<int, 0>{});
+            if (s + 1 < seg_end) {                                         // (only the launch's last group can be short)
+                step_body(s + 1, std::integral_constant<int, 1>{});
+                if (s + 2 < seg_end) {
+                    step_body(s + 2, std::integral_constant<int, 2>{});
+                    if (s + 3 < seg_end) step_body(s + 3, std::integral_constant<int, 3>{});
+                }
+            }
+        }
+    } else {
+        #pragma unroll 1
+        for (int seg = 0, s = 0; seg < 4; ++seg)                           // four priority segments (LoopPrio)
+        for (const int seg_end = prio.segment(seg); s < seg_end; ++s) step_body(s, s & 3);
     }
     // the state is the loop's carry: it lived in registers and reaches memory once (a lane that never stepped writes back
     // what it read; BattleShip's ship words only if some step of the launch dealt a new board)

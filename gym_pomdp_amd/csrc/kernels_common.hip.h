@@ -446,6 +446,11 @@ constexpr int64_t ROCK_PAIR_MIN_LANES = POMDP_ROCK_PAIR_MIN_LANES, STOCHROCK_PAI
 #else
 constexpr int64_t ROCK_PAIR_MIN_LANES = (3 << 17) + 1, STOCHROCK_PAIR_MIN_LANES = 3 << 17;
 #endif
+#ifdef POMDP_NO_STEP_LOOP_UNROLL4                              // the A arm: the time-shared one-lane-per-thread loops step by step
+constexpr bool STEP_LOOP_UNROLL4 = false;
+#else
+constexpr bool STEP_LOOP_UNROLL4 = true;
+#endif
 #ifdef POMDP_POLICY_AFTER_STEP                                 // the A arm: the policy's block drawn after the lane step (until round 6)
 constexpr bool POLICY_WITH_STEP_BLOCKS = false;
 #else
