@@ -167,7 +167,7 @@ struct RockEnv {
                     // passes through an opaque register move, so this call stays where it is needed.
                     uint32_t lane_ = lane;
                     asm volatile("" : "+v"(lane_));
-                    l = elem(reset_block<AUTO>(key, lane_, 1u), lane & 3u);
+                    l = elem(reset_block<AUTO>(rare_key(key), lane_, 1u), lane & 3u);
                     have_lo = true;
                 }
                 const uint32_t c = rock_code_lo(__builtin_rotateright32(l, rot));

@@ -156,6 +156,40 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
     }
     wait_loads();
     const LoopPrio prio(k_steps);
+    constexpr bool POLICY_WITH_STEP = quad_policy && !TAPE && POLICY_WITH_STEP_BLOCKS &&
+                                      (Env::QUAD_SENSOR || quad_word_env<Env>::value || quad_words_of<Env>::value == 3);
+    // The one-lane-per-thread loops with time-shared blocks serve the small shards (2^14 .. 2^18 lanes: one to four waves per
+    // SIMD, a step is one wave's dependent chain).  Unrolled by four, a step's picks are register names instead of three
+    // selects each and the every-fourth-step branch is straight-line code (UNROLL4).  A lone wave issues an instruction every
+    // five to nine cycles whatever it depends on: what counts there is the NUMBER of instructions per step (the next group's
+    // blocks drawn in instalments beside the step's own chain, the table entry asked for a step ahead: no gain, docs/HISTORY.md).
+    constexpr bool UNROLL4 = quad_policy && LPT == 1 && !TAPE && STEP_LOOP_UNROLL4;
+    constexpr bool UNROLL4_TAIL = REC && L::ID != LAYOUT_RETURNS && STEP_LOOP_UNROLL4_TAIL;
+    constexpr int N_STEP_BLOCKS = quad_words_of<Env>::value == 3 ? 3 : 1;
+    const uint32_t qe = glane[0] & 3u;                       // this lane's place in its quad: it draws the blocks of step s + qe
+    // this lane's block of the policy for the group of four steps starting at s: that of step s + e, transposed within the quad
+    // — component J is then THIS lane's word of step s + J.  Drawn in the same branch as the step's own time-shared blocks
+    // (POLICY_WITH_STEP): the chains are independent, one block after the other costs a lone wave the latency of both.
+    auto policy_quarter = [&](const int s) __attribute__((always_inline)) {
+        const uint64_t te = ta0 + (uint64_t)s + (uint64_t)qe;
+        aq = quad_transpose4(philox4x32_10(glane[0] >> 2, (uint32_t)te, (uint32_t)(te >> 32),
+                                           (uint32_t)POMDP_STREAM_ACTION << 24, akey0.k0, akey0.k1), qe);
+    };
+    // ... and its blocks of the step stream (RockSample: the sensor block, which the fresh episodes of the steps' done lanes
+    // start from as well; Tiger, Tag: the one STEP block; Network: three) — every Env::quad_block is stream STEP of lane >> 2
+    auto step_quarter = [&](const int s) __attribute__((always_inline)) {
+        const uint64_t te = t0 + (uint64_t)s + (uint64_t)qe;
+        RngKey ke = key0;
+        ke.t_lo = (uint32_t)te; ke.t_hi = (uint32_t)(te >> 32);
+        if constexpr (N_STEP_BLOCKS == 3) {
+            nq0 = quad_transpose4(stream_block(ke, glane[0] >> 2, POMDP_STREAM_STEP, 0u), qe);
+            nq1 = quad_transpose4(stream_block(ke, glane[0] >> 2, POMDP_STREAM_STEP, 1u), qe);
+            nq2 = quad_transpose4(stream_block(ke, glane[0] >> 2, POMDP_STREAM_STEP, 2u), qe);
+        } else {
+            sq = quad_transpose4(stream_block(ke, glane[0] >> 2, POMDP_STREAM_STEP, 0u), qe);
+            rq = sq;
+        }
+    };
     // One step.  `sj_`: the step's place in its group of four (s & 3) — the time-shared blocks are drawn at place 0 and every
     // step picks its words by place: a run-time, wave-uniform select in the plain loop, a compile-time constant in the loop
     // unrolled by four (UNROLL4 below).
@@ -173,18 +207,6 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
         bool live[LPT], valid[LPT], fresh[LPT];
         int a_next[LPT];
         typename Env::State before[LPT];
-        // this lane's block of the policy: that of step s + e, transposed within the quad — component J is then THIS lane's word
-        // of step s + J.  Drawn in the same branch as the step's own time-shared blocks (POLICY_WITH_STEP): the chains are
-        // independent and a shard this loop serves has two to four waves per SIMD — one block after the other costs it twice
-        // the latency of both together.
-        auto policy_quarter = [&]() {
-            const uint32_t e = glane[0] & 3u;
-            const uint64_t te = ta0 + (uint64_t)s + (uint64_t)e;
-            aq = quad_transpose4(philox4x32_10(glane[0] >> 2, (uint32_t)te, (uint32_t)(te >> 32),
-                                               (uint32_t)POMDP_STREAM_ACTION << 24, akey0.k0, akey0.k1), e);
-        };
-        constexpr bool POLICY_WITH_STEP = quad_policy && !TAPE && POLICY_WITH_STEP_BLOCKS &&
-                                          (Env::QUAD_SENSOR || quad_word_env<Env>::value || quad_words_of<Env>::value == 3);
 #pragma unroll
         for (int j = 0; j < LPT; ++j) {
             before[j] = st[j];
@@ -194,21 +216,14 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
                 // one lane per thread, the sensor block shared by the quad (RockSample shards below the pooled kernels' gates):
                 // lane e computes the block of step s + e once per four steps and the words reach their lanes by the same
                 // transpose as the policy's — one Philox block per lane per four steps instead of one per step
-                if (sj == 0) {
-                    const uint64_t te = t0 + (uint64_t)s + (uint64_t)(glane[0] & 3u);
-                    RngKey ke = key0;
-                    ke.t_lo = (uint32_t)te; ke.t_hi = (uint32_t)(te >> 32);
-                    sq = quad_transpose4(Env::quad_block(ke, glane[0], 0u), glane[0] & 3u);
-                    rq = sq;                       // ... and the fresh episodes of the steps' done lanes start from the same words
-                    if constexpr (POLICY_WITH_STEP) policy_quarter();
-                }
+                if (sj == 0) { step_quarter(s); if constexpr (POLICY_WITH_STEP) policy_quarter(s); }
                 const uint32_t H = sj == 0 ? sq.x : sj == 1 ? sq.y : sj == 2 ? sq.z : sq.w;
                 if constexpr (REC) {
                     // the step and, where it ends the episode, the fresh one (which starts from the same word H: auto-reset contract)
                     typename Env::S sj = st[j].s;
                     const uint32_t lane_ = glane[j];
                     Env::step_rec(sh, tab, sj, (uint32_t)a_cur[j], H, Env::fresh_state(p, H, key, lane_), recv[j],
-                                  [&]() { return Env::elem(Env::quad_block(key, lane_, 1u), lane_ & 3u); });
+                                  [&]() { return Env::elem(Env::quad_block(rare_key(key), lane_, 1u), lane_ & 3u); });
                     st[j].s = sj;
                     o[j] = (int)__builtin_amdgcn_ubfe(recv[j], 8u, 8u);
                     r[j] = (typename Env::Reward)__builtin_amdgcn_sbfe(recv[j], 16u, 8u);
@@ -219,29 +234,14 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
             else if constexpr (quad_policy && quad_word_env<Env>::value) {
                 // Tiger, Tag: ONE word per lane-step from the quad's STEP block, time-shared the same way; the auto-reset of a
                 // done lane reads the same word (fresh_w below)
-                if (sj == 0) {
-                    const uint64_t te = t0 + (uint64_t)s + (uint64_t)(glane[0] & 3u);
-                    RngKey ke = key0;
-                    ke.t_lo = (uint32_t)te; ke.t_hi = (uint32_t)(te >> 32);
-                    sq = quad_transpose4(Env::quad_block(ke, glane[0], 0u), glane[0] & 3u);
-                    if constexpr (POLICY_WITH_STEP) policy_quarter();
-                }
+                if (sj == 0) { step_quarter(s); if constexpr (POLICY_WITH_STEP) policy_quarter(s); }
                 const uint32_t W = sj == 0 ? sq.x : sj == 1 ? sq.y : sj == 2 ? sq.z : sq.w;
                 Env::step_w(sh, p, st[j], valid[j] ? a_cur[j] : 0, key, glane[j], W, o[j], r[j], d[j]);
             }
             else if constexpr (quad_policy && quad_words_of<Env>::value == 3) {
                 // the step's quad-shared blocks, time-shared: lane e of a quad computes the three blocks of step s + e once per
                 // four steps, three 4 x 4 transposes hand every lane its own word of each block of each step
-                if (sj == 0) {
-                    const uint32_t e = glane[0] & 3u;
-                    const uint64_t te = t0 + (uint64_t)s + (uint64_t)e;
-                    RngKey ke = key0;
-                    ke.t_lo = (uint32_t)te; ke.t_hi = (uint32_t)(te >> 32);
-                    nq0 = quad_transpose4(Env::quad_block(ke, glane[0], 0u), e);
-                    nq1 = quad_transpose4(Env::quad_block(ke, glane[0], 1u), e);
-                    nq2 = quad_transpose4(Env::quad_block(ke, glane[0], 2u), e);
-                    if constexpr (POLICY_WITH_STEP) policy_quarter();
-                }
+                if (sj == 0) { step_quarter(s); if constexpr (POLICY_WITH_STEP) policy_quarter(s); }
                 auto pick = [&](const uint4 &q) { return sj == 0 ? q.x : sj == 1 ? q.y : sj == 2 ? q.z : q.w; };
                 Env::step_words(sh, p, st[j], valid[j] ? a_cur[j] : 0, key, glane[j], pick(nq0), pick(nq1), pick(nq2), o[j], r[j], d[j]);
             }
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
             a_next[j] = 0;
         }
         if constexpr (quad_policy) {
-            if constexpr (!TAPE && !POLICY_WITH_STEP) { if (sj == 0) policy_quarter(); }
+            if constexpr (!TAPE && !POLICY_WITH_STEP) { if (sj == 0) policy_quarter(s); }
             if constexpr (REC) {
                 // step_rec already moved the fresh episode in
             } else if constexpr (Env::QUAD_SENSOR) {                         // RockSample: this lane's RESET word of step s
@@ -286,11 +286,23 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
         out.next_row();
         if constexpr (Fin::LOOP_BARRIER && !quad_policy) __syncthreads();
     };
-    // The one-lane-per-thread loops with time-shared blocks serve the small shards (2^14 .. 2^18 lanes: one to four waves per
-    // SIMD, a step is one wave's dependent chain).  Unrolled by four, a step's picks are register names instead of three
-    // selects each and the every-fourth-step branch is straight-line code.
-    constexpr bool UNROLL4 = quad_policy && LPT == 1 && !TAPE && STEP_LOOP_UNROLL4;
-    if constexpr (UNROLL4) {
+    if constexpr (UNROLL4 && UNROLL4_TAIL) {
+        // whole groups of four, then the launch's last one to three steps in the plain form (a fifth copy of the step: the
+        // table-driven RockSample step affords it, the others lose registers and time to it)
+        #pragma unroll 1
+        for (int seg = 0, s = 0; seg < 4; ++seg) {                         // four priority segments (LoopPrio), ending at multiples of four
+            const int seg_end = prio.template segment<4>(seg);
+            #pragma unroll 1
+            for (; s + 4 <= seg_end; s += 4) {
+                step_body(s, std::integral_constant<int, 0>{});
+                step_body(s + 1, std::integral_constant<int, 1>{});
+                step_body(s + 2, std::integral_constant<int, 2>{});
+                step_body(s + 3, std::integral_constant<int, 3>{});
+            }
+            #pragma unroll 1
+            for (; s < seg_end; ++s) step_body(s, s & 3);
+        }
+    } else if constexpr (UNROLL4) {
         #pragma unroll 1
         for (int seg = 0, s = 0; seg < 4; ++seg)                           // four priority segments (LoopPrio), ending at multiples of four
         for (const int seg_end = prio.template segment<4>(seg); s < seg_end; s += 4) {

@@ -451,6 +451,11 @@ constexpr bool STEP_LOOP_UNROLL4 = false;
 #else
 constexpr bool STEP_LOOP_UNROLL4 = true;
 #endif
+#ifdef POMDP_NO_STEP_LOOP_UNROLL4_TAIL                         // the A arm: every step of a group of four behind its own bound check
+constexpr bool STEP_LOOP_UNROLL4_TAIL = false;
+#else
+constexpr bool STEP_LOOP_UNROLL4_TAIL = true;
+#endif
 #ifdef POMDP_POLICY_AFTER_STEP                                 // the A arm: the policy's block drawn after the lane step (until round 6)
 constexpr bool POLICY_WITH_STEP_BLOCKS = false;
 #else

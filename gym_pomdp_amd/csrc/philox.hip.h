@@ -74,6 +74,17 @@ __device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
     return make_uint4(c0, c1, c2, c3);
 }
 
+// The key as a rare branch sees it: a copy the compiler cannot see through.  A Philox block's first rounds on the wave-uniform
+// counter words are cheap to speculate, and two rare branches of one step that draw the same block (a sensor tie, a reset tie)
+// make them a common subexpression: hoisted in front of both — into EVERY step (RockSample, one lane per thread: two scalar
+// and three vector multiplies per step for draws that happen once in 2^27).
+__device__ __forceinline__ RngKey rare_key(const RngKey &k)
+{
+    RngKey r = k;
+    asm volatile("" : "+s"(r.t_lo), "+s"(r.t_hi));
+    return r;
+}
+
 __device__ __forceinline__ uint4 stream_block(const RngKey &k, uint32_t lane, uint32_t stream, uint32_t block)
 {
     return philox4x32_10(lane, k.t_lo, k.t_hi, (stream << 24) | block, k.k0, k.k1);
