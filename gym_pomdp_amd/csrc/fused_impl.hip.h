@@ -467,7 +467,9 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
 // them where they stand.  (Until round 5 both had per-lane blocks, pooled per wave of 256 lanes through LDS: two ballots, a rank
 // and an LDS round trip per lane for one Philox pass — 70 of the loop's 273 vector instructions per thread-step.)  The outputs
 // leave as 16-byte stores.
-template <bool TAB, class L = Columns, class Pol = SyntheticQuad>   // TAB: the lane step reads the (cells, action) table built when the launch starts (from 16 steps per launch)
+// LPT = 2 (round 6): half a quad per thread for the shards the quad loop leaves two waves per SIMD (2^19 lanes), the quad's STEP
+// block time-shared by its two threads like the policy's (pair_shared; see steps_quad_kernel).
+template <bool TAB, class L = Columns, class Pol = SyntheticQuad, int LPT = 4>   // TAB: the lane step reads the (cells, action) table built when the launch starts (from 16 steps per launch)
 __global__ __launch_bounds__(BLOCK) void tag_steps_quad_kernel(uint32_t *__restrict__ state, int32_t *__restrict__ action,
                                                                int32_t *__restrict__ ob, float *__restrict__ reward,
                                                                uint8_t *__restrict__ done, int64_t n, RngKey key0,
@@ -475,18 +477,28 @@ __global__ __launch_bounds__(BLOCK) void tag_steps_quad_kernel(uint32_t *__restr
                                                                int gen_first, const TagEnv::Params p, TapeRef tape)
 {
     using Env = TagEnv;
+    static_assert(LPT == 4 || LPT == 2, "a quad or half a quad per thread");
     __shared__ Env::Shared sh;
     __shared__ typename std::conditional<TAB, Env::StepTab, NoTab>::type tab;
     const uint32_t n_act = (uint32_t)Env::n_actions(p);
-    FusedCtx<L, Pol> cx(action, ob, reward, done, rec, lane0, key0, akey0, n_act, k_steps, tape);
+    FusedCtx<L, Pol, LPT> cx(action, ob, reward, done, rec, lane0, key0, akey0, n_act, k_steps, tape);
     const uint32_t l0 = cx.l0, glane0 = cx.glane0;
-    Env::State st[4];
-    int a_cur[4];
+    const uint32_t e0 = LPT == 4 ? 0u : (glane0 & 2u);       // the first lane's element of its quad's blocks
+    Env::State st[LPT];
+    int a_cur[LPT];
+    uint32_t sp0 = 0, sp1 = 0;                               // LPT = 2: the odd step's words of the time-shared STEP block
     {
-        const u32x4 s4 = ld_stream4(state + l0);
-        cx.first(gen_first, a_cur);
+        if constexpr (LPT == 4) {
+            const u32x4 s4 = ld_stream4(state + l0);
+            cx.first(gen_first, a_cur);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) st[j].w = s4[j];
+            for (int j = 0; j < 4; ++j) st[j].w = s4[j];
+        } else {
+            const u32x2 s2 = ld_stream2(state + l0);
+            cx.first(gen_first, a_cur);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) st[j].w = s2[j];
+        }
     }
     Env::stage(sh, p, (int)threadIdx.x);
     __syncthreads();
@@ -497,15 +509,21 @@ __global__ __launch_bounds__(BLOCK) void tag_steps_quad_kernel(uint32_t *__restr
     const LoopPrio prio(k_steps);
     POMDP_FUSED_STEP_LOOP(prio, s) {
         const RngKey key = cx.key(key0, s);
-        uint32_t a_next[4];
+        uint32_t a_next[LPT];
         cx.pol.begin(s, a_next);
-        int o[4], d[4];
-        float r[4];
-        const uint32_t a_taken[4] = {(uint32_t)a_cur[0], (uint32_t)a_cur[1], (uint32_t)a_cur[2], (uint32_t)a_cur[3]};
-        const uint4 qw = Env::quad_block(key, glane0, 0u);
-        const uint32_t W[4] = {qw.x, qw.y, qw.z, qw.w};
+        int o[LPT], d[LPT];
+        float r[LPT];
+        uint32_t a_taken[LPT], W[LPT];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < LPT; ++j) a_taken[j] = (uint32_t)a_cur[j];
+        if constexpr (LPT == 4) {
+            const uint4 qw = Env::quad_block(key, glane0, 0u);
+            W[0] = qw.x; W[1] = qw.y; W[2] = qw.z; W[3] = qw.w;
+        } else {
+            pair_shared(s, e0 != 0u, [&](int sb) { return Env::quad_block(cx.key(key0, sb), glane0, 0u); }, W, sp0, sp1);
+        }
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) {
             Env::Flight f;
             const bool valid = !Pol::TAPE || a_taken[j] < n_act;      // a tape's out-of-range action: the lane is left untouched and counted
             const Env::State before = st[j];
@@ -514,23 +532,23 @@ __global__ __launch_bounds__(BLOCK) void tag_steps_quad_kernel(uint32_t *__restr
             else Env::step_one_opponent_pre(sh, p, st[j], a, o[j], r[j], d[j], f);
             const uint32_t lane = glane0 + (uint32_t)j;
             if constexpr (Pol::TAPE) { if (!valid) { f.need = false; o[j] = 0; r[j] = 0.f; d[j] = 0; cx.n_bad++; } }
-            Env::flee_word(sh, p, st[j], f, W[j], [&]() { return Env::elem(Env::quad_block(key, lane, 1u), (uint32_t)j); });
+            Env::flee_word(sh, p, st[j], f, W[j], [&]() { return Env::elem(Env::quad_block(key, lane, 1u), e0 + (uint32_t)j); });
             if (d[j]) Env::auto_reset_word(p, st[j], W[j], key, lane);
             if constexpr (Pol::TAPE) st[j] = valid ? st[j] : before;
         }
-        const uint32_t o4[4] = {(uint32_t)o[0], (uint32_t)o[1], (uint32_t)o[2], (uint32_t)o[3]};
-        const uint32_t r4[4] = {__float_as_uint(r[0]), __float_as_uint(r[1]), __float_as_uint(r[2]), __float_as_uint(r[3])};
-        const uint32_t d4[4] = {(uint32_t)d[0], (uint32_t)d[1], (uint32_t)d[2], (uint32_t)d[3]};
-        uint32_t rc[4] = {0, 0, 0, 0};
-        if constexpr (L::CODES) {
+        uint32_t o4[LPT], r4[LPT], d4[LPT], rc[LPT];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) rc[j] = Env::reward_code(r[j]);
+        for (int j = 0; j < LPT; ++j) {
+            o4[j] = (uint32_t)o[j]; r4[j] = __float_as_uint(r[j]); d4[j] = (uint32_t)d[j];
+            rc[j] = 0;
+            if constexpr (L::CODES) rc[j] = Env::reward_code(r[j]);
         }
         cx.out.put(a_taken, a_next, o4, r4, rc, d4);
         cx.advance(s, a_next, a_cur);
     }
     cx.finish(k_steps);
-    st_stream4(state + l0, st[0].w, st[1].w, st[2].w, st[3].w);
+    if constexpr (LPT == 4) st_stream4(state + l0, st[0].w, st[1].w, st[2].w, st[3].w);
+    else st_stream2(state + l0, st[0].w, st[1].w);
 }
 
 // Network with a quad per thread.  The reference draws one double per UP machine and one for the action (network.py:94-109);
@@ -1133,8 +1151,24 @@ static int launch_steps_fused_l(const typename Env::Params &p, uint32_t *state, 
     if (taped) quad_ok = quad_ok && (reinterpret_cast<uintptr_t>(tape.base) & 3u) == 0 && tape.stride % 4 == 0;   // a quad's row = one dword
     const dim3 qgrid((unsigned)(n / (4 * BLOCK)));
     bool launched = false;
+    // half a quad per thread (4-byte and returns sinks): KERNEL<..., L, Pol, 2> over n / 2 threads
+#define POMDP_LAUNCH_PAIR(...)                                                                                           \
+    do {                                                                                                                 \
+        const dim3 pgrid((unsigned)(n / (2 * BLOCK)));                                                                   \
+        if (taped) hipLaunchKernelGGL((__VA_ARGS__, TapeQuad, 2>), pgrid, dim3(BLOCK), 0, (hipStream_t)stream, POMDP_QUAD_ARGS); \
+        else hipLaunchKernelGGL((__VA_ARGS__, SyntheticQuad, 2>), pgrid, dim3(BLOCK), 0, (hipStream_t)stream, POMDP_QUAD_ARGS); \
+    } while (0)
     if constexpr (std::is_same<Env, TagEnv>::value) {
-        if (quad_ok && n >= QUAD_MIN_TAG && p.num_opponents == 1) {
+        if constexpr (pair_sink<L>::value) {
+            if (quad_ok && n >= TAG_PAIR_MIN_LANES && n <= TAG_PAIR_MAX_LANES && p.num_opponents == 1 && k >= 16 && TagEnv::tab_ok(p)) {
+                char pname[40];
+                snprintf(pname, sizeof pname, "%s, 2", lname);
+                note_fused("tag_steps_quad_kernel", "true", pname);
+                POMDP_LAUNCH_PAIR(tag_steps_quad_kernel<true, L);
+                launched = true;
+            }
+        }
+        if (!launched && quad_ok && n >= QUAD_MIN_TAG && p.num_opponents == 1) {
             if (k >= 16 && TagEnv::tab_ok(p)) {
                 note_fused("tag_steps_quad_kernel", "true", lname);
                 POMDP_LAUNCH_QUAD(tag_steps_quad_kernel<true, L);

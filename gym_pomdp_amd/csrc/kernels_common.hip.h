@@ -300,13 +300,13 @@ static __device__ __forceinline__ uint4 quad_transpose4(const uint4 &v, uint32_t
 {
     const bool b0 = e & 1u, b1 = e & 2u;
     const uint32_t s0 = b0 ? v.x : v.y, s1 = b0 ? v.z : v.w;
-    const uint32_t r0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s0, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
-    const uint32_t r1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s1, 0xB1, 0xF, 0xF, false);
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_update_dpp((int)s0, (int)s0, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+    const uint32_t r1 = (uint32_t)__builtin_amdgcn_update_dpp((int)s1, (int)s1, 0xB1, 0xF, 0xF, false);
     // column (e & 1) / 2 + (e & 1) of the rows (e & ~1, e | 1)
     const uint32_t p0 = b0 ? r0 : v.x, p1 = b0 ? v.y : r0, q0 = b0 ? r1 : v.z, q1 = b0 ? v.w : r1;
     const uint32_t u0 = b1 ? p0 : q0, u1 = b1 ? p1 : q1;
-    const uint32_t w0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)u0, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
-    const uint32_t w1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)u1, 0x4E, 0xF, 0xF, false);
+    const uint32_t w0 = (uint32_t)__builtin_amdgcn_update_dpp((int)u0, (int)u0, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    const uint32_t w1 = (uint32_t)__builtin_amdgcn_update_dpp((int)u1, (int)u1, 0x4E, 0xF, 0xF, false);
     return make_uint4(b1 ? w0 : p0, b1 ? w1 : p1, b1 ? q0 : w0, b1 ? q1 : w1);
 }
 // Every load issued so far has landed.  Placed in front of a storing loop: gfx9 counts loads and stores on one counter, and
@@ -460,6 +460,20 @@ constexpr bool STEP_LOOP_UNROLL4_TAIL = true;
 constexpr bool POLICY_WITH_STEP_BLOCKS = false;
 #else
 constexpr bool POLICY_WITH_STEP_BLOCKS = true;
+#endif
+// Tag (one opponent, table-driven) the same way (tag_steps_quad_kernel<.., 2>), every pair sink: ahead of the one-lane-per-thread
+// loop from 3 * 2^17 lanes (0.91 -> 0.80 us per step of records; 7 * 2^16: 1.21 -> 0.92; 2^19, against the quad loop: 1.08 ->
+// 0.92; returns 1.18 -> 1.03), level with the quad loop at 3 * 2^18 (profiles/r06_tag_pair_ab.txt).  Tiger's loop in this form
+// is level with its quad loop at 2^19 (0.63) and behind below: not built.
+#ifdef POMDP_TAG_PAIR_MAX_LANES
+constexpr int64_t TAG_PAIR_MAX_LANES = POMDP_TAG_PAIR_MAX_LANES;
+#else
+constexpr int64_t TAG_PAIR_MAX_LANES = (3 << 18) - 1;
+#endif
+#ifdef POMDP_TAG_PAIR_MIN_LANES
+constexpr int64_t TAG_PAIR_MIN_LANES = POMDP_TAG_PAIR_MIN_LANES;
+#else
+constexpr int64_t TAG_PAIR_MIN_LANES = 3 << 17;
 #endif
 #ifdef POMDP_BS_VIS_LDS_MAX_LANES                             // the visited mask in LDS up to this many lanes (48 B of LDS per lane)
 constexpr int64_t BS_VIS_LDS_MAX_LANES = POMDP_BS_VIS_LDS_MAX_LANES;

@@ -145,7 +145,7 @@ struct TapeQuad {
 // Philox block per thread per two steps, as many per lane-step as in the quad-per-thread loops.
 static __device__ __forceinline__ uint32_t pair_swap(uint32_t v)      // v of the neighbouring thread (lanes 2 i <-> 2 i + 1 of the wave)
 {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
 }
 // the two words of a quad-shared block stream that belong to this thread's two lanes, at step s: at every even s thread `hi`
 // (lanes 2, 3 of the quad) computes the block of step s + 1, its neighbour the block of step s, and they swap the halves

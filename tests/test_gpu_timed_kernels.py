@@ -92,7 +92,9 @@ TAPES = [("rock", {}, 1 << 20, 80), ("rock", dict(board_size=15, num_rocks=15), 
          ("rock", {}, 1 << 17, 66), ("rock", {}, 4099, 70), ("tag", dict(num_opponents=2), 1 << 18, 40), ("tiger", {}, 3, 70),
          ("network", dict(n_machines=16, problem_type=1), 777, 40), ("battleship", {}, 259, 70),
          # RockSample's half-quad-per-thread loop (7 * 2^16 .. 3 * 2^18 lanes)
-         ("rock", {}, 1 << 19, 80), ("rock", dict(board_size=15, num_rocks=15), 5 << 17, 40)]
+         ("rock", {}, 1 << 19, 80), ("rock", dict(board_size=15, num_rocks=15), 5 << 17, 40),
+         # ... and Tag's (3 * 2^17 .. 3 * 2^18 - 1 lanes)
+         ("tag", {}, 1 << 19, 80), ("tag", {}, 3 << 17, 40)]
 
 
 def _tape(rng, n_actions, steps, n, bad_every):
@@ -139,7 +141,8 @@ def test_tape_driven_rows_equal_the_oracle(oracle_lib, fuse64, env, kw, n, steps
     name = _native.lib().pomdp_last_fused_kernel().decode()
     assert name.endswith(", Tape>") or ", Tape" in name, name
     # the quad-per-thread loops' gates (kernels_common.hip.h); RockSample's records ride the half-quad form from above 3 * 2^17 lanes
-    quad_from = {"battleship": 1 << 16, "rock": (3 << 17) + 1 if layout == "packed" else 3 << 18}.get(env, 1 << 19)
+    quad_from = {"battleship": 1 << 16, "rock": (3 << 17) + 1 if layout == "packed" else 3 << 18,
+                 "tag": 3 << 17 if layout == "packed" and kw.get("num_opponents", 1) == 1 else 1 << 19}.get(env, 1 << 19)
     if n >= quad_from:
         assert name.startswith(want_kernel + "<"), name                    # the quad-per-thread loop took it
     elif n < 1 << 16 or n % 1024:
@@ -619,7 +622,9 @@ LAYOUT_FULL = [("rock", {}, 1 << 20, 70), ("rock", {}, 1 << 20, 20), ("rock", di
                # RockSample's half-quad-per-thread loop (above 3 * 2^17, below 3 * 2^18 lanes; 2^19 is above) and StochasticRock's
                # (3 * 2^17 .. 2^19 - 1)
                ("rock", {}, 7 << 16, 40), ("rock", dict(board_size=15, num_rocks=15), 5 << 17, 40), ("rock", {}, (3 << 18) - 1024, 20),
-               ("stochrock", dict(board_size=11, num_rocks=11), 3 << 17, 30), ("stochrock", {}, (1 << 19) - 1024, 40)]
+               ("stochrock", dict(board_size=11, num_rocks=11), 3 << 17, 30), ("stochrock", {}, (1 << 19) - 1024, 40),
+               # Tag's (3 * 2^17 .. 3 * 2^18 - 1 lanes)
+               ("tag", {}, 1 << 19, 66), ("tag", dict(move_prob=0.4), 5 << 17, 40), ("tag", {}, 3 << 17, 40), ("tag", {}, (3 << 18) - 1024, 20)]
 
 
 LAYOUTS = ("blocked", "packed", "narrow")
@@ -691,6 +696,9 @@ def test_layout_kernels_are_the_quad_loops_with_another_sink():
             ("rock", {}, 1 << 19, 64, "packed", "steps_quad_kernel<RockEnv<1>, Packed, 2>"), ("rock", {}, 3 << 17, 64, "narrow", "steps_kernel<RockEnv<1>, 1, true, true, Narrow>"),
             ("rock", {}, (3 << 17) + 1024, 64, "narrow", "steps_quad_kernel<RockEnv<1>, Narrow, 2>"), ("rock", {}, 3 << 18, 64, "packed", "steps_quad_kernel<RockEnv<1>, Packed>"),
             ("rock", dict(board_size=15, num_rocks=15), 5 << 17, 64, "narrow", "steps_quad_kernel<RockEnv<2>, Narrow, 2>"), ("rock", {}, 1 << 19, 8, "packed", "steps_kernel<RockEnv<1>, 2, true, false, Packed>"),
+            ("tag", {}, 1 << 19, 64, "packed", "tag_steps_quad_kernel<true, Packed, 2>"), ("tag", {}, 1 << 19, 8, "packed", "tag_steps_quad_kernel<false, Packed>"),
+            ("tag", {}, 3 << 18, 64, "narrow", "tag_steps_quad_kernel<true, Narrow>"), ("tag", {}, 3 << 17, 64, "narrow", "tag_steps_quad_kernel<true, Narrow, 2>"),
+            ("tag", {}, 1 << 19, 64, "blocked", "tag_steps_quad_kernel<true, Blocked>"),
             ("stochrock", {}, 1 << 19, 64, "packed", "steps_quad_kernel<StochasticRockEnv<1>, Packed>"), ("stochrock", {}, 3 << 17, 64, "packed", "steps_quad_kernel<StochasticRockEnv<1>, Packed, 2>"),
             ("tiger", {}, 1000, 64, "packed", "steps_kernel<TigerEnv, 1, false, false, Packed>")]
     for env, kw, n, k, layout, name in want:
@@ -756,7 +764,8 @@ RETURNS_FULL = [("rock", {}, 1 << 20, (70, 20)), ("rock", dict(board_size=15, nu
                 ("tiger", {}, 1 << 17, (66, 4)), ("network", {}, 1 << 18, (66, 4)), ("battleship", {}, 1 << 17, (66, 4)),
                 ("rock", {}, 4099, (70, 9)), ("tag", {}, (1 << 18) + 5, (20, 9)), ("network", {}, 777, (70, 9)), ("tiger", {}, 3, (70, 9)),
                 ("battleship", {}, 259, (70, 9)), ("rock", dict(board_size=15, num_rocks=15), (1 << 19) + 4, (30, 9)),
-                ("rock", dict(board_size=15, num_rocks=15), 5 << 17, (40, 9)), ("stochrock", {}, 7 << 16, (30, 9))]   # between the gates
+                ("rock", dict(board_size=15, num_rocks=15), 5 << 17, (40, 9)), ("stochrock", {}, 7 << 16, (30, 9)),   # between the gates
+                ("tag", {}, 1 << 19, (66, 4)), ("tag", {}, 3 << 17, (40, 9))]
 
 
 @pytest.mark.parametrize("env,kw,n,ks", RETURNS_FULL, ids=["%s%s-%d" % (c[0], "-".join(str(v) for v in c[1].values()), c[2]) for c in RETURNS_FULL])
