@@ -588,11 +588,13 @@ def quick_step_config(args, gpa, _native, cp, dev, env_key, n, lane_offset, seed
                          "counters_stale": None if rf["valu"] is None else rf["valu"]["counters_stale"]}}
 
 
-def quick_tape_config(args, gpa, _native, cp, dev, env_key, n, seed, layout, k=512):
+def quick_tape_config(args, gpa, _native, cp, dev, env_key, n, seed, layout, k=1024):
     """The fused launches on the CALLER's actions (pomdp_collect_tape*: rock.py:562-566, `env.step(action)` with whatever the
     caller chose): the headline's protocol on a tape of uniform random bytes in [0, n_actions) that torch generated — 256
     rows, replayed for every 256-step launch of the K-step regions — in the packed sink or the returns-only sink.  What the
-    tape costs against the synthetic policy: one 4-byte load per quad-step instead of one Philox block."""
+    tape costs against the synthetic policy: one 4-byte load per quad-step instead of one Philox block — `vs_synthetic` is
+    the ratio of the two kernels' times under THIS protocol (same env, same sink, same regions of four 256-step launches: a
+    region starts on an idle GPU, so the first call's host time is inside it — 3 % of a 1024-step region, 7 % of a 512-step one)."""
     env_id, kwargs, label, bytes_per_step, _ = WORKLOADS[env_key]
     e = gpa.make(env_id, batch_size=n, device=dev, seed=seed, reuse_buffers=True, **kwargs)
     e.reset()
@@ -610,10 +612,22 @@ def quick_tape_config(args, gpa, _native, cp, dev, env_key, n, seed, layout, k=5
                 e.collect_tape(tape[:c], out=sink, layout=layout)
             left -= c
 
+    def run_synthetic(steps):
+        left = steps
+        while left > 0:
+            c = min(left, rows)
+            if layout == "returns":
+                e.collect_returns(c, stats=sink)
+            else:
+                e.collect_synthetic(c, out=sink)
+            left -= c
+
     run(args.warmup)
     run(k)
     walls, evs = timed_regions(run, k, 9, dev, cp)
     kernel = _native.lib().pomdp_last_fused_kernel().decode()
+    run_synthetic(k)
+    _, evs_syn = timed_regions(run_synthetic, k, 9, dev, cp)
     spl = min(fuse_max(env_key, layout), rows, k)
     kern_ms = median(evs) / k
     alg = fused_alg_bytes(bytes_per_step, spl, layout) + 1.0          # + the tape's byte
@@ -625,6 +639,7 @@ def quick_tape_config(args, gpa, _native, cp, dev, env_key, n, seed, layout, k=5
                         % (label, n, "returns-only sink" if layout == "returns" else layout + " layout", k),
             "value": n * k / median(walls), "unit": "env-steps/s", "ms_per_step": median(walls) / k * 1e3, "kernel": kernel,
             "kernel_ms": kern_ms, "steps_per_launch": spl, "bytes_per_lane_step": alg, "invalid_actions": bad,
+            "synthetic_kernel_ms": median(evs_syn) / k, "vs_synthetic": median(evs) / median(evs_syn),
             "roofline": {"bound": "hbm", "frac": hbm, "hbm_frac": hbm, "valu_frac": None, "counters_stale": None,
                          "note": "no PMC record for the tape kernels: compare kernel_ms with the same sink under the synthetic policy"}}
 

@@ -357,7 +357,10 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
     // lane-step with one state word)
     __shared__ typename Env::RecTab tab;
     const uint32_t n_act = (uint32_t)Env::n_actions(p);
-    FusedCtx<L, Pol, LPT> cx(action, ob, reward, done, rec, lane0, key0, akey0, n_act, k_steps, tape);
+    // a quad per thread on a tape: the loop unrolled by two, the tape read two steps ahead (TapeQuadAhead)
+    constexpr bool AHEAD2 = Pol::TAPE && LPT == 4 && TAPE_TWO_STEPS_AHEAD;
+    using PolT = typename std::conditional<AHEAD2, TapeQuadAhead, Pol>::type;
+    FusedCtx<L, PolT, LPT> cx(action, ob, reward, done, rec, lane0, key0, akey0, n_act, k_steps, tape);
     const uint32_t l0 = cx.l0, glane0 = cx.glane0;           // the thread's first lane within the shard; its global id (a multiple of LPT)
     const uint32_t e0 = LPT == 4 ? 0u : (glane0 & 2u);       // ... and that lane's element of its quad's blocks (LPT = 2: 0 or 2)
     typename Env::State st[LPT];
@@ -389,7 +392,8 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
     const int K = p.num_rocks;
     const uint32_t start = (uint32_t)p.start_x | ((uint32_t)p.start_y << 4);
     const LoopPrio prio(k_steps);
-    POMDP_FUSED_STEP_LOOP(prio, s) {
+    auto step_body = [&](const int s, const auto par_) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(par_)::value;           // AHEAD2: s & 1
         const RngKey key = cx.key(key0, s);
         // the quad's sensor words of this step (StochasticRock: block 2 of the stream — block 0 gates the actions, rock.py:443)
         // — the words its fresh episodes start from as well — and the actions of the next call counter
@@ -402,7 +406,8 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
             pair_shared(s, e0 != 0u, [&](int sb) { return Env::quad_block(cx.key(key0, sb), glane0, SENSOR_BLOCK); }, H, sp0, sp1);
         }
         uint32_t a_next[LPT];
-        cx.pol.begin(s, a_next);
+        if constexpr (AHEAD2) cx.pol.template begin_par<PAR>(s, a_next);
+        else cx.pol.begin(s, a_next);
         // (a lane's step draws EITHER its sensor reading OR its next episode: the fresh episodes start from the same words, R = H)
         bool acts[LPT];
 #pragma unroll
@@ -447,7 +452,21 @@ __global__ __launch_bounds__(BLOCK) void steps_quad_kernel(uint32_t *__restrict_
             st[j].s = sj;
         }
         cx.out.put_records(rec, a_next);
-        cx.advance(s, a_next, a_cur);
+        if constexpr (AHEAD2) {
+            cx.pol.template end_par<PAR>(s, a_next);
+#pragma unroll
+            for (int j = 0; j < LPT; ++j) a_cur[j] = (int)a_next[j];
+        } else cx.advance(s, a_next, a_cur);
+    };
+    if constexpr (AHEAD2) {
+        wait_loads();
+        _Pragma("unroll 1") for (int seg = 0, s = 0; seg < 4; ++seg)           // (LoopPrio's segments, ending at even steps)
+            for (const int seg_end = prio.template segment<2>(seg); s < seg_end; s += 2) {
+                step_body(s, std::integral_constant<int, 0>{});
+                if (s + 1 < seg_end) step_body(s + 1, std::integral_constant<int, 1>{});
+            }
+    } else {
+        POMDP_FUSED_STEP_LOOP(prio, s) step_body(s, std::integral_constant<int, 0>{});
     }
     // the state is the loop's carry: it reaches memory once
     cx.finish(k_steps);

@@ -456,6 +456,11 @@ constexpr bool STEP_LOOP_UNROLL4_TAIL = false;
 #else
 constexpr bool STEP_LOOP_UNROLL4_TAIL = true;
 #endif
+#ifdef POMDP_NO_TAPE_TWO_STEPS_AHEAD                           // the A arm: the tape's row of step s + 1 asked for at the top of step s
+constexpr bool TAPE_TWO_STEPS_AHEAD = false;
+#else
+constexpr bool TAPE_TWO_STEPS_AHEAD = true;
+#endif
 #ifdef POMDP_POLICY_AFTER_STEP                                 // the A arm: the policy's block drawn after the lane step (until round 6)
 constexpr bool POLICY_WITH_STEP_BLOCKS = false;
 #else

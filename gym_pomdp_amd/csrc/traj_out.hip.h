@@ -139,6 +139,33 @@ struct TapeQuad {
     __device__ __forceinline__ void count_bad(uint32_t n_bad) const { if (n_bad && err) atomicAdd(err, n_bad); }
 };
 
+// The same tape read TWO steps ahead, for a loop unrolled by two (steps_quad_kernel): row r lives in register r & 1; the top
+// of step s asks for row s + 2 into the register row s left (its actions were taken over when step s - 1 ended), the end of
+// step s reads row s + 1 — asked for at the top of step s - 1, two steps' arithmetic and one step's stores ago.  The register
+// names are compile-time (PAR = s & 1): a pending load is never moved, selected or indexed, only waited for where it is read,
+// and the wait counts the younger loads and stores exactly (tests/test_host_logic.py checks the compiled loop).
+struct TapeQuadAhead {
+    static constexpr bool TAPE = true;
+    TapeColumn<uint32_t> col;
+    uint32_t *err;
+    uint32_t even, odd;      // rows 2 i, 2 i + 1 of the tape as they come round
+    __device__ __forceinline__ TapeQuadAhead(const TapeRef &t, uint32_t l0, uint32_t, const RngKey &, const RngKey &, uint32_t, int k_steps)
+        : col(t, l0, k_steps), err(t.err), even(0), odd(col.row(1)) {}
+    __device__ __forceinline__ u32x4 first() const
+    {
+        uint32_t a[4];
+        TapeQuad::unpack(col.first, a);
+        return u32x4{a[0], a[1], a[2], a[3]};
+    }
+    template <int PAR> __device__ __forceinline__ void begin_par(int s, uint32_t (&a)[4])
+    {
+        if constexpr (PAR == 0) even = col.row(s + 2); else odd = col.row(s + 2);
+        a[0] = a[1] = a[2] = a[3] = 0;
+    }
+    template <int PAR> __device__ __forceinline__ void end_par(int, uint32_t (&a)[4]) const { TapeQuad::unpack(PAR == 0 ? odd : even, a); }
+    __device__ __forceinline__ void count_bad(uint32_t n_bad) const { if (n_bad && err) atomicAdd(err, n_bad); }
+};
+
 // ---- two lanes per thread: half a quad (BattleShip's small shards, fused_impl.hip.h) ----------------------------------------
 // The policy's block belongs to a quad, i.e. to a PAIR of neighbouring threads: thread e (0 / 1: lanes 0-1 / 2-3 of the quad)
 // computes the block of step s + e at every even s, and the pair swaps the halves the partner needs (two DPP moves) — one

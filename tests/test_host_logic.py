@@ -215,7 +215,10 @@ def test_fused_step_loops_never_wait_for_their_own_stores():
                 # the tape-driven loops (pomdp_collect_tape*) read one row per step: requested at the top of the step, first touched
                 # at its end — ONE wait per iteration, a whole step after the previous step's stores were issued (traj_out.hip.h)
                 taped += 1
-                assert len(waits) == 1, (name, waits)
+                # (the quad loop reads its tape two steps ahead in a loop unrolled by two — TapeQuadAhead: one wait per step, two
+                # per iteration)
+                two_ahead = "TapeQuad, 4>(" in name
+                assert len(waits) == (2 if two_ahead else 1), (name, waits)
                 continue
             seen += 1
             assert waits == [], (name, waits)

@@ -3,7 +3,7 @@
 library variant given: python tools/gpu_small_shards.py [libA.so libB.so ...]   (default: the product library).
 Variants come from tools/ab_build.sh (e.g. -DPOMDP_QUAD_MIN_LANES=4096: the quad-per-thread loops from 4096 lanes up).
 Prints us per step of collect_synthetic($SHARD_K or 256, layout=$SHARD_LAYOUT or "packed"; "returns": collect_returns) by HIP
-events, and the kernel the launcher picked."""
+events, and the kernel the launcher picked.  SHARD_TAPE=1: the same launches on a tape of the caller's actions (collect_tape)."""
 import os
 import subprocess
 import sys
@@ -37,12 +37,15 @@ def one(lib_path):
             e.reset()
             K = int(os.environ.get("SHARD_K", "256"))
             layout = os.environ.get("SHARD_LAYOUT", "packed")
+            tape = None
+            if os.environ.get("SHARD_TAPE"):           # the caller's actions (pomdp_collect_tape*): K rows of uniform random bytes
+                tape = torch.randint(0, e.action_space.n, (K, n), dtype=torch.uint8, device="cuda")
             if layout == "returns":                    # no trajectory: the episode-return reduction (pomdp_collect_returns)
                 tr = e.collect_returns(K)
-                run = lambda: e.collect_returns(K, stats=tr)
+                run = (lambda: e.collect_tape(tape, stats=tr)) if tape is not None else (lambda: e.collect_returns(K, stats=tr))
             else:
                 tr = e.collect_synthetic(K, layout=layout)
-                run = lambda: e.collect_synthetic(K, out=tr)
+                run = (lambda: e.collect_tape(tape, out=tr, layout=layout)) if tape is not None else (lambda: e.collect_synthetic(K, out=tr))
             for _ in range(8):
                 run()
             torch.cuda.synchronize()
