@@ -83,7 +83,10 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
                                                       RngKey key0, uint32_t lane0, int flags, RngKey akey0, int k_steps,
                                                       int64_t rec, const typename Env::Params p, TapeRef tape)
 {
-    static_assert(!TAPE || (LPT == 1 && !SIMPLE && !TAB), "a tape drives the general one-lane-per-thread instantiation");
+    // a tape drives the one-lane-per-thread instantiations: the general one, and (round 6) the SIMPLE ones of the envs whose blocks
+    // are time-shared — full workgroups, auto-reset, but the actions are the caller's and may be out of range (counted, the lane
+    // untouched), so `valid` / `live` stay run-time there
+    static_assert(!TAPE || LPT == 1, "a tape drives the one-lane-per-thread instantiations");
     __shared__ typename Env::Shared sh;
     // TAB: the lane step reads the (position, action) table built below (RockEnv::step_rec: the lane's packed record and its
     // new state, fresh episode included, in one go); one lane per thread, the quad's blocks time-shared
@@ -163,8 +166,15 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
     // selects each and the every-fourth-step branch is straight-line code (UNROLL4).  A lone wave issues an instruction every
     // five to nine cycles whatever it depends on: what counts there is the NUMBER of instructions per step (the next group's
     // blocks drawn in instalments beside the step's own chain, the table entry asked for a step ahead: no gain, docs/HISTORY.md).
-    constexpr bool UNROLL4 = quad_policy && LPT == 1 && !TAPE && STEP_LOOP_UNROLL4;
-    constexpr bool UNROLL4_TAIL = REC && L::ID != LAYOUT_RETURNS && STEP_LOOP_UNROLL4_TAIL;
+    constexpr bool UNROLL4 = quad_policy && LPT == 1 && (!TAPE || SIMPLE) && STEP_LOOP_UNROLL4;
+    constexpr bool UNROLL4_TAIL = REC && L::ID != LAYOUT_RETURNS && !TAPE && STEP_LOOP_UNROLL4_TAIL;
+    // A tape in the unrolled loop is read FOUR rows ahead: row r lives in slot r & 3 (compile-time names: a pending load is never
+    // moved or selected); the top of step s asks for row s + 4 into the slot row s left when step s - 1 ended, the end of step s
+    // reads row s + 1 — asked for three steps ago, which at a small shard's 0.3 us per step is about the latency of the load.
+    // (One row ahead, as in the general loop, every step of a 2^17-lane shard waited for its load: 0.98 against 0.31 us.)
+    constexpr bool TAPE4 = TAPE && UNROLL4;
+    uint32_t tq[4] = {0, 0, 0, 0};
+    if constexpr (TAPE4) { tq[1] = col.row(1); tq[2] = col.row(2); tq[3] = col.row(3); }
     constexpr int N_STEP_BLOCKS = quad_words_of<Env>::value == 3 ? 3 : 1;
     const uint32_t qe = glane[0] & 3u;                       // this lane's place in its quad: it draws the blocks of step s + qe
     // this lane's block of the policy for the group of four steps starting at s: that of step s + e, transposed within the quad
@@ -195,7 +205,17 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
     // unrolled by four (UNROLL4 below).
     auto step_body = [&](const int s, const auto sj_) __attribute__((always_inline)) {
         const int sj = sj_;
-        if constexpr (TAPE) col.request(s);                  // the row of step s + 1: first touched after this step's stores
+        // this step's word of a time-shared block.  In the plain loop (sj a run-time value) the words pass through an opaque
+        // register definition first: as plain reads of the captured uint4 the compiler folds the selects into ONE read at a
+        // run-time index — of an array it then keeps in scratch memory, with a `s_waitcnt vmcnt(0)` after the read, in every step
+        // (the general tape loop after the step became a lambda: 32 B of scratch, 0.98 us per step at 2^17 lanes).
+        auto pick4 = [&](const uint4 &q) __attribute__((always_inline)) -> uint32_t {
+            uint32_t x = q.x, y = q.y, z = q.z, w = q.w;
+            if constexpr (std::is_same<std::decay_t<decltype(sj_)>, int>::value) asm volatile("" : "+v"(x), "+v"(y), "+v"(z), "+v"(w));
+            return sj == 0 ? x : sj == 1 ? y : sj == 2 ? z : w;
+        };
+        if constexpr (TAPE4) tq[std::decay_t<decltype(sj_)>::value] = col.row(s + 4);
+        else if constexpr (TAPE) col.request(s);             // the row of step s + 1: first touched after this step's stores
         RngKey key = key0, akey = akey0;
         key.t_lo = (uint32_t)(t0 + (uint64_t)s); key.t_hi = (uint32_t)((t0 + (uint64_t)s) >> 32);
         akey.t_lo = (uint32_t)(ta0 + (uint64_t)s); akey.t_hi = (uint32_t)((ta0 + (uint64_t)s) >> 32);
@@ -210,20 +230,21 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
 #pragma unroll
         for (int j = 0; j < LPT; ++j) {
             before[j] = st[j];
-            valid[j] = SIMPLE || (unsigned)a_cur[j] < (unsigned)n_act;
-            live[j] = SIMPLE || (in_range[j] && valid[j] && !was_done[j]);
+            valid[j] = (SIMPLE && !TAPE) || (unsigned)a_cur[j] < (unsigned)n_act;
+            live[j] = SIMPLE ? valid[j] : (in_range[j] && valid[j] && !was_done[j]);
             if constexpr (quad_policy && Env::QUAD_SENSOR) {
                 // one lane per thread, the sensor block shared by the quad (RockSample shards below the pooled kernels' gates):
                 // lane e computes the block of step s + e once per four steps and the words reach their lanes by the same
                 // transpose as the policy's — one Philox block per lane per four steps instead of one per step
                 if (sj == 0) { step_quarter(s); if constexpr (POLICY_WITH_STEP) policy_quarter(s); }
-                const uint32_t H = sj == 0 ? sq.x : sj == 1 ? sq.y : sj == 2 ? sq.z : sq.w;
+                const uint32_t H = pick4(sq);
                 if constexpr (REC) {
                     // the step and, where it ends the episode, the fresh one (which starts from the same word H: auto-reset contract)
                     typename Env::S sj = st[j].s;
                     const uint32_t lane_ = glane[j];
-                    Env::step_rec(sh, tab, sj, (uint32_t)a_cur[j], H, Env::fresh_state(p, H, key, lane_), recv[j],
+                    Env::step_rec(sh, tab, sj, valid[j] ? (uint32_t)a_cur[j] : 0u, H, Env::fresh_state(p, H, key, lane_), recv[j],
                                   [&]() { return Env::elem(Env::quad_block(rare_key(key), lane_, 1u), lane_ & 3u); });
+                    if constexpr (TAPE) recv[j] = valid[j] ? recv[j] : ((uint32_t)a_cur[j] & 0xFFu);   // the record keeps the byte: (ob, reward, done) = (0, 0, 0)
                     st[j].s = sj;
                     o[j] = (int)__builtin_amdgcn_ubfe(recv[j], 8u, 8u);
                     r[j] = (typename Env::Reward)__builtin_amdgcn_sbfe(recv[j], 16u, 8u);
@@ -235,14 +256,14 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
                 // Tiger, Tag: ONE word per lane-step from the quad's STEP block, time-shared the same way; the auto-reset of a
                 // done lane reads the same word (fresh_w below)
                 if (sj == 0) { step_quarter(s); if constexpr (POLICY_WITH_STEP) policy_quarter(s); }
-                const uint32_t W = sj == 0 ? sq.x : sj == 1 ? sq.y : sj == 2 ? sq.z : sq.w;
+                const uint32_t W = pick4(sq);
                 Env::step_w(sh, p, st[j], valid[j] ? a_cur[j] : 0, key, glane[j], W, o[j], r[j], d[j]);
             }
             else if constexpr (quad_policy && quad_words_of<Env>::value == 3) {
                 // the step's quad-shared blocks, time-shared: lane e of a quad computes the three blocks of step s + e once per
                 // four steps, three 4 x 4 transposes hand every lane its own word of each block of each step
                 if (sj == 0) { step_quarter(s); if constexpr (POLICY_WITH_STEP) policy_quarter(s); }
-                auto pick = [&](const uint4 &q) { return sj == 0 ? q.x : sj == 1 ? q.y : sj == 2 ? q.z : q.w; };
+                auto pick = [&](const uint4 &q) { return pick4(q); };
                 Env::step_words(sh, p, st[j], valid[j] ? a_cur[j] : 0, key, glane[j], pick(nq0), pick(nq1), pick(nq2), o[j], r[j], d[j]);
             }
             else Fin::lane_step(sh, p, st[j], valid[j] ? a_cur[j] : 0, key, glane[j], o[j], r[j], d[j], aux[j]);
@@ -255,14 +276,14 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
             if constexpr (REC) {
                 // step_rec already moved the fresh episode in
             } else if constexpr (Env::QUAD_SENSOR) {                         // RockSample: this lane's RESET word of step s
-                const uint32_t rword = sj == 0 ? rq.x : sj == 1 ? rq.y : sj == 2 ? rq.z : rq.w;
+                const uint32_t rword = pick4(rq);
                 st[0].s = fresh[0] ? Env::fresh_state(p, rword, key, glane[0]) : st[0].s;
             } else if constexpr (quad_word_env<Env>::value) {
-                Env::fresh_w(sh, p, st[0], fresh[0], key, glane[0], sj == 0 ? sq.x : sj == 1 ? sq.y : sj == 2 ? sq.z : sq.w);
+                Env::fresh_w(sh, p, st[0], fresh[0], key, glane[0], pick4(sq));
             } else {
                 Fin::resets_only(sh, p, st, fresh, key, glane);
             }
-            const uint32_t word = sj == 0 ? aq.x : sj == 1 ? aq.y : sj == 2 ? aq.z : aq.w;
+            const uint32_t word = pick4(aq);
             if constexpr (!TAPE) a_next[0] = (int)__umulhi(word, (uint32_t)n_act);
         } else {
             Fin::run(sh, p, st, fresh, key, glane, akey, (uint32_t)n_act, a_next, aux, o);
@@ -279,7 +300,8 @@ __global__ __launch_bounds__(BLOCK) void steps_kernel(uint32_t *__restrict__ sta
                 else out.put(j, rel[j], a_cur[j], o[j], r[j], rcode, d[j]);
                 if (!valid[j] && !was_done[j] && err) atomicAdd(err, 1u);
             }
-            if constexpr (TAPE) a_next[j] = (int)col.nxt;                   // the tape's row of step s + 1, requested when this step began
+            if constexpr (TAPE4) a_next[j] = (int)tq[(std::decay_t<decltype(sj_)>::value + 1) & 3];   // the tape's row of step s + 1, asked for three steps ago
+            else if constexpr (TAPE) a_next[j] = (int)col.nxt;              // the tape's row of step s + 1, requested when this step began
             a_cur[j] = a_next[j];
             was_done[j] = auto_reset ? false : (d[j] != 0);
         }
@@ -1276,6 +1298,23 @@ static int launch_steps_fused_l(const typename Env::Params &p, uint32_t *state, 
     }
     if (taped) {
         if constexpr (!std::is_same<L, Columns>::value) {
+            if constexpr (quad_policy_of<Finisher<Env, 1, true>>::value) {
+                // full workgroups of an auto-reset batch below the quad gates: the small shards' loops (time-shared blocks, unrolled
+                // by four, RockSample's table-driven step) with the tape read four rows ahead
+                if (!launched && TAPE_SMALL_SHARD_LOOPS && (flags & POMDP_AUTO_RESET) && n % BLOCK == 0) {
+                    bool tab = false;
+                    if constexpr (quad_tab<Env>::value && Env::QUAD_SENSOR) tab = k >= 16 && p.num_rocks + 5 <= Env::TAB_ACTIONS;
+                    snprintf(variant, sizeof variant, ", 1, true, %s%s", tab ? "true" : "false", lname);
+                    note_fused("steps_kernel", Env::NAME, variant);
+                    if constexpr (quad_tab<Env>::value && Env::QUAD_SENSOR) {
+                        if (tab) hipLaunchKernelGGL((steps_kernel<Env, 1, true, true, L, true>), grid, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob,
+                                                    reward, done, err, n, make_key(seed, t), lane0, kflags, make_key(action_seed, t + 1), k, rec, p, tape);
+                    }
+                    if (!tab) hipLaunchKernelGGL((steps_kernel<Env, 1, true, false, L, true>), grid, dim3(BLOCK), 0, (hipStream_t)stream, state, action, ob,
+                                                 reward, done, err, n, make_key(seed, t), lane0, kflags, make_key(action_seed, t + 1), k, rec, p, tape);
+                    launched = true;
+                }
+            }
             if (!launched) {                                 // any batch, any alignment: one lane per thread, the general form
                 snprintf(variant, sizeof variant, ", 1, false%s%s", COLS ? "" : ", false", lname);
                 note_fused("steps_kernel", Env::NAME, variant);

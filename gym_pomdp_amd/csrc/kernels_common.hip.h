@@ -461,6 +461,11 @@ constexpr bool TAPE_TWO_STEPS_AHEAD = false;
 #else
 constexpr bool TAPE_TWO_STEPS_AHEAD = true;
 #endif
+#ifdef POMDP_NO_TAPE_SMALL_SHARD_LOOPS                         // the A arm: a tape below the quad gates always takes the general loop
+constexpr bool TAPE_SMALL_SHARD_LOOPS = false;
+#else
+constexpr bool TAPE_SMALL_SHARD_LOOPS = true;
+#endif
 #ifdef POMDP_POLICY_AFTER_STEP                                 // the A arm: the policy's block drawn after the lane step (until round 6)
 constexpr bool POLICY_WITH_STEP_BLOCKS = false;
 #else

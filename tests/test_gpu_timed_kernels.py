@@ -94,7 +94,11 @@ TAPES = [("rock", {}, 1 << 20, 80), ("rock", dict(board_size=15, num_rocks=15), 
          # RockSample's half-quad-per-thread loop (7 * 2^16 .. 3 * 2^18 lanes)
          ("rock", {}, 1 << 19, 80), ("rock", dict(board_size=15, num_rocks=15), 5 << 17, 40),
          # ... and Tag's (3 * 2^17 .. 3 * 2^18 - 1 lanes)
-         ("tag", {}, 1 << 19, 80), ("tag", {}, 3 << 17, 40)]
+         ("tag", {}, 1 << 19, 80), ("tag", {}, 3 << 17, 40),
+         # full workgroups below the quad gates: the small shards' loops with the tape read four rows ahead (RockSample's table-driven
+         # step from 16 steps per launch: 66 = 64 + 2, the last launch takes the table-free form)
+         ("rock", dict(board_size=15, num_rocks=15), 1 << 18, 66), ("rock", {}, 5120, 37), ("tiger", {}, 1 << 17, 70),
+         ("tag", {}, 1 << 17, 66), ("network", {}, 1 << 18, 40), ("network", dict(n_machines=16, problem_type=1), 2048, 23)]
 
 
 def _tape(rng, n_actions, steps, n, bad_every):
