@@ -235,6 +235,23 @@ def test_fused_step_loops_never_wait_for_their_own_stores():
     assert taped_small == 5, sorted(res)    # the small shards' loop on a tape, each sink
 
 
+def test_step_loops_keep_nothing_in_scratch_memory():
+    """Static property of the compiled kernels (tools/kernel_resources.py: hipcc's resource remarks, no GPU needed): no step kernel
+    spills to, or indexes an array in, scratch memory.  Round 6 shipped the general tape loop for a day with its time-shared words
+    in a 32-byte scratch array read at a run-time index — and a `s_waitcnt vmcnt(0)` behind every read: results stay right, the GPU
+    suite stays green, only the time shows it.  Known and documented exceptions: the heuristic policy's loop and
+    BattleShip's returns sink with a quad of three- or four-word boards per thread (128 registers)."""
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import kernel_resources as kr
+    rows = kr.collect()
+    assert len(rows) > 300
+    known = lambda k: k.startswith("heuristic_steps_kernel<") or (k.startswith("battleship_steps_quad_kernel<") and "Returns<" in k and ", 4, false>" in k)
+    bad = [(r["kernel"], r["scratch"]) for r in rows if r["scratch"] not in ("0", "?") and not known(r["kernel"])]
+    assert not bad, bad
+    assert sum(1 for r in rows if r["kernel"].startswith(("steps_kernel<", "steps_quad_kernel<"))) > 150
+
+
 def test_library_override_by_environment_variable():
     """GYM_POMDP_AMD_LIB points the package at another build of the library (tools/ab_build.sh variants for same-box A/B
     runs); unset, the in-tree product library is what loads."""
