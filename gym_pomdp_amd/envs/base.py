@@ -769,6 +769,10 @@ class BatchedEnv(compat.EnvBase):
         this env's device whose rows are contiguous is used in place (e.g. the action plane `traj["traj"][:, 0]` of a narrow
         trajectory); anything else is converted, an action that does not fit a byte becoming 255 (out of range for every env,
         so it stays the invalid action it was)."""
+        if (isinstance(actions, torch.Tensor) and actions.dtype == torch.uint8 and actions.device == self.device and actions.dim() == 2
+                and actions.shape[1] == self.batch_size and actions.stride(1) == 1
+                and (actions.shape[0] <= 1 or actions.stride(0) >= actions.shape[1])):
+            return actions                                    # already a tape: the common case costs one test
         t = torch.as_tensor(actions, device=self.device) if not isinstance(actions, torch.Tensor) else actions.to(self.device)
         if t.dim() != 2 or t.shape[1] != self.batch_size:
             raise ValueError("tape: expected actions of shape (steps, %d), got %s" % (self.batch_size, tuple(t.shape)))
